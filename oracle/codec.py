@@ -1,0 +1,197 @@
+"""oracle/codec.py -- ctypes access to the plain-C oracle (liboracle.so).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import zlib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    """Compile oracle/*.c into oracle/liboracle.so (gcc, no dependencies)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.pna_oracle_zstd_decompress.restype = ctypes.c_long
+        L.pna_oracle_zstd_decompress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                 ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def zstd_decompress(data: bytes, max_out: int) -> bytes:
+    """RFC 8878 decode of all concatenated frames (oracle/zstd_dec.c)."""
+    out = ctypes.create_string_buffer(max_out + 64)
+    frames = ctypes.c_int()
+    r = lib().pna_oracle_zstd_decompress(bytes(data), len(data), out, max_out + 64, ctypes.byref(frames))
+    if r < 0:
+        raise ValueError(f"zstd oracle decode error {r}")
+    return out.raw[:r]
+
+
+def zstd_frame_count(data: bytes, max_out: int) -> int:
+    out = ctypes.create_string_buffer(max_out + 64)
+    frames = ctypes.c_int()
+    r = lib().pna_oracle_zstd_decompress(bytes(data), len(data), out, max_out + 64, ctypes.byref(frames))
+    if r < 0:
+        raise ValueError(f"zstd oracle decode error {r}")
+    return frames.value
+
+
+def zlib_decompress(data: bytes) -> bytes:
+    """RFC 1950 decode through the stdlib (independent of the product)."""
+    d = zlib.decompressobj()
+    out = d.decompress(data)
+    if not d.eof or d.unused_data:
+        raise ValueError("zlib stream not terminated exactly")
+    return out
+
+
+def decode_payload(compression: int, data: bytes, max_out: int) -> bytes:
+    """decompress_reader dispatch -- lib/src/entry/read.rs:171-190."""
+    if compression == 0:
+        return bytes(data)
+    if compression == 1:
+        return zlib_decompress(data)
+    if compression == 2:
+        return zstd_decompress(data, max_out)
+    raise ValueError(f"unsupported compression {compression}")
+
+
+_SYS_ZSTD = None
+
+
+def system_libzstd():
+    """System libzstd (independent decoder / CPU baseline codec), or None when absent."""
+    global _SYS_ZSTD
+    if _SYS_ZSTD is None:
+        for name in ("libzstd.so.1", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"):
+            try:
+                Z = ctypes.CDLL(name)
+            except OSError:
+                continue
+            Z.ZSTD_compressBound.restype = ctypes.c_size_t
+            Z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+            Z.ZSTD_compress.restype = ctypes.c_size_t
+            Z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+            Z.ZSTD_decompress.restype = ctypes.c_size_t
+            Z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+            Z.ZSTD_isError.restype = ctypes.c_uint
+            Z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+            Z.ZSTD_versionNumber.restype = ctypes.c_uint
+            Z.ZSTD_createDStream.restype = ctypes.c_void_p
+            Z.ZSTD_freeDStream.argtypes = [ctypes.c_void_p]
+            Z.ZSTD_decompressStream.restype = ctypes.c_size_t
+            Z.ZSTD_decompressStream.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            _SYS_ZSTD = Z
+            break
+        else:
+            _SYS_ZSTD = False
+    return _SYS_ZSTD or None
+
+
+class _Buf(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
+def libzstd_decompress_stream(data: bytes, max_out: int) -> bytes:
+    """Multi-frame streaming decode with the system libzstd (what zstd-rs Decoder does)."""
+    Z = system_libzstd()
+    if Z is None:
+        raise RuntimeError("system libzstd not available")
+    ds = Z.ZSTD_createDStream()
+    src = ctypes.create_string_buffer(bytes(data), len(data))
+    dst = ctypes.create_string_buffer(max_out + 64)
+    ib = _Buf(ctypes.cast(src, ctypes.c_void_p), len(data), 0)
+    ob = _Buf(ctypes.cast(dst, ctypes.c_void_p), max_out + 64, 0)
+    try:
+        while ib.pos < ib.size:
+            r = Z.ZSTD_decompressStream(ds, ctypes.byref(ob), ctypes.byref(ib))
+            if Z.ZSTD_isError(r):
+                raise ValueError("libzstd decode error")
+            if r == 0 and ib.pos >= ib.size:
+                break
+            if ob.pos >= ob.size:
+                raise ValueError("libzstd output overflow")
+        if ib.pos >= ib.size and len(data) and r != 0:
+            raise ValueError("libzstd: truncated frame")
+    finally:
+        Z.ZSTD_freeDStream(ds)
+    return dst.raw[:ob.pos]
+
+
+def libzstd_compress(data: bytes, level: int = 3) -> bytes:
+    Z = system_libzstd()
+    cap = Z.ZSTD_compressBound(len(data))
+    buf = ctypes.create_string_buffer(cap)
+    n = Z.ZSTD_compress(buf, cap, bytes(data), len(data), level)
+    if Z.ZSTD_isError(n):
+        raise ValueError("libzstd compress error")
+    return buf.raw[:n]
+
+
+class ZstdParams(ctypes.Structure):
+    """Mirror of pna_zstd_params (oracle/zstd_model.h)."""
+    _fields_ = [("hash_log", ctypes.c_uint32), ("min_match", ctypes.c_uint32), ("tile", ctypes.c_uint32),
+                ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32)]
+
+
+F_HUF, F_FSE, F_LAZY = 1, 2, 4
+
+
+def default_params() -> ZstdParams:
+    p = ZstdParams()
+    lib().pna_zstd_default_params(ctypes.byref(p))
+    return p
+
+
+def model_compress(data: bytes, params: ZstdParams | None = None) -> bytes:
+    """The deterministic zstd-format encoder model (oracle/zstd_model.c)."""
+    L = lib()
+    L.pna_zstd_bound.restype = ctypes.c_size_t
+    L.pna_zstd_bound.argtypes = [ctypes.c_size_t]
+    L.pna_zstd_model_compress.restype = ctypes.c_size_t
+    L.pna_zstd_model_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.POINTER(ZstdParams)]
+    if params is None:
+        params = default_params()
+    cap = L.pna_zstd_bound(len(data))
+    buf = ctypes.create_string_buffer(cap)
+    n = L.pna_zstd_model_compress(bytes(data), len(data), buf, cap, ctypes.byref(params))
+    if n == 0:
+        raise ValueError("model compress failed")
+    return buf.raw[:n]
+
+
+_CORPUS = None
+
+
+def corpus_tables():
+    global _CORPUS
+    if _CORPUS is None:
+        vocab = ctypes.create_string_buffer(50000 * 16)
+        cum = (ctypes.c_uint64 * 50000)()
+        ph = (ctypes.c_uint32 * (8192 * 4))()
+        lib().pna_corpus_tables(vocab, cum, ph)
+        _CORPUS = (vocab, cum, ph)
+    return _CORPUS
+
+
+def corpus_file(kind: int, idx: int, n: int) -> bytes:
+    """Synthetic corpus file (oracle/corpus_model.c): kind 0 enwik-style, 1 random-text, 2 random bytes, 3 zeros, 4 'x'."""
+    vocab, cum, ph = corpus_tables()
+    out = ctypes.create_string_buffer(max(n, 1))
+    lib().pna_corpus_file(ctypes.c_int(kind), ctypes.c_uint64(idx), out, ctypes.c_size_t(n), vocab, cum, ph)
+    return out.raw[:n]

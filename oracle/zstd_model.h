@@ -1,0 +1,52 @@
+/*
+ * oracle/zstd_model.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C model ("the spec") of the MI355X zstd-format encoder that replaces, behind
+ * Compression::ZStandard, the third-party encoder the reference calls at
+ *   lib/src/entry/write.rs:260-262  (zstd::stream::write::Encoder::new(writer, level))
+ *   lib/src/compress.rs:32-41,66-75 (CompressionWriter::write / try_into_inner = finish)
+ * The reference pins only DECOMPRESSED bytes at this boundary, so the model is free to
+ * choose its own parse; what it fixes is a deterministic algorithm that the HIP kernels must reproduce
+ * BIT-EXACTLY (tests/test_gpu_parity.py), and whose output must decode with the RFC 8878 decoder in
+ * zstd_dec.c and with the system libzstd to the input (tests/test_oracle_zstd_model.py).
+ */
+#ifndef PNA_ORACLE_ZSTD_MODEL_H
+#define PNA_ORACLE_ZSTD_MODEL_H
+#include <stdint.h>
+#include <stddef.h>
+
+#define PNA_SEG_SIZE   (1u << 20)   /* one zstd frame per 1 MiB segment of an entry            */
+#define PNA_BLK_SIZE   (1u << 17)   /* zstd Block_Maximum_Size                                  */
+
+#define PNA_F_HUF      1u           /* Huffman-compressed literals allowed                      */
+#define PNA_F_FSE      2u           /* FSE_Compressed sequence tables allowed (else predefined) */
+#define PNA_F_LAZY     4u           /* one-step lazy deferral inside a 64-position group        */
+#define PNA_F_REP      8u           /* repeat-offset codes (block-local history)                */
+
+typedef struct {
+    uint32_t hash_log;    /* LDS hash table entries = 1 << hash_log (u32 each)                 */
+    uint32_t min_match;   /* bytes hashed and minimum match length (4..6)                       */
+    uint32_t tile;        /* positions matched per synchronous step                             */
+    uint32_t max_off;     /* largest usable offset (bytes kept in the LDS look-back window)     */
+    uint32_t cap1;        /* per-position match length cap before cooperative extension         */
+    uint32_t lookahead;   /* bytes beyond the tile end that an extension may read               */
+    uint32_t flags;       /* PNA_F_*                                                            */
+} pna_zstd_params;
+
+typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */
+
+void   pna_zstd_default_params(pna_zstd_params *p);
+size_t pna_zstd_bound(size_t n);
+/* Compress one entry (any length) into concatenated frames.  Returns bytes written or 0 if cap too small. */
+size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const pna_zstd_params *p);
+
+/* stage-level entry points used by the parity tests */
+/* LZ stage for one block of a segment: fills seqs/lits, returns nseq; *nlit_out = literal bytes. `table`
+ * (1<<hash_log u32, zero at segment start) carries across the blocks of one segment. */
+uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, uint32_t blk_len,
+                      uint32_t *table, const pna_zstd_params *p,
+                      pna_seq *seqs, uint8_t *lits, uint32_t *nlit_out);
+/* entropy + block framing for one block: returns the size of the block INCLUDING its 3-byte header */
+size_t pna_zstd_encode_block(const uint8_t *blk, uint32_t blk_len, const pna_seq *seqs, uint32_t nseq,
+                             const uint8_t *lits, uint32_t nlit, int last, uint32_t flags, uint8_t *dst);
+#endif
