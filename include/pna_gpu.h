@@ -1,0 +1,119 @@
+/*
+ * include/pna_gpu.h -- C ABI of libpna_gpu.so, the MI355X-native replacement for the per-entry compression
+ * path of ChanTsune/Portable-Network-Archive (reference paths relative to /root/reference).
+ *
+ * The reference has no FFI for this path; the seam is the crate-private Rust type
+ *     enum CompressionWriter<W: Write> { No, Deflate(ZlibEncoder<W>), ZStd(ZstdEncoder<W>), Xz(..) }
+ *     lib/src/compress.rs:21-76, constructed only by compression_writer() lib/src/entry/write.rs:251-265.
+ * Each entry point below names the reference interface it replaces; INTEGRATION.md shows the Rust `extern "C"`
+ * stub a maintainer would add behind the Compression::{ZStandard,Deflate} arms.
+ *
+ * Conventions: every function returns 0 (PNA_OK) or a negative PNA_E_* code; no global state; a ctx may be used
+ * from one thread at a time (the reference creates one encoder per rayon task, cli/src/command/core.rs:505-517;
+ * here one ctx owns one GPU and batches those tasks).  Pointers are host pointers unless the name says `_device`.
+ * There is NO CPU fallback: without a usable HIP device pna_gpu_init fails with PNA_E_NODEVICE.
+ */
+#ifndef PNA_GPU_H
+#define PNA_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNA_OK            0
+#define PNA_E_NODEVICE   (-1)   /* no HIP device / HIP runtime error at init                        */
+#define PNA_E_INVAL      (-2)   /* bad argument (io::ErrorKind::InvalidInput in the reference)       */
+#define PNA_E_NOMEM      (-3)   /* device or host allocation failed                                  */
+#define PNA_E_DSTSIZE    (-4)   /* destination capacity smaller than pna_gpu_bound()                 */
+#define PNA_E_HIP        (-5)   /* a HIP call or kernel failed; pna_gpu_last_error() has the text    */
+#define PNA_E_SINK       (-6)   /* the sink callback (== W::write) returned non-zero                 */
+#define PNA_E_UNSUPPORTED (-7)  /* algorithm not offered by this build                               */
+
+/* == Compression::to_byte(), lib/src/entry/options.rs:241-247 */
+#define PNA_ALGO_STORE    0
+#define PNA_ALGO_DEFLATE  1
+#define PNA_ALGO_ZSTD     2
+
+/* encoder feature bits (pna_gpu_init flags, low byte); default = all of them */
+#define PNA_F_HUF   1u
+#define PNA_F_FSE   2u
+#define PNA_F_LAZY  4u
+#define PNA_F_REP   8u
+#define PNA_F_DEFAULT 0x80000000u   /* let the library choose */
+
+typedef struct pna_gpu_ctx pna_gpu_ctx;
+
+/* One context per (process, GPU).  Replaces the per-entry encoder construction
+ * ZstdEncoder::new(writer, level) / ZlibEncoder::new(writer, level) (lib/src/entry/write.rs:257-262). */
+int  pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags);
+void pna_gpu_shutdown(pna_gpu_ctx *ctx);
+const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
+const char *pna_gpu_strerror(int code);
+
+/* Worst-case compressed size of one entry (zstd: ZSTD_compressBound-like; zlib: deflateBound-like). */
+size_t pna_gpu_bound(int algo, size_t src_len);
+
+/* Level mapping of the reference, restated so callers can pass CompressionLevel values through unchanged:
+ * lib/src/compress/zstandard.rs:43-57 (Default -> 3, clamp to min..max) and lib/src/compress/deflate.rs:89-101
+ * (Default -> 6, clamp 0..9).  `level` < 0 with level == PNA_LEVEL_DEFAULT means default. */
+#define PNA_LEVEL_DEFAULT  (-1000)
+int  pna_gpu_clamp_level(int algo, int level);
+
+/* ---- batch of independent entries: the data-parallel fan-out of spawn_entry_results()/create_entry()
+ * (cli/src/command/core.rs:496-537,915-977).  Entry i becomes one independent stream in dst[i]
+ * (zstd: concatenated frames; deflate: one zlib stream), exactly what FileEntryBuilder::build() hands to
+ * NormalEntry as FDAT payload (lib/src/entry/builder/file.rs:131-135). */
+int  pna_gpu_compress_batch(pna_gpu_ctx *ctx, int algo, int level, size_t n,
+                            const void *const *src, const size_t *src_len,
+                            void *const *dst, const size_t *dst_cap, size_t *dst_len);
+
+/* Same, with the inputs already resident in HBM (bench / pipelined callers).
+ *   d_src      device buffer holding all entries; entry i = [src_off[i], src_off[i] + src_len[i]);
+ *              every src_off[i] must be a multiple of 16 and the buffer must extend 4 KiB past the last entry.
+ *   d_dst      device buffer of dst_cap bytes receiving the compressed entries back to back.
+ *   dst_off    host array of n+1 offsets (out): entry i's stream = d_dst[dst_off[i] .. dst_off[i+1]).
+ * Work is enqueued on `hip_stream` (a hipStream_t, or NULL for the ctx's own stream) and the call returns after
+ * the stream has finished (dst_off needs the sizes). */
+int  pna_gpu_compress_batch_device(pna_gpu_ctx *ctx, int algo, int level, size_t n,
+                                   const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                   void *d_dst, size_t dst_cap, uint64_t *dst_off, void *hip_stream);
+
+/* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
+ * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write). */
+typedef int (*pna_sink_fn)(void *user, const void *buf, size_t len);
+typedef struct pna_gpu_stream pna_gpu_stream;
+int  pna_gpu_stream_new(pna_gpu_ctx *ctx, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out);
+int  pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len);
+int  pna_gpu_stream_flush(pna_gpu_stream *s);           /* no-op like the buffered encoders' flush        */
+int  pna_gpu_stream_finish(pna_gpu_stream *s);          /* consumes s                                      */
+void pna_gpu_stream_abort(pna_gpu_stream *s);           /* drop without output (failed builder is discarded) */
+
+/* ---- solid mode: one logical stream, split into independent 1 MiB frames inside the kernels
+ * (replaces the single serial encoder of SolidArchive, lib/src/archive/write.rs:443-470,575-580,716-727). */
+int  pna_gpu_compress_solid(pna_gpu_ctx *ctx, int algo, int level, const void *src, size_t src_len,
+                            pna_sink_fn sink, void *user);
+
+/* ---- introspection used by tests and the benchmark */
+typedef struct {
+    double   ms_lz, ms_stats, ms_lit, ms_seq, ms_pack;   /* HIP-event time of each stage of the last batch     */
+    uint64_t in_bytes, out_bytes, n_segments, n_blocks;
+} pna_gpu_timing;
+int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
+
+/* LZ-stage outputs of the last device batch for one block (tests compare them with the oracle's pna_lz_block).
+ * seqs: packed u64 (off:20 | ml:18<<20 | ll:18<<38). Copies at most cap_* items; returns counts. */
+int  pna_gpu_debug_block(pna_gpu_ctx *ctx, uint32_t block, uint64_t *seqs, uint32_t cap_seqs, uint32_t *nseq,
+                         uint8_t *lits, uint32_t cap_lits, uint32_t *nlit);
+
+/* ---- benchmark support (not part of the reference's surface): fills d_dst with `n_files` synthetic files of
+ * `file_len` bytes each (file i at i * stride), bit-identical to oracle/corpus_model.c. kind: 0 enwik-style text,
+ * 1 random-text, 2 random bytes, 3 zeros, 4 repeated byte. */
+int  pna_bench_corpus_fill_device(pna_gpu_ctx *ctx, int kind, uint64_t first_file, uint64_t n_files,
+                                  uint64_t file_len, uint64_t stride, void *d_dst, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

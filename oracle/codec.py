@@ -195,3 +195,30 @@ def corpus_file(kind: int, idx: int, n: int) -> bytes:
     out = ctypes.create_string_buffer(max(n, 1))
     lib().pna_corpus_file(ctypes.c_int(kind), ctypes.c_uint64(idx), out, ctypes.c_size_t(n), vocab, cum, ph)
     return out.raw[:n]
+
+
+class _Seq(ctypes.Structure):
+    _fields_ = [("ll", ctypes.c_uint32), ("ml", ctypes.c_uint32), ("off", ctypes.c_uint32)]
+
+
+def model_lz_segment(seg: bytes, params: ZstdParams | None = None):
+    """LZ stage of the model for one segment (<= 1 MiB): list over blocks of ([(ll, ml, off)...], literal bytes)."""
+    L = lib()
+    if params is None:
+        params = default_params()
+    assert len(seg) <= (1 << 20)
+    L.pna_lz_block.restype = ctypes.c_uint32
+    L.pna_lz_block.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                               ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ZstdParams),
+                               ctypes.POINTER(_Seq), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    table = (ctypes.c_uint32 * (1 << params.hash_log))()
+    out = []
+    BLK = 1 << 17
+    seqs = (_Seq * (BLK // 4))()
+    lits = ctypes.create_string_buffer(BLK + 8)
+    for b0 in range(0, len(seg), BLK):
+        bl = min(BLK, len(seg) - b0)
+        nlit = ctypes.c_uint32()
+        ns = L.pna_lz_block(bytes(seg), len(seg), b0, bl, table, ctypes.byref(params), seqs, lits, ctypes.byref(nlit))
+        out.append(([(seqs[i].ll, seqs[i].ml, seqs[i].off) for i in range(ns)], lits.raw[:nlit.value]))
+    return out

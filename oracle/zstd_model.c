@@ -320,62 +320,6 @@ static size_t huf_encode_stream(uint8_t *dst, const uint8_t *sym, uint32_t m, co
     return bw_close_marker(&w);
 }
 
-/* literals section; returns bytes written */
-static size_t encode_literals(uint8_t *dst, const uint8_t *lits, uint32_t nlit, uint32_t flags) {
-    /* raw header size */
-    size_t raw_h = nlit < 32 ? 1 : (nlit < 4096 ? 2 : 3);
-    if ((flags & PNA_F_HUF) && nlit >= 64) {
-        uint32_t count[256] = {0}; int max_sym = 0; uint32_t maxc = 0;
-        for (uint32_t i = 0; i < nlit; i++) count[lits[i]]++;
-        for (int s = 0; s < 256; s++) if (count[s]) { max_sym = s; if (count[s] > maxc) maxc = count[s]; }
-        if (maxc == nlit) { /* RLE literals */
-            if (raw_h == 1) dst[0] = (uint8_t)(1 | (nlit << 3));
-            else if (raw_h == 2) { dst[0] = (uint8_t)(1 | (1 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); }
-            else { dst[0] = (uint8_t)(1 | (3 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); dst[2] = (uint8_t)(nlit >> 12); }
-            dst[raw_h] = lits[0];
-            return raw_h + 1;
-        }
-        uint8_t lens[256]; uint16_t codes[256];
-        int np = huf_build_lens(count, 256, lens);
-        if (np >= 2) {
-            int maxbits = 0;
-            for (int s = 0; s <= max_sym; s++) if (lens[s] > maxbits) maxbits = lens[s];
-            huf_assign_codes(lens, max_sym + 1, maxbits, codes);
-            int streams4 = nlit >= 256;
-            size_t lh = 3 + (nlit >= 1024) + (nlit >= 16384);
-            uint8_t *body = dst + lh;
-            size_t ts = huf_write_tree(body, lens, max_sym, maxbits);
-            if (ts) {
-                size_t csz = ts;
-                if (!streams4) csz += huf_encode_stream(body + csz, lits, nlit, lens, codes);
-                else {
-                    uint32_t seg = (nlit + 3) / 4;
-                    uint8_t *jt = body + csz; csz += 6;
-                    for (int k = 0; k < 4; k++) {
-                        uint32_t a = (uint32_t)k * seg, m = k < 3 ? seg : nlit - 3 * seg;
-                        size_t ss = huf_encode_stream(body + csz, lits + a, m, lens, codes);
-                        if (k < 3) { jt[2 * k] = (uint8_t)ss; jt[2 * k + 1] = (uint8_t)(ss >> 8); }
-                        csz += ss;
-                    }
-                }
-                if (lh + csz < raw_h + nlit) {
-                    uint64_t h;
-                    if (lh == 3) h = 2u | ((uint64_t)(streams4 ? 1 : 0) << 2) | ((uint64_t)nlit << 4) | ((uint64_t)csz << 14);
-                    else if (lh == 4) h = 2u | (2u << 2) | ((uint64_t)nlit << 4) | ((uint64_t)csz << 18);
-                    else h = 2u | (3u << 2) | ((uint64_t)nlit << 4) | ((uint64_t)csz << 22);
-                    for (size_t i = 0; i < lh; i++) dst[i] = (uint8_t)(h >> (8 * i));
-                    return lh + csz;
-                }
-            }
-        }
-    }
-    if (raw_h == 1) dst[0] = (uint8_t)(nlit << 3);
-    else if (raw_h == 2) { dst[0] = (uint8_t)((1 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); }
-    else { dst[0] = (uint8_t)((3 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); dst[2] = (uint8_t)(nlit >> 12); }
-    memcpy(dst + raw_h, lits, nlit);
-    return raw_h + nlit;
-}
-
 /* ======================================================================== sequences */
 
 static const int16_t LL_DEF[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
@@ -389,20 +333,45 @@ static const uint8_t  ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0
 static int ll_code(uint32_t v) { int c = 35; while (LL_BASE[c] > v) c--; return c; }
 static int ml_code(uint32_t v) { int c = 52; while (ML_BASE[c] > v) c--; return c; }
 
-/* table for one of LL/OF/ML: chooses mode, writes its description, builds the encoder table.
- * mode: 0 predefined, 1 RLE, 2 FSE_Compressed. */
-static int seq_make_table(fse_ctable *ct, const uint8_t *codes, uint32_t nseq, int alphabet, int max_log,
-                          const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *desc, size_t *desc_len) {
-    uint32_t count[64] = {0}; int maxs = 0, distinct = 0;
-    for (uint32_t i = 0; i < nseq; i++) count[codes[i]]++;
+/* ======================================================================== per-segment entropy tables
+ *
+ * ONE Huffman table and ONE set of LL/OF/ML tables per segment (1 MiB frame), built from the statistics of all
+ * the segment's blocks.  The first block that uses a table carries its description (Compressed literals /
+ * FSE_Compressed or RLE modes); later blocks of the segment reuse it (Treeless literals / Repeat_Mode).
+ * This is what lets the GPU encode sequences with one lane per block while the lanes of a segment share one
+ * table image in LDS.
+ */
+typedef struct {
+    int      huf_ok, max_sym, maxbits;
+    uint8_t  lens[256]; uint16_t codes[256];
+    uint8_t  tree[160]; size_t tree_len;
+    int      mode[3];                 /* 0 predefined, 1 RLE, 2 FSE_Compressed; order LL, OF, ML */
+    fse_ctable ct[3];
+    uint8_t  desc[3][96]; size_t desc_len[3];
+} seg_tables;
+
+static void seg_build_huf(seg_tables *t, const uint32_t *count) {
+    t->huf_ok = 0; t->tree_len = 0; t->max_sym = 0; t->maxbits = 0;
+    int np = huf_build_lens(count, 256, t->lens);
+    if (np < 2) return;
+    for (int s = 0; s < 256; s++) if (count[s]) t->max_sym = s;
+    for (int s = 0; s <= t->max_sym; s++) if (t->lens[s] > t->maxbits) t->maxbits = t->lens[s];
+    huf_assign_codes(t->lens, t->max_sym + 1, t->maxbits, t->codes);
+    t->tree_len = huf_write_tree(t->tree, t->lens, t->max_sym, t->maxbits);
+    t->huf_ok = t->tree_len > 0;
+}
+
+/* returns 0 on success, -1 when no valid table exists (caller emits raw blocks) */
+static int seg_build_seq_table(seg_tables *t, int which, const uint32_t *count, uint32_t nseq, int alphabet, int max_log,
+                               const int16_t *def, int def_n, int def_log, uint32_t flags) {
+    int maxs = 0, distinct = 0;
     for (int s = 0; s < alphabet; s++) if (count[s]) { maxs = s; distinct++; }
-    *desc_len = 0;
-    if (distinct == 1 && nseq > 2) { desc[0] = (uint8_t)maxs; *desc_len = 1; ct->tlog = 0; return 1; }
+    t->desc_len[which] = 0;
+    if (distinct == 1 && nseq > 2) { t->desc[which][0] = (uint8_t)maxs; t->desc_len[which] = 1; t->ct[which].tlog = 0; t->mode[which] = 1; return 0; }
     int def_ok = maxs < def_n;
-    if (def_ok) for (int s = 0; s <= maxs; s++) if (count[s] && def[s] == 0) def_ok = 0;
     if (!(flags & PNA_F_FSE) || (nseq < 64 && def_ok)) {
         if (!def_ok) return -1;
-        fse_build_ctable(ct, def, def_n, def_log); return 0;
+        fse_build_ctable(&t->ct[which], def, def_n, def_log); t->mode[which] = 0; return 0;
     }
     int tlog = hb32(nseq - 1) - 2, minlog = 5;
     while ((1 << minlog) < distinct) minlog++;
@@ -410,23 +379,16 @@ static int seq_make_table(fse_ctable *ct, const uint8_t *codes, uint32_t nseq, i
     if (tlog > max_log) tlog = max_log;
     int16_t norm[64];
     fse_normalize(count, maxs + 1, nseq, tlog, norm);
-    *desc_len = fse_write_ncount(desc, norm, maxs + 1, tlog);
-    fse_build_ctable(ct, norm, maxs + 1, tlog);
-    return 2;
+    t->desc_len[which] = fse_write_ncount(t->desc[which], norm, maxs + 1, tlog);
+    fse_build_ctable(&t->ct[which], norm, maxs + 1, tlog);
+    t->mode[which] = 2;
+    return 0;
 }
 
-/* sequences section; returns bytes written (0 => cannot encode, caller emits a raw block) */
-static size_t encode_sequences(uint8_t *dst, const pna_seq *seqs, uint32_t nseq, uint32_t flags) {
-    size_t pos = 0;
-    if (nseq < 128) dst[pos++] = (uint8_t)nseq;
-    else if (nseq < 0x7F00) { dst[pos++] = (uint8_t)((nseq >> 8) + 128); dst[pos++] = (uint8_t)nseq; }
-    else { dst[pos++] = 255; dst[pos++] = (uint8_t)(nseq - 0x7F00); dst[pos++] = (uint8_t)((nseq - 0x7F00) >> 8); }
-    if (nseq == 0) return pos;
-    uint8_t *llc = (uint8_t *)malloc(nseq * 3), *ofc = llc + nseq, *mlc = ofc + nseq;
-    uint32_t *ofb = (uint32_t *)malloc(nseq * sizeof(uint32_t));
-    /* offBase: offset+3, or a repeat code 1..3 when PNA_F_REP.  Only history established INSIDE this block is
-     * used (rep[k] == 0 means "unknown"), so a block stays decodable whatever the previous blocks were
-     * (raw fallback drops their sequences and with them their history updates). */
+/* offBase for every sequence of ONE block: offset+3, or a repeat code 1..3 when PNA_F_REP.  Only history
+ * established INSIDE this block is used (rep[k] == 0 means "unknown"), so a block stays decodable whatever
+ * happened to the previous blocks (a raw fallback drops their sequences and with them their history updates). */
+static void block_offbase(const pna_seq *seqs, uint32_t nseq, uint32_t flags, uint32_t *ofb) {
     uint32_t rep[3] = {0, 0, 0};
     for (uint32_t i = 0; i < nseq; i++) {
         uint32_t off = seqs[i].off, ob = off + 3;
@@ -443,62 +405,148 @@ static size_t encode_sequences(uint8_t *dst, const pna_seq *seqs, uint32_t nseq,
         }
         if (ob > 3) { rep[2] = rep[1]; rep[1] = rep[0]; rep[0] = off; }
         ofb[i] = ob;
-        llc[i] = (uint8_t)ll_code(seqs[i].ll); mlc[i] = (uint8_t)ml_code(seqs[i].ml);
-        ofc[i] = (uint8_t)hb32(ob);
     }
-    fse_ctable *ctl = (fse_ctable *)malloc(3 * sizeof(fse_ctable)), *cto = ctl + 1, *ctm = ctl + 2;
-    uint8_t *modes = dst + pos++; size_t dl;
-    int ml_ = seq_make_table(ctl, llc, nseq, 36, 9, LL_DEF, 36, 6, flags, dst + pos, &dl); pos += dl;
-    int mo_ = seq_make_table(cto, ofc, nseq, 32, 8, OF_DEF, 29, 5, flags, dst + pos, &dl); pos += dl;
-    int mm_ = seq_make_table(ctm, mlc, nseq, 53, 9, ML_DEF, 53, 6, flags, dst + pos, &dl); pos += dl;
-    if (ml_ < 0 || mo_ < 0 || mm_ < 0) { free(llc); free(ctl); free(ofb); return 0; }
-    *modes = (uint8_t)((ml_ << 6) | (mo_ << 4) | (mm_ << 2));
-    bitw w; bw_init(&w, dst + pos);
-    uint32_t i = nseq - 1;
-    uint32_t sm = mm_ == 1 ? 0 : ctm->first_state[mlc[i]];
-    uint32_t so = mo_ == 1 ? 0 : cto->first_state[ofc[i]];
-    uint32_t sl = ml_ == 1 ? 0 : ctl->first_state[llc[i]];
-    bw_add(&w, seqs[i].ll - LL_BASE[llc[i]], LL_BITS[llc[i]]);
-    bw_add(&w, seqs[i].ml - ML_BASE[mlc[i]], ML_BITS[mlc[i]]);
-    bw_add(&w, ofb[i] - (1u << ofc[i]), ofc[i]);
-    while (i-- > 0) {
-        if (mo_ != 1) so = fse_encode(cto, &w, so, ofc[i]);
-        if (mm_ != 1) sm = fse_encode(ctm, &w, sm, mlc[i]);
-        if (ml_ != 1) sl = fse_encode(ctl, &w, sl, llc[i]);
-        bw_add(&w, seqs[i].ll - LL_BASE[llc[i]], LL_BITS[llc[i]]);
-        bw_add(&w, seqs[i].ml - ML_BASE[mlc[i]], ML_BITS[mlc[i]]);
-        bw_add(&w, ofb[i] - (1u << ofc[i]), ofc[i]);
-    }
-    if (mm_ != 1) bw_add(&w, sm, ctm->tlog);
-    if (mo_ != 1) bw_add(&w, so, cto->tlog);
-    if (ml_ != 1) bw_add(&w, sl, ctl->tlog);
-    pos += bw_close_marker(&w);
-    free(llc); free(ctl); free(ofb);
-    return pos;
 }
 
-/* ======================================================================== block / frame */
+/* Huffman body of one block (jump table + streams, no tree); returns bytes */
+static size_t block_huf_body(const seg_tables *t, const uint8_t *lits, uint32_t nlit, uint8_t *dst) {
+    if (nlit < 256) return huf_encode_stream(dst, lits, nlit, t->lens, t->codes);
+    uint32_t seg = (nlit + 3) / 4; size_t csz = 6;
+    for (int k = 0; k < 4; k++) {
+        uint32_t a = (uint32_t)k * seg, m = k < 3 ? seg : nlit - 3 * seg;
+        size_t ss = huf_encode_stream(dst + csz, lits + a, m, t->lens, t->codes);
+        if (k < 3) { dst[2 * k] = (uint8_t)ss; dst[2 * k + 1] = (uint8_t)(ss >> 8); }
+        csz += ss;
+    }
+    return csz;
+}
 
-size_t pna_zstd_encode_block(const uint8_t *blk, uint32_t blk_len, const pna_seq *seqs, uint32_t nseq,
-                             const uint8_t *lits, uint32_t nlit, int last, uint32_t flags, uint8_t *dst) {
-    uint8_t *tmp = (uint8_t *)malloc((size_t)blk_len * 2 + (size_t)nseq * 12 + 1024);
-    size_t csz = 0;
-    if (nseq > 0 || nlit > 0) {
-        size_t ls = encode_literals(tmp, lits, nlit, flags);
-        size_t ss = encode_sequences(tmp + ls, seqs, nseq, flags);
-        csz = ss ? ls + ss : 0;
+/* sequence bitstream of one block (no headers); returns bytes */
+static size_t block_seq_bits(const seg_tables *t, const pna_seq *seqs, const uint32_t *ofb, uint32_t nseq, uint8_t *dst) {
+    bitw w; bw_init(&w, dst);
+    const fse_ctable *ctl = &t->ct[0], *cto = &t->ct[1], *ctm = &t->ct[2];
+    uint32_t i = nseq - 1;
+    int llc = ll_code(seqs[i].ll), mlc = ml_code(seqs[i].ml), ofc = hb32(ofb[i]);
+    uint32_t sm = t->mode[2] == 1 ? 0 : ctm->first_state[mlc];
+    uint32_t so = t->mode[1] == 1 ? 0 : cto->first_state[ofc];
+    uint32_t sl = t->mode[0] == 1 ? 0 : ctl->first_state[llc];
+    bw_add(&w, seqs[i].ll - LL_BASE[llc], LL_BITS[llc]);
+    bw_add(&w, seqs[i].ml - ML_BASE[mlc], ML_BITS[mlc]);
+    bw_add(&w, ofb[i] - (1u << ofc), ofc);
+    while (i-- > 0) {
+        llc = ll_code(seqs[i].ll); mlc = ml_code(seqs[i].ml); ofc = hb32(ofb[i]);
+        if (t->mode[1] != 1) so = fse_encode(cto, &w, so, ofc);
+        if (t->mode[2] != 1) sm = fse_encode(ctm, &w, sm, mlc);
+        if (t->mode[0] != 1) sl = fse_encode(ctl, &w, sl, llc);
+        bw_add(&w, seqs[i].ll - LL_BASE[llc], LL_BITS[llc]);
+        bw_add(&w, seqs[i].ml - ML_BASE[mlc], ML_BITS[mlc]);
+        bw_add(&w, ofb[i] - (1u << ofc), ofc);
     }
-    uint32_t hdr;
-    if (csz == 0 || csz >= blk_len) {
-        hdr = (uint32_t)(last ? 1 : 0) | (0u << 1) | (blk_len << 3);
-        memcpy(dst + 3, blk, blk_len); csz = blk_len;
-    } else {
-        hdr = (uint32_t)(last ? 1 : 0) | (2u << 1) | ((uint32_t)csz << 3);
-        memcpy(dst + 3, tmp, csz);
+    if (t->mode[2] != 1) bw_add(&w, sm, ctm->tlog);
+    if (t->mode[1] != 1) bw_add(&w, so, cto->tlog);
+    if (t->mode[0] != 1) bw_add(&w, sl, ctl->tlog);
+    return bw_close_marker(&w);
+}
+
+static size_t put_raw_lit_header(uint8_t *dst, int type, uint32_t nlit) {
+    if (nlit < 32) { dst[0] = (uint8_t)(type | (nlit << 3)); return 1; }
+    if (nlit < 4096) { dst[0] = (uint8_t)(type | (1 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); return 2; }
+    dst[0] = (uint8_t)(type | (3 << 2) | ((nlit & 15) << 4)); dst[1] = (uint8_t)(nlit >> 4); dst[2] = (uint8_t)(nlit >> 12); return 3;
+}
+
+/* ======================================================================== segment = one frame
+ *
+ * blk_nseq/blk_nlit/seqs/lits are the LZ stage's outputs for the segment's blocks (seqs and lits are stored at
+ * the block's input offset scaled: seqs at index b*(BLK/4), lits at byte b*BLK).  Returns frame bytes.
+ */
+size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_seq *seqs, const uint8_t *lits,
+                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint8_t *dst) {
+    uint32_t nblk = (seg_len + PNA_BLK_SIZE - 1) / PNA_BLK_SIZE;
+    static const uint8_t fh[6] = {0x28,0xB5,0x2F,0xFD,0x00,0x50};
+    size_t op = 0;
+    memcpy(dst, fh, 6); op = 6;
+    /* segment statistics */
+    uint32_t lcount[256] = {0}, scount[3][64]; memset(scount, 0, sizeof(scount));
+    uint32_t nseq_seg = 0;
+    uint32_t *ofb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nblk * (PNA_BLK_SIZE / 4));
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE;
+        const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
+        uint32_t *bo = ofb + (size_t)b * (PNA_BLK_SIZE / 4);
+        for (uint32_t i = 0; i < blk_nlit[b]; i++) lcount[bl[i]]++;
+        block_offbase(bs, blk_nseq[b], flags, bo);
+        for (uint32_t i = 0; i < blk_nseq[b]; i++) {
+            scount[0][ll_code(bs[i].ll)]++; scount[1][hb32(bo[i])]++; scount[2][ml_code(bs[i].ml)]++;
+        }
+        nseq_seg += blk_nseq[b];
     }
-    dst[0] = (uint8_t)hdr; dst[1] = (uint8_t)(hdr >> 8); dst[2] = (uint8_t)(hdr >> 16);
-    free(tmp);
-    return 3 + csz;
+    seg_tables *t = (seg_tables *)calloc(1, sizeof(seg_tables));
+    if (flags & PNA_F_HUF) seg_build_huf(t, lcount);
+    int seq_ok = 1;
+    if (nseq_seg) {
+        if (seg_build_seq_table(t, 0, scount[0], nseq_seg, 36, 8, LL_DEF, 36, 6, flags)) seq_ok = 0;
+        if (seg_build_seq_table(t, 1, scount[1], nseq_seg, 32, 8, OF_DEF, 29, 5, flags)) seq_ok = 0;
+        if (seg_build_seq_table(t, 2, scount[2], nseq_seg, 53, 8, ML_DEF, 53, 6, flags)) seq_ok = 0;
+    }
+    /* blocks, in order; have_huf / have_seq record whether a previous block of the frame carried the tables */
+    int have_huf = 0, have_seq = 0;
+    uint8_t *tmpblk = (uint8_t *)malloc(PNA_BLK_SIZE * 2 + 1024);
+    uint8_t *hbody = (uint8_t *)malloc(PNA_BLK_SIZE * 2 + 64), *sbits = (uint8_t *)malloc((size_t)(PNA_BLK_SIZE / 4) * 12 + 64);
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t b0 = b * PNA_BLK_SIZE, bl_len = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
+        const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE;
+        const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
+        uint32_t nlit = blk_nlit[b], nseq = blk_nseq[b];
+        int last = (b + 1 == nblk);
+        uint8_t *out = tmpblk; size_t csz = 0, sb = 0; int ok = seq_ok || nseq == 0;
+        int used_huf = 0;
+        if (ok) {
+            /* literals section */
+            int rle = 0;
+            if ((flags & PNA_F_HUF) && nlit >= 64) { rle = 1; for (uint32_t i = 1; i < nlit; i++) if (bl[i] != bl[0]) { rle = 0; break; } }
+            size_t raw_h = nlit < 32 ? 1 : (nlit < 4096 ? 2 : 3);
+            if (rle) { csz = put_raw_lit_header(out, 1, nlit); out[csz++] = bl[0]; }
+            else {
+                size_t hs = 0, lh = 3 + (nlit >= 1024) + (nlit >= 16384), ts = have_huf ? 0 : t->tree_len;
+                if (t->huf_ok && nlit >= 64) hs = block_huf_body(t, bl, nlit, hbody);
+                if (hs && lh + ts + hs < raw_h + nlit) {
+                    uint64_t type = have_huf ? 3u : 2u, comp = ts + hs, h;
+                    if (lh == 3) h = type | ((uint64_t)(nlit >= 256 ? 1 : 0) << 2) | ((uint64_t)nlit << 4) | (comp << 14);
+                    else if (lh == 4) h = type | (2u << 2) | ((uint64_t)nlit << 4) | (comp << 18);
+                    else h = type | (3u << 2) | ((uint64_t)nlit << 4) | (comp << 22);
+                    for (size_t i = 0; i < lh; i++) out[csz++] = (uint8_t)(h >> (8 * i));
+                    memcpy(out + csz, t->tree, ts); csz += ts;
+                    memcpy(out + csz, hbody, hs); csz += hs;
+                    used_huf = 1;
+                } else { csz = put_raw_lit_header(out, 0, nlit); memcpy(out + csz, bl, nlit); csz += nlit; }
+            }
+            /* sequences section */
+            if (nseq < 128) out[csz++] = (uint8_t)nseq;
+            else if (nseq < 0x7F00) { out[csz++] = (uint8_t)((nseq >> 8) + 128); out[csz++] = (uint8_t)nseq; }
+            else { out[csz++] = 255; out[csz++] = (uint8_t)(nseq - 0x7F00); out[csz++] = (uint8_t)((nseq - 0x7F00) >> 8); }
+            if (nseq) {
+                int m[3];
+                for (int k = 0; k < 3; k++) m[k] = t->mode[k] == 0 ? 0 : (have_seq ? 3 : t->mode[k]);
+                out[csz++] = (uint8_t)((m[0] << 6) | (m[1] << 4) | (m[2] << 2));
+                if (!have_seq) for (int k = 0; k < 3; k++) { memcpy(out + csz, t->desc[k], t->desc_len[k]); csz += t->desc_len[k]; }
+                sb = block_seq_bits(t, bs, ofb + (size_t)b * (PNA_BLK_SIZE / 4), nseq, sbits);
+            }
+        }
+        uint32_t hdr;
+        if (!ok || csz + sb >= bl_len) {
+            hdr = (uint32_t)last | (0u << 1) | (bl_len << 3);
+            memcpy(dst + op + 3, seg + b0, bl_len); csz = bl_len;
+        } else {
+            memcpy(dst + op + 3, out, csz); memcpy(dst + op + 3 + csz, sbits, sb); csz += sb;
+            hdr = (uint32_t)last | (2u << 1) | ((uint32_t)csz << 3);
+            if (used_huf) have_huf = 1;
+            if (nseq) have_seq = 1;
+        }
+        dst[op] = (uint8_t)hdr; dst[op + 1] = (uint8_t)(hdr >> 8); dst[op + 2] = (uint8_t)(hdr >> 16);
+        op += 3 + csz;
+    }
+    free(tmpblk); free(hbody); free(sbits); free(ofb); free(t);
+    return op;
 }
 
 size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const pna_zstd_params *p) {
@@ -506,19 +554,21 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     size_t op = 0;
     if (n == 0) { static const uint8_t e[9] = {0x28,0xB5,0x2F,0xFD,0x20,0x00,0x01,0x00,0x00}; memcpy(dst, e, 9); return 9; }
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) << p->hash_log);
-    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (PNA_BLK_SIZE / 3 + 8));
-    uint8_t *lits = (uint8_t *)malloc(PNA_BLK_SIZE + 8);
+    uint32_t maxblk = PNA_SEG_SIZE / PNA_BLK_SIZE;
+    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (PNA_BLK_SIZE / 4));
+    uint8_t *lits = (uint8_t *)malloc((size_t)PNA_SEG_SIZE + 8);
+    uint32_t blk_nseq[PNA_SEG_SIZE / PNA_BLK_SIZE], blk_nlit[PNA_SEG_SIZE / PNA_BLK_SIZE];
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
-        static const uint8_t fh[6] = {0x28,0xB5,0x2F,0xFD,0x00,0x50};
-        memcpy(dst + op, fh, 6); op += 6;
         memset(table, 0, sizeof(uint32_t) << p->hash_log);
-        for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE) {
+        uint32_t b = 0;
+        for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE, b++) {
             uint32_t bl = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
-            uint32_t nlit, nseq = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs, lits, &nlit);
-            op += pna_zstd_encode_block(seg + b0, bl, seqs, nseq, lits, nlit, b0 + bl >= seg_len, p->flags, dst + op);
+            blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)b * (PNA_BLK_SIZE / 4),
+                                       lits + (size_t)b * PNA_BLK_SIZE, &blk_nlit[b]);
         }
+        op += pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, dst + op);
     }
     free(table); free(seqs); free(lits);
     return op;

@@ -46,7 +46,8 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
 uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, uint32_t blk_len,
                       uint32_t *table, const pna_zstd_params *p,
                       pna_seq *seqs, uint8_t *lits, uint32_t *nlit_out);
-/* entropy + block framing for one block: returns the size of the block INCLUDING its 3-byte header */
-size_t pna_zstd_encode_block(const uint8_t *blk, uint32_t blk_len, const pna_seq *seqs, uint32_t nseq,
-                             const uint8_t *lits, uint32_t nlit, int last, uint32_t flags, uint8_t *dst);
+/* entropy + framing for one segment (= one frame) from the LZ stage's per-block outputs; seqs of block b start at
+ * index b*(PNA_BLK_SIZE/4), its literals at byte b*PNA_BLK_SIZE.  Returns the frame size. */
+size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_seq *seqs, const uint8_t *lits,
+                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint8_t *dst);
 #endif

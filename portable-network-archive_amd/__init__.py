@@ -1,0 +1,246 @@
+"""portable-network-archive_amd -- MI355X-native per-entry compression path of PNA (host-side Python binding).
+
+Thin ctypes layer over the C ABI of ``libpna_gpu.so`` (include/pna_gpu.h).  It mirrors the names of the reference's
+seam -- ``Compression`` (lib/src/entry/options.rs:241-247), ``CompressionLevel`` defaults
+(lib/src/compress/zstandard.rs:13, lib/src/compress/deflate.rs:33-38) and a ``CompressionWriter`` with
+``write`` / ``flush`` / ``try_into_inner`` (lib/src/compress.rs:21-76) -- so tests read like the reference's own.
+
+There is no CPU fallback: if the HIP extension is missing or no GPU is usable, construction raises.
+(The package directory name contains a hyphen; import it with ``importlib.import_module("portable-network-archive_amd")``.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Iterable, List, Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpna_gpu.so")
+
+PNA_OK = 0
+ALGO_STORE, ALGO_DEFLATE, ALGO_ZSTD = 0, 1, 2
+LEVEL_DEFAULT = -1000
+F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
+
+SEG_SIZE = 1 << 20
+BLK_SIZE = 1 << 17
+SEQ_CAP = 22016
+
+
+class Compression:
+    """Compression::to_byte() values -- lib/src/entry/options.rs:241-247."""
+    No = ALGO_STORE
+    Deflate = ALGO_DEFLATE
+    ZStandard = ALGO_ZSTD
+
+
+class PnaGpuError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"pna_gpu error {code}: {text}")
+        self.code = code
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("ms_lz", ctypes.c_double), ("ms_stats", ctypes.c_double), ("ms_lit", ctypes.c_double),
+                ("ms_seq", ctypes.c_double), ("ms_pack", ctypes.c_double), ("in_bytes", ctypes.c_uint64),
+                ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64)]
+
+
+SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+_lib = None
+
+EXPORTS = [
+    "pna_gpu_init", "pna_gpu_shutdown", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
+    "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
+    "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_bench_corpus_fill_device",
+]
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libpna_gpu.so (built in-tree by __graft_entry__.build()).  Fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the compression path)")
+    try:  # share PyTorch's HIP runtime when torch is used in the same process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u32, u64p = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)
+    L.pna_gpu_init.restype = ctypes.c_int
+    L.pna_gpu_init.argtypes = [ctypes.POINTER(vp), ctypes.c_int, u32]
+    L.pna_gpu_shutdown.restype = None
+    L.pna_gpu_shutdown.argtypes = [vp]
+    L.pna_gpu_last_error.restype = ctypes.c_char_p
+    L.pna_gpu_last_error.argtypes = [vp]
+    L.pna_gpu_strerror.restype = ctypes.c_char_p
+    L.pna_gpu_strerror.argtypes = [ctypes.c_int]
+    L.pna_gpu_bound.restype = sz
+    L.pna_gpu_bound.argtypes = [ctypes.c_int, sz]
+    L.pna_gpu_clamp_level.restype = ctypes.c_int
+    L.pna_gpu_clamp_level.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pna_gpu_compress_batch.restype = ctypes.c_int
+    L.pna_gpu_compress_batch.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                         ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.pna_gpu_compress_batch_device.restype = ctypes.c_int
+    L.pna_gpu_compress_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, vp, u64p, u64p, vp, sz, u64p, vp]
+    L.pna_gpu_stream_new.restype = ctypes.c_int
+    L.pna_gpu_stream_new.argtypes = [vp, ctypes.c_int, ctypes.c_int, SINK_FN, vp, ctypes.POINTER(vp)]
+    L.pna_gpu_stream_write.restype = ctypes.c_int
+    L.pna_gpu_stream_write.argtypes = [vp, ctypes.c_char_p, sz]
+    L.pna_gpu_stream_flush.restype = ctypes.c_int
+    L.pna_gpu_stream_flush.argtypes = [vp]
+    L.pna_gpu_stream_finish.restype = ctypes.c_int
+    L.pna_gpu_stream_finish.argtypes = [vp]
+    L.pna_gpu_stream_abort.restype = None
+    L.pna_gpu_stream_abort.argtypes = [vp]
+    L.pna_gpu_compress_solid.restype = ctypes.c_int
+    L.pna_gpu_compress_solid.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, SINK_FN, vp]
+    L.pna_gpu_last_timing.restype = ctypes.c_int
+    L.pna_gpu_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+    L.pna_gpu_debug_block.restype = ctypes.c_int
+    L.pna_gpu_debug_block.argtypes = [vp, u32, u64p, u32, ctypes.POINTER(u32), ctypes.c_char_p, u32, ctypes.POINTER(u32)]
+    L.pna_bench_corpus_fill_device.restype = ctypes.c_int
+    L.pna_bench_corpus_fill_device.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_uint64, vp, vp]
+    _lib = L
+    return L
+
+
+def bound(algo: int, n: int) -> int:
+    return load_library().pna_gpu_bound(algo, n)
+
+
+def clamp_level(algo: int, level: int = LEVEL_DEFAULT) -> int:
+    """From<CompressionLevel> mappings -- compress/zstandard.rs:43-57, compress/deflate.rs:89-101."""
+    return load_library().pna_gpu_clamp_level(algo, level)
+
+
+class Context:
+    """One GPU context (pna_gpu_init).  Raises PnaGpuError(PNA_E_NODEVICE) without a usable MI355X."""
+
+    def __init__(self, device: int = 0, flags: int = F_DEFAULT):
+        self._L = load_library()
+        h = ctypes.c_void_p()
+        rc = self._L.pna_gpu_init(ctypes.byref(h), device, flags)
+        if rc != PNA_OK:
+            raise PnaGpuError(rc, self._L.pna_gpu_strerror(rc).decode())
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.pna_gpu_shutdown(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != PNA_OK:
+            raise PnaGpuError(rc, self._L.pna_gpu_last_error(self._h).decode() or self._L.pna_gpu_strerror(rc).decode())
+
+    # ---- batch of independent entries (host buffers)
+    def compress_batch(self, entries: Sequence[bytes], algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT) -> List[bytes]:
+        n = len(entries)
+        if n == 0:
+            return []
+        srcs = [ctypes.create_string_buffer(bytes(e), max(len(e), 1)) for e in entries]
+        caps = [self._L.pna_gpu_bound(algo, len(e)) for e in entries]
+        dsts = [ctypes.create_string_buffer(c) for c in caps]
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        a_src = (vp * n)(*[ctypes.cast(b, vp) for b in srcs])
+        a_len = (sz * n)(*[len(e) for e in entries])
+        a_dst = (vp * n)(*[ctypes.cast(b, vp) for b in dsts])
+        a_cap = (sz * n)(*caps)
+        a_out = (sz * n)()
+        self._check(self._L.pna_gpu_compress_batch(self._h, algo, level, n, a_src, a_len, a_dst, a_cap, a_out))
+        return [dsts[i].raw[:a_out[i]] for i in range(n)]
+
+    # ---- batch resident in HBM (raw device pointers; torch tensors via .data_ptr())
+    def compress_batch_device(self, d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int, dst_cap: int,
+                              algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0) -> List[int]:
+        n = len(src_len)
+        a_off = (ctypes.c_uint64 * (n + 1))(*src_off) if len(src_off) == n + 1 else (ctypes.c_uint64 * (n + 1))(*list(src_off), 0)
+        a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+        a_out = (ctypes.c_uint64 * (n + 1))()
+        self._check(self._L.pna_gpu_compress_batch_device(self._h, algo, level, n, ctypes.c_void_p(d_src), a_off, a_len,
+                                                          ctypes.c_void_p(d_dst), dst_cap, a_out,
+                                                          ctypes.c_void_p(stream) if stream else None))
+        return list(a_out)
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._check(self._L.pna_gpu_last_timing(self._h, ctypes.byref(t)))
+        return t
+
+    def debug_block(self, block: int):
+        """LZ-stage output of one block of the last device batch: (list of (ll, ml, off), literal bytes)."""
+        seqs = (ctypes.c_uint64 * SEQ_CAP)()
+        lits = ctypes.create_string_buffer(BLK_SIZE)
+        ns, nl = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._L.pna_gpu_debug_block(self._h, block, seqs, SEQ_CAP, ctypes.byref(ns), lits, BLK_SIZE, ctypes.byref(nl)))
+        out = [((s >> 38) & 0x3FFFF, (s >> 20) & 0x3FFFF, s & 0xFFFFF) for s in seqs[:ns.value]]
+        return out, lits.raw[:nl.value]
+
+    def corpus_fill_device(self, kind: int, first_file: int, n_files: int, file_len: int, stride: int, d_dst: int) -> None:
+        self._check(self._L.pna_bench_corpus_fill_device(self._h, kind, first_file, n_files, file_len, stride,
+                                                         ctypes.c_void_p(d_dst), None))
+
+    # ---- streaming facade
+    def writer(self, sink, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT) -> "CompressionWriter":
+        return CompressionWriter(self, sink, algo, level)
+
+    def compress_solid(self, data: bytes, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT) -> List[bytes]:
+        """SolidArchive payload: returns the pieces pushed to the sink (one SDAT chunk each in the reference)."""
+        pieces: List[bytes] = []
+
+        def _sink(_u, buf, n):
+            pieces.append(ctypes.string_at(buf, n))
+            return 0
+        cb = SINK_FN(_sink)
+        self._check(self._L.pna_gpu_compress_solid(self._h, algo, level, bytes(data), len(data), cb, None))
+        return pieces
+
+
+class CompressionWriter:
+    """Shape of CompressionWriter<W> -- lib/src/compress.rs:21-76: write(), flush(), try_into_inner() (= finish)."""
+
+    def __init__(self, ctx: Context, sink, algo: int, level: int):
+        self._ctx, self._sink_obj = ctx, sink
+
+        def _sink(_u, buf, n):
+            try:
+                sink.write(ctypes.string_at(buf, n))
+                return 0
+            except Exception:
+                return 1
+        self._cb = SINK_FN(_sink)
+        h = ctypes.c_void_p()
+        ctx._check(ctx._L.pna_gpu_stream_new(ctx._h, algo, level, self._cb, None, ctypes.byref(h)))
+        self._h = h
+
+    def write(self, data: bytes) -> int:
+        self._ctx._check(self._ctx._L.pna_gpu_stream_write(self._h, bytes(data), len(data)))
+        return len(data)
+
+    def flush(self) -> None:
+        self._ctx._check(self._ctx._L.pna_gpu_stream_flush(self._h))
+
+    def try_into_inner(self):
+        h, self._h = self._h, None
+        self._ctx._check(self._ctx._L.pna_gpu_stream_finish(h))
+        return self._sink_obj

@@ -1,0 +1,618 @@
+// k_entropy.hip -- entropy stage of the gfx950 zstd-format encoder:
+//   k_stats  one workgroup per segment: literal / LL / OF / ML histograms (LDS atomics), then the segment's
+//            Huffman code (<= 11 bits) + tree description and the three FSE tables + descriptions.
+//   k_lit    one workgroup per block: RLE test and 1- or 4-stream Huffman bit packing (one wave per stream,
+//            wave scan of bit lengths, 32-bit atomic OR into the zeroed body).
+//   k_seq    one LANE per block, the lanes of one segment sharing the segment's tables in LDS: the serial tANS
+//            state chain of the sequences bitstream.
+//   k_plan   one thread per segment: block types, which block carries the table descriptions, sizes.
+//   k_scan   exclusive scan of segment sizes -> output offsets.
+//   k_write  one workgroup per block: frame/block/section headers + payload into the packed output.
+// Replaces libzstd's HUF_compress4X / ZSTD_encodeSequences / block+frame assembly behind
+// lib/src/entry/write.rs:260-262.  Integer/bit work only.
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+// ------------------------------------------------------------------ code tables (RFC 8878 3.1.1.3.2.1)
+__constant__ uint8_t C_LL_CODE[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
+__constant__ uint8_t C_ML_CODE[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+                                       32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+                                       40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+                                       42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42};
+__constant__ uint32_t C_LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+__constant__ uint8_t  C_LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__constant__ uint32_t C_ML_BASE[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+__constant__ uint8_t  C_ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+__constant__ int16_t C_LL_DEF[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__constant__ int16_t C_ML_DEF[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+__constant__ int16_t C_OF_DEF[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+
+__device__ __forceinline__ uint32_t hb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+__device__ __forceinline__ uint32_t ll_code(uint32_t v) { return v < 64 ? C_LL_CODE[v] : hb(v) + 19; }
+__device__ __forceinline__ uint32_t ml_code(uint32_t ml) { uint32_t b = ml - 3; return b < 128 ? C_ML_CODE[b] : hb(b) + 36; }
+
+// ------------------------------------------------------------------ serial bit writer (thread-private)
+struct BitW { uint8_t *p; uint32_t pos; uint64_t acc; uint32_t nb; };
+__device__ __forceinline__ void bw_init(BitW &w, uint8_t *p) { w.p = p; w.pos = 0; w.acc = 0; w.nb = 0; }
+__device__ __forceinline__ void bw_add(BitW &w, uint32_t v, uint32_t n) {
+    if (n == 0) return;
+    w.acc |= (uint64_t)(v & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u))) << w.nb; w.nb += n;
+    while (w.nb >= 8) { w.p[w.pos++] = (uint8_t)w.acc; w.acc >>= 8; w.nb -= 8; }
+}
+__device__ __forceinline__ uint32_t bw_close(BitW &w, bool marker) {
+    if (marker) bw_add(w, 1, 1);
+    if (w.nb > 0) { w.p[w.pos++] = (uint8_t)w.acc; w.acc = 0; w.nb = 0; }
+    return w.pos;
+}
+
+// ------------------------------------------------------------------ FSE helpers (thread 0 of k_stats)
+// counts -> normalised counts summing to 1 << tlog (every present symbol >= 1, no "-1" entries)
+__device__ void fse_normalize(const uint32_t *count, int nsym, uint32_t total, int tlog, int16_t *norm) {
+    int size = 1 << tlog, sum = 0, best = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        uint32_t q = (uint32_t)(((uint64_t)count[s] << tlog) / total);
+        if (q == 0) q = 1;
+        norm[s] = (int16_t)q; sum += (int)q;
+        if (count[s] > count[best]) best = s;
+    }
+    while (sum > size) {
+        int m = 0;
+        for (int s = 1; s < nsym; s++) if (norm[s] > norm[m]) m = s;
+        norm[m]--; sum--;
+    }
+    if (sum < size) norm[best] = (int16_t)(norm[best] + (size - sum));
+}
+
+__device__ uint32_t fse_write_ncount(uint8_t *dst, const int16_t *norm, int nsym, int tlog) {
+    BitW w; bw_init(w, dst);
+    bw_add(w, (uint32_t)(tlog - 5), 4);
+    int remaining = (1 << tlog) + 1, threshold = 1 << tlog, nbits = tlog + 1, s = 0;
+    while (remaining > 1 && s < nsym) {
+        int count = norm[s++];
+        int mx = (2 * threshold - 1) - remaining;
+        remaining -= count < 0 ? -count : count;
+        int v = count + 1;
+        if (v >= threshold) v += mx;
+        bw_add(w, (uint32_t)v, (uint32_t)(nbits - (v < mx ? 1 : 0)));
+        if (count == 0) {
+            int z = 0;
+            while (s + z < nsym && norm[s + z] == 0) z++;
+            s += z;
+            while (z >= 3) { bw_add(w, 3, 2); z -= 3; }
+            bw_add(w, (uint32_t)z, 2);
+        }
+        while (remaining < threshold) { nbits--; threshold >>= 1; }
+    }
+    return bw_close(w, false);
+}
+
+// encoder table from normalised counts; `cell` is scratch of 1 << tlog bytes
+__device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int tlog, uint8_t *cell) {
+    int size = 1 << tlog, high = size - 1;
+    for (int s = 0; s < nsym; s++) if (norm[s] == -1) cell[high--] = (uint8_t)s;
+    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) { cell[pos] = (uint8_t)s; do { pos = (pos + step) & mask; } while (pos > high); }
+    int cum = 0;
+    for (int s = 0; s < nsym; s++) {
+        int n = norm[s] == -1 ? 1 : norm[s];
+        SeqSym y; y.delta_nb = 0; y.delta_find = 0; y.first_state = 0;
+        if (n > 0) {
+            int maxbits = (n == 1) ? tlog : tlog - (int)hb((uint32_t)(n - 1));
+            y.delta_nb = (uint32_t)((maxbits << 16) - (n << maxbits));
+            y.delta_find = (int16_t)(cum - n);
+        }
+        t->sym[s] = y;
+        // cells of symbol s in ascending cell order -> state[cum .. cum+n)
+        int k = cum;
+        for (int u = 0; u < size && k < cum + n; u++) if (cell[u] == s) { if (k == cum) t->sym[s].first_state = (uint16_t)(size + u); t->state[k++] = (uint16_t)(size + u); }
+        cum += n;
+    }
+}
+
+// ------------------------------------------------------------------ k_stats
+constexpr uint32_t ST_THREADS = 256;
+constexpr int HUF_MAX = 11;
+
+__device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint8_t *depth) {
+    int n = 0;
+    for (int s = 0; s < 256; s++) { lens[s] = 0; if (count[s]) order[n++] = (uint16_t)s; }
+    if (n < 2) return n;
+    for (int i = 1; i < n; i++) {                      // sort by (count asc, symbol asc)
+        uint16_t x = order[i]; int j = i - 1;
+        while (j >= 0 && count[order[j]] > count[x]) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = x;
+    }
+    for (int i = 0; i < n; i++) wt[i] = count[order[i]];
+    int lq = 0, iq = n, nn = n;
+    while (nn < 2 * n - 1) {                           // two-queue Huffman, leaves win ties
+        int a, b;
+        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
+        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
+        wt[nn] = wt[a] + wt[b]; parent[a] = (uint16_t)nn; parent[b] = (uint16_t)nn; nn++;
+    }
+    depth[nn - 1] = 0;
+    for (int i = nn - 2; i >= 0; i--) depth[i] = (uint8_t)(depth[parent[i]] + 1);   // depth < 256 for n <= 256
+    bool over = false;
+    for (int i = 0; i < n; i++) { int d = depth[i]; if (d > HUF_MAX) { d = HUF_MAX; over = true; } lens[order[i]] = (uint8_t)d; }
+    if (!over) return n;
+    int K = 0;
+    for (int i = 0; i < n; i++) K += 1 << (HUF_MAX - lens[order[i]]);
+    int debt = K - (1 << HUF_MAX);
+    while (debt > 0) {
+        int pick = -1, bl = 0;
+        for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < HUF_MAX && l > bl) { bl = l; pick = i; } }
+        lens[order[pick]]++; debt -= 1 << (HUF_MAX - 1 - bl);
+    }
+    while (debt < 0) {
+        int pick = -1, bl = 99, slack = -debt;
+        for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (HUF_MAX - l)) <= slack && l < bl) { bl = l; pick = i; } }
+        if (pick < 0) return -1;
+        lens[order[pick]]--; debt += 1 << (HUF_MAX - bl);
+    }
+    return n;
+}
+
+// Huffman tree description (direct 4-bit weights or FSE-compressed weights); returns bytes (0 = not representable)
+__device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sym, int maxbits, uint8_t *wts, uint8_t *tmp,
+                                   SeqTable *scratch_tab, uint8_t *cell) {
+    int nw = max_sym;
+    for (int s = 0; s < nw; s++) wts[s] = lens[s] ? (uint8_t)(maxbits + 1 - lens[s]) : 0;
+    uint32_t fse_size = 0;
+    {
+        uint32_t cnt[16]; for (int i = 0; i < 16; i++) cnt[i] = 0;
+        int maxw = 0, distinct = 0; uint32_t maxc = 0;
+        for (int i = 0; i < nw; i++) { cnt[wts[i]]++; if (wts[i] > maxw) maxw = wts[i]; }
+        for (int v = 0; v <= maxw; v++) { if (cnt[v]) distinct++; if (cnt[v] > maxc) maxc = cnt[v]; }
+        if (distinct >= 2 && nw >= 2 && maxc > 1) {
+            int tlog = (int)hb((uint32_t)(nw - 1)) - 2, minlog = 5;
+            while ((1 << minlog) < distinct) minlog++;
+            if (tlog < minlog) tlog = minlog;
+            if (tlog > 6) tlog = 6;
+            int16_t norm[16];
+            fse_normalize(cnt, maxw + 1, (uint32_t)nw, tlog, norm);
+            uint32_t hs = fse_write_ncount(tmp + 1, norm, maxw + 1, tlog);
+            fse_build_table(scratch_tab, norm, maxw + 1, tlog, cell);
+            BitW w; bw_init(w, tmp + 1 + hs);
+            int i = nw; uint32_t s1, s2;
+            auto enc = [&](uint32_t st, int sy) -> uint32_t {
+                const SeqSym y = scratch_tab->sym[sy];
+                uint32_t nb = (st + y.delta_nb) >> 16;
+                bw_add(w, st, nb);
+                return scratch_tab->state[(int)(st >> nb) + y.delta_find];
+            };
+            if (nw & 1) { s1 = scratch_tab->sym[wts[--i]].first_state; s2 = scratch_tab->sym[wts[--i]].first_state; s1 = enc(s1, wts[--i]); }
+            else { s2 = scratch_tab->sym[wts[--i]].first_state; s1 = scratch_tab->sym[wts[--i]].first_state; }
+            while (i > 0) { s2 = enc(s2, wts[--i]); s1 = enc(s1, wts[--i]); }
+            bw_add(w, s2, (uint32_t)tlog); bw_add(w, s1, (uint32_t)tlog);
+            uint32_t bs = bw_close(w, true);
+            if (hs + bs < 128) { fse_size = hs + bs; tmp[0] = (uint8_t)fse_size; }
+        }
+    }
+    uint32_t direct = (nw <= 128) ? (uint32_t)(nw + 1) / 2 : 0;
+    if (fse_size && (!direct || fse_size < direct)) { for (uint32_t i = 0; i < 1 + fse_size; i++) dst[i] = tmp[i]; return 1 + fse_size; }
+    if (!direct) return 0;
+    dst[0] = (uint8_t)(127 + nw);
+    for (int i = 0; i < nw; i += 2) dst[1 + i / 2] = (uint8_t)((wts[i] << 4) | (i + 1 < nw ? wts[i + 1] : 0));
+    return 1 + direct;
+}
+
+// one of LL / OF / ML: mode + description + encoder table; returns false when no valid table exists
+__device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32_t nseq, int alphabet,
+                          const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *cell) {
+    int maxs = 0, distinct = 0;
+    for (int s = 0; s < alphabet; s++) if (count[s]) { maxs = s; distinct++; }
+    T->desc_len[which] = 0;
+    if (distinct == 1 && nseq > 2) { T->desc[which][0] = (uint8_t)maxs; T->desc_len[which] = 1; T->tlog[which] = 0; T->mode[which] = 1; return true; }
+    bool def_ok = maxs < def_n;
+    if (!(flags & F_FSE) || (nseq < 64 && def_ok)) {
+        if (!def_ok) return false;
+        fse_build_table(&T->tab[which], def, def_n, def_log, cell); T->tlog[which] = (uint32_t)def_log; T->mode[which] = 0; return true;
+    }
+    int tlog = (int)hb(nseq - 1) - 2, minlog = 5;
+    while ((1 << minlog) < distinct) minlog++;
+    if (tlog < minlog) tlog = minlog;
+    if (tlog > (int)SEQ_MAX_LOG) tlog = (int)SEQ_MAX_LOG;
+    int16_t norm[64];
+    fse_normalize(count, maxs + 1, nseq, tlog, norm);
+    T->desc_len[which] = fse_write_ncount(T->desc[which], norm, maxs + 1, tlog);
+    fse_build_table(&T->tab[which], norm, maxs + 1, tlog, cell);
+    T->tlog[which] = (uint32_t)tlog; T->mode[which] = 2;
+    return true;
+}
+
+__global__ __launch_bounds__(ST_THREADS)
+void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
+             const BlkInfo *__restrict__ blk, SegTables *__restrict__ tabs, uint32_t flags) {
+    __shared__ uint32_t h_lit[8][256];
+    __shared__ uint32_t h_seq[3][4][64];
+    __shared__ uint32_t count[256];
+    __shared__ uint32_t scount[3][64];
+    __shared__ uint16_t order[256];
+    __shared__ uint32_t wt[512];
+    __shared__ uint16_t parent[512];
+    __shared__ uint8_t  depth[512];
+    __shared__ uint8_t  lens[256];
+    __shared__ uint8_t  wts[256];
+    __shared__ uint8_t  tmp[320];
+    __shared__ uint8_t  cell[256];
+    __shared__ SeqTable wtab;
+    const uint32_t tid = threadIdx.x;
+    const SegDesc sd = segs[blockIdx.x];
+    SegTables *T = tabs + blockIdx.x;
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+
+    for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
+    __syncthreads();
+    uint32_t nseq_seg = 0;
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t g = sd.blk_base + b;
+        const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
+        nseq_seg += nseq;
+        const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+        uint32_t *hl = h_lit[tid & 7];
+        const uint32_t n16 = nlit >> 4;
+        for (uint32_t i = tid; i < n16; i += ST_THREADS) {
+            uint4 v = ((const uint4 *)bl)[i];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&hl[w[k] & 0xFF], 1u); atomicAdd(&hl[(w[k] >> 8) & 0xFF], 1u);
+                atomicAdd(&hl[(w[k] >> 16) & 0xFF], 1u); atomicAdd(&hl[w[k] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += ST_THREADS) atomicAdd(&hl[bl[i]], 1u);
+        const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+        for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
+            uint64_t s = bs[i];
+            atomicAdd(&h_seq[0][tid & 3][ll_code(seq_ll(s))], 1u);
+            atomicAdd(&h_seq[1][tid & 3][hb(seq_off(s) + 3)], 1u);
+            atomicAdd(&h_seq[2][tid & 3][ml_code(seq_ml(s))], 1u);
+        }
+    }
+    __syncthreads();
+    { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; count[tid] = c; }
+    if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63; scount[w][s] = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; }
+    __syncthreads();
+    if (tid != 0) return;
+
+    // ---- thread 0: tables (serial, mirrors DESIGN.md "Encoder specification")
+    T->huf_ok = 0; T->tree_len = 0; T->max_sym = 0; T->maxbits = 0; T->seq_ok = 1; T->nseq_seg = nseq_seg;
+    for (int k = 0; k < 3; k++) { T->mode[k] = 0; T->tlog[k] = 0; T->desc_len[k] = 0; }
+    if (flags & F_HUF) {
+        int np = huf_build_lens(count, lens, order, wt, parent, depth);
+        if (np >= 2) {
+            int max_sym = 0, maxbits = 0;
+            for (int s = 0; s < 256; s++) if (count[s]) max_sym = s;
+            for (int s = 0; s <= max_sym; s++) if (lens[s] > maxbits) maxbits = lens[s];
+            // canonical codes: weight-1 symbols first (ascending symbol), code = cell index >> (weight-1)
+            uint32_t pos = 0;
+            for (int s = 0; s < 256; s++) T->huf_code[s] = 0;
+            for (int w = 1; w <= maxbits; w++) {
+                int l = maxbits + 1 - w;
+                for (int s = 0; s <= max_sym; s++) if (lens[s] == l) { T->huf_code[s] = (pos >> (w - 1)) | ((uint32_t)l << 16); pos += 1u << (w - 1); }
+            }
+            uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell);
+            T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0;
+        }
+    }
+    if (nseq_seg) {
+        bool ok = true;
+        ok &= seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell);
+        ok &= seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell);
+        ok &= seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell);
+        T->seq_ok = ok ? 1u : 0u;
+    }
+}
+
+// ------------------------------------------------------------------ k_lit
+constexpr uint32_t LIT_THREADS = 256;
+
+__global__ __launch_bounds__(LIT_THREADS)
+void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint8_t *__restrict__ lits,
+           BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags) {
+    __shared__ uint32_t code[256];
+    __shared__ uint32_t sbits[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x;
+    const SegTables *T = tabs + blk_seg[g];
+    const uint32_t nlit = blk[g].nlit;
+    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    uint32_t *out32 = (uint32_t *)(litc + (size_t)g * BLK_SIZE);
+    if (!(flags & F_HUF) || nlit < 64) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
+    // RLE test
+    {
+        const uint8_t b0 = bl[0]; int same = 1;
+        for (uint32_t i = tid; i < nlit; i += LIT_THREADS) same &= (bl[i] == b0);
+        same = __syncthreads_and(same);
+        if (same) { if (tid == 0) { blk[g].lit_rle = 1; blk[g].lit_body = 0; } return; }
+    }
+    if (!T->huf_ok) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
+    code[tid] = T->huf_code[tid];
+    __syncthreads();
+    const uint32_t nstreams = nlit >= 256 ? 4u : 1u;
+    const uint32_t segsz = nstreams == 4 ? (nlit + 3) / 4 : nlit;
+    // stream `wave`: symbols [a, a+m)
+    uint32_t a = wave * segsz, m = 0;
+    if (wave < nstreams) m = (nstreams == 4 && wave == 3) ? nlit - 3 * segsz : segsz;
+    const uint32_t chunk = (m + 63) / 64;
+    uint32_t c0 = a + lane * chunk, c1 = c0 + chunk; if (c1 > a + m) c1 = a + m; if (c0 > c1) c0 = c1;
+    uint32_t bits = 0;
+    for (uint32_t i = c0; i < c1; i++) bits += code[bl[i]] >> 16;
+    uint32_t sc = bits;                                            // inclusive scan over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
+    const uint32_t total = (uint32_t)__shfl((int)sc, 63);
+    if (lane == 0 && wave < 4) sbits[wave] = wave < nstreams ? total : 0;
+    __syncthreads();
+    // stream byte sizes and offsets
+    uint32_t sz[4], off[4], body = nstreams == 4 ? 6u : 0u;
+    for (uint32_t k = 0; k < 4; k++) { sz[k] = k < nstreams ? (sbits[k] >> 3) + 1 : 0; off[k] = body; body += sz[k]; }
+    if (tid == 0) { blk[g].lit_body = body; blk[g].lit_rle = 0; }
+    if (body >= nlit || body > BLK_SIZE) return;                   // Huffman cannot win: k_plan picks raw literals
+    for (uint32_t i = tid; i < (body + 3) / 4; i += LIT_THREADS) out32[i] = 0;
+    __syncthreads();
+    if (wave < nstreams) {
+        // lane's symbols occupy stream bits [total - sc, total - sc + bits); later symbols sit at lower bits
+        uint64_t pos = (uint64_t)off[wave] * 8 + (total - sc);
+        uint32_t widx = (uint32_t)(pos >> 5); uint32_t nb = (uint32_t)(pos & 31); uint64_t acc = 0;
+        for (uint32_t i = c1; i-- > c0;) {
+            uint32_t cv = code[bl[i]];
+            acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
+            if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+        }
+        if (lane == 0) { acc |= (uint64_t)1 << nb; nb += 1; if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; } }
+        if (nb) atomicOr(&out32[widx], (uint32_t)acc);
+    }
+    if (tid == 0 && nstreams == 4) {
+        atomicOr(&out32[0], sz[0] | (sz[1] << 16));
+        atomicOr(&out32[1], sz[2]);
+    }
+}
+
+// ------------------------------------------------------------------ k_seq : one lane per block
+constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // 8 segments x 8 blocks = 64 lanes
+
+__global__ __launch_bounds__(64)
+void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
+           const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc) {
+    __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
+        const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
+        uint32_t *dstw = (uint32_t *)&tab[s][0];
+        for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
+    }
+    __syncthreads();
+    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
+    if (sidx >= nseg) return;
+    const SegDesc sd = segs[sidx];
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    if (b >= nblk) return;
+    const uint32_t g = sd.blk_base + b;
+    const SegTables *T = tabs + sidx;
+    const uint32_t nseq = blk[g].nseq;
+    if (nseq == 0 || !T->seq_ok) { blk[g].seq_bits = 0; return; }
+    const uint32_t mll = T->mode[0], mof = T->mode[1], mml = T->mode[2];
+    const uint32_t tl_ll = T->tlog[0], tl_of = T->tlog[1], tl_ml = T->tlog[2];
+    const SeqTable *tll = &tab[sl][0], *tof = &tab[sl][1], *tml = &tab[sl][2];
+    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+    uint32_t *out32 = (uint32_t *)(seqc + (size_t)g * BLK_SIZE);
+    const uint32_t cap_words = BLK_SIZE / 4;
+    uint64_t acc = 0; uint32_t nb = 0, widx = 0;
+    auto put = [&](uint32_t v, uint32_t n) {               // n <= 20, v < 2^n
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
+    };
+    uint32_t i = nseq - 1;
+    uint64_t s = bs[i];
+    uint32_t llv = seq_ll(s), mlv = seq_ml(s), ofb = seq_off(s) + 3;
+    uint32_t lc = ll_code(llv), mc = ml_code(mlv), oc = hb(ofb);
+    uint32_t st_ml = mml == 1 ? 0u : tml->sym[mc].first_state;
+    uint32_t st_of = mof == 1 ? 0u : tof->sym[oc].first_state;
+    uint32_t st_ll = mll == 1 ? 0u : tll->sym[lc].first_state;
+    put(llv - C_LL_BASE[lc], C_LL_BITS[lc]);
+    put(mlv - C_ML_BASE[mc], C_ML_BITS[mc]);
+    put(ofb - (1u << oc), oc);
+    while (i-- > 0) {
+        s = bs[i];
+        llv = seq_ll(s); mlv = seq_ml(s); ofb = seq_off(s) + 3;
+        lc = ll_code(llv); mc = ml_code(mlv); oc = hb(ofb);
+        if (mof != 1) { const SeqSym y = tof->sym[oc]; uint32_t n = (st_of + y.delta_nb) >> 16; put(st_of & ((1u << n) - 1), n); st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
+        if (mml != 1) { const SeqSym y = tml->sym[mc]; uint32_t n = (st_ml + y.delta_nb) >> 16; put(st_ml & ((1u << n) - 1), n); st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
+        if (mll != 1) { const SeqSym y = tll->sym[lc]; uint32_t n = (st_ll + y.delta_nb) >> 16; put(st_ll & ((1u << n) - 1), n); st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
+        put(llv - C_LL_BASE[lc], C_LL_BITS[lc]);
+        put(mlv - C_ML_BASE[mc], C_ML_BITS[mc]);
+        put(ofb - (1u << oc), oc);
+    }
+    if (mml != 1) put(st_ml & ((1u << tl_ml) - 1), tl_ml);
+    if (mof != 1) put(st_of & ((1u << tl_of) - 1), tl_of);
+    if (mll != 1) put(st_ll & ((1u << tl_ll) - 1), tl_ll);
+    put(1, 1);
+    uint32_t bytes = widx * 4 + (nb + 7) / 8;
+    if (nb && widx < cap_words) out32[widx] = (uint32_t)acc;
+    blk[g].seq_bits = bytes;
+}
+
+// ------------------------------------------------------------------ k_plan : one thread per segment
+__device__ __forceinline__ uint32_t raw_lit_hdr(uint32_t nlit) { return nlit < 32 ? 1u : (nlit < 4096 ? 2u : 3u); }
+__device__ __forceinline__ uint32_t nseq_hdr(uint32_t nseq) { return nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u); }
+
+__global__ void k_plan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk,
+                       const SegTables *__restrict__ tabs, uint64_t *__restrict__ seg_size, uint32_t flags) {
+    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseg) return;
+    const SegDesc sd = segs[sidx];
+    const SegTables *T = tabs + sidx;
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t desc_total = T->desc_len[0] + T->desc_len[1] + T->desc_len[2];
+    bool have_huf = false, have_seq = false;
+    uint64_t off = 6;
+    if (sd.len == 0) { seg_size[sidx] = 9; return; }           // empty entry: the reference's 9-byte empty frame
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t g = sd.blk_base + b;
+        const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+        const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
+        const bool ok = T->seq_ok || nseq == 0;
+        uint32_t plan = 0, csz = 0;
+        if (ok) {
+            const uint32_t raw_h = raw_lit_hdr(nlit);
+            const bool rle = (flags & F_HUF) && nlit >= 64 && blk[g].lit_rle;
+            if (rle) { csz = raw_h + 1; plan |= 16; }
+            else {
+                const uint32_t hs = (T->huf_ok && nlit >= 64) ? blk[g].lit_body : 0;
+                const uint32_t lh = 3 + (nlit >= 1024) + (nlit >= 16384), ts = have_huf ? 0 : T->tree_len;
+                if (hs && lh + ts + hs < raw_h + nlit) { csz = lh + ts + hs; plan |= 2; if (!have_huf) plan |= 4; }
+                else csz = raw_h + nlit;
+            }
+            csz += nseq_hdr(nseq);
+            if (nseq) { csz += 1 + (have_seq ? 0 : desc_total) + blk[g].seq_bits; if (!have_seq) plan |= 8; }
+        }
+        if (!ok || csz >= bl_len) { plan = 0; csz = bl_len; }
+        else { plan |= 1; if (plan & 2) have_huf = true; if (nseq) have_seq = true; }
+        blk[g].plan = plan; blk[g].out_size = 3 + csz; blk[g].out_off = off;
+        off += 3 + csz;
+    }
+    seg_size[sidx] = off;
+}
+
+// ------------------------------------------------------------------ k_scan : exclusive scan (single workgroup)
+__global__ __launch_bounds__(1024)
+void k_scan(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n) {
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t a = tid * per, e = a + per < n ? a + per : n;
+    uint64_t s = 0;
+    for (uint32_t i = a; i < e; i++) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { uint64_t r = 0; for (uint32_t i = 0; i < 1024; i++) { uint64_t t = part[i]; part[i] = r; r += t; } out[n] = r; }
+    __syncthreads();
+    uint64_t r = part[tid];
+    for (uint32_t i = a; i < e; i++) { out[i] = r; r += in[i]; }
+}
+
+// ------------------------------------------------------------------ k_write : one workgroup per block
+constexpr uint32_t WR_THREADS = 256;
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t tid) {
+    for (uint32_t i = tid; i < n; i += WR_THREADS) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(WR_THREADS)
+void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg,
+             const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, const uint64_t *__restrict__ seg_off,
+             const uint8_t *__restrict__ lits, const uint8_t *__restrict__ litc, const uint8_t *__restrict__ seqc,
+             uint8_t *__restrict__ dst) {
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t sidx = blk_seg[g];
+    const SegDesc sd = segs[sidx];
+    const SegTables *T = tabs + sidx;
+    const BlkInfo bi = blk[g];
+    const uint32_t b = g - sd.blk_base;
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const uint32_t last = (b + 1 == nblk) ? 1u : 0u;
+    uint8_t *fr = dst + seg_off[sidx];
+    uint8_t *out = fr + bi.out_off;
+    if (b == 0 && tid < 6) { const uint8_t fh[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50}; fr[tid] = fh[tid]; }
+    const uint32_t csz = bi.out_size - 3;
+    if (tid < 3) { uint32_t hdr = last | ((bi.plan & 1 ? 2u : 0u) << 1) | (csz << 3); out[tid] = (uint8_t)(hdr >> (8 * tid)); }
+    out += 3;
+    if (!(bi.plan & 1)) { copy_bytes(out, src + sd.src_off + b0, bl_len, tid); return; }
+    const uint32_t nlit = bi.nlit, nseq = bi.nseq;
+    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    uint32_t pos = 0;
+    // literals section
+    if (bi.plan & 16) {
+        uint32_t h = raw_lit_hdr(nlit);
+        if (tid == 0) {
+            if (h == 1) out[0] = (uint8_t)(1 | (nlit << 3));
+            else if (h == 2) { out[0] = (uint8_t)(1 | (1 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); }
+            else { out[0] = (uint8_t)(1 | (3 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); out[2] = (uint8_t)(nlit >> 12); }
+            out[h] = bl[0];
+        }
+        pos = h + 1;
+    } else if (bi.plan & 2) {
+        const uint32_t lh = 3 + (nlit >= 1024) + (nlit >= 16384), ts = (bi.plan & 4) ? T->tree_len : 0, hs = bi.lit_body;
+        if (tid == 0) {
+            uint64_t type = (bi.plan & 4) ? 2u : 3u, comp = ts + hs, h;
+            if (lh == 3) h = type | ((uint64_t)(nlit >= 256 ? 1 : 0) << 2) | ((uint64_t)nlit << 4) | (comp << 14);
+            else if (lh == 4) h = type | (2u << 2) | ((uint64_t)nlit << 4) | (comp << 18);
+            else h = type | (3u << 2) | ((uint64_t)nlit << 4) | (comp << 22);
+            for (uint32_t i = 0; i < lh; i++) out[i] = (uint8_t)(h >> (8 * i));
+        }
+        copy_bytes(out + lh, T->tree, ts, tid);
+        copy_bytes(out + lh + ts, litc + (size_t)g * BLK_SIZE, hs, tid);
+        pos = lh + ts + hs;
+    } else {
+        uint32_t h = raw_lit_hdr(nlit);
+        if (tid == 0) {
+            if (h == 1) out[0] = (uint8_t)(nlit << 3);
+            else if (h == 2) { out[0] = (uint8_t)((1 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); }
+            else { out[0] = (uint8_t)((3 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); out[2] = (uint8_t)(nlit >> 12); }
+        }
+        copy_bytes(out + h, bl, nlit, tid);
+        pos = h + nlit;
+    }
+    // sequences section
+    const uint32_t nh = nseq_hdr(nseq);
+    if (tid == 0) {
+        if (nh == 1) out[pos] = (uint8_t)nseq;
+        else if (nh == 2) { out[pos] = (uint8_t)((nseq >> 8) + 128); out[pos + 1] = (uint8_t)nseq; }
+        else { out[pos] = 255; out[pos + 1] = (uint8_t)(nseq - 0x7F00); out[pos + 2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+    }
+    pos += nh;
+    if (nseq) {
+        const bool carry = (bi.plan & 8) != 0;
+        if (tid == 0) {
+            uint32_t m[3];
+            for (int k = 0; k < 3; k++) m[k] = T->mode[k] == 0 ? 0u : (carry ? T->mode[k] : 3u);
+            out[pos] = (uint8_t)((m[0] << 6) | (m[1] << 4) | (m[2] << 2));
+        }
+        pos += 1;
+        if (carry) for (int k = 0; k < 3; k++) { copy_bytes(out + pos, T->desc[k], T->desc_len[k], tid); pos += T->desc_len[k]; }
+        copy_bytes(out + pos, seqc + (size_t)g * BLK_SIZE, bi.seq_bits, tid);
+    }
+}
+
+// empty entries: 28 B5 2F FD 20 00 01 00 00 (what the reference emits, tests/golden/zstd.pna raw/empty.txt)
+__global__ void k_empty(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ dst) {
+    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseg || segs[sidx].len != 0) return;
+    const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00};
+    uint8_t *o = dst + seg_off[sidx];
+    for (int i = 0; i < 9; i++) o[i] = e[i];
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
+                    const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
+                    uint64_t *seg_size, uint64_t *seg_off, uint8_t *dst, uint32_t flags, hipStream_t st,
+                    hipEvent_t *ev /* 5 events: after stats, lit, seq, (plan+scan), write; may be null */) {
+    hipLaunchKernelGGL(k_stats, dim3(nseg), dim3(ST_THREADS), 0, st, segs, seqs, lits, blk, tabs, flags);
+    if (ev) (void)hipEventRecord(ev[0], st);
+    if (nblk) hipLaunchKernelGGL(k_lit, dim3(nblk), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_seq, dim3((nseg + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs, nseg, seqs, blk, tabs, seqc);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_plan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, tabs, seg_size, flags);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, seg_size, seg_off, nseg);
+    if (ev) (void)hipEventRecord(ev[3], st);
+    (void)dst; (void)src;
+}
+
+void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
+                  const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
+                  const uint8_t *seqc, uint8_t *dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_empty, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, seg_off, dst);
+    if (nblk) hipLaunchKernelGGL(k_write, dim3(nblk), dim3(WR_THREADS), 0, st, src, segs, blk_seg, blk, tabs, seg_off, lits, litc, seqc, dst);
+}
+
+} // namespace pna

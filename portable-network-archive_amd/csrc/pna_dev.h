@@ -1,0 +1,72 @@
+// pna_dev.h -- shared host/device declarations of the gfx950 zstd-format encoder.
+//
+// Normative algorithm: DESIGN.md §"Encoder specification".  The same rules are restated independently in plain C
+// under oracle/ (test infrastructure); tests require the two to agree byte for byte.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace pna {
+
+constexpr uint32_t SEG_SIZE   = 1u << 20;   // one zstd frame per segment of an entry
+constexpr uint32_t BLK_SIZE   = 1u << 17;   // zstd Block_Maximum_Size
+constexpr uint32_t BLK_PER_SEG = SEG_SIZE / BLK_SIZE;
+
+// LZ stage (k_lz)
+constexpr uint32_t LZ_THREADS = 1024;       // 16 waves, one workgroup per CU (LDS-bound)
+constexpr uint32_t LZ_WAVES   = LZ_THREADS / 64;
+constexpr uint32_t TILE       = 2048;       // positions matched per synchronous step (2 per lane)
+constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
+constexpr uint32_t HASH_LOG   = 14;
+constexpr uint32_t MIN_MATCH  = 6;
+constexpr uint32_t MAX_OFF    = 61440;
+constexpr uint32_t CAP1       = 32;
+constexpr uint32_t LOOKAHEAD  = 1024;
+constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
+constexpr uint32_t SEQ_CAP    = 22016;      // sequences per block: BLK_SIZE / MIN_MATCH rounded up to 256
+
+constexpr uint32_t F_HUF = 1, F_FSE = 2, F_LAZY = 4, F_REP = 8;
+
+// packed sequence: off(20) | ml(18) << 20 | ll(18) << 38
+__host__ __device__ inline uint64_t seq_pack(uint32_t ll, uint32_t ml, uint32_t off) {
+    return (uint64_t)off | ((uint64_t)ml << 20) | ((uint64_t)ll << 38);
+}
+__host__ __device__ inline uint32_t seq_off(uint64_t s) { return (uint32_t)(s & 0xFFFFF); }
+__host__ __device__ inline uint32_t seq_ml(uint64_t s)  { return (uint32_t)((s >> 20) & 0x3FFFF); }
+__host__ __device__ inline uint32_t seq_ll(uint64_t s)  { return (uint32_t)((s >> 38) & 0x3FFFF); }
+
+struct SegDesc {
+    uint64_t src_off;     // byte offset of the segment in the batch input buffer (multiple of 16)
+    uint32_t len;         // 1 .. SEG_SIZE
+    uint32_t blk_base;    // index of the segment's first block in the per-block arrays
+    uint32_t entry;       // entry the segment belongs to
+    uint32_t first;       // 1 if it is the entry's first segment
+};
+
+// per-segment entropy tables (k_stats output; 4 KiB-ish, read by k_lit / k_seq / k_pack)
+constexpr uint32_t SEQ_MAX_LOG = 8;
+struct SeqSym { uint32_t delta_nb; int16_t delta_find; uint16_t first_state; };
+struct SeqTable { uint16_t state[1u << SEQ_MAX_LOG]; SeqSym sym[56]; };   // 512 + 448 bytes
+struct SegTables {
+    uint32_t huf_ok, tree_len, max_sym, maxbits;
+    uint32_t mode[3], tlog[3], desc_len[3], seq_ok;
+    uint32_t nseq_seg, pad[2], pad2;
+    uint32_t huf_code[256];            // code | len << 16
+    uint8_t  tree[160];
+    uint8_t  desc[3][96];
+    SeqTable tab[3];                   // LL, OF, ML
+};
+
+// per-block results
+struct BlkInfo {
+    uint32_t nseq, nlit;
+    uint32_t lit_body;     // bytes of Huffman body (jump table + streams), 0 if not produced
+    uint32_t lit_rle;      // 1 if all literals are the same byte
+    uint32_t seq_bits;     // bytes of the sequence bitstream
+    uint32_t out_size;     // final block size incl. 3-byte header (k_plan)
+    uint32_t plan;         // bit0 compressed block, bit1 huffman literals, bit2 carries tree, bit3 carries seq tables, bit4 rle literals
+    uint32_t pad;
+    uint64_t out_off;      // offset of the block header in the batch output buffer
+};
+
+} // namespace pna

@@ -1,0 +1,367 @@
+// pna_host.cpp -- host side of libpna_gpu.so: context, workspace, batch planning and the C ABI of
+// include/pna_gpu.h.  Mirrors the construction/finish protocol of the reference's CompressionWriter
+// (lib/src/compress.rs:21-76, lib/src/entry/write.rs:251-265) and the per-entry fan-out of
+// cli/src/command/core.rs:496-537.  No CPU compression path exists here: everything goes through the HIP kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "pna_dev.h"
+#include "../../include/pna_gpu.h"
+
+namespace pna {
+void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk,
+               uint32_t flags, hipStream_t st);
+void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
+                    const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
+                    uint64_t *seg_size, uint64_t *seg_off, uint8_t *dst, uint32_t flags, hipStream_t st, hipEvent_t *ev);
+void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
+                  const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
+                  const uint8_t *seqc, uint8_t *dst, hipStream_t st);
+void launch_corpus(int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len, uint64_t stride,
+                   const uint8_t *vocab, const uint64_t *cum, const uint32_t *phrases, uint8_t *dst, hipStream_t st);
+}
+using namespace pna;
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 3) + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return -1; } want = n; }
+        cap = want; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct pna_gpu_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out;
+    DevBuf c_vocab, c_cum, c_phr;
+    bool corpus_ready = false;
+    std::string err;
+    pna_gpu_timing timing = {};
+    uint32_t last_nblk = 0;
+    size_t max_blocks = 1u << 17;          // blocks per sub-batch (16 GiB of input)
+};
+
+static int fail(pna_gpu_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    if (c) { c->err = what; if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); } }
+    return code;
+}
+#define HIPCHK(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail((c), PNA_E_HIP, #call, e__); } while (0)
+
+extern "C" const char *pna_gpu_strerror(int code) {
+    switch (code) {
+        case PNA_OK: return "ok";
+        case PNA_E_NODEVICE: return "no usable HIP device";
+        case PNA_E_INVAL: return "invalid argument";
+        case PNA_E_NOMEM: return "out of memory";
+        case PNA_E_DSTSIZE: return "destination too small";
+        case PNA_E_HIP: return "HIP error";
+        case PNA_E_SINK: return "sink callback failed";
+        case PNA_E_UNSUPPORTED: return "algorithm not supported by this build";
+        default: return "unknown error";
+    }
+}
+extern "C" const char *pna_gpu_last_error(const pna_gpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
+    if (!out) return PNA_E_INVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PNA_E_NODEVICE;
+    if (device_id < 0 || device_id >= n) return PNA_E_INVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return PNA_E_NODEVICE;
+    pna_gpu_ctx *c = new pna_gpu_ctx();
+    c->device = device_id;
+    c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
+    c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
+    *out = c;
+    return PNA_OK;
+}
+
+extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" size_t pna_gpu_bound(int algo, size_t n) {
+    if (algo == PNA_ALGO_STORE) return n;
+    size_t segs = (n + SEG_SIZE - 1) / SEG_SIZE; if (segs == 0) segs = 1;
+    size_t blks = (n + BLK_SIZE - 1) / BLK_SIZE + segs;
+    return n + segs * 6 + blks * 3 + 16;
+}
+
+extern "C" int pna_gpu_clamp_level(int algo, int level) {
+    if (algo == PNA_ALGO_ZSTD) {            // lib/src/compress/zstandard.rs:13,43-57 (min_c_level .. 22, default 3)
+        if (level == PNA_LEVEL_DEFAULT) return 3;
+        if (level < -131072) return -131072;
+        return level > 22 ? 22 : level;
+    }
+    if (algo == PNA_ALGO_DEFLATE) {         // lib/src/compress/deflate.rs:33-38,89-101
+        if (level == PNA_LEVEL_DEFAULT) return 6;
+        return level < 0 ? 0 : (level > 9 ? 9 : level);
+    }
+    return 0;
+}
+
+extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
+    if (!c || !out) return PNA_E_INVAL;
+    *out = c->timing; return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One sub-batch: entries [e0, e1) -> segments -> kernels; output appended at d_dst + out_base.
+static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                        size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
+                        hipStream_t st, bool timed) {
+    std::vector<SegDesc> segs; std::vector<uint32_t> blk_seg; std::vector<uint32_t> entry_first_seg;
+    uint32_t nblk = 0;
+    for (size_t e = e0; e < e1; e++) {
+        entry_first_seg.push_back((uint32_t)segs.size());
+        uint64_t len = src_len[e], off = src_off[e];
+        if (off & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
+        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 1}; segs.push_back(s); continue; }
+        for (uint64_t p = 0; p < len; p += SEG_SIZE) {
+            uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
+            SegDesc s{off + p, sl, nblk, (uint32_t)e, p == 0 ? 1u : 0u};
+            uint32_t nb = (sl + BLK_SIZE - 1) / BLK_SIZE;
+            for (uint32_t b = 0; b < nb; b++) blk_seg.push_back((uint32_t)segs.size());
+            nblk += nb; segs.push_back(s);
+        }
+    }
+    entry_first_seg.push_back((uint32_t)segs.size());
+    const uint32_t nseg = (uint32_t)segs.size();
+    if (nseg == 0) return PNA_OK;
+    if (c->segs.ensure(nseg * sizeof(SegDesc)) || c->blk_seg.ensure((size_t)(nblk + 1) * 4) ||
+        c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * sizeof(SegTables)) ||
+        c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
+        c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
+        c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
+        return fail(c, PNA_E_NOMEM, "workspace allocation failed");
+    HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+    if (nblk) HIPCHK(c, hipMemcpyAsync(c->blk_seg.p, blk_seg.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->blk.p, 0, (size_t)(nblk + 1) * sizeof(BlkInfo), st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, c->flags, st);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    launch_entropy(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
+                   (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p,
+                   (uint8_t *)c->seqc.p, (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, d_dst, c->flags, st,
+                   timed ? &c->ev[2] : nullptr);
+    HIPCHK(c, hipGetLastError());
+    // the output offsets are needed on the host before the write pass can be bounds-checked
+    std::vector<uint64_t> seg_off(nseg + 1);
+    HIPCHK(c, hipMemcpyAsync(seg_off.data(), c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint64_t total = seg_off[nseg];
+    if (out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+    launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
+                 (const SegTables *)c->tabs.p, (const uint64_t *)c->seg_off.p, (const uint8_t *)c->lits.p,
+                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst + out_base, st);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
+    HIPCHK(c, hipGetLastError());
+    for (size_t e = e0; e < e1; e++) dst_off[e] = out_base + seg_off[entry_first_seg[e - e0]];
+    dst_off[e1] = out_base + total;
+    c->last_nblk = nblk;
+    if (timed) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        float ms[6] = {0, 0, 0, 0, 0, 0};
+        (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&ms[3], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&ms[4], c->ev[4], c->ev[5]);
+        (void)hipEventElapsedTime(&ms[5], c->ev[5], c->ev[6]);
+        c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
+        c->timing.ms_pack += ms[4] + ms[5];
+        c->timing.n_segments += nseg; c->timing.n_blocks += nblk;
+    }
+    return PNA_OK;
+}
+
+extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level, size_t n, const void *d_src,
+                                             const uint64_t *src_off, const uint64_t *src_len, void *d_dst, size_t dst_cap,
+                                             uint64_t *dst_off, void *hip_stream) {
+    if (!c || !src_off || !src_len || !dst_off || (!d_src && n) || (!d_dst && n)) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented on the device path");
+    (void)level;                                     // one parameter set (hash_log 14, min_match 6, greedy+lazy1)
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->timing = pna_gpu_timing{};
+    dst_off[0] = 0;
+    uint64_t out_base = 0, in_total = 0;
+    size_t e = 0;
+    while (e < n) {
+        size_t e1 = e; size_t blocks = 0;
+        while (e1 < n) {
+            size_t nb = (size_t)((src_len[e1] + BLK_SIZE - 1) / BLK_SIZE);
+            if (e1 > e && blocks + nb > c->max_blocks) break;
+            blocks += nb; in_total += src_len[e1]; e1++;
+        }
+        int rc = run_subbatch(c, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap, out_base, dst_off, st, true);
+        if (rc) return rc;
+        out_base = dst_off[e1];
+        e = e1;
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->timing.in_bytes = in_total; c->timing.out_bytes = out_base;
+    return PNA_OK;
+}
+
+extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_t n, const void *const *src,
+                                      const size_t *src_len, void *const *dst, const size_t *dst_cap, size_t *dst_len) {
+    if (!c || (n && (!src || !src_len || !dst || !dst_cap || !dst_len))) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> off(n + 1), len(n), doff(n + 1);
+    uint64_t pos = 0, bound = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (dst_cap[i] < pna_gpu_bound(algo, src_len[i])) return fail(c, PNA_E_DSTSIZE, "dst_cap below pna_gpu_bound");
+        off[i] = pos; len[i] = src_len[i]; pos = (pos + src_len[i] + 15) & ~(uint64_t)15; bound += pna_gpu_bound(algo, src_len[i]);
+    }
+    off[n] = pos;
+    if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(bound + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    for (size_t i = 0; i < n; i++)
+        if (src_len[i]) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->stage_in.p + off[i], src[i], src_len[i], hipMemcpyHostToDevice, c->stream));
+    int rc = pna_gpu_compress_batch_device(c, algo, level, n, c->stage_in.p, off.data(), len.data(), c->stage_out.p, bound + 64, doff.data(), nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) {
+        dst_len[i] = (size_t)(doff[i + 1] - doff[i]);
+        HIPCHK(c, hipMemcpyAsync(dst[i], (uint8_t *)c->stage_out.p + doff[i], dst_len[i], hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct pna_gpu_stream {
+    pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user; std::vector<uint8_t> buf;
+};
+
+extern "C" int pna_gpu_stream_new(pna_gpu_ctx *c, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out) {
+    if (!c || !sink || !out) return PNA_E_INVAL;
+    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented");
+    *out = new pna_gpu_stream{c, algo, level, sink, user, {}};
+    return PNA_OK;
+}
+extern "C" int pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len) {
+    if (!s || (!buf && len)) return PNA_E_INVAL;
+    s->buf.insert(s->buf.end(), (const uint8_t *)buf, (const uint8_t *)buf + len);
+    return PNA_OK;
+}
+extern "C" int pna_gpu_stream_flush(pna_gpu_stream *s) { return s ? PNA_OK : PNA_E_INVAL; }
+extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { delete s; }
+extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
+    if (!s) return PNA_E_INVAL;
+    std::vector<uint8_t> out(pna_gpu_bound(s->algo, s->buf.size()));
+    const void *src = s->buf.data(); size_t sl = s->buf.size(); void *dst = out.data(); size_t cap = out.size(), dl = 0;
+    int rc = pna_gpu_compress_batch(s->ctx, s->algo, s->level, 1, &src, &sl, &dst, &cap, &dl);
+    if (rc == PNA_OK) {
+        // the reference's zstd writer drains in bursts of at most 32 KiB (zio::Writer); keep that shape
+        for (size_t p = 0; p < dl && rc == PNA_OK; p += 32768) {
+            size_t k = std::min<size_t>(32768, dl - p);
+            if (s->sink(s->user, out.data() + p, k) != 0) rc = fail(s->ctx, PNA_E_SINK, "sink failed");
+        }
+    }
+    delete s;
+    return rc;
+}
+
+extern "C" int pna_gpu_compress_solid(pna_gpu_ctx *c, int algo, int level, const void *src, size_t src_len,
+                                      pna_sink_fn sink, void *user) {
+    if (!c || !sink || (!src && src_len)) return PNA_E_INVAL;
+    pna_gpu_stream *s = nullptr;
+    int rc = pna_gpu_stream_new(c, algo, level, sink, user, &s);
+    if (rc) return rc;
+    rc = pna_gpu_stream_write(s, src, src_len);
+    if (rc) { pna_gpu_stream_abort(s); return rc; }
+    return pna_gpu_stream_finish(s);
+}
+
+extern "C" int pna_gpu_debug_block(pna_gpu_ctx *c, uint32_t block, uint64_t *seqs, uint32_t cap_seqs, uint32_t *nseq,
+                                   uint8_t *lits, uint32_t cap_lits, uint32_t *nlit) {
+    if (!c || block >= c->last_nblk) return PNA_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    BlkInfo bi;
+    HIPCHK(c, hipMemcpy(&bi, (BlkInfo *)c->blk.p + block, sizeof(bi), hipMemcpyDeviceToHost));
+    if (nseq) *nseq = bi.nseq;
+    if (nlit) *nlit = bi.nlit;
+    if (seqs) HIPCHK(c, hipMemcpy(seqs, (uint64_t *)c->seqs.p + (size_t)block * SEQ_CAP, (size_t)std::min(cap_seqs, bi.nseq) * 8, hipMemcpyDeviceToHost));
+    if (lits) HIPCHK(c, hipMemcpy(lits, (uint8_t *)c->lits.p + (size_t)block * BLK_SIZE, std::min(cap_lits, bi.nlit), hipMemcpyDeviceToHost));
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// corpus tables (integer-only; same construction as the checker's corpus model, written independently here)
+static uint64_t splitmix(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static int ensure_corpus(pna_gpu_ctx *c) {
+    if (c->corpus_ready) return PNA_OK;
+    const int VOCAB = 50000, SLOT = 16, NPHRASE = 8192;
+    static const uint16_t LCUM[26] = {817, 966, 1244, 1669, 2939, 3162, 3364, 3973, 4670, 4685, 4762, 5165, 5406,
+                                      6081, 6832, 7025, 7035, 7634, 8267, 9173, 9449, 9547, 9783, 9798, 9995, 10000};
+    std::vector<uint8_t> vocab((size_t)VOCAB * SLOT, 0); std::vector<uint64_t> cum(VOCAB); std::vector<uint32_t> phr((size_t)NPHRASE * 4, 0);
+    uint64_t s = 0x504E41ull;
+    for (int w = 0; w < VOCAB; w++) {
+        uint64_t r = splitmix(s);
+        int len = 2 + (int)((r & 0xFFFF) * 11 >> 16);
+        if (w < 64) len = 2 + (int)((r & 0xFFFF) * 3 >> 16);
+        else if (w < 1024) len = 3 + (int)((r & 0xFFFF) * 5 >> 16);
+        uint8_t *slot = &vocab[(size_t)w * SLOT];
+        slot[0] = (uint8_t)len;
+        for (int i = 0; i < len; i++) { uint32_t x = (uint32_t)(splitmix(s) >> 33) % 10000u; int ch = 0; while (LCUM[ch] <= x) ch++; slot[1 + i] = (uint8_t)('a' + ch); }
+    }
+    uint64_t acc = 0;
+    for (int k = 0; k < VOCAB; k++) { acc += (1ull << 40) / (uint64_t)(k + 1); cum[k] = acc; }
+    auto draw = [&](uint64_t r, int n) {
+        unsigned __int128 m = (unsigned __int128)r * cum[n - 1]; uint64_t x = (uint64_t)(m >> 64);
+        int lo = 0, hi = n - 1; while (lo < hi) { int mid = (lo + hi) >> 1; if (cum[mid] > x) hi = mid; else lo = mid + 1; } return lo;
+    };
+    for (int p = 0; p < NPHRASE; p++) {
+        uint64_t r = splitmix(s);
+        phr[4 * p] = (uint32_t)(2 + (int)(r & 1));
+        for (int i = 0; i < 3; i++) phr[4 * p + 1 + i] = (uint32_t)draw(splitmix(s), VOCAB);
+    }
+    if (c->c_vocab.ensure(vocab.size()) || c->c_cum.ensure(cum.size() * 8) || c->c_phr.ensure(phr.size() * 4)) return fail(c, PNA_E_NOMEM, "corpus tables");
+    HIPCHK(c, hipMemcpy(c->c_vocab.p, vocab.data(), vocab.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->c_cum.p, cum.data(), cum.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->c_phr.p, phr.data(), phr.size() * 4, hipMemcpyHostToDevice));
+    c->corpus_ready = true;
+    return PNA_OK;
+}
+
+extern "C" int pna_bench_corpus_fill_device(pna_gpu_ctx *c, int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len,
+                                            uint64_t stride, void *d_dst, void *hip_stream) {
+    if (!c || !d_dst || kind < 0 || kind > 4 || stride < file_len) return fail(c, PNA_E_INVAL, "bad corpus argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_corpus(c); if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    launch_corpus(kind, first_file, n_files, file_len, stride, (const uint8_t *)c->c_vocab.p, (const uint64_t *)c->c_cum.p,
+                  (const uint32_t *)c->c_phr.p, (uint8_t *)d_dst, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    return PNA_OK;
+}
