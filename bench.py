@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- archive-create throughput of the MI355X compression path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (LZ -> entropy -> pack into the packed compressed stream) over the whole
+synthetic corpus of this rank: `--files` enwik-style text files of `--file-mib` MiB each (BASELINE.json configs[1]:
+10 000 x 1 MiB, zstd).  Inputs are generated on the device and are resident in HBM when the timed region starts.
+N > 1: one process per GPU (torch.distributed / RCCL), every rank compresses its own shard of the corpus (weak
+scaling), then the compressed shards are gathered in rank order onto rank 0 over RCCL (the ordered gather of the
+serial PNA stream).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(sample_files: int, file_len: int) -> dict:
+    """Reference pipeline restated on the host cores (oracle/cpu_baseline.c): one entry per task, libzstd level 3."""
+    from oracle import codec
+    L = codec.lib()
+    cores = os.cpu_count() or 1
+    data = b"".join(codec.corpus_file(0, i, file_len) for i in range(min(sample_files, 64)))
+    n_unique = len(data) // file_len
+    L.pna_cpu_zstd_version.restype = ctypes.c_uint
+    ver = L.pna_cpu_zstd_version()
+    if ver == 0:
+        # no libzstd on this host: time the oracle's own encoder model instead (single thread) and say so
+        t0 = time.time()
+        out = 0
+        for i in range(min(4, n_unique)):
+            out += len(codec.model_compress(data[i * file_len:(i + 1) * file_len]))
+        dt = time.time() - t0
+        n = min(4, n_unique) * file_len
+        return {"value": n / dt / 2**20, "unit": "MiB/s", "cores": 1, "kind": "port",
+                "sample": f"{min(4, n_unique)} x {file_len} B, oracle model encoder (libzstd absent on this host)",
+                "ratio": n / max(out, 1)}
+    L.pna_cpu_baseline_zstd.restype = ctypes.c_double
+    L.pna_cpu_baseline_zstd.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+    # replicate the unique files so that every core gets ~2 s of work (files are re-used: identical CPU cost)
+    reps = max(1, (sample_files + n_unique - 1) // n_unique)
+    buf = data * reps
+    n_files = len(buf) // file_len
+    out = ctypes.c_uint64()
+    secs = L.pna_cpu_baseline_zstd(buf, n_files, file_len, file_len, cores, 3, ctypes.byref(out))
+    out1 = ctypes.c_uint64()
+    n1 = min(n_files, 16)
+    secs1 = L.pna_cpu_baseline_zstd(buf, n1, file_len, file_len, 1, 3, ctypes.byref(out1))
+    return {"value": n_files * file_len / secs / 2**20, "unit": "MiB/s", "cores": cores, "kind": "port",
+            "sample": f"{n_files} x {file_len} B enwik-style files ({n_unique} unique), host libzstd {ver // 10000}.{ver // 100 % 100}.{ver % 100} "
+                      f"level 3 streaming, one entry per task on {cores} threads",
+            "ratio": n_files * file_len / max(out.value, 1),
+            "single_thread_mib_s": n1 * file_len / secs1 / 2**20}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--files", type=int, default=10000)
+    ap.add_argument("--file-mib", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    pna = importlib.import_module("portable-network-archive_amd")
+    ctx = pna.Context(dev.index)
+
+    n_files, file_len = args.files, int(args.file_mib * (1 << 20))
+    stride = (file_len + 15) & ~15
+    src = torch.empty(n_files * stride + 8192, dtype=torch.uint8, device=dev)
+    ctx.corpus_fill_device(0, rank * n_files, n_files, file_len, stride, src.data_ptr())
+    src_off = [i * stride for i in range(n_files)] + [n_files * stride]
+    src_len = [file_len] * n_files
+    dst_cap = sum(pna.bound(pna.ALGO_ZSTD, file_len) for _ in range(1)) * n_files + 4096
+    dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
+    gather_buf = None
+
+    def step():
+        offs = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap)
+        total = offs[-1]
+        if world > 1:
+            # ordered gather of the compressed shards into the serial stream on rank 0 (RCCL send/recv over xGMI)
+            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+            mine = torch.tensor([total], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sizes, mine)
+            if rank == 0:
+                sz = sizes.tolist()
+                nonlocal gather_buf
+                need = sum(sz)
+                if gather_buf is None or gather_buf.numel() < need:
+                    gather_buf = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=dev)
+                pos = sz[0]
+                gather_buf[:pos].copy_(dst[:pos])
+                ops = []
+                for r in range(1, world):
+                    ops.append(dist.P2POp(dist.irecv, gather_buf[pos:pos + sz[r]], r))
+                    pos += sz[r]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            else:
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, dst[:total], 0)]):
+                    w.wait()
+        return total
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lz_ms = stage_ms = 0.0
+    t0 = time.perf_counter()
+    out_total = 0
+    for _ in range(args.steps):
+        out_total = step()
+        tm = ctx.timing()
+        lz_ms += tm.ms_lz
+        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        o = torch.tensor([out_total], dtype=torch.int64, device=dev)
+        dist.all_reduce(o)
+        out_all = int(o.item())
+    else:
+        out_all = out_total
+    in_rank = n_files * file_len
+    in_all = in_rank * world
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = in_all / (dt / args.steps) / 2**20
+        lz_avg_s = lz_ms / args.steps / 1e3
+        alg_bytes = in_rank + out_total                      # each input byte read once + each output byte written once
+        achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
+        tm = ctx.timing()
+        line = {
+            "metric": "archive-create MiB/s (input bytes/sec), zstd, 10k x 1MiB corpus",
+            "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic enwik-style text per GPU, Compression::ZStandard "
+                                   f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1), inputs resident in HBM",
+                       "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
+            "ratio": round(in_all / max(out_all, 1), 4),
+            "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(lz_ms / args.steps, 3), "all_kernels_ms": round(stage_ms / args.steps, 3)},
+            "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
+                                    "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                sample = args.cpu_sample_files or 48 * (os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline(sample, file_len)
+            except Exception as e:  # never lose the GPU number because the CPU leg failed
+                line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

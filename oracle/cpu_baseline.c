@@ -1,0 +1,95 @@
+/*
+ * oracle/cpu_baseline.c -- TEST / BENCH INFRASTRUCTURE ONLY (bench.py's `cpu_baseline` leg).
+ *
+ * CPU restatement of the reference's create pipeline for timing purposes:
+ *   cli/src/command/core.rs:496-537  rayon scope_fifo, one entry per task on all logical CPUs
+ *   lib/src/entry/write.rs:260-262   zstd::stream::write::Encoder::new(w, 3): streaming libzstd level 3,
+ *                                    no pledged size, no checksum (frames start 28 B5 2F FD 00 58)
+ * libzstd is the reference's own codec (Cargo.lock:3547-3572 pins 1.5.7; the host's libzstd.so.1 is used here
+ * and its version is reported).  It is loaded with dlopen so the oracle has no link-time dependency; when it is
+ * absent the caller falls back to timing the model encoder and says so.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef struct { const void *src; size_t size; size_t pos; } zin;
+typedef struct { void *dst; size_t size; size_t pos; } zout;
+typedef void *(*fn_create)(void);
+typedef size_t (*fn_free)(void *);
+typedef size_t (*fn_setp)(void *, int, int);
+typedef size_t (*fn_stream2)(void *, zout *, zin *, int);
+typedef unsigned (*fn_iserr)(size_t);
+typedef unsigned (*fn_ver)(void);
+typedef size_t (*fn_reset)(void *, int);
+
+static struct { void *h; fn_create create; fn_free freec; fn_setp setp; fn_stream2 stream2; fn_iserr iserr; fn_ver ver; fn_reset reset; } Z;
+
+static int load_zstd(void) {
+    if (Z.h) return 0;
+    const char *names[] = {"libzstd.so.1", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1", 0};
+    for (int i = 0; names[i] && !Z.h; i++) Z.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!Z.h) return -1;
+    Z.create = (fn_create)dlsym(Z.h, "ZSTD_createCCtx"); Z.freec = (fn_free)dlsym(Z.h, "ZSTD_freeCCtx");
+    Z.setp = (fn_setp)dlsym(Z.h, "ZSTD_CCtx_setParameter"); Z.stream2 = (fn_stream2)dlsym(Z.h, "ZSTD_compressStream2");
+    Z.iserr = (fn_iserr)dlsym(Z.h, "ZSTD_isError"); Z.ver = (fn_ver)dlsym(Z.h, "ZSTD_versionNumber");
+    Z.reset = (fn_reset)dlsym(Z.h, "ZSTD_CCtx_reset");
+    if (!Z.create || !Z.freec || !Z.setp || !Z.stream2 || !Z.iserr || !Z.ver || !Z.reset) { dlclose(Z.h); Z.h = 0; return -1; }
+    return 0;
+}
+
+unsigned pna_cpu_zstd_version(void) { return load_zstd() ? 0 : Z.ver(); }
+
+typedef struct {
+    const uint8_t *data; size_t n_files, file_len, stride; int level;
+    volatile long *next; uint64_t out_bytes; int err;
+} job;
+
+static void *worker(void *arg) {
+    job *j = (job *)arg;
+    void *cctx = Z.create();
+    size_t cap = j->file_len + (j->file_len >> 7) + 1024;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    for (;;) {
+        long i = __sync_fetch_and_add(j->next, 1);
+        if ((size_t)i >= j->n_files) break;
+        /* a fresh encoder per entry, as the reference builds one per FileEntryBuilder */
+        Z.reset(cctx, 1 /* ZSTD_reset_session_only */);
+        Z.setp(cctx, 100 /* ZSTD_c_compressionLevel */, j->level);
+        zin in = {j->data + (size_t)i * j->stride, j->file_len, 0};
+        zout out = {buf, cap, 0};
+        size_t r = Z.stream2(cctx, &out, &in, 0 /* ZSTD_e_continue */);
+        if (Z.iserr(r)) { j->err = 1; break; }
+        do { r = Z.stream2(cctx, &out, &in, 2 /* ZSTD_e_end */); if (Z.iserr(r)) { j->err = 1; break; } } while (r != 0);
+        j->out_bytes += out.pos;
+    }
+    free(buf); Z.freec(cctx);
+    return 0;
+}
+
+/* Compress n_files files of file_len bytes (file i at data + i*stride) with `threads` workers.
+ * Returns seconds (wall) or a negative value on failure; *out_total receives the compressed bytes. */
+double pna_cpu_baseline_zstd(const uint8_t *data, size_t n_files, size_t file_len, size_t stride, int threads, int level,
+                             uint64_t *out_total) {
+    if (load_zstd()) return -1.0;
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    pthread_t th[1024]; job jobs[1024];
+    volatile long next = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        job jj = {data, n_files, file_len, stride, level, &next, 0, 0}; jobs[t] = jj;
+        pthread_create(&th[t], 0, worker, &jobs[t]);
+    }
+    uint64_t total = 0; int err = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], 0); total += jobs[t].out_bytes; err |= jobs[t].err; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (out_total) *out_total = total;
+    if (err) return -2.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

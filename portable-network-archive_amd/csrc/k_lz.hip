@@ -313,15 +313,19 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
             seq_run += seq_tile; len_run += len_tile;
 
-            // ---- emission
+            // ---- emission (shuffles stay outside divergent code: an inactive source lane would read as 0)
+            uint32_t end_g0 = 0;                                    // end of the last selected match of group 0
+            if (fsel[0]) { uint32_t sp = 63 - clz64(fsel[0]); end_g0 = t0 + wbase + sp + rdlane(fl[0], sp); }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
+                const uint64_t pm = fsel[r] & lane_lt;
+                const uint32_t sp = pm ? 63 - clz64(pm) : 0u;
+                const uint32_t pfl = (uint32_t)__shfl((int)fl[r], (int)sp);
+                uint32_t prev_end;
+                if (pm) prev_end = t0 + wbase + 64 * r + sp + pfl;
+                else if (r == 1 && fsel[0]) prev_end = end_g0;
+                else prev_end = rr.lit_start;
                 if ((fsel[r] >> lane) & 1) {
-                    uint64_t pm = fsel[r] & lane_lt;
-                    uint32_t prev_end;
-                    if (pm) { uint32_t sp = 63 - clz64(pm); prev_end = t0 + wbase + 64 * r + sp + (uint32_t)__shfl((int)fl[r], (int)sp); }
-                    else if (r == 1 && fsel[0]) { uint32_t sp = 63 - clz64(fsel[0]); prev_end = t0 + wbase + sp + (uint32_t)__shfl((int)fl[0], (int)sp); }
-                    else prev_end = rr.lit_start;
                     uint32_t rank = (uint32_t)__popcll(pm) + (r ? nsel0 : 0u);
                     uint32_t idx = seq_base + rank;
                     if (idx < SEQ_CAP) bseq[idx] = seq_pack(q[r] - prev_end, fl[r], off[r]);
