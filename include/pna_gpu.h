@@ -107,6 +107,9 @@ int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
 int  pna_gpu_debug_block(pna_gpu_ctx *ctx, uint32_t block, uint64_t *seqs, uint32_t cap_seqs, uint32_t *nseq,
                          uint8_t *lits, uint32_t cap_lits, uint32_t *nlit);
 
+/* Diagnostic build of the LZ kernel (ctx created with flag 0x100): per-phase s_memtime sums of wave 0, cleared on read. */
+int  pna_gpu_debug_lz_stamps(pna_gpu_ctx *ctx, unsigned long long *out8);
+
 /* ---- benchmark support (not part of the reference's surface): fills d_dst with `n_files` synthetic files of
  * `file_len` bytes each (file i at i * stride), bit-identical to oracle/corpus_model.c. kind: 0 enwik-style text,
  * 1 random-text, 2 random bytes, 3 zeros, 4 repeated byte. */

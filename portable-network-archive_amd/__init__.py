@@ -54,7 +54,7 @@ EXPORTS = [
     "pna_gpu_init", "pna_gpu_shutdown", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
-    "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_bench_corpus_fill_device",
+    "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
 ]
 
 
@@ -105,6 +105,8 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_last_timing.argtypes = [vp, ctypes.POINTER(Timing)]
     L.pna_gpu_debug_block.restype = ctypes.c_int
     L.pna_gpu_debug_block.argtypes = [vp, u32, u64p, u32, ctypes.POINTER(u32), ctypes.c_char_p, u32, ctypes.POINTER(u32)]
+    L.pna_gpu_debug_lz_stamps.restype = ctypes.c_int
+    L.pna_gpu_debug_lz_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     L.pna_bench_corpus_fill_device.restype = ctypes.c_int
     L.pna_bench_corpus_fill_device.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_uint64, vp, vp]
@@ -195,6 +197,11 @@ class Context:
         self._check(self._L.pna_gpu_debug_block(self._h, block, seqs, SEQ_CAP, ctypes.byref(ns), lits, BLK_SIZE, ctypes.byref(nl)))
         out = [((s >> 38) & 0x3FFFF, (s >> 20) & 0x3FFFF, s & 0xFFFFF) for s in seqs[:ns.value]]
         return out, lits.raw[:nl.value]
+
+    def lz_stamps(self):
+        a = (ctypes.c_ulonglong * 8)()
+        self._check(self._L.pna_gpu_debug_lz_stamps(self._h, a))
+        return list(a)
 
     def corpus_fill_device(self, kind: int, first_file: int, n_files: int, file_len: int, stride: int, d_dst: int) -> None:
         self._check(self._L.pna_bench_corpus_fill_device(self._h, kind, first_file, n_files, file_len, stride,

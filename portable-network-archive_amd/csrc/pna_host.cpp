@@ -22,6 +22,7 @@ void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, cons
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
                   const uint8_t *seqc, uint8_t *dst, hipStream_t st);
+void lz_read_stamps(unsigned long long *out);
 void launch_corpus(int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len, uint64_t stride,
                    const uint8_t *vocab, const uint64_t *cum, const uint32_t *phrases, uint8_t *dst, hipStream_t st);
 }
@@ -86,6 +87,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->device = device_id;
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
+    if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0x300u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     *out = c;
@@ -363,5 +365,12 @@ extern "C" int pna_bench_corpus_fill_device(pna_gpu_ctx *c, int kind, uint64_t f
                   (const uint32_t *)c->c_phr.p, (uint8_t *)d_dst, st);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
+    return PNA_OK;
+}
+
+extern "C" int pna_gpu_debug_lz_stamps(pna_gpu_ctx *c, unsigned long long *out8) {
+    if (!c || !out8) return PNA_E_INVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    lz_read_stamps(out8);
     return PNA_OK;
 }

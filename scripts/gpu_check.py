@@ -13,9 +13,10 @@ def first_diff(a, b):
             return i
     return n if len(a) != len(b) else -1
 
-def main():
+def main(extra_flags=0):
     print("torch", torch.__version__, "cuda", torch.cuda.is_available(), torch.cuda.get_device_name(0) if torch.cuda.is_available() else None)
-    ctx = pna.Context(0)
+    ctx = pna.Context(0, flags=(pna.F_HUF | pna.F_FSE | pna.F_LAZY | extra_flags))
+    print("ctx flags extra", hex(extra_flags))
     # 1. corpus generator parity
     for kind, n in ((0, 20000), (1, 4096), (2, 8192), (0, 1 << 20)):
         t = torch.empty(n * 2 + 4096, dtype=torch.uint8, device="cuda")
@@ -84,4 +85,6 @@ def main():
     return bad
 
 if __name__ == "__main__":
-    sys.exit(1 if main() else 0)
+    rc = main(0)
+    rc += main(0x200)   # same cases through the serial fallback of k_lz
+    sys.exit(1 if rc else 0)

@@ -1,0 +1,16 @@
+"""Diagnostic: per-phase cycle shares of k_lz (wave 0), on the GPU box."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pna = importlib.import_module("portable-network-archive_amd")
+n, L = 1024, 1 << 20
+ctx = pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | 0x100)
+src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())
+dst = torch.empty(n * (L + 1024), dtype=torch.uint8, device="cuda")
+for it in range(2):
+    ctx.compress_batch_device(src.data_ptr(), [i * L for i in range(n + 1)], [L] * n, dst.data_ptr(), dst.numel())
+    st = ctx.lz_stamps(); tm = ctx.timing()
+    tot = sum(st)
+    names = ["load->B1", "lookup->B2", "insert+match", "spec parse->B3", "chain->B4", "finalize->B5", "emit"]
+    print("lz ms", round(tm.ms_lz, 3), "cycles/tile/WG", round(tot / (n * 512)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})
