@@ -26,11 +26,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cores() -> int:
+    """Logical CPUs this process may actually use: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sample_files: int, file_len: int) -> dict:
     """Reference pipeline restated on the host cores (oracle/cpu_baseline.c): one entry per task, libzstd level 3."""
     from oracle import codec
     L = codec.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     data = b"".join(codec.corpus_file(0, i, file_len) for i in range(min(sample_files, 64)))
     n_unique = len(data) // file_len
     L.pna_cpu_zstd_version.restype = ctypes.c_uint
@@ -60,7 +72,8 @@ def cpu_baseline(sample_files: int, file_len: int) -> dict:
     secs1 = L.pna_cpu_baseline_zstd(buf, n1, file_len, file_len, 1, 3, ctypes.byref(out1))
     return {"value": n_files * file_len / secs / 2**20, "unit": "MiB/s", "cores": cores, "kind": "port",
             "sample": f"{n_files} x {file_len} B enwik-style files ({n_unique} unique), host libzstd {ver // 10000}.{ver // 100 % 100}.{ver % 100} "
-                      f"level 3 streaming, one entry per task on {cores} threads",
+                      f"level 3 streaming, one entry per task on {cores} threads (= usable cores: affinity / cgroup cpu.max; "
+                      f"host has {os.cpu_count()} logical CPUs)",
             "ratio": n_files * file_len / max(out.value, 1),
             "single_thread_mib_s": n1 * file_len / secs1 / 2**20}
 
@@ -100,33 +113,18 @@ def main() -> None:
     src_len = [file_len] * n_files
     dst_cap = sum(pna.bound(pna.ALGO_ZSTD, file_len) for _ in range(1)) * n_files + 4096
     dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
-    gather_buf = None
+
+    shard = importlib.import_module("portable-network-archive_amd.shard")
+    gather_out = [None]
 
     def step():
         offs = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap)
         total = offs[-1]
         if world > 1:
             # ordered gather of the compressed shards into the serial stream on rank 0 (RCCL send/recv over xGMI)
-            sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-            mine = torch.tensor([total], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-            if rank == 0:
-                sz = sizes.tolist()
-                nonlocal gather_buf
-                need = sum(sz)
-                if gather_buf is None or gather_buf.numel() < need:
-                    gather_buf = torch.empty(int(need * 1.05) + 4096, dtype=torch.uint8, device=dev)
-                pos = sz[0]
-                gather_buf[:pos].copy_(dst[:pos])
-                ops = []
-                for r in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, gather_buf[pos:pos + sz[r]], r))
-                    pos += sz[r]
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            else:
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, dst[:total], 0)]):
-                    w.wait()
+            if rank == 0 and gather_out[0] is None:
+                gather_out[0] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
+            shard.gather_ordered(dst, total, rank, world, out=gather_out[0])
         return total
 
     for _ in range(args.warmup):
@@ -181,7 +179,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                sample = args.cpu_sample_files or 48 * (os.cpu_count() or 1)
+                sample = args.cpu_sample_files or 64 * usable_cores()
                 line["cpu_baseline"] = cpu_baseline(sample, file_len)
             except Exception as e:  # never lose the GPU number because the CPU leg failed
                 line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}

@@ -1,0 +1,56 @@
+/*
+ * include/pna_archive.h -- C ABI of the host-side PNA container writer in libpna_gpu.so.
+ *
+ * Restates, byte for byte, the writer half of libpna that the compression path feeds
+ * (reference paths relative to /root/reference):
+ *   Archive::write_header / add_entry / finalize          lib/src/archive/write.rs:92-101,368-370,438-440
+ *   NormalEntry::write_chunks_to (FHED fSIZ FDAT* FEND)   lib/src/entry.rs:888-913
+ *   write_chunk (len BE | type | data | crc32 BE)         lib/src/io.rs:183-197, lib/src/format/chunk.rs:7-12
+ *   FlattenWriter splitting of the payload into FDATs     lib/src/util/io.rs:60-77
+ *   Archive::write_solid_header / SolidArchive            lib/src/archive/write.rs:443-470,545-548,575-580,716-727
+ *   create_archive_file driver                            cli/src/command/create.rs:575-635
+ * Compression itself is done by the kernels behind pna_gpu.h; PNA_ALGO_STORE needs no GPU.
+ */
+#ifndef PNA_ARCHIVE_H
+#define PNA_ARCHIVE_H
+#include <stddef.h>
+#include <stdint.h>
+#include "pna_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CRC-32 (IEEE) as crc32fast computes it for chunk_crc(type || data); start with crc = 0. */
+uint32_t pna_crc32(uint32_t crc, const void *buf, size_t len);
+
+typedef struct pna_archive pna_archive;
+
+/* Archive::write_header: emits the signature and AHED(archive_number) into the sink at once. */
+int  pna_archive_new(pna_sink_fn sink, void *user, uint32_t archive_number, pna_archive **out);
+/* Archive::add_entry for a file entry whose payload is ALREADY the compressed stream (what FileEntryBuilder::build
+ * produced).  compression is Compression::to_byte(); raw_size < 0 omits fSIZ; max_chunk_size 0 = u32::MAX. */
+int  pna_archive_add_file(pna_archive *a, const char *name, int compression, int64_t raw_size,
+                          const void *payload, size_t payload_len, uint32_t max_chunk_size);
+/* Directory entry: FHED(kind 1, store) FEND, no fSIZ/FDAT (lib/src/entry/builder/dir.rs:52-54). */
+int  pna_archive_add_dir(pna_archive *a, const char *name);
+/* Solid entry from an already compressed stream: SHED SDAT* SEND; each piece becomes one SDAT chunk. */
+int  pna_archive_add_solid(pna_archive *a, int compression, const void *const *pieces, const size_t *piece_len, size_t n_pieces);
+/* Serialise one inner STORE entry (FHED fSIZ FDAT FEND as raw chunk bytes) -- what SolidArchive::add_entry feeds
+ * the compressor (lib/src/archive/write.rs:575-580).  Returns the number of bytes written to dst (cap checked), or
+ * the required size when dst is NULL. */
+size_t pna_archive_inner_entry_bytes(const char *name, const void *data, size_t len, void *dst, size_t cap);
+/* Archive::finalize: AEND.  Consumes the handle. */
+int  pna_archive_finalize(pna_archive *a);
+void pna_archive_abort(pna_archive *a);
+
+/* pna create, non-solid or solid (cli/src/command/create.rs:575-635): compress the n entries on the GPU in one
+ * batch (entry-parallel, like spawn_entry_results), then write them in index order.  algo PNA_ALGO_STORE works
+ * without a GPU (ctx may be NULL). */
+int  pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int solid, size_t n, const char *const *names,
+                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

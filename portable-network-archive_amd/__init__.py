@@ -55,6 +55,9 @@ EXPORTS = [
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
+    # include/pna_archive.h
+    "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
+    "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
 ]
 
 
@@ -110,6 +113,25 @@ def load_library() -> ctypes.CDLL:
     L.pna_bench_corpus_fill_device.restype = ctypes.c_int
     L.pna_bench_corpus_fill_device.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_uint64, vp, vp]
+    L.pna_crc32.restype = ctypes.c_uint32
+    L.pna_crc32.argtypes = [ctypes.c_uint32, ctypes.c_char_p, sz]
+    L.pna_archive_new.restype = ctypes.c_int
+    L.pna_archive_new.argtypes = [SINK_FN, vp, u32, ctypes.POINTER(vp)]
+    L.pna_archive_add_file.restype = ctypes.c_int
+    L.pna_archive_add_file.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int64, ctypes.c_char_p, sz, u32]
+    L.pna_archive_add_dir.restype = ctypes.c_int
+    L.pna_archive_add_dir.argtypes = [vp, ctypes.c_char_p]
+    L.pna_archive_add_solid.restype = ctypes.c_int
+    L.pna_archive_add_solid.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz), sz]
+    L.pna_archive_inner_entry_bytes.restype = sz
+    L.pna_archive_inner_entry_bytes.argtypes = [ctypes.c_char_p, ctypes.c_char_p, sz, vp, sz]
+    L.pna_archive_finalize.restype = ctypes.c_int
+    L.pna_archive_finalize.argtypes = [vp]
+    L.pna_archive_abort.restype = None
+    L.pna_archive_abort.argtypes = [vp]
+    L.pna_create_archive.restype = ctypes.c_int
+    L.pna_create_archive.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p),
+                                     ctypes.POINTER(vp), ctypes.POINTER(sz), SINK_FN, vp]
     _lib = L
     return L
 
@@ -251,3 +273,84 @@ class CompressionWriter:
         h, self._h = self._h, None
         self._ctx._check(self._ctx._L.pna_gpu_stream_finish(h))
         return self._sink_obj
+
+
+class Archive:
+    """Archive<W> writer -- lib/src/archive/write.rs: write_header (constructor), add_entry, finalize.
+
+    The sink is any object with .write(bytes).  Payloads handed to add_file() are already-compressed streams."""
+
+    def __init__(self, sink, archive_number: int = 0):
+        self._L = load_library()
+        self._sink_obj = sink
+
+        def _sink(_u, buf, n):
+            try:
+                sink.write(ctypes.string_at(buf, n))
+                return 0
+            except Exception:
+                return 1
+        self._cb = SINK_FN(_sink)
+        h = ctypes.c_void_p()
+        rc = self._L.pna_archive_new(self._cb, None, archive_number, ctypes.byref(h))
+        if rc:
+            raise PnaGpuError(rc, self._L.pna_gpu_strerror(rc).decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc:
+            raise PnaGpuError(rc, self._L.pna_gpu_strerror(rc).decode())
+
+    def add_file(self, name: str, compression: int, raw_size: Optional[int], payload: bytes, max_chunk_size: int = 0):
+        self._check(self._L.pna_archive_add_file(self._h, name.encode(), compression, -1 if raw_size is None else raw_size,
+                                                 bytes(payload), len(payload), max_chunk_size))
+
+    def add_dir(self, name: str):
+        self._check(self._L.pna_archive_add_dir(self._h, name.encode()))
+
+    def add_solid(self, compression: int, pieces: Sequence[bytes]):
+        n = len(pieces)
+        bufs = [ctypes.create_string_buffer(bytes(p), max(len(p), 1)) for p in pieces]
+        pp = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+        pl = (ctypes.c_size_t * max(n, 1))(*[len(p) for p in pieces])
+        self._check(self._L.pna_archive_add_solid(self._h, compression, pp, pl, n))
+
+    def finalize(self):
+        h, self._h = self._h, None
+        self._check(self._L.pna_archive_finalize(h))
+        return self._sink_obj
+
+
+def inner_entry_bytes(name: str, data: bytes) -> bytes:
+    """One STORE entry serialised as chunk bytes (what SolidArchive::add_entry feeds the compressor)."""
+    L = load_library()
+    need = L.pna_archive_inner_entry_bytes(name.encode(), bytes(data), len(data), None, 0)
+    buf = ctypes.create_string_buffer(need)
+    got = L.pna_archive_inner_entry_bytes(name.encode(), bytes(data), len(data), buf, need)
+    return buf.raw[:got]
+
+
+def crc32(data: bytes, crc: int = 0) -> int:
+    return load_library().pna_crc32(crc, bytes(data), len(data))
+
+
+def create_archive(ctx: Optional[Context], names: Sequence[str], entries: Sequence[bytes], algo: int = ALGO_ZSTD,
+                   level: int = LEVEL_DEFAULT, solid: bool = False) -> bytes:
+    """`pna create` (cli/src/command/create.rs:575-635): entry-parallel compression on the GPU, ordered write."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend(ctypes.string_at(buf, k))
+        return 0
+    cb = SINK_FN(_sink)
+    bufs = [ctypes.create_string_buffer(bytes(e), max(len(e), 1)) for e in entries]
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
+    rc = L.pna_create_archive(ctx._h if ctx is not None else None, algo, level, 1 if solid else 0, n, a_names, a_src, a_len, cb, None)
+    if rc:
+        msg = L.pna_gpu_last_error(ctx._h).decode() if ctx is not None else ""
+        raise PnaGpuError(rc, msg or L.pna_gpu_strerror(rc).decode())
+    return bytes(out)

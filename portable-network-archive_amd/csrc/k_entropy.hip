@@ -342,8 +342,14 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     if (wave < nstreams) m = (nstreams == 4 && wave == 3) ? nlit - 3 * segsz : segsz;
     const uint32_t chunk = (m + 63) / 64;
     uint32_t c0 = a + lane * chunk, c1 = c0 + chunk; if (c1 > a + m) c1 = a + m; if (c0 > c1) c0 = c1;
+    // aligned dword loads over the lane's chunk; bytes outside [c0, c1) are skipped
+    const uint32_t *bl32 = (const uint32_t *)bl;
     uint32_t bits = 0;
-    for (uint32_t i = c0; i < c1; i++) bits += code[bl[i]] >> 16;
+    for (uint32_t w = c0 >> 2; w < ((c1 + 3) >> 2) && c0 < c1; w++) {
+        const uint32_t v = bl32[w], base = w << 2;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t i = base + k; if (i >= c0 && i < c1) bits += code[(v >> (8 * k)) & 0xFF] >> 16; }
+    }
     uint32_t sc = bits;                                            // inclusive scan over lanes
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
@@ -361,10 +367,17 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
         // lane's symbols occupy stream bits [total - sc, total - sc + bits); later symbols sit at lower bits
         uint64_t pos = (uint64_t)off[wave] * 8 + (total - sc);
         uint32_t widx = (uint32_t)(pos >> 5); uint32_t nb = (uint32_t)(pos & 31); uint64_t acc = 0;
-        for (uint32_t i = c1; i-- > c0;) {
-            uint32_t cv = code[bl[i]];
-            acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
-            if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+        if (c0 < c1) for (uint32_t w = (c1 + 3) >> 2; w-- > (c0 >> 2);) {
+            const uint32_t v = bl32[w], base = w << 2;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const uint32_t i = base + (uint32_t)k;
+                if (i >= c0 && i < c1) {
+                    const uint32_t cv = code[(v >> (8 * k)) & 0xFF];
+                    acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
+                    if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+                }
+            }
         }
         if (lane == 0) { acc |= (uint64_t)1 << nb; nb += 1; if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; } }
         if (nb) atomicOr(&out32[widx], (uint32_t)acc);
@@ -382,8 +395,11 @@ __global__ __launch_bounds__(64)
 void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
            const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc) {
     __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
+    __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 | base << 16 (small values only)
     const uint32_t lane = threadIdx.x;
     const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8) | (C_LL_BASE[c] << 16); }
+    for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8) | (C_ML_BASE[c] << 16); }
     for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
         const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
         uint32_t *dstw = (uint32_t *)&tab[s][0];
@@ -410,26 +426,48 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
         acc |= (uint64_t)v << nb; nb += n;
         if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
     };
-    uint32_t i = nseq - 1;
-    uint64_t s = bs[i];
-    uint32_t llv = seq_ll(s), mlv = seq_ml(s), ofb = seq_off(s) + 3;
-    uint32_t lc = ll_code(llv), mc = ml_code(mlv), oc = hb(ofb);
-    uint32_t st_ml = mml == 1 ? 0u : tml->sym[mc].first_state;
-    uint32_t st_of = mof == 1 ? 0u : tof->sym[oc].first_state;
-    uint32_t st_ll = mll == 1 ? 0u : tll->sym[lc].first_state;
-    put(llv - C_LL_BASE[lc], C_LL_BITS[lc]);
-    put(mlv - C_ML_BASE[mc], C_ML_BITS[mc]);
-    put(ofb - (1u << oc), oc);
-    while (i-- > 0) {
-        s = bs[i];
-        llv = seq_ll(s); mlv = seq_ml(s); ofb = seq_off(s) + 3;
-        lc = ll_code(llv); mc = ml_code(mlv); oc = hb(ofb);
-        if (mof != 1) { const SeqSym y = tof->sym[oc]; uint32_t n = (st_of + y.delta_nb) >> 16; put(st_of & ((1u << n) - 1), n); st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
-        if (mml != 1) { const SeqSym y = tml->sym[mc]; uint32_t n = (st_ml + y.delta_nb) >> 16; put(st_ml & ((1u << n) - 1), n); st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
-        if (mll != 1) { const SeqSym y = tll->sym[lc]; uint32_t n = (st_ll + y.delta_nb) >> 16; put(st_ll & ((1u << n) - 1), n); st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
-        put(llv - C_LL_BASE[lc], C_LL_BITS[lc]);
-        put(mlv - C_ML_BASE[mc], C_ML_BITS[mc]);
-        put(ofb - (1u << oc), oc);
+    // Sequences are consumed last-to-first in 32-byte chunks (4 sequences, two 16-byte loads per lane); the next
+    // chunk is requested before the current one is encoded so the HBM/L2 latency overlaps the serial tANS chain.
+    uint32_t st_ml = 0, st_of = 0, st_ll = 0;
+    bool first = true;
+    const uint32_t top = nseq - 1;
+    uint32_t k = top >> 2;
+    const uint4 *bs4 = (const uint4 *)bs;
+    uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
+    for (;;) {
+        uint4 n0 = a0, n1 = a1;
+        if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
+        const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
+                                (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            if (4 * k + (uint32_t)j > top) continue;
+            const uint64_t s = sq[j];
+            const uint32_t llv = seq_ll(s), mlv = seq_ml(s), ofb = seq_off(s) + 3;
+            // code / extra-bit count / base: LDS LUT for small values, arithmetic above (code = highbit + 19 / 36)
+            uint32_t lc, lbits, lbase, mc, mbits, mbase;
+            if (llv < 64) { const uint32_t t = lut_ll[llv]; lc = t & 0xFF; lbits = (t >> 8) & 0xFF; lbase = t >> 16; }
+            else { lbits = hb(llv); lc = lbits + 19; lbase = 1u << lbits; }
+            const uint32_t mb = mlv - 3;
+            if (mb < 128) { const uint32_t t = lut_ml[mb]; mc = t & 0xFF; mbits = (t >> 8) & 0xFF; mbase = t >> 16; }
+            else { mbits = hb(mb); mc = mbits + 36; mbase = (1u << mbits) + 3; }
+            const uint32_t oc = hb(ofb);
+            if (first) {
+                st_ml = mml == 1 ? 0u : tml->sym[mc].first_state;
+                st_of = mof == 1 ? 0u : tof->sym[oc].first_state;
+                st_ll = mll == 1 ? 0u : tll->sym[lc].first_state;
+                first = false;
+            } else {
+                if (mof != 1) { const SeqSym y = tof->sym[oc]; uint32_t n = (st_of + y.delta_nb) >> 16; put(st_of & ((1u << n) - 1), n); st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
+                if (mml != 1) { const SeqSym y = tml->sym[mc]; uint32_t n = (st_ml + y.delta_nb) >> 16; put(st_ml & ((1u << n) - 1), n); st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
+                if (mll != 1) { const SeqSym y = tll->sym[lc]; uint32_t n = (st_ll + y.delta_nb) >> 16; put(st_ll & ((1u << n) - 1), n); st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
+            }
+            put(llv - lbase, lbits);
+            put(mlv - mbase, mbits);
+            put(ofb - (1u << oc), oc);
+        }
+        if (k == 0) break;
+        k--; a0 = n0; a1 = n1;
     }
     if (mml != 1) put(st_ml & ((1u << tl_ml) - 1), tl_ml);
     if (mof != 1) put(st_of & ((1u << tl_of) - 1), tl_of);

@@ -1,0 +1,188 @@
+// pna_archive.cpp -- host-side PNA container writer (C ABI in include/pna_archive.h).
+// Byte-exact restatement of the reference's writer for the chunks the compression path produces; every function
+// cites the reference code it mirrors.  No compression happens here.
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include "../../include/pna_archive.h"
+
+namespace {
+
+// ---- CRC-32 (IEEE 802.3, reflected 0xEDB88320), slice-by-8 -- chunk_crc, lib/src/format/chunk.rs:7-12
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int s = 1; s < 8; s++) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
+    }
+};
+const CrcTables &crc_tables() { static CrcTables T; return T; }
+
+void put_be32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+
+} // namespace
+
+extern "C" uint32_t pna_crc32(uint32_t crc, const void *buf, size_t len) {
+    const CrcTables &T = crc_tables();
+    const uint8_t *p = (const uint8_t *)buf;
+    uint32_t c = ~crc;
+    while (len && ((uintptr_t)p & 7)) { c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8); len--; }
+    while (len >= 8) {
+        uint64_t v; memcpy(&v, p, 8);
+        uint32_t lo = (uint32_t)v ^ c, hi = (uint32_t)(v >> 32);
+        c = T.t[7][lo & 0xFF] ^ T.t[6][(lo >> 8) & 0xFF] ^ T.t[5][(lo >> 16) & 0xFF] ^ T.t[4][lo >> 24] ^
+            T.t[3][hi & 0xFF] ^ T.t[2][(hi >> 8) & 0xFF] ^ T.t[1][(hi >> 16) & 0xFF] ^ T.t[0][hi >> 24];
+        p += 8; len -= 8;
+    }
+    while (len--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return ~c;
+}
+
+struct pna_archive {
+    pna_sink_fn sink; void *user; int err;
+    int emit(const void *p, size_t n) { if (err) return err; if (n && sink(user, p, n) != 0) err = PNA_E_SINK; return err; }
+    // write_chunk: length BE | type | data | crc32(type||data) BE -- lib/src/io.rs:183-197
+    int chunk(const char ty[4], const void *data, size_t len) {
+        if (len > 0xFFFFFFFFull) return err = PNA_E_INVAL;
+        uint8_t head[8]; put_be32(head, (uint32_t)len); memcpy(head + 4, ty, 4);
+        uint32_t crc = pna_crc32(pna_crc32(0, ty, 4), data, len);
+        uint8_t tail[4]; put_be32(tail, crc);
+        emit(head, 8); emit(data, len); return emit(tail, 4);
+    }
+};
+
+static std::string sanitize(const char *name) {          // EntryName::sanitize, lib/src/entry/name.rs:72-80
+    std::string out, cur; std::string s(name ? name : "");
+    auto flush = [&]() { if (!cur.empty() && cur != "." && cur != "..") { if (!out.empty()) out += '/'; out += cur; } cur.clear(); };
+    for (char ch : s) { if (ch == '/' || ch == '\\') flush(); else cur += ch; }
+    flush();
+    return out;
+}
+
+static std::vector<uint8_t> fhed(int kind, int compression, int encryption, int cipher_mode, const std::string &name) {
+    // EntryHeader::to_bytes, lib/src/entry/header.rs:123-134
+    std::vector<uint8_t> h = {0, 0, (uint8_t)kind, (uint8_t)compression, (uint8_t)encryption, (uint8_t)cipher_mode};
+    h.insert(h.end(), name.begin(), name.end());
+    return h;
+}
+
+static size_t fsiz(uint64_t raw, uint8_t out[16]) {        // u128 BE, leading zeros stripped -- lib/src/entry.rs:900-903
+    uint8_t be[16] = {0};
+    for (int i = 0; i < 8; i++) be[15 - i] = (uint8_t)(raw >> (8 * i));
+    size_t skip = 0; while (skip < 16 && be[skip] == 0) skip++;
+    memcpy(out, be + skip, 16 - skip);
+    return 16 - skip;
+}
+
+extern "C" int pna_archive_new(pna_sink_fn sink, void *user, uint32_t archive_number, pna_archive **out) {
+    if (!sink || !out) return PNA_E_INVAL;
+    pna_archive *a = new pna_archive{sink, user, 0};
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};     // lib/src/format/signature.rs:6
+    uint8_t ahed[8] = {0, 0, 0, 0, 0, 0, 0, 0}; put_be32(ahed + 4, archive_number);     // lib/src/archive/header.rs:27-39
+    a->emit(sig, 8); a->chunk("AHED", ahed, 8);
+    if (a->err) { int e = a->err; delete a; return e; }
+    *out = a; return PNA_OK;
+}
+
+extern "C" int pna_archive_add_file(pna_archive *a, const char *name, int compression, int64_t raw_size,
+                                    const void *payload, size_t payload_len, uint32_t max_chunk_size) {
+    if (!a || (!payload && payload_len)) return PNA_E_INVAL;
+    // cipher_mode is CTR (1) when unencrypted: lib/src/entry/options.rs:156-159
+    std::vector<uint8_t> h = fhed(0, compression, 0, 1, sanitize(name));
+    a->chunk("FHED", h.data(), h.size());
+    if (raw_size >= 0) { uint8_t b[16]; size_t n = fsiz((uint64_t)raw_size, b); a->chunk("fSIZ", b, n); }
+    // FlattenWriter: one write of the whole stream -> pieces of at most max_chunk_size, lib/src/util/io.rs:60-77
+    size_t mx = max_chunk_size ? max_chunk_size : 0xFFFFFFFFull;
+    for (size_t p = 0; p < payload_len; p += mx) a->chunk("FDAT", (const uint8_t *)payload + p, std::min(mx, payload_len - p));
+    return a->chunk("FEND", nullptr, 0);
+}
+
+extern "C" int pna_archive_add_dir(pna_archive *a, const char *name) {
+    if (!a) return PNA_E_INVAL;
+    std::vector<uint8_t> h = fhed(1, 0, 0, 0, sanitize(name));                            // lib/src/entry/header.rs:44-52,65-67
+    a->chunk("FHED", h.data(), h.size());
+    return a->chunk("FEND", nullptr, 0);
+}
+
+extern "C" int pna_archive_add_solid(pna_archive *a, int compression, const void *const *pieces, const size_t *piece_len, size_t n) {
+    if (!a || (n && (!pieces || !piece_len))) return PNA_E_INVAL;
+    uint8_t shed[5] = {0, 0, (uint8_t)compression, 0, 1};                                 // lib/src/entry/header.rs:274-282
+    a->chunk("SHED", shed, 5);
+    for (size_t i = 0; i < n; i++) if (piece_len[i]) a->chunk("SDAT", pieces[i], piece_len[i]);   // chunk/write.rs:32-47
+    return a->chunk("SEND", nullptr, 0);
+}
+
+extern "C" size_t pna_archive_inner_entry_bytes(const char *name, const void *data, size_t len, void *dst, size_t cap) {
+    std::vector<uint8_t> h = fhed(0, 0, 0, 1, sanitize(name));
+    uint8_t fs[16]; size_t fn = fsiz(len, fs);
+    size_t need = (12 + h.size()) + (12 + fn) + (len ? 12 + len : 0) + 12;
+    if (!dst) return need;
+    if (cap < need) return 0;
+    struct Mem { uint8_t *p; size_t pos; } m{(uint8_t *)dst, 0};
+    auto sink = [](void *u, const void *b, size_t n) -> int { Mem *mm = (Mem *)u; memcpy(mm->p + mm->pos, b, n); mm->pos += n; return 0; };
+    pna_archive tmp{sink, &m, 0};
+    tmp.chunk("FHED", h.data(), h.size());
+    tmp.chunk("fSIZ", fs, fn);
+    if (len) tmp.chunk("FDAT", data, len);                    // an empty payload produces no FDAT (FlattenWriter ignores empty writes)
+    tmp.chunk("FEND", nullptr, 0);
+    return m.pos;
+}
+
+extern "C" int pna_archive_finalize(pna_archive *a) {
+    if (!a) return PNA_E_INVAL;
+    int rc = a->chunk("AEND", nullptr, 0);                     // lib/src/io.rs:45-51
+    delete a; return rc;
+}
+extern "C" void pna_archive_abort(pna_archive *a) { delete a; }
+
+// create_archive_file -- cli/src/command/create.rs:575-635
+extern "C" int pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int solid, size_t n, const char *const *names,
+                                  const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    if (!sink || (n && (!names || !src || !src_len))) return PNA_E_INVAL;
+    if (algo != PNA_ALGO_STORE && !ctx) return PNA_E_NODEVICE;
+    pna_archive *a = nullptr;
+    int rc = pna_archive_new(sink, user, 0, &a);
+    if (rc) return rc;
+    if (!solid) {
+        std::vector<std::vector<uint8_t>> out(n);
+        if (algo != PNA_ALGO_STORE) {
+            std::vector<void *> dst(n); std::vector<size_t> cap(n), dl(n);
+            for (size_t i = 0; i < n; i++) { out[i].resize(pna_gpu_bound(algo, src_len[i])); dst[i] = out[i].data(); cap[i] = out[i].size(); }
+            rc = pna_gpu_compress_batch(ctx, algo, level, n, src, src_len, dst.data(), cap.data(), dl.data());
+            if (rc) { pna_archive_abort(a); return rc; }
+            for (size_t i = 0; i < n; i++) out[i].resize(dl[i]);
+        }
+        for (size_t i = 0; i < n && !rc; i++) {               // drain_entry_results: index order, core.rs:471-493
+            const void *p = algo == PNA_ALGO_STORE ? src[i] : out[i].data();
+            size_t l = algo == PNA_ALGO_STORE ? src_len[i] : out[i].size();
+            rc = pna_archive_add_file(a, names[i], algo, (int64_t)src_len[i], p, l, 0);
+        }
+    } else {
+        // solid: inner entries are STORE (create.rs:594-598), serialised as chunk bytes, then ONE compressed stream
+        std::vector<uint8_t> plain;
+        for (size_t i = 0; i < n; i++) {
+            size_t need = pna_archive_inner_entry_bytes(names[i], src[i], src_len[i], nullptr, 0);
+            size_t at = plain.size(); plain.resize(at + need);
+            pna_archive_inner_entry_bytes(names[i], src[i], src_len[i], plain.data() + at, need);
+        }
+        struct Pieces { std::vector<std::vector<uint8_t>> v; } pcs;
+        if (algo == PNA_ALGO_STORE) { if (!plain.empty()) pcs.v.push_back(plain); }
+        else {
+            auto psink = [](void *u, const void *b, size_t l) -> int { ((Pieces *)u)->v.emplace_back((const uint8_t *)b, (const uint8_t *)b + l); return 0; };
+            rc = pna_gpu_compress_solid(ctx, algo, level, plain.data(), plain.size(), psink, &pcs);
+            if (rc) { pna_archive_abort(a); return rc; }
+        }
+        std::vector<const void *> pp; std::vector<size_t> pl;
+        for (auto &v : pcs.v) { pp.push_back(v.data()); pl.push_back(v.size()); }
+        rc = pna_archive_add_solid(a, algo, pp.data(), pl.data(), pp.size());
+    }
+    if (rc) { pna_archive_abort(a); return rc; }
+    return pna_archive_finalize(a);
+}

@@ -1,0 +1,61 @@
+"""Entry sharding across ranks and the ordered gather of compressed shards (one process per GPU).
+
+The reference is data-parallel one-entry-per-task on CPU threads and re-orders results by index on one thread
+(cli/src/command/core.rs:496-537 spawn_entry_results, :471-493 drain_entry_results, core/iter.rs ReorderByIndex).
+Here rank r owns a CONTIGUOUS index range balanced by input bytes, so the final stream is the concatenation of the
+ranks' outputs in rank order -- the only exchange is that gather (RCCL send/recv over xGMI on GPUs, gloo in tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def partition_entries(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Contiguous [start, end) per rank, balanced by bytes (greedy on the running prefix)."""
+    n, total = len(sizes), sum(sizes)
+    bounds, acc, start = [], 0, 0
+    for r in range(world):
+        target = total * (r + 1) / world
+        end = start
+        while end < n and (acc + sizes[end] <= target or r == world - 1):
+            acc += sizes[end]
+            end += 1
+        if r < world - 1 and end < n and end == start and n - start > world - 1 - r:
+            acc += sizes[end]
+            end += 1
+        bounds.append((start, end))
+        start = end
+    bounds[-1] = (bounds[-1][0], n)
+    return bounds
+
+
+def gather_ordered(local, local_bytes: int, rank: int, world: int, out=None):
+    """Gather every rank's first `local_bytes` bytes of the uint8 tensor `local` onto rank 0, in rank order.
+
+    Returns (tensor, sizes) on rank 0 and (None, sizes) elsewhere.  Works for CUDA tensors over the nccl (=RCCL)
+    backend and CPU tensors over gloo."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local[:local_bytes], [local_bytes]
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([local_bytes], dtype=torch.int64, device=local.device))
+    sizes = [int(x) for x in sizes_t.tolist()]
+    if rank == 0:
+        need = sum(sizes)
+        if out is None or out.numel() < need:
+            out = torch.empty(need, dtype=torch.uint8, device=local.device)
+        out[:sizes[0]].copy_(local[:sizes[0]])
+        ops, pos = [], sizes[0]
+        for r in range(1, world):
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[pos:pos + sizes[r]], r))
+            pos += sizes[r]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return out[:need], sizes
+    if local_bytes:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]):
+            w.wait()
+    return None, sizes

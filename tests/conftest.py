@@ -1,0 +1,50 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def codec():
+    from oracle import codec as c
+    c.lib()  # builds oracle/liboracle.so on first use
+    return c
+
+
+@pytest.fixture(scope="session")
+def pf():
+    from oracle import pna_format
+    return pna_format
+
+
+@pytest.fixture(scope="session")
+def pna():
+    """The product package; building it needs hipcc (present here and on the GPU box)."""
+    lib = os.path.join(ROOT, "portable-network-archive_amd", "libpna_gpu.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+        g.build()
+    return importlib.import_module("portable-network-archive_amd")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(pna):
+    import torch  # noqa: F401  (shares its HIP runtime with the extension)
+    ctx = pna.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def golden(name: str) -> bytes:
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        return f.read()

@@ -1,0 +1,117 @@
+"""C-ABI surface and host logic (no GPU needed): the library loads, exports every declared symbol, the container
+writer is byte-exact against the oracle and the reference fixtures, and there is no CPU compression fallback."""
+import io
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, golden
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pna_[a-z0-9_]+)\s*\(", txt)) - {"pna_sink_fn"})
+
+
+def test_library_exports_every_declared_symbol(pna):
+    lib = pna.load_library()
+    names = _declared("pna_gpu.h") + _declared("pna_archive.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(set(names)) == sorted(set(pna.EXPORTS))
+
+
+def test_no_cpu_fallback(pna):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pna.PnaGpuError) as e:
+        pna.Context(0)
+    assert e.value.code == -1                                   # PNA_E_NODEVICE
+    with pytest.raises(pna.PnaGpuError):
+        pna.create_archive(None, ["a"], [b"abc"], algo=pna.ALGO_ZSTD)
+
+
+def test_bound_and_levels(pna):
+    assert pna.bound(pna.ALGO_ZSTD, 0) >= 9
+    for n in (1, 4096, (1 << 20), (1 << 20) + 1, 5 << 20):
+        assert pna.bound(pna.ALGO_ZSTD, n) >= n + 6 * ((n + (1 << 20) - 1) >> 20) + 3 * ((n + (1 << 17) - 1) >> 17)
+    # lib/src/compress/zstandard.rs:91-146 and lib/src/compress/deflate.rs:128-187
+    assert pna.clamp_level(pna.ALGO_ZSTD) == 3 and pna.clamp_level(pna.ALGO_ZSTD, 100) == 22 and pna.clamp_level(pna.ALGO_ZSTD, 7) == 7
+    assert pna.clamp_level(pna.ALGO_DEFLATE) == 6 and pna.clamp_level(pna.ALGO_DEFLATE, 100) == 9 and pna.clamp_level(pna.ALGO_DEFLATE, -5) == 0
+
+
+def test_crc_and_empty_archive(pna):
+    assert pna.crc32(b"FDAT" + bytes([0xAA, 0xBB, 0xCC, 0xDD])) == 0x47F32B10
+    assert pna.crc32(b"FDAT\x01\x02\x03") == 2776590148
+    assert pna.crc32(b"AEND") == 0x6BF6486D
+    data = os.urandom(100003)
+    import zlib
+    assert pna.crc32(data) == zlib.crc32(data)
+    assert pna.crc32(data[5000:], pna.crc32(data[:5000])) == zlib.crc32(data)
+    buf = io.BytesIO()
+    pna.Archive(buf).finalize()
+    assert buf.getvalue() == golden("empty.pna")
+
+
+@pytest.mark.parametrize("name", ["deflate.pna", "zstd.pna"])
+def test_writer_reproduces_reference_fixture(pna, pf, name):
+    # lib/tests/copy_entries.rs:15-21 with the C++ writer
+    raw = golden(name)
+    n, items = pf.read_archive(raw)
+    buf = io.BytesIO()
+    a = pna.Archive(buf, n)
+    for it in items:
+        a.add_file(it.name, it.compression, it.raw_file_size, it.data)
+    a.finalize()
+    assert buf.getvalue() == raw
+
+
+def test_store_create_matches_oracle_writer(pna, pf, codec):
+    # BASELINE.json configs[0] plumbing: 100 x 64 KiB random-text entries through the archive writer (no GPU)
+    names = [f"corpus/f{i:05d}.txt" for i in range(100)]
+    ents = [codec.corpus_file(1, i, 65536) for i in range(100)]
+    arc = pna.create_archive(None, names, ents, algo=pna.ALGO_STORE)
+    exp = pf.write_archive_header() + b"".join(
+        pf.write_normal_entry(pf.file_entry_header(0, nm), pf.flatten_writer([e]), len(e)) for nm, e in zip(names, ents)) + pf.finalize_archive()
+    assert arc == exp
+    _, items = pf.read_archive(arc)
+    assert [it.name for it in items] == names and all(it.data == e for it, e in zip(items, ents))   # create/entry_order.rs:9-67
+
+
+def test_deflate_payloads_through_writer(pna, pf, codec):
+    """Container path with the reference's other codec: payloads from stdlib zlib (level 6, header 78 9C)."""
+    import zlib
+    ents = [codec.corpus_file(1, i, 65536) for i in range(8)] + [b""]
+    buf = io.BytesIO()
+    a = pna.Archive(buf)
+    for i, e in enumerate(ents):
+        a.add_file(f"d/{i}", pna.ALGO_DEFLATE, len(e), zlib.compress(e, 6))
+    a.finalize()
+    _, items = pf.read_archive(buf.getvalue())
+    assert [codec.decode_payload(it.compression, it.data, 1 << 20) for it in items] == ents
+    assert items[0].data[:2] == b"\x78\x9c" and items[-1].data == bytes.fromhex("789C030000000001")
+
+
+def test_fdat_splitting_and_dirs(pna, pf):
+    buf = io.BytesIO()
+    a = pna.Archive(buf)
+    a.add_dir("some/dir/")
+    a.add_file("f", 0, 11, b"hello world", max_chunk_size=4)
+    a.finalize()
+    _, items = pf.read_archive(buf.getvalue())
+    assert items[0].kind == 1 and items[0].name == "some/dir" and [t for t, _ in items[0].chunks] == [b"FHED", b"FEND"]
+    assert [d for t, d in items[1].chunks if t == b"FDAT"] == [b"hell", b"o wo", b"rld"]
+
+
+def test_solid_store(pna, pf):
+    names, ents = ["a.txt", "b/c.bin", "empty"], [b"hello" * 50, bytes(range(256)), b""]
+    arc = pna.create_archive(None, names, ents, algo=pna.ALGO_STORE, solid=True)
+    _, items = pf.read_archive(arc)
+    assert isinstance(items[0], pf.ParsedSolid) and items[0].compression == 0
+    inner = pf.read_solid_inner(items[0].data)
+    assert [(e.name, e.data, e.raw_file_size) for e in inner] == [(n, d, len(d)) for n, d in zip(names, ents)]
+    assert pna.inner_entry_bytes("a.txt", ents[0]) == pf.write_normal_entry(pf.file_entry_header(0, "a.txt"), [ents[0]], len(ents[0]))

@@ -1,0 +1,100 @@
+"""The container restatement (oracle/pna_format.py) against the reference's own known answers and fixtures."""
+import hashlib
+import struct
+import zlib
+
+import pytest
+
+from conftest import golden
+
+
+def test_empty_archive_is_golden(pf):
+    # lib/src/archive/write.rs:792-798: write_header + finalize == resources/test/empty.pna (40 bytes)
+    assert pf.write_archive_header() + pf.finalize_archive() == golden("empty.pna")
+    assert golden("empty.pna").hex() == ("89504e410d0a1a0a" "00000008" "41484544" "0000000000000000" "47755bb5"
+                                         "00000000" "41454e44" "6bf6486d")
+
+
+def test_crc_known_answers(pf):
+    assert pf.chunk_crc(b"FDAT", bytes([0xAA, 0xBB, 0xCC, 0xDD])) == 0x47F32B10   # lib/src/format/chunk.rs:30-32
+    assert pf.chunk_crc(b"FDAT", bytes([1, 2, 3])) == 2776590148                   # lib/src/chunk/traits.rs:20-24
+    assert pf.chunk_crc(b"AEND", b"") == 0x6BF6486D                                # lib/src/io.rs:176-179
+    assert pf.chunk_crc(b"FEND", b"") == 0xF62170D4
+    assert pf.chunk_crc(b"SEND", b"") == 0x91E6D779
+
+
+def test_chunk_layout(pf):
+    # lib/src/chunk/write.rs:55-63: "hello world" as FDAT is 23 bytes, length prefix 0x0000000B
+    c = pf.write_chunk(b"FDAT", b"hello world")
+    assert len(c) == 23 and c[:4] == bytes([0, 0, 0, 0x0B]) and c[4:8] == b"FDAT"
+    # lib/src/chunk/write.rs:76-92: max chunk size 4 -> chunks of 4, 4, 3 ... at offsets 0, 16, 32
+    s = pf.chunk_stream_writer(b"FDAT", [b"hello world"], 4)
+    sizes, pos = [], 0
+    while pos < len(s):
+        (n,) = struct.unpack_from(">I", s, pos); sizes.append(n); pos += 12 + n
+    assert sizes == [4, 4, 3] and len(s) == 3 * 12 + 11
+
+
+def test_header_layouts(pf):
+    assert pf.archive_header_bytes(1, 2, 3) == bytes([1, 2, 0, 0, 0, 0, 0, 3])     # lib/src/archive/header.rs:64-74
+    assert pf.file_entry_header(pf.COMPRESSION_ZSTD, "name") == bytes([0, 0, 0, 2, 0, 1]) + b"name"
+    assert pf.file_entry_header(pf.COMPRESSION_DEFLATE, "n") == bytes([0, 0, 0, 1, 0, 1]) + b"n"
+    assert pf.solid_header_bytes(pf.COMPRESSION_ZSTD) == bytes([0, 0, 2, 0, 1])
+    assert pf.entry_header_bytes(0, 0, 0, 1, "test.txt") == bytes([0, 0, 0, 0, 0, 1]) + b"test.txt"  # lib/src/entry.rs:1366-1375
+    assert pf.dir_entry_header("d") == bytes([0, 0, 1, 0, 0, 0]) + b"d"
+    assert pf.fsiz_bytes(0) == b"" and pf.fsiz_bytes(10) == b"\x0a" and pf.fsiz_bytes(51475) == bytes([0xC9, 0x13])
+
+
+def test_flatten_writer(pf):
+    # lib/src/util/io.rs:209-233: writes coalesce up to max_chunk_size, then split
+    assert pf.flatten_writer([b"abc", b"def"]) == [b"abcdef"]
+    assert pf.flatten_writer([b"abc", b"defgh"], 4) == [b"abcd", b"efgh"]
+    assert pf.flatten_writer([b"", b"a" * 9], 4) == [b"aaaa", b"aaaa", b"a"]
+    assert pf.flatten_writer([]) == []
+
+
+def test_name_sanitize(pf):
+    assert pf.sanitize_name("/a/./b/../c/") == "a/b/c"   # lib/src/entry/name.rs:72-80 keeps Normal components only
+    assert pf.sanitize_name("corpus/f00000.txt") == "corpus/f00000.txt"
+
+
+@pytest.mark.parametrize("name", ["deflate.pna", "zstd.pna", "zstd_with_raw_file_size.pna"])
+def test_reserialise_fixture_byte_exact(pf, name):
+    # lib/tests/copy_entries.rs:15-21: read -> re-add reproduces the archive byte for byte
+    raw = golden(name)
+    n, items = pf.read_archive(raw)
+    out = pf.write_archive_header(n)
+    for it in items:
+        out += pf.write_normal_entry(pf.entry_header_bytes(it.kind, it.compression, it.encryption, it.cipher_mode, it.name),
+                                     [d for t, d in it.chunks if t == b"FDAT"], it.raw_file_size)
+    out += pf.finalize_archive()
+    assert out == raw
+
+
+def test_reader_rejects_bad_crc_and_unknown_critical_chunk(pf):
+    raw = bytearray(golden("zstd.pna"))
+    raw[60] ^= 1
+    with pytest.raises(ValueError):
+        pf.read_archive(bytes(raw))
+    # lib/src/entry.rs:1651-1688: unknown critical chunk inside an entry is an error, ancillary is kept
+    bad = pf.write_archive_header() + pf.write_chunk(b"FHED", pf.file_entry_header(0, "x")) + pf.write_chunk(b"XXXX", b"") \
+        + pf.write_chunk(b"FEND") + pf.finalize_archive()
+    with pytest.raises(ValueError):
+        pf.read_archive(bad)
+    ok = pf.write_archive_header() + pf.write_chunk(b"FHED", pf.file_entry_header(0, "x")) + pf.write_chunk(b"xxXx", b"") \
+        + pf.write_chunk(b"FEND") + pf.finalize_archive()
+    assert len(pf.read_archive(ok)[1]) == 1
+
+
+def test_fixture_payload_hashes(pf, codec):
+    # sha256[:16] of the decoded payloads of the reference's golden archives
+    want = {"raw/text.txt": "f4796bff42910365", "raw/images/icon.png": "3edb62033736e171", "raw/images/icon.svg": "2379e0d74449ad06",
+            "raw/first/second/third/pna.txt": "471bc8030879f3f0", "raw/pna/nest.pna": "84c6c86c8d7de359", "raw/pna/empty.pna": "d379f9324878088c"}
+    for arc in ("zstd.pna", "deflate.pna"):
+        _, items = pf.read_archive(golden(arc))
+        assert len(items) == 9                                      # lib/tests/extract_compatibility.rs asserts 9 entries
+        got = {it.name: hashlib.sha256(codec.decode_payload(it.compression, it.data, 8 << 20)).hexdigest()[:16] for it in items}
+        for k, v in want.items():
+            assert got[k] == v
+    assert hashlib.sha256(golden("zstd.pna")).hexdigest()[:16] == "5185fd6444089203"
+    assert hashlib.sha256(golden("deflate.pna")).hexdigest()[:16] == "fbb4240ebad45d1c"
