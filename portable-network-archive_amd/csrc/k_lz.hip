@@ -5,15 +5,18 @@
 //
 // LDS (one workgroup per CU, ~146 KiB of the 160 KiB):
 //   win   [65536 B]  circular copy of the segment's most recent 64 KiB (look-back + 1 KiB look-ahead)
-//   table [16384 x u32] hash table: position+1 of the latest occurrence (0 = empty); inserts are ds_max_u32
-//   len/off/fixlen [2048 x u16 each]  per-position results of the current tile (fallback path only reads them)
+//   table [16384 x u32] hash table: (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
+//         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
+//   len/off/fixlen [2048 x u16 each]  written and read by the serial fallback only
 //   per-wave records
 // Per tile of 2048 positions (2 per lane):
 //   window chunk (register-prefetched during the previous tile) -> B1 -> lookup -> B2 -> insert + match +
-//   per-wave SPECULATIVE parse (as if the parse entered the wave at its first position) -> B3 ->
-//   every wave resolves its TRUE entry in parallel (carry chained through the speculative exits of the earlier,
-//   not fully covered waves); it walks from there until it lands on a position its speculative parse also stood on -> finalise ->
-//   B4 -> prefix sums over the waves' counts -> emission of sequences and literals straight to HBM.
+//   per-wave SPECULATIVE parse (as if the parse entered the wave at its first position; scalar loops that also
+//   build the coverage bit masks) -> B3 -> every wave resolves its TRUE entry in parallel (carry chained through
+//   the speculative exits of the earlier, not fully covered waves) and walks from there until it lands on a
+//   position its speculative parse also stood on -> masks of selected matches / literals -> B4 -> 16-lane DPP
+//   scans of the waves' counts -> emission of sequences and literals straight to HBM.
+//   Cross-lane traffic on this path: ballots, readlanes, DPP and one ds_bpermute per 64 positions.
 //   The parallel resolution is exact when every not-fully-covered wave re-synchronises (checked); otherwise the
 //   tile falls back to a serial resolution by wave 0 (rare; forced with flag 0x200 for testing).
 #include <hip/hip_runtime.h>
@@ -22,6 +25,7 @@
 namespace pna {
 
 constexpr uint32_t WMASK32 = WIN_BYTES / 4 - 1;
+constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 
 // LDS layout (byte offsets into the dynamic shared array)
 constexpr uint32_t L_WIN    = 0;
@@ -30,15 +34,15 @@ constexpr uint32_t L_LEN    = L_TABLE + (4u << HASH_LOG);
 constexpr uint32_t L_OFF    = L_LEN + 2 * TILE;
 constexpr uint32_t L_FIXLEN = L_OFF + 2 * TILE;
 constexpr uint32_t L_WMETA  = L_FIXLEN + 2 * TILE;          // 16 x 64 B
-constexpr uint32_t L_WRES   = L_WMETA + 64 * LZ_WAVES;      // 16 x 32 B
-constexpr uint32_t L_WPUB   = L_WRES + 32 * LZ_WAVES;       // 16 x 16 B
+constexpr uint32_t L_WRES   = L_WMETA + 64 * LZ_WAVES;      // 16 x 48 B
+constexpr uint32_t L_WPUB   = L_WRES + 48 * LZ_WAVES;       // 16 x 16 B
 constexpr uint32_t L_STATE  = L_WPUB + 16 * LZ_WAVES;       // 16 B
 constexpr uint32_t L_TOTAL  = L_STATE + 16;
 
-struct WMeta { uint64_t sel[2]; uint64_t vis[2]; uint64_t eff[2]; uint32_t exit0; uint32_t last_end0; uint32_t pad[2]; };
-struct WRes  { uint64_t fix[2]; uint32_t carry; uint32_t sync; uint32_t lit_start; uint32_t pad; };
-struct WPub  { uint32_t nsel, sumlen, last_end, bad; };
-static_assert(sizeof(WMeta) == 64 && sizeof(WRes) == 32 && sizeof(WPub) == 16, "LDS record sizes");
+struct WMeta { uint64_t sel[2]; uint64_t vis[2]; uint64_t eff[2]; uint32_t exit0; uint32_t pad[3]; };
+struct WRes  { uint64_t fix[2]; uint64_t fcov[2]; uint32_t carry; uint32_t sync; uint32_t exit; uint32_t pad; };
+struct WPub  { uint32_t cnt; uint32_t gl; uint32_t bad; uint32_t exit; };   // cnt = nsel | nlit << 16; gl = local literal index of the last match + 1 (0 = no match)
+static_assert(sizeof(WMeta) == 64 && sizeof(WRes) == 48 && sizeof(WPub) == 16, "LDS record sizes");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_FALLBACK = 0x200u;
 
@@ -49,15 +53,18 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l) {
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 __device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = v > t ? v : t; }
-    return v;
+__device__ __forceinline__ uint64_t mlow(uint32_t n) { return n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1); }   // bits [0, n)
+
+// DPP helpers (VALU only): value of lane i-k inside each row of 16 lanes (0 outside), and of lane i+1 of the wave
+#define DPP_ROW_SHR(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (k), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t row_scan_add(uint32_t v) {          // inclusive prefix sum inside a row of 16 lanes
+    v += DPP_ROW_SHR(v, 1); v += DPP_ROW_SHR(v, 2); v += DPP_ROW_SHR(v, 4); v += DPP_ROW_SHR(v, 8); return v;
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-    return v;
+__device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
+    uint32_t t;
+    t = DPP_ROW_SHR(v, 1); v = v > t ? v : t; t = DPP_ROW_SHR(v, 2); v = v > t ? v : t;
+    t = DPP_ROW_SHR(v, 4); v = v > t ? v : t; t = DPP_ROW_SHR(v, 8); v = v > t ? v : t; return v;
 }
 
 // 8 / 4 bytes at an arbitrary segment position from the circular window
@@ -96,6 +103,13 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// coverage of a match at wave-relative position p (0..127) with length L, as bit masks of the wave's two groups
+__device__ __forceinline__ void cover(uint64_t &c0, uint64_t &c1, uint32_t p, uint32_t L) {
+    const uint32_t end = p + L;
+    if (p < 64) c0 |= mlow(end) & ~mlow(p);
+    if (end > 64) c1 |= mlow(end - 64) & ~mlow(p > 64 ? p - 64 : 0u);
+}
+
 // diagnostic build only (STAMP = true): wave 0 / lane 0 accumulates s_memtime deltas per phase
 __device__ unsigned long long g_lz_stamps[8];
 
@@ -112,7 +126,6 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     WMeta    *wmeta   = (WMeta *)(lds + L_WMETA);
     WRes     *wres    = (WRes *)(lds + L_WRES);
     WPub     *wpub    = (WPub *)(lds + L_WPUB);
-    uint32_t *state   = (uint32_t *)(lds + L_STATE);      // fallback: [0] next_free (abs), [1] lit_start (abs)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SegDesc sd = segs[blockIdx.x];
@@ -142,8 +155,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
         const uint32_t gblk = sd.blk_base + b;
         uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
         uint8_t  *blit = lits + (size_t)gblk * BLK_SIZE;
-        uint32_t next_free = blk_start, lit_start = blk_start;     // uniform across the workgroup
-        uint32_t seq_run = 0, len_run = 0;
+        // block-level parse state, uniform across the workgroup
+        uint32_t next_free = blk_start;      // first position not covered by an emitted match
+        uint32_t seq_run = 0, lit_run = 0;   // sequences / literals emitted so far
+        uint32_t g_last1 = 1;                // 1 + literal index at the most recent match (0 literals before the block start)
 
         for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE) {
             const uint32_t t1 = (blk_end - t0 < TILE) ? blk_end : t0 + TILE;
@@ -158,16 +173,17 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             LZ_STAMP(0);
 
             // ---- lookup
-            uint32_t q[2], lo[2], hi[2], hsh[2], c1[2];
-            bool inb[2], hv[2];
+            uint32_t q[2], lo[2], hi[2], hsh[2], tag[2], ent[2];
+            bool hv[2];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 q[r] = t0 + wbase + 64 * r + lane;
-                inb[r] = q[r] < t1;
-                hv[r] = inb[r] && (q[r] + 8 <= seg_len);
+                hv[r] = (q[r] < t1) && (q[r] + 8 <= seg_len);
                 fetch8(win32, q[r], lo[r], hi[r]);
-                hsh[r] = (lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu) >> (32 - HASH_LOG);
-                c1[r] = hv[r] ? table[hsh[r]] : 0u;
+                const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
+                hsh[r] = h32 >> (32 - HASH_LOG);
+                tag[r] = (h32 >> (32 - HASH_LOG - TAG_BITS)) & TAG_MASK;
+                ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
             __syncthreads();                                                        // B2
             LZ_STAMP(1);
@@ -177,10 +193,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             uint64_t effm[2];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                if (hv[r]) atomicMax(&table[hsh[r]], q[r] + 1);
+                if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
                 uint32_t l = 0, o = 0;
-                if (c1[r] != 0) {
-                    uint32_t c = c1[r] - 1; o = q[r] - c;
+                const uint32_t c1 = ent[r] >> TAG_BITS;
+                // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
+                if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r]) {
+                    uint32_t c = c1 - 1; o = q[r] - c;
                     if (o <= MAX_OFF) {
                         uint32_t lim = blk_end - q[r]; lim = lim < CAP1 ? lim : CAP1;
                         uint32_t clo, chi;
@@ -203,76 +221,63 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     }
                 }
                 len[r] = l; off[r] = o; flen[r] = l;
-                len_arr[wbase + 64 * r + lane] = (uint16_t)l;
-                off_arr[wbase + 64 * r + lane] = (uint16_t)o;
-                uint32_t nl = (uint32_t)__shfl_down((int)l, 1);
-                bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
+                const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)
+                const bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
                 effm[r] = __ballot(eff);
             }
             LZ_STAMP(2);
 
-            // ---- speculative parse of this wave's 128 positions (entry at its first position)
-            uint64_t sel[2] = {0, 0};
-            uint32_t entry[2];
-            uint32_t cur = 0, last_end0 = 0xFFFFFFFFu;
+            // ---- speculative parse of this wave's 128 positions (entry at its first position).  The scalar loop only
+            // picks the match starts; coverage masks are rebuilt afterwards with one cross-lane gather per group
+            // (the scalar unit is the bottleneck of this kernel, the LDS crossbar is not).
+            uint64_t sel[2] = {0, 0}, cov[2];
+            uint32_t cur = 0;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                uint32_t e = cur > 64u * r ? cur - 64u * r : 0u;
-                entry[r] = e;
-                while (e < 64) {
-                    uint64_t mm = (effm[r] >> e) << e;
-                    if (!mm) { e = 64; break; }
-                    uint32_t s = ctz64(mm);
+                const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the previous group's last match
+                uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
+                uint32_t e_last = e0;
+                while (rem) {
+                    const uint32_t s = ctz64(rem);
                     uint32_t L = rdlane(len[r], s);
                     if (L == CAP1) {
-                        uint32_t qs = t0 + wbase + 64 * r + s;
+                        const uint32_t qs = t0 + wbase + 64 * r + s;
                         L = lz_extend(win32, qs, qs - rdlane(off[r], s), ext_lim - qs, lane);
+                        if (lane == s) flen[r] = L;
                     }
-                    if (lane == s) flen[r] = L;
                     sel[r] |= (uint64_t)1 << s;
-                    e = s + L;
-                    last_end0 = 64 * r + e;
+                    e_last = s + L;
+                    rem = e_last < 64 ? rem & (~(uint64_t)0 << e_last) : 0;
                 }
-                cur = 64 * r + e;
+                cur = 64 * r + (e_last > 64 ? e_last : 64u);
+                // coverage (starts included): nearest selected start at or below the lane, its length via bpermute
+                const uint64_t m_le = sel[r] & (lane_lt | ((uint64_t)1 << lane));
+                const uint32_t sl = m_le ? 63 - clz64(m_le) : 0u;
+                const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
+                cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
             }
-            // positions the speculative parse stands on (not covered by a speculative match)
-            uint64_t vis[2];
-            {
-                uint32_t ce_prev = 0;   // wave-relative end of the last match of the previous group
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    uint64_t m_le = sel[r] & (lane_lt | ((uint64_t)1 << lane));
-                    uint32_t sl = m_le ? 63 - clz64(m_le) : 0;
-                    uint32_t fl = (uint32_t)__shfl((int)flen[r], (int)sl);
-                    // a match START is a position the parse stands on; only its interior is "covered"
-                    bool cov = (m_le != 0 && lane > sl && lane < sl + fl) || (64u * r + lane < ce_prev) || (lane < entry[r]);
-                    vis[r] = __ballot(!cov);   // positions past the tile end count as stood-on
-                    if (sel[r]) { uint32_t s = 63 - clz64(sel[r]); ce_prev = 64 * r + s + rdlane(flen[r], s); }
-                }
-            }
+            // positions the speculative parse stands on: everything except match interiors (starts are stood on;
+            // positions past the tile end count as stood on so a walk stops there)
+            const uint64_t vis[2] = {~cov[0] | sel[0], ~cov[1] | sel[1]};
             const uint32_t flen_spec[2] = {flen[0], flen[1]};
             if (lane == 0) {
                 WMeta m;
                 m.sel[0] = sel[0]; m.sel[1] = sel[1]; m.vis[0] = vis[0]; m.vis[1] = vis[1];
-                m.eff[0] = effm[0]; m.eff[1] = effm[1]; m.exit0 = cur; m.last_end0 = last_end0; m.pad[0] = m.pad[1] = 0;
+                m.eff[0] = effm[0]; m.eff[1] = effm[1]; m.exit0 = cur; m.pad[0] = m.pad[1] = m.pad[2] = 0;
                 wmeta[wave] = m;
             }
             __syncthreads();                                                        // B3
             LZ_STAMP(3);
 
-            // ---- parallel resolution: assumed carry = max(tile carry, speculative exits of all earlier waves)
+            // ---- parallel resolution.  Carry chain over the speculative exits: a wave the carry already covers
+            // passes it through, any other wave is assumed to re-synchronise and to leave at its speculative exit.
             const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;             // tile-relative
             const uint32_t ex_l = lane < LZ_WAVES ? lane * 128 + wmeta[lane & (LZ_WAVES - 1)].exit0 : 0u;
-            // carry chain over the speculative exits: a wave the carry already covers passes it through, any other
-            // wave is assumed to re-synchronise and therefore to leave at its speculative exit (checked below)
-            uint32_t A = c_in, c_chain = c_in;
-            for (uint32_t j = 0; j < LZ_WAVES; j++) {
-                if (j == wave) A = c_chain;
-                if (c_chain < j * 128 + 128) c_chain = rdlane(ex_l, j);
-            }
-            const uint32_t cw = A > wbase ? A - wbase : 0u;                         // wave-relative entry
-            uint64_t fix[2] = {0, 0};
-            uint32_t e_sync = 128, last_fix_end = 0;
+            uint32_t A = c_in;
+            for (uint32_t j = 0; j < wave; j++) if (A < j * 128 + 128) A = rdlane(ex_l, j);
+            uint32_t cw = A > wbase ? A - wbase : 0u;                               // wave-relative entry
+            uint64_t fix[2] = {0, 0}, fcov[2] = {0, 0};
+            uint32_t e_sync = 128;
             bool synced = false;
             {
                 uint32_t e = cw;
@@ -291,159 +296,128 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         const uint32_t o = r1 ? rdlane(off[1], b2) : rdlane(off[0], b2);
                         const uint32_t qs = t0 + wbase + e;
                         L = lz_extend(win32, qs, qs - o, ext_lim - qs, lane);
+                        if (lane == b2) { if (r1) flen[1] = L; else flen[0] = L; }
                     }
-                    if (r1) { fix[1] |= (uint64_t)1 << b2; if (lane == b2) flen[1] = L; }
-                    else    { fix[0] |= (uint64_t)1 << b2; if (lane == b2) flen[0] = L; }
-                    e += L; last_fix_end = e;
+                    if (r1) fix[1] |= (uint64_t)1 << b2; else fix[0] |= (uint64_t)1 << b2;
+                    cover(fcov[0], fcov[1], e, L);
+                    e += L;
                 }
-            }
-            const bool bad_w = !synced && cw < 128;                                 // walked off the wave without re-synchronising
-
-            // ---- finalisation (shared by both paths): selection, coverage, literal mask, in-wave prefix of lengths
-            uint64_t fsel[2]; uint32_t fl[2]; bool islit[2]; uint32_t pre[2]; uint32_t tot_len = 0;
-            uint32_t carry_w = cw, sync_w = e_sync;
-            uint64_t fixm[2] = {fix[0], fix[1]};
-            auto finalize = [&](bool from_lds) {
-                tot_len = 0;
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    uint64_t keep;
-                    if (sync_w >= 64u * (r + 1)) keep = 0;
-                    else if (sync_w <= 64u * r) keep = ~(uint64_t)0;
-                    else keep = (~(uint64_t)0) << (sync_w - 64u * r);
-                    fsel[r] = (sel[r] & keep) | fixm[r];
-                    if (from_lds) fl[r] = ((fixm[r] >> lane) & 1) ? (uint32_t)fix_arr[wbase + 64 * r + lane] : flen_spec[r];
-                    else fl[r] = flen[r];
-                }
-                uint32_t ce_prev = 0;
-#pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    uint64_t m_le = fsel[r] & (lane_lt | ((uint64_t)1 << lane));
-                    uint32_t sl = m_le ? 63 - clz64(m_le) : 0;
-                    uint32_t fs = (uint32_t)__shfl((int)fl[r], (int)sl);
-                    bool cov = (m_le != 0 && lane < sl + fs) || (64u * r + lane < ce_prev) || (64u * r + lane < carry_w);
-                    islit[r] = inb[r] && !cov;
-                    if (fsel[r]) { uint32_t s = 63 - clz64(fsel[r]); ce_prev = 64 * r + s + rdlane(fl[r], s); }
-                    uint32_t v = ((fsel[r] >> lane) & 1) ? fl[r] : 0u, sc = v;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
-                    pre[r] = tot_len + sc - v;
-                    tot_len += rdlane(sc, 63);
-                }
-            };
-            finalize(false);
-            uint32_t nsel0 = (uint32_t)__popcll(fsel[0]), nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
-            if (lane == 0) {
-                uint32_t le = 0;                                                    // abs end of this wave's last true match
-                if (synced) {
-                    bool later = e_sync < 64 ? (((sel[0] >> e_sync) != 0) || sel[1] != 0) : ((sel[1] >> (e_sync - 64)) != 0);
-                    if (later) le = t0 + wbase + last_end0;
-                }
-                if (le == 0 && last_fix_end) le = t0 + wbase + last_fix_end;
-                WPub p; p.nsel = nsel; p.sumlen = tot_len; p.last_end = le; p.bad = bad_w ? 1u : 0u;
-                wpub[wave] = p;
-            }
-            __syncthreads();                                                        // B4
-            LZ_STAMP(4);
-
-            WPub pl = wpub[lane & (LZ_WAVES - 1)];
-            const bool lv = lane < LZ_WAVES;
-            const bool any_bad = __ballot(lv && pl.bad) != 0;
-            uint32_t seq_base, len_base, lit_start_w;
-            if (!any_bad && !force_fb) {
-                seq_base = seq_run + wave_sum(lv && lane < wave ? pl.nsel : 0u);
-                len_base = len_run + wave_sum(lv && lane < wave ? pl.sumlen : 0u);
-                seq_run += wave_sum(lv ? pl.nsel : 0u);
-                len_run += wave_sum(lv ? pl.sumlen : 0u);
-                uint32_t le_before = wave_max(lv && lane < wave ? pl.last_end : 0u);
-                lit_start_w = le_before > lit_start ? le_before : lit_start;
-                uint32_t le_all = wave_max(lv ? pl.last_end : 0u);
-                lit_start = le_all > lit_start ? le_all : lit_start;
-                next_free = t0 + c_chain;
-            } else {
-                // ---- fallback: wave 0 resolves the true entry of every wave serially (scalar code)
-                if (wave == 0) {
-                    WMeta m = wmeta[lane & (LZ_WAVES - 1)];
-                    uint32_t c = c_in;
-                    uint32_t ls = lit_start;
-                    for (uint32_t w = 0; w < LZ_WAVES; w++) {
-                        const uint32_t base = w * 128;
-                        uint32_t cw2 = c > base ? c - base : 0u;
-                        const uint64_t vis0 = rdlane64(m.vis[0], w), vis1 = rdlane64(m.vis[1], w);
-                        const uint64_t eff0 = rdlane64(m.eff[0], w), eff1 = rdlane64(m.eff[1], w);
-                        const uint64_t sel0 = rdlane64(m.sel[0], w), sel1 = rdlane64(m.sel[1], w);
-                        const uint32_t exit0 = rdlane(m.exit0, w), le0 = rdlane(m.last_end0, w);
-                        uint64_t fix0 = 0, fix1 = 0;
-                        uint32_t e = cw2, ls_in = ls;
-                        bool sy = false;
-                        while (e < 128) {
-                            const uint32_t bp = e & 63;
-                            const uint64_t visr = e < 64 ? vis0 : vis1, effr = e < 64 ? eff0 : eff1;
-                            if ((visr >> bp) & 1) { sy = true; break; }
-                            if ((effr >> bp) & 1) {
-                                const uint32_t pq = base + e;
-                                uint32_t L = uni(len_arr[pq]);
-                                const uint32_t o = uni(off_arr[pq]);
-                                const uint32_t qs = t0 + pq;
-                                if (L == CAP1) L = lz_extend(win32, qs, qs - o, ext_lim - qs, lane);
-                                if (lane == 0) fix_arr[pq] = (uint16_t)L;
-                                if (e < 64) fix0 |= (uint64_t)1 << bp; else fix1 |= (uint64_t)1 << bp;
-                                e += L; ls = t0 + base + e;
-                            } else e += 1;
-                        }
-                        if (sy) {
-                            bool later = e < 64 ? (((sel0 >> e) != 0) || sel1 != 0) : ((sel1 >> (e - 64)) != 0);
-                            if (later) ls = t0 + base + le0;
-                            c = base + exit0;
-                        } else c = base + e;
-                        if (lane == 0) {
-                            WRes rr; rr.fix[0] = fix0; rr.fix[1] = fix1; rr.carry = cw2; rr.sync = sy ? e : 128u;
-                            rr.lit_start = ls_in; rr.pad = 0;
-                            wres[w] = rr;
+                // true exit of this wave (tile-relative) under the assumption; published for the next tile's carry
+                uint32_t my_exit = cw >= 128 ? A : (synced ? wbase + cur : wbase + e);
+                // a wave that neither is covered nor re-synchronises breaks the assumption made by its successors
+                const bool bad_w = !synced && cw < 128;
+                // ---- masks of the final selection
+                uint64_t fsel[2], litm[2];
+                uint32_t nsel, nlit, nsel0, nlit0, gl;
+                bool done_fb = false;
+                uint32_t seq_base = 0, lit_base = 0, glast1_before = 1;
+                for (;;) {
+                    const uint64_t keep0 = e_sync >= 64 ? 0 : ~mlow(e_sync), keep1 = e_sync >= 128 ? 0 : (e_sync <= 64 ? ~(uint64_t)0 : ~mlow(e_sync - 64));
+                    const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;       // in-range positions of the wave
+                    fsel[0] = (sel[0] & keep0) | fix[0]; fsel[1] = (sel[1] & keep1) | fix[1];
+                    litm[0] = mlow(in0) & ~((cov[0] & keep0) | fcov[0] | mlow(cw));
+                    litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~((cov[1] & keep1) | fcov[1] | mlow(cw > 64 ? cw - 64 : 0u));
+                    nsel0 = (uint32_t)__popcll(fsel[0]); nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
+                    nlit0 = (uint32_t)__popcll(litm[0]); nlit = nlit0 + (uint32_t)__popcll(litm[1]);
+                    // local literal index of the wave's last match (+1), 0 when it has none
+                    gl = 0;
+                    if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
+                    else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl; p.bad = (bad_w && !done_fb) ? 1u : 0u; p.exit = my_exit; wpub[wave] = p; }
+                    __syncthreads();                                                // B4
+                    if (!done_fb) LZ_STAMP(4);
+                    const WPub pl = wpub[lane & (LZ_WAVES - 1)];
+                    const bool lv = lane < LZ_WAVES;
+                    const bool any_bad = __ballot(lv && pl.bad) != 0;
+                    if (done_fb || (!any_bad && !force_fb)) {
+                        // 16-lane DPP scans over the waves' records
+                        const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
+                        const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + pl.gl : 0u;      // 1 + literal index of wave j's last match
+                        const uint32_t gmax = row_scan_max(gabs);
+                        const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
+                        seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
+                        const uint32_t gb = wave ? rdlane(gmax, wave - 1) : 0u;
+                        glast1_before = gb > g_last1 ? gb : g_last1;
+                        const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
+                        g_last1 = ga > g_last1 ? ga : g_last1;
+                        seq_run += tot & 0xFFFF; lit_run += tot >> 16;
+                        next_free = t0 + rdlane(pl.exit, LZ_WAVES - 1);
+                        break;
+                    }
+                    // ---- fallback: wave 0 resolves the true entry of every wave serially (scalar code)
+                    len_arr[wbase + lane] = (uint16_t)len[0]; len_arr[wbase + 64 + lane] = (uint16_t)len[1];
+                    off_arr[wbase + lane] = (uint16_t)off[0]; off_arr[wbase + 64 + lane] = (uint16_t)off[1];
+                    __syncthreads();
+                    if (wave == 0) {
+                        const WMeta m = wmeta[lane & (LZ_WAVES - 1)];
+                        uint32_t c = c_in;
+                        for (uint32_t w = 0; w < LZ_WAVES; w++) {
+                            const uint32_t base = w * 128;
+                            const uint32_t cw2 = c > base ? c - base : 0u;
+                            const uint64_t vis0 = rdlane64(m.vis[0], w), vis1 = rdlane64(m.vis[1], w);
+                            const uint64_t eff0 = rdlane64(m.eff[0], w), eff1 = rdlane64(m.eff[1], w);
+                            const uint32_t exit0 = rdlane(m.exit0, w);
+                            uint64_t fx0 = 0, fx1 = 0, fc0 = 0, fc1 = 0;
+                            uint32_t e2 = cw2;
+                            bool sy = false;
+                            while (e2 < 128) {
+                                const uint32_t bp = e2 & 63;
+                                const uint64_t visr = e2 < 64 ? vis0 : vis1, effr = e2 < 64 ? eff0 : eff1;
+                                if ((visr >> bp) & 1) { sy = true; break; }
+                                if ((effr >> bp) & 1) {
+                                    const uint32_t pq = base + e2;
+                                    uint32_t L = uni(len_arr[pq]);
+                                    const uint32_t o = uni(off_arr[pq]);
+                                    const uint32_t qs = t0 + pq;
+                                    if (L == CAP1) L = lz_extend(win32, qs, qs - o, ext_lim - qs, lane);
+                                    if (lane == 0) fix_arr[pq] = (uint16_t)L;
+                                    if (e2 < 64) fx0 |= (uint64_t)1 << bp; else fx1 |= (uint64_t)1 << bp;
+                                    cover(fc0, fc1, e2, L);
+                                    e2 += L;
+                                } else e2 += 1;
+                            }
+                            c = sy ? base + exit0 : base + e2;
+                            if (lane == 0) {
+                                WRes rr; rr.fix[0] = fx0; rr.fix[1] = fx1; rr.fcov[0] = fc0; rr.fcov[1] = fc1;
+                                rr.carry = cw2; rr.sync = sy ? e2 : 128u; rr.exit = c; rr.pad = 0;
+                                wres[w] = rr;
+                            }
                         }
                     }
-                    if (lane == 0) { state[0] = t0 + c; state[1] = ls; }
+                    __syncthreads();
+                    {
+                        const WRes rr = wres[wave];
+                        fix[0] = rr.fix[0]; fix[1] = rr.fix[1]; fcov[0] = rr.fcov[0]; fcov[1] = rr.fcov[1];
+                        cw = rr.carry; e_sync = rr.sync;
+                        my_exit = wres[LZ_WAVES - 1].exit;                           // every wave publishes the tile exit
+                        flen[0] = ((fix[0] >> lane) & 1) ? (uint32_t)fix_arr[wbase + lane] : flen_spec[0];
+                        flen[1] = ((fix[1] >> lane) & 1) ? (uint32_t)fix_arr[wbase + 64 + lane] : flen_spec[1];
+                    }
+                    done_fb = true;
+                    LZ_STAMP(5);
                 }
-                __syncthreads();
-                const WRes rr = wres[wave];
-                next_free = state[0]; lit_start = state[1];
-                carry_w = rr.carry; sync_w = rr.sync; fixm[0] = rr.fix[0]; fixm[1] = rr.fix[1];
-                lit_start_w = rr.lit_start;
-                finalize(true);
-                nsel0 = (uint32_t)__popcll(fsel[0]); nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
-                __syncthreads();                                                    // everyone has read wpub / state
-                if (lane == 0) { WPub p; p.nsel = nsel; p.sumlen = tot_len; p.last_end = 0; p.bad = 0; wpub[wave] = p; }
-                __syncthreads();
-                pl = wpub[lane & (LZ_WAVES - 1)];
-                seq_base = seq_run + wave_sum(lv && lane < wave ? pl.nsel : 0u);
-                len_base = len_run + wave_sum(lv && lane < wave ? pl.sumlen : 0u);
-                seq_run += wave_sum(lv ? pl.nsel : 0u);
-                len_run += wave_sum(lv ? pl.sumlen : 0u);
-                LZ_STAMP(5);
-            }
 
-            // ---- emission (shuffles stay outside divergent code: an inactive source lane would read as 0)
-            uint32_t end_g0 = 0;                                    // end of the last selected match of group 0
-            if (fsel[0]) { uint32_t sp = 63 - clz64(fsel[0]); end_g0 = t0 + wbase + sp + rdlane(fl[0], sp); }
+                // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)
+                const uint32_t sp0 = fsel[0] ? 63 - clz64(fsel[0]) : 0u;
+                const uint32_t tail0 = fsel[0] ? (uint32_t)__popcll(litm[0] & ~mlow(sp0 + 1)) : 0u;   // literals of group 0 after its last match
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const uint64_t pm = fsel[r] & lane_lt;
-                const uint32_t sp = pm ? 63 - clz64(pm) : 0u;
-                const uint32_t pfl = (uint32_t)__shfl((int)fl[r], (int)sp);
-                uint32_t prev_end;
-                if (pm) prev_end = t0 + wbase + 64 * r + sp + pfl;
-                else if (r == 1 && fsel[0]) prev_end = end_g0;
-                else prev_end = lit_start_w;
-                if ((fsel[r] >> lane) & 1) {
-                    uint32_t rank = (uint32_t)__popcll(pm) + (r ? nsel0 : 0u);
-                    uint32_t idx = seq_base + rank;
-                    if (idx < SEQ_CAP) bseq[idx] = seq_pack(q[r] - prev_end, fl[r], off[r]);
+                for (int r = 0; r < 2; r++) {
+                    const uint32_t lb = (r ? nlit0 : 0u) + (uint32_t)__popcll(litm[r] & lane_lt);     // literals of the wave before this lane
+                    if ((fsel[r] >> lane) & 1) {
+                        const uint64_t pm = fsel[r] & lane_lt;
+                        uint32_t ll;
+                        if (pm) { const uint32_t sp = 63 - clz64(pm); ll = (uint32_t)__popcll(litm[r] & lane_lt & ~mlow(sp + 1)); }
+                        else if (r == 1 && fsel[0]) ll = tail0 + (uint32_t)__popcll(litm[1] & lane_lt);
+                        else ll = lit_base + lb - (glast1_before - 1);
+                        const uint32_t idx = seq_base + (uint32_t)__popcll(pm) + (r ? nsel0 : 0u);
+                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, flen[r], off[r]);
+                    }
+                    if ((litm[r] >> lane) & 1) { const uint32_t li = lit_base + lb; if (li < BLK_SIZE) blit[li] = (uint8_t)lo[r]; }
                 }
-                if (islit[r]) { uint32_t li = (q[r] - blk_start) - (len_base + pre[r]); if (li < BLK_SIZE) blit[li] = (uint8_t)lo[r]; }
             }
             LZ_STAMP(6);
         } // tiles
-        if (tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = (blk_end - blk_start) - len_run; }
+        if (tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
     } // blocks
     if (STAMP && tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
