@@ -85,6 +85,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--files", type=int, default=10000)
     ap.add_argument("--file-mib", type=float, default=1.0)
+    ap.add_argument("--algo", choices=["zstd", "deflate"], default="zstd")
+    ap.add_argument("--kind", type=int, default=0, help="corpus kind (0 enwik-style text, 1 random-text)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
     args = ap.parse_args()
@@ -108,17 +110,18 @@ def main() -> None:
     n_files, file_len = args.files, int(args.file_mib * (1 << 20))
     stride = (file_len + 15) & ~15
     src = torch.empty(n_files * stride + 8192, dtype=torch.uint8, device=dev)
-    ctx.corpus_fill_device(0, rank * n_files, n_files, file_len, stride, src.data_ptr())
+    algo = pna.ALGO_ZSTD if args.algo == "zstd" else pna.ALGO_DEFLATE
+    ctx.corpus_fill_device(args.kind, rank * n_files, n_files, file_len, stride, src.data_ptr())
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]
     src_len = [file_len] * n_files
-    dst_cap = sum(pna.bound(pna.ALGO_ZSTD, file_len) for _ in range(1)) * n_files + 4096
+    dst_cap = pna.bound(algo, file_len) * n_files + 4096
     dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
 
     shard = importlib.import_module("portable-network-archive_amd.shard")
     gather_out = [None]
 
     def step():
-        offs = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap)
+        offs = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)
         total = offs[-1]
         if world > 1:
             # ordered gather of the compressed shards into the serial stream on rank 0 (RCCL send/recv over xGMI)
@@ -163,11 +166,11 @@ def main() -> None:
         achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
         tm = ctx.timing()
         line = {
-            "metric": "archive-create MiB/s (input bytes/sec), zstd, 10k x 1MiB corpus",
+            "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}, 10k x 1MiB corpus",
             "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic enwik-style text per GPU, Compression::ZStandard "
+            "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text per GPU, Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} "
                                    f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1), inputs resident in HBM",
                        "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
             "ratio": round(in_all / max(out_all, 1), 4),
@@ -177,7 +180,7 @@ def main() -> None:
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
                                     "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.algo == "zstd":
             try:
                 sample = args.cpu_sample_files or 64 * usable_cores()
                 line["cpu_baseline"] = cpu_baseline(sample, file_len)

@@ -145,7 +145,7 @@ class ZstdParams(ctypes.Structure):
     """Mirror of pna_zstd_params (oracle/zstd_model.h)."""
     _fields_ = [("hash_log", ctypes.c_uint32), ("min_match", ctypes.c_uint32), ("tile", ctypes.c_uint32),
                 ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
-                ("flags", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
@@ -222,3 +222,27 @@ def model_lz_segment(seg: bytes, params: ZstdParams | None = None):
         ns = L.pna_lz_block(bytes(seg), len(seg), b0, bl, table, ctypes.byref(params), seqs, lits, ctypes.byref(nlit))
         out.append(([(seqs[i].ll, seqs[i].ml, seqs[i].off) for i in range(ns)], lits.raw[:nlit.value]))
     return out
+
+
+def deflate_default_params() -> ZstdParams:
+    p = ZstdParams()
+    lib().pna_deflate_default_params(ctypes.byref(p))
+    return p
+
+
+def deflate_model_compress(data: bytes, params: ZstdParams | None = None) -> bytes:
+    """The deterministic zlib/deflate encoder model (oracle/deflate_model.c)."""
+    L = lib()
+    L.pna_deflate_bound.restype = ctypes.c_size_t
+    L.pna_deflate_bound.argtypes = [ctypes.c_size_t]
+    L.pna_deflate_model_compress.restype = ctypes.c_size_t
+    L.pna_deflate_model_compress.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                             ctypes.POINTER(ZstdParams)]
+    if params is None:
+        params = deflate_default_params()
+    cap = L.pna_deflate_bound(len(data))
+    buf = ctypes.create_string_buffer(cap)
+    n = L.pna_deflate_model_compress(bytes(data), len(data), buf, cap, ctypes.byref(params))
+    if n == 0:
+        raise ValueError("deflate model compress failed")
+    return buf.raw[:n]

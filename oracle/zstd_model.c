@@ -23,7 +23,7 @@ static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; 
 
 void pna_zstd_default_params(pna_zstd_params *p) {
     p->hash_log = 14; p->min_match = 6; p->tile = 2048; p->max_off = 61440; p->cap1 = 32;
-    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP;
+    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0;
 }
 
 size_t pna_zstd_bound(size_t n) {
@@ -97,7 +97,11 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
             if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
             if (!take) { q++; continue; }
             uint32_t c = cand[q - t0] - 1;
-            if (l == p->cap1) while (q + l < ext_lim && seg[q + l] == seg[c + l]) l++;
+            if (l == p->cap1) {
+                uint32_t el = ext_lim;
+                if (p->max_len && q + p->max_len < el) el = q + p->max_len;
+                while (q + l < el && seg[q + l] == seg[c + l]) l++;
+            }
             seqs[nseq].ll = q - lit_start; seqs[nseq].ml = l; seqs[nseq].off = q - c; nseq++;
             memcpy(lits + nlit, seg + lit_start, q - lit_start); nlit += q - lit_start;
             q += l; lit_start = q; next_free = q;

@@ -31,6 +31,7 @@ typedef struct {
     uint32_t cap1;        /* per-position match length cap before cooperative extension         */
     uint32_t lookahead;   /* bytes beyond the tile end that an extension may read               */
     uint32_t flags;       /* PNA_F_*                                                            */
+    uint32_t max_len;     /* longest match (0 = only limited by the look-ahead); 258 for deflate          */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */

@@ -1,0 +1,369 @@
+// k_deflate.hip -- zlib/deflate emitter on top of the k_lz sequences (gfx950).
+//   k_dstats  one workgroup per segment: lit/len (286) + distance (30) histograms over all the segment's blocks, then
+//             thread 0: Huffman lengths (<= 15), canonical bit-reversed codes, dynamic-block table description.
+//   k_adler   one workgroup per block: Adler-32 halves of the block's input (combined per entry in k_dfinal).
+//   k_dblock  one LANE per block, the 8 blocks of a segment sharing its code tables in LDS: serial LSB-first packing
+//             of header + literals + (length, distance) pairs + EOB (+ the sync-flush header bits).
+//   k_dplan   one thread per segment: dynamic vs stored per block, sizes.
+//   k_dwrite  one workgroup per block: payload (or stored blocks) + sync flush into the packed output.
+//   k_dfinal  one thread per entry: 78 9C header, Adler-32 trailer (combine over blocks), empty entries.
+// Replaces miniz_oxide behind flate2::write::ZlibEncoder (lib/src/entry/write.rs:257-259).  Integer/bit work only.
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+__constant__ uint16_t D_LEN_BASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+__constant__ uint8_t  D_LEN_EXTRA[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+__constant__ uint8_t  D_CL_ORDER[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+constexpr uint32_t ADLER_P = 65521;
+
+__device__ __forceinline__ uint32_t dhb(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+// length 3..258 -> (code index 0..28, extra bits, extra value); distance 1..32768 -> (code 0..29, extra bits, value)
+__device__ __forceinline__ void len_sym(uint32_t l, uint32_t &c, uint32_t &eb, uint32_t &ev) {
+    const uint32_t d = l - 3;
+    if (d < 8) { c = d; eb = 0; ev = 0; }
+    else if (d == 255) { c = 28; eb = 0; ev = 0; }
+    else { eb = dhb(d) - 2; c = 4 + 4 * eb + ((d >> eb) & 3); ev = d & ((1u << eb) - 1); }
+}
+__device__ __forceinline__ void dist_sym(uint32_t dist, uint32_t &c, uint32_t &eb, uint32_t &ev) {
+    const uint32_t dd = dist - 1;
+    if (dd < 4) { c = dd; eb = 0; ev = 0; }
+    else { const uint32_t h = dhb(dd); eb = h - 1; c = 2 * h + ((dd >> eb) & 1); ev = dd & ((1u << eb) - 1); }
+}
+
+struct DBitW { uint8_t *p; uint32_t pos; uint64_t acc; uint32_t nb; };
+__device__ __forceinline__ void dw_add(DBitW &w, uint32_t v, uint32_t n) {
+    if (!n) return;
+    w.acc |= (uint64_t)(v & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u))) << w.nb; w.nb += n;
+    while (w.nb >= 8) { w.p[w.pos++] = (uint8_t)w.acc; w.acc >>= 8; w.nb -= 8; }
+}
+
+// code lengths <= maxlen (two-queue Huffman + Kraft repair; identical procedure to the zstd literal code)
+__device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint8_t *depth) {
+    int n = 0;
+    for (int s = 0; s < nsym; s++) { lens[s] = 0; if (count[s]) order[n++] = (uint16_t)s; }
+    if (n == 0) return 0;
+    if (n == 1) { lens[order[0]] = 1; return 1; }
+    for (int i = 1; i < n; i++) { uint16_t x = order[i]; int j = i - 1; while (j >= 0 && count[order[j]] > count[x]) { order[j + 1] = order[j]; j--; } order[j + 1] = x; }
+    for (int i = 0; i < n; i++) wt[i] = count[order[i]];
+    int lq = 0, iq = n, nn = n;
+    while (nn < 2 * n - 1) {
+        int a, b;
+        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
+        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
+        wt[nn] = wt[a] + wt[b]; parent[a] = (uint16_t)nn; parent[b] = (uint16_t)nn; nn++;
+    }
+    depth[nn - 1] = 0;
+    for (int i = nn - 2; i >= 0; i--) depth[i] = (uint8_t)(depth[parent[i]] + 1);
+    bool over = false;
+    for (int i = 0; i < n; i++) { int d = depth[i]; if (d > maxlen) { d = maxlen; over = true; } lens[order[i]] = (uint8_t)d; }
+    if (!over) return n;
+    int K = 0;
+    for (int i = 0; i < n; i++) K += 1 << (maxlen - lens[order[i]]);
+    int debt = K - (1 << maxlen);
+    while (debt > 0) {
+        int pick = -1, bl = 0;
+        for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < maxlen && l > bl) { bl = l; pick = i; } }
+        lens[order[pick]]++; debt -= 1 << (maxlen - 1 - bl);
+    }
+    while (debt < 0) {
+        int pick = -1, bl = 99, slack = -debt;
+        for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (maxlen - l)) <= slack && l < bl) { bl = l; pick = i; } }
+        if (pick < 0) break;
+        lens[order[pick]]--; debt += 1 << (maxlen - bl);
+    }
+    return n;
+}
+// canonical codes, bit-reversed; out[s] = code | len << 16
+__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out) {
+    int bl_count[16], next[16];
+    for (int b = 0; b < 16; b++) bl_count[b] = 0;
+    for (int s = 0; s < nsym; s++) bl_count[lens[s]]++;
+    bl_count[0] = 0;
+    int code = 0;
+    for (int b = 1; b <= 15; b++) { code = (code + bl_count[b - 1]) << 1; next[b] = code; }
+    for (int s = 0; s < nsym; s++) {
+        int l = lens[s]; out[s] = 0;
+        if (!l) continue;
+        int c = next[l]++, r = 0;
+        for (int i = 0; i < l; i++) r |= ((c >> i) & 1) << (l - 1 - i);
+        out[s] = (uint32_t)r | ((uint32_t)l << 16);
+    }
+}
+
+constexpr uint32_t DS_THREADS = 256;
+__global__ __launch_bounds__(DS_THREADS)
+void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
+              const BlkInfo *__restrict__ blk, DeflTables *__restrict__ tabs) {
+    __shared__ uint32_t h_lit[8][256];
+    __shared__ uint32_t h_len[4][32], h_dist[4][32];
+    __shared__ uint32_t llc[288], dc[32], clc[19];
+    __shared__ uint16_t order[288]; __shared__ uint32_t wt[576]; __shared__ uint16_t parent[576]; __shared__ uint8_t depth[576];
+    __shared__ uint8_t ll_len[288], d_len[32], cl_len[19], seq[320], sym[320], ext[320];
+    __shared__ uint32_t cl_code[19];
+    const uint32_t tid = threadIdx.x;
+    const SegDesc sd = segs[blockIdx.x];
+    DeflTables *T = tabs + blockIdx.x;
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    for (uint32_t i = tid; i < 8 * 256; i += DS_THREADS) (&h_lit[0][0])[i] = 0;
+    if (tid < 128) { (&h_len[0][0])[tid] = 0; (&h_dist[0][0])[tid] = 0; }
+    __syncthreads();
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t g = sd.blk_base + b;
+        const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
+        const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+        uint32_t *hl = h_lit[tid & 7];
+        const uint32_t n16 = nlit >> 4;
+        for (uint32_t i = tid; i < n16; i += DS_THREADS) {
+            uint4 v = ((const uint4 *)bl)[i];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&hl[w[k] & 0xFF], 1u); atomicAdd(&hl[(w[k] >> 8) & 0xFF], 1u);
+                atomicAdd(&hl[(w[k] >> 16) & 0xFF], 1u); atomicAdd(&hl[w[k] >> 24], 1u);
+            }
+        }
+        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += DS_THREADS) atomicAdd(&hl[bl[i]], 1u);
+        const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+        for (uint32_t i = tid; i < nseq; i += DS_THREADS) {
+            const uint64_t s = bs[i];
+            uint32_t c, eb, ev;
+            len_sym(seq_ml(s), c, eb, ev); atomicAdd(&h_len[tid & 3][c], 1u);
+            dist_sym(seq_off(s), c, eb, ev); atomicAdd(&h_dist[tid & 3][c], 1u);
+        }
+    }
+    __syncthreads();
+    { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; llc[tid] = c; }
+    if (tid < 32) {
+        llc[256 + tid] = tid == 0 ? nblk : (tid <= 29 ? h_len[0][tid - 1] + h_len[1][tid - 1] + h_len[2][tid - 1] + h_len[3][tid - 1] : 0u);
+        dc[tid] = tid < 30 ? h_dist[0][tid] + h_dist[1][tid] + h_dist[2][tid] + h_dist[3][tid] : 0u;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    d_build_lens(llc, 286, 15, ll_len, order, wt, parent, depth);
+    d_build_lens(dc, 30, 15, d_len, order, wt, parent, depth);
+    d_assign(ll_len, 286, T->ll_code);
+    d_assign(d_len, 30, T->d_code);
+    T->ll_code[286] = T->ll_code[287] = 0; T->d_code[30] = T->d_code[31] = 0;
+    int nll = 286; while (nll > 257 && ll_len[nll - 1] == 0) nll--;
+    int nd = 30; while (nd > 1 && d_len[nd - 1] == 0) nd--;
+    int n = 0, ns = 0;
+    for (int i = 0; i < nll; i++) seq[n++] = ll_len[i];
+    for (int i = 0; i < nd; i++) seq[n++] = d_len[i];
+    for (int i = 0; i < n;) {
+        if (seq[i] == 0) {
+            int z = 1; while (i + z < n && seq[i + z] == 0 && z < 138) z++;
+            if (z >= 11) { sym[ns] = 18; ext[ns++] = (uint8_t)(z - 11); i += z; continue; }
+            if (z >= 3) { sym[ns] = 17; ext[ns++] = (uint8_t)(z - 3); i += z; continue; }
+        }
+        sym[ns] = seq[i]; ext[ns++] = 0; i++;
+    }
+    for (int i = 0; i < 19; i++) clc[i] = 0;
+    for (int i = 0; i < ns; i++) clc[sym[i]]++;
+    if (d_build_lens(clc, 19, 7, cl_len, order, wt, parent, depth) == 1)
+        for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; break; }
+    d_assign(cl_len, 19, cl_code);
+    int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;
+    DBitW w; w.p = T->hdr; w.pos = 0; w.acc = 0; w.nb = 0;
+    dw_add(w, (uint32_t)(nll - 257), 5); dw_add(w, (uint32_t)(nd - 1), 5); dw_add(w, (uint32_t)(ncl - 4), 4);
+    for (int i = 0; i < ncl; i++) dw_add(w, cl_len[D_CL_ORDER[i]], 3);
+    for (int i = 0; i < ns; i++) {
+        dw_add(w, cl_code[sym[i]] & 0xFFFF, cl_code[sym[i]] >> 16);
+        if (sym[i] == 17) dw_add(w, ext[i], 3);
+        if (sym[i] == 18) dw_add(w, ext[i], 7);
+    }
+    T->hdr_bits = w.pos * 8 + w.nb;
+    if (w.nb) T->hdr[w.pos] = (uint8_t)w.acc;
+}
+
+// ------------------------------------------------------------------ Adler-32 halves of one block's input
+__global__ __launch_bounds__(256)
+void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, BlkInfo *__restrict__ blk) {
+    __shared__ unsigned long long r1[256], r2[256];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const SegDesc sd = segs[blk_seg[g]];
+    const uint32_t b0 = (g - sd.blk_base) * BLK_SIZE, n = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const uint8_t *p = src + sd.src_off + b0;
+    unsigned long long s1 = 0, s2 = 0;
+    // S1 = sum d_i ; S2 = sum (n - i) d_i   (16-byte vector loads; src offsets are 16-byte aligned)
+    for (uint32_t i = tid * 16; i < n; i += 256 * 16) {
+        if (i + 16 <= n) {
+            const uint4 v = *(const uint4 *)(p + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) { const uint32_t d = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; s1 += d; s2 += (unsigned long long)(n - i - k) * d; }
+        } else for (uint32_t k = i; k < n; k++) { const uint32_t d = p[k]; s1 += d; s2 += (unsigned long long)(n - k) * d; }
+    }
+    r1[tid] = s1; r2[tid] = s2;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; } __syncthreads(); }
+    if (tid == 0) { blk[g].adler_a = (uint32_t)((1 + r1[0]) % ADLER_P); blk[g].adler_b = (uint32_t)((n + r2[0]) % ADLER_P); }
+}
+
+// ------------------------------------------------------------------ k_dblock : one lane per block
+constexpr uint32_t DB_SEGS_PER_WG = 64 / BLK_PER_SEG;
+__global__ __launch_bounds__(64)
+void k_dblock(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
+              BlkInfo *__restrict__ blk, const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc) {
+    __shared__ uint32_t t_ll[DB_SEGS_PER_WG][288];
+    __shared__ uint32_t t_d[DB_SEGS_PER_WG][32];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg0 = blockIdx.x * DB_SEGS_PER_WG;
+    for (uint32_t s = 0; s < DB_SEGS_PER_WG && seg0 + s < nseg; s++) {
+        const DeflTables *T = tabs + seg0 + s;
+        for (uint32_t i = lane; i < 288; i += 64) t_ll[s][i] = T->ll_code[i];
+        if (lane < 32) t_d[s][lane] = T->d_code[lane];
+    }
+    __syncthreads();
+    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
+    if (sidx >= nseg) return;
+    const SegDesc sd = segs[sidx];
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    if (b >= nblk) return;
+    const uint32_t g = sd.blk_base + b;
+    const DeflTables *T = tabs + sidx;
+    const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
+    const bool last = (sd.first & 2) && (b + 1 == nblk);
+    const uint32_t *ll = t_ll[sl], *dd = t_d[sl];
+    uint32_t *out32 = (uint32_t *)(outc + (size_t)g * BLK_SIZE);
+    const uint32_t cap_words = BLK_SIZE / 4;
+    uint64_t acc = 0; uint32_t nb = 0, widx = 0;
+    auto put = [&](uint32_t v, uint32_t n) {               // n <= 24, v < 2^n
+        acc |= (uint64_t)v << nb; nb += n;
+        if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
+    };
+    put(last ? 1u : 0u, 1); put(2, 2);
+    { uint32_t hb = T->hdr_bits, i = 0; while (hb >= 8) { put(T->hdr[i++], 8); hb -= 8; } if (hb) put(T->hdr[i] & ((1u << hb) - 1), hb); }
+    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    const uint32_t *bl32 = (const uint32_t *)bl;
+    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+    uint32_t li = 0, lw = 0;
+    auto lit = [&]() {                                      // next literal byte (dword-buffered)
+        if ((li & 3) == 0) lw = bl32[li >> 2];
+        const uint32_t c = ll[(lw >> (8 * (li & 3))) & 0xFF]; li++;
+        put(c & 0xFFFF, c >> 16);
+    };
+    for (uint32_t i = 0; i < nseq; i++) {
+        const uint64_t s = bs[i];
+        const uint32_t run = seq_ll(s);
+        for (uint32_t k = 0; k < run; k++) lit();
+        uint32_t c, eb, ev;
+        len_sym(seq_ml(s), c, eb, ev);
+        const uint32_t lc = ll[257 + c]; put(lc & 0xFFFF, lc >> 16); put(ev, eb);
+        dist_sym(seq_off(s), c, eb, ev);
+        const uint32_t dcv = dd[c]; put(dcv & 0xFFFF, dcv >> 16); put(ev, eb);
+    }
+    while (li < nlit) lit();
+    { const uint32_t c = ll[256]; put(c & 0xFFFF, c >> 16); }
+    if (!last) put(0, 3);                                   // header of the empty stored block (sync flush)
+    const uint32_t bytes = widx * 4 + (nb + 7) / 8;
+    if (nb && widx < cap_words) out32[widx] = (uint32_t)acc;
+    blk[g].lit_body = bytes;
+}
+
+// ------------------------------------------------------------------ k_dplan : one thread per segment
+__global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk, uint64_t *__restrict__ seg_size) {
+    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseg) return;
+    const SegDesc sd = segs[sidx];
+    if (sd.len == 0) { seg_size[sidx] = 8; return; }        // empty entry: 78 9C 03 00 00 00 00 01
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    uint64_t off = (sd.first & 1) ? 2 : 0;                  // zlib header in front of the entry's first segment
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t g = sd.blk_base + b;
+        const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+        const bool last = (sd.first & 2) && (b + 1 == nblk);
+        const uint32_t dyn = blk[g].lit_body, stored = bl_len + 5 * ((bl_len + 65534) / 65535);
+        uint32_t sz, plan;
+        if (dyn >= stored || dyn > BLK_SIZE) { plan = 0; sz = stored + (last ? 0 : 5); }
+        else { plan = 1; sz = dyn + (last ? 0 : 4); }
+        blk[g].plan = plan; blk[g].out_size = sz; blk[g].out_off = off;
+        off += sz;
+    }
+    if (sd.first & 2) off += 4;                             // Adler-32 trailer
+    seg_size[sidx] = off;
+}
+
+// ------------------------------------------------------------------ k_dwrite : one workgroup per block
+__global__ __launch_bounds__(256)
+void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg,
+              const BlkInfo *__restrict__ blk, const uint64_t *__restrict__ seg_off, const uint8_t *__restrict__ outc,
+              uint8_t *__restrict__ dst) {
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t sidx = blk_seg[g];
+    const SegDesc sd = segs[sidx];
+    const BlkInfo bi = blk[g];
+    const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const bool last = (sd.first & 2) && (b + 1 == nblk);
+    uint8_t *out = dst + seg_off[sidx] + bi.out_off;
+    if (bi.plan & 1) {
+        const uint8_t *p = outc + (size_t)g * BLK_SIZE;
+        for (uint32_t i = tid; i < bi.lit_body; i += 256) out[i] = p[i];
+        if (!last && tid < 4) out[bi.lit_body + tid] = (tid < 2) ? 0x00 : 0xFF;
+    } else {
+        const uint8_t *p = src + sd.src_off + b0;
+        uint32_t pos = 0;
+        for (uint32_t o = 0; o < bl_len; o += 65535) {
+            const uint32_t k = bl_len - o < 65535 ? bl_len - o : 65535;
+            if (tid == 0) {
+                out[pos] = (last && o + k >= bl_len) ? 1 : 0;
+                out[pos + 1] = (uint8_t)k; out[pos + 2] = (uint8_t)(k >> 8); out[pos + 3] = (uint8_t)~k; out[pos + 4] = (uint8_t)(~k >> 8);
+            }
+            for (uint32_t i = tid; i < k; i += 256) out[pos + 5 + i] = p[o + i];
+            pos += 5 + k;
+        }
+        if (!last && tid < 5) out[pos + tid] = (tid < 3) ? 0x00 : 0xFF;
+    }
+}
+
+// ------------------------------------------------------------------ k_dfinal : one thread per entry
+__global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ entry_seg, uint32_t nentry,
+                         const BlkInfo *__restrict__ blk, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ dst) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nentry) return;
+    const uint32_t s0 = entry_seg[e], s1 = entry_seg[e + 1];
+    uint8_t *o = dst + seg_off[s0];
+    if (segs[s0].len == 0) { const uint8_t z[8] = {0x78, 0x9C, 0x03, 0x00, 0x00, 0x00, 0x00, 0x01}; for (int i = 0; i < 8; i++) o[i] = z[i]; return; }
+    o[0] = 0x78; o[1] = 0x9C;
+    // adler(X || Y): A = A_x + A_y - 1, B = B_x + B_y + len_y * (A_x - 1)   (mod 65521)
+    unsigned long long A = 1, B = 0;
+    for (uint32_t s = s0; s < s1; s++) {
+        const SegDesc sd = segs[s];
+        const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+        for (uint32_t b = 0; b < nblk; b++) {
+            const BlkInfo bi = blk[sd.blk_base + b];
+            const uint32_t n = sd.len - b * BLK_SIZE < BLK_SIZE ? sd.len - b * BLK_SIZE : BLK_SIZE;
+            B = (B + bi.adler_b + (unsigned long long)(n % ADLER_P) * ((A + ADLER_P - 1) % ADLER_P)) % ADLER_P;
+            A = (A + bi.adler_a + ADLER_P - 1) % ADLER_P;
+        }
+    }
+    uint8_t *t = dst + seg_off[s1] - 4;
+    t[0] = (uint8_t)(B >> 8); t[1] = (uint8_t)B; t[2] = (uint8_t)(A >> 8); t[3] = (uint8_t)A;
+}
+
+void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st);
+
+void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
+                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, DeflTables *tabs, uint8_t *outc,
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev) {
+    hipLaunchKernelGGL(k_dstats, dim3(nseg), dim3(DS_THREADS), 0, st, segs, seqs, lits, blk, tabs);
+    if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
+    if (ev) (void)hipEventRecord(ev[0], st);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_dblock, dim3((nseg + DB_SEGS_PER_WG - 1) / DB_SEGS_PER_WG), dim3(64), 0, st, segs, nseg, seqs, lits, blk, tabs, outc);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size);
+    k_scan_launch(seg_size, seg_off, nseg, st);
+    if (ev) (void)hipEventRecord(ev[3], st);
+}
+
+void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
+                          const uint64_t *seg_off, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
+                          uint8_t *dst, hipStream_t st) {
+    if (nblk) hipLaunchKernelGGL(k_dwrite, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk, seg_off, outc, dst);
+    hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, dst);
+}
+
+} // namespace pna

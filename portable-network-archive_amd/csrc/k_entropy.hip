@@ -630,6 +630,10 @@ __global__ void k_empty(const SegDesc *__restrict__ segs, uint32_t nseg, const u
 }
 
 // ------------------------------------------------------------------ launchers
+void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+
 void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                     const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
                     uint64_t *seg_size, uint64_t *seg_off, uint8_t *dst, uint32_t flags, hipStream_t st,

@@ -116,7 +116,7 @@ __device__ unsigned long long g_lz_stamps[8];
 template <bool STAMP>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
-          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint32_t flags) {
+          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint32_t flags, uint32_t max_off, uint32_t max_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -199,7 +199,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
                 if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r]) {
                     uint32_t c = c1 - 1; o = q[r] - c;
-                    if (o <= MAX_OFF) {
+                    if (o <= max_off) {
                         uint32_t lim = blk_end - q[r]; lim = lim < CAP1 ? lim : CAP1;
                         uint32_t clo, chi;
                         fetch8(win32, c, clo, chi);
@@ -242,7 +242,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     uint32_t L = rdlane(len[r], s);
                     if (L == CAP1) {
                         const uint32_t qs = t0 + wbase + 64 * r + s;
-                        L = lz_extend(win32, qs, qs - rdlane(off[r], s), ext_lim - qs, lane);
+                        L = lz_extend(win32, qs, qs - rdlane(off[r], s), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
                         if (lane == s) flen[r] = L;
                     }
                     sel[r] |= (uint64_t)1 << s;
@@ -295,7 +295,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     if (L == CAP1) {
                         const uint32_t o = r1 ? rdlane(off[1], b2) : rdlane(off[0], b2);
                         const uint32_t qs = t0 + wbase + e;
-                        L = lz_extend(win32, qs, qs - o, ext_lim - qs, lane);
+                        L = lz_extend(win32, qs, qs - o, (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
                         if (lane == b2) { if (r1) flen[1] = L; else flen[0] = L; }
                     }
                     if (r1) fix[1] |= (uint64_t)1 << b2; else fix[0] |= (uint64_t)1 << b2;
@@ -369,7 +369,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                                     uint32_t L = uni(len_arr[pq]);
                                     const uint32_t o = uni(off_arr[pq]);
                                     const uint32_t qs = t0 + pq;
-                                    if (L == CAP1) L = lz_extend(win32, qs, qs - o, ext_lim - qs, lane);
+                                    if (L == CAP1) L = lz_extend(win32, qs, qs - o, (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
                                     if (lane == 0) fix_arr[pq] = (uint16_t)L;
                                     if (e2 < 64) fx0 |= (uint64_t)1 << bp; else fx1 |= (uint64_t)1 << bp;
                                     cover(fc0, fc1, e2, L);
@@ -423,15 +423,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 }
 
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk,
-               uint32_t flags, hipStream_t st) {
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_lz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         (void)hipFuncSetAttribute((const void *)k_lz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         attr_set = true;
     }
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags);
-    else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags);
+    if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags, max_off, max_len);
+    else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags, max_off, max_len);
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

@@ -40,7 +40,7 @@ struct SegDesc {
     uint32_t len;         // 1 .. SEG_SIZE
     uint32_t blk_base;    // index of the segment's first block in the per-block arrays
     uint32_t entry;       // entry the segment belongs to
-    uint32_t first;       // 1 if it is the entry's first segment
+    uint32_t first;       // bit0: entry's first segment, bit1: entry's last segment
 };
 
 // per-segment entropy tables (k_stats output; 4 KiB-ish, read by k_lit / k_seq / k_pack)
@@ -67,6 +67,15 @@ struct BlkInfo {
     uint32_t plan;         // bit0 compressed block, bit1 huffman literals, bit2 carries tree, bit3 carries seq tables, bit4 rle literals
     uint32_t pad;
     uint64_t out_off;      // offset of the block header in the batch output buffer
+    uint32_t adler_a, adler_b;   // deflate: Adler-32 halves of this block's input started from adler = 1
+};
+
+// deflate: per-segment Huffman tables (k_dstats output)
+struct DeflTables {
+    uint32_t ll_code[288];   // bit-reversed code | len << 16 (literals 0..255, EOB 256, lengths 257..285)
+    uint32_t d_code[32];
+    uint32_t hdr_bits, pad[3];
+    uint8_t  hdr[400];       // HLIT HDIST HCLEN + code-length code + coded lengths, LSB-first
 };
 
 } // namespace pna

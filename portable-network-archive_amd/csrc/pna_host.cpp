@@ -15,7 +15,13 @@
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk,
-               uint32_t flags, hipStream_t st);
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st);
+void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
+                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, DeflTables *tabs, uint8_t *outc,
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev);
+void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
+                          const uint64_t *seg_off, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
+                          uint8_t *dst, hipStream_t st);
 void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                     const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
                     uint64_t *seg_size, uint64_t *seg_off, uint8_t *dst, uint32_t flags, hipStream_t st, hipEvent_t *ev);
@@ -46,7 +52,7 @@ struct pna_gpu_ctx {
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out;
+    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg;
     DevBuf c_vocab, c_cum, c_phr;
     bool corpus_ready = false;
     std::string err;
@@ -99,7 +105,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -107,6 +113,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
 
 extern "C" size_t pna_gpu_bound(int algo, size_t n) {
     if (algo == PNA_ALGO_STORE) return n;
+    if (algo == PNA_ALGO_DEFLATE) { size_t b = (n + BLK_SIZE - 1) / BLK_SIZE; if (!b) b = 1; return n + b * 23 + 16; }
     size_t segs = (n + SEG_SIZE - 1) / SEG_SIZE; if (segs == 0) segs = 1;
     size_t blks = (n + BLK_SIZE - 1) / BLK_SIZE + segs;
     return n + segs * 6 + blks * 3 + 16;
@@ -132,7 +139,7 @@ extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
 
 // ---------------------------------------------------------------------------------------------------------
 // One sub-batch: entries [e0, e1) -> segments -> kernels; output appended at d_dst + out_base.
-static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
+static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
                         hipStream_t st, bool timed) {
     std::vector<SegDesc> segs; std::vector<uint32_t> blk_seg; std::vector<uint32_t> entry_first_seg;
@@ -141,10 +148,10 @@ static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *sr
         entry_first_seg.push_back((uint32_t)segs.size());
         uint64_t len = src_len[e], off = src_off[e];
         if (off & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
-        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 1}; segs.push_back(s); continue; }
+        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3}; segs.push_back(s); continue; }
         for (uint64_t p = 0; p < len; p += SEG_SIZE) {
             uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
-            SegDesc s{off + p, sl, nblk, (uint32_t)e, p == 0 ? 1u : 0u};
+            SegDesc s{off + p, sl, nblk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u)};
             uint32_t nb = (sl + BLK_SIZE - 1) / BLK_SIZE;
             for (uint32_t b = 0; b < nb; b++) blk_seg.push_back((uint32_t)segs.size());
             nblk += nb; segs.push_back(s);
@@ -154,7 +161,8 @@ static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *sr
     const uint32_t nseg = (uint32_t)segs.size();
     if (nseg == 0) return PNA_OK;
     if (c->segs.ensure(nseg * sizeof(SegDesc)) || c->blk_seg.ensure((size_t)(nblk + 1) * 4) ||
-        c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * sizeof(SegTables)) ||
+        c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
+        c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) ||
         c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
@@ -162,10 +170,18 @@ static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *sr
     HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
     if (nblk) HIPCHK(c, hipMemcpyAsync(c->blk_seg.p, blk_seg.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(c->blk.p, 0, (size_t)(nblk + 1) * sizeof(BlkInfo), st));
+    const bool defl = algo == PNA_ALGO_DEFLATE;
+    if (defl) HIPCHK(c, hipMemcpyAsync(c->entry_seg.p, entry_first_seg.data(), entry_first_seg.size() * 4, hipMemcpyHostToDevice, st));
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
-    launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, c->flags, st);
+    if (defl) launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
+                        (c->flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
+    else launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, c->flags,
+                   MAX_OFF, 0xFFFFFFFFu, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
-    launch_entropy(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
+    if (defl) launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
+                                    (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
+                                    (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr);
+    else launch_entropy(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                    (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p,
                    (uint8_t *)c->seqc.p, (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, d_dst, c->flags, st,
                    timed ? &c->ev[2] : nullptr);
@@ -176,7 +192,10 @@ static int run_subbatch(pna_gpu_ctx *c, const uint8_t *d_src, const uint64_t *sr
     HIPCHK(c, hipStreamSynchronize(st));
     const uint64_t total = seg_off[nseg];
     if (out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
-    launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
+    if (defl) launch_deflate_write(d_src, (const SegDesc *)c->segs.p, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
+                                   (const uint64_t *)c->seg_off.p, (const uint8_t *)c->litc.p, (const uint32_t *)c->entry_seg.p,
+                                   (uint32_t)(e1 - e0), d_dst + out_base, st);
+    else launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, (const uint64_t *)c->seg_off.p, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst + out_base, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -204,7 +223,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
                                              const uint64_t *src_off, const uint64_t *src_len, void *d_dst, size_t dst_cap,
                                              uint64_t *dst_off, void *hip_stream) {
     if (!c || !src_off || !src_len || !dst_off || (!d_src && n) || (!d_dst && n)) return fail(c, PNA_E_INVAL, "null argument");
-    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented on the device path");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     (void)level;                                     // one parameter set (hash_log 14, min_match 6, greedy+lazy1)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -219,7 +238,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
             if (e1 > e && blocks + nb > c->max_blocks) break;
             blocks += nb; in_total += src_len[e1]; e1++;
         }
-        int rc = run_subbatch(c, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap, out_base, dst_off, st, true);
+        int rc = run_subbatch(c, algo, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap, out_base, dst_off, st, true);
         if (rc) return rc;
         out_base = dst_off[e1];
         e = e1;
@@ -232,7 +251,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
 extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_t n, const void *const *src,
                                       const size_t *src_len, void *const *dst, const size_t *dst_cap, size_t *dst_len) {
     if (!c || (n && (!src || !src_len || !dst || !dst_cap || !dst_len))) return fail(c, PNA_E_INVAL, "null argument");
-    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> off(n + 1), len(n), doff(n + 1);
     uint64_t pos = 0, bound = 0;
@@ -261,7 +280,7 @@ struct pna_gpu_stream {
 
 extern "C" int pna_gpu_stream_new(pna_gpu_ctx *c, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out) {
     if (!c || !sink || !out) return PNA_E_INVAL;
-    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only PNA_ALGO_ZSTD is implemented");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented");
     *out = new pna_gpu_stream{c, algo, level, sink, user, {}};
     return PNA_OK;
 }

@@ -53,6 +53,23 @@ def main(extra_flags=0):
         print(f"{k:10s} in {len(d):8d} gpu {len(o):8d} model {len(exp):8d} decode {'OK' if dec_ok else 'FAIL'} bitexact {'OK' if same else 'DIFF@%d' % first_diff(o, exp)}")
         if not (same and dec_ok):
             bad += 1
+    # 2b. deflate parity (zlib streams): bit-exact vs the model, inflate with stdlib zlib
+    import zlib
+    outs = ctx.compress_batch([cases[k] for k in names], algo=pna.ALGO_DEFLATE)
+    tm = ctx.timing()
+    print("deflate timing ms: lz %.3f stats %.3f lit %.3f seq %.3f pack %.3f" % (tm.ms_lz, tm.ms_stats, tm.ms_lit, tm.ms_seq, tm.ms_pack))
+    for k, o in zip(names, outs):
+        d = cases[k]
+        exp = codec.deflate_model_compress(d)
+        try:
+            dec_ok = zlib.decompress(o) == d
+        except Exception as e:
+            dec_ok = False
+        same = o == exp
+        if not (same and dec_ok):
+            bad += 1
+            print(f"DEFLATE {k:10s} in {len(d):8d} gpu {len(o):8d} model {len(exp):8d} inflate {'OK' if dec_ok else 'FAIL'} bitexact {'OK' if same else 'DIFF@%d' % first_diff(o, exp)}")
+    print("deflate cases done")
     # 3. LZ stage detail for a single-entry batch when something is off
     if bad:
         for k in names:

@@ -197,3 +197,44 @@ def test_full_size_properties_10k_x_1mib(gpu_ctx, pna, codec):
     for i in (0, 4999, 9999):
         assert host[offs[i]:offs[i + 1]] == codec.model_compress(codec.corpus_file(0, i, L), p), i
     assert 2.3 < n * L / offs[-1] < 3.2
+
+
+def test_deflate_bit_exact_and_inflatable(gpu_ctx, pna, codec):
+    """Compression::Deflate on the device: zlib streams equal to the model, inflate with stdlib zlib."""
+    cases = _cases(codec)
+    names = sorted(cases)
+    outs = gpu_ctx.compress_batch([cases[k] for k in names], algo=pna.ALGO_DEFLATE)
+    for k, o in zip(names, outs):
+        d = cases[k]
+        assert zlib.decompress(o) == d, k
+        assert o == codec.deflate_model_compress(d), k
+        assert len(o) <= pna.bound(pna.ALGO_DEFLATE, len(d)), k
+    assert outs[names.index("empty")] == bytes.fromhex("789C030000000001")
+
+
+def test_deflate_config0_archive(gpu_ctx, pna, pf, codec):
+    """BASELINE.json configs[0]: 100 x 64 KiB random-text files, Compression::Deflate -> archive -> read back."""
+    names = [f"corpus/f{i:05d}.txt" for i in range(100)]
+    ents = [codec.corpus_file(1, i, 65536) for i in range(100)]
+    for solid in (False, True):
+        arc = pna.create_archive(gpu_ctx, names, ents, algo=pna.ALGO_DEFLATE, solid=solid)
+        _, items = pf.read_archive(arc)
+        if solid:
+            inner = pf.read_solid_inner(codec.decode_payload(1, items[0].data, 16 << 20))
+            assert [(e.name, e.data) for e in inner] == list(zip(names, ents))
+        else:
+            assert [it.name for it in items] == names and all(it.compression == 1 for it in items)
+            assert all(codec.decode_payload(1, it.data, 1 << 20) == e for it, e in zip(items, ents))
+            ratio = sum(map(len, ents)) / sum(len(it.data) for it in items)
+            assert ratio > 2.0
+
+
+def test_deflate_many_small_entries(gpu_ctx, pna, codec):
+    """BASELINE.json configs[4] shape at reduced count: 4 KiB entries (one block, one segment each)."""
+    n = 2000
+    ents = [codec.corpus_file(1, 100 + i, 4096) for i in range(n)]
+    outs = gpu_ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
+    for i in range(0, n, 37):
+        assert zlib.decompress(outs[i]) == ents[i]
+        assert outs[i] == codec.deflate_model_compress(ents[i])
+    assert all(zlib.decompress(o) == e for o, e in zip(outs[:200], ents[:200]))

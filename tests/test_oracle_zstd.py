@@ -96,3 +96,24 @@ def test_model_frames_and_ratio(codec):
     assert codec.zstd_frame_count(c, len(d)) == 3               # one frame per 1 MiB segment
     assert c[:6] == bytes.fromhex("28B52FFD0050")               # FHD 0x00, window descriptor 0x50 (1 MiB)
     assert len(d) / len(c) > 2.3                                # enwik-style corpus; libzstd-3 gets ~2.83
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_deflate_model_inflates_with_zlib(codec, name):
+    """The zlib/deflate encoder model against an independent RFC 1950/1951 decoder (stdlib zlib)."""
+    import zlib
+    d = MODEL_CASES[name](codec)
+    c = codec.deflate_model_compress(d)
+    assert c[:2] == b"\x78\x9c"
+    assert codec.zlib_decompress(c) == d
+    assert len(c) <= len(d) + 23 * (len(d) // (1 << 17) + 1) + 16
+    assert c == codec.deflate_model_compress(d)
+    if name == "empty":
+        assert c == bytes.fromhex("789C030000000001")          # the reference's empty zlib stream (tests/golden/deflate.pna)
+    assert c[-4:] == zlib.adler32(d).to_bytes(4, "big")
+
+
+def test_deflate_model_ratio(codec):
+    import zlib
+    d = codec.corpus_file(1, 3, 65536)                          # BASELINE.json configs[0] shape: 64 KiB random-text
+    assert len(codec.deflate_model_compress(d)) < 1.05 * len(zlib.compress(d, 6))
