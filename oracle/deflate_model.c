@@ -205,7 +205,7 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
             if (!last) dw_add(&w, 0, 3);                   /* header of the empty stored block (sync flush), then align */
             size_t dyn = dw_align(&w);
             size_t stored = (size_t)bl_len + 5 * (((size_t)bl_len + 65534) / 65535);
-            if (dyn >= stored) {
+            if (dyn >= stored || dyn > PNA_BLK_SIZE) {       /* second clause: the device's per-block scratch is one block */
                 for (uint32_t o = 0; o < bl_len; o += 65535) {
                     uint32_t k = bl_len - o < 65535 ? bl_len - o : 65535;
                     dst[op++] = (uint8_t)((last && o + k >= bl_len) ? 1 : 0);

@@ -201,65 +201,113 @@ void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     if (tid == 0) { blk[g].adler_a = (uint32_t)((1 + r1[0]) % ADLER_P); blk[g].adler_b = (uint32_t)((n + r2[0]) % ADLER_P); }
 }
 
-// ------------------------------------------------------------------ k_dblock : one lane per block
-constexpr uint32_t DB_SEGS_PER_WG = 64 / BLK_PER_SEG;
+// ------------------------------------------------------------------ k_dblock : one WAVE per block, one lane per tile
+// k_lz's chunk table gives, for each 2 KiB tile of the block, the sequence / literal stream positions at the tile start
+// and the literal index of the tile's first match, so lane t can encode the elements that belong to tile t on its own:
+// pass 1 counts its bits, a wave scan places the pieces, pass 2 ORs them into the zeroed output at their bit offsets.
 __global__ __launch_bounds__(64)
-void k_dblock(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
-              BlkInfo *__restrict__ blk, const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc) {
-    __shared__ uint32_t t_ll[DB_SEGS_PER_WG][288];
-    __shared__ uint32_t t_d[DB_SEGS_PER_WG][32];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t seg0 = blockIdx.x * DB_SEGS_PER_WG;
-    for (uint32_t s = 0; s < DB_SEGS_PER_WG && seg0 + s < nseg; s++) {
-        const DeflTables *T = tabs + seg0 + s;
-        for (uint32_t i = lane; i < 288; i += 64) t_ll[s][i] = T->ll_code[i];
-        if (lane < 32) t_d[s][lane] = T->d_code[lane];
-    }
-    __syncthreads();
-    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
-    if (sidx >= nseg) return;
+void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs,
+              const uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, const uint4 *__restrict__ ctab,
+              const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc, uint32_t dbg) {
+    __shared__ uint32_t t_ll[288];
+    __shared__ uint32_t t_d[32];
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t sidx = blk_seg[g];
     const SegDesc sd = segs[sidx];
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
-    if (b >= nblk) return;
-    const uint32_t g = sd.blk_base + b;
     const DeflTables *T = tabs + sidx;
-    const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
+    for (uint32_t i = lane; i < 288; i += 64) t_ll[i] = T->ll_code[i];
+    if (lane < 32) t_d[lane] = T->d_code[lane];
+    __syncthreads();
+    const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t bl_len = sd.len - b * BLK_SIZE < BLK_SIZE ? sd.len - b * BLK_SIZE : BLK_SIZE;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
-    const uint32_t *ll = t_ll[sl], *dd = t_d[sl];
-    uint32_t *out32 = (uint32_t *)(outc + (size_t)g * BLK_SIZE);
-    const uint32_t cap_words = BLK_SIZE / 4;
-    uint64_t acc = 0; uint32_t nb = 0, widx = 0;
-    auto put = [&](uint32_t v, uint32_t n) {               // n <= 24, v < 2^n
-        acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
-    };
-    put(last ? 1u : 0u, 1); put(2, 2);
-    { uint32_t hb = T->hdr_bits, i = 0; while (hb >= 8) { put(T->hdr[i++], 8); hb -= 8; } if (hb) put(T->hdr[i] & ((1u << hb) - 1), hb); }
+    const uint32_t ntile = (bl_len + TILE - 1) / TILE;
+    const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
+    const bool act = lane < ntile;
+    uint32_t s0 = 0, s1 = 0, l0 = 0, l1 = 0, gf = 0;
+    if (act) {
+        const uint4 c = ctab[(size_t)g * (BLK_SIZE / TILE) + lane];
+        s0 = c.x; l0 = c.y; gf = c.z;
+        if (lane + 1 < ntile) { const uint4 cn = ctab[(size_t)g * (BLK_SIZE / TILE) + lane + 1]; s1 = cn.x; l1 = cn.y; }
+        else { s1 = nseq; l1 = nlit; }
+        if (s0 == s1) gf = l1;
+    }
     const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
     const uint32_t *bl32 = (const uint32_t *)bl;
     const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    uint32_t li = 0, lw = 0;
-    auto lit = [&]() {                                      // next literal byte (dword-buffered)
-        if ((li & 3) == 0) lw = bl32[li >> 2];
-        const uint32_t c = ll[(lw >> (8 * (li & 3))) & 0xFF]; li++;
-        put(c & 0xFFFF, c >> 16);
+    uint32_t *out32 = (uint32_t *)(outc + (size_t)g * BLK_SIZE);
+    const uint32_t hdr_total = 3 + T->hdr_bits;
+    const uint32_t eob = t_ll[256];
+
+    // walk of this lane's elements; EMIT = false only counts bits
+    uint64_t acc = 0; uint32_t nb = 0, widx = 0, bits = 0;
+    auto run = [&](bool emit) {
+        uint32_t sblk = 0;
+        auto put = [&](uint32_t v, uint32_t n) {
+            if (!emit) { bits += n; return; }
+            acc |= (uint64_t)v << nb; nb += n;
+            if (nb >= 32) { if (dbg & 0x800) out32[widx++] = (uint32_t)acc; else atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+        };
+        if (lane == 0) {
+            put(last ? 1u : 0u, 1); put(2, 2);
+            uint32_t hb = T->hdr_bits, i = 0;
+            while (hb >= 8) { put(T->hdr[i++], 8); hb -= 8; }
+            if (hb) put(T->hdr[i] & ((1u << hb) - 1), hb);
+        }
+        // literal and sequence streams are read through 16-byte double buffers: the next block is requested one block
+        // ahead, so a lane waits for memory once per 16 literals / 2 sequences instead of once per element
+        const uint4 *bl16 = (const uint4 *)bl;
+        const uint4 *bs16 = (const uint4 *)bs;
+        uint32_t li = l0;
+        uint4 lcur = make_uint4(0, 0, 0, 0), lnxt = lcur, scur = lcur, snxt = lcur;
+        if (act) { lcur = bl16[li >> 4]; lnxt = bl16[(li >> 4) + 1]; scur = bs16[s0 >> 1]; snxt = bs16[(s0 >> 1) + 1]; }
+        auto lit_run = [&](uint32_t end) {
+            while (li < end) {
+                const uint32_t q4 = (li >> 2) & 3;
+                const uint32_t w = q4 == 0 ? lcur.x : (q4 == 1 ? lcur.y : (q4 == 2 ? lcur.z : lcur.w));
+                const uint32_t c = t_ll[(w >> (8 * (li & 3))) & 0xFF]; li++;
+                if ((li & 15) == 0) { lcur = lnxt; lnxt = bl16[(li >> 4) + 1]; }
+                put(c & 0xFFFF, c >> 16);
+            }
+        };
+        auto seq_at = [&](uint32_t k) -> uint64_t {          // k is the stream position: only k and k+1 are ever asked for
+            const bool hi = (k >> 1) != (s0 >> 1) + sblk;
+            const uint4 v = hi ? snxt : scur;
+            return (k & 1) ? ((uint64_t)v.z | ((uint64_t)v.w << 32)) : ((uint64_t)v.x | ((uint64_t)v.y << 32));
+        };
+        if (act) {
+            lit_run(gf);
+            for (uint32_t k = s0; k < s1; k++) {
+                if ((k >> 1) != (s0 >> 1) + sblk) { sblk++; scur = snxt; snxt = bs16[(s0 >> 1) + sblk + 1]; }
+                const uint64_t s = seq_at(k);
+                uint32_t c, eb, ev;
+                len_sym(seq_ml(s), c, eb, ev);
+                const uint32_t lc = t_ll[257 + c]; put(lc & 0xFFFF, lc >> 16); put(ev, eb);
+                dist_sym(seq_off(s), c, eb, ev);
+                const uint32_t dcv = t_d[c]; put(dcv & 0xFFFF, dcv >> 16); put(ev, eb);
+                if (k + 1 < s1) lit_run(li + seq_ll(seq_at(k + 1)));
+            }
+            lit_run(l1);
+            if (lane + 1 == ntile) { put(eob & 0xFFFF, eob >> 16); if (!last) put(0, 3); }
+        }
     };
-    for (uint32_t i = 0; i < nseq; i++) {
-        const uint64_t s = bs[i];
-        const uint32_t run = seq_ll(s);
-        for (uint32_t k = 0; k < run; k++) lit();
-        uint32_t c, eb, ev;
-        len_sym(seq_ml(s), c, eb, ev);
-        const uint32_t lc = ll[257 + c]; put(lc & 0xFFFF, lc >> 16); put(ev, eb);
-        dist_sym(seq_off(s), c, eb, ev);
-        const uint32_t dcv = dd[c]; put(dcv & 0xFFFF, dcv >> 16); put(ev, eb);
-    }
-    while (li < nlit) lit();
-    { const uint32_t c = ll[256]; put(c & 0xFFFF, c >> 16); }
-    if (!last) put(0, 3);                                   // header of the empty stored block (sync flush)
-    const uint32_t bytes = widx * 4 + (nb + 7) / 8;
-    if (nb && widx < cap_words) out32[widx] = (uint32_t)acc;
-    blk[g].lit_body = bytes;
+    run(false);
+    // inclusive scan of the pieces' bit counts over the wave
+    uint32_t sc = bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
+    const uint32_t total_bits = (uint32_t)__shfl((int)sc, 63);
+    const uint32_t bytes = (total_bits + 7) / 8;
+    if (lane == 0) blk[g].lit_body = bytes;
+    (void)hdr_total;
+    if (bytes > BLK_SIZE) return;                                   // k_dplan falls back to stored blocks
+    for (uint32_t i = lane; i < (bytes + 3) / 4; i += 64) out32[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0);                                  // zeros are in L2 before the atomic ORs are issued
+    __syncthreads();
+    const uint32_t start = sc - bits;
+    widx = start >> 5; nb = start & 31; acc = 0;
+    if (!(dbg & 0x400)) run(true);
+    if (nb) atomicOr(&out32[widx], (uint32_t)acc);
 }
 
 // ------------------------------------------------------------------ k_dplan : one thread per segment
@@ -276,7 +324,7 @@ __global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo
         const bool last = (sd.first & 2) && (b + 1 == nblk);
         const uint32_t dyn = blk[g].lit_body, stored = bl_len + 5 * ((bl_len + 65534) / 65535);
         uint32_t sz, plan;
-        if (dyn >= stored || dyn > BLK_SIZE) { plan = 0; sz = stored + (last ? 0 : 5); }
+        if (dyn >= stored || dyn > BLK_SIZE) { plan = 0; sz = stored + (last ? 0 : 5); }   // same rule in the model
         else { plan = 1; sz = dyn + (last ? 0 : 4); }
         blk[g].plan = plan; blk[g].out_size = sz; blk[g].out_off = off;
         off += sz;
@@ -346,13 +394,13 @@ __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__res
 void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st);
 
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
-                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev) {
+                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg) {
     hipLaunchKernelGGL(k_dstats, dim3(nseg), dim3(DS_THREADS), 0, st, segs, seqs, lits, blk, tabs);
     if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_dblock, dim3((nseg + DB_SEGS_PER_WG - 1) / DB_SEGS_PER_WG), dim3(64), 0, st, segs, nseg, seqs, lits, blk, tabs, outc);
+    if (nblk) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(64), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size);
     k_scan_launch(seg_size, seg_off, nseg, st);

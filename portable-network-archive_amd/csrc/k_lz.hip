@@ -10,7 +10,7 @@
 //   len/off/fixlen [2048 x u16 each]  written and read by the serial fallback only
 //   per-wave records
 // Per tile of 2048 positions (2 per lane):
-//   window chunk (register-prefetched during the previous tile) -> B1 -> lookup -> B2 -> insert + match +
+//   (next window chunk requested into registers) lookup -> B2 -> insert + match +
 //   per-wave SPECULATIVE parse (as if the parse entered the wave at its first position; scalar loops that also
 //   build the coverage bit masks) -> B3 -> every wave resolves its TRUE entry in parallel (carry chained through
 //   the speculative exits of the earlier, not fully covered waves) and walks from there until it lands on a
@@ -41,7 +41,7 @@ constexpr uint32_t L_TOTAL  = L_STATE + 16;
 
 struct WMeta { uint64_t sel[2]; uint64_t vis[2]; uint64_t eff[2]; uint32_t exit0; uint32_t pad[3]; };
 struct WRes  { uint64_t fix[2]; uint64_t fcov[2]; uint32_t carry; uint32_t sync; uint32_t exit; uint32_t pad; };
-struct WPub  { uint32_t cnt; uint32_t gl; uint32_t bad; uint32_t exit; };   // cnt = nsel | nlit << 16; gl = local literal index of the last match + 1 (0 = no match)
+struct WPub  { uint32_t cnt; uint32_t gl; uint32_t bad; uint32_t exit; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
 static_assert(sizeof(WMeta) == 64 && sizeof(WRes) == 48 && sizeof(WPub) == 16, "LDS record sizes");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_FALLBACK = 0x200u;
@@ -116,7 +116,7 @@ __device__ unsigned long long g_lz_stamps[8];
 template <bool STAMP>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
-          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint32_t flags, uint32_t max_off, uint32_t max_len) {
+          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -141,12 +141,14 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && tid == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
 
-    // initial window fill [0, TILE + LOOKAHEAD + 16); afterwards one TILE-sized chunk per tile, prefetched in registers
+    // initial window fill [0, TILE + LOOKAHEAD + 16); afterwards one TILE-sized chunk per tile: requested at the top of
+    // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
+    // positions below t0 - 60400 < t0 - MAX_OFF, which no match of tile t can reference.
     uint32_t loaded_end = TILE + LOOKAHEAD + 16;
     for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16)
         *(uint4 *)(lds + L_WIN + i) = load_chunk(seg, i, seg_len);
+    __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
-    bool have_pf = false;
 
     const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
     for (uint32_t b = 0; b < nblk; b++) {
@@ -164,12 +166,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             const uint32_t t1 = (blk_end - t0 < TILE) ? blk_end : t0 + TILE;
             const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
 
-            // ---- window: store the chunk prefetched during the previous tile, then prefetch the next one.
-            // Invariant at B1: window holds [t0 + TILE + LOOKAHEAD + 16 - 65536, t0 + TILE + LOOKAHEAD + 16).
-            if (have_pf && tid < TILE / 16) *(uint4 *)(lds + L_WIN + ((loaded_end - TILE + tid * 16) & (WIN_BYTES - 1))) = pf;
-            __syncthreads();                                                        // B1
+            // ---- request the next tile's window chunk (consumed before B3)
             if (tid < TILE / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
-            loaded_end += TILE; have_pf = true;
             LZ_STAMP(0);
 
             // ---- lookup
@@ -260,6 +258,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // positions past the tile end count as stood on so a walk stops there)
             const uint64_t vis[2] = {~cov[0] | sel[0], ~cov[1] | sel[1]};
             const uint32_t flen_spec[2] = {flen[0], flen[1]};
+            if (tid < TILE / 16) *(uint4 *)(lds + L_WIN + ((loaded_end + tid * 16) & (WIN_BYTES - 1))) = pf;
+            loaded_end += TILE;
             if (lane == 0) {
                 WMeta m;
                 m.sel[0] = sel[0]; m.sel[1] = sel[1]; m.vis[0] = vis[0]; m.vis[1] = vis[1];
@@ -323,7 +323,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     gl = 0;
                     if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
                     else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl; p.bad = (bad_w && !done_fb) ? 1u : 0u; p.exit = my_exit; wpub[wave] = p; }
+                    uint32_t gf = 0;                                                // same for the wave's first match
+                    if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+                    else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
+                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); p.bad = (bad_w && !done_fb) ? 1u : 0u; p.exit = my_exit; wpub[wave] = p; }
                     __syncthreads();                                                // B4
                     if (!done_fb) LZ_STAMP(4);
                     const WPub pl = wpub[lane & (LZ_WAVES - 1)];
@@ -332,7 +335,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     if (done_fb || (!any_bad && !force_fb)) {
                         // 16-lane DPP scans over the waves' records
                         const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
-                        const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + pl.gl : 0u;      // 1 + literal index of wave j's last match
+                        const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + (pl.gl & 0xFFFF) : 0u;   // 1 + literal index of wave j's last match
                         const uint32_t gmax = row_scan_max(gabs);
                         const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
                         seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
@@ -340,6 +343,14 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         glast1_before = gb > g_last1 ? gb : g_last1;
                         const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
                         g_last1 = ga > g_last1 ? ga : g_last1;
+                        if (ctab) {
+                            // chunk table: state of the block's sequence / literal streams at this tile's start and the
+                            // literal index of the tile's first match (lets later stages split a block by tiles)
+                            const uint64_t hm = __ballot(lv && pl.gl);
+                            uint32_t g_first = lit_run + (tot >> 16);
+                            if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
+                            if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
+                        }
                         seq_run += tot & 0xFFFF; lit_run += tot >> 16;
                         next_free = t0 + rdlane(pl.exit, LZ_WAVES - 1);
                         break;
@@ -422,7 +433,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk,
+void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -430,8 +441,8 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
         (void)hipFuncSetAttribute((const void *)k_lz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         attr_set = true;
     }
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags, max_off, max_len);
-    else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, flags, max_off, max_len);
+    if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

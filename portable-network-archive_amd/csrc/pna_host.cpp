@@ -14,11 +14,11 @@
 #include "../../include/pna_gpu.h"
 
 namespace pna {
-void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk,
+void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st);
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
-                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev);
+                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
                           uint8_t *dst, hipStream_t st);
@@ -52,7 +52,7 @@ struct pna_gpu_ctx {
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg;
+    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     bool corpus_ready = false;
     std::string err;
@@ -93,7 +93,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->device = device_id;
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
-    if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0x300u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
+    if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0xF00u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     *out = c;
@@ -105,7 +105,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -162,7 +162,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (nseg == 0) return PNA_OK;
     if (c->segs.ensure(nseg * sizeof(SegDesc)) || c->blk_seg.ensure((size_t)(nblk + 1) * 4) ||
         c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
-        c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) ||
+        c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) || (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
         c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
@@ -174,13 +174,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (defl) HIPCHK(c, hipMemcpyAsync(c->entry_seg.p, entry_first_seg.data(), entry_first_seg.size() * 4, hipMemcpyHostToDevice, st));
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (defl) launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
-                        (c->flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
-    else launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, c->flags,
+                        (uint4 *)c->ctab.p, (c->flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
+    else launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->flags,
                    MAX_OFF, 0xFFFFFFFFu, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (defl) launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
-                                    (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
-                                    (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr);
+                                    (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
+                                    (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->flags);
     else launch_entropy(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                    (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p,
                    (uint8_t *)c->seqc.p, (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, d_dst, c->flags, st,
