@@ -91,12 +91,17 @@ __device__ uint32_t fse_write_ncount(uint8_t *dst, const int16_t *norm, int nsym
 }
 
 // encoder table from normalised counts; `cell` is scratch of 1 << tlog bytes
-__device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int tlog, uint8_t *cell) {
+__device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int tlog, uint8_t *cell, uint16_t *tmp192) {
     int size = 1 << tlog, high = size - 1;
     for (int s = 0; s < nsym; s++) if (norm[s] == -1) cell[high--] = (uint8_t)s;
     int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
     for (int s = 0; s < nsym; s++)
         for (int i = 0; i < norm[s]; i++) { cell[pos] = (uint8_t)s; do { pos = (pos + step) & mask; } while (pos > high); }
+    // one pass over the cells in ascending order fills state[cum[s] .. cum[s]+n_s)
+    uint16_t *fill = tmp192, *first = tmp192 + 64;
+    // first cell (lowest index) of every symbol
+    for (int s = 0; s < nsym; s++) first[s] = 0xFFFF;
+    for (int u = size - 1; u >= 0; u--) first[cell[u]] = (uint16_t)(size + u);
     int cum = 0;
     for (int s = 0; s < nsym; s++) {
         int n = norm[s] == -1 ? 1 : norm[s];
@@ -105,13 +110,13 @@ __device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int 
             int maxbits = (n == 1) ? tlog : tlog - (int)hb((uint32_t)(n - 1));
             y.delta_nb = (uint32_t)((maxbits << 16) - (n << maxbits));
             y.delta_find = (int16_t)(cum - n);
+            y.first_state = first[s];
         }
         t->sym[s] = y;
-        // cells of symbol s in ascending cell order -> state[cum .. cum+n)
-        int k = cum;
-        for (int u = 0; u < size && k < cum + n; u++) if (cell[u] == s) { if (k == cum) t->sym[s].first_state = (uint16_t)(size + u); t->state[k++] = (uint16_t)(size + u); }
+        fill[s] = (uint16_t)cum;
         cum += n;
     }
+    for (int u = 0; u < size; u++) { const int s = cell[u]; t->state[fill[s]++] = (uint16_t)(size + u); }
 }
 
 // ------------------------------------------------------------------ k_stats
@@ -159,7 +164,7 @@ __device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *or
 
 // Huffman tree description (direct 4-bit weights or FSE-compressed weights); returns bytes (0 = not representable)
 __device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sym, int maxbits, uint8_t *wts, uint8_t *tmp,
-                                   SeqTable *scratch_tab, uint8_t *cell) {
+                                   SeqTable *scratch_tab, uint8_t *cell, uint16_t *tmp192) {
     int nw = max_sym;
     for (int s = 0; s < nw; s++) wts[s] = lens[s] ? (uint8_t)(maxbits + 1 - lens[s]) : 0;
     uint32_t fse_size = 0;
@@ -176,7 +181,7 @@ __device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sy
             int16_t norm[16];
             fse_normalize(cnt, maxw + 1, (uint32_t)nw, tlog, norm);
             uint32_t hs = fse_write_ncount(tmp + 1, norm, maxw + 1, tlog);
-            fse_build_table(scratch_tab, norm, maxw + 1, tlog, cell);
+            fse_build_table(scratch_tab, norm, maxw + 1, tlog, cell, tmp192);
             BitW w; bw_init(w, tmp + 1 + hs);
             int i = nw; uint32_t s1, s2;
             auto enc = [&](uint32_t st, int sy) -> uint32_t {
@@ -203,7 +208,7 @@ __device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sy
 
 // one of LL / OF / ML: mode + description + encoder table; returns false when no valid table exists
 __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32_t nseq, int alphabet,
-                          const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *cell) {
+                          const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *cell, uint16_t *tmp192) {
     int maxs = 0, distinct = 0;
     for (int s = 0; s < alphabet; s++) if (count[s]) { maxs = s; distinct++; }
     T->desc_len[which] = 0;
@@ -211,7 +216,7 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
     bool def_ok = maxs < def_n;
     if (!(flags & F_FSE) || (nseq < 64 && def_ok)) {
         if (!def_ok) return false;
-        fse_build_table(&T->tab[which], def, def_n, def_log, cell); T->tlog[which] = (uint32_t)def_log; T->mode[which] = 0; return true;
+        fse_build_table(&T->tab[which], def, def_n, def_log, cell, tmp192); T->tlog[which] = (uint32_t)def_log; T->mode[which] = 0; return true;
     }
     int tlog = (int)hb(nseq - 1) - 2, minlog = 5;
     while ((1 << minlog) < distinct) minlog++;
@@ -220,7 +225,7 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
     int16_t norm[64];
     fse_normalize(count, maxs + 1, nseq, tlog, norm);
     T->desc_len[which] = fse_write_ncount(T->desc[which], norm, maxs + 1, tlog);
-    fse_build_table(&T->tab[which], norm, maxs + 1, tlog, cell);
+    fse_build_table(&T->tab[which], norm, maxs + 1, tlog, cell, tmp192);
     T->tlog[which] = (uint32_t)tlog; T->mode[which] = 2;
     return true;
 }
@@ -297,15 +302,15 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
                 int l = maxbits + 1 - w;
                 for (int s = 0; s <= max_sym; s++) if (lens[s] == l) { T->huf_code[s] = (pos >> (w - 1)) | ((uint32_t)l << 16); pos += 1u << (w - 1); }
             }
-            uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell);
+            uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell, order);
             T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0;
         }
     }
     if (nseq_seg) {
         bool ok = true;
-        ok &= seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell);
-        ok &= seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell);
-        ok &= seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell);
+        ok &= seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell, order);
+        ok &= seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell, order);
+        ok &= seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell, order);
         T->seq_ok = ok ? 1u : 0u;
     }
 }
@@ -342,13 +347,20 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     if (wave < nstreams) m = (nstreams == 4 && wave == 3) ? nlit - 3 * segsz : segsz;
     const uint32_t chunk = (m + 63) / 64;
     uint32_t c0 = a + lane * chunk, c1 = c0 + chunk; if (c1 > a + m) c1 = a + m; if (c0 > c1) c0 = c1;
-    // aligned dword loads over the lane's chunk; bytes outside [c0, c1) are skipped
-    const uint32_t *bl32 = (const uint32_t *)bl;
+    // the lane's chunk is read in aligned 16-byte granules, two granules ahead of the one being processed, so the
+    // HBM/L2 latency of these lane-private streams overlaps the table lookups; bytes outside [c0, c1) are skipped
+    const uint4 *bl16 = (const uint4 *)bl;
+    const uint32_t g0 = c0 >> 4, g1 = c0 < c1 ? (c1 + 15) >> 4 : g0;
     uint32_t bits = 0;
-    for (uint32_t w = c0 >> 2; w < ((c1 + 3) >> 2) && c0 < c1; w++) {
-        const uint32_t v = bl32[w], base = w << 2;
+    {
+        uint4 v0 = g0 < g1 ? bl16[g0] : make_uint4(0, 0, 0, 0), v1 = g0 + 1 < g1 ? bl16[g0 + 1] : v0, v2 = v1;
+        for (uint32_t gi = g0; gi < g1; gi++) {
+            v2 = gi + 2 < g1 ? bl16[gi + 2] : v2;
+            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w}, base = gi << 4;
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t i = base + k; if (i >= c0 && i < c1) bits += code[(v >> (8 * k)) & 0xFF] >> 16; }
+            for (uint32_t k = 0; k < 16; k++) { const uint32_t i = base + k; if (i >= c0 && i < c1) bits += code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF] >> 16; }
+            v0 = v1; v1 = v2;
+        }
     }
     uint32_t sc = bits;                                            // inclusive scan over lanes
 #pragma unroll
@@ -367,16 +379,21 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
         // lane's symbols occupy stream bits [total - sc, total - sc + bits); later symbols sit at lower bits
         uint64_t pos = (uint64_t)off[wave] * 8 + (total - sc);
         uint32_t widx = (uint32_t)(pos >> 5); uint32_t nb = (uint32_t)(pos & 31); uint64_t acc = 0;
-        if (c0 < c1) for (uint32_t w = (c1 + 3) >> 2; w-- > (c0 >> 2);) {
-            const uint32_t v = bl32[w], base = w << 2;
+        {
+            uint4 v0 = g0 < g1 ? bl16[g1 - 1] : make_uint4(0, 0, 0, 0), v1 = g0 + 1 < g1 ? bl16[g1 - 2] : v0, v2 = v1;
+            for (uint32_t gi = g1; gi-- > g0;) {
+                v2 = gi >= g0 + 2 ? bl16[gi - 2] : v2;
+                const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w}, base = gi << 4;
 #pragma unroll
-            for (int k = 3; k >= 0; k--) {
-                const uint32_t i = base + (uint32_t)k;
-                if (i >= c0 && i < c1) {
-                    const uint32_t cv = code[(v >> (8 * k)) & 0xFF];
-                    acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
-                    if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+                for (int k = 15; k >= 0; k--) {
+                    const uint32_t i = base + (uint32_t)k;
+                    if (i >= c0 && i < c1) {
+                        const uint32_t cv = code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                        acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
+                        if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+                    }
                 }
+                v0 = v1; v1 = v2;
             }
         }
         if (lane == 0) { acc |= (uint64_t)1 << nb; nb += 1; if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; } }
