@@ -316,24 +316,34 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
 }
 
 // ------------------------------------------------------------------ k_lit
+// One workgroup per block, one wave per Huffman stream.  Both passes read the literals with coalesced 16-byte loads
+// (lane i <- granule base+i): pass 1 sums the code lengths of each stream, pass 2 walks each stream from its END in
+// rounds of 64 granules (later symbols sit at lower bit positions), places the lanes' 16-symbol pieces with a wave
+// suffix scan, ORs them into a per-wave LDS staging buffer (64-bit LDS atomics) and flushes completed qwords to the
+// zeroed body with coalesced 64-bit atomic ORs (neighbouring streams share their boundary qwords).
 constexpr uint32_t LIT_THREADS = 256;
+constexpr uint32_t LIT_STAGE_Q = 184;            // qwords of staging per wave: 64 lanes x 176 bits + carry
 
 __global__ __launch_bounds__(LIT_THREADS)
 void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags) {
     __shared__ uint32_t code[256];
     __shared__ uint32_t sbits[4];
+    __shared__ unsigned long long stage[4][LIT_STAGE_Q];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = blockIdx.x;
     const SegTables *T = tabs + blk_seg[g];
     const uint32_t nlit = blk[g].nlit;
     const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
-    uint32_t *out32 = (uint32_t *)(litc + (size_t)g * BLK_SIZE);
+    const uint4 *bl16 = (const uint4 *)bl;
+    unsigned long long *out64 = (unsigned long long *)(litc + (size_t)g * BLK_SIZE);
     if (!(flags & F_HUF) || nlit < 64) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
-    // RLE test
+    // RLE test (coalesced)
     {
-        const uint8_t b0 = bl[0]; int same = 1;
-        for (uint32_t i = tid; i < nlit; i += LIT_THREADS) same &= (bl[i] == b0);
+        const uint32_t b0 = bl[0] * 0x01010101u; int same = 1;
+        const uint32_t n16 = nlit >> 4;
+        for (uint32_t i = tid; i < n16; i += LIT_THREADS) { const uint4 v = bl16[i]; same &= (v.x == b0) & (v.y == b0) & (v.z == b0) & (v.w == b0); }
+        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += LIT_THREADS) same &= (bl[i] == (uint8_t)b0);
         same = __syncthreads_and(same);
         if (same) { if (tid == 0) { blk[g].lit_rle = 1; blk[g].lit_body = 0; } return; }
     }
@@ -343,66 +353,86 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     const uint32_t nstreams = nlit >= 256 ? 4u : 1u;
     const uint32_t segsz = nstreams == 4 ? (nlit + 3) / 4 : nlit;
     // stream `wave`: symbols [a, a+m)
-    uint32_t a = wave * segsz, m = 0;
+    const uint32_t a = wave * segsz;
+    uint32_t m = 0;
     if (wave < nstreams) m = (nstreams == 4 && wave == 3) ? nlit - 3 * segsz : segsz;
-    const uint32_t chunk = (m + 63) / 64;
-    uint32_t c0 = a + lane * chunk, c1 = c0 + chunk; if (c1 > a + m) c1 = a + m; if (c0 > c1) c0 = c1;
-    // the lane's chunk is read in aligned 16-byte granules, two granules ahead of the one being processed, so the
-    // HBM/L2 latency of these lane-private streams overlaps the table lookups; bytes outside [c0, c1) are skipped
-    const uint4 *bl16 = (const uint4 *)bl;
-    const uint32_t g0 = c0 >> 4, g1 = c0 < c1 ? (c1 + 15) >> 4 : g0;
-    uint32_t bits = 0;
+    const uint32_t e = a + m;
+    const uint32_t gfirst = a >> 4, gend = m ? (e + 15) >> 4 : gfirst;
+    // ---- pass 1: bits of the stream
     {
-        uint4 v0 = g0 < g1 ? bl16[g0] : make_uint4(0, 0, 0, 0), v1 = g0 + 1 < g1 ? bl16[g0 + 1] : v0, v2 = v1;
-        for (uint32_t gi = g0; gi < g1; gi++) {
-            v2 = gi + 2 < g1 ? bl16[gi + 2] : v2;
-            const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w}, base = gi << 4;
+        uint32_t bits = 0;
+        for (uint32_t gi = gfirst + lane; gi < gend; gi += 64) {
+            const uint4 v = bl16[gi];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w}, base = gi << 4;
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) { const uint32_t i = base + k; if (i >= c0 && i < c1) bits += code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF] >> 16; }
-            v0 = v1; v1 = v2;
+            for (uint32_t k = 0; k < 16; k++) { const uint32_t i = base + k; if (i >= a && i < e) bits += code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF] >> 16; }
         }
-    }
-    uint32_t sc = bits;                                            // inclusive scan over lanes
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
-    const uint32_t total = (uint32_t)__shfl((int)sc, 63);
-    if (lane == 0 && wave < 4) sbits[wave] = wave < nstreams ? total : 0;
+        for (int d = 32; d >= 1; d >>= 1) bits += (uint32_t)__shfl_xor((int)bits, d);
+        if (lane == 0) sbits[wave] = wave < nstreams ? bits : 0;
+    }
     __syncthreads();
     // stream byte sizes and offsets
     uint32_t sz[4], off[4], body = nstreams == 4 ? 6u : 0u;
     for (uint32_t k = 0; k < 4; k++) { sz[k] = k < nstreams ? (sbits[k] >> 3) + 1 : 0; off[k] = body; body += sz[k]; }
     if (tid == 0) { blk[g].lit_body = body; blk[g].lit_rle = 0; }
     if (body >= nlit || body > BLK_SIZE) return;                   // Huffman cannot win: k_plan picks raw literals
-    for (uint32_t i = tid; i < (body + 3) / 4; i += LIT_THREADS) out32[i] = 0;
+    for (uint32_t i = tid; i < (body + 7) / 8; i += LIT_THREADS) out64[i] = 0;
+    for (uint32_t i = lane; i < LIT_STAGE_Q; i += 64) stage[wave][i] = 0;
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (wave < nstreams) {
-        // lane's symbols occupy stream bits [total - sc, total - sc + bits); later symbols sit at lower bits
-        uint64_t pos = (uint64_t)off[wave] * 8 + (total - sc);
-        uint32_t widx = (uint32_t)(pos >> 5); uint32_t nb = (uint32_t)(pos & 31); uint64_t acc = 0;
-        {
-            uint4 v0 = g0 < g1 ? bl16[g1 - 1] : make_uint4(0, 0, 0, 0), v1 = g0 + 1 < g1 ? bl16[g1 - 2] : v0, v2 = v1;
-            for (uint32_t gi = g1; gi-- > g0;) {
-                v2 = gi >= g0 + 2 ? bl16[gi - 2] : v2;
-                const uint32_t w[4] = {v0.x, v0.y, v0.z, v0.w}, base = gi << 4;
+        unsigned long long *st = stage[wave];
+        uint32_t pos = off[wave] * 8;                              // next free bit of the body (global bit address)
+        uint32_t qfl = pos >> 6;                                   // st[0] holds body qword qfl
+        const uint32_t nround = (gend - gfirst + 63) / 64;
+        for (uint32_t r = 0; r < nround; r++) {
+            const int32_t gi = (int32_t)gend - 64 * (int32_t)(r + 1) + (int32_t)lane;
+            const bool act = gi >= (int32_t)gfirst;
+            unsigned long long gv[4] = {0, 0, 0, 0}; uint32_t gl[4] = {0, 0, 0, 0};
+            if (act) {
+                const uint4 v = bl16[gi];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w}, base = (uint32_t)gi << 4;
 #pragma unroll
-                for (int k = 15; k >= 0; k--) {
+                for (int k = 15; k >= 0; k--) {                    // later symbols first (lower bit positions)
                     const uint32_t i = base + (uint32_t)k;
-                    if (i >= c0 && i < c1) {
+                    if (i >= a && i < e) {
                         const uint32_t cv = code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                        acc |= (uint64_t)(cv & 0xFFFF) << nb; nb += cv >> 16;
-                        if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
+                        const int grp = 3 - (k >> 2);
+                        gv[grp] |= (unsigned long long)(cv & 0xFFFF) << gl[grp]; gl[grp] += cv >> 16;
                     }
                 }
-                v0 = v1; v1 = v2;
             }
+            const uint32_t ltot = gl[0] + gl[1] + gl[2] + gl[3];
+            uint32_t sc = ltot;                                    // inclusive prefix over lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
+            const uint32_t rtot = (uint32_t)__shfl((int)sc, 63);
+            uint32_t p = pos + (rtot - sc) - (qfl << 6);           // staging bit of this lane's first group (lane 63 lowest)
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) {
+                if (gl[grp]) {
+                    const uint32_t qi = p >> 6, sh = p & 63;
+                    atomicOr(&st[qi], gv[grp] << sh);
+                    if (sh + gl[grp] > 64) atomicOr(&st[qi + 1], gv[grp] >> (64 - sh));
+                    p += gl[grp];
+                }
+            }
+            pos += rtot;
+            // flush completed qwords, keep the partial one at st[0]
+            const uint32_t nq = (pos >> 6) - qfl;
+            const unsigned long long part = st[nq];
+            for (uint32_t j = lane; j < nq; j += 64) { const unsigned long long x = st[j]; if (x) atomicOr(&out64[qfl + j], x); }
+            for (uint32_t j = lane; j <= nq; j += 64) st[j] = (j == 0) ? part : 0ull;
+            qfl += nq;
         }
-        if (lane == 0) { acc |= (uint64_t)1 << nb; nb += 1; if (nb >= 32) { atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; } }
-        if (nb) atomicOr(&out32[widx], (uint32_t)acc);
+        // closing 1-bit, then flush what is left (at most two qwords)
+        if (lane == 0) atomicOr(&st[(pos - (qfl << 6)) >> 6], 1ull << ((pos - (qfl << 6)) & 63));
+        pos += 1;
+        const uint32_t nq = ((pos - (qfl << 6)) + 63) >> 6;
+        for (uint32_t j = lane; j < nq; j += 64) { const unsigned long long x = st[j]; if (x) atomicOr(&out64[qfl + j], x); }
     }
-    if (tid == 0 && nstreams == 4) {
-        atomicOr(&out32[0], sz[0] | (sz[1] << 16));
-        atomicOr(&out32[1], sz[2]);
-    }
+    if (tid == 0 && nstreams == 4) atomicOr(&out64[0], (unsigned long long)sz[0] | ((unsigned long long)sz[1] << 16) | ((unsigned long long)sz[2] << 32));
 }
 
 // ------------------------------------------------------------------ k_seq : one lane per block
