@@ -257,6 +257,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // positions the speculative parse stands on: everything except match interiors (starts are stood on;
             // positions past the tile end count as stood on so a walk stops there)
             const uint64_t vis[2] = {~cov[0] | sel[0], ~cov[1] | sel[1]};
+            LZ_STAMP(7);
             const uint32_t flen_spec[2] = {flen[0], flen[1]};
             if (tid < TILE / 16) *(uint4 *)(lds + L_WIN + ((loaded_end + tid * 16) & (WIN_BYTES - 1))) = pf;
             loaded_end += TILE;
@@ -327,6 +328,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
                     else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
                     if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); p.bad = (bad_w && !done_fb) ? 1u : 0u; p.exit = my_exit; wpub[wave] = p; }
+                    if (!done_fb) LZ_STAMP(5);
                     __syncthreads();                                                // B4
                     if (!done_fb) LZ_STAMP(4);
                     const WPub pl = wpub[lane & (LZ_WAVES - 1)];
@@ -405,7 +407,6 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         flen[1] = ((fix[1] >> lane) & 1) ? (uint32_t)fix_arr[wbase + 64 + lane] : flen_spec[1];
                     }
                     done_fb = true;
-                    LZ_STAMP(5);
                 }
 
                 // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)

@@ -20,7 +20,7 @@ constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
 constexpr uint32_t HASH_LOG   = 14;
 constexpr uint32_t MIN_MATCH  = 6;
 constexpr uint32_t MAX_OFF    = 59392;      // 64 KiB window - 2 tiles - look-ahead - slack
-constexpr uint32_t CAP1       = 32;
+constexpr uint32_t CAP1       = 16;
 constexpr uint32_t LOOKAHEAD  = 1024;
 constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
 constexpr uint32_t SEQ_CAP    = 22016;      // sequences per block: BLK_SIZE / MIN_MATCH rounded up to 256
