@@ -205,17 +205,19 @@ void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
 // k_lz's chunk table gives, for each 2 KiB tile of the block, the sequence / literal stream positions at the tile start
 // and the literal index of the tile's first match, so lane t can encode the elements that belong to tile t on its own:
 // pass 1 counts its bits, a wave scan places the pieces, pass 2 ORs them into the zeroed output at their bit offsets.
-__global__ __launch_bounds__(64)
+constexpr uint32_t DB_THREADS = BLK_SIZE / TILE;            // one lane per tile of the block
+__global__ __launch_bounds__(DB_THREADS)
 void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs,
               const uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, const uint4 *__restrict__ ctab,
               const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc, uint32_t dbg) {
     __shared__ uint32_t t_ll[288];
     __shared__ uint32_t t_d[32];
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    __shared__ uint32_t wtot[(DB_THREADS + 63) / 64 + 1];
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;        // "lane" = piece index 0..127 (two waves)
     const uint32_t sidx = blk_seg[g];
     const SegDesc sd = segs[sidx];
     const DeflTables *T = tabs + sidx;
-    for (uint32_t i = lane; i < 288; i += 64) t_ll[i] = T->ll_code[i];
+    for (uint32_t i = lane; i < 288; i += DB_THREADS) t_ll[i] = T->ll_code[i];
     if (lane < 32) t_d[lane] = T->d_code[lane];
     __syncthreads();
     const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
@@ -292,16 +294,19 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
         }
     };
     run(false);
-    // inclusive scan of the pieces' bit counts over the wave
+    // inclusive scan of the pieces' bit counts over the two waves
     uint32_t sc = bits;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if (lane >= (uint32_t)d) sc += t; }
-    const uint32_t total_bits = (uint32_t)__shfl((int)sc, 63);
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if ((lane & 63) >= (uint32_t)d) sc += t; }
+    if ((lane & 63) == 63) wtot[lane >> 6] = sc;
+    __syncthreads();
+    uint32_t total_bits = 0;
+    for (uint32_t w = 0; w < (DB_THREADS + 63) / 64; w++) { if (w < (lane >> 6)) sc += wtot[w]; total_bits += wtot[w]; }
     const uint32_t bytes = (total_bits + 7) / 8;
     if (lane == 0) blk[g].lit_body = bytes;
     (void)hdr_total;
     if (bytes > BLK_SIZE) return;                                   // k_dplan falls back to stored blocks
-    for (uint32_t i = lane; i < (bytes + 3) / 4; i += 64) out32[i] = 0;
+    for (uint32_t i = lane; i < (bytes + 3) / 4; i += DB_THREADS) out32[i] = 0;
     __builtin_amdgcn_s_waitcnt(0);                                  // zeros are in L2 before the atomic ORs are issued
     __syncthreads();
     const uint32_t start = sc - bits;
@@ -400,7 +405,7 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
     if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (ev) (void)hipEventRecord(ev[1], st);
-    if (nblk) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(64), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
+    if (nblk) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(DB_THREADS), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size);
     k_scan_launch(seg_size, seg_off, nseg, st);
