@@ -3,8 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (LZ -> entropy -> pack into the packed compressed stream) over the whole
-synthetic corpus of this rank: `--files` enwik-style text files of `--file-mib` MiB each (BASELINE.json configs[1]:
+One "step" = one pass of the hot path over the whole synthetic corpus of this rank, ending with the complete `.pna`
+archive bytes in HBM (LZ -> entropy -> payloads written at their archive offsets -> chunk framing + FDAT CRC-32;
+`--framing none` stops at the packed compressed entries): `--files` enwik-style text files of `--file-mib` MiB each (BASELINE.json configs[1]:
 10 000 x 1 MiB, zstd).  Inputs are generated on the device and are resident in HBM when the timed region starts.
 N > 1: one process per GPU (torch.distributed / RCCL), every rank compresses its own shard of the corpus (weak
 scaling), then the compressed shards are gathered in rank order onto rank 0 over RCCL (the ordered gather of the
@@ -87,6 +88,8 @@ def main() -> None:
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--algo", choices=["zstd", "deflate"], default="zstd")
     ap.add_argument("--kind", type=int, default=0, help="corpus kind (0 enwik-style text, 1 random-text)")
+    ap.add_argument("--framing", choices=["archive", "none"], default="archive",
+                    help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
     args = ap.parse_args()
@@ -114,15 +117,23 @@ def main() -> None:
     ctx.corpus_fill_device(args.kind, rank * n_files, n_files, file_len, stride, src.data_ptr())
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]
     src_len = [file_len] * n_files
-    dst_cap = pna.bound(algo, file_len) * n_files + 4096
+    names = [f"enwik/part{rank * n_files + i:07d}.txt" for i in range(n_files)]
+    if args.framing == "archive":
+        dst_cap = pna.archive_bound(algo, names, src_len)
+    else:
+        dst_cap = pna.bound(algo, file_len) * n_files + 4096
     dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
+    arg_cache: dict = {}
 
     shard = importlib.import_module("portable-network-archive_amd.shard")
     gather_out = [None]
 
     def step():
-        offs = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)
-        total = offs[-1]
+        if args.framing == "archive":
+            total, _ = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo,
+                                                 _cache=arg_cache)
+        else:
+            total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
         if world > 1:
             # ordered gather of the compressed shards into the serial stream on rank 0 (RCCL send/recv over xGMI)
             if rank == 0 and gather_out[0] is None:
@@ -142,7 +153,7 @@ def main() -> None:
         out_total = step()
         tm = ctx.timing()
         lz_ms += tm.ms_lz
-        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack
+        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,14 +182,16 @@ def main() -> None:
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text per GPU, Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} "
-                                   f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1), inputs resident in HBM",
+                                   f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1), inputs resident in HBM, "
+                                   + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
+                                      else "output = packed compressed entry streams in HBM"),
                        "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
             "ratio": round(in_all / max(out_all, 1), 4),
             "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "kernel_ms": round(lz_ms / args.steps, 3), "all_kernels_ms": round(stage_ms / args.steps, 3)},
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
-                                    "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3)},
+                                    "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3), "frame": round(tm.ms_frame, 3)},
         }
         if world == 1 and not args.no_cpu_baseline and args.algo == "zstd":
             try:

@@ -80,6 +80,21 @@ int  pna_gpu_compress_batch_device(pna_gpu_ctx *ctx, int algo, int level, size_t
                                    const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                    void *d_dst, size_t dst_cap, uint64_t *dst_off, void *hip_stream);
 
+/* ---- non-solid archive assembled in HBM: what create_archive_file() (cli/src/command/create.rs:575-635) writes through
+ * Archive::write_header / add_entry / finalize (lib/src/archive/write.rs:92-101,368-370,438-441) for file entries whose
+ * records are FHED | fSIZ | FDAT | FEND (NormalEntry::write_chunks_to, lib/src/entry.rs:895-911; write_chunk and its
+ * CRC-32, lib/src/io.rs:183-197, lib/src/format/chunk.rs:7-12).  The compressed payloads are written once, straight at
+ * their archive offsets; the FDAT CRCs are computed on the device.  Same inputs as pna_gpu_compress_batch_device plus
+ * names[i] (host strings, sanitised like EntryName::sanitize).  d_dst: 16-byte aligned device buffer of at least
+ * pna_gpu_archive_bound() bytes; on return d_dst[0 .. *archive_len) is the complete .pna file and, if entry_off is not
+ * NULL, entry_off[i] (n + 1 values) is the offset of entry i's FHED chunk.  Byte-identical to pna_create_archive()
+ * (include/pna_archive.h) over the same entries. */
+size_t pna_gpu_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len);
+int  pna_gpu_create_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                   const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                   void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
+                                   void *hip_stream);
+
 /* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
  * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write). */
 typedef int (*pna_sink_fn)(void *user, const void *buf, size_t len);
@@ -99,6 +114,7 @@ int  pna_gpu_compress_solid(pna_gpu_ctx *ctx, int algo, int level, const void *s
 typedef struct {
     double   ms_lz, ms_stats, ms_lit, ms_seq, ms_pack;   /* HIP-event time of each stage of the last batch     */
     uint64_t in_bytes, out_bytes, n_segments, n_blocks;
+    double   ms_frame;                                   /* k_frame (pna_gpu_create_archive_device only)       */
 } pna_gpu_timing;
 int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
 
@@ -106,6 +122,10 @@ int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
  * seqs: packed u64 (off:20 | ml:18<<20 | ll:18<<38). Copies at most cap_* items; returns counts. */
 int  pna_gpu_debug_block(pna_gpu_ctx *ctx, uint32_t block, uint64_t *seqs, uint32_t cap_seqs, uint32_t *nseq,
                          uint8_t *lits, uint32_t cap_lits, uint32_t *nlit);
+
+/* Host walk through the device CRC schedule of k_frame with the same tables; returns crc32("FDAT" || payload).
+ * CPU-only tests use it to check the table construction; it is not on any product path. */
+uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len);
 
 /* Diagnostic build of the LZ kernel (ctx created with flag 0x100): per-phase s_memtime sums of wave 0, cleared on read. */
 int  pna_gpu_debug_lz_stamps(pna_gpu_ctx *ctx, unsigned long long *out8);

@@ -43,7 +43,8 @@ class PnaGpuError(RuntimeError):
 class Timing(ctypes.Structure):
     _fields_ = [("ms_lz", ctypes.c_double), ("ms_stats", ctypes.c_double), ("ms_lit", ctypes.c_double),
                 ("ms_seq", ctypes.c_double), ("ms_pack", ctypes.c_double), ("in_bytes", ctypes.c_uint64),
-                ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64)]
+                ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64),
+                ("ms_frame", ctypes.c_double)]
 
 
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -55,6 +56,7 @@ EXPORTS = [
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
+    "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_debug_crc_schedule",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -92,6 +94,13 @@ def load_library() -> ctypes.CDLL:
                                          ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     L.pna_gpu_compress_batch_device.restype = ctypes.c_int
     L.pna_gpu_compress_batch_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, vp, u64p, u64p, vp, sz, u64p, vp]
+    L.pna_gpu_archive_bound.restype = sz
+    L.pna_gpu_archive_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p]
+    L.pna_gpu_create_archive_device.restype = ctypes.c_int
+    L.pna_gpu_create_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
+                                                vp, sz, u64p, u64p, vp]
+    L.pna_gpu_debug_crc_schedule.restype = ctypes.c_uint32
+    L.pna_gpu_debug_crc_schedule.argtypes = [ctypes.c_char_p, sz]
     L.pna_gpu_stream_new.restype = ctypes.c_int
     L.pna_gpu_stream_new.argtypes = [vp, ctypes.c_int, ctypes.c_int, SINK_FN, vp, ctypes.POINTER(vp)]
     L.pna_gpu_stream_write.restype = ctypes.c_int
@@ -205,6 +214,26 @@ class Context:
                                                           ctypes.c_void_p(d_dst), dst_cap, a_out,
                                                           ctypes.c_void_p(stream) if stream else None))
         return list(a_out)
+
+    def create_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
+                              dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
+                              _cache: Optional[dict] = None):
+        """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_device).  Returns (archive_len, entry_off)."""
+        n = len(src_len)
+        if _cache is not None and "a" in _cache:
+            a_names, a_off, a_len = _cache["a"]
+        else:
+            a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+            a_off = (ctypes.c_uint64 * (n + 1))(*(list(src_off)[:n] + [0]))
+            a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+            if _cache is not None:
+                _cache["a"] = (a_names, a_off, a_len)
+        a_out = (ctypes.c_uint64 * (n + 1))()
+        total = ctypes.c_uint64()
+        self._check(self._L.pna_gpu_create_archive_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
+                                                          ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total),
+                                                          ctypes.c_void_p(stream) if stream else None))
+        return total.value, list(a_out)
 
     def timing(self) -> Timing:
         t = Timing()
@@ -328,6 +357,18 @@ def inner_entry_bytes(name: str, data: bytes) -> bytes:
     buf = ctypes.create_string_buffer(need)
     got = L.pna_archive_inner_entry_bytes(name.encode(), bytes(data), len(data), buf, need)
     return buf.raw[:got]
+
+
+def archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> int:
+    n = len(src_len)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+    return load_library().pna_gpu_archive_bound(algo, n, a_names, a_len)
+
+
+def crc_schedule(payload: bytes) -> int:
+    """crc32(b"FDAT" + payload) computed by the host walk through k_frame's lane schedule (table self-check)."""
+    return load_library().pna_gpu_debug_crc_schedule(payload, len(payload))
 
 
 def crc32(data: bytes, crc: int = 0) -> int:

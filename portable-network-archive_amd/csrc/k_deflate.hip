@@ -373,7 +373,8 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
 
 // ------------------------------------------------------------------ k_dfinal : one thread per entry
 __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ entry_seg, uint32_t nentry,
-                         const BlkInfo *__restrict__ blk, const uint64_t *__restrict__ seg_off, uint8_t *__restrict__ dst) {
+                         const BlkInfo *__restrict__ blk, const uint64_t *__restrict__ seg_off, const uint64_t *__restrict__ seg_size,
+                         uint8_t *__restrict__ dst) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nentry) return;
     const uint32_t s0 = entry_seg[e], s1 = entry_seg[e + 1];
@@ -392,7 +393,7 @@ __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__res
             A = (A + bi.adler_a + ADLER_P - 1) % ADLER_P;
         }
     }
-    uint8_t *t = dst + seg_off[s1] - 4;
+    uint8_t *t = dst + seg_off[s1 - 1] + seg_size[s1 - 1] - 4;     // segment offsets need not be contiguous (in-HBM framing)
     t[0] = (uint8_t)(B >> 8); t[1] = (uint8_t)B; t[2] = (uint8_t)(A >> 8); t[3] = (uint8_t)A;
 }
 
@@ -413,10 +414,10 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
 }
 
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
-                          const uint64_t *seg_off, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
+                          const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
                           uint8_t *dst, hipStream_t st) {
     if (nblk) hipLaunchKernelGGL(k_dwrite, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk, seg_off, outc, dst);
-    hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, dst);
+    hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, seg_size, dst);
 }
 
 } // namespace pna

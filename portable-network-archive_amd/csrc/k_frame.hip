@@ -1,0 +1,121 @@
+// k_frame.hip -- PNA entry framing in HBM: chunk headers, the FDAT CRC-32 and FEND around a payload that the write
+// kernels have already placed at its final archive offset.  One 256-thread workgroup per entry.
+//
+// Mirrors write_chunk (lib/src/io.rs:183-197: length BE | type | data | crc32(type || data) BE, crc = chunk_crc,
+// lib/src/format/chunk.rs:7-12) for the chunks of NormalEntry::write_chunks_to (lib/src/entry.rs:895-911).
+//
+// CRC-32 (reflected 0xEDB88320) of a long message on 256 lanes.  With R(s, M) the raw register update (no init / final
+// xor) the code relies on three identities of the linear map R:
+//   (1) R(0xFFFFFFFF, M) = R(0, M ^ FF FF FF FF 00 00 ...)        |M| >= 4: the init value folds into the first 4 bytes
+//   (2) R(0, 0^k || M)   = R(0, M)                                zero bytes in front of the message are free
+//   (3) R(0, A || B)     = Z_|B|(R(0, A)) ^ R(0, B)               Z_k = "append k zero bytes" = multiply by x^(8k) mod P
+// The message "FDAT" || payload is front-padded (2) to a whole number of 16 KiB tiles.  Lane t owns the 64-byte piece t of
+// every tile; between tiles its state is advanced by Z_16320 (four table look-ups), so after the last tile lane t holds
+// the contribution of its pieces as if piece t of the LAST tile were the end of the message.  A log-step tree applies (3)
+// with the fixed shifts 64 * 2^j to fold the 256 lane states into R(0, M').
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+constexpr uint32_t FR_THREADS = 256;
+constexpr uint32_t FR_TILE = FR_THREADS * 64;              // 16 KiB of message per step
+constexpr uint32_t FR_TILE_DW = FR_TILE / 4 + 4;           // + one 16-byte word for the misalignment of the source
+
+__device__ __forceinline__ uint32_t lds_pad(uint32_t d) { return d + (d >> 4); }   // 17-dword row pitch: lane stride 16 dwords -> conflict-free
+
+// a * b mod P, reflected bit order (bit 31 = x^0)
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(FR_THREADS)
+void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct,
+             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc) {
+    __shared__ uint32_t sT[4][256], sZ[4][256];
+    __shared__ uint32_t tile[FR_TILE_DW + FR_TILE_DW / 16 + 8];
+    __shared__ uint32_t part[FR_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const FrameDesc d = fd[blockIdx.x];
+    for (uint32_t i = tid; i < 1024; i += FR_THREADS) { (&sT[0][0])[i] = (&ct->T[0][0])[i]; (&sZ[0][0])[i] = (&ct->Z[0][0])[i]; }
+    for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
+
+    const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
+    const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
+    const uint32_t ntile = (n + FR_TILE - 1) / FR_TILE;
+    const uint32_t pad = ntile * FR_TILE - n;                        // zero bytes put in front, < FR_TILE
+    const int64_t base = (int64_t)pay - 4 - (int64_t)pad;            // dst offset of message position 0 (may be negative)
+    const uint32_t a = (uint32_t)(base & 15);                        // two's complement: correct for negative base too
+    const uint32_t ty_x = ~0x54414446u;                              // "FDAT" little-endian, complemented (identity 1)
+    uint32_t state = 0;
+
+    for (uint32_t k = 0; k < ntile; k++) {
+        const int64_t A = base + (int64_t)k * FR_TILE - a;           // multiple of 16
+        __syncthreads();
+        for (uint32_t i = tid; i < FR_TILE / 16 + 1; i += FR_THREADS) {
+            const int64_t o = A + (int64_t)i * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o >= 0 && (uint64_t)o + 16 <= cap16) v = *reinterpret_cast<const uint4 *>(dst + o);
+            tile[lds_pad(4 * i)] = v.x; tile[lds_pad(4 * i + 1)] = v.y; tile[lds_pad(4 * i + 2)] = v.z; tile[lds_pad(4 * i + 3)] = v.w;
+        }
+        __syncthreads();
+        uint32_t w[17];
+        const uint32_t d0 = (a >> 2) + tid * 16;
+#pragma unroll
+        for (int j = 0; j < 17; j++) w[j] = tile[lds_pad(d0 + j)];
+        const uint32_t sh = (a & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 16; j++) w[j] = (uint32_t)((((uint64_t)w[j + 1] << 32) | w[j]) >> sh);
+        const uint32_t p0 = k * FR_TILE + tid * 64;                  // message position of this piece
+        if (p0 < pad + 4) {                                          // first tile only: zero padding and the type bytes
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                uint32_t m = 0, x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t p = p0 + 4 * j + b;
+                    if (p >= pad + 4) m |= 0xFFu << (8 * b);
+                    else if (p >= pad) x |= ((ty_x >> (8 * (p - pad))) & 0xFFu) << (8 * b);
+                }
+                w[j] = (w[j] & m) | x;
+            }
+        }
+        state = sZ[0][state & 0xFF] ^ sZ[1][(state >> 8) & 0xFF] ^ sZ[2][(state >> 16) & 0xFF] ^ sZ[3][state >> 24];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t c = state ^ w[j];
+            state = sT[3][c & 0xFF] ^ sT[2][(c >> 8) & 0xFF] ^ sT[1][(c >> 16) & 0xFF] ^ sT[0][c >> 24];
+        }
+    }
+    part[tid] = state;
+    __syncthreads();
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t st = 1u << j;
+        if ((tid & (2 * st - 1)) == 0) part[tid] = gf2_mulmod(ct->sh[j], part[tid]) ^ part[tid + st];
+        __syncthreads();
+    }
+    if (tid < 16) {
+        const uint32_t crc = ~part[0];
+        // crc BE | 00 00 00 00 | "FEND" | crc("FEND") BE
+        const uint32_t fe = 0x444E4546u;                              // "FEND" little-endian
+        uint8_t v;
+        if (tid < 4) v = (uint8_t)(crc >> (24 - 8 * tid));
+        else if (tid < 8) v = 0;
+        else if (tid < 12) v = (uint8_t)(fe >> (8 * (tid - 8)));
+        else v = (uint8_t)(fend_crc >> (24 - 8 * (tid - 12)));
+        dst[pay + d.payload_len + tid] = v;
+    }
+}
+
+void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
+                  uint32_t fend_crc, hipStream_t st) {
+    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc);
+}
+
+} // namespace pna

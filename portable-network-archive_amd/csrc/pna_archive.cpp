@@ -81,6 +81,32 @@ static size_t fsiz(uint64_t raw, uint8_t out[16]) {        // u128 BE, leading z
     return 16 - skip;
 }
 
+// ---- pieces of the entry record used by the in-HBM framing path (pna_gpu_create_archive_device, pna_host.cpp)
+namespace pna {
+static void put_chunk(std::vector<uint8_t> &o, const char ty[4], const uint8_t *data, size_t len) {
+    uint8_t head[8]; put_be32(head, (uint32_t)len); memcpy(head + 4, ty, 4);
+    uint8_t tail[4]; put_be32(tail, pna_crc32(pna_crc32(0, ty, 4), data, len));
+    o.insert(o.end(), head, head + 8); if (len) o.insert(o.end(), data, data + len); o.insert(o.end(), tail, tail + 4);
+}
+// signature + AHED -- lib/src/archive/write.rs (write_header), lib/src/archive/header.rs:27-39
+void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number) {
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+    uint8_t ahed[8] = {0, 0, 0, 0, 0, 0, 0, 0}; put_be32(ahed + 4, archive_number);
+    o.insert(o.end(), sig, sig + 8); put_chunk(o, "AHED", ahed, 8);
+}
+void frame_archive_tail(std::vector<uint8_t> &o) { put_chunk(o, "AEND", nullptr, 0); }
+// FHED | fSIZ | FDAT length + type: everything of a file entry that precedes its payload (NormalEntry::write_chunks_to, lib/src/entry.rs:895-911)
+void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len) {
+    std::vector<uint8_t> h = fhed(0, compression, 0, 1, sanitize(name));
+    put_chunk(o, "FHED", h.data(), h.size());
+    uint8_t b[16]; size_t n = fsiz(raw_size, b); put_chunk(o, "fSIZ", b, n);
+    uint8_t head[8]; put_be32(head, payload_len); memcpy(head + 4, "FDAT", 4);
+    o.insert(o.end(), head, head + 8);
+}
+size_t frame_entry_prefix_bound(const char *name) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 8; }
+uint32_t frame_fend_crc() { return pna_crc32(0, "FEND", 4); }
+} // namespace pna
+
 extern "C" int pna_archive_new(pna_sink_fn sink, void *user, uint32_t archive_number, pna_archive **out) {
     if (!sink || !out) return PNA_E_INVAL;
     pna_archive *a = new pna_archive{sink, user, 0};

@@ -78,4 +78,18 @@ struct DeflTables {
     uint8_t  hdr[400];       // HLIT HDIST HCLEN + code-length code + coded lengths, LSB-first
 };
 
+// in-HBM framing (k_frame): one descriptor per entry
+struct FrameDesc {
+    uint64_t arc_off;        // offset of the entry's first byte (FHED chunk) in the archive buffer
+    uint32_t payload_len;    // bytes of the FDAT payload, already in place at arc_off + prefix_len
+    uint32_t prefix_off;     // offset of the entry's prefix (FHED | fSIZ | FDAT length + type) in the prefix blob
+    uint32_t prefix_len;
+    uint32_t pad;
+};
+struct CrcTabs {
+    uint32_t T[4][256];      // slice-by-4 tables of the reflected CRC-32
+    uint32_t Z[4][256];      // "append 16320 zero bytes" as four byte-indexed tables
+    uint32_t sh[8];          // x^(8 * 64 * 2^j) mod P, j = 0..7
+};
+
 } // namespace pna

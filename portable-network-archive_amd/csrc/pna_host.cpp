@@ -20,7 +20,7 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
-                          const uint64_t *seg_off, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
+                          const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
                           uint8_t *dst, hipStream_t st);
 void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                     const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
@@ -29,6 +29,13 @@ void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const 
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
                   const uint8_t *seqc, uint8_t *dst, hipStream_t st);
 void lz_read_stamps(unsigned long long *out);
+void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
+                  uint32_t fend_crc, hipStream_t st);
+void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number);
+void frame_archive_tail(std::vector<uint8_t> &o);
+void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len);
+size_t frame_entry_prefix_bound(const char *name);
+uint32_t frame_fend_crc();
 void launch_corpus(int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len, uint64_t stride,
                    const uint8_t *vocab, const uint64_t *cum, const uint32_t *phrases, uint8_t *dst, hipStream_t st);
 }
@@ -47,6 +54,19 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct PinBuf {                                  // page-locked host staging: async copies that really are asynchronous
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 2) + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+        cap = want; return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
@@ -54,6 +74,9 @@ struct pna_gpu_ctx {
     hipEvent_t ev[8] = {};
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
+    DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
+    PinBuf h_desc, h_blob, h_segdst, h_segoff;
+    bool crc_ready = false;
     bool corpus_ready = false;
     std::string err;
     pna_gpu_timing timing = {};
@@ -105,7 +128,9 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr}) b->release();
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs}) b->release();
+    for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff}) b->release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -139,9 +164,70 @@ extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
 
 // ---------------------------------------------------------------------------------------------------------
 // One sub-batch: entries [e0, e1) -> segments -> kernels; output appended at d_dst + out_base.
+// ---- CRC-32 tables of the framing kernel (k_frame.hip explains the algebra)
+static uint32_t gf2_mulmod(uint32_t a, uint32_t b) {          // a * b mod P, reflected bit order (bit 31 = x^0)
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) { if (a & 0x80000000u) p ^= b; a <<= 1; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+static uint32_t gf2_xpow(uint64_t e) {                        // x^e mod P
+    uint32_t r = 0x80000000u, base = 0x40000000u;
+    while (e) { if (e & 1) r = gf2_mulmod(base, r); base = gf2_mulmod(base, base); e >>= 1; }
+    return r;
+}
+static void build_crc_tabs(CrcTabs &t) {
+    for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1) ? (v >> 1) ^ 0xEDB88320u : v >> 1; t.T[0][i] = v; }
+    for (int k = 1; k < 4; k++) for (uint32_t i = 0; i < 256; i++) t.T[k][i] = (t.T[k - 1][i] >> 8) ^ t.T[0][t.T[k - 1][i] & 0xFF];
+    const uint32_t z = gf2_xpow(8ull * 16320);
+    for (int j = 0; j < 4; j++) for (uint32_t b = 0; b < 256; b++) t.Z[j][b] = gf2_mulmod(z, b << (8 * j));
+    for (int j = 0; j < 8; j++) t.sh[j] = gf2_xpow(8ull * 64 << j);
+}
+static int ensure_crc(pna_gpu_ctx *c) {
+    if (c->crc_ready) return PNA_OK;
+    CrcTabs t; build_crc_tabs(t);
+    if (c->crc_tabs.ensure(sizeof(t))) return fail(c, PNA_E_NOMEM, "crc tables");
+    HIPCHK(c, hipMemcpy(c->crc_tabs.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    c->crc_ready = true;
+    return PNA_OK;
+}
+
+// Host walk through k_frame's CRC schedule with the same tables (lane states, Z_16320 between tiles, fold tree): lets the
+// CPU-only test suite check the algebra and the table construction against pna_crc32 without a GPU.  Not a product path.
+extern "C" uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len) {
+    static CrcTabs t; static bool ready = false;
+    if (!ready) { build_crc_tabs(t); ready = true; }
+    const uint8_t *pl = (const uint8_t *)payload;
+    const uint64_t n = 4 + (uint64_t)len, ntile = (n + 16383) / 16384, pad = ntile * 16384 - n;
+    static const uint8_t ty[4] = {0x46 ^ 0xFF, 0x44 ^ 0xFF, 0x41 ^ 0xFF, 0x54 ^ 0xFF};
+    uint32_t lane[256] = {0};
+    for (uint64_t k = 0; k < ntile; k++)
+        for (uint32_t l = 0; l < 256; l++) {
+            uint32_t s = lane[l];
+            s = t.Z[0][s & 0xFF] ^ t.Z[1][(s >> 8) & 0xFF] ^ t.Z[2][(s >> 16) & 0xFF] ^ t.Z[3][s >> 24];
+            for (uint32_t j = 0; j < 16; j++) {
+                uint32_t w = 0;
+                for (uint32_t b = 0; b < 4; b++) {
+                    const uint64_t p = k * 16384 + l * 64 + 4 * j + b;
+                    const uint8_t v = p < pad ? 0 : (p < pad + 4 ? ty[p - pad] : pl[p - pad - 4]);
+                    w |= (uint32_t)v << (8 * b);
+                }
+                const uint32_t x = s ^ w;
+                s = t.T[3][x & 0xFF] ^ t.T[2][(x >> 8) & 0xFF] ^ t.T[1][(x >> 16) & 0xFF] ^ t.T[0][x >> 24];
+            }
+            lane[l] = s;
+        }
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t st = 1u << j;
+        for (uint32_t l = 0; l < 256; l += 2 * st) lane[l] = gf2_mulmod(t.sh[j], lane[l]) ^ lane[l + st];
+    }
+    return ~lane[0];
+}
+
+struct FrameJob { const char *const *names; };               // names[e] for the batch's global entry index e
+
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
-                        hipStream_t st, bool timed) {
+                        hipStream_t st, bool timed, const FrameJob *fj = nullptr) {
     std::vector<SegDesc> segs; std::vector<uint32_t> blk_seg; std::vector<uint32_t> entry_first_seg;
     uint32_t nblk = 0;
     for (size_t e = e0; e < e1; e++) {
@@ -186,26 +272,79 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                    (uint8_t *)c->seqc.p, (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, d_dst, c->flags, st,
                    timed ? &c->ev[2] : nullptr);
     HIPCHK(c, hipGetLastError());
+    // while the kernels run: the name-dependent part of every entry record (FHED and fSIZ chunks with their CRCs)
+    FrameDesc *fds = nullptr; uint8_t *blob = nullptr; uint64_t *segdst = nullptr; size_t blob_len = 0;
+    if (fj) {
+        std::vector<uint8_t> tmp;
+        size_t bound = 0;
+        for (size_t e = e0; e < e1; e++) bound += frame_entry_prefix_bound(fj->names[e]);
+        if (c->h_desc.ensure((e1 - e0) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
+            return fail(c, PNA_E_NOMEM, "framing staging");
+        fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
+        for (size_t e = e0; e < e1; e++) {
+            tmp.clear();
+            frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
+            memcpy(blob + blob_len, tmp.data(), tmp.size());
+            fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
+            blob_len += tmp.size();
+        }
+    }
     // the output offsets are needed on the host before the write pass can be bounds-checked
-    std::vector<uint64_t> seg_off(nseg + 1);
-    HIPCHK(c, hipMemcpyAsync(seg_off.data(), c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (c->h_segoff.ensure((size_t)(nseg + 1) * 8)) return fail(c, PNA_E_NOMEM, "offset staging");
+    const uint64_t *seg_off = (const uint64_t *)c->h_segoff.p;
+    HIPCHK(c, hipMemcpyAsync(c->h_segoff.p, c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    const uint64_t total = seg_off[nseg];
-    if (out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+    uint64_t total = seg_off[nseg];
+    const uint64_t *d_segdst = (const uint64_t *)c->seg_off.p;
+    uint8_t *wbase = d_dst + out_base;
+    if (fj) {
+        // archive layout of this sub-batch: [prefix | payload | crc | FEND] per entry; the write kernels put every
+        // segment straight at its final place, k_frame adds the rest (no second copy of the payload)
+        uint64_t pos = out_base;
+        for (size_t e = e0; e < e1; e++) {
+            const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
+            const uint64_t plen = seg_off[s1] - seg_off[s0];
+            if (plen >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "entry payload too large for one FDAT chunk");
+            FrameDesc &f = fds[e - e0];
+            const uint32_t pl = f.prefix_len;
+            uint8_t *lenf = &blob[f.prefix_off + pl - 8];          // FDAT chunk length, big-endian
+            lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
+            f.arc_off = pos; f.payload_len = (uint32_t)plen;
+            dst_off[e] = pos;
+            for (uint32_t s = s0; s < s1; s++) segdst[s] = pos + pl + (seg_off[s] - seg_off[s0]);
+            pos += pl + plen + 16;
+        }
+        segdst[nseg] = pos;
+        total = pos - out_base;
+        if (pos + 16 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+        if (c->fr_desc.ensure((e1 - e0) * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8))
+            return fail(c, PNA_E_NOMEM, "framing workspace");
+        int rc = ensure_crc(c); if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->fr_desc.p, fds, (e1 - e0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->fr_blob.p, blob, blob_len, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->fr_segdst.p, segdst, (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, st));
+        d_segdst = (const uint64_t *)c->fr_segdst.p; wbase = d_dst;
+    } else if (out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     if (defl) launch_deflate_write(d_src, (const SegDesc *)c->segs.p, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
-                                   (const uint64_t *)c->seg_off.p, (const uint8_t *)c->litc.p, (const uint32_t *)c->entry_seg.p,
-                                   (uint32_t)(e1 - e0), d_dst + out_base, st);
+                                   d_segdst, (const uint64_t *)c->seg_size.p, (const uint8_t *)c->litc.p, (const uint32_t *)c->entry_seg.p,
+                                   (uint32_t)(e1 - e0), wbase, st);
     else launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
-                 (const SegTables *)c->tabs.p, (const uint64_t *)c->seg_off.p, (const uint8_t *)c->lits.p,
-                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst + out_base, st);
+                 (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
+                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
+    if (fj) launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)(e1 - e0), (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
+                         d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), st);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
     HIPCHK(c, hipGetLastError());
-    for (size_t e = e0; e < e1; e++) dst_off[e] = out_base + seg_off[entry_first_seg[e - e0]];
+    if (!fj) for (size_t e = e0; e < e1; e++) dst_off[e] = out_base + seg_off[entry_first_seg[e - e0]];
     dst_off[e1] = out_base + total;
     c->last_nblk = nblk;
+    if (fj && !timed) HIPCHK(c, hipStreamSynchronize(st));        // the staging buffers are reused by the next sub-batch
     if (timed) {
         HIPCHK(c, hipStreamSynchronize(st));
-        float ms[6] = {0, 0, 0, 0, 0, 0};
+        float ms[6] = {0, 0, 0, 0, 0, 0}, msf = 0;
+        (void)hipEventElapsedTime(&msf, c->ev[6], c->ev[7]);
+        c->timing.ms_frame += msf;
         (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
         (void)hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
@@ -245,6 +384,54 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
     }
     HIPCHK(c, hipStreamSynchronize(st));
     c->timing.in_bytes = in_total; c->timing.out_bytes = out_base;
+    return PNA_OK;
+}
+
+extern "C" size_t pna_gpu_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len) {
+    size_t b = 28 + 12 + 64;                                    // signature + AHED, AEND, alignment slack of the CRC reads
+    for (size_t i = 0; i < n; i++) b += frame_entry_prefix_bound(names ? names[i] : nullptr) + pna_gpu_bound(algo, (size_t)src_len[i]) + 16;
+    return b;
+}
+
+// Non-solid `pna create` with the archive assembled in HBM: create_archive_file (cli/src/command/create.rs:575-635) +
+// Archive::write_header / add_entry / finalize (lib/src/archive/write.rs) for file entries carrying FHED, fSIZ, FDAT, FEND.
+extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                             const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                             void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
+                                             void *hip_stream) {
+    if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
+    if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
+    (void)level;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->timing = pna_gpu_timing{};
+    std::vector<uint8_t> head, tail; frame_archive_head(head, 0); frame_archive_tail(tail);
+    if (head.size() + tail.size() + 16 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+    HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    std::vector<uint64_t> offs(n + 1);
+    uint64_t pos = head.size(), in_total = 0;
+    FrameJob fj{names};
+    size_t e = 0;
+    while (e < n) {
+        size_t e1 = e, blocks = 0;
+        while (e1 < n) {
+            size_t nb = (size_t)((src_len[e1] + BLK_SIZE - 1) / BLK_SIZE);
+            if (e1 > e && blocks + nb > c->max_blocks) break;
+            blocks += nb; in_total += src_len[e1]; e1++;
+        }
+        int rc = run_subbatch(c, algo, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap - tail.size(), pos, offs.data(), st, true, &fj);
+        if (rc) return rc;
+        pos = offs[e1];
+        e = e1;
+    }
+    offs[n] = pos;
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + pos, tail.data(), tail.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    pos += tail.size();
+    if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
+    *archive_len = pos;
+    c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
     return PNA_OK;
 }
 

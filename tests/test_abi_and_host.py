@@ -115,3 +115,21 @@ def test_solid_store(pna, pf):
     inner = pf.read_solid_inner(items[0].data)
     assert [(e.name, e.data, e.raw_file_size) for e in inner] == [(n, d, len(d)) for n, d in zip(names, ents)]
     assert pna.inner_entry_bytes("a.txt", ents[0]) == pf.write_normal_entry(pf.file_entry_header(0, "a.txt"), [ents[0]], len(ents[0]))
+
+
+def test_device_crc_schedule_matches_crc32(pna):
+    """The lane schedule of k_frame (front padding, init folded into the type bytes, Z_16320 between tiles, fold tree)
+    walked on the host with the kernel's own tables must equal chunk_crc (lib/src/format/chunk.rs:7-12)."""
+    import random
+    import zlib
+    rnd = random.Random(7)
+    for n in [0, 1, 3, 4, 5, 59, 60, 61, 64, 16379, 16380, 16381, 16384, 32764, 32765, 50001, (1 << 20) + 7]:
+        b = rnd.randbytes(n)
+        assert pna.crc_schedule(b) == zlib.crc32(b"FDAT" + b) == pna.crc32(b, pna.crc32(b"FDAT")), n
+
+
+def test_archive_bound_covers_framing(pna):
+    names = ["a/b.txt", "x" * 200]
+    lens = [0, 3 << 20]
+    b = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
+    assert b >= 40 + sum(pna.bound(pna.ALGO_ZSTD, n) + 12 + 6 + len(nm) + 12 + 8 + 12 + 12 for nm, n in zip(names, lens))

@@ -238,3 +238,51 @@ def test_deflate_many_small_entries(gpu_ctx, pna, codec):
         assert zlib.decompress(outs[i]) == ents[i]
         assert outs[i] == codec.deflate_model_compress(ents[i])
     assert all(zlib.decompress(o) == e for o, e in zip(outs[:200], ents[:200]))
+
+
+@pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
+def test_archive_assembled_in_hbm_equals_host_framing(gpu_ctx, pna, pf, codec, algo_name):
+    """pna_gpu_create_archive_device: payloads written at their archive offsets + k_frame (prefix, FDAT CRC, FEND) must give
+    the very bytes pna_create_archive() produces through the host-side chunk writer, and the oracle's reader parses them."""
+    import torch
+    algo = pna.ALGO_ZSTD if algo_name == "zstd" else pna.ALGO_DEFLATE
+    lens = [0, 1, 5, 4095, 16372, 16373, 16384, 70001, 131072, 131073, 300000, (1 << 20), (1 << 20) + 1, 2500000, 12, 65536]
+    ents = [codec.corpus_file(i % 2, 50 + i, n) if n else b"" for i, n in enumerate(lens)]
+    ents[3] = bytes(4095)                                  # rle / tiny payloads shift every later entry to odd offsets
+    names = [f"dir{i % 3}/./f{i:03d}.txt" if i % 4 else f"/abs//n{i}" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    cap = pna.archive_bound(algo, names, lens)
+    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo)
+    got = dst[:total].cpu().numpy().tobytes()
+    want = pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=False)
+    assert len(got) == len(want) and got == want
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16            # nothing written past the archive
+    _, items = pf.read_archive(got)                         # the reader checks every chunk CRC
+    assert [it.name for it in items] == [it.name for it in pf.read_archive(want)[1]]
+    for it, e, o in zip(items, ents, eoff):
+        assert got[o + 4:o + 8] == b"FHED" and it.raw_file_size == len(e)
+        assert codec.decode_payload(algo, it.data, len(e) + 64) == e
+    assert gpu_ctx.timing().ms_frame > 0
+
+
+def test_archive_in_hbm_full_size_crc_property(gpu_ctx, pna, pf):
+    """2048 x 1 MiB in HBM: every chunk CRC of the device-assembled archive verifies (host CRC-32 over all chunks)."""
+    import torch
+    n, L = 2048, 1 << 20
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 7000, n, L, L, src.data_ptr())
+    names = [f"enwik/part{i:05d}" for i in range(n)]
+    cap = pna.archive_bound(pna.ALGO_ZSTD, names, [L] * n)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), [i * L for i in range(n)], [L] * n, dst.data_ptr(), cap)
+    arc = dst[:total].cpu().numpy().tobytes()
+    _, items = pf.read_archive(arc)
+    assert len(items) == n and [it.name for it in items] == names and all(it.raw_file_size == L for it in items)
+    assert eoff[0] == 28 and eoff[-1] + 12 == total
