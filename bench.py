@@ -39,6 +39,19 @@ def usable_cores() -> int:
     return n
 
 
+def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing: str):
+    """HBM bytes per k_lz launch from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh); counters cannot be
+    read from inside this process, so the figure is only reported for the exact workload it was measured on, else null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        w = d["workload"]
+        if (w["files"], w["file_bytes"], w["algo"], w["kind"], w["framing"]) == (n_files, file_len, algo, kind, framing):
+            return d["k_lz"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sample_files: int, file_len: int) -> dict:
     """Reference pipeline restated on the host cores (oracle/cpu_baseline.c): one entry per task, libzstd level 3."""
     from oracle import codec
@@ -188,7 +201,9 @@ def main() -> None:
                        "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
             "ratio": round(in_all / max(out_all, 1), 4),
             "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing),
+                         "algorithmic_bytes": alg_bytes,
                          "kernel_ms": round(lz_ms / args.steps, 3), "all_kernels_ms": round(stage_ms / args.steps, 3)},
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
                                     "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3), "frame": round(tm.ms_frame, 3)},

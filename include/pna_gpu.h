@@ -44,6 +44,8 @@ extern "C" {
 #define PNA_F_DEFAULT 0x80000000u   /* let the library choose */
 
 typedef struct pna_gpu_ctx pna_gpu_ctx;
+/* == W::write of the reference's sink: non-zero return aborts with PNA_E_SINK */
+typedef int (*pna_sink_fn)(void *user, const void *buf, size_t len);
 
 /* One context per (process, GPU).  Replaces the per-entry encoder construction
  * ZstdEncoder::new(writer, level) / ZlibEncoder::new(writer, level) (lib/src/entry/write.rs:257-262). */
@@ -95,9 +97,17 @@ int  pna_gpu_create_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t
                                    void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
                                    void *hip_stream);
 
+/* Same archive from host memory with a bounded in-flight window: entries stream through two page-locked staging slots
+ * (<= ~256 MiB of input each); staging of sub-batch k+1, the H2D copy, the kernels of sub-batch k and the D2H copy of
+ * sub-batch k-1 overlap.  The sink receives the signature + AHED, then one piece per sub-batch, then AEND.  Replaces the
+ * reference's fan-out that keeps every compressed entry in RAM until the rayon scope ends
+ * (cli/src/command/core.rs:496-537, cli/src/command/create.rs:575-635).  pna_create_archive() uses it for non-solid
+ * zstd / deflate archives. */
+int  pna_gpu_create_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                 const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
+
 /* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
  * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write). */
-typedef int (*pna_sink_fn)(void *user, const void *buf, size_t len);
 typedef struct pna_gpu_stream pna_gpu_stream;
 int  pna_gpu_stream_new(pna_gpu_ctx *ctx, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out);
 int  pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len);

@@ -56,7 +56,7 @@ EXPORTS = [
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
-    "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_debug_crc_schedule",
+    "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -383,12 +383,12 @@ def create_archive(ctx: Optional[Context], names: Sequence[str], entries: Sequen
     out = bytearray()
 
     def _sink(_u, buf, k):
-        out.extend(ctypes.string_at(buf, k))
+        out.extend((ctypes.c_char * k).from_address(buf))      # one copy out of the (page-locked) staging buffer
         return 0
     cb = SINK_FN(_sink)
-    bufs = [ctypes.create_string_buffer(bytes(e), max(len(e), 1)) for e in entries]
+    bufs = [e if isinstance(e, bytes) else bytes(e) for e in entries]      # kept alive; passed by pointer, not copied
     a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
-    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
     a_len = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
     rc = L.pna_create_archive(ctx._h if ctx is not None else None, algo, level, 1 if solid else 0, n, a_names, a_src, a_len, cb, None)
     if rc:

@@ -127,7 +127,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     WRes     *wres    = (WRes *)(lds + L_WRES);
     WPub     *wpub    = (WPub *)(lds + L_WPUB);
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = uni(tid >> 6);                  // tell the compiler it is wave-uniform: keeps the parse walks on the scalar unit
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;

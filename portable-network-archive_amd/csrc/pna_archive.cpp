@@ -173,23 +173,14 @@ extern "C" int pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int sol
                                   const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
     if (!sink || (n && (!names || !src || !src_len))) return PNA_E_INVAL;
     if (algo != PNA_ALGO_STORE && !ctx) return PNA_E_NODEVICE;
+    // non-solid compressed archives: pipelined device path, archive bytes (framing + CRC included) come back from the GPU
+    if (!solid && algo != PNA_ALGO_STORE) return pna_gpu_create_archive_host(ctx, algo, level, n, names, src, src_len, sink, user);
     pna_archive *a = nullptr;
     int rc = pna_archive_new(sink, user, 0, &a);
     if (rc) return rc;
     if (!solid) {
-        std::vector<std::vector<uint8_t>> out(n);
-        if (algo != PNA_ALGO_STORE) {
-            std::vector<void *> dst(n); std::vector<size_t> cap(n), dl(n);
-            for (size_t i = 0; i < n; i++) { out[i].resize(pna_gpu_bound(algo, src_len[i])); dst[i] = out[i].data(); cap[i] = out[i].size(); }
-            rc = pna_gpu_compress_batch(ctx, algo, level, n, src, src_len, dst.data(), cap.data(), dl.data());
-            if (rc) { pna_archive_abort(a); return rc; }
-            for (size_t i = 0; i < n; i++) out[i].resize(dl[i]);
-        }
-        for (size_t i = 0; i < n && !rc; i++) {               // drain_entry_results: index order, core.rs:471-493
-            const void *p = algo == PNA_ALGO_STORE ? src[i] : out[i].data();
-            size_t l = algo == PNA_ALGO_STORE ? src_len[i] : out[i].size();
-            rc = pna_archive_add_file(a, names[i], algo, (int64_t)src_len[i], p, l, 0);
-        }
+        for (size_t i = 0; i < n && !rc; i++)                 // STORE; drain_entry_results: index order, core.rs:471-493
+            rc = pna_archive_add_file(a, names[i], algo, (int64_t)src_len[i], src[i], src_len[i], 0);
     } else {
         // solid: inner entries are STORE (create.rs:594-598), serialised as chunk bytes, then ONE compressed stream
         std::vector<uint8_t> plain;

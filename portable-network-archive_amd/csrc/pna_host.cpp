@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <thread>
 #include "pna_dev.h"
 #include "../../include/pna_gpu.h"
 
@@ -76,6 +77,11 @@ struct pna_gpu_ctx {
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
+    // pipelined host path (pna_gpu_create_archive_host): two slots of staging
+    PinBuf hp_in[2], hp_out[2];
+    DevBuf dp_in[2], dp_out[2];
+    hipStream_t cp_in = nullptr, cp_out = nullptr;
+    hipEvent_t ev_in[2] = {}, ev_out[2] = {};
     bool crc_ready = false;
     bool corpus_ready = false;
     std::string err;
@@ -130,7 +136,11 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs}) b->release();
-    for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff}) b->release();
+    for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
+    for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
+    for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
+    if (c->cp_in) (void)hipStreamDestroy(c->cp_in);
+    if (c->cp_out) (void)hipStreamDestroy(c->cp_out);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -432,6 +442,120 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
     if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
     *archive_len = pos;
     c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host-memory `pna create` (non-solid), bounded memory: the entries stream through two staging slots of at most
+// ~256 MiB of input each.  While the GPU compresses and frames sub-batch k, helper threads stage sub-batch k+1 into
+// page-locked memory and its H2D copy runs on a second stream; the archive bytes of sub-batch k-1 travel back on a
+// third stream and are handed to the sink in one piece.  Replaces the reference's "every compressed entry in RAM until
+// the scope ends" (cli/src/command/core.rs:496-537, create.rs:575-635) with a fixed in-flight window.
+static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *src_len, const uint64_t *off, size_t e0, size_t e1, unsigned threads) {
+    uint64_t total = 0;
+    for (size_t e = e0; e < e1; e++) total += src_len[e];
+    if (threads <= 1 || total < (8u << 20)) { for (size_t e = e0; e < e1; e++) if (src_len[e]) memcpy(dst + off[e], src[e], src_len[e]); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (total + threads - 1) / threads;
+    size_t e = e0;
+    for (unsigned t = 0; t < threads && e < e1; t++) {
+        size_t b = e; uint64_t acc = 0;
+        while (e < e1 && (acc < per || t + 1 == threads)) acc += src_len[e++];
+        th.emplace_back([=]() { for (size_t i = b; i < e; i++) if (src_len[i]) memcpy(dst + off[i], src[i], src_len[i]); });
+    }
+    for (auto &x : th) x.join();
+}
+
+extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                           const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
+    (void)level;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->cp_in) {
+        HIPCHK(c, hipStreamCreate(&c->cp_in)); HIPCHK(c, hipStreamCreate(&c->cp_out));
+        for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)); }
+    }
+    c->timing = pna_gpu_timing{};
+    std::vector<uint8_t> head, tail; frame_archive_head(head, 0); frame_archive_tail(tail);
+    if (sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    // sub-batches of at most SUB input bytes (an entry larger than that is a sub-batch of its own)
+    const uint64_t SUB = 256ull << 20;
+    struct Sub { size_t e0, e1; uint64_t in_bytes, out_cap; };
+    std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
+    for (size_t e = 0; e < n;) {
+        Sub sb{e, e, 0, 64}; uint64_t pos = 0; size_t blocks = 0;
+        while (sb.e1 < n) {
+            const size_t i = sb.e1; const uint64_t l = src_len[i];
+            const size_t nb = (size_t)((l + BLK_SIZE - 1) / BLK_SIZE);
+            if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
+            off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
+            sb.out_cap += frame_entry_prefix_bound(names[i]) + pna_gpu_bound(algo, (size_t)l) + 16;
+            sb.e1++;
+        }
+        sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned threads = std::min(8u, std::max(1u, hw / 2));
+    FrameJob fj{names};
+    std::vector<uint64_t> eoff(n + 1);
+    uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
+    for (size_t e = 0; e < n; e++) in_total += src_len[e];
+    auto ensure_slot = [&](size_t k) -> int {
+        const Sub &sb = subs[k]; const int sl = (int)(k & 1);
+        if (c->hp_in[sl].ensure(sb.in_bytes + 8192) || c->dp_in[sl].ensure(sb.in_bytes + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+        return PNA_OK;
+    };
+    int rc = PNA_OK;
+    std::thread stager; int stager_rc = PNA_OK;
+    if (!subs.empty()) {
+        rc = ensure_slot(0); if (rc) return rc;
+        parallel_stage((uint8_t *)c->hp_in[0].p, src, src_len, off.data(), subs[0].e0, subs[0].e1, threads);
+        HIPCHK(c, hipMemcpyAsync(c->dp_in[0].p, c->hp_in[0].p, subs[0].in_bytes, hipMemcpyHostToDevice, c->cp_in));
+        HIPCHK(c, hipEventRecord(c->ev_in[0], c->cp_in));
+    }
+    for (size_t k = 0; k < subs.size() && rc == PNA_OK; k++) {
+        const Sub &sb = subs[k]; const int sl = (int)(k & 1);
+        if (k + 1 < subs.size()) {                               // stage the next sub-batch while the GPU works on this one
+            stager_rc = ensure_slot(k + 1);
+            if (stager_rc == PNA_OK) {
+                const Sub nx = subs[k + 1]; uint8_t *hb = (uint8_t *)c->hp_in[sl ^ 1].p;
+                stager = std::thread([=, &off]() { parallel_stage(hb, src, src_len, off.data(), nx.e0, nx.e1, threads); });
+            }
+        }
+        if (c->dp_out[sl].ensure(sb.out_cap + 64) || c->hp_out[sl].ensure(sb.out_cap + 64)) rc = fail(c, PNA_E_NOMEM, "staging allocation failed");
+        if (rc == PNA_OK && hipEventSynchronize(c->ev_in[sl]) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
+        if (rc == PNA_OK)
+            rc = run_subbatch(c, algo, (const uint8_t *)c->dp_in[sl].p, off.data(), len64.data(), sb.e0, sb.e1, (uint8_t *)c->dp_out[sl].p,
+                              sb.out_cap + 64, 0, eoff.data(), c->stream, true, &fj);
+        if (rc == PNA_OK) {
+            out_len[sl] = eoff[sb.e1];
+            if (hipMemcpyAsync(c->hp_out[sl].p, c->dp_out[sl].p, out_len[sl], hipMemcpyDeviceToHost, c->cp_out) != hipSuccess ||
+                hipEventRecord(c->ev_out[sl], c->cp_out) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+        }
+        if (stager.joinable()) stager.join();
+        if (rc == PNA_OK && stager_rc != PNA_OK) rc = stager_rc;
+        if (rc == PNA_OK && k + 1 < subs.size()) {
+            if (hipMemcpyAsync(c->dp_in[sl ^ 1].p, c->hp_in[sl ^ 1].p, subs[k + 1].in_bytes, hipMemcpyHostToDevice, c->cp_in) != hipSuccess ||
+                hipEventRecord(c->ev_in[sl ^ 1], c->cp_in) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
+        }
+        if (rc == PNA_OK && k > 0) {                             // archive bytes of the previous sub-batch -> sink
+            if (hipEventSynchronize(c->ev_out[sl ^ 1]) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+            else if (out_len[sl ^ 1] && sink(user, c->hp_out[sl ^ 1].p, out_len[sl ^ 1]) != 0) rc = fail(c, PNA_E_SINK, "sink failed");
+            out_total += out_len[sl ^ 1];
+        }
+    }
+    if (stager.joinable()) stager.join();
+    if (rc != PNA_OK) { (void)hipDeviceSynchronize(); return rc; }
+    if (!subs.empty()) {
+        const int sl = (int)((subs.size() - 1) & 1);
+        HIPCHK(c, hipEventSynchronize(c->ev_out[sl]));
+        if (out_len[sl] && sink(user, c->hp_out[sl].p, out_len[sl]) != 0) return fail(c, PNA_E_SINK, "sink failed");
+        out_total += out_len[sl];
+    }
+    if (sink(user, tail.data(), tail.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    out_total += tail.size();
+    c->timing.in_bytes = in_total; c->timing.out_bytes = out_total;
     return PNA_OK;
 }
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# SQ issue/wait breakdown of the kernels (one pass, 8 SQ slots).  Run on the GPU box from the repo root.
+set -u
+FILES=${1:-2048}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/pmc_sq
+mkdir -p "$OUT"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES \
+  --kernel-trace --output-format csv -d "$OUT" -o sq -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT.log" 2>&1
+tail -1 "$OUT.log" | cut -c1-120
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys
+from collections import defaultdict
+res = defaultdict(dict)
+for p in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(p)):
+        k = row["Kernel_Name"].split("(")[0]
+        res[k][row["Counter_Name"]] = res[k].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+for k, v in res.items():
+    if "pna" not in k: continue
+    wc = v.get("SQ_WAVE_CYCLES", 1) or 1
+    print(k, {n: round(x / wc, 3) for n, x in v.items() if n != "SQ_WAVE_CYCLES"}, "wave_cycles", wc)
+PY

@@ -261,8 +261,23 @@ def test_archive_assembled_in_hbm_equals_host_framing(gpu_ctx, pna, pf, codec, a
     dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
     total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo)
     got = dst[:total].cpu().numpy().tobytes()
-    want = pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=False)
+    # expected bytes, built without k_frame: payloads from the batch API, framing by (1) the oracle's container writer
+    # and (2) the host chunk writer of include/pna_archive.h (host CRC-32)
+    payloads = gpu_ctx.compress_batch(ents, algo=algo)
+    want = pf.write_archive_header() + b"".join(
+        pf.write_normal_entry(pf.file_entry_header(algo, pf.sanitize_name(nm)), [pl], len(e)) for nm, pl, e in zip(names, payloads, ents)
+    ) + pf.finalize_archive()
+
+    class Sink:
+        def __init__(self): self.parts = []
+        def write(self, b): self.parts.append(b)
+    sk = Sink(); arc = pna.Archive(sk)
+    for nm, pl, e in zip(names, payloads, ents):
+        arc.add_file(nm, algo, len(e), pl)
+    arc.finalize()
+    assert b"".join(sk.parts) == want
     assert len(got) == len(want) and got == want
+    assert pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=False) == want      # pipelined host path, one sub-batch
     assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16            # nothing written past the archive
     _, items = pf.read_archive(got)                         # the reader checks every chunk CRC
     assert [it.name for it in items] == [it.name for it in pf.read_archive(want)[1]]
@@ -286,3 +301,33 @@ def test_archive_in_hbm_full_size_crc_property(gpu_ctx, pna, pf):
     _, items = pf.read_archive(arc)
     assert len(items) == n and [it.name for it in items] == names and all(it.raw_file_size == L for it in items)
     assert eoff[0] == 28 and eoff[-1] + 12 == total
+
+
+def test_host_pipeline_many_sub_batches(gpu_ctx, pna, pf, codec):
+    """pna_gpu_create_archive_host with > 256 MiB of input: several staging slots in flight, sink pieces in order,
+    result identical to the one-shot in-HBM archive of the same entries."""
+    import torch
+    n, L = 700, 1 << 20
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 300, n, L, L, src.data_ptr())
+    host = src[:n * L].cpu().numpy()
+    ents = [host[i * L:(i + 1) * L].tobytes() for i in range(n)]
+    ents[5] = b""; ents[6] = ents[6][:12345]
+    names = [f"p/{i:04d}" for i in range(n)]
+    arc = pna.create_archive(gpu_ctx, names, ents)
+    _, items = pf.read_archive(arc)
+    assert [it.name for it in items] == names and [it.raw_file_size for it in items] == [len(e) for e in ents]
+    for i in (0, 5, 6, 255, 256, 257, 511, 512, 699):
+        assert codec.decode_payload(2, items[i].data, L + 64) == ents[i]
+    lens = [len(e) for e in ents]
+    offs, pos = [], 0
+    for l in lens:
+        offs.append(pos); pos = (pos + l + 15) & ~15
+    dsrc = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            dsrc[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    cap = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, _ = gpu_ctx.create_archive_device(names, dsrc.data_ptr(), offs, lens, dst.data_ptr(), cap)
+    assert dst[:total].cpu().numpy().tobytes() == arc
