@@ -2,8 +2,8 @@
 //   k_dstats  one workgroup per segment: lit/len (286) + distance (30) histograms over all the segment's blocks, then
 //             thread 0: Huffman lengths (<= 15), canonical bit-reversed codes, dynamic-block table description.
 //   k_adler   one workgroup per block: Adler-32 halves of the block's input (combined per entry in k_dfinal).
-//   k_dblock  one LANE per block, the 8 blocks of a segment sharing its code tables in LDS: serial LSB-first packing
-//             of header + literals + (length, distance) pairs + EOB (+ the sync-flush header bits).
+//   k_dblock  one workgroup per block, token-parallel inside k_lz's 2 KiB tiles: header + literals + (length, distance)
+//             pairs + EOB (+ the sync-flush header bits) placed by two packed prefix scans per tile, staged in LDS.
 //   k_dplan   one thread per segment: dynamic vs stored per block, sizes.
 //   k_dwrite  one workgroup per block: payload (or stored blocks) + sync flush into the packed output.
 //   k_dfinal  one thread per entry: 78 9C header, Adler-32 trailer (combine over blocks), empty entries.
@@ -201,118 +201,196 @@ void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     if (tid == 0) { blk[g].adler_a = (uint32_t)((1 + r1[0]) % ADLER_P); blk[g].adler_b = (uint32_t)((n + r2[0]) % ADLER_P); }
 }
 
-// ------------------------------------------------------------------ k_dblock : one WAVE per block, one lane per tile
-// k_lz's chunk table gives, for each 2 KiB tile of the block, the sequence / literal stream positions at the tile start
-// and the literal index of the tile's first match, so lane t can encode the elements that belong to tile t on its own:
-// pass 1 counts its bits, a wave scan places the pieces, pass 2 ORs them into the zeroed output at their bit offsets.
-constexpr uint32_t DB_THREADS = BLK_SIZE / TILE;            // one lane per tile of the block
+// ------------------------------------------------------------------ k_dblock : one workgroup per block, token-parallel
+// The block's tiles (k_lz's 2 KiB parse tiles) are packed one after the other by all 256 threads; inside a tile every
+// literal and every match is placed independently.  k_lz's chunk table gives the sequence / literal stream positions at the
+// tile start and the literal index of the tile's first match.  With literal SLOT s = local literal index, a match sits in
+// the slot of the literal that follows it (slot nl = after the tile's last literal), so in stream order a slot is
+// [its matches..., its literal].  One packed scan over the sequences yields (slot, Mx = match bits before this match),
+// one packed scan over the slots yields (Lx = literal bits before the slot, match bits in earlier slots):
+//     literal s at  base + Lx[s] + Mb[<s] + wm[s]          match k at  base + Lx[slot(k)] + Mx[k]
+// Tokens are ORed into an LDS staging area (64-bit units) and flushed with coalesced stores; the partial unit at the tile
+// end is carried into the next tile, so the global stream is written exactly once and never read.
+constexpr uint32_t DB_THREADS = 256;
+constexpr uint32_t DB_STAGE = 768;                           // u64 units: 2048 x 15 + 342 x 48 bits per tile + carry
+static_assert(TILE == 2048 && TILE / MIN_MATCH <= 2 * DB_THREADS, "k_dblock handles two sequences and eight literal slots per thread and tile");
+
+#define DB_ROW_SHR(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (k), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t db_wave_scan(uint32_t v, uint32_t lane) {     // inclusive, 64 lanes, VALU only
+    v += DB_ROW_SHR(v, 1); v += DB_ROW_SHR(v, 2); v += DB_ROW_SHR(v, 4); v += DB_ROW_SHR(v, 8);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = lane >> 4;
+    return v + (row > 0 ? r0 : 0u) + (row > 1 ? r1 : 0u) + (row > 2 ? r2 : 0u);
+}
+// inclusive scan over the workgroup's 256 threads (one barrier); total = sum over all threads
+__device__ __forceinline__ uint32_t db_wg_scan(uint32_t v, uint32_t *wsum, uint32_t tid, uint32_t &total) {
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    uint32_t sc = db_wave_scan(v, lane);
+    if (lane == 63) wsum[wave] = sc;
+    __syncthreads();
+    const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+    total = w0 + w1 + w2 + w3;
+    return sc + (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+}
+__device__ __forceinline__ void db_put(unsigned long long *st, uint32_t off, unsigned long long v, uint32_t n) {
+    if (!n) return;
+    const uint32_t u = off >> 6, sh = off & 63;
+    atomicOr(&st[u], v << sh);
+    if (sh + n > 64) atomicOr(&st[u + 1], v >> (64 - sh));
+}
+
 __global__ __launch_bounds__(DB_THREADS)
 void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs,
               const uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, const uint4 *__restrict__ ctab,
               const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc, uint32_t dbg) {
     __shared__ uint32_t t_ll[288];
     __shared__ uint32_t t_d[32];
-    __shared__ uint32_t wtot[(DB_THREADS + 63) / 64 + 1];
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;        // "lane" = piece index 0..127 (two waves)
+    __shared__ uint32_t wm[TILE + 8];                        // match bits per literal slot
+    __shared__ uint32_t scanx[TILE + 8];                     // exclusive packed scan per slot: literal bits | match bits << 16
+    __shared__ uint32_t litbuf[TILE / 4 + 8];
+    __shared__ unsigned long long stage[DB_STAGE];
+    __shared__ uint32_t wsum1[4], wsum2[4];
+    (void)dbg;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
     const uint32_t sidx = blk_seg[g];
     const SegDesc sd = segs[sidx];
     const DeflTables *T = tabs + sidx;
-    for (uint32_t i = lane; i < 288; i += DB_THREADS) t_ll[i] = T->ll_code[i];
-    if (lane < 32) t_d[lane] = T->d_code[lane];
-    __syncthreads();
+    for (uint32_t i = tid; i < 288; i += DB_THREADS) t_ll[i] = T->ll_code[i];
+    if (tid < 32) t_d[tid] = T->d_code[tid];
+    for (uint32_t i = tid; i < DB_STAGE; i += DB_THREADS) stage[i] = 0;
+    for (uint32_t i = tid; i < TILE + 8; i += DB_THREADS) wm[i] = 0;
     const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
     const uint32_t bl_len = sd.len - b * BLK_SIZE < BLK_SIZE ? sd.len - b * BLK_SIZE : BLK_SIZE;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     const uint32_t ntile = (bl_len + TILE - 1) / TILE;
     const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
-    const bool act = lane < ntile;
-    uint32_t s0 = 0, s1 = 0, l0 = 0, l1 = 0, gf = 0;
-    if (act) {
-        const uint4 c = ctab[(size_t)g * (BLK_SIZE / TILE) + lane];
-        s0 = c.x; l0 = c.y; gf = c.z;
-        if (lane + 1 < ntile) { const uint4 cn = ctab[(size_t)g * (BLK_SIZE / TILE) + lane + 1]; s1 = cn.x; l1 = cn.y; }
-        else { s1 = nseq; l1 = nlit; }
-        if (s0 == s1) gf = l1;
-    }
     const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
-    const uint32_t *bl32 = (const uint32_t *)bl;
     const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    uint32_t *out32 = (uint32_t *)(outc + (size_t)g * BLK_SIZE);
-    const uint32_t hdr_total = 3 + T->hdr_bits;
-    const uint32_t eob = t_ll[256];
+    unsigned long long *out64 = (unsigned long long *)(outc + (size_t)g * BLK_SIZE);
+    const uint32_t hdr_bits = T->hdr_bits;
+    __syncthreads();
 
-    // walk of this lane's elements; EMIT = false only counts bits
-    uint64_t acc = 0; uint32_t nb = 0, widx = 0, bits = 0;
-    auto run = [&](bool emit) {
-        uint32_t sblk = 0;
-        auto put = [&](uint32_t v, uint32_t n) {
-            if (!emit) { bits += n; return; }
-            acc |= (uint64_t)v << nb; nb += n;
-            if (nb >= 32) { if (dbg & 0x800) out32[widx++] = (uint32_t)acc; else atomicOr(&out32[widx++], (uint32_t)acc); acc >>= 32; nb -= 32; }
-        };
-        if (lane == 0) {
-            put(last ? 1u : 0u, 1); put(2, 2);
-            uint32_t hb = T->hdr_bits, i = 0;
-            while (hb >= 8) { put(T->hdr[i++], 8); hb -= 8; }
-            if (hb) put(T->hdr[i] & ((1u << hb) - 1), hb);
-        }
-        // literal and sequence streams are read through 16-byte double buffers: the next block is requested one block
-        // ahead, so a lane waits for memory once per 16 literals / 2 sequences instead of once per element
-        const uint4 *bl16 = (const uint4 *)bl;
-        const uint4 *bs16 = (const uint4 *)bs;
-        uint32_t li = l0;
-        uint4 lcur = make_uint4(0, 0, 0, 0), lnxt = lcur, scur = lcur, snxt = lcur;
-        if (act) { lcur = bl16[li >> 4]; lnxt = bl16[(li >> 4) + 1]; scur = bs16[s0 >> 1]; snxt = bs16[(s0 >> 1) + 1]; }
-        auto lit_run = [&](uint32_t end) {
-            while (li < end) {
-                const uint32_t q4 = (li >> 2) & 3;
-                const uint32_t w = q4 == 0 ? lcur.x : (q4 == 1 ? lcur.y : (q4 == 2 ? lcur.z : lcur.w));
-                const uint32_t c = t_ll[(w >> (8 * (li & 3))) & 0xFF]; li++;
-                if ((li & 15) == 0) { lcur = lnxt; lnxt = bl16[(li >> 4) + 1]; }
-                put(c & 0xFFFF, c >> 16);
-            }
-        };
-        auto seq_at = [&](uint32_t k) -> uint64_t {          // k is the stream position: only k and k+1 are ever asked for
-            const bool hi = (k >> 1) != (s0 >> 1) + sblk;
-            const uint4 v = hi ? snxt : scur;
-            return (k & 1) ? ((uint64_t)v.z | ((uint64_t)v.w << 32)) : ((uint64_t)v.x | ((uint64_t)v.y << 32));
-        };
-        if (act) {
-            lit_run(gf);
-            for (uint32_t k = s0; k < s1; k++) {
-                if ((k >> 1) != (s0 >> 1) + sblk) { sblk++; scur = snxt; snxt = bs16[(s0 >> 1) + sblk + 1]; }
-                const uint64_t s = seq_at(k);
-                uint32_t c, eb, ev;
-                len_sym(seq_ml(s), c, eb, ev);
-                const uint32_t lc = t_ll[257 + c]; put(lc & 0xFFFF, lc >> 16); put(ev, eb);
-                dist_sym(seq_off(s), c, eb, ev);
-                const uint32_t dcv = t_d[c]; put(dcv & 0xFFFF, dcv >> 16); put(ev, eb);
-                if (k + 1 < s1) lit_run(li + seq_ll(seq_at(k + 1)));
-            }
-            lit_run(l1);
-            if (lane + 1 == ntile) { put(eob & 0xFFFF, eob >> 16); if (!last) put(0, 3); }
-        }
+    // block header: BFINAL, BTYPE = 2, then the table description (one byte per thread)
+    if (tid == 0) db_put(stage, 0, (last ? 1u : 0u) | (2u << 1), 3);
+    for (uint32_t i = tid; i * 8 < hdr_bits; i += DB_THREADS) {
+        const uint32_t n = hdr_bits - 8 * i < 8 ? hdr_bits - 8 * i : 8;
+        db_put(stage, 3 + 8 * i, (unsigned long long)(T->hdr[i] & ((1u << n) - 1)), n);
+    }
+    uint32_t bitpos = 3 + hdr_bits;                          // bits produced so far (uniform)
+    uint32_t flushed = 0;                                    // 64-bit units already stored to global
+
+    // flush the complete units of the staging area, carry the partial one to its front, clear the rest and the slots
+    auto flush = [&](uint32_t nslots) {
+        __syncthreads();
+        const uint32_t nfull = (bitpos >> 6) - flushed;
+        for (uint32_t i = tid; i < nfull; i += DB_THREADS) if (flushed + i < BLK_SIZE / 8) out64[flushed + i] = stage[i];
+        const unsigned long long carry = stage[nfull];
+        __syncthreads();
+        for (uint32_t i = tid; i <= nfull + 1 && i < DB_STAGE; i += DB_THREADS) stage[i] = i == 0 ? carry : 0ull;
+        for (uint32_t i = tid; i <= nslots; i += DB_THREADS) wm[i] = 0;
+        flushed += nfull;
+        __syncthreads();
     };
-    run(false);
-    // inclusive scan of the pieces' bit counts over the two waves
-    uint32_t sc = bits;
+    flush(0);
+
+    for (uint32_t t = 0; t < ntile; t++) {
+        const uint4 c = ctab[(size_t)g * (BLK_SIZE / TILE) + t];
+        const uint32_t s0 = c.x, l0 = c.y;
+        uint32_t s1 = nseq, l1 = nlit;
+        if (t + 1 < ntile) { const uint4 cn = ctab[(size_t)g * (BLK_SIZE / TILE) + t + 1]; s1 = cn.x; l1 = cn.y; }
+        const uint32_t ns = s1 - s0, nl = l1 - l0;
+        const uint32_t gf = (ns ? c.z : l1) - l0;            // slot of the tile's first match
+        const uint32_t base = bitpos - (flushed << 6);      // staging bit offset of the tile's first token
+
+        // literal bytes of the tile -> LDS (aligned dword loads)
+        const uint32_t a0 = l0 & ~3u, ndw = nl ? ((l1 + 3 - a0) >> 2) : 0u;
+        for (uint32_t i = tid; i < ndw; i += DB_THREADS) litbuf[i] = *(const uint32_t *)(bl + a0 + 4 * i);
+
+        // ---- sequences: two per thread
+        uint32_t mb[2] = {0, 0}, inc[2] = {0, 0};
+        unsigned long long tok[2] = {0, 0};
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)sc, d); if ((lane & 63) >= (uint32_t)d) sc += t; }
-    if ((lane & 63) == 63) wtot[lane >> 6] = sc;
+        for (int r = 0; r < 2; r++) {
+            const uint32_t k = 2 * tid + r;
+            if (k < ns) {
+                const uint64_t s = bs[s0 + k];
+                uint32_t lc_i, leb, lev, dc_i, deb, dev;
+                len_sym(seq_ml(s), lc_i, leb, lev);
+                dist_sym(seq_off(s), dc_i, deb, dev);
+                const uint32_t lc = t_ll[257 + lc_i], dc = t_d[dc_i];
+                const uint32_t ln = lc >> 16, dn = dc >> 16;
+                unsigned long long v = lc & 0xFFFF; uint32_t n = ln;
+                v |= (unsigned long long)lev << n; n += leb;
+                v |= (unsigned long long)(dc & 0xFFFF) << n; n += dn;
+                v |= (unsigned long long)dev << n; n += deb;
+                tok[r] = v; mb[r] = n;
+                inc[r] = k == 0 ? gf : seq_ll(s);
+            }
+        }
+        uint32_t tot1;
+        const uint32_t p1 = (inc[0] + inc[1]) | ((mb[0] + mb[1]) << 16);
+        const uint32_t ex1 = db_wg_scan(p1, wsum1, tid, tot1) - p1;
+        const uint32_t slot0 = (ex1 & 0xFFFF) + inc[0], slot1 = slot0 + inc[1];
+        const uint32_t mx0 = ex1 >> 16, mx1 = mx0 + mb[0];
+        if (mb[0]) atomicAdd(&wm[slot0], mb[0]);
+        if (mb[1]) atomicAdd(&wm[slot1], mb[1]);
+        __syncthreads();
+
+        // ---- literal slots: eight per thread
+        uint32_t code[8], wmv[8];
+        uint32_t lsum = 0, msum = 0;
+        {
+            const uint32_t bo = (l0 - a0) + tid * 8;       // byte offset of this thread's first literal in litbuf
+            const uint32_t d0 = bo >> 2, sh = (bo & 3) * 8;
+            const uint32_t w0 = litbuf[d0], w1 = litbuf[d0 + 1], w2 = litbuf[d0 + 2];
+            const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t sl = tid * 8 + i;
+                const uint32_t byte = ((i < 4 ? x0 : x1) >> (8 * (i & 3))) & 0xFF;
+                code[i] = sl < nl ? t_ll[byte] : 0u;
+                wmv[i] = wm[sl];
+                lsum += code[i] >> 16; msum += wmv[i];
+            }
+        }
+        uint32_t tot2;
+        const uint32_t p2 = lsum | (msum << 16);
+        uint32_t run = db_wg_scan(p2, wsum2, tid, tot2) - p2;
+        {
+            unsigned long long acc = 0; uint32_t nacc = 0, aoff = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t sl = tid * 8 + i;
+                scanx[sl] = run;
+                const uint32_t ln = code[i] >> 16;
+                if (wmv[i] && nacc) { db_put(stage, aoff, acc, nacc); acc = 0; nacc = 0; }
+                if (ln) {
+                    if (!nacc) aoff = base + (run & 0xFFFF) + (run >> 16) + wmv[i];
+                    acc |= (unsigned long long)(code[i] & 0xFFFF) << nacc; nacc += ln;
+                    if (nacc > 48) { db_put(stage, aoff, acc, nacc); acc = 0; nacc = 0; }
+                }
+                run += ln | (wmv[i] << 16);
+            }
+            if (nacc) db_put(stage, aoff, acc, nacc);
+            if (tid == DB_THREADS - 1) scanx[TILE] = run;
+        }
+        __syncthreads();
+
+        // ---- matches
+        if (mb[0]) db_put(stage, base + (scanx[slot0] & 0xFFFF) + mx0, tok[0], mb[0]);
+        if (mb[1]) db_put(stage, base + (scanx[slot1] & 0xFFFF) + mx1, tok[1], mb[1]);
+        bitpos += (tot2 & 0xFFFF) + (tot1 >> 16);
+        flush(nl);
+    }
+    // end of block, and the empty stored block header of the sync flush when more blocks follow
+    if (tid == 0) { const uint32_t eob = t_ll[256]; db_put(stage, bitpos - (flushed << 6), eob & 0xFFFF, eob >> 16); }
+    bitpos += (t_ll[256] >> 16) + (last ? 0u : 3u);
     __syncthreads();
-    uint32_t total_bits = 0;
-    for (uint32_t w = 0; w < (DB_THREADS + 63) / 64; w++) { if (w < (lane >> 6)) sc += wtot[w]; total_bits += wtot[w]; }
-    const uint32_t bytes = (total_bits + 7) / 8;
-    if (lane == 0) blk[g].lit_body = bytes;
-    (void)hdr_total;
-    if (bytes > BLK_SIZE) return;                                   // k_dplan falls back to stored blocks
-    for (uint32_t i = lane; i < (bytes + 3) / 4; i += DB_THREADS) out32[i] = 0;
-    __builtin_amdgcn_s_waitcnt(0);                                  // zeros are in L2 before the atomic ORs are issued
-    __syncthreads();
-    const uint32_t start = sc - bits;
-    widx = start >> 5; nb = start & 31; acc = 0;
-    if (!(dbg & 0x400)) run(true);
-    if (nb) atomicOr(&out32[widx], (uint32_t)acc);
+    const uint32_t bytes = (bitpos + 7) / 8;
+    const uint32_t nun = (bitpos + 63) / 64 - flushed;
+    for (uint32_t i = tid; i < nun; i += DB_THREADS) if (flushed + i < BLK_SIZE / 8) out64[flushed + i] = stage[i];
+    if (tid == 0) blk[g].lit_body = bytes;
 }
 
 // ------------------------------------------------------------------ k_dplan : one thread per segment
