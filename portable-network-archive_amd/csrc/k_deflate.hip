@@ -39,57 +39,88 @@ __device__ __forceinline__ void dw_add(DBitW &w, uint32_t v, uint32_t n) {
     while (w.nb >= 8) { w.p[w.pos++] = (uint8_t)w.acc; w.acc >>= 8; w.nb -= 8; }
 }
 
-// code lengths <= maxlen (two-queue Huffman + Kraft repair; identical procedure to the zstd literal code)
-__device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint8_t *depth) {
-    int n = 0;
-    for (int s = 0; s < nsym; s++) { lens[s] = 0; if (count[s]) order[n++] = (uint16_t)s; }
+// code lengths <= maxlen (two-queue Huffman + Kraft repair; identical procedure to the zstd literal code), executed by the
+// whole workgroup: stable rank sort by count and the leaf depths are parallel, the two-queue merge (n - 1 dependent steps)
+// and the rare Kraft repair stay on thread 0.  Every thread of the workgroup must call it; returns the number of used symbols.
+__device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent,
+                            uint32_t *sh /* [2] scratch */, uint32_t tid, uint32_t nthr) {
+    if (tid == 0) { sh[0] = 0; sh[1] = 0; }
+    __syncthreads();
+    for (int s = (int)tid; s < nsym; s += (int)nthr) {
+        lens[s] = 0;
+        const uint32_t c = count[s];
+        if (!c) continue;
+        uint32_t rank = 0;
+        for (int o = 0; o < nsym; o++) { const uint32_t co = count[o]; rank += (co != 0 && (co < c || (co == c && o < s))) ? 1u : 0u; }
+        order[rank] = (uint16_t)s;
+        atomicAdd(&sh[0], 1u);
+    }
+    __syncthreads();
+    const int n = (int)sh[0];
     if (n == 0) return 0;
-    if (n == 1) { lens[order[0]] = 1; return 1; }
-    for (int i = 1; i < n; i++) { uint16_t x = order[i]; int j = i - 1; while (j >= 0 && count[order[j]] > count[x]) { order[j + 1] = order[j]; j--; } order[j + 1] = x; }
-    for (int i = 0; i < n; i++) wt[i] = count[order[i]];
-    int lq = 0, iq = n, nn = n;
-    while (nn < 2 * n - 1) {
-        int a, b;
-        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
-        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
-        wt[nn] = wt[a] + wt[b]; parent[a] = (uint16_t)nn; parent[b] = (uint16_t)nn; nn++;
+    if (n == 1) { if (tid == 0) lens[order[0]] = 1; __syncthreads(); return 1; }
+    for (int i = (int)tid; i < n; i += (int)nthr) wt[i] = count[order[i]];
+    __syncthreads();
+    const int nn = 2 * n - 1;
+    if (tid == 0) {
+        int lq = 0, iq = n, m = n;
+        while (m < nn) {
+            int a, b;
+            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
+            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
+            wt[m] = wt[a] + wt[b]; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; m++;
+        }
     }
-    depth[nn - 1] = 0;
-    for (int i = nn - 2; i >= 0; i--) depth[i] = (uint8_t)(depth[parent[i]] + 1);
-    bool over = false;
-    for (int i = 0; i < n; i++) { int d = depth[i]; if (d > maxlen) { d = maxlen; over = true; } lens[order[i]] = (uint8_t)d; }
-    if (!over) return n;
-    int K = 0;
-    for (int i = 0; i < n; i++) K += 1 << (maxlen - lens[order[i]]);
-    int debt = K - (1 << maxlen);
-    while (debt > 0) {
-        int pick = -1, bl = 0;
-        for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < maxlen && l > bl) { bl = l; pick = i; } }
-        lens[order[pick]]++; debt -= 1 << (maxlen - 1 - bl);
+    __syncthreads();
+    for (int i = (int)tid; i < n; i += (int)nthr) {
+        int d = 0, q = i;
+        while (q != nn - 1) { q = parent[q]; d++; }
+        if (d > maxlen) { d = maxlen; sh[1] = 1; }
+        lens[order[i]] = (uint8_t)d;
     }
-    while (debt < 0) {
-        int pick = -1, bl = 99, slack = -debt;
-        for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (maxlen - l)) <= slack && l < bl) { bl = l; pick = i; } }
-        if (pick < 0) break;
-        lens[order[pick]]--; debt += 1 << (maxlen - bl);
+    __syncthreads();
+    if (sh[1] && tid == 0) {
+        int K = 0;
+        for (int i = 0; i < n; i++) K += 1 << (maxlen - lens[order[i]]);
+        int debt = K - (1 << maxlen);
+        while (debt > 0) {
+            int pick = -1, bl = 0;
+            for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < maxlen && l > bl) { bl = l; pick = i; } }
+            lens[order[pick]]++; debt -= 1 << (maxlen - 1 - bl);
+        }
+        while (debt < 0) {
+            int pick = -1, bl = 99, slack = -debt;
+            for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (maxlen - l)) <= slack && l < bl) { bl = l; pick = i; } }
+            if (pick < 0) break;
+            lens[order[pick]]--; debt += 1 << (maxlen - bl);
+        }
     }
+    __syncthreads();
     return n;
 }
-// canonical codes, bit-reversed; out[s] = code | len << 16
-__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out) {
-    int bl_count[16], next[16];
-    for (int b = 0; b < 16; b++) bl_count[b] = 0;
-    for (int s = 0; s < nsym; s++) bl_count[lens[s]]++;
-    bl_count[0] = 0;
-    int code = 0;
-    for (int b = 1; b <= 15; b++) { code = (code + bl_count[b - 1]) << 1; next[b] = code; }
-    for (int s = 0; s < nsym; s++) {
-        int l = lens[s]; out[s] = 0;
-        if (!l) continue;
-        int c = next[l]++, r = 0;
-        for (int i = 0; i < l; i++) r |= ((c >> i) & 1) << (l - 1 - i);
-        out[s] = (uint32_t)r | ((uint32_t)l << 16);
+// canonical codes, bit-reversed; out[s] = code | len << 16.  Workgroup-wide: code of s = first code of its length + number of
+// lower-numbered symbols of the same length.
+__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, uint32_t tid, uint32_t nthr) {
+    if (tid == 0) {
+        int bl_count[16];
+        for (int b = 0; b < 16; b++) bl_count[b] = 0;
+        for (int s = 0; s < nsym; s++) bl_count[lens[s]]++;
+        bl_count[0] = 0;
+        int code = 0; first[0] = 0;
+        for (int b = 1; b <= 15; b++) { code = (code + bl_count[b - 1]) << 1; first[b] = (uint32_t)code; }
     }
+    __syncthreads();
+    for (int s = (int)tid; s < nsym; s += (int)nthr) {
+        const uint32_t l = lens[s];
+        uint32_t v = 0;
+        if (l) {
+            uint32_t c = first[l];
+            for (int o = 0; o < s; o++) c += lens[o] == l ? 1u : 0u;
+            v = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
+        }
+        out[s] = v;
+    }
+    __syncthreads();
 }
 
 constexpr uint32_t DS_THREADS = 256;
@@ -99,9 +130,10 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     __shared__ uint32_t h_lit[8][256];
     __shared__ uint32_t h_len[4][32], h_dist[4][32];
     __shared__ uint32_t llc[288], dc[32], clc[19];
-    __shared__ uint16_t order[288]; __shared__ uint32_t wt[576]; __shared__ uint16_t parent[576]; __shared__ uint8_t depth[576];
+    __shared__ uint16_t order[288]; __shared__ uint32_t wt[576]; __shared__ uint16_t parent[576];
     __shared__ uint8_t ll_len[288], d_len[32], cl_len[19], seq[320], sym[320], ext[320];
     __shared__ uint32_t cl_code[19];
+    __shared__ uint32_t ll_code_s[288], d_code_s[32], first_s[16], sh2[2], hsh[3];
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     DeflTables *T = tabs + blockIdx.x;
@@ -140,30 +172,39 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         dc[tid] = tid < 30 ? h_dist[0][tid] + h_dist[1][tid] + h_dist[2][tid] + h_dist[3][tid] : 0u;
     }
     __syncthreads();
-    if (tid != 0) return;
-    d_build_lens(llc, 286, 15, ll_len, order, wt, parent, depth);
-    d_build_lens(dc, 30, 15, d_len, order, wt, parent, depth);
-    d_assign(ll_len, 286, T->ll_code);
-    d_assign(d_len, 30, T->d_code);
-    T->ll_code[286] = T->ll_code[287] = 0; T->d_code[30] = T->d_code[31] = 0;
-    int nll = 286; while (nll > 257 && ll_len[nll - 1] == 0) nll--;
-    int nd = 30; while (nd > 1 && d_len[nd - 1] == 0) nd--;
-    int n = 0, ns = 0;
-    for (int i = 0; i < nll; i++) seq[n++] = ll_len[i];
-    for (int i = 0; i < nd; i++) seq[n++] = d_len[i];
-    for (int i = 0; i < n;) {
-        if (seq[i] == 0) {
-            int z = 1; while (i + z < n && seq[i + z] == 0 && z < 138) z++;
-            if (z >= 11) { sym[ns] = 18; ext[ns++] = (uint8_t)(z - 11); i += z; continue; }
-            if (z >= 3) { sym[ns] = 17; ext[ns++] = (uint8_t)(z - 3); i += z; continue; }
+    d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, tid, DS_THREADS);
+    d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, tid, DS_THREADS);
+    d_assign(ll_len, 286, ll_code_s, first_s, tid, DS_THREADS);
+    d_assign(d_len, 30, d_code_s, first_s, tid, DS_THREADS);
+    for (uint32_t i = tid; i < 288; i += DS_THREADS) T->ll_code[i] = i < 286 ? ll_code_s[i] : 0u;
+    if (tid < 32) T->d_code[tid] = tid < 30 ? d_code_s[tid] : 0u;
+    // table description: run-length tokens of the code lengths (serial scan), their 19-symbol code, the header bits
+    if (tid == 0) {
+        int nll = 286; while (nll > 257 && ll_len[nll - 1] == 0) nll--;
+        int nd = 30; while (nd > 1 && d_len[nd - 1] == 0) nd--;
+        int n = 0, ns = 0;
+        for (int i = 0; i < nll; i++) seq[n++] = ll_len[i];
+        for (int i = 0; i < nd; i++) seq[n++] = d_len[i];
+        for (int i = 0; i < n;) {
+            if (seq[i] == 0) {
+                int z = 1; while (i + z < n && seq[i + z] == 0 && z < 138) z++;
+                if (z >= 11) { sym[ns] = 18; ext[ns++] = (uint8_t)(z - 11); i += z; continue; }
+                if (z >= 3) { sym[ns] = 17; ext[ns++] = (uint8_t)(z - 3); i += z; continue; }
+            }
+            sym[ns] = seq[i]; ext[ns++] = 0; i++;
         }
-        sym[ns] = seq[i]; ext[ns++] = 0; i++;
+        for (int i = 0; i < 19; i++) clc[i] = 0;
+        for (int i = 0; i < ns; i++) clc[sym[i]]++;
+        hsh[0] = (uint32_t)nll; hsh[1] = (uint32_t)nd; hsh[2] = (uint32_t)ns;
     }
-    for (int i = 0; i < 19; i++) clc[i] = 0;
-    for (int i = 0; i < ns; i++) clc[sym[i]]++;
-    if (d_build_lens(clc, 19, 7, cl_len, order, wt, parent, depth) == 1)
-        for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; break; }
-    d_assign(cl_len, 19, cl_code);
+    __syncthreads();
+    if (d_build_lens(clc, 19, 7, cl_len, order, wt, parent, sh2, tid, DS_THREADS) == 1) {
+        if (tid == 0) for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; break; }
+        __syncthreads();
+    }
+    d_assign(cl_len, 19, cl_code, first_s, tid, DS_THREADS);
+    if (tid != 0) return;
+    const int nll = (int)hsh[0], nd = (int)hsh[1], ns = (int)hsh[2];
     int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;
     DBitW w; w.p = T->hdr; w.pos = 0; w.acc = 0; w.nb = 0;
     dw_add(w, (uint32_t)(nll - 257), 5); dw_add(w, (uint32_t)(nd - 1), 5); dw_add(w, (uint32_t)(ncl - 4), 4);
