@@ -171,6 +171,22 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             if (tid < TILE / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
             LZ_STAMP(0);
 
+#ifdef LZ_EXP_PAD
+            // issue-model experiment: 128 extra independent SALU (flag 0x400) or VALU (flag 0x800) instructions per wave and tile
+            if (flags & 0x400u) {
+                uint32_t a0 = tid, a1 = 1, a2 = 2, a3 = 3;
+                a0 = uni(a0);
+#pragma unroll
+                for (int k = 0; k < 32; k++) asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3) :: "scc");
+                if (a0 + a1 + a2 + a3 == 0x7FFFFFF0u) lits[0] = 1;
+            }
+            if (flags & 0x800u) {
+                uint32_t a0 = tid, a1 = 1, a2 = 2, a3 = 3;
+#pragma unroll
+                for (int k = 0; k < 32; k++) asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                if (a0 + a1 + a2 + a3 == 0x7FFFFFF0u) lits[0] = 1;
+            }
+#endif
             // ---- lookup
             uint32_t q[2], lo[2], hi[2], hsh[2], tag[2], ent[2];
             bool hv[2];

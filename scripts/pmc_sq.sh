@@ -5,7 +5,7 @@ FILES=${1:-2048}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_sq
 mkdir -p "$OUT"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES \
+rocprofv3 --pmc ${PMC_LIST:-SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES} \
   --kernel-trace --output-format csv -d "$OUT" -o sq -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT.log" 2>&1
 tail -1 "$OUT.log" | cut -c1-120
 python3 - "$OUT" <<'PY'
