@@ -24,12 +24,12 @@
 
 namespace pna {
 
-constexpr uint32_t WMASK32 = WIN_BYTES / 4 - 1;
 constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 
 // LDS layout (byte offsets into the dynamic shared array)
 constexpr uint32_t L_WIN    = 0;
-constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES;
+constexpr uint32_t WIN_MIRROR = 16;                        // the window's first 16 bytes again behind its end: unaligned reads never wrap
+constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
 constexpr uint32_t L_LEN    = L_TABLE + (4u << HASH_LOG);
 constexpr uint32_t L_OFF    = L_LEN + 2 * TILE;
 constexpr uint32_t L_FIXLEN = L_OFF + 2 * TILE;
@@ -45,6 +45,7 @@ struct WPub  { uint32_t cnt; uint32_t gl; uint32_t bad; uint32_t exit; };   // c
 static_assert(sizeof(WMeta) == 64 && sizeof(WRes) == 48 && sizeof(WPub) == 16, "LDS record sizes");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_FALLBACK = 0x200u;
+static_assert(CAP1 == 16, "the match step compares 8 + 8 bytes");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l) {
@@ -69,14 +70,15 @@ __device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
 
 // 8 / 4 bytes at an arbitrary segment position from the circular window
 __device__ __forceinline__ void fetch8(const uint32_t *win32, uint32_t pos, uint32_t &lo, uint32_t &hi) {
-    uint32_t w = (pos & (WIN_BYTES - 1)) >> 2, sh = (pos & 3) * 8;
-    uint32_t d0 = win32[w], d1 = win32[(w + 1) & WMASK32], d2 = win32[(w + 2) & WMASK32];
+    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);                    // p[1], p[2] may lie in the mirror
+    const uint32_t sh = (pos & 3) * 8;
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
     lo = __builtin_amdgcn_alignbit(d1, d0, sh);
     hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 }
 __device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) {
-    uint32_t w = (pos & (WIN_BYTES - 1)) >> 2, sh = (pos & 3) * 8;
-    return __builtin_amdgcn_alignbit(win32[(w + 1) & WMASK32], win32[w], sh);
+    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);
+    return __builtin_amdgcn_alignbit(p[1], p[0], (pos & 3) * 8);
 }
 
 // Wave-cooperative extension of a match that reached CAP1: q, c, lim are wave-uniform; returns the full length
@@ -146,8 +148,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
     // positions below t0 - 60400 < t0 - MAX_OFF, which no match of tile t can reference.
     uint32_t loaded_end = TILE + LOOKAHEAD + 16;
-    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16)
-        *(uint4 *)(lds + L_WIN + i) = load_chunk(seg, i, seg_len);
+    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
+        const uint4 v = load_chunk(seg, i, seg_len);
+        *(uint4 *)(lds + L_WIN + i) = v;
+        if (i == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = v;
+    }
     __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
 
@@ -220,16 +225,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         fetch8(win32, c, clo, chi);
                         uint64_t x = (uint64_t)(lo[r] ^ clo) | ((uint64_t)(hi[r] ^ chi) << 32);
                         if (x) l = ctz64(x) >> 3;
-                        else {
-                            l = 8;
-                            while (l < lim) {
-                                uint32_t alo, ahi;
-                                fetch8(win32, q[r] + l, alo, ahi);
-                                fetch8(win32, c + l, clo, chi);
-                                x = (uint64_t)(alo ^ clo) | ((uint64_t)(ahi ^ chi) << 32);
-                                if (x) { l += ctz64(x) >> 3; break; }
-                                l += 8;
-                            }
+                        else {                                                      // bytes 8..15 (CAP1 == 16: one more step at most)
+                            uint32_t alo, ahi;
+                            fetch8(win32, q[r] + 8, alo, ahi);
+                            fetch8(win32, c + 8, clo, chi);
+                            x = (uint64_t)(alo ^ clo) | ((uint64_t)(ahi ^ chi) << 32);
+                            l = x ? 8 + (ctz64(x) >> 3) : 16;
                         }
                         l = l < lim ? l : lim;
                         if (l < MIN_MATCH) l = 0;
@@ -252,17 +253,21 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the previous group's last match
                 uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
                 uint32_t e_last = e0;
+                const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
+                const uint64_t capm = __ballot(len[r] == CAP1);
                 while (rem) {
                     const uint32_t s = ctz64(rem);
-                    uint32_t L = rdlane(len[r], s);
-                    if (L == CAP1) {
+                    uint32_t e = rdlane(endp, s);
+                    if ((capm >> s) & 1) {
                         const uint32_t qs = t0 + wbase + 64 * r + s;
-                        L = lz_extend(win32, qs, qs - rdlane(off[r], s), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
+                        const uint32_t L = lz_extend(win32, qs, qs - rdlane(off[r], s), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
                         if (lane == s) flen[r] = L;
+                        e = s + L;
                     }
                     sel[r] |= (uint64_t)1 << s;
-                    e_last = s + L;
-                    rem = e_last < 64 ? rem & (~(uint64_t)0 << e_last) : 0;
+                    e_last = e;
+                    const uint32_t ec = e < 64 ? e : 64u;                           // e >= s + MIN_MATCH, so ec - 1 is a valid shift
+                    rem &= (~(uint64_t)0 << 1) << (ec - 1);
                 }
                 cur = 64 * r + (e_last > 64 ? e_last : 64u);
                 // coverage (starts included): nearest selected start at or below the lane, its length via bpermute
@@ -276,7 +281,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             const uint64_t vis[2] = {~cov[0] | sel[0], ~cov[1] | sel[1]};
             LZ_STAMP(7);
             const uint32_t flen_spec[2] = {flen[0], flen[1]};
-            if (tid < TILE / 16) *(uint4 *)(lds + L_WIN + ((loaded_end + tid * 16) & (WIN_BYTES - 1))) = pf;
+            if (tid < TILE / 16) {
+                const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
+                *(uint4 *)(lds + L_WIN + wo) = pf;
+                if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
+            }
             loaded_end += TILE;
             if (lane == 0) {
                 WMeta m;
