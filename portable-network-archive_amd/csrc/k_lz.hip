@@ -307,27 +307,32 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             uint32_t e_sync = 128;
             bool synced = false;
             {
+                // walk from the true entry until the parse stands on a position the speculative parse also stood on;
+                // one copy of the loop per 64-position group keeps the masks and the readlane sources fixed inside it
                 uint32_t e = cw;
-                while (e < 128) {
-                    const uint32_t r1 = e >> 6, bp = e & 63;
-                    const uint64_t vs = (r1 ? vis[1] : vis[0]) >> bp, es = (r1 ? effm[1] : effm[0]) >> bp;
-                    const uint32_t nv = vs ? ctz64(vs) : 64u, ne = es ? ctz64(es) : 64u;
-                    if (nv <= ne) {
-                        if (!vs) { e = 64 * (r1 + 1); continue; }
-                        e += nv; synced = true; e_sync = e; break;
+#pragma unroll
+                for (int r1 = 0; r1 < 2; r1++) {
+                    const uint64_t V = ~cov[r1] | sel[r1], E = effm[r1];            // positions the speculative parse stood on; match starts
+                    while (!synced && e < 64u * (r1 + 1)) {
+                        const uint32_t bp = e - 64u * r1;
+                        const uint64_t vs = V >> bp, es = E >> bp;
+                        const uint32_t nv = vs ? ctz64(vs) : 64u, ne = es ? ctz64(es) : 64u;
+                        if (nv <= ne) {
+                            if (!vs) { e = 64u * (r1 + 1); break; }
+                            e += nv; synced = true; e_sync = e; break;
+                        }
+                        const uint32_t b2 = bp + ne;
+                        e += ne;
+                        uint32_t L = rdlane(len[r1], b2);
+                        if (L == CAP1) {
+                            const uint32_t qs = t0 + wbase + e;
+                            L = lz_extend(win32, qs, qs - rdlane(off[r1], b2), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
+                            if (lane == b2) flen[r1] = L;
+                        }
+                        fix[r1] |= (uint64_t)1 << b2;
+                        cover(fcov[0], fcov[1], e, L);
+                        e += L;
                     }
-                    e += ne;
-                    const uint32_t b2 = e & 63;
-                    uint32_t L = r1 ? rdlane(len[1], b2) : rdlane(len[0], b2);
-                    if (L == CAP1) {
-                        const uint32_t o = r1 ? rdlane(off[1], b2) : rdlane(off[0], b2);
-                        const uint32_t qs = t0 + wbase + e;
-                        L = lz_extend(win32, qs, qs - o, (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
-                        if (lane == b2) { if (r1) flen[1] = L; else flen[0] = L; }
-                    }
-                    if (r1) fix[1] |= (uint64_t)1 << b2; else fix[0] |= (uint64_t)1 << b2;
-                    cover(fcov[0], fcov[1], e, L);
-                    e += L;
                 }
                 // true exit of this wave (tile-relative) under the assumption; published for the next tile's carry
                 uint32_t my_exit = cw >= 128 ? A : (synced ? wbase + cur : wbase + e);
@@ -335,55 +340,38 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const bool bad_w = !synced && cw < 128;
                 // ---- masks of the final selection
                 uint64_t fsel[2], litm[2];
-                uint32_t nsel, nlit, nsel0, nlit0, gl;
-                bool done_fb = false;
-                uint32_t seq_base = 0, lit_base = 0, glast1_before = 1;
-                for (;;) {
+                uint32_t nsel0, nlit0;
+                const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;           // in-range positions of the wave
+                auto masks_and_publish = [&](const uint64_t s0m, const uint64_t s1m, const uint64_t c0m, const uint64_t c1m, uint32_t badflag) {
                     const uint64_t keep0 = e_sync >= 64 ? 0 : ~mlow(e_sync), keep1 = e_sync >= 128 ? 0 : (e_sync <= 64 ? ~(uint64_t)0 : ~mlow(e_sync - 64));
-                    const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;       // in-range positions of the wave
-                    fsel[0] = (sel[0] & keep0) | fix[0]; fsel[1] = (sel[1] & keep1) | fix[1];
-                    litm[0] = mlow(in0) & ~((cov[0] & keep0) | fcov[0] | mlow(cw));
-                    litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~((cov[1] & keep1) | fcov[1] | mlow(cw > 64 ? cw - 64 : 0u));
-                    nsel0 = (uint32_t)__popcll(fsel[0]); nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
-                    nlit0 = (uint32_t)__popcll(litm[0]); nlit = nlit0 + (uint32_t)__popcll(litm[1]);
-                    // local literal index of the wave's last match (+1), 0 when it has none
-                    gl = 0;
+                    fsel[0] = (s0m & keep0) | fix[0]; fsel[1] = (s1m & keep1) | fix[1];
+                    litm[0] = mlow(in0) & ~((c0m & keep0) | fcov[0] | mlow(cw));
+                    litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~((c1m & keep1) | fcov[1] | mlow(cw > 64 ? cw - 64 : 0u));
+                    nsel0 = (uint32_t)__popcll(fsel[0]);
+                    const uint32_t nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
+                    nlit0 = (uint32_t)__popcll(litm[0]);
+                    const uint32_t nlit = nlit0 + (uint32_t)__popcll(litm[1]);
+                    // local literal index of the wave's last match (+1), 0 when it has none; the same for its first match
+                    // (needed by the chunk table only)
+                    uint32_t gl = 0, gf = 0;
                     if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
                     else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                    uint32_t gf = 0;                                                // same for the wave's first match
-                    if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                    else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
-                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); p.bad = (bad_w && !done_fb) ? 1u : 0u; p.exit = my_exit; wpub[wave] = p; }
-                    if (!done_fb) LZ_STAMP(5);
-                    __syncthreads();                                                // B4
-                    if (!done_fb) LZ_STAMP(4);
-                    const WPub pl = wpub[lane & (LZ_WAVES - 1)];
-                    const bool lv = lane < LZ_WAVES;
-                    const bool any_bad = __ballot(lv && pl.bad) != 0;
-                    if (done_fb || (!any_bad && !force_fb)) {
-                        // 16-lane DPP scans over the waves' records
-                        const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
-                        const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + (pl.gl & 0xFFFF) : 0u;   // 1 + literal index of wave j's last match
-                        const uint32_t gmax = row_scan_max(gabs);
-                        const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
-                        seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
-                        const uint32_t gb = wave ? rdlane(gmax, wave - 1) : 0u;
-                        glast1_before = gb > g_last1 ? gb : g_last1;
-                        const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
-                        g_last1 = ga > g_last1 ? ga : g_last1;
-                        if (ctab) {
-                            // chunk table: state of the block's sequence / literal streams at this tile's start and the
-                            // literal index of the tile's first match (lets later stages split a block by tiles)
-                            const uint64_t hm = __ballot(lv && pl.gl);
-                            uint32_t g_first = lit_run + (tot >> 16);
-                            if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
-                            if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
-                        }
-                        seq_run += tot & 0xFFFF; lit_run += tot >> 16;
-                        next_free = t0 + rdlane(pl.exit, LZ_WAVES - 1);
-                        break;
+                    if (ctab) {
+                        if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+                        else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
                     }
-                    // ---- fallback: wave 0 resolves the true entry of every wave serially (scalar code)
+                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); p.bad = badflag; p.exit = my_exit; wpub[wave] = p; }
+                };
+                masks_and_publish(sel[0], sel[1], cov[0], cov[1], bad_w ? 1u : 0u);
+                LZ_STAMP(5);
+                __syncthreads();                                                    // B4
+                LZ_STAMP(4);
+                WPub pl = wpub[lane & (LZ_WAVES - 1)];
+                const bool lv = lane < LZ_WAVES;
+                if (__ballot(lv && pl.bad) != 0 || force_fb) {
+                    // ---- rare: some wave broke the assumption.  Wave 0 resolves the true entry of every wave serially
+                    // (scalar code); everything is re-derived from the LDS records so that the common path above keeps no
+                    // state alive for it.
                     len_arr[wbase + lane] = (uint16_t)len[0]; len_arr[wbase + 64 + lane] = (uint16_t)len[1];
                     off_arr[wbase + lane] = (uint16_t)off[0]; off_arr[wbase + 64 + lane] = (uint16_t)off[1];
                     __syncthreads();
@@ -426,13 +414,40 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     __syncthreads();
                     {
                         const WRes rr = wres[wave];
+                        const WMeta mm = wmeta[wave];
                         fix[0] = rr.fix[0]; fix[1] = rr.fix[1]; fcov[0] = rr.fcov[0]; fcov[1] = rr.fcov[1];
                         cw = rr.carry; e_sync = rr.sync;
                         my_exit = wres[LZ_WAVES - 1].exit;                           // every wave publishes the tile exit
                         flen[0] = ((fix[0] >> lane) & 1) ? (uint32_t)fix_arr[wbase + lane] : flen_spec[0];
                         flen[1] = ((fix[1] >> lane) & 1) ? (uint32_t)fix_arr[wbase + 64 + lane] : flen_spec[1];
+                        // speculative selection and coverage back from the record: vis = ~cov | sel and sel is a subset of cov
+                        masks_and_publish(mm.sel[0], mm.sel[1], ~mm.vis[0] | mm.sel[0], ~mm.vis[1] | mm.sel[1], 0u);
                     }
-                    done_fb = true;
+                    __syncthreads();
+                    pl = wpub[lane & (LZ_WAVES - 1)];
+                }
+                // ---- 16-lane DPP scans over the waves' records
+                uint32_t seq_base, lit_base, glast1_before;
+                {
+                    const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
+                    const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + (pl.gl & 0xFFFF) : 0u;   // 1 + literal index of wave j's last match
+                    const uint32_t gmax = row_scan_max(gabs);
+                    const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
+                    seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
+                    const uint32_t gb = wave ? rdlane(gmax, wave - 1) : 0u;
+                    glast1_before = gb > g_last1 ? gb : g_last1;
+                    const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
+                    g_last1 = ga > g_last1 ? ga : g_last1;
+                    if (ctab) {
+                        // chunk table: state of the block's sequence / literal streams at this tile's start and the
+                        // literal index of the tile's first match (lets later stages split a block by tiles)
+                        const uint64_t hm = __ballot(lv && pl.gl);
+                        uint32_t g_first = lit_run + (tot >> 16);
+                        if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
+                        if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
+                    }
+                    seq_run += tot & 0xFFFF; lit_run += tot >> 16;
+                    next_free = t0 + rdlane(pl.exit, LZ_WAVES - 1);
                 }
 
                 // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)
