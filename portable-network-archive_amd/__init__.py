@@ -15,7 +15,7 @@ import os
 from typing import Iterable, List, Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpna_gpu.so")
+LIB_PATH = os.environ.get("PNA_GPU_LIB") or os.path.join(_HERE, "libpna_gpu.so")
 
 PNA_OK = 0
 ALGO_STORE, ALGO_DEFLATE, ALGO_ZSTD = 0, 1, 2
