@@ -23,7 +23,7 @@ static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; 
 
 void pna_zstd_default_params(pna_zstd_params *p) {
     p->hash_log = 14; p->min_match = 6; p->tile = 2048; p->max_off = 59392; p->cap1 = 16;
-    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0;
+    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 128;
 }
 
 size_t pna_zstd_bound(size_t n) {
@@ -52,9 +52,16 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
  *   I  every such position stores table[hash(q)] = max(old, q+1)   (ascending q here == atomic max on the GPU);
  *   M  len[q] = length of the common prefix of seg[q..] and seg[c..] (c = cand-1), capped to cap1 and to the
  *      block end; a candidate is usable iff cand != 0 and q - c <= max_off; len < min_match counts as 0;
- *   P  greedy parse in ascending q from `next_free`: position q starts a match iff len[q] >= min_match and not
- *      (LAZY and (q & 63) != 63 and q+1 < tile end and len[q+1] > len[q]); a chosen match whose len == cap1 is
- *      extended byte-wise up to min(block end, tile end + lookahead); the parse then continues at q + len.
+ *   P  region-local greedy parse.  The tile is cut into regions of p->region positions (what one GPU wave owns; region 0
+ *      = the whole tile).  Every region is parsed on its own, in ascending q from max(region start, next_free): position q
+ *      starts a match iff len[q] >= min_match and not (LAZY and (q & 63) != 63 and q+1 < tile end and len[q+1] > len[q]);
+ *      a chosen match whose len == cap1 is extended byte-wise up to min(block end, tile end + lookahead) (and max_len);
+ *      the region's parse continues at q + len and stops at the region end (its last match may reach beyond it).
+ *   F  merge of the regions in ascending order against the running end E of the emitted matches (E = next_free at the
+ *      tile start): a region that lies entirely below E contributes nothing; otherwise a match that ends at or before E
+ *      is dropped, a match that starts before E and ends r bytes after it is cut from the front (start E, length r, same
+ *      offset) when r >= 3 and dropped otherwise, and any other match is emitted as parsed.  E becomes the end of every
+ *      emitted match; next_free = E after the tile.
  * Literals are the bytes not covered by matches, in order; the block's last literals follow the last sequence.
  */
 uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, uint32_t blk_len,
@@ -66,6 +73,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     uint32_t T = p->tile;
     uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * T);
     uint16_t *len = (uint16_t *)malloc(sizeof(uint16_t) * (T + 1));
+    uint32_t *mq = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1) * 4), *ml = mq + T + 1, *mc = ml + T + 1, *mr = mc + T + 1;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
         uint32_t t1 = t0 + T < blk_end ? t0 + T : blk_end;
         /* L */
@@ -91,24 +99,41 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         len[t1 - t0] = 0;
         /* P */
         uint32_t ext_lim = t1 + p->lookahead < blk_end ? t1 + p->lookahead : blk_end;
-        for (uint32_t q = (next_free > t0 ? next_free : t0); q < t1; ) {
-            uint32_t l = len[q - t0];
-            int take = l >= p->min_match;
-            if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
-            if (!take) { q++; continue; }
-            uint32_t c = cand[q - t0] - 1;
-            if (l == p->cap1) {
-                uint32_t el = ext_lim;
-                if (p->max_len && q + p->max_len < el) el = q + p->max_len;
-                while (q + l < el && seg[q + l] == seg[c + l]) l++;
+        uint32_t R = p->region ? p->region : T;
+        uint32_t nm = 0;                                  /* matches of this tile: mq (start), ml (length), mc (candidate) */
+        for (uint32_t r0 = t0; r0 < t1; r0 += R) {
+            uint32_t r1 = r0 + R < t1 ? r0 + R : t1;
+            for (uint32_t q = (next_free > r0 ? next_free : r0); q < r1; ) {
+                uint32_t l = len[q - t0];
+                int take = l >= p->min_match;
+                if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
+                if (!take) { q++; continue; }
+                uint32_t c = cand[q - t0] - 1;
+                if (l == p->cap1) {
+                    uint32_t el = ext_lim;
+                    if (p->max_len && q + p->max_len < el) el = q + p->max_len;
+                    while (q + l < el && seg[q + l] == seg[c + l]) l++;
+                }
+                mq[nm] = q; ml[nm] = l; mc[nm] = c; mr[nm] = r1; nm++;
+                q += l;
+            }
+        }
+        /* F */
+        for (uint32_t i = 0; i < nm; i++) {
+            uint32_t q = mq[i], l = ml[i], c = mc[i];
+            if (q + l <= next_free || mr[i] <= next_free) continue;      /* mr = end of the match's region */
+            if (q < next_free) {
+                uint32_t r = q + l - next_free;
+                if (r < 3) continue;
+                c += next_free - q; q = next_free; l = r;
             }
             seqs[nseq].ll = q - lit_start; seqs[nseq].ml = l; seqs[nseq].off = q - c; nseq++;
             memcpy(lits + nlit, seg + lit_start, q - lit_start); nlit += q - lit_start;
-            q += l; lit_start = q; next_free = q;
+            lit_start = q + l; next_free = lit_start;
         }
     }
     memcpy(lits + nlit, seg + lit_start, blk_end - lit_start); nlit += blk_end - lit_start;
-    free(cand); free(len);
+    free(cand); free(len); free(mq);
     *nlit_out = nlit;
     return nseq;
 }

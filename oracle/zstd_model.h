@@ -32,6 +32,7 @@ typedef struct {
     uint32_t lookahead;   /* bytes beyond the tile end that an extension may read               */
     uint32_t flags;       /* PNA_F_*                                                            */
     uint32_t max_len;     /* longest match (0 = only limited by the look-ahead); 258 for deflate          */
+    uint32_t region;      /* positions parsed as one unit (128 = one GPU wave); 0 = one exact greedy parse per tile */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */

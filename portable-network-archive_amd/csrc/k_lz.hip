@@ -3,22 +3,22 @@
 // Replaces the match finder inside the third-party encoder the reference drives at
 // lib/src/compress.rs:32-41 (CompressionWriter::write -> ZstdEncoder::write).  Integer/byte work, no MFMA.
 //
-// LDS (one workgroup per CU, ~146 KiB of the 160 KiB):
-//   win   [65536 B]  circular copy of the segment's most recent 64 KiB (look-back + 1 KiB look-ahead)
+// LDS (one workgroup per CU, ~129 KiB of the 160 KiB):
+//   win   [65536 + 16 B]  circular copy of the segment's most recent 64 KiB (look-back + 1 KiB look-ahead); the first
+//         16 bytes are mirrored behind the end so that unaligned reads never wrap
 //   table [16384 x u32] hash table: (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
 //         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
-//   len/off/fixlen [2048 x u16 each]  written and read by the serial fallback only
-//   per-wave records
+//   per-wave records (end of the wave's last match; counts)
 // Per tile of 2048 positions (2 per lane):
 //   (next window chunk requested into registers) lookup -> B2 -> insert + match +
-//   per-wave SPECULATIVE parse (as if the parse entered the wave at its first position; scalar loops that also
-//   build the coverage bit masks) -> B3 -> every wave resolves its TRUE entry in parallel (carry chained through
-//   the speculative exits of the earlier, not fully covered waves) and walks from there until it lands on a
-//   position its speculative parse also stood on -> masks of selected matches / literals -> B4 -> 16-lane DPP
-//   scans of the waves' counts -> emission of sequences and literals straight to HBM.
+//   REGION-LOCAL parse: every wave parses its own 128 positions greedily from max(its first position, the tile's carry)
+//   with scalar loops on ballot masks, and publishes the end of its last match -> B3 -> MERGE: the running end E of the
+//   earlier waves' matches is a 16-lane prefix maximum (exact unless an end falls 1-2 bytes behind E: then a short serial
+//   scan); a wave entirely below E emits nothing, matches that end before E are dropped, the one straddling E is cut from
+//   the front (>= 3 bytes must remain),
+//   everything else stands -> selection / literal masks -> counts -> B4 -> 16-lane DPP scans of the waves' counts ->
+//   emission of sequences and literals straight to HBM.
 //   Cross-lane traffic on this path: ballots, readlanes, DPP and one ds_bpermute per 64 positions.
-//   The parallel resolution is exact when every not-fully-covered wave re-synchronises (checked); otherwise the
-//   tile falls back to a serial resolution by wave 0 (rare; forced with flag 0x200 for testing).
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
@@ -30,21 +30,14 @@ constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr uint32_t L_WIN    = 0;
 constexpr uint32_t WIN_MIRROR = 16;                        // the window's first 16 bytes again behind its end: unaligned reads never wrap
 constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
-constexpr uint32_t L_LEN    = L_TABLE + (4u << HASH_LOG);
-constexpr uint32_t L_OFF    = L_LEN + 2 * TILE;
-constexpr uint32_t L_FIXLEN = L_OFF + 2 * TILE;
-constexpr uint32_t L_WMETA  = L_FIXLEN + 2 * TILE;          // 16 x 64 B
-constexpr uint32_t L_WRES   = L_WMETA + 64 * LZ_WAVES;      // 16 x 48 B
-constexpr uint32_t L_WPUB   = L_WRES + 48 * LZ_WAVES;       // 16 x 16 B
-constexpr uint32_t L_STATE  = L_WPUB + 16 * LZ_WAVES;       // 16 B
-constexpr uint32_t L_TOTAL  = L_STATE + 16;
+constexpr uint32_t L_WEND   = L_TABLE + (4u << HASH_LOG);   // 16 x u32: tile-relative end of each wave's last match (0 = none)
+constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
+constexpr uint32_t L_TOTAL  = L_WPUB + 8 * LZ_WAVES;
 
-struct WMeta { uint64_t sel[2]; uint64_t vis[2]; uint64_t eff[2]; uint32_t exit0; uint32_t pad[3]; };
-struct WRes  { uint64_t fix[2]; uint64_t fcov[2]; uint32_t carry; uint32_t sync; uint32_t exit; uint32_t pad; };
-struct WPub  { uint32_t cnt; uint32_t gl; uint32_t bad; uint32_t exit; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
-static_assert(sizeof(WMeta) == 64 && sizeof(WRes) == 48 && sizeof(WPub) == 16, "LDS record sizes");
+struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
+static_assert(sizeof(WPub) == 8, "LDS record size");
 
-constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_FALLBACK = 0x200u;
+constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
 static_assert(CAP1 == 16, "the match step compares 8 + 8 bytes");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -122,11 +115,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
-    uint16_t *len_arr = (uint16_t *)(lds + L_LEN);
-    uint16_t *off_arr = (uint16_t *)(lds + L_OFF);
-    uint16_t *fix_arr = (uint16_t *)(lds + L_FIXLEN);
-    WMeta    *wmeta   = (WMeta *)(lds + L_WMETA);
-    WRes     *wres    = (WRes *)(lds + L_WRES);
+    uint32_t *wend    = (uint32_t *)(lds + L_WEND);
     WPub     *wpub    = (WPub *)(lds + L_WPUB);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -135,7 +124,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t lazy = flags & F_LAZY;
-    const bool force_fb = (flags & FLAG_FORCE_FALLBACK) != 0;
+    const bool force_serial = (flags & FLAG_FORCE_SERIAL) != 0;
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * (64 * GROUPS_PER_WAVE); // tile-relative first position of this wave
 
@@ -243,14 +232,16 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
             LZ_STAMP(2);
 
-            // ---- speculative parse of this wave's 128 positions (entry at its first position).  The scalar loop only
-            // picks the match starts; coverage masks are rebuilt afterwards with one cross-lane gather per group
-            // (the scalar unit is the bottleneck of this kernel, the LDS crossbar is not).
+            // ---- region-local parse of this wave's 128 positions, from the tile's carry if that reaches into them.  The
+            // scalar loop only picks the match starts; coverage masks are rebuilt afterwards with one cross-lane gather
+            // per group (the scalar unit is the bottleneck of this kernel, the LDS crossbar is not).
+            const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;             // tile-relative carry
             uint64_t sel[2] = {0, 0}, cov[2];
-            uint32_t cur = 0;
+            uint32_t cur = c_in > wbase ? (c_in - wbase < 128u ? c_in - wbase : 128u) : 0u;
+            uint32_t el = 0;                                                        // wave-relative end of the last selected match
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the previous group's last match
+                const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the carry / the previous group's last match
                 uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
                 uint32_t e_last = e0;
                 const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
@@ -269,6 +260,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const uint32_t ec = e < 64 ? e : 64u;                           // e >= s + MIN_MATCH, so ec - 1 is a valid shift
                     rem &= (~(uint64_t)0 << 1) << (ec - 1);
                 }
+                if (sel[r]) el = 64 * r + e_last;
                 cur = 64 * r + (e_last > 64 ? e_last : 64u);
                 // coverage (starts included): nearest selected start at or below the lane, its length via bpermute
                 const uint64_t m_le = sel[r] & (lane_lt | ((uint64_t)1 << lane));
@@ -276,181 +268,122 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
                 cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
             }
-            // positions the speculative parse stands on: everything except match interiors (starts are stood on;
-            // positions past the tile end count as stood on so a walk stops there)
-            const uint64_t vis[2] = {~cov[0] | sel[0], ~cov[1] | sel[1]};
             LZ_STAMP(7);
-            const uint32_t flen_spec[2] = {flen[0], flen[1]};
             if (tid < TILE / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
             }
             loaded_end += TILE;
-            if (lane == 0) {
-                WMeta m;
-                m.sel[0] = sel[0]; m.sel[1] = sel[1]; m.vis[0] = vis[0]; m.vis[1] = vis[1];
-                m.eff[0] = effm[0]; m.eff[1] = effm[1]; m.exit0 = cur; m.pad[0] = m.pad[1] = m.pad[2] = 0;
-                wmeta[wave] = m;
-            }
+            if (lane == 0) wend[wave] = el ? wbase + el : 0u;
             __syncthreads();                                                        // B3
             LZ_STAMP(3);
 
-            // ---- parallel resolution.  Carry chain over the speculative exits: a wave the carry already covers
-            // passes it through, any other wave is assumed to re-synchronise and to leave at its speculative exit.
-            const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;             // tile-relative
-            const uint32_t ex_l = lane < LZ_WAVES ? lane * 128 + wmeta[lane & (LZ_WAVES - 1)].exit0 : 0u;
-            uint32_t A = c_in;
-            for (uint32_t j = 0; j < wave; j++) if (A < j * 128 + 128) A = rdlane(ex_l, j);
-            uint32_t cw = A > wbase ? A - wbase : 0u;                               // wave-relative entry
-            uint64_t fix[2] = {0, 0}, fcov[2] = {0, 0};
-            uint32_t e_sync = 128;
-            bool synced = false;
+            // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E
+            // to its end iff E lies inside the wave's region and that end is at least 3 bytes behind E (a wave entirely below
+            // E contributes nothing, a shorter remainder is dropped by its owner).  Without such a case this is a prefix maximum.
+            uint32_t E, tile_exit;
             {
-                // walk from the true entry until the parse stands on a position the speculative parse also stood on;
-                // one copy of the loop per 64-position group keeps the masks and the readlane sources fixed inside it
-                uint32_t e = cw;
-#pragma unroll
-                for (int r1 = 0; r1 < 2; r1++) {
-                    const uint64_t V = ~cov[r1] | sel[r1], E = effm[r1];            // positions the speculative parse stood on; match starts
-                    while (!synced && e < 64u * (r1 + 1)) {
-                        const uint32_t bp = e - 64u * r1;
-                        const uint64_t vs = V >> bp, es = E >> bp;
-                        const uint32_t nv = vs ? ctz64(vs) : 64u, ne = es ? ctz64(es) : 64u;
-                        if (nv <= ne) {
-                            if (!vs) { e = 64u * (r1 + 1); break; }
-                            e += nv; synced = true; e_sync = e; break;
-                        }
-                        const uint32_t b2 = bp + ne;
-                        e += ne;
-                        uint32_t L = rdlane(len[r1], b2);
-                        if (L == CAP1) {
-                            const uint32_t qs = t0 + wbase + e;
-                            L = lz_extend(win32, qs, qs - rdlane(off[r1], b2), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
-                            if (lane == b2) flen[r1] = L;
-                        }
-                        fix[r1] |= (uint64_t)1 << b2;
-                        cover(fcov[0], fcov[1], e, L);
-                        e += L;
-                    }
-                }
-                // true exit of this wave (tile-relative) under the assumption; published for the next tile's carry
-                uint32_t my_exit = cw >= 128 ? A : (synced ? wbase + cur : wbase + e);
-                // a wave that neither is covered nor re-synchronises breaks the assumption made by its successors
-                const bool bad_w = !synced && cw < 128;
-                // ---- masks of the final selection
-                uint64_t fsel[2], litm[2];
-                uint32_t nsel0, nlit0;
-                const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;           // in-range positions of the wave
-                auto masks_and_publish = [&](const uint64_t s0m, const uint64_t s1m, const uint64_t c0m, const uint64_t c1m, uint32_t badflag) {
-                    const uint64_t keep0 = e_sync >= 64 ? 0 : ~mlow(e_sync), keep1 = e_sync >= 128 ? 0 : (e_sync <= 64 ? ~(uint64_t)0 : ~mlow(e_sync - 64));
-                    fsel[0] = (s0m & keep0) | fix[0]; fsel[1] = (s1m & keep1) | fix[1];
-                    litm[0] = mlow(in0) & ~((c0m & keep0) | fcov[0] | mlow(cw));
-                    litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~((c1m & keep1) | fcov[1] | mlow(cw > 64 ? cw - 64 : 0u));
-                    nsel0 = (uint32_t)__popcll(fsel[0]);
-                    const uint32_t nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
-                    nlit0 = (uint32_t)__popcll(litm[0]);
-                    const uint32_t nlit = nlit0 + (uint32_t)__popcll(litm[1]);
-                    // local literal index of the wave's last match (+1), 0 when it has none; the same for its first match
-                    // (needed by the chunk table only)
-                    uint32_t gl = 0, gf = 0;
-                    if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
-                    else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                    if (ctab) {
-                        if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                        else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
-                    }
-                    if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); p.bad = badflag; p.exit = my_exit; wpub[wave] = p; }
-                };
-                masks_and_publish(sel[0], sel[1], cov[0], cov[1], bad_w ? 1u : 0u);
-                LZ_STAMP(5);
-                __syncthreads();                                                    // B4
-                LZ_STAMP(4);
-                WPub pl = wpub[lane & (LZ_WAVES - 1)];
                 const bool lv = lane < LZ_WAVES;
-                if (__ballot(lv && pl.bad) != 0 || force_fb) {
-                    // ---- rare: some wave broke the assumption.  Wave 0 resolves the true entry of every wave serially
-                    // (scalar code); everything is re-derived from the LDS records so that the common path above keeps no
-                    // state alive for it.
-                    len_arr[wbase + lane] = (uint16_t)len[0]; len_arr[wbase + 64 + lane] = (uint16_t)len[1];
-                    off_arr[wbase + lane] = (uint16_t)off[0]; off_arr[wbase + 64 + lane] = (uint16_t)off[1];
-                    __syncthreads();
-                    if (wave == 0) {
-                        const WMeta m = wmeta[lane & (LZ_WAVES - 1)];
-                        uint32_t c = c_in;
-                        for (uint32_t w = 0; w < LZ_WAVES; w++) {
-                            const uint32_t base = w * 128;
-                            const uint32_t cw2 = c > base ? c - base : 0u;
-                            const uint64_t vis0 = rdlane64(m.vis[0], w), vis1 = rdlane64(m.vis[1], w);
-                            const uint64_t eff0 = rdlane64(m.eff[0], w), eff1 = rdlane64(m.eff[1], w);
-                            const uint32_t exit0 = rdlane(m.exit0, w);
-                            uint64_t fx0 = 0, fx1 = 0, fc0 = 0, fc1 = 0;
-                            uint32_t e2 = cw2;
-                            bool sy = false;
-                            while (e2 < 128) {
-                                const uint32_t bp = e2 & 63;
-                                const uint64_t visr = e2 < 64 ? vis0 : vis1, effr = e2 < 64 ? eff0 : eff1;
-                                if ((visr >> bp) & 1) { sy = true; break; }
-                                if ((effr >> bp) & 1) {
-                                    const uint32_t pq = base + e2;
-                                    uint32_t L = uni(len_arr[pq]);
-                                    const uint32_t o = uni(off_arr[pq]);
-                                    const uint32_t qs = t0 + pq;
-                                    if (L == CAP1) L = lz_extend(win32, qs, qs - o, (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
-                                    if (lane == 0) fix_arr[pq] = (uint16_t)L;
-                                    if (e2 < 64) fx0 |= (uint64_t)1 << bp; else fx1 |= (uint64_t)1 << bp;
-                                    cover(fc0, fc1, e2, L);
-                                    e2 += L;
-                                } else e2 += 1;
-                            }
-                            c = sy ? base + exit0 : base + e2;
-                            if (lane == 0) {
-                                WRes rr; rr.fix[0] = fx0; rr.fix[1] = fx1; rr.fcov[0] = fc0; rr.fcov[1] = fc1;
-                                rr.carry = cw2; rr.sync = sy ? e2 : 128u; rr.exit = c; rr.pad = 0;
-                                wres[w] = rr;
-                            }
+                const uint32_t el_l = lv ? wend[lane & (LZ_WAVES - 1)] : 0u;
+                const uint32_t incl = row_scan_max(el_l);
+                const uint32_t before = DPP_ROW_SHR(incl, 1);                       // maximum over the earlier waves (0 for wave 0)
+                const uint32_t prev = before > c_in ? before : c_in;
+                const bool near = lv && el_l > prev && (el_l < prev + 3 || prev >= lane * 128 + 128);
+                if (__ballot(near) == 0 && !force_serial) {
+                    const uint32_t m = wave ? rdlane(incl, wave - 1) : 0u, ma = rdlane(incl, LZ_WAVES - 1);
+                    E = m > c_in ? m : c_in;
+                    tile_exit = ma > c_in ? ma : c_in;
+                } else {
+                    uint32_t x = c_in; E = c_in;
+                    for (uint32_t j = 0; j < LZ_WAVES; j++) {
+                        if (j == wave) E = x;
+                        const uint32_t ej = rdlane(el_l, j);
+                        if (x < j * 128 + 128 && ej >= x + 3) x = ej;
+                    }
+                    tile_exit = x;
+                }
+            }
+            // ---- masks of the final selection
+            uint64_t fsel[2], litm[2];
+            uint32_t nsel0, nlit0;
+            {
+                const uint32_t Ew = E > wbase ? (E - wbase < 128u ? E - wbase : 128u) : 0u;    // wave-relative, 0..128
+                const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;       // in-range positions of the wave
+                const uint64_t K0 = mlow(Ew < 64 ? Ew : 64u), K1 = Ew > 64 ? mlow(Ew - 64) : 0;   // positions below E
+                fsel[0] = sel[0] & ~K0; fsel[1] = sel[1] & ~K1;
+                uint64_t cv0 = cov[0], cv1 = cov[1];
+                if (Ew > 0 && Ew < 128) {
+                    const uint32_t grp = Ew >> 6, b = Ew & 63;
+                    const uint64_t cg = grp ? cov[1] : cov[0], sg = grp ? sel[1] : sel[0];
+                    if (((cg >> b) & 1) && !((sg >> b) & 1)) {
+                        // position E lies inside a match that starts below it: cut that match from the front
+                        const uint64_t below = sg & mlow(b);
+                        const uint32_t g2 = below ? grp : 0u;
+                        const uint32_t s2 = below ? 63 - clz64(below) : 63 - clz64(sel[0]);
+                        const uint32_t l2 = g2 ? rdlane(flen[1], s2) : rdlane(flen[0], s2);
+                        const uint32_t o2 = g2 ? rdlane(off[1], s2) : rdlane(off[0], s2);
+                        const uint32_t end2 = 64 * g2 + s2 + l2;                    // wave-relative end of the straddling match
+                        const uint32_t rmn = end2 - Ew;
+                        if (rmn >= 3) {
+                            if (grp) { fsel[1] |= (uint64_t)1 << b; if (lane == b) { flen[1] = rmn; off[1] = o2; } }
+                            else     { fsel[0] |= (uint64_t)1 << b; if (lane == b) { flen[0] = rmn; off[0] = o2; } }
+                        } else {
+                            // its last 1-2 bytes stay literals
+                            const uint32_t a0 = Ew < 64 ? Ew : 64u, z0 = end2 < 64 ? end2 : 64u;
+                            cv0 &= ~(mlow(z0) & ~mlow(a0));
+                            const uint32_t a1 = Ew > 64 ? Ew - 64 : 0u, z1 = end2 > 64 ? (end2 - 64 < 64 ? end2 - 64 : 64u) : 0u;
+                            cv1 &= ~(mlow(z1) & ~mlow(a1));
                         }
                     }
-                    __syncthreads();
-                    {
-                        const WRes rr = wres[wave];
-                        const WMeta mm = wmeta[wave];
-                        fix[0] = rr.fix[0]; fix[1] = rr.fix[1]; fcov[0] = rr.fcov[0]; fcov[1] = rr.fcov[1];
-                        cw = rr.carry; e_sync = rr.sync;
-                        my_exit = wres[LZ_WAVES - 1].exit;                           // every wave publishes the tile exit
-                        flen[0] = ((fix[0] >> lane) & 1) ? (uint32_t)fix_arr[wbase + lane] : flen_spec[0];
-                        flen[1] = ((fix[1] >> lane) & 1) ? (uint32_t)fix_arr[wbase + 64 + lane] : flen_spec[1];
-                        // speculative selection and coverage back from the record: vis = ~cov | sel and sel is a subset of cov
-                        masks_and_publish(mm.sel[0], mm.sel[1], ~mm.vis[0] | mm.sel[0], ~mm.vis[1] | mm.sel[1], 0u);
-                    }
-                    __syncthreads();
-                    pl = wpub[lane & (LZ_WAVES - 1)];
                 }
-                // ---- 16-lane DPP scans over the waves' records
-                uint32_t seq_base, lit_base, glast1_before;
-                {
-                    const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
-                    const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + (pl.gl & 0xFFFF) : 0u;   // 1 + literal index of wave j's last match
-                    const uint32_t gmax = row_scan_max(gabs);
-                    const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
-                    seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
-                    const uint32_t gb = wave ? rdlane(gmax, wave - 1) : 0u;
-                    glast1_before = gb > g_last1 ? gb : g_last1;
-                    const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
-                    g_last1 = ga > g_last1 ? ga : g_last1;
-                    if (ctab) {
-                        // chunk table: state of the block's sequence / literal streams at this tile's start and the
-                        // literal index of the tile's first match (lets later stages split a block by tiles)
-                        const uint64_t hm = __ballot(lv && pl.gl);
-                        uint32_t g_first = lit_run + (tot >> 16);
-                        if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
-                        if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
-                    }
-                    seq_run += tot & 0xFFFF; lit_run += tot >> 16;
-                    next_free = t0 + rdlane(pl.exit, LZ_WAVES - 1);
+                litm[0] = mlow(in0) & ~(cv0 | K0);
+                litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~(cv1 | K1);
+                nsel0 = (uint32_t)__popcll(fsel[0]);
+                const uint32_t nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
+                nlit0 = (uint32_t)__popcll(litm[0]);
+                const uint32_t nlit = nlit0 + (uint32_t)__popcll(litm[1]);
+                // local literal index of the wave's last match (+1), 0 when it has none; the same for its first match
+                // (needed by the chunk table only)
+                uint32_t gl = 0, gf = 0;
+                if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
+                else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+                if (ctab) {
+                    if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+                    else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
                 }
-
-                // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)
+                if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); wpub[wave] = p; }
+            }
+            LZ_STAMP(5);
+            __syncthreads();                                                        // B4
+            LZ_STAMP(4);
+            // ---- 16-lane DPP scans over the waves' records
+            uint32_t seq_base, lit_base, glast1_before;
+            {
+                const bool lv = lane < LZ_WAVES;
+                const WPub pl = wpub[lane & (LZ_WAVES - 1)];
+                const uint32_t incl = row_scan_add(lv ? pl.cnt : 0u), excl = incl - (lv ? pl.cnt : 0u);
+                const uint32_t gabs = (lv && pl.gl) ? lit_run + (excl >> 16) + (pl.gl & 0xFFFF) : 0u;   // 1 + literal index of wave j's last match
+                const uint32_t gmax = row_scan_max(gabs);
+                const uint32_t ex_w = rdlane(excl, wave), tot = rdlane(incl, LZ_WAVES - 1);
+                seq_base = seq_run + (ex_w & 0xFFFF); lit_base = lit_run + (ex_w >> 16);
+                const uint32_t gb = wave ? rdlane(gmax, wave - 1) : 0u;
+                glast1_before = gb > g_last1 ? gb : g_last1;
+                const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
+                g_last1 = ga > g_last1 ? ga : g_last1;
+                if (ctab) {
+                    // chunk table: state of the block's sequence / literal streams at this tile's start and the
+                    // literal index of the tile's first match (lets later stages split a block by tiles)
+                    const uint64_t hm = __ballot(lv && pl.gl);
+                    uint32_t g_first = lit_run + (tot >> 16);
+                    if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
+                    if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
+                }
+                seq_run += tot & 0xFFFF; lit_run += tot >> 16;
+                next_free = t0 + tile_exit;
+            }
+            // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)
+            {
                 const uint32_t sp0 = fsel[0] ? 63 - clz64(fsel[0]) : 0u;
                 const uint32_t tail0 = fsel[0] ? (uint32_t)__popcll(litm[0] & ~mlow(sp0 + 1)) : 0u;   // literals of group 0 after its last match
 #pragma unroll
