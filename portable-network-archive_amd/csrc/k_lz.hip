@@ -200,8 +200,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // ---- insert + match
             uint32_t len[2], off[2], flen[2];
             uint64_t effm[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
+            auto do_match = [&](const int r) __attribute__((always_inline)) {
                 if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
                 uint32_t l = 0, o = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS;
@@ -229,7 +228,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)
                 const bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
                 effm[r] = __ballot(eff);
-            }
+            };
             LZ_STAMP(2);
 
             // ---- region-local parse of this wave's 128 positions, from the tile's carry if that reaches into them.  The
@@ -239,8 +238,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             uint64_t sel[2] = {0, 0}, cov[2];
             uint32_t cur = c_in > wbase ? (c_in - wbase < 128u ? c_in - wbase : 128u) : 0u;
             uint32_t el = 0;                                                        // wave-relative end of the last selected match
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
+            auto do_parse = [&](const int r) __attribute__((always_inline)) {
                 const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the carry / the previous group's last match
                 uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
                 uint32_t e_last = e0;
@@ -267,7 +265,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t sl = m_le ? 63 - clz64(m_le) : 0u;
                 const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
                 cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
-            }
+            };
+            // half of the waves of a SIMD run match(0) match(1) parse(0) parse(1), the other half match(0) parse(0) match(1)
+            // parse(1): vector-heavy and scalar-heavy stretches of different waves then overlap at the issue port (-3 %)
+            if ((wave >> 2) & 1) { do_match(0); do_match(1); do_parse(0); do_parse(1); }
+            else { do_match(0); do_parse(0); do_match(1); do_parse(1); }
             LZ_STAMP(7);
             if (tid < TILE / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
