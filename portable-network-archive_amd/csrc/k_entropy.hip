@@ -123,43 +123,64 @@ __device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int 
 constexpr uint32_t ST_THREADS = 256;
 constexpr int HUF_MAX = 11;
 
-__device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint8_t *depth) {
-    int n = 0;
-    for (int s = 0; s < 256; s++) { lens[s] = 0; if (count[s]) order[n++] = (uint16_t)s; }
+// Executed by ONE WAVE (all 64 lanes call it; LDS arrays): stable rank sort by count and the leaf depths run on the lanes, the
+// two-queue merge (n - 1 dependent steps) and the rare Kraft repair on lane 0.  Returns the number of used symbols, -1 when
+// the length limit cannot be met.  Same procedure, ties and results as the serial form in oracle/zstd_model.c.
+__device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint32_t *sh, uint32_t lane) {
+    if (lane == 0) { sh[0] = 0; sh[1] = 0; sh[2] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t mine = 0;
+    for (int s = (int)lane; s < 256; s += 64) {
+        lens[s] = 0;
+        const uint32_t c = count[s];
+        if (!c) continue;
+        uint32_t rank = 0;
+        for (int o = 0; o < 256; o++) { const uint32_t co = count[o]; rank += (co != 0 && (co < c || (co == c && o < s))) ? 1u : 0u; }   // sort by (count asc, symbol asc)
+        order[rank] = (uint16_t)s;
+        mine++;
+    }
+    if (mine) atomicAdd(&sh[0], mine);
+    __builtin_amdgcn_wave_barrier();
+    const int n = (int)sh[0];
     if (n < 2) return n;
-    for (int i = 1; i < n; i++) {                      // sort by (count asc, symbol asc)
-        uint16_t x = order[i]; int j = i - 1;
-        while (j >= 0 && count[order[j]] > count[x]) { order[j + 1] = order[j]; j--; }
-        order[j + 1] = x;
+    for (int i = (int)lane; i < n; i += 64) wt[i] = count[order[i]];
+    __builtin_amdgcn_wave_barrier();
+    const int nn = 2 * n - 1;
+    if (lane == 0) {
+        int lq = 0, iq = n, m = n;
+        while (m < nn) {                               // two-queue Huffman, leaves win ties
+            int a, b;
+            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
+            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
+            wt[m] = wt[a] + wt[b]; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; m++;
+        }
     }
-    for (int i = 0; i < n; i++) wt[i] = count[order[i]];
-    int lq = 0, iq = n, nn = n;
-    while (nn < 2 * n - 1) {                           // two-queue Huffman, leaves win ties
-        int a, b;
-        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
-        if (lq < n && (iq >= nn || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
-        wt[nn] = wt[a] + wt[b]; parent[a] = (uint16_t)nn; parent[b] = (uint16_t)nn; nn++;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = (int)lane; i < n; i += 64) {
+        int d = 0, q = i;
+        while (q != nn - 1) { q = parent[q]; d++; }
+        if (d > HUF_MAX) { d = HUF_MAX; sh[1] = 1; }
+        lens[order[i]] = (uint8_t)d;
     }
-    depth[nn - 1] = 0;
-    for (int i = nn - 2; i >= 0; i--) depth[i] = (uint8_t)(depth[parent[i]] + 1);   // depth < 256 for n <= 256
-    bool over = false;
-    for (int i = 0; i < n; i++) { int d = depth[i]; if (d > HUF_MAX) { d = HUF_MAX; over = true; } lens[order[i]] = (uint8_t)d; }
-    if (!over) return n;
-    int K = 0;
-    for (int i = 0; i < n; i++) K += 1 << (HUF_MAX - lens[order[i]]);
-    int debt = K - (1 << HUF_MAX);
-    while (debt > 0) {
-        int pick = -1, bl = 0;
-        for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < HUF_MAX && l > bl) { bl = l; pick = i; } }
-        lens[order[pick]]++; debt -= 1 << (HUF_MAX - 1 - bl);
+    __builtin_amdgcn_wave_barrier();
+    if (sh[1] && lane == 0) {
+        int K = 0;
+        for (int i = 0; i < n; i++) K += 1 << (HUF_MAX - lens[order[i]]);
+        int debt = K - (1 << HUF_MAX);
+        while (debt > 0) {
+            int pick = -1, bl = 0;
+            for (int i = 0; i < n; i++) { int l = lens[order[i]]; if (l < HUF_MAX && l > bl) { bl = l; pick = i; } }
+            lens[order[pick]]++; debt -= 1 << (HUF_MAX - 1 - bl);
+        }
+        while (debt < 0) {
+            int pick = -1, bl = 99, slack = -debt;
+            for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (HUF_MAX - l)) <= slack && l < bl) { bl = l; pick = i; } }
+            if (pick < 0) { sh[2] = 1; break; }
+            lens[order[pick]]--; debt += 1 << (HUF_MAX - bl);
+        }
     }
-    while (debt < 0) {
-        int pick = -1, bl = 99, slack = -debt;
-        for (int i = n - 1; i >= 0; i--) { int l = lens[order[i]]; if (l > 1 && (1 << (HUF_MAX - l)) <= slack && l < bl) { bl = l; pick = i; } }
-        if (pick < 0) return -1;
-        lens[order[pick]]--; debt += 1 << (HUF_MAX - bl);
-    }
-    return n;
+    __builtin_amdgcn_wave_barrier();
+    return sh[2] ? -1 : n;
 }
 
 // Huffman tree description (direct 4-bit weights or FSE-compressed weights); returns bytes (0 = not representable)
@@ -240,11 +261,12 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     __shared__ uint16_t order[256];
     __shared__ uint32_t wt[512];
     __shared__ uint16_t parent[512];
-    __shared__ uint8_t  depth[512];
     __shared__ uint8_t  lens[256];
     __shared__ uint8_t  wts[256];
     __shared__ uint8_t  tmp[320];
-    __shared__ uint8_t  cell[256];
+    __shared__ uint8_t  cell[4][256];            // one scratch set per table-building task (waves 0..3)
+    __shared__ uint16_t tmp192[4][192];
+    __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2];
     __shared__ SeqTable wtab;
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
@@ -253,6 +275,10 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
 
     for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
     for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
+    if (tid == 0) {
+        T->huf_ok = 0; T->tree_len = 0; T->max_sym = 0; T->maxbits = 0; T->seq_ok = 1;
+        for (int k = 0; k < 3; k++) { T->mode[k] = 0; T->tlog[k] = 0; T->desc_len[k] = 0; }
+    }
     __syncthreads();
     uint32_t nseq_seg = 0;
     for (uint32_t b = 0; b < nblk; b++) {
@@ -284,35 +310,49 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; count[tid] = c; }
     if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63; scount[w][s] = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; }
     __syncthreads();
-    if (tid != 0) return;
-
-    // ---- thread 0: tables (serial, mirrors DESIGN.md "Encoder specification")
-    T->huf_ok = 0; T->tree_len = 0; T->max_sym = 0; T->maxbits = 0; T->seq_ok = 1; T->nseq_seg = nseq_seg;
-    for (int k = 0; k < 3; k++) { T->mode[k] = 0; T->tlog[k] = 0; T->desc_len[k] = 0; }
-    if (flags & F_HUF) {
-        int np = huf_build_lens(count, lens, order, wt, parent, depth);
-        if (np >= 2) {
-            int max_sym = 0, maxbits = 0;
-            for (int s = 0; s < 256; s++) if (count[s]) max_sym = s;
-            for (int s = 0; s <= max_sym; s++) if (lens[s] > maxbits) maxbits = lens[s];
-            // canonical codes: weight-1 symbols first (ascending symbol), code = cell index >> (weight-1)
-            uint32_t pos = 0;
-            for (int s = 0; s < 256; s++) T->huf_code[s] = 0;
-            for (int w = 1; w <= maxbits; w++) {
-                int l = maxbits + 1 - w;
-                for (int s = 0; s <= max_sym; s++) if (lens[s] == l) { T->huf_code[s] = (pos >> (w - 1)) | ((uint32_t)l << 16); pos += 1u << (w - 1); }
-            }
-            uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell, order);
-            T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0;
+    // ---- tables: wave 0 builds the literal code, lane 0 of waves 1..3 one sequence table each (LL, OF, ML), concurrently
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    if (wave != 0) {
+        if (lane != 0 || !nseq_seg) return;
+        bool ok;
+        if (wave == 1) ok = seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell[1], tmp192[1]);
+        else if (wave == 2) ok = seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell[2], tmp192[2]);
+        else ok = seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell[3], tmp192[3]);
+        if (!ok) atomicAnd(&T->seq_ok, 0u);
+        return;
+    }
+    if (!(flags & F_HUF)) return;
+    const int np = huf_build_lens(count, lens, order, wt, parent, hsh, lane);
+    if (np < 2) return;
+    // canonical codes: weight-1 symbols first (ascending symbol), code = cell index >> (weight-1); symbol s sits behind all
+    // symbols of smaller weight and the lower-numbered ones of its own weight
+    if (lane == 0) {
+        int max_sym = 0, maxbits = 0;
+        for (int s2 = 0; s2 < 256; s2++) if (count[s2]) max_sym = s2;
+        for (int s2 = 0; s2 <= max_sym; s2++) if (lens[s2] > maxbits) maxbits = lens[s2];
+        uint32_t cntw[HUF_MAX + 2];
+        for (int w = 0; w <= HUF_MAX + 1; w++) cntw[w] = 0;
+        for (int s2 = 0; s2 <= max_sym; s2++) if (lens[s2]) cntw[maxbits + 1 - lens[s2]]++;
+        uint32_t pos = 0;
+        for (int w = 1; w <= maxbits; w++) { wbase_s[w] = pos; pos += cntw[w] << (w - 1); }
+        hsh[3] = (uint32_t)max_sym; hsh[4] = (uint32_t)maxbits;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int max_sym = (int)hsh[3], maxbits = (int)hsh[4];
+    for (int s2 = (int)lane; s2 < 256; s2 += 64) {
+        uint32_t v = 0;
+        const uint32_t l = lens[s2];
+        if (l && s2 <= max_sym) {
+            const uint32_t w = (uint32_t)maxbits + 1 - l;
+            uint32_t before = 0;
+            for (int o = 0; o < s2; o++) before += lens[o] == l ? 1u : 0u;
+            v = ((wbase_s[w] + (before << (w - 1))) >> (w - 1)) | (l << 16);
         }
+        T->huf_code[s2] = v;
     }
-    if (nseq_seg) {
-        bool ok = true;
-        ok &= seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell, order);
-        ok &= seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell, order);
-        ok &= seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell, order);
-        T->seq_ok = ok ? 1u : 0u;
-    }
+    if (lane != 0) return;
+    const uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell[0], tmp192[0]);
+    T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0;
 }
 
 // ------------------------------------------------------------------ k_lit
@@ -469,7 +509,7 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     uint32_t *out32 = (uint32_t *)(seqc + (size_t)g * BLK_SIZE);
     const uint32_t cap_words = BLK_SIZE / 4;
     uint64_t acc = 0; uint32_t nb = 0, widx = 0;
-    auto put = [&](uint32_t v, uint32_t n) {               // n <= 20, v < 2^n
+    auto put = [&](uint32_t v, uint32_t n) {               // n <= 32, v < 2^n (the accumulator holds < 32 bits before)
         acc |= (uint64_t)v << nb; nb += n;
         if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
     };
@@ -505,12 +545,15 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
                 st_ll = mll == 1 ? 0u : tll->sym[lc].first_state;
                 first = false;
             } else {
-                if (mof != 1) { const SeqSym y = tof->sym[oc]; uint32_t n = (st_of + y.delta_nb) >> 16; put(st_of & ((1u << n) - 1), n); st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
-                if (mml != 1) { const SeqSym y = tml->sym[mc]; uint32_t n = (st_ml + y.delta_nb) >> 16; put(st_ml & ((1u << n) - 1), n); st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
-                if (mll != 1) { const SeqSym y = tll->sym[lc]; uint32_t n = (st_ll + y.delta_nb) >> 16; put(st_ll & ((1u << n) - 1), n); st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
+                // the three state flushes (<= 9 bits each) go out as one field
+                uint32_t fv = 0, fn = 0;
+                if (mof != 1) { const SeqSym y = tof->sym[oc]; const uint32_t n = (st_of + y.delta_nb) >> 16; fv = st_of & ((1u << n) - 1); fn = n; st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
+                if (mml != 1) { const SeqSym y = tml->sym[mc]; const uint32_t n = (st_ml + y.delta_nb) >> 16; fv |= (st_ml & ((1u << n) - 1)) << fn; fn += n; st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
+                if (mll != 1) { const SeqSym y = tll->sym[lc]; const uint32_t n = (st_ll + y.delta_nb) >> 16; fv |= (st_ll & ((1u << n) - 1)) << fn; fn += n; st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
+                put(fv, fn);
             }
-            put(llv - lbase, lbits);
-            put(mlv - mbase, mbits);
+            // literal-length and match-length extra bits (<= 16 + 16) as one field, then the offset's
+            put((llv - lbase) | ((mlv - mbase) << lbits), lbits + mbits);
             put(ofb - (1u << oc), oc);
         }
         if (k == 0) break;
