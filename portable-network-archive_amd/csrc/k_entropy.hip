@@ -366,12 +366,12 @@ constexpr uint32_t LIT_STAGE_Q = 184;            // qwords of staging per wave: 
 
 __global__ __launch_bounds__(LIT_THREADS)
 void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint8_t *__restrict__ lits,
-           BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags) {
+           BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags, uint32_t g0) {
     __shared__ uint32_t code[256];
     __shared__ uint32_t sbits[4];
     __shared__ unsigned long long stage[4][LIT_STAGE_Q];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t g = blockIdx.x;
+    const uint32_t g = blockIdx.x + g0;                          // g0: first block of the chunk of segments this launch covers
     const SegTables *T = tabs + blk_seg[g];
     const uint32_t nlit = blk[g].nlit;
     const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
@@ -724,22 +724,24 @@ void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
 }
 
-void launch_entropy(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
-                    const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
-                    uint64_t *seg_size, uint64_t *seg_off, uint8_t *dst, uint32_t flags, hipStream_t st,
-                    hipEvent_t *ev /* 5 events: after stats, lit, seq, (plan+scan), write; may be null */) {
-    hipLaunchKernelGGL(k_stats, dim3(nseg), dim3(ST_THREADS), 0, st, segs, seqs, lits, blk, tabs, flags);
+// Entropy stage of the segments [s0, s0 + ns) whose blocks are [g0, g0 + nb): statistics + tables, literal streams,
+// sequence streams.  `tabs`, `segs` are the arrays of the whole batch.
+void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
+                          const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
+                          uint32_t flags, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
+    hipLaunchKernelGGL(k_stats, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags);
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (nblk) hipLaunchKernelGGL(k_lit, dim3(nblk), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags);
+    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0);
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_seq, dim3((nseg + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs, nseg, seqs, blk, tabs, seqc);
+    hipLaunchKernelGGL(k_seq, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc);
     if (ev) (void)hipEventRecord(ev[2], st);
+}
+// sizes of all segments -> offsets
+void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
+                 uint32_t flags, hipStream_t st) {
     hipLaunchKernelGGL(k_plan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, tabs, seg_size, flags);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, seg_size, seg_off, nseg);
-    if (ev) (void)hipEventRecord(ev[3], st);
-    (void)dst; (void)src;
 }
-
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
                   const uint8_t *seqc, uint8_t *dst, hipStream_t st) {
