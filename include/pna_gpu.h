@@ -97,6 +97,19 @@ int  pna_gpu_create_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t
                                    void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
                                    void *hip_stream);
 
+/* `pna create --solid` assembled in HBM: the inner entries are serialised as STORE records (FHED | fSIZ | FDAT | FEND, their
+ * CRC-32 on the device) into one stream, the stream is compressed as ONE entry and every segment's output becomes one SDAT
+ * chunk between SHED and SEND (create_archive_file's solid branch, cli/src/command/create.rs:594-598,603-617;
+ * lib/src/archive/write.rs:443-470,575-580,716-727; SolidHeader::to_bytes, lib/src/entry/header.rs:274-282).
+ * Arguments as pna_gpu_create_archive_device; inner entries >= 2 GiB are rejected (one FDAT chunk each). */
+size_t pna_gpu_solid_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len);
+int  pna_gpu_create_solid_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                         const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                         void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream);
+
+int  pna_gpu_create_solid_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                       const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
+
 /* Same archive from host memory with a bounded in-flight window: entries stream through two page-locked staging slots
  * (<= ~256 MiB of input each); staging of sub-batch k+1, the H2D copy, the kernels of sub-batch k and the D2H copy of
  * sub-batch k-1 overlap.  The sink receives the signature + AHED, then one piece per sub-batch, then AEND.  Replaces the

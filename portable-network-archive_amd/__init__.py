@@ -24,7 +24,7 @@ F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
 
 SEG_SIZE = 1 << 20
 BLK_SIZE = 1 << 17
-SEQ_CAP = 22016
+SEQ_CAP = 22528
 
 
 class Compression:
@@ -57,6 +57,7 @@ EXPORTS = [
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
+    "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -99,6 +100,11 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_device.restype = ctypes.c_int
     L.pna_gpu_create_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                 vp, sz, u64p, u64p, vp]
+    L.pna_gpu_solid_archive_bound.restype = sz
+    L.pna_gpu_solid_archive_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p]
+    L.pna_gpu_create_solid_archive_device.restype = ctypes.c_int
+    L.pna_gpu_create_solid_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
+                                                      vp, sz, u64p, vp]
     L.pna_gpu_debug_crc_schedule.restype = ctypes.c_uint32
     L.pna_gpu_debug_crc_schedule.argtypes = [ctypes.c_char_p, sz]
     L.pna_gpu_stream_new.restype = ctypes.c_int
@@ -235,6 +241,25 @@ class Context:
                                                           ctypes.c_void_p(stream) if stream else None))
         return total.value, list(a_out)
 
+    def create_solid_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
+                                    dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
+                                    _cache: Optional[dict] = None) -> int:
+        """`pna create --solid` assembled in HBM (pna_gpu_create_solid_archive_device).  Returns the archive length."""
+        n = len(src_len)
+        if _cache is not None and "a" in _cache:
+            a_names, a_off, a_len = _cache["a"]
+        else:
+            a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+            a_off = (ctypes.c_uint64 * (n + 1))(*(list(src_off)[:n] + [0]))
+            a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+            if _cache is not None:
+                _cache["a"] = (a_names, a_off, a_len)
+        total = ctypes.c_uint64()
+        self._check(self._L.pna_gpu_create_solid_archive_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
+                                                                ctypes.c_void_p(d_dst), dst_cap, ctypes.byref(total),
+                                                                ctypes.c_void_p(stream) if stream else None))
+        return total.value
+
     def timing(self) -> Timing:
         t = Timing()
         self._check(self._L.pna_gpu_last_timing(self._h, ctypes.byref(t)))
@@ -364,6 +389,13 @@ def archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> in
     a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
     a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
     return load_library().pna_gpu_archive_bound(algo, n, a_names, a_len)
+
+
+def solid_archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> int:
+    n = len(src_len)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+    return load_library().pna_gpu_solid_archive_bound(algo, n, a_names, a_len)
 
 
 def crc_schedule(payload: bytes) -> int:

@@ -4,7 +4,7 @@
 // Mirrors write_chunk (lib/src/io.rs:183-197: length BE | type | data | crc32(type || data) BE, crc = chunk_crc,
 // lib/src/format/chunk.rs:7-12) for the chunks of NormalEntry::write_chunks_to (lib/src/entry.rs:895-911).
 //
-// CRC-32 (reflected 0xEDB88320) of a long message on 256 lanes.  With R(s, M) the raw register update (no init / final
+// CRC-32 (reflected 0xEDB88320) of a long message (chunk type || payload) on 256 lanes.  With R(s, M) the raw register update (no init / final
 // xor) the code relies on three identities of the linear map R:
 //   (1) R(0xFFFFFFFF, M) = R(0, M ^ FF FF FF FF 00 00 ...)        |M| >= 4: the init value folds into the first 4 bytes
 //   (2) R(0, 0^k || M)   = R(0, M)                                zero bytes in front of the message are free
@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
 
 __global__ __launch_bounds__(FR_THREADS)
 void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct,
-             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc) {
+             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend) {
     __shared__ uint32_t sT[4][256], sZ[4][256];
     __shared__ uint32_t tile[FR_TILE_DW + FR_TILE_DW / 16 + 8];
     __shared__ uint32_t part[FR_THREADS];
@@ -45,6 +45,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     const FrameDesc d = fd[blockIdx.x];
     for (uint32_t i = tid; i < 1024; i += FR_THREADS) { (&sT[0][0])[i] = (&ct->T[0][0])[i]; (&sZ[0][0])[i] = (&ct->Z[0][0])[i]; }
     for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
+    if (d.pad) return;                                               // record without a data chunk: the prefix is all of it
 
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
     const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
@@ -52,7 +53,6 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     const uint32_t pad = ntile * FR_TILE - n;                        // zero bytes put in front, < FR_TILE
     const int64_t base = (int64_t)pay - 4 - (int64_t)pad;            // dst offset of message position 0 (may be negative)
     const uint32_t a = (uint32_t)(base & 15);                        // two's complement: correct for negative base too
-    const uint32_t ty_x = ~0x54414446u;                              // "FDAT" little-endian, complemented (identity 1)
     uint32_t state = 0;
 
     for (uint32_t k = 0; k < ntile; k++) {
@@ -100,7 +100,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         if ((tid & (2 * st - 1)) == 0) part[tid] = gf2_mulmod(ct->sh[j], part[tid]) ^ part[tid + st];
         __syncthreads();
     }
-    if (tid < 16) {
+    if (tid < (with_fend ? 16u : 4u)) {
         const uint32_t crc = ~part[0];
         // crc BE | 00 00 00 00 | "FEND" | crc("FEND") BE
         const uint32_t fe = 0x444E4546u;                              // "FEND" little-endian
@@ -113,9 +113,40 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     }
 }
 
+// ------------------------------------------------------------------ k_place : byte ranges to arbitrary offsets
+// One workgroup per piece (<= 1 MiB) of an entry: dst[dst_off .. +len) = src[src_off .. +len).  src_off is 16-byte aligned,
+// dst_off is not: whole destination dwords are assembled from two aligned source dwords, the <= 3 bytes at either end are
+// written singly.
+struct PlaceDesc { uint64_t src_off, dst_off; uint32_t len, pad; };
+__global__ __launch_bounds__(256)
+void k_place(const PlaceDesc *__restrict__ pd, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst) {
+    const PlaceDesc d = pd[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    const uint8_t *s = src + d.src_off;
+    uint8_t *o = dst + d.dst_off;
+    const uint32_t head = (uint32_t)((4 - (d.dst_off & 3)) & 3) < d.len ? (uint32_t)((4 - (d.dst_off & 3)) & 3) : d.len;
+    if (tid < head) o[tid] = s[tid];
+    const uint32_t body = (d.len - head) >> 2;                       // whole destination dwords
+    const uint32_t *s32 = (const uint32_t *)s;                       // aligned (src_off % 16 == 0)
+    uint32_t *o32 = (uint32_t *)(o + head);
+    const uint32_t sh = head * 8;                                    // source byte head + 4 i = dword i, shifted by head bytes
+    for (uint32_t i = tid; i < body; i += 256) {
+        const uint32_t lo = s32[i], hi = head ? s32[i + 1] : 0u;     // i + 1 stays inside the entry's 16-byte padded slot
+        o32[i] = head ? __builtin_amdgcn_alignbit(hi, lo, sh) : lo;
+    }
+    const uint32_t done = head + 4 * body;
+    if (tid < d.len - done) o[done + tid] = s[done + tid];
+}
+
+void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_place, dim3(n), dim3(256), 0, st, (const PlaceDesc *)pd, src, dst);
+}
+
+// ty: chunk type as it stands in the file (e.g. "FDAT"); with_fend: append an FEND chunk behind the data chunk's CRC
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
-                  uint32_t fend_crc, hipStream_t st) {
-    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc);
+                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st) {
+    const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
+    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u);
 }
 
 } // namespace pna

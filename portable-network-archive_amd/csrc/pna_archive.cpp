@@ -103,6 +103,16 @@ void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compressi
     uint8_t head[8]; put_be32(head, payload_len); memcpy(head + 4, "FDAT", 4);
     o.insert(o.end(), head, head + 8);
 }
+// an inner entry of a solid archive without data: FHED | fSIZ | FEND, no FDAT (FlattenWriter ignores empty writes)
+void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name) {
+    std::vector<uint8_t> h = fhed(0, 0, 0, 1, sanitize(name));
+    put_chunk(o, "FHED", h.data(), h.size());
+    uint8_t b[16]; size_t n = fsiz(0, b); put_chunk(o, "fSIZ", b, n);
+    put_chunk(o, "FEND", nullptr, 0);
+}
+// SHED chunk of an unencrypted solid entry -- lib/src/entry/header.rs:274-282; SEND -- lib/src/archive/write.rs:716-727
+void frame_solid_head(std::vector<uint8_t> &o, int compression) { const uint8_t shed[5] = {0, 0, (uint8_t)compression, 0, 1}; put_chunk(o, "SHED", shed, 5); }
+void frame_solid_tail(std::vector<uint8_t> &o) { put_chunk(o, "SEND", nullptr, 0); }
 size_t frame_entry_prefix_bound(const char *name) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 8; }
 uint32_t frame_fend_crc() { return pna_crc32(0, "FEND", 4); }
 } // namespace pna
@@ -175,6 +185,7 @@ extern "C" int pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int sol
     if (algo != PNA_ALGO_STORE && !ctx) return PNA_E_NODEVICE;
     // non-solid compressed archives: pipelined device path, archive bytes (framing + CRC included) come back from the GPU
     if (!solid && algo != PNA_ALGO_STORE) return pna_gpu_create_archive_host(ctx, algo, level, n, names, src, src_len, sink, user);
+    if (solid && algo != PNA_ALGO_STORE) return pna_gpu_create_solid_archive_host(ctx, algo, level, n, names, src, src_len, sink, user);
     pna_archive *a = nullptr;
     int rc = pna_archive_new(sink, user, 0, &a);
     if (rc) return rc;

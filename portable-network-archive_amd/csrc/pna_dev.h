@@ -23,7 +23,7 @@ constexpr uint32_t MAX_OFF    = 59392;      // 64 KiB window - 2 tiles - look-ah
 constexpr uint32_t CAP1       = 16;
 constexpr uint32_t LOOKAHEAD  = 1024;
 constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
-constexpr uint32_t SEQ_CAP    = 22016;      // sequences per block: BLK_SIZE / MIN_MATCH rounded up to 256
+constexpr uint32_t SEQ_CAP    = 22528;      // sequences per block: (BLK_SIZE - 3 * 1024) / MIN_MATCH + one front-cut match (>= 3 bytes) per wave region, rounded up to 256
 
 constexpr uint32_t F_HUF = 1, F_FSE = 2, F_LAZY = 4, F_REP = 8;
 

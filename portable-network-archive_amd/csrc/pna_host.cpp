@@ -33,7 +33,11 @@ void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const 
                   const uint8_t *seqc, uint8_t *dst, hipStream_t st);
 void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
-                  uint32_t fend_crc, hipStream_t st);
+                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
+void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
+void frame_solid_head(std::vector<uint8_t> &o, int compression);
+void frame_solid_tail(std::vector<uint8_t> &o);
 void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number);
 void frame_archive_tail(std::vector<uint8_t> &o);
 void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len);
@@ -78,6 +82,7 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
+    DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[2], hp_out[2];
@@ -140,7 +145,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -242,7 +247,7 @@ extern "C" uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len) 
     return ~lane[0];
 }
 
-struct FrameJob { const char *const *names; };               // names[e] for the batch's global entry index e
+struct FrameJob { const char *const *names; int solid; };    // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry
 
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
@@ -322,7 +327,15 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     HIPCHK(c, hipGetLastError());
     // while the kernels run: the name-dependent part of every entry record (FHED and fSIZ chunks with their CRCs)
     FrameDesc *fds = nullptr; uint8_t *blob = nullptr; uint64_t *segdst = nullptr; size_t blob_len = 0;
-    if (fj) {
+    const bool solid = fj && fj->solid;
+    size_t nunit = e1 - e0;                                    // framed units: entries, or the segments of the solid stream
+    if (solid) {
+        if (e1 - e0 != 1) return fail(c, PNA_E_INVAL, "a solid stream is one entry");
+        nunit = nseg;
+        if (c->h_desc.ensure(nunit * sizeof(FrameDesc)) || c->h_blob.ensure(nunit * 8 + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
+            return fail(c, PNA_E_NOMEM, "framing staging");
+        fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
+    } else if (fj) {
         std::vector<uint8_t> tmp;
         size_t bound = 0;
         for (size_t e = e0; e < e1; e++) bound += frame_entry_prefix_bound(fj->names[e]);
@@ -349,6 +362,20 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         // archive layout of this sub-batch: [prefix | payload | crc | FEND] per entry; the write kernels put every
         // segment straight at its final place, k_frame adds the rest (no second copy of the payload)
         uint64_t pos = out_base;
+        if (solid) {
+            // solid stream: one SDAT chunk per segment (= per zstd frame / per run of deflate blocks): [len "SDAT" | payload | crc]
+            dst_off[e0] = pos;
+            for (uint32_t sg = 0; sg < nseg; sg++) {
+                const uint64_t plen = seg_off[sg + 1] - seg_off[sg];
+                uint8_t *pf = blob + 8 * (size_t)sg;
+                pf[0] = (uint8_t)(plen >> 24); pf[1] = (uint8_t)(plen >> 16); pf[2] = (uint8_t)(plen >> 8); pf[3] = (uint8_t)plen;
+                memcpy(pf + 4, "SDAT", 4);
+                fds[sg] = FrameDesc{pos, (uint32_t)plen, 8u * sg, 8u, 0};
+                segdst[sg] = pos + 8;
+                pos += 8 + plen + 4;
+            }
+            blob_len = 8 * (size_t)nseg;
+        } else
         for (size_t e = e0; e < e1; e++) {
             const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
             const uint64_t plen = seg_off[s1] - seg_off[s0];
@@ -365,10 +392,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         segdst[nseg] = pos;
         total = pos - out_base;
         if (pos + 16 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
-        if (c->fr_desc.ensure((e1 - e0) * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8))
+        if (c->fr_desc.ensure(nunit * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing workspace");
         int rc = ensure_crc(c); if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->fr_desc.p, fds, (e1 - e0) * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->fr_desc.p, fds, nunit * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->fr_blob.p, blob, blob_len, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->fr_segdst.p, segdst, (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, st));
         d_segdst = (const uint64_t *)c->fr_segdst.p; wbase = d_dst;
@@ -380,8 +407,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
-    if (fj) launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)(e1 - e0), (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
-                         d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), st);
+    if (fj) launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)nunit, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
+                         d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), solid ? "SDAT" : "FDAT", !solid, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
     HIPCHK(c, hipGetLastError());
     if (!fj) for (size_t e = e0; e < e1; e++) dst_off[e] = out_base + seg_off[entry_first_seg[e - e0]];
@@ -474,7 +501,7 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
     HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    FrameJob fj{names};
+    FrameJob fj{names, 0};
     size_t e = 0;
     while (e < n) {
         size_t e1 = e, blocks = 0;
@@ -495,6 +522,114 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
     if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
     *archive_len = pos;
     c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// `pna create --solid` with the archive assembled in HBM (create_archive_file's solid branch, cli/src/command/create.rs:594-598,
+// 603-617; SolidArchive / SolidEntryBuilder, lib/src/archive/write.rs:443-470,575-580,716-727):
+//   1. the inner entries are serialised as STORE records FHED | fSIZ | FDAT | FEND (their FDAT CRC-32 computed by k_frame) into
+//      one stream in HBM,
+//   2. that stream is compressed as ONE entry (independent 1 MiB frames / zlib blocks inside the kernels),
+//   3. every segment's output becomes one SDAT chunk between SHED and SEND.
+struct PlaceDescH { uint64_t src_off, dst_off; uint32_t len, pad; };
+
+extern "C" size_t pna_gpu_solid_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len) {
+    uint64_t plain = 0;
+    for (size_t i = 0; i < n; i++) plain += frame_entry_prefix_bound(names ? names[i] : nullptr) + src_len[i] + 16;
+    const uint64_t segs = (plain + SEG_SIZE - 1) / SEG_SIZE + 1;
+    return 28 + 17 + pna_gpu_bound(algo, (size_t)plain) + 12 * segs + 12 + 12 + 64;
+}
+
+extern "C" int pna_gpu_create_solid_archive_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                   const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                   void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream) {
+    if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
+    if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
+    (void)level;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    // ---- 1. layout of the serialised inner entries (all sizes are known up front)
+    std::vector<FrameDesc> fds(n); std::vector<uint8_t> blob; std::vector<PlaceDescH> places;
+    uint64_t pos = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (src_off[i] & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
+        if (src_len[i] >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "inner entry too large for one FDAT chunk");
+        const size_t po = blob.size();
+        if (src_len[i] == 0) {
+            frame_inner_entry_empty(blob, names[i]);
+            fds[i] = FrameDesc{pos, 0, (uint32_t)po, (uint32_t)(blob.size() - po), 1};
+            pos += blob.size() - po;
+            continue;
+        }
+        frame_entry_prefix(blob, names[i], PNA_ALGO_STORE, src_len[i], (uint32_t)src_len[i]);
+        const uint32_t pl = (uint32_t)(blob.size() - po);
+        fds[i] = FrameDesc{pos, (uint32_t)src_len[i], (uint32_t)po, pl, 0};
+        for (uint64_t k = 0; k < src_len[i]; k += SEG_SIZE)
+            places.push_back(PlaceDescH{src_off[i] + k, pos + pl + k, (uint32_t)std::min<uint64_t>(SEG_SIZE, src_len[i] - k), 0});
+        pos += pl + src_len[i] + 16;
+    }
+    const uint64_t plain_len = pos;
+    if (c->solid_plain.ensure(plain_len + 8192) || c->solid_desc.ensure(n * sizeof(FrameDesc) + 16) || c->solid_blob.ensure(blob.size() + 16) ||
+        c->solid_place.ensure(places.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "solid workspace");
+    int rc = ensure_crc(c); if (rc) return rc;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, fds.data(), n * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->solid_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+        if (!places.empty()) HIPCHK(c, hipMemcpyAsync(c->solid_place.p, places.data(), places.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
+        launch_place(c->solid_place.p, (uint32_t)places.size(), (const uint8_t *)d_src, (uint8_t *)c->solid_plain.p, st);
+        launch_frame((const FrameDesc *)c->solid_desc.p, (uint32_t)n, (const uint8_t *)c->solid_blob.p, (const CrcTabs *)c->crc_tabs.p,
+                     (uint8_t *)c->solid_plain.p, (uint64_t)c->solid_plain.cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));                     // the host vectors above are read by the async copies
+    }
+    // ---- 2 + 3. one entry -> SDAT chunks, between the fixed chunks
+    c->timing = pna_gpu_timing{};
+    std::vector<uint8_t> head, tail;
+    frame_archive_head(head, 0); frame_solid_head(head, algo);
+    frame_solid_tail(tail); frame_archive_tail(tail);
+    if (head.size() + tail.size() + 64 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+    HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    const uint64_t off0 = 0, len0 = plain_len; uint64_t offs[2] = {0, 0};
+    FrameJob fj{nullptr, 1};
+    rc = run_subbatch(c, algo, (const uint8_t *)c->solid_plain.p, &off0, &len0, 0, 1, (uint8_t *)d_dst, dst_cap - tail.size(), head.size(), offs, st, true, &fj);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + offs[1], tail.data(), tail.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *archive_len = offs[1] + tail.size();
+    uint64_t in_total = 0; for (size_t i = 0; i < n; i++) in_total += src_len[i];
+    c->timing.in_bytes = in_total; c->timing.out_bytes = *archive_len;
+    return PNA_OK;
+}
+
+static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *src_len, const uint64_t *off, size_t e0, size_t e1, unsigned threads);
+
+// The same from host memory: one H2D of the entries, the device path above, one D2H of the archive, handed to the sink in
+// pieces of at most 16 MiB.  (The whole solid stream is in flight at once: a solid entry is one compression unit.)
+extern "C" int pna_gpu_create_solid_archive_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                 const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> off(n + 1), len(n);
+    uint64_t pos = 0;
+    for (size_t i = 0; i < n; i++) { off[i] = pos; len[i] = src_len[i]; pos = (pos + src_len[i] + 15) & ~(uint64_t)15; }
+    off[n] = pos;
+    const size_t cap = pna_gpu_solid_archive_bound(algo, n, names, len.data());
+    if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(cap + 64) || c->hp_in[0].ensure(pos + 64) || c->hp_out[0].ensure(cap + 64))
+        return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    parallel_stage((uint8_t *)c->hp_in[0].p, src, src_len, off.data(), 0, n, std::min(8u, std::max(1u, hw / 2)));
+    if (pos) HIPCHK(c, hipMemcpyAsync(c->stage_in.p, c->hp_in[0].p, pos, hipMemcpyHostToDevice, c->stream));
+    uint64_t total = 0;
+    int rc = pna_gpu_create_solid_archive_device(c, algo, level, n, names, c->stage_in.p, off.data(), len.data(), c->stage_out.p, cap + 64, &total, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->hp_out[0].p, c->stage_out.p, total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint64_t p = 0; p < total; p += (16u << 20)) {
+        const size_t k = (size_t)std::min<uint64_t>(16u << 20, total - p);
+        if (sink(user, (const uint8_t *)c->hp_out[0].p + p, k) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    }
     return PNA_OK;
 }
 
@@ -550,7 +685,7 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned threads = std::min(8u, std::max(1u, hw / 2));
-    FrameJob fj{names};
+    FrameJob fj{names, 0};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
     for (size_t e = 0; e < n; e++) in_total += src_len[e];

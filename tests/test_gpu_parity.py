@@ -331,3 +331,53 @@ def test_host_pipeline_many_sub_batches(gpu_ctx, pna, pf, codec):
     dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     total, _ = gpu_ctx.create_archive_device(names, dsrc.data_ptr(), offs, lens, dst.data_ptr(), cap)
     assert dst[:total].cpu().numpy().tobytes() == arc
+
+
+def test_many_short_matches_bit_exact(gpu_ctx, pna, codec):
+    """Adversarial for the per-block sequence capacity and for the merge of the waves' parses: 7-byte words from a small
+    vocabulary (back-to-back minimum-length matches, ends that fall 1-2 bytes behind the running end)."""
+    import random
+    rnd = random.Random(11)
+    vocab = [bytes(rnd.randrange(97, 123) for _ in range(7)) for _ in range(48)]
+    d1 = b"".join(rnd.choice(vocab) for _ in range(60000))                      # 420 000 B
+    vocab2 = [bytes(rnd.randrange(65, 91) for _ in range(rnd.choice((6, 7, 8, 9)))) for _ in range(300)]
+    d2 = b"".join(rnd.choice(vocab2) for _ in range(150000))[: (1 << 20) + 333]
+    for d in (d1, d2):
+        out = gpu_ctx.compress_batch([d])[0]
+        assert out == codec.model_compress(d, _params(codec))
+        assert codec.zstd_decompress(out, len(d) + 64) == d
+        dz = gpu_ctx.compress_batch([d], algo=pna.ALGO_DEFLATE)[0]
+        assert dz == codec.deflate_model_compress(d) and zlib.decompress(dz) == d
+
+
+@pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
+def test_solid_archive_assembled_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
+    """pna_gpu_create_solid_archive_device: inner STORE records (device CRC-32) -> one compressed stream -> one SDAT chunk per
+    segment.  The oracle's reader checks every chunk CRC (outer and inner) and the inner entries must equal the inputs; the
+    serialised inner stream must equal the oracle writer's bytes."""
+    import torch
+    algo = pna.ALGO_ZSTD if algo_name == "zstd" else pna.ALGO_DEFLATE
+    lens = [0, 1, 3, 4095, 65536, 70001, (1 << 20) - 13, (1 << 20), (1 << 20) + 1, 2500000, 12, 0, 300000]
+    ents = [codec.corpus_file(i % 2, 80 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"solid/d{i % 2}/f{i:03d}.bin" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    cap = pna.solid_archive_bound(algo, names, lens)
+    dst = torch.full((cap,), 0x5A, dtype=torch.uint8, device="cuda")
+    total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo)
+    arc = dst[:total].cpu().numpy().tobytes()
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\x5A" * 16
+    _, items = pf.read_archive(arc)
+    assert len(items) == 1 and items[0].compression == algo
+    plain = codec.decode_payload(algo, items[0].data, 16 << 20)
+    want_plain = b"".join(pf.write_normal_entry(pf.file_entry_header(0, pf.sanitize_name(nm)), [e] if e else [], len(e)) for nm, e in zip(names, ents))
+    assert plain == want_plain
+    inner = pf.read_solid_inner(plain)
+    assert [(e.name, e.data) for e in inner] == list(zip(names, ents))
+    # the host entry point takes the same route
+    assert pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=True) == arc
