@@ -101,8 +101,9 @@ def main() -> None:
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--algo", choices=["zstd", "deflate"], default="zstd")
     ap.add_argument("--kind", type=int, default=0, help="corpus kind (0 enwik-style text, 1 random-text)")
-    ap.add_argument("--framing", choices=["archive", "none"], default="archive",
-                    help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only")
+    ap.add_argument("--framing", choices=["archive", "none", "solid"], default="archive",
+                    help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only; "
+                         "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
     args = ap.parse_args()
@@ -133,6 +134,8 @@ def main() -> None:
     names = [f"enwik/part{rank * n_files + i:07d}.txt" for i in range(n_files)]
     if args.framing == "archive":
         dst_cap = pna.archive_bound(algo, names, src_len)
+    elif args.framing == "solid":
+        dst_cap = pna.solid_archive_bound(algo, names, src_len)
     else:
         dst_cap = pna.bound(algo, file_len) * n_files + 4096
     dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
@@ -145,6 +148,8 @@ def main() -> None:
         if args.framing == "archive":
             total, _ = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo,
                                                  _cache=arg_cache)
+        elif args.framing == "solid":
+            total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache)
         else:
             total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
         if world > 1:
@@ -197,6 +202,7 @@ def main() -> None:
             "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text per GPU, Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} "
                                    f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1), inputs resident in HBM, "
                                    + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
+                                      else "--solid: inner STORE records serialised + one compressed stream + SDAT framing, all in HBM" if args.framing == "solid"
                                       else "output = packed compressed entry streams in HBM"),
                        "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
             "ratio": round(in_all / max(out_all, 1), 4),

@@ -429,8 +429,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             (void)hipEventElapsedTime(&ms[5], c->ev[5], c->ev[6]);
         } else {
             // k_lz: first launch to last completion on the main stream; the entropy stages are summed over the chunks on the
-            // auxiliary stream (they overlap k_lz, so the stage times add up to more than the wall time); "pack" = from the
-            // end of the last k_lz to the end of the write kernels (drain of the last chunk + plan + scan + write)
+            // auxiliary stream (with more than one chunk they overlap k_lz and add up to more than the wall time); "pack" = from the
+            // end of the last chunk's entropy stage to the end of the write kernels (plan + scan + offsets to the host + write)
             (void)hipEventElapsedTime(&ms[0], c->ev_lz[0], c->ev_lz[nch]);
             for (int k = 0; k < nch; k++) {
                 float a = 0, b2 = 0, d = 0;
@@ -439,7 +439,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 (void)hipEventElapsedTime(&d, c->ev_en[k][2], c->ev_en[k][3]);
                 ms[1] += a; ms[2] += b2; ms[3] += d;
             }
-            (void)hipEventElapsedTime(&ms[4], c->ev_lz[nch], c->ev[6]);
+            (void)hipEventElapsedTime(&ms[4], c->ev_en[nch - 1][3], c->ev[6]);
         }
         c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
         c->timing.ms_pack += ms[4] + ms[5];
