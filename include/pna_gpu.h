@@ -92,6 +92,15 @@ int  pna_gpu_compress_batch_device(pna_gpu_ctx *ctx, int algo, int level, size_t
  * NULL, entry_off[i] (n + 1 values) is the offset of entry i's FHED chunk.  Byte-identical to pna_create_archive()
  * (include/pna_archive.h) over the same entries. */
 size_t pna_gpu_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len);
+/* One shard of an archive whose entries are split over several producers (one rank per GPU): only the shard with
+ * PNA_PART_HEAD carries the signature + AHED, only the one with PNA_PART_TAIL the AEND; the shards' outputs concatenated
+ * in entry order are the archive (the ordered drain of drain_entry_results, cli/src/command/core.rs:471-493). */
+#define PNA_PART_HEAD 1u
+#define PNA_PART_TAIL 2u
+int  pna_gpu_create_archive_part_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                        const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                        void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
+                                        uint32_t part_flags, void *hip_stream);
 int  pna_gpu_create_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                    const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                    void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,

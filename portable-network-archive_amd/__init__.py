@@ -23,6 +23,7 @@ LEVEL_DEFAULT = -1000
 F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
 
 SEG_SIZE = 1 << 20
+PART_HEAD, PART_TAIL = 1, 2
 BLK_SIZE = 1 << 17
 SEQ_CAP = 22528
 
@@ -58,6 +59,7 @@ EXPORTS = [
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
+    "pna_gpu_create_archive_part_device",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -100,6 +102,9 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_device.restype = ctypes.c_int
     L.pna_gpu_create_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                 vp, sz, u64p, u64p, vp]
+    L.pna_gpu_create_archive_part_device.restype = ctypes.c_int
+    L.pna_gpu_create_archive_part_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
+                                                     vp, sz, u64p, u64p, u32, vp]
     L.pna_gpu_solid_archive_bound.restype = sz
     L.pna_gpu_solid_archive_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p]
     L.pna_gpu_create_solid_archive_device.restype = ctypes.c_int
@@ -223,8 +228,9 @@ class Context:
 
     def create_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                               dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
-                              _cache: Optional[dict] = None):
-        """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_device).  Returns (archive_len, entry_off)."""
+                              _cache: Optional[dict] = None, part: int = PART_HEAD | PART_TAIL):
+        """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_part_device; `part` selects whether this shard
+        carries the archive header / AEND).  Returns (archive_len, entry_off)."""
         n = len(src_len)
         if _cache is not None and "a" in _cache:
             a_names, a_off, a_len = _cache["a"]
@@ -236,9 +242,9 @@ class Context:
                 _cache["a"] = (a_names, a_off, a_len)
         a_out = (ctypes.c_uint64 * (n + 1))()
         total = ctypes.c_uint64()
-        self._check(self._L.pna_gpu_create_archive_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
-                                                          ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total),
-                                                          ctypes.c_void_p(stream) if stream else None))
+        self._check(self._L.pna_gpu_create_archive_part_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
+                                                               ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total), part,
+                                                               ctypes.c_void_p(stream) if stream else None))
         return total.value, list(a_out)
 
     def create_solid_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,

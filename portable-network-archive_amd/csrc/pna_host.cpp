@@ -489,6 +489,16 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
                                              const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                              void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
                                              void *hip_stream) {
+    return pna_gpu_create_archive_part_device(c, algo, level, n, names, d_src, src_off, src_len, d_dst, dst_cap, entry_off, archive_len,
+                                              PNA_PART_HEAD | PNA_PART_TAIL, hip_stream);
+}
+
+// One shard of an archive whose entries are split over several producers (ranks): only the first shard carries the signature +
+// AHED, only the last one AEND; the shards' outputs concatenated in entry order are the archive.
+extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                  const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                  void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
+                                                  uint32_t part_flags, void *hip_stream) {
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
@@ -496,9 +506,11 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->timing = pna_gpu_timing{};
-    std::vector<uint8_t> head, tail; frame_archive_head(head, 0); frame_archive_tail(tail);
+    std::vector<uint8_t> head, tail;
+    if (part_flags & PNA_PART_HEAD) frame_archive_head(head, 0);
+    if (part_flags & PNA_PART_TAIL) frame_archive_tail(tail);
     if (head.size() + tail.size() + 16 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
-    HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
     FrameJob fj{names, 0};
@@ -516,7 +528,7 @@ extern "C" int pna_gpu_create_archive_device(pna_gpu_ctx *c, int algo, int level
         e = e1;
     }
     offs[n] = pos;
-    HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + pos, tail.data(), tail.size(), hipMemcpyHostToDevice, st));
+    if (!tail.empty()) HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + pos, tail.data(), tail.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));
     pos += tail.size();
     if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);

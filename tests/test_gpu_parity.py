@@ -5,6 +5,7 @@ with two independent decoders (oracle/zstd_dec.c, system libzstd) to the input, 
 the fixture-pinned container reader to the original tree.
 """
 import hashlib
+import importlib
 import io
 import os
 import zlib
@@ -381,3 +382,32 @@ def test_solid_archive_assembled_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
     assert [(e.name, e.data) for e in inner] == list(zip(names, ents))
     # the host entry point takes the same route
     assert pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=True) == arc
+
+
+def test_archive_shards_concatenate(gpu_ctx, pna, pf, codec):
+    """Two producers (ranks) each assemble their contiguous range of entries; head only on the first, AEND only on the last:
+    the concatenation in rank order must be byte-identical to the archive one producer makes of all entries."""
+    import torch
+    shard = importlib.import_module("portable-network-archive_amd.shard")
+    lens = [70000 + 977 * i for i in range(24)] + [0, 5, 1 << 20]
+    ents = [codec.corpus_file(0, 400 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"s/{i:03d}" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    cap = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, _ = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap)
+    whole = dst[:total].cpu().numpy().tobytes()
+    parts = []
+    bounds = shard.partition_entries(lens, 2)
+    for r, (a, b) in enumerate(bounds):
+        part = (pna.PART_HEAD if r == 0 else 0) | (pna.PART_TAIL if r == len(bounds) - 1 else 0)
+        t, _ = gpu_ctx.create_archive_device(names[a:b], src.data_ptr(), offs[a:b], lens[a:b], dst.data_ptr(), cap, part=part)
+        parts.append(dst[:t].cpu().numpy().tobytes())
+    assert b"".join(parts) == whole
+    assert [it.name for it in pf.read_archive(whole)[1]] == names
