@@ -59,7 +59,7 @@ EXPORTS = [
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
-    "pna_gpu_create_archive_part_device",
+    "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -105,6 +105,10 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_part_device.restype = ctypes.c_int
     L.pna_gpu_create_archive_part_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                      vp, sz, u64p, u64p, u32, vp]
+    L.pna_gpu_decompress_batch.restype = ctypes.c_int
+    L.pna_gpu_decompress_batch.argtypes = [vp, ctypes.c_int, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    L.pna_gpu_decompress_batch_device.restype = ctypes.c_int
+    L.pna_gpu_decompress_batch_device.argtypes = [vp, ctypes.c_int, sz, vp, u64p, u64p, vp, u64p, u64p, vp]
     L.pna_gpu_solid_archive_bound.restype = sz
     L.pna_gpu_solid_archive_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p]
     L.pna_gpu_create_solid_archive_device.restype = ctypes.c_int
@@ -265,6 +269,26 @@ class Context:
                                                                 ctypes.c_void_p(d_dst), dst_cap, ctypes.byref(total),
                                                                 ctypes.c_void_p(stream) if stream else None))
         return total.value
+
+    def decompress_batch(self, payloads: Sequence[bytes], raw_sizes: Sequence[int], algo: int = ALGO_ZSTD) -> List[bytes]:
+        """decompress_reader for a batch of entries: payload i (concatenated FDAT bodies) -> raw_sizes[i] bytes."""
+        n = len(payloads)
+        keep = [p if isinstance(p, bytes) else bytes(p) for p in payloads]
+        outs = [ctypes.create_string_buffer(max(r, 1)) for r in raw_sizes]
+        a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in keep])
+        a_sl = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in keep])
+        a_dst = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(o, ctypes.c_void_p) for o in outs])
+        a_rl = (ctypes.c_size_t * max(n, 1))(*raw_sizes)
+        self._check(self._L.pna_gpu_decompress_batch(self._h, algo, n, a_src, a_sl, a_dst, a_rl))
+        return [o.raw[:r] for o, r in zip(outs, raw_sizes)]
+
+    def decompress_batch_device(self, d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int, dst_off: Sequence[int],
+                                raw_len: Sequence[int], algo: int = ALGO_ZSTD, stream: int = 0) -> None:
+        n = len(src_len)
+        mk = lambda xs: (ctypes.c_uint64 * max(n, 1))(*list(xs)[:n])
+        self._check(self._L.pna_gpu_decompress_batch_device(self._h, algo, n, ctypes.c_void_p(d_src), mk(src_off), mk(src_len),
+                                                            ctypes.c_void_p(d_dst), mk(dst_off), mk(raw_len),
+                                                            ctypes.c_void_p(stream) if stream else None))
 
     def timing(self) -> Timing:
         t = Timing()

@@ -1,0 +1,513 @@
+// k_zdec.hip -- zstd frame decoder for gfx950: the read side of the compression seam,
+// decompress_reader() -> zstd::stream::read::Decoder (lib/src/entry/read.rs:171-190), used by extract / verify
+// (cli/src/command/extract.rs:594-640, verify.rs:140-188).  General RFC 8878 frames without dictionary (what the reference
+// and this repository's encoder write): raw / RLE / compressed blocks, raw / RLE / Huffman / treeless literals with direct
+// or FSE-compressed weights, predefined / RLE / FSE / repeat sequence tables, repeat offsets.
+//
+// One 256-thread workgroup per frame, blocks in order (a block may copy from everything before it in the frame):
+//   thread 0 parses the block and section headers and builds the Huffman weights / FSE distributions (short serial codes),
+//   all threads fill the Huffman decoding table, 1 or 4 lanes decode the literal streams INTO THE TAIL OF THE FRAME'S OUTPUT
+//   region (the write position of the block can never pass the literals still to be read), lane 0 of wave 0 runs the serial
+//   FSE chain in batches of 256 sequences and wave 0 executes each batch with 64-lane copies straight in the output buffer.
+//   A workgroup-scope fence is issued only when a match reaches into bytes written since the previous fence.
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+constexpr uint32_t ZD_THREADS = 256;
+constexpr int ZD_HUF_MAX = 11;
+constexpr uint32_t ZD_BATCH = 256;
+enum { ZD_OK = 0, ZD_CORRUPT = 1, ZD_UNSUPPORTED = 2, ZD_DSTSIZE = 3 };
+
+typedef unsigned long long zd_u64u __attribute__((aligned(1)));
+
+__constant__ int16_t ZD_LL_DEF[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__constant__ int16_t ZD_ML_DEF[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+__constant__ int16_t ZD_OF_DEF[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+__constant__ uint32_t ZD_LL_BASE[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+__constant__ uint8_t  ZD_LL_BITS[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__constant__ uint32_t ZD_ML_BASE[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+__constant__ uint8_t  ZD_ML_BITS[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+
+__device__ __forceinline__ int zd_hb(uint32_t v) { return 31 - (int)__builtin_clz(v); }           // v != 0
+
+// n bits (<= 56) at bit offset off >= 0 of the little-endian bit string p; reads 8 bytes at p + off / 8 (the source buffer
+// carries 8 bytes of slack behind its last stream)
+__device__ __forceinline__ uint64_t zd_bits(const uint8_t *p, int64_t off, uint32_t n) {
+    const uint64_t v = *(const zd_u64u *)(p + (off >> 3)) >> (off & 7);
+    return v & (((uint64_t)1 << n) - 1);
+}
+// backward reader: `off` = number of unread bits below the cursor; bits below the start of the string read as zero
+struct ZdBits { const uint8_t *p; int64_t off; };
+__device__ __forceinline__ bool zd_binit(ZdBits &b, const uint8_t *p, uint32_t len) {
+    if (len == 0) return false;
+    const uint32_t last = p[len - 1];
+    if (last == 0) return false;
+    b.p = p; b.off = (int64_t)len * 8 - (8 - zd_hb(last));
+    return true;
+}
+__device__ __forceinline__ uint64_t zd_bread(ZdBits &b, uint32_t n) {
+    if (n == 0) return 0;
+    b.off -= n;
+    if (b.off >= 0) return zd_bits(b.p, b.off, n);
+    const int64_t have = (int64_t)n + b.off;                       // bits that exist
+    if (have <= 0) return 0;
+    return zd_bits(b.p, 0, (uint32_t)have) << (uint32_t)(-b.off);
+}
+
+// FSE decoding table (sym | nbits << 8 | base << 16) from a normalised distribution; serial (one thread)
+__device__ bool zd_fse_build(uint32_t *tab, const int16_t *norm, int nsym, int alog, uint16_t *next /* [256] scratch */) {
+    if (alog > 9) return false;
+    const int size = 1 << alog;
+    int high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+        if (norm[s] == -1) { tab[high--] = (uint32_t)s; next[s] = 1; }
+        else next[s] = (uint16_t)norm[s];
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++)
+        for (int i = 0; i < norm[s]; i++) { tab[pos] = (uint32_t)s; do { pos = (pos + step) & mask; } while (pos > high); }
+    if (pos != 0) return false;
+    for (int u = 0; u < size; u++) {
+        const uint32_t s = tab[u] & 0xFF;
+        const uint32_t ns = next[s]++;
+        const uint32_t nb = (uint32_t)(alog - zd_hb(ns));
+        tab[u] = s | (nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFF) << 16);
+    }
+    return true;
+}
+
+// FSE table description (forward bits); returns bytes consumed, 0 on error
+__device__ uint32_t zd_fse_desc(const uint8_t *src, uint32_t len, int16_t *norm, int *nsym_out, int *alog_out, int max_sym, int max_alog) {
+    if (len < 1) return 0;
+    uint64_t bitpos = 0;
+    auto peek = [&](uint32_t n) -> uint32_t {
+        uint64_t v = 0; const uint64_t byte = bitpos >> 3;
+        for (int i = 0; i < 5; i++) if (byte + i < len) v |= (uint64_t)src[byte + i] << (8 * i);
+        return (uint32_t)((v >> (bitpos & 7)) & (((uint64_t)1 << n) - 1));
+    };
+    const int alog = (int)peek(4) + 5; bitpos += 4;
+    if (alog > max_alog) return 0;
+    int remaining = (1 << alog) + 1, threshold = 1 << alog, nbits = alog + 1, sym = 0;
+    for (int i = 0; i <= max_sym; i++) norm[i] = 0;
+    while (remaining > 1 && sym <= max_sym) {
+        const int mx = (2 * threshold - 1) - remaining;
+        int count;
+        const uint32_t v = peek((uint32_t)nbits);
+        if ((int)(v & (uint32_t)(threshold - 1)) < mx) { count = (int)(v & (uint32_t)(threshold - 1)); bitpos += (uint32_t)(nbits - 1); }
+        else { count = (int)(v & (uint32_t)(2 * threshold - 1)); if (count >= threshold) count -= mx; bitpos += (uint32_t)nbits; }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        norm[sym++] = (int16_t)count;
+        if (count == 0) {
+            for (;;) {
+                const uint32_t rep = peek(2); bitpos += 2;
+                for (uint32_t i = 0; i < rep && sym <= max_sym; i++) norm[sym++] = 0;
+                if (rep != 3) break;
+            }
+        }
+        while (remaining < threshold) { nbits--; threshold >>= 1; }
+        if ((bitpos + 7) / 8 > len) return 0;
+    }
+    if (remaining != 1 || sym > max_sym + 1) return 0;
+    *nsym_out = sym; *alog_out = alog;
+    return (uint32_t)((bitpos + 7) / 8);
+}
+
+struct ZdBlk {                 // what thread 0 tells the workgroup about the current block
+    uint32_t status;           // ZD_*
+    uint32_t last, type, size; // block header
+    uint32_t ltype, regen, streams, lit_off, lit_csize;   // literals: payload offset (block-relative) and compressed size behind the tree
+    uint32_t new_tree, nweights, maxbits;
+    uint32_t nseq, seq_off, seq_len;                      // sequence bitstream (block-relative)
+    uint32_t alog[3];
+};
+
+__global__ __launch_bounds__(ZD_THREADS)
+void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst) {
+    __shared__ uint16_t huf_tab[1 << ZD_HUF_MAX];      // sym | nbits << 8
+    __shared__ uint32_t fse_tab[3][512];               // LL, OF, ML
+    __shared__ uint8_t  weights[256];
+    __shared__ int16_t  norm[256];
+    __shared__ uint16_t nexts[256];
+    __shared__ ZdBlk    B;
+    __shared__ uint64_t sq[ZD_BATCH];                  // ll | ml << 20 | offset value << 40
+    __shared__ uint32_t wtab[64];                      // weight-decoding table (alog <= 6)
+    __shared__ uint32_t s_nb, s_ok[3], s_alog[3], s_huf_ok, s_hufbits, s_err, s_op, s_rep[3];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ZFrame fr = frames[blockIdx.x];
+    const uint8_t *in = src + fr.src_off;
+    uint8_t *out = dst + fr.dst_off;
+    const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    uint32_t ip = 0, op = 0;
+    uint32_t status = ZD_OK;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    if (tid == 0) { s_ok[0] = s_ok[1] = s_ok[2] = 0; s_huf_ok = 0; s_err = 0; }
+
+    // ---- frame header (uniform)
+    {
+        if (in_len < 6) status = ZD_CORRUPT;
+        else {
+            const uint32_t magic = in[0] | (in[1] << 8) | (in[2] << 16) | ((uint32_t)in[3] << 24);
+            if (magic != 0xFD2FB528u) status = ZD_CORRUPT;
+            else {
+                const uint32_t fhd = in[4];
+                const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+                ip = 5;
+                if (fhd & 0x08) status = ZD_CORRUPT;
+                if (!single) ip += 1;                                    // window descriptor: the whole frame is addressable here
+                if (dict) status = ZD_UNSUPPORTED;
+                const uint32_t fsz = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+                if (ip + fsz > in_len) status = ZD_CORRUPT;
+                else {
+                    uint64_t fcs = 0;
+                    for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
+                    if (fsz == 2) fcs += 256;
+                    if (fsz && fcs != cap) status = ZD_DSTSIZE;
+                    ip += fsz;
+                }
+                if ((fhd >> 2) & 1) { /* content checksum: 4 bytes after the last block, not verified */ }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (fr.status) status = fr.status;                                 // set by the scan
+    bool done = status != ZD_OK;
+    while (!done) {
+        // ================= thread 0: headers, weights, distributions
+        if (tid == 0) {
+            ZdBlk b; b.status = ZD_OK; b.new_tree = 0; b.nseq = 0; b.regen = 0; b.ltype = 0; b.streams = 1; b.lit_off = 0; b.lit_csize = 0;
+            b.seq_off = 0; b.seq_len = 0; b.nweights = 0; b.maxbits = 0; b.alog[0] = b.alog[1] = b.alog[2] = 0;
+            b.last = 1; b.type = 0; b.size = 0;
+            do {
+                if (ip + 3 > in_len) { b.status = ZD_CORRUPT; break; }
+                const uint32_t bh = in[ip] | (in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
+                b.last = bh & 1; b.type = (bh >> 1) & 3; b.size = bh >> 3;
+                if (b.type == 3 || b.size > (128u << 10)) { b.status = ZD_CORRUPT; break; }
+                const uint32_t body = ip + 3;
+                if (b.type == 1) { if (body + 1 > in_len) b.status = ZD_CORRUPT; break; }
+                if (body + b.size > in_len) { b.status = ZD_CORRUPT; break; }
+                if (b.type == 0) break;
+                // ---- compressed block: literals section
+                const uint8_t *p = in + body; const uint32_t len = b.size;
+                if (len < 1) { b.status = ZD_CORRUPT; break; }
+                const uint32_t ltype = p[0] & 3, sf = (p[0] >> 2) & 3;
+                uint32_t regen, comp = 0, hdr, streams = 1;
+                if (ltype < 2) {
+                    if (sf == 0 || sf == 2) { regen = p[0] >> 3; hdr = 1; }
+                    else if (sf == 1) { if (len < 2) { b.status = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4); hdr = 2; }
+                    else { if (len < 3) { b.status = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4) + ((uint32_t)p[2] << 12); hdr = 3; }
+                } else {
+                    if (len < 5) { b.status = ZD_CORRUPT; break; }
+                    uint64_t v = 0; for (int i = 0; i < 5; i++) v |= (uint64_t)p[i] << (8 * i);
+                    if (sf == 0) { streams = 1; hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                    else if (sf == 1) { streams = 4; hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                    else if (sf == 2) { streams = 4; hdr = 4; regen = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; }
+                    else { streams = 4; hdr = 5; regen = (v >> 4) & 0x3FFFF; comp = (v >> 22) & 0x3FFFF; }
+                }
+                if (regen > (128u << 10) || regen > cap) { b.status = ZD_CORRUPT; break; }
+                b.ltype = ltype; b.regen = regen; b.streams = streams;
+                uint32_t pos = hdr;
+                if (ltype == 0) { if (pos + regen > len) { b.status = ZD_CORRUPT; break; } b.lit_off = pos; pos += regen; }
+                else if (ltype == 1) { if (pos + 1 > len) { b.status = ZD_CORRUPT; break; } b.lit_off = pos; pos += 1; }
+                else {
+                    if (pos + comp > len) { b.status = ZD_CORRUPT; break; }
+                    const uint8_t *cs = p + pos; uint32_t cl = comp, used = 0;
+                    if (ltype == 2) {
+                        // ---- Huffman tree description -> weights[0 .. nw), the last weight is implied
+                        if (cl < 1) { b.status = ZD_CORRUPT; break; }
+                        const uint32_t hbyte = cs[0];
+                        uint32_t nw = 0;
+                        if (hbyte >= 128) {
+                            nw = hbyte - 127;
+                            const uint32_t bytes = (nw + 1) / 2;
+                            if (1 + bytes > cl) { b.status = ZD_CORRUPT; break; }
+                            for (uint32_t i = 0; i < nw; i++) { const uint32_t by = cs[1 + i / 2]; weights[i] = (uint8_t)((i & 1) ? (by & 15) : (by >> 4)); }
+                            used = 1 + bytes;
+                        } else {
+                            const uint32_t csize = hbyte;
+                            if (csize == 0 || 1 + csize > cl) { b.status = ZD_CORRUPT; break; }
+                            int nsym, alog;
+                            const uint32_t dl = zd_fse_desc(cs + 1, csize, norm, &nsym, &alog, 255, 6);
+                            if (!dl || dl >= csize || !zd_fse_build(wtab, norm, nsym, alog, nexts)) { b.status = ZD_CORRUPT; break; }
+                            ZdBits bb;
+                            if (!zd_binit(bb, cs + 1 + dl, csize - dl)) { b.status = ZD_CORRUPT; break; }
+                            uint32_t s1 = (uint32_t)zd_bread(bb, (uint32_t)alog), s2 = (uint32_t)zd_bread(bb, (uint32_t)alog);
+                            bool bad = false;
+                            for (;;) {
+                                if (nw >= 255) { bad = true; break; }
+                                weights[nw++] = (uint8_t)(wtab[s1] & 0xFF);
+                                s1 = (wtab[s1] >> 16) + (uint32_t)zd_bread(bb, (wtab[s1] >> 8) & 0xFF);
+                                if (bb.off < 0) { if (nw >= 255) { bad = true; break; } weights[nw++] = (uint8_t)(wtab[s2] & 0xFF); break; }
+                                if (nw >= 255) { bad = true; break; }
+                                weights[nw++] = (uint8_t)(wtab[s2] & 0xFF);
+                                s2 = (wtab[s2] >> 16) + (uint32_t)zd_bread(bb, (wtab[s2] >> 8) & 0xFF);
+                                if (bb.off < 0) { if (nw >= 255) { bad = true; break; } weights[nw++] = (uint8_t)(wtab[s1] & 0xFF); break; }
+                            }
+                            if (bad) { b.status = ZD_CORRUPT; break; }
+                            used = 1 + csize;
+                        }
+                        uint32_t total = 0; bool badw = false;
+                        for (uint32_t i = 0; i < nw; i++) { if (weights[i] > ZD_HUF_MAX) badw = true; else if (weights[i]) total += 1u << (weights[i] - 1); }
+                        if (badw || total == 0 || nw < 1) { b.status = ZD_CORRUPT; break; }
+                        const uint32_t maxbits = (uint32_t)zd_hb(total) + 1;
+                        const uint32_t rest = (1u << maxbits) - total;
+                        if (maxbits > (uint32_t)ZD_HUF_MAX || rest == 0 || (rest & (rest - 1))) { b.status = ZD_CORRUPT; break; }
+                        weights[nw] = (uint8_t)(zd_hb(rest) + 1);
+                        b.new_tree = 1; b.nweights = nw + 1; b.maxbits = maxbits; s_huf_ok = 1; s_hufbits = maxbits;
+                    } else if (!s_huf_ok) { b.status = ZD_CORRUPT; break; }
+                    if (used > cl) { b.status = ZD_CORRUPT; break; }
+                    b.lit_off = pos + used; b.lit_csize = cl - used;
+                    pos += comp;
+                }
+                // ---- sequences section
+                if (pos >= len) { b.status = ZD_CORRUPT; break; }
+                uint32_t nseq; const uint32_t b0 = p[pos++];
+                if (b0 < 128) nseq = b0;
+                else if (b0 < 255) { if (pos >= len) { b.status = ZD_CORRUPT; break; } nseq = ((b0 - 128) << 8) + p[pos++]; }
+                else { if (pos + 2 > len) { b.status = ZD_CORRUPT; break; } nseq = p[pos] + ((uint32_t)p[pos + 1] << 8) + 0x7F00; pos += 2; }
+                b.nseq = nseq;
+                if (nseq == 0) { if (pos != len) b.status = ZD_CORRUPT; break; }
+                if (pos >= len) { b.status = ZD_CORRUPT; break; }
+                const uint32_t modes = p[pos++];
+                if (modes & 3) { b.status = ZD_CORRUPT; break; }
+                bool ok = true;
+                for (int k = 0; k < 3 && ok; k++) {                         // LL, OF, ML in stream order
+                    const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+                    const int16_t *def = k == 0 ? ZD_LL_DEF : (k == 1 ? ZD_OF_DEF : ZD_ML_DEF);
+                    const int def_n = k == 0 ? 36 : (k == 1 ? 29 : 53), def_log = k == 1 ? 5 : 6;
+                    const int max_sym = k == 0 ? 35 : (k == 1 ? 31 : 52), max_log = k == 1 ? 8 : 9;
+                    if (mode == 0) {
+                        for (int i = 0; i < def_n; i++) norm[i] = def[i];
+                        ok = zd_fse_build(fse_tab[k], norm, def_n, def_log, nexts); s_ok[k] = 1; s_alog[k] = (uint32_t)def_log;
+                    } else if (mode == 1) {
+                        if (pos >= len || p[pos] > max_sym) { ok = false; break; }
+                        fse_tab[k][0] = p[pos]; pos++; s_ok[k] = 1; s_alog[k] = 0;
+                    } else if (mode == 2) {
+                        int nsym, alog;
+                        const uint32_t used = zd_fse_desc(p + pos, len - pos, norm, &nsym, &alog, max_sym, max_log);
+                        if (!used) { ok = false; break; }
+                        ok = zd_fse_build(fse_tab[k], norm, nsym, alog, nexts); pos += used; s_ok[k] = 1; s_alog[k] = (uint32_t)alog;
+                    } else if (!s_ok[k]) ok = false;
+                    b.alog[k] = s_alog[k];
+                }
+                if (!ok || pos >= len) { b.status = ZD_CORRUPT; break; }
+                b.seq_off = pos; b.seq_len = len - pos;
+            } while (false);
+            B = b;
+        }
+        __syncthreads();
+        const ZdBlk b = B;
+        if (b.status != ZD_OK) { status = b.status; break; }
+        const uint32_t body = ip + 3;
+        if (b.type == 0 || b.type == 1) {                               // raw / RLE block
+            if (op + b.size > cap) { status = ZD_DSTSIZE; break; }
+            const uint32_t rle = in[body];
+            for (uint32_t i = tid; i < b.size; i += ZD_THREADS) out[op + i] = b.type == 0 ? in[body + i] : (uint8_t)rle;
+            op += b.size; ip = body + (b.type == 0 ? b.size : 1);
+            __threadfence_block(); __syncthreads();
+            if (b.last) break;
+            continue;
+        }
+        const uint8_t *p = in + body;
+        // ================= Huffman table (all threads): symbol s of weight w owns 2^(w-1) cells behind all symbols of smaller
+        // weight and the lower-numbered symbols of its own weight
+        if (b.new_tree) {
+            for (uint32_t s = tid; s < b.nweights; s += ZD_THREADS) {
+                const uint32_t w = weights[s];
+                if (!w) continue;
+                uint32_t pos = 0;
+                for (uint32_t o = 0; o < b.nweights; o++) { const uint32_t wo = weights[o]; if (wo && (wo < w || (wo == w && o < s))) pos += 1u << (wo - 1); }
+                const uint32_t n = 1u << (w - 1), cell = s | ((b.maxbits + 1 - w) << 8);
+                for (uint32_t i = 0; i < n; i++) huf_tab[pos + i] = (uint16_t)cell;
+            }
+        }
+        __syncthreads();
+        // ================= literals -> tail of the frame's output region
+        uint8_t *lit_stage = out + (cap - b.regen);
+        if (b.ltype >= 2) {
+            const uint32_t mb = s_hufbits;
+            if (lane == 0 && wave < b.streams) {
+                const uint8_t *cs = p + b.lit_off; const uint32_t cl = b.lit_csize;
+                uint32_t s_off = 0, s_len = cl, o_off = 0, o_len = b.regen;
+                bool okh = true;
+                if (b.streams == 4) {
+                    if (cl < 6) okh = false;
+                    else {
+                        const uint32_t l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
+                        const uint32_t seg = (b.regen + 3) / 4;
+                        if (6 + l1 + l2 + l3 > cl || seg * 3 > b.regen) okh = false;
+                        else {
+                            const uint32_t l4 = cl - 6 - l1 - l2 - l3;
+                            s_off = 6 + (wave > 0 ? l1 : 0) + (wave > 1 ? l2 : 0) + (wave > 2 ? l3 : 0);
+                            s_len = wave == 0 ? l1 : (wave == 1 ? l2 : (wave == 2 ? l3 : l4));
+                            o_off = wave * seg; o_len = wave < 3 ? seg : b.regen - 3 * seg;
+                        }
+                    }
+                }
+                ZdBits bb;
+                if (okh && !zd_binit(bb, cs + s_off, s_len)) okh = false;
+                if (okh) {
+                    for (uint32_t i = 0; i < o_len; i++) {
+                        ZdBits t = bb;
+                        const uint32_t cell = huf_tab[(uint32_t)zd_bread(t, mb)];
+                        lit_stage[o_off + i] = (uint8_t)cell;
+                        bb.off -= cell >> 8;
+                        if (bb.off < 0) { okh = false; break; }
+                    }
+                    if (bb.off != 0) okh = false;
+                }
+                if (!okh) atomicOr(&s_err, 1u);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (s_err) { status = ZD_CORRUPT; break; }
+        // ================= sequences: wave 0 alternates "lane 0 decodes a batch" / "64 lanes execute it"
+        if (wave == 0) {
+            const uint8_t *lit_raw = p + b.lit_off;
+            uint32_t litpos = 0, fenced = op;                           // output below `fenced` is visible to every lane
+            ZdBits bb; uint32_t sll = 0, sof = 0, sml = 0;
+            bool okq = true;
+            if (b.nseq) {
+                if (!zd_binit(bb, p + b.seq_off, b.seq_len)) okq = false;
+                else { sll = (uint32_t)zd_bread(bb, b.alog[0]); sof = (uint32_t)zd_bread(bb, b.alog[1]); sml = (uint32_t)zd_bread(bb, b.alog[2]); }
+            }
+            for (uint32_t base = 0; base < b.nseq && okq; base += ZD_BATCH) {
+                const uint32_t nb = b.nseq - base < ZD_BATCH ? b.nseq - base : ZD_BATCH;
+                if (lane == 0) {
+                    for (uint32_t i = 0; i < nb; i++) {
+                        const uint32_t cl = fse_tab[0][sll], co = fse_tab[1][sof], cm = fse_tab[2][sml];
+                        const uint32_t llc = cl & 0xFF, ofc = co & 0xFF, mlc = cm & 0xFF;
+                        if (ofc > 31 || mlc > 52 || llc > 35) { okq = false; break; }
+                        const uint64_t ofv = ((uint64_t)1 << ofc) + zd_bread(bb, ofc);
+                        const uint32_t ml = ZD_ML_BASE[mlc] + (uint32_t)zd_bread(bb, ZD_ML_BITS[mlc]);
+                        const uint32_t ll = ZD_LL_BASE[llc] + (uint32_t)zd_bread(bb, ZD_LL_BITS[llc]);
+                        if (bb.off < 0 || ofv > 0xFFFFFFu) { okq = false; break; }
+                        if (base + i + 1 < b.nseq) {
+                            sll = (cl >> 16) + (uint32_t)zd_bread(bb, (cl >> 8) & 0xFF);
+                            sml = (cm >> 16) + (uint32_t)zd_bread(bb, (cm >> 8) & 0xFF);
+                            sof = (co >> 16) + (uint32_t)zd_bread(bb, (co >> 8) & 0xFF);
+                            if (bb.off < 0) { okq = false; break; }
+                        }
+                        sq[i] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
+                    }
+                    if (okq && base + nb == b.nseq && bb.off != 0) okq = false;
+                    s_nb = okq ? 1u : 0u;
+                }
+                __builtin_amdgcn_wave_barrier();
+                okq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nb) != 0;
+                if (!okq) break;
+                for (uint32_t i = 0; i < nb; i++) {
+                    const uint64_t s = sq[i];
+                    const uint32_t ll = (uint32_t)(s & 0xFFFFF), ml = (uint32_t)((s >> 20) & 0xFFFFF), ofv = (uint32_t)(s >> 40);
+                    uint32_t offset;
+                    if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                    else {
+                        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
+                        if (idx == 0) offset = rep0;
+                        else {
+                            offset = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
+                            if (offset == 0) { okq = false; break; }
+                            if (idx > 1) rep2 = rep1;
+                            rep1 = rep0; rep0 = offset;
+                        }
+                    }
+                    if (litpos + ll > b.regen || op + ll + ml > cap || offset > op + ll) { okq = false; break; }
+                    // literals (the staged ones sit at or behind the write position: never overtaken)
+                    for (uint32_t k = lane; k < ll; k += 64)
+                        out[op + k] = b.ltype == 0 ? lit_raw[litpos + k] : (b.ltype == 1 ? lit_raw[0] : lit_stage[litpos + k]);
+                    op += ll; litpos += ll;
+                    // match: bytes written since the last fence must be visible before they are copied
+                    if (op - offset + (ml < offset ? ml : offset) > fenced) { __threadfence_block(); fenced = op; }
+                    const uint32_t m0 = op - offset;
+                    if (offset >= 64) { for (uint32_t k = lane; k < ml; k += 64) { if (k >= offset) break; out[op + k] = out[m0 + k]; } }
+                    if (offset < 64 || ml > offset) {
+                        // overlapping: the match is periodic with period `offset`; every byte comes from the part in front of it
+                        const uint32_t start = offset >= 64 ? offset : 0u;      // bytes below `start` were copied above
+                        for (uint32_t k = start + lane; k < ml; k += 64) out[op + k] = out[m0 + k % offset];
+                    }
+                    op += ml;
+                }
+            }
+            if (okq) {
+                const uint32_t rest = b.regen - litpos;
+                if (op + rest > cap) okq = false;
+                else {
+                    for (uint32_t k = lane; k < rest; k += 64)
+                        out[op + k] = b.ltype == 0 ? lit_raw[litpos + k] : (b.ltype == 1 ? lit_raw[0] : lit_stage[litpos + k]);
+                    op += rest;
+                }
+            }
+            if (lane == 0) { s_op = op; s_rep[0] = rep0; s_rep[1] = rep1; s_rep[2] = rep2; if (!okq) s_err = 1; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (s_err) { status = ZD_CORRUPT; break; }
+        op = s_op; rep0 = s_rep[0]; rep1 = s_rep[1]; rep2 = s_rep[2];
+        ip = body + b.size;
+        __syncthreads();
+        if (b.last) break;
+    }
+    if (status == ZD_OK && op != cap) status = ZD_DSTSIZE;
+    if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; }
+}
+
+// ------------------------------------------------------------------ k_zscan : one thread per entry
+// An entry's payload is one or more concatenated frames (zstd-rs' Decoder reads them all).  Frames carry no content size here,
+// so the split of the entry's raw size over its frames follows this repository's encoder: every frame but the last holds
+// SEG_SIZE bytes (a single-frame entry -- what the reference writes -- holds all of it); k_zdec verifies the sizes.
+__global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8_t *__restrict__ src, ZFrame *__restrict__ frames) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const ZEntry en = ents[e];
+    const uint8_t *p = src + en.src_off;
+    const uint64_t len = en.src_len;
+    const uint32_t nfr = en.n_frames;
+    uint64_t ip = 0;
+    for (uint32_t f = 0; f < nfr; f++) {
+        ZFrame fr; fr.src_off = en.src_off + ip; fr.dst_off = en.dst_off + (uint64_t)f * SEG_SIZE; fr.status = 0; fr.out_len = 0;
+        const uint64_t done = (uint64_t)f * SEG_SIZE;
+        fr.dst_len = (uint32_t)(en.raw_len - done < SEG_SIZE || f + 1 == nfr ? (en.raw_len > done ? en.raw_len - done : 0) : SEG_SIZE);
+        if (en.raw_len - done > 0xFFFFFFFFull && f + 1 == nfr) fr.status = 2;
+        // walk the frame: header, blocks, optional checksum
+        uint64_t q = ip; bool ok = q + 6 <= len;
+        if (ok) {
+            const uint32_t magic = p[q] | (p[q + 1] << 8) | (p[q + 2] << 16) | ((uint32_t)p[q + 3] << 24);
+            ok = magic == 0xFD2FB528u;
+            const uint32_t fhd = p[q + 4];
+            const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+            q += 5 + (single ? 0 : 1) + (dict == 0 ? 0 : (dict == 1 ? 1 : (dict == 2 ? 2 : 4)));
+            q += fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+            while (ok) {
+                if (q + 3 > len) { ok = false; break; }
+                const uint32_t bh = p[q] | (p[q + 1] << 8) | ((uint32_t)p[q + 2] << 16);
+                const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+                q += 3 + (type == 1 ? 1 : size);
+                if (type == 3 || q > len) { ok = false; break; }
+                if (bh & 1) break;
+            }
+            if (ok && ((fhd >> 2) & 1)) q += 4;
+            if (q > len) ok = false;
+        }
+        if (!ok) { fr.status = 1; fr.src_len = 0; frames[en.first_frame + f] = fr; for (uint32_t g = f + 1; g < nfr; g++) { fr.src_off = 0; frames[en.first_frame + g] = fr; } return; }
+        fr.src_len = (uint32_t)(q - ip);
+        frames[en.first_frame + f] = fr;
+        ip = q;
+    }
+    if (ip != len && nfr) frames[en.first_frame + nfr - 1].status = 1;      // bytes left over behind the last frame
+}
+
+void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zscan, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, frames);
+}
+
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst);
+}
+
+} // namespace pna

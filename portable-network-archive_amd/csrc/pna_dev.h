@@ -92,4 +92,20 @@ struct CrcTabs {
     uint32_t sh[8];          // x^(8 * 64 * 2^j) mod P, j = 0..7
 };
 
+// zstd decoder (k_zdec): one descriptor per frame
+struct ZFrame {
+    uint64_t src_off;        // frame start in the compressed buffer
+    uint64_t dst_off;        // where its content goes
+    uint32_t src_len;        // bytes of the frame
+    uint32_t dst_len;        // bytes of content it must produce
+    uint32_t status;         // out: 0 ok, 1 corrupt, 2 unsupported, 3 size mismatch
+    uint32_t out_len;        // out: bytes produced
+};
+
+struct ZEntry {              // k_zscan input: one compressed entry
+    uint64_t src_off, src_len;   // its payload (concatenated frames) in the compressed buffer
+    uint64_t dst_off, raw_len;   // where the content goes and how long it is (fSIZ)
+    uint32_t first_frame, n_frames;
+};
+
 } // namespace pna

@@ -35,6 +35,8 @@ void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
 void frame_solid_tail(std::vector<uint8_t> &o);
@@ -83,6 +85,7 @@ struct pna_gpu_ctx {
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
+    DevBuf z_ents, z_frames;                                   // decoder descriptors
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[2], hp_out[2];
@@ -145,7 +148,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -780,6 +783,67 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
         dst_len[i] = (size_t)(doff[i + 1] - doff[i]);
         HIPCHK(c, hipMemcpyAsync(dst[i], (uint8_t *)c->stage_out.p + doff[i], dst_len[i], hipMemcpyDeviceToHost, c->stream));
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Read side: decompress_reader (lib/src/entry/read.rs:171-190).  zstd only; entries already in device memory.
+extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t n, const void *d_src, const uint64_t *src_off,
+                                               const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
+                                               void *hip_stream) {
+    if (!c || (n && (!d_src || !src_off || !src_len || !d_dst || !dst_off || !raw_len))) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only zstd streams are decoded on the device");
+    if (!n) return PNA_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    std::vector<ZEntry> ents(n);
+    uint64_t nfr = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t k = raw_len[i] ? (raw_len[i] + SEG_SIZE - 1) / SEG_SIZE : 1;
+        if (nfr + k > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "too many frames");
+        ents[i] = ZEntry{src_off[i], src_len[i], dst_off[i], raw_len[i], (uint32_t)nfr, (uint32_t)k};
+        nfr += k;
+    }
+    if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame))) return fail(c, PNA_E_NOMEM, "decoder descriptors");
+    HIPCHK(c, hipMemcpyAsync(c->z_ents.p, ents.data(), n * sizeof(ZEntry), hipMemcpyHostToDevice, st));
+    launch_zscan((const ZEntry *)c->z_ents.p, (uint32_t)n, (const uint8_t *)d_src, (ZFrame *)c->z_frames.p, st);
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_zdec((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (uint8_t *)d_dst, st);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipGetLastError());
+    std::vector<ZFrame> frs(nfr);
+    HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms;            // decoder kernel time reported in the first stage slot
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t f = 0; f < ents[i].n_frames; f++) {
+            const ZFrame &fr = frs[ents[i].first_frame + f];
+            if (fr.status) {
+                char msg[160];
+                snprintf(msg, sizeof msg, "entry %zu frame %u: %s (produced %u of %u bytes)", i, f,
+                         fr.status == 2 ? "unsupported stream" : (fr.status == 3 ? "size mismatch (foreign multi-frame stream?)" : "corrupt stream"), fr.out_len, fr.dst_len);
+                return fail(c, fr.status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
+            }
+        }
+    return PNA_OK;
+}
+
+// The same for payloads in host memory (extract / verify of an archive read from disk).
+extern "C" int pna_gpu_decompress_batch(pna_gpu_ctx *c, int algo, size_t n, const void *const *src, const size_t *src_len,
+                                        void *const *dst, const size_t *raw_len) {
+    if (!c || (n && (!src || !src_len || !dst || !raw_len))) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only zstd streams are decoded on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> so(n), sl(n), dof(n), rl(n);
+    uint64_t sp = 0, dp = 0;
+    for (size_t i = 0; i < n; i++) { so[i] = sp; sl[i] = src_len[i]; sp = (sp + src_len[i] + 15) & ~(uint64_t)15; dof[i] = dp; rl[i] = raw_len[i]; dp = (dp + raw_len[i] + 15) & ~(uint64_t)15; }
+    if (c->stage_in.ensure(sp + 64) || c->stage_out.ensure(dp + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    for (size_t i = 0; i < n; i++) if (src_len[i]) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->stage_in.p + so[i], src[i], src_len[i], hipMemcpyHostToDevice, c->stream));
+    int rc = pna_gpu_decompress_batch_device(c, algo, n, c->stage_in.p, so.data(), sl.data(), c->stage_out.p, dof.data(), rl.data(), nullptr);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) if (raw_len[i]) HIPCHK(c, hipMemcpyAsync(dst[i], (uint8_t *)c->stage_out.p + dof[i], raw_len[i], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PNA_OK;
 }
