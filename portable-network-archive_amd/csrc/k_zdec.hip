@@ -6,18 +6,20 @@
 //
 // One 256-thread workgroup per frame, blocks in order (a block may copy from everything before it in the frame):
 //   thread 0 parses the block and section headers and builds the Huffman weights / FSE distributions (short serial codes),
-//   all threads fill the Huffman decoding table, 1 or 4 lanes decode the literal streams INTO THE TAIL OF THE FRAME'S OUTPUT
-//   region (the write position of the block can never pass the literals still to be read), lane 0 of wave 0 runs the serial
-//   FSE chain in batches of 256 sequences and wave 0 executes each batch with 64-lane copies straight in the output buffer.
-//   A workgroup-scope fence is issued only when a match reaches into bytes written since the previous fence.
+//   all threads fill the Huffman decoding table, 1 or 4 lanes decode the literal streams into the frame's 128 KiB scratch slot
+//   (bit windows in registers, next word prefetched), lane 0 of wave 0 runs the serial FSE chain in batches of 64 sequences and
+//   the wave executes each batch one sequence per lane: positions by a wave scan, literal runs in parallel, matches in
+//   dependency passes with a workgroup-scope fence between them.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "pna_dev.h"
 
 namespace pna {
 
 constexpr uint32_t ZD_THREADS = 256;
 constexpr int ZD_HUF_MAX = 11;
-constexpr uint32_t ZD_BATCH = 256;
+constexpr uint32_t ZD_STAGE_W = 6144;                 // 48 KiB
+constexpr uint32_t ZD_BATCH = 64;                     // sequences decoded by lane 0, then executed one per lane
 enum { ZD_OK = 0, ZD_CORRUPT = 1, ZD_UNSUPPORTED = 2, ZD_DSTSIZE = 3 };
 
 typedef unsigned long long zd_u64u __attribute__((aligned(1)));
@@ -54,6 +56,37 @@ __device__ __forceinline__ uint64_t zd_bread(ZdBits &b, uint32_t n) {
     const int64_t have = (int64_t)n + b.off;                       // bits that exist
     if (have <= 0) return 0;
     return zd_bits(b.p, 0, (uint32_t)have) << (uint32_t)(-b.off);
+}
+
+// The same reader with a 128-bit window in registers (words k, k+1 of the string, 8 bytes each) and word k-1 already requested.
+// `fetch(j)` returns word j of the string: from the LDS copy of the stream when it fits (the serial Huffman / FSE chains then
+// never wait for HBM), else straight from global memory.
+struct ZdWin { int64_t off; int64_t k; uint64_t lo, hi, pre; };
+template <class F> __device__ __forceinline__ bool zd_winit(ZdWin &w, F &&fetch, uint32_t last_byte, uint32_t len) {
+    if (len == 0 || last_byte == 0) return false;
+    w.off = (int64_t)len * 8 - (8 - zd_hb(last_byte));
+    w.k = ((w.off + 63) >> 6) - 2; if (w.k < 0) w.k = 0;
+    w.lo = fetch(w.k); w.hi = fetch(w.k + 1); w.pre = w.k > 0 ? fetch(w.k - 1) : 0;
+    return true;
+}
+// the n (<= 57) bits below the cursor, not consumed
+template <class F> __device__ __forceinline__ uint64_t zd_wpeek(ZdWin &w, F &&fetch, uint32_t n) {
+    const int64_t lo_bit = w.off - (int64_t)n;
+    const int64_t need = lo_bit < 0 ? 0 : lo_bit;
+    while (need < 64 * w.k) { w.hi = w.lo; w.lo = w.pre; w.k--; w.pre = w.k > 0 ? fetch(w.k - 1) : 0; }
+    const uint32_t sft = (uint32_t)(need - 64 * w.k);              // 0..127
+    uint64_t v = sft < 64 ? (w.lo >> sft) | (sft ? w.hi << (64 - sft) : 0) : w.hi >> (sft - 64);
+    if (lo_bit < 0) {                                              // part of the field lies below the start: zero there
+        if (w.off <= 0) return 0;
+        v = (v & (((uint64_t)1 << (uint32_t)w.off) - 1)) << (uint32_t)(-lo_bit);
+    }
+    return v & (((uint64_t)1 << n) - 1);
+}
+template <class F> __device__ __forceinline__ uint64_t zd_wread(ZdWin &w, F &&fetch, uint32_t n) {
+    if (n == 0) return 0;
+    const uint64_t v = zd_wpeek(w, fetch, n);
+    w.off -= n;
+    return v;
 }
 
 // FSE decoding table (sym | nbits << 8 | base << 16) from a normalised distribution; serial (one thread)
@@ -126,15 +159,16 @@ struct ZdBlk {                 // what thread 0 tells the workgroup about the cu
 };
 
 __global__ __launch_bounds__(ZD_THREADS)
-void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst) {
+void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint8_t *__restrict__ lit_scratch, uint32_t dbg) {
     __shared__ uint16_t huf_tab[1 << ZD_HUF_MAX];      // sym | nbits << 8
     __shared__ uint32_t fse_tab[3][512];               // LL, OF, ML
     __shared__ uint8_t  weights[256];
     __shared__ int16_t  norm[256];
     __shared__ uint16_t nexts[256];
     __shared__ ZdBlk    B;
-    __shared__ uint64_t sq[ZD_BATCH];                  // ll | ml << 20 | offset value << 40
+    __shared__ uint64_t sq[ZD_BATCH];                  // ll | ml << 20 | resolved offset << 40
     __shared__ uint32_t wtab[64];                      // weight-decoding table (alog <= 6)
+    __shared__ uint64_t stage64[ZD_STAGE_W];           // LDS copy of the stream(s) being decoded (8-byte aligned starts)
     __shared__ uint32_t s_nb, s_ok[3], s_alog[3], s_huf_ok, s_hufbits, s_err, s_op, s_rep[3];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -328,120 +362,186 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
         }
         __syncthreads();
         // ================= literals -> tail of the frame's output region
-        uint8_t *lit_stage = out + (cap - b.regen);
-        if (b.ltype >= 2) {
+        uint8_t *lit_stage = lit_scratch + (size_t)blockIdx.x * (128u << 10);   // this frame's slot for decoded literals
+        if (b.ltype >= 2 && !(dbg & 4)) {
             const uint32_t mb = s_hufbits;
-            if (lane == 0 && wave < b.streams) {
-                const uint8_t *cs = p + b.lit_off; const uint32_t cl = b.lit_csize;
-                uint32_t s_off = 0, s_len = cl, o_off = 0, o_len = b.regen;
-                bool okh = true;
-                if (b.streams == 4) {
-                    if (cl < 6) okh = false;
+            const uint8_t *cs = p + b.lit_off; const uint32_t cl = b.lit_csize;
+            // stream s: bytes [s_off, s_off + s_len) of the section, regenerates o_len bytes at o_off
+            uint32_t sof4[4] = {0, 0, 0, 0}, sln4[4] = {cl, 0, 0, 0}, oof4[4] = {0, 0, 0, 0}, oln4[4] = {b.regen, 0, 0, 0};
+            bool okh = true;
+            if (b.streams == 4) {
+                if (cl < 6) okh = false;
+                else {
+                    const uint32_t l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
+                    const uint32_t seg = (b.regen + 3) / 4;
+                    if (6 + l1 + l2 + l3 > cl || seg * 3 > b.regen) okh = false;
                     else {
-                        const uint32_t l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
-                        const uint32_t seg = (b.regen + 3) / 4;
-                        if (6 + l1 + l2 + l3 > cl || seg * 3 > b.regen) okh = false;
-                        else {
-                            const uint32_t l4 = cl - 6 - l1 - l2 - l3;
-                            s_off = 6 + (wave > 0 ? l1 : 0) + (wave > 1 ? l2 : 0) + (wave > 2 ? l3 : 0);
-                            s_len = wave == 0 ? l1 : (wave == 1 ? l2 : (wave == 2 ? l3 : l4));
-                            o_off = wave * seg; o_len = wave < 3 ? seg : b.regen - 3 * seg;
-                        }
+                        sof4[0] = 6; sln4[0] = l1; sof4[1] = 6 + l1; sln4[1] = l2; sof4[2] = 6 + l1 + l2; sln4[2] = l3;
+                        sof4[3] = 6 + l1 + l2 + l3; sln4[3] = cl - sof4[3];
+                        for (int q = 0; q < 4; q++) { oof4[q] = q * seg; oln4[q] = q < 3 ? seg : b.regen - 3 * seg; }
                     }
                 }
-                ZdBits bb;
-                if (okh && !zd_binit(bb, cs + s_off, s_len)) okh = false;
-                if (okh) {
-                    for (uint32_t i = 0; i < o_len; i++) {
-                        ZdBits t = bb;
-                        const uint32_t cell = huf_tab[(uint32_t)zd_bread(t, mb)];
-                        lit_stage[o_off + i] = (uint8_t)cell;
-                        bb.off -= cell >> 8;
-                        if (bb.off < 0) { okh = false; break; }
-                    }
-                    if (bb.off != 0) okh = false;
-                }
-                if (!okh) atomicOr(&s_err, 1u);
             }
+            // LDS copies of the streams (each starts on an 8-byte boundary, 16 bytes of slack behind the last)
+            uint32_t lw4[4] = {0, 0, 0, 0}, words = 0;
+            for (uint32_t q = 0; q < b.streams; q++) { lw4[q] = words; words += (sln4[q] + 7) / 8 + 1; }
+            const bool staged = okh && words + 2 <= ZD_STAGE_W;
+            if (staged) {
+                uint8_t *st8 = (uint8_t *)stage64;
+                for (uint32_t q = 0; q < b.streams; q++)
+                    for (uint32_t i = tid; i < sln4[q]; i += ZD_THREADS) st8[8 * lw4[q] + i] = cs[sof4[q] + i];
+                __syncthreads();
+            }
+            if (okh && lane == 0 && wave < b.streams) {
+                const uint32_t s_off = sof4[wave], s_len = sln4[wave], o_off = oof4[wave], o_len = oln4[wave];
+                const uint32_t last = s_len ? cs[s_off + s_len - 1] : 0u;
+                auto run = [&](auto fetch) {
+                    ZdWin bw;
+                    if (!zd_winit(bw, fetch, last, s_len)) { okh = false; return; }
+                    uint32_t i = 0;
+                    for (; i + 4 <= o_len; i += 4) {                       // four symbols per store
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t cell = huf_tab[(uint32_t)zd_wpeek(bw, fetch, mb)];
+                            word |= (cell & 0xFF) << (8 * q);
+                            bw.off -= cell >> 8;
+                        }
+                        if (bw.off < 0) { okh = false; return; }
+                        if (((o_off + i) & 3) == 0) *(uint32_t *)(lit_stage + o_off + i) = word;
+                        else { lit_stage[o_off + i] = (uint8_t)word; lit_stage[o_off + i + 1] = (uint8_t)(word >> 8); lit_stage[o_off + i + 2] = (uint8_t)(word >> 16); lit_stage[o_off + i + 3] = (uint8_t)(word >> 24); }
+                    }
+                    for (; i < o_len; i++) {
+                        const uint32_t cell = huf_tab[(uint32_t)zd_wpeek(bw, fetch, mb)];
+                        lit_stage[o_off + i] = (uint8_t)cell;
+                        bw.off -= cell >> 8;
+                        if (bw.off < 0) { okh = false; return; }
+                    }
+                    if (bw.off != 0) okh = false;
+                };
+                const uint32_t lw = lw4[wave];
+                const uint8_t *gs = cs + s_off;
+                if (staged) run([&](int64_t j) -> uint64_t { return stage64[lw + j]; });
+                else run([&](int64_t j) -> uint64_t { return *(const zd_u64u *)(gs + 8 * j); });
+            }
+            if (!okh) atomicOr(&s_err, 1u);
         }
         __threadfence_block();
         __syncthreads();
         if (s_err) { status = ZD_CORRUPT; break; }
-        // ================= sequences: wave 0 alternates "lane 0 decodes a batch" / "64 lanes execute it"
+        if (b.nseq && (b.seq_len + 7) / 8 + 3 <= ZD_STAGE_W) {                   // LDS copy of the sequence bitstream
+            uint8_t *st8 = (uint8_t *)stage64; const uint8_t *gq = p + b.seq_off;
+            for (uint32_t i = tid; i < b.seq_len; i += ZD_THREADS) st8[i] = gq[i];
+            __syncthreads();
+        }
+        // ================= sequences: wave 0 alternates "lane 0 decodes 64 sequences (FSE chain, repeat offsets)" and "every lane
+        // executes one of them": output positions by a wave scan, literal runs in parallel, then the matches in passes -- a match
+        // is ready when its source ends at or below the output start of the first match still pending (usually 1-3 passes).
         if (wave == 0) {
             const uint8_t *lit_raw = p + b.lit_off;
-            uint32_t litpos = 0, fenced = op;                           // output below `fenced` is visible to every lane
-            ZdBits bb; uint32_t sll = 0, sof = 0, sml = 0;
+            auto LIT = [&](uint32_t i) -> uint8_t { return b.ltype == 0 ? lit_raw[i] : (b.ltype == 1 ? lit_raw[0] : lit_stage[i]); };
+            uint32_t litpos = 0;
+            ZdWin bw; uint32_t sll = 0, sof = 0, sml = 0;
             bool okq = true;
+            const uint8_t *gq = p + b.seq_off;
+            const bool qstaged = (b.seq_len + 7) / 8 + 3 <= ZD_STAGE_W;        // staged by the whole workgroup before this branch
+            auto fq = [&](int64_t j) -> uint64_t { return qstaged ? stage64[j] : *(const zd_u64u *)(gq + 8 * j); };
             if (b.nseq) {
-                if (!zd_binit(bb, p + b.seq_off, b.seq_len)) okq = false;
-                else { sll = (uint32_t)zd_bread(bb, b.alog[0]); sof = (uint32_t)zd_bread(bb, b.alog[1]); sml = (uint32_t)zd_bread(bb, b.alog[2]); }
+                if (!zd_winit(bw, fq, b.seq_len ? gq[b.seq_len - 1] : 0u, b.seq_len)) okq = false;
+                else { sll = (uint32_t)zd_wread(bw, fq, b.alog[0]); sof = (uint32_t)zd_wread(bw, fq, b.alog[1]); sml = (uint32_t)zd_wread(bw, fq, b.alog[2]); }
             }
-            for (uint32_t base = 0; base < b.nseq && okq; base += ZD_BATCH) {
+            for (uint32_t base = 0; base < b.nseq && okq && !(dbg & 2); base += ZD_BATCH) {
                 const uint32_t nb = b.nseq - base < ZD_BATCH ? b.nseq - base : ZD_BATCH;
                 if (lane == 0) {
                     for (uint32_t i = 0; i < nb; i++) {
                         const uint32_t cl = fse_tab[0][sll], co = fse_tab[1][sof], cm = fse_tab[2][sml];
                         const uint32_t llc = cl & 0xFF, ofc = co & 0xFF, mlc = cm & 0xFF;
                         if (ofc > 31 || mlc > 52 || llc > 35) { okq = false; break; }
-                        const uint64_t ofv = ((uint64_t)1 << ofc) + zd_bread(bb, ofc);
-                        const uint32_t ml = ZD_ML_BASE[mlc] + (uint32_t)zd_bread(bb, ZD_ML_BITS[mlc]);
-                        const uint32_t ll = ZD_LL_BASE[llc] + (uint32_t)zd_bread(bb, ZD_LL_BITS[llc]);
-                        if (bb.off < 0 || ofv > 0xFFFFFFu) { okq = false; break; }
+                        const uint64_t ofv = ((uint64_t)1 << ofc) + zd_wread(bw, fq, ofc);
+                        const uint32_t ml = ZD_ML_BASE[mlc] + (uint32_t)zd_wread(bw, fq, ZD_ML_BITS[mlc]);
+                        const uint32_t ll = ZD_LL_BASE[llc] + (uint32_t)zd_wread(bw, fq, ZD_LL_BITS[llc]);
+                        if (bw.off < 0 || ofv > 0xFFFFFFu) { okq = false; break; }
                         if (base + i + 1 < b.nseq) {
-                            sll = (cl >> 16) + (uint32_t)zd_bread(bb, (cl >> 8) & 0xFF);
-                            sml = (cm >> 16) + (uint32_t)zd_bread(bb, (cm >> 8) & 0xFF);
-                            sof = (co >> 16) + (uint32_t)zd_bread(bb, (co >> 8) & 0xFF);
-                            if (bb.off < 0) { okq = false; break; }
+                            sll = (cl >> 16) + (uint32_t)zd_wread(bw, fq, (cl >> 8) & 0xFF);
+                            sml = (cm >> 16) + (uint32_t)zd_wread(bw, fq, (cm >> 8) & 0xFF);
+                            sof = (co >> 16) + (uint32_t)zd_wread(bw, fq, (co >> 8) & 0xFF);
+                            if (bw.off < 0) { okq = false; break; }
                         }
-                        sq[i] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
+                        uint32_t offset;
+                        if (ofv > 3) { offset = (uint32_t)ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                        else {
+                            const uint32_t idx = (uint32_t)ofv - 1 + (ll == 0 ? 1u : 0u);
+                            if (idx == 0) offset = rep0;
+                            else {
+                                offset = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
+                                if (offset == 0) { okq = false; break; }
+                                if (idx > 1) rep2 = rep1;
+                                rep1 = rep0; rep0 = offset;
+                            }
+                        }
+                        sq[i] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)offset << 40);
                     }
-                    if (okq && base + nb == b.nseq && bb.off != 0) okq = false;
+                    if (okq && base + nb == b.nseq && bw.off != 0) okq = false;
                     s_nb = okq ? 1u : 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
                 okq = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_nb) != 0;
                 if (!okq) break;
-                for (uint32_t i = 0; i < nb; i++) {
-                    const uint64_t s = sq[i];
-                    const uint32_t ll = (uint32_t)(s & 0xFFFFF), ml = (uint32_t)((s >> 20) & 0xFFFFF), ofv = (uint32_t)(s >> 40);
-                    uint32_t offset;
-                    if (ofv > 3) { offset = ofv - 3; rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                    else {
-                        const uint32_t idx = ofv - 1 + (ll == 0 ? 1u : 0u);
-                        if (idx == 0) offset = rep0;
-                        else {
-                            offset = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1);
-                            if (offset == 0) { okq = false; break; }
-                            if (idx > 1) rep2 = rep1;
-                            rep1 = rep0; rep0 = offset;
-                        }
-                    }
-                    if (litpos + ll > b.regen || op + ll + ml > cap || offset > op + ll) { okq = false; break; }
-                    // literals (the staged ones sit at or behind the write position: never overtaken)
-                    for (uint32_t k = lane; k < ll; k += 64)
-                        out[op + k] = b.ltype == 0 ? lit_raw[litpos + k] : (b.ltype == 1 ? lit_raw[0] : lit_stage[litpos + k]);
-                    op += ll; litpos += ll;
-                    // match: bytes written since the last fence must be visible before they are copied
-                    if (op - offset + (ml < offset ? ml : offset) > fenced) { __threadfence_block(); fenced = op; }
-                    const uint32_t m0 = op - offset;
-                    if (offset >= 64) { for (uint32_t k = lane; k < ml; k += 64) { if (k >= offset) break; out[op + k] = out[m0 + k]; } }
-                    if (offset < 64 || ml > offset) {
-                        // overlapping: the match is periodic with period `offset`; every byte comes from the part in front of it
-                        const uint32_t start = offset >= 64 ? offset : 0u;      // bytes below `start` were copied above
-                        for (uint32_t k = start + lane; k < ml; k += 64) out[op + k] = out[m0 + k % offset];
-                    }
-                    op += ml;
+                if (dbg & 1) continue;
+                const bool act = lane < nb;
+                const uint64_t sv = act ? sq[lane] : 0;
+                const uint32_t ll = (uint32_t)(sv & 0xFFFFF), ml = (uint32_t)((sv >> 20) & 0xFFFFF), offset = (uint32_t)(sv >> 40);
+                uint32_t incl = ll + ml, lincl = ll;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t1 = (uint32_t)__shfl_up((int)incl, d), t2 = (uint32_t)__shfl_up((int)lincl, d);
+                    if (lane >= (uint32_t)d) { incl += t1; lincl += t2; }
                 }
+                const uint32_t o0 = op + incl - (ll + ml), l0 = litpos + lincl - ll;       // this sequence's output / literal start
+                const uint32_t T = (uint32_t)__shfl((int)incl, 63), TL = (uint32_t)__shfl((int)lincl, 63);
+                const bool bad = act && (l0 + ll > b.regen || (uint64_t)o0 + ll + ml > cap || offset == 0 || offset > o0 + ll);
+                if (__ballot(bad)) { okq = false; break; }
+                // ---- literal runs: up to 32 bytes per lane in lock step, the longer ones by the whole wave
+                {
+                    const uint32_t ls = ll < 32 ? ll : 32u;
+                    for (uint32_t k = 0; __ballot(k < ls); k++) if (k < ls) out[o0 + k] = LIT(l0 + k);
+                    uint64_t longm = __ballot(ll > 32);
+                    while (longm) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
+                        const uint32_t oj = (uint32_t)__shfl((int)o0, (int)j), lj = (uint32_t)__shfl((int)l0, (int)j), nj = (uint32_t)__shfl((int)ll, (int)j);
+                        for (uint32_t k = 32 + lane; k < nj; k += 64) out[oj + k] = LIT(lj + k);
+                    }
+                }
+                // ---- matches in passes
+                const uint32_t dstp = o0 + ll, m0 = dstp - offset;
+                const uint32_t src_end = m0 + (ml < offset ? ml : offset);
+                bool pending = act && ml != 0;
+                for (;;) {
+                    const uint64_t pm = __ballot(pending);
+                    if (!pm) break;
+                    __threadfence_block();                                       // everything written so far is visible to every lane
+                    const uint32_t frontier = (uint32_t)__shfl((int)dstp, (int)__builtin_ctzll(pm));
+                    const bool ready = pending && src_end <= frontier;
+                    // short ready matches: one per lane, byte-serial inside the lane (an overlapping match reads what it wrote)
+                    const bool shortr = ready && ml <= 32;
+                    for (uint32_t k = 0; __ballot(shortr && k < ml); k++) if (shortr && k < ml) out[dstp + k] = out[m0 + k];
+                    uint64_t longm = __ballot(ready && ml > 32);
+                    while (longm) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
+                        const uint32_t dj = (uint32_t)__shfl((int)dstp, (int)j), mj = (uint32_t)__shfl((int)m0, (int)j);
+                        const uint32_t nj = (uint32_t)__shfl((int)ml, (int)j), fj = (uint32_t)__shfl((int)offset, (int)j);
+                        // periodic with period fj: every byte comes from the fj bytes in front of the match
+                        if (fj >= nj) { for (uint32_t k = lane; k < nj; k += 64) out[dj + k] = out[mj + k]; }
+                        else { for (uint32_t k = lane; k < nj; k += 64) out[dj + k] = out[mj + k % fj]; }
+                    }
+                    pending = pending && !ready;
+                }
+                op += T; litpos += TL;
             }
             if (okq) {
                 const uint32_t rest = b.regen - litpos;
-                if (op + rest > cap) okq = false;
-                else {
-                    for (uint32_t k = lane; k < rest; k += 64)
-                        out[op + k] = b.ltype == 0 ? lit_raw[litpos + k] : (b.ltype == 1 ? lit_raw[0] : lit_stage[litpos + k]);
-                    op += rest;
-                }
+                if ((uint64_t)op + rest > cap) okq = false;
+                else { for (uint32_t k = lane; k < rest; k += 64) out[op + k] = LIT(litpos + k); op += rest; }
             }
             if (lane == 0) { s_op = op; s_rep[0] = rep0; s_rep[1] = rep1; s_rep[2] = rep2; if (!okq) s_err = 1; }
         }
@@ -453,7 +553,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
         __syncthreads();
         if (b.last) break;
     }
-    if (status == ZD_OK && op != cap) status = ZD_DSTSIZE;
+    if (status == ZD_OK && op != cap && !dbg) status = ZD_DSTSIZE;
     if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; }
 }
 
@@ -506,8 +606,9 @@ void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *fr
     if (n) hipLaunchKernelGGL(k_zscan, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, frames);
 }
 
-void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst);
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st) {
+    const char *e = getenv("PNA_ZDEC_DBG");                     // diagnostics: 1 skip execution, 2 skip sequences, 4 skip Huffman streams
+    if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst, lit_scratch, e ? (uint32_t)atoi(e) : 0u);
 }
 
 } // namespace pna

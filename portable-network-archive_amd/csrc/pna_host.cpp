@@ -35,7 +35,7 @@ void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
-void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
@@ -85,7 +85,7 @@ struct pna_gpu_ctx {
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
-    DevBuf z_ents, z_frames;                                   // decoder descriptors
+    DevBuf z_ents, z_frames, z_lit;                            // decoder descriptors, 128 KiB of literal scratch per frame
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[2], hp_out[2];
@@ -148,7 +148,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -805,11 +805,12 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
         ents[i] = ZEntry{src_off[i], src_len[i], dst_off[i], raw_len[i], (uint32_t)nfr, (uint32_t)k};
         nfr += k;
     }
-    if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame))) return fail(c, PNA_E_NOMEM, "decoder descriptors");
+    if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame)) || c->z_lit.ensure(nfr * (size_t)(128u << 10) + 64))
+        return fail(c, PNA_E_NOMEM, "decoder workspace");
     HIPCHK(c, hipMemcpyAsync(c->z_ents.p, ents.data(), n * sizeof(ZEntry), hipMemcpyHostToDevice, st));
     launch_zscan((const ZEntry *)c->z_ents.p, (uint32_t)n, (const uint8_t *)d_src, (ZFrame *)c->z_frames.p, st);
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    launch_zdec((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (uint8_t *)d_dst, st);
+    launch_zdec((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, st);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     HIPCHK(c, hipGetLastError());
     std::vector<ZFrame> frs(nfr);
