@@ -557,6 +557,505 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; }
 }
 
+// =====================================================================================================================
+// Lane-parallel pipeline (the default): the serial chains of MANY blocks run side by side, one lane each.
+//   k_zparse  one wave per frame: lane 0 walks the blocks (headers, Huffman weights, FSE distributions), tables are built in
+//             LDS and copied to the frame's table slots; every block gets a descriptor, every Huffman stream and every block
+//             with sequences an entry in a work list
+//   k_zhuf    one lane per Huffman stream   (tables in global memory / L2, bit windows in registers)
+//   k_zfse    one lane per block: the FSE chain -> sequence records (ll, ml, offset value), block output size
+//   k_zoff    one thread per frame: output offsets of its blocks
+//   k_zexec   one wave per frame, blocks in order: 64 sequences at a time, one per lane (as in k_zdec)
+// Frames that do not fit the bounded per-frame resources (table slots, block descriptors, sequence records) are flagged and
+// go through k_zdec.
+struct ZWork { uint32_t n_huf, n_seq, pad0, pad1; };
+
+__global__ __launch_bounds__(64)
+void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
+              ZTables *__restrict__ tabs, uint32_t *__restrict__ huf_list, uint32_t *__restrict__ seq_list, ZWork *__restrict__ work) {
+    __shared__ uint16_t huf_tab[1 << ZD_HUF_MAX];
+    __shared__ uint32_t fse_tab[512];
+    __shared__ uint8_t  weights[256];
+    __shared__ int16_t  norm[256];
+    __shared__ uint16_t nexts[256];
+    __shared__ uint32_t wtab[64];
+    __shared__ uint32_t s_cmd[8];          // lane 0 -> wave: [0] what to flush (1 huffman, 2 fse), [1] slot, [2] which, [3] maxbits / alog, [4] nweights
+    const uint32_t lane = threadIdx.x, f = blockIdx.x;
+    ZFrame fr = frames[f];
+    ZFrameX x = fx[f];
+    const uint8_t *in = src + fr.src_off;
+    const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    uint32_t status = fr.status, ip = 0;
+    // ---- frame header
+    if (status == ZD_OK) {
+        if (in_len < 6) status = ZD_CORRUPT;
+        else {
+            const uint32_t magic = in[0] | (in[1] << 8) | (in[2] << 16) | ((uint32_t)in[3] << 24);
+            const uint32_t fhd = in[4];
+            const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+            if (magic != 0xFD2FB528u || (fhd & 0x08)) status = ZD_CORRUPT;
+            else if (dict) status = ZD_UNSUPPORTED;
+            else {
+                ip = 5 + (single ? 0 : 1);
+                const uint32_t fsz = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+                if (ip + fsz > in_len) status = ZD_CORRUPT;
+                else {
+                    uint64_t fcs = 0;
+                    for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
+                    if (fsz == 2) fcs += 256;
+                    if (fsz && fcs != cap) status = ZD_DSTSIZE;
+                    ip += fsz;
+                }
+            }
+        }
+    }
+    uint32_t nblk = 0, next_slot = 0, huf_slot = 0xFFFFFFFFu, slot3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t lit_pos = 0; uint64_t seq_pos = 0;
+    bool last = status != ZD_OK;
+    while (!last) {
+        // lane 0 parses one block; whenever a table is complete in LDS the whole wave copies it out
+        ZBlock b;
+        uint32_t bstat = ZD_OK;
+        if (lane == 0) {
+            b.body = 0; b.out_off = 0; b.seq_pos = x.seq_base + seq_pos; b.size = 0; b.type = 0; b.ltype = 0; b.regen = 0; b.streams = 1; b.lit_off = 0; b.lit_csize = 0;
+            b.lit_pos = lit_pos; b.nseq = 0; b.seq_off = 0; b.seq_len = 0; b.frame = f; b.out_len = 0; b.status = 0; b.uses_rep = 0;
+            for (int i = 0; i < 7; i++) b.pad[i] = 0;
+        }
+        // ---- phase 1 (lane 0): headers + literals section + Huffman weights
+        uint32_t p1_tree = 0;
+        if (lane == 0) {
+            do {
+                if (nblk >= x.blk_cap) { bstat = ZD_UNSUPPORTED; break; }
+                if (ip + 3 > in_len) { bstat = ZD_CORRUPT; break; }
+                const uint32_t bh = in[ip] | (in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
+                b.type = (bh >> 1) & 3; b.size = bh >> 3; b.pad[0] = bh & 1;
+                b.body = fr.src_off + ip + 3;
+                if (b.type == 3 || b.size > (128u << 10)) { bstat = ZD_CORRUPT; break; }
+                if (b.type == 1) { if (ip + 4 > in_len) bstat = ZD_CORRUPT; b.out_len = b.size; break; }
+                if (ip + 3 + b.size > in_len) { bstat = ZD_CORRUPT; break; }
+                if (b.type == 0) { b.out_len = b.size; break; }
+                const uint8_t *p = in + ip + 3; const uint32_t len = b.size;
+                if (len < 1) { bstat = ZD_CORRUPT; break; }
+                const uint32_t ltype = p[0] & 3, sf = (p[0] >> 2) & 3;
+                uint32_t regen, comp = 0, hdr, streams = 1;
+                if (ltype < 2) {
+                    if (sf == 0 || sf == 2) { regen = p[0] >> 3; hdr = 1; }
+                    else if (sf == 1) { if (len < 2) { bstat = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4); hdr = 2; }
+                    else { if (len < 3) { bstat = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4) + ((uint32_t)p[2] << 12); hdr = 3; }
+                } else {
+                    if (len < 5) { bstat = ZD_CORRUPT; break; }
+                    uint64_t v = 0; for (int i = 0; i < 5; i++) v |= (uint64_t)p[i] << (8 * i);
+                    if (sf == 0) { streams = 1; hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                    else if (sf == 1) { streams = 4; hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                    else if (sf == 2) { streams = 4; hdr = 4; regen = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; }
+                    else { streams = 4; hdr = 5; regen = (v >> 4) & 0x3FFFF; comp = (v >> 22) & 0x3FFFF; }
+                }
+                if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { bstat = regen > (128u << 10) ? ZD_CORRUPT : ZD_DSTSIZE; break; }
+                b.ltype = ltype; b.regen = regen; b.streams = streams;
+                uint32_t pos = hdr;
+                if (ltype == 0) { if (pos + regen > len) { bstat = ZD_CORRUPT; break; } b.lit_off = pos; pos += regen; }
+                else if (ltype == 1) { if (pos + 1 > len) { bstat = ZD_CORRUPT; break; } b.lit_off = pos; pos += 1; }
+                else {
+                    if (pos + comp > len) { bstat = ZD_CORRUPT; break; }
+                    const uint8_t *cs = p + pos; const uint32_t cl = comp; uint32_t used = 0;
+                    if (ltype == 2) {
+                        if (cl < 1) { bstat = ZD_CORRUPT; break; }
+                        const uint32_t hbyte = cs[0];
+                        uint32_t nw = 0;
+                        if (hbyte >= 128) {
+                            nw = hbyte - 127;
+                            const uint32_t bytes = (nw + 1) / 2;
+                            if (1 + bytes > cl) { bstat = ZD_CORRUPT; break; }
+                            for (uint32_t i = 0; i < nw; i++) { const uint32_t by = cs[1 + i / 2]; weights[i] = (uint8_t)((i & 1) ? (by & 15) : (by >> 4)); }
+                            used = 1 + bytes;
+                        } else {
+                            const uint32_t csize = hbyte;
+                            if (csize == 0 || 1 + csize > cl) { bstat = ZD_CORRUPT; break; }
+                            int nsym, alog;
+                            const uint32_t dl = zd_fse_desc(cs + 1, csize, norm, &nsym, &alog, 255, 6);
+                            if (!dl || dl >= csize || !zd_fse_build(wtab, norm, nsym, alog, nexts)) { bstat = ZD_CORRUPT; break; }
+                            ZdBits bb;
+                            if (!zd_binit(bb, cs + 1 + dl, csize - dl)) { bstat = ZD_CORRUPT; break; }
+                            uint32_t s1 = (uint32_t)zd_bread(bb, (uint32_t)alog), s2 = (uint32_t)zd_bread(bb, (uint32_t)alog);
+                            bool bad = false;
+                            for (;;) {
+                                if (nw >= 255) { bad = true; break; }
+                                weights[nw++] = (uint8_t)(wtab[s1] & 0xFF);
+                                s1 = (wtab[s1] >> 16) + (uint32_t)zd_bread(bb, (wtab[s1] >> 8) & 0xFF);
+                                if (bb.off < 0) { if (nw >= 255) { bad = true; break; } weights[nw++] = (uint8_t)(wtab[s2] & 0xFF); break; }
+                                if (nw >= 255) { bad = true; break; }
+                                weights[nw++] = (uint8_t)(wtab[s2] & 0xFF);
+                                s2 = (wtab[s2] >> 16) + (uint32_t)zd_bread(bb, (wtab[s2] >> 8) & 0xFF);
+                                if (bb.off < 0) { if (nw >= 255) { bad = true; break; } weights[nw++] = (uint8_t)(wtab[s1] & 0xFF); break; }
+                            }
+                            if (bad) { bstat = ZD_CORRUPT; break; }
+                            used = 1 + csize;
+                        }
+                        uint32_t total = 0; bool badw = false;
+                        for (uint32_t i = 0; i < nw; i++) { if (weights[i] > ZD_HUF_MAX) badw = true; else if (weights[i]) total += 1u << (weights[i] - 1); }
+                        if (badw || total == 0 || nw < 1) { bstat = ZD_CORRUPT; break; }
+                        const uint32_t maxbits = (uint32_t)zd_hb(total) + 1;
+                        const uint32_t rest = (1u << maxbits) - total;
+                        if (maxbits > (uint32_t)ZD_HUF_MAX || rest == 0 || (rest & (rest - 1))) { bstat = ZD_CORRUPT; break; }
+                        weights[nw] = (uint8_t)(zd_hb(rest) + 1);
+                        if (next_slot >= x.slot_cap) { bstat = ZD_UNSUPPORTED; break; }
+                        huf_slot = x.slot_base + next_slot;             // this block's own slot (shared with its FSE tables below)
+                        p1_tree = 1; s_cmd[3] = maxbits; s_cmd[4] = nw + 1;
+                    } else if (huf_slot == 0xFFFFFFFFu) { bstat = ZD_CORRUPT; break; }
+                    if (used > cl) { bstat = ZD_CORRUPT; break; }
+                    b.lit_off = pos + used; b.lit_csize = cl - used;
+                    pos += comp;
+                }
+                b.seq_off = pos;                                          // provisional: start of the sequences section
+            } while (false);
+            s_cmd[0] = p1_tree; s_cmd[5] = bstat;
+        }
+        __builtin_amdgcn_wave_barrier();
+        bstat = s_cmd[5];
+        if (s_cmd[0]) {
+            // ---- Huffman table: all lanes (same construction as k_zdec)
+            const uint32_t nwt = s_cmd[4], mbits = s_cmd[3];
+            for (uint32_t sy = lane; sy < nwt; sy += 64) {
+                const uint32_t w = weights[sy];
+                if (!w) continue;
+                uint32_t pos = 0;
+                for (uint32_t o = 0; o < nwt; o++) { const uint32_t wo = weights[o]; if (wo && (wo < w || (wo == w && o < sy))) pos += 1u << (wo - 1); }
+                const uint32_t n = 1u << (w - 1), cell = sy | ((mbits + 1 - w) << 8);
+                for (uint32_t i = 0; i < n; i++) huf_tab[pos + i] = (uint16_t)cell;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t sl = (uint32_t)__builtin_amdgcn_readfirstlane((int)huf_slot);
+            ZTables *T = tabs + sl;
+            for (uint32_t i = lane; i < (1u << mbits); i += 64) T->huf[i] = huf_tab[i];
+            if (lane == 0) T->hufbits = mbits;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- phase 2 (lane 0 with the wave flushing tables): sequences section
+        bool own_slot = s_cmd[0] != 0;                                    // does this block already occupy next_slot?
+        if (bstat == ZD_OK && (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane == 0 ? b.type : 0)) == 2) {
+            uint32_t nseq = 0, modes = 0, pos = 0, len = 0;
+            const uint8_t *p = in + ip + 3;
+            if (lane == 0) {
+                len = b.size; pos = b.seq_off;
+                do {
+                    if (pos >= len) { bstat = ZD_CORRUPT; break; }
+                    const uint32_t b0 = p[pos++];
+                    if (b0 < 128) nseq = b0;
+                    else if (b0 < 255) { if (pos >= len) { bstat = ZD_CORRUPT; break; } nseq = ((b0 - 128) << 8) + p[pos++]; }
+                    else { if (pos + 2 > len) { bstat = ZD_CORRUPT; break; } nseq = p[pos] + ((uint32_t)p[pos + 1] << 8) + 0x7F00; pos += 2; }
+                    if (nseq == 0) { if (pos != len) bstat = ZD_CORRUPT; break; }
+                    if (pos >= len) { bstat = ZD_CORRUPT; break; }
+                    modes = p[pos++];
+                    if (modes & 3) bstat = ZD_CORRUPT;
+                } while (false);
+                s_cmd[5] = bstat; s_cmd[6] = nseq; s_cmd[7] = modes;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bstat = s_cmd[5]; nseq = s_cmd[6]; modes = s_cmd[7];
+            for (int k = 0; k < 3 && bstat == ZD_OK && nseq; k++) {        // LL, OF, ML in stream order
+                const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+                if (mode == 3) { if (slot3[k] == 0xFFFFFFFFu) bstat = ZD_CORRUPT; continue; }
+                if (lane == 0) {
+                    uint32_t st2 = ZD_OK, alog_out = 0;
+                    const int16_t *def = k == 0 ? ZD_LL_DEF : (k == 1 ? ZD_OF_DEF : ZD_ML_DEF);
+                    const int def_n = k == 0 ? 36 : (k == 1 ? 29 : 53), def_log = k == 1 ? 5 : 6;
+                    const int max_sym = k == 0 ? 35 : (k == 1 ? 31 : 52), max_log = k == 1 ? 8 : 9;
+                    if (!own_slot && next_slot >= x.slot_cap) st2 = ZD_UNSUPPORTED;
+                    else if (mode == 0) {
+                        for (int i = 0; i < def_n; i++) norm[i] = def[i];
+                        if (!zd_fse_build(fse_tab, norm, def_n, def_log, nexts)) st2 = ZD_CORRUPT;
+                        alog_out = (uint32_t)def_log;
+                    } else if (mode == 1) {
+                        if (pos >= len || p[pos] > max_sym) st2 = ZD_CORRUPT; else { fse_tab[0] = p[pos]; pos++; alog_out = 0; }
+                    } else {
+                        int nsym, alog;
+                        const uint32_t used = zd_fse_desc(p + pos, len - pos, norm, &nsym, &alog, max_sym, max_log);
+                        if (!used || !zd_fse_build(fse_tab, norm, nsym, alog, nexts)) st2 = ZD_CORRUPT; else { pos += used; alog_out = (uint32_t)alog; }
+                    }
+                    s_cmd[5] = st2; s_cmd[3] = alog_out;
+                }
+                __builtin_amdgcn_wave_barrier();
+                bstat = s_cmd[5];
+                if (bstat != ZD_OK) break;
+                own_slot = true;
+                slot3[k] = x.slot_base + next_slot;
+                ZTables *T = tabs + slot3[k];
+                const uint32_t alog = s_cmd[3];
+                for (uint32_t i = lane; i < (1u << alog); i += 64) T->fse[k][i] = fse_tab[i];
+                if (lane == 0) T->alog[k] = alog;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0 && bstat == ZD_OK) {
+                b.nseq = nseq;
+                if (nseq) {
+                    if (pos >= len) bstat = ZD_CORRUPT;
+                    else if (seq_pos + nseq > x.seq_cap) bstat = ZD_UNSUPPORTED;
+                    else { b.seq_off = pos; b.seq_len = len - pos; }
+                }
+                s_cmd[5] = bstat;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bstat = s_cmd[5];
+        }
+        if (own_slot) next_slot++;
+        // ---- record the block, enqueue its work
+        if (bstat != ZD_OK) { status = bstat; break; }
+        if (lane == 0) {
+            b.huf_slot = huf_slot; b.slot[0] = slot3[0]; b.slot[1] = slot3[1]; b.slot[2] = slot3[2];
+            const uint32_t bi = x.blk_base + nblk;
+            blocks[bi] = b;
+            if (b.type == 2 && b.ltype >= 2) {
+                const uint32_t q = atomicAdd(&work->n_huf, b.streams);
+                for (uint32_t sq2 = 0; sq2 < b.streams; sq2++) huf_list[q + sq2] = bi * 4 + sq2;
+            }
+            if (b.type == 2) { const uint32_t q = atomicAdd(&work->n_seq, 1u); seq_list[q] = bi; }
+            s_cmd[1] = (uint32_t)b.pad[0]; s_cmd[2] = b.size; s_cmd[3] = b.type; s_cmd[4] = b.regen; s_cmd[6] = b.nseq;
+        }
+        __builtin_amdgcn_wave_barrier();
+        last = s_cmd[1] != 0;
+        ip += 3 + (s_cmd[3] == 1 ? 1 : s_cmd[2]);
+        if (s_cmd[3] == 2) { lit_pos += s_cmd[4]; seq_pos += s_cmd[6]; }
+        nblk++;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { fx[f].nblk = nblk; frames[f].status = status; }
+}
+
+// ------------------------------------------------------------------ k_zhuf : one lane per Huffman stream
+__global__ __launch_bounds__(64)
+void k_zhuf(const uint32_t *__restrict__ huf_list, const ZWork *__restrict__ work, ZBlock *__restrict__ blocks, const ZFrame *__restrict__ frames,
+            const ZTables *__restrict__ tabs, const uint8_t *__restrict__ src, uint8_t *__restrict__ lit_scratch) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= work->n_huf) return;
+    const uint32_t item = huf_list[i], bi = item >> 2, sidx = item & 3;
+    const ZBlock b = blocks[bi];
+    const uint8_t *cs = src + b.body + b.lit_off;
+    const uint32_t cl = b.lit_csize;
+    uint32_t s_off = 0, s_len = cl, o_off = 0, o_len = b.regen;
+    bool ok = true;
+    if (b.streams == 4) {
+        if (cl < 6) ok = false;
+        else {
+            const uint32_t l1 = cs[0] | (cs[1] << 8), l2 = cs[2] | (cs[3] << 8), l3 = cs[4] | (cs[5] << 8);
+            const uint32_t seg = (b.regen + 3) / 4;
+            if (6 + l1 + l2 + l3 > cl || seg * 3 > b.regen) ok = false;
+            else {
+                s_off = 6 + (sidx > 0 ? l1 : 0) + (sidx > 1 ? l2 : 0) + (sidx > 2 ? l3 : 0);
+                s_len = sidx == 0 ? l1 : (sidx == 1 ? l2 : (sidx == 2 ? l3 : cl - 6 - l1 - l2 - l3));
+                o_off = sidx * seg; o_len = sidx < 3 ? seg : b.regen - 3 * seg;
+            }
+        }
+    }
+    if (ok) {
+        const ZTables *T = tabs + b.huf_slot;
+        const uint32_t mb = T->hufbits;
+        const uint8_t *gs = cs + s_off;
+        uint8_t *lit = lit_scratch + frames[b.frame].dst_off + b.lit_pos + o_off;
+        auto fetch = [&](int64_t j) -> uint64_t { return *(const zd_u64u *)(gs + 8 * j); };
+        ZdWin bw;
+        if (!zd_winit(bw, fetch, s_len ? gs[s_len - 1] : 0u, s_len)) ok = false;
+        else {
+            for (uint32_t k = 0; k < o_len; k++) {
+                const uint32_t cell = T->huf[(uint32_t)zd_wpeek(bw, fetch, mb)];
+                lit[k] = (uint8_t)cell;
+                bw.off -= cell >> 8;
+                if (bw.off < 0) { ok = false; break; }
+            }
+            if (ok && bw.off != 0) ok = false;
+        }
+    }
+    if (!ok) atomicOr(&blocks[bi].status, (uint32_t)ZD_CORRUPT);
+}
+
+// ------------------------------------------------------------------ k_zfse : one lane per block with sequences
+__global__ __launch_bounds__(64)
+void k_zfse(const uint32_t *__restrict__ seq_list, const ZWork *__restrict__ work, ZBlock *__restrict__ blocks, const ZTables *__restrict__ tabs,
+            const uint8_t *__restrict__ src, uint64_t *__restrict__ seqs) {
+    __shared__ uint32_t t_llb[36], t_mlb[53];
+    __shared__ uint8_t  t_lln[36], t_mln[53];
+    if (threadIdx.x < 36) { t_llb[threadIdx.x] = ZD_LL_BASE[threadIdx.x]; t_lln[threadIdx.x] = ZD_LL_BITS[threadIdx.x]; }
+    if (threadIdx.x < 53) { t_mlb[threadIdx.x] = ZD_ML_BASE[threadIdx.x]; t_mln[threadIdx.x] = ZD_ML_BITS[threadIdx.x]; }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= work->n_seq) return;
+    const uint32_t bi = seq_list[i];
+    const ZBlock b = blocks[bi];
+    uint32_t out_len = b.regen, uses_rep = 0;
+    bool ok = true;
+    if (b.nseq) {
+        const uint32_t *tl = tabs[b.slot[0]].fse[0], *to = tabs[b.slot[1]].fse[1], *tm = tabs[b.slot[2]].fse[2];
+        const uint32_t al = tabs[b.slot[0]].alog[0], ao = tabs[b.slot[1]].alog[1], am = tabs[b.slot[2]].alog[2];
+        const uint8_t *gq = src + b.body + b.seq_off;
+        auto fetch = [&](int64_t j) -> uint64_t { return *(const zd_u64u *)(gq + 8 * j); };
+        ZdWin bw;
+        if (!zd_winit(bw, fetch, b.seq_len ? gq[b.seq_len - 1] : 0u, b.seq_len)) ok = false;
+        else {
+            uint32_t sll = (uint32_t)zd_wread(bw, fetch, al), sof = (uint32_t)zd_wread(bw, fetch, ao), sml = (uint32_t)zd_wread(bw, fetch, am);
+            uint64_t *rec = seqs + b.seq_pos;
+            uint64_t total = b.regen;
+            for (uint32_t k = 0; k < b.nseq; k++) {
+                const uint32_t cl = tl[sll], co = to[sof], cm = tm[sml];
+                const uint32_t llc = cl & 0xFF, ofc = co & 0xFF, mlc = cm & 0xFF;
+                if (ofc > 31 || mlc > 52 || llc > 35) { ok = false; break; }
+                const uint64_t ofv = ((uint64_t)1 << ofc) + zd_wread(bw, fetch, ofc);
+                const uint32_t ml = t_mlb[mlc] + (uint32_t)zd_wread(bw, fetch, t_mln[mlc]);
+                const uint32_t ll = t_llb[llc] + (uint32_t)zd_wread(bw, fetch, t_lln[llc]);
+                if (bw.off < 0 || ofv > 0xFFFFFFu) { ok = false; break; }
+                if (k + 1 < b.nseq) {
+                    sll = (cl >> 16) + (uint32_t)zd_wread(bw, fetch, (cl >> 8) & 0xFF);
+                    sml = (cm >> 16) + (uint32_t)zd_wread(bw, fetch, (cm >> 8) & 0xFF);
+                    sof = (co >> 16) + (uint32_t)zd_wread(bw, fetch, (co >> 8) & 0xFF);
+                    if (bw.off < 0) { ok = false; break; }
+                }
+                if (ofv <= 3) uses_rep = 1;
+                rec[k] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
+                total += ml;
+            }
+            if (ok && bw.off != 0) ok = false;
+            if (total > (128u << 10)) ok = false;
+            out_len = (uint32_t)total;
+        }
+    }
+    blocks[bi].out_len = out_len; blocks[bi].uses_rep = uses_rep;
+    if (!ok) atomicOr(&blocks[bi].status, (uint32_t)ZD_CORRUPT);
+}
+
+// ------------------------------------------------------------------ k_zoff : one thread per frame
+__global__ void k_zoff(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, uint32_t n, ZBlock *__restrict__ blocks) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    if (frames[f].status) return;
+    const ZFrameX x = fx[f];
+    uint64_t off = frames[f].dst_off, total = 0; uint32_t st = 0;
+    for (uint32_t k = 0; k < x.nblk; k++) {
+        ZBlock *b = blocks + x.blk_base + k;
+        b->out_off = off + total; total += b->out_len; st |= b->status;
+    }
+    if (st) frames[f].status = ZD_CORRUPT;
+    else if (total != frames[f].dst_len) frames[f].status = ZD_DSTSIZE;
+}
+
+// ------------------------------------------------------------------ k_zexec : one wave per frame, blocks in order
+__global__ __launch_bounds__(64)
+void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src,
+             const uint8_t *__restrict__ lit_scratch, const uint64_t *__restrict__ seqs, uint8_t *__restrict__ dst) {
+    const uint32_t lane = threadIdx.x, f = blockIdx.x;
+    const ZFrame fr = frames[f];
+    if (fr.status) return;
+    const ZFrameX x = fx[f];
+    uint8_t *out = dst + fr.dst_off;                                  // frame-relative positions below
+    const uint32_t cap = fr.dst_len;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    bool okq = true;
+    for (uint32_t k = 0; k < x.nblk && okq; k++) {
+        const ZBlock b = blocks[x.blk_base + k];
+        uint32_t op = (uint32_t)(b.out_off - fr.dst_off);
+        const uint8_t *body = src + b.body;
+        if (b.type < 2) {
+            const uint32_t rle = body[0];
+            for (uint32_t i = lane; i < b.size; i += 64) out[op + i] = b.type == 0 ? body[i] : (uint8_t)rle;
+            continue;
+        }
+        const uint8_t *lit_raw = body + b.lit_off;
+        const uint8_t *lit_dec = lit_scratch + fr.dst_off + b.lit_pos;
+        auto LIT = [&](uint32_t i) -> uint8_t { return b.ltype == 0 ? lit_raw[i] : (b.ltype == 1 ? lit_raw[0] : lit_dec[i]); };
+        const uint64_t *rec = seqs + b.seq_pos;
+        uint32_t litpos = 0;
+        for (uint32_t base = 0; base < b.nseq && okq; base += 64) {
+            const uint32_t nb = b.nseq - base < 64 ? b.nseq - base : 64u;
+            const bool act = lane < nb;
+            const uint64_t sv = act ? rec[base + lane] : 0;
+            const uint32_t ll = (uint32_t)(sv & 0xFFFFF), ml = (uint32_t)((sv >> 20) & 0xFFFFF), ofv = (uint32_t)(sv >> 40);
+            // ---- offsets: without repeat codes in the batch every offset is its own value - 3 and the history is simply
+            // the last three offsets; otherwise lane order has to be walked
+            uint32_t offset = ofv - 3;
+            const uint64_t repm = __ballot(act && ofv <= 3);
+            if (!repm) {
+                if (nb >= 3) { rep2 = (uint32_t)__shfl((int)offset, (int)nb - 3); rep1 = (uint32_t)__shfl((int)offset, (int)nb - 2); rep0 = (uint32_t)__shfl((int)offset, (int)nb - 1); }
+                else if (nb == 2) { rep2 = rep0; rep1 = (uint32_t)__shfl((int)offset, 0); rep0 = (uint32_t)__shfl((int)offset, 1); }
+                else { rep2 = rep1; rep1 = rep0; rep0 = (uint32_t)__shfl((int)offset, 0); }
+            } else {
+                for (uint32_t j = 0; j < nb; j++) {
+                    const uint32_t vj = (uint32_t)__shfl((int)ofv, (int)j), lj = (uint32_t)__shfl((int)ll, (int)j);
+                    uint32_t o;
+                    if (vj > 3) { o = vj - 3; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                    else {
+                        const uint32_t idx = vj - 1 + (lj == 0 ? 1u : 0u);
+                        if (idx == 0) o = rep0;
+                        else { o = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1); if (idx > 1) rep2 = rep1; rep1 = rep0; rep0 = o; }
+                    }
+                    if (lane == j) offset = o;
+                }
+            }
+            uint32_t incl = ll + ml, lincl = ll;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t1 = (uint32_t)__shfl_up((int)incl, d), t2 = (uint32_t)__shfl_up((int)lincl, d);
+                if (lane >= (uint32_t)d) { incl += t1; lincl += t2; }
+            }
+            const uint32_t o0 = op + incl - (ll + ml), l0 = litpos + lincl - ll;
+            const uint32_t T = (uint32_t)__shfl((int)incl, 63), TL = (uint32_t)__shfl((int)lincl, 63);
+            const bool bad = act && (l0 + ll > b.regen || (uint64_t)o0 + ll + ml > cap || offset == 0 || offset > o0 + ll);
+            if (__ballot(bad)) { okq = false; break; }
+            {
+                const uint32_t ls = ll < 32 ? ll : 32u;
+                for (uint32_t i = 0; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = LIT(l0 + i);
+                uint64_t longm = __ballot(ll > 32);
+                while (longm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
+                    const uint32_t oj = (uint32_t)__shfl((int)o0, (int)j), lj = (uint32_t)__shfl((int)l0, (int)j), nj = (uint32_t)__shfl((int)ll, (int)j);
+                    for (uint32_t i = 32 + lane; i < nj; i += 64) out[oj + i] = LIT(lj + i);
+                }
+            }
+            const uint32_t dstp = o0 + ll, m0 = dstp - offset;
+            const uint32_t src_end = m0 + (ml < offset ? ml : offset);
+            bool pending = act && ml != 0;
+            for (;;) {
+                const uint64_t pm = __ballot(pending);
+                if (!pm) break;
+                __threadfence_block();
+                const uint32_t frontier = (uint32_t)__shfl((int)dstp, (int)__builtin_ctzll(pm));
+                const bool ready = pending && src_end <= frontier;
+                const bool shortr = ready && ml <= 32;
+                for (uint32_t i = 0; __ballot(shortr && i < ml); i++) if (shortr && i < ml) out[dstp + i] = out[m0 + i];
+                uint64_t longm = __ballot(ready && ml > 32);
+                while (longm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
+                    const uint32_t dj = (uint32_t)__shfl((int)dstp, (int)j), mj = (uint32_t)__shfl((int)m0, (int)j);
+                    const uint32_t nj = (uint32_t)__shfl((int)ml, (int)j), fj = (uint32_t)__shfl((int)offset, (int)j);
+                    if (fj >= nj) { for (uint32_t i = lane; i < nj; i += 64) out[dj + i] = out[mj + i]; }
+                    else { for (uint32_t i = lane; i < nj; i += 64) out[dj + i] = out[mj + i % fj]; }
+                }
+                pending = pending && !ready;
+            }
+            op += T; litpos += TL;
+        }
+        if (okq) {
+            const uint32_t rest = b.regen - litpos;
+            if ((uint64_t)op + rest > cap) okq = false;
+            else for (uint32_t i = lane; i < rest; i += 64) out[op + i] = LIT(litpos + i);
+        }
+        __threadfence_block();
+    }
+    if (!okq && lane == 0) frames[f].status = ZD_CORRUPT;
+}
+
+void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
+                   void *work, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zparse, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, tabs, huf_list, seq_list, (ZWork *)work);
+}
+void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
+                     const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
+    if (n_huf) hipLaunchKernelGGL(k_zhuf, dim3((n_huf + 63) / 64), dim3(64), 0, st, huf_list, (const ZWork *)work, blocks, frames, tabs, src, lit_scratch);
+    if (n_seq) hipLaunchKernelGGL(k_zfse, dim3((n_seq + 63) / 64), dim3(64), 0, st, seq_list, (const ZWork *)work, blocks, tabs, src, seqs);
+}
+void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
+                  const uint64_t *seqs, uint8_t *dst, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_zoff, dim3((n + 63) / 64), dim3(64), 0, st, frames, fx, n, blocks);
+    hipLaunchKernelGGL(k_zexec, dim3(n), dim3(64), 0, st, frames, fx, blocks, src, lit_scratch, seqs, dst);
+}
+
 // ------------------------------------------------------------------ k_zscan : one thread per entry
 // An entry's payload is one or more concatenated frames (zstd-rs' Decoder reads them all).  Frames carry no content size here,
 // so the split of the entry's raw size over its frames follows this repository's encoder: every frame but the last holds

@@ -102,6 +102,33 @@ struct ZFrame {
     uint32_t out_len;        // out: bytes produced
 };
 
+// ---- lane-parallel decoder (k_zparse / k_zhuf / k_zfse / k_zoff / k_zexec)
+struct ZFrameX {             // per frame: where its blocks, table slots and sequence records live
+    uint64_t seq_base;       // first record of the frame in the sequence scratch
+    uint32_t blk_base, blk_cap;      // its region of the block array
+    uint32_t slot_base, slot_cap;    // its table slots
+    uint32_t seq_cap;                // records available
+    uint32_t nblk;                   // out
+};
+struct ZBlock {
+    uint64_t body;           // offset of the block body in the compressed buffer
+    uint64_t out_off;        // absolute output offset (k_zoff)
+    uint64_t seq_pos;        // first sequence record (absolute index into the scratch)
+    uint32_t size, type;     // body bytes; 0 raw, 1 RLE, 2 compressed
+    uint32_t ltype, regen, streams, lit_off, lit_csize;    // literals: section payload (body-relative) behind the tree description
+    uint32_t lit_pos;        // where the block's decoded literals go in the frame's literal scratch (frame-relative)
+    uint32_t huf_slot, slot[3];      // table slots that apply (Huffman; LL, OF, ML)
+    uint32_t nseq, seq_off, seq_len; // sequence bitstream (body-relative)
+    uint32_t frame, out_len, status, uses_rep;
+    uint32_t pad[7];
+};
+static_assert(sizeof(ZBlock) == 128, "ZBlock layout");
+struct ZTables {             // one slot
+    uint16_t huf[2048];      // sym | nbits << 8
+    uint32_t fse[3][512];    // sym | nbits << 8 | base << 16
+    uint32_t hufbits, alog[3];
+};
+
 struct ZEntry {              // k_zscan input: one compressed entry
     uint64_t src_off, src_len;   // its payload (concatenated frames) in the compressed buffer
     uint64_t dst_off, raw_len;   // where the content goes and how long it is (fSIZ)

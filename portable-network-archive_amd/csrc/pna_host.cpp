@@ -37,6 +37,12 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
+void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
+                   void *work, hipStream_t st);
+void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
+                     const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
+void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
+                  const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
 void frame_solid_tail(std::vector<uint8_t> &o);
@@ -85,7 +91,8 @@ struct pna_gpu_ctx {
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
-    DevBuf z_ents, z_frames, z_lit;                            // decoder descriptors, 128 KiB of literal scratch per frame
+    DevBuf z_ents, z_frames, z_lit;                            // decoder descriptors, literal scratch
+    DevBuf z_fx, z_blocks, z_tabs, z_seqs, z_hlist, z_slist, z_work, z_fb;   // lane-parallel decoder workspace
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[2], hp_out[2];
@@ -148,7 +155,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -805,19 +812,71 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
         ents[i] = ZEntry{src_off[i], src_len[i], dst_off[i], raw_len[i], (uint32_t)nfr, (uint32_t)k};
         nfr += k;
     }
-    if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame)) || c->z_lit.ensure(nfr * (size_t)(128u << 10) + 64))
+    // per-frame bounds of the lane-parallel pipeline (frames that exceed them fall back to the one-workgroup-per-frame kernel)
+    std::vector<ZFrameX> fxs(nfr);
+    uint64_t nblk_cap = 0, nslot = 0, nseq_cap = 0, out_span = 0;
+    for (size_t i = 0; i < n; i++) {
+        out_span = std::max<uint64_t>(out_span, dst_off[i] + raw_len[i]);
+        for (uint32_t f = 0; f < ents[i].n_frames; f++) {
+            const uint64_t done = (uint64_t)f * SEG_SIZE;
+            const uint64_t dl = (f + 1 == ents[i].n_frames) ? (raw_len[i] > done ? raw_len[i] - done : 0) : SEG_SIZE;
+            ZFrameX &x = fxs[ents[i].first_frame + f];
+            x.blk_base = (uint32_t)nblk_cap; x.blk_cap = (uint32_t)std::min<uint64_t>((dl >> 12) + 4, 1u << 20);
+            x.slot_base = (uint32_t)nslot; x.slot_cap = (uint32_t)std::min<uint64_t>((dl >> 17) + 2, 1u << 16);
+            x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(dl / 4 + 16, 0x7FFFFFFFu); x.nblk = 0;
+            nblk_cap += x.blk_cap; nslot += x.slot_cap; nseq_cap += x.seq_cap;
+            if (nblk_cap > 0x3FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
+        }
+    }
+    const bool serial_only = getenv("PNA_ZDEC_SERIAL") != nullptr;     // diagnostics: one workgroup per frame for everything
+    if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame)) || c->z_lit.ensure(out_span + 64) ||
+        c->z_fx.ensure(nfr * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk_cap * sizeof(ZBlock)) || c->z_tabs.ensure(nslot * sizeof(ZTables)) ||
+        c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_hlist.ensure(nblk_cap * 16 + 16) || c->z_slist.ensure(nblk_cap * 4 + 16) || c->z_work.ensure(64))
         return fail(c, PNA_E_NOMEM, "decoder workspace");
     HIPCHK(c, hipMemcpyAsync(c->z_ents.p, ents.data(), n * sizeof(ZEntry), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), nfr * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(c->z_work.p, 0, 64, st));
     launch_zscan((const ZEntry *)c->z_ents.p, (uint32_t)n, (const uint8_t *)d_src, (ZFrame *)c->z_frames.p, st);
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    launch_zdec((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, st);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
-    HIPCHK(c, hipGetLastError());
     std::vector<ZFrame> frs(nfr);
-    HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+    if (!serial_only) {
+        // sequence records of frame f start at seq_base: k_zparse adds it to the block's running count
+        launch_zparse((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)nfr, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (ZTables *)c->z_tabs.p,
+                      (uint32_t *)c->z_hlist.p, (uint32_t *)c->z_slist.p, c->z_work.p, st);
+        uint32_t work[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(work, c->z_work.p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        launch_zstreams(work[0], work[1], (const uint32_t *)c->z_hlist.p, (const uint32_t *)c->z_slist.p, c->z_work.p, (ZBlock *)c->z_blocks.p,
+                        (const ZFrame *)c->z_frames.p, (const ZTables *)c->z_tabs.p, (const uint8_t *)d_src, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
+        launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)nfr, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
+                     (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (auto &fr : frs) if (fr.status == 0) fr.status = 2;        // route every well-formed frame through the fallback below
+    }
+    // ---- frames the bounded pipeline could not take: one workgroup per frame
+    std::vector<uint32_t> fb;
+    for (uint64_t f = 0; f < nfr; f++) if (frs[f].status == 2) fb.push_back((uint32_t)f);
+    if (!fb.empty()) {
+        std::vector<ZFrame> sub(fb.size());
+        for (size_t k = 0; k < fb.size(); k++) { sub[k] = frs[fb[k]]; sub[k].status = 0; sub[k].out_len = 0; }
+        if (c->z_fb.ensure(sub.size() * sizeof(ZFrame)) || c->z_lit.ensure(std::max<uint64_t>(out_span + 64, sub.size() * (uint64_t)(128u << 10) + 64)))
+            return fail(c, PNA_E_NOMEM, "decoder workspace");
+        HIPCHK(c, hipMemcpyAsync(c->z_fb.p, sub.data(), sub.size() * sizeof(ZFrame), hipMemcpyHostToDevice, st));
+        launch_zdec((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(sub.data(), c->z_fb.p, sub.size() * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (size_t k = 0; k < fb.size(); k++) frs[fb[k]] = sub[k];
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-    c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms;            // decoder kernel time reported in the first stage slot
+    c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms;            // decoder time reported in the first stage slot
     for (size_t i = 0; i < n; i++)
         for (uint32_t f = 0; f < ents[i].n_frames; f++) {
             const ZFrame &fr = frs[ents[i].first_frame + f];
