@@ -822,13 +822,34 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
 }
 
 // ------------------------------------------------------------------ k_zhuf : one lane per Huffman stream
+// The 64 streams of a wave belong to ~16 consecutive blocks, i.e. to a handful of frames: up to four distinct decoding tables
+// are copied into LDS once (a lane whose table did not get a place reads it from global memory).
+constexpr uint32_t ZH_CACHE = 4;
 __global__ __launch_bounds__(64)
 void k_zhuf(const uint32_t *__restrict__ huf_list, const ZWork *__restrict__ work, ZBlock *__restrict__ blocks, const ZFrame *__restrict__ frames,
             const ZTables *__restrict__ tabs, const uint8_t *__restrict__ src, uint8_t *__restrict__ lit_scratch) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= work->n_huf) return;
-    const uint32_t item = huf_list[i], bi = item >> 2, sidx = item & 3;
-    const ZBlock b = blocks[bi];
+    __shared__ uint16_t ctab[ZH_CACHE][1 << ZD_HUF_MAX];
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    const bool valid = i < work->n_huf;
+    const uint32_t item = valid ? huf_list[i] : 0u, bi = item >> 2, sidx = item & 3;
+    ZBlock b; if (valid) b = blocks[bi]; else { b.huf_slot = 0xFFFFFFFFu; b.streams = 1; b.regen = 0; b.lit_csize = 0; b.body = 0; b.lit_off = 0; b.frame = 0; b.lit_pos = 0; }
+    // ---- table cache
+    uint32_t mine = ZH_CACHE;
+    {
+        uint64_t rem = __ballot(valid);
+        for (uint32_t c = 0; c < ZH_CACHE && rem; c++) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(rem);
+            const uint32_t sl = (uint32_t)__shfl((int)b.huf_slot, (int)leader);
+            const uint32_t *g = (const uint32_t *)tabs[sl].huf;
+            uint32_t *l = (uint32_t *)ctab[c];
+            for (uint32_t k = lane; k < (1u << ZD_HUF_MAX) / 2; k += 64) l[k] = g[k];
+            const bool same = valid && b.huf_slot == sl;
+            if (same) mine = c;
+            rem &= ~__ballot(same);
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
     const uint8_t *cs = src + b.body + b.lit_off;
     const uint32_t cl = b.lit_csize;
     uint32_t s_off = 0, s_len = cl, o_off = 0, o_len = b.regen;
@@ -852,39 +873,97 @@ void k_zhuf(const uint32_t *__restrict__ huf_list, const ZWork *__restrict__ wor
         const uint8_t *gs = cs + s_off;
         uint8_t *lit = lit_scratch + frames[b.frame].dst_off + b.lit_pos + o_off;
         auto fetch = [&](int64_t j) -> uint64_t { return *(const zd_u64u *)(gs + 8 * j); };
+        auto cellof = [&](uint32_t idx) -> uint32_t { return mine < ZH_CACHE ? (uint32_t)ctab[mine][idx] : (uint32_t)T->huf[idx]; };
         ZdWin bw;
         if (!zd_winit(bw, fetch, s_len ? gs[s_len - 1] : 0u, s_len)) ok = false;
         else {
-            for (uint32_t k = 0; k < o_len; k++) {
-                const uint32_t cell = T->huf[(uint32_t)zd_wpeek(bw, fetch, mb)];
-                lit[k] = (uint8_t)cell;
-                bw.off -= cell >> 8;
-                if (bw.off < 0) { ok = false; break; }
+            uint32_t k = 0;
+            // head: single bytes up to a 4-byte boundary of the destination, then four symbols per store
+            for (; k < o_len && ((uintptr_t)(lit + k) & 3); k++) {
+                const uint32_t cell = cellof((uint32_t)zd_wpeek(bw, fetch, mb));
+                lit[k] = (uint8_t)cell; bw.off -= cell >> 8;
             }
-            if (ok && bw.off != 0) ok = false;
+            // sixteen symbols per store once the destination is 16-byte aligned (fewer stores for the window loads to wait behind)
+            for (; ok && k + 4 <= o_len && ((uintptr_t)(lit + k) & 15); k += 4) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cell = cellof((uint32_t)zd_wpeek(bw, fetch, mb));
+                    word |= (cell & 0xFF) << (8 * q); bw.off -= cell >> 8;
+                }
+                if (bw.off < 0) ok = false;
+                else *(uint32_t *)(lit + k) = word;
+            }
+            for (; ok && k + 16 <= o_len; k += 16) {
+                uint32_t w4[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t cell = cellof((uint32_t)zd_wpeek(bw, fetch, mb));
+                    w4[q >> 2] |= (cell & 0xFF) << (8 * (q & 3)); bw.off -= cell >> 8;
+                }
+                if (bw.off < 0) ok = false;
+                else *(uint4 *)(lit + k) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            for (; ok && k + 4 <= o_len; k += 4) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cell = cellof((uint32_t)zd_wpeek(bw, fetch, mb));
+                    word |= (cell & 0xFF) << (8 * q); bw.off -= cell >> 8;
+                }
+                if (bw.off < 0) ok = false;
+                else *(uint32_t *)(lit + k) = word;
+            }
+            for (; ok && k < o_len; k++) {
+                const uint32_t cell = cellof((uint32_t)zd_wpeek(bw, fetch, mb));
+                lit[k] = (uint8_t)cell; bw.off -= cell >> 8;
+            }
+            if (bw.off != 0) ok = false;
         }
     }
     if (!ok) atomicOr(&blocks[bi].status, (uint32_t)ZD_CORRUPT);
 }
 
 // ------------------------------------------------------------------ k_zfse : one lane per block with sequences
+// The 64 blocks of a wave belong to a few frames: up to eight distinct (LL, OF, ML) table sets are copied into LDS.
+constexpr uint32_t ZF_CACHE = 8;
 __global__ __launch_bounds__(64)
 void k_zfse(const uint32_t *__restrict__ seq_list, const ZWork *__restrict__ work, ZBlock *__restrict__ blocks, const ZTables *__restrict__ tabs,
             const uint8_t *__restrict__ src, uint64_t *__restrict__ seqs) {
+    __shared__ uint32_t cfse[ZF_CACHE][3][512];
+    __shared__ uint64_t rbuf[64][9];                   // eight records per lane (+1: conflict-free pitch), flushed together
     __shared__ uint32_t t_llb[36], t_mlb[53];
     __shared__ uint8_t  t_lln[36], t_mln[53];
-    if (threadIdx.x < 36) { t_llb[threadIdx.x] = ZD_LL_BASE[threadIdx.x]; t_lln[threadIdx.x] = ZD_LL_BITS[threadIdx.x]; }
-    if (threadIdx.x < 53) { t_mlb[threadIdx.x] = ZD_ML_BASE[threadIdx.x]; t_mln[threadIdx.x] = ZD_ML_BITS[threadIdx.x]; }
+    const uint32_t lane = threadIdx.x;
+    if (lane < 36) { t_llb[lane] = ZD_LL_BASE[lane]; t_lln[lane] = ZD_LL_BITS[lane]; }
+    if (lane < 53) { t_mlb[lane] = ZD_ML_BASE[lane]; t_mln[lane] = ZD_ML_BITS[lane]; }
+    const uint32_t i = blockIdx.x * 64 + lane;
+    const bool valid = i < work->n_seq;
+    const uint32_t bi = valid ? seq_list[i] : 0u;
+    ZBlock b; if (valid) b = blocks[bi]; else { b.nseq = 0; b.slot[0] = b.slot[1] = b.slot[2] = 0xFFFFFFFFu; b.regen = 0; }
+    const bool want = valid && b.nseq != 0;
+    uint32_t mine = ZF_CACHE;
+    {
+        uint64_t rem = __ballot(want);
+        for (uint32_t c = 0; c < ZF_CACHE && rem; c++) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(rem);
+            const uint32_t s0 = (uint32_t)__shfl((int)b.slot[0], (int)leader), s1 = (uint32_t)__shfl((int)b.slot[1], (int)leader), s2 = (uint32_t)__shfl((int)b.slot[2], (int)leader);
+            for (uint32_t k = lane; k < 512; k += 64) { cfse[c][0][k] = tabs[s0].fse[0][k]; cfse[c][1][k] = tabs[s1].fse[1][k]; cfse[c][2][k] = tabs[s2].fse[2][k]; }
+            const bool same = want && b.slot[0] == s0 && b.slot[1] == s1 && b.slot[2] == s2;
+            if (same) mine = c;
+            rem &= ~__ballot(same);
+        }
+    }
     __syncthreads();
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= work->n_seq) return;
-    const uint32_t bi = seq_list[i];
-    const ZBlock b = blocks[bi];
+    if (!valid) return;
     uint32_t out_len = b.regen, uses_rep = 0;
     bool ok = true;
     if (b.nseq) {
-        const uint32_t *tl = tabs[b.slot[0]].fse[0], *to = tabs[b.slot[1]].fse[1], *tm = tabs[b.slot[2]].fse[2];
+        const uint32_t *gl = tabs[b.slot[0]].fse[0], *go = tabs[b.slot[1]].fse[1], *gm = tabs[b.slot[2]].fse[2];
         const uint32_t al = tabs[b.slot[0]].alog[0], ao = tabs[b.slot[1]].alog[1], am = tabs[b.slot[2]].alog[2];
+        auto TL = [&](uint32_t st) -> uint32_t { return mine < ZF_CACHE ? cfse[mine][0][st] : gl[st]; };
+        auto TO = [&](uint32_t st) -> uint32_t { return mine < ZF_CACHE ? cfse[mine][1][st] : go[st]; };
+        auto TM = [&](uint32_t st) -> uint32_t { return mine < ZF_CACHE ? cfse[mine][2][st] : gm[st]; };
         const uint8_t *gq = src + b.body + b.seq_off;
         auto fetch = [&](int64_t j) -> uint64_t { return *(const zd_u64u *)(gq + 8 * j); };
         ZdWin bw;
@@ -894,22 +973,32 @@ void k_zfse(const uint32_t *__restrict__ seq_list, const ZWork *__restrict__ wor
             uint64_t *rec = seqs + b.seq_pos;
             uint64_t total = b.regen;
             for (uint32_t k = 0; k < b.nseq; k++) {
-                const uint32_t cl = tl[sll], co = to[sof], cm = tm[sml];
+                const uint32_t cl = TL(sll & 511), co = TO(sof & 511), cm = TM(sml & 511);
                 const uint32_t llc = cl & 0xFF, ofc = co & 0xFF, mlc = cm & 0xFF;
                 if (ofc > 31 || mlc > 52 || llc > 35) { ok = false; break; }
+                // three window reads per sequence: offset bits | match-length + literal-length bits | the three state updates
+                // (a field read earlier sits above the later ones in a combined read)
                 const uint64_t ofv = ((uint64_t)1 << ofc) + zd_wread(bw, fetch, ofc);
-                const uint32_t ml = t_mlb[mlc] + (uint32_t)zd_wread(bw, fetch, t_mln[mlc]);
-                const uint32_t ll = t_llb[llc] + (uint32_t)zd_wread(bw, fetch, t_lln[llc]);
+                const uint32_t nm = t_mln[mlc], nl = t_lln[llc];
+                const uint32_t e2 = (uint32_t)zd_wread(bw, fetch, nm + nl);
+                const uint32_t ml = t_mlb[mlc] + (e2 >> nl);
+                const uint32_t ll = t_llb[llc] + (e2 & ((1u << nl) - 1));
                 if (bw.off < 0 || ofv > 0xFFFFFFu) { ok = false; break; }
                 if (k + 1 < b.nseq) {
-                    sll = (cl >> 16) + (uint32_t)zd_wread(bw, fetch, (cl >> 8) & 0xFF);
-                    sml = (cm >> 16) + (uint32_t)zd_wread(bw, fetch, (cm >> 8) & 0xFF);
-                    sof = (co >> 16) + (uint32_t)zd_wread(bw, fetch, (co >> 8) & 0xFF);
+                    const uint32_t bl = (cl >> 8) & 0xFF, bm = (cm >> 8) & 0xFF, bo = (co >> 8) & 0xFF;
+                    const uint32_t e3 = (uint32_t)zd_wread(bw, fetch, bl + bm + bo);
+                    sll = (cl >> 16) + (e3 >> (bm + bo));
+                    sml = (cm >> 16) + ((e3 >> bo) & ((1u << bm) - 1));
+                    sof = (co >> 16) + (e3 & ((1u << bo) - 1));
                     if (bw.off < 0) { ok = false; break; }
                 }
                 if (ofv <= 3) uses_rep = 1;
-                rec[k] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
+                rbuf[lane][k & 7] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
                 total += ml;
+                if ((k & 7) == 7 || k + 1 == b.nseq) {
+                    const uint32_t k0 = k & ~7u;
+                    for (uint32_t q = 0; q <= (k & 7); q++) rec[k0 + q] = rbuf[lane][q];
+                }
             }
             if (ok && bw.off != 0) ok = false;
             if (total > (128u << 10)) ok = false;
@@ -999,7 +1088,15 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
             if (__ballot(bad)) { okq = false; break; }
             {
                 const uint32_t ls = ll < 32 ? ll : 32u;
-                for (uint32_t i = 0; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = LIT(l0 + i);
+                if (b.ltype == 1) { for (uint32_t i = 0; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = lit_raw[0]; }
+                else {
+                    // eight bytes per step while eight remain (unaligned 64-bit accesses), single bytes for the rest
+                    const uint8_t *ls_src = (b.ltype == 0 ? lit_raw : lit_dec) + l0;
+                    uint32_t i = 0;
+                    for (; __ballot(i + 8 <= ls); i += 8) if (i + 8 <= ls) *(zd_u64u *)(out + o0 + i) = *(const zd_u64u *)(ls_src + i);
+                    i = ls & ~7u;
+                    for (; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = ls_src[i];
+                }
                 uint64_t longm = __ballot(ll > 32);
                 while (longm) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
@@ -1017,7 +1114,14 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
                 const uint32_t frontier = (uint32_t)__shfl((int)dstp, (int)__builtin_ctzll(pm));
                 const bool ready = pending && src_end <= frontier;
                 const bool shortr = ready && ml <= 32;
-                for (uint32_t i = 0; __ballot(shortr && i < ml); i++) if (shortr && i < ml) out[dstp + i] = out[m0 + i];
+                {
+                    // distance >= 8: eight bytes per step; closer matches copy byte by byte (they read what they just wrote)
+                    const bool wide = shortr && offset >= 8;
+                    uint32_t i = 0;
+                    for (; __ballot(wide && i + 8 <= ml); i += 8) if (wide && i + 8 <= ml) *(zd_u64u *)(out + dstp + i) = *(const zd_u64u *)(out + m0 + i);
+                    i = wide ? (ml & ~7u) : 0u;
+                    for (; __ballot(shortr && i < ml); i++) if (shortr && i < ml) out[dstp + i] = out[m0 + i];
+                }
                 uint64_t longm = __ballot(ready && ml > 32);
                 while (longm) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(longm); longm &= longm - 1;
