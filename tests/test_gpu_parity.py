@@ -69,7 +69,7 @@ def test_batch_bit_exact_and_decodable(gpu_ctx, codec):
 
 
 def test_serial_fallback_path_is_identical(pna, codec):
-    """Flag 0x200 forces k_lz's serial carry resolution on every tile; results must not change."""
+XX
     import torch  # noqa: F401
     cases = _cases(codec)
     names = sorted(cases)
@@ -170,7 +170,8 @@ def test_device_batch_properties_256mib(gpu_ctx, pna, codec):
 
 def test_full_size_properties_10k_x_1mib(gpu_ctx, pna, codec):
     """BASELINE.json configs[1] at full size through size-independent properties: offsets partition the output,
-    the run is reproducible (checksum of the whole stream), and sampled entries decode / are bit-exact."""
+    the run is reproducible (checksum of the whole stream), sampled entries decode on the host / are bit-exact, and ALL
+    entries round-trip through the device decoder."""
     import torch
     n, L = 10000, 1 << 20
     free, _ = torch.cuda.mem_get_info()
@@ -198,6 +199,11 @@ def test_full_size_properties_10k_x_1mib(gpu_ctx, pna, codec):
     for i in (0, 4999, 9999):
         assert host[offs[i]:offs[i + 1]] == codec.model_compress(codec.corpus_file(0, i, L), p), i
     assert 2.3 < n * L / offs[-1] < 3.2
+    # every entry, every byte: decoded on the device and compared with the source in HBM (the sampled entries above went
+    # through the independent host decoders)
+    back = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(dst.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(), so[:n], sl)
+    assert torch.equal(back[:n * L], src[:n * L])
 
 
 def test_deflate_bit_exact_and_inflatable(gpu_ctx, pna, codec):
