@@ -41,9 +41,6 @@ constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: 
 static_assert(CAP1 == 16, "the match step compares 8 + 8 bytes");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint64_t rdlane64(uint64_t v, uint32_t l) {
-    return (uint64_t)rdlane((uint32_t)v, l) | ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32);
-}
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 __device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
@@ -96,13 +93,6 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint
     uint32_t w[4] = {0, 0, 0, 0};
     for (uint32_t k = 0; k < 16; k++) if (i + k < seg_len) w[k >> 2] |= (uint32_t)seg[i + k] << (8 * (k & 3));
     return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// coverage of a match at wave-relative position p (0..127) with length L, as bit masks of the wave's two groups
-__device__ __forceinline__ void cover(uint64_t &c0, uint64_t &c1, uint32_t p, uint32_t L) {
-    const uint32_t end = p + L;
-    if (p < 64) c0 |= mlow(end) & ~mlow(p);
-    if (end > 64) c1 |= mlow(end - 64) & ~mlow(p > 64 ? p - 64 : 0u);
 }
 
 // diagnostic build only (STAMP = true): wave 0 / lane 0 accumulates s_memtime deltas per phase
