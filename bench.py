@@ -138,13 +138,23 @@ def main() -> None:
         dst_cap = pna.solid_archive_bound(algo, names, src_len)
     else:
         dst_cap = pna.bound(algo, file_len) * n_files + 4096
-    dst = torch.empty(dst_cap, dtype=torch.uint8, device=dev)
+    # N > 1: two output buffers, so the ordered gather of step k (RCCL send/recv over xGMI) overlaps the compression of step k+1
+    dsts = [torch.empty(dst_cap, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
     arg_cache: dict = {}
 
     shard = importlib.import_module("portable-network-archive_amd.shard")
     gather_out = [None]
+    pending = [None]
+    cur = [0]
+
+    def finish_gather():
+        if pending[0] is not None:
+            shard.gather_ordered_wait(pending[0])
+            torch.cuda.current_stream().synchronize()         # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
+            pending[0] = None
 
     def step():
+        dst = dsts[cur[0]]
         if args.framing == "archive":
             # rank 0 writes the archive header, the last rank AEND: the shards gathered in rank order are ONE archive
             part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
@@ -155,14 +165,16 @@ def main() -> None:
         else:
             total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
         if world > 1:
-            # ordered gather of the compressed shards into the serial stream on rank 0 (RCCL send/recv over xGMI)
+            finish_gather()                                   # the previous step's gather (it used the other buffer and gather_out)
             if rank == 0 and gather_out[0] is None:
                 gather_out[0] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
-            shard.gather_ordered(dst, total, rank, world, out=gather_out[0])
+            pending[0] = shard.gather_ordered_start(dst, total, rank, world, out=gather_out[0])
+            cur[0] ^= 1
         return total
 
     for _ in range(args.warmup):
         step()
+    finish_gather()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,6 +186,7 @@ def main() -> None:
         tm = ctx.timing()
         lz_ms += tm.ms_lz
         stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame
+    finish_gather()                                           # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -59,3 +59,36 @@ def gather_ordered(local, local_bytes: int, rank: int, world: int, out=None):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]):
             w.wait()
     return None, sizes
+
+
+def gather_ordered_start(local, local_bytes: int, rank: int, world: int, out=None):
+    """Asynchronous form of gather_ordered: posts the size exchange and the sends / receives and returns a handle for
+    gather_ordered_wait().  `local` (and `out` on rank 0) must stay untouched until the wait returns -- callers that keep
+    producing double-buffer `local`, so the gather of shard k overlaps the compression of shard k+1."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return {"works": [], "out": local[:local_bytes], "sizes": [local_bytes]}
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([local_bytes], dtype=torch.int64, device=local.device))
+    sizes = [int(x) for x in sizes_t.tolist()]
+    if rank == 0:
+        need = sum(sizes)
+        if out is None or out.numel() < need:
+            out = torch.empty(need, dtype=torch.uint8, device=local.device)
+        out[:sizes[0]].copy_(local[:sizes[0]], non_blocking=True)
+        ops, pos = [], sizes[0]
+        for r in range(1, world):
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[pos:pos + sizes[r]], r))
+            pos += sizes[r]
+        return {"works": dist.batch_isend_irecv(ops) if ops else [], "out": out[:need], "sizes": sizes}
+    works = dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]) if local_bytes else []
+    return {"works": works, "out": None, "sizes": sizes}
+
+
+def gather_ordered_wait(handle):
+    """Completes a gather_ordered_start(); returns (tensor on rank 0 / None elsewhere, sizes)."""
+    for w in handle["works"]:
+        w.wait()
+    return handle["out"], handle["sizes"]

@@ -34,6 +34,10 @@ def _worker(rank, world, port, q):
     lens = torch.tensor([len(m) for m in mine], dtype=torch.int64)
     blob = torch.frombuffer(bytearray(b"".join(mine) or b"\0"), dtype=torch.uint8)
     got, shard_bytes = shard.gather_ordered(blob, sum(len(m) for m in mine), rank, world)
+    # the asynchronous form used by bench.py (gather of shard k overlapped with the compression of shard k + 1)
+    h = shard.gather_ordered_start(blob, sum(len(m) for m in mine), rank, world)
+    got2, shard_bytes2 = shard.gather_ordered_wait(h)
+    assert shard_bytes2 == shard_bytes and (rank != 0 or bytes(got2.numpy().tobytes()) == bytes(got.numpy().tobytes()))
     all_lens = [torch.zeros(bounds[r][1] - bounds[r][0], dtype=torch.int64) for r in range(world)]
     dist.all_gather(all_lens, lens) if len({b[1] - b[0] for b in bounds}) == 1 else None
     if len({b[1] - b[0] for b in bounds}) != 1:          # ragged shards: gather lengths by object
