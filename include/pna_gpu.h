@@ -120,7 +120,7 @@ int  pna_gpu_create_solid_archive_host(pna_gpu_ctx *ctx, int algo, int level, si
                                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 
 /* Same archive from host memory with a bounded in-flight window: entries stream through two page-locked staging slots
- * (<= ~256 MiB of input each); staging of sub-batch k+1, the H2D copy, the kernels of sub-batch k and the D2H copy of
+ * (<= ~1 GiB of input each); staging of sub-batch k+1, the H2D copy, the kernels of sub-batch k and the D2H copy of
  * sub-batch k-1 overlap.  The sink receives the signature + AHED, then one piece per sub-batch, then AEND.  Replaces the
  * reference's fan-out that keeps every compressed entry in RAM until the rayon scope ends
  * (cli/src/command/core.rs:496-537, cli/src/command/create.rs:575-635).  pna_create_archive() uses it for non-solid

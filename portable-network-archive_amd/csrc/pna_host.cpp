@@ -657,7 +657,7 @@ extern "C" int pna_gpu_create_solid_archive_host(pna_gpu_ctx *c, int algo, int l
 
 // ---------------------------------------------------------------------------------------------------------
 // Host-memory `pna create` (non-solid), bounded memory: the entries stream through two staging slots of at most
-// ~256 MiB of input each.  While the GPU compresses and frames sub-batch k, helper threads stage sub-batch k+1 into
+// ~1 GiB of input each.  While the GPU compresses and frames sub-batch k, helper threads stage sub-batch k+1 into
 // page-locked memory and its H2D copy runs on a second stream; the archive bytes of sub-batch k-1 travel back on a
 // third stream and are handed to the sink in one piece.  Replaces the reference's "every compressed entry in RAM until
 // the scope ends" (cli/src/command/core.rs:496-537, create.rs:575-635) with a fixed in-flight window.
@@ -690,7 +690,10 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
     std::vector<uint8_t> head, tail; frame_archive_head(head, 0); frame_archive_tail(tail);
     if (sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
     // sub-batches of at most SUB input bytes (an entry larger than that is a sub-batch of its own)
-    const uint64_t SUB = 256ull << 20;
+    // sub-batch size: the entropy kernels have a fixed latency of a few ms per launch (serial chains), so small sub-batches waste
+    // the GPU; 1 GiB keeps the pipeline above the PCIe rate while the in-flight window stays bounded (2 x 1 GiB in, 2 x out)
+    uint64_t SUB = 1024ull << 20;
+    if (const char *e = getenv("PNA_SUB_MIB")) { const long v = atol(e); if (v >= 16 && v <= 16384) SUB = (uint64_t)v << 20; }
     struct Sub { size_t e0, e1; uint64_t in_bytes, out_cap; };
     std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
     for (size_t e = 0; e < n;) {
@@ -706,7 +709,8 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
         sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned threads = std::min(8u, std::max(1u, hw / 2));
+    unsigned threads = std::min(8u, std::max(1u, hw / 2));
+    if (const char *e = getenv("PNA_STAGE_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 64) threads = (unsigned)t; }
     FrameJob fj{names, 0};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
@@ -718,19 +722,35 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
     };
     int rc = PNA_OK;
     std::thread stager; int stager_rc = PNA_OK;
+    // staging of one sub-batch in groups of ~128 MiB; every group's H2D copy is issued right behind it, so the copy engine
+    // works while the next group is still being staged (runs on the stager thread: its own hipSetDevice)
+    const int dev_id = c->device;
+    hipStream_t cp_in = c->cp_in;
+    auto stage_and_copy = [=, &off](const Sub nx, uint8_t *hb, uint8_t *db, hipEvent_t ev) -> int {
+        if (hipSetDevice(dev_id) != hipSuccess) return PNA_E_HIP;
+        size_t g0 = nx.e0;
+        while (g0 < nx.e1) {
+            size_t g1 = g0; uint64_t acc = 0;
+            while (g1 < nx.e1 && acc < (128ull << 20)) acc += src_len[g1++];
+            parallel_stage(hb, src, src_len, off.data(), g0, g1, threads);
+            const uint64_t b0 = off[g0], b1 = g1 < nx.e1 ? off[g1] : nx.in_bytes;
+            if (b1 > b0 && hipMemcpyAsync(db + b0, hb + b0, b1 - b0, hipMemcpyHostToDevice, cp_in) != hipSuccess) return PNA_E_HIP;
+            g0 = g1;
+        }
+        return hipEventRecord(ev, cp_in) == hipSuccess ? PNA_OK : PNA_E_HIP;
+    };
     if (!subs.empty()) {
         rc = ensure_slot(0); if (rc) return rc;
-        parallel_stage((uint8_t *)c->hp_in[0].p, src, src_len, off.data(), subs[0].e0, subs[0].e1, threads);
-        HIPCHK(c, hipMemcpyAsync(c->dp_in[0].p, c->hp_in[0].p, subs[0].in_bytes, hipMemcpyHostToDevice, c->cp_in));
-        HIPCHK(c, hipEventRecord(c->ev_in[0], c->cp_in));
+        if (stage_and_copy(subs[0], (uint8_t *)c->hp_in[0].p, (uint8_t *)c->dp_in[0].p, c->ev_in[0]) != PNA_OK) return fail(c, PNA_E_HIP, "H2D copy failed");
     }
     for (size_t k = 0; k < subs.size() && rc == PNA_OK; k++) {
         const Sub &sb = subs[k]; const int sl = (int)(k & 1);
         if (k + 1 < subs.size()) {                               // stage the next sub-batch while the GPU works on this one
             stager_rc = ensure_slot(k + 1);
             if (stager_rc == PNA_OK) {
-                const Sub nx = subs[k + 1]; uint8_t *hb = (uint8_t *)c->hp_in[sl ^ 1].p;
-                stager = std::thread([=, &off]() { parallel_stage(hb, src, src_len, off.data(), nx.e0, nx.e1, threads); });
+                const Sub nx = subs[k + 1]; uint8_t *hb = (uint8_t *)c->hp_in[sl ^ 1].p, *db = (uint8_t *)c->dp_in[sl ^ 1].p;
+                hipEvent_t evn = c->ev_in[sl ^ 1];
+                stager = std::thread([=, &stager_rc]() { stager_rc = stage_and_copy(nx, hb, db, evn); });
             }
         }
         if (c->dp_out[sl].ensure(sb.out_cap + 64) || c->hp_out[sl].ensure(sb.out_cap + 64)) rc = fail(c, PNA_E_NOMEM, "staging allocation failed");
@@ -744,11 +764,7 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
                 hipEventRecord(c->ev_out[sl], c->cp_out) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
         }
         if (stager.joinable()) stager.join();
-        if (rc == PNA_OK && stager_rc != PNA_OK) rc = stager_rc;
-        if (rc == PNA_OK && k + 1 < subs.size()) {
-            if (hipMemcpyAsync(c->dp_in[sl ^ 1].p, c->hp_in[sl ^ 1].p, subs[k + 1].in_bytes, hipMemcpyHostToDevice, c->cp_in) != hipSuccess ||
-                hipEventRecord(c->ev_in[sl ^ 1], c->cp_in) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
-        }
+        if (rc == PNA_OK && stager_rc != PNA_OK) rc = fail(c, stager_rc, "staging / H2D copy failed");
         if (rc == PNA_OK && k > 0) {                             // archive bytes of the previous sub-batch -> sink
             if (hipEventSynchronize(c->ev_out[sl ^ 1]) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
             else if (out_len[sl ^ 1] && sink(user, c->hp_out[sl ^ 1].p, out_len[sl ^ 1]) != 0) rc = fail(c, PNA_E_SINK, "sink failed");

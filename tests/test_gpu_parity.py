@@ -311,7 +311,7 @@ def test_archive_in_hbm_full_size_crc_property(gpu_ctx, pna, pf):
 
 
 def test_host_pipeline_many_sub_batches(gpu_ctx, pna, pf, codec):
-    """pna_gpu_create_archive_host with > 256 MiB of input: several staging slots in flight, sink pieces in order,
+    """pna_gpu_create_archive_host with several sub-batches: both staging slots in flight, sink pieces in order,
     result identical to the one-shot in-HBM archive of the same entries."""
     import torch
     n, L = 700, 1 << 20
@@ -321,7 +321,11 @@ def test_host_pipeline_many_sub_batches(gpu_ctx, pna, pf, codec):
     ents = [host[i * L:(i + 1) * L].tobytes() for i in range(n)]
     ents[5] = b""; ents[6] = ents[6][:12345]
     names = [f"p/{i:04d}" for i in range(n)]
-    arc = pna.create_archive(gpu_ctx, names, ents)
+    os.environ["PNA_SUB_MIB"] = "128"                      # several sub-batches (the default window is 1 GiB per slot)
+    try:
+        arc = pna.create_archive(gpu_ctx, names, ents)
+    finally:
+        del os.environ["PNA_SUB_MIB"]
     _, items = pf.read_archive(arc)
     assert [it.name for it in items] == names and [it.raw_file_size for it in items] == [len(e) for e in ents]
     for i in (0, 5, 6, 255, 256, 257, 511, 512, 699):
