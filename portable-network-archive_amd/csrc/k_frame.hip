@@ -45,7 +45,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     const FrameDesc d = fd[blockIdx.x];
     for (uint32_t i = tid; i < 1024; i += FR_THREADS) { (&sT[0][0])[i] = (&ct->T[0][0])[i]; (&sZ[0][0])[i] = (&ct->Z[0][0])[i]; }
     for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
-    if (d.pad) return;                                               // record without a data chunk: the prefix is all of it
+    if (d.pad & 1) return;                                           // record without a data chunk: the prefix is all of it
 
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
     const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
@@ -100,7 +100,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         if ((tid & (2 * st - 1)) == 0) part[tid] = gf2_mulmod(ct->sh[j], part[tid]) ^ part[tid + st];
         __syncthreads();
     }
-    if (tid < (with_fend ? 16u : 4u)) {
+    if (tid < ((with_fend && !(d.pad & 2)) ? 16u : 4u)) {                // pad bit 1: another data chunk of the same entry follows, no FEND yet
         const uint32_t crc = ~part[0];
         // crc BE | 00 00 00 00 | "FEND" | crc("FEND") BE
         const uint32_t fe = 0x444E4546u;                              // "FEND" little-endian

@@ -349,7 +349,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         std::vector<uint8_t> tmp;
         size_t bound = 0;
         for (size_t e = e0; e < e1; e++) bound += frame_entry_prefix_bound(fj->names[e]);
-        if (c->h_desc.ensure((e1 - e0) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
+        // (a payload beyond the FDAT limit is cut into several FDAT chunks at segment boundaries: room for one more descriptor and
+        // 8 more prefix bytes per segment)
+        if (c->h_desc.ensure(((e1 - e0) + nseg) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * (size_t)nseg + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing staging");
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
         for (size_t e = e0; e < e1; e++) {
@@ -385,19 +387,37 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 pos += 8 + plen + 4;
             }
             blob_len = 8 * (size_t)nseg;
-        } else
-        for (size_t e = e0; e < e1; e++) {
-            const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
-            const uint64_t plen = seg_off[s1] - seg_off[s0];
-            if (plen >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "entry payload too large for one FDAT chunk");
-            FrameDesc &f = fds[e - e0];
-            const uint32_t pl = f.prefix_len;
-            uint8_t *lenf = &blob[f.prefix_off + pl - 8];          // FDAT chunk length, big-endian
-            lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
-            f.arc_off = pos; f.payload_len = (uint32_t)plen;
-            dst_off[e] = pos;
-            for (uint32_t s = s0; s < s1; s++) segdst[s] = pos + pl + (seg_off[s] - seg_off[s0]);
-            pos += pl + plen + 16;
+        } else {
+            // FlattenWriter cuts an entry's stream into FDAT chunks of at most max_chunk_size (lib/src/util/io.rs:60-77); here the
+            // cut points are segment boundaries and the limit is 1 GiB (PNA_FDAT_MAX_MIB for tests)
+            uint64_t fdat_max = 1024ull << 20;
+            if (const char *ev = getenv("PNA_FDAT_MAX_MIB")) { const long v = atol(ev); if (v >= 1 && v <= 2047) fdat_max = (uint64_t)v << 20; }
+            std::vector<FrameDesc> units; units.reserve(e1 - e0);
+            for (size_t e = e0; e < e1; e++) {
+                const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
+                const FrameDesc f0 = fds[e - e0];                  // prefix of the entry: FHED | fSIZ | first FDAT header
+                dst_off[e] = pos;
+                uint32_t g0 = s0;
+                bool first = true;
+                do {
+                    uint32_t g1 = g0 + 1;
+                    while (g1 < s1 && seg_off[g1 + 1] - seg_off[g0] <= fdat_max) g1++;
+                    const uint64_t plen = seg_off[g1] - seg_off[g0];
+                    if (plen >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "segment group too large for one FDAT chunk");
+                    FrameDesc u;
+                    if (first) u = f0;
+                    else { u.prefix_off = (uint32_t)blob_len; u.prefix_len = 8; memcpy(blob + blob_len + 4, "FDAT", 4); blob_len += 8; }
+                    uint8_t *lenf = &blob[u.prefix_off + u.prefix_len - 8];  // FDAT chunk length, big-endian
+                    lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
+                    u.arc_off = pos; u.payload_len = (uint32_t)plen; u.pad = g1 < s1 ? 2u : 0u;
+                    for (uint32_t sg = g0; sg < g1; sg++) segdst[sg] = pos + u.prefix_len + (seg_off[sg] - seg_off[g0]);
+                    pos += u.prefix_len + plen + 4 + (g1 < s1 ? 0 : 12);
+                    units.push_back(u);
+                    g0 = g1; first = false;
+                } while (g0 < s1);
+            }
+            nunit = units.size();
+            memcpy(fds, units.data(), nunit * sizeof(FrameDesc));
         }
         segdst[nseg] = pos;
         total = pos - out_base;
@@ -489,7 +509,10 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
 
 extern "C" size_t pna_gpu_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len) {
     size_t b = 28 + 12 + 64;                                    // signature + AHED, AEND, alignment slack of the CRC reads
-    for (size_t i = 0; i < n; i++) b += frame_entry_prefix_bound(names ? names[i] : nullptr) + pna_gpu_bound(algo, (size_t)src_len[i]) + 16;
+    for (size_t i = 0; i < n; i++) {
+        const size_t pb = pna_gpu_bound(algo, (size_t)src_len[i]);
+        b += frame_entry_prefix_bound(names ? names[i] : nullptr) + pb + 16 + 12 * (src_len[i] >> 20);    // + one FDAT header / CRC per possible cut
+    }
     return b;
 }
 

@@ -498,3 +498,44 @@ def test_error_codes_at_the_boundary(gpu_ctx, pna, codec):
     assert call(3, 0, 1 << 20) == -7                              # PNA_E_UNSUPPORTED (xz)
     assert b"aligned" in L.pna_gpu_last_error(gpu_ctx._h) or True
     assert gpu_ctx.compress_batch([d])[0] == codec.model_compress(d, _params(codec))
+
+
+def test_large_payload_is_cut_into_several_fdat_chunks(gpu_ctx, pna, pf, codec):
+    """FlattenWriter semantics (lib/src/util/io.rs:60-77) on the device path: a payload beyond the FDAT limit becomes several
+    FDAT chunks, cut at segment boundaries (limit lowered to 1 MiB here; 1 GiB by default)."""
+    import torch
+    lens = [(3 << 20) + 4567, 1000, (5 << 20), 0]
+    ents = [codec.corpus_file(2 if i == 2 else 0, 600 + i, n) if n else b"" for i, n in enumerate(lens)]   # entry 2 is incompressible
+    names = [f"big/{i}" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    cap = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    os.environ["PNA_FDAT_MAX_MIB"] = "1"
+    try:
+        total, _ = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap)
+    finally:
+        del os.environ["PNA_FDAT_MAX_MIB"]
+    got = dst[:total].cpu().numpy().tobytes()
+    # expected: frames of the 1 MiB segments, grouped greedily while the group stays within 1 MiB (at least one segment per group)
+    want = pf.write_archive_header()
+    for nm, e in zip(names, ents):
+        segs = [e[i:i + (1 << 20)] for i in range(0, len(e), 1 << 20)] or [b""]
+        frames = gpu_ctx.compress_batch(segs)
+        pieces, cur = [], b""
+        for fr in frames:
+            if cur and len(cur) + len(fr) > (1 << 20):
+                pieces.append(cur); cur = b""
+            cur += fr
+        pieces.append(cur)
+        want += pf.write_normal_entry(pf.file_entry_header(2, nm), pieces, len(e))
+    want += pf.finalize_archive()
+    assert got == want
+    _, items = pf.read_archive(got)
+    assert [codec.decode_payload(2, it.data, len(e) + 64) for it, e in zip(items, ents)] == ents
+    assert sum(1 for t, _ in items[2].chunks if t == b"FDAT") >= 5
