@@ -103,5 +103,5 @@ def main(extra_flags=0):
 
 if __name__ == "__main__":
     rc = main(0)
-    rc += main(0x200)   # same cases through the serial fallback of k_lz
+    rc += main(0x200)   # same cases with the serial form of k_lz's end scan forced
     sys.exit(1 if rc else 0)

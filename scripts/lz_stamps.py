@@ -14,5 +14,5 @@ for it in range(2):
     ctx.compress_batch_device(src.data_ptr(), [i * L for i in range(n + 1)], [L] * n, dst.data_ptr(), dst.numel())
     st = ctx.lz_stamps(); tm = ctx.timing()
     tot = sum(st)
-    names = ["load", "lookup->B2", "insert+match", "wait B3 (+publish)", "wait B4", "resolve+masks (own work)", "emit", "spec loops+coverage (own work)"]
+    names = ["load", "lookup->B2", "insert+match", "wait B3 (+publish)", "wait B4", "merge+masks (own work)", "emit", "parse loops+coverage (own work)"]
     print("lz ms", round(tm.ms_lz, 3), "cycles/tile/WG", round(tot / (n * 512)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})

@@ -68,7 +68,7 @@ def test_batch_bit_exact_and_decodable(gpu_ctx, codec):
         assert len(o) <= gpu_ctx._L.pna_gpu_bound(2, len(d)), k
 
 
-def test_serial_fallback_path_is_identical(pna, codec):
+def test_serial_end_scan_is_identical(pna, codec):
     """Flag 0x200 forces the serial form of k_lz's end scan (the merge of the waves' parses) on every tile; results must not change."""
     import torch  # noqa: F401
     cases = _cases(codec)
