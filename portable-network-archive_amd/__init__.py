@@ -206,17 +206,22 @@ class Context:
         n = len(entries)
         if n == 0:
             return []
-        srcs = [ctypes.create_string_buffer(bytes(e), max(len(e), 1)) for e in entries]
-        caps = [self._L.pna_gpu_bound(algo, len(e)) for e in entries]
-        dsts = [ctypes.create_string_buffer(c) for c in caps]
+        srcs = [e if isinstance(e, bytes) else bytes(e) for e in entries]       # passed by pointer, not copied
+        caps = [self._L.pna_gpu_bound(algo, len(e)) for e in srcs]
+        arena = bytearray(sum(caps) + 1)                                        # one output arena, entry i at offs[i]
+        base = ctypes.addressof((ctypes.c_char * len(arena)).from_buffer(arena))
+        offs, pos = [], 0
+        for c in caps:
+            offs.append(pos); pos += c
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
-        a_src = (vp * n)(*[ctypes.cast(b, vp) for b in srcs])
-        a_len = (sz * n)(*[len(e) for e in entries])
-        a_dst = (vp * n)(*[ctypes.cast(b, vp) for b in dsts])
+        a_src = (vp * n)(*[ctypes.cast(ctypes.c_char_p(b), vp) for b in srcs])
+        a_len = (sz * n)(*[len(e) for e in srcs])
+        a_dst = (vp * n)(*[base + o for o in offs])
         a_cap = (sz * n)(*caps)
         a_out = (sz * n)()
         self._check(self._L.pna_gpu_compress_batch(self._h, algo, level, n, a_src, a_len, a_dst, a_cap, a_out))
-        return [dsts[i].raw[:a_out[i]] for i in range(n)]
+        mv = memoryview(arena)
+        return [bytes(mv[offs[i]:offs[i] + a_out[i]]) for i in range(n)]
 
     # ---- batch resident in HBM (raw device pointers; torch tensors via .data_ptr())
     def compress_batch_device(self, d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int, dst_cap: int,

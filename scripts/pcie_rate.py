@@ -49,3 +49,7 @@ for it in range(3):
     rc = Lb.pna_gpu_create_archive_host(ctx._h, pna.ALGO_ZSTD, pna.LEVEL_DEFAULT, m, a_names, a_src, a_len, cb, None)
     t1 = time.perf_counter()
     print(f"(c) pna_gpu_create_archive_host, {m} x 1 MiB pageable host entries, counting sink: rc {rc}  {1e3*(t1-t0):.1f} ms = {m*L/(t1-t0)/2**20:.0f} MiB/s  (archive {count[0]} B)", flush=True)
+# (d) the batch API of the seam (pna_gpu_compress_batch): host buffers in, host buffers out
+outs = ctx.compress_batch(ents[:2048])
+t0 = time.perf_counter(); outs = ctx.compress_batch(ents[:2048]); t1 = time.perf_counter()
+print(f"(d) pna_gpu_compress_batch, {len(ents[:2048])} x 1 MiB host entries -> host buffers (incl. the Python wrapper's copies): {1e3*(t1-t0):.1f} ms = {len(ents[:2048])*L/(t1-t0)/2**20:.0f} MiB/s", flush=True)
