@@ -104,6 +104,7 @@ def main() -> None:
     ap.add_argument("--framing", choices=["archive", "none", "solid"], default="archive",
                     help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only; "
                          "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive (zstd, archive framing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
     args = ap.parse_args()
@@ -200,6 +201,26 @@ def main() -> None:
         out_all = int(o.item())
     else:
         out_all = out_total
+    # ---- outside the timed region: decode every entry of this rank's last archive on the device and compare with the inputs
+    verified = None
+    tm_last = ctx.timing()                                   # stage split of the last timed step (the check below runs more kernels)
+    if args.framing == "archive" and args.algo == "zstd" and not args.no_verify:
+        dst_last = dsts[cur[0] ^ 1] if world > 1 else dsts[0]
+        part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
+        total, eoff = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst_last.data_ptr(), dst_cap, algo=algo,
+                                                _cache=arg_cache, part=part)
+        fs = max(1, (file_len.bit_length() + 7) // 8) if file_len else 0          # fSIZ payload: minimal big-endian
+        pay_off, pay_len = [], []
+        for i in range(n_files):
+            pre = 12 + 6 + len(names[i].encode()) + 12 + fs + 8
+            nxt = eoff[i + 1]
+            pay_off.append(eoff[i] + pre); pay_len.append(nxt - eoff[i] - pre - 16)
+        back = torch.empty(n_files * stride + 64, dtype=torch.uint8, device=dev)
+        ctx.decompress_batch_device(dst_last.data_ptr(), pay_off, pay_len, back.data_ptr(), src_off[:n_files], src_len)
+        ok = all(bool(torch.equal(back[i * stride:i * stride + file_len], src[i * stride:i * stride + file_len])) for i in range(0, n_files, max(1, n_files // 64))) \
+            and (stride != file_len or bool(torch.equal(back[:n_files * stride], src[:n_files * stride])))
+        verified = bool(ok)
+        del back
     in_rank = n_files * file_len
     in_all = in_rank * world
     if rank == 0:
@@ -208,7 +229,7 @@ def main() -> None:
         lz_avg_s = lz_ms / args.steps / 1e3
         alg_bytes = in_rank + out_total                      # each input byte read once + each output byte written once
         achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
-        tm = ctx.timing()
+        tm = tm_last
         line = {
             "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}, 10k x 1MiB corpus",
             "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -221,6 +242,7 @@ def main() -> None:
                                       else "output = packed compressed entry streams in HBM"),
                        "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
             "ratio": round(in_all / max(out_all, 1), 4),
+            "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing),
