@@ -128,13 +128,16 @@ int  pna_gpu_create_solid_archive_host(pna_gpu_ctx *ctx, int algo, int level, si
 int  pna_gpu_create_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                  const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 
-/* ---- read side (extract / verify): replaces decompress_reader() -> zstd::stream::read::Decoder for Compression::ZStandard
+/* ---- read side (extract / verify): replaces decompress_reader() -> zstd::stream::read::Decoder / flate2::read::ZlibDecoder
  * (lib/src/entry/read.rs:171-190; callers cli/src/command/extract.rs:594-640, verify.rs:140-188).  Entry i's payload (the
- * concatenated FDAT bodies = one or more zstd frames) is decoded to raw_len[i] bytes (the entry's fSIZ).  General RFC 8878
- * frames without dictionary; a multi-frame payload must follow this library's segmentation (every frame but the last holds
- * 1 MiB) because frames carry no content size -- single-frame payloads, which is what the reference writes, always work.
+ * concatenated FDAT bodies) is decoded to raw_len[i] bytes (the entry's fSIZ).
+ *   PNA_ALGO_ZSTD: one or more RFC 8878 frames without dictionary; a multi-frame payload must follow this library's
+ *     segmentation (every frame but the last holds 1 MiB) because frames carry no content size -- single-frame payloads, which
+ *     is what the reference writes, always work.
+ *   PNA_ALGO_DEFLATE: one RFC 1950 zlib stream (any block types, sync-flush markers, window <= 32 KiB); Adler-32 is verified;
+ *     entries below 4 GiB.
  * Errors: PNA_E_INVAL for corrupt / mismatching streams (pna_gpu_last_error names the entry), PNA_E_UNSUPPORTED for
- * dictionaries and for algo != PNA_ALGO_ZSTD. */
+ * dictionaries and other algorithms. */
 int  pna_gpu_decompress_batch(pna_gpu_ctx *ctx, int algo, size_t n, const void *const *src, const size_t *src_len,
                               void *const *dst, const size_t *raw_len);
 int  pna_gpu_decompress_batch_device(pna_gpu_ctx *ctx, int algo, size_t n, const void *d_src, const uint64_t *src_off,

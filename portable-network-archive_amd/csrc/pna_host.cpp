@@ -41,6 +41,9 @@ void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, 
                    void *work, hipStream_t st);
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
+void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
+void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
+                   void *part, hipStream_t st);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
@@ -92,7 +95,7 @@ struct pna_gpu_ctx {
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
     DevBuf z_ents, z_frames, z_lit;                            // decoder descriptors, literal scratch
-    DevBuf z_fx, z_blocks, z_tabs, z_seqs, z_hlist, z_slist, z_work, z_fb;   // lane-parallel decoder workspace
+    DevBuf z_fx, z_blocks, z_tabs, z_seqs, z_hlist, z_slist, z_work, z_fb, z_cbase, z_apart;   // lane-parallel decoder workspace
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[2], hp_out[2];
@@ -155,7 +158,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -846,15 +849,72 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Read side: decompress_reader (lib/src/entry/read.rs:171-190).  zstd only; entries already in device memory.
+// Read side, Compression::Deflate: one zlib stream per entry (flate2::read::ZlibDecoder, lib/src/entry/read.rs:178-179).
+// k_inflate turns each stream into literals + (run, length, distance) records, k_zoff / k_zexec execute them, k_iadler_* check
+// the Adler-32 trailer.
+static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                                const uint64_t *dst_off, const uint64_t *raw_len, hipStream_t st) {
+    if (n > 0x3FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
+    std::vector<ZFrame> frs(n);
+    std::vector<ZFrameX> fxs(n);
+    std::vector<uint32_t> cbase(n + 1);
+    uint64_t nseq_cap = 0, out_span = 0, pieces = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (raw_len[i] > 0xFFFFFFFFull || src_len[i] > 0xFFFFFFFFull) return fail(c, PNA_E_UNSUPPORTED, "entries of 4 GiB and more are not decoded on the device");
+        frs[i] = ZFrame{src_off[i], dst_off[i], (uint32_t)src_len[i], (uint32_t)raw_len[i], 0, 0};
+        ZFrameX &x = fxs[i];
+        x.blk_base = (uint32_t)i; x.blk_cap = 1; x.slot_base = 0; x.slot_cap = 0; x.nblk = 0;
+        x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(raw_len[i] / 3 + (raw_len[i] >> 16) + 16, 0x7FFFFFFFu);   // matches are >= 3 bytes; + literal-run splits
+        nseq_cap += x.seq_cap;
+        out_span = std::max<uint64_t>(out_span, dst_off[i] + raw_len[i]);
+        cbase[i] = (uint32_t)pieces;
+        pieces += (raw_len[i] + 65535) >> 16;
+        if (pieces > 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
+    }
+    cbase[n] = (uint32_t)pieces;
+    if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(n * sizeof(ZBlock)) ||
+        c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8))
+        return fail(c, PNA_E_NOMEM, "decoder workspace");
+    HIPCHK(c, hipMemcpyAsync(c->z_frames.p, frs.data(), n * sizeof(ZFrame), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), n * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->z_cbase.p, cbase.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    launch_inflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
+                   (uint64_t *)c->z_seqs.p, st);
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
+                 (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    launch_iadler((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (const ZBlock *)c->z_blocks.p, (uint32_t)n, (const uint32_t *)c->z_cbase.p,
+                  (uint32_t)pieces, (const uint8_t *)d_dst, c->z_apart.p, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, n * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0, ms_h = 0, ms_x = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&ms_h, c->ev[0], c->ev[2]); (void)hipEventElapsedTime(&ms_x, c->ev[2], c->ev[3]);
+    c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms; c->timing.ms_stats = ms_h; c->timing.ms_lit = ms_x;   // total, Huffman walk, execution
+    for (size_t i = 0; i < n; i++)
+        if (frs[i].status) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "entry %zu: %s (produced %u of %u bytes)", i,
+                     frs[i].status == 2 ? "unsupported stream" : (frs[i].status == 3 ? "size mismatch" : "corrupt stream"), frs[i].out_len, frs[i].dst_len);
+            return fail(c, frs[i].status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
+        }
+    return PNA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Read side: decompress_reader (lib/src/entry/read.rs:171-190); entries already in device memory.
 extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t n, const void *d_src, const uint64_t *src_off,
                                                const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
                                                void *hip_stream) {
     if (!c || (n && (!d_src || !src_off || !src_len || !d_dst || !dst_off || !raw_len))) return fail(c, PNA_E_INVAL, "null argument");
-    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only zstd streams are decoded on the device");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "only zstd and deflate streams are decoded on the device");
     if (!n) return PNA_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (algo == PNA_ALGO_DEFLATE) return inflate_batch_device(c, n, d_src, src_off, src_len, d_dst, dst_off, raw_len, st);
     std::vector<ZEntry> ents(n);
     uint64_t nfr = 0;
     for (size_t i = 0; i < n; i++) {
@@ -945,7 +1005,7 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
 extern "C" int pna_gpu_decompress_batch(pna_gpu_ctx *c, int algo, size_t n, const void *const *src, const size_t *src_len,
                                         void *const *dst, const size_t *raw_len) {
     if (!c || (n && (!src || !src_len || !dst || !raw_len))) return fail(c, PNA_E_INVAL, "null argument");
-    if (algo != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "only zstd streams are decoded on the device");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "only zstd and deflate streams are decoded on the device");
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> so(n), sl(n), dof(n), rl(n);
     uint64_t sp = 0, dp = 0;

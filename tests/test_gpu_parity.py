@@ -539,3 +539,94 @@ def test_large_payload_is_cut_into_several_fdat_chunks(gpu_ctx, pna, pf, codec):
     _, items = pf.read_archive(got)
     assert [codec.decode_payload(2, it.data, len(e) + 64) for it, e in zip(items, ents)] == ents
     assert sum(1 for t, _ in items[2].chunks if t == b"FDAT") >= 5
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Device inflate (k_inflate -> k_zoff / k_zexec -> k_iadler): flate2::read::ZlibDecoder behind decompress_reader
+def _zlib_streams(codec):
+    """(name, raw, zlib stream) made by the system zlib: every block type, long codes, sync flushes, long stored runs."""
+    text = codec.corpus_file(0, 21, 1 << 20)
+    rnd = codec.corpus_file(2, 21, 200000)
+    out = []
+    for lvl in (0, 1, 6, 9):
+        out.append((f"text-l{lvl}", text, zlib.compress(text, lvl)))
+    for name, raw, kw in (("fixed", text[:70000], dict(strategy=zlib.Z_FIXED)), ("huffman-only", text[:70000], dict(strategy=zlib.Z_HUFFMAN_ONLY)),
+                          ("rle", bytes([7]) * 300000 + b"xyz" * 50000, {}), ("random", rnd, {}), ("empty", b"", {}), ("one", b"a", {}),
+                          ("six-bit", bytes(b & 0x3F for b in rnd[:100000]), dict(level=9)), ("wbits9", text[:100000], dict(wbits=9)),
+                          ("png", _raw("raw/images/icon.png"), {}), ("nest", _raw("raw/pna/nest.pna"), {})):
+        co = zlib.compressobj(kw.get("level", 6), zlib.DEFLATED, kw.get("wbits", 15), 9, kw.get("strategy", zlib.Z_DEFAULT_STRATEGY))
+        out.append((name, raw, co.compress(raw) + co.flush()))
+    co = zlib.compressobj(6)
+    z = b"".join(co.compress(text[i:i + 50000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 400000, 50000)) + co.flush()
+    out.append(("sync-flush", text[:400000], z))
+    big = codec.corpus_file(2, 22, 3 << 20)
+    out.append(("stored-3MiB", big, zlib.compress(big, 0)))                  # literal runs beyond one record: split records
+    return out
+
+
+def test_device_inflate_reads_zlib_streams(gpu_ctx, pna, codec):
+    cs = _zlib_streams(codec)
+    back = gpu_ctx.decompress_batch([z for _, _, z in cs], [len(r) for _, r, _ in cs], algo=pna.ALGO_DEFLATE)
+    for (name, raw, _), b in zip(cs, back):
+        assert b == raw, name
+
+
+def test_device_inflate_round_trips_own_encoder(gpu_ctx, pna, codec):
+    cases = _cases(codec)
+    names = list(cases)
+    outs = gpu_ctx.compress_batch([cases[k] for k in names], algo=pna.ALGO_DEFLATE)
+    back = gpu_ctx.decompress_batch(outs, [len(cases[k]) for k in names], algo=pna.ALGO_DEFLATE)
+    for k, b in zip(names, back):
+        assert b == cases[k], k
+
+
+def test_device_inflate_reads_reference_fixtures(gpu_ctx, pna, pf):
+    """zlib streams written by the reference's own encoder (flate2 / miniz_oxide): the FDAT payloads of deflate.pna."""
+    _, items = pf.read_archive(open(os.path.join(GOLDEN, "deflate.pna"), "rb").read())
+    items = [it for it in items if getattr(it, "kind", 1) == 0 and it.compression == 1]
+    assert items
+    raws = [zlib.decompress(it.data) for it in items]
+    for it, r in zip(items, raws):
+        path = os.path.join(GOLDEN, it.name)
+        if os.path.isfile(path):
+            assert open(path, "rb").read() == r, it.name
+    back = gpu_ctx.decompress_batch([it.data for it in items], [len(r) for r in raws], algo=pna.ALGO_DEFLATE)
+    for it, r, b in zip(items, raws, back):
+        assert b == r, it.name
+
+
+def test_device_inflate_rejects_corruption(gpu_ctx, pna, codec):
+    d = codec.corpus_file(0, 78, 300000)
+    good = zlib.compress(d, 6)
+    bad = {
+        "adler": good[:-1] + bytes([good[-1] ^ 1]), "truncated": good[:1000], "header check": b"\x78\x9d" + good[2:],
+        "preset dictionary": b"\x78\xbb" + good[2:], "method": b"\x79\x9c" + good[2:],
+        "stored length": b"\x78\x01\x01\x05\x00\xfa\xfe" + b"hello" + zlib.adler32(b"hello").to_bytes(4, "big"),
+        "reserved block type": b"\x78\x9c\x07" + bytes(8),
+    }
+    for name, z in bad.items():
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx.decompress_batch([z], [len(d) if name != "stored length" else 5], algo=pna.ALGO_DEFLATE)
+    with pytest.raises(pna.PnaGpuError):
+        gpu_ctx.decompress_batch([good], [len(d) - 1], algo=pna.ALGO_DEFLATE)        # size mismatch
+    with pytest.raises(pna.PnaGpuError):
+        gpu_ctx.decompress_batch([good], [len(d) + 1], algo=pna.ALGO_DEFLATE)
+    flipped = bytearray(good); flipped[len(good) // 2] ^= 0x10
+    with pytest.raises(pna.PnaGpuError):
+        gpu_ctx.decompress_batch([bytes(flipped)], [len(d)], algo=pna.ALGO_DEFLATE)   # caught by the structure or by Adler-32
+    assert gpu_ctx.decompress_batch([good], [len(d)], algo=pna.ALGO_DEFLATE)[0] == d  # the context stays usable
+
+
+def test_device_inflate_many_small_entries_in_hbm(gpu_ctx, pna):
+    """65 536 x 4 KiB (the shape of BASELINE config 5): deflate in HBM, inflate in HBM, compare in HBM."""
+    import torch
+    n, L = 65536, 4096
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(1, 0, n, L, L, src.data_ptr())
+    cap = n * pna.bound(pna.ALGO_DEFLATE, L) + 64
+    comp = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    offs = gpu_ctx.compress_batch_device(src.data_ptr(), [i * L for i in range(n + 1)], [L] * n, comp.data_ptr(), cap, algo=pna.ALGO_DEFLATE)
+    back = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(comp.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(),
+                                    [i * L for i in range(n)], [L] * n, algo=pna.ALGO_DEFLATE)
+    assert torch.equal(back[:n * L], src[:n * L])
