@@ -246,3 +246,107 @@ def deflate_model_compress(data: bytes, params: ZstdParams | None = None) -> byt
     if n == 0:
         raise ValueError("deflate model compress failed")
     return buf.raw[:n]
+
+
+# ----------------------------------------------------------------------------- cipher layer (oracle/cipher_model.c)
+
+def aes_block(key: bytes, block: bytes, decrypt: bool = False) -> bytes:
+    out = ctypes.create_string_buffer(16)
+    lib().pna_oracle_aes_block(bytes(key), len(key), bytes(block), out, int(decrypt))
+    return out.raw
+
+
+def aes_ctr(key: bytes, iv: bytes, data: bytes, pos: int = 0, flavor: int = 0) -> bytes:
+    """CTR keystream XOR (encrypt == decrypt); flavor 0 = Ctr128BE (the reference's writer), 1 = Ctr64LE (its unit test)."""
+    buf = ctypes.create_string_buffer(bytes(data), len(data))
+    lib().pna_oracle_aes_ctr(bytes(key), len(key), bytes(iv), flavor, ctypes.c_uint64(pos), buf, ctypes.c_size_t(len(data)))
+    return buf.raw[:len(data)]
+
+
+def aes_cbc_encrypt(key: bytes, iv: bytes, data: bytes) -> bytes:
+    L = lib()
+    L.pna_oracle_aes_cbc_encrypt.restype = ctypes.c_size_t
+    out = ctypes.create_string_buffer((len(data) // 16 + 1) * 16)
+    n = L.pna_oracle_aes_cbc_encrypt(bytes(key), len(key), bytes(iv), bytes(data), ctypes.c_size_t(len(data)), out)
+    return out.raw[:n]
+
+
+def aes_cbc_decrypt(key: bytes, iv: bytes, data: bytes) -> bytes:
+    L = lib()
+    L.pna_oracle_aes_cbc_decrypt.restype = ctypes.c_long
+    out = ctypes.create_string_buffer(max(len(data), 16))
+    n = L.pna_oracle_aes_cbc_decrypt(bytes(key), len(key), bytes(iv), bytes(data), ctypes.c_size_t(len(data)), out)
+    if n < 0:
+        raise ValueError("CBC: bad length or padding")
+    return out.raw[:n]
+
+
+def blake2b(data: bytes, outlen: int = 64) -> bytes:
+    out = ctypes.create_string_buffer(outlen)
+    lib().pna_oracle_blake2b(bytes(data), ctypes.c_size_t(len(data)), out, ctypes.c_size_t(outlen))
+    return out.raw
+
+
+def sha256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    lib().pna_oracle_sha256(bytes(data), ctypes.c_size_t(len(data)), out)
+    return out.raw
+
+
+def pbkdf2_sha256(password: bytes, salt: bytes, rounds: int, outlen: int = 32) -> bytes:
+    out = ctypes.create_string_buffer(outlen)
+    lib().pna_oracle_pbkdf2_sha256(bytes(password), ctypes.c_size_t(len(password)), bytes(salt), ctypes.c_size_t(len(salt)),
+                                   ctypes.c_uint32(rounds), out, ctypes.c_size_t(outlen))
+    return out.raw
+
+
+def argon2(kind: int, password: bytes, salt: bytes, t_cost: int, m_cost: int, lanes: int, outlen: int = 32) -> bytes:
+    """kind: 0 Argon2d, 1 Argon2i, 2 Argon2id (version 0x13)."""
+    out = ctypes.create_string_buffer(outlen)
+    r = lib().pna_oracle_argon2(kind, bytes(password), len(password), bytes(salt), len(salt), t_cost, m_cost, lanes, out, outlen)
+    if r:
+        raise ValueError("argon2 parameters rejected")
+    return out.raw
+
+
+def _b64_nopad(s: str) -> bytes:
+    import base64
+    return base64.b64decode(s + "=" * (-len(s) % 4))
+
+
+def derive_key_from_phsf(phsf: str, password: bytes, key_len: int = 32) -> bytes:
+    """derive_password_hash -- lib/src/hash.rs:47-88: the PHC string (hash part removed, lib/src/entry/write.rs:181-186)
+    names the algorithm, its parameters and the B64 salt; the key is the hash output of key_size() bytes (write.rs:146-151)."""
+    f = phsf.split("$")
+    if len(f) < 4 or f[0] != "":
+        raise ValueError("not a PHC string")
+    alg = f[1]
+    if alg in ("argon2id", "argon2i", "argon2d"):
+        if not f[2].startswith("v="):
+            raise ValueError("argon2 version missing")
+        if int(f[2][2:]) != 19:
+            raise ValueError("argon2 version")
+        prm = dict(kv.split("=") for kv in f[3].split(","))
+        salt = _b64_nopad(f[4])
+        return argon2({"argon2d": 0, "argon2i": 1, "argon2id": 2}[alg], password, salt, int(prm["t"]), int(prm["m"]), int(prm["p"]), key_len)
+    if alg == "pbkdf2-sha256":
+        prm = dict(kv.split("=") for kv in f[2].split(","))
+        salt = _b64_nopad(f[3])
+        return pbkdf2_sha256(password, salt, int(prm["i"]), int(prm.get("l", key_len)))
+    raise ValueError(f"unsupported password hash {alg}")
+
+
+def decrypt_payload(encryption: int, cipher_mode: int, key: bytes, data: bytes) -> bytes:
+    """decrypt_reader -- lib/src/entry/read.rs:59-104: the first 16 bytes of the data stream are the IV (CBC/CTR)."""
+    if encryption == 0:
+        return bytes(data)
+    if encryption != 1:
+        raise ValueError("only AES in the oracle")
+    iv, body = bytes(data[:16]), bytes(data[16:])
+    if len(iv) != 16:
+        raise ValueError("missing IV")
+    if cipher_mode == 1:
+        return aes_ctr(key, iv, body)
+    if cipher_mode == 0:
+        return aes_cbc_decrypt(key, iv, body)
+    raise ValueError("cipher mode not in the oracle")

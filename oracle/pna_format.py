@@ -133,6 +133,24 @@ def write_normal_entry(header: bytes, data_pieces: List[bytes], raw_file_size: O
     return bytes(out)
 
 
+def write_encrypted_file_entry(compression: int, encryption: int, cipher_mode: int, name: str, phsf: str, iv: bytes,
+                               ciphertext: bytes, raw_file_size: Optional[int], max_chunk_size: int = MAX_CHUNK_DATA_LENGTH) -> bytes:
+    """A file entry written with a cipher: FHED (encryption, cipher_mode set), fSIZ, PHSF, FDAT(iv), FDAT(ciphertext)*, FEND.
+    The IV is the data-stream prefix and becomes its own data piece: EntryBuilderCore::build -> prepend_data_prefix splices
+    prefix.chunks(max) in front of the FlattenWriter pieces (lib/src/entry/builder.rs:62-69,171-188; prefix_bytes,
+    lib/src/entry/write.rs:46-51); PHSF sits between the metadata and the data chunks (lib/src/entry.rs:905-910)."""
+    header = entry_header_bytes(KIND_FILE, compression, encryption, cipher_mode, name)
+    out = bytearray(write_chunk(b"FHED", header))
+    if raw_file_size is not None:
+        out += write_chunk(b"fSIZ", fsiz_bytes(raw_file_size))
+    out += write_chunk(b"PHSF", phsf.encode("utf-8"))
+    pieces = [iv[i:i + max_chunk_size] for i in range(0, len(iv), max_chunk_size)] + flatten_writer([ciphertext], max_chunk_size)
+    for d in pieces:
+        out += write_chunk(b"FDAT", d)
+    out += write_chunk(b"FEND")
+    return bytes(out)
+
+
 def write_solid_entry(compression: int, sdat_pieces: List[bytes]) -> bytes:
     """SHED, SDAT*, SEND -- lib/src/archive/write.rs:443-470,716-727; lib/src/entry.rs:465-484."""
     out = bytearray(write_chunk(b"SHED", solid_header_bytes(compression)))
