@@ -106,6 +106,38 @@ int  pna_gpu_create_archive_device(pna_gpu_ctx *ctx, int algo, int level, size_t
                                    void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
                                    void *hip_stream);
 
+/* ---- cipher stage: the reference stacks compress -> cipher -> sink (get_writer, lib/src/entry/write.rs:268-274); the cipher
+ * writers CipherWriter::{CtrAes, CbcAes} (encryption_writer, lib/src/entry/write.rs:189-248: Ctr128BE<Aes256>, CBC + PKCS#7) run
+ * here as kernels over the compressed payload where it already sits in the archive buffer, before the chunk CRC-32.
+ * The key is the password hash the Rust host derives once per WriteOptions (derive_key_material, lib/src/entry/write.rs:64-72;
+ * pna_kdf_pbkdf2_sha256 in pna_archive.h is the C++ host's equivalent); `phsf` is the PHC string that goes into each entry's PHSF
+ * chunk.  Every entry gets its own IV (random::random_vec in to_hashed, lib/src/entry/write.rs:108-121): ivs[16 * i ..) for
+ * entry i, or NULL to draw them from the OS.  Entry record: FHED(encryption, cipher_mode) | fSIZ | PHSF | FDAT(iv) |
+ * FDAT(ciphertext) | FEND (lib/src/entry.rs:895-911; the IV is its own data piece: prepend_data_prefix, lib/src/entry/builder.rs:62-69). */
+#define PNA_ENC_NONE      0     /* == Encryption::to_byte(), lib/src/entry/options.rs */
+#define PNA_ENC_AES       1
+#define PNA_ENC_CAMELLIA  2     /* not offered: PNA_E_UNSUPPORTED */
+#define PNA_MODE_CBC      0     /* == CipherMode::to_byte() */
+#define PNA_MODE_CTR      1
+typedef struct {
+    int encryption;             /* PNA_ENC_* */
+    int cipher_mode;            /* PNA_MODE_* */
+    uint8_t key[32];            /* AES-256 key */
+    const char *phsf;           /* body of the PHSF chunk */
+    const uint8_t *ivs;         /* n x 16 bytes (host), or NULL */
+} pna_gpu_cipher;
+size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher);
+/* pna_gpu_create_archive_part_device with a cipher (cipher == NULL or encryption == PNA_ENC_NONE: identical to it). */
+int  pna_gpu_create_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                       const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                       const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *entry_off,
+                                       uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
+/* The cipher alone, in place, over n byte ranges of a device buffer: range i = d_buf[off[i] .. off[i] + len[i]) is one cipher
+ * stream with IV ivs[16 * i ..).  CTR: encrypt == decrypt (DecryptReader::CtrAes, lib/src/entry/read.rs:83-88).  CBC: encryption
+ * only (decrypt != 0 is PNA_E_UNSUPPORTED); the ciphertext is (len / 16 + 1) * 16 bytes long, the caller leaves that room. */
+int  pna_gpu_cipher_apply_device(pna_gpu_ctx *ctx, const pna_gpu_cipher *cipher, int decrypt, size_t n, void *d_buf,
+                                 const uint64_t *off, const uint64_t *len, void *hip_stream);
+
 /* `pna create --solid` assembled in HBM: the inner entries are serialised as STORE records (FHED | fSIZ | FDAT | FEND, their
  * CRC-32 on the device) into one stream, the stream is compressed as ONE entry and every segment's output becomes one SDAT
  * chunk between SHED and SEND (create_archive_file's solid branch, cli/src/command/create.rs:594-598,603-617;
@@ -163,6 +195,7 @@ typedef struct {
     double   ms_lz, ms_stats, ms_lit, ms_seq, ms_pack;   /* HIP-event time of each stage of the last batch     */
     uint64_t in_bytes, out_bytes, n_segments, n_blocks;
     double   ms_frame;                                   /* k_frame (pna_gpu_create_archive_device only)       */
+    double   ms_cipher;                                  /* k_aes_* (archives written with a cipher)           */
 } pna_gpu_timing;
 int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
 

@@ -45,7 +45,40 @@ class Timing(ctypes.Structure):
     _fields_ = [("ms_lz", ctypes.c_double), ("ms_stats", ctypes.c_double), ("ms_lit", ctypes.c_double),
                 ("ms_seq", ctypes.c_double), ("ms_pack", ctypes.c_double), ("in_bytes", ctypes.c_uint64),
                 ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64),
-                ("ms_frame", ctypes.c_double)]
+                ("ms_frame", ctypes.c_double), ("ms_cipher", ctypes.c_double)]
+
+
+ENC_NONE, ENC_AES, ENC_CAMELLIA = 0, 1, 2          # Encryption::to_byte()
+MODE_CBC, MODE_CTR = 0, 1                          # CipherMode::to_byte()
+
+
+class CipherStruct(ctypes.Structure):
+    """pna_gpu_cipher (include/pna_gpu.h)."""
+    _fields_ = [("encryption", ctypes.c_int), ("cipher_mode", ctypes.c_int), ("key", ctypes.c_uint8 * 32),
+                ("phsf", ctypes.c_char_p), ("ivs", ctypes.c_void_p)]
+
+
+class Cipher:
+    """What WriteCipher carries (lib/src/entry/write.rs:54-57): algorithm, mode, the derived key, the PHSF string; plus the
+    per-entry IVs (None = drawn by the library like random::random_vec)."""
+
+    def __init__(self, key: bytes, phsf: str, mode: int = MODE_CTR, encryption: int = ENC_AES, ivs: Optional[bytes] = None):
+        assert len(key) == 32
+        self.key, self.phsf, self.mode, self.encryption, self.ivs = bytes(key), phsf, mode, encryption, ivs
+        self._keep = None
+
+    def struct(self, n: int) -> CipherStruct:
+        c = CipherStruct()
+        c.encryption, c.cipher_mode = self.encryption, self.mode
+        c.key = (ctypes.c_uint8 * 32)(*self.key)
+        c.phsf = self.phsf.encode()
+        if self.ivs is not None:
+            assert len(self.ivs) >= 16 * n
+            self._keep = ctypes.create_string_buffer(bytes(self.ivs), max(len(self.ivs), 1))
+            c.ivs = ctypes.cast(self._keep, ctypes.c_void_p)
+        else:
+            c.ivs = None
+        return c
 
 
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -60,6 +93,7 @@ EXPORTS = [
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
+    "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -105,6 +139,13 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_part_device.restype = ctypes.c_int
     L.pna_gpu_create_archive_part_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                      vp, sz, u64p, u64p, u32, vp]
+    L.pna_gpu_archive_enc_bound.restype = sz
+    L.pna_gpu_archive_enc_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p, ctypes.POINTER(CipherStruct)]
+    L.pna_gpu_create_archive_enc_device.restype = ctypes.c_int
+    L.pna_gpu_create_archive_enc_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
+                                                    ctypes.POINTER(CipherStruct), vp, sz, u64p, u64p, u32, vp]
+    L.pna_gpu_cipher_apply_device.restype = ctypes.c_int
+    L.pna_gpu_cipher_apply_device.argtypes = [vp, ctypes.POINTER(CipherStruct), ctypes.c_int, sz, vp, u64p, u64p, vp]
     L.pna_gpu_decompress_batch.restype = ctypes.c_int
     L.pna_gpu_decompress_batch.argtypes = [vp, ctypes.c_int, sz, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
     L.pna_gpu_decompress_batch_device.restype = ctypes.c_int
@@ -237,9 +278,10 @@ class Context:
 
     def create_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                               dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
-                              _cache: Optional[dict] = None, part: int = PART_HEAD | PART_TAIL):
-        """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_part_device; `part` selects whether this shard
-        carries the archive header / AEND).  Returns (archive_len, entry_off)."""
+                              _cache: Optional[dict] = None, part: int = PART_HEAD | PART_TAIL, cipher: Optional[Cipher] = None):
+        """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_enc_device; `part` selects whether this shard
+        carries the archive header / AEND; `cipher` adds the AES stage between compression and chunk CRC).
+        Returns (archive_len, entry_off)."""
         n = len(src_len)
         if _cache is not None and "a" in _cache:
             a_names, a_off, a_len = _cache["a"]
@@ -251,10 +293,21 @@ class Context:
                 _cache["a"] = (a_names, a_off, a_len)
         a_out = (ctypes.c_uint64 * (n + 1))()
         total = ctypes.c_uint64()
-        self._check(self._L.pna_gpu_create_archive_part_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
-                                                               ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total), part,
-                                                               ctypes.c_void_p(stream) if stream else None))
+        cs = cipher.struct(n) if cipher is not None else None
+        self._check(self._L.pna_gpu_create_archive_enc_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
+                                                              ctypes.byref(cs) if cs is not None else None,
+                                                              ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total), part,
+                                                              ctypes.c_void_p(stream) if stream else None))
         return total.value, list(a_out)
+
+    def cipher_apply_device(self, cipher: Cipher, d_buf: int, off: Sequence[int], length: Sequence[int], decrypt: bool = False,
+                            stream: int = 0) -> None:
+        """The cipher stage alone, in place, over byte ranges of a device buffer (range i uses cipher.ivs[16 i ..))."""
+        n = len(length)
+        cs = cipher.struct(n)
+        mk = lambda xs: (ctypes.c_uint64 * max(n, 1))(*list(xs)[:n])
+        self._check(self._L.pna_gpu_cipher_apply_device(self._h, ctypes.byref(cs), 1 if decrypt else 0, n, ctypes.c_void_p(d_buf),
+                                                        mk(off), mk(length), ctypes.c_void_p(stream) if stream else None))
 
     def create_solid_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                                     dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
@@ -424,6 +477,14 @@ def archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> in
     a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
     a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
     return load_library().pna_gpu_archive_bound(algo, n, a_names, a_len)
+
+
+def archive_enc_bound(algo: int, names: Sequence[str], src_len: Sequence[int], cipher: Optional[Cipher]) -> int:
+    n = len(src_len)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+    cs = cipher.struct(0) if cipher is not None and cipher.ivs is None else (cipher.struct(n) if cipher is not None else None)
+    return load_library().pna_gpu_archive_enc_bound(algo, n, a_names, a_len, ctypes.byref(cs) if cs is not None else None)
 
 
 def solid_archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> int:

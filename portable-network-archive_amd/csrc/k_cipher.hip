@@ -1,0 +1,127 @@
+// k_cipher.hip -- the cipher stage between the compressor and the chunk sink, on gfx950: AES-256 in CTR (Ctr128BE) and CBC
+// (PKCS#7) mode over payloads that already sit at their archive offsets in HBM.
+//
+// Replaces CipherWriter::{CtrAes, CbcAes} (lib/src/entry/write.rs:189-248 encryption_writer; lib/src/cipher/stream/write.rs:52-58
+// apply_keystream; lib/src/cipher/block/write.rs:44-57,67-107) in the stack compress -> cipher -> sink (get_writer,
+// lib/src/entry/write.rs:268-274) and, on the read side, DecryptReader::CtrAes / CbcAes (lib/src/entry/read.rs:77-88).
+//
+// Integer/table work, no MFMA.  One 16-byte AES block per lane and step; the four 1 KiB round tables live in LDS, the 15 round
+// keys arrive as kernel arguments (scalar registers).  CTR: block j of a stream is AES(IV + j) with the IV read as one 128-bit
+// big-endian counter; every block is independent, so a stream is cut into units of <= 256 KiB (any byte position: the unit
+// carries its stream offset) and each unit is one workgroup.  CBC encryption chains its blocks, so there the parallelism is
+// across entries only: one lane per entry.
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any byte address (unaligned dwordx4 access)
+
+constexpr uint32_t CI_THREADS = 256;
+
+__device__ __forceinline__ void aes_load_tables(uint32_t (*sT)[256], const AesTabs *__restrict__ tabs, uint32_t tid, uint32_t nthr) {
+    for (uint32_t i = tid; i < 1024; i += nthr) (&sT[0][0])[i] = (&tabs->Te[0][0])[i];
+}
+
+// state words are the columns, little-endian (byte 0 = row 0)
+__device__ __forceinline__ void aes256_encrypt(const uint32_t (*sT)[256], const AesKey &k, uint32_t &s0, uint32_t &s1, uint32_t &s2, uint32_t &s3) {
+    s0 ^= k.rk[0]; s1 ^= k.rk[1]; s2 ^= k.rk[2]; s3 ^= k.rk[3];
+#pragma unroll
+    for (int r = 1; r < 14; r++) {
+        const uint32_t t0 = sT[0][s0 & 0xFF] ^ sT[1][(s1 >> 8) & 0xFF] ^ sT[2][(s2 >> 16) & 0xFF] ^ sT[3][s3 >> 24] ^ k.rk[4 * r];
+        const uint32_t t1 = sT[0][s1 & 0xFF] ^ sT[1][(s2 >> 8) & 0xFF] ^ sT[2][(s3 >> 16) & 0xFF] ^ sT[3][s0 >> 24] ^ k.rk[4 * r + 1];
+        const uint32_t t2 = sT[0][s2 & 0xFF] ^ sT[1][(s3 >> 8) & 0xFF] ^ sT[2][(s0 >> 16) & 0xFF] ^ sT[3][s1 >> 24] ^ k.rk[4 * r + 2];
+        const uint32_t t3 = sT[0][s3 & 0xFF] ^ sT[1][(s0 >> 8) & 0xFF] ^ sT[2][(s1 >> 16) & 0xFF] ^ sT[3][s2 >> 24] ^ k.rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    // last round: SubBytes + ShiftRows only; S[x] is byte 1 of Te0[x]
+#define SBX(v) ((sT[0][(v) & 0xFF] >> 8) & 0xFF)
+    const uint32_t u0 = SBX(s0) | (SBX(s1 >> 8) << 8) | (SBX(s2 >> 16) << 16) | (SBX(s3 >> 24) << 24);
+    const uint32_t u1 = SBX(s1) | (SBX(s2 >> 8) << 8) | (SBX(s3 >> 16) << 16) | (SBX(s0 >> 24) << 24);
+    const uint32_t u2 = SBX(s2) | (SBX(s3 >> 8) << 8) | (SBX(s0 >> 16) << 16) | (SBX(s1 >> 24) << 24);
+    const uint32_t u3 = SBX(s3) | (SBX(s0 >> 8) << 8) | (SBX(s1 >> 16) << 16) | (SBX(s2 >> 24) << 24);
+#undef SBX
+    s0 = u0 ^ k.rk[56]; s1 = u1 ^ k.rk[57]; s2 = u2 ^ k.rk[58]; s3 = u3 ^ k.rk[59];
+}
+
+// ------------------------------------------------------------------ CTR (Ctr128BE), in place; encrypt == decrypt
+// Unit u covers buf[off .. off + len) = stream bytes [pos, pos + len) of the stream whose IV is ivs[iv_idx].
+__global__ __launch_bounds__(CI_THREADS)
+void k_aes_ctr(const CipherUnit *__restrict__ units, const uint8_t *__restrict__ ivs, const AesTabs *__restrict__ tabs,
+               uint8_t *__restrict__ buf, const AesKey key) {
+    __shared__ uint32_t sT[4][256];
+    const uint32_t tid = threadIdx.x;
+    aes_load_tables(sT, tabs, tid, CI_THREADS);
+    const CipherUnit u = units[blockIdx.x];
+    const uint8_t *ivp = ivs + (size_t)u.iv_idx * 16;
+    // the IV as a 128-bit big-endian number: hi = bytes 0..7, lo = bytes 8..15
+    uint64_t iv_hi = 0, iv_lo = 0;
+    for (int b = 0; b < 8; b++) { iv_hi = (iv_hi << 8) | ivp[b]; iv_lo = (iv_lo << 8) | ivp[8 + b]; }
+    __syncthreads();
+    const uint64_t b0 = u.pos >> 4;                                   // first keystream block of the unit
+    const uint64_t end = u.pos + u.len;
+    const uint32_t nblk = (uint32_t)(((end + 15) >> 4) - b0);
+    const int64_t base = (int64_t)u.off - (int64_t)(u.pos & 15);      // buf offset of keystream block b0's byte 0
+    for (uint32_t j = tid; j < nblk; j += CI_THREADS) {
+        const uint64_t ctr = b0 + j;
+        const uint64_t lo = iv_lo + ctr, hi = iv_hi + (lo < iv_lo ? 1u : 0u);
+        uint32_t s0 = __builtin_bswap32((uint32_t)(hi >> 32)), s1 = __builtin_bswap32((uint32_t)hi);
+        uint32_t s2 = __builtin_bswap32((uint32_t)(lo >> 32)), s3 = __builtin_bswap32((uint32_t)lo);
+        aes256_encrypt(sT, key, s0, s1, s2, s3);
+        const int64_t a = base + (int64_t)j * 16;
+        const uint64_t sp = (b0 + j) << 4;                            // stream position of this block
+        if (sp >= u.pos && sp + 16 <= end) {
+            U4u *q = (U4u *)(buf + a);
+            U4u v = *q;
+            v.x ^= s0; v.y ^= s1; v.z ^= s2; v.w ^= s3;
+            *q = v;
+        } else {                                                      // first / last block of the unit: only the bytes inside it
+            const uint32_t ks[4] = {s0, s1, s2, s3};
+            for (uint32_t b = 0; b < 16; b++) {
+                const uint64_t p = sp + b;
+                if (p >= u.pos && p < end) buf[a + b] ^= (uint8_t)(ks[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ CBC encryption with PKCS#7 padding, in place, one lane per entry
+// Entry e: plaintext buf[off .. off + len) becomes (len / 16 + 1) * 16 bytes of ciphertext at the same offset (the layout
+// leaves room for the padding block).
+__global__ __launch_bounds__(64)
+void k_aes_cbc_enc(const CipherUnit *__restrict__ units, uint32_t n, const uint8_t *__restrict__ ivs, const AesTabs *__restrict__ tabs,
+                   uint8_t *__restrict__ buf, const AesKey key) {
+    __shared__ uint32_t sT[4][256];
+    aes_load_tables(sT, tabs, threadIdx.x, 64);
+    __syncthreads();
+    const uint32_t e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n) return;
+    const CipherUnit u = units[e];
+    const U4u iv = *(const U4u *)(ivs + (size_t)u.iv_idx * 16);
+    uint32_t c0 = iv.x, c1 = iv.y, c2 = iv.z, c3 = iv.w;
+    const uint32_t nb = u.len / 16 + 1;
+    uint8_t *p = buf + u.off;
+    for (uint32_t b = 0; b < nb; b++) {
+        uint32_t x0, x1, x2, x3;
+        if (b + 1 < nb) { const U4u v = *(const U4u *)(p + 16 * (size_t)b); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
+        else {
+            const uint32_t have = u.len - 16 * b, padv = 16 - have;
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k2 = 0; k2 < 16; k2++) { const uint32_t byte = k2 < have ? p[16 * (size_t)b + k2] : padv; w[k2 >> 2] |= byte << (8 * (k2 & 3)); }
+            x0 = w[0]; x1 = w[1]; x2 = w[2]; x3 = w[3];
+        }
+        c0 ^= x0; c1 ^= x1; c2 ^= x2; c3 ^= x3;
+        aes256_encrypt(sT, key, c0, c1, c2, c3);
+        U4u o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+        *(U4u *)(p + 16 * (size_t)b) = o;
+    }
+}
+
+void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_aes_ctr, dim3(n), dim3(CI_THREADS), 0, st, units, ivs, tabs, buf, key);
+}
+void launch_aes_cbc_enc(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_aes_cbc_enc, dim3((n + 63) / 64), dim3(64), 0, st, units, n, ivs, tabs, buf, key);
+}
+
+} // namespace pna

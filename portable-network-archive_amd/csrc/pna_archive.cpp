@@ -103,6 +103,20 @@ void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compressi
     uint8_t head[8]; put_be32(head, payload_len); memcpy(head + 4, "FDAT", 4);
     o.insert(o.end(), head, head + 8);
 }
+// The same for an entry written with a cipher: FHED(encryption, cipher_mode) | fSIZ | PHSF | FDAT(iv) | FDAT length + type.  The IV is
+// the data-stream prefix and becomes a data piece of its own (prepend_data_prefix, lib/src/entry/builder.rs:62-69,171-188); PHSF
+// stands between the metadata and the data chunks (lib/src/entry.rs:905-910).
+void frame_entry_prefix_enc(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, int encryption, int cipher_mode,
+                            const char *phsf, const uint8_t iv[16]) {
+    std::vector<uint8_t> h = fhed(0, compression, encryption, cipher_mode, sanitize(name));
+    put_chunk(o, "FHED", h.data(), h.size());
+    uint8_t b[16]; size_t n = fsiz(raw_size, b); put_chunk(o, "fSIZ", b, n);
+    put_chunk(o, "PHSF", (const uint8_t *)phsf, strlen(phsf));
+    put_chunk(o, "FDAT", iv, 16);
+    uint8_t head[8]; put_be32(head, 0); memcpy(head + 4, "FDAT", 4);
+    o.insert(o.end(), head, head + 8);
+}
+size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 12 + strlen(phsf) + 28 + 8; }
 // an inner entry of a solid archive without data: FHED | fSIZ | FEND, no FDAT (FlattenWriter ignores empty writes)
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name) {
     std::vector<uint8_t> h = fhed(0, 0, 0, 1, sanitize(name));

@@ -92,6 +92,16 @@ struct CrcTabs {
     uint32_t sh[8];          // x^(8 * 64 * 2^j) mod P, j = 0..7
 };
 
+// cipher stage (k_cipher.hip)
+struct AesTabs { uint32_t Te[4][256]; };   // Te[0][x] = bytes (2S, S, S, 3S) of S = sbox[x], little-endian; Te[k] = Te[0] rotated left by 8k bits
+struct AesKey  { uint32_t rk[60]; };       // AES-256 round keys, word 4r + c = column c of round r, little-endian
+struct CipherUnit {
+    uint64_t off;            // first byte of the unit in the buffer
+    uint64_t pos;            // CTR: its byte position in the entry's cipher stream (keystream block = pos / 16)
+    uint32_t len;            // bytes (CBC: plaintext bytes of the whole entry)
+    uint32_t iv_idx;         // which 16-byte IV of the IV array belongs to it
+};
+
 // zstd decoder (k_zdec): one descriptor per frame
 struct ZFrame {
     uint64_t src_off;        // frame start in the compressed buffer

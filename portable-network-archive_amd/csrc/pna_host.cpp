@@ -11,6 +11,7 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <sys/random.h>
 #include "pna_dev.h"
 #include "../../include/pna_gpu.h"
 
@@ -54,6 +55,11 @@ void frame_archive_tail(std::vector<uint8_t> &o);
 void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len);
 size_t frame_entry_prefix_bound(const char *name);
 uint32_t frame_fend_crc();
+void frame_entry_prefix_enc(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, int encryption, int cipher_mode,
+                            const char *phsf, const uint8_t iv[16]);
+size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf);
+void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st);
+void launch_aes_cbc_enc(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st);
 void launch_corpus(int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len, uint64_t stride,
                    const uint8_t *vocab, const uint64_t *cum, const uint32_t *phrases, uint8_t *dst, hipStream_t st);
 }
@@ -93,6 +99,9 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
+    DevBuf aes_tabs, ci_units, ci_ivs;                         // cipher stage: round tables, unit descriptors, IVs
+    bool aes_ready = false;
+    hipEvent_t ev_ci[2] = {};
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
     DevBuf z_ents, z_frames, z_lit;                            // decoder descriptors, literal scratch
     DevBuf z_fx, z_blocks, z_tabs, z_seqs, z_hlist, z_slist, z_work, z_fb, z_cbase, z_apart;   // lane-parallel decoder workspace
@@ -158,11 +167,12 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     for (auto &e : c->ev_lz) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_ci) if (e) (void)hipEventDestroy(e);
     for (auto &r : c->ev_en) for (auto &e : r) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -260,7 +270,57 @@ extern "C" uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len) 
     return ~lane[0];
 }
 
-struct FrameJob { const char *const *names; int solid; };    // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry
+// ---- cipher stage: AES-256 key schedule and round tables (FIPS-197), built on the host once per context / per call
+static void aes_sbox(uint8_t sb[256]) {
+    uint8_t p = 1, q = 1;                                      // p walks the multiplicative group of GF(2^8), q is its inverse
+    do {
+        p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1B : 0));
+        q ^= (uint8_t)(q << 1); q ^= (uint8_t)(q << 2); q ^= (uint8_t)(q << 4); if (q & 0x80) q ^= 0x09;
+        const uint8_t r1 = (uint8_t)((q << 1) | (q >> 7)), r2 = (uint8_t)((q << 2) | (q >> 6)), r3 = (uint8_t)((q << 3) | (q >> 5)), r4 = (uint8_t)((q << 4) | (q >> 4));
+        sb[p] = (uint8_t)(q ^ r1 ^ r2 ^ r3 ^ r4 ^ 0x63);
+    } while (p != 1);
+    sb[0] = 0x63;
+}
+static void build_aes_tabs(AesTabs &t) {
+    uint8_t sb[256]; aes_sbox(sb);
+    for (uint32_t x = 0; x < 256; x++) {
+        const uint32_t s1 = sb[x], s2 = ((s1 << 1) ^ ((s1 & 0x80) ? 0x1B : 0)) & 0xFF, s3 = s2 ^ s1;
+        const uint32_t w = s2 | (s1 << 8) | (s1 << 16) | (s3 << 24);
+        t.Te[0][x] = w; t.Te[1][x] = (w << 8) | (w >> 24); t.Te[2][x] = (w << 16) | (w >> 16); t.Te[3][x] = (w << 24) | (w >> 8);
+    }
+}
+static void aes256_expand(const uint8_t key[32], AesKey &k) {
+    uint8_t sb[256]; aes_sbox(sb);
+    uint8_t w[60][4]; uint8_t rc = 1;
+    memcpy(w, key, 32);
+    for (int i = 8; i < 60; i++) {
+        uint8_t t[4]; memcpy(t, w[i - 1], 4);
+        if (i % 8 == 0) { const uint8_t t0 = t[0]; t[0] = (uint8_t)(sb[t[1]] ^ rc); t[1] = sb[t[2]]; t[2] = sb[t[3]]; t[3] = sb[t0]; rc = (uint8_t)((rc << 1) ^ ((rc & 0x80) ? 0x1B : 0)); }
+        else if (i % 8 == 4) for (int j = 0; j < 4; j++) t[j] = sb[t[j]];
+        for (int j = 0; j < 4; j++) w[i][j] = (uint8_t)(w[i - 8][j] ^ t[j]);
+    }
+    for (int i = 0; i < 60; i++) k.rk[i] = (uint32_t)w[i][0] | ((uint32_t)w[i][1] << 8) | ((uint32_t)w[i][2] << 16) | ((uint32_t)w[i][3] << 24);
+}
+static int ensure_aes(pna_gpu_ctx *c) {
+    if (c->aes_ready) return PNA_OK;
+    AesTabs t; build_aes_tabs(t);
+    if (c->aes_tabs.ensure(sizeof(t))) return fail(c, PNA_E_NOMEM, "aes tables");
+    HIPCHK(c, hipMemcpy(c->aes_tabs.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    for (auto &e : c->ev_ci) HIPCHK(c, hipEventCreate(&e));
+    c->aes_ready = true;
+    return PNA_OK;
+}
+static int check_cipher(pna_gpu_ctx *c, const pna_gpu_cipher *ci) {
+    if (ci->encryption == PNA_ENC_CAMELLIA) return fail(c, PNA_E_UNSUPPORTED, "Camellia is not offered on the device path");
+    if (ci->encryption != PNA_ENC_AES) return fail(c, PNA_E_INVAL, "unknown encryption");
+    if (ci->cipher_mode != PNA_MODE_CTR && ci->cipher_mode != PNA_MODE_CBC) return fail(c, PNA_E_UNSUPPORTED, "cipher mode not offered on the device path");
+    return PNA_OK;
+}
+constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR work unit (one workgroup)
+
+// names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry; cipher + ivs (16 bytes per
+// global entry index): the payloads are encrypted in place before their CRC-32 is taken
+struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; };
 
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
@@ -351,7 +411,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     } else if (fj) {
         std::vector<uint8_t> tmp;
         size_t bound = 0;
-        for (size_t e = e0; e < e1; e++) bound += frame_entry_prefix_bound(fj->names[e]);
+        for (size_t e = e0; e < e1; e++) bound += fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e]);
         // (a payload beyond the FDAT limit is cut into several FDAT chunks at segment boundaries: room for one more descriptor and
         // 8 more prefix bytes per segment)
         if (c->h_desc.ensure(((e1 - e0) + nseg) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * (size_t)nseg + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
@@ -359,7 +419,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
         for (size_t e = e0; e < e1; e++) {
             tmp.clear();
-            frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
+            if (fj->cipher) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e);
+            else frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
             memcpy(blob + blob_len, tmp.data(), tmp.size());
             fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
             blob_len += tmp.size();
@@ -371,6 +432,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     HIPCHK(c, hipMemcpyAsync(c->h_segoff.p, c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     uint64_t total = seg_off[nseg];
+    std::vector<CipherUnit> cunits;
     const uint64_t *d_segdst = (const uint64_t *)c->seg_off.p;
     uint8_t *wbase = d_dst + out_base;
     if (fj) {
@@ -396,16 +458,32 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             uint64_t fdat_max = 1024ull << 20;
             if (const char *ev = getenv("PNA_FDAT_MAX_MIB")) { const long v = atol(ev); if (v >= 1 && v <= 2047) fdat_max = (uint64_t)v << 20; }
             std::vector<FrameDesc> units; units.reserve(e1 - e0);
+            const bool cbc = fj->cipher && fj->cipher->cipher_mode == PNA_MODE_CBC;
             for (size_t e = e0; e < e1; e++) {
                 const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
                 const FrameDesc f0 = fds[e - e0];                  // prefix of the entry: FHED | fSIZ | first FDAT header
                 dst_off[e] = pos;
                 uint32_t g0 = s0;
                 bool first = true;
+                uint64_t cpos = 0;                                 // position in the entry's cipher stream
                 do {
                     uint32_t g1 = g0 + 1;
                     while (g1 < s1 && seg_off[g1 + 1] - seg_off[g0] <= fdat_max) g1++;
-                    const uint64_t plen = seg_off[g1] - seg_off[g0];
+                    uint64_t plen = seg_off[g1] - seg_off[g0];
+                    if (fj->cipher) {
+                        // the payload is encrypted where it stands: CTR keeps its length and may be cut anywhere; CBC chains the whole
+                        // entry (one lane) and appends the PKCS#7 padding block
+                        const uint64_t p0 = pos + (first ? f0.prefix_len : 8);
+                        if (cbc) {
+                            if (g1 < s1 || !first) return fail(c, PNA_E_UNSUPPORTED, "CBC entry beyond one FDAT chunk");
+                            cunits.push_back(CipherUnit{p0, 0, (uint32_t)plen, (uint32_t)(e - e0)});
+                            plen = (plen / 16 + 1) * 16;
+                        } else {
+                            for (uint64_t o = 0; o < plen; o += CTR_UNIT)
+                                cunits.push_back(CipherUnit{p0 + o, cpos + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
+                            cpos += plen;
+                        }
+                    }
                     if (plen >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "segment group too large for one FDAT chunk");
                     FrameDesc u;
                     if (first) u = f0;
@@ -439,6 +517,20 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     else launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, st);
+    if (fj && fj->cipher) {
+        if (solid) return fail(c, PNA_E_UNSUPPORTED, "cipher on the solid device path");
+        int rc = ensure_aes(c); if (rc) return rc;
+        if (c->ci_units.ensure(cunits.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure((e1 - e0) * 16 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+        AesKey key; aes256_expand(fj->cipher->key, key);
+        HIPCHK(c, hipMemcpyAsync(c->ci_units.p, cunits.data(), cunits.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, fj->ivs + 16 * e0, (e1 - e0) * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->ev_ci[0], st));
+        if (fj->cipher->cipher_mode == PNA_MODE_CTR)
+            launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, st);
+        else
+            launch_aes_cbc_enc((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, st);
+        HIPCHK(c, hipEventRecord(c->ev_ci[1], st));
+    }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
     if (fj) launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)nunit, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
                          d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), solid ? "SDAT" : "FDAT", !solid, st);
@@ -453,6 +545,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         float ms[6] = {0, 0, 0, 0, 0, 0}, msf = 0;
         (void)hipEventElapsedTime(&msf, c->ev[6], c->ev[7]);
         c->timing.ms_frame += msf;
+        float mc = 0;                                             // the cipher kernels run inside the "pack" interval: report them apart
+        if (fj && fj->cipher) { (void)hipEventElapsedTime(&mc, c->ev_ci[0], c->ev_ci[1]); c->timing.ms_cipher += mc; c->timing.ms_pack -= mc; }
         if (defl) {
             (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
             (void)hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
@@ -535,9 +629,42 @@ extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int 
                                                   const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                                   void *d_dst, size_t dst_cap, uint64_t *entry_off, uint64_t *archive_len,
                                                   uint32_t part_flags, void *hip_stream) {
+    return pna_gpu_create_archive_enc_device(c, algo, level, n, names, d_src, src_off, src_len, nullptr, d_dst, dst_cap, entry_off, archive_len,
+                                             part_flags, hip_stream);
+}
+
+extern "C" size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher) {
+    size_t b = pna_gpu_archive_bound(algo, n, names, src_len);
+    if (cipher && cipher->encryption != PNA_ENC_NONE && cipher->phsf) b += n * (12 + strlen(cipher->phsf) + 28 + 16);   // PHSF, FDAT(iv), CBC padding
+    return b;
+}
+
+// The same with the cipher stage between the write kernels and the chunk CRC (get_writer: compress -> cipher -> sink,
+// lib/src/entry/write.rs:268-274): entry record FHED | fSIZ | PHSF | FDAT(iv) | FDAT(ciphertext) | FEND.
+extern "C" int pna_gpu_create_archive_enc_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                 const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                 const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *entry_off,
+                                                 uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
+    if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
+    std::vector<uint8_t> own_ivs;
+    const uint8_t *ivs = nullptr;
+    if (cipher) {
+        int rc = check_cipher(c, cipher); if (rc) return rc;
+        if (!cipher->phsf) return fail(c, PNA_E_INVAL, "cipher without a PHSF string");
+        ivs = cipher->ivs;
+        if (!ivs) {                                          // random::random_vec(block_size) per entry, lib/src/entry/write.rs:108-112
+            own_ivs.resize(n * 16 + 16);
+            for (size_t o = 0; o < n * 16;) {
+                const ssize_t got = getrandom(own_ivs.data() + o, std::min<size_t>(n * 16 - o, 1u << 20), 0);
+                if (got <= 0) return fail(c, PNA_E_INVAL, "getrandom failed");
+                o += (size_t)got;
+            }
+            ivs = own_ivs.data();
+        }
+    }
     (void)level;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -549,7 +676,7 @@ extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int 
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    FrameJob fj{names, 0};
+    FrameJob fj{names, 0, cipher, ivs};
     size_t e = 0;
     while (e < n) {
         size_t e1 = e, blocks = 0;
@@ -570,6 +697,40 @@ extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int 
     if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
     *archive_len = pos;
     c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
+    return PNA_OK;
+}
+
+// The cipher stage alone over byte ranges of a device buffer (read side: DecryptReader::CtrAes, lib/src/entry/read.rs:83-88).
+extern "C" int pna_gpu_cipher_apply_device(pna_gpu_ctx *c, const pna_gpu_cipher *cipher, int decrypt, size_t n, void *d_buf,
+                                           const uint64_t *off, const uint64_t *len, void *hip_stream) {
+    if (!c || !cipher || (n && (!d_buf || !off || !len || !cipher->ivs))) return fail(c, PNA_E_INVAL, "null argument");
+    int rc = check_cipher(c, cipher); if (rc) return rc;
+    const bool cbc = cipher->cipher_mode == PNA_MODE_CBC;
+    if (cbc && decrypt) return fail(c, PNA_E_UNSUPPORTED, "CBC decryption is not offered on the device path");
+    if (n == 0) return PNA_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    rc = ensure_aes(c); if (rc) return rc;
+    std::vector<CipherUnit> units;
+    for (size_t i = 0; i < n; i++) {
+        if (len[i] >= 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "cipher range too long");
+        if (cbc) units.push_back(CipherUnit{off[i], 0, (uint32_t)len[i], (uint32_t)i});
+        else for (uint64_t o = 0; o < len[i]; o += CTR_UNIT) units.push_back(CipherUnit{off[i] + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, len[i] - o), (uint32_t)i});
+    }
+    if (c->ci_units.ensure(units.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure(n * 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+    AesKey key; aes256_expand(cipher->key, key);
+    c->timing = pna_gpu_timing{};
+    HIPCHK(c, hipMemcpyAsync(c->ci_units.p, units.data(), units.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, cipher->ivs, n * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_ci[0], st));
+    if (cbc) launch_aes_cbc_enc((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)d_buf, key, st);
+    else launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)d_buf, key, st);
+    HIPCHK(c, hipEventRecord(c->ev_ci[1], st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    float mc = 0; (void)hipEventElapsedTime(&mc, c->ev_ci[0], c->ev_ci[1]);
+    c->timing.ms_cipher = mc;
+    for (size_t i = 0; i < n; i++) c->timing.in_bytes += len[i];
     return PNA_OK;
 }
 

@@ -1,0 +1,163 @@
+"""The cipher stage on the device (k_cipher.hip) against the oracle's cipher layer (oracle/cipher_model.c), through the C ABI.
+Integer work: bit-exact."""
+import hashlib
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes(range(32))
+PHSF = "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0"
+
+
+def test_fips197_block_on_device(gpu_ctx, pna):
+    """CTR over 16 zero bytes with IV = the FIPS-197 C.3 plaintext yields AES-256(key, IV): the appendix ciphertext."""
+    import torch
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ci = pna.Cipher(KEY, PHSF, pna.MODE_CTR, ivs=bytes.fromhex("00112233445566778899aabbccddeeff"))
+    gpu_ctx.cipher_apply_device(ci, buf.data_ptr(), [0], [16])
+    out = bytes(buf.cpu().numpy())
+    assert out[:16].hex() == "8ea2b7ca516745bfeafc49904b496089" and out[16:] == bytes(48)
+
+
+def test_sp800_38a_ctr_on_device(gpu_ctx, pna):
+    import torch
+    key = bytes.fromhex("603deb1015ca71be2b73aef0857d77811f352c073b6108d72d9810a30914dff4")
+    pt = bytes.fromhex("6bc1bee22e409f96e93d7e117393172aae2d8a571e03ac9c9eb76fac45af8e51"
+                       "30c81c46a35ce411e5fbc1191a0a52eff69f2445df4f9b17ad2b417be66c3710")
+    buf = torch.frombuffer(bytearray(pt), dtype=torch.uint8).cuda()
+    gpu_ctx.cipher_apply_device(pna.Cipher(key, PHSF, pna.MODE_CTR, ivs=bytes.fromhex("f0f1f2f3f4f5f6f7f8f9fafbfcfdfeff")), buf.data_ptr(), [0], [64])
+    assert bytes(buf.cpu().numpy()).hex() == ("601ec313775789a5b7a7f504bbf3d228f443e3ca4d62b59aca84e990cacaf5c5"
+                                              "2b0930daa23de94ce87017ba2d84988ddfc9c58db67aada613c2dd08457941a6")
+
+
+def test_ctr_ranges_equal_oracle(gpu_ctx, pna, codec):
+    """Ragged ranges at odd byte offsets, lengths around the 16-byte block and the 256 KiB unit size, a counter that carries through
+    all 128 bits; bytes between the ranges stay untouched; applying it twice restores the input."""
+    import torch
+    lens = [0, 1, 15, 16, 17, 31, 33, 4096, 65537, (256 << 10) - 1, 256 << 10, (256 << 10) + 1, 700001, 3]
+    blobs = [os.urandom(n) for n in lens]
+    gaps = [os.urandom(1 + (i * 7) % 13) for i in range(len(lens))]
+    flat, offs = bytearray(), []
+    for b, g in zip(blobs, gaps):
+        flat += g; offs.append(len(flat)); flat += b
+    flat += bytes(64)
+    ivs = bytearray(os.urandom(16 * len(lens)))
+    ivs[16 * 8:16 * 9] = bytes([0xFF] * 16)                   # entry 8: IV + 1 wraps to zero
+    ivs[16 * 9:16 * 10] = bytes([0] * 7 + [0xFF] * 9)         # carry across the low 64 bits
+    buf = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    ci = pna.Cipher(KEY, PHSF, pna.MODE_CTR, ivs=bytes(ivs))
+    gpu_ctx.cipher_apply_device(ci, buf.data_ptr(), offs, lens)
+    got = bytes(buf.cpu().numpy())
+    want = bytearray(flat)
+    for i, (o, b) in enumerate(zip(offs, blobs)):
+        want[o:o + len(b)] = codec.aes_ctr(KEY, bytes(ivs[16 * i:16 * i + 16]), b)
+    assert got == bytes(want)
+    gpu_ctx.cipher_apply_device(ci, buf.data_ptr(), offs, lens, decrypt=True)
+    assert bytes(buf.cpu().numpy()) == bytes(flat)
+    assert gpu_ctx.timing().ms_cipher > 0
+
+
+def test_cbc_encrypt_equals_oracle(gpu_ctx, pna, codec):
+    import torch
+    lens = [0, 1, 15, 16, 17, 32, 1000, 65536, 100003] + list(range(40, 72))
+    blobs = [os.urandom(n) for n in lens]
+    flat, offs = bytearray(), []
+    for i, b in enumerate(blobs):
+        flat += os.urandom(1 + i % 5); offs.append(len(flat)); flat += b + bytes(16 - len(b) % 16)     # room for the padding block
+    flat += bytes(64)
+    ivs = os.urandom(16 * len(lens))
+    buf = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, pna.MODE_CBC, ivs=ivs), buf.data_ptr(), offs, lens)
+    got = bytes(buf.cpu().numpy())
+    want = bytearray(flat)
+    for i, (o, b) in enumerate(zip(offs, blobs)):
+        c = codec.aes_cbc_encrypt(KEY, ivs[16 * i:16 * i + 16], b)
+        want[o:o + len(c)] = c
+        assert codec.aes_cbc_decrypt(KEY, ivs[16 * i:16 * i + 16], got[o:o + len(c)]) == b
+    assert got == bytes(want)
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, pna.MODE_CBC, ivs=ivs), buf.data_ptr(), offs, lens, decrypt=True)
+    assert ei.value.code == -7
+
+
+@pytest.mark.parametrize("mode_name", ["ctr", "cbc"])
+@pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
+def test_encrypted_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec, algo_name, mode_name):
+    """pna_gpu_create_archive_enc_device: compress -> cipher -> chunk CRC, all in HBM.  Expected bytes: the plain batch API's payloads,
+    encrypted by the oracle, framed by the oracle's container writer (FHED | fSIZ | PHSF | FDAT(iv) | FDAT(ciphertext) | FEND)."""
+    import torch
+    algo = pna.ALGO_ZSTD if algo_name == "zstd" else pna.ALGO_DEFLATE
+    mode = pna.MODE_CTR if mode_name == "ctr" else pna.MODE_CBC
+    lens = [0, 1, 5, 4095, 16373, 70001, 131073, 300000, (1 << 20) + 1, 2500000, 12, 65536]
+    ents = [codec.corpus_file(i % 2, 150 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"dir{i % 3}/f{i:03d}.txt" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    ivs = os.urandom(16 * len(lens))
+    ci = pna.Cipher(KEY, PHSF, mode, ivs=ivs)
+    cap = pna.archive_enc_bound(algo, names, lens, ci)
+    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+    got = dst[:total].cpu().numpy().tobytes()
+    assert gpu_ctx.timing().ms_cipher > 0
+    payloads = gpu_ctx.compress_batch(ents, algo=algo)
+    enc = (lambda iv, p: codec.aes_ctr(KEY, iv, p)) if mode == pna.MODE_CTR else (lambda iv, p: codec.aes_cbc_encrypt(KEY, iv, p))
+    want = pf.write_archive_header() + b"".join(
+        pf.write_encrypted_file_entry(algo, 1, mode, pf.sanitize_name(nm), PHSF, ivs[16 * i:16 * i + 16], enc(ivs[16 * i:16 * i + 16], pl), len(e))
+        for i, (nm, pl, e) in enumerate(zip(names, payloads, ents))) + pf.finalize_archive()
+    assert len(got) == len(want) and got == want
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+    # read back the way the reference does: CRC of every chunk, key from the PHSF string, IV = first 16 bytes, then decompress
+    _, items = pf.read_archive(got)
+    for it, e in zip(items, ents):
+        assert (it.encryption, it.cipher_mode, it.raw_file_size) == (1, mode, len(e))
+        comp = codec.decrypt_payload(it.encryption, it.cipher_mode, KEY, it.data)
+        assert codec.decode_payload(algo, comp, len(e) + 64) == e
+
+
+def test_encrypted_archive_library_ivs_and_device_read_back(gpu_ctx, pna, pf, codec):
+    """IVs drawn by the library (ivs = NULL): distinct per entry; the archive is read back on the device: CTR decrypt in place
+    (pna_gpu_cipher_apply_device) then the device zstd decoder."""
+    import torch
+    n, L = 64, 1 << 20
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 900, n, L, L, src.data_ptr())
+    names = [f"e/{i:04d}" for i in range(n)]
+    key = hashlib.pbkdf2_hmac("sha256", b"password", b"saltsaltsalt", 1000, 32)
+    ci = pna.Cipher(key, PHSF, pna.MODE_CTR)
+    cap = pna.archive_enc_bound(pna.ALGO_ZSTD, names, [L] * n, ci)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), [i * L for i in range(n)], [L] * n, dst.data_ptr(), cap, cipher=ci)
+    arc = dst[:total].cpu().numpy().tobytes()
+    _, items = pf.read_archive(arc)
+    assert len(items) == n
+    ivs = [it.chunks[3][1] for it in items]
+    assert all(ty == b"FDAT" and len(iv) == 16 for (ty, iv) in (it.chunks[3] for it in items)) and len(set(ivs)) == n
+    assert codec.derive_key_from_phsf(PHSF, b"password") == key
+    # device read-back: locate each ciphertext chunk in the archive buffer, decrypt in place, decode
+    p_off, p_len = [], []
+    for it, o in zip(items, eoff):
+        rel = arc.index(it.chunks[4][1][:32], o)                        # body of the second FDAT chunk
+        p_off.append(rel); p_len.append(len(it.chunks[4][1]))
+    gpu_ctx.cipher_apply_device(pna.Cipher(key, PHSF, pna.MODE_CTR, ivs=b"".join(ivs)), dst.data_ptr(), p_off, p_len, decrypt=True)
+    out = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(dst.data_ptr(), p_off, p_len, out.data_ptr(), [i * L for i in range(n)], [L] * n)
+    assert torch.equal(out, src[:n * L])
+
+
+def test_cipher_error_codes(gpu_ctx, pna):
+    import torch
+    buf = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, pna.MODE_CTR, encryption=pna.ENC_CAMELLIA, ivs=bytes(16)), buf.data_ptr(), [0], [16])
+    assert ei.value.code == -7
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, 2, ivs=bytes(16)), buf.data_ptr(), [0], [16])      # GCM
+    assert ei.value.code == -7
