@@ -104,6 +104,8 @@ def main() -> None:
     ap.add_argument("--framing", choices=["archive", "none", "solid"], default="archive",
                     help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only; "
                          "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
+    ap.add_argument("--encrypt", choices=["none", "aes-ctr", "aes-cbc"], default="none",
+                    help="archive framing only: AES-256 cipher stage between compression and chunk CRC (`pna create --aes [ctr|cbc]`)")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive (archive framing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
@@ -133,8 +135,18 @@ def main() -> None:
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]
     src_len = [file_len] * n_files
     names = [f"enwik/part{rank * n_files + i:07d}.txt" for i in range(n_files)]
+    cipher = None
+    if args.encrypt != "none":
+        if args.framing != "archive":
+            ap.error("--encrypt needs --framing archive")
+        import hashlib
+        # the key a host derives once per WriteOptions (derive_key_material); fixed salt / IV seed: the bench is deterministic
+        key = hashlib.pbkdf2_hmac("sha256", b"password", b"saltsaltsalt", 1000, 32)
+        iv_seed = hashlib.sha256(b"bench-ivs-%d" % rank).digest()
+        ivs = b"".join(hashlib.sha256(iv_seed + i.to_bytes(4, "little")).digest()[:16] for i in range(n_files))
+        cipher = pna.Cipher(key, "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0", pna.MODE_CTR if args.encrypt == "aes-ctr" else pna.MODE_CBC, ivs=ivs)
     if args.framing == "archive":
-        dst_cap = pna.archive_bound(algo, names, src_len)
+        dst_cap = pna.archive_enc_bound(algo, names, src_len, cipher)
     elif args.framing == "solid":
         dst_cap = pna.solid_archive_bound(algo, names, src_len)
     else:
@@ -160,7 +172,7 @@ def main() -> None:
             # rank 0 writes the archive header, the last rank AEND: the shards gathered in rank order are ONE archive
             part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
             total, _ = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo,
-                                                 _cache=arg_cache, part=part)
+                                                 _cache=arg_cache, part=part, cipher=cipher)
         elif args.framing == "solid":
             total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache)
         else:
@@ -186,7 +198,7 @@ def main() -> None:
         out_total = step()
         tm = ctx.timing()
         lz_ms += tm.ms_lz
-        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame
+        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
     finish_gather()                                           # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -204,17 +216,20 @@ def main() -> None:
     # ---- outside the timed region: decode every entry of this rank's last archive on the device and compare with the inputs
     verified = None
     tm_last = ctx.timing()                                   # stage split of the last timed step (the check below runs more kernels)
-    if args.framing == "archive" and not args.no_verify:
+    if args.framing == "archive" and not args.no_verify and args.encrypt != "aes-cbc":
         dst_last = dsts[cur[0] ^ 1] if world > 1 else dsts[0]
         part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
         total, eoff = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst_last.data_ptr(), dst_cap, algo=algo,
-                                                _cache=arg_cache, part=part)
+                                                _cache=arg_cache, part=part, cipher=cipher)
         fs = max(1, (file_len.bit_length() + 7) // 8) if file_len else 0          # fSIZ payload: minimal big-endian
         pay_off, pay_len = [], []
+        extra = (12 + len(cipher.phsf.encode()) + 28) if cipher is not None else 0    # PHSF chunk + FDAT(iv) chunk
         for i in range(n_files):
-            pre = 12 + 6 + len(names[i].encode()) + 12 + fs + 8
+            pre = 12 + 6 + len(names[i].encode()) + 12 + fs + extra + 8
             nxt = eoff[i + 1]
             pay_off.append(eoff[i] + pre); pay_len.append(nxt - eoff[i] - pre - 16)
+        if cipher is not None:                                # read side: CTR decrypt in place, then decode
+            ctx.cipher_apply_device(cipher, dst_last.data_ptr(), pay_off, pay_len, decrypt=True)
         back = torch.empty(n_files * stride + 64, dtype=torch.uint8, device=dev)
         ctx.decompress_batch_device(dst_last.data_ptr(), pay_off, pay_len, back.data_ptr(), src_off[:n_files], src_len, algo=algo)
         ok = all(bool(torch.equal(back[i * stride:i * stride + file_len], src[i * stride:i * stride + file_len])) for i in range(0, n_files, max(1, n_files // 64))) \
@@ -251,6 +266,11 @@ def main() -> None:
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
                                     "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3), "frame": round(tm.ms_frame, 3)},
         }
+        if cipher is not None:
+            line["config"]["workload"] += f", cipher stage {args.encrypt} (AES-256) on the compressed payloads in HBM"
+            line["stages_ms_last_step"]["cipher"] = round(tm.ms_cipher, 3)
+            line["cipher"] = {"mode": args.encrypt, "ms": round(tm.ms_cipher, 3),
+                              "GB_per_s": round(out_total / max(tm.ms_cipher, 1e-9) / 1e6, 1)}
         if world == 1 and not args.no_cpu_baseline and args.algo == "zstd":
             try:
                 sample = args.cpu_sample_files or 64 * usable_cores()

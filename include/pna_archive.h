@@ -50,6 +50,17 @@ void pna_archive_abort(pna_archive *a);
 int  pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int solid, size_t n, const char *const *names,
                         const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 
+/* Password hash -> cipher key on the C++ host: PBKDF2-HMAC-SHA-256 as hash::pbkdf2_with_salt drives it (lib/src/hash.rs:35-45;
+ * lib/src/entry/write.rs:171-186).  `salt` is the raw salt (what the B64 SaltString decodes to).  When phsf != NULL it receives the PHC
+ * string without the hash, "$pbkdf2-sha256$i=<rounds>,l=32$<salt B64, no padding>" -- the body of the PHSF chunk. */
+int  pna_kdf_pbkdf2_sha256(const void *password, size_t password_len, const void *salt, size_t salt_len, uint32_t rounds,
+                           uint8_t *key, size_t key_len, char *phsf, size_t phsf_cap);
+/* pna create --aes [ctr|cbc] --pbkdf2 (non-solid, zstd / deflate): one key derivation per archive (random 16-byte salt; rounds 0 =
+ * the pbkdf2 crate's default 600 000), a fresh random IV per entry, cipher stage on the device (pna_gpu_create_archive_enc_host). */
+int  pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                  const void *const *src, const size_t *src_len, const void *password, size_t password_len,
+                                  int cipher_mode, uint32_t rounds, pna_sink_fn sink, void *user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,10 @@ int  pna_gpu_create_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, si
                                        const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                        const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *entry_off,
                                        uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
+/* pna_gpu_create_archive_host (bounded in-flight window from host memory) with the cipher stage. */
+int  pna_gpu_create_archive_enc_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                     pna_sink_fn sink, void *user);
 /* The cipher alone, in place, over n byte ranges of a device buffer: range i = d_buf[off[i] .. off[i] + len[i]) is one cipher
  * stream with IV ivs[16 * i ..).  CTR: encrypt == decrypt (DecryptReader::CtrAes, lib/src/entry/read.rs:83-88).  CBC: encryption
  * only (decrypt != 0 is PNA_E_UNSUPPORTED); the ciphertext is (len / 16 + 1) * 16 bytes long, the caller leaves that room. */

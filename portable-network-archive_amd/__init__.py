@@ -93,10 +93,11 @@ EXPORTS = [
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
-    "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device",
+    "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
+    "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted",
 ]
 
 
@@ -197,6 +198,14 @@ def load_library() -> ctypes.CDLL:
     L.pna_create_archive.restype = ctypes.c_int
     L.pna_create_archive.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p),
                                      ctypes.POINTER(vp), ctypes.POINTER(sz), SINK_FN, vp]
+    L.pna_gpu_create_archive_enc_host.restype = ctypes.c_int
+    L.pna_gpu_create_archive_enc_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                                  ctypes.POINTER(sz), ctypes.POINTER(CipherStruct), SINK_FN, vp]
+    L.pna_kdf_pbkdf2_sha256.restype = ctypes.c_int
+    L.pna_kdf_pbkdf2_sha256.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+    L.pna_create_archive_encrypted.restype = ctypes.c_int
+    L.pna_create_archive_encrypted.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                               ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_int, u32, SINK_FN, vp]
     _lib = L
     return L
 
@@ -522,4 +531,40 @@ def create_archive(ctx: Optional[Context], names: Sequence[str], entries: Sequen
     if rc:
         msg = L.pna_gpu_last_error(ctx._h).decode() if ctx is not None else ""
         raise PnaGpuError(rc, msg or L.pna_gpu_strerror(rc).decode())
+    return bytes(out)
+
+
+def kdf_pbkdf2_sha256(password: bytes, salt: bytes, rounds: int, key_len: int = 32):
+    """hash::pbkdf2_with_salt on the C++ host (include/pna_archive.h): returns (key, PHSF string)."""
+    key = ctypes.create_string_buffer(key_len)
+    phsf = ctypes.create_string_buffer(256)
+    rc = load_library().pna_kdf_pbkdf2_sha256(bytes(password), len(password), bytes(salt), len(salt), rounds, key, key_len, phsf, 256)
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return key.raw, phsf.value.decode()
+
+
+def create_archive_encrypted(ctx: Context, names: Sequence[str], entries: Sequence[bytes], password: bytes, algo: int = ALGO_ZSTD,
+                             level: int = LEVEL_DEFAULT, mode: int = MODE_CTR, rounds: int = 0, cipher: Optional[Cipher] = None) -> bytes:
+    """`pna create --aes [ctr|cbc] --pbkdf2`: key derivation on the host, compression + cipher + framing on the device.
+    With `cipher` the caller supplies key / PHSF / IVs itself (pna_gpu_create_archive_enc_host)."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend((ctypes.c_char * k).from_address(buf))
+        return 0
+    cb = SINK_FN(_sink)
+    bufs = [e if isinstance(e, bytes) else bytes(e) for e in entries]
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
+    if cipher is not None:
+        cs = cipher.struct(n)
+        rc = L.pna_gpu_create_archive_enc_host(ctx._h, algo, level, n, a_names, a_src, a_len, ctypes.byref(cs), cb, None)
+    else:
+        rc = L.pna_create_archive_encrypted(ctx._h, algo, level, n, a_names, a_src, a_len, bytes(password), len(password), mode, rounds, cb, None)
+    if rc:
+        raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
     return bytes(out)

@@ -101,10 +101,15 @@ void k_aes_cbc_enc(const CipherUnit *__restrict__ units, uint32_t n, const uint8
     uint32_t c0 = iv.x, c1 = iv.y, c2 = iv.z, c3 = iv.w;
     const uint32_t nb = u.len / 16 + 1;
     uint8_t *p = buf + u.off;
+    // the chain is serial, the loads are not: block b + 1 is requested before block b goes through the 14 rounds
+    U4u nx = {0, 0, 0, 0};
+    if (nb > 1) nx = *(const U4u *)p;
     for (uint32_t b = 0; b < nb; b++) {
         uint32_t x0, x1, x2, x3;
-        if (b + 1 < nb) { const U4u v = *(const U4u *)(p + 16 * (size_t)b); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
-        else {
+        if (b + 1 < nb) {
+            x0 = nx.x; x1 = nx.y; x2 = nx.z; x3 = nx.w;
+            if (b + 2 < nb) nx = *(const U4u *)(p + 16 * (size_t)(b + 1));
+        } else {
             const uint32_t have = u.len - 16 * b, padv = 16 - have;
             uint32_t w[4] = {0, 0, 0, 0};
             for (uint32_t k2 = 0; k2 < 16; k2++) { const uint32_t byte = k2 < have ? p[16 * (size_t)b + k2] : padv; w[k2 >> 2] |= byte << (8 * (k2 & 3)); }

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <sys/random.h>
 #include "../../include/pna_archive.h"
 
 namespace {
@@ -227,4 +228,119 @@ extern "C" int pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int sol
     }
     if (rc) { pna_archive_abort(a); return rc; }
     return pna_archive_finalize(a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Password hashing for `pna create --aes --pbkdf2` on the C++ host: PBKDF2-HMAC-SHA-256 (FIPS 180-4, RFC 2104, RFC 8018), the
+// reference's hash::pbkdf2_with_salt (lib/src/hash.rs:35-45; pbkdf2 0.12 defaults: 600 000 rounds, 32-byte output) with a
+// password-hash SaltString (16 random bytes, B64 without padding; the hash function is fed the decoded bytes).
+namespace {
+struct Sha256 {
+    uint32_t h[8]; uint64_t len; uint8_t buf[64]; size_t fill;
+    static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void init() {
+        static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        memcpy(h, iv, sizeof iv); len = 0; fill = 0;
+    }
+    void block(const uint8_t *p) {
+        static uint32_t K[64]; static bool kr = false;
+        if (!kr) {                                             // K[i] = frac(cbrt(prime_i)) * 2^32, by integer cube root of prime << 96
+            int cnt = 0;
+            for (uint32_t c = 2; cnt < 64; c++) {
+                bool pr = true; for (uint32_t d = 2; d * d <= c; d++) if (c % d == 0) { pr = false; break; }
+                if (!pr) continue;
+                unsigned __int128 target = (unsigned __int128)c << 96, lo = 0, hi = (unsigned __int128)1 << 36;
+                while (hi - lo > 1) { unsigned __int128 mid = (lo + hi) / 2; if (mid * mid * mid <= target) lo = mid; else hi = mid; }
+                K[cnt++] = (uint32_t)lo;
+            }
+            kr = true;
+        }
+        uint32_t w[64], a[8];
+        for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+        memcpy(a, h, sizeof a);
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = a[7] + (ror(a[4], 6) ^ ror(a[4], 11) ^ ror(a[4], 25)) + ((a[4] & a[5]) ^ (~a[4] & a[6])) + K[i] + w[i];
+            const uint32_t t2 = (ror(a[0], 2) ^ ror(a[0], 13) ^ ror(a[0], 22)) + ((a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]));
+            a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+        }
+        for (int i = 0; i < 8; i++) h[i] += a[i];
+    }
+    void update(const void *d, size_t n) {
+        const uint8_t *p = (const uint8_t *)d; len += n;
+        while (n) { size_t k = std::min(n, 64 - fill); memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 64) { block(buf); fill = 0; } }
+    }
+    void final(uint8_t out[32]) {
+        const uint64_t bits = len * 8; uint8_t pad[72] = {0x80}; const size_t padn = (fill < 56 ? 56 : 120) - fill;
+        update(pad, padn);
+        uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(lb, 8);
+        for (int i = 0; i < 8; i++) put_be32(out + 4 * i, h[i]);
+    }
+};
+struct Hmac {                                                  // inner / outer states after the key pads: two compressions per PBKDF2 round
+    Sha256 in0, out0;
+    void key(const uint8_t *k, size_t n) {
+        uint8_t kb[64] = {0}, pad[64];
+        if (n > 64) { Sha256 t; t.init(); t.update(k, n); t.final(kb); } else memcpy(kb, k, n);
+        for (int i = 0; i < 64; i++) pad[i] = kb[i] ^ 0x36;
+        in0.init(); in0.update(pad, 64);
+        for (int i = 0; i < 64; i++) pad[i] = kb[i] ^ 0x5c;
+        out0.init(); out0.update(pad, 64);
+    }
+    void mac(const void *a, size_t an, const void *b, size_t bn, uint8_t out[32]) const {
+        Sha256 s = in0; s.update(a, an); if (bn) s.update(b, bn);
+        uint8_t inner[32]; s.final(inner);
+        Sha256 o = out0; o.update(inner, 32); o.final(out);
+    }
+};
+const char B64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+std::string b64_nopad(const uint8_t *p, size_t n) {
+    std::string o;
+    for (size_t i = 0; i < n; i += 3) {
+        const uint32_t v = ((uint32_t)p[i] << 16) | ((i + 1 < n ? (uint32_t)p[i + 1] : 0u) << 8) | (i + 2 < n ? (uint32_t)p[i + 2] : 0u);
+        o += B64[(v >> 18) & 63]; o += B64[(v >> 12) & 63];
+        if (i + 1 < n) o += B64[(v >> 6) & 63];
+        if (i + 2 < n) o += B64[v & 63];
+    }
+    return o;
+}
+} // namespace
+
+extern "C" int pna_kdf_pbkdf2_sha256(const void *password, size_t password_len, const void *salt, size_t salt_len, uint32_t rounds,
+                                     uint8_t *key, size_t key_len, char *phsf, size_t phsf_cap) {
+    if ((!password && password_len) || (!salt && salt_len) || !key || rounds == 0) return PNA_E_INVAL;
+    Hmac hm; hm.key((const uint8_t *)password, password_len);
+    for (uint32_t blk = 1; key_len; blk++) {
+        uint8_t be[4]; put_be32(be, blk);
+        uint8_t u[32], t[32];
+        hm.mac(salt, salt_len, be, 4, u); memcpy(t, u, 32);
+        for (uint32_t r = 1; r < rounds; r++) { hm.mac(u, 32, nullptr, 0, u); for (int i = 0; i < 32; i++) t[i] ^= u[i]; }
+        const size_t k = std::min<size_t>(key_len, 32);
+        memcpy(key, t, k); key += k; key_len -= k;
+    }
+    if (phsf) {                                                // PasswordHash::to_string() after hash.take(): "$pbkdf2-sha256$i=<rounds>,l=<len>$<salt>"
+        const std::string s = "$pbkdf2-sha256$i=" + std::to_string(rounds) + ",l=32$" + b64_nopad((const uint8_t *)salt, salt_len);
+        if (s.size() + 1 > phsf_cap) return PNA_E_DSTSIZE;
+        memcpy(phsf, s.c_str(), s.size() + 1);
+    }
+    return PNA_OK;
+}
+
+// `pna create --aes [ctr|cbc] --password ... --pbkdf2`: one key derivation per archive (WriteOptions caches it, lib/src/entry/options.rs),
+// a fresh IV per entry; non-solid zstd / deflate archives on the device path.
+extern "C" int pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                            const void *const *src, const size_t *src_len, const void *password, size_t password_len,
+                                            int cipher_mode, uint32_t rounds, pna_sink_fn sink, void *user) {
+    if (!ctx) return PNA_E_NODEVICE;
+    if (!sink || (!password && password_len)) return PNA_E_INVAL;
+    uint8_t salt[16];
+    if (getrandom(salt, sizeof salt, 0) != (ssize_t)sizeof salt) return PNA_E_INVAL;
+    pna_gpu_cipher ci{};
+    ci.encryption = PNA_ENC_AES; ci.cipher_mode = cipher_mode; ci.ivs = nullptr;
+    char phsf[128];
+    int rc = pna_kdf_pbkdf2_sha256(password, password_len, salt, sizeof salt, rounds ? rounds : 600000u, ci.key, 32, phsf, sizeof phsf);
+    if (rc) return rc;
+    ci.phsf = phsf;
+    return pna_gpu_create_archive_enc_host(ctx, algo, level, n, names, src, src_len, &ci, sink, user);
 }

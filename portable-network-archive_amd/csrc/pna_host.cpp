@@ -316,6 +316,21 @@ static int check_cipher(pna_gpu_ctx *c, const pna_gpu_cipher *ci) {
     if (ci->cipher_mode != PNA_MODE_CTR && ci->cipher_mode != PNA_MODE_CBC) return fail(c, PNA_E_UNSUPPORTED, "cipher mode not offered on the device path");
     return PNA_OK;
 }
+// the per-entry IVs of a cipher job: the caller's, or random ones (random::random_vec(block_size) per entry, lib/src/entry/write.rs:108-112)
+static int resolve_ivs(pna_gpu_ctx *c, const pna_gpu_cipher *cipher, size_t n, std::vector<uint8_t> &own, const uint8_t **ivs) {
+    int rc = check_cipher(c, cipher); if (rc) return rc;
+    if (!cipher->phsf) return fail(c, PNA_E_INVAL, "cipher without a PHSF string");
+    *ivs = cipher->ivs;
+    if (*ivs) return PNA_OK;
+    own.resize(n * 16 + 16);
+    for (size_t o = 0; o < n * 16;) {
+        const ssize_t got = getrandom(own.data() + o, std::min<size_t>(n * 16 - o, 1u << 20), 0);
+        if (got <= 0) return fail(c, PNA_E_INVAL, "getrandom failed");
+        o += (size_t)got;
+    }
+    *ivs = own.data();
+    return PNA_OK;
+}
 constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR work unit (one workgroup)
 
 // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry; cipher + ivs (16 bytes per
@@ -651,20 +666,7 @@ extern "C" int pna_gpu_create_archive_enc_device(pna_gpu_ctx *c, int algo, int l
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
-    if (cipher) {
-        int rc = check_cipher(c, cipher); if (rc) return rc;
-        if (!cipher->phsf) return fail(c, PNA_E_INVAL, "cipher without a PHSF string");
-        ivs = cipher->ivs;
-        if (!ivs) {                                          // random::random_vec(block_size) per entry, lib/src/entry/write.rs:108-112
-            own_ivs.resize(n * 16 + 16);
-            for (size_t o = 0; o < n * 16;) {
-                const ssize_t got = getrandom(own_ivs.data() + o, std::min<size_t>(n * 16 - o, 1u << 20), 0);
-                if (got <= 0) return fail(c, PNA_E_INVAL, "getrandom failed");
-                o += (size_t)got;
-            }
-            ivs = own_ivs.data();
-        }
-    }
+    if (cipher) { int rc = resolve_ivs(c, cipher, n, own_ivs, &ivs); if (rc) return rc; }
     (void)level;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
@@ -865,9 +867,19 @@ static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *s
 
 extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                            const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    return pna_gpu_create_archive_enc_host(c, algo, level, n, names, src, src_len, nullptr, sink, user);
+}
+
+extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                               const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                               pna_sink_fn sink, void *user) {
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     (void)level;
+    if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
+    std::vector<uint8_t> own_ivs;
+    const uint8_t *ivs = nullptr;
+    if (cipher) { int rc0 = resolve_ivs(c, cipher, n, own_ivs, &ivs); if (rc0) return rc0; }
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->cp_in) {
         HIPCHK(c, hipStreamCreate(&c->cp_in)); HIPCHK(c, hipStreamCreate(&c->cp_out));
@@ -890,7 +902,7 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
             const size_t nb = (size_t)((l + BLK_SIZE - 1) / BLK_SIZE);
             if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
             off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
-            sb.out_cap += frame_entry_prefix_bound(names[i]) + pna_gpu_bound(algo, (size_t)l) + 16;
+            sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + pna_gpu_bound(algo, (size_t)l) + 16;
             sb.e1++;
         }
         sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
@@ -898,7 +910,7 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (const char *e = getenv("PNA_STAGE_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 64) threads = (unsigned)t; }
-    FrameJob fj{names, 0};
+    FrameJob fj{names, 0, cipher, ivs};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
     for (size_t e = 0; e < n; e++) in_total += src_len[e];

@@ -133,3 +133,18 @@ def test_archive_bound_covers_framing(pna):
     lens = [0, 3 << 20]
     b = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
     assert b >= 40 + sum(pna.bound(pna.ALGO_ZSTD, n) + 12 + 6 + len(nm) + 12 + 8 + 12 + 12 for nm, n in zip(names, lens))
+
+
+def test_host_kdf_matches_hashlib(pna):
+    """pna_kdf_pbkdf2_sha256 (the C++ host's hash::pbkdf2_with_salt, lib/src/hash.rs:35-45) against hashlib, and its PHC string."""
+    import base64
+    import hashlib
+    for pw, salt, rounds, kl in [(b"password", bytes(range(16)), 1000, 32), (b"", b"s", 1, 32), (b"p" * 100, b"salt" * 5, 7, 70)]:
+        key, phsf = pna.kdf_pbkdf2_sha256(pw, salt, rounds, kl)
+        assert key == hashlib.pbkdf2_hmac("sha256", pw, salt, rounds, kl)
+        assert phsf == f"$pbkdf2-sha256$i={rounds},l=32$" + base64.b64encode(salt).decode().rstrip("=")
+
+
+def test_host_kdf_phsf_is_read_by_the_oracle(pna, codec):
+    key, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
+    assert codec.derive_key_from_phsf(phsf, b"password") == key

@@ -161,3 +161,38 @@ def test_cipher_error_codes(gpu_ctx, pna):
     with pytest.raises(pna.PnaGpuError) as ei:
         gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, 2, ivs=bytes(16)), buf.data_ptr(), [0], [16])      # GCM
     assert ei.value.code == -7
+
+
+@pytest.mark.parametrize("mode_name", ["ctr", "cbc"])
+def test_create_archive_encrypted_from_host_memory(gpu_ctx, pna, pf, codec, mode_name):
+    """pna_create_archive_encrypted: PBKDF2 on the host, pipelined device path (two sub-batches), random salt and IVs.  Read back the
+    way the reference reads: key from PHSF + password, IV = first data chunk, decrypt, decompress."""
+    mode = pna.MODE_CTR if mode_name == "ctr" else pna.MODE_CBC
+    ents = [codec.corpus_file(0, 300 + i, n) for i, n in enumerate([1 << 20, 70000, 0, 3, (1 << 20) + 17, 65536, 250000, 999])] * 3
+    names = [f"h/{i:03d}.txt" for i in range(len(ents))]
+    os.environ["PNA_SUB_MIB"] = "16"
+    try:
+        arc = pna.create_archive_encrypted(gpu_ctx, names, ents, b"password", mode=mode, rounds=1000)
+    finally:
+        del os.environ["PNA_SUB_MIB"]
+    _, items = pf.read_archive(arc)
+    assert [it.name for it in items] == names
+    phsfs = {[d for ty, d in it.chunks if ty == b"PHSF"][0] for it in items}
+    assert len(phsfs) == 1                                     # one key derivation per archive
+    phsf = phsfs.pop().decode()
+    assert phsf.startswith("$pbkdf2-sha256$i=1000,l=32$")
+    key = codec.derive_key_from_phsf(phsf, b"password")
+    assert len({it.data[:16] for it in items}) == len(items)   # a fresh IV per entry
+    for it, e in zip(items, ents):
+        assert (it.encryption, it.cipher_mode, it.raw_file_size) == (1, mode, len(e))
+        assert codec.decode_payload(2, codec.decrypt_payload(1, mode, key, it.data), len(e) + 64) == e
+    # the same entries with caller-supplied key / IVs give the device-path bytes
+    ivs = os.urandom(16 * len(ents))
+    ci = pna.Cipher(key, phsf, mode, ivs=ivs)
+    a1 = pna.create_archive_encrypted(gpu_ctx, names, ents, b"", cipher=ci)
+    payloads = gpu_ctx.compress_batch(ents)
+    enc = (lambda iv, p: codec.aes_ctr(key, iv, p)) if mode == pna.MODE_CTR else (lambda iv, p: codec.aes_cbc_encrypt(key, iv, p))
+    want = pf.write_archive_header() + b"".join(
+        pf.write_encrypted_file_entry(2, 1, mode, nm, phsf, ivs[16 * i:16 * i + 16], enc(ivs[16 * i:16 * i + 16], pl), len(e))
+        for i, (nm, pl, e) in enumerate(zip(names, payloads, ents))) + pf.finalize_archive()
+    assert a1 == want
