@@ -152,6 +152,14 @@ int  pna_gpu_create_solid_archive_device(pna_gpu_ctx *ctx, int algo, int level, 
                                          const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                          void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream);
 
+/* With a cipher (CTR only: CBC would be one serial chain over the whole stream): SHED(encryption, cipher_mode) | PHSF | SDAT(iv) |
+ * SDAT(ciphertext)* | SEND, one cipher stream over all SDAT bodies (into_solid_archive, lib/src/archive/write.rs:443-470).
+ * cipher->ivs is ONE 16-byte IV or NULL; pna_gpu_archive_enc_bound-style slack: add 64 + strlen(phsf) bytes to the plain bound. */
+int  pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                             const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                             const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *archive_len,
+                                             void *hip_stream);
+
 int  pna_gpu_create_solid_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 

@@ -94,6 +94,7 @@ EXPORTS = [
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
+    "pna_gpu_create_solid_archive_enc_device",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -156,6 +157,9 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_solid_archive_device.restype = ctypes.c_int
     L.pna_gpu_create_solid_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                       vp, sz, u64p, vp]
+    L.pna_gpu_create_solid_archive_enc_device.restype = ctypes.c_int
+    L.pna_gpu_create_solid_archive_enc_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
+                                                          ctypes.POINTER(CipherStruct), vp, sz, u64p, vp]
     L.pna_gpu_debug_crc_schedule.restype = ctypes.c_uint32
     L.pna_gpu_debug_crc_schedule.argtypes = [ctypes.c_char_p, sz]
     L.pna_gpu_stream_new.restype = ctypes.c_int
@@ -320,8 +324,9 @@ class Context:
 
     def create_solid_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                                     dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
-                                    _cache: Optional[dict] = None) -> int:
-        """`pna create --solid` assembled in HBM (pna_gpu_create_solid_archive_device).  Returns the archive length."""
+                                    _cache: Optional[dict] = None, cipher: Optional[Cipher] = None) -> int:
+        """`pna create --solid` assembled in HBM (pna_gpu_create_solid_archive_enc_device; `cipher`: CTR, one IV).
+        Returns the archive length."""
         n = len(src_len)
         if _cache is not None and "a" in _cache:
             a_names, a_off, a_len = _cache["a"]
@@ -332,9 +337,11 @@ class Context:
             if _cache is not None:
                 _cache["a"] = (a_names, a_off, a_len)
         total = ctypes.c_uint64()
-        self._check(self._L.pna_gpu_create_solid_archive_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
-                                                                ctypes.c_void_p(d_dst), dst_cap, ctypes.byref(total),
-                                                                ctypes.c_void_p(stream) if stream else None))
+        cs = cipher.struct(1) if cipher is not None else None
+        self._check(self._L.pna_gpu_create_solid_archive_enc_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
+                                                                    ctypes.byref(cs) if cs is not None else None,
+                                                                    ctypes.c_void_p(d_dst), dst_cap, ctypes.byref(total),
+                                                                    ctypes.c_void_p(stream) if stream else None))
         return total.value
 
     def decompress_batch(self, payloads: Sequence[bytes], raw_sizes: Sequence[int], algo: int = ALGO_ZSTD) -> List[bytes]:

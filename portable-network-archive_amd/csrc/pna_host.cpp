@@ -49,6 +49,7 @@ void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
+void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t iv[16]);
 void frame_solid_tail(std::vector<uint8_t> &o);
 void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number);
 void frame_archive_tail(std::vector<uint8_t> &o);
@@ -464,6 +465,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 memcpy(pf + 4, "SDAT", 4);
                 fds[sg] = FrameDesc{pos, (uint32_t)plen, 8u * sg, 8u, 0};
                 segdst[sg] = pos + 8;
+                if (fj->cipher)                                    // one cipher stream over all SDAT bodies: the keystream position runs on
+                    for (uint64_t o = 0; o < plen; o += CTR_UNIT)
+                        cunits.push_back(CipherUnit{pos + 8 + o, (seg_off[sg] - seg_off[0]) + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), 0u});
                 pos += 8 + plen + 4;
             }
             blob_len = 8 * (size_t)nseg;
@@ -533,7 +537,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, st);
     if (fj && fj->cipher) {
-        if (solid) return fail(c, PNA_E_UNSUPPORTED, "cipher on the solid device path");
+        if (solid && fj->cipher->cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "solid archives: only CTR on the device path (CBC is one serial chain)");
         int rc = ensure_aes(c); if (rc) return rc;
         if (c->ci_units.ensure(cunits.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure((e1 - e0) * 16 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
         AesKey key; aes256_expand(fj->cipher->key, key);
@@ -755,6 +759,20 @@ extern "C" size_t pna_gpu_solid_archive_bound(int algo, size_t n, const char *co
 extern "C" int pna_gpu_create_solid_archive_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                    const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                                    void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream) {
+    return pna_gpu_create_solid_archive_enc_device(c, algo, level, n, names, d_src, src_off, src_len, nullptr, d_dst, dst_cap, archive_len, hip_stream);
+}
+
+// With a cipher (CTR): SHED(encryption, cipher_mode) | PHSF | SDAT(iv) | SDAT(ciphertext)* | SEND -- into_solid_archive writes the PHSF
+// chunk behind SHED and the IV as the first write of the SDAT stream (lib/src/archive/write.rs:443-470); one cipher stream runs over
+// all SDAT bodies.  cipher->ivs: ONE 16-byte IV (or NULL).
+extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                       const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                       const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *archive_len,
+                                                       void *hip_stream) {
+    if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
+    std::vector<uint8_t> own_ivs;
+    const uint8_t *ivs = nullptr;
+    if (cipher) { int rc0 = resolve_ivs(c, cipher, 1, own_ivs, &ivs); if (rc0) return rc0; }
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
@@ -798,12 +816,13 @@ extern "C" int pna_gpu_create_solid_archive_device(pna_gpu_ctx *c, int algo, int
     // ---- 2 + 3. one entry -> SDAT chunks, between the fixed chunks
     c->timing = pna_gpu_timing{};
     std::vector<uint8_t> head, tail;
-    frame_archive_head(head, 0); frame_solid_head(head, algo);
+    frame_archive_head(head, 0);
+    if (cipher) frame_solid_head_enc(head, algo, cipher->encryption, cipher->cipher_mode, cipher->phsf, ivs); else frame_solid_head(head, algo);
     frame_solid_tail(tail); frame_archive_tail(tail);
     if (head.size() + tail.size() + 64 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     const uint64_t off0 = 0, len0 = plain_len; uint64_t offs[2] = {0, 0};
-    FrameJob fj{nullptr, 1};
+    FrameJob fj{nullptr, 1, cipher, ivs};
     rc = run_subbatch(c, algo, (const uint8_t *)c->solid_plain.p, &off0, &len0, 0, 1, (uint8_t *)d_dst, dst_cap - tail.size(), head.size(), offs, st, true, &fj);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + offs[1], tail.data(), tail.size(), hipMemcpyHostToDevice, st));

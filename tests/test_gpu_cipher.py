@@ -196,3 +196,49 @@ def test_create_archive_encrypted_from_host_memory(gpu_ctx, pna, pf, codec, mode
         pf.write_encrypted_file_entry(2, 1, mode, nm, phsf, ivs[16 * i:16 * i + 16], enc(ivs[16 * i:16 * i + 16], pl), len(e))
         for i, (nm, pl, e) in enumerate(zip(names, payloads, ents))) + pf.finalize_archive()
     assert a1 == want
+
+
+@pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
+def test_encrypted_solid_archive_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
+    """pna create --solid --aes ctr in HBM: SHED(enc) | PHSF | SDAT(iv) | SDAT(ciphertext)* | SEND with ONE keystream over all SDAT
+    bodies.  Byte-exact against the plain solid archive with the oracle's cipher applied to the concatenated SDAT bodies."""
+    import torch
+    algo = pna.ALGO_ZSTD if algo_name == "zstd" else pna.ALGO_DEFLATE
+    lens = [300000, 0, 5, (1 << 20) + 3, 70001, 2500000, 12]
+    ents = [codec.corpus_file(i % 2, 400 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"s/{i}.txt" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    iv = os.urandom(16)
+    ci = pna.Cipher(KEY, PHSF, pna.MODE_CTR, ivs=iv)
+    cap = pna.solid_archive_bound(algo, names, lens) + 256
+    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+    got = dst[:total].cpu().numpy().tobytes()
+    assert gpu_ctx.timing().ms_cipher > 0
+    dst2 = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total2 = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst2.data_ptr(), cap, algo=algo)
+    (plain_solid,) = pf.read_archive(dst2[:total2].cpu().numpy().tobytes())[1]
+    bodies = [d for ty, d in plain_solid.chunks if ty == b"SDAT"]
+    ct = codec.aes_ctr(KEY, iv, b"".join(bodies))
+    want = pf.write_archive_header() + pf.write_chunk(b"SHED", pf.solid_header_bytes(algo, 1, pf.CIPHER_MODE_CTR)) + pf.write_chunk(b"PHSF", PHSF.encode())
+    want += pf.write_chunk(b"SDAT", iv)
+    p = 0
+    for b in bodies:
+        want += pf.write_chunk(b"SDAT", ct[p:p + len(b)]); p += len(b)
+    want += pf.write_chunk(b"SEND") + pf.finalize_archive()
+    assert got == want
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+    # the reference's read path: decrypt the concatenated SDAT bodies (IV first), decompress, walk the inner entries
+    (so,) = pf.read_archive(got)[1]
+    assert (so.encryption, so.cipher_mode) == (1, 1)
+    inner = pf.read_solid_inner(codec.decode_payload(algo, codec.decrypt_payload(1, 1, KEY, so.data), sum(lens) + 4096))
+    assert [e.name for e in inner] == names and [e.data for e in inner] == ents
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=pna.Cipher(KEY, PHSF, pna.MODE_CBC, ivs=iv))
+    assert ei.value.code == -7
