@@ -408,3 +408,77 @@ void pna_oracle_pbkdf2_sha256(const uint8_t *pwd, size_t pwd_len, const uint8_t 
         memcpy(out, t, k); out += k; out_len -= k;
     }
 }
+
+/* ------------------------------------------------------------------ HKDF-SHA-256 (RFC 5869), AES-GCM (NIST SP 800-38D)
+ * Cipher mode 2 of the reference ("GCM STREAM", lib/src/cipher/aead.rs, lib/src/cipher/gcm.rs): third-party crates hkdf 0.13 / sha2 /
+ * aes-gcm; restated from the published algorithms. */
+void pna_oracle_hkdf_sha256(const uint8_t *ikm, size_t ikm_len, const uint8_t *salt, size_t salt_len, const uint8_t *info, size_t info_len,
+                            uint8_t *okm, size_t okm_len) {
+    uint8_t zero[32] = {0}, prk[32], t[32];
+    if (salt_len == 0) { salt = zero; salt_len = 32; }                 /* RFC 5869 2.2: absent salt = HashLen zeros */
+    hmac_sha256(salt, salt_len, ikm, ikm_len, NULL, 0, prk);
+    size_t tl = 0;
+    for (uint8_t ctr = 1; okm_len; ctr++) {
+        /* T(n) = HMAC(PRK, T(n-1) || info || n) */
+        uint8_t buf[32 + 1024 + 1]; size_t n = 0;
+        if (info_len > 1024) return;
+        memcpy(buf, t, tl); n += tl; memcpy(buf + n, info, info_len); n += info_len; buf[n++] = ctr;
+        hmac_sha256(prk, 32, buf, n, NULL, 0, t); tl = 32;
+        const size_t k = okm_len < 32 ? okm_len : 32;
+        memcpy(okm, t, k); okm += k; okm_len -= k;
+    }
+}
+
+/* GF(2^128) multiply, GCM bit order (bit 0 = most significant bit of byte 0) */
+static void gf128_mul(const uint8_t x[16], const uint8_t y[16], uint8_t out[16]) {
+    uint8_t z[16] = {0}, v[16];
+    memcpy(v, y, 16);
+    for (int i = 0; i < 128; i++) {
+        if ((x[i >> 3] >> (7 - (i & 7))) & 1) for (int j = 0; j < 16; j++) z[j] ^= v[j];
+        const int lsb = v[15] & 1;
+        for (int j = 15; j > 0; j--) v[j] = (uint8_t)((v[j] >> 1) | (v[j - 1] << 7));
+        v[0] >>= 1;
+        if (lsb) v[0] ^= 0xE1;
+    }
+    memcpy(out, z, 16);
+}
+static void ghash(const uint8_t h[16], const uint8_t *aad, size_t aad_len, const uint8_t *c, size_t c_len, uint8_t out[16]) {
+    uint8_t y[16] = {0};
+    const uint8_t *parts[2] = {aad, c}; const size_t lens[2] = {aad_len, c_len};
+    for (int p = 0; p < 2; p++)
+        for (size_t o = 0; o < lens[p]; o += 16) {
+            const size_t k = lens[p] - o < 16 ? lens[p] - o : 16;
+            for (size_t j = 0; j < k; j++) y[j] ^= parts[p][o + j];
+            gf128_mul(y, h, y);
+        }
+    uint8_t lb[16];
+    const uint64_t ab = (uint64_t)aad_len * 8, cb = (uint64_t)c_len * 8;
+    for (int i = 0; i < 8; i++) { lb[i] = (uint8_t)(ab >> (56 - 8 * i)); lb[8 + i] = (uint8_t)(cb >> (56 - 8 * i)); }
+    for (int j = 0; j < 16; j++) y[j] ^= lb[j];
+    gf128_mul(y, h, y);
+    memcpy(out, y, 16);
+}
+/* AES-GCM with a 96-bit nonce: buf is encrypted / decrypted in place; tag (16 bytes) is written (encrypt) or compared (decrypt:
+ * returns -1 on mismatch, the buffer then holds garbage). */
+int pna_oracle_aes_gcm(const uint8_t *key, int key_len, const uint8_t nonce[12], const uint8_t *aad, size_t aad_len,
+                       uint8_t *buf, size_t n, uint8_t tag[16], int decrypt) {
+    aes_key k; pna_aes_expand(key, key_len, &k);
+    uint8_t h[16], zero[16] = {0}, j0[16], ej0[16], s[16];
+    pna_aes_encrypt_block(&k, zero, h);
+    memcpy(j0, nonce, 12); j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+    pna_aes_encrypt_block(&k, j0, ej0);
+    if (decrypt) {
+        ghash(h, aad, aad_len, buf, n, s);
+        uint8_t diff = 0; for (int j = 0; j < 16; j++) diff |= (uint8_t)(s[j] ^ ej0[j] ^ tag[j]);
+        if (diff) return -1;
+    }
+    uint32_t ctr = 2;
+    for (size_t o = 0; o < n; o += 16, ctr++) {
+        uint8_t cb[16], ks[16];
+        memcpy(cb, nonce, 12); cb[12] = (uint8_t)(ctr >> 24); cb[13] = (uint8_t)(ctr >> 16); cb[14] = (uint8_t)(ctr >> 8); cb[15] = (uint8_t)ctr;
+        pna_aes_encrypt_block(&k, cb, ks);
+        for (size_t j = 0; j < 16 && o + j < n; j++) buf[o + j] ^= ks[j];
+    }
+    if (!decrypt) { ghash(h, aad, aad_len, buf, n, s); for (int j = 0; j < 16; j++) tag[j] = (uint8_t)(s[j] ^ ej0[j]); }
+    return 0;
+}

@@ -350,3 +350,101 @@ def decrypt_payload(encryption: int, cipher_mode: int, key: bytes, data: bytes) 
     if cipher_mode == 0:
         return aes_cbc_decrypt(key, iv, body)
     raise ValueError("cipher mode not in the oracle")
+
+
+# ----------------------------------------------------------------------------- cipher mode 2: GCM STREAM (lib/src/cipher/aead.rs, gcm.rs)
+
+STREAM_HEADER_LEN, GCM_TAG_LEN = 75, 16      # aead.rs:15-16
+DEFAULT_SEGMENT_SIZE, MAX_SEGMENT_SIZE = 1 << 20, 64 << 20   # aead.rs:17-18
+
+
+def hkdf_sha256(ikm: bytes, salt: bytes, info: bytes, outlen: int = 32) -> bytes:
+    """hkdf_sha256 -- lib/src/cipher/aead.rs:151-157."""
+    out = ctypes.create_string_buffer(outlen)
+    lib().pna_oracle_hkdf_sha256(bytes(ikm), ctypes.c_size_t(len(ikm)), bytes(salt), ctypes.c_size_t(len(salt)), bytes(info),
+                                 ctypes.c_size_t(len(info)), out, ctypes.c_size_t(outlen))
+    return out.raw
+
+
+def aes_gcm(key: bytes, nonce: bytes, data: bytes, tag: bytes | None = None, aad: bytes = b""):
+    """Encrypt (tag is None): returns (ciphertext, tag).  Decrypt: returns the plaintext or raises on a tag mismatch."""
+    assert len(nonce) == 12
+    buf = ctypes.create_string_buffer(bytes(data), max(len(data), 1))
+    t = ctypes.create_string_buffer(bytes(tag) if tag is not None else bytes(16), 16)
+    r = lib().pna_oracle_aes_gcm(bytes(key), len(key), bytes(nonce), bytes(aad), ctypes.c_size_t(len(aad)), buf, ctypes.c_size_t(len(data)),
+                                 t, 0 if tag is None else 1)
+    if r:
+        raise ValueError("GCM authentication failure")
+    return (buf.raw[:len(data)], t.raw) if tag is None else buf.raw[:len(data)]
+
+
+def key_confirmation(k_master: bytes) -> bytes:
+    """aead.rs:161-163: HKDF with an empty salt and the info "PNA-KC-v1"."""
+    return hkdf_sha256(k_master, b"", b"PNA-KC-v1")
+
+
+def stream_header_bytes(salt: bytes, nonce_prefix: bytes, segment_size: int, k_master: bytes) -> bytes:
+    """StreamHeader::to_bytes -- aead.rs:130-137: salt(32) || nonce_prefix(7) || segment_size(u32 BE) || key_confirmation(32)."""
+    assert len(salt) == 32 and len(nonce_prefix) == 7 and 1 <= segment_size <= MAX_SEGMENT_SIZE
+    return bytes(salt) + bytes(nonce_prefix) + segment_size.to_bytes(4, "big") + key_confirmation(k_master)
+
+
+def entry_context(nonce_prefix: bytes, segment_size: int, header_chunk_type: bytes, header_chunk_data: bytes, phsf: bytes) -> bytes:
+    """aead.rs:165-182: "PNA-STREAM-v1" || sha256(type || header data) || sha256(phsf) || nonce_prefix || segment_size BE."""
+    return b"PNA-STREAM-v1" + sha256(header_chunk_type + header_chunk_data) + sha256(phsf) + bytes(nonce_prefix) + segment_size.to_bytes(4, "big")
+
+
+def derive_stream_key(k_master: bytes, salt: bytes, nonce_prefix: bytes, segment_size: int, header_chunk_type: bytes,
+                      header_chunk_data: bytes, phsf: bytes) -> bytes:
+    """aead.rs:184-199: HKDF(ikm = K_master, salt = header.salt, info = entry_context)."""
+    return hkdf_sha256(k_master, salt, entry_context(nonce_prefix, segment_size, header_chunk_type, header_chunk_data, phsf))
+
+
+def segment_nonce(nonce_prefix: bytes, counter: int, is_final: bool) -> bytes:
+    """aead.rs:201-207."""
+    return bytes(nonce_prefix) + counter.to_bytes(4, "big") + (b"\x01" if is_final else b"\x00")
+
+
+def gcm_stream_encrypt(k_stream: bytes, nonce_prefix: bytes, segment_size: int, plain: bytes) -> bytes:
+    """GcmEncryptWriter -- gcm.rs:45-90: segments of segment_size bytes, each followed by its tag; a segment is flushed as non-final
+    only when more data follows, finish() flushes the last one (possibly empty, possibly full) with the final flag."""
+    out, counter, pos = bytearray(), 0, 0
+    while len(plain) - pos > segment_size:
+        c, t = aes_gcm(k_stream, segment_nonce(nonce_prefix, counter, False), plain[pos:pos + segment_size])
+        out += c + t; pos += segment_size; counter += 1
+    c, t = aes_gcm(k_stream, segment_nonce(nonce_prefix, counter, True), plain[pos:])
+    return bytes(out + c + t)
+
+
+def gcm_stream_decrypt(k_stream: bytes, nonce_prefix: bytes, segment_size: int, data: bytes) -> bytes:
+    """GcmDecryptReader -- gcm.rs:206-290: a segment is final when the stream ends behind it."""
+    out, counter, pos = bytearray(), 0, 0
+    if len(data) < GCM_TAG_LEN:
+        raise ValueError("datastream shorter than a tag")
+    while True:
+        seg = data[pos:pos + segment_size + GCM_TAG_LEN]
+        pos += len(seg)
+        final = pos >= len(data)
+        if not final and len(seg) < segment_size + GCM_TAG_LEN:
+            raise ValueError("short non-final segment")
+        if len(seg) < GCM_TAG_LEN:
+            raise ValueError("truncated segment")
+        out += aes_gcm(k_stream, segment_nonce(nonce_prefix, counter, final), seg[:-GCM_TAG_LEN], tag=seg[-GCM_TAG_LEN:])
+        if final:
+            return bytes(out)
+        counter += 1
+
+
+def decrypt_payload_gcm(k_master: bytes, data: bytes, header_chunk_type: bytes, header_chunk_data: bytes, phsf: bytes) -> bytes:
+    """decrypt_reader, (_, CipherMode::GCM) -- lib/src/entry/read.rs:105-140: 75-byte stream header first, key confirmation checked
+    before any segment is processed, K_stream bound to the entry's header chunk and PHSF."""
+    if len(data) < STREAM_HEADER_LEN:
+        raise ValueError("datastream shorter than the stream header")
+    hd = data[:STREAM_HEADER_LEN]
+    salt, prefix, seg = hd[:32], hd[32:39], int.from_bytes(hd[39:43], "big")
+    if not 1 <= seg <= MAX_SEGMENT_SIZE:
+        raise ValueError("segment size out of range")
+    if hd[43:75] != key_confirmation(k_master):
+        raise ValueError("wrong password (key confirmation)")
+    ks = derive_stream_key(k_master, salt, prefix, seg, header_chunk_type, header_chunk_data, phsf)
+    return gcm_stream_decrypt(ks, prefix, seg, data[STREAM_HEADER_LEN:])

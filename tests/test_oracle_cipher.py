@@ -125,3 +125,68 @@ def test_encrypted_entry_writer_reads_back(codec, pf):
     assert (it.encryption, it.cipher_mode, it.raw_file_size) == (1, 1, 6000) and it.chunks[3][1] == iv
     assert codec.derive_key_from_phsf(phsf, b"pw") == hashlib.pbkdf2_hmac("sha256", b"pw", b"saltsaltsalt", 1000, 32)
     assert codec.decode_payload(2, codec.decrypt_payload(1, 1, key, it.data), 1 << 20) == b"hello " * 1000
+
+
+# ----------------------------------------------------------------------------- cipher mode 2: GCM STREAM
+
+def test_hkdf_rfc5869_and_reference_stream_key_vector(codec):
+    # lib/src/cipher/aead.rs:321-330 (RFC 5869 test case 1) and :399-405 (K_STREAM_FHED, "produced by an RFC 5869 implementation
+    # outside this crate")
+    okm = codec.hkdf_sha256(bytes([0x0b] * 22), bytes(range(13)), bytes(range(0xf0, 0xfa)), 42)
+    assert okm.hex() == "3cb25f25faacd57a90434f64d0362f2a2d2d0a90cf1a5a4c5db02d56ecc4c5bf34007208d5b887185865"
+    ks = codec.derive_stream_key(b"master_key", bytes([0x42] * 32), bytes([0x5A] * 7), 0x01020304, b"FHED", b"header", b"phsf")
+    assert ks.hex() == "b88e2edc07538bdd2b9afff57fb0d3433a1f4498d22a5911507e6827590fadb5"
+    # entry_context layout, aead.rs:370-381
+    ctx = codec.entry_context(bytes([0x5A] * 7), 0x01020304, b"FHED", b"test_header", b"test_phsf")
+    assert ctx == b"PNA-STREAM-v1" + hashlib.sha256(b"FHEDtest_header").digest() + hashlib.sha256(b"test_phsf").digest() + bytes([0x5A] * 7) + bytes([1, 2, 3, 4])
+    assert codec.segment_nonce(bytes([3] * 7), 0x01020304, True) == bytes([3] * 7) + bytes([1, 2, 3, 4, 1])
+
+
+def test_gcm_nist_vectors(codec):
+    # NIST GCM test cases 13 and 14 (AES-256, 96-bit IV)
+    c, t = codec.aes_gcm(bytes(32), bytes(12), b"")
+    assert c == b"" and t.hex() == "530f8afbc74536b9a963b4f1c4cb738b"
+    c, t = codec.aes_gcm(bytes(32), bytes(12), bytes(16))
+    assert c.hex() == "cea7403d4d606b6e074ec5d3baf39d18" and t.hex() == "d0d1c8a799996bf0265b98b5d48ab919"
+    assert codec.aes_gcm(bytes(32), bytes(12), c, tag=t) == bytes(16)
+    with pytest.raises(ValueError):
+        codec.aes_gcm(bytes(32), bytes(12), c, tag=bytes(16))
+
+
+def test_gcm_stream_segmentation(codec):
+    # lib/src/cipher/gcm.rs:417-462: KEY = [7; 32], PREFIX = [3; 7], segment size 4
+    key, prefix = bytes([7] * 32), bytes([3] * 7)
+    for plain, nseg in [(b"", 1), (b"abc", 1), (b"abcd", 1), (b"abcdefgh", 2), (b"abcdefghi", 3)]:
+        ct = codec.gcm_stream_encrypt(key, prefix, 4, plain)
+        assert len(ct) == len(plain) + 16 * nseg
+        assert codec.gcm_stream_decrypt(key, prefix, 4, ct) == plain
+    ct = codec.gcm_stream_encrypt(key, prefix, 4, b"abcdefgh")
+    with pytest.raises(ValueError):                            # swapped segments: authentication failure (gcm.rs:762-770)
+        codec.gcm_stream_decrypt(key, prefix, 4, ct[20:40] + ct[:20])
+    with pytest.raises(ValueError):                            # removed final segment (gcm.rs:782-788)
+        codec.gcm_stream_decrypt(key, prefix, 4, ct[:20])
+
+
+@pytest.mark.parametrize("fixture", ["zstd_aes_gcm.pna", "solid_zstd_aes_gcm.pna"])
+def test_reference_gcm_archives_decrypt(codec, pf, fixture):
+    """The reference's GCM STREAM fixtures: stream header (key confirmation), per-entry HKDF stream key bound to the FHED / SHED
+    chunk and the PHSF string, segment tags -- then zstd."""
+    _, items = pf.read_archive(golden(fixture))
+    for it in items:
+        assert it.cipher_mode == 2
+        phsf = [d for ty, d in it.chunks if ty == b"PHSF"][0]
+        km = codec.derive_key_from_phsf(phsf.decode(), b"password")
+        hty, hdat = it.chunks[0]
+        comp = codec.decrypt_payload_gcm(km, it.data, hty, hdat, phsf)
+        plain = codec.decode_payload(it.compression, comp, 16 << 20)
+        if isinstance(it, pf.ParsedSolid):
+            inner = pf.read_solid_inner(plain)
+            assert len(inner) == 9
+            for e in inner:
+                _check_entry(e.name, e.data)
+        else:
+            _check_entry(it.name, plain)
+    it = items[0]
+    phsf = [d for ty, d in it.chunks if ty == b"PHSF"][0]
+    with pytest.raises(ValueError, match="wrong password"):
+        codec.decrypt_payload_gcm(codec.derive_key_from_phsf(phsf.decode(), b"passw0rd"), it.data, it.chunks[0][0], it.chunks[0][1], phsf)
