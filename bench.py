@@ -104,7 +104,7 @@ def main() -> None:
     ap.add_argument("--framing", choices=["archive", "none", "solid"], default="archive",
                     help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only; "
                          "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
-    ap.add_argument("--encrypt", choices=["none", "aes-ctr", "aes-cbc"], default="none",
+    ap.add_argument("--encrypt", choices=["none", "aes-ctr", "aes-cbc", "aes-gcm"], default="none",
                     help="archive framing only: AES-256 cipher stage between compression and chunk CRC (`pna create --aes [ctr|cbc]`)")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive (archive framing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,8 +143,11 @@ def main() -> None:
         # the key a host derives once per WriteOptions (derive_key_material); fixed salt / IV seed: the bench is deterministic
         key = hashlib.pbkdf2_hmac("sha256", b"password", b"saltsaltsalt", 1000, 32)
         iv_seed = hashlib.sha256(b"bench-ivs-%d" % rank).digest()
-        ivs = b"".join(hashlib.sha256(iv_seed + i.to_bytes(4, "little")).digest()[:16] for i in range(n_files))
-        cipher = pna.Cipher(key, "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0", pna.MODE_CTR if args.encrypt == "aes-ctr" else pna.MODE_CBC, ivs=ivs)
+        mode = {"aes-ctr": pna.MODE_CTR, "aes-cbc": pna.MODE_CBC, "aes-gcm": pna.MODE_GCM}[args.encrypt]
+        per = 39 if mode == pna.MODE_GCM else 16               # GCM STREAM: salt(32) || nonce_prefix(7) per entry
+        ivs = b"".join((hashlib.sha256(iv_seed + i.to_bytes(4, "little")).digest() + hashlib.sha256(iv_seed + b"x" + i.to_bytes(4, "little")).digest())[:per]
+                       for i in range(n_files))
+        cipher = pna.Cipher(key, "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0", mode, ivs=ivs)
     if args.framing == "archive":
         dst_cap = pna.archive_enc_bound(algo, names, src_len, cipher)
     elif args.framing == "solid":
@@ -216,7 +219,7 @@ def main() -> None:
     # ---- outside the timed region: decode every entry of this rank's last archive on the device and compare with the inputs
     verified = None
     tm_last = ctx.timing()                                   # stage split of the last timed step (the check below runs more kernels)
-    if args.framing == "archive" and not args.no_verify and args.encrypt != "aes-cbc":
+    if args.framing == "archive" and not args.no_verify and args.encrypt in ("none", "aes-ctr"):
         dst_last = dsts[cur[0] ^ 1] if world > 1 else dsts[0]
         part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
         total, eoff = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst_last.data_ptr(), dst_cap, algo=algo,

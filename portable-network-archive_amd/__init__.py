@@ -49,22 +49,24 @@ class Timing(ctypes.Structure):
 
 
 ENC_NONE, ENC_AES, ENC_CAMELLIA = 0, 1, 2          # Encryption::to_byte()
-MODE_CBC, MODE_CTR = 0, 1                          # CipherMode::to_byte()
+MODE_CBC, MODE_CTR, MODE_GCM = 0, 1, 2             # CipherMode::to_byte()
 
 
 class CipherStruct(ctypes.Structure):
     """pna_gpu_cipher (include/pna_gpu.h)."""
     _fields_ = [("encryption", ctypes.c_int), ("cipher_mode", ctypes.c_int), ("key", ctypes.c_uint8 * 32),
-                ("phsf", ctypes.c_char_p), ("ivs", ctypes.c_void_p)]
+                ("phsf", ctypes.c_char_p), ("ivs", ctypes.c_void_p), ("gcm_segment_size", ctypes.c_uint32)]
 
 
 class Cipher:
     """What WriteCipher carries (lib/src/entry/write.rs:54-57): algorithm, mode, the derived key, the PHSF string; plus the
     per-entry IVs (None = drawn by the library like random::random_vec)."""
 
-    def __init__(self, key: bytes, phsf: str, mode: int = MODE_CTR, encryption: int = ENC_AES, ivs: Optional[bytes] = None):
+    def __init__(self, key: bytes, phsf: str, mode: int = MODE_CTR, encryption: int = ENC_AES, ivs: Optional[bytes] = None,
+                 gcm_segment_size: int = 0):
         assert len(key) == 32
         self.key, self.phsf, self.mode, self.encryption, self.ivs = bytes(key), phsf, mode, encryption, ivs
+        self.gcm_segment_size = gcm_segment_size
         self._keep = None
 
     def struct(self, n: int) -> CipherStruct:
@@ -72,8 +74,9 @@ class Cipher:
         c.encryption, c.cipher_mode = self.encryption, self.mode
         c.key = (ctypes.c_uint8 * 32)(*self.key)
         c.phsf = self.phsf.encode()
+        c.gcm_segment_size = self.gcm_segment_size
         if self.ivs is not None:
-            assert len(self.ivs) >= 16 * n
+            assert len(self.ivs) >= (39 if self.mode == MODE_GCM else 16) * n
             self._keep = ctypes.create_string_buffer(bytes(self.ivs), max(len(self.ivs), 1))
             c.ivs = ctypes.cast(self._keep, ctypes.c_void_p)
         else:

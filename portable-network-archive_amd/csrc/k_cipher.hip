@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t rotl24(uint32_t w) { return __builtin_amdgcn
 
 __global__ __launch_bounds__(CTR_THREADS)
 void k_aes_ctr(const CipherUnit *__restrict__ units, uint32_t nunits, const uint8_t *__restrict__ ivs, const AesTabs *__restrict__ tabs,
-               uint8_t *__restrict__ buf, const AesKey key) {
+               uint8_t *__restrict__ buf, const AesKey key0, const AesKey *__restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sR[];
     const uint32_t tid = threadIdx.x;
     {   // thread t owns table entry (t >> 8, t & 255): one global read, 32 bank copies
@@ -77,6 +77,8 @@ void k_aes_ctr(const CipherUnit *__restrict__ units, uint32_t nunits, const uint
     // the table image is built once per workgroup; the workgroups stride over the units
     for (uint32_t ui = blockIdx.x; ui < nunits; ui += gridDim.x) {
     const CipherUnit u = units[ui];
+    AesKey key = key0;
+    if (keys) key = keys[u.iv_idx];                                   // GCM STREAM: every entry has its own stream key (wave-uniform load)
     const uint8_t *ivp = ivs + (size_t)u.iv_idx * 16;
     // the IV as a 128-bit big-endian number: hi = bytes 0..7, lo = bytes 8..15
     uint64_t iv_hi = 0, iv_lo = 0;
@@ -165,11 +167,122 @@ void k_aes_cbc_enc(const CipherUnit *__restrict__ units, uint32_t n, const uint8
     }
 }
 
-void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st) {
+
+// ------------------------------------------------------------------ GHASH + tag of AES-GCM (NIST SP 800-38D), one workgroup per segment
+// Cipher mode 2 of the reference ("GCM STREAM": GcmEncryptWriter::flush_segment, lib/src/cipher/gcm.rs:45-60 -- AES-256-GCM, 96-bit
+// nonce, no associated data, detached 16-byte tag behind the segment).  The CTR part runs in k_aes_ctr (counter block nonce || 2 ...);
+// this kernel computes  tag = GHASH_H(ciphertext) ^ E(K, nonce || 1)  over the ciphertext where it stands.
+//
+// GHASH = sum_i Y_i * H^(N - i) over the blocks Y_0 .. Y_(N-1) = [zero blocks in front (free), ciphertext blocks, length block],
+// N a multiple of the 256 lanes.  Lane j runs Horner over Y_j, Y_(j+256), ... with the multiplier H^256 (4-bit table method, the
+// table of the 16 nibble multiples of H^256 shared in LDS), then a log-step tree folds the lanes with H, H^2, H^4 .. H^128 (bitwise
+// multiplies) and a last multiply by H finishes the sum.  128-bit values are four big-endian words (word 0 = bytes 0..3); "times x"
+// is a right shift of that number with 0xE1 << 120 folded in when a bit drops out.
+constexpr uint32_t GH_THREADS = 256;
+struct G128 { uint32_t a, b, c, d; };
+__device__ __forceinline__ G128 gx(const G128 &p, const G128 &q) { return G128{p.a ^ q.a, p.b ^ q.b, p.c ^ q.c, p.d ^ q.d}; }
+__device__ __forceinline__ G128 g_mulx(const G128 &v) {
+    const uint32_t carry = (0u - (v.d & 1u)) & 0xE1000000u;
+    return G128{(v.a >> 1) ^ carry, (v.b >> 1) | (v.a << 31), (v.c >> 1) | (v.b << 31), (v.d >> 1) | (v.c << 31)};
+}
+__device__ G128 g_mul_bitwise(const G128 &x, G128 v) {                 // x * v, 128 conditional adds
+    G128 z{0, 0, 0, 0};
+    const uint32_t xw[4] = {x.a, x.b, x.c, x.d};
+    for (int w = 0; w < 4; w++)
+        for (int b = 31; b >= 0; b--) {
+            const uint32_t m = 0u - ((xw[w] >> b) & 1u);
+            z.a ^= v.a & m; z.b ^= v.b & m; z.c ^= v.c & m; z.d ^= v.d & m;
+            v = g_mulx(v);
+        }
+    return z;
+}
+__device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
+
+__global__ __launch_bounds__(GH_THREADS)
+void k_gcm_tag(const GcmEntry *__restrict__ ents, uint8_t *__restrict__ buf) {
+    __shared__ G128 sM[16];                  // nibble multiples of H^256: sM[8] = H^256, sM[4] = H^256 x, sM[2], sM[1], the rest by addition
+    __shared__ uint32_t sR[16];              // what the four bits dropped by a 4-bit shift fold back into the top 16 bits
+    __shared__ G128 sHp[9];                  // H^(2^k), k = 0..8
+    __shared__ G128 sAcc[GH_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const GcmEntry e = ents[blockIdx.x];
+    if (tid == 0) {
+        G128 h{e.h[0], e.h[1], e.h[2], e.h[3]};
+        sHp[0] = h;
+        for (int k = 1; k <= 8; k++) { h = g_mul_bitwise(h, h); sHp[k] = h; }
+        G128 m = h;                                                    // H^256
+        sM[0] = G128{0, 0, 0, 0};
+        sM[8] = m; m = g_mulx(m); sM[4] = m; m = g_mulx(m); sM[2] = m; m = g_mulx(m); sM[1] = m;
+        for (int i = 2; i <= 8; i <<= 1) for (int j = 1; j < i; j++) sM[i + j] = gx(sM[i], sM[j]);
+    }
+    if (tid < 16) {
+        uint32_t r = 0;
+        for (int p = 0; p < 4; p++) if ((tid >> p) & 1) r ^= 0xE100u >> (3 - p);
+        sR[tid] = r << 16;
+    }
+    __syncthreads();
+    const uint32_t m = (e.len + 15) / 16;                              // ciphertext blocks; block m is the length block
+    const uint32_t N = (m + 1 + GH_THREADS - 1) / GH_THREADS * GH_THREADS;
+    const uint32_t pad = N - (m + 1);                                  // zero blocks in front
+    const uint8_t *ct = buf + e.off;
+    G128 acc{0, 0, 0, 0};
+    for (uint32_t i = tid; i < N; i += GH_THREADS) {
+        // acc = acc * H^256 (table method: 32 nibbles of acc, last nibble first), then + Y_i
+        {
+            const uint32_t xw[4] = {acc.a, acc.b, acc.c, acc.d};
+            G128 z{0, 0, 0, 0};
+#pragma unroll
+            for (int n = 0; n < 32; n++) {                             // nibble n: n = 0 is the low nibble of byte 15
+                const uint32_t nib = (xw[3 - (n >> 3)] >> (4 * (n & 7))) & 0xF;
+                if (n) {
+                    const uint32_t rem = z.d & 0xF;
+                    z.d = (z.d >> 4) | (z.c << 28); z.c = (z.c >> 4) | (z.b << 28); z.b = (z.b >> 4) | (z.a << 28); z.a = (z.a >> 4) ^ sR[rem];
+                }
+                const G128 t = sM[nib];
+                z.a ^= t.a; z.b ^= t.b; z.c ^= t.c; z.d ^= t.d;
+            }
+            acc = z;
+        }
+        if (i >= pad) {
+            const uint32_t bi = i - pad;
+            if (bi < m) {
+                const uint64_t o = (uint64_t)bi * 16;
+                if (o + 16 <= e.len) { const U4u v = *(const U4u *)(ct + o); acc.a ^= be32(v.x); acc.b ^= be32(v.y); acc.c ^= be32(v.z); acc.d ^= be32(v.w); }
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t k = 0; o + k < e.len; k++) w[k >> 2] |= (uint32_t)ct[o + k] << (24 - 8 * (k & 3));
+                    acc.a ^= w[0]; acc.b ^= w[1]; acc.c ^= w[2]; acc.d ^= w[3];
+                }
+            } else {                                                   // len(A) = 0 || len(C) in bits
+                const uint64_t bits = (uint64_t)e.len * 8;
+                acc.c ^= (uint32_t)(bits >> 32); acc.d ^= (uint32_t)bits;
+            }
+        }
+    }
+    // fold the lanes: P = sum_j acc_j * H^(255 - j)
+    sAcc[tid] = acc;
+    __syncthreads();
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t st = 1u << k;
+        if ((tid & (2 * st - 1)) == 0) sAcc[tid] = gx(g_mul_bitwise(sAcc[tid], sHp[k]), sAcc[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const G128 s = g_mul_bitwise(sAcc[0], sHp[0]);
+        U4u t; t.x = be32(s.a ^ e.ej0[0]); t.y = be32(s.b ^ e.ej0[1]); t.z = be32(s.c ^ e.ej0[2]); t.w = be32(s.d ^ e.ej0[3]);
+        *(U4u *)(buf + e.off + e.len) = t;
+    }
+}
+
+void launch_gcm_tag(const GcmEntry *ents, uint32_t n, uint8_t *buf, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_gcm_tag, dim3(n), dim3(GH_THREADS), 0, st, ents, buf);
+}
+
+void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, const AesKey *keys, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_aes_ctr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTR_LDS); attr_set = true; }
     // one workgroup per CU at a time (128 KiB of LDS); a few per CU in the grid even out the ragged units
-    if (n) hipLaunchKernelGGL(k_aes_ctr, dim3(n < 1024 ? n : 1024), dim3(CTR_THREADS), CTR_LDS, st, units, n, ivs, tabs, buf, key);
+    if (n) hipLaunchKernelGGL(k_aes_ctr, dim3(n < 1024 ? n : 1024), dim3(CTR_THREADS), CTR_LDS, st, units, n, ivs, tabs, buf, key, keys);
 }
 void launch_aes_cbc_enc(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_aes_cbc_enc, dim3((n + 63) / 64), dim3(64), 0, st, units, n, ivs, tabs, buf, key);

@@ -108,16 +108,18 @@ void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compressi
 // the data-stream prefix and becomes a data piece of its own (prepend_data_prefix, lib/src/entry/builder.rs:62-69,171-188); PHSF
 // stands between the metadata and the data chunks (lib/src/entry.rs:905-910).
 void frame_entry_prefix_enc(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, int encryption, int cipher_mode,
-                            const char *phsf, const uint8_t iv[16]) {
+                            const char *phsf, const uint8_t *prefix, size_t prefix_len) {
     std::vector<uint8_t> h = fhed(0, compression, encryption, cipher_mode, sanitize(name));
     put_chunk(o, "FHED", h.data(), h.size());
     uint8_t b[16]; size_t n = fsiz(raw_size, b); put_chunk(o, "fSIZ", b, n);
     put_chunk(o, "PHSF", (const uint8_t *)phsf, strlen(phsf));
-    put_chunk(o, "FDAT", iv, 16);
+    put_chunk(o, "FDAT", prefix, prefix_len);                  // block IV (CBC / CTR) or the 75-byte GCM stream header: prefix_bytes(), lib/src/entry/write.rs:46-51
     uint8_t head[8]; put_be32(head, 0); memcpy(head + 4, "FDAT", 4);
     o.insert(o.end(), head, head + 8);
 }
-size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 12 + strlen(phsf) + 28 + 8; }
+size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 12 + strlen(phsf) + 12 + 75 + 8; }
+// body of the FHED chunk of a file entry (what the GCM stream key is bound to: entry_context, lib/src/cipher/aead.rs:165-182)
+std::vector<uint8_t> frame_fhed_bytes(const char *name, int compression, int encryption, int cipher_mode) { return fhed(0, compression, encryption, cipher_mode, sanitize(name)); }
 // an inner entry of a solid archive without data: FHED | fSIZ | FEND, no FDAT (FlattenWriter ignores empty writes)
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name) {
     std::vector<uint8_t> h = fhed(0, 0, 0, 1, sanitize(name));
@@ -313,6 +315,20 @@ std::string b64_nopad(const uint8_t *p, size_t n) {
     return o;
 }
 } // namespace
+
+namespace pna {
+void sha256_bytes(const void *a, size_t an, const void *b, size_t bn, uint8_t out[32]) { Sha256 s; s.init(); s.update(a, an); if (bn) s.update(b, bn); s.final(out); }
+// HKDF-SHA-256 with one output block (RFC 5869): hkdf_sha256, lib/src/cipher/aead.rs:151-157
+void hkdf_sha256_32(const void *ikm, size_t ikm_len, const void *salt, size_t salt_len, const void *info, size_t info_len, uint8_t okm[32]) {
+    static const uint8_t zero[32] = {0};
+    Hmac ex; if (salt_len) ex.key((const uint8_t *)salt, salt_len); else ex.key(zero, 32);
+    uint8_t prk[32]; ex.mac(ikm, ikm_len, nullptr, 0, prk);
+    Hmac xp; xp.key(prk, 32);
+    const uint8_t one = 1;
+    std::vector<uint8_t> m((const uint8_t *)info, (const uint8_t *)info + info_len); m.push_back(one);
+    xp.mac(m.data(), m.size(), nullptr, 0, okm);
+}
+}
 
 extern "C" int pna_kdf_pbkdf2_sha256(const void *password, size_t password_len, const void *salt, size_t salt_len, uint32_t rounds,
                                      uint8_t *key, size_t key_len, char *phsf, size_t phsf_cap) {

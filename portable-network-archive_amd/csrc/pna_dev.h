@@ -102,6 +102,13 @@ struct CipherUnit {
     uint32_t iv_idx;         // which 16-byte IV of the IV array belongs to it
 };
 
+struct GcmEntry {            // k_gcm_tag: one GCM segment (this library writes one per entry)
+    uint64_t off;            // first ciphertext byte in the buffer; the 16-byte tag goes to off + len
+    uint32_t len, pad;
+    uint32_t h[4];           // hash subkey H = E(K, 0^128), big-endian words (word 0 = bytes 0..3)
+    uint32_t ej0[4];         // E(K, nonce || 00000001), same form
+};
+
 // zstd decoder (k_zdec): one descriptor per frame
 struct ZFrame {
     uint64_t src_off;        // frame start in the compressed buffer

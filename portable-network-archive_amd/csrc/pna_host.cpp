@@ -57,9 +57,13 @@ void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compressi
 size_t frame_entry_prefix_bound(const char *name);
 uint32_t frame_fend_crc();
 void frame_entry_prefix_enc(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, int encryption, int cipher_mode,
-                            const char *phsf, const uint8_t iv[16]);
+                            const char *phsf, const uint8_t *prefix, size_t prefix_len);
+std::vector<uint8_t> frame_fhed_bytes(const char *name, int compression, int encryption, int cipher_mode);
+void sha256_bytes(const void *a, size_t an, const void *b, size_t bn, uint8_t out[32]);
+void hkdf_sha256_32(const void *ikm, size_t ikm_len, const void *salt, size_t salt_len, const void *info, size_t info_len, uint8_t okm[32]);
+void launch_gcm_tag(const GcmEntry *ents, uint32_t n, uint8_t *buf, hipStream_t st);
 size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf);
-void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st);
+void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, const AesKey *keys, hipStream_t st);
 void launch_aes_cbc_enc(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st);
 void launch_corpus(int kind, uint64_t first_file, uint64_t n_files, uint64_t file_len, uint64_t stride,
                    const uint8_t *vocab, const uint64_t *cum, const uint32_t *phrases, uint8_t *dst, hipStream_t st);
@@ -100,7 +104,7 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
-    DevBuf aes_tabs, ci_units, ci_ivs;                         // cipher stage: round tables, unit descriptors, IVs
+    DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
     hipEvent_t ev_ci[2] = {};
     DevBuf solid_plain, solid_desc, solid_blob, solid_place;   // serialised inner entries of a solid archive
@@ -168,7 +172,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -314,8 +318,54 @@ static int ensure_aes(pna_gpu_ctx *c) {
 static int check_cipher(pna_gpu_ctx *c, const pna_gpu_cipher *ci) {
     if (ci->encryption == PNA_ENC_CAMELLIA) return fail(c, PNA_E_UNSUPPORTED, "Camellia is not offered on the device path");
     if (ci->encryption != PNA_ENC_AES) return fail(c, PNA_E_INVAL, "unknown encryption");
-    if (ci->cipher_mode != PNA_MODE_CTR && ci->cipher_mode != PNA_MODE_CBC) return fail(c, PNA_E_UNSUPPORTED, "cipher mode not offered on the device path");
+    if (ci->cipher_mode != PNA_MODE_CTR && ci->cipher_mode != PNA_MODE_CBC && ci->cipher_mode != PNA_MODE_GCM) return fail(c, PNA_E_UNSUPPORTED, "cipher mode not offered on the device path");
+    if (ci->cipher_mode == PNA_MODE_GCM && ci->gcm_segment_size > (64u << 20)) return fail(c, PNA_E_INVAL, "GCM segment size beyond 64 MiB");
     return PNA_OK;
+}
+// one AES-256 block on the host (FIPS-197 with the round tables of the kernels): hash subkey and E(K, J0) of a GCM segment
+static void aes256_block_host(const AesKey &k, const uint8_t in[16], uint8_t out[16]) {
+    static AesTabs T; static bool ready = false;
+    if (!ready) { build_aes_tabs(T); ready = true; }
+    uint32_t s[4], t[4];
+    for (int i = 0; i < 4; i++) s[i] = ((uint32_t)in[4 * i] | ((uint32_t)in[4 * i + 1] << 8) | ((uint32_t)in[4 * i + 2] << 16) | ((uint32_t)in[4 * i + 3] << 24)) ^ k.rk[i];
+    for (int r = 1; r < 14; r++) {
+        for (int i = 0; i < 4; i++)
+            t[i] = T.Te[0][s[i] & 0xFF] ^ T.Te[1][(s[(i + 1) & 3] >> 8) & 0xFF] ^ T.Te[2][(s[(i + 2) & 3] >> 16) & 0xFF] ^ T.Te[3][s[(i + 3) & 3] >> 24] ^ k.rk[4 * r + i];
+        memcpy(s, t, sizeof s);
+    }
+    auto sb = [&](uint32_t v) { return (T.Te[0][v & 0xFF] >> 8) & 0xFF; };
+    for (int i = 0; i < 4; i++)
+        t[i] = (sb(s[i]) | (sb(s[(i + 1) & 3] >> 8) << 8) | (sb(s[(i + 2) & 3] >> 16) << 16) | (sb(s[(i + 3) & 3] >> 24) << 24)) ^ k.rk[56 + i];
+    for (int i = 0; i < 4; i++) { out[4 * i] = (uint8_t)t[i]; out[4 * i + 1] = (uint8_t)(t[i] >> 8); out[4 * i + 2] = (uint8_t)(t[i] >> 16); out[4 * i + 3] = (uint8_t)(t[i] >> 24); }
+}
+// GCM STREAM material of one entry (lib/src/entry/write.rs:81-107 to_hashed; lib/src/cipher/aead.rs): stream header, stream key bound to
+// the FHED chunk and the PHSF string, round keys, hash subkey, E(K, J0) of the (single, final) segment 0 and its first counter block.
+struct GcmMaterial { uint8_t header[75]; AesKey rk; uint32_t h[4], ej0[4]; uint8_t ctr_iv[16]; };
+static void gcm_entry_material(const pna_gpu_cipher *ci, const uint8_t kc[32], const uint8_t phsf_hash[32], const uint8_t salt_prefix[39],
+                               uint32_t seg_size, const char *name, int compression, GcmMaterial &m) {
+    memcpy(m.header, salt_prefix, 39);
+    m.header[39] = (uint8_t)(seg_size >> 24); m.header[40] = (uint8_t)(seg_size >> 16); m.header[41] = (uint8_t)(seg_size >> 8); m.header[42] = (uint8_t)seg_size;
+    memcpy(m.header + 43, kc, 32);
+    const std::vector<uint8_t> fh = frame_fhed_bytes(name, compression, ci->encryption, PNA_MODE_GCM);
+    uint8_t info[88];
+    memcpy(info, "PNA-STREAM-v1", 13);
+    sha256_bytes("FHED", 4, fh.data(), fh.size(), info + 13);
+    memcpy(info + 45, phsf_hash, 32);
+    memcpy(info + 77, salt_prefix + 32, 7);
+    memcpy(info + 84, m.header + 39, 4);
+    uint8_t ks[32];
+    hkdf_sha256_32(ci->key, 32, salt_prefix, 32, info, 88, ks);
+    aes256_expand(ks, m.rk);
+    uint8_t zero[16] = {0}, hb[16], j0[16], eb[16];
+    aes256_block_host(m.rk, zero, hb);
+    memcpy(j0, salt_prefix + 32, 7); j0[7] = j0[8] = j0[9] = j0[10] = 0; j0[11] = 1;      // segment_nonce(prefix, 0, final)
+    j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+    aes256_block_host(m.rk, j0, eb);
+    for (int i = 0; i < 4; i++) {
+        m.h[i] = ((uint32_t)hb[4 * i] << 24) | ((uint32_t)hb[4 * i + 1] << 16) | ((uint32_t)hb[4 * i + 2] << 8) | hb[4 * i + 3];
+        m.ej0[i] = ((uint32_t)eb[4 * i] << 24) | ((uint32_t)eb[4 * i + 1] << 16) | ((uint32_t)eb[4 * i + 2] << 8) | eb[4 * i + 3];
+    }
+    memcpy(m.ctr_iv, j0, 16); m.ctr_iv[15] = 2;                                           // first data block: counter 2
 }
 // the per-entry IVs of a cipher job: the caller's, or random ones (random::random_vec(block_size) per entry, lib/src/entry/write.rs:108-112)
 static int resolve_ivs(pna_gpu_ctx *c, const pna_gpu_cipher *cipher, size_t n, std::vector<uint8_t> &own, const uint8_t **ivs) {
@@ -323,9 +373,10 @@ static int resolve_ivs(pna_gpu_ctx *c, const pna_gpu_cipher *cipher, size_t n, s
     if (!cipher->phsf) return fail(c, PNA_E_INVAL, "cipher without a PHSF string");
     *ivs = cipher->ivs;
     if (*ivs) return PNA_OK;
-    own.resize(n * 16 + 16);
-    for (size_t o = 0; o < n * 16;) {
-        const ssize_t got = getrandom(own.data() + o, std::min<size_t>(n * 16 - o, 1u << 20), 0);
+    const size_t per = cipher->cipher_mode == PNA_MODE_GCM ? 39 : 16;  // GCM: salt(32) || nonce_prefix(7) per stream (to_hashed, write.rs:83-86)
+    own.resize(n * per + 16);
+    for (size_t o = 0; o < n * per;) {
+        const ssize_t got = getrandom(own.data() + o, std::min<size_t>(n * per - o, 1u << 20), 0);
         if (got <= 0) return fail(c, PNA_E_INVAL, "getrandom failed");
         o += (size_t)got;
     }
@@ -417,6 +468,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     // while the kernels run: the name-dependent part of every entry record (FHED and fSIZ chunks with their CRCs)
     FrameDesc *fds = nullptr; uint8_t *blob = nullptr; uint64_t *segdst = nullptr; size_t blob_len = 0;
     const bool solid = fj && fj->solid;
+    const bool gcm = fj && fj->cipher && fj->cipher->cipher_mode == PNA_MODE_GCM;
+    const uint32_t gcm_seg = gcm ? (fj->cipher->gcm_segment_size ? fj->cipher->gcm_segment_size : (64u << 20)) : 0u;
+    std::vector<GcmMaterial> gmat; std::vector<GcmEntry> gents;
     size_t nunit = e1 - e0;                                    // framed units: entries, or the segments of the solid stream
     if (solid) {
         if (e1 - e0 != 1) return fail(c, PNA_E_INVAL, "a solid stream is one entry");
@@ -433,9 +487,26 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         if (c->h_desc.ensure(((e1 - e0) + nseg) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * (size_t)nseg + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing staging");
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
+        if (gcm) {
+            // GCM STREAM: per entry a stream header, an HKDF stream key bound to its FHED chunk, round keys, hash subkey, E(K, J0);
+            // a few host threads share the entries (SHA-256 / HKDF / key schedule: a few microseconds each) while k_lz runs
+            gmat.resize(e1 - e0);
+            uint8_t kc[32], ph[32];
+            hkdf_sha256_32(fj->cipher->key, 32, nullptr, 0, "PNA-KC-v1", 9, kc);               // key_confirmation, aead.rs:161-163
+            sha256_bytes(fj->cipher->phsf, strlen(fj->cipher->phsf), nullptr, 0, ph);
+            const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (e1 - e0) / 256));
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    for (size_t e = e0 + t; e < e1; e += nt)
+                        gcm_entry_material(fj->cipher, kc, ph, fj->ivs + 39 * e, gcm_seg, fj->names[e], algo, gmat[e - e0]);
+                });
+            for (auto &x : th) x.join();
+        }
         for (size_t e = e0; e < e1; e++) {
             tmp.clear();
-            if (fj->cipher) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e);
+            if (gcm) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, PNA_MODE_GCM, fj->cipher->phsf, gmat[e - e0].header, 75);
+            else if (fj->cipher) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e, 16);
             else frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
             memcpy(blob + blob_len, tmp.data(), tmp.size());
             fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
@@ -497,6 +568,15 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                             if (g1 < s1 || !first) return fail(c, PNA_E_UNSUPPORTED, "CBC entry beyond one FDAT chunk");
                             cunits.push_back(CipherUnit{p0, 0, (uint32_t)plen, (uint32_t)(e - e0)});
                             plen = (plen / 16 + 1) * 16;
+                        } else if (gcm) {
+                            // one final GCM segment per entry: ciphertext, then its 16-byte tag (GcmEncryptWriter::finish, gcm.rs:62-66)
+                            if (g1 < s1 || !first || plen > gcm_seg) return fail(c, PNA_E_UNSUPPORTED, "GCM entry beyond one stream segment");
+                            for (uint64_t o = 0; o < plen; o += CTR_UNIT)
+                                cunits.push_back(CipherUnit{p0 + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
+                            GcmEntry ge{p0, (uint32_t)plen, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                            memcpy(ge.h, gmat[e - e0].h, 16); memcpy(ge.ej0, gmat[e - e0].ej0, 16);
+                            gents.push_back(ge);
+                            plen += 16;
                         } else {
                             for (uint64_t o = 0; o < plen; o += CTR_UNIT)
                                 cunits.push_back(CipherUnit{p0 + o, cpos + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
@@ -542,10 +622,23 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         if (c->ci_units.ensure(cunits.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure((e1 - e0) * 16 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
         AesKey key; aes256_expand(fj->cipher->key, key);
         HIPCHK(c, hipMemcpyAsync(c->ci_units.p, cunits.data(), cunits.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, fj->ivs + 16 * e0, (e1 - e0) * 16, hipMemcpyHostToDevice, st));
+        std::vector<uint8_t> giv; std::vector<AesKey> gkeys;
+        if (gcm) {
+            if (solid) return fail(c, PNA_E_UNSUPPORTED, "GCM on the solid device path");
+            giv.resize((e1 - e0) * 16); gkeys.resize(e1 - e0);
+            for (size_t i = 0; i < e1 - e0; i++) { memcpy(&giv[16 * i], gmat[i].ctr_iv, 16); gkeys[i] = gmat[i].rk; }
+            if (c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) || c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+            HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, giv.data(), giv.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->ci_keys.p, gkeys.data(), gkeys.size() * sizeof(AesKey), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->ci_gcm.p, gents.data(), gents.size() * sizeof(GcmEntry), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));                  // the host vectors above go out of scope
+        } else HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, fj->ivs + 16 * e0, (e1 - e0) * 16, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipEventRecord(c->ev_ci[0], st));
-        if (fj->cipher->cipher_mode == PNA_MODE_CTR)
-            launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, st);
+        if (gcm) {
+            launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, (const AesKey *)c->ci_keys.p, st);
+            launch_gcm_tag((const GcmEntry *)c->ci_gcm.p, (uint32_t)gents.size(), d_dst, st);
+        } else if (fj->cipher->cipher_mode == PNA_MODE_CTR)
+            launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, nullptr, st);
         else
             launch_aes_cbc_enc((const CipherUnit *)c->ci_units.p, (uint32_t)cunits.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, d_dst, key, st);
         HIPCHK(c, hipEventRecord(c->ev_ci[1], st));
@@ -654,7 +747,7 @@ extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int 
 
 extern "C" size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher) {
     size_t b = pna_gpu_archive_bound(algo, n, names, src_len);
-    if (cipher && cipher->encryption != PNA_ENC_NONE && cipher->phsf) b += n * (12 + strlen(cipher->phsf) + 28 + 16);   // PHSF, FDAT(iv), CBC padding
+    if (cipher && cipher->encryption != PNA_ENC_NONE && cipher->phsf) b += n * (12 + strlen(cipher->phsf) + 12 + 75 + 16);   // PHSF, FDAT(iv | stream header), CBC padding / GCM tag
     return b;
 }
 
@@ -712,6 +805,7 @@ extern "C" int pna_gpu_cipher_apply_device(pna_gpu_ctx *c, const pna_gpu_cipher 
     if (!c || !cipher || (n && (!d_buf || !off || !len || !cipher->ivs))) return fail(c, PNA_E_INVAL, "null argument");
     int rc = check_cipher(c, cipher); if (rc) return rc;
     const bool cbc = cipher->cipher_mode == PNA_MODE_CBC;
+    if (cipher->cipher_mode == PNA_MODE_GCM) return fail(c, PNA_E_UNSUPPORTED, "GCM STREAM is offered by the archive entry points only");
     if (cbc && decrypt) return fail(c, PNA_E_UNSUPPORTED, "CBC decryption is not offered on the device path");
     if (n == 0) return PNA_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -730,7 +824,7 @@ extern "C" int pna_gpu_cipher_apply_device(pna_gpu_ctx *c, const pna_gpu_cipher 
     HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, cipher->ivs, n * 16, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev_ci[0], st));
     if (cbc) launch_aes_cbc_enc((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)d_buf, key, st);
-    else launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)d_buf, key, st);
+    else launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)d_buf, key, nullptr, st);
     HIPCHK(c, hipEventRecord(c->ev_ci[1], st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
@@ -772,6 +866,7 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
+    if (cipher && cipher->cipher_mode == PNA_MODE_GCM) return fail(c, PNA_E_UNSUPPORTED, "GCM on the solid device path");
     if (cipher) { int rc0 = resolve_ivs(c, cipher, 1, own_ivs, &ivs); if (rc0) return rc0; }
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");

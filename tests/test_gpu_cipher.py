@@ -159,7 +159,10 @@ def test_cipher_error_codes(gpu_ctx, pna):
         gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, pna.MODE_CTR, encryption=pna.ENC_CAMELLIA, ivs=bytes(16)), buf.data_ptr(), [0], [16])
     assert ei.value.code == -7
     with pytest.raises(pna.PnaGpuError) as ei:
-        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, 2, ivs=bytes(16)), buf.data_ptr(), [0], [16])      # GCM
+        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, pna.MODE_GCM, ivs=bytes(39)), buf.data_ptr(), [0], [16])   # GCM: archive entry points only
+    assert ei.value.code == -7
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.cipher_apply_device(pna.Cipher(KEY, PHSF, 3, ivs=bytes(16)), buf.data_ptr(), [0], [16])              # unknown mode
     assert ei.value.code == -7
 
 
@@ -241,4 +244,66 @@ def test_encrypted_solid_archive_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
     assert [e.name for e in inner] == names and [e.data for e in inner] == ents
     with pytest.raises(pna.PnaGpuError) as ei:
         gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=pna.Cipher(KEY, PHSF, pna.MODE_CBC, ivs=iv))
+    assert ei.value.code == -7
+
+
+@pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
+def test_gcm_stream_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec, algo_name):
+    """Cipher mode 2 (GCM STREAM) in HBM: per-entry stream header + HKDF stream key on the host, CTR keystream and GHASH + tag on the
+    device.  Byte-exact against the oracle (stream header, one final segment: ciphertext || tag) and read back the reference's way
+    (key confirmation, stream key bound to FHED + PHSF, tag verification)."""
+    import torch
+    algo = pna.ALGO_ZSTD if algo_name == "zstd" else pna.ALGO_DEFLATE
+    lens = [0, 1, 5, 15, 16, 17, 4095, 16373, 70001, 131073, 300000, (1 << 20) + 1, 2500000, 12, 65536, 4081 * 16]
+    ents = [codec.corpus_file(i % 2, 250 + i, n) if n else b"" for i, n in enumerate(lens)]
+    ents[9] = codec.corpus_file(2, 5, lens[9])                # incompressible: ciphertext longer than 256 lanes x 16 B x several rounds
+    names = [f"g{i % 3}/f{i:03d}.bin" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    k_master = hashlib.pbkdf2_hmac("sha256", b"password", b"saltsaltsalt", 1000, 32)
+    sp = os.urandom(39 * len(lens))
+    seg = 64 << 20
+    ci = pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp)
+    cap = pna.archive_enc_bound(algo, names, lens, ci)
+    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+    got = dst[:total].cpu().numpy().tobytes()
+    assert gpu_ctx.timing().ms_cipher > 0
+    payloads = gpu_ctx.compress_batch(ents, algo=algo)
+    want = bytearray(pf.write_archive_header())
+    for i, (nm, pl, e) in enumerate(zip(names, payloads, ents)):
+        salt, prefix = sp[39 * i:39 * i + 32], sp[39 * i + 32:39 * i + 39]
+        fhed = pf.entry_header_bytes(pf.KIND_FILE, algo, 1, 2, pf.sanitize_name(nm))
+        ks = codec.derive_stream_key(k_master, salt, prefix, seg, b"FHED", fhed, PHSF.encode())
+        want += pf.write_encrypted_file_entry(algo, 1, 2, pf.sanitize_name(nm), PHSF, codec.stream_header_bytes(salt, prefix, seg, k_master),
+                                              codec.gcm_stream_encrypt(ks, prefix, seg, pl), len(e))
+    want += pf.finalize_archive()
+    assert len(got) == len(want) and got == bytes(want)
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+    _, items = pf.read_archive(got)
+    for it, e in zip(items, ents):
+        assert (it.encryption, it.cipher_mode, it.raw_file_size) == (1, 2, len(e))
+        phsf = [d for ty, d in it.chunks if ty == b"PHSF"][0]
+        comp = codec.decrypt_payload_gcm(k_master, it.data, it.chunks[0][0], it.chunks[0][1], phsf)
+        assert codec.decode_payload(algo, comp, len(e) + 64) == e
+    # library-drawn salts / prefixes through the host pipeline; a tampered byte is an authentication failure
+    arc = pna.create_archive_encrypted(gpu_ctx, names, ents, b"password", algo=algo, mode=pna.MODE_GCM, rounds=1000)
+    _, items = pf.read_archive(arc)
+    assert len({it.data[:39] for it in items}) == len(items)
+    phsf = [d for ty, d in items[0].chunks if ty == b"PHSF"][0]
+    km = codec.derive_key_from_phsf(phsf.decode(), b"password")
+    for it, e in zip(items, ents):
+        assert codec.decode_payload(algo, codec.decrypt_payload_gcm(km, it.data, it.chunks[0][0], it.chunks[0][1], phsf), len(e) + 64) == e
+    bad = bytearray(items[8].data); bad[100] ^= 1
+    with pytest.raises(ValueError, match="authentication"):
+        codec.decrypt_payload_gcm(km, bytes(bad), items[8].chunks[0][0], items[8].chunks[0][1], phsf)
+    # an entry beyond one stream segment is refused, not mis-framed
+    with pytest.raises(pna.PnaGpuError) as ei:
+        gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo,
+                                      cipher=pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp, gcm_segment_size=65536))
     assert ei.value.code == -7
