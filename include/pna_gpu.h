@@ -196,6 +196,18 @@ int  pna_gpu_decompress_batch_device(pna_gpu_ctx *ctx, int algo, size_t n, const
                                      const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
                                      void *hip_stream);
 
+/* Read-side driver for non-solid archives in host memory: `pna extract` / `pna verify` (cli/src/command/extract.rs:594-640,
+ * verify.rs:140-188; Archive::read_header + entries, lib/src/archive/read.rs:22-66; read_chunk's mandatory CRC check, lib/src/io.rs:117-149;
+ * decrypt_reader / decompress_reader, lib/src/entry/read.rs:59-104,171-190).  The chunk walk and the small chunks' CRCs are host work;
+ * the FDAT CRC-32s, the gather of every entry's data pieces, AES-CTR decryption (key from a "$pbkdf2-sha256$..." PHSF string and
+ * `password`) and zstd / deflate / store decoding run on the device.  cb is called once per entry in archive order (kind =
+ * DataKind::to_byte(): 0 file, 1 directory, ...); `data` is valid during the call.  PNA_E_INVAL: structural damage, CRC mismatch, corrupt
+ * stream; PNA_E_UNSUPPORTED: solid / multipart archives, xz, Argon2 password hashes, cipher modes other than CTR, compressed entries
+ * without fSIZ. */
+typedef int (*pna_entry_fn)(void *user, size_t index, const char *name, int kind, const void *data, size_t len);
+int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t archive_len, const void *password, size_t password_len,
+                                  pna_entry_fn cb, void *user);
+
 /* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
  * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write). */
 typedef struct pna_gpu_stream pna_gpu_stream;

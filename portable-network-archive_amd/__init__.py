@@ -85,6 +85,7 @@ class Cipher:
 
 
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)
 
 _lib = None
 
@@ -97,7 +98,7 @@ EXPORTS = [
     "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
-    "pna_gpu_create_solid_archive_enc_device",
+    "pna_gpu_create_solid_archive_enc_device", "pna_gpu_extract_archive_host",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -208,6 +209,8 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_enc_host.restype = ctypes.c_int
     L.pna_gpu_create_archive_enc_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                                   ctypes.POINTER(sz), ctypes.POINTER(CipherStruct), SINK_FN, vp]
+    L.pna_gpu_extract_archive_host.restype = ctypes.c_int
+    L.pna_gpu_extract_archive_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ENTRY_FN, vp]
     L.pna_kdf_pbkdf2_sha256.restype = ctypes.c_int
     L.pna_kdf_pbkdf2_sha256.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
     L.pna_create_archive_encrypted.restype = ctypes.c_int
@@ -578,3 +581,18 @@ def create_archive_encrypted(ctx: Context, names: Sequence[str], entries: Sequen
     if rc:
         raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
     return bytes(out)
+
+
+def extract_archive(ctx: Context, archive: bytes, password: Optional[bytes] = None):
+    """`pna extract` for a non-solid archive (pna_gpu_extract_archive_host): returns [(name, kind, data)] in archive order; chunk CRCs
+    are verified (data chunks on the device), entries are decrypted (AES-CTR) and decoded on the device."""
+    out = []
+
+    def _cb(_u, idx, name, kind, data, n):
+        out.append((name.decode("utf-8"), kind, ctypes.string_at(data, n) if n else b""))
+        return 0
+    cb = ENTRY_FN(_cb)
+    buf = archive if isinstance(archive, bytes) else bytes(archive)
+    rc = ctx._L.pna_gpu_extract_archive_host(ctx._h, buf, len(buf), password, len(password) if password else 0, cb, None)
+    ctx._check(rc)
+    return out

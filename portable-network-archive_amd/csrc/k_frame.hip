@@ -37,14 +37,15 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
 
 __global__ __launch_bounds__(FR_THREADS)
 void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct,
-             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend) {
+             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t *__restrict__ verify) {
     __shared__ uint32_t sT[4][256], sZ[4][256];
     __shared__ uint32_t tile[FR_TILE_DW + FR_TILE_DW / 16 + 8];
     __shared__ uint32_t part[FR_THREADS];
     const uint32_t tid = threadIdx.x;
     const FrameDesc d = fd[blockIdx.x];
     for (uint32_t i = tid; i < 1024; i += FR_THREADS) { (&sT[0][0])[i] = (&ct->T[0][0])[i]; (&sZ[0][0])[i] = (&ct->Z[0][0])[i]; }
-    for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
+    // verify != NULL: read side (read_chunk, lib/src/io.rs:117-149) -- nothing is written, the CRC is compared with the stored one
+    if (!verify) for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
     if (d.pad & 1) return;                                           // record without a data chunk: the prefix is all of it
 
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
@@ -100,6 +101,14 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         if ((tid & (2 * st - 1)) == 0) part[tid] = gf2_mulmod(ct->sh[j], part[tid]) ^ part[tid + st];
         __syncthreads();
     }
+    if (verify) {
+        if (tid == 0) {
+            const uint8_t *q = dst + pay + d.payload_len;
+            const uint32_t stored = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+            if (stored != ~part[0]) { atomicAdd(&verify[0], 1u); atomicMin(&verify[1], blockIdx.x); }
+        }
+        return;
+    }
     if (tid < ((with_fend && !(d.pad & 2)) ? 16u : 4u)) {                // pad bit 1: another data chunk of the same entry follows, no FEND yet
         const uint32_t crc = ~part[0];
         // crc BE | 00 00 00 00 | "FEND" | crc("FEND") BE
@@ -146,7 +155,31 @@ void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, 
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
-    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u);
+    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u, (uint32_t *)nullptr);
+}
+// Read side: CRC-32 of n data chunks of type `ty` where they stand in buf (FrameDesc: arc_off = chunk start, prefix_len = 8,
+// payload_len = chunk length); verify[0] counts mismatches, verify[1] keeps the lowest failing descriptor index.
+void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st) {
+    const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
+    if (n) hipLaunchKernelGGL(k_frame, dim3(n), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, verify);
+}
+
+// ------------------------------------------------------------------ k_gather : byte ranges from arbitrary offsets to 16-byte aligned ones
+// The reverse of k_place (read side): piece p = src[src_off .. +len) goes to dst[dst_off .. +len); dst_off is a multiple of 16 only for
+// the first piece of a stream, so both sides are treated as unaligned 16-byte accesses, the tail bytewise.
+__global__ __launch_bounds__(256)
+void k_gather(const PlaceDesc *__restrict__ pd, const uint8_t *__restrict__ src, uint8_t *__restrict__ dst) {
+    struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
+    const PlaceDesc d = pd[blockIdx.x];
+    const uint8_t *s = src + d.src_off;
+    uint8_t *o = dst + d.dst_off;
+    const uint32_t n16 = d.len >> 4;
+    for (uint32_t i = threadIdx.x; i < n16; i += 256) *(U4 *)(o + 16 * (size_t)i) = *(const U4 *)(s + 16 * (size_t)i);
+    const uint32_t done = n16 << 4;
+    if (threadIdx.x < d.len - done) o[done + threadIdx.x] = s[done + threadIdx.x];
+}
+void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_gather, dim3(n), dim3(256), 0, st, (const PlaceDesc *)pd, src, dst);
 }
 
 } // namespace pna

@@ -1164,6 +1164,28 @@ void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks,
 // An entry's payload is one or more concatenated frames (zstd-rs' Decoder reads them all).  Frames carry no content size here,
 // so the split of the entry's raw size over its frames follows this repository's encoder: every frame but the last holds
 // SEG_SIZE bytes (a single-frame entry -- what the reference writes -- holds all of it); k_zdec verifies the sizes.
+// walk one frame starting at p[ip]: header, blocks, optional checksum; returns its end or 0 when it is malformed / truncated
+__device__ uint64_t zscan_frame_end(const uint8_t *p, uint64_t ip, uint64_t len) {
+    uint64_t q = ip;
+    if (q + 6 > len) return 0;
+    const uint32_t magic = p[q] | (p[q + 1] << 8) | (p[q + 2] << 16) | ((uint32_t)p[q + 3] << 24);
+    if (magic != 0xFD2FB528u) return 0;
+    const uint32_t fhd = p[q + 4];
+    const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+    q += 5 + (single ? 0 : 1) + (dict == 0 ? 0 : (dict == 1 ? 1 : (dict == 2 ? 2 : 4)));
+    q += fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+    for (;;) {
+        if (q + 3 > len) return 0;
+        const uint32_t bh = p[q] | (p[q + 1] << 8) | ((uint32_t)p[q + 2] << 16);
+        const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+        q += 3 + (type == 1 ? 1 : size);
+        if (type == 3 || q > len) return 0;
+        if (bh & 1) break;
+    }
+    if ((fhd >> 2) & 1) q += 4;
+    return q > len ? 0 : q;
+}
+
 __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8_t *__restrict__ src, ZFrame *__restrict__ frames) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -1171,33 +1193,25 @@ __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8
     const uint8_t *p = src + en.src_off;
     const uint64_t len = en.src_len;
     const uint32_t nfr = en.n_frames;
+    // ONE frame that holds the whole entry, however large (what the reference writes: libzstd streaming, one frame per entry): it
+    // gets all of raw_len and goes to the one-workgroup-per-frame kernel (the bounded per-frame resources are sized for SEG_SIZE);
+    // the other frame slots planned for the entry are void
+    if (nfr > 1 && zscan_frame_end(p, 0, len) == len) {
+        ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = (uint32_t)len; fr.out_len = 0;
+        fr.dst_len = (uint32_t)en.raw_len; fr.status = (en.raw_len > 0xFFFFFFFFull || len > 0xFFFFFFFFull) ? 1u : 2u;
+        frames[en.first_frame] = fr;
+        fr.src_len = 0; fr.dst_len = 0; fr.status = 4;              // ZD_VOID
+        for (uint32_t g = 1; g < nfr; g++) frames[en.first_frame + g] = fr;
+        return;
+    }
     uint64_t ip = 0;
     for (uint32_t f = 0; f < nfr; f++) {
         ZFrame fr; fr.src_off = en.src_off + ip; fr.dst_off = en.dst_off + (uint64_t)f * SEG_SIZE; fr.status = 0; fr.out_len = 0;
         const uint64_t done = (uint64_t)f * SEG_SIZE;
         fr.dst_len = (uint32_t)(en.raw_len - done < SEG_SIZE || f + 1 == nfr ? (en.raw_len > done ? en.raw_len - done : 0) : SEG_SIZE);
         if (en.raw_len - done > 0xFFFFFFFFull && f + 1 == nfr) fr.status = 2;
-        // walk the frame: header, blocks, optional checksum
-        uint64_t q = ip; bool ok = q + 6 <= len;
-        if (ok) {
-            const uint32_t magic = p[q] | (p[q + 1] << 8) | (p[q + 2] << 16) | ((uint32_t)p[q + 3] << 24);
-            ok = magic == 0xFD2FB528u;
-            const uint32_t fhd = p[q + 4];
-            const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
-            q += 5 + (single ? 0 : 1) + (dict == 0 ? 0 : (dict == 1 ? 1 : (dict == 2 ? 2 : 4)));
-            q += fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
-            while (ok) {
-                if (q + 3 > len) { ok = false; break; }
-                const uint32_t bh = p[q] | (p[q + 1] << 8) | ((uint32_t)p[q + 2] << 16);
-                const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
-                q += 3 + (type == 1 ? 1 : size);
-                if (type == 3 || q > len) { ok = false; break; }
-                if (bh & 1) break;
-            }
-            if (ok && ((fhd >> 2) & 1)) q += 4;
-            if (q > len) ok = false;
-        }
-        if (!ok) { fr.status = 1; fr.src_len = 0; frames[en.first_frame + f] = fr; for (uint32_t g = f + 1; g < nfr; g++) { fr.src_off = 0; frames[en.first_frame + g] = fr; } return; }
+        const uint64_t q = zscan_frame_end(p, ip, len);
+        if (!q) { fr.status = 1; fr.src_len = 0; frames[en.first_frame + f] = fr; for (uint32_t g = f + 1; g < nfr; g++) { fr.src_off = 0; frames[en.first_frame + g] = fr; } return; }
         fr.src_len = (uint32_t)(q - ip);
         frames[en.first_frame + f] = fr;
         ip = q;

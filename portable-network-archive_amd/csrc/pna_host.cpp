@@ -14,6 +14,7 @@
 #include <sys/random.h>
 #include "pna_dev.h"
 #include "../../include/pna_gpu.h"
+#include "../../include/pna_archive.h"
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
@@ -36,6 +37,8 @@ void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
@@ -104,6 +107,7 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
+    DevBuf x_arc, x_pk, x_raw, x_desc, x_place, x_flag;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
     DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
     hipEvent_t ev_ci[2] = {};
@@ -172,7 +176,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw, &c->x_desc, &c->x_place, &c->x_flag, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -1098,6 +1102,187 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
     return PNA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Read side driver: `pna extract` / `pna verify` for non-solid archives (cli/src/command/extract.rs:594-640, verify.rs:140-188;
+// Archive::read_header + next_raw_item, lib/src/archive/read.rs:22-66; TryFrom<RawEntry>, lib/src/entry.rs:757-885; read_chunk with its
+// mandatory CRC check, lib/src/io.rs:117-149; decrypt_reader / decompress_reader, lib/src/entry/read.rs:59-104,171-190).
+// The chunk walk and the small chunks' CRCs are host work; the data chunks' CRC-32 (k_frame in verify mode), the gather of every
+// entry's data pieces into one stream (k_gather), AES-CTR decryption and the zstd / deflate decoding run on the device.
+namespace {
+struct XPiece { uint64_t off; uint32_t len; };
+struct XEntry {
+    std::string name; int kind = 0, compression = 0, encryption = 0, cipher_mode = 0;
+    bool has_size = false; uint64_t raw_size = 0; std::string phsf;
+    std::vector<XPiece> pieces; uint64_t stream_len = 0;
+    uint64_t pk_off = 0, pay_len = 0, raw_off = 0;            // payload (prefix stripped) in the packed buffer; decoded bytes in the raw buffer
+};
+uint32_t rd_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+int b64_val(char ch) {
+    if (ch >= 'A' && ch <= 'Z') return ch - 'A'; if (ch >= 'a' && ch <= 'z') return ch - 'a' + 26;
+    if (ch >= '0' && ch <= '9') return ch - '0' + 52; if (ch == '+') return 62; if (ch == '/') return 63; return -1;
+}
+bool b64_decode_nopad(const std::string &s, std::vector<uint8_t> &out) {
+    uint32_t acc = 0; int bits = 0;
+    for (char ch : s) { const int v = b64_val(ch); if (v < 0) return false; acc = (acc << 6) | (uint32_t)v; bits += 6; if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); } }
+    return true;
+}
+}
+
+extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive, size_t archive_len, const void *password, size_t password_len,
+                                            pna_entry_fn cb, void *user) {
+    if (!c || !archive || !cb || (!password && password_len)) return fail(c, PNA_E_INVAL, "null argument");
+    const uint8_t *a = (const uint8_t *)archive;
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+    if (archive_len < 8 + 20 + 12 || memcmp(a, sig, 8) != 0) return fail(c, PNA_E_INVAL, "not a PNA archive");
+    // ---- 1. chunk walk (host): structure, small-chunk CRCs, data-chunk descriptors
+    std::vector<XEntry> ents; std::vector<FrameDesc> dchunks;
+    XEntry cur; bool in_entry = false, seen_ahed = false, ended = false;
+    size_t pos = 8;
+    while (pos < archive_len) {
+        if (archive_len - pos < 12) return fail(c, PNA_E_INVAL, "truncated chunk header");
+        const uint32_t len = rd_be32(a + pos); const uint8_t *ty = a + pos + 4, *data = a + pos + 8;
+        if (archive_len - pos - 12 < len) return fail(c, PNA_E_INVAL, "truncated chunk body");
+        const bool is_fdat = memcmp(ty, "FDAT", 4) == 0;
+        if (is_fdat) { if (len >= 0xFFFFFFF0u) return fail(c, PNA_E_INVAL, "data chunk too long"); dchunks.push_back(FrameDesc{pos, len, 0, 8, 0}); }
+        else if (pna_crc32(pna_crc32(0, ty, 4), data, len) != rd_be32(data + len)) return fail(c, PNA_E_INVAL, "chunk CRC mismatch");
+        if (!seen_ahed) {
+            if (memcmp(ty, "AHED", 4) != 0 || len != 8 || data[0] != 0) return fail(c, PNA_E_INVAL, "first chunk must be AHED (major version 0)");
+            seen_ahed = true;
+        } else if (memcmp(ty, "AEND", 4) == 0) { ended = true; break; }
+        else if (memcmp(ty, "ANXT", 4) == 0) return fail(c, PNA_E_UNSUPPORTED, "multipart archives are not read by this driver");
+        else if (memcmp(ty, "SHED", 4) == 0 || memcmp(ty, "SDAT", 4) == 0 || memcmp(ty, "SEND", 4) == 0)
+            return fail(c, PNA_E_UNSUPPORTED, "solid archives are not read by this driver (the stream carries no size)");
+        else if (memcmp(ty, "FHED", 4) == 0) {
+            if (in_entry || len < 6 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad entry header");
+            cur = XEntry(); in_entry = true;
+            cur.kind = data[2]; cur.compression = data[3]; cur.encryption = data[4]; cur.cipher_mode = data[5];
+            cur.name.assign((const char *)data + 6, len - 6);
+        } else if (!in_entry) { if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk between entries"); }
+        else if (is_fdat) { cur.pieces.push_back(XPiece{pos + 8, len}); cur.stream_len += len; }
+        else if (memcmp(ty, "fSIZ", 4) == 0) { if (len > 8) return fail(c, PNA_E_UNSUPPORTED, "entry beyond 2^64 bytes"); cur.has_size = true; cur.raw_size = 0; for (uint32_t i = 0; i < len; i++) cur.raw_size = (cur.raw_size << 8) | data[i]; }
+        else if (memcmp(ty, "PHSF", 4) == 0) cur.phsf.assign((const char *)data, len);
+        else if (memcmp(ty, "FEND", 4) == 0) { ents.push_back(std::move(cur)); in_entry = false; }
+        else if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk");      // chunk/types.rs: bit 5 of byte 0 clear = critical
+        pos += 12 + (size_t)len;
+    }
+    if (!ended || in_entry) return fail(c, PNA_E_INVAL, "archive not terminated by AEND");
+    const size_t n = ents.size();
+    // ---- 2. keys (one derivation per distinct PHSF string), layout of the packed payloads and of the decoded entries
+    std::vector<std::pair<std::string, std::vector<uint8_t>>> keys;
+    auto key_for = [&](const std::string &phsf, const uint8_t **out) -> int {
+        for (auto &k : keys) if (k.first == phsf) { *out = k.second.data(); return PNA_OK; }
+        // "$pbkdf2-sha256$i=<rounds>,l=<len>$<salt>" (derive_password_hash, lib/src/hash.rs:47-88); Argon2 strings need the Rust host
+        if (phsf.rfind("$pbkdf2-sha256$", 0) != 0) return fail(c, PNA_E_UNSUPPORTED, "password hash other than pbkdf2-sha256");
+        const size_t p1 = 15, p2 = phsf.find('$', p1);
+        if (p2 == std::string::npos) return fail(c, PNA_E_INVAL, "malformed PHSF");
+        uint32_t rounds = 600000;
+        const std::string prm = phsf.substr(p1, p2 - p1);
+        const size_t ip = prm.find("i=");
+        if (ip != std::string::npos) rounds = (uint32_t)strtoul(prm.c_str() + ip + 2, nullptr, 10);
+        std::vector<uint8_t> salt;
+        std::string sb = phsf.substr(p2 + 1); const size_t p3 = sb.find('$'); if (p3 != std::string::npos) sb.resize(p3);
+        if (!b64_decode_nopad(sb, salt) || rounds == 0) return fail(c, PNA_E_INVAL, "malformed PHSF");
+        std::vector<uint8_t> key(32);
+        int rc = pna_kdf_pbkdf2_sha256(password, password_len, salt.data(), salt.size(), rounds, key.data(), 32, nullptr, 0);
+        if (rc) return fail(c, rc, "key derivation failed");
+        keys.emplace_back(phsf, std::move(key)); *out = keys.back().second.data();
+        return PNA_OK;
+    };
+    uint64_t pk_total = 0, raw_total = 0;
+    std::vector<PlaceDescH> places; std::vector<uint8_t> ivs; std::vector<size_t> enc_idx;
+    for (size_t i = 0; i < n; i++) {
+        XEntry &e = ents[i];
+        uint64_t prefix = 0;
+        if (e.encryption != PNA_ENC_NONE) {
+            if (e.encryption != PNA_ENC_AES || e.cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "only AES-CTR entries are decrypted by this driver");
+            if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
+            if (e.phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
+            if (e.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
+            prefix = 16;
+            uint8_t iv[16]; uint64_t got = 0;                   // the IV may span data pieces (prepend_data_prefix makes it a piece of its own)
+            for (const XPiece &p : e.pieces) for (uint32_t k = 0; k < p.len && got < 16; k++) iv[got++] = a[p.off + k];
+            ivs.insert(ivs.end(), iv, iv + 16); enc_idx.push_back(i);
+        }
+        if (e.compression != PNA_ALGO_STORE && e.compression != PNA_ALGO_ZSTD && e.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "compression method not decoded on the device (xz)");
+        e.pk_off = pk_total; e.pay_len = e.stream_len - prefix;
+        uint64_t skip = prefix, at = e.pk_off;
+        for (const XPiece &p : e.pieces) {
+            uint64_t o = p.off, l = p.len;
+            if (skip) { const uint64_t s = std::min<uint64_t>(skip, l); o += s; l -= s; skip -= s; }
+            for (uint64_t k = 0; k < l; k += (1u << 20)) { places.push_back(PlaceDescH{o + k, at + k, (uint32_t)std::min<uint64_t>(1u << 20, l - k), 0}); }
+            at += l;
+        }
+        pk_total = (pk_total + e.pay_len + 15) & ~(uint64_t)15;
+        if (e.compression != PNA_ALGO_STORE) {
+            if (!e.has_size) return fail(c, PNA_E_UNSUPPORTED, "compressed entry without fSIZ");
+            e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15;
+        }
+    }
+    // ---- 3. device: upload, data-chunk CRCs, gather, decrypt, decode
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    int rc = ensure_crc(c); if (rc) return rc;
+    if (c->x_arc.ensure(archive_len + 64) || c->x_pk.ensure(pk_total + 8192) || c->x_raw.ensure(raw_total + 64) || c->x_flag.ensure(64) ||
+        c->x_desc.ensure(dchunks.size() * sizeof(FrameDesc) + 16) || c->x_place.ensure(places.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
+    HIPCHK(c, hipMemcpyAsync(c->x_arc.p, a, archive_len, hipMemcpyHostToDevice, st));
+    const uint32_t flag0[2] = {0u, 0xFFFFFFFFu};
+    HIPCHK(c, hipMemcpyAsync(c->x_flag.p, flag0, 8, hipMemcpyHostToDevice, st));
+    if (!dchunks.empty()) {
+        HIPCHK(c, hipMemcpyAsync(c->x_desc.p, dchunks.data(), dchunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        launch_frame_verify((const FrameDesc *)c->x_desc.p, (uint32_t)dchunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)c->x_arc.p,
+                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st);
+    }
+    if (!places.empty()) {
+        HIPCHK(c, hipMemcpyAsync(c->x_place.p, places.data(), places.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
+        launch_gather(c->x_place.p, (uint32_t)places.size(), (const uint8_t *)c->x_arc.p, (uint8_t *)c->x_pk.p, st);
+    }
+    uint32_t flag[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (flag[0]) { c->err = "FDAT chunk CRC mismatch (data chunk " + std::to_string(flag[1]) + ")"; return PNA_E_INVAL; }
+    if (!enc_idx.empty()) {
+        // entries sharing a PHSF string share the key: one cipher call per key
+        std::vector<bool> done(enc_idx.size(), false);
+        for (size_t j = 0; j < enc_idx.size(); j++) {
+            if (done[j]) continue;
+            const uint8_t *key = nullptr;
+            rc = key_for(ents[enc_idx[j]].phsf, &key); if (rc) return rc;
+            std::vector<uint64_t> off, len; std::vector<uint8_t> iv2;
+            for (size_t k = j; k < enc_idx.size(); k++)
+                if (!done[k] && ents[enc_idx[k]].phsf == ents[enc_idx[j]].phsf) {
+                    done[k] = true; off.push_back(ents[enc_idx[k]].pk_off); len.push_back(ents[enc_idx[k]].pay_len);
+                    iv2.insert(iv2.end(), ivs.begin() + 16 * k, ivs.begin() + 16 * k + 16);
+                }
+            pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv2.data();
+            rc = pna_gpu_cipher_apply_device(c, &ci, 1, off.size(), c->x_pk.p, off.data(), len.data(), st);
+            if (rc) return rc;
+        }
+    }
+    for (int algo : {PNA_ALGO_ZSTD, PNA_ALGO_DEFLATE}) {
+        std::vector<uint64_t> so, sl, dof, rl;
+        for (const XEntry &e : ents) if (e.compression == algo) { so.push_back(e.pk_off); sl.push_back(e.pay_len); dof.push_back(e.raw_off); rl.push_back(e.raw_size); }
+        if (so.empty()) continue;
+        rc = pna_gpu_decompress_batch_device(c, algo, so.size(), c->x_pk.p, so.data(), sl.data(), c->x_raw.p, dof.data(), rl.data(), st);
+        if (rc) return rc;
+    }
+    // ---- 4. back to the host, entries in archive order
+    if (c->hp_out[0].ensure(raw_total + 64) || c->hp_in[0].ensure(pk_total + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    if (raw_total) HIPCHK(c, hipMemcpyAsync(c->hp_out[0].p, c->x_raw.p, raw_total, hipMemcpyDeviceToHost, st));
+    bool any_store = false; for (const XEntry &e : ents) any_store |= e.compression == PNA_ALGO_STORE && e.pay_len;
+    if (any_store) HIPCHK(c, hipMemcpyAsync(c->hp_in[0].p, c->x_pk.p, pk_total, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++) {
+        const XEntry &e = ents[i];
+        const uint8_t *d = e.compression == PNA_ALGO_STORE ? (const uint8_t *)c->hp_in[0].p + e.pk_off : (const uint8_t *)c->hp_out[0].p + e.raw_off;
+        const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
+        if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
+        if (cb(user, i, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+    }
+    return PNA_OK;
+}
+
 extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_t n, const void *const *src,
                                       const size_t *src_len, void *const *dst, const size_t *dst_cap, size_t *dst_len) {
     if (!c || (n && (!src || !src_len || !dst || !dst_cap || !dst_len))) return fail(c, PNA_E_INVAL, "null argument");
@@ -1278,7 +1463,7 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
     for (size_t i = 0; i < n; i++)
         for (uint32_t f = 0; f < ents[i].n_frames; f++) {
             const ZFrame &fr = frs[ents[i].first_frame + f];
-            if (fr.status) {
+            if (fr.status && fr.status != 4) {                    // 4: void slot behind a single frame that holds the whole entry
                 char msg[160];
                 snprintf(msg, sizeof msg, "entry %zu frame %u: %s (produced %u of %u bytes)", i, f,
                          fr.status == 2 ? "unsupported stream" : (fr.status == 3 ? "size mismatch (foreign multi-frame stream?)" : "corrupt stream"), fr.out_len, fr.dst_len);

@@ -307,3 +307,20 @@ def test_gcm_stream_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec,
         gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo,
                                       cipher=pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp, gcm_segment_size=65536))
     assert ei.value.code == -7
+
+
+def test_extract_driver_decrypts_ctr_archives(gpu_ctx, pna, codec):
+    """create (PBKDF2 + AES-CTR on the device) -> extract (key from the PHSF string + password, CTR decrypt and decode on the device)."""
+    ents = [codec.corpus_file(0, 700 + i, n) for i, n in enumerate([1 << 20, 70000, 0, 3, (1 << 20) + 17, 65536])]
+    names = [f"e/{i}.txt" for i in range(len(ents))]
+    arc = pna.create_archive_encrypted(gpu_ctx, names, ents, b"password", rounds=1000)
+    got = pna.extract_archive(gpu_ctx, arc, b"password")
+    assert [n for n, _, _ in got] == names and [d for _, _, d in got] == ents
+    with pytest.raises(pna.PnaGpuError):                        # wrong key: garbage that is not a zstd stream
+        pna.extract_archive(gpu_ctx, arc, b"passw0rd")
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, arc)
+    assert ei.value.code == -2
+    with pytest.raises(pna.PnaGpuError) as ei:                  # the reference's fixture: Argon2id PHSF needs the Rust host's KDF
+        pna.extract_archive(gpu_ctx, open(os.path.join(os.path.dirname(__file__), "golden", "zstd_aes_ctr.pna"), "rb").read(), b"password")
+    assert ei.value.code == -7

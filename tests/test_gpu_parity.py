@@ -433,7 +433,7 @@ def test_device_decoder_round_trips_cases(gpu_ctx, pna, codec):
         assert b == cases[k], k
 
 
-def test_device_decoder_reads_reference_fixtures(gpu_ctx, pna, pf):
+def test_device_decoder_reads_reference_fixtures(gpu_ctx, pna, pf, codec):
     """Frames written by the reference's own encoder (libzstd through zstd-rs: 2 MiB window, per-block tables, repeat
     offsets): the FDAT payloads of the golden archives decode to resources/test/raw/*."""
     for arc in ("zstd.pna", "zstd_with_raw_file_size.pna", "zstd_keep_all.pna"):
@@ -442,8 +442,10 @@ def test_device_decoder_reads_reference_fixtures(gpu_ctx, pna, pf):
         raws = []
         for it in items:
             path = os.path.join(GOLDEN, it.name)
-            raws.append(open(path, "rb").read() if os.path.isfile(path) else None)
+            # raw/images/icon.bmp (4 MiB, ONE frame with a 2 MiB window) exists only inside the fixtures: the oracle decoder is its reference
+            raws.append(open(path, "rb").read() if os.path.isfile(path) else codec.decode_payload(2, it.data, 8 << 20))
         sel = [(it, r) for it, r in zip(items, raws) if r is not None]
+        assert any(len(r) > (4 << 20) for _, r in sel)
         back = gpu_ctx.decompress_batch([it.data for it, _ in sel], [len(r) for _, r in sel])
         for (it, r), b in zip(sel, back):
             assert b == r, (arc, it.name)
@@ -630,3 +632,52 @@ def test_device_inflate_many_small_entries_in_hbm(gpu_ctx, pna):
     gpu_ctx.decompress_batch_device(comp.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(),
                                     [i * L for i in range(n)], [L] * n, algo=pna.ALGO_DEFLATE)
     assert torch.equal(back[:n * L], src[:n * L])
+
+
+def test_extract_driver_round_trips_archives(gpu_ctx, pna, pf, codec):
+    """pna_gpu_extract_archive_host: chunk walk + small-chunk CRCs on the host, FDAT CRC-32 / gather / decode on the device, over
+    archives of this library (zstd, deflate, several FDAT chunks per entry) and of the host chunk writer (STORE, directories)."""
+    lens = [0, 1, 5, 4095, 70001, 131073, 300000, (1 << 20) + 1, 2500000, 12, 65536]
+    ents = [codec.corpus_file(i % 2, 600 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"x{i % 3}/f{i:03d}.txt" for i in range(len(lens))]
+    for algo in (pna.ALGO_ZSTD, pna.ALGO_DEFLATE):
+        arc = pna.create_archive(gpu_ctx, names, ents, algo=algo)
+        got = pna.extract_archive(gpu_ctx, arc)
+        assert [(n, k) for n, k, _ in got] == [(n, 0) for n in names] and [d for _, _, d in got] == ents
+    # several FDAT chunks per entry (FlattenWriter max_chunk_size), a directory, a stored entry
+    class Sink:
+        def __init__(self): self.parts = []
+        def write(self, b): self.parts.append(b)
+    sk = Sink(); ar = pna.Archive(sk)
+    pay = gpu_ctx.compress_batch(ents)
+    ar.add_dir("x0")
+    for nm, pl, e in zip(names, pay, ents):
+        ar.add_file(nm, pna.ALGO_ZSTD, len(e), pl, max_chunk_size=1000)
+    ar.add_file("stored.bin", pna.ALGO_STORE, 5000, codec.corpus_file(2, 1, 5000))
+    ar.finalize()
+    arc = b"".join(sk.parts)
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert got[0] == ("x0", 1, b"") and got[-1] == ("stored.bin", 0, codec.corpus_file(2, 1, 5000))
+    assert [d for _, _, d in got[1:-1]] == ents
+    # the reference's own archive with fSIZ chunks
+    ref = open(os.path.join(GOLDEN, "zstd_with_raw_file_size.pna"), "rb").read()
+    items = pf.read_archive(ref)[1]
+    got = pna.extract_archive(gpu_ctx, ref)
+    assert [n for n, _, _ in got] == [it.name for it in items]
+    for (n, _, d), it in zip(got, items):
+        assert d == codec.decode_payload(it.compression, it.data, 8 << 20)
+    # damage: a flipped payload byte is a CRC mismatch found on the device, a flipped name byte one found on the host
+    bad = bytearray(arc); bad[len(arc) // 2] ^= 1
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, bytes(bad))
+    assert ei.value.code == -2 and "CRC" in str(ei.value)
+    bad = bytearray(arc); bad[8 + 20 + 8 + 7] ^= 1
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, bytes(bad))
+    assert ei.value.code == -2
+    with pytest.raises(pna.PnaGpuError) as ei:                  # no fSIZ: the decoder cannot size its output
+        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "zstd.pna"), "rb").read())
+    assert ei.value.code == -7
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "solid_zstd.pna"), "rb").read())
+    assert ei.value.code == -7
