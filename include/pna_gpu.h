@@ -196,14 +196,22 @@ int  pna_gpu_decompress_batch_device(pna_gpu_ctx *ctx, int algo, size_t n, const
                                      const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
                                      void *hip_stream);
 
-/* Read-side driver for non-solid archives in host memory: `pna extract` / `pna verify` (cli/src/command/extract.rs:594-640,
+/* A zstd stream whose decoded size is recorded nowhere (the SDAT stream of a solid entry).  Step 1 counts its frames; the caller
+ * provides frames x 1 MiB of room (this library's segmentation) -- for ONE frame, as the reference writes it, any capacity it sees fit;
+ * step 2 decodes and reports the size found (PNA_E_INVAL when the stream does not fit). */
+int  pna_gpu_zstd_stream_frames_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t src_off, uint64_t src_len, uint32_t *n_frames, void *hip_stream);
+int  pna_gpu_zstd_decompress_open_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off,
+                                         uint64_t dst_cap, uint64_t *raw_len, void *hip_stream);
+
+/* Read-side driver for archives in host memory (normal and solid entries): `pna extract` / `pna verify` (cli/src/command/extract.rs:594-640,
  * verify.rs:140-188; Archive::read_header + entries, lib/src/archive/read.rs:22-66; read_chunk's mandatory CRC check, lib/src/io.rs:117-149;
  * decrypt_reader / decompress_reader, lib/src/entry/read.rs:59-104,171-190).  The chunk walk and the small chunks' CRCs are host work;
  * the FDAT CRC-32s, the gather of every entry's data pieces, AES-CTR decryption (key from a "$pbkdf2-sha256$..." PHSF string and
  * `password`) and zstd / deflate / store decoding run on the device.  cb is called once per entry in archive order (kind =
  * DataKind::to_byte(): 0 file, 1 directory, ...); `data` is valid during the call.  PNA_E_INVAL: structural damage, CRC mismatch, corrupt
- * stream; PNA_E_UNSUPPORTED: solid / multipart archives, xz, Argon2 password hashes, cipher modes other than CTR, compressed entries
- * without fSIZ. */
+ * stream; PNA_E_UNSUPPORTED: multipart archives, xz, Argon2 password hashes, cipher modes other than CTR, compressed entries
+ * without fSIZ, solid streams other than zstd / store or with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND):
+ * SDAT CRCs and the inner FDAT CRCs on the device, the stream is decoded without a recorded size (frames counted first). */
 typedef int (*pna_entry_fn)(void *user, size_t index, const char *name, int kind, const void *data, size_t len);
 int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t archive_len, const void *password, size_t password_len,
                                   pna_entry_fn cb, void *user);

@@ -176,6 +176,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     const uint8_t *in = src + fr.src_off;
     uint8_t *out = dst + fr.dst_off;
     const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    const bool open = (fr.out_len & ZF_OPEN) != 0;                     // cap is only a capacity
     uint32_t ip = 0, op = 0;
     uint32_t status = ZD_OK;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
@@ -200,7 +201,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                     uint64_t fcs = 0;
                     for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
                     if (fsz == 2) fcs += 256;
-                    if (fsz && fcs != cap) status = ZD_DSTSIZE;
+                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
                 if ((fhd >> 2) & 1) { /* content checksum: 4 bytes after the last block, not verified */ }
@@ -553,8 +554,8 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
         __syncthreads();
         if (b.last) break;
     }
-    if (status == ZD_OK && op != cap && !dbg) status = ZD_DSTSIZE;
-    if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; }
+    if (status == ZD_OK && op != cap && !dbg && !open) status = ZD_DSTSIZE;
+    if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; if (open && status == ZD_OK) frames[blockIdx.x].dst_len = op; }
 }
 
 // =====================================================================================================================
@@ -585,6 +586,7 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
     ZFrameX x = fx[f];
     const uint8_t *in = src + fr.src_off;
     const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    const bool open = (fr.out_len & ZF_OPEN) != 0;
     uint32_t status = fr.status, ip = 0;
     // ---- frame header
     if (status == ZD_OK) {
@@ -603,7 +605,7 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
                     uint64_t fcs = 0;
                     for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
                     if (fsz == 2) fcs += 256;
-                    if (fsz && fcs != cap) status = ZD_DSTSIZE;
+                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
             }
@@ -1021,6 +1023,7 @@ __global__ void k_zoff(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ 
         b->out_off = off + total; total += b->out_len; st |= b->status;
     }
     if (st) frames[f].status = ZD_CORRUPT;
+    else if (frames[f].out_len & ZF_OPEN) { if (total > frames[f].dst_len) frames[f].status = ZD_DSTSIZE; else frames[f].dst_len = (uint32_t)total; }
     else if (total != frames[f].dst_len) frames[f].status = ZD_DSTSIZE;
 }
 
@@ -1197,7 +1200,7 @@ __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8
     // gets all of raw_len and goes to the one-workgroup-per-frame kernel (the bounded per-frame resources are sized for SEG_SIZE);
     // the other frame slots planned for the entry are void
     if (nfr > 1 && zscan_frame_end(p, 0, len) == len) {
-        ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = (uint32_t)len; fr.out_len = 0;
+        ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = (uint32_t)len; fr.out_len = en.open ? ZF_OPEN : 0u;
         fr.dst_len = (uint32_t)en.raw_len; fr.status = (en.raw_len > 0xFFFFFFFFull || len > 0xFFFFFFFFull) ? 1u : 2u;
         frames[en.first_frame] = fr;
         fr.src_len = 0; fr.dst_len = 0; fr.status = 4;              // ZD_VOID
@@ -1213,10 +1216,30 @@ __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8
         const uint64_t q = zscan_frame_end(p, ip, len);
         if (!q) { fr.status = 1; fr.src_len = 0; frames[en.first_frame + f] = fr; for (uint32_t g = f + 1; g < nfr; g++) { fr.src_off = 0; frames[en.first_frame + g] = fr; } return; }
         fr.src_len = (uint32_t)(q - ip);
+        if (en.open && f + 1 == nfr) fr.out_len = ZF_OPEN;             // the last frame of a stream of unknown size
         frames[en.first_frame + f] = fr;
         ip = q;
     }
     if (ip != len && nfr) frames[en.first_frame + nfr - 1].status = 1;      // bytes left over behind the last frame
+}
+
+// number of frames of every entry's payload (0: malformed) -- the planning step for streams that carry no size (solid)
+__global__ void k_zcount(const ZEntry *__restrict__ ents, uint32_t n, const uint8_t *__restrict__ src, uint32_t *__restrict__ counts) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const ZEntry en = ents[e];
+    const uint8_t *p = src + en.src_off;
+    uint64_t ip = 0; uint32_t cnt = 0;
+    while (ip < en.src_len) {
+        const uint64_t q = zscan_frame_end(p, ip, en.src_len);
+        if (!q) { cnt = 0; break; }
+        ip = q; cnt++;
+        if (cnt == 0x7FFFFFFFu) { cnt = 0; break; }
+    }
+    counts[e] = cnt;
+}
+void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zcount, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, counts);
 }
 
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st) {

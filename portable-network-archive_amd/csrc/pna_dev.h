@@ -150,6 +150,8 @@ struct ZEntry {              // k_zscan input: one compressed entry
     uint64_t src_off, src_len;   // its payload (concatenated frames) in the compressed buffer
     uint64_t dst_off, raw_len;   // where the content goes and how long it is (fSIZ)
     uint32_t first_frame, n_frames;
+    uint32_t open, pad;          // open != 0: raw_len is only a capacity -- the last frame's size is found by decoding (streams without fSIZ: solid)
 };
+constexpr uint32_t ZF_OPEN = 0x80000000u;   // ZFrame.out_len on input: dst_len is a capacity, the decoder writes the size it found back to dst_len
 
 } // namespace pna

@@ -41,6 +41,7 @@ void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst,
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
+void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st);
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
                    void *work, hipStream_t st);
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
@@ -1117,6 +1118,12 @@ struct XEntry {
     std::vector<XPiece> pieces; uint64_t stream_len = 0;
     uint64_t pk_off = 0, pay_len = 0, raw_off = 0;            // payload (prefix stripped) in the packed buffer; decoded bytes in the raw buffer
 };
+struct XSolid {                                                // SHED [PHSF] SDAT* SEND -- lib/src/entry.rs:465-484,567-583
+    int compression = 0, encryption = 0, cipher_mode = 0; std::string phsf;
+    std::vector<XPiece> pieces; uint64_t stream_len = 0;
+    size_t order = 0;                                          // number of normal entries in front of it
+    uint64_t pk_off = 0, pay_len = 0;
+};
 uint32_t rd_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 int b64_val(char ch) {
     if (ch >= 'A' && ch <= 'Z') return ch - 'A'; if (ch >= 'a' && ch <= 'z') return ch - 'a' + 26;
@@ -1136,23 +1143,32 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
     if (archive_len < 8 + 20 + 12 || memcmp(a, sig, 8) != 0) return fail(c, PNA_E_INVAL, "not a PNA archive");
     // ---- 1. chunk walk (host): structure, small-chunk CRCs, data-chunk descriptors
-    std::vector<XEntry> ents; std::vector<FrameDesc> dchunks;
+    std::vector<XEntry> ents; std::vector<FrameDesc> dchunks, schunks;
+    std::vector<XSolid> solids; XSolid scur; bool in_solid = false;
     XEntry cur; bool in_entry = false, seen_ahed = false, ended = false;
     size_t pos = 8;
     while (pos < archive_len) {
         if (archive_len - pos < 12) return fail(c, PNA_E_INVAL, "truncated chunk header");
         const uint32_t len = rd_be32(a + pos); const uint8_t *ty = a + pos + 4, *data = a + pos + 8;
         if (archive_len - pos - 12 < len) return fail(c, PNA_E_INVAL, "truncated chunk body");
-        const bool is_fdat = memcmp(ty, "FDAT", 4) == 0;
-        if (is_fdat) { if (len >= 0xFFFFFFF0u) return fail(c, PNA_E_INVAL, "data chunk too long"); dchunks.push_back(FrameDesc{pos, len, 0, 8, 0}); }
+        const bool is_fdat = memcmp(ty, "FDAT", 4) == 0, is_sdat = memcmp(ty, "SDAT", 4) == 0;
+        if (is_fdat || is_sdat) { if (len >= 0xFFFFFFF0u) return fail(c, PNA_E_INVAL, "data chunk too long"); (is_fdat ? dchunks : schunks).push_back(FrameDesc{pos, len, 0, 8, 0}); }
         else if (pna_crc32(pna_crc32(0, ty, 4), data, len) != rd_be32(data + len)) return fail(c, PNA_E_INVAL, "chunk CRC mismatch");
         if (!seen_ahed) {
             if (memcmp(ty, "AHED", 4) != 0 || len != 8 || data[0] != 0) return fail(c, PNA_E_INVAL, "first chunk must be AHED (major version 0)");
             seen_ahed = true;
         } else if (memcmp(ty, "AEND", 4) == 0) { ended = true; break; }
         else if (memcmp(ty, "ANXT", 4) == 0) return fail(c, PNA_E_UNSUPPORTED, "multipart archives are not read by this driver");
-        else if (memcmp(ty, "SHED", 4) == 0 || memcmp(ty, "SDAT", 4) == 0 || memcmp(ty, "SEND", 4) == 0)
-            return fail(c, PNA_E_UNSUPPORTED, "solid archives are not read by this driver (the stream carries no size)");
+        else if (memcmp(ty, "SHED", 4) == 0) {
+            if (in_entry || in_solid || len != 5 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad solid header");
+            scur = XSolid(); in_solid = true; scur.order = ents.size();
+            scur.compression = data[2]; scur.encryption = data[3]; scur.cipher_mode = data[4];
+        } else if (in_solid) {
+            if (memcmp(ty, "SDAT", 4) == 0) { scur.pieces.push_back(XPiece{pos + 8, len}); scur.stream_len += len; }
+            else if (memcmp(ty, "PHSF", 4) == 0) scur.phsf.assign((const char *)data, len);
+            else if (memcmp(ty, "SEND", 4) == 0) { solids.push_back(std::move(scur)); in_solid = false; }
+            else if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk in a solid entry");
+        }
         else if (memcmp(ty, "FHED", 4) == 0) {
             if (in_entry || len < 6 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad entry header");
             cur = XEntry(); in_entry = true;
@@ -1166,7 +1182,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         else if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk");      // chunk/types.rs: bit 5 of byte 0 clear = critical
         pos += 12 + (size_t)len;
     }
-    if (!ended || in_entry) return fail(c, PNA_E_INVAL, "archive not terminated by AEND");
+    if (!ended || in_entry || in_solid) return fail(c, PNA_E_INVAL, "archive not terminated by AEND");
     const size_t n = ents.size();
     // ---- 2. keys (one derivation per distinct PHSF string), layout of the packed payloads and of the decoded entries
     std::vector<std::pair<std::string, std::vector<uint8_t>>> keys;
@@ -1219,6 +1235,26 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15;
         }
     }
+    for (XSolid &so : solids) {
+        uint64_t prefix = 0;
+        if (so.encryption != PNA_ENC_NONE) {
+            if (so.encryption != PNA_ENC_AES || so.cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "only AES-CTR entries are decrypted by this driver");
+            if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
+            if (so.phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
+            if (so.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
+            prefix = 16;
+        }
+        if (so.compression != PNA_ALGO_STORE && so.compression != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "solid stream: only zstd and store are decoded (no size is recorded for it)");
+        so.pk_off = pk_total; so.pay_len = so.stream_len - prefix;
+        uint64_t skip = prefix, at = so.pk_off;
+        for (const XPiece &p : so.pieces) {
+            uint64_t o = p.off, l = p.len;
+            if (skip) { const uint64_t sk = std::min<uint64_t>(skip, l); o += sk; l -= sk; skip -= sk; }
+            for (uint64_t k = 0; k < l; k += (1u << 20)) places.push_back(PlaceDescH{o + k, at + k, (uint32_t)std::min<uint64_t>(1u << 20, l - k), 0});
+            at += l;
+        }
+        pk_total = (pk_total + so.pay_len + 15) & ~(uint64_t)15;
+    }
     // ---- 3. device: upload, data-chunk CRCs, gather, decrypt, decode
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1233,6 +1269,12 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         launch_frame_verify((const FrameDesc *)c->x_desc.p, (uint32_t)dchunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)c->x_arc.p,
                             (uint64_t)c->x_arc.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st);
     }
+    if (!schunks.empty()) {
+        if (c->solid_desc.ensure(schunks.size() * sizeof(FrameDesc) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
+        HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, schunks.data(), schunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        launch_frame_verify((const FrameDesc *)c->solid_desc.p, (uint32_t)schunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)c->x_arc.p,
+                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "SDAT", (uint32_t *)c->x_flag.p, st);
+    }
     if (!places.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->x_place.p, places.data(), places.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
         launch_gather(c->x_place.p, (uint32_t)places.size(), (const uint8_t *)c->x_arc.p, (uint8_t *)c->x_pk.p, st);
@@ -1241,7 +1283,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
-    if (flag[0]) { c->err = "FDAT chunk CRC mismatch (data chunk " + std::to_string(flag[1]) + ")"; return PNA_E_INVAL; }
+    if (flag[0]) { c->err = "data chunk CRC mismatch (" + std::to_string(flag[0]) + " FDAT / SDAT chunks)"; return PNA_E_INVAL; }
     if (!enc_idx.empty()) {
         // entries sharing a PHSF string share the key: one cipher call per key
         std::vector<bool> done(enc_idx.size(), false);
@@ -1267,20 +1309,100 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         rc = pna_gpu_decompress_batch_device(c, algo, so.size(), c->x_pk.p, so.data(), sl.data(), c->x_raw.p, dof.data(), rl.data(), st);
         if (rc) return rc;
     }
+    // ---- solid entries: decrypt (CTR), decode a stream of unknown size, walk the inner records
+    struct Inner { std::string name; int kind; std::vector<XPiece> pieces; uint64_t len; };
+    std::vector<std::vector<Inner>> inner(solids.size());
+    std::vector<std::vector<uint8_t>> plain(solids.size());
+    for (size_t si = 0; si < solids.size(); si++) {
+        XSolid &so = solids[si];
+        if (so.encryption != PNA_ENC_NONE) {
+            const uint8_t *key = nullptr;
+            rc = key_for(so.phsf, &key); if (rc) return rc;
+            uint8_t iv[16]; uint64_t got = 0;
+            for (const XPiece &p : so.pieces) for (uint32_t k = 0; k < p.len && got < 16; k++) iv[got++] = a[p.off + k];
+            pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv;
+            rc = pna_gpu_cipher_apply_device(c, &ci, 1, 1, c->x_pk.p, &so.pk_off, &so.pay_len, st);
+            if (rc) return rc;
+        }
+        uint64_t plen = so.pay_len; const void *d_plain = (const uint8_t *)c->x_pk.p + so.pk_off;
+        if (so.compression == PNA_ALGO_ZSTD) {
+            uint32_t nfr = 0;
+            rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, so.pk_off, so.pay_len, &nfr, st); if (rc) return rc;
+            // this library's solid streams: frames of 1 MiB; one frame (the reference's writer): a bounded guess of its size
+            const uint64_t cap = nfr > 1 ? (uint64_t)nfr * SEG_SIZE : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, 64 * so.pay_len));
+            if (c->solid_plain.ensure(cap + 8192)) return fail(c, PNA_E_NOMEM, "solid stream buffer");
+            rc = pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, so.pk_off, so.pay_len, c->solid_plain.p, 0, cap, &plen, st); if (rc) return rc;
+            d_plain = c->solid_plain.p;
+        }
+        plain[si].resize(plen);
+        if (plen) HIPCHK(c, hipMemcpy(plain[si].data(), d_plain, plen, hipMemcpyDeviceToHost));
+        // read_next_normal_entry_from_stream over the decoded stream (lib/src/entry.rs:401-424): small chunks checked here, the
+        // inner FDAT CRCs on the device over the decoded stream where it stands
+        const uint8_t *b = plain[si].data();
+        std::vector<FrameDesc> ichunks; Inner ic; bool in_i = false;
+        for (size_t q = 0; q < plen;) {
+            if (plen - q < 12) return fail(c, PNA_E_INVAL, "solid stream: truncated chunk header");
+            const uint32_t len = rd_be32(b + q); const uint8_t *ty = b + q + 4, *data = b + q + 8;
+            if (plen - q - 12 < len) return fail(c, PNA_E_INVAL, "solid stream: truncated chunk body");
+            const bool fd = memcmp(ty, "FDAT", 4) == 0;
+            if (fd) { if (len >= 0xFFFFFFF0u) return fail(c, PNA_E_INVAL, "data chunk too long"); ichunks.push_back(FrameDesc{q, len, 0, 8, 0}); }
+            else if (pna_crc32(pna_crc32(0, ty, 4), data, len) != rd_be32(data + len)) return fail(c, PNA_E_INVAL, "solid stream: chunk CRC mismatch");
+            if (memcmp(ty, "FHED", 4) == 0) {
+                if (in_i || len < 6 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "solid stream: bad entry header");
+                if (data[3] != PNA_ALGO_STORE || data[4] != PNA_ENC_NONE) return fail(c, PNA_E_UNSUPPORTED, "solid stream: inner entry that is not stored");
+                ic = Inner(); in_i = true; ic.kind = data[2]; ic.len = 0; ic.name.assign((const char *)data + 6, len - 6);
+            } else if (!in_i) { if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "solid stream: unknown critical chunk"); }
+            else if (fd) { ic.pieces.push_back(XPiece{q + 8, len}); ic.len += len; }
+            else if (memcmp(ty, "FEND", 4) == 0) { inner[si].push_back(std::move(ic)); in_i = false; }
+            else if (memcmp(ty, "fSIZ", 4) != 0 && !(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "solid stream: unknown critical chunk");
+            q += 12 + (size_t)len;
+        }
+        if (in_i) return fail(c, PNA_E_INVAL, "solid stream: dangling chunks");
+        if (!ichunks.empty()) {
+            if (c->solid_desc.ensure(ichunks.size() * sizeof(FrameDesc) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
+            HIPCHK(c, hipMemcpyAsync(c->x_flag.p, flag0, 8, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, ichunks.data(), ichunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+            const DevBuf &pb = so.compression == PNA_ALGO_ZSTD ? c->solid_plain : c->x_pk;
+            std::vector<FrameDesc> adj;
+            if (so.compression != PNA_ALGO_ZSTD) {                // descriptors are relative to the stream's start inside the packed buffer
+                adj = ichunks; for (auto &f : adj) f.arc_off += so.pk_off;
+                HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, adj.data(), adj.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+            }
+            launch_frame_verify((const FrameDesc *)c->solid_desc.p, (uint32_t)ichunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)pb.p,
+                                (uint64_t)pb.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st);
+            HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (flag[0]) return fail(c, PNA_E_INVAL, "solid stream: inner FDAT CRC mismatch");
+        }
+    }
     // ---- 4. back to the host, entries in archive order
     if (c->hp_out[0].ensure(raw_total + 64) || c->hp_in[0].ensure(pk_total + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
     if (raw_total) HIPCHK(c, hipMemcpyAsync(c->hp_out[0].p, c->x_raw.p, raw_total, hipMemcpyDeviceToHost, st));
     bool any_store = false; for (const XEntry &e : ents) any_store |= e.compression == PNA_ALGO_STORE && e.pay_len;
     if (any_store) HIPCHK(c, hipMemcpyAsync(c->hp_in[0].p, c->x_pk.p, pk_total, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    size_t index = 0, si = 0;
+    std::vector<uint8_t> joined;
+    auto deliver_solids = [&](size_t upto) -> int {
+        for (; si < solids.size() && solids[si].order <= upto; si++)
+            for (const Inner &ie : inner[si]) {
+                const uint8_t *d = plain[si].data();
+                if (ie.pieces.size() == 1) d += ie.pieces[0].off;
+                else { joined.clear(); for (const XPiece &p : ie.pieces) joined.insert(joined.end(), d + p.off, d + p.off + p.len); d = joined.data(); }
+                if (cb(user, index++, ie.name.c_str(), ie.kind, ie.len ? d : nullptr, (size_t)ie.len) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+            }
+        return PNA_OK;
+    };
     for (size_t i = 0; i < n; i++) {
+        rc = deliver_solids(i); if (rc) return rc;
         const XEntry &e = ents[i];
         const uint8_t *d = e.compression == PNA_ALGO_STORE ? (const uint8_t *)c->hp_in[0].p + e.pk_off : (const uint8_t *)c->hp_out[0].p + e.raw_off;
         const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
         if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
-        if (cb(user, i, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+        if (cb(user, index++, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
     }
-    return PNA_OK;
+    return deliver_solids(n);
 }
 
 extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_t n, const void *const *src,
@@ -1378,6 +1500,9 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
 
 // ---------------------------------------------------------------------------------------------------------
 // Read side: decompress_reader (lib/src/entry/read.rs:171-190); entries already in device memory.
+static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st);
+
 extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t n, const void *d_src, const uint64_t *src_off,
                                                const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
                                                void *hip_stream) {
@@ -1387,12 +1512,41 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (algo == PNA_ALGO_DEFLATE) return inflate_batch_device(c, n, d_src, src_off, src_len, d_dst, dst_off, raw_len, st);
+    return zstd_decode_device(c, n, d_src, src_off, src_len, d_dst, dst_off, raw_len, false, nullptr, st);
+}
+
+// A zstd stream whose decoded size is not recorded anywhere (the SDAT stream of a solid entry: SHED carries no size): step 1 counts
+// its frames, the caller provides frames x 1 MiB (this library's segmentation; one frame of any size: `cap` bytes), step 2 decodes
+// and reports the size found.
+extern "C" int pna_gpu_zstd_stream_frames_device(pna_gpu_ctx *c, const void *d_src, uint64_t src_off, uint64_t src_len, uint32_t *n_frames, void *hip_stream) {
+    if (!c || !d_src || !n_frames) return fail(c, PNA_E_INVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->z_ents.ensure(sizeof(ZEntry)) || c->z_work.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+    const ZEntry en{src_off, src_len, 0, 0, 0, 0, 1, 0};
+    HIPCHK(c, hipMemcpyAsync(c->z_ents.p, &en, sizeof en, hipMemcpyHostToDevice, st));
+    launch_zcount((const ZEntry *)c->z_ents.p, 1, (const uint8_t *)d_src, (uint32_t *)c->z_work.p, st);
+    HIPCHK(c, hipMemcpyAsync(n_frames, c->z_work.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (*n_frames == 0 && src_len) return fail(c, PNA_E_INVAL, "not a sequence of zstd frames");
+    return PNA_OK;
+}
+extern "C" int pna_gpu_zstd_decompress_open_device(pna_gpu_ctx *c, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off,
+                                                   uint64_t dst_cap, uint64_t *raw_len, void *hip_stream) {
+    if (!c || !d_src || !d_dst || !raw_len) return fail(c, PNA_E_INVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    return zstd_decode_device(c, 1, d_src, &src_off, &src_len, d_dst, &dst_off, &dst_cap, true, raw_len, st);
+}
+
+static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
+                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st) {
     std::vector<ZEntry> ents(n);
     uint64_t nfr = 0;
     for (size_t i = 0; i < n; i++) {
         const uint64_t k = raw_len[i] ? (raw_len[i] + SEG_SIZE - 1) / SEG_SIZE : 1;
         if (nfr + k > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "too many frames");
-        ents[i] = ZEntry{src_off[i], src_len[i], dst_off[i], raw_len[i], (uint32_t)nfr, (uint32_t)k};
+        ents[i] = ZEntry{src_off[i], src_len[i], dst_off[i], raw_len[i], (uint32_t)nfr, (uint32_t)k, open ? 1u : 0u, 0u};
         nfr += k;
     }
     // per-frame bounds of the lane-parallel pipeline (frames that exceed them fall back to the one-workgroup-per-frame kernel)
@@ -1447,6 +1601,12 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
     if (!fb.empty()) {
         std::vector<ZFrame> sub(fb.size());
         for (size_t k = 0; k < fb.size(); k++) { sub[k] = frs[fb[k]]; sub[k].status = 0; sub[k].out_len = 0; }
+        if (open)                                                 // the frame that closes a stream of unknown size keeps its flag
+            for (size_t k = 0; k < fb.size(); k++)
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t f0 = ents[i].first_frame, f1 = f0 + ents[i].n_frames;
+                    if (fb[k] >= f0 && fb[k] < f1 && (fb[k] + 1 == f1 || (fb[k] == f0 && f1 - f0 > 1 && frs[f0 + 1].status == 4))) sub[k].out_len = ZF_OPEN;
+                }
         if (c->z_fb.ensure(sub.size() * sizeof(ZFrame)) || c->z_lit.ensure(std::max<uint64_t>(out_span + 64, sub.size() * (uint64_t)(128u << 10) + 64)))
             return fail(c, PNA_E_NOMEM, "decoder workspace");
         HIPCHK(c, hipMemcpyAsync(c->z_fb.p, sub.data(), sub.size() * sizeof(ZFrame), hipMemcpyHostToDevice, st));
@@ -1469,6 +1629,12 @@ extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t 
                          fr.status == 2 ? "unsupported stream" : (fr.status == 3 ? "size mismatch (foreign multi-frame stream?)" : "corrupt stream"), fr.out_len, fr.dst_len);
                 return fail(c, fr.status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
             }
+        }
+    if (open && raw_out)
+        for (size_t i = 0; i < n; i++) {                          // sizes found by the decoder: frames in front hold SEG_SIZE each
+            uint64_t total = 0;
+            for (uint32_t f = 0; f < ents[i].n_frames; f++) { const ZFrame &fr = frs[ents[i].first_frame + f]; if (fr.status != 4) total += fr.dst_len; }
+            raw_out[i] = total;
         }
     return PNA_OK;
 }

@@ -245,6 +245,13 @@ def test_encrypted_solid_archive_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
     with pytest.raises(pna.PnaGpuError) as ei:
         gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=pna.Cipher(KEY, PHSF, pna.MODE_CBC, ivs=iv))
     assert ei.value.code == -7
+    if algo == pna.ALGO_ZSTD:
+        # and through the read-side driver: PHSF -> key, SDAT CRCs, CTR decrypt, open-size decode, inner CRCs, all but the walk on the device
+        key, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
+        ci2 = pna.Cipher(key, phsf, pna.MODE_CTR, ivs=iv)
+        total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci2)
+        back = pna.extract_archive(gpu_ctx, dst[:total].cpu().numpy().tobytes(), b"password")
+        assert [n for n, _, _ in back] == names and [d for _, _, d in back] == ents
 
 
 @pytest.mark.parametrize("algo_name", ["zstd", "deflate"])

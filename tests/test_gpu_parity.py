@@ -678,6 +678,32 @@ def test_extract_driver_round_trips_archives(gpu_ctx, pna, pf, codec):
     with pytest.raises(pna.PnaGpuError) as ei:                  # no fSIZ: the decoder cannot size its output
         pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "zstd.pna"), "rb").read())
     assert ei.value.code == -7
+
+
+def test_extract_driver_reads_solid_archives(gpu_ctx, pna, pf, codec):
+    """Solid entries carry no size: the frames of the SDAT stream are counted, the stream is decoded "open" (every frame but the last
+    holds 1 MiB, the last reports its size), the inner records are walked on the host, SDAT and inner FDAT CRCs are checked on the device."""
+    lens = [300000, 0, 5, (1 << 20) + 3, 70001, 2500000, 12, 1 << 20]
+    ents = [codec.corpus_file(i % 2, 800 + i, n) if n else b"" for i, n in enumerate(lens)]
+    names = [f"s/{i}.txt" for i in range(len(lens))]
+    arc = pna.create_archive(gpu_ctx, names, ents, solid=True)
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert [n for n, _, _ in got] == names and [d for _, _, d in got] == ents
+    # a stream that ends exactly on a frame boundary, and a tiny one
+    for sub in (slice(7, 8), slice(2, 3), slice(1, 2)):
+        a2 = pna.create_archive(gpu_ctx, names[sub], ents[sub], solid=True)
+        assert [d for _, _, d in pna.extract_archive(gpu_ctx, a2)] == ents[sub]
+    # the reference's own solid archive: ONE zstd frame written by libzstd, inner entries stored
+    ref = open(os.path.join(GOLDEN, "solid_zstd.pna"), "rb").read()
+    (so,) = pf.read_archive(ref)[1]
+    inner = pf.read_solid_inner(codec.decode_payload(so.compression, so.data, 16 << 20))
+    got = pna.extract_archive(gpu_ctx, ref)
+    assert [(n, d) for n, _, d in got] == [(e.name, e.data) for e in inner] and len(got) == 9
+    # damage inside an SDAT body: found by the device CRC
+    bad = bytearray(arc); bad[len(arc) // 2] ^= 1
     with pytest.raises(pna.PnaGpuError) as ei:
-        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "solid_zstd.pna"), "rb").read())
+        pna.extract_archive(gpu_ctx, bytes(bad))
+    assert ei.value.code == -2 and "CRC" in str(ei.value)
+    with pytest.raises(pna.PnaGpuError) as ei:                  # deflate solid stream: no size, and inflate needs one
+        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "solid_deflate.pna"), "rb").read())
     assert ei.value.code == -7
