@@ -55,6 +55,11 @@ int  pna_create_archive(pna_gpu_ctx *ctx, int algo, int level, int solid, size_t
  * string without the hash, "$pbkdf2-sha256$i=<rounds>,l=32$<salt B64, no padding>" -- the body of the PHSF chunk. */
 int  pna_kdf_pbkdf2_sha256(const void *password, size_t password_len, const void *salt, size_t salt_len, uint32_t rounds,
                            uint8_t *key, size_t key_len, char *phsf, size_t phsf_cap);
+/* Argon2 (RFC 9106, v0x13; kind 0 = d, 1 = i, 2 = id) on the C++ host: the reference's default password hash (hash::argon2_with_salt,
+ * derive_password_hash, lib/src/hash.rs:6-33,47-70).  The read side (pna_gpu_extract_archive_host) uses it to open archives whose PHSF
+ * is "$argon2id$v=19$m=..,t=..,p=..$salt". */
+int  pna_kdf_argon2(int kind, const void *password, size_t password_len, const void *salt, size_t salt_len,
+                    uint32_t t_cost, uint32_t m_cost_kib, uint32_t lanes, uint8_t *key, size_t key_len);
 /* pna create --aes [ctr|cbc] --pbkdf2 (non-solid, zstd / deflate): one key derivation per archive (random 16-byte salt; rounds 0 =
  * the pbkdf2 crate's default 600 000), a fresh random IV per entry, cipher stage on the device (pna_gpu_create_archive_enc_host). */
 int  pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,

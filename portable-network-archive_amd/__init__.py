@@ -103,7 +103,7 @@ EXPORTS = [
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
-    "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted",
+    "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted", "pna_kdf_argon2",
 ]
 
 
@@ -214,6 +214,8 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_extract_archive_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ENTRY_FN, vp]
     L.pna_kdf_pbkdf2_sha256.restype = ctypes.c_int
     L.pna_kdf_pbkdf2_sha256.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+    L.pna_kdf_argon2.restype = ctypes.c_int
+    L.pna_kdf_argon2.argtypes = [ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, u32, u32, ctypes.c_char_p, sz]
     L.pna_create_archive_encrypted.restype = ctypes.c_int
     L.pna_create_archive_encrypted.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                                ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_int, u32, SINK_FN, vp]
@@ -597,3 +599,12 @@ def extract_archive(ctx: Context, archive: bytes, password: Optional[bytes] = No
     rc = ctx._L.pna_gpu_extract_archive_host(ctx._h, buf, len(buf), password, len(password) if password else 0, cb, None)
     ctx._check(rc)
     return out
+
+
+def kdf_argon2(kind: int, password: bytes, salt: bytes, t_cost: int, m_cost_kib: int, lanes: int, key_len: int = 32) -> bytes:
+    """hash::argon2_with_salt on the C++ host (include/pna_archive.h); kind 0 = Argon2d, 1 = Argon2i, 2 = Argon2id."""
+    key = ctypes.create_string_buffer(key_len)
+    rc = load_library().pna_kdf_argon2(kind, bytes(password), len(password), bytes(salt), len(salt), t_cost, m_cost_kib, lanes, key, key_len)
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return key.raw

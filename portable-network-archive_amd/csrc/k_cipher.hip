@@ -199,7 +199,7 @@ __device__ G128 g_mul_bitwise(const G128 &x, G128 v) {                 // x * v,
 __device__ __forceinline__ uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
 
 __global__ __launch_bounds__(GH_THREADS)
-void k_gcm_tag(const GcmEntry *__restrict__ ents, uint8_t *__restrict__ buf) {
+void k_gcm_tag(const GcmEntry *__restrict__ ents, uint8_t *__restrict__ buf, const uint8_t *__restrict__ expect, uint32_t *__restrict__ bad) {
     __shared__ G128 sM[16];                  // nibble multiples of H^256: sM[8] = H^256, sM[4] = H^256 x, sM[2], sM[1], the rest by addition
     __shared__ uint32_t sR[16];              // what the four bits dropped by a 4-bit shift fold back into the top 16 bits
     __shared__ G128 sHp[9];                  // H^(2^k), k = 0..8
@@ -270,12 +270,79 @@ void k_gcm_tag(const GcmEntry *__restrict__ ents, uint8_t *__restrict__ buf) {
     if (tid == 0) {
         const G128 s = g_mul_bitwise(sAcc[0], sHp[0]);
         U4u t; t.x = be32(s.a ^ e.ej0[0]); t.y = be32(s.b ^ e.ej0[1]); t.z = be32(s.c ^ e.ej0[2]); t.w = be32(s.d ^ e.ej0[3]);
-        *(U4u *)(buf + e.off + e.len) = t;
+        if (expect) {                                                  // read side: the tag is compared, nothing is written
+            const U4u x = *(const U4u *)(expect + 16 * (size_t)blockIdx.x);
+            if (((t.x ^ x.x) | (t.y ^ x.y) | (t.z ^ x.z) | (t.w ^ x.w)) != 0) atomicAdd(bad, 1u);
+        } else *(U4u *)(buf + e.off + e.len) = t;
     }
 }
 
 void launch_gcm_tag(const GcmEntry *ents, uint32_t n, uint8_t *buf, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_gcm_tag, dim3(n), dim3(GH_THREADS), 0, st, ents, buf);
+    if (n) hipLaunchKernelGGL(k_gcm_tag, dim3(n), dim3(GH_THREADS), 0, st, ents, buf, (const uint8_t *)nullptr, (uint32_t *)nullptr);
+}
+void launch_gcm_verify(const GcmEntry *ents, uint32_t n, const uint8_t *buf, const uint8_t *expect, uint32_t *bad, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_gcm_tag, dim3(n), dim3(GH_THREADS), 0, st, ents, const_cast<uint8_t *>(buf), expect, bad);
+}
+
+
+// ------------------------------------------------------------------ CBC decryption (read side: DecryptCbcAes256Reader, lib/src/cipher/block/read.rs)
+// P_j = D(C_j) ^ C_(j-1), C_(-1) = IV: every block is independent once its predecessor's ciphertext is at hand.  One workgroup per
+// entry, 256 blocks per step, in place: a step loads its ciphertext (and the block in front of it) before anything is written, the
+// last ciphertext block of a step is carried to the next one through LDS.  The PKCS#7 padding is checked at the end and the
+// plaintext length reported (0xFFFFFFFF: bad length or padding -- wrong key or damage).  `key` holds the round keys of the
+// equivalent inverse cipher (FIPS-197 5.3.5).
+__global__ __launch_bounds__(256)
+void k_aes_cbc_dec(const CipherUnit *__restrict__ units, const uint8_t *__restrict__ ivs, const AesDecTabs *__restrict__ tabs,
+                   uint8_t *__restrict__ buf, const AesKey key, uint32_t *__restrict__ plain_len) {
+    __shared__ uint32_t sD[4][256], sS[256];
+    __shared__ uint32_t carry[4];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 1024; i += 256) (&sD[0][0])[i] = (&tabs->Td[0][0])[i];
+    sS[tid] = tabs->Sd[tid];
+    const CipherUnit u = units[blockIdx.x];
+    if (tid == 0) { const U4u iv = *(const U4u *)(ivs + (size_t)u.iv_idx * 16); carry[0] = iv.x; carry[1] = iv.y; carry[2] = iv.z; carry[3] = iv.w; }
+    __syncthreads();
+    if (u.len == 0 || (u.len & 15)) { if (tid == 0) plain_len[blockIdx.x] = 0xFFFFFFFFu; return; }
+    const uint32_t nb = u.len >> 4;
+    uint8_t *p = buf + u.off;
+    for (uint32_t base = 0; base < nb; base += 256) {
+        const uint32_t j = base + tid;
+        U4u cj = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
+        if (j < nb) {
+            cj = *(const U4u *)(p + 16 * (size_t)j);
+            if (tid) pv = *(const U4u *)(p + 16 * (size_t)(j - 1)); else { pv.x = carry[0]; pv.y = carry[1]; pv.z = carry[2]; pv.w = carry[3]; }
+        }
+        __syncthreads();                                             // everyone holds its ciphertext: the step may overwrite it now
+        if (j < nb) {
+            uint32_t s0 = cj.x ^ key.rk[0], s1 = cj.y ^ key.rk[1], s2 = cj.z ^ key.rk[2], s3 = cj.w ^ key.rk[3];
+#pragma unroll
+            for (int r = 1; r < 14; r++) {
+                const uint32_t t0 = sD[0][s0 & 0xFF] ^ sD[1][(s3 >> 8) & 0xFF] ^ sD[2][(s2 >> 16) & 0xFF] ^ sD[3][s1 >> 24] ^ key.rk[4 * r];
+                const uint32_t t1 = sD[0][s1 & 0xFF] ^ sD[1][(s0 >> 8) & 0xFF] ^ sD[2][(s3 >> 16) & 0xFF] ^ sD[3][s2 >> 24] ^ key.rk[4 * r + 1];
+                const uint32_t t2 = sD[0][s2 & 0xFF] ^ sD[1][(s1 >> 8) & 0xFF] ^ sD[2][(s0 >> 16) & 0xFF] ^ sD[3][s3 >> 24] ^ key.rk[4 * r + 2];
+                const uint32_t t3 = sD[0][s3 & 0xFF] ^ sD[1][(s2 >> 8) & 0xFF] ^ sD[2][(s1 >> 16) & 0xFF] ^ sD[3][s0 >> 24] ^ key.rk[4 * r + 3];
+                s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+            }
+            const uint32_t u0 = sS[s0 & 0xFF] | (sS[(s3 >> 8) & 0xFF] << 8) | (sS[(s2 >> 16) & 0xFF] << 16) | (sS[s1 >> 24] << 24);
+            const uint32_t u1 = sS[s1 & 0xFF] | (sS[(s0 >> 8) & 0xFF] << 8) | (sS[(s3 >> 16) & 0xFF] << 16) | (sS[s2 >> 24] << 24);
+            const uint32_t u2 = sS[s2 & 0xFF] | (sS[(s1 >> 8) & 0xFF] << 8) | (sS[(s0 >> 16) & 0xFF] << 16) | (sS[s3 >> 24] << 24);
+            const uint32_t u3 = sS[s3 & 0xFF] | (sS[(s2 >> 8) & 0xFF] << 8) | (sS[(s1 >> 16) & 0xFF] << 16) | (sS[s0 >> 24] << 24);
+            U4u o; o.x = u0 ^ key.rk[56] ^ pv.x; o.y = u1 ^ key.rk[57] ^ pv.y; o.z = u2 ^ key.rk[58] ^ pv.z; o.w = u3 ^ key.rk[59] ^ pv.w;
+            *(U4u *)(p + 16 * (size_t)j) = o;
+            if (tid == 255) { carry[0] = cj.x; carry[1] = cj.y; carry[2] = cj.z; carry[3] = cj.w; }
+            if (j + 1 == nb) {                                       // PKCS#7: the last byte names the padding length, all padding bytes repeat it
+                const uint32_t pad = o.w >> 24;
+                bool ok = pad >= 1 && pad <= 16;
+                const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+                for (uint32_t k = 0; ok && k < pad; k++) { const uint32_t bi = 15 - k; ok = ((w[bi >> 2] >> (8 * (bi & 3))) & 0xFF) == pad; }
+                plain_len[blockIdx.x] = ok ? u.len - pad : 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();                                             // the carry is in place before the next step's lane 0 reads it
+    }
+}
+void launch_aes_cbc_dec(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesDecTabs *tabs, uint8_t *buf, const AesKey &dkey, uint32_t *plain_len, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_aes_cbc_dec, dim3(n), dim3(256), 0, st, units, ivs, tabs, buf, dkey, plain_len);
 }
 
 void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, const AesKey *keys, hipStream_t st) {

@@ -350,6 +350,155 @@ extern "C" int pna_kdf_pbkdf2_sha256(const void *password, size_t password_len, 
     return PNA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Argon2 (RFC 9106, version 0x13, no secret / associated data) on the C++ host: the reference's default password hash
+// (hash::argon2_with_salt / derive_password_hash, lib/src/hash.rs:6-33,47-70; argon2 0.5.3).  The read side needs it to open archives
+// the reference wrote; the key is the raw hash output of key_size() bytes (lib/src/entry/write.rs:146-151).
+namespace {
+struct Blake2b {                                               // RFC 7693, unkeyed
+    uint64_t h[8], t = 0; uint8_t buf[128]; size_t fill = 0, outlen = 64;
+    static uint64_t ror(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    static const uint64_t *iv() {
+        static const uint64_t IV[8] = {0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+                                       0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+        return IV;
+    }
+    explicit Blake2b(size_t out) : outlen(out) { memcpy(h, iv(), 64); h[0] ^= 0x01010000ull ^ (uint64_t)out; }
+    void compress(const uint8_t *blk, bool last) {
+        static const uint8_t SG[10][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+        uint64_t m[16], v[16];
+        for (int i = 0; i < 16; i++) { m[i] = 0; for (int b = 0; b < 8; b++) m[i] |= (uint64_t)blk[8 * i + b] << (8 * b); }
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = iv()[i]; }
+        v[12] ^= t; if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint64_t x, uint64_t y) {
+            v[a] += v[b] + x; v[d] = ror(v[d] ^ v[a], 32); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 24);
+            v[a] += v[b] + y; v[d] = ror(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = SG[r % 10];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    }
+    void update(const void *d, size_t n) {
+        const uint8_t *p = (const uint8_t *)d;
+        while (n) {
+            if (fill == 128) { t += 128; compress(buf, false); fill = 0; }
+            const size_t k = std::min(n, 128 - fill);
+            memcpy(buf + fill, p, k); fill += k; p += k; n -= k;
+        }
+    }
+    void u32(uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; update(b, 4); }
+    void final(uint8_t *out) {
+        t += fill; memset(buf + fill, 0, 128 - fill); compress(buf, true);
+        uint8_t full[64]; for (int i = 0; i < 8; i++) for (int b = 0; b < 8; b++) full[8 * i + b] = (uint8_t)(h[i] >> (8 * b));
+        memcpy(out, full, outlen);
+    }
+};
+// H' of RFC 9106 3.3: output of any length from 64-byte BLAKE2b digests, 32 bytes kept of each but the last
+void argon_hprime(const uint8_t *in, size_t n, uint8_t *out, uint32_t T) {
+    if (T <= 64) { Blake2b b(T); b.u32(T); b.update(in, n); b.final(out); return; }
+    uint8_t v[64];
+    { Blake2b b(64); b.u32(T); b.update(in, n); b.final(v); }
+    size_t done = 0;
+    for (;;) {
+        memcpy(out + done, v, 32); done += 32;
+        if (T - done <= 64) break;
+        uint8_t nx[64]; { Blake2b b(64); b.update(v, 64); b.final(nx); } memcpy(v, nx, 64);
+    }
+    { Blake2b b(T - done); b.update(v, 64); b.final(out + done); }
+}
+typedef uint64_t ABlock[128];
+inline uint64_t a_mix(uint64_t x, uint64_t y) { return x + y + 2 * (x & 0xFFFFFFFFull) * (y & 0xFFFFFFFFull); }
+inline void a_quarter(uint64_t &a, uint64_t &b, uint64_t &c, uint64_t &d) {
+    a = a_mix(a, b); d = Blake2b::ror(d ^ a, 32); c = a_mix(c, d); b = Blake2b::ror(b ^ c, 24);
+    a = a_mix(a, b); d = Blake2b::ror(d ^ a, 16); c = a_mix(c, d); b = Blake2b::ror(b ^ c, 63);
+}
+inline void a_perm(uint64_t *v, const int idx[16]) {
+    auto q = [&](int a, int b, int c, int d) { a_quarter(v[idx[a]], v[idx[b]], v[idx[c]], v[idx[d]]); };
+    q(0, 4, 8, 12); q(1, 5, 9, 13); q(2, 6, 10, 14); q(3, 7, 11, 15); q(0, 5, 10, 15); q(1, 6, 11, 12); q(2, 7, 8, 13); q(3, 4, 9, 14);
+}
+// next = P(prev ^ ref) ^ prev ^ ref (^ old next from the second pass on), P = the BLAKE2b round on rows then columns of 8 x 8 registers
+void argon_g(const uint64_t *prev, const uint64_t *ref, uint64_t *next, bool xor_old) {
+    uint64_t r[128], keep[128];
+    for (int i = 0; i < 128; i++) { r[i] = prev[i] ^ ref[i]; keep[i] = xor_old ? r[i] ^ next[i] : r[i]; }
+    int idx[16];
+    for (int row = 0; row < 8; row++) { for (int k = 0; k < 16; k++) idx[k] = 16 * row + k; a_perm(r, idx); }
+    for (int col = 0; col < 8; col++) { for (int k = 0; k < 8; k++) { idx[2 * k] = 16 * k + 2 * col; idx[2 * k + 1] = 16 * k + 2 * col + 1; } a_perm(r, idx); }
+    for (int i = 0; i < 128; i++) next[i] = r[i] ^ keep[i];
+}
+} // namespace
+
+// kind: 0 Argon2d, 1 Argon2i, 2 Argon2id
+extern "C" int pna_kdf_argon2(int kind, const void *password, size_t password_len, const void *salt, size_t salt_len,
+                              uint32_t t_cost, uint32_t m_cost_kib, uint32_t lanes, uint8_t *key, size_t key_len) {
+    if ((!password && password_len) || (!salt && salt_len) || !key || kind < 0 || kind > 2) return PNA_E_INVAL;
+    if (lanes < 1 || lanes > 0xFFFFFF || t_cost < 1 || m_cost_kib < 8 * lanes || key_len < 4 || key_len > 1024 || m_cost_kib > (1u << 24)) return PNA_E_INVAL;
+    const uint32_t blocks = 4 * lanes * (m_cost_kib / (4 * lanes)), lane_len = blocks / lanes, seg = lane_len / 4;
+    std::vector<uint64_t> mem;
+    try { mem.resize((size_t)blocks * 128); } catch (...) { return PNA_E_NOMEM; }
+    auto B = [&](uint32_t lane, uint32_t col) -> uint64_t * { return mem.data() + ((size_t)lane * lane_len + col) * 128; };
+    uint8_t h0[72];
+    {
+        Blake2b b(64);
+        b.u32(lanes); b.u32((uint32_t)key_len); b.u32(m_cost_kib); b.u32(t_cost); b.u32(0x13); b.u32((uint32_t)kind);
+        b.u32((uint32_t)password_len); b.update(password, password_len);
+        b.u32((uint32_t)salt_len); b.update(salt, salt_len);
+        b.u32(0); b.u32(0);
+        b.final(h0);
+    }
+    for (uint32_t l = 0; l < lanes; l++)
+        for (uint32_t j = 0; j < 2; j++) {
+            uint8_t raw[1024];
+            for (int k = 0; k < 4; k++) { h0[64 + k] = (uint8_t)(j >> (8 * k)); h0[68 + k] = (uint8_t)(l >> (8 * k)); }
+            argon_hprime(h0, 72, raw, 1024);
+            uint64_t *blk = B(l, j);
+            for (int i = 0; i < 128; i++) { blk[i] = 0; for (int k = 0; k < 8; k++) blk[i] |= (uint64_t)raw[8 * i + k] << (8 * k); }
+        }
+    const ABlock zero = {0};
+    for (uint32_t pass = 0; pass < t_cost; pass++)
+        for (uint32_t slice = 0; slice < 4; slice++)
+            for (uint32_t lane = 0; lane < lanes; lane++) {
+                const bool indep = kind == 1 || (kind == 2 && pass == 0 && slice < 2);     // data-independent addressing
+                ABlock in = {0}, addr = {0};
+                if (indep) { in[0] = pass; in[1] = lane; in[2] = slice; in[3] = blocks; in[4] = t_cost; in[5] = (uint64_t)kind; }
+                auto next_addr = [&]() { in[6]++; ABlock t = {0}; argon_g(zero, in, t, false); argon_g(zero, t, addr, false); };
+                uint32_t first = 0;
+                if (pass == 0 && slice == 0) { first = 2; if (indep) next_addr(); }
+                for (uint32_t i = first; i < seg; i++) {
+                    const uint32_t col = slice * seg + i, pcol = col ? col - 1 : lane_len - 1;
+                    uint64_t rnd;
+                    if (indep) { if (i % 128 == 0) next_addr(); rnd = addr[i % 128]; } else rnd = B(lane, pcol)[0];
+                    uint32_t rl = (uint32_t)((rnd >> 32) % lanes);
+                    if (pass == 0 && slice == 0) rl = lane;
+                    const bool same = rl == lane;
+                    // number of blocks that may be referenced (RFC 9106 3.4.1.1 / 3.4.2)
+                    uint64_t area;
+                    if (pass == 0) area = slice == 0 ? i - 1 : (same ? (uint64_t)slice * seg + i - 1 : (uint64_t)slice * seg - (i == 0 ? 1 : 0));
+                    else area = same ? (uint64_t)lane_len - seg + i - 1 : (uint64_t)lane_len - seg - (i == 0 ? 1 : 0);
+                    uint64_t x = rnd & 0xFFFFFFFFull; x = (x * x) >> 32;
+                    const uint64_t rel = area - 1 - ((area * x) >> 32);
+                    const uint64_t start = (pass == 0 || slice == 3) ? 0 : (uint64_t)(slice + 1) * seg;
+                    const uint32_t rcol = (uint32_t)((start + rel) % lane_len);
+                    argon_g(B(lane, pcol), B(rl, rcol), B(lane, col), pass != 0);
+                }
+            }
+    uint64_t fin[128];
+    memcpy(fin, B(0, lane_len - 1), sizeof fin);
+    for (uint32_t l = 1; l < lanes; l++) for (int i = 0; i < 128; i++) fin[i] ^= B(l, lane_len - 1)[i];
+    uint8_t raw[1024];
+    for (int i = 0; i < 128; i++) for (int k = 0; k < 8; k++) raw[8 * i + k] = (uint8_t)(fin[i] >> (8 * k));
+    argon_hprime(raw, 1024, key, (uint32_t)key_len);
+    return PNA_OK;
+}
+
 // `pna create --aes [ctr|cbc] --password ... --pbkdf2`: one key derivation per archive (WriteOptions caches it, lib/src/entry/options.rs),
 // a fresh IV per entry; non-solid zstd / deflate archives on the device path.
 extern "C" int pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,

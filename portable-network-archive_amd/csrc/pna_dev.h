@@ -95,6 +95,7 @@ struct CrcTabs {
 // cipher stage (k_cipher.hip)
 struct AesTabs { uint32_t Te[4][256]; };   // Te[0][x] = bytes (2S, S, S, 3S) of S = sbox[x], little-endian; Te[k] = Te[0] rotated left by 8k bits
 struct AesKey  { uint32_t rk[60]; };       // AES-256 round keys, word 4r + c = column c of round r, little-endian
+struct AesDecTabs { uint32_t Td[4][256]; uint32_t Sd[256]; };   // equivalent inverse cipher: Td[0][x] = bytes (14, 9, 13, 11) x Si[x]; Sd = inverse S-box
 struct CipherUnit {
     uint64_t off;            // first byte of the unit in the buffer
     uint64_t pos;            // CTR: its byte position in the entry's cipher stream (keystream block = pos / 16)

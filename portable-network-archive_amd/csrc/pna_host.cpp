@@ -66,6 +66,8 @@ std::vector<uint8_t> frame_fhed_bytes(const char *name, int compression, int enc
 void sha256_bytes(const void *a, size_t an, const void *b, size_t bn, uint8_t out[32]);
 void hkdf_sha256_32(const void *ikm, size_t ikm_len, const void *salt, size_t salt_len, const void *info, size_t info_len, uint8_t okm[32]);
 void launch_gcm_tag(const GcmEntry *ents, uint32_t n, uint8_t *buf, hipStream_t st);
+void launch_gcm_verify(const GcmEntry *ents, uint32_t n, const uint8_t *buf, const uint8_t *expect, uint32_t *bad, hipStream_t st);
+void launch_aes_cbc_dec(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesDecTabs *tabs, uint8_t *buf, const AesKey &dkey, uint32_t *plain_len, hipStream_t st);
 size_t frame_entry_prefix_enc_bound(const char *name, const char *phsf);
 void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, const AesKey *keys, hipStream_t st);
 void launch_aes_cbc_enc(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, hipStream_t st);
@@ -108,7 +110,8 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
-    DevBuf x_arc, x_pk, x_raw, x_desc, x_place, x_flag;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
+    DevBuf x_arc, x_pk, x_raw, x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
+    bool aes_dec_ready = false;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
     DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
     hipEvent_t ev_ci[2] = {};
@@ -177,7 +180,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw, &c->x_desc, &c->x_place, &c->x_flag, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw, &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -310,6 +313,38 @@ static void aes256_expand(const uint8_t key[32], AesKey &k) {
         for (int j = 0; j < 4; j++) w[i][j] = (uint8_t)(w[i - 8][j] ^ t[j]);
     }
     for (int i = 0; i < 60; i++) k.rk[i] = (uint32_t)w[i][0] | ((uint32_t)w[i][1] << 8) | ((uint32_t)w[i][2] << 16) | ((uint32_t)w[i][3] << 24);
+}
+static uint8_t gf_mul8(uint8_t a, uint8_t b) { uint8_t r = 0; while (b) { if (b & 1) r ^= a; a = (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1B : 0)); b >>= 1; } return r; }
+// equivalent inverse cipher (FIPS-197 5.3.5): tables of InvSubBytes + InvMixColumns, round keys reversed with InvMixColumns applied to
+// the middle ones
+static void build_aes_dec_tabs(AesDecTabs &t) {
+    uint8_t sb[256], si[256]; aes_sbox(sb);
+    for (int x = 0; x < 256; x++) si[sb[x]] = (uint8_t)x;
+    for (uint32_t x = 0; x < 256; x++) {
+        const uint8_t v = si[x];
+        const uint32_t w = (uint32_t)gf_mul8(v, 14) | ((uint32_t)gf_mul8(v, 9) << 8) | ((uint32_t)gf_mul8(v, 13) << 16) | ((uint32_t)gf_mul8(v, 11) << 24);
+        t.Td[0][x] = w; t.Td[1][x] = (w << 8) | (w >> 24); t.Td[2][x] = (w << 16) | (w >> 16); t.Td[3][x] = (w << 24) | (w >> 8);
+        t.Sd[x] = v;
+    }
+}
+static void aes256_dec_key(const AesKey &k, AesKey &d) {
+    for (int c4 = 0; c4 < 4; c4++) { d.rk[c4] = k.rk[56 + c4]; d.rk[56 + c4] = k.rk[c4]; }
+    for (int r = 1; r < 14; r++)
+        for (int c4 = 0; c4 < 4; c4++) {
+            const uint32_t w = k.rk[4 * (14 - r) + c4];
+            const uint8_t a0 = (uint8_t)w, a1 = (uint8_t)(w >> 8), a2 = (uint8_t)(w >> 16), a3 = (uint8_t)(w >> 24);
+            const uint8_t r0 = gf_mul8(a0, 14) ^ gf_mul8(a1, 11) ^ gf_mul8(a2, 13) ^ gf_mul8(a3, 9), r1 = gf_mul8(a0, 9) ^ gf_mul8(a1, 14) ^ gf_mul8(a2, 11) ^ gf_mul8(a3, 13);
+            const uint8_t r2 = gf_mul8(a0, 13) ^ gf_mul8(a1, 9) ^ gf_mul8(a2, 14) ^ gf_mul8(a3, 11), r3 = gf_mul8(a0, 11) ^ gf_mul8(a1, 13) ^ gf_mul8(a2, 9) ^ gf_mul8(a3, 14);
+            d.rk[4 * r + c4] = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)r2 << 16) | ((uint32_t)r3 << 24);
+        }
+}
+static int ensure_aes_dec(pna_gpu_ctx *c) {
+    if (c->aes_dec_ready) return PNA_OK;
+    static AesDecTabs t; build_aes_dec_tabs(t);
+    if (c->aes_dtabs.ensure(sizeof(t))) return fail(c, PNA_E_NOMEM, "aes tables");
+    HIPCHK(c, hipMemcpy(c->aes_dtabs.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    c->aes_dec_ready = true;
+    return PNA_OK;
 }
 static int ensure_aes(pna_gpu_ctx *c) {
     if (c->aes_ready) return PNA_OK;
@@ -1117,6 +1152,8 @@ struct XEntry {
     bool has_size = false; uint64_t raw_size = 0; std::string phsf;
     std::vector<XPiece> pieces; uint64_t stream_len = 0;
     uint64_t pk_off = 0, pay_len = 0, raw_off = 0;            // payload (prefix stripped) in the packed buffer; decoded bytes in the raw buffer
+    std::vector<uint8_t> fhed;                                 // FHED body: the GCM stream key is bound to it
+    uint32_t gcm_seg = 0;                                      // GCM STREAM: segment size of the stream header
 };
 struct XSolid {                                                // SHED [PHSF] SDAT* SEND -- lib/src/entry.rs:465-484,567-583
     int compression = 0, encryption = 0, cipher_mode = 0; std::string phsf;
@@ -1173,7 +1210,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             if (in_entry || len < 6 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad entry header");
             cur = XEntry(); in_entry = true;
             cur.kind = data[2]; cur.compression = data[3]; cur.encryption = data[4]; cur.cipher_mode = data[5];
-            cur.name.assign((const char *)data + 6, len - 6);
+            cur.name.assign((const char *)data + 6, len - 6); cur.fhed.assign(data, data + len);
         } else if (!in_entry) { if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk between entries"); }
         else if (is_fdat) { cur.pieces.push_back(XPiece{pos + 8, len}); cur.stream_len += len; }
         else if (memcmp(ty, "fSIZ", 4) == 0) { if (len > 8) return fail(c, PNA_E_UNSUPPORTED, "entry beyond 2^64 bytes"); cur.has_size = true; cur.raw_size = 0; for (uint32_t i = 0; i < len; i++) cur.raw_size = (cur.raw_size << 8) | data[i]; }
@@ -1189,7 +1226,31 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     auto key_for = [&](const std::string &phsf, const uint8_t **out) -> int {
         for (auto &k : keys) if (k.first == phsf) { *out = k.second.data(); return PNA_OK; }
         // "$pbkdf2-sha256$i=<rounds>,l=<len>$<salt>" (derive_password_hash, lib/src/hash.rs:47-88); Argon2 strings need the Rust host
-        if (phsf.rfind("$pbkdf2-sha256$", 0) != 0) return fail(c, PNA_E_UNSUPPORTED, "password hash other than pbkdf2-sha256");
+        if (phsf.rfind("$argon2", 0) == 0) {
+            // "$argon2id$v=19$m=<KiB>,t=<passes>,p=<lanes>$<salt>" (argon2 0.5: Params::try_from(&PasswordHash), lib/src/hash.rs:56-70)
+            int kind = -1; size_t p1 = 0;
+            if (phsf.rfind("$argon2id$", 0) == 0) { kind = 2; p1 = 10; } else if (phsf.rfind("$argon2i$", 0) == 0) { kind = 1; p1 = 9; } else if (phsf.rfind("$argon2d$", 0) == 0) { kind = 0; p1 = 9; }
+            if (kind < 0) return fail(c, PNA_E_INVAL, "malformed PHSF");
+            if (phsf.compare(p1, 2, "v=") == 0) { const size_t q = phsf.find('$', p1); if (q == std::string::npos || strtoul(phsf.c_str() + p1 + 2, nullptr, 10) != 19) return fail(c, PNA_E_UNSUPPORTED, "argon2 version other than 0x13"); p1 = q + 1; }
+            const size_t p2 = phsf.find('$', p1);
+            if (p2 == std::string::npos) return fail(c, PNA_E_INVAL, "malformed PHSF");
+            uint32_t m = 19456, t = 2, lanes = 1;                 // argon2 0.5 defaults
+            const std::string prm = phsf.substr(p1, p2 - p1);
+            for (size_t q = 0; q < prm.size();) {
+                const size_t e2 = prm.find(',', q); const std::string kv = prm.substr(q, e2 == std::string::npos ? std::string::npos : e2 - q);
+                if (kv.size() > 2 && kv[1] == '=') { const uint32_t v = (uint32_t)strtoul(kv.c_str() + 2, nullptr, 10); if (kv[0] == 'm') m = v; else if (kv[0] == 't') t = v; else if (kv[0] == 'p') lanes = v; }
+                if (e2 == std::string::npos) break; q = e2 + 1;
+            }
+            std::vector<uint8_t> salt;
+            std::string sb = phsf.substr(p2 + 1); const size_t p3 = sb.find('$'); if (p3 != std::string::npos) sb.resize(p3);
+            if (!b64_decode_nopad(sb, salt)) return fail(c, PNA_E_INVAL, "malformed PHSF");
+            std::vector<uint8_t> key(32);
+            int rc = pna_kdf_argon2(kind, password, password_len, salt.data(), salt.size(), t, m, lanes, key.data(), 32);
+            if (rc) return fail(c, rc, "key derivation failed (argon2 parameters)");
+            keys.emplace_back(phsf, std::move(key)); *out = keys.back().second.data();
+            return PNA_OK;
+        }
+        if (phsf.rfind("$pbkdf2-sha256$", 0) != 0) return fail(c, PNA_E_UNSUPPORTED, "password hash other than argon2 / pbkdf2-sha256");
         const size_t p1 = 15, p2 = phsf.find('$', p1);
         if (p2 == std::string::npos) return fail(c, PNA_E_INVAL, "malformed PHSF");
         uint32_t rounds = 600000;
@@ -1206,33 +1267,59 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         return PNA_OK;
     };
     uint64_t pk_total = 0, raw_total = 0;
-    std::vector<PlaceDescH> places; std::vector<uint8_t> ivs; std::vector<size_t> enc_idx;
+    std::vector<PlaceDescH> places; std::vector<uint8_t> ivs; std::vector<size_t> enc_idx, gcm_idx, nosize_idx;
+    std::vector<std::vector<uint8_t>> nosize_data;
     for (size_t i = 0; i < n; i++) {
         XEntry &e = ents[i];
         uint64_t prefix = 0;
+        // bytes [lo, hi) of the entry's data stream (the concatenated FDAT bodies) -> host buffer / gather descriptors
+        auto stream_read = [&](uint64_t lo, uint64_t n2, uint8_t *out) {
+            uint64_t at2 = 0, got = 0;
+            for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < n2; k++) if (at2 + k >= lo) out[got++] = a[p.off + k]; at2 += p.len; if (got >= n2) break; }
+        };
+        auto stream_place = [&](uint64_t lo, uint64_t hi, uint64_t dst) {
+            uint64_t at2 = 0;
+            for (const XPiece &p : e.pieces) {
+                const uint64_t s0 = std::max<uint64_t>(lo, at2), s1 = std::min<uint64_t>(hi, at2 + p.len);
+                for (uint64_t k = s0; k < s1; k += (1u << 20)) places.push_back(PlaceDescH{p.off + (k - at2), dst + (k - lo), (uint32_t)std::min<uint64_t>(1u << 20, s1 - k), 0});
+                at2 += p.len;
+            }
+        };
+        if (e.compression != PNA_ALGO_STORE && e.compression != PNA_ALGO_ZSTD && e.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "compression method not decoded on the device (xz)");
+        e.pk_off = pk_total;
         if (e.encryption != PNA_ENC_NONE) {
-            if (e.encryption != PNA_ENC_AES || e.cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "only AES-CTR entries are decrypted by this driver");
+            if (e.encryption != PNA_ENC_AES) return fail(c, PNA_E_UNSUPPORTED, "only AES entries are decrypted by this driver");
             if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
             if (e.phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
-            if (e.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
-            prefix = 16;
-            uint8_t iv[16]; uint64_t got = 0;                   // the IV may span data pieces (prepend_data_prefix makes it a piece of its own)
-            for (const XPiece &p : e.pieces) for (uint32_t k = 0; k < p.len && got < 16; k++) iv[got++] = a[p.off + k];
-            ivs.insert(ivs.end(), iv, iv + 16); enc_idx.push_back(i);
-        }
-        if (e.compression != PNA_ALGO_STORE && e.compression != PNA_ALGO_ZSTD && e.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "compression method not decoded on the device (xz)");
-        e.pk_off = pk_total; e.pay_len = e.stream_len - prefix;
-        uint64_t skip = prefix, at = e.pk_off;
-        for (const XPiece &p : e.pieces) {
-            uint64_t o = p.off, l = p.len;
-            if (skip) { const uint64_t s = std::min<uint64_t>(skip, l); o += s; l -= s; skip -= s; }
-            for (uint64_t k = 0; k < l; k += (1u << 20)) { places.push_back(PlaceDescH{o + k, at + k, (uint32_t)std::min<uint64_t>(1u << 20, l - k), 0}); }
-            at += l;
-        }
+            if (e.cipher_mode == PNA_MODE_CTR || e.cipher_mode == PNA_MODE_CBC) {
+                if (e.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
+                prefix = 16;
+                uint8_t iv[16]; stream_read(0, 16, iv);          // the IV may span data pieces (prepend_data_prefix makes it a piece of its own)
+                ivs.insert(ivs.end(), iv, iv + 16); enc_idx.push_back(i);
+                e.pay_len = e.stream_len - prefix;
+                stream_place(prefix, e.stream_len, e.pk_off);
+            } else if (e.cipher_mode == PNA_MODE_GCM) {
+                // stream header, then segments of (segment size + 16-byte tag), the last one shorter: only the ciphertext is gathered
+                if (e.stream_len < 75 + 16) return fail(c, PNA_E_INVAL, "datastream shorter than the stream header");
+                uint8_t hd[75]; stream_read(0, 75, hd);
+                e.gcm_seg = rd_be32(hd + 39);
+                if (e.gcm_seg == 0 || e.gcm_seg > (64u << 20)) return fail(c, PNA_E_INVAL, "GCM segment size out of range");
+                gcm_idx.push_back(i);
+                uint64_t rest = e.stream_len - 75, at2 = 75, outp = e.pk_off;
+                while (rest) {
+                    const uint64_t segl = std::min<uint64_t>(rest, (uint64_t)e.gcm_seg + 16);
+                    if (segl < 16) return fail(c, PNA_E_INVAL, "GCM segment shorter than a tag");
+                    stream_place(at2, at2 + segl - 16, outp);
+                    outp += segl - 16; at2 += segl; rest -= segl;
+                }
+                e.pay_len = outp - e.pk_off;
+            } else return fail(c, PNA_E_UNSUPPORTED, "unknown cipher mode");
+        } else { e.pay_len = e.stream_len; stream_place(0, e.stream_len, e.pk_off); }
         pk_total = (pk_total + e.pay_len + 15) & ~(uint64_t)15;
         if (e.compression != PNA_ALGO_STORE) {
-            if (!e.has_size) return fail(c, PNA_E_UNSUPPORTED, "compressed entry without fSIZ");
-            e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15;
+            // fSIZ is optional (older writers omit it): a zstd payload is then decoded like a solid stream, its size found by the decoder
+            if (!e.has_size) { if (e.compression != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "deflate entry without fSIZ"); nosize_idx.push_back(i); }
+            else { e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15; }
         }
     }
     for (XSolid &so : solids) {
@@ -1285,29 +1372,122 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     HIPCHK(c, hipStreamSynchronize(st));
     if (flag[0]) { c->err = "data chunk CRC mismatch (" + std::to_string(flag[0]) + " FDAT / SDAT chunks)"; return PNA_E_INVAL; }
     if (!enc_idx.empty()) {
-        // entries sharing a PHSF string share the key: one cipher call per key
+        // entries sharing a PHSF string and a mode share the key: one cipher call per group
         std::vector<bool> done(enc_idx.size(), false);
         for (size_t j = 0; j < enc_idx.size(); j++) {
             if (done[j]) continue;
+            const XEntry &e0 = ents[enc_idx[j]];
             const uint8_t *key = nullptr;
-            rc = key_for(ents[enc_idx[j]].phsf, &key); if (rc) return rc;
-            std::vector<uint64_t> off, len; std::vector<uint8_t> iv2;
+            rc = key_for(e0.phsf, &key); if (rc) return rc;
+            std::vector<uint64_t> off, len; std::vector<uint8_t> iv2; std::vector<size_t> who;
             for (size_t k = j; k < enc_idx.size(); k++)
-                if (!done[k] && ents[enc_idx[k]].phsf == ents[enc_idx[j]].phsf) {
-                    done[k] = true; off.push_back(ents[enc_idx[k]].pk_off); len.push_back(ents[enc_idx[k]].pay_len);
+                if (!done[k] && ents[enc_idx[k]].phsf == e0.phsf && ents[enc_idx[k]].cipher_mode == e0.cipher_mode) {
+                    done[k] = true; off.push_back(ents[enc_idx[k]].pk_off); len.push_back(ents[enc_idx[k]].pay_len); who.push_back(enc_idx[k]);
                     iv2.insert(iv2.end(), ivs.begin() + 16 * k, ivs.begin() + 16 * k + 16);
                 }
-            pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv2.data();
-            rc = pna_gpu_cipher_apply_device(c, &ci, 1, off.size(), c->x_pk.p, off.data(), len.data(), st);
-            if (rc) return rc;
+            if (e0.cipher_mode == PNA_MODE_CTR) {
+                pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv2.data();
+                rc = pna_gpu_cipher_apply_device(c, &ci, 1, off.size(), c->x_pk.p, off.data(), len.data(), st);
+                if (rc) return rc;
+            } else {                                              // CBC: DecryptCbcAes256Reader, lib/src/entry/read.rs:77-82
+                rc = ensure_aes_dec(c); if (rc) return rc;
+                std::vector<CipherUnit> units(off.size());
+                for (size_t q = 0; q < off.size(); q++) { if (len[q] >= 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "cipher range too long"); units[q] = CipherUnit{off[q], 0, (uint32_t)len[q], (uint32_t)q}; }
+                if (c->ci_units.ensure(units.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure(iv2.size() + 16) || c->x_plen.ensure(units.size() * 4 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+                AesKey ek, dk; aes256_expand(key, ek); aes256_dec_key(ek, dk);
+                std::vector<uint32_t> plen(units.size());
+                HIPCHK(c, hipMemcpyAsync(c->ci_units.p, units.data(), units.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
+                HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, iv2.data(), iv2.size(), hipMemcpyHostToDevice, st));
+                launch_aes_cbc_dec((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesDecTabs *)c->aes_dtabs.p,
+                                   (uint8_t *)c->x_pk.p, dk, (uint32_t *)c->x_plen.p, st);
+                HIPCHK(c, hipMemcpyAsync(plen.data(), c->x_plen.p, units.size() * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(st));
+                for (size_t q = 0; q < who.size(); q++) {
+                    if (plen[q] == 0xFFFFFFFFu) return fail(c, PNA_E_INVAL, "CBC: bad length or padding (wrong password or damaged data)");
+                    ents[who[q]].pay_len = plen[q];
+                }
+            }
         }
+    }
+    if (!gcm_idx.empty()) {
+        // cipher mode 2 (decrypt_reader, (_, CipherMode::GCM): lib/src/entry/read.rs:105-140): key confirmation first -- a wrong password is
+        // told apart from tampering --, then every segment's tag (k_gcm_tag in verify mode), then the CTR keystream with the stream keys
+        rc = ensure_aes(c); if (rc) return rc;
+        std::vector<GcmEntry> gents; std::vector<uint8_t> tags, giv; std::vector<AesKey> gkeys; std::vector<CipherUnit> units;
+        for (size_t gi : gcm_idx) {
+            XEntry &e = ents[gi];
+            const uint8_t *km = nullptr;
+            rc = key_for(e.phsf, &km); if (rc) return rc;
+            uint8_t hd[75]; { uint64_t got = 0; for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < 75; k++) hd[got++] = a[p.off + k]; if (got >= 75) break; } }
+            uint8_t kc[32]; hkdf_sha256_32(km, 32, nullptr, 0, "PNA-KC-v1", 9, kc);
+            if (memcmp(kc, hd + 43, 32) != 0) return fail(c, PNA_E_INVAL, "GCM STREAM: key confirmation failed (wrong password)");
+            uint8_t info[88], ph[32], ks[32];
+            memcpy(info, "PNA-STREAM-v1", 13);
+            sha256_bytes("FHED", 4, e.fhed.data(), e.fhed.size(), info + 13);
+            sha256_bytes(e.phsf.data(), e.phsf.size(), nullptr, 0, ph); memcpy(info + 45, ph, 32);
+            memcpy(info + 77, hd + 32, 7); memcpy(info + 84, hd + 39, 4);
+            hkdf_sha256_32(km, 32, hd, 32, info, 88, ks);
+            AesKey rk; aes256_expand(ks, rk);
+            uint8_t zero[16] = {0}, hb[16]; aes256_block_host(rk, zero, hb);
+            uint64_t rest = e.stream_len - 75, at2 = 75, outp = e.pk_off; uint32_t counter = 0;
+            while (rest) {
+                const uint64_t segl = std::min<uint64_t>(rest, (uint64_t)e.gcm_seg + 16), ctl = segl - 16;
+                const bool fin = segl == rest;
+                uint8_t j0[16], eb[16], tag[16];
+                memcpy(j0, hd + 32, 7); j0[7] = (uint8_t)(counter >> 24); j0[8] = (uint8_t)(counter >> 16); j0[9] = (uint8_t)(counter >> 8); j0[10] = (uint8_t)counter; j0[11] = fin ? 1 : 0;
+                j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+                aes256_block_host(rk, j0, eb);
+                GcmEntry ge{outp, (uint32_t)ctl, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                for (int w = 0; w < 4; w++) {
+                    ge.h[w] = ((uint32_t)hb[4 * w] << 24) | ((uint32_t)hb[4 * w + 1] << 16) | ((uint32_t)hb[4 * w + 2] << 8) | hb[4 * w + 3];
+                    ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
+                }
+                { uint64_t p2 = 0, got = 0; const uint64_t lo = at2 + ctl;      // the stored tag, wherever the chunk boundaries fall
+                  for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < 16; k++) if (p2 + k >= lo) tag[got++] = a[p.off + k]; p2 += p.len; if (got >= 16) break; } }
+                const uint32_t idx = (uint32_t)gents.size();
+                gents.push_back(ge); tags.insert(tags.end(), tag, tag + 16); gkeys.push_back(rk);
+                j0[15] = 2; giv.insert(giv.end(), j0, j0 + 16);
+                for (uint64_t o = 0; o < ctl; o += CTR_UNIT) units.push_back(CipherUnit{outp + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, ctl - o), idx});
+                outp += ctl; at2 += segl; rest -= segl; counter++;
+                if (!fin && segl != (uint64_t)e.gcm_seg + 16) return fail(c, PNA_E_INVAL, "GCM STREAM: short non-final segment");
+            }
+        }
+        if (c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16) || c->x_tags.ensure(tags.size() + 16) || c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) ||
+            c->ci_ivs.ensure(giv.size() + 16) || c->ci_units.ensure(units.size() * sizeof(CipherUnit) + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+        HIPCHK(c, hipMemcpyAsync(c->x_flag.p, flag0, 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ci_gcm.p, gents.data(), gents.size() * sizeof(GcmEntry), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->x_tags.p, tags.data(), tags.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ci_keys.p, gkeys.data(), gkeys.size() * sizeof(AesKey), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, giv.data(), giv.size(), hipMemcpyHostToDevice, st));
+        if (!units.empty()) HIPCHK(c, hipMemcpyAsync(c->ci_units.p, units.data(), units.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
+        launch_gcm_verify((const GcmEntry *)c->ci_gcm.p, (uint32_t)gents.size(), (const uint8_t *)c->x_pk.p, (const uint8_t *)c->x_tags.p, (uint32_t *)c->x_flag.p, st);
+        HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (flag[0]) return fail(c, PNA_E_INVAL, "GCM STREAM: authentication failure (a segment tag does not match)");
+        AesKey k0{};
+        launch_aes_ctr((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesTabs *)c->aes_tabs.p, (uint8_t *)c->x_pk.p, k0, (const AesKey *)c->ci_keys.p, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
     }
     for (int algo : {PNA_ALGO_ZSTD, PNA_ALGO_DEFLATE}) {
         std::vector<uint64_t> so, sl, dof, rl;
-        for (const XEntry &e : ents) if (e.compression == algo) { so.push_back(e.pk_off); sl.push_back(e.pay_len); dof.push_back(e.raw_off); rl.push_back(e.raw_size); }
+        for (const XEntry &e : ents) if (e.compression == algo && e.has_size) { so.push_back(e.pk_off); sl.push_back(e.pay_len); dof.push_back(e.raw_off); rl.push_back(e.raw_size); }
         if (so.empty()) continue;
         rc = pna_gpu_decompress_batch_device(c, algo, so.size(), c->x_pk.p, so.data(), sl.data(), c->x_raw.p, dof.data(), rl.data(), st);
         if (rc) return rc;
+    }
+    for (size_t i : nosize_idx) {                                 // compatibility path, one decode call per entry
+        XEntry &e = ents[i];
+        uint32_t nfr = 0; uint64_t got = 0;
+        rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, e.pk_off, e.pay_len, &nfr, st); if (rc) return rc;
+        const uint64_t cap = nfr > 1 ? (uint64_t)nfr * SEG_SIZE : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, 64 * e.pay_len));
+        if (c->solid_plain.ensure(cap + 8192)) return fail(c, PNA_E_NOMEM, "entry buffer");
+        rc = pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, e.pk_off, e.pay_len, c->solid_plain.p, 0, cap, &got, st); if (rc) return rc;
+        nosize_data.emplace_back((size_t)got);
+        if (got) HIPCHK(c, hipMemcpy(nosize_data.back().data(), c->solid_plain.p, got, hipMemcpyDeviceToHost));
+        e.raw_size = got; e.raw_off = nosize_data.size() - 1;      // index into nosize_data
     }
     // ---- solid entries: decrypt (CTR), decode a stream of unknown size, walk the inner records
     struct Inner { std::string name; int kind; std::vector<XPiece> pieces; uint64_t len; };
@@ -1397,7 +1577,8 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     for (size_t i = 0; i < n; i++) {
         rc = deliver_solids(i); if (rc) return rc;
         const XEntry &e = ents[i];
-        const uint8_t *d = e.compression == PNA_ALGO_STORE ? (const uint8_t *)c->hp_in[0].p + e.pk_off : (const uint8_t *)c->hp_out[0].p + e.raw_off;
+        const uint8_t *d = e.compression == PNA_ALGO_STORE ? (const uint8_t *)c->hp_in[0].p + e.pk_off
+                         : (e.has_size ? (const uint8_t *)c->hp_out[0].p + e.raw_off : nosize_data[(size_t)e.raw_off].data());
         const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
         if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
         if (cb(user, index++, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");

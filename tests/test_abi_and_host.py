@@ -148,3 +148,14 @@ def test_host_kdf_matches_hashlib(pna):
 def test_host_kdf_phsf_is_read_by_the_oracle(pna, codec):
     key, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
     assert codec.derive_key_from_phsf(phsf, b"password") == key
+
+
+def test_host_argon2_matches_the_oracle(pna, codec):
+    """pna_kdf_argon2 (the C++ host's hash::argon2_with_salt) against the oracle's Argon2, which is pinned by the reference's encrypted
+    fixtures: all three kinds, one and several lanes, several passes, odd output lengths."""
+    for kind, pw, salt, t, m, p, kl in [(2, b"password", bytes(range(16)), 3, 4096, 1, 32), (2, b"password", b"saltsalt", 1, 50, 1, 32),
+                                        (2, b"pw", b"0123456789abcdef", 2, 64, 4, 32), (1, b"pw", b"0123456789abcdef", 2, 64, 2, 24),
+                                        (0, b"", b"0123456789abcdef", 1, 32, 2, 70), (2, b"x" * 100, b"y" * 33, 4, 19, 2, 16)]:
+        assert pna.kdf_argon2(kind, pw, salt, t, m, p, kl) == codec.argon2(kind, pw, salt, t, m, p, kl), (kind, t, m, p)
+    with pytest.raises(pna.PnaGpuError):
+        pna.kdf_argon2(2, b"pw", b"salt", 1, 4, 1)             # m < 8 p

@@ -328,6 +328,60 @@ def test_extract_driver_decrypts_ctr_archives(gpu_ctx, pna, codec):
     with pytest.raises(pna.PnaGpuError) as ei:
         pna.extract_archive(gpu_ctx, arc)
     assert ei.value.code == -2
-    with pytest.raises(pna.PnaGpuError) as ei:                  # the reference's fixture: Argon2id PHSF needs the Rust host's KDF
-        pna.extract_archive(gpu_ctx, open(os.path.join(os.path.dirname(__file__), "golden", "zstd_aes_ctr.pna"), "rb").read(), b"password")
-    assert ei.value.code == -7
+
+
+@pytest.mark.parametrize("fixture", ["zstd_aes_ctr.pna", "zstd_aes_cbc.pna", "zstd_aes_gcm.pna"])
+def test_extract_driver_opens_the_reference_encrypted_archives(gpu_ctx, pna, pf, codec, fixture):
+    """The reference's encrypted golden archives through the read-side driver: Argon2id on the C++ host, CTR / CBC / GCM-STREAM on
+    the device (GCM: key confirmation, segment tags), zstd entries without fSIZ sized by the decoder.  Expected: the oracle's reading."""
+    arc = open(os.path.join(os.path.dirname(__file__), "golden", fixture), "rb").read()
+    got = pna.extract_archive(gpu_ctx, arc, b"password")
+    _, items = pf.read_archive(arc)
+    assert [n for n, _, _ in got] == [it.name for it in items] and len(got) == 9
+    for (n, _, d), it in zip(got, items):
+        phsf = [x for ty, x in it.chunks if ty == b"PHSF"][0]
+        km = codec.derive_key_from_phsf(phsf.decode(), b"password")
+        comp = (codec.decrypt_payload_gcm(km, it.data, it.chunks[0][0], it.chunks[0][1], phsf) if it.cipher_mode == 2
+                else codec.decrypt_payload(it.encryption, it.cipher_mode, km, it.data))
+        assert d == codec.decode_payload(it.compression, comp, 8 << 20), n
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, arc, b"passw0rd")
+    assert ei.value.code == -2
+    if fixture.endswith("gcm.pna"):
+        assert "key confirmation" in str(ei.value)
+        bad = bytearray(arc); bad[arc.index(b"FDAT", 2000) + 4 + 75 + 40] ^= 1      # inside a ciphertext: CRC first ...
+        with pytest.raises(pna.PnaGpuError) as ei:
+            pna.extract_archive(gpu_ctx, bytes(bad), b"password")
+        assert ei.value.code == -2
+
+
+@pytest.mark.parametrize("mode_name", ["cbc", "gcm"])
+def test_extract_driver_round_trips_cbc_and_gcm(gpu_ctx, pna, pf, codec, mode_name):
+    """create (device cipher stage) -> extract (device decrypt): CBC with its padding, GCM STREAM with tag verification; a GCM archive
+    whose ciphertext is altered but whose chunk CRC is repaired fails on the tag."""
+    import zlib
+    mode = pna.MODE_CBC if mode_name == "cbc" else pna.MODE_GCM
+    ents = [codec.corpus_file(0, 900 + i, n) for i, n in enumerate([1 << 20, 70000, 0, 3, (1 << 20) + 17, 65536, 15, 16, 17])]
+    names = [f"m/{i}.txt" for i in range(len(ents))]
+    arc = pna.create_archive_encrypted(gpu_ctx, names, ents, b"password", mode=mode, rounds=1000)
+    got = pna.extract_archive(gpu_ctx, arc, b"password")
+    assert [n for n, _, _ in got] == names and [d for _, _, d in got] == ents
+    with pytest.raises(pna.PnaGpuError):
+        pna.extract_archive(gpu_ctx, arc, b"passw0rd")
+    # an Argon2id PHSF string on an archive of this library: the C++ host's Argon2 derives the key
+    salt = bytes(range(16))
+    key = codec.argon2(2, b"password", salt, 2, 64, 1)
+    import base64
+    phsf = "$argon2id$v=19$m=64,t=2,p=1$" + base64.b64encode(salt).decode().rstrip("=")
+    a2 = pna.create_archive_encrypted(gpu_ctx, names, ents, b"", cipher=pna.Cipher(key, phsf, mode))
+    assert [d for _, _, d in pna.extract_archive(gpu_ctx, a2, b"password")] == ents
+    if mode == pna.MODE_GCM:
+        _, items = pf.read_archive(arc)
+        body = items[0].chunks[4][1]                          # FDAT(ciphertext || tag) of the first entry
+        at = arc.index(body[:64])
+        bad = bytearray(arc); bad[at + 100] ^= 1
+        crc_at = at + len(body)
+        bad[crc_at:crc_at + 4] = (zlib.crc32(bytes(bad[at:at + len(body)]), zlib.crc32(b"FDAT")) & 0xFFFFFFFF).to_bytes(4, "big")
+        with pytest.raises(pna.PnaGpuError) as ei:
+            pna.extract_archive(gpu_ctx, bytes(bad), b"password")
+        assert ei.value.code == -2 and "authentication" in str(ei.value)

@@ -675,8 +675,16 @@ def test_extract_driver_round_trips_archives(gpu_ctx, pna, pf, codec):
     with pytest.raises(pna.PnaGpuError) as ei:
         pna.extract_archive(gpu_ctx, bytes(bad))
     assert ei.value.code == -2
-    with pytest.raises(pna.PnaGpuError) as ei:                  # no fSIZ: the decoder cannot size its output
-        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "zstd.pna"), "rb").read())
+    # entries without fSIZ (older writers): sized by the decoder, like a solid stream; deflate without fSIZ is refused
+    for name in ("zstd.pna", "zstd_keep_all.pna"):
+        ref = open(os.path.join(GOLDEN, name), "rb").read()
+        items = pf.read_archive(ref)[1]
+        got = pna.extract_archive(gpu_ctx, ref)
+        assert [n for n, _, _ in got] == [it.name for it in items]
+        for (n, _, d), it in zip(got, items):
+            assert d == codec.decode_payload(it.compression, it.data, 8 << 20), n
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, open(os.path.join(GOLDEN, "deflate.pna"), "rb").read())
     assert ei.value.code == -7
 
 
