@@ -203,15 +203,19 @@ int  pna_gpu_zstd_stream_frames_device(pna_gpu_ctx *ctx, const void *d_src, uint
 int  pna_gpu_zstd_decompress_open_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off,
                                          uint64_t dst_cap, uint64_t *raw_len, void *hip_stream);
 
+/* The same for one zlib stream (deflate entries without fSIZ, deflate solid streams). */
+int  pna_gpu_inflate_open_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off,
+                                 uint64_t dst_cap, uint64_t *raw_len, void *hip_stream);
+
 /* Read-side driver for archives in host memory (normal and solid entries): `pna extract` / `pna verify` (cli/src/command/extract.rs:594-640,
  * verify.rs:140-188; Archive::read_header + entries, lib/src/archive/read.rs:22-66; read_chunk's mandatory CRC check, lib/src/io.rs:117-149;
  * decrypt_reader / decompress_reader, lib/src/entry/read.rs:59-104,171-190).  The chunk walk and the small chunks' CRCs are host work;
  * the FDAT CRC-32s, the gather of every entry's data pieces, AES decryption -- CTR, CBC (PKCS#7 checked), GCM STREAM (key confirmation,
  * every segment tag verified) -- with the key derived from the PHSF string ("$argon2{d,i,id}$..." or "$pbkdf2-sha256$...") and `password`,
- * and zstd / deflate / store decoding run on the device; zstd entries without fSIZ are sized by the decoder.  cb is called once per entry in archive order (kind =
+ * and zstd / deflate / store decoding run on the device; entries without fSIZ are sized by the decoder.  cb is called once per entry in archive order (kind =
  * DataKind::to_byte(): 0 file, 1 directory, ...); `data` is valid during the call.  PNA_E_INVAL: structural damage, CRC mismatch, corrupt
  * stream, wrong password (GCM key confirmation, CBC padding), authentication failure; PNA_E_UNSUPPORTED: multipart archives, xz,
- * Camellia, deflate entries without fSIZ, solid streams other than zstd / store (CTR or plain) or with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND):
+ * Camellia, CBC / GCM solid streams, solid streams with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND):
  * SDAT CRCs and the inner FDAT CRCs on the device, the stream is decoded without a recorded size (frames counted first). */
 typedef int (*pna_entry_fn)(void *user, size_t index, const char *name, int kind, const void *data, size_t len);
 int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t archive_len, const void *password, size_t password_len,

@@ -99,7 +99,7 @@ EXPORTS = [
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
     "pna_gpu_create_solid_archive_enc_device", "pna_gpu_extract_archive_host", "pna_gpu_zstd_stream_frames_device",
-    "pna_gpu_zstd_decompress_open_device",
+    "pna_gpu_zstd_decompress_open_device", "pna_gpu_inflate_open_device",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",

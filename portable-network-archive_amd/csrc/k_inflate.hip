@@ -118,6 +118,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     const uint64_t src_off = (uint64_t)IF_U((uint32_t)frames[f].src_off) | ((uint64_t)IF_U((uint32_t)(frames[f].src_off >> 32)) << 32);
     const uint64_t dst_off = (uint64_t)IF_U((uint32_t)frames[f].dst_off) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_off >> 32)) << 32);
     const uint32_t src_len = IF_U(frames[f].src_len), dst_len = IF_U(frames[f].dst_len);
+    const bool open = (IF_U(frames[f].out_len) & ZF_OPEN) != 0;        // dst_len is a capacity: the stream's size is reported back
     const uint64_t seq_base = (uint64_t)IF_U((uint32_t)fx[f].seq_base) | ((uint64_t)IF_U((uint32_t)(fx[f].seq_base >> 32)) << 32);
     const uint32_t seq_cap = IF_U(fx[f].seq_cap), blk_base = IF_U(fx[f].blk_base), blk_cap = IF_U(fx[f].blk_cap);
     const uint64_t a0 = src_off & ~(uint64_t)3;
@@ -332,7 +333,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     }
     // ---- one block record for k_zoff / k_zexec
     const uint64_t total = (uint64_t)nlit_tot + mtot;
-    if (status == IF_OK && total != dst_len) status = IF_DSTSIZE;
+    if (status == IF_OK && (open ? total > dst_len : total != dst_len)) status = IF_DSTSIZE;
     if (l0) {
         ZBlock b;
         b.body = 0; b.out_off = dst_off; b.seq_pos = seq_base; b.size = 0; b.type = 2;
@@ -345,6 +346,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
         fx[f].nblk = status == IF_OK ? 1u : 0u;
         frames[f].status = status;
         frames[f].out_len = (uint32_t)total;
+        if (open && status == IF_OK) frames[f].dst_len = (uint32_t)total;
     }
 }
 
@@ -360,7 +362,7 @@ void k_iadler_part(const ZFrame *__restrict__ frames, const uint32_t *__restrict
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cbase[mid] <= c) lo = mid; else hi = mid; }
     const ZFrame fr = frames[lo];
     const uint64_t start = (uint64_t)(c - cbase[lo]) * IF_ADLER_PIECE;
-    const uint32_t len = fr.status ? 0u : (uint32_t)(fr.dst_len - start < IF_ADLER_PIECE ? fr.dst_len - start : IF_ADLER_PIECE);
+    const uint32_t len = (fr.status || start >= fr.dst_len) ? 0u : (uint32_t)(fr.dst_len - start < IF_ADLER_PIECE ? fr.dst_len - start : IF_ADLER_PIECE);
     const uint8_t *p = dst + fr.dst_off + start;
     unsigned long long s1 = 0, s2 = 0;
     for (uint32_t i = tid * 8; i < len; i += 256 * 8) {

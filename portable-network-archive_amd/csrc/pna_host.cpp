@@ -1317,8 +1317,8 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         } else { e.pay_len = e.stream_len; stream_place(0, e.stream_len, e.pk_off); }
         pk_total = (pk_total + e.pay_len + 15) & ~(uint64_t)15;
         if (e.compression != PNA_ALGO_STORE) {
-            // fSIZ is optional (older writers omit it): a zstd payload is then decoded like a solid stream, its size found by the decoder
-            if (!e.has_size) { if (e.compression != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "deflate entry without fSIZ"); nosize_idx.push_back(i); }
+            // fSIZ is optional (older writers omit it): the payload is then decoded like a solid stream, its size found by the decoder
+            if (!e.has_size) nosize_idx.push_back(i);
             else { e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15; }
         }
     }
@@ -1331,7 +1331,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             if (so.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
             prefix = 16;
         }
-        if (so.compression != PNA_ALGO_STORE && so.compression != PNA_ALGO_ZSTD) return fail(c, PNA_E_UNSUPPORTED, "solid stream: only zstd and store are decoded (no size is recorded for it)");
+        if (so.compression != PNA_ALGO_STORE && so.compression != PNA_ALGO_ZSTD && so.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "solid stream: compression method not decoded on the device (xz)");
         so.pk_off = pk_total; so.pay_len = so.stream_len - prefix;
         uint64_t skip = prefix, at = so.pk_off;
         for (const XPiece &p : so.pieces) {
@@ -1480,11 +1480,13 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     }
     for (size_t i : nosize_idx) {                                 // compatibility path, one decode call per entry
         XEntry &e = ents[i];
-        uint32_t nfr = 0; uint64_t got = 0;
-        rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, e.pk_off, e.pay_len, &nfr, st); if (rc) return rc;
+        uint32_t nfr = 1; uint64_t got = 0;
+        if (e.compression == PNA_ALGO_ZSTD) { rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, e.pk_off, e.pay_len, &nfr, st); if (rc) return rc; }
         const uint64_t cap = nfr > 1 ? (uint64_t)nfr * SEG_SIZE : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, 64 * e.pay_len));
         if (c->solid_plain.ensure(cap + 8192)) return fail(c, PNA_E_NOMEM, "entry buffer");
-        rc = pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, e.pk_off, e.pay_len, c->solid_plain.p, 0, cap, &got, st); if (rc) return rc;
+        rc = e.compression == PNA_ALGO_ZSTD ? pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, e.pk_off, e.pay_len, c->solid_plain.p, 0, cap, &got, st)
+                                            : pna_gpu_inflate_open_device(c, c->x_pk.p, e.pk_off, e.pay_len, c->solid_plain.p, 0, cap, &got, st);
+        if (rc) return rc;
         nosize_data.emplace_back((size_t)got);
         if (got) HIPCHK(c, hipMemcpy(nosize_data.back().data(), c->solid_plain.p, got, hipMemcpyDeviceToHost));
         e.raw_size = got; e.raw_off = nosize_data.size() - 1;      // index into nosize_data
@@ -1505,13 +1507,15 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             if (rc) return rc;
         }
         uint64_t plen = so.pay_len; const void *d_plain = (const uint8_t *)c->x_pk.p + so.pk_off;
-        if (so.compression == PNA_ALGO_ZSTD) {
-            uint32_t nfr = 0;
-            rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, so.pk_off, so.pay_len, &nfr, st); if (rc) return rc;
-            // this library's solid streams: frames of 1 MiB; one frame (the reference's writer): a bounded guess of its size
+        if (so.compression != PNA_ALGO_STORE) {
+            uint32_t nfr = 1;
+            if (so.compression == PNA_ALGO_ZSTD) { rc = pna_gpu_zstd_stream_frames_device(c, c->x_pk.p, so.pk_off, so.pay_len, &nfr, st); if (rc) return rc; }
+            // this library's zstd solid streams: frames of 1 MiB; one frame / one zlib stream: a bounded guess of its size
             const uint64_t cap = nfr > 1 ? (uint64_t)nfr * SEG_SIZE : std::min<uint64_t>(1ull << 30, std::max<uint64_t>(64ull << 20, 64 * so.pay_len));
             if (c->solid_plain.ensure(cap + 8192)) return fail(c, PNA_E_NOMEM, "solid stream buffer");
-            rc = pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, so.pk_off, so.pay_len, c->solid_plain.p, 0, cap, &plen, st); if (rc) return rc;
+            rc = so.compression == PNA_ALGO_ZSTD ? pna_gpu_zstd_decompress_open_device(c, c->x_pk.p, so.pk_off, so.pay_len, c->solid_plain.p, 0, cap, &plen, st)
+                                                 : pna_gpu_inflate_open_device(c, c->x_pk.p, so.pk_off, so.pay_len, c->solid_plain.p, 0, cap, &plen, st);
+            if (rc) return rc;
             d_plain = c->solid_plain.p;
         }
         plain[si].resize(plen);
@@ -1542,9 +1546,9 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             if (c->solid_desc.ensure(ichunks.size() * sizeof(FrameDesc) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
             HIPCHK(c, hipMemcpyAsync(c->x_flag.p, flag0, 8, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, ichunks.data(), ichunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-            const DevBuf &pb = so.compression == PNA_ALGO_ZSTD ? c->solid_plain : c->x_pk;
+            const DevBuf &pb = so.compression != PNA_ALGO_STORE ? c->solid_plain : c->x_pk;
             std::vector<FrameDesc> adj;
-            if (so.compression != PNA_ALGO_ZSTD) {                // descriptors are relative to the stream's start inside the packed buffer
+            if (so.compression == PNA_ALGO_STORE) {                // descriptors are relative to the stream's start inside the packed buffer
                 adj = ichunks; for (auto &f : adj) f.arc_off += so.pk_off;
                 HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, adj.data(), adj.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
             }
@@ -1628,7 +1632,7 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
 // k_inflate turns each stream into literals + (run, length, distance) records, k_zoff / k_zexec execute them, k_iadler_* check
 // the Adler-32 trailer.
 static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
-                                const uint64_t *dst_off, const uint64_t *raw_len, hipStream_t st) {
+                                const uint64_t *dst_off, const uint64_t *raw_len, hipStream_t st, bool open = false, uint64_t *raw_out = nullptr) {
     if (n > 0x3FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
     std::vector<ZFrame> frs(n);
     std::vector<ZFrameX> fxs(n);
@@ -1636,7 +1640,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     uint64_t nseq_cap = 0, out_span = 0, pieces = 0;
     for (size_t i = 0; i < n; i++) {
         if (raw_len[i] > 0xFFFFFFFFull || src_len[i] > 0xFFFFFFFFull) return fail(c, PNA_E_UNSUPPORTED, "entries of 4 GiB and more are not decoded on the device");
-        frs[i] = ZFrame{src_off[i], dst_off[i], (uint32_t)src_len[i], (uint32_t)raw_len[i], 0, 0};
+        frs[i] = ZFrame{src_off[i], dst_off[i], (uint32_t)src_len[i], (uint32_t)raw_len[i], 0, open ? ZF_OPEN : 0u};   // open: raw_len is a capacity
         ZFrameX &x = fxs[i];
         x.blk_base = (uint32_t)i; x.blk_cap = 1; x.slot_base = 0; x.slot_cap = 0; x.nblk = 0;
         x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(raw_len[i] / 3 + (raw_len[i] >> 16) + 16, 0x7FFFFFFFu);   // matches are >= 3 bytes; + literal-run splits
@@ -1676,7 +1680,19 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
                      frs[i].status == 2 ? "unsupported stream" : (frs[i].status == 3 ? "size mismatch" : "corrupt stream"), frs[i].out_len, frs[i].dst_len);
             return fail(c, frs[i].status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
         }
+    if (open && raw_out) for (size_t i = 0; i < n; i++) raw_out[i] = frs[i].dst_len;
     return PNA_OK;
+}
+
+// A zlib stream whose decoded size is recorded nowhere (deflate entries without fSIZ, deflate solid streams): decoded into dst_cap
+// bytes of room, the size found is reported (PNA_E_INVAL when it does not fit).
+extern "C" int pna_gpu_inflate_open_device(pna_gpu_ctx *c, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off,
+                                           uint64_t dst_cap, uint64_t *raw_len, void *hip_stream) {
+    if (!c || !d_src || !d_dst || !raw_len) return fail(c, PNA_E_INVAL, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (dst_cap > 0xFFFFFFFFull) dst_cap = 0xFFFFFFFFull;
+    return inflate_batch_device(c, 1, d_src, &src_off, &src_len, d_dst, &dst_off, &dst_cap, st, true, raw_len);
 }
 
 // ---------------------------------------------------------------------------------------------------------

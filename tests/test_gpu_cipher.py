@@ -385,3 +385,17 @@ def test_extract_driver_round_trips_cbc_and_gcm(gpu_ctx, pna, pf, codec, mode_na
         with pytest.raises(pna.PnaGpuError) as ei:
             pna.extract_archive(gpu_ctx, bytes(bad), b"password")
         assert ei.value.code == -2 and "authentication" in str(ei.value)
+
+
+def test_extract_driver_opens_the_reference_encrypted_solid_archive(gpu_ctx, pna, pf, codec):
+    """solid_zstd_aes_ctr.pna: SHED | PHSF (Argon2id) | SDAT* (IV first) | SEND, one zstd frame, inner entries stored."""
+    arc = open(os.path.join(os.path.dirname(__file__), "golden", "solid_zstd_aes_ctr.pna"), "rb").read()
+    (so,) = pf.read_archive(arc)[1]
+    phsf = [d for ty, d in so.chunks if ty == b"PHSF"][0].decode()
+    km = codec.derive_key_from_phsf(phsf, b"password")
+    inner = pf.read_solid_inner(codec.decode_payload(so.compression, codec.decrypt_payload(so.encryption, so.cipher_mode, km, so.data), 16 << 20))
+    got = pna.extract_archive(gpu_ctx, arc, b"password")
+    assert [(n, d) for n, _, d in got] == [(e.name, e.data) for e in inner] and len(got) == 9
+    with pytest.raises(pna.PnaGpuError) as ei:                  # CBC over a solid stream stays with the reference's reader
+        pna.extract_archive(gpu_ctx, open(os.path.join(os.path.dirname(__file__), "golden", "solid_zstd_aes_cbc.pna"), "rb").read(), b"password")
+    assert ei.value.code == -7
