@@ -176,7 +176,7 @@ def main() -> None:
             # rank 0 writes the archive header, the last rank AEND: the shards gathered in rank order are ONE archive
             part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
             total, _ = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo,
-                                                 _cache=arg_cache, part=part, cipher=cipher)
+                                                 _cache=arg_cache, part=part, cipher=cipher, want_offsets=False)
         elif args.framing == "solid":
             total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache)
         else:

@@ -300,7 +300,8 @@ class Context:
 
     def create_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                               dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
-                              _cache: Optional[dict] = None, part: int = PART_HEAD | PART_TAIL, cipher: Optional[Cipher] = None):
+                              _cache: Optional[dict] = None, part: int = PART_HEAD | PART_TAIL, cipher: Optional[Cipher] = None,
+                              want_offsets: bool = True):
         """Whole non-solid archive assembled in HBM (pna_gpu_create_archive_enc_device; `part` selects whether this shard
         carries the archive header / AEND; `cipher` adds the AES stage between compression and chunk CRC).
         Returns (archive_len, entry_off)."""
@@ -313,14 +314,22 @@ class Context:
             a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
             if _cache is not None:
                 _cache["a"] = (a_names, a_off, a_len)
-        a_out = (ctypes.c_uint64 * (n + 1))()
+        if _cache is not None and "out" in _cache:
+            a_out = _cache["out"]
+        else:
+            a_out = (ctypes.c_uint64 * (n + 1))()
+            if _cache is not None:
+                _cache["out"] = a_out
         total = ctypes.c_uint64()
-        cs = cipher.struct(n) if cipher is not None else None
+        if cipher is not None and _cache is not None:
+            cs = _cache.get("cs") or _cache.setdefault("cs", cipher.struct(n))
+        else:
+            cs = cipher.struct(n) if cipher is not None else None
         self._check(self._L.pna_gpu_create_archive_enc_device(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len,
                                                               ctypes.byref(cs) if cs is not None else None,
                                                               ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total), part,
                                                               ctypes.c_void_p(stream) if stream else None))
-        return total.value, list(a_out)
+        return total.value, (list(a_out) if want_offsets else None)      # the list conversion costs milliseconds for 10^5 entries
 
     def cipher_apply_device(self, cipher: Cipher, d_buf: int, off: Sequence[int], length: Sequence[int], decrypt: bool = False,
                             stream: int = 0) -> None:

@@ -43,20 +43,25 @@ __device__ __forceinline__ void dw_add(DBitW &w, uint32_t v, uint32_t n) {
 // whole workgroup: stable rank sort by count and the leaf depths are parallel, the two-queue merge (n - 1 dependent steps)
 // and the rare Kraft repair stay on thread 0.  Every thread of the workgroup must call it; returns the number of used symbols.
 __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent,
-                            uint32_t *sh /* [2] scratch */, uint32_t tid, uint32_t nthr) {
+                            uint32_t *sh /* [2] scratch */, uint16_t *used /* [nsym]: the symbols that occur, in no particular order */,
+                            uint32_t tid, uint32_t nthr) {
     if (tid == 0) { sh[0] = 0; sh[1] = 0; }
     __syncthreads();
+    // the symbols that occur (a 4 KiB entry uses ~70 of the 286): the rank sort below and the code assignment only walk these
     for (int s = (int)tid; s < nsym; s += (int)nthr) {
         lens[s] = 0;
-        const uint32_t c = count[s];
-        if (!c) continue;
-        uint32_t rank = 0;
-        for (int o = 0; o < nsym; o++) { const uint32_t co = count[o]; rank += (co != 0 && (co < c || (co == c && o < s))) ? 1u : 0u; }
-        order[rank] = (uint16_t)s;
-        atomicAdd(&sh[0], 1u);
+        if (count[s]) used[atomicAdd(&sh[0], 1u)] = (uint16_t)s;
     }
     __syncthreads();
     const int n = (int)sh[0];
+    for (int k = (int)tid; k < n; k += (int)nthr) {
+        const int s = used[k];
+        const uint32_t c = count[s];
+        uint32_t rank = 0;
+        for (int j = 0; j < n; j++) { const int o = used[j]; const uint32_t co = count[o]; rank += (co < c || (co == c && o < s)) ? 1u : 0u; }
+        order[rank] = (uint16_t)s;
+    }
+    __syncthreads();
     if (n == 0) return 0;
     if (n == 1) { if (tid == 0) lens[order[0]] = 1; __syncthreads(); return 1; }
     for (int i = (int)tid; i < n; i += (int)nthr) wt[i] = count[order[i]];
@@ -100,25 +105,26 @@ __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t
 }
 // canonical codes, bit-reversed; out[s] = code | len << 16.  Workgroup-wide: code of s = first code of its length + number of
 // lower-numbered symbols of the same length.
-__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, uint32_t tid, uint32_t nthr) {
+__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, const uint16_t *used, int n_used,
+                         uint32_t tid, uint32_t nthr) {
     if (tid == 0) {
         int bl_count[16];
         for (int b = 0; b < 16; b++) bl_count[b] = 0;
-        for (int s = 0; s < nsym; s++) bl_count[lens[s]]++;
+        for (int k = 0; k < n_used; k++) bl_count[lens[used[k]]]++;        // unused symbols have length 0
         bl_count[0] = 0;
         int code = 0; first[0] = 0;
         for (int b = 1; b <= 15; b++) { code = (code + bl_count[b - 1]) << 1; first[b] = (uint32_t)code; }
     }
+    for (int s = (int)tid; s < nsym; s += (int)nthr) out[s] = 0;
     __syncthreads();
-    for (int s = (int)tid; s < nsym; s += (int)nthr) {
+    for (int k = (int)tid; k < n_used; k += (int)nthr) {
+        const int s = used[k];
         const uint32_t l = lens[s];
-        uint32_t v = 0;
         if (l) {
             uint32_t c = first[l];
-            for (int o = 0; o < s; o++) c += lens[o] == l ? 1u : 0u;
-            v = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
+            for (int j = 0; j < n_used; j++) { const int o = used[j]; c += (o < s && lens[o] == l) ? 1u : 0u; }
+            out[s] = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
         }
-        out[s] = v;
     }
     __syncthreads();
 }
@@ -134,6 +140,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     __shared__ uint8_t ll_len[288], d_len[32], cl_len[19], seq[320], sym[320], ext[320];
     __shared__ uint32_t cl_code[19];
     __shared__ uint32_t ll_code_s[288], d_code_s[32], first_s[16], sh2[2], hsh[3];
+    __shared__ uint16_t used_ll[288], used_d[32], used_cl[20];
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     DeflTables *T = tabs + blockIdx.x;
@@ -172,10 +179,10 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         dc[tid] = tid < 30 ? h_dist[0][tid] + h_dist[1][tid] + h_dist[2][tid] + h_dist[3][tid] : 0u;
     }
     __syncthreads();
-    d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, tid, DS_THREADS);
-    d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, tid, DS_THREADS);
-    d_assign(ll_len, 286, ll_code_s, first_s, tid, DS_THREADS);
-    d_assign(d_len, 30, d_code_s, first_s, tid, DS_THREADS);
+    const int n_ll = d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, used_ll, tid, DS_THREADS);
+    const int n_d = d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, used_d, tid, DS_THREADS);
+    d_assign(ll_len, 286, ll_code_s, first_s, used_ll, n_ll, tid, DS_THREADS);
+    d_assign(d_len, 30, d_code_s, first_s, used_d, n_d, tid, DS_THREADS);
     for (uint32_t i = tid; i < 288; i += DS_THREADS) T->ll_code[i] = i < 286 ? ll_code_s[i] : 0u;
     if (tid < 32) T->d_code[tid] = tid < 30 ? d_code_s[tid] : 0u;
     // table description: run-length tokens of the code lengths (serial scan), their 19-symbol code, the header bits
@@ -198,11 +205,13 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         hsh[0] = (uint32_t)nll; hsh[1] = (uint32_t)nd; hsh[2] = (uint32_t)ns;
     }
     __syncthreads();
-    if (d_build_lens(clc, 19, 7, cl_len, order, wt, parent, sh2, tid, DS_THREADS) == 1) {
-        if (tid == 0) for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; break; }
+    int n_cl = d_build_lens(clc, 19, 7, cl_len, order, wt, parent, sh2, used_cl, tid, DS_THREADS);
+    if (n_cl == 1) {
+        if (tid == 0) for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; used_cl[1] = (uint16_t)k; break; }
+        n_cl = 2;
         __syncthreads();
     }
-    d_assign(cl_len, 19, cl_code, first_s, tid, DS_THREADS);
+    d_assign(cl_len, 19, cl_code, first_s, used_cl, n_cl, tid, DS_THREADS);
     if (tid != 0) return;
     const int nll = (int)hsh[0], nd = (int)hsh[1], ns = (int)hsh[2];
     int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;

@@ -97,6 +97,42 @@ void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number) {
 }
 void frame_archive_tail(std::vector<uint8_t> &o) { put_chunk(o, "AEND", nullptr, 0); }
 // FHED | fSIZ | FDAT length + type: everything of a file entry that precedes its payload (NormalEntry::write_chunks_to, lib/src/entry.rs:895-911)
+// true when EntryName::sanitize would return the name unchanged: relative, '/'-separated, no empty / "." / ".." component, no '\\'
+static bool name_is_clean(const char *name, size_t n) {
+    if (n == 0 || name[0] == '/' || name[n - 1] == '/') return false;
+    size_t comp = 0;
+    for (size_t i = 0; i <= n; i++) {
+        const char ch = i < n ? name[i] : '/';
+        if (ch == '\\') return false;
+        if (ch == '/') {
+            if (comp == 0) return false;
+            if (comp == 1 && name[i - 1] == '.') return false;
+            if (comp == 2 && name[i - 1] == '.' && name[i - 2] == '.') return false;
+            comp = 0;
+        } else comp++;
+    }
+    return true;
+}
+// the same record pieces written straight into `out` (>= frame_entry_prefix_bound(name) bytes); returns the length.  The many-entry path
+// (hundreds of thousands of 4 KiB files) builds one of these per entry on the host while the kernels run: no allocation, no string copy
+// for names that are already in sanitised form.
+size_t frame_entry_prefix_into(uint8_t *out, const char *name, int compression, uint64_t raw_size) {
+    std::string tmp;
+    const char *nm = name ? name : ""; size_t nl = strlen(nm);
+    if (!name_is_clean(nm, nl)) { tmp = sanitize(nm); nm = tmp.c_str(); nl = tmp.size(); }
+    uint8_t *p = out;
+    put_be32(p, (uint32_t)(6 + nl)); memcpy(p + 4, "FHED", 4);
+    p[8] = 0; p[9] = 0; p[10] = 0; p[11] = (uint8_t)compression; p[12] = 0; p[13] = 1;      // cipher_mode CTR (1) when unencrypted
+    memcpy(p + 14, nm, nl);
+    put_be32(p + 14 + nl, pna_crc32(0, p + 4, 4 + 6 + nl));
+    p += 12 + 6 + nl;
+    uint8_t b[16]; const size_t n = fsiz(raw_size, b);
+    put_be32(p, (uint32_t)n); memcpy(p + 4, "fSIZ", 4); memcpy(p + 8, b, n);
+    put_be32(p + 8 + n, pna_crc32(0, p + 4, 4 + n));
+    p += 12 + n;
+    put_be32(p, 0); memcpy(p + 4, "FDAT", 4);
+    return (size_t)(p + 8 - out);
+}
 void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len) {
     std::vector<uint8_t> h = fhed(0, compression, 0, 1, sanitize(name));
     put_chunk(o, "FHED", h.data(), h.size());

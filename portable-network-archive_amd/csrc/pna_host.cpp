@@ -59,6 +59,7 @@ void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number);
 void frame_archive_tail(std::vector<uint8_t> &o);
 void frame_entry_prefix(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, uint32_t payload_len);
 size_t frame_entry_prefix_bound(const char *name);
+size_t frame_entry_prefix_into(uint8_t *out, const char *name, int compression, uint64_t raw_size);
 uint32_t frame_fend_crc();
 void frame_entry_prefix_enc(std::vector<uint8_t> &o, const char *name, int compression, uint64_t raw_size, int encryption, int cipher_mode,
                             const char *phsf, const uint8_t *prefix, size_t prefix_len);
@@ -543,11 +544,25 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 });
             for (auto &x : th) x.join();
         }
+        if (!fj->cipher) {
+            // plain entries: the prefixes are written straight into the staging blob; with many entries several threads share them
+            // (each thread fills the slots of its range at the bound offsets, a compaction pass closes the gaps)
+            const size_t ne = e1 - e0;
+            const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, ne / 8192));
+            std::vector<uint32_t> plen(ne); std::vector<size_t> slot(ne + 1); slot[0] = 0;
+            for (size_t i = 0; i < ne; i++) slot[i + 1] = slot[i] + frame_entry_prefix_bound(fj->names[e0 + i]);
+            auto work = [&](unsigned t) { for (size_t i = t; i < ne; i += nt) plen[i] = (uint32_t)frame_entry_prefix_into(blob + slot[i], fj->names[e0 + i], algo, src_len[e0 + i]); };
+            if (nt > 1) { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); } else work(0);
+            for (size_t i = 0; i < ne; i++) {
+                if (blob_len != slot[i]) memmove(blob + blob_len, blob + slot[i], plen[i]);
+                fds[i] = FrameDesc{0, 0, (uint32_t)blob_len, plen[i], 0};
+                blob_len += plen[i];
+            }
+        } else
         for (size_t e = e0; e < e1; e++) {
             tmp.clear();
             if (gcm) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, PNA_MODE_GCM, fj->cipher->phsf, gmat[e - e0].header, 75);
-            else if (fj->cipher) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e, 16);
-            else frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
+            else frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e, 16);
             memcpy(blob + blob_len, tmp.data(), tmp.size());
             fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
             blob_len += tmp.size();
