@@ -98,7 +98,8 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     __syncthreads();
     for (uint32_t j = 0; j < 8; j++) {
         const uint32_t st = 1u << j;
-        if ((tid & (2 * st - 1)) == 0) part[tid] = gf2_mulmod(ct->sh[j], part[tid]) ^ part[tid + st];
+        // (a zero state stays zero: the lanes in front of a short message -- most of them for a 4 KiB entry -- skip the multiply)
+        if ((tid & (2 * st - 1)) == 0) { const uint32_t pv = part[tid]; part[tid] = (pv ? gf2_mulmod(ct->sh[j], pv) : 0u) ^ part[tid + st]; }
         __syncthreads();
     }
     if (verify) {
