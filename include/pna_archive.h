@@ -66,6 +66,15 @@ int  pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int level, size_t 
                                   const void *const *src, const size_t *src_len, const void *password, size_t password_len,
                                   int cipher_mode, uint32_t rounds, pna_sink_fn sink, void *user);
 
+/* `pna create --split`: re-frame ONE archive image into parts of at most max_part_bytes (SplitParts, lib/src/archive/split_parts.rs:
+ * signature + AHED(archive number) ... [ANXT] AEND per part; chunks that fit keep their bytes, FDAT / SDAT chunks are cut at the budget
+ * boundary and only the fragments get new CRCs).  sink(user, part_index, buf, len) receives the bytes of part `part_index` in order.
+ * PNA_E_INVAL: max_part_bytes below MIN_SPLIT_PART_BYTES (64), a non-stream chunk larger than a part, malformed input. */
+typedef int (*pna_part_sink_fn)(void *user, uint32_t part_index, const void *buf, size_t len);
+int  pna_split_archive(const void *archive, size_t len, size_t max_part_bytes, pna_part_sink_fn sink, void *user, uint32_t *n_parts);
+/* The reading side (Archive::read_next_archive): the parts in order -> one archive image for pna_gpu_extract_archive_host. */
+int  pna_join_parts(const void *const *parts, const size_t *part_len, size_t n, pna_sink_fn sink, void *user);
+
 #ifdef __cplusplus
 }
 #endif

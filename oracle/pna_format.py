@@ -271,3 +271,99 @@ def read_solid_inner(plain: bytes) -> List[ParsedEntry]:
     if cur:
         raise ValueError("dangling chunks in solid stream")
     return entries
+
+
+# ----------------------------------------------------------------------------- multipart (lib/src/archive/split_parts.rs)
+
+MIN_CHUNK_BYTES = 12                                   # lib/src/chunk.rs:24 (length + type + crc)
+PART_HEADER_BYTES = 8 + MIN_CHUNK_BYTES + 8            # split_parts.rs:17: signature + AHED
+SPLIT_ARCHIVE_OVERHEAD_BYTES = PART_HEADER_BYTES + 2 * MIN_CHUNK_BYTES   # :20: + ANXT + AEND
+MIN_SPLIT_PART_BYTES = SPLIT_ARCHIVE_OVERHEAD_BYTES + MIN_CHUNK_BYTES    # :23
+
+
+def split_parts(chunks: Iterable[Tuple[bytes, bytes]], max_part_bytes: int) -> List[bytes]:
+    """SplitParts as a pure function: the (type, data) chunks of an archive body (everything between AHED and AEND) -> the bytes of
+    every part.  put_chunk / put_stream / roll_over / write_part_framing / finalize_archive -- split_parts.rs:76-80,109-173,176-179,
+    215-218: a chunk that fits goes out intact; a non-stream chunk that does not fit opens the next part; a stream chunk (FDAT / SDAT,
+    chunk/types.rs:318-320) is cut at the budget boundary, its fragments framed and CRC'd anew."""
+    if max_part_bytes < MIN_SPLIT_PART_BYTES:
+        raise ValueError(f"max_part_bytes must be at least {MIN_SPLIT_PART_BYTES} bytes")
+    budget = max_part_bytes - SPLIT_ARCHIVE_OVERHEAD_BYTES
+    parts = [bytearray(write_archive_header(0))]
+    remaining = budget
+
+    def roll_over():
+        nonlocal remaining
+        parts[-1] += write_chunk(b"ANXT") + write_chunk(b"AEND")
+        parts.append(bytearray(write_archive_header(len(parts))))      # `parts` doubles as the next part's archive number
+        remaining = budget
+
+    def put(ty, data):
+        nonlocal remaining
+        c = write_chunk(ty, data)
+        parts[-1] += c
+        remaining -= len(c)
+
+    for ty, data in chunks:
+        clen = MIN_CHUNK_BYTES + len(data)
+        if clen <= remaining:
+            put(ty, data); continue
+        if ty not in (b"FDAT", b"SDAT"):
+            if clen > budget:
+                raise ValueError("chunk does not fit within the maximum part size")
+            roll_over(); put(ty, data); continue
+        if clen <= budget and remaining <= MIN_CHUNK_BYTES:
+            roll_over(); put(ty, data); continue
+        rest = data
+        while True:                                                    # put_stream
+            if MIN_CHUNK_BYTES + len(rest) <= remaining:
+                put(ty, rest); break
+            if remaining > MIN_CHUNK_BYTES:
+                take = remaining - MIN_CHUNK_BYTES
+                put(ty, rest[:take]); rest = rest[take:]
+            elif budget <= MIN_CHUNK_BYTES:
+                raise ValueError("chunk does not fit within the maximum part size")
+            roll_over()
+    parts[-1] += write_chunk(b"AEND")
+    return [bytes(p) for p in parts]
+
+
+def archive_body_chunks(buf: bytes) -> List[Tuple[bytes, bytes]]:
+    """(type, data) of every chunk between AHED and AEND of one archive image (CRCs checked)."""
+    if buf[:8] != PNA_SIGNATURE:
+        raise ValueError("bad signature")
+    out = []
+    for i, (ty, d, _) in enumerate(read_chunks(buf, 8)):
+        if i == 0:
+            if ty != b"AHED":
+                raise ValueError("first chunk must be AHED")
+            continue
+        if ty == b"AEND":
+            return out
+        out.append((ty, d))
+    raise ValueError("archive not terminated by AEND")
+
+
+def join_parts(parts: Iterable[bytes]) -> List[Tuple[bytes, bytes]]:
+    """The reading side of a multipart archive (Archive::read_next_archive, lib/src/archive/read.rs): part k carries archive number k,
+    every part but the last ends ANXT | AEND; the chunk streams concatenated are the archive body."""
+    out = []
+    parts = list(parts)
+    for k, p in enumerate(parts):
+        if p[:8] != PNA_SIGNATURE:
+            raise ValueError("bad signature")
+        it = read_chunks(p, 8)
+        ty, d, _ = next(it)
+        if ty != b"AHED" or struct.unpack(">I", d[4:8])[0] != k:
+            raise ValueError("part out of order")
+        body = [(t, x) for t, x, _ in it]
+        if not body or body[-1][0] != b"AEND":
+            raise ValueError("part not terminated by AEND")
+        body.pop()
+        has_next = bool(body) and body[-1][0] == b"ANXT"
+        if has_next:
+            body.pop()
+        if has_next != (k + 1 < len(parts)):
+            raise ValueError("ANXT does not match the number of parts")
+        out += body
+    return out

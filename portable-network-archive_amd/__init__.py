@@ -85,6 +85,7 @@ class Cipher:
 
 
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+PART_SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t)
 ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)
 
 _lib = None
@@ -103,7 +104,7 @@ EXPORTS = [
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
-    "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted", "pna_kdf_argon2",
+    "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted", "pna_kdf_argon2", "pna_split_archive", "pna_join_parts",
 ]
 
 
@@ -214,6 +215,10 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_extract_archive_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ENTRY_FN, vp]
     L.pna_kdf_pbkdf2_sha256.restype = ctypes.c_int
     L.pna_kdf_pbkdf2_sha256.argtypes = [ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, ctypes.c_char_p, sz, ctypes.c_char_p, sz]
+    L.pna_split_archive.restype = ctypes.c_int
+    L.pna_split_archive.argtypes = [ctypes.c_char_p, sz, sz, PART_SINK_FN, vp, ctypes.POINTER(u32)]
+    L.pna_join_parts.restype = ctypes.c_int
+    L.pna_join_parts.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(sz), sz, SINK_FN, vp]
     L.pna_kdf_argon2.restype = ctypes.c_int
     L.pna_kdf_argon2.argtypes = [ctypes.c_int, ctypes.c_char_p, sz, ctypes.c_char_p, sz, u32, u32, u32, ctypes.c_char_p, sz]
     L.pna_create_archive_encrypted.restype = ctypes.c_int
@@ -617,3 +622,39 @@ def kdf_argon2(kind: int, password: bytes, salt: bytes, t_cost: int, m_cost_kib:
     if rc:
         raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
     return key.raw
+
+
+def split_archive(archive: bytes, max_part_bytes: int) -> List[bytes]:
+    """`pna create --split` (pna_split_archive): one archive image -> the bytes of every part."""
+    parts: List[bytearray] = []
+
+    def _sink(_u, idx, buf, n):
+        while len(parts) <= idx:
+            parts.append(bytearray())
+        parts[idx] += ctypes.string_at(buf, n)
+        return 0
+    cb = PART_SINK_FN(_sink)
+    cnt = ctypes.c_uint32()
+    rc = load_library().pna_split_archive(bytes(archive), len(archive), max_part_bytes, cb, None, ctypes.byref(cnt))
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    assert cnt.value == len(parts)
+    return [bytes(p) for p in parts]
+
+
+def join_parts(parts: Sequence[bytes]) -> bytes:
+    """Parts of a multipart archive, in order -> one archive image (pna_join_parts)."""
+    out = bytearray()
+
+    def _sink(_u, buf, n):
+        out.extend(ctypes.string_at(buf, n))
+        return 0
+    cb = SINK_FN(_sink)
+    n = len(parts)
+    keep = [bytes(p) for p in parts]
+    a = (ctypes.c_char_p * max(n, 1))(*keep)
+    l = (ctypes.c_size_t * max(n, 1))(*[len(p) for p in keep])
+    rc = load_library().pna_join_parts(a, l, n, cb, None)
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return bytes(out)

@@ -552,3 +552,114 @@ extern "C" int pna_create_archive_encrypted(pna_gpu_ctx *ctx, int algo, int leve
     ci.phsf = phsf;
     return pna_gpu_create_archive_enc_host(ctx, algo, level, n, names, src, src_len, &ci, sink, user);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Multipart archives (`pna create --split`): SplitParts, lib/src/archive/split_parts.rs.  The device paths produce ONE archive image;
+// this re-frames its chunk stream into parts of at most max_part_bytes: every part opens with the signature + AHED(archive number),
+// closes with [ANXT] AEND; a chunk that fits goes out untouched (its CRC is reused), a non-stream chunk that does not fit opens the next
+// part, an FDAT / SDAT chunk is cut at the budget boundary and only its fragments get new CRCs (put_chunk / put_stream, :140-173).
+namespace {
+struct PartOut {
+    pna_part_sink_fn sink; void *user; uint32_t part = 0; int err = 0;
+    void emit(const void *p, size_t n) { if (!err && n && sink(user, part, p, n) != 0) err = PNA_E_SINK; }
+    void header() {
+        static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+        uint8_t c[20]; put_be32(c, 8); memcpy(c + 4, "AHED", 4); memset(c + 8, 0, 4); put_be32(c + 12, part);
+        put_be32(c + 16, pna_crc32(0, c + 4, 12));
+        emit(sig, 8); emit(c, 20);
+    }
+    void empty_chunk(const char ty[4]) { uint8_t c[12]; put_be32(c, 0); memcpy(c + 4, ty, 4); put_be32(c + 8, pna_crc32(0, ty, 4)); emit(c, 12); }
+    void fresh_chunk(const uint8_t *ty, const uint8_t *data, size_t n) {
+        uint8_t h[8], t[4]; put_be32(h, (uint32_t)n); memcpy(h + 4, ty, 4);
+        put_be32(t, pna_crc32(pna_crc32(0, ty, 4), data, n));
+        emit(h, 8); emit(data, n); emit(t, 4);
+    }
+};
+}
+
+extern "C" int pna_split_archive(const void *archive, size_t len, size_t max_part_bytes, pna_part_sink_fn sink, void *user, uint32_t *n_parts) {
+    if (!archive || !sink) return PNA_E_INVAL;
+    const size_t MINC = 12, OVER = 8 + 20 + 2 * MINC;          // MIN_CHUNK_BYTES_SIZE, SPLIT_ARCHIVE_OVERHEAD_BYTES (split_parts.rs:14-23)
+    if (max_part_bytes < OVER + MINC) return PNA_E_INVAL;      // MIN_SPLIT_PART_BYTES
+    const uint8_t *a = (const uint8_t *)archive;
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+    if (len < 8 + 20 + 12 || memcmp(a, sig, 8) != 0 || memcmp(a + 12, "AHED", 4) != 0) return PNA_E_INVAL;
+    const size_t budget = max_part_bytes - OVER;
+    size_t remaining = budget;
+    PartOut o{sink, user};
+    o.header();
+    auto roll_over = [&]() -> int {
+        if (o.part == 0xFFFFFFFFu) return PNA_E_INVAL;          // part_number_overflow_error
+        o.empty_chunk("ANXT"); o.empty_chunk("AEND");
+        o.part++; o.header(); remaining = budget;
+        return o.err;
+    };
+    size_t pos = 8 + 20; bool ended = false;
+    while (pos < len && !o.err) {
+        if (len - pos < 12) return PNA_E_INVAL;
+        const uint32_t dl = ((uint32_t)a[pos] << 24) | ((uint32_t)a[pos + 1] << 16) | ((uint32_t)a[pos + 2] << 8) | a[pos + 3];
+        const uint8_t *ty = a + pos + 4, *data = a + pos + 8;
+        if (len - pos - 12 < dl) return PNA_E_INVAL;
+        const size_t clen = MINC + dl;
+        if (memcmp(ty, "AEND", 4) == 0) { ended = true; break; }
+        if (memcmp(ty, "ANXT", 4) == 0) return PNA_E_INVAL;     // already a part of a multipart archive
+        const bool stream = memcmp(ty, "FDAT", 4) == 0 || memcmp(ty, "SDAT", 4) == 0;
+        if (clen <= remaining) { o.emit(a + pos, clen); remaining -= clen; }
+        else if (!stream) {
+            if (clen > budget) return PNA_E_INVAL;              // chunk_does_not_fit_error
+            int rc = roll_over(); if (rc) return rc;
+            o.emit(a + pos, clen); remaining -= clen;
+        } else if (clen <= budget && remaining <= MINC) {
+            int rc = roll_over(); if (rc) return rc;
+            o.emit(a + pos, clen); remaining -= clen;
+        } else {
+            const uint8_t *rest = data; size_t rl = dl; bool first = true;
+            for (;;) {
+                if (MINC + rl <= remaining) {
+                    if (first) o.emit(a + pos, clen); else o.fresh_chunk(ty, rest, rl);   // (cannot be `first` here, kept for symmetry)
+                    remaining -= MINC + rl; break;
+                }
+                if (remaining > MINC) {
+                    const size_t take = remaining - MINC;
+                    o.fresh_chunk(ty, rest, take); rest += take; rl -= take; remaining -= MINC + take; first = false;
+                } else if (budget <= MINC) return PNA_E_INVAL;
+                int rc = roll_over(); if (rc) return rc;
+            }
+        }
+        pos += clen;
+    }
+    if (!ended) return o.err ? o.err : PNA_E_INVAL;
+    o.empty_chunk("AEND");                                      // finalize_archive: the last part has no ANXT
+    if (n_parts) *n_parts = o.part + 1;
+    return o.err;
+}
+
+// The reading side (Archive::read_next_archive): parts in order -> ONE archive image (signature + AHED(0) + the concatenated chunk
+// streams + AEND) that pna_gpu_extract_archive_host and every other reader take; FDAT / SDAT fragments stay separate chunks (their
+// bodies are concatenated by the entry reader anyway).
+extern "C" int pna_join_parts(const void *const *parts, const size_t *part_len, size_t n, pna_sink_fn sink, void *user) {
+    if (!parts || !part_len || !sink || n == 0) return PNA_E_INVAL;
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+    auto out = [&](const void *p, size_t k) { return k == 0 || sink(user, p, k) == 0; };
+    for (size_t k = 0; k < n; k++) {
+        const uint8_t *a = (const uint8_t *)parts[k]; const size_t len = part_len[k];
+        if (!a || len < 8 + 20 + 12 || memcmp(a, sig, 8) != 0 || memcmp(a + 12, "AHED", 4) != 0) return PNA_E_INVAL;
+        const uint32_t num = ((uint32_t)a[20] << 24) | ((uint32_t)a[21] << 16) | ((uint32_t)a[22] << 8) | a[23];      // AHED body: major, minor, 0, 0, archive number
+        if (num != k || pna_crc32(0, a + 12, 12) != (((uint32_t)a[24] << 24) | ((uint32_t)a[25] << 16) | ((uint32_t)a[26] << 8) | a[27])) return PNA_E_INVAL;
+        if (k == 0 && !out(a, 28)) return PNA_E_SINK;
+        size_t pos = 28; bool has_next = false, ended = false;
+        while (pos < len) {
+            if (len - pos < 12) return PNA_E_INVAL;
+            const uint32_t dl = ((uint32_t)a[pos] << 24) | ((uint32_t)a[pos + 1] << 16) | ((uint32_t)a[pos + 2] << 8) | a[pos + 3];
+            if (len - pos - 12 < dl) return PNA_E_INVAL;
+            const uint8_t *ty = a + pos + 4;
+            if (memcmp(ty, "AEND", 4) == 0) { ended = true; break; }
+            if (memcmp(ty, "ANXT", 4) == 0) has_next = true;
+            else { if (has_next) return PNA_E_INVAL; if (!out(a + pos, 12 + (size_t)dl)) return PNA_E_SINK; }
+            pos += 12 + (size_t)dl;
+        }
+        if (!ended || has_next != (k + 1 < n)) return PNA_E_INVAL;
+    }
+    uint8_t c[12]; put_be32(c, 0); memcpy(c + 4, "AEND", 4); put_be32(c + 8, pna_crc32(0, "AEND", 4));
+    return out(c, 12) ? PNA_OK : PNA_E_SINK;
+}

@@ -159,3 +159,40 @@ def test_host_argon2_matches_the_oracle(pna, codec):
         assert pna.kdf_argon2(kind, pw, salt, t, m, p, kl) == codec.argon2(kind, pw, salt, t, m, p, kl), (kind, t, m, p)
     with pytest.raises(pna.PnaGpuError):
         pna.kdf_argon2(2, b"pw", b"salt", 1, 4, 1)             # m < 8 p
+
+
+def test_split_archive_equals_the_oracle_and_joins_back(pna, pf, codec):
+    """pna_split_archive / pna_join_parts (host only): equal to the oracle's SplitParts for a range of part sizes, including sizes
+    that cut FDAT chunks several times, leave no room behind a chunk, or fit everything into one part; the reference's own multipart
+    fixture is reproduced from its joined image."""
+    import os
+    from conftest import golden
+    payloads = [os.urandom(n) for n in (0, 5, 1000, 3000, 70)]
+    arc = pf.write_archive_header()
+    for i, pl in enumerate(payloads):
+        arc += pf.write_normal_entry(pf.file_entry_header(0, f"d/f{i}.bin"), [pl] if pl else [], len(pl))
+    arc += pf.write_solid_entry(0, [os.urandom(500), os.urandom(40)]) + pf.finalize_archive()
+    body = pf.archive_body_chunks(arc)
+    for size in (64, 65, 77, 100, 128, 200, 564, 1000, 1024, 4096, 1 << 20):
+        try:
+            want = pf.split_parts(body, size)
+        except ValueError:
+            with pytest.raises(pna.PnaGpuError):
+                pna.split_archive(arc, size)
+            continue
+        got = pna.split_archive(arc, size)
+        assert got == want and all(len(p) <= size for p in got), size
+        joined = pna.join_parts(got)
+        assert pf.join_parts(got) == pf.archive_body_chunks(joined)
+        # the entries read back identically from the joined image
+        a, b = pf.read_archive(arc)[1], pf.read_archive(joined)[1]
+        assert [(x.data, getattr(x, "name", None)) for x in a] == [(y.data, getattr(y, "name", None)) for y in b]
+    with pytest.raises(pna.PnaGpuError):
+        pna.split_archive(arc, 63)
+    p1, p2 = golden("multipart.part1.pna"), golden("multipart.part2.pna")
+    one = pna.join_parts([p1, p2])
+    (it,) = pf.read_archive(one)[1]
+    whole = pf.write_archive_header() + pf.write_normal_entry(it.chunks[0][1], [it.data], None) + pf.finalize_archive()
+    assert pna.split_archive(whole, len(p1)) == [p1, p2]
+    with pytest.raises(pna.PnaGpuError):
+        pna.join_parts([p2, p1])

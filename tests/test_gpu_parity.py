@@ -722,3 +722,23 @@ def test_extract_driver_reads_solid_archives(gpu_ctx, pna, pf, codec):
     assert [(n, d) for n, _, d in pna.extract_archive(gpu_ctx, ref)] == [(e.name, e.data) for e in inner]
     arc_d = pna.create_archive(gpu_ctx, names, ents, algo=pna.ALGO_DEFLATE, solid=True)
     assert [d for _, _, d in pna.extract_archive(gpu_ctx, arc_d)] == ents
+
+
+def test_multipart_create_split_join_extract(gpu_ctx, pna, pf, codec):
+    """`pna create --split`: the device-assembled archive image re-framed into parts (pna_split_archive == the oracle's SplitParts),
+    then read back: parts joined (pna_join_parts) and extracted on the device; the reference's multipart fixture through the same path."""
+    ents = [codec.corpus_file(0, 950 + i, n) for i, n in enumerate([300000, 5, 0, 70001, (1 << 20) + 9])]
+    names = [f"mp/{i}.txt" for i in range(len(ents))]
+    arc = pna.create_archive(gpu_ctx, names, ents)
+    for size in (4096, 100000, 300000):
+        parts = pna.split_archive(arc, size)
+        assert parts == pf.split_parts(pf.archive_body_chunks(arc), size) and len(parts) > 1 and all(len(p) <= size for p in parts)
+        got = pna.extract_archive(gpu_ctx, pna.join_parts(parts))
+        assert [n for n, _, _ in got] == names and [d for _, _, d in got] == ents
+    with pytest.raises(pna.PnaGpuError) as ei:                  # a single part of a multipart archive is not a whole archive
+        pna.extract_archive(gpu_ctx, parts[0])
+    assert ei.value.code == -7
+    ref = pna.join_parts([open(os.path.join(GOLDEN, f"multipart.part{k}.pna"), "rb").read() for k in (1, 2)])
+    ((name, kind, data),) = pna.extract_archive(gpu_ctx, ref)
+    (it,) = pf.read_archive(ref)[1]
+    assert name == it.name and data == codec.decode_payload(it.compression, it.data, 1 << 20)

@@ -98,3 +98,24 @@ def test_fixture_payload_hashes(pf, codec):
             assert got[k] == v
     assert hashlib.sha256(golden("zstd.pna")).hexdigest()[:16] == "5185fd6444089203"
     assert hashlib.sha256(golden("deflate.pna")).hexdigest()[:16] == "fbb4240ebad45d1c"
+
+
+def test_split_parts_reproduces_the_reference_multipart_fixture(pf):
+    """resources/test/multipart.part{1,2}.pna: joining the parts, merging the FDAT fragments back into the chunk the writer was handed
+    and splitting again at the fixture's part size gives the very same parts (SplitParts, lib/src/archive/split_parts.rs:140-173)."""
+    p1, p2 = golden("multipart.part1.pna"), golden("multipart.part2.pna")
+    body = pf.join_parts([p1, p2])
+    assert [(t, len(d)) for t, d in body] == [(b"FHED", 24), (b"FDAT", 464), (b"FDAT", 357), (b"FEND", 0)]
+    merged = []
+    for t, d in body:
+        if merged and t == merged[-1][0] == b"FDAT":
+            merged[-1] = (t, merged[-1][1] + d)
+        else:
+            merged.append((t, d))
+    assert pf.split_parts(merged, len(p1)) == [p1, p2]
+    with pytest.raises(ValueError):
+        pf.split_parts(merged, pf.MIN_SPLIT_PART_BYTES - 1)                  # split_parts.rs:88-94
+    with pytest.raises(ValueError):
+        pf.join_parts([p2, p1])
+    # budget arithmetic of split_parts.rs:14-23
+    assert (pf.PART_HEADER_BYTES, pf.SPLIT_ARCHIVE_OVERHEAD_BYTES, pf.MIN_SPLIT_PART_BYTES) == (28, 52, 64)
