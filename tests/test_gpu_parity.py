@@ -742,3 +742,19 @@ def test_multipart_create_split_join_extract(gpu_ctx, pna, pf, codec):
     ((name, kind, data),) = pna.extract_archive(gpu_ctx, ref)
     (it,) = pf.read_archive(ref)[1]
     assert name == it.name and data == codec.decode_payload(it.compression, it.data, 1 << 20)
+
+
+def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec):
+    """Frames produced by the host's libzstd (the reference's codec, any version present) at levels 1..19 and on several kinds of data:
+    single frames with content size, windows up to 8 MiB, repeat offsets, RLE / raw blocks, long matches -- beyond what the golden
+    archives happen to contain.  Skipped when the box has no libzstd."""
+    if codec.system_libzstd() is None:
+        pytest.skip("no system libzstd on this host")
+    datas = [codec.corpus_file(0, 40, 700000), codec.corpus_file(1, 41, 300000), bytes(200000), codec.corpus_file(2, 42, 150000),
+             (b"abcdefghij" * 30000)[:250007], codec.corpus_file(0, 43, 3 << 20), b"x", b"",
+             codec.corpus_file(0, 44, 100000) * 9]                               # long-range repeats across a > 1 MiB distance
+    for level in (1, 2, 3, 5, 7, 9, 12, 15, 19):
+        comp = [codec.libzstd_compress(d, level) for d in datas]
+        back = gpu_ctx.decompress_batch(comp, [len(d) for d in datas])
+        for i, (b, d) in enumerate(zip(back, datas)):
+            assert b == d, (level, i)
