@@ -106,6 +106,7 @@ struct PinBuf {                                  // page-locked host staging: as
 struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
+    uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
@@ -169,6 +170,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
     if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0xF00u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
+    c->call_flags = c->flags;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     *out = c;
@@ -216,6 +218,15 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
         return level < 0 ? 0 : (level > 9 ? 9 : level);
     }
     return 0;
+}
+
+// Two parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
+// lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101): levels below the default (zstd < 3, deflate < 6) take the plain greedy parse,
+// the default and everything above it greedy + one-step lazy deferral (the best this encoder has).  PNA_LEVEL_DEFAULT = the default.
+static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
+    const int lv = pna_gpu_clamp_level(algo, level);
+    const int dflt = algo == PNA_ALGO_DEFLATE ? 6 : 3;
+    return lv < dflt ? (c->flags & ~F_LAZY) : c->flags;
 }
 
 extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
@@ -467,11 +478,11 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
-                  (uint4 *)c->ctab.p, (c->flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
+                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
-                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->flags);
+                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags);
     } else {
         // zstd: the segments go through k_lz in chunks on `st`; the entropy stage of a finished chunk runs on the auxiliary
         // stream next to the following chunk's k_lz (latency-bound kernels hide in the issue slots k_lz leaves free)
@@ -490,19 +501,19 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
             launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr,
-                      c->flags & 0x3FFu, MAX_OFF, 0xFFFFFFFFu, st);
+                      c->call_flags & 0x3FFu, MAX_OFF, 0xFFFFFFFFu, st);
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));
             launch_entropy_chunk((const SegDesc *)c->segs.p, s0, s1 - s0, (const uint32_t *)c->blk_seg.p, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
-                                 c->flags, c->aux, &c->ev_en[k][1]);
+                                 c->call_flags, c->aux, &c->ev_en[k][1]);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         if (timed) HIPCHK(c, hipEventRecord(c->ev[4], st));
         launch_plan((const SegDesc *)c->segs.p, nseg, (BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (uint64_t *)c->seg_size.p,
-                    (uint64_t *)c->seg_off.p, c->flags, st);
+                    (uint64_t *)c->seg_off.p, c->call_flags, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[5], st));
     }
     HIPCHK(c, hipGetLastError());
@@ -747,7 +758,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
                                              uint64_t *dst_off, void *hip_stream) {
     if (!c || !src_off || !src_len || !dst_off || (!d_src && n) || (!d_dst && n)) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
-    (void)level;                                     // one parameter set (hash_log 14, min_match 6, greedy+lazy1)
+    c->call_flags = level_flags(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->timing = pna_gpu_timing{};
@@ -819,7 +830,7 @@ extern "C" int pna_gpu_create_archive_enc_device(pna_gpu_ctx *c, int algo, int l
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
     if (cipher) { int rc = resolve_ivs(c, cipher, n, own_ivs, &ivs); if (rc) return rc; }
-    (void)level;
+    c->call_flags = level_flags(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->timing = pna_gpu_timing{};
@@ -926,7 +937,7 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
-    (void)level;
+    c->call_flags = level_flags(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // ---- 1. layout of the serialised inner entries (all sizes are known up front)
@@ -1044,7 +1055,7 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
                                                pna_sink_fn sink, void *user) {
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
-    (void)level;
+    c->call_flags = level_flags(c, algo, level);
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;

@@ -758,3 +758,23 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
         back = gpu_ctx.decompress_batch(comp, [len(d) for d in datas])
         for i, (b, d) in enumerate(zip(back, datas)):
             assert b == d, (level, i)
+
+
+def test_levels_select_the_parse(gpu_ctx, pna, codec):
+    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto two parameter sets: below the
+    default (zstd < 3, deflate < 6) the plain greedy parse, from the default upwards greedy + lazy; both bit-exact with the model."""
+    data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
+    pz = codec.default_params()
+    for level, lazy in ((-5, False), (1, False), (2, False), (3, True), (pna.LEVEL_DEFAULT, True), (19, True), (22, True), (99, True)):
+        pz.flags = codec.F_HUF | codec.F_FSE | (codec.F_LAZY if lazy else 0)
+        outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
+        assert outs == [codec.model_compress(d, pz) for d in data], level
+    pd = codec.deflate_default_params()
+    base = pd.flags
+    for level, lazy in ((0, False), (1, False), (5, False), (6, True), (pna.LEVEL_DEFAULT, True), (9, True)):
+        pd.flags = (base | codec.F_LAZY) if lazy else (base & ~codec.F_LAZY)
+        outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
+        assert outs == [codec.deflate_model_compress(d, pd) for d in data], level
+        assert all(codec.zlib_decompress(o) == d for o, d in zip(outs, data))
+    lazy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=3))); greedy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=1)))
+    assert lazy_sz < greedy_sz
