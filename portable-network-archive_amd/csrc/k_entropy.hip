@@ -482,9 +482,11 @@ __global__ __launch_bounds__(64)
 void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
            const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc) {
     __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
+    __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 | base << 16 (small values only)
     const uint32_t lane = threadIdx.x;
     const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
     { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8) | (C_LL_BASE[c] << 16); }
     for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8) | (C_ML_BASE[c] << 16); }
     for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
@@ -504,7 +506,9 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     if (nseq == 0 || !T->seq_ok) { blk[g].seq_bits = 0; return; }
     const uint32_t mll = T->mode[0], mof = T->mode[1], mml = T->mode[2];
     const uint32_t tl_ll = T->tlog[0], tl_of = T->tlog[1], tl_ml = T->tlog[2];
-    const SeqTable *tll = &tab[sl][0], *tof = &tab[sl][1], *tml = &tab[sl][2];
+    // RLE mode (one symbol, no state bits) runs through the same code on an all-zero table: delta_nb = 0 gives 0 bits, state[0] = 0
+    // keeps the state at 0 -- no per-sequence branch on the mode
+    const SeqTable *tll = mll == 1 ? &ztab : &tab[sl][0], *tof = mof == 1 ? &ztab : &tab[sl][1], *tml = mml == 1 ? &ztab : &tab[sl][2];
     const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
     uint32_t *out32 = (uint32_t *)(seqc + (size_t)g * BLK_SIZE);
     const uint32_t cap_words = BLK_SIZE / 4;
@@ -513,14 +517,28 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
         acc |= (uint64_t)v << nb; nb += n;
         if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
     };
+    // code / extra-bit count / base of a literal length and a match length: LDS LUT for small values, arithmetic above (code = highbit +
+    // 19 / 36), both computed and selected (no divergent branch)
+    auto codes = [&](uint64_t s, uint32_t &llv, uint32_t &mlv, uint32_t &ofb, uint32_t &lc, uint32_t &lbits, uint32_t &lbase,
+                     uint32_t &mc, uint32_t &mbits, uint32_t &mbase, uint32_t &oc) {
+        llv = seq_ll(s); mlv = seq_ml(s); ofb = seq_off(s) + 3;
+        const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
+        const bool ls = llv < 64;
+        lc = ls ? (tl & 0xFF) : hl + 19; lbits = ls ? ((tl >> 8) & 0xFF) : hl; lbase = ls ? (tl >> 16) : (1u << hl);
+        const uint32_t mb = mlv - 3;
+        const uint32_t tm = lut_ml[mb < 128 ? mb : 127u], hm = hb(mb | 1u);
+        const bool ms = mb < 128;
+        mc = ms ? (tm & 0xFF) : hm + 36; mbits = ms ? ((tm >> 8) & 0xFF) : hm; mbase = ms ? (tm >> 16) : ((1u << hm) + 3);
+        oc = hb(ofb);
+    };
     // Sequences are consumed last-to-first in 32-byte chunks (4 sequences, two 16-byte loads per lane); the next
     // chunk is requested before the current one is encoded so the HBM/L2 latency overlaps the serial tANS chain.
     uint32_t st_ml = 0, st_of = 0, st_ll = 0;
-    bool first = true;
     const uint32_t top = nseq - 1;
     uint32_t k = top >> 2;
     const uint4 *bs4 = (const uint4 *)bs;
     uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
+    bool first = true;
     for (;;) {
         uint4 n0 = a0, n1 = a1;
         if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
@@ -529,28 +547,20 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
 #pragma unroll
         for (int j = 3; j >= 0; j--) {
             if (4 * k + (uint32_t)j > top) continue;
-            const uint64_t s = sq[j];
-            const uint32_t llv = seq_ll(s), mlv = seq_ml(s), ofb = seq_off(s) + 3;
-            // code / extra-bit count / base: LDS LUT for small values, arithmetic above (code = highbit + 19 / 36)
-            uint32_t lc, lbits, lbase, mc, mbits, mbase;
-            if (llv < 64) { const uint32_t t = lut_ll[llv]; lc = t & 0xFF; lbits = (t >> 8) & 0xFF; lbase = t >> 16; }
-            else { lbits = hb(llv); lc = lbits + 19; lbase = 1u << lbits; }
-            const uint32_t mb = mlv - 3;
-            if (mb < 128) { const uint32_t t = lut_ml[mb]; mc = t & 0xFF; mbits = (t >> 8) & 0xFF; mbase = t >> 16; }
-            else { mbits = hb(mb); mc = mbits + 36; mbase = (1u << mbits) + 3; }
-            const uint32_t oc = hb(ofb);
-            if (first) {
-                st_ml = mml == 1 ? 0u : tml->sym[mc].first_state;
-                st_of = mof == 1 ? 0u : tof->sym[oc].first_state;
-                st_ll = mll == 1 ? 0u : tll->sym[lc].first_state;
+            uint32_t llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc;
+            codes(sq[j], llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc);
+            const SeqSym yo = tof->sym[oc], ym = tml->sym[mc], yl = tll->sym[lc];
+            if (first) {                                       // the last sequence of the block only sets the initial states
+                st_ml = ym.first_state; st_of = yo.first_state; st_ll = yl.first_state;
                 first = false;
             } else {
                 // the three state flushes (<= 9 bits each) go out as one field
-                uint32_t fv = 0, fn = 0;
-                if (mof != 1) { const SeqSym y = tof->sym[oc]; const uint32_t n = (st_of + y.delta_nb) >> 16; fv = st_of & ((1u << n) - 1); fn = n; st_of = tof->state[(int)(st_of >> n) + y.delta_find]; }
-                if (mml != 1) { const SeqSym y = tml->sym[mc]; const uint32_t n = (st_ml + y.delta_nb) >> 16; fv |= (st_ml & ((1u << n) - 1)) << fn; fn += n; st_ml = tml->state[(int)(st_ml >> n) + y.delta_find]; }
-                if (mll != 1) { const SeqSym y = tll->sym[lc]; const uint32_t n = (st_ll + y.delta_nb) >> 16; fv |= (st_ll & ((1u << n) - 1)) << fn; fn += n; st_ll = tll->state[(int)(st_ll >> n) + y.delta_find]; }
-                put(fv, fn);
+                const uint32_t no = (st_of + yo.delta_nb) >> 16, nm = (st_ml + ym.delta_nb) >> 16, nl = (st_ll + yl.delta_nb) >> 16;
+                const uint32_t fv = (st_of & ((1u << no) - 1)) | ((st_ml & ((1u << nm) - 1)) << no) | ((st_ll & ((1u << nl) - 1)) << (no + nm));
+                st_of = tof->state[(int)(st_of >> no) + yo.delta_find];
+                st_ml = tml->state[(int)(st_ml >> nm) + ym.delta_find];
+                st_ll = tll->state[(int)(st_ll >> nl) + yl.delta_find];
+                put(fv, no + nm + nl);
             }
             // literal-length and match-length extra bits (<= 16 + 16) as one field, then the offset's
             put((llv - lbase) | ((mlv - mbase) << lbits), lbits + mbits);
