@@ -1,6 +1,6 @@
 """CPU baseline thread sweep on the GPU box's host cores (oracle/cpu_baseline.c)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import codec
 L = codec.lib()
 L.pna_cpu_baseline_zstd.restype = ctypes.c_double

@@ -1,6 +1,6 @@
 """Diagnostic: LZ-stage output (sequences) of the device vs the model for one small input, deflate or zstd parameters."""
 import importlib, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import codec
 pna = importlib.import_module("portable-network-archive_amd")

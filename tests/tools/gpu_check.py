@@ -1,6 +1,6 @@
-"""Stage-by-stage GPU-vs-oracle diagnosis (run on the GPU box): python scripts/gpu_check.py"""
+"""Stage-by-stage GPU-vs-oracle diagnosis (run on the GPU box): python tests/tools/gpu_check.py"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from oracle import codec
