@@ -1345,7 +1345,13 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         if (e.compression != PNA_ALGO_STORE) {
             // fSIZ is optional (older writers omit it): the payload is then decoded like a solid stream, its size found by the decoder
             if (!e.has_size) nosize_idx.push_back(i);
-            else { e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15; }
+            else {
+                // fSIZ comes from the archive: a size no payload of this length can decode to (deflate tops out at 1032 : 1, zstd at a few
+                // thousand : 1 through RLE blocks) is damage, not a reason to ask the device for exabytes
+                if (e.raw_size > (1ull << 40) || e.raw_size / 65536 > e.pay_len + 1) return fail(c, PNA_E_INVAL, "fSIZ is out of proportion to the entry's data");
+                e.raw_off = raw_total; raw_total = (raw_total + e.raw_size + 15) & ~(uint64_t)15;
+                if (raw_total > (1ull << 42)) return fail(c, PNA_E_NOMEM, "archive decodes to more than this driver takes in one call");
+            }
         }
     }
     for (XSolid &so : solids) {

@@ -675,6 +675,19 @@ def test_extract_driver_round_trips_archives(gpu_ctx, pna, pf, codec):
     with pytest.raises(pna.PnaGpuError) as ei:
         pna.extract_archive(gpu_ctx, bytes(bad))
     assert ei.value.code == -2
+    # a forged fSIZ (CRC repaired): sizes out of proportion to the data are refused before anything is allocated, plausible wrong
+    # ones are caught by the decoder's size check
+    import zlib
+    hostile = pf.write_archive_header() + pf.write_chunk(b"FHED", pf.file_entry_header(2, "x")) + pf.write_chunk(b"fSIZ", (1 << 62).to_bytes(8, "big")) \
+        + pf.write_chunk(b"FDAT", gpu_ctx.compress_batch([b"hello"])[0]) + pf.write_chunk(b"FEND") + pf.finalize_archive()
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, hostile)
+    assert ei.value.code == -2
+    wrong = pf.write_archive_header() + pf.write_chunk(b"FHED", pf.file_entry_header(2, "x")) + pf.write_chunk(b"fSIZ", (7).to_bytes(1, "big")) \
+        + pf.write_chunk(b"FDAT", gpu_ctx.compress_batch([b"hello"])[0]) + pf.write_chunk(b"FEND") + pf.finalize_archive()
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, wrong)
+    assert ei.value.code == -2
     # entries without fSIZ (older writers): sized by the decoder, like a solid stream; deflate without fSIZ is refused
     for name in ("zstd.pna", "zstd_keep_all.pna"):
         ref = open(os.path.join(GOLDEN, name), "rb").read()
