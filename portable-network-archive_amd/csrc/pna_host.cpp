@@ -1180,12 +1180,17 @@ struct XEntry {
     uint64_t pk_off = 0, pay_len = 0, raw_off = 0;            // payload (prefix stripped) in the packed buffer; decoded bytes in the raw buffer
     std::vector<uint8_t> fhed;                                 // FHED body: the GCM stream key is bound to it
     uint32_t gcm_seg = 0;                                      // GCM STREAM: segment size of the stream header
+    size_t d0 = 0, d1 = 0;                                     // its FDAT chunks in the descriptor list
+    uint64_t lo = 0, hi = 0;                                   // archive bytes [lo, hi) that hold its data chunks
 };
+typedef std::vector<std::pair<std::string, std::vector<uint8_t>>> XKeys;
 struct XSolid {                                                // SHED [PHSF] SDAT* SEND -- lib/src/entry.rs:465-484,567-583
     int compression = 0, encryption = 0, cipher_mode = 0; std::string phsf;
     std::vector<XPiece> pieces; uint64_t stream_len = 0;
     size_t order = 0;                                          // number of normal entries in front of it
     uint64_t pk_off = 0, pay_len = 0;
+    size_t s0 = 0, s1 = 0;                                     // its SDAT chunks in the descriptor list
+    uint64_t lo = 0, hi = 0;
 };
 uint32_t rd_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 int b64_val(char ch) {
@@ -1198,6 +1203,10 @@ bool b64_decode_nopad(const std::string &s, std::vector<uint8_t> &out) {
     return true;
 }
 }
+
+static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, const void *password, size_t password_len, pna_entry_fn cb, void *user,
+                          std::vector<XEntry> &ents, std::vector<FrameDesc> &dchunks, std::vector<FrameDesc> &schunks, std::vector<XSolid> &solids,
+                          XKeys &keys, size_t &index);
 
 extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive, size_t archive_len, const void *password, size_t password_len,
                                             pna_entry_fn cb, void *user) {
@@ -1224,31 +1233,77 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         else if (memcmp(ty, "ANXT", 4) == 0) return fail(c, PNA_E_UNSUPPORTED, "multipart archives are not read by this driver");
         else if (memcmp(ty, "SHED", 4) == 0) {
             if (in_entry || in_solid || len != 5 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad solid header");
-            scur = XSolid(); in_solid = true; scur.order = ents.size();
+            scur = XSolid(); in_solid = true; scur.order = ents.size(); scur.s0 = schunks.size(); scur.lo = pos;
             scur.compression = data[2]; scur.encryption = data[3]; scur.cipher_mode = data[4];
         } else if (in_solid) {
             if (memcmp(ty, "SDAT", 4) == 0) { scur.pieces.push_back(XPiece{pos + 8, len}); scur.stream_len += len; }
             else if (memcmp(ty, "PHSF", 4) == 0) scur.phsf.assign((const char *)data, len);
-            else if (memcmp(ty, "SEND", 4) == 0) { solids.push_back(std::move(scur)); in_solid = false; }
+            else if (memcmp(ty, "SEND", 4) == 0) { scur.s1 = schunks.size(); scur.hi = pos + 12; solids.push_back(std::move(scur)); in_solid = false; }
             else if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk in a solid entry");
         }
         else if (memcmp(ty, "FHED", 4) == 0) {
             if (in_entry || len < 6 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad entry header");
-            cur = XEntry(); in_entry = true;
+            cur = XEntry(); in_entry = true; cur.d0 = dchunks.size(); cur.lo = pos;
             cur.kind = data[2]; cur.compression = data[3]; cur.encryption = data[4]; cur.cipher_mode = data[5];
             cur.name.assign((const char *)data + 6, len - 6); cur.fhed.assign(data, data + len);
         } else if (!in_entry) { if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk between entries"); }
         else if (is_fdat) { cur.pieces.push_back(XPiece{pos + 8, len}); cur.stream_len += len; }
         else if (memcmp(ty, "fSIZ", 4) == 0) { if (len > 8) return fail(c, PNA_E_UNSUPPORTED, "entry beyond 2^64 bytes"); cur.has_size = true; cur.raw_size = 0; for (uint32_t i = 0; i < len; i++) cur.raw_size = (cur.raw_size << 8) | data[i]; }
         else if (memcmp(ty, "PHSF", 4) == 0) cur.phsf.assign((const char *)data, len);
-        else if (memcmp(ty, "FEND", 4) == 0) { ents.push_back(std::move(cur)); in_entry = false; }
+        else if (memcmp(ty, "FEND", 4) == 0) { cur.d1 = dchunks.size(); cur.hi = pos + 12; ents.push_back(std::move(cur)); in_entry = false; }
         else if (!(ty[0] & 0x20)) return fail(c, PNA_E_INVAL, "unknown critical chunk");      // chunk/types.rs: bit 5 of byte 0 clear = critical
         pos += 12 + (size_t)len;
     }
     if (!ended || in_entry || in_solid) return fail(c, PNA_E_INVAL, "archive not terminated by AEND");
+    // ---- 2. windows: a run of entries whose archive bytes, packed payloads and decoded bytes stay within a few GiB each goes through the
+    // device at a time (an archive of any size in host memory against a bounded footprint in HBM); a solid entry is a window of its own
+    XKeys keys; size_t index = 0, si = 0, w0 = 0;
+    const size_t n_all = ents.size();
+    uint64_t WIN = 4ull << 30;
+    if (const char *ev = getenv("PNA_EXTRACT_WIN_MIB")) { const long v = atol(ev); if (v >= 1 && v <= (1 << 20)) WIN = (uint64_t)v << 20; }
+    auto rebase_run = [&](size_t e0, size_t e1, std::vector<XEntry> &we, std::vector<FrameDesc> &wd, uint64_t base) {
+        we.assign(std::make_move_iterator(ents.begin() + e0), std::make_move_iterator(ents.begin() + e1));
+        wd.assign(dchunks.begin() + we.front().d0, dchunks.begin() + we.back().d1);
+        for (auto &f : wd) f.arc_off -= base;
+        for (auto &e : we) for (auto &p : e.pieces) p.off -= base;
+    };
+    while (w0 < n_all || si < solids.size()) {
+        std::vector<XEntry> we; std::vector<FrameDesc> wd, ws; std::vector<XSolid> wso;
+        if (si < solids.size() && solids[si].order <= w0) {
+            XSolid so = std::move(solids[si]);
+            const uint64_t base = so.lo;
+            ws.assign(schunks.begin() + so.s0, schunks.begin() + so.s1);
+            for (auto &f : ws) f.arc_off -= base;
+            for (auto &p : so.pieces) p.off -= base;
+            const uint64_t span = so.hi - base;
+            so.order = 0; wso.push_back(std::move(so)); si++;
+            int rc = extract_window(c, a + base, (size_t)span, password, password_len, cb, user, we, wd, ws, wso, keys, index);
+            if (rc) return rc;
+            continue;
+        }
+        size_t w1 = w0; uint64_t raw = 0, pk = 0;
+        const size_t stop = si < solids.size() ? std::min(n_all, solids[si].order) : n_all;
+        while (w1 < stop) {
+            const XEntry &e = ents[w1];
+            const uint64_t r = e.has_size ? e.raw_size : 0;
+            if (w1 > w0 && (e.hi - ents[w0].lo > WIN || raw + r > 3 * WIN || pk + e.stream_len > WIN)) break;
+            raw += r; pk += e.stream_len; w1++;
+        }
+        const uint64_t base = ents[w0].lo, span = ents[w1 - 1].hi - base;
+        rebase_run(w0, w1, we, wd, base);
+        int rc = extract_window(c, a + base, (size_t)span, password, password_len, cb, user, we, wd, ws, wso, keys, index);
+        if (rc) return rc;
+        w0 = w1;
+    }
+    return PNA_OK;
+}
+
+// One window of the driver above: `a` / archive_len are the window's bytes, every offset in ents / dchunks / schunks / solids is relative to it.
+static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, const void *password, size_t password_len, pna_entry_fn cb, void *user,
+                          std::vector<XEntry> &ents, std::vector<FrameDesc> &dchunks, std::vector<FrameDesc> &schunks, std::vector<XSolid> &solids,
+                          XKeys &keys, size_t &index) {
     const size_t n = ents.size();
-    // ---- 2. keys (one derivation per distinct PHSF string), layout of the packed payloads and of the decoded entries
-    std::vector<std::pair<std::string, std::vector<uint8_t>>> keys;
+    // keys (one derivation per distinct PHSF string), layout of the packed payloads and of the decoded entries
     auto key_for = [&](const std::string &phsf, const uint8_t **out) -> int {
         for (auto &k : keys) if (k.first == phsf) { *out = k.second.data(); return PNA_OK; }
         // "$pbkdf2-sha256$i=<rounds>,l=<len>$<salt>" (derive_password_hash, lib/src/hash.rs:47-88); Argon2 strings need the Rust host
@@ -1598,7 +1653,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     bool any_store = false; for (const XEntry &e : ents) any_store |= e.compression == PNA_ALGO_STORE && e.pay_len;
     if (any_store) HIPCHK(c, hipMemcpyAsync(c->hp_in[0].p, c->x_pk.p, pk_total, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    size_t index = 0, si = 0;
+    size_t si = 0;
     std::vector<uint8_t> joined;
     auto deliver_solids = [&](size_t upto) -> int {
         for (; si < solids.size() && solids[si].order <= upto; si++)

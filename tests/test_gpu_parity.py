@@ -791,3 +791,25 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
         assert all(codec.zlib_decompress(o) == d for o, d in zip(outs, data))
     lazy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=3))); greedy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=1)))
     assert lazy_sz < greedy_sz
+
+
+def test_extract_driver_windows(gpu_ctx, pna, pf, codec):
+    """The driver walks the archive in windows of bounded size (PNA_EXTRACT_WIN_MIB; 4 GiB by default): with 1 MiB windows every large
+    entry is a window of its own and small ones share one -- same entries, same order, solid entries in between included."""
+    ents = [codec.corpus_file(i % 2, 1000 + i, n) for i, n in enumerate([300000, 5, 0, 2500000, 70001, (1 << 20) + 9, 12, 65536, 900000, 3])]
+    names = [f"w/{i:02d}.txt" for i in range(len(ents))]
+    arc = pna.create_archive(gpu_ctx, names, ents)
+    solid = pna.create_archive(gpu_ctx, ["s/a", "s/b"], [ents[0], ents[4]], solid=True)
+    # splice the solid entry between the 4th and 5th normal entries: [head | e0..e3 | SHED..SEND | e4.. | AEND]
+    chunks = pf.archive_body_chunks(arc); so_chunks = pf.archive_body_chunks(solid)
+    cut = [i for i, (t, _) in enumerate(chunks) if t == b"FEND"][3] + 1
+    mixed = pf.write_archive_header() + b"".join(pf.write_chunk(t, d) for t, d in chunks[:cut] + so_chunks + chunks[cut:]) + pf.finalize_archive()
+    want = [(n, d) for n, d in zip(names[:4], ents[:4])] + [("s/a", ents[0]), ("s/b", ents[4])] + [(n, d) for n, d in zip(names[4:], ents[4:])]
+    for win in (None, "1", "3"):
+        if win:
+            os.environ["PNA_EXTRACT_WIN_MIB"] = win
+        try:
+            got = pna.extract_archive(gpu_ctx, mixed)
+        finally:
+            os.environ.pop("PNA_EXTRACT_WIN_MIB", None)
+        assert [(n, d) for n, _, d in got] == want, win
