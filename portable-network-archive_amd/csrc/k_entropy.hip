@@ -268,6 +268,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     __shared__ uint16_t tmp192[4][192];
     __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2];
     __shared__ SeqTable wtab;
+    __shared__ uint8_t s_llc[64], s_mlc[128];
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     SegTables *T = tabs + blockIdx.x;
@@ -275,6 +276,9 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
 
     for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
     for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
+    // code look-ups of the small literal / match lengths from LDS (a per-lane index into __constant__ memory is a global load)
+    if (tid < 64) s_llc[tid] = C_LL_CODE[tid];
+    if (tid < 128) s_mlc[tid] = C_ML_CODE[tid];
     if (tid == 0) {
         T->huf_ok = 0; T->tree_len = 0; T->max_sym = 0; T->maxbits = 0; T->seq_ok = 1;
         for (int k = 0; k < 3; k++) { T->mode[k] = 0; T->tlog[k] = 0; T->desc_len[k] = 0; }
@@ -297,13 +301,14 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
                 atomicAdd(&hl[(w[k] >> 16) & 0xFF], 1u); atomicAdd(&hl[w[k] >> 24], 1u);
             }
         }
-        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += ST_THREADS) atomicAdd(&hl[bl[i]], 1u);
+        for (uint32_t j = (n16 << 4) + tid; j < nlit; j += ST_THREADS) atomicAdd(&hl[bl[j]], 1u);
         const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
         for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
-            uint64_t s = bs[i];
-            atomicAdd(&h_seq[0][tid & 3][ll_code(seq_ll(s))], 1u);
+            const uint64_t s = bs[i];
+            const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
+            atomicAdd(&h_seq[0][tid & 3][llv < 64 ? (uint32_t)s_llc[llv] : hb(llv) + 19], 1u);
             atomicAdd(&h_seq[1][tid & 3][hb(seq_off(s) + 3)], 1u);
-            atomicAdd(&h_seq[2][tid & 3][ml_code(seq_ml(s))], 1u);
+            atomicAdd(&h_seq[2][tid & 3][mb < 128 ? (uint32_t)s_mlc[mb] : hb(mb) + 36], 1u);
         }
     }
     __syncthreads();
