@@ -383,16 +383,16 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     const uint4 *bl16 = (const uint4 *)bl;
     unsigned long long *out64 = (unsigned long long *)(litc + (size_t)g * BLK_SIZE);
     if (!(flags & F_HUF) || nlit < 64) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
-    // RLE test (coalesced)
-    {
+    if (!T->huf_ok) {
+        // no Huffman code for this segment: only the RLE test is left (coalesced)
         const uint32_t b0 = bl[0] * 0x01010101u; int same = 1;
         const uint32_t n16 = nlit >> 4;
         for (uint32_t i = tid; i < n16; i += LIT_THREADS) { const uint4 v = bl16[i]; same &= (v.x == b0) & (v.y == b0) & (v.z == b0) & (v.w == b0); }
         for (uint32_t i = (n16 << 4) + tid; i < nlit; i += LIT_THREADS) same &= (bl[i] == (uint8_t)b0);
         same = __syncthreads_and(same);
-        if (same) { if (tid == 0) { blk[g].lit_rle = 1; blk[g].lit_body = 0; } return; }
+        if (tid == 0) { blk[g].lit_rle = same ? 1u : 0u; blk[g].lit_body = 0; }
+        return;
     }
-    if (!T->huf_ok) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
     code[tid] = T->huf_code[tid];
     __syncthreads();
     const uint32_t nstreams = nlit >= 256 ? 4u : 1u;
@@ -403,20 +403,25 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     if (wave < nstreams) m = (nstreams == 4 && wave == 3) ? nlit - 3 * segsz : segsz;
     const uint32_t e = a + m;
     const uint32_t gfirst = a >> 4, gend = m ? (e + 15) >> 4 : gfirst;
-    // ---- pass 1: bits of the stream
+    // ---- pass 1: bits of the stream, and the RLE test (all literals equal) in the same read: the waves' ranges cover every literal
     {
-        uint32_t bits = 0;
+        const uint32_t b0 = bl[0];
+        uint32_t bits = 0; int same = 1;
         for (uint32_t gi = gfirst + lane; gi < gend; gi += 64) {
             const uint4 v = bl16[gi];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w}, base = gi << 4;
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) { const uint32_t i = base + k; if (i >= a && i < e) bits += code[(w[k >> 2] >> (8 * (k & 3))) & 0xFF] >> 16; }
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t i = base + k, sym = (w[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                if (i >= a && i < e) { bits += code[sym] >> 16; same &= (sym == b0); }
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) bits += (uint32_t)__shfl_xor((int)bits, d);
         if (lane == 0) sbits[wave] = wave < nstreams ? bits : 0;
+        same = __syncthreads_and(same);
+        if (same) { if (tid == 0) { blk[g].lit_rle = 1; blk[g].lit_body = 0; } return; }
     }
-    __syncthreads();
     // stream byte sizes and offsets
     uint32_t sz[4], off[4], body = nstreams == 4 ? 6u : 0u;
     for (uint32_t k = 0; k < 4; k++) { sz[k] = k < nstreams ? (sbits[k] >> 3) + 1 : 0; off[k] = body; body += sz[k]; }
