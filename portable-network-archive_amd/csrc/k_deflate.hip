@@ -141,6 +141,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     __shared__ uint32_t cl_code[19];
     __shared__ uint32_t ll_code_s[288], d_code_s[32], first_s[16], sh2[2], hsh[3];
     __shared__ uint16_t used_ll[288], used_d[32], used_cl[20];
+    __shared__ uint32_t hbuf[104], wsum[8], wsum2[8];
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     DeflTables *T = tabs + blockIdx.x;
@@ -185,25 +186,54 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     d_assign(d_len, 30, d_code_s, first_s, used_d, n_d, tid, DS_THREADS);
     for (uint32_t i = tid; i < 288; i += DS_THREADS) T->ll_code[i] = i < 286 ? ll_code_s[i] : 0u;
     if (tid < 32) T->d_code[tid] = tid < 30 ? d_code_s[tid] : 0u;
-    // table description: run-length tokens of the code lengths (serial scan), their 19-symbol code, the header bits
-    if (tid == 0) {
-        int nll = 286; while (nll > 257 && ll_len[nll - 1] == 0) nll--;
-        int nd = 30; while (nd > 1 && d_len[nd - 1] == 0) nd--;
-        int n = 0, ns = 0;
-        for (int i = 0; i < nll; i++) seq[n++] = ll_len[i];
-        for (int i = 0; i < nd; i++) seq[n++] = d_len[i];
-        for (int i = 0; i < n;) {
-            if (seq[i] == 0) {
-                int z = 1; while (i + z < n && seq[i + z] == 0 && z < 138) z++;
-                if (z >= 11) { sym[ns] = 18; ext[ns++] = (uint8_t)(z - 11); i += z; continue; }
-                if (z >= 3) { sym[ns] = 17; ext[ns++] = (uint8_t)(z - 3); i += z; continue; }
+    // table description: run-length tokens of the code lengths, their 19-symbol code, the header bits -- all of it on the whole
+    // workgroup (for 4 KiB entries this used to be one lane walking ~300 lengths and ~150 tokens: the largest per-entry cost)
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { hsh[0] = 257; hsh[1] = 1; }
+    if (tid < 19) clc[tid] = 0;
+    for (uint32_t i = tid; i < 104; i += DS_THREADS) hbuf[i] = 0;
+    __syncthreads();
+    for (uint32_t s2 = 257 + tid; s2 < 286; s2 += DS_THREADS) if (ll_len[s2]) atomicMax(&hsh[0], s2 + 1);
+    if (tid >= 1 && tid < 30 && d_len[tid]) atomicMax(&hsh[1], tid + 1);
+    __syncthreads();
+    const uint32_t nll = hsh[0], nd = hsh[1], n = nll + nd;
+    for (uint32_t i = tid; i < n; i += DS_THREADS) seq[i] = i < nll ? ll_len[i] : d_len[i - nll];
+    __syncthreads();
+    // token starts: a non-zero length is its own token; a run of R zeros is R / 138 tokens "18 x 138", then one "18" (rest >= 11), one
+    // "17" (rest >= 3) or the rest as literal zeros -- what the greedy left-to-right scan produces
+    uint32_t tsym[2] = {0, 0}, text[2] = {0, 0}, tidx[2] = {0, 0}; bool tst[2] = {false, false};
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+        const uint32_t i = (uint32_t)c2 * DS_THREADS + tid;
+        if (i < n) {
+            const uint32_t v = seq[i];
+            if (v) { tst[c2] = true; tsym[c2] = v; }
+            else {
+                uint32_t a = i, e = i;
+                while (a > 0 && seq[a - 1] == 0) a--;
+                while (e + 1 < n && seq[e + 1] == 0) e++;
+                const uint32_t R = e - a + 1, o = i - a, q = R / 138, rem = R - q * 138;
+                if (o < q * 138) { tst[c2] = (o % 138) == 0; tsym[c2] = 18; text[c2] = 138 - 11; }
+                else if (rem >= 11) { tst[c2] = o == q * 138; tsym[c2] = 18; text[c2] = rem - 11; }
+                else if (rem >= 3) { tst[c2] = o == q * 138; tsym[c2] = 17; text[c2] = rem - 3; }
+                else { tst[c2] = true; tsym[c2] = 0; }
             }
-            sym[ns] = seq[i]; ext[ns++] = 0; i++;
         }
-        for (int i = 0; i < 19; i++) clc[i] = 0;
-        for (int i = 0; i < ns; i++) clc[sym[i]]++;
-        hsh[0] = (uint32_t)nll; hsh[1] = (uint32_t)nd; hsh[2] = (uint32_t)ns;
+        const uint64_t m = __ballot(tst[c2]);
+        tidx[c2] = (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1));
+        if (lane == 0) wsum[c2 * 4 + wv] = (uint32_t)__popcll(m);
     }
+    __syncthreads();
+    uint32_t ns = 0;
+    for (int k = 0; k < 8; k++) ns += wsum[k];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++)
+        if (tst[c2]) {
+            uint32_t base = 0;
+            for (uint32_t k = 0; k < (uint32_t)c2 * 4 + wv; k++) base += wsum[k];
+            sym[base + tidx[c2]] = (uint8_t)tsym[c2]; ext[base + tidx[c2]] = (uint8_t)text[c2];
+            atomicAdd(&clc[tsym[c2]], 1u);
+        }
     __syncthreads();
     int n_cl = d_build_lens(clc, 19, 7, cl_len, order, wt, parent, sh2, used_cl, tid, DS_THREADS);
     if (n_cl == 1) {
@@ -212,19 +242,44 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         __syncthreads();
     }
     d_assign(cl_len, 19, cl_code, first_s, used_cl, n_cl, tid, DS_THREADS);
-    if (tid != 0) return;
-    const int nll = (int)hsh[0], nd = (int)hsh[1], ns = (int)hsh[2];
     int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;
-    DBitW w; w.p = T->hdr; w.pos = 0; w.acc = 0; w.nb = 0;
-    dw_add(w, (uint32_t)(nll - 257), 5); dw_add(w, (uint32_t)(nd - 1), 5); dw_add(w, (uint32_t)(ncl - 4), 4);
-    for (int i = 0; i < ncl; i++) dw_add(w, cl_len[D_CL_ORDER[i]], 3);
-    for (int i = 0; i < ns; i++) {
-        dw_add(w, cl_code[sym[i]] & 0xFFFF, cl_code[sym[i]] >> 16);
-        if (sym[i] == 17) dw_add(w, ext[i], 3);
-        if (sym[i] == 18) dw_add(w, ext[i], 7);
+    // bit lengths of the tokens -> positions (two packed scans of 256) -> ORed into the header image in LDS
+    auto put_bits = [&](uint32_t pos, uint32_t v, uint32_t nb2) {       // nb2 <= 14: at most two words
+        if (!nb2) return;
+        const uint32_t w2 = pos >> 5, sh = pos & 31;
+        atomicOr(&hbuf[w2], v << sh);
+        if (sh + nb2 > 32) atomicOr(&hbuf[w2 + 1], v >> (32 - sh));
+    };
+    uint32_t tl[2] = {0, 0}, tv[2] = {0, 0}, tp[2] = {0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+        const uint32_t k = (uint32_t)c2 * DS_THREADS + tid;
+        if (k < ns) {
+            const uint32_t sy = sym[k], cc = cl_code[sy], cl = cc >> 16, eb = sy == 17 ? 3u : (sy == 18 ? 7u : 0u);
+            tl[c2] = cl + eb; tv[c2] = (cc & 0xFFFF) | ((uint32_t)ext[k] << cl);
+        }
+        uint32_t x = tl[c2];                                            // inclusive prefix over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)lane >= d) x += y; }
+        tp[c2] = x - tl[c2];
+        if (lane == 63) wsum2[c2 * 4 + wv] = x;
     }
-    T->hdr_bits = w.pos * 8 + w.nb;
-    if (w.nb) T->hdr[w.pos] = (uint8_t)w.acc;
+    __syncthreads();
+    const uint32_t hbits = 14 + 3 * (uint32_t)ncl;
+    uint32_t total = hbits;
+    for (int k = 0; k < 8; k++) total += wsum2[k];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++)
+        if (tl[c2]) {
+            uint32_t base = hbits;
+            for (uint32_t k = 0; k < (uint32_t)c2 * 4 + wv; k++) base += wsum2[k];
+            put_bits(base + tp[c2], tv[c2], tl[c2]);
+        }
+    if (tid == 0) { put_bits(0, nll - 257, 5); put_bits(5, nd - 1, 5); put_bits(10, (uint32_t)(ncl - 4), 4); T->hdr_bits = total; }
+    if (tid < (uint32_t)ncl) put_bits(14 + 3 * tid, cl_len[D_CL_ORDER[tid]], 3);
+    __syncthreads();
+    for (uint32_t i = tid; i < 100; i += DS_THREADS) ((uint32_t *)T->hdr)[i] = hbuf[i];
 }
 
 // ------------------------------------------------------------------ Adler-32 halves of one block's input
