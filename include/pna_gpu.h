@@ -142,6 +142,22 @@ int  pna_gpu_create_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, si
                                        const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                        const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *entry_off,
                                        uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
+/* Per-entry metadata: chunks the host has ALREADY framed (length | type | data | CRC-32) and that NormalEntry::write_chunks_to places
+ * around fSIZ (lib/src/entry.rs:895-911): `extra[i]` between FHED and fSIZ (user-defined chunks), `facets[i]` between fSIZ and PHSF / FDAT
+ * (cTIM mTIM aTIM fPRM fUId fGId fONm fGNm xATR ...: try_for_each_metadata_facet, lib/src/entry.rs:124-180) -- what `pna create
+ * --keep-timestamp --keep-permission --keep-xattr` adds.  NULL arrays or zero lengths mean none.  Every blob is checked (chunk lengths,
+ * CRCs, none of the chunk types this library writes itself): PNA_E_INVAL otherwise.  The caller's bound grows by the blobs' lengths. */
+typedef struct {
+    const void *const *extra;  const size_t *extra_len;
+    const void *const *facets; const size_t *facets_len;
+} pna_gpu_entry_meta;
+int  pna_gpu_create_archive_meta_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                        const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                        const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, void *d_dst, size_t dst_cap,
+                                        uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
+int  pna_gpu_create_archive_meta_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                      const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                      const pna_gpu_entry_meta *meta, pna_sink_fn sink, void *user);
 /* pna_gpu_create_archive_host (bounded in-flight window from host memory) with the cipher stage. */
 int  pna_gpu_create_archive_enc_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                      const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,

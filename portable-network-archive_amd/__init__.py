@@ -58,6 +58,12 @@ class CipherStruct(ctypes.Structure):
                 ("phsf", ctypes.c_char_p), ("ivs", ctypes.c_void_p), ("gcm_segment_size", ctypes.c_uint32)]
 
 
+class MetaStruct(ctypes.Structure):
+    """pna_gpu_entry_meta (include/pna_gpu.h)."""
+    _fields_ = [("extra", ctypes.POINTER(ctypes.c_void_p)), ("extra_len", ctypes.POINTER(ctypes.c_size_t)),
+                ("facets", ctypes.POINTER(ctypes.c_void_p)), ("facets_len", ctypes.POINTER(ctypes.c_size_t))]
+
+
 class Cipher:
     """What WriteCipher carries (lib/src/entry/write.rs:54-57): algorithm, mode, the derived key, the PHSF string; plus the
     per-entry IVs (None = drawn by the library like random::random_vec)."""
@@ -100,7 +106,8 @@ EXPORTS = [
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
     "pna_gpu_create_solid_archive_enc_device", "pna_gpu_extract_archive_host", "pna_gpu_zstd_stream_frames_device",
-    "pna_gpu_zstd_decompress_open_device", "pna_gpu_inflate_open_device",
+    "pna_gpu_zstd_decompress_open_device", "pna_gpu_inflate_open_device", "pna_gpu_create_archive_meta_device",
+    "pna_gpu_create_archive_meta_host",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -211,6 +218,9 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_enc_host.restype = ctypes.c_int
     L.pna_gpu_create_archive_enc_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                                   ctypes.POINTER(sz), ctypes.POINTER(CipherStruct), SINK_FN, vp]
+    L.pna_gpu_create_archive_meta_host.restype = ctypes.c_int
+    L.pna_gpu_create_archive_meta_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                                   ctypes.POINTER(sz), ctypes.POINTER(CipherStruct), ctypes.POINTER(MetaStruct), SINK_FN, vp]
     L.pna_gpu_extract_archive_host.restype = ctypes.c_int
     L.pna_gpu_extract_archive_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.c_char_p, sz, ENTRY_FN, vp]
     L.pna_kdf_pbkdf2_sha256.restype = ctypes.c_int
@@ -657,4 +667,41 @@ def join_parts(parts: Sequence[bytes]) -> bytes:
     rc = load_library().pna_join_parts(a, l, n, cb, None)
     if rc:
         raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return bytes(out)
+
+
+def create_archive_with_metadata(ctx: Context, names: Sequence[str], entries: Sequence[bytes], facets: Optional[Sequence[bytes]] = None,
+                                 extra: Optional[Sequence[bytes]] = None, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT,
+                                 cipher: Optional[Cipher] = None) -> bytes:
+    """`pna create --keep-timestamp --keep-permission ...` (pna_gpu_create_archive_meta_host): facets[i] / extra[i] are chunks the
+    caller has already framed (length | type | data | crc); they land around fSIZ exactly where NormalEntry::write_chunks_to puts them."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend((ctypes.c_char * k).from_address(buf))
+        return 0
+    cb = SINK_FN(_sink)
+    bufs = [e if isinstance(e, bytes) else bytes(e) for e in entries]
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
+    ms = MetaStruct()
+    keep = []
+    for field, blobs in (("extra", extra), ("facets", facets)):
+        if blobs is None:
+            continue
+        bb = [bytes(b) for b in blobs]
+        keep.append(bb)
+        arr = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) if b else None for b in bb])
+        lens = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bb])
+        keep += [arr, lens]
+        setattr(ms, field, ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)))
+        setattr(ms, field + "_len", ctypes.cast(lens, ctypes.POINTER(ctypes.c_size_t)))
+    cs = cipher.struct(n) if cipher is not None else None
+    rc = L.pna_gpu_create_archive_meta_host(ctx._h, algo, level, n, a_names, a_src, a_len, ctypes.byref(cs) if cs is not None else None,
+                                            ctypes.byref(ms), cb, None)
+    if rc:
+        raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
     return bytes(out)

@@ -439,7 +439,38 @@ constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR
 
 // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry; cipher + ivs (16 bytes per
 // global entry index): the payloads are encrypted in place before their CRC-32 is taken
-struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; };
+struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; const pna_gpu_entry_meta *meta = nullptr; };
+static size_t meta_len(const pna_gpu_entry_meta *m, size_t e) {
+    if (!m) return 0;
+    return (m->extra && m->extra_len ? m->extra_len[e] : 0) + (m->facets && m->facets_len ? m->facets_len[e] : 0);
+}
+// a blob of already framed chunks: lengths consistent, CRCs right, none of the chunk types this library writes itself
+static bool meta_blob_ok(const uint8_t *p, size_t n) {
+    size_t pos = 0;
+    while (pos < n) {
+        if (n - pos < 12) return false;
+        const uint32_t dl = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+        if (n - pos - 12 < dl) return false;
+        const uint8_t *ty = p + pos + 4;
+        for (const char *own : {"FHED", "FDAT", "FEND", "fSIZ", "PHSF", "SHED", "SDAT", "SEND", "AHED", "AEND", "ANXT"}) if (memcmp(ty, own, 4) == 0) return false;
+        const uint8_t *cp = p + pos + 8 + dl;
+        if (pna_crc32(0, ty, 4 + (size_t)dl) != (((uint32_t)cp[0] << 24) | ((uint32_t)cp[1] << 16) | ((uint32_t)cp[2] << 8) | cp[3])) return false;
+        pos += 12 + (size_t)dl;
+    }
+    return true;
+}
+// prefix = FHED | fSIZ | rest  ->  FHED | extra | fSIZ | facets | rest   (NormalEntry::write_chunks_to, lib/src/entry.rs:895-911)
+static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, size_t e) {
+    if (!meta_len(m, e)) return;
+    const size_t c0 = 12 + ((size_t)pre[0] << 24 | (size_t)pre[1] << 16 | (size_t)pre[2] << 8 | pre[3]);
+    const size_t c1 = 12 + ((size_t)pre[c0] << 24 | (size_t)pre[c0 + 1] << 16 | (size_t)pre[c0 + 2] << 8 | pre[c0 + 3]);
+    std::vector<uint8_t> out(pre.begin(), pre.begin() + c0);
+    if (m->extra && m->extra_len && m->extra_len[e]) out.insert(out.end(), (const uint8_t *)m->extra[e], (const uint8_t *)m->extra[e] + m->extra_len[e]);
+    out.insert(out.end(), pre.begin() + c0, pre.begin() + c0 + c1);
+    if (m->facets && m->facets_len && m->facets_len[e]) out.insert(out.end(), (const uint8_t *)m->facets[e], (const uint8_t *)m->facets[e] + m->facets_len[e]);
+    out.insert(out.end(), pre.begin() + c0 + c1, pre.end());
+    pre.swap(out);
+}
 
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
@@ -533,7 +564,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     } else if (fj) {
         std::vector<uint8_t> tmp;
         size_t bound = 0;
-        for (size_t e = e0; e < e1; e++) bound += fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e]);
+        for (size_t e = e0; e < e1; e++) bound += (fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e])) + meta_len(fj->meta, e);
         // (a payload beyond the FDAT limit is cut into several FDAT chunks at segment boundaries: room for one more descriptor and
         // 8 more prefix bytes per segment)
         if (c->h_desc.ensure(((e1 - e0) + nseg) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * (size_t)nseg + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
@@ -555,7 +586,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 });
             for (auto &x : th) x.join();
         }
-        if (!fj->cipher) {
+        if (!fj->cipher && !fj->meta) {
             // plain entries: the prefixes are written straight into the staging blob; with many entries several threads share them
             // (each thread fills the slots of its range at the bound offsets, a compaction pass closes the gaps)
             const size_t ne = e1 - e0;
@@ -573,7 +604,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (size_t e = e0; e < e1; e++) {
             tmp.clear();
             if (gcm) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, PNA_MODE_GCM, fj->cipher->phsf, gmat[e - e0].header, 75);
-            else frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e, 16);
+            else if (fj->cipher) frame_entry_prefix_enc(tmp, fj->names[e], algo, src_len[e], fj->cipher->encryption, fj->cipher->cipher_mode, fj->cipher->phsf, fj->ivs + 16 * e, 16);
+            else frame_entry_prefix(tmp, fj->names[e], algo, src_len[e], 0);
+            splice_meta(tmp, fj->meta, e);
             memcpy(blob + blob_len, tmp.data(), tmp.size());
             fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
             blob_len += tmp.size();
@@ -823,6 +856,27 @@ extern "C" int pna_gpu_create_archive_enc_device(pna_gpu_ctx *c, int algo, int l
                                                  const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                                  const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *entry_off,
                                                  uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
+    return pna_gpu_create_archive_meta_device(c, algo, level, n, names, d_src, src_off, src_len, cipher, nullptr, d_dst, dst_cap, entry_off, archive_len,
+                                              part_flags, hip_stream);
+}
+
+static int check_meta(pna_gpu_ctx *c, const pna_gpu_entry_meta *meta, size_t n) {
+    if (!meta) return PNA_OK;
+    if ((meta->extra && !meta->extra_len) || (meta->facets && !meta->facets_len)) return fail(c, PNA_E_INVAL, "metadata blobs without lengths");
+    for (size_t e = 0; e < n; e++) {
+        if (meta->extra && meta->extra_len[e] && (!meta->extra[e] || !meta_blob_ok((const uint8_t *)meta->extra[e], meta->extra_len[e]))) return fail(c, PNA_E_INVAL, "extra chunks of an entry are not well-formed chunks");
+        if (meta->facets && meta->facets_len[e] && (!meta->facets[e] || !meta_blob_ok((const uint8_t *)meta->facets[e], meta->facets_len[e]))) return fail(c, PNA_E_INVAL, "metadata chunks of an entry are not well-formed chunks");
+    }
+    return PNA_OK;
+}
+
+// ... and with per-entry metadata: chunks the host has already framed (timestamps, permissions, owner, xattr: try_for_each_metadata_facet,
+// lib/src/entry.rs:124-180; user-defined extra chunks) are placed where NormalEntry::write_chunks_to puts them.
+extern "C" int pna_gpu_create_archive_meta_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                  const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                  const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, void *d_dst, size_t dst_cap,
+                                                  uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
+    { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
@@ -841,7 +895,7 @@ extern "C" int pna_gpu_create_archive_enc_device(pna_gpu_ctx *c, int algo, int l
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    FrameJob fj{names, 0, cipher, ivs};
+    FrameJob fj{names, 0, cipher, ivs, meta};
     size_t e = 0;
     while (e < n) {
         size_t e1 = e, blocks = 0;
@@ -1053,6 +1107,13 @@ extern "C" int pna_gpu_create_archive_host(pna_gpu_ctx *c, int algo, int level, 
 extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                                pna_sink_fn sink, void *user) {
+    return pna_gpu_create_archive_meta_host(c, algo, level, n, names, src, src_len, cipher, nullptr, sink, user);
+}
+
+extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                                const pna_gpu_entry_meta *meta, pna_sink_fn sink, void *user) {
+    { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     c->call_flags = level_flags(c, algo, level);
@@ -1082,7 +1143,7 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
             const size_t nb = (size_t)((l + BLK_SIZE - 1) / BLK_SIZE);
             if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
             off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
-            sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + pna_gpu_bound(algo, (size_t)l) + 16;
+            sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
             sb.e1++;
         }
         sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
@@ -1090,7 +1151,7 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (const char *e = getenv("PNA_STAGE_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 64) threads = (unsigned)t; }
-    FrameJob fj{names, 0, cipher, ivs};
+    FrameJob fj{names, 0, cipher, ivs, meta};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
     for (size_t e = 0; e < n; e++) in_total += src_len[e];

@@ -813,3 +813,39 @@ def test_extract_driver_windows(gpu_ctx, pna, pf, codec):
         finally:
             os.environ.pop("PNA_EXTRACT_WIN_MIB", None)
         assert [(n, d) for n, _, d in got] == want, win
+
+
+def test_archive_with_metadata_chunks(gpu_ctx, pna, pf, codec):
+    """Per-entry metadata (what --keep-timestamp / --keep-permission / --keep-xattr add: try_for_each_metadata_facet, lib/src/entry.rs:124-180)
+    and user-defined extra chunks go through the device path as blobs of framed chunks; wire order FHED, extra*, fSIZ, facets*, FDAT, FEND
+    (lib/src/entry.rs:895-911).  Byte-exact against the oracle's writer; the extract driver skips the ancillary chunks."""
+    import struct
+    ents = [codec.corpus_file(0, 1100 + i, n) for i, n in enumerate([300000, 5, 0, 70001, 9000])]
+    names = [f"meta/{i}.txt" for i in range(len(ents))]
+    fac, ext = [], []
+    for i in range(len(ents)):
+        f = [(b"cTIM", struct.pack(">Q", 1700000000 + i)), (b"mTIM", struct.pack(">Q", 1700000100 + i)), (b"fPRM", b"\x00\x00\x03\xe8\x04user\x00\x00\x03\xe8\x05group\x01\xa4")]
+        fac.append(f if i != 2 else [])                               # one entry without facets
+        ext.append([(b"abCd", bytes([i, 7, 7]))] if i % 2 else [])    # a private ancillary chunk on every other entry
+    blob = lambda chunks: b"".join(pf.write_chunk(t, d) for t, d in chunks)
+    arc = pna.create_archive_with_metadata(gpu_ctx, names, ents, facets=[blob(f) for f in fac], extra=[blob(x) for x in ext])
+    payloads = gpu_ctx.compress_batch(ents)
+    want = pf.write_archive_header() + b"".join(
+        pf.write_normal_entry(pf.file_entry_header(2, nm), [pl], len(e), extra=x, facets=f) for nm, pl, e, x, f in zip(names, payloads, ents, ext, fac)
+    ) + pf.finalize_archive()
+    assert arc == want
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert [n for n, _, _ in got] == names and [d for _, _, d in got] == ents
+    # with the cipher stage: PHSF and the data chunks come behind the facets
+    key, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
+    ivs = os.urandom(16 * len(ents))
+    a2 = pna.create_archive_with_metadata(gpu_ctx, names, ents, facets=[blob(f) for f in fac], cipher=pna.Cipher(key, phsf, pna.MODE_CTR, ivs=ivs))
+    _, items = pf.read_archive(a2)
+    assert [[t for t, _ in it.chunks] for it in items][0] == [b"FHED", b"fSIZ", b"cTIM", b"mTIM", b"fPRM", b"PHSF", b"FDAT", b"FDAT", b"FEND"]
+    assert [d for _, _, d in pna.extract_archive(gpu_ctx, a2, b"password")] == ents
+    # malformed blobs are refused: a broken CRC, a chunk type the library writes itself
+    bad = bytearray(blob(fac[0])); bad[-1] ^= 1
+    for b in (bytes(bad), pf.write_chunk(b"FDAT", b"x")):
+        with pytest.raises(pna.PnaGpuError) as ei:
+            pna.create_archive_with_metadata(gpu_ctx, names, ents, facets=[b] * len(ents))
+        assert ei.value.code == -2
