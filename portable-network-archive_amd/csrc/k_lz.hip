@@ -10,9 +10,10 @@
 //         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
 //   per-wave records (end of the wave's last match; counts)
 // Per tile of 2048 positions (2 per lane):
-//   (next window chunk requested into registers) lookup -> B2 -> insert + match +
+//   (next window chunk requested into registers) lookup -> match (the tile's inserts wait until every wave has looked up: they
+//   go behind B3, so lookups and inserts need no barrier of their own) +
 //   REGION-LOCAL parse: every wave parses its own 128 positions greedily from max(its first position, the tile's carry)
-//   with scalar loops on ballot masks, and publishes the end of its last match -> B3 -> MERGE: the running end E of the
+//   with scalar loops on ballot masks, and publishes the end of its last match -> B3 -> inserts (ds_max_u32) -> MERGE: the running end E of the
 //   earlier waves' matches is a 16-lane prefix maximum (exact unless an end falls 1-2 bytes behind E: then a short serial
 //   scan); a wave entirely below E emits nothing, matches that end before E are dropped, the one straddling E is cut from
 //   the front (>= 3 bytes must remain),
@@ -95,7 +96,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// diagnostic build only (STAMP = true): wave 0 / lane 0 accumulates s_memtime deltas per phase
+// diagnostic build only (STAMP = true): lane 0 of every wave accumulates s_memtime deltas per phase (sums over the 16 waves)
 __device__ unsigned long long g_lz_stamps[8];
 
 template <bool STAMP>
@@ -120,8 +121,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 
     for (uint32_t i = tid; i < (1u << HASH_LOG); i += LZ_THREADS) table[i] = 0;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
-    if (STAMP && tid == 0) st_prev = __builtin_amdgcn_s_memtime();
-#define LZ_STAMP(k) do { if (STAMP && tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
+    if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
+#define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
 
     // initial window fill [0, TILE + LOOKAHEAD + 16); afterwards one TILE-sized chunk per tile: requested at the top of
     // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
@@ -184,14 +185,18 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 tag[r] = (h32 >> (32 - HASH_LOG - TAG_BITS)) & TAG_MASK;
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
+#ifdef LZ_WITH_B2
             __syncthreads();                                                        // B2
+#endif
             LZ_STAMP(1);
 
             // ---- insert + match
             uint32_t len[2], off[2], flen[2];
             uint64_t effm[2];
             auto do_match = [&](const int r) __attribute__((always_inline)) {
+#ifdef LZ_WITH_B2
                 if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+#endif
                 uint32_t l = 0, o = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS;
                 // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
@@ -269,6 +274,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             loaded_end += TILE;
             if (lane == 0) wend[wave] = el ? wbase + el : 0u;
             __syncthreads();                                                        // B3
+#ifndef LZ_WITH_B2
+            // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
+#pragma unroll
+            for (int r = 0; r < 2; r++) if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+#endif
             LZ_STAMP(3);
 
             // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E
@@ -397,7 +407,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
         } // tiles
         if (tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
     } // blocks
-    if (STAMP && tid == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
+    if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,

@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of k_lz (wave 0), on the GPU box."""
+"""Diagnostic: per-phase cycle shares of k_lz (mean over the 16 waves of a workgroup), on the GPU box."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,4 +15,4 @@ for it in range(2):
     st = ctx.lz_stamps(); tm = ctx.timing()
     tot = sum(st)
     names = ["load", "lookup->B2", "insert+match", "wait B3 (+publish)", "wait B4", "merge+masks (own work)", "emit", "parse loops+coverage (own work)"]
-    print("lz ms", round(tm.ms_lz, 3), "cycles/tile/WG", round(tot / (n * 512)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})
+    print("lz ms", round(tm.ms_lz, 3), "cycles/tile/WG", round(tot / (n * 512 * 16)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})
