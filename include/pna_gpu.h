@@ -240,13 +240,21 @@ int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t 
                                   pna_entry_fn cb, void *user);
 
 /* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
- * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write). */
+ * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write).
+ * THREADS: unlike the rest of this header, the stream functions may be called from any number of host threads on ONE context at
+ * the same time -- that is how the reference drives its encoders (one writer per rayon task, cli/src/command/core.rs:505-517).
+ * finish() is a group commit: concurrent finishes are collected into one device batch (the thread that finds no batch in flight
+ * leads it; finishes arriving meanwhile form the next batch) and every caller receives its own stream through its own sink on
+ * its own thread.  Each stream object belongs to one thread; do not mix stream calls with the context's other entry points without
+ * external synchronisation.  PNA_STREAM_LINGER_US (environment, default 0) makes a leader wait for stragglers before it submits. */
 typedef struct pna_gpu_stream pna_gpu_stream;
 int  pna_gpu_stream_new(pna_gpu_ctx *ctx, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out);
 int  pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len);
 int  pna_gpu_stream_flush(pna_gpu_stream *s);           /* no-op like the buffered encoders' flush        */
 int  pna_gpu_stream_finish(pna_gpu_stream *s);          /* consumes s                                      */
 void pna_gpu_stream_abort(pna_gpu_stream *s);           /* drop without output (failed builder is discarded) */
+/* device batches run / entries carried / largest batch so far on behalf of pna_gpu_stream_finish (any pointer may be NULL) */
+int  pna_gpu_stream_stats(pna_gpu_ctx *ctx, uint64_t *batches, uint64_t *entries, uint64_t *largest_batch);
 
 /* ---- solid mode: one logical stream, split into independent 1 MiB frames inside the kernels
  * (replaces the single serial encoder of SolidArchive, lib/src/archive/write.rs:443-470,575-580,716-727). */
@@ -279,6 +287,11 @@ int  pna_gpu_debug_lz_stamps(pna_gpu_ctx *ctx, unsigned long long *out8);
  * 1 random-text, 2 random bytes, 3 zeros, 4 repeated byte. */
 int  pna_bench_corpus_fill_device(pna_gpu_ctx *ctx, int kind, uint64_t first_file, uint64_t n_files,
                                   uint64_t file_len, uint64_t stride, void *d_dst, void *hip_stream);
+/* The reference's fan-out (one entry per task, FIFO, cli/src/command/core.rs:496-537) on `threads` host threads over the streaming
+ * facade: stream_new / one write of the whole entry / finish into a counting sink.  Returns seconds; *out_bytes = compressed bytes
+ * the sinks received, *rc = first error. */
+double pna_bench_stream_threads(pna_gpu_ctx *ctx, int algo, int level, unsigned threads, size_t n, const void *const *src,
+                                const size_t *src_len, uint64_t *out_bytes, int *rc);
 
 #ifdef __cplusplus
 }

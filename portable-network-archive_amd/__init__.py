@@ -107,7 +107,7 @@ EXPORTS = [
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
     "pna_gpu_create_solid_archive_enc_device", "pna_gpu_extract_archive_host", "pna_gpu_zstd_stream_frames_device",
     "pna_gpu_zstd_decompress_open_device", "pna_gpu_inflate_open_device", "pna_gpu_create_archive_meta_device",
-    "pna_gpu_create_archive_meta_host",
+    "pna_gpu_create_archive_meta_host", "pna_gpu_stream_stats", "pna_bench_stream_threads",
     # include/pna_archive.h
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
@@ -185,6 +185,11 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_stream_finish.argtypes = [vp]
     L.pna_gpu_stream_abort.restype = None
     L.pna_gpu_stream_abort.argtypes = [vp]
+    L.pna_gpu_stream_stats.restype = ctypes.c_int
+    L.pna_gpu_stream_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.pna_bench_stream_threads.restype = ctypes.c_double
+    L.pna_bench_stream_threads.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
+                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
     L.pna_gpu_compress_solid.restype = ctypes.c_int
     L.pna_gpu_compress_solid.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, SINK_FN, vp]
     L.pna_gpu_last_timing.restype = ctypes.c_int
@@ -422,7 +427,25 @@ class Context:
 
     # ---- streaming facade
     def writer(self, sink, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT) -> "CompressionWriter":
+        """One writer per entry; writers of one context may be driven from many threads at once (their finishes are batched)."""
         return CompressionWriter(self, sink, algo, level)
+
+    def stream_stats(self):
+        """(device batches, entries, largest batch) run so far on behalf of CompressionWriter.try_into_inner()."""
+        b, e, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._L.pna_gpu_stream_stats(self._h, ctypes.byref(b), ctypes.byref(e), ctypes.byref(m)))
+        return b.value, e.value, m.value
+
+    def bench_stream_threads(self, entries: Sequence[bytes], threads: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT):
+        """The reference's one-entry-per-task fan-out on `threads` native host threads over the streaming facade; (seconds, compressed bytes)."""
+        n = len(entries)
+        keep = [ctypes.create_string_buffer(e, len(e)) for e in entries]
+        src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(k, ctypes.c_void_p) for k in keep])
+        sl = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
+        out, rc = ctypes.c_uint64(), ctypes.c_int()
+        secs = self._L.pna_bench_stream_threads(self._h, algo, level, threads, n, src, sl, ctypes.byref(out), ctypes.byref(rc))
+        self._check(rc.value)
+        return secs, out.value
 
     def compress_solid(self, data: bytes, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT) -> List[bytes]:
         """SolidArchive payload: returns the pieces pushed to the sink (one SDAT chunk each in the reference)."""

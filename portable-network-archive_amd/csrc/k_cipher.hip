@@ -346,8 +346,8 @@ void launch_aes_cbc_dec(const CipherUnit *units, uint32_t n, const uint8_t *ivs,
 }
 
 void launch_aes_ctr(const CipherUnit *units, uint32_t n, const uint8_t *ivs, const AesTabs *tabs, uint8_t *buf, const AesKey &key, const AesKey *keys, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_aes_ctr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTR_LDS); attr_set = true; }
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_aes_ctr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTR_LDS);   // once, thread-safe
+    (void)attr_set;
     // one workgroup per CU at a time (128 KiB of LDS); a few per CU in the grid even out the ragged units
     if (n) hipLaunchKernelGGL(k_aes_ctr, dim3(n < 1024 ? n : 1024), dim3(CTR_THREADS), CTR_LDS, st, units, n, ivs, tabs, buf, key, keys);
 }

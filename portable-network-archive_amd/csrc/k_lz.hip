@@ -412,12 +412,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
         (void)hipFuncSetAttribute((const void *)k_lz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        (void)hipFuncSetAttribute((const void *)k_lz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        attr_set = true;
-    }
+        return hipFuncSetAttribute((const void *)k_lz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+    }();
+    (void)attr_set;
     if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
     else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
 }

@@ -288,18 +288,21 @@ struct Sha256 {
         memcpy(h, iv, sizeof iv); len = 0; fill = 0;
     }
     void block(const uint8_t *p) {
-        static uint32_t K[64]; static bool kr = false;
-        if (!kr) {                                             // K[i] = frac(cbrt(prime_i)) * 2^32, by integer cube root of prime << 96
-            int cnt = 0;
+        struct KTab { uint32_t v[64]; };
+        // K[i] = frac(cbrt(prime_i)) * 2^32, by integer cube root of prime << 96; built once (C++11 static: safe when several host
+        // threads hash at the same time, as the per-entry GCM key derivation does)
+        static const KTab KT = [] {
+            KTab t; int cnt = 0;
             for (uint32_t c = 2; cnt < 64; c++) {
                 bool pr = true; for (uint32_t d = 2; d * d <= c; d++) if (c % d == 0) { pr = false; break; }
                 if (!pr) continue;
                 unsigned __int128 target = (unsigned __int128)c << 96, lo = 0, hi = (unsigned __int128)1 << 36;
                 while (hi - lo > 1) { unsigned __int128 mid = (lo + hi) / 2; if (mid * mid * mid <= target) lo = mid; else hi = mid; }
-                K[cnt++] = (uint32_t)lo;
+                t.v[cnt++] = (uint32_t)lo;
             }
-            kr = true;
-        }
+            return t;
+        }();
+        const uint32_t *K = KT.v;
         uint32_t w[64], a[8];
         for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
         for (int i = 16; i < 64; i++) w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));

@@ -11,6 +11,11 @@
 #include <vector>
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <chrono>
+#include <new>
 #include <sys/random.h>
 #include "pna_dev.h"
 #include "../../include/pna_gpu.h"
@@ -103,6 +108,7 @@ struct PinBuf {                                  // page-locked host staging: as
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+struct pna_gpu_stream;
 struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
@@ -135,6 +141,13 @@ struct pna_gpu_ctx {
     pna_gpu_timing timing = {};
     uint32_t last_nblk = 0;
     size_t max_blocks = 1u << 17;          // blocks per sub-batch (16 GiB of input)
+    // group commit of the streaming facade (pna_gpu_stream_finish from many host threads -> one device batch)
+    std::mutex comb_mu, run_mu;            // comb_mu: queue + leader flag; run_mu: the device batch itself and ctx->err
+    std::condition_variable comb_cv;
+    std::vector<pna_gpu_stream *> comb_queue;
+    bool comb_leader = false;
+    uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0;
+    uint32_t comb_linger_us = 0;           // PNA_STREAM_LINGER_US: the leader waits this long for more finishes before it submits
 };
 
 static int fail(pna_gpu_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -169,6 +182,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->device = device_id;
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
+    if (const char *lg = getenv("PNA_STREAM_LINGER_US")) c->comb_linger_us = (uint32_t)std::min<unsigned long>(strtoul(lg, nullptr, 10), 100000ul);
     if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0xF00u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
     c->call_flags = c->flags;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
@@ -266,8 +280,7 @@ static int ensure_crc(pna_gpu_ctx *c) {
 // Host walk through k_frame's CRC schedule with the same tables (lane states, Z_16320 between tiles, fold tree): lets the
 // CPU-only test suite check the algebra and the table construction against pna_crc32 without a GPU.  Not a product path.
 extern "C" uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len) {
-    static CrcTabs t; static bool ready = false;
-    if (!ready) { build_crc_tabs(t); ready = true; }
+    static const CrcTabs t = [] { CrcTabs x; build_crc_tabs(x); return x; }();      // initialised once, thread-safe (C++11 static)
     const uint8_t *pl = (const uint8_t *)payload;
     const uint64_t n = 4 + (uint64_t)len, ntile = (n + 16383) / 16384, pad = ntile * 16384 - n;
     static const uint8_t ty[4] = {0x46 ^ 0xFF, 0x44 ^ 0xFF, 0x41 ^ 0xFF, 0x54 ^ 0xFF};
@@ -376,8 +389,7 @@ static int check_cipher(pna_gpu_ctx *c, const pna_gpu_cipher *ci) {
 }
 // one AES-256 block on the host (FIPS-197 with the round tables of the kernels): hash subkey and E(K, J0) of a GCM segment
 static void aes256_block_host(const AesKey &k, const uint8_t in[16], uint8_t out[16]) {
-    static AesTabs T; static bool ready = false;
-    if (!ready) { build_aes_tabs(T); ready = true; }
+    static const AesTabs T = [] { AesTabs x; build_aes_tabs(x); return x; }();      // called from several host threads: C++11 static initialisation is thread-safe
     uint32_t s[4], t[4];
     for (int i = 0; i < 4; i++) s[i] = ((uint32_t)in[4 * i] | ((uint32_t)in[4 * i + 1] << 8) | ((uint32_t)in[4 * i + 2] << 16) | ((uint32_t)in[4 * i + 3] << 24)) ^ k.rk[i];
     for (int r = 1; r < 14; r++) {
@@ -2003,37 +2015,118 @@ extern "C" int pna_gpu_decompress_batch(pna_gpu_ctx *c, int algo, size_t n, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The seam is used the way the reference uses its encoders: one writer per rayon task, many tasks in flight on many host threads
+// (cli/src/command/core.rs:505-517).  One entry per device batch would leave the GPU idle, so finish() is a GROUP COMMIT: the
+// stream joins the context's queue; the first thread to find no leader becomes the leader, takes everything queued so far, runs
+// ONE pna_gpu_compress_batch for it and wakes the owners, each of which drains its own stream into its own sink on its own thread
+// (W::write is never called from a foreign thread).  While a batch runs, the finishes that arrive pile up and form the next,
+// larger batch -- no timer needed under load (PNA_STREAM_LINGER_US adds an optional wait for stragglers).
 struct pna_gpu_stream {
     pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user; std::vector<uint8_t> buf;
+    std::vector<uint8_t> out; size_t out_len = 0; int rc = PNA_OK; bool done = false;
 };
 
 extern "C" int pna_gpu_stream_new(pna_gpu_ctx *c, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out) {
     if (!c || !sink || !out) return PNA_E_INVAL;
-    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented");
-    *out = new pna_gpu_stream{c, algo, level, sink, user, {}};
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return PNA_E_UNSUPPORTED;   // no fail(): other threads may be inside the context
+    pna_gpu_stream *s = new (std::nothrow) pna_gpu_stream();
+    if (!s) return PNA_E_NOMEM;
+    s->ctx = c; s->algo = algo; s->level = level; s->sink = sink; s->user = user;
+    *out = s;
     return PNA_OK;
 }
 extern "C" int pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len) {
     if (!s || (!buf && len)) return PNA_E_INVAL;
-    s->buf.insert(s->buf.end(), (const uint8_t *)buf, (const uint8_t *)buf + len);
+    try { s->buf.insert(s->buf.end(), (const uint8_t *)buf, (const uint8_t *)buf + len); } catch (const std::bad_alloc &) { return PNA_E_NOMEM; }
     return PNA_OK;
 }
 extern "C" int pna_gpu_stream_flush(pna_gpu_stream *s) { return s ? PNA_OK : PNA_E_INVAL; }
 extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { delete s; }
+
+// one device batch per (algo, level) group of the streams the leader took
+static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch) {
+    std::lock_guard<std::mutex> run(c->run_mu);
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); i++) {
+        if (taken[i]) continue;
+        std::vector<pna_gpu_stream *> grp;
+        for (size_t j = i; j < batch.size(); j++)
+            if (!taken[j] && batch[j]->algo == batch[i]->algo && batch[j]->level == batch[i]->level) { taken[j] = 1; grp.push_back(batch[j]); }
+        const size_t n = grp.size();
+        std::vector<const void *> src(n); std::vector<size_t> sl(n), cap(n), dl(n, 0); std::vector<void *> dst(n);
+        for (size_t k = 0; k < n; k++) { src[k] = grp[k]->buf.data(); sl[k] = grp[k]->buf.size(); dst[k] = grp[k]->out.data(); cap[k] = grp[k]->out.size(); }
+        const int rc = pna_gpu_compress_batch(c, grp[0]->algo, grp[0]->level, n, src.data(), sl.data(), dst.data(), cap.data(), dl.data());
+        for (size_t k = 0; k < n; k++) { grp[k]->rc = rc; grp[k]->out_len = rc == PNA_OK ? dl[k] : 0; }
+    }
+}
+
 extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
     if (!s) return PNA_E_INVAL;
-    std::vector<uint8_t> out(pna_gpu_bound(s->algo, s->buf.size()));
-    const void *src = s->buf.data(); size_t sl = s->buf.size(); void *dst = out.data(); size_t cap = out.size(), dl = 0;
-    int rc = pna_gpu_compress_batch(s->ctx, s->algo, s->level, 1, &src, &sl, &dst, &cap, &dl);
+    pna_gpu_ctx *c = s->ctx;
+    try { s->out.resize(pna_gpu_bound(s->algo, s->buf.size())); } catch (const std::bad_alloc &) { delete s; return PNA_E_NOMEM; }
+    {
+        std::unique_lock<std::mutex> lk(c->comb_mu);
+        c->comb_queue.push_back(s);
+        while (!s->done) {
+            if (c->comb_leader) { c->comb_cv.wait(lk); continue; }
+            c->comb_leader = true;                                   // s is still queued, so the batch taken below contains it
+            if (c->comb_linger_us) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(c->comb_linger_us)); lk.lock(); }
+            std::vector<pna_gpu_stream *> batch; batch.swap(c->comb_queue);
+            lk.unlock();
+            stream_run_batch(c, batch);
+            lk.lock();
+            for (pna_gpu_stream *x : batch) x->done = true;          // owners may free their streams as soon as the lock is released
+            c->comb_leader = false; c->comb_batches++; c->comb_entries += batch.size(); c->comb_max = std::max<uint64_t>(c->comb_max, batch.size());
+            c->comb_cv.notify_all();
+        }
+    }
+    int rc = s->rc;
     if (rc == PNA_OK) {
         // the reference's zstd writer drains in bursts of at most 32 KiB (zio::Writer); keep that shape
-        for (size_t p = 0; p < dl && rc == PNA_OK; p += 32768) {
-            size_t k = std::min<size_t>(32768, dl - p);
-            if (s->sink(s->user, out.data() + p, k) != 0) rc = fail(s->ctx, PNA_E_SINK, "sink failed");
+        for (size_t p = 0; p < s->out_len && rc == PNA_OK; p += 32768) {
+            const size_t k = std::min<size_t>(32768, s->out_len - p);
+            if (s->sink(s->user, s->out.data() + p, k) != 0) { std::lock_guard<std::mutex> run(c->run_mu); rc = fail(c, PNA_E_SINK, "sink failed"); }
         }
     }
     delete s;
     return rc;
+}
+extern "C" int pna_gpu_stream_stats(pna_gpu_ctx *c, uint64_t *batches, uint64_t *entries, uint64_t *largest_batch) {
+    if (!c) return PNA_E_INVAL;
+    std::lock_guard<std::mutex> lk(c->comb_mu);
+    if (batches) *batches = c->comb_batches;
+    if (entries) *entries = c->comb_entries;
+    if (largest_batch) *largest_batch = c->comb_max;
+    return PNA_OK;
+}
+
+// Benchmark support: the reference's fan-out restated on host threads (cli/src/command/core.rs:496-537) over the streaming facade --
+// `threads` workers take entries FIFO, each entry = stream_new / write (whole entry in one call, core.rs:900-902) / finish into a
+// counting sink.  Returns the seconds spent; *out_bytes = compressed bytes seen by the sinks.
+static int counting_sink(void *user, const void *, size_t len) { ((std::atomic<uint64_t> *)user)->fetch_add(len, std::memory_order_relaxed); return 0; }
+extern "C" double pna_bench_stream_threads(pna_gpu_ctx *c, int algo, int level, unsigned threads, size_t n, const void *const *src,
+                                           const size_t *src_len, uint64_t *out_bytes, int *rc_out) {
+    if (!c || !threads || (n && (!src || !src_len))) { if (rc_out) *rc_out = PNA_E_INVAL; return 0.0; }
+    std::atomic<size_t> next{0}; std::atomic<uint64_t> total{0}; std::atomic<int> rc_all{PNA_OK};
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                pna_gpu_stream *s = nullptr;
+                int rc = pna_gpu_stream_new(c, algo, level, counting_sink, &total, &s);
+                if (rc == PNA_OK) { rc = pna_gpu_stream_write(s, src[i], src_len[i]); if (rc != PNA_OK) pna_gpu_stream_abort(s); }
+                if (rc == PNA_OK) rc = pna_gpu_stream_finish(s);
+                if (rc != PNA_OK) { rc_all.store(rc); break; }
+            }
+        });
+    for (auto &x : th) x.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out_bytes) *out_bytes = total.load();
+    if (rc_out) *rc_out = rc_all.load();
+    return secs;
 }
 
 extern "C" int pna_gpu_compress_solid(pna_gpu_ctx *c, int algo, int level, const void *src, size_t src_len,

@@ -117,6 +117,55 @@ def test_compression_writer_facade(gpu_ctx, pna, codec):
     assert b"".join(sink.parts) == codec.model_compress(d, _params(codec))
 
 
+def test_compression_writers_on_many_threads_are_batched(pna, codec):
+    """The seam as the reference drives it (one writer per task, many tasks in flight, cli/src/command/core.rs:505-517): writers of ONE
+    context finished from 24 threads at once.  Every sink receives exactly its own entry's stream (== the oracle's encoder), in order and
+    on its own thread; the finishes were carried by fewer device batches than there are entries (group commit)."""
+    import threading
+    import torch  # noqa: F401
+    ctx = pna.Context(0)
+    try:
+        sizes = [0, 1, 777, 4096, 65536, 200000, 300001, 1 << 20]
+        n_threads, per = 24, 4
+        data = {(t, k): codec.corpus_file(1 if (t + k) % 3 == 0 else 0, 1000 + 7 * t + k, sizes[(3 * t + k) % len(sizes)]) for t in range(n_threads) for k in range(per)}
+        algo = {(t, k): pna.ALGO_DEFLATE if (t + k) % 5 == 0 else pna.ALGO_ZSTD for (t, k) in data}
+        got, errs = {}, []
+        start = threading.Barrier(n_threads)
+
+        class Sink:
+            def __init__(self): self.parts, self.tids = [], set()
+            def write(self, b): self.parts.append(bytes(b)); self.tids.add(threading.get_ident())
+
+        def worker(t):
+            try:
+                start.wait()
+                for k in range(per):
+                    w = ctx.writer(Sink(), algo=algo[(t, k)])
+                    d = data[(t, k)]
+                    for i in range(0, len(d), 99991):
+                        w.write(d[i:i + 99991])
+                    sink = w.try_into_inner()
+                    assert sink.tids <= {threading.get_ident()}            # W::write is never called from a foreign thread
+                    got[(t, k)] = b"".join(sink.parts)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        for x in th: x.start()
+        for x in th: x.join()
+        assert not errs, errs[:3]
+        p, dp = _params(codec), codec.deflate_default_params()
+        for key, d in data.items():
+            want = codec.deflate_model_compress(d, dp) if algo[key] == pna.ALGO_DEFLATE else codec.model_compress(d, p)
+            assert got[key] == want, key
+        batches, entries, largest = ctx.stream_stats()
+        assert entries == n_threads * per and batches < entries and largest > 1, (batches, entries, largest)
+        # the native fan-out used for the rate measurement gives the same total
+        secs, out_bytes = ctx.bench_stream_threads([data[k] for k in sorted(data) if algo[k] == pna.ALGO_ZSTD], threads=16)
+        assert out_bytes == sum(len(got[k]) for k in sorted(data) if algo[k] == pna.ALGO_ZSTD) and secs > 0
+    finally:
+        ctx.close()
+
+
 def test_create_archive_round_trip(gpu_ctx, pna, pf, codec):
     """cli/tests/cli/combination.rs style: create -> read back -> trees equal; order == argv order."""
     names, ents = [], []
