@@ -3,8 +3,10 @@
 //            Huffman code (<= 11 bits) + tree description and the three FSE tables + descriptions.
 //   k_lit    one workgroup per block: RLE test and 1- or 4-stream Huffman bit packing (one wave per stream,
 //            wave scan of bit lengths, 32-bit atomic OR into the zeroed body).
-//   k_seq    one LANE per block, the lanes of one segment sharing the segment's tables in LDS: the serial tANS
-//            state chain of the sequences bitstream.
+//   k_seqa   one LANE per block, the lanes of one segment sharing the segment's tables in LDS: the serial tANS
+//            state chain of the sequences bitstream -- states only: per sequence the three state flushes as one field.
+//   k_seqb   one workgroup per block: the sequences bitstream assembled token-parallel from those fields and the
+//            extra bits (prefix sums of the field lengths, 64-bit ORs into an LDS stage, coalesced stores).
 //   k_plan   one thread per segment: block types, which block carries the table descriptions, sizes.
 //   k_scan   exclusive scan of segment sizes -> output offsets.
 //   k_write  one workgroup per block: frame/block/section headers + payload into the packed output.
@@ -485,9 +487,106 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     if (tid == 0 && nstreams == 4) atomicOr(&out64[0], (unsigned long long)sz[0] | ((unsigned long long)sz[1] << 16) | ((unsigned long long)sz[2] << 32));
 }
 
-// ------------------------------------------------------------------ k_seq : one lane per block
+// ------------------------------------------------------------------ k_seqa / k_seqb : sequence bitstreams in two phases
+// The FSE states of a block form one serial chain (each sequence's state depends on the next one's), but only the STATES do: the
+// extra bits of the literal length / match length / offset and the position of every field follow from prefix sums.  So the chain
+// kernel k_seqa (one LANE per block, the lanes of a segment sharing its tables in LDS) walks the sequences last to first and records,
+// per sequence, just the three state flushes as one field (<= 24 bits + its length, one u32) and counts the stream's bits; k_seqb
+// (one workgroup per block) then assembles the bitstream token-parallel: 256 sequences per round, field lengths -> workgroup scan ->
+// 64-bit ORs into an LDS stage -> coalesced stores.  The chain is ~3x shorter than with the bit packing inside it (it was ~350
+// dependent instructions per sequence), and the chain's latency is what bounds this stage -- for one entry as for ten thousand.
 constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // 8 segments x 8 blocks = 64 lanes
+constexpr uint32_t SEQ_TWO_PHASE_MAX_BLOCKS = 40960;    // 640 chain waves: at most one per SIMD with room to spare (256 CUs x 4 SIMDs)
+static_assert(SEQ_MAX_LOG <= 8, "k_seqa packs three state flushes into 24 bits and the final states into 3 x 8 bits");
 
+__global__ __launch_bounds__(64)
+void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
+            const SegTables *__restrict__ tabs, uint32_t *__restrict__ seqw) {
+    __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
+    __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
+    __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 (small values only)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
+    { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8); }
+    for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8); }
+    for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
+        const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
+        uint32_t *dstw = (uint32_t *)&tab[s][0];
+        for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
+    }
+    __syncthreads();
+    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
+    if (sidx >= nseg) return;
+    const SegDesc sd = segs[sidx];
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    if (b >= nblk) return;
+    const uint32_t g = sd.blk_base + b;
+    const SegTables *T = tabs + sidx;
+    const uint32_t nseq = blk[g].nseq;
+    if (nseq == 0 || !T->seq_ok) { blk[g].seq_bits = 0; return; }
+    const uint32_t mll = T->mode[0], mof = T->mode[1], mml = T->mode[2];
+    const uint32_t tl_ll = T->tlog[0], tl_of = T->tlog[1], tl_ml = T->tlog[2];
+    // RLE mode (one symbol, no state bits) runs through the same code on an all-zero table: delta_nb = 0 gives 0 bits, state[0] = 0
+    // keeps the state at 0 -- no per-sequence branch on the mode
+    const SeqTable *tll = mll == 1 ? &ztab : &tab[sl][0], *tof = mof == 1 ? &ztab : &tab[sl][1], *tml = mml == 1 ? &ztab : &tab[sl][2];
+    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+    uint4 *w4 = (uint4 *)(seqw + (size_t)g * SEQ_CAP);
+    // Sequences are consumed last-to-first in 32-byte chunks (4 sequences, two 16-byte loads per lane); the next chunk is
+    // requested before the current one is walked so the HBM/L2 latency overlaps the chain.
+    uint32_t st_ml = 0, st_of = 0, st_ll = 0, bits_total = 0;
+    const uint32_t top = nseq - 1;
+    uint32_t k = top >> 2;
+    const uint4 *bs4 = (const uint4 *)bs;
+    uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
+    bool first = true;
+    for (;;) {
+        uint4 n0 = a0, n1 = a1;
+        if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
+        const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
+                                (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
+        uint32_t rec[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            if (4 * k + (uint32_t)j > top) continue;
+            const uint32_t llv = seq_ll(sq[j]), mb = seq_ml(sq[j]) - 3, ofb = seq_off(sq[j]) + 3;
+            // code and extra-bit count: LDS LUT for small values, arithmetic above (code = highbit + 19 / 36), selected without a branch
+            const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
+            const uint32_t lc = llv < 64 ? (tl & 0xFF) : hl + 19, lbits = llv < 64 ? (tl >> 8) : hl;
+            const uint32_t tm = lut_ml[mb < 128 ? mb : 127u], hm = hb(mb | 1u);
+            const uint32_t mc = mb < 128 ? (tm & 0xFF) : hm + 36, mbits = mb < 128 ? (tm >> 8) : hm;
+            const uint32_t oc = hb(ofb);
+            const SeqSym yo = tof->sym[oc], ym = tml->sym[mc], yl = tll->sym[lc];
+            uint32_t nst = 0;
+            if (first) {                                       // the last sequence of the block only sets the initial states
+                st_ml = ym.first_state; st_of = yo.first_state; st_ll = yl.first_state;
+                first = false;
+            } else {
+                // the three state flushes (<= 8 bits each) as one field: offset state lowest, then match length, then literal length
+                const uint32_t no = (st_of + yo.delta_nb) >> 16, nm = (st_ml + ym.delta_nb) >> 16, nl = (st_ll + yl.delta_nb) >> 16;
+                const uint32_t fv = (st_of & ((1u << no) - 1)) | ((st_ml & ((1u << nm) - 1)) << no) | ((st_ll & ((1u << nl) - 1)) << (no + nm));
+                st_of = tof->state[(int)(st_of >> no) + yo.delta_find];
+                st_ml = tml->state[(int)(st_ml >> nm) + ym.delta_find];
+                st_ll = tll->state[(int)(st_ll >> nl) + yl.delta_find];
+                nst = no + nm + nl;
+                rec[j] = fv | (nst << 24);
+            }
+            bits_total += nst + lbits + mbits + oc;
+        }
+        w4[k] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        if (k == 0) break;
+        k--; a0 = n0; a1 = n1;
+    }
+    // the final states and the closing 1-bit are appended by k_seqb
+    bits_total += (mml != 1 ? tl_ml : 0u) + (mof != 1 ? tl_of : 0u) + (mll != 1 ? tl_ll : 0u) + 1u;
+    blk[g].pad = (st_ml & ((1u << tl_ml) - 1)) | ((st_of & ((1u << tl_of) - 1)) << 8) | ((st_ll & ((1u << tl_ll) - 1)) << 16);
+    blk[g].seq_bits = (bits_total + 7) >> 3;
+}
+
+// The one-kernel form: the same chain with the bit packing inside it (~350 instructions per sequence instead of ~95).  Slower per
+// chain, but it touches the sequences once and writes nothing in between; it wins when the launch has more chain waves than the
+// chip has SIMDs, where k_seqa's time is set by 4-cycle VALU issue on the SIMDs that hold two waves and k_seqb's by its 12 bytes of
+// traffic per sequence (10 000 x 1 MiB: 6.4 ms against 4.7 + 2.4 ms; 1 GiB sub-batches and single entries: 3.4 ms against 1.9 + 0.2 ms).
 __global__ __launch_bounds__(64)
 void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
            const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc) {
@@ -586,6 +685,94 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     uint32_t bytes = widx * 4 + (nb + 7) / 8;
     if (nb && widx < cap_words) out32[widx] = (uint32_t)acc;
     blk[g].seq_bits = bytes;
+}
+
+constexpr uint32_t SB_THREADS = 256;
+constexpr uint32_t SB_STAGE_Q = 320;                    // 256 sequences x <= 76 bits = 304 qwords, + the carried partial one
+
+__global__ __launch_bounds__(SB_THREADS)
+void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint32_t *__restrict__ seqw,
+            const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t g0) {
+    __shared__ unsigned long long st[SB_STAGE_Q];
+    __shared__ uint32_t wtot[SB_THREADS / 64];
+    __shared__ uint32_t lut_ll[64], lut_ml[128];       // extra bits | base << 8 (small values only)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = blockIdx.x + g0;
+    const BlkInfo bi = blk[g];
+    const SegTables *T = tabs + blk_seg[g];
+    const uint32_t n = bi.nseq;
+    if (n == 0 || !T->seq_ok || bi.seq_bits >= BLK_SIZE) return;       // nothing to encode / cannot beat a raw block (k_plan)
+    if (tid < 64) { const uint32_t c = C_LL_CODE[tid]; lut_ll[tid] = (uint32_t)C_LL_BITS[c] | (C_LL_BASE[c] << 8); }
+    if (tid < 128) { const uint32_t c = C_ML_CODE[tid]; lut_ml[tid] = (uint32_t)C_ML_BITS[c] | (C_ML_BASE[c] << 8); }
+    for (uint32_t i = tid; i < SB_STAGE_Q; i += SB_THREADS) st[i] = 0;
+    __syncthreads();
+    unsigned long long *out64 = (unsigned long long *)(seqc + (size_t)g * BLK_SIZE);
+    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+    const uint32_t *w = seqw + (size_t)g * SEQ_CAP;
+    uint32_t pos = 0, qfl = 0;                                          // next free bit of the stream; st[0] holds stream qword qfl
+    for (uint32_t hi = n; hi > 0; hi = hi > SB_THREADS ? hi - SB_THREADS : 0u) {
+        // thread t takes sequence hi - 1 - t: later sequences lie at lower bit positions
+        unsigned long long lo64 = 0; uint32_t nlo = 0, oval = 0, oc = 0;
+        if (tid < hi) {
+            const uint32_t i = hi - 1 - tid;
+            const uint64_t s = bs[i];
+            const uint32_t rec = w[i];
+            const uint32_t llv = seq_ll(s), mlv = seq_ml(s), mb = mlv - 3, ofb = seq_off(s) + 3;
+            const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
+            const uint32_t lbits = llv < 64 ? (tl & 0xFF) : hl, lbase = llv < 64 ? (tl >> 8) : (1u << hl);
+            const uint32_t tm = lut_ml[mb < 128 ? mb : 127u], hm = hb(mb | 1u);
+            const uint32_t mbits = mb < 128 ? (tm & 0xFF) : hm, mbase = mb < 128 ? (tm >> 8) : ((1u << hm) + 3);
+            oc = hb(ofb); oval = ofb - (1u << oc);
+            const uint32_t nst = rec >> 24;
+            lo64 = (unsigned long long)(rec & 0xFFFFFFu) | ((unsigned long long)(llv - lbase) << nst) | ((unsigned long long)(mlv - mbase) << (nst + lbits));
+            nlo = nst + lbits + mbits;                                  // <= 24 + 16 + 16
+        }
+        const uint32_t tot = nlo + oc;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += y; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, ctot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SB_THREADS / 64; k++) { const uint32_t x = wtot[k]; ctot += x; if (k < wave) base += x; }
+        uint32_t p = pos + base + incl - tot - (qfl << 6);              // stage-relative bit of this sequence's first field
+        if (nlo) {
+            const uint32_t qi = p >> 6, sh = p & 63;
+            atomicOr(&st[qi], lo64 << sh);
+            if (sh + nlo > 64) atomicOr(&st[qi + 1], lo64 >> (64 - sh));
+        }
+        p += nlo;
+        if (oc) {
+            const uint32_t qi = p >> 6, sh = p & 63;
+            atomicOr(&st[qi], (unsigned long long)oval << sh);
+            if (sh + oc > 64) atomicOr(&st[qi + 1], (unsigned long long)oval >> (64 - sh));
+        }
+        pos += ctot;
+        __syncthreads();
+        // flush the completed qwords, carry the partial one to st[0]
+        const uint32_t nq = (pos >> 6) - qfl;
+        const unsigned long long part = st[nq];
+        for (uint32_t j = tid; j < nq; j += SB_THREADS) out64[qfl + j] = st[j];
+        __syncthreads();
+        for (uint32_t j = tid; j <= nq; j += SB_THREADS) st[j] = (j == 0) ? part : 0ull;
+        qfl += nq;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // final states (match length, offset, literal length; none for an RLE-mode table), then the closing 1-bit
+        unsigned long long acc = st[0]; uint32_t nb = pos - (qfl << 6);
+        auto put = [&](uint32_t v, uint32_t k) {                        // k <= 8, nb < 64
+            acc |= (unsigned long long)v << nb;
+            if (nb + k >= 64) { out64[qfl++] = acc; acc = (nb + k > 64) ? (unsigned long long)v >> (64 - nb) : 0ull; nb = nb + k - 64; }
+            else nb += k;
+        };
+        if (T->mode[2] != 1) put(bi.pad & 0xFF, T->tlog[2]);
+        if (T->mode[1] != 1) put((bi.pad >> 8) & 0xFF, T->tlog[1]);
+        if (T->mode[0] != 1) put((bi.pad >> 16) & 0xFF, T->tlog[0]);
+        put(1, 1);
+        if (nb) out64[qfl] = acc;
+    }
 }
 
 // ------------------------------------------------------------------ k_plan : one thread per segment
@@ -747,13 +934,19 @@ void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st
 // Entropy stage of the segments [s0, s0 + ns) whose blocks are [g0, g0 + nb): statistics + tables, literal streams,
 // sequence streams.  `tabs`, `segs` are the arrays of the whole batch.
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
-                          const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
+                          const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
     hipLaunchKernelGGL(k_stats, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0);
     if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_seq, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc);
+    // two phases (short chain, parallel packing) while the chain waves fit the SIMDs, the one-kernel form beyond (see k_seq)
+    if (!(flags & 0x1000u) && (nb <= SEQ_TWO_PHASE_MAX_BLOCKS || (flags & 0x2000u))) {
+        hipLaunchKernelGGL(k_seqa, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqw);
+        if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, seqw, blk, tabs, seqc, g0);
+    } else {
+        hipLaunchKernelGGL(k_seq, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc);
+    }
     if (ev) (void)hipEventRecord(ev[2], st);
 }
 // sizes of all segments -> offsets

@@ -31,7 +31,7 @@ void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
                           uint8_t *dst, hipStream_t st);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
-                          const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc,
+                          const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, hipStream_t st, hipEvent_t *ev);
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st);
@@ -115,7 +115,7 @@ struct pna_gpu_ctx {
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
+    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf x_arc, x_pk, x_raw, x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
@@ -183,7 +183,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
     if (const char *lg = getenv("PNA_STREAM_LINGER_US")) c->comb_linger_us = (uint32_t)std::min<unsigned long>(strtoul(lg, nullptr, 10), 100000ul);
-    if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0xF00u;   // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz
+    if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0x3F00u;  // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz, 0x1000 / 0x2000 force the one-kernel / two-phase sequence coder
     c->call_flags = c->flags;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
@@ -195,7 +195,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seg_size,
+    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw, &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
@@ -510,6 +510,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) || (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
         c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
+        (algo == PNA_ALGO_ZSTD && c->seqw.ensure((size_t)(nblk + 1) * SEQ_CAP * 4)) ||
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
         return fail(c, PNA_E_NOMEM, "workspace allocation failed");
     HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
@@ -550,7 +551,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));
             launch_entropy_chunk((const SegDesc *)c->segs.p, s0, s1 - s0, (const uint32_t *)c->blk_seg.p, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
-                                 c->call_flags, c->aux, &c->ev_en[k][1]);
+                                 (uint32_t *)c->seqw.p, c->call_flags, c->aux, &c->ev_en[k][1]);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));

@@ -80,6 +80,20 @@ def test_serial_end_scan_is_identical(pna, codec):
         assert o == codec.model_compress(cases[k], p), k
 
 
+@pytest.mark.parametrize("form", [0x1000, 0x2000])
+def test_both_sequence_coder_forms_are_identical(pna, codec, form):
+    """The sequences bitstream has two implementations picked by batch size (k_seqa + k_seqb: short state chain, token-parallel packing;
+    k_seq: one kernel); flags 0x1000 / 0x2000 force one of them.  Both must equal the oracle's encoder."""
+    import torch  # noqa: F401
+    cases = _cases(codec)
+    names = sorted(cases)
+    with pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | form) as ctx:
+        outs = ctx.compress_batch([cases[k] for k in names])
+    p = _params(codec)
+    for k, o in zip(names, outs):
+        assert o == codec.model_compress(cases[k], p), k
+
+
 @pytest.mark.parametrize("flags", [0, 1, 2, 3, 4])
 def test_feature_subsets_bit_exact(pna, codec, flags):
     import torch  # noqa: F401
