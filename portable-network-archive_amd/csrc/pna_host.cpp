@@ -146,8 +146,14 @@ struct pna_gpu_ctx {
     std::condition_variable comb_cv;
     std::vector<pna_gpu_stream *> comb_queue;
     bool comb_leader = false;
-    uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0;
+    uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0, comb_seq = 0;
     uint32_t comb_linger_us = 0;           // PNA_STREAM_LINGER_US: the leader waits this long for more finishes before it submits
+    // page-locked memory of the streaming facade: write() copies straight into 1 MiB slabs of a pool (no staging copy before the H2D
+    // copy), the compressed streams come back into one of two page-locked output slots and the owners drain them from there
+    std::mutex pool_mu;
+    std::vector<void *> pool_arenas; std::vector<uint8_t *> pool_free; size_t pool_bytes = 0, pool_cap = 4096ull << 20;
+    PinBuf s_out[2];
+    uint64_t slot_pending[2] = {0, 0};     // streams of the slot's last batch that have not been drained yet (under comb_mu)
 };
 
 static int fail(pna_gpu_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -182,6 +188,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->device = device_id;
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
+    if (const char *pm = getenv("PNA_STREAM_POOL_MIB")) c->pool_cap = (size_t)std::min<unsigned long>(strtoul(pm, nullptr, 10), 1ul << 20) << 20;
     if (const char *lg = getenv("PNA_STREAM_LINGER_US")) c->comb_linger_us = (uint32_t)std::min<unsigned long>(strtoul(lg, nullptr, 10), 100000ul);
     if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0x3F00u;  // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz, 0x1000 / 0x2000 force the one-kernel / two-phase sequence coder
     c->call_flags = c->flags;
@@ -192,6 +199,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
 }
 
 extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
+    if (c) { for (void *a : c->pool_arenas) (void)hipHostFree(a); c->pool_arenas.clear(); c->pool_free.clear(); c->s_out[0].release(); c->s_out[1].release(); }
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -2022,10 +2030,33 @@ extern "C" int pna_gpu_decompress_batch(pna_gpu_ctx *c, int algo, size_t n, cons
 // ONE pna_gpu_compress_batch for it and wakes the owners, each of which drains its own stream into its own sink on its own thread
 // (W::write is never called from a foreign thread).  While a batch runs, the finishes that arrive pile up and form the next,
 // larger batch -- no timer needed under load (PNA_STREAM_LINGER_US adds an optional wait for stragglers).
+constexpr size_t S_SLAB = 1u << 20, S_ARENA = 64u << 20, S_MAX_SLABS = 256;   // a stream beyond 256 MiB continues in pageable memory
 struct pna_gpu_stream {
-    pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user; std::vector<uint8_t> buf;
-    std::vector<uint8_t> out; size_t out_len = 0; int rc = PNA_OK; bool done = false;
+    pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user;
+    std::vector<uint8_t *> slabs; size_t slab_len = 0;      // page-locked mode: bytes [k * S_SLAB, ...) live in slabs[k]
+    bool pageable = false; std::vector<uint8_t> buf;        // pageable mode (pool exhausted / very large stream): everything in buf
+    const uint8_t *out = nullptr; size_t out_len = 0; int rc = PNA_OK, slot = 0; bool done = false;
+    size_t total() const { return pageable ? buf.size() : slab_len; }
 };
+
+static uint8_t *pool_get(pna_gpu_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    if (c->pool_free.empty()) {
+        if (c->pool_bytes + S_ARENA > c->pool_cap) return nullptr;
+        void *p = nullptr;
+        if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, S_ARENA, hipHostMallocDefault) != hipSuccess) return nullptr;
+        c->pool_arenas.push_back(p); c->pool_bytes += S_ARENA;
+        for (size_t k = 0; k < S_ARENA / S_SLAB; k++) c->pool_free.push_back((uint8_t *)p + k * S_SLAB);
+    }
+    uint8_t *r = c->pool_free.back(); c->pool_free.pop_back();
+    return r;
+}
+static void pool_put(pna_gpu_ctx *c, std::vector<uint8_t *> &slabs) {
+    if (slabs.empty()) return;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    for (uint8_t *p : slabs) c->pool_free.push_back(p);
+    slabs.clear();
+}
 
 extern "C" int pna_gpu_stream_new(pna_gpu_ctx *c, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out) {
     if (!c || !sink || !out) return PNA_E_INVAL;
@@ -2038,15 +2069,40 @@ extern "C" int pna_gpu_stream_new(pna_gpu_ctx *c, int algo, int level, pna_sink_
 }
 extern "C" int pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len) {
     if (!s || (!buf && len)) return PNA_E_INVAL;
-    try { s->buf.insert(s->buf.end(), (const uint8_t *)buf, (const uint8_t *)buf + len); } catch (const std::bad_alloc &) { return PNA_E_NOMEM; }
+    const uint8_t *p = (const uint8_t *)buf; size_t left = len;
+    try {
+        while (left && !s->pageable) {
+            const size_t in_slab = s->slab_len % S_SLAB;
+            if (s->slab_len == s->slabs.size() * S_SLAB) {                  // the last slab is full (or there is none yet)
+                uint8_t *sl = s->slabs.size() < S_MAX_SLABS ? pool_get(s->ctx) : nullptr;
+                if (!sl) {                                                  // continue in pageable memory
+                    s->buf.reserve(s->slab_len + left);
+                    for (size_t k = 0; k < s->slabs.size(); k++) s->buf.insert(s->buf.end(), s->slabs[k], s->slabs[k] + std::min(S_SLAB, s->slab_len - k * S_SLAB));
+                    pool_put(s->ctx, s->slabs); s->slab_len = 0; s->pageable = true;
+                    break;
+                }
+                s->slabs.push_back(sl);
+            }
+            const size_t k = std::min(left, S_SLAB - in_slab);
+            memcpy(s->slabs.back() + in_slab, p, k); p += k; left -= k; s->slab_len += k;
+        }
+        if (left) s->buf.insert(s->buf.end(), p, p + left);
+    } catch (const std::bad_alloc &) { return PNA_E_NOMEM; }
     return PNA_OK;
 }
 extern "C" int pna_gpu_stream_flush(pna_gpu_stream *s) { return s ? PNA_OK : PNA_E_INVAL; }
-extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { delete s; }
+extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { if (s) { pool_put(s->ctx, s->slabs); delete s; } }
 
-// one device batch per (algo, level) group of the streams the leader took
-static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch) {
+// One device batch per (algo, level) group of the streams the leader took: H2D copies straight from the streams' page-locked slabs
+// (pageable streams are staged first), the device batch, ONE D2H copy of the group's streams into the slot's page-locked output.
+static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch, int slot) {
     std::lock_guard<std::mutex> run(c->run_mu);
+    auto fail_all = [&](int rc) { for (pna_gpu_stream *x : batch) if (x->rc == PNA_OK && !x->out) { x->rc = rc; x->out_len = 0; } };
+    if (hipSetDevice(c->device) != hipSuccess) { fail_all(fail(c, PNA_E_HIP, "hipSetDevice failed")); return; }
+    uint64_t out_cap = 64, page_bytes = 0;
+    for (pna_gpu_stream *x : batch) { out_cap += pna_gpu_bound(x->algo, x->total()) + 16; if (x->pageable) page_bytes += (x->buf.size() + 15) & ~(size_t)15; }
+    if (c->s_out[slot].ensure(out_cap) || (page_bytes && c->hp_in[0].ensure(page_bytes + 64))) { fail_all(fail(c, PNA_E_NOMEM, "staging allocation failed")); return; }
+    uint64_t out_base = 0;
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); i++) {
         if (taken[i]) continue;
@@ -2054,40 +2110,88 @@ static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *>
         for (size_t j = i; j < batch.size(); j++)
             if (!taken[j] && batch[j]->algo == batch[i]->algo && batch[j]->level == batch[i]->level) { taken[j] = 1; grp.push_back(batch[j]); }
         const size_t n = grp.size();
-        std::vector<const void *> src(n); std::vector<size_t> sl(n), cap(n), dl(n, 0); std::vector<void *> dst(n);
-        for (size_t k = 0; k < n; k++) { src[k] = grp[k]->buf.data(); sl[k] = grp[k]->buf.size(); dst[k] = grp[k]->out.data(); cap[k] = grp[k]->out.size(); }
-        const int rc = pna_gpu_compress_batch(c, grp[0]->algo, grp[0]->level, n, src.data(), sl.data(), dst.data(), cap.data(), dl.data());
-        for (size_t k = 0; k < n; k++) { grp[k]->rc = rc; grp[k]->out_len = rc == PNA_OK ? dl[k] : 0; }
+        std::vector<uint64_t> off(n + 1), len(n), doff(n + 1);
+        uint64_t pos = 0, bound = 0;
+        for (size_t k = 0; k < n; k++) { off[k] = pos; len[k] = grp[k]->total(); pos = (pos + len[k] + 15) & ~(uint64_t)15; bound += pna_gpu_bound(grp[k]->algo, (size_t)len[k]); }
+        off[n] = pos;
+        int rc = PNA_OK;
+        static const bool trace = getenv("PNA_STREAM_TRACE") != nullptr;     // per-batch phase times on stderr
+        const auto t0 = std::chrono::steady_clock::now();
+        if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(bound + 64)) rc = fail(c, PNA_E_NOMEM, "staging allocation failed");
+        uint64_t ppos = 0;
+        for (size_t k = 0; k < n && rc == PNA_OK; k++) {
+            pna_gpu_stream *x = grp[k];
+            uint8_t *d = (uint8_t *)c->stage_in.p + off[k];
+            if (x->pageable) {
+                if (!x->buf.empty()) {
+                    memcpy((uint8_t *)c->hp_in[0].p + ppos, x->buf.data(), x->buf.size());
+                    if (hipMemcpyAsync(d, (uint8_t *)c->hp_in[0].p + ppos, x->buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
+                    ppos += (x->buf.size() + 15) & ~(size_t)15;
+                }
+            } else {
+                for (size_t b = 0; b < x->slabs.size() && rc == PNA_OK; b++) {
+                    const size_t nb = std::min(S_SLAB, x->slab_len - b * S_SLAB);
+                    if (hipMemcpyAsync(d + b * S_SLAB, x->slabs[b], nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
+                }
+            }
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        if (trace) (void)hipStreamSynchronize(c->stream);
+        const auto t2 = std::chrono::steady_clock::now();
+        if (rc == PNA_OK) rc = pna_gpu_compress_batch_device(c, grp[0]->algo, grp[0]->level, n, c->stage_in.p, off.data(), len.data(), c->stage_out.p, bound + 64, doff.data(), nullptr);
+        const auto t3 = std::chrono::steady_clock::now();
+        if (rc == PNA_OK && doff[n] && hipMemcpyAsync((uint8_t *)c->s_out[slot].p + out_base, c->stage_out.p, doff[n], hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PNA_OK) rc = fail(c, PNA_E_HIP, "device batch failed");
+        if (trace) {
+            const auto t4 = std::chrono::steady_clock::now();
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[pna stream batch] %zu entries, %.1f MiB in: issue H2D %.2f ms, H2D done +%.2f ms, device batch %.2f ms, D2H %.2f ms\n",
+                    n, pos / 1048576.0, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+        }
+        for (size_t k = 0; k < n; k++) {
+            grp[k]->rc = rc;
+            grp[k]->out = (const uint8_t *)c->s_out[slot].p + out_base + (rc == PNA_OK ? doff[k] : 0);
+            grp[k]->out_len = rc == PNA_OK ? (size_t)(doff[k + 1] - doff[k]) : 0;
+        }
+        if (rc == PNA_OK) out_base += (doff[n] + 15) & ~(uint64_t)15;
     }
 }
 
 extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
     if (!s) return PNA_E_INVAL;
     pna_gpu_ctx *c = s->ctx;
-    try { s->out.resize(pna_gpu_bound(s->algo, s->buf.size())); } catch (const std::bad_alloc &) { delete s; return PNA_E_NOMEM; }
     {
         std::unique_lock<std::mutex> lk(c->comb_mu);
         c->comb_queue.push_back(s);
         while (!s->done) {
             if (c->comb_leader) { c->comb_cv.wait(lk); continue; }
             c->comb_leader = true;                                   // s is still queued, so the batch taken below contains it
+            const int slot = (int)(c->comb_seq++ & 1);
+            while (c->slot_pending[slot]) c->comb_cv.wait(lk);       // the batch before the last one is still being drained from this slot
             if (c->comb_linger_us) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(c->comb_linger_us)); lk.lock(); }
             std::vector<pna_gpu_stream *> batch; batch.swap(c->comb_queue);
+            c->slot_pending[slot] = batch.size();
+            for (pna_gpu_stream *x : batch) x->slot = slot;
             lk.unlock();
-            stream_run_batch(c, batch);
+            stream_run_batch(c, batch, slot);
             lk.lock();
             for (pna_gpu_stream *x : batch) x->done = true;          // owners may free their streams as soon as the lock is released
             c->comb_leader = false; c->comb_batches++; c->comb_entries += batch.size(); c->comb_max = std::max<uint64_t>(c->comb_max, batch.size());
             c->comb_cv.notify_all();
         }
     }
+    pool_put(c, s->slabs);                                           // the input has been copied to the device
     int rc = s->rc;
     if (rc == PNA_OK) {
         // the reference's zstd writer drains in bursts of at most 32 KiB (zio::Writer); keep that shape
         for (size_t p = 0; p < s->out_len && rc == PNA_OK; p += 32768) {
             const size_t k = std::min<size_t>(32768, s->out_len - p);
-            if (s->sink(s->user, s->out.data() + p, k) != 0) { std::lock_guard<std::mutex> run(c->run_mu); rc = fail(c, PNA_E_SINK, "sink failed"); }
+            if (s->sink(s->user, s->out + p, k) != 0) { std::lock_guard<std::mutex> run(c->run_mu); rc = fail(c, PNA_E_SINK, "sink failed"); }
         }
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->comb_mu);
+        if (--c->slot_pending[s->slot] == 0) c->comb_cv.notify_all();
     }
     delete s;
     return rc;

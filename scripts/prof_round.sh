@@ -1,16 +1,18 @@
 #!/bin/bash
-# Round-end evidence on the GPU box: kernel-trace stats of the default bench and of the encrypted variant, the bench lines next to them,
-# and the HBM traffic of the cipher kernel (separate PMC passes).  Output under gpurun_out/prof_h/.
+# Round-end evidence on the GPU box: kernel-trace stats of the default bench, the bench lines of the named configurations next to them.
+# Output under gpurun_out/prof_$TAG/ (TAG defaults to "i"); copy what is to be judged into profiles/.
 set -u
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/prof_h
+TAG=${1:-i}
+OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 bench.py --encrypt aes-ctr --no-cpu-baseline > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/kt_default.log" 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_aes" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --encrypt aes-ctr > "$OUT/kt_aes.log" 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  d=$OUT/pmc_$(echo $c | tr A-Z a-z | cut -d_ -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o pmc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify --encrypt aes-ctr > "$d.log" 2>&1
-done
-find "$OUT" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+python3 bench.py --no-cpu-baseline --framing solid --files 8192 > "$OUT/bench_solid.json" 2> "$OUT/bench_solid.err"
+python3 bench.py --no-cpu-baseline --algo deflate --files 2048 > "$OUT/bench_deflate.json" 2> "$OUT/bench_deflate.err"
+python3 bench.py --no-cpu-baseline --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
+python3 bench.py --no-cpu-baseline --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
+python3 bench.py --no-cpu-baseline --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
+python3 scripts/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
+python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
+find "$OUT" -name "*kernel_stats.csv" | head
