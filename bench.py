@@ -9,7 +9,9 @@ archive bytes in HBM (LZ -> entropy -> payloads written at their archive offsets
 10 000 x 1 MiB, zstd).  Inputs are generated on the device and are resident in HBM when the timed region starts.
 N > 1: one process per GPU (torch.distributed / RCCL), every rank compresses its own shard of the corpus (weak
 scaling), then the compressed shards are gathered in rank order onto rank 0 over RCCL (the ordered gather of the
-serial PNA stream).  Rank 0 prints ONE JSON line.
+serial PNA stream).  A rank's shard is cut into `--gather-pieces` contiguous pieces (2 when N > 1): piece h of all ranks
+forms the h-th stretch of the archive, so the gather of piece h runs while piece h + 1 is being compressed and only the
+last piece's gather is exposed at the end of a step.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -107,6 +109,9 @@ def main() -> None:
                          "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
     ap.add_argument("--encrypt", choices=["none", "aes-ctr", "aes-cbc", "aes-gcm"], default="none",
                     help="archive framing only: AES-256 cipher stage between compression and chunk CRC (`pna create --aes [ctr|cbc]`)")
+    ap.add_argument("--gather-pieces", type=int, default=0,
+                    help="archive framing: cut every rank's shard into this many pieces, each compressed and gathered on its own "
+                         "(0 = 2 when N > 1, else 1)")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive (archive framing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
@@ -132,11 +137,23 @@ def main() -> None:
     stride = (file_len + 15) & ~15
     src = torch.empty(n_files * stride + 8192, dtype=torch.uint8, device=dev)
     algo = pna.ALGO_ZSTD if args.algo == "zstd" else pna.ALGO_DEFLATE
-    ctx.corpus_fill_device(args.kind, rank * n_files, n_files, file_len, stride, src.data_ptr())
+    # pieces: piece h of rank r holds the files [(h * world + r) * n_piece, ... + n_piece) of the corpus -- in archive order all ranks'
+    # pieces 0 come first, then all pieces 1, ...: every piece is gathered in rank order as soon as it is compressed
+    pieces = args.gather_pieces or (2 if world > 1 else 1)
+    if args.framing != "archive" or pieces < 1 or n_files % pieces:
+        pieces = 1
+    n_piece = n_files // pieces
+    first_file = [(h * world + rank) * n_piece for h in range(pieces)]
+    for h in range(pieces):
+        ctx.corpus_fill_device(args.kind, first_file[h], n_piece, file_len, stride, src.data_ptr() + h * n_piece * stride)
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]
     src_len = [file_len] * n_files
-    names = [f"enwik/part{rank * n_files + i:07d}.txt" for i in range(n_files)]
+    names = [f"enwik/part{first_file[i // n_piece] + i % n_piece:07d}.txt" for i in range(n_files)]
+    p_names = [names[h * n_piece:(h + 1) * n_piece] for h in range(pieces)]
+    p_off = [src_off[h * n_piece:(h + 1) * n_piece] + [src_off[(h + 1) * n_piece]] for h in range(pieces)]
+    p_len = [src_len[h * n_piece:(h + 1) * n_piece] for h in range(pieces)]
     cipher = None
+    p_cipher = [None] * pieces
     if args.encrypt != "none":
         if args.framing != "archive":
             ap.error("--encrypt needs --framing archive")
@@ -149,45 +166,62 @@ def main() -> None:
         ivs = b"".join((hashlib.sha256(iv_seed + i.to_bytes(4, "little")).digest() + hashlib.sha256(iv_seed + b"x" + i.to_bytes(4, "little")).digest())[:per]
                        for i in range(n_files))
         cipher = pna.Cipher(key, "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0", mode, ivs=ivs)
+        p_cipher = [cipher if pieces == 1 else pna.Cipher(key, "$pbkdf2-sha256$i=1000,l=32$c2FsdHNhbHRzYWx0", mode, ivs=ivs[h * n_piece * per:(h + 1) * n_piece * per])
+                    for h in range(pieces)]
     if args.framing == "archive":
-        dst_cap = pna.archive_enc_bound(algo, names, src_len, cipher)
+        dst_cap = max(pna.archive_enc_bound(algo, p_names[h], p_len[h], p_cipher[h]) for h in range(pieces))
     elif args.framing == "solid":
         dst_cap = pna.solid_archive_bound(algo, names, src_len)
     else:
         dst_cap = pna.bound(algo, file_len) * n_files + 4096
-    # N > 1: two output buffers, so the ordered gather of step k (RCCL send/recv over xGMI) overlaps the compression of step k+1
-    dsts = [torch.empty(dst_cap, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    arg_cache: dict = {}
+    # two output buffers when pieces are gathered: the ordered gather of one piece (RCCL send/recv over xGMI) overlaps the compression
+    # of the next piece (of this step or of the next one)
+    nbuf = 2 if (world > 1 or pieces > 1) else 1
+    dsts = [torch.empty(dst_cap, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    arg_cache = [dict() for _ in range(pieces)]
 
     shard = importlib.import_module("portable-network-archive_amd.shard")
-    gather_out = [None]
-    pending = [None]
+    gather_out = [None] * pieces                              # rank 0: where the pieces h of all ranks land, in rank order
+    pending = [None] * nbuf                                   # the gather that still reads dsts[b]
     cur = [0]
 
-    def finish_gather():
-        if pending[0] is not None:
-            shard.gather_ordered_wait(pending[0])
-            torch.cuda.current_stream().synchronize()         # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
-            pending[0] = None
+    def finish_gather(b=None):
+        for k in (range(nbuf) if b is None else [b]):
+            if pending[k] is not None:
+                shard.gather_ordered_wait(pending[k])
+                torch.cuda.current_stream().synchronize()     # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
+                pending[k] = None
+
+    def part_flags(h):
+        # the first piece of rank 0 carries the archive header, the last piece of the last rank AEND: all pieces in order are ONE archive
+        return (pna.PART_HEAD if (rank == 0 and h == 0) else 0) | (pna.PART_TAIL if (rank == world - 1 and h == pieces - 1) else 0)
+
+    lz_acc = [0.0, 0.0]
 
     def step():
-        dst = dsts[cur[0]]
-        if args.framing == "archive":
-            # rank 0 writes the archive header, the last rank AEND: the shards gathered in rank order are ONE archive
-            part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
-            total, _ = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo,
-                                                 _cache=arg_cache, part=part, cipher=cipher, want_offsets=False)
-        elif args.framing == "solid":
-            total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache)
-        else:
-            total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
-        if world > 1:
-            finish_gather()                                   # the previous step's gather (it used the other buffer and gather_out)
-            if rank == 0 and gather_out[0] is None:
-                gather_out[0] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
-            pending[0] = shard.gather_ordered_start(dst, total, rank, world, out=gather_out[0])
-            cur[0] ^= 1
-        return total
+        total_all = 0
+        for h in range(pieces):
+            b = cur[0]
+            finish_gather(b)                                  # the gather that used this buffer two pieces ago
+            dst = dsts[b]
+            if args.framing == "archive":
+                total, _ = ctx.create_archive_device(p_names[h], src.data_ptr(), p_off[h], p_len[h], dst.data_ptr(), dst_cap, algo=algo,
+                                                     _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h], want_offsets=False)
+            elif args.framing == "solid":
+                total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0])
+            else:
+                total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
+            tm = ctx.timing()
+            lz_acc[0] += tm.ms_lz
+            lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
+            if world > 1:
+                if rank == 0 and gather_out[h] is None:
+                    gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
+                pending[b] = shard.gather_ordered_start(dst, total, rank, world, out=gather_out[h])
+            if nbuf > 1:
+                cur[0] ^= 1
+            total_all += total
+        return total_all
 
     for _ in range(args.warmup):
         step()
@@ -195,19 +229,17 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    lz_ms = stage_ms = 0.0
+    lz_acc[0] = lz_acc[1] = 0.0
     t0 = time.perf_counter()
     out_total = 0
     for _ in range(args.steps):
         out_total = step()
-        tm = ctx.timing()
-        lz_ms += tm.ms_lz
-        stage_ms += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
-    finish_gather()                                           # the last step's gather is inside the timed region
+    finish_gather()                                           # the last piece's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    lz_ms, stage_ms = lz_acc
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,25 +251,25 @@ def main() -> None:
         out_all = out_total
     # ---- outside the timed region: decode every entry of this rank's last archive on the device and compare with the inputs
     verified = None
-    tm_last = ctx.timing()                                   # stage split of the last timed step (the check below runs more kernels)
+    tm_last = ctx.timing()                                   # stage split of the last timed launch (the check below runs more kernels)
     if args.framing == "archive" and not args.no_verify and args.encrypt in ("none", "aes-ctr"):
-        dst_last = dsts[cur[0] ^ 1] if world > 1 else dsts[0]
-        part = (pna.PART_HEAD if rank == 0 else 0) | (pna.PART_TAIL if rank == world - 1 else 0)
-        total, eoff = ctx.create_archive_device(names, src.data_ptr(), src_off, src_len, dst_last.data_ptr(), dst_cap, algo=algo,
-                                                _cache=arg_cache, part=part, cipher=cipher)
+        ok = True
         fs = max(1, (file_len.bit_length() + 7) // 8) if file_len else 0          # fSIZ payload: minimal big-endian
-        pay_off, pay_len = [], []
         extra = (12 + len(cipher.phsf.encode()) + 28) if cipher is not None else 0    # PHSF chunk + FDAT(iv) chunk
-        for i in range(n_files):
-            pre = 12 + 6 + len(names[i].encode()) + 12 + fs + extra + 8
-            nxt = eoff[i + 1]
-            pay_off.append(eoff[i] + pre); pay_len.append(nxt - eoff[i] - pre - 16)
-        if cipher is not None:                                # read side: CTR decrypt in place, then decode
-            ctx.cipher_apply_device(cipher, dst_last.data_ptr(), pay_off, pay_len, decrypt=True)
-        back = torch.empty(n_files * stride + 64, dtype=torch.uint8, device=dev)
-        ctx.decompress_batch_device(dst_last.data_ptr(), pay_off, pay_len, back.data_ptr(), src_off[:n_files], src_len, algo=algo)
-        ok = all(bool(torch.equal(back[i * stride:i * stride + file_len], src[i * stride:i * stride + file_len])) for i in range(0, n_files, max(1, n_files // 64))) \
-            and (stride != file_len or bool(torch.equal(back[:n_files * stride], src[:n_files * stride])))
+        back = torch.empty(n_piece * stride + 64, dtype=torch.uint8, device=dev)
+        for h in range(pieces):
+            total, eoff = ctx.create_archive_device(p_names[h], src.data_ptr(), p_off[h], p_len[h], dsts[0].data_ptr(), dst_cap, algo=algo,
+                                                    _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h])
+            pay_off, pay_len = [], []
+            for i in range(n_piece):
+                pre = 12 + 6 + len(p_names[h][i].encode()) + 12 + fs + extra + 8
+                pay_off.append(eoff[i] + pre); pay_len.append(eoff[i + 1] - eoff[i] - pre - 16)
+            if cipher is not None:                            # read side: CTR decrypt in place, then decode
+                ctx.cipher_apply_device(p_cipher[h], dsts[0].data_ptr(), pay_off, pay_len, decrypt=True)
+            ctx.decompress_batch_device(dsts[0].data_ptr(), pay_off, pay_len, back.data_ptr(), [i * stride for i in range(n_piece)], p_len[h], algo=algo)
+            ref = src[h * n_piece * stride:(h + 1) * n_piece * stride]
+            ok = ok and all(bool(torch.equal(back[i * stride:i * stride + file_len], ref[i * stride:i * stride + file_len])) for i in range(0, n_piece, max(1, n_piece // 64))) \
+                and (stride != file_len or bool(torch.equal(back[:n_piece * stride], ref)))
         verified = bool(ok)
         del back
     in_rank = n_files * file_len
@@ -259,7 +291,8 @@ def main() -> None:
                                    + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
                                       else "--solid: inner STORE records serialised + one compressed stream + SDAT framing, all in HBM" if args.framing == "solid"
                                       else "output = packed compressed entry streams in HBM"),
-                       "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}"},
+                       "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}",
+                       "gather_pieces": pieces},
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -267,6 +300,7 @@ def main() -> None:
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing),
                          "algorithmic_bytes": alg_bytes,
                          "kernel_ms": round(lz_ms / args.steps, 3), "all_kernels_ms": round(stage_ms / args.steps, 3)},
+            # the last launch of the last step: with gather_pieces = P that is one piece, 1 / P of a step
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
                                     "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3), "frame": round(tm.ms_frame, 3)},
         }
@@ -274,7 +308,7 @@ def main() -> None:
             line["config"]["workload"] += f", cipher stage {args.encrypt} (AES-256) on the compressed payloads in HBM"
             line["stages_ms_last_step"]["cipher"] = round(tm.ms_cipher, 3)
             line["cipher"] = {"mode": args.encrypt, "ms": round(tm.ms_cipher, 3),
-                              "GB_per_s": round(out_total / max(tm.ms_cipher, 1e-9) / 1e6, 1)}
+                              "GB_per_s": round(out_total / pieces / max(tm.ms_cipher, 1e-9) / 1e6, 1)}
         if world == 1 and not args.no_cpu_baseline and args.algo == "zstd":
             try:
                 sample = args.cpu_sample_files or 64 * usable_cores()
