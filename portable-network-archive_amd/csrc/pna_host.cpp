@@ -2030,6 +2030,19 @@ extern "C" int pna_gpu_decompress_batch(pna_gpu_ctx *c, int algo, size_t n, cons
 // ONE pna_gpu_compress_batch for it and wakes the owners, each of which drains its own stream into its own sink on its own thread
 // (W::write is never called from a foreign thread).  While a batch runs, the finishes that arrive pile up and form the next,
 // larger batch -- no timer needed under load (PNA_STREAM_LINGER_US adds an optional wait for stragglers).
+// one large copy on several threads (a pageable stream of GiBs, e.g. pna_gpu_compress_solid over a whole solid archive)
+static void big_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = n < (64u << 20) ? 1u : std::min(8u, std::max(1u, hw / 2));
+    if (T == 1) { memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n + T - 1) / T + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < T; t++) {
+        const size_t a = std::min(n, (size_t)t * per), b = std::min(n, a + per);
+        if (b > a) th.emplace_back([=]() { memcpy(dst + a, src + a, b - a); });
+    }
+    for (auto &x : th) x.join();
+}
 constexpr size_t S_SLAB = 1u << 20, S_ARENA = 64u << 20, S_MAX_SLABS = 256;   // a stream beyond 256 MiB continues in pageable memory
 struct pna_gpu_stream {
     pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user;
@@ -2124,7 +2137,7 @@ static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *>
             uint8_t *d = (uint8_t *)c->stage_in.p + off[k];
             if (x->pageable) {
                 if (!x->buf.empty()) {
-                    memcpy((uint8_t *)c->hp_in[0].p + ppos, x->buf.data(), x->buf.size());
+                    big_memcpy((uint8_t *)c->hp_in[0].p + ppos, x->buf.data(), x->buf.size());
                     if (hipMemcpyAsync(d, (uint8_t *)c->hp_in[0].p + ppos, x->buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
                     ppos += (x->buf.size() + 15) & ~(size_t)15;
                 }

@@ -180,6 +180,34 @@ def test_compression_writers_on_many_threads_are_batched(pna, codec):
         ctx.close()
 
 
+def test_stream_spills_to_pageable_memory(pna, codec, monkeypatch):
+    """write() fills page-locked slabs of the context's pool; with the pool capped at one 64 MiB arena a 66 MiB stream must continue in
+    pageable memory (and a second writer finds the pool empty from its first byte) -- the streams stay equal to the oracle's."""
+    import torch  # noqa: F401
+    monkeypatch.setenv("PNA_STREAM_POOL_MIB", "64")
+    ctx = pna.Context(0)
+    try:
+        big = b"".join(codec.corpus_file(0, 500 + i, 1 << 20) for i in range(6)) * 11          # 66 MiB
+
+        class Sink:
+            def __init__(self): self.parts = []
+            def write(self, b): self.parts.append(bytes(b))
+        w1 = ctx.writer(Sink())
+        for i in range(0, len(big), 5 << 20):
+            w1.write(big[i:i + (5 << 20)])
+        small = codec.corpus_file(1, 9, 300000)
+        w2 = ctx.writer(Sink(), algo=pna.ALGO_DEFLATE)          # the pool is exhausted: pageable from the start
+        w2.write(small)
+        got2 = b"".join(w2.try_into_inner().parts)
+        got1 = b"".join(w1.try_into_inner().parts)
+        assert got2 == codec.deflate_model_compress(small)
+        assert got1 == codec.model_compress(big, _params(codec))
+        pieces = ctx.compress_solid(small)                       # pna_gpu_compress_solid rides on the same stream
+        assert b"".join(pieces) == codec.model_compress(small, _params(codec)) and max(len(x) for x in pieces) <= 32768
+    finally:
+        ctx.close()
+
+
 def test_create_archive_round_trip(gpu_ctx, pna, pf, codec):
     """cli/tests/cli/combination.rs style: create -> read back -> trees equal; order == argv order."""
     names, ents = [], []
