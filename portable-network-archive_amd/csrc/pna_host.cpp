@@ -16,6 +16,8 @@
 #include <atomic>
 #include <chrono>
 #include <new>
+#include <functional>
+#include <memory>
 #include <sys/random.h>
 #include "pna_dev.h"
 #include "../../include/pna_gpu.h"
@@ -118,7 +120,8 @@ struct pna_gpu_ctx {
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
-    DevBuf x_arc, x_pk, x_raw, x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
+    DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
+    hipStream_t x_cp = nullptr; hipEvent_t x_ev[2] = {}, x_done = nullptr;   // extract driver: D2H of window k on x_cp next to window k+1's work
     bool aes_dec_ready = false;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
     DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
@@ -205,7 +208,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw, &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -1286,9 +1289,12 @@ bool b64_decode_nopad(const std::string &s, std::vector<uint8_t> &out) {
 }
 }
 
+// what a window leaves behind for later: `issue` starts the D2H copy of its decoded entries (called by the NEXT window once its own bytes
+// are on the device, so the copy runs next to that window's kernels), `deliver` waits for it and hands the entries out
+struct XDeferred { std::function<int()> issue, deliver; bool issued = false; explicit operator bool() const { return (bool)deliver; } };
 static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, const void *password, size_t password_len, pna_entry_fn cb, void *user,
                           std::vector<XEntry> &ents, std::vector<FrameDesc> &dchunks, std::vector<FrameDesc> &schunks, std::vector<XSolid> &solids,
-                          XKeys &keys, size_t &index);
+                          XKeys &keys, size_t &index, int slot, XDeferred *later, XDeferred *prev);
 
 extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive, size_t archive_len, const void *password, size_t password_len,
                                             pna_entry_fn cb, void *user) {
@@ -1341,13 +1347,31 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     // device at a time (an archive of any size in host memory against a bounded footprint in HBM); a solid entry is a window of its own
     XKeys keys; size_t index = 0, si = 0, w0 = 0;
     const size_t n_all = ents.size();
-    uint64_t WIN = 4ull << 30;
+    uint64_t WIN = 1ull << 30;                                  // 1 GiB of archive (and at most 3 GiB decoded) per window: small enough to pipeline, large enough for the kernels
     if (const char *ev = getenv("PNA_EXTRACT_WIN_MIB")) { const long v = atol(ev); if (v >= 1 && v <= (1 << 20)) WIN = (uint64_t)v << 20; }
     auto rebase_run = [&](size_t e0, size_t e1, std::vector<XEntry> &we, std::vector<FrameDesc> &wd, uint64_t base) {
         we.assign(std::make_move_iterator(ents.begin() + e0), std::make_move_iterator(ents.begin() + e1));
         wd.assign(dchunks.begin() + we.front().d0, dchunks.begin() + we.back().d1);
         for (auto &f : wd) f.arc_off -= base;
         for (auto &e : we) for (auto &p : e.pieces) p.off -= base;
+    };
+    // Windows are pipelined against each other: the decoded entries of window k travel to the host (their own stream, their own pair of
+    // buffers) while window k + 1 is copied in and decoded; window k's entries are handed out once k + 1 has been launched, before k + 1's.
+    XDeferred pending; int slot = 0;
+    auto finish_pending = [&]() -> int {
+        if (!pending) return PNA_OK;
+        XDeferred f = std::move(pending); pending = XDeferred();
+        if (!f.issued) { const int r = f.issue(); if (r) return r; }
+        return f.deliver();
+    };
+    auto run_window = [&](const uint8_t *wa, size_t wlen, std::vector<XEntry> &we, std::vector<FrameDesc> &wd, std::vector<FrameDesc> &ws, std::vector<XSolid> &wso) -> int {
+        XDeferred cur;
+        int rc = extract_window(c, wa, wlen, password, password_len, cb, user, we, wd, ws, wso, keys, index, slot, &cur, pending ? &pending : nullptr);
+        const int rc2 = finish_pending();
+        if (rc == PNA_OK) rc = rc2;
+        if (rc != PNA_OK) { (void)hipDeviceSynchronize(); return rc; }
+        pending = std::move(cur); slot ^= 1;
+        return PNA_OK;
     };
     while (w0 < n_all || si < solids.size()) {
         std::vector<XEntry> we; std::vector<FrameDesc> wd, ws; std::vector<XSolid> wso;
@@ -1359,7 +1383,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
             for (auto &p : so.pieces) p.off -= base;
             const uint64_t span = so.hi - base;
             so.order = 0; wso.push_back(std::move(so)); si++;
-            int rc = extract_window(c, a + base, (size_t)span, password, password_len, cb, user, we, wd, ws, wso, keys, index);
+            int rc = run_window(a + base, (size_t)span, we, wd, ws, wso);
             if (rc) return rc;
             continue;
         }
@@ -1373,17 +1397,17 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         }
         const uint64_t base = ents[w0].lo, span = ents[w1 - 1].hi - base;
         rebase_run(w0, w1, we, wd, base);
-        int rc = extract_window(c, a + base, (size_t)span, password, password_len, cb, user, we, wd, ws, wso, keys, index);
+        int rc = run_window(a + base, (size_t)span, we, wd, ws, wso);
         if (rc) return rc;
         w0 = w1;
     }
-    return PNA_OK;
+    return finish_pending();
 }
 
 // One window of the driver above: `a` / archive_len are the window's bytes, every offset in ents / dchunks / schunks / solids is relative to it.
 static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, const void *password, size_t password_len, pna_entry_fn cb, void *user,
                           std::vector<XEntry> &ents, std::vector<FrameDesc> &dchunks, std::vector<FrameDesc> &schunks, std::vector<XSolid> &solids,
-                          XKeys &keys, size_t &index) {
+                          XKeys &keys, size_t &index, int slot, XDeferred *later, XDeferred *prev) {
     const size_t n = ents.size();
     // keys (one derivation per distinct PHSF string), layout of the packed payloads and of the decoded entries
     auto key_for = [&](const std::string &phsf, const uint8_t **out) -> int {
@@ -1514,8 +1538,11 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
     // ---- 3. device: upload, data-chunk CRCs, gather, decrypt, decode
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    static const bool xtrace = getenv("PNA_EXTRACT_TRACE") != nullptr;   // per-window phase times on stderr
+    const auto xt0 = std::chrono::steady_clock::now();
+    auto xms = [&](std::chrono::steady_clock::time_point a2) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a2).count(); };
     int rc = ensure_crc(c); if (rc) return rc;
-    if (c->x_arc.ensure(archive_len + 64) || c->x_pk.ensure(pk_total + 8192) || c->x_raw.ensure(raw_total + 64) || c->x_flag.ensure(64) ||
+    if (c->x_arc.ensure(archive_len + 64) || c->x_pk.ensure(pk_total + 8192) || c->x_raw[slot].ensure(raw_total + 64) || c->x_flag.ensure(64) ||
         c->x_desc.ensure(dchunks.size() * sizeof(FrameDesc) + 16) || c->x_place.ensure(places.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
     HIPCHK(c, hipMemcpyAsync(c->x_arc.p, a, archive_len, hipMemcpyHostToDevice, st));
     const uint32_t flag0[2] = {0u, 0xFFFFFFFFu};
@@ -1539,6 +1566,11 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
     HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
+    const double x_in = xms(xt0);
+    // This window's bytes are on the device: now the previous window's decoded entries start their way back, next to this window's
+    // decryption and decoding.  (Issued earlier, the two copies share the link -- H2D of 1 GiB next to D2H of 2.5 GiB took 67 ms, as long
+    // as one after the other -- and the kernels would again run with the link idle.)
+    if (prev && *prev && !prev->issued) { prev->issued = true; const int r = prev->issue(); if (r) return r; }
     if (flag[0]) { c->err = "data chunk CRC mismatch (" + std::to_string(flag[0]) + " FDAT / SDAT chunks)"; return PNA_E_INVAL; }
     if (!enc_idx.empty()) {
         // entries sharing a PHSF string and a mode share the key: one cipher call per group
@@ -1644,7 +1676,7 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
         std::vector<uint64_t> so, sl, dof, rl;
         for (const XEntry &e : ents) if (e.compression == algo && e.has_size) { so.push_back(e.pk_off); sl.push_back(e.pay_len); dof.push_back(e.raw_off); rl.push_back(e.raw_size); }
         if (so.empty()) continue;
-        rc = pna_gpu_decompress_batch_device(c, algo, so.size(), c->x_pk.p, so.data(), sl.data(), c->x_raw.p, dof.data(), rl.data(), st);
+        rc = pna_gpu_decompress_batch_device(c, algo, so.size(), c->x_pk.p, so.data(), sl.data(), c->x_raw[slot].p, dof.data(), rl.data(), st);
         if (rc) return rc;
     }
     for (size_t i : nosize_idx) {                                 // compatibility path, one decode call per entry
@@ -1729,34 +1761,72 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
             if (flag[0]) return fail(c, PNA_E_INVAL, "solid stream: inner FDAT CRC mismatch");
         }
     }
-    // ---- 4. back to the host, entries in archive order
-    if (c->hp_out[0].ensure(raw_total + 64) || c->hp_in[0].ensure(pk_total + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
-    if (raw_total) HIPCHK(c, hipMemcpyAsync(c->hp_out[0].p, c->x_raw.p, raw_total, hipMemcpyDeviceToHost, st));
+    // ---- 4. back to the host, entries in archive order.  Deferred form (no stored entries in the window): the D2H copy runs on its own
+    // stream behind the window's kernels and the hand-out happens later (see the driver); everything it needs moves into `D`.
     bool any_store = false; for (const XEntry &e : ents) any_store |= e.compression == PNA_ALGO_STORE && e.pay_len;
-    if (any_store) HIPCHK(c, hipMemcpyAsync(c->hp_in[0].p, c->x_pk.p, pk_total, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    size_t si = 0;
-    std::vector<uint8_t> joined;
-    auto deliver_solids = [&](size_t upto) -> int {
-        for (; si < solids.size() && solids[si].order <= upto; si++)
-            for (const Inner &ie : inner[si]) {
-                const uint8_t *d = plain[si].data();
-                if (ie.pieces.size() == 1) d += ie.pieces[0].off;
-                else { joined.clear(); for (const XPiece &p : ie.pieces) joined.insert(joined.end(), d + p.off, d + p.off + p.len); d = joined.data(); }
-                if (cb(user, index++, ie.name.c_str(), ie.kind, ie.len ? d : nullptr, (size_t)ie.len) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
-            }
-        return PNA_OK;
+    const bool defer = later != nullptr && !any_store;
+    if (xtrace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[pna extract window] %zu entries, %.0f MiB in -> %.0f MiB out: H2D + CRC + gather %.1f ms, decrypt + decode %.1f ms (slot %d, %s)\n", n, archive_len / 1048576.0, raw_total / 1048576.0, x_in, xms(xt0) - x_in, slot, defer ? "deferred hand-out" : "immediate"); }
+    if (c->hp_out[slot].ensure(raw_total + 64) || (any_store && c->hp_in[0].ensure(pk_total + 64))) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    const uint64_t raw_bytes = raw_total;
+    auto issue = [c, slot, raw_bytes]() -> int {                      // the window's kernels are complete on c->stream when this runs or are ordered before it by x_done
+        if (raw_bytes && hipMemcpyAsync(c->hp_out[slot].p, c->x_raw[slot].p, raw_bytes, hipMemcpyDeviceToHost, c->x_cp) != hipSuccess) return fail(c, PNA_E_HIP, "D2H copy failed");
+        return hipEventRecord(c->x_ev[slot], c->x_cp) == hipSuccess ? PNA_OK : fail(c, PNA_E_HIP, "D2H copy failed");
     };
-    for (size_t i = 0; i < n; i++) {
-        rc = deliver_solids(i); if (rc) return rc;
-        const XEntry &e = ents[i];
-        const uint8_t *d = e.compression == PNA_ALGO_STORE ? (const uint8_t *)c->hp_in[0].p + e.pk_off
-                         : (e.has_size ? (const uint8_t *)c->hp_out[0].p + e.raw_off : nosize_data[(size_t)e.raw_off].data());
-        const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
-        if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
-        if (cb(user, index++, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+    if (defer) {
+        if (!c->x_cp) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->x_cp, hipStreamNonBlocking));
+            for (auto &e : c->x_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->x_done, hipEventDisableTiming));
+        }
+        HIPCHK(c, hipEventRecord(c->x_done, st));
+        HIPCHK(c, hipStreamWaitEvent(c->x_cp, c->x_done, 0));
+    } else {
+        if (raw_total) HIPCHK(c, hipMemcpyAsync(c->hp_out[slot].p, c->x_raw[slot].p, raw_total, hipMemcpyDeviceToHost, st));
+        if (any_store) HIPCHK(c, hipMemcpyAsync(c->hp_in[0].p, c->x_pk.p, pk_total, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     }
-    return deliver_solids(n);
+    struct Deliver {
+        std::vector<XEntry> ents; std::vector<size_t> solid_order; std::vector<std::vector<Inner>> inner; std::vector<std::vector<uint8_t>> plain, nosize_data;
+        size_t index0 = 0;
+    };
+    auto D = std::make_shared<Deliver>();
+    D->index0 = index;
+    for (const XSolid &so : solids) D->solid_order.push_back(so.order);
+    index += n; for (const auto &v : inner) index += v.size();
+    D->ents = std::move(ents); D->inner = std::move(inner); D->plain = std::move(plain); D->nosize_data = std::move(nosize_data);
+    const uint8_t *raw_host = (const uint8_t *)c->hp_out[slot].p, *pk_host = (const uint8_t *)c->hp_in[0].p;
+    hipEvent_t wait_ev = defer ? c->x_ev[slot] : nullptr;
+    auto deliver = [c, cb, user, D, raw_host, pk_host, wait_ev]() -> int {
+        const auto dt0 = std::chrono::steady_clock::now();
+        if (wait_ev && hipEventSynchronize(wait_ev) != hipSuccess) return fail(c, PNA_E_HIP, "D2H copy failed");
+        const double dwait = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dt0).count();
+        struct Tr { double w; std::chrono::steady_clock::time_point t; ~Tr() { if (getenv("PNA_EXTRACT_TRACE")) fprintf(stderr, "[pna extract hand-out] waited %.1f ms for the D2H copy, callbacks %.1f ms\n", w, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } tr{dwait, std::chrono::steady_clock::now()};
+        size_t idx = D->index0, si = 0;
+        const size_t n = D->ents.size();
+        std::vector<uint8_t> joined;
+        auto deliver_solids = [&](size_t upto) -> int {
+            for (; si < D->solid_order.size() && D->solid_order[si] <= upto; si++)
+                for (const Inner &ie : D->inner[si]) {
+                    const uint8_t *d = D->plain[si].data();
+                    if (ie.pieces.size() == 1) d += ie.pieces[0].off;
+                    else { joined.clear(); for (const XPiece &p : ie.pieces) joined.insert(joined.end(), d + p.off, d + p.off + p.len); d = joined.data(); }
+                    if (cb(user, idx++, ie.name.c_str(), ie.kind, ie.len ? d : nullptr, (size_t)ie.len) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+                }
+            return PNA_OK;
+        };
+        for (size_t i = 0; i < n; i++) {
+            int rc = deliver_solids(i); if (rc) return rc;
+            const XEntry &e = D->ents[i];
+            const uint8_t *d = e.compression == PNA_ALGO_STORE ? pk_host + e.pk_off
+                             : (e.has_size ? raw_host + e.raw_off : D->nosize_data[(size_t)e.raw_off].data());
+            const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
+            if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
+            if (cb(user, idx++, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+        }
+        return deliver_solids(n);
+    };
+    if (defer) { later->issue = issue; later->deliver = deliver; later->issued = false; return PNA_OK; }
+    return deliver();
 }
 
 extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_t n, const void *const *src,
