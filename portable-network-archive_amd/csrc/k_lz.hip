@@ -99,10 +99,16 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint
 // diagnostic build only (STAMP = true): lane 0 of every wave accumulates s_memtime deltas per phase (sums over the 16 waves)
 __device__ unsigned long long g_lz_stamps[8];
 
-template <bool STAMP>
+// G = positions per lane and tile (groups of 64 positions per wave): the wave's G groups are ONE parse region of 64 G positions, a tile is
+// 1024 G positions.  Deflate runs G = 2 (k_dblock walks 2 KiB tiles), zstd G = LZ_G_ZSTD.
+template <bool STAMP, int G>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len) {
+    constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
+    constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : MAX_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -117,17 +123,17 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint32_t lazy = flags & F_LAZY;
     const bool force_serial = (flags & FLAG_FORCE_SERIAL) != 0;
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
-    const uint32_t wbase = wave * (64 * GROUPS_PER_WAVE); // tile-relative first position of this wave
+    const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
 
     for (uint32_t i = tid; i < (1u << HASH_LOG); i += LZ_THREADS) table[i] = 0;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
 
-    // initial window fill [0, TILE + LOOKAHEAD + 16); afterwards one TILE-sized chunk per tile: requested at the top of
+    // initial window fill [0, TILE_G + LOOKAHEAD + 16); afterwards one tile-sized chunk per tile: requested at the top of
     // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
-    // positions below t0 - 60400 < t0 - MAX_OFF, which no match of tile t can reference.
-    uint32_t loaded_end = TILE + LOOKAHEAD + 16;
+    // positions below t0 + 2 TILE_G + LOOKAHEAD + 16 - 64 Ki <= t0 - max_off, which no match of tile t can reference.
+    uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
     for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         *(uint4 *)(lds + L_WIN + i) = v;
@@ -148,12 +154,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
         uint32_t seq_run = 0, lit_run = 0;   // sequences / literals emitted so far
         uint32_t g_last1 = 1;                // 1 + literal index at the most recent match (0 literals before the block start)
 
-        for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE) {
-            const uint32_t t1 = (blk_end - t0 < TILE) ? blk_end : t0 + TILE;
+        for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
+            const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
             const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
 
             // ---- request the next tile's window chunk (consumed before B3)
-            if (tid < TILE / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
+            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
             LZ_STAMP(0);
 
 #ifdef LZ_EXP_PAD
@@ -173,10 +179,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
 #endif
             // ---- lookup
-            uint32_t q[2], lo[2], hi[2], hsh[2], tag[2], ent[2];
-            bool hv[2];
+            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G];
+            bool hv[G];
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
+            for (int r = 0; r < G; r++) {
                 q[r] = t0 + wbase + 64 * r + lane;
                 hv[r] = (q[r] < t1) && (q[r] + 8 <= seg_len);
                 fetch8(win32, q[r], lo[r], hi[r]);
@@ -185,18 +191,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 tag[r] = (h32 >> (32 - HASH_LOG - TAG_BITS)) & TAG_MASK;
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
-#ifdef LZ_WITH_B2
-            __syncthreads();                                                        // B2
-#endif
             LZ_STAMP(1);
 
-            // ---- insert + match
-            uint32_t len[2], off[2], flen[2];
-            uint64_t effm[2];
+            // ---- match (the inserts of this tile wait behind B3)
+            uint32_t len[G], off[G], flen[G];
+            uint64_t effm[G];
             auto do_match = [&](const int r) __attribute__((always_inline)) {
-#ifdef LZ_WITH_B2
-                if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
-#endif
                 uint32_t l = 0, o = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS;
                 // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
@@ -226,12 +226,14 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             };
             LZ_STAMP(2);
 
-            // ---- region-local parse of this wave's 128 positions, from the tile's carry if that reaches into them.  The
+            // ---- region-local parse of this wave's 64 G positions, from the tile's carry if that reaches into them.  The
             // scalar loop only picks the match starts; coverage masks are rebuilt afterwards with one cross-lane gather
             // per group (the scalar unit is the bottleneck of this kernel, the LDS crossbar is not).
             const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;             // tile-relative carry
-            uint64_t sel[2] = {0, 0}, cov[2];
-            uint32_t cur = c_in > wbase ? (c_in - wbase < 128u ? c_in - wbase : 128u) : 0u;
+            uint64_t sel[G], cov[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) sel[r] = 0;
+            uint32_t cur = c_in > wbase ? (c_in - wbase < RW ? c_in - wbase : RW) : 0u;
             uint32_t el = 0;                                                        // wave-relative end of the last selected match
             auto do_parse = [&](const int r) __attribute__((always_inline)) {
                 const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;             // positions covered by the carry / the previous group's last match
@@ -261,24 +263,29 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
                 cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
             };
-            // half of the waves of a SIMD run match(0) match(1) parse(0) parse(1), the other half match(0) parse(0) match(1)
-            // parse(1): vector-heavy and scalar-heavy stretches of different waves then overlap at the issue port (-3 %)
-            if ((wave >> 2) & 1) { do_match(0); do_match(1); do_parse(0); do_parse(1); }
-            else { do_match(0); do_parse(0); do_match(1); do_parse(1); }
+            // half of the waves of a SIMD run all matches, then all parses, the other half match / parse group by group:
+            // vector-heavy and scalar-heavy stretches of different waves then overlap at the issue port (-3 %)
+            if ((wave >> 2) & 1) {
+#pragma unroll
+                for (int r = 0; r < G; r++) do_match(r);
+#pragma unroll
+                for (int r = 0; r < G; r++) do_parse(r);
+            } else {
+#pragma unroll
+                for (int r = 0; r < G; r++) { do_match(r); do_parse(r); }
+            }
             LZ_STAMP(7);
-            if (tid < TILE / 16) {
+            if (tid < TILE_G / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
             }
-            loaded_end += TILE;
+            loaded_end += TILE_G;
             if (lane == 0) wend[wave] = el ? wbase + el : 0u;
             __syncthreads();                                                        // B3
-#ifndef LZ_WITH_B2
             // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
 #pragma unroll
-            for (int r = 0; r < 2; r++) if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
-#endif
+            for (int r = 0; r < G; r++) if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
             LZ_STAMP(3);
 
             // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E
@@ -291,7 +298,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t incl = row_scan_max(el_l);
                 const uint32_t before = DPP_ROW_SHR(incl, 1);                       // maximum over the earlier waves (0 for wave 0)
                 const uint32_t prev = before > c_in ? before : c_in;
-                const bool near = lv && el_l > prev && (el_l < prev + 3 || prev >= lane * 128 + 128);
+                const bool near = lv && el_l > prev && (el_l < prev + 3 || prev >= lane * RW + RW);
                 if (__ballot(near) == 0 && !force_serial) {
                     const uint32_t m = wave ? rdlane(incl, wave - 1) : 0u, ma = rdlane(incl, LZ_WAVES - 1);
                     E = m > c_in ? m : c_in;
@@ -301,60 +308,72 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     for (uint32_t j = 0; j < LZ_WAVES; j++) {
                         if (j == wave) E = x;
                         const uint32_t ej = rdlane(el_l, j);
-                        if (x < j * 128 + 128 && ej >= x + 3) x = ej;
+                        if (x < j * RW + RW && ej >= x + 3) x = ej;
                     }
                     tile_exit = x;
                 }
             }
             // ---- masks of the final selection
-            uint64_t fsel[2], litm[2];
-            uint32_t nsel0, nlit0;
+            uint64_t fsel[G], litm[G];
+            uint32_t nselp[G + 1], nlitp[G + 1];                                    // counts of the groups before group r
             {
-                const uint32_t Ew = E > wbase ? (E - wbase < 128u ? E - wbase : 128u) : 0u;    // wave-relative, 0..128
+                const uint32_t Ew = E > wbase ? (E - wbase < RW ? E - wbase : RW) : 0u;         // wave-relative, 0..RW
                 const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;       // in-range positions of the wave
-                const uint64_t K0 = mlow(Ew < 64 ? Ew : 64u), K1 = Ew > 64 ? mlow(Ew - 64) : 0;   // positions below E
-                fsel[0] = sel[0] & ~K0; fsel[1] = sel[1] & ~K1;
-                uint64_t cv0 = cov[0], cv1 = cov[1];
-                if (Ew > 0 && Ew < 128) {
+                uint64_t K[G], cv[G];                                               // positions below E; coverage
+#pragma unroll
+                for (int r = 0; r < G; r++) {
+                    const uint32_t e = Ew > 64u * r ? Ew - 64u * r : 0u;
+                    K[r] = mlow(e < 64 ? e : 64u); fsel[r] = sel[r] & ~K[r]; cv[r] = cov[r];
+                }
+                if (Ew > 0 && Ew < RW) {
                     const uint32_t grp = Ew >> 6, b = Ew & 63;
-                    const uint64_t cg = grp ? cov[1] : cov[0], sg = grp ? sel[1] : sel[0];
+                    uint64_t cg = cov[0], sg = sel[0];
+#pragma unroll
+                    for (int r = 1; r < G; r++) if (grp == (uint32_t)r) { cg = cov[r]; sg = sel[r]; }
                     if (((cg >> b) & 1) && !((sg >> b) & 1)) {
-                        // position E lies inside a match that starts below it: cut that match from the front
-                        const uint64_t below = sg & mlow(b);
-                        const uint32_t g2 = below ? grp : 0u;
-                        const uint32_t s2 = below ? 63 - clz64(below) : 63 - clz64(sel[0]);
-                        const uint32_t l2 = g2 ? rdlane(flen[1], s2) : rdlane(flen[0], s2);
-                        const uint32_t o2 = g2 ? rdlane(off[1], s2) : rdlane(off[0], s2);
+                        // position E lies inside a match that starts below it (the nearest selected start): cut that match from the front
+                        uint64_t below = sg & mlow(b);
+                        uint32_t g2 = grp;
+#pragma unroll
+                        for (int r = G - 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
+                        const uint32_t s2 = 63 - clz64(below);
+                        uint32_t l2 = rdlane(flen[0], s2), o2 = rdlane(off[0], s2);
+#pragma unroll
+                        for (int r = 1; r < G; r++) if (g2 == (uint32_t)r) { l2 = rdlane(flen[r], s2); o2 = rdlane(off[r], s2); }
                         const uint32_t end2 = 64 * g2 + s2 + l2;                    // wave-relative end of the straddling match
                         const uint32_t rmn = end2 - Ew;
                         if (rmn >= 3) {
-                            if (grp) { fsel[1] |= (uint64_t)1 << b; if (lane == b) { flen[1] = rmn; off[1] = o2; } }
-                            else     { fsel[0] |= (uint64_t)1 << b; if (lane == b) { flen[0] = rmn; off[0] = o2; } }
+#pragma unroll
+                            for (int r = 0; r < G; r++) if (grp == (uint32_t)r) { fsel[r] |= (uint64_t)1 << b; if (lane == b) { flen[r] = rmn; off[r] = o2; } }
                         } else {
                             // its last 1-2 bytes stay literals
-                            const uint32_t a0 = Ew < 64 ? Ew : 64u, z0 = end2 < 64 ? end2 : 64u;
-                            cv0 &= ~(mlow(z0) & ~mlow(a0));
-                            const uint32_t a1 = Ew > 64 ? Ew - 64 : 0u, z1 = end2 > 64 ? (end2 - 64 < 64 ? end2 - 64 : 64u) : 0u;
-                            cv1 &= ~(mlow(z1) & ~mlow(a1));
+#pragma unroll
+                            for (int r = 0; r < G; r++) {
+                                const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
+                                const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
+                                cv[r] &= ~(mlow(z0) & ~mlow(a0));
+                            }
                         }
                     }
                 }
-                litm[0] = mlow(in0) & ~(cv0 | K0);
-                litm[1] = mlow(in0 > 64 ? in0 - 64 : 0u) & ~(cv1 | K1);
-                nsel0 = (uint32_t)__popcll(fsel[0]);
-                const uint32_t nsel = nsel0 + (uint32_t)__popcll(fsel[1]);
-                nlit0 = (uint32_t)__popcll(litm[0]);
-                const uint32_t nlit = nlit0 + (uint32_t)__popcll(litm[1]);
+                nselp[0] = 0; nlitp[0] = 0;
+#pragma unroll
+                for (int r = 0; r < G; r++) {
+                    const uint32_t ir = in0 > 64u * r ? in0 - 64u * r : 0u;
+                    litm[r] = mlow(ir < 64 ? ir : 64u) & ~(cv[r] | K[r]);
+                    nselp[r + 1] = nselp[r] + (uint32_t)__popcll(fsel[r]);
+                    nlitp[r + 1] = nlitp[r] + (uint32_t)__popcll(litm[r]);
+                }
                 // local literal index of the wave's last match (+1), 0 when it has none; the same for its first match
                 // (needed by the chunk table only)
                 uint32_t gl = 0, gf = 0;
-                if (fsel[1]) { const uint32_t sp = 63 - clz64(fsel[1]); gl = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
-                else if (fsel[0]) { const uint32_t sp = 63 - clz64(fsel[0]); gl = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
+#pragma unroll
+                for (int r = G - 1; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
                 if (ctab) {
-                    if (fsel[0]) { const uint32_t sp = ctz64(fsel[0]); gf = 1 + (uint32_t)__popcll(litm[0] & mlow(sp)); }
-                    else if (fsel[1]) { const uint32_t sp = ctz64(fsel[1]); gf = 1 + nlit0 + (uint32_t)__popcll(litm[1] & mlow(sp)); }
+#pragma unroll
+                    for (int r = 0; r < G; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
                 }
-                if (lane == 0) { WPub p; p.cnt = nsel | (nlit << 16); p.gl = gl | (gf << 16); wpub[wave] = p; }
+                if (lane == 0) { WPub p; p.cnt = nselp[G] | (nlitp[G] << 16); p.gl = gl | (gf << 16); wpub[wave] = p; }
             }
             LZ_STAMP(5);
             __syncthreads();                                                        // B4
@@ -379,25 +398,35 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const uint64_t hm = __ballot(lv && pl.gl);
                     uint32_t g_first = lit_run + (tot >> 16);
                     if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
-                    if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE] = make_uint4(seq_run, lit_run, g_first, 0u);
+                    if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE_G) + (t0 - blk_start) / TILE_G] = make_uint4(seq_run, lit_run, g_first, 0u);
                 }
                 seq_run += tot & 0xFFFF; lit_run += tot >> 16;
                 next_free = t0 + tile_exit;
             }
             // ---- emission: all indices come from popcounts of the masks (no cross-lane data movement)
             {
-                const uint32_t sp0 = fsel[0] ? 63 - clz64(fsel[0]) : 0u;
-                const uint32_t tail0 = fsel[0] ? (uint32_t)__popcll(litm[0] & ~mlow(sp0 + 1)) : 0u;   // literals of group 0 after its last match
+                // literals between the wave's last match before group r and the start of group r (NONE: no match before it in this wave)
+                uint32_t since[G];
+                {
+                    uint32_t acc = NONE;
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const uint32_t lb = (r ? nlit0 : 0u) + (uint32_t)__popcll(litm[r] & lane_lt);     // literals of the wave before this lane
+                    for (int r = 0; r < G; r++) {
+                        since[r] = acc;
+                        if (fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); acc = (uint32_t)__popcll(litm[r] & ~mlow(sp + 1)); }
+                        else if (acc != NONE) acc += nlitp[r + 1] - nlitp[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < G; r++) {
+                    const uint32_t lq = (uint32_t)__popcll(litm[r] & lane_lt);       // literals of the group before this lane
+                    const uint32_t lb = nlitp[r] + lq;                               // ... of the wave
                     if ((fsel[r] >> lane) & 1) {
                         const uint64_t pm = fsel[r] & lane_lt;
                         uint32_t ll;
                         if (pm) { const uint32_t sp = 63 - clz64(pm); ll = (uint32_t)__popcll(litm[r] & lane_lt & ~mlow(sp + 1)); }
-                        else if (r == 1 && fsel[0]) ll = tail0 + (uint32_t)__popcll(litm[1] & lane_lt);
+                        else if (since[r] != NONE) ll = since[r] + lq;
                         else ll = lit_base + lb - (glast1_before - 1);
-                        const uint32_t idx = seq_base + (uint32_t)__popcll(pm) + (r ? nsel0 : 0u);
+                        const uint32_t idx = seq_base + nselp[r] + (uint32_t)__popcll(pm);
                         if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, flen[r], off[r]);
                     }
                     if ((litm[r] >> lane) & 1) { const uint32_t li = lit_base + lb; if (li < BLK_SIZE) blit[li] = (uint8_t)lo[r]; }
@@ -410,15 +439,22 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+template <int G>
+static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
+                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        return hipFuncSetAttribute((const void *)k_lz<true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL(k_lz<true>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
-    else hipLaunchKernelGGL(k_lz<false>, dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    else hipLaunchKernelGGL((k_lz<false, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+}
+// zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches two (k_dblock walks 2 KiB tiles)
+void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+    if (ctab || LZ_G_ZSTD == 2) launch_lz_g<2>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+    else launch_lz_g<LZ_G_ZSTD>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

@@ -19,7 +19,9 @@ constexpr uint32_t TILE       = 2048;       // positions matched per synchronous
 constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
 constexpr uint32_t HASH_LOG   = 14;
 constexpr uint32_t MIN_MATCH  = 6;
-constexpr uint32_t MAX_OFF    = 59392;      // 64 KiB window - 2 tiles - look-ahead - slack
+constexpr uint32_t LZ_G_ZSTD  = 4;          // positions per lane and tile of the zstd launches of k_lz (tile = 1024 x this; deflate: 2)
+constexpr uint32_t MAX_OFF_G2 = 59392;      // 64 KiB window - 2 tiles of 2 048 - look-ahead - slack
+constexpr uint32_t MAX_OFF    = LZ_G_ZSTD == 4 ? 56064 : MAX_OFF_G2;   // zstd: 64 KiB window - 2 tiles - look-ahead - slack
 constexpr uint32_t CAP1       = 16;
 constexpr uint32_t LOOKAHEAD  = 1024;
 constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
