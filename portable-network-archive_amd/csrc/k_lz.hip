@@ -9,10 +9,10 @@
 //   table [16384 x u32] hash table: (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
 //         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
 //   per-wave records (end of the wave's last match; counts)
-// Per tile of 2048 positions (2 per lane):
+// Per tile of 1024 G positions (G per lane: 4 for zstd -- tiles of 4 096, deflate 2):
 //   (next window chunk requested into registers) lookup -> match (the tile's inserts wait until every wave has looked up: they
 //   go behind B3, so lookups and inserts need no barrier of their own) +
-//   REGION-LOCAL parse: every wave parses its own 128 positions greedily from max(its first position, the tile's carry)
+//   REGION-LOCAL parse: every wave parses its own 64 G positions greedily from max(its first position, the tile's carry)
 //   with scalar loops on ballot masks, and publishes the end of its last match -> B3 -> inserts (ds_max_u32) -> MERGE: the running end E of the
 //   earlier waves' matches is a 16-lane prefix maximum (exact unless an end falls 1-2 bytes behind E: then a short serial
 //   scan); a wave entirely below E emits nothing, matches that end before E are dropped, the one straddling E is cut from
@@ -40,6 +40,7 @@ static_assert(sizeof(WPub) == 8, "LDS record size");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
 static_assert(CAP1 == 16, "the match step compares 8 + 8 bytes");
+static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
