@@ -15,4 +15,4 @@ for it in range(2):
     st = ctx.lz_stamps(); tm = ctx.timing()
     tot = sum(st)
     names = ["load", "lookup->B2", "insert+match", "wait B3 (+publish)", "wait B4", "merge+masks (own work)", "emit", "parse loops+coverage (own work)"]
-    print("lz ms", round(tm.ms_lz, 3), "cycles/tile/WG", round(tot / (n * 512 * 16)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})
+    print("lz ms", round(tm.ms_lz, 3), "cycles per 4096-position tile and wave", round(tot / (n * 256 * 16)), {k: f"{100 * v / tot:.1f}%" for k, v in zip(names, st)})
