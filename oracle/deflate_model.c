@@ -152,7 +152,6 @@ size_t pna_deflate_bound(size_t n) {
 
 void pna_deflate_default_params(pna_zstd_params *p) {
     pna_zstd_default_params(p);
-    p->tile = 2048; p->region = 128;                     /* the deflate launches keep 2 KiB tiles (k_dblock walks them) and 128-position regions */
     p->max_off = 32768; p->max_len = 258; p->flags = PNA_F_LAZY;
 }
 

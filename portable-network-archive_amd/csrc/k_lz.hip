@@ -101,7 +101,7 @@ __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint
 __device__ unsigned long long g_lz_stamps[8];
 
 // G = positions per lane and tile (groups of 64 positions per wave): the wave's G groups are ONE parse region of 64 G positions, a tile is
-// 1024 G positions.  Deflate runs G = 2 (k_dblock walks 2 KiB tiles), zstd G = LZ_G_ZSTD.
+// 1024 G positions (zstd: LZ_G_ZSTD, deflate: LZ_G_DEFLATE; the deflate chunk table keeps one entry per 2 KiB).
 template <bool STAMP, int G>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
@@ -109,7 +109,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : MAX_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
+    static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : MAX_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -394,12 +394,19 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
                 g_last1 = ga > g_last1 ? ga : g_last1;
                 if (ctab) {
-                    // chunk table: state of the block's sequence / literal streams at this tile's start and the
-                    // literal index of the tile's first match (lets later stages split a block by tiles)
+                    // chunk table (deflate): one entry per 2 KiB of positions (a tile holds CH = G / 2 of them, each the share of
+                    // 16 / CH consecutive waves): state of the block's sequence / literal streams at the chunk's start and the
+                    // literal index of the chunk's first match -- k_dblock packs a block chunk by chunk
+                    constexpr uint32_t CH = TILE_G / TILE, WPC = LZ_WAVES / CH;
                     const uint64_t hm = __ballot(lv && pl.gl);
-                    uint32_t g_first = lit_run + (tot >> 16);
-                    if (hm) { const uint32_t j0 = ctz64(hm); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
-                    if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE_G) + (t0 - blk_start) / TILE_G] = make_uint4(seq_run, lit_run, g_first, 0u);
+#pragma unroll
+                    for (uint32_t h = 0; h < CH; h++) {
+                        const uint32_t ex_h = rdlane(excl, h * WPC);
+                        const uint64_t hm_h = hm & (mlow(WPC) << (h * WPC));
+                        uint32_t g_first = lit_run + (tot >> 16);
+                        if (hm_h) { const uint32_t j0 = ctz64(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
+                        if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
+                    }
                 }
                 seq_run += tot & 0xFFFF; lit_run += tot >> 16;
                 next_free = t0 + tile_exit;
@@ -451,10 +458,10 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
     if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
     else hipLaunchKernelGGL((k_lz<false, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
 }
-// zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches two (k_dblock walks 2 KiB tiles)
+// zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
-    if (ctab || LZ_G_ZSTD == 2) launch_lz_g<2>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+    if (ctab) launch_lz_g<LZ_G_DEFLATE>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
     else launch_lz_g<LZ_G_ZSTD>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
 }
 

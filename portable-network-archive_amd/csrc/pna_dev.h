@@ -15,13 +15,14 @@ constexpr uint32_t BLK_PER_SEG = SEG_SIZE / BLK_SIZE;
 // LZ stage (k_lz)
 constexpr uint32_t LZ_THREADS = 1024;       // 16 waves, one workgroup per CU (LDS-bound)
 constexpr uint32_t LZ_WAVES   = LZ_THREADS / 64;
-constexpr uint32_t TILE       = 2048;       // positions matched per synchronous step of the DEFLATE launches (2 per lane; k_dblock walks these tiles)
+constexpr uint32_t TILE       = 2048;       // positions per entry of the deflate chunk table (k_dblock packs a block in chunks of this many positions); k_lz's own tile is 1024 G
 constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
 constexpr uint32_t HASH_LOG   = 14;
 constexpr uint32_t MIN_MATCH  = 6;
 #ifndef LZ_G_ZSTD_VALUE
 #define LZ_G_ZSTD_VALUE 4
 #endif
+constexpr uint32_t LZ_G_DEFLATE = 4;        // the same for the deflate launches (look-back 32 KiB: any G fits the window)
 constexpr uint32_t LZ_G_ZSTD  = LZ_G_ZSTD_VALUE;          // positions per lane and tile of the zstd launches of k_lz (tile = 1024 x this; deflate: 2)
 constexpr uint32_t MAX_OFF_G2 = 59392;      // 64 KiB window - 2 tiles of 2 048 - look-ahead - slack
 constexpr uint32_t MAX_OFF    = LZ_G_ZSTD == 2 ? MAX_OFF_G2 : 65536 - 2 * 1024 * LZ_G_ZSTD - 1024 - 16 - 240;   // zstd: 64 KiB window - 2 tiles - look-ahead - slack (G = 4: 56 064)
