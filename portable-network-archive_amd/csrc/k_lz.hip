@@ -9,7 +9,7 @@
 //   table [16384 x u32] hash table: (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
 //         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
 //   per-wave records (end of the wave's last match; counts)
-// Per tile of 1024 G positions (G per lane: 4 for zstd -- tiles of 4 096, deflate 2):
+// Per tile of 1024 G positions (G per lane; both codecs run G = 4: tiles of 4 096):
 //   (next window chunk requested into registers) lookup -> match (the tile's inserts wait until every wave has looked up: they
 //   go behind B3, so lookups and inserts need no barrier of their own) +
 //   REGION-LOCAL parse: every wave parses its own 64 G positions greedily from max(its first position, the tile's carry)
@@ -102,7 +102,8 @@ __device__ unsigned long long g_lz_stamps[8];
 
 // G = positions per lane and tile (groups of 64 positions per wave): the wave's G groups are ONE parse region of 64 G positions, a tile is
 // 1024 G positions (zstd: LZ_G_ZSTD, deflate: LZ_G_DEFLATE; the deflate chunk table keeps one entry per 2 KiB).
-template <bool STAMP, int G>
+// CT: the launch fills the deflate chunk table (a template parameter so that the zstd instance carries none of that code).
+template <bool STAMP, int G, bool CT>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len) {
@@ -126,7 +127,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
 
-    for (uint32_t i = tid; i < (1u << HASH_LOG); i += LZ_THREADS) table[i] = 0;
+    for (uint32_t i = tid; i < (1u << HASH_LOG) / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 64 KiB, 16 bytes per store
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
@@ -370,7 +371,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint32_t gl = 0, gf = 0;
 #pragma unroll
                 for (int r = G - 1; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
-                if (ctab) {
+                if (CT) {
 #pragma unroll
                     for (int r = 0; r < G; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
                 }
@@ -393,7 +394,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 glast1_before = gb > g_last1 ? gb : g_last1;
                 const uint32_t ga = rdlane(gmax, LZ_WAVES - 1);
                 g_last1 = ga > g_last1 ? ga : g_last1;
-                if (ctab) {
+                if (CT) {
                     // chunk table (deflate): one entry per 2 KiB of positions (a tile holds CH = G / 2 of them, each the share of
                     // 16 / CH consecutive waves): state of the block's sequence / literal streams at the chunk's start and the
                     // literal index of the chunk's first match -- k_dblock packs a block chunk by chunk
@@ -447,22 +448,22 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-template <int G>
+template <int G, bool CT>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        return hipFuncSetAttribute((const void *)k_lz<true, G, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
-    else hipLaunchKernelGGL((k_lz<false, G>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    else hipLaunchKernelGGL((k_lz<false, G, CT>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
-    if (ctab) launch_lz_g<LZ_G_DEFLATE>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
-    else launch_lz_g<LZ_G_ZSTD>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+    if (ctab) launch_lz_g<LZ_G_DEFLATE, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+    else launch_lz_g<LZ_G_ZSTD, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)
