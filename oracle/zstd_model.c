@@ -22,7 +22,7 @@
 static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 void pna_zstd_default_params(pna_zstd_params *p) {
-    p->hash_log = 14; p->min_match = 6; p->tile = 4096; p->max_off = 56064; p->cap1 = 16;
+    p->hash_log = 14; p->min_match = 6; p->tile = 4096; p->max_off = 56064; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 256;
 }
 

@@ -26,7 +26,10 @@ constexpr uint32_t LZ_G_DEFLATE = 4;        // the same for the deflate launches
 constexpr uint32_t LZ_G_ZSTD  = LZ_G_ZSTD_VALUE;          // positions per lane and tile of the zstd launches of k_lz (tile = 1024 x this; deflate: 2)
 constexpr uint32_t MAX_OFF_G2 = 59392;      // 64 KiB window - 2 tiles of 2 048 - look-ahead - slack
 constexpr uint32_t MAX_OFF    = LZ_G_ZSTD == 2 ? MAX_OFF_G2 : 65536 - 2 * 1024 * LZ_G_ZSTD - 1024 - 16 - 240;   // zstd: 64 KiB window - 2 tiles - look-ahead - slack (G = 4: 56 064)
-constexpr uint32_t CAP1       = 16;
+#ifndef LZ_CAP1_VALUE
+#define LZ_CAP1_VALUE 32
+#endif
+constexpr uint32_t CAP1       = LZ_CAP1_VALUE;
 constexpr uint32_t LOOKAHEAD  = 1024;
 constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
 constexpr uint32_t SEQ_CAP    = 22528;      // sequences per block: (BLK_SIZE - 3 * 1024) / MIN_MATCH + one front-cut match (>= 3 bytes) per wave region, rounded up to 256
