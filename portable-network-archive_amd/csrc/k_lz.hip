@@ -39,7 +39,7 @@ struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = 
 static_assert(sizeof(WPub) == 8, "LDS record size");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
-static_assert(CAP1 == 16 || CAP1 == 32, "the match step compares 16 bytes, and 16 more where those matched");
+static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 64, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
 static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -217,18 +217,21 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ __builtin_amdgcn_alignbit(d4, d3, shc);
                         const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
                         l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
-                        if (CAP1 == 32 && l == 16) {
-                            // bytes 16 .. 31, only for the lanes whose first 16 matched (same alignment as above): most capped matches end
-                            // here, which keeps them off the wave-cooperative extension in the parse loop
-                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2), *pq2 = win32 + (((q[r] + 16) & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                            const uint32_t g0 = pq2[0], g1 = pq2[1], g2 = pq2[2], g3 = pq2[3], g4 = pq2[4];
-                            const uint32_t y0 = __builtin_amdgcn_alignbit(g1, g0, shq) ^ __builtin_amdgcn_alignbit(f1, f0, shc);
-                            const uint32_t y1 = __builtin_amdgcn_alignbit(g2, g1, shq) ^ __builtin_amdgcn_alignbit(f2, f1, shc);
-                            const uint32_t y2 = __builtin_amdgcn_alignbit(g3, g2, shq) ^ __builtin_amdgcn_alignbit(f3, f2, shc);
-                            const uint32_t y3 = __builtin_amdgcn_alignbit(g4, g3, shq) ^ __builtin_amdgcn_alignbit(f4, f3, shc);
-                            const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-                            l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+#pragma unroll
+                        for (uint32_t k16 = 16; k16 < CAP1; k16 += 16) {
+                            if (l == k16) {
+                                // the next 16 bytes, only for the lanes where everything before matched (same alignment as above): most capped
+                                // matches end here, which keeps them off the wave-cooperative extension in the parse loop
+                                const uint32_t *pc2 = win32 + (((c + k16) & (WIN_BYTES - 1)) >> 2), *pq2 = win32 + (((q[r] + k16) & (WIN_BYTES - 1)) >> 2);
+                                const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                                const uint32_t g0 = pq2[0], g1 = pq2[1], g2 = pq2[2], g3 = pq2[3], g4 = pq2[4];
+                                const uint32_t y0 = __builtin_amdgcn_alignbit(g1, g0, shq) ^ __builtin_amdgcn_alignbit(f1, f0, shc);
+                                const uint32_t y1 = __builtin_amdgcn_alignbit(g2, g1, shq) ^ __builtin_amdgcn_alignbit(f2, f1, shc);
+                                const uint32_t y2 = __builtin_amdgcn_alignbit(g3, g2, shq) ^ __builtin_amdgcn_alignbit(f3, f2, shc);
+                                const uint32_t y3 = __builtin_amdgcn_alignbit(g4, g3, shq) ^ __builtin_amdgcn_alignbit(f4, f3, shc);
+                                const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
+                                l = k16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+                            }
                         }
                         l = l < lim ? l : lim;
                         if (l < MIN_MATCH) l = 0;
