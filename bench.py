@@ -287,7 +287,7 @@ def main() -> None:
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text per GPU, Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} "
-                                   f"(GPU encoder: hash_log 14, min_match 6, greedy+lazy1, 4096-position tiles), inputs resident in HBM, "
+                                   f"(GPU encoder: 24512-entry LDS hash table, min_match 6, greedy+lazy1, 4096-position tiles), inputs resident in HBM, "
                                    + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
                                       else "--solid: inner STORE records serialised + one compressed stream + SDAT framing, all in HBM" if args.framing == "solid"
                                       else "output = packed compressed entry streams in HBM"),

@@ -211,7 +211,7 @@ def model_lz_segment(seg: bytes, params: ZstdParams | None = None):
     L.pna_lz_block.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ZstdParams),
                                ctypes.POINTER(_Seq), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
-    table = (ctypes.c_uint32 * (1 << params.hash_log))()
+    table = (ctypes.c_uint32 * ((1 << params.hash_log) if params.hash_log <= 31 else params.hash_log))()
     out = []
     BLK = 1 << 17
     seqs = (_Seq * (BLK // 4))()

@@ -160,7 +160,8 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     if (n == 0) { static const uint8_t e[8] = {0x78,0x9C,0x03,0x00,0x00,0x00,0x00,0x01}; memcpy(dst, e, 8); return 8; }
     size_t op = 0;
     dst[op++] = 0x78; dst[op++] = 0x9C;
-    uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) << p->hash_log);
+    const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     uint32_t maxblk = PNA_SEG_SIZE / PNA_BLK_SIZE;
     pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (PNA_BLK_SIZE / 4));
     uint8_t *lits = (uint8_t *)malloc((size_t)PNA_SEG_SIZE + 8);
@@ -170,7 +171,7 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
-        memset(table, 0, sizeof(uint32_t) << p->hash_log);
+        memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t nb = 0;
         for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE, nb++) {
             uint32_t bl = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;

@@ -22,7 +22,7 @@
 static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 void pna_zstd_default_params(pna_zstd_params *p) {
-    p->hash_log = 14; p->min_match = 6; p->tile = 4096; p->max_off = 56064; p->cap1 = 32;
+    p->hash_log = 24512; p->min_match = 6; p->tile = 4096; p->max_off = 56064; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 256;
 }
 
@@ -43,7 +43,9 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
     if (min_match >= 5) hi = p[4];
     if (min_match >= 6) hi |= (uint32_t)p[5] << 8;
     uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA6Bu;
-    return h >> (32 - hash_log);
+    /* hash_log <= 31: a table of 2^hash_log entries, index = the top bits; larger values ARE the entry count (any size that fits the
+     * LDS): index = floor(h * count / 2^32) */
+    return hash_log <= 31 ? h >> (32 - hash_log) : (uint32_t)(((uint64_t)h * hash_log) >> 32);
 }
 
 /*
@@ -582,7 +584,8 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     if (cap < pna_zstd_bound(n)) return 0;
     size_t op = 0;
     if (n == 0) { static const uint8_t e[9] = {0x28,0xB5,0x2F,0xFD,0x20,0x00,0x01,0x00,0x00}; memcpy(dst, e, 9); return 9; }
-    uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) << p->hash_log);
+    const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     uint32_t maxblk = PNA_SEG_SIZE / PNA_BLK_SIZE;
     pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (PNA_BLK_SIZE / 4));
     uint8_t *lits = (uint8_t *)malloc((size_t)PNA_SEG_SIZE + 8);
@@ -590,7 +593,7 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
-        memset(table, 0, sizeof(uint32_t) << p->hash_log);
+        memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t b = 0;
         for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE, b++) {
             uint32_t bl = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;

@@ -24,7 +24,7 @@
 #define PNA_F_REP      8u           /* repeat-offset codes (block-local history)                */
 
 typedef struct {
-    uint32_t hash_log;    /* LDS hash table entries = 1 << hash_log (u32 each)                 */
+    uint32_t hash_log;    /* LDS hash table: <= 31: 1 << hash_log entries (u32 each); larger: the entry count itself */
     uint32_t min_match;   /* bytes hashed and minimum match length (4..6)                       */
     uint32_t tile;        /* positions matched per synchronous step                             */
     uint32_t max_off;     /* largest usable offset (bytes kept in the LDS look-back window)     */

@@ -3,10 +3,10 @@
 // Replaces the match finder inside the third-party encoder the reference drives at
 // lib/src/compress.rs:32-41 (CompressionWriter::write -> ZstdEncoder::write).  Integer/byte work, no MFMA.
 //
-// LDS (one workgroup per CU, ~129 KiB of the 160 KiB):
+// LDS (one workgroup per CU, 163 792 of the 163 840 bytes):
 //   win   [65536 + 16 B]  circular copy of the segment's most recent 64 KiB (look-back + 1 KiB look-ahead); the first
 //         16 bytes are mirrored behind the end so that unaligned reads never wrap
-//   table [16384 x u32] hash table: (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
+//   table [24512 x u32] hash table (what fits next to the window): (position+1) << 11 | 11-bit tag of the latest occurrence (0 = empty);
 //         inserts are ds_max_u32, the tag lets a lookup skip candidates whose 6 bytes cannot match
 //   per-wave records (end of the wave's last match; counts)
 // Per tile of 1024 G positions (G per lane; both codecs run G = 4: tiles of 4 096):
@@ -31,12 +31,13 @@ constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr uint32_t L_WIN    = 0;
 constexpr uint32_t WIN_MIRROR = 16;                        // the window's first 16 bytes again behind its end: unaligned reads never wrap
 constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
-constexpr uint32_t L_WEND   = L_TABLE + (4u << HASH_LOG);   // 16 x u32: tile-relative end of each wave's last match (0 = none)
+constexpr uint32_t L_WEND   = L_TABLE + 4u * HASH_ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
 constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
 constexpr uint32_t L_TOTAL  = L_WPUB + 8 * LZ_WAVES;
 
 struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
 static_assert(sizeof(WPub) == 8, "LDS record size");
+static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
 static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 64, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
@@ -127,7 +128,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
 
-    for (uint32_t i = tid; i < (1u << HASH_LOG) / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 64 KiB, 16 bytes per store
+    for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 16 bytes per store
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
@@ -189,8 +190,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 hv[r] = (q[r] < t1) && (q[r] + 8 <= seg_len);
                 fetch8(win32, q[r], lo[r], hi[r]);
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
-                hsh[r] = h32 >> (32 - HASH_LOG);
-                tag[r] = (h32 >> (32 - HASH_LOG - TAG_BITS)) & TAG_MASK;
+                hsh[r] = __umulhi(h32, HASH_ENTRIES);                               // floor(h32 * entries / 2^32): any table size
+                tag[r] = (h32 >> 6) & TAG_MASK;                                     // a filter only: any function of the hash will do
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
             LZ_STAMP(1);

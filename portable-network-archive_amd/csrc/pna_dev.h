@@ -17,7 +17,10 @@ constexpr uint32_t LZ_THREADS = 1024;       // 16 waves, one workgroup per CU (L
 constexpr uint32_t LZ_WAVES   = LZ_THREADS / 64;
 constexpr uint32_t TILE       = 2048;       // positions per entry of the deflate chunk table (k_dblock packs a block in chunks of this many positions); k_lz's own tile is 1024 G
 constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
-constexpr uint32_t HASH_LOG   = 14;
+#ifndef LZ_HASH_ENTRIES_VALUE
+#define LZ_HASH_ENTRIES_VALUE 24512
+#endif
+constexpr uint32_t HASH_ENTRIES = LZ_HASH_ENTRIES_VALUE;   // LDS hash table of k_lz: as many u32 entries as fit next to the 64 KiB window (index = mulhi(hash, entries))
 constexpr uint32_t MIN_MATCH  = 6;
 #ifndef LZ_G_ZSTD_VALUE
 #define LZ_G_ZSTD_VALUE 4
