@@ -279,7 +279,7 @@ int  pna_gpu_debug_block(pna_gpu_ctx *ctx, uint32_t block, uint64_t *seqs, uint3
  * CPU-only tests use it to check the table construction; it is not on any product path. */
 uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len);
 
-/* Diagnostic build of the LZ kernel (ctx created with flag 0x100): per-phase s_memtime sums of wave 0, cleared on read. */
+/* Diagnostic build of the LZ kernel (ctx created with flag 0x100): per-phase s_memtime sums over all waves, cleared on read. */
 int  pna_gpu_debug_lz_stamps(pna_gpu_ctx *ctx, unsigned long long *out8);
 
 /* ---- benchmark support (not part of the reference's surface): fills d_dst with `n_files` synthetic files of
