@@ -143,7 +143,8 @@ def main() -> None:
     if args.framing != "archive" or pieces < 1 or n_files % pieces:
         pieces = 1
     n_piece = n_files // pieces
-    first_file = [(h * world + rank) * n_piece for h in range(pieces)]
+    shard_mod = importlib.import_module("portable-network-archive_amd.shard")
+    first_file = [lo for lo, _ in shard_mod.piece_ranges(rank, world, pieces, n_piece)]
     for h in range(pieces):
         ctx.corpus_fill_device(args.kind, first_file[h], n_piece, file_len, stride, src.data_ptr() + h * n_piece * stride)
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]

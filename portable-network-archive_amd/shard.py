@@ -29,6 +29,13 @@ def partition_entries(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]
     return bounds
 
 
+def piece_ranges(rank: int, world: int, pieces: int, per_piece: int) -> List[Tuple[int, int]]:
+    """Weak-scaling layout with piecewise gathers: piece h of rank r holds the entries [(h * world + r) * per_piece, ... + per_piece).
+    In archive order all ranks' pieces 0 come first (in rank order), then all pieces 1, ...: each piece can be gathered in rank order as
+    soon as it is compressed, and the concatenation of the gathered pieces is the archive."""
+    return [((h * world + rank) * per_piece, (h * world + rank + 1) * per_piece) for h in range(pieces)]
+
+
 def gather_ordered(local, local_bytes: int, rank: int, world: int, out=None):
     """Gather every rank's first `local_bytes` bytes of the uint8 tensor `local` onto rank 0, in rank order.
 

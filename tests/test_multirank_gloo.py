@@ -38,6 +38,21 @@ def _worker(rank, world, port, q):
     h = shard.gather_ordered_start(blob, sum(len(m) for m in mine), rank, world)
     got2, shard_bytes2 = shard.gather_ordered_wait(h)
     assert shard_bytes2 == shard_bytes and (rank != 0 or bytes(got2.numpy().tobytes()) == bytes(got.numpy().tobytes()))
+    # two gathers in flight at once, each into its own destination -- what bench.py does with --gather-pieces 2 (piece 0 travels while
+    # piece 1 is compressed into the other buffer)
+    half = len(mine) // 2
+    pa, pb = b"".join(mine[:half]), b"".join(mine[half:])
+    ta = torch.frombuffer(bytearray(pa or b"\0"), dtype=torch.uint8); tb = torch.frombuffer(bytearray(pb or b"\0"), dtype=torch.uint8)
+    ha = shard.gather_ordered_start(ta, len(pa), rank, world)
+    hb = shard.gather_ordered_start(tb, len(pb), rank, world)
+    ga, sa = shard.gather_ordered_wait(ha)
+    gb, sb = shard.gather_ordered_wait(hb)
+    la = torch.tensor([len(pa), len(pb)], dtype=torch.int64); alls = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(alls, la)
+    assert sa == [int(x[0]) for x in alls] and sb == [int(x[1]) for x in alls]
+    if rank == 0:
+        assert bytes(ga.numpy().tobytes())[:len(pa)] == pa and bytes(gb.numpy().tobytes())[:len(pb)] == pb
+        assert len(ga) == sum(sa) and len(gb) == sum(sb)
     all_lens = [torch.zeros(bounds[r][1] - bounds[r][0], dtype=torch.int64) for r in range(world)]
     dist.all_gather(all_lens, lens) if len({b[1] - b[0] for b in bounds}) == 1 else None
     if len({b[1] - b[0] for b in bounds}) != 1:          # ragged shards: gather lengths by object
@@ -68,6 +83,20 @@ def test_partition_properties():
         assert all(b[i][1] == b[i + 1][0] for i in range(world - 1)) and all(s <= e for s, e in b)
     b = shard.partition_entries([1 << 20] * 10000, 8)
     assert all(e - s == 1250 for s, e in b)
+
+
+def test_piece_ranges_tile_the_archive_in_gather_order():
+    """bench.py --gather-pieces: walking the pieces in gather order (piece-major, rank-minor) must walk the corpus front to back."""
+    import importlib
+    shard = importlib.import_module("portable-network-archive_amd.shard")
+    for world, pieces, per in ((1, 1, 10000), (2, 2, 5000), (8, 2, 5000), (4, 4, 7), (3, 1, 5)):
+        pos = 0
+        for h in range(pieces):
+            for r in range(world):
+                lo, hi = shard.piece_ranges(r, world, pieces, per)[h]
+                assert lo == pos and hi == lo + per
+                pos = hi
+        assert pos == world * pieces * per
 
 
 @pytest.mark.timeout(180)
