@@ -68,12 +68,24 @@ __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t
     __syncthreads();
     const int nn = 2 * n - 1;
     if (tid == 0) {
+        // two-queue merge, n - 1 dependent steps on one lane.  The two heads of each queue are kept in registers (the leaf queue is read
+        // one element ahead, a new internal node enters the head registers directly when the queue is that short), so no step waits for
+        // an LDS round trip; weights are < 2^31, INF marks an exhausted / not yet filled head.  Same picks, same order as
+        // `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
+        constexpr uint32_t INF = 0xFFFFFFFFu;
         int lq = 0, iq = n, m = n;
+        uint32_t l0 = wt[0], l1 = n > 1 ? wt[1] : INF, i0 = INF, i1 = INF;
+        auto take = [&](uint32_t &w) -> int {
+            if (l0 != INF && l0 <= i0) { w = l0; const int a = lq++; l0 = l1; l1 = (lq + 1 < n) ? wt[lq + 1] : INF; return a; }
+            w = i0; const int a = iq++; i0 = i1; i1 = (iq + 1 < m) ? wt[iq + 1] : INF; return a;
+        };
         while (m < nn) {
-            int a, b;
-            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
-            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
-            wt[m] = wt[a] + wt[b]; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; m++;
+            uint32_t wa, wb;
+            const int a = take(wa), b = take(wb);
+            const uint32_t sum = wa + wb;
+            wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m;
+            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum;      // the new node is (or follows) the head of the internal queue
+            m++;
         }
     }
     __syncthreads();
