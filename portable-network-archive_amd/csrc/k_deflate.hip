@@ -214,16 +214,38 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     // token starts: a non-zero length is its own token; a run of R zeros is R / 138 tokens "18 x 138", then one "18" (rest >= 11), one
     // "17" (rest >= 3) or the rest as literal zeros -- what the greedy left-to-right scan produces
     uint32_t tsym[2] = {0, 0}, text[2] = {0, 0}, tidx[2] = {0, 0}; bool tst[2] = {false, false};
+    // the zero runs' ends come from ballots instead of walks along the run (a 4 KiB entry leaves runs of a hundred zeros and more, and every
+    // lane of a run walked all of it): per (round, wave) the first / last position that is non-zero -- or beyond n, which ends a run too
+    __shared__ int16_t nz_first[8], nz_last[8];
+    uint32_t vv[2]; uint64_t nzm[2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+        const uint32_t i = (uint32_t)c2 * DS_THREADS + tid;
+        vv[c2] = i < n ? (uint32_t)seq[i] : 1u;
+        nzm[c2] = __ballot(vv[c2] != 0);
+        if (lane == 0) {
+            const int base = c2 * (int)DS_THREADS + (int)wv * 64;
+            nz_first[c2 * 4 + wv] = nzm[c2] ? (int16_t)(base + __builtin_ctzll(nzm[c2])) : (int16_t)-1;
+            nz_last[c2 * 4 + wv] = nzm[c2] ? (int16_t)(base + 63 - __builtin_clzll(nzm[c2])) : (int16_t)-1;
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int c2 = 0; c2 < 2; c2++) {
         const uint32_t i = (uint32_t)c2 * DS_THREADS + tid;
         if (i < n) {
-            const uint32_t v = seq[i];
+            const uint32_t v = vv[c2];
             if (v) { tst[c2] = true; tsym[c2] = v; }
             else {
-                uint32_t a = i, e = i;
-                while (a > 0 && seq[a - 1] == 0) a--;
-                while (e + 1 < n && seq[e + 1] == 0) e++;
+                const int slot = c2 * 4 + (int)wv, base = c2 * (int)DS_THREADS + (int)wv * 64;
+                const uint64_t lt = ((uint64_t)1 << lane) - 1;
+                const uint64_t below = nzm[c2] & lt, above = nzm[c2] & ~(lt | ((uint64_t)1 << lane));
+                int pb = -1, pa = (int)n;                                  // nearest run-ending position below / above (position n always ends a run)
+                if (below) pb = base + 63 - __builtin_clzll(below);
+                else for (int s2 = slot - 1; s2 >= 0; s2--) if (nz_last[s2] >= 0) { pb = nz_last[s2]; break; }
+                if (above) pa = base + __builtin_ctzll(above);
+                else for (int s2 = slot + 1; s2 < 8; s2++) if (nz_first[s2] >= 0) { pa = nz_first[s2]; break; }
+                const uint32_t a = (uint32_t)(pb + 1), e = (uint32_t)(pa - 1);
                 const uint32_t R = e - a + 1, o = i - a, q = R / 138, rem = R - q * 138;
                 if (o < q * 138) { tst[c2] = (o % 138) == 0; tsym[c2] = 18; text[c2] = 138 - 11; }
                 else if (rem >= 11) { tst[c2] = o == q * 138; tsym[c2] = 18; text[c2] = rem - 11; }
