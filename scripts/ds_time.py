@@ -1,3 +1,6 @@
+"""Stage-1 time (k_dstats + k_adler) of the deflate path on 131 072 x 4 KiB entries for each library given on the command line: python scripts/ds_time.py lib1.so lib2.so ...
+Used for phase timing by early exits: variants of k_deflate.hip with a temporary `return` behind the histogram / the code builds / the code assignment,
+built with scripts/build_variant2.sh NAME k_deflate.hip (the exits are not kept in the tree)."""
 import importlib, os, sys, subprocess
 child = r'''
 import importlib, os, sys
