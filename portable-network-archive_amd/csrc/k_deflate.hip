@@ -115,27 +115,46 @@ __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t
     __syncthreads();
     return n;
 }
-// canonical codes, bit-reversed; out[s] = code | len << 16.  Workgroup-wide: code of s = first code of its length + number of
-// lower-numbered symbols of the same length.
-__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, const uint16_t *used, int n_used,
-                         uint32_t tid, uint32_t nthr) {
-    if (tid == 0) {
-        int bl_count[16];
-        for (int b = 0; b < 16; b++) bl_count[b] = 0;
-        for (int k = 0; k < n_used; k++) bl_count[lens[used[k]]]++;        // unused symbols have length 0
-        bl_count[0] = 0;
-        int code = 0; first[0] = 0;
-        for (int b = 1; b <= 15; b++) { code = (code + bl_count[b - 1]) << 1; first[b] = (uint32_t)code; }
+// canonical codes, bit-reversed; out[s] = code | len << 16.  Workgroup-wide (256 threads, symbol s on thread s mod 256 of round s / 256):
+// code of s = first code of its length + number of lower-numbered symbols of the same length.  That rank comes from one ballot per code
+// length -- lanes below in the wave, plus the counts of the earlier waves / rounds from LDS -- instead of every symbol looping over all
+// others.  cntw: 9 x 16 words of scratch.
+__device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, uint32_t *cntw, uint32_t tid) {
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    uint32_t myl[2], myrank[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int sy = r * 256 + (int)tid;
+        const uint32_t l = sy < nsym ? (uint32_t)lens[sy] : 0u;
+        myl[r] = l; uint32_t rk = 0;
+        for (uint32_t L = 1; L <= 15; L++) {
+            const uint64_t m = __ballot(l == L);
+            if (l == L) rk = (uint32_t)__popcll(m & lt);
+            if (lane == 0) cntw[(r * 4 + wv) * 16 + L] = (uint32_t)__popcll(m);
+        }
+        myrank[r] = rk;
     }
-    for (int s = (int)tid; s < nsym; s += (int)nthr) out[s] = 0;
     __syncthreads();
-    for (int k = (int)tid; k < n_used; k += (int)nthr) {
-        const int s = used[k];
-        const uint32_t l = lens[s];
-        if (l) {
-            uint32_t c = first[l];
-            for (int j = 0; j < n_used; j++) { const int o = used[j]; c += (o < s && lens[o] == l) ? 1u : 0u; }
-            out[s] = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
+    if (tid >= 1 && tid < 16) { uint32_t c = 0; for (int k = 0; k < 8; k++) c += cntw[k * 16 + tid]; cntw[8 * 16 + tid] = c; }   // symbols per length
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t code = 0; first[0] = 0;
+        for (int b = 1; b <= 15; b++) { code = (code + (b > 1 ? cntw[8 * 16 + b - 1] : 0u)) << 1; first[b] = code; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int sy = r * 256 + (int)tid;
+        if (sy < nsym) {
+            const uint32_t l = myl[r];
+            uint32_t v = 0;
+            if (l) {
+                uint32_t c = first[l] + myrank[r];
+                for (uint32_t k = 0; k < (uint32_t)r * 4 + wv; k++) c += cntw[k * 16 + l];
+                v = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
+            }
+            out[sy] = v;
         }
     }
     __syncthreads();
@@ -153,7 +172,8 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     __shared__ uint32_t cl_code[19];
     __shared__ uint32_t ll_code_s[288], d_code_s[32], first_s[16], sh2[2], hsh[3];
     __shared__ uint16_t used_ll[288], used_d[32], used_cl[20];
-    __shared__ uint32_t hbuf[104], wsum[8], wsum2[8];
+    __shared__ uint32_t hbuf[104], wsum[8], wsum2[8], cntw_s[9 * 16];
+    static_assert(DS_THREADS == 256, "d_assign lays 2 x 256 symbols over the workgroup");
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     DeflTables *T = tabs + blockIdx.x;
@@ -192,10 +212,10 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         dc[tid] = tid < 30 ? h_dist[0][tid] + h_dist[1][tid] + h_dist[2][tid] + h_dist[3][tid] : 0u;
     }
     __syncthreads();
-    const int n_ll = d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, used_ll, tid, DS_THREADS);
-    const int n_d = d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, used_d, tid, DS_THREADS);
-    d_assign(ll_len, 286, ll_code_s, first_s, used_ll, n_ll, tid, DS_THREADS);
-    d_assign(d_len, 30, d_code_s, first_s, used_d, n_d, tid, DS_THREADS);
+    (void)d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, used_ll, tid, DS_THREADS);
+    (void)d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, used_d, tid, DS_THREADS);
+    d_assign(ll_len, 286, ll_code_s, first_s, cntw_s, tid);
+    d_assign(d_len, 30, d_code_s, first_s, cntw_s, tid);
     for (uint32_t i = tid; i < 288; i += DS_THREADS) T->ll_code[i] = i < 286 ? ll_code_s[i] : 0u;
     if (tid < 32) T->d_code[tid] = tid < 30 ? d_code_s[tid] : 0u;
     // table description: run-length tokens of the code lengths, their 19-symbol code, the header bits -- all of it on the whole
@@ -275,7 +295,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         n_cl = 2;
         __syncthreads();
     }
-    d_assign(cl_len, 19, cl_code, first_s, used_cl, n_cl, tid, DS_THREADS);
+    d_assign(cl_len, 19, cl_code, first_s, cntw_s, tid);
     int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;
     // bit lengths of the tokens -> positions (two packed scans of 256) -> ORed into the header image in LDS
     auto put_bits = [&](uint32_t pos, uint32_t v, uint32_t nb2) {       // nb2 <= 14: at most two words
