@@ -145,7 +145,9 @@ class ZstdParams(ctypes.Structure):
     """Mirror of pna_zstd_params (oracle/zstd_model.h)."""
     _fields_ = [("hash_log", ctypes.c_uint32), ("min_match", ctypes.c_uint32), ("tile", ctypes.c_uint32),
                 ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
-                ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32), ("region", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32), ("region", ctypes.c_uint32),
+                ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
+                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4

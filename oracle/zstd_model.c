@@ -22,8 +22,9 @@
 static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 void pna_zstd_default_params(pna_zstd_params *p) {
-    p->hash_log = 24512; p->min_match = 6; p->tile = 4096; p->max_off = 56064; p->cap1 = 32;
+    p->hash_log = 24512; p->min_match = 6; p->tile = 4096; p->max_off = 1u << 20; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 256;
+    p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 56064; p->cap_far = 16;
 }
 
 size_t pna_zstd_bound(size_t n) {
@@ -51,13 +52,21 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
 /*
  * One 128 KiB block.  For each tile of p->tile positions, in this order:
  *   L  every position q with q + 8 <= seg_len looks up cand[q] = table[hash(q)] (value = position+1, 0 = empty);
- *   I  every such position stores table[hash(q)] = max(old, q+1)   (ascending q here == atomic max on the GPU);
- *   M  len[q] = length of the common prefix of seg[q..] and seg[c..] (c = cand-1), capped to cap1 and to the
- *      block end; a candidate is usable iff cand != 0 and q - c <= max_off; len < min_match counts as 0;
+ *   M  len[q] = length of the common prefix of seg[q..] and seg[c..] (c = cand-1), capped to cap(q) and to the block end;
+ *      a candidate is usable iff cand != 0 and q - c <= max_off; len < min_match counts as 0.  cap(q) = cap1 when the offset
+ *      q - c <= near_off (the candidate lies in the GPU's LDS window) and cap_far otherwise (the candidate is read from
+ *      HBM/L2).  For a usable match back[q] = number of equal bytes immediately before q and c, at most min(back_cap, c);
+ *   A  backward adoption, rounds of shift s (the nibbles of p->rounds, lowest first; the GPU's DPP lane shifts): all positions
+ *      at once, from the values of the previous round: position q with (q & 63) + s <= 63 adopts the match of j = q + s --
+ *      len[q] = len[j] + s (not capped again), cand[q] = cand[j] - s, back[q] = back[j] - s, same cap kind -- iff
+ *      len[j] >= min_match, back[j] >= s and len[j] + s > len[q].  (A match found one or two positions late -- the table
+ *      holds every ins_mod-th position only -- is thereby moved to its true start.)
+ *   I  every position q with q + 8 <= seg_len and q % ins_mod == 0 stores table[hash(q)] = max(old, q+1)   (ascending q here
+ *      == atomic max on the GPU; after L for the whole tile, so the positions of one tile do not see each other);
  *   P  region-local greedy parse.  The tile is cut into regions of p->region positions (what one GPU wave owns; region 0
  *      = the whole tile).  Every region is parsed on its own, in ascending q from max(region start, next_free): position q
  *      starts a match iff len[q] >= min_match and not (LAZY and (q & 63) != 63 and q+1 < tile end and len[q+1] > len[q]);
- *      a chosen match whose len == cap1 is extended byte-wise up to min(block end, tile end + lookahead) (and max_len);
+ *      a chosen match whose len >= its cap is extended byte-wise up to min(block end, tile end + lookahead) (and max_len);
  *      the region's parse continues at q + len and stops at the region end (its last match may reach beyond it).
  *   F  merge of the regions in ascending order against the running end E of the emitted matches (E = next_free at the
  *      tile start): a region that lies entirely below E contributes nothing; otherwise a match that ends at or before E
@@ -75,6 +84,10 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     uint32_t T = p->tile;
     uint32_t *cand = (uint32_t *)malloc(sizeof(uint32_t) * T);
     uint16_t *len = (uint16_t *)malloc(sizeof(uint16_t) * (T + 1));
+    uint8_t *back = (uint8_t *)calloc(2 * (T + 1), 1), *far = back + T + 1;      /* back[q]; far[q] = 1: cap kind cap_far */
+    uint16_t *len0 = (uint16_t *)malloc(sizeof(uint16_t) * (T + 1)); uint32_t *cand0 = (uint32_t *)malloc(sizeof(uint32_t) * T);
+    uint8_t *back0 = (uint8_t *)malloc(2 * (T + 1)), *far0 = back0 + T + 1;
+    const uint32_t ins_mod = p->ins_mod ? p->ins_mod : 1;
     uint32_t *mq = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1) * 4), *ml = mq + T + 1, *mc = ml + T + 1, *mr = mc + T + 1;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
         uint32_t t1 = t0 + T < blk_end ? t0 + T : blk_end;
@@ -85,20 +98,34 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         for (uint32_t q = t0; q < t1; q++)
             if (q + 8 <= seg_len) {
                 uint32_t h = lz_hash(seg + q, p->min_match, p->hash_log);
-                if (table[h] < q + 1) table[h] = q + 1;
+                if (q % ins_mod == 0 && table[h] < q + 1) table[h] = q + 1;
             }
         /* M */
         for (uint32_t q = t0; q < t1; q++) {
-            uint32_t c1 = cand[q - t0], l = 0;
+            uint32_t c1 = cand[q - t0], l = 0, bk = 0, fr = 0;
             if (c1 != 0 && q - (c1 - 1) <= p->max_off) {
                 uint32_t c = c1 - 1, lim = blk_end - q;
-                if (lim > p->cap1) lim = p->cap1;
+                fr = p->near_off && q - c > p->near_off;
+                uint32_t cap = fr ? p->cap_far : p->cap1;
+                if (lim > cap) lim = cap;
                 while (l < lim && seg[q + l] == seg[c + l]) l++;
                 if (l < p->min_match) l = 0;
+                if (l) while (bk < p->back_cap && bk < c && seg[q - 1 - bk] == seg[c - 1 - bk]) bk++;
             }
-            len[q - t0] = (uint16_t)l;
+            len[q - t0] = (uint16_t)l; back[q - t0] = (uint8_t)bk; far[q - t0] = (uint8_t)(l ? fr : 0);
         }
         len[t1 - t0] = 0;
+        /* A */
+        for (uint32_t rr = p->rounds; rr; rr >>= 4) {
+            const uint32_t sft = rr & 15;
+            memcpy(len0, len, sizeof(uint16_t) * (T + 1)); memcpy(cand0, cand, sizeof(uint32_t) * T); memcpy(back0, back, 2 * (T + 1));
+            for (uint32_t q = t0; q + sft < t1; q++) {
+                const uint32_t j = q + sft - t0;
+                if ((q & 63) + sft > 63 || len0[j] < p->min_match || back0[j] < sft || len0[j] + sft <= len0[q - t0]) continue;
+                len[q - t0] = (uint16_t)(len0[j] + sft); cand[q - t0] = cand0[j] - sft;
+                back[q - t0] = (uint8_t)(back0[j] - sft); far[q - t0] = far0[j];
+            }
+        }
         /* P */
         uint32_t ext_lim = t1 + p->lookahead < blk_end ? t1 + p->lookahead : blk_end;
         uint32_t R = p->region ? p->region : T;
@@ -111,7 +138,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
                 if (!take) { q++; continue; }
                 uint32_t c = cand[q - t0] - 1;
-                if (l == p->cap1) {
+                if (l >= (far[q - t0] ? p->cap_far : p->cap1)) {
                     uint32_t el = ext_lim;
                     if (p->max_len && q + p->max_len < el) el = q + p->max_len;
                     while (q + l < el && seg[q + l] == seg[c + l]) l++;
@@ -135,7 +162,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         }
     }
     memcpy(lits + nlit, seg + lit_start, blk_end - lit_start); nlit += blk_end - lit_start;
-    free(cand); free(len); free(mq);
+    free(cand); free(len); free(mq); free(back); free(len0); free(cand0); free(back0);
     *nlit_out = nlit;
     return nseq;
 }

@@ -27,12 +27,17 @@ typedef struct {
     uint32_t hash_log;    /* LDS hash table: <= 31: 1 << hash_log entries (u32 each); larger: the entry count itself */
     uint32_t min_match;   /* bytes hashed and minimum match length (4..6)                       */
     uint32_t tile;        /* positions matched per synchronous step                             */
-    uint32_t max_off;     /* largest usable offset (bytes kept in the LDS look-back window)     */
+    uint32_t max_off;     /* largest usable offset (zstd: the whole 1 MiB segment; deflate: 32 KiB) */
     uint32_t cap1;        /* per-position match length cap before cooperative extension         */
     uint32_t lookahead;   /* bytes beyond the tile end that an extension may read               */
     uint32_t flags;       /* PNA_F_*                                                            */
     uint32_t max_len;     /* longest match (0 = only limited by the look-ahead); 258 for deflate          */
     uint32_t region;      /* positions parsed as one unit (128 = one GPU wave); 0 = one exact greedy parse per tile */
+    uint32_t ins_mod;     /* only positions q with q % ins_mod == 0 enter the hash table (0 / 1 = all)                      */
+    uint32_t back_cap;    /* bytes a match may be known to continue backwards (0 = no backward adoption)                    */
+    uint32_t rounds;      /* backward adoption rounds: nibbles = lane shifts, lowest first (0x21 = shift 1, then shift 2)   */
+    uint32_t near_off;    /* offsets above it are "far" (outside the GPU's LDS window): per-position cap cap_far; 0 = none  */
+    uint32_t cap_far;     /* per-position match length cap of far candidates                                                */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */

@@ -19,7 +19,14 @@
 //   the front (>= 3 bytes must remain),
 //   everything else stands -> selection / literal masks -> counts -> B4 -> 16-lane DPP scans of the waves' counts ->
 //   emission of sequences and literals straight to HBM.
-//   Cross-lane traffic on this path: ballots, readlanes, DPP and one ds_bpermute per 64 positions.
+//   Cross-lane traffic on this path: ballots, readlanes, DPP and two ds_bpermute per 64 positions.
+// Look-back beyond the LDS window: the table keeps positions of the whole 1 MiB segment (20 bits + 1), a candidate more than
+//   NEAR_OFF bytes back ("far") is verified against the segment in HBM / L2 -- its 16 + 4 bytes are requested right behind the
+//   table look-ups and consumed after the near candidates of the tile went through the LDS path.
+// Table load: only EVEN positions are inserted (half the pressure on 24 512 slots); a match that is therefore found one or
+//   two positions late is moved back to its true start by BACKWARD ADOPTION: every match knows how many bytes (<= 3) before it
+//   also agree with its candidate, and two DPP rounds (lane + 1, then lane + 2) let a position take over its right
+//   neighbours' matches, one / two bytes longer.
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
@@ -40,7 +47,7 @@ static_assert(sizeof(WPub) == 8, "LDS record size");
 static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
-static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 64, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
+static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && CAP_FAR == 16 && BACK_CAP == 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
 static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -74,13 +81,19 @@ __device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) 
     return __builtin_amdgcn_alignbit(p[1], p[0], (pos & 3) * 8);
 }
 
-// Wave-cooperative extension of a match that reached CAP1: q, c, lim are wave-uniform; returns the full length
-// (<= lim).  64 lanes x 4 bytes per step.
-__device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, uint32_t q, uint32_t c, uint32_t lim, uint32_t lane) {
-    uint32_t L = CAP1;
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any byte address
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+// Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
+// full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
+// segment in HBM / L2 (c + lim < q, so every address is inside the segment).
+template <bool FARC>
+__device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, const uint8_t *seg, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
+    uint32_t L = L0;
     for (;;) {
         uint32_t pos = L + lane * 4;
-        uint32_t x = fetch4(win32, q + pos) ^ fetch4(win32, c + pos);
+        const uint32_t cw = FARC ? *(const u32u *)(seg + c + pos) : fetch4(win32, c + pos);
+        uint32_t x = fetch4(win32, q + pos) ^ cw;
         uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
         uint32_t room = lim > pos ? lim - pos : 0u;
         nb = nb < room ? nb : room;
@@ -111,7 +124,9 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : MAX_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
+    constexpr bool FAR = !CT;                               // deflate offsets (<= 32 KiB) never leave the LDS window
+    constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : NEAR_OFF;
+    static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : NEAR_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -182,46 +197,77 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
 #endif
             // ---- lookup
-            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G];
+            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G];
             bool hv[G];
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 q[r] = t0 + wbase + 64 * r + lane;
                 hv[r] = (q[r] < t1) && (q[r] + 8 <= seg_len);
-                fetch8(win32, q[r], lo[r], hi[r]);
+                {
+                    const uint32_t *p = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);    // p[1], p[2] may lie in the mirror
+                    const uint32_t sh = (q[r] & 3) * 8;
+                    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], dm = win32[((q[r] - 4) & (WIN_BYTES - 1)) >> 2];
+                    lo[r] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                    hi[r] = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    bq[r] = __builtin_amdgcn_alignbit(d0, dm, sh);                  // the 4 bytes before q (q - 1 in the top byte)
+                }
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
                 hsh[r] = __umulhi(h32, HASH_ENTRIES);                               // floor(h32 * entries / 2^32): any table size
                 tag[r] = (h32 >> 6) & TAG_MASK;                                     // a filter only: any function of the hash will do
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
+            // ---- far candidates (beyond the LDS window): request their 16 + 4 bytes from the segment now, use them after the near ones
+            U4u fa[G]; uint32_t fm[G];
+            if (FAR) {
+#pragma unroll
+                for (int r = 0; r < G; r++) {
+                    const uint32_t c1 = ent[r] >> TAG_BITS, c = c1 - 1, o = q[r] - c;
+                    fa[r].x = fa[r].y = fa[r].z = fa[r].w = 0; fm[r] = 0;
+                    if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r] && o > NEAR && o <= max_off) {
+                        fa[r] = *(const U4u *)(seg + c);
+                        fm[r] = c >= 4 ? *(const u32u *)(seg + c - 4) : (*(const u32u *)seg << ((32u - 8u * c) & 31u));
+                    }
+                }
+            }
             LZ_STAMP(1);
 
             // ---- match (the inserts of this tile wait behind B3)
             uint32_t len[G], off[G], flen[G];
-            uint64_t effm[G];
+            uint64_t effm[G], cpm[G];                                               // cpm: matches that reached their cap (extended when selected)
             auto do_match = [&](const int r) __attribute__((always_inline)) {
-                uint32_t l = 0, o = 0;
+                uint32_t l = 0, o = 0, bk = 0;
+                bool isfar = false;
                 const uint32_t c1 = ent[r] >> TAG_BITS;
                 // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
                 if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r]) {
                     uint32_t c = c1 - 1; o = q[r] - c;
                     if (o <= max_off) {
-                        uint32_t lim = blk_end - q[r]; lim = lim < CAP1 ? lim : CAP1;
+                        isfar = FAR && o > NEAR;
+                        const uint32_t cap = isfar ? CAP_FAR : CAP1;
+                        uint32_t lim = blk_end - q[r]; lim = lim < cap ? lim : cap;
                         // all 16 bytes at once: in a wave of 64 candidates some lane nearly always needs bytes 8..15, so a
                         // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
-                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2), *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
+                        const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
                         const uint32_t shc = (c & 3) * 8, shq = (q[r] & 3) * 8;
-                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4];
+                        uint32_t w0, w1, w2, w3, bc;                                // 16 bytes at c, the 4 bytes before c
+                        if (isfar) { w0 = fa[r].x; w1 = fa[r].y; w2 = fa[r].z; w3 = fa[r].w; bc = fm[r]; }
+                        else {
+                            const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
+                            const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
+                            w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                            w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                            bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                        }
                         const uint32_t e2 = pq[2], e3 = pq[3], e4 = pq[4];
-                        const uint32_t x0 = lo[r] ^ __builtin_amdgcn_alignbit(d1, d0, shc), x1 = hi[r] ^ __builtin_amdgcn_alignbit(d2, d1, shc);
-                        const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ __builtin_amdgcn_alignbit(d3, d2, shc);
-                        const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ __builtin_amdgcn_alignbit(d4, d3, shc);
+                        const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
+                        const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ w2;
+                        const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ w3;
                         const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
                         l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
 #pragma unroll
                         for (uint32_t k16 = 16; k16 < CAP1; k16 += 16) {
-                            if (l == k16) {
-                                // the next 16 bytes, only for the lanes where everything before matched (same alignment as above): most capped
+                            if (l == k16 && !isfar) {
+                                // the next 16 bytes, only for the (near) lanes where everything before matched (same alignment as above): most capped
                                 // matches end here, which keeps them off the wave-cooperative extension in the parse loop
                                 const uint32_t *pc2 = win32 + (((c + k16) & (WIN_BYTES - 1)) >> 2), *pq2 = win32 + (((q[r] + k16) & (WIN_BYTES - 1)) >> 2);
                                 const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
@@ -236,9 +282,28 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         }
                         l = l < lim ? l : lim;
                         if (l < MIN_MATCH) l = 0;
+                        // bytes before q and c that agree as well (nearest first), at most BACK_CAP and never before the segment start
+                        const uint32_t xk = bq[r] ^ bc;
+                        bk = xk ? (uint32_t)__builtin_clz(xk) >> 3 : 4u;
+                        bk = bk < BACK_CAP ? bk : BACK_CAP; bk = bk < c ? bk : c;
                     }
                 }
+                // ---- backward adoption.  K = len << 5 | far << 4 | back << 2 | lanes the match was moved by
+                uint32_t K = l ? (l << 5) | (isfar ? 16u : 0u) | (bk << 2) : 0u;
+                {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
+                    const uint32_t K1 = dpp_next_lane(K), T = K1 + 29u;
+                    const bool ok = K1 >= (MIN_MATCH << 5) && (K1 & 0xCu) != 0 && (T >> 5) > (K >> 5);
+                    K = ok ? T : K;
+                }
+                {   // round 2: the match two lanes to the right (after round 1), two bytes longer
+                    const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 58u;
+                    const bool ok = K2 >= (MIN_MATCH << 5) && (K2 & 0x8u) != 0 && (T >> 5) > (K >> 5);
+                    K = ok ? T : K;
+                }
+                l = K >> 5;
+                o = (uint32_t)__shfl((int)o, (int)(lane + (K & 3u)));               // the offset travels with the match
                 len[r] = l; off[r] = o; flen[r] = l;
+                cpm[r] = __ballot(l >= ((K & 16u) ? CAP_FAR : CAP1));
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)
                 const bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
                 effm[r] = __ballot(eff);
@@ -259,13 +324,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
                 uint32_t e_last = e0;
                 const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
-                const uint64_t capm = __ballot(len[r] == CAP1);
+                const uint64_t capm = cpm[r];
                 while (rem) {
                     const uint32_t s = ctz64(rem);
                     uint32_t e = rdlane(endp, s);
                     if ((capm >> s) & 1) {
-                        const uint32_t qs = t0 + wbase + 64 * r + s;
-                        const uint32_t L = lz_extend(win32, qs, qs - rdlane(off[r], s), (ext_lim - qs < max_len ? ext_lim - qs : max_len), lane);
+                        const uint32_t qs = t0 + wbase + 64 * r + s, os = rdlane(off[r], s), L0 = e - s;
+                        const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
+                        const uint32_t L = (FAR && os > NEAR) ? lz_extend<true>(win32, seg, qs, qs - os, L0, xl, lane)
+                                                              : lz_extend<false>(win32, seg, qs, qs - os, L0, xl, lane);
                         if (lane == s) flen[r] = L;
                         e = s + L;
                     }
@@ -304,7 +371,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             __syncthreads();                                                        // B3
             // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
 #pragma unroll
-            for (int r = 0; r < G; r++) if (hv[r]) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+            for (int r = 0; r < G; r++) if (hv[r] && !(lane & 1)) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);   // even positions only
             LZ_STAMP(3);
 
             // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E
