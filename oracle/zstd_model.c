@@ -24,7 +24,7 @@ static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; 
 void pna_zstd_default_params(pna_zstd_params *p) {
     p->hash_log = 24512; p->min_match = 6; p->tile = 4096; p->max_off = 1u << 20; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 256;
-    p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 56064; p->cap_far = 16;
+    p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 56064; p->cap_far = 32;
 }
 
 size_t pna_zstd_bound(size_t n) {
@@ -53,9 +53,9 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
  * One 128 KiB block.  For each tile of p->tile positions, in this order:
  *   L  every position q with q + 8 <= seg_len looks up cand[q] = table[hash(q)] (value = position+1, 0 = empty);
  *   M  len[q] = length of the common prefix of seg[q..] and seg[c..] (c = cand-1), capped to cap(q) and to the block end;
- *      a candidate is usable iff cand != 0 and q - c <= max_off; len < min_match counts as 0.  cap(q) = cap1 when the offset
+ *      a candidate is usable iff c >= 4 and q - c <= max_off; len < min_match counts as 0.  cap(q) = cap1 when the offset
  *      q - c <= near_off (the candidate lies in the GPU's LDS window) and cap_far otherwise (the candidate is read from
- *      HBM/L2).  For a usable match back[q] = number of equal bytes immediately before q and c, at most min(back_cap, c);
+ *      HBM/L2).  For a usable match back[q] = number of equal bytes immediately before q and c, at most back_cap (<= 4);
  *   A  backward adoption, rounds of shift s (the nibbles of p->rounds, lowest first; the GPU's DPP lane shifts): all positions
  *      at once, from the values of the previous round: position q with (q & 63) + s <= 63 adopts the match of j = q + s --
  *      len[q] = len[j] + s (not capped again), cand[q] = cand[j] - s, back[q] = back[j] - s, same cap kind -- iff
@@ -103,14 +103,14 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         /* M */
         for (uint32_t q = t0; q < t1; q++) {
             uint32_t c1 = cand[q - t0], l = 0, bk = 0, fr = 0;
-            if (c1 != 0 && q - (c1 - 1) <= p->max_off) {
+            if (c1 > 4 && q - (c1 - 1) <= p->max_off) {                  /* candidates at positions 0..3 are not used: 4 bytes before a candidate always exist */
                 uint32_t c = c1 - 1, lim = blk_end - q;
                 fr = p->near_off && q - c > p->near_off;
                 uint32_t cap = fr ? p->cap_far : p->cap1;
                 if (lim > cap) lim = cap;
                 while (l < lim && seg[q + l] == seg[c + l]) l++;
                 if (l < p->min_match) l = 0;
-                if (l) while (bk < p->back_cap && bk < c && seg[q - 1 - bk] == seg[c - 1 - bk]) bk++;
+                if (l) while (bk < p->back_cap && seg[q - 1 - bk] == seg[c - 1 - bk]) bk++;
             }
             len[q - t0] = (uint16_t)l; back[q - t0] = (uint8_t)bk; far[q - t0] = (uint8_t)(l ? fr : 0);
         }

@@ -30,6 +30,12 @@
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
+#ifdef LZ_EXP_ALLINS
+#define LZ_INS_COND true
+#else
+#define LZ_INS_COND !(lane & 1)
+#endif
+
 namespace pna {
 
 constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
@@ -47,7 +53,7 @@ static_assert(sizeof(WPub) == 8, "LDS record size");
 static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
-static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && CAP_FAR == 16 && BACK_CAP == 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
+static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
 static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -124,7 +130,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
+#ifdef LZ_EXP_NOFAR
+    constexpr bool FAR = false; max_off = max_off < NEAR_OFF ? max_off : NEAR_OFF;   // timing experiment: no look-back beyond the LDS window
+#else
     constexpr bool FAR = !CT;                               // deflate offsets (<= 32 KiB) never leave the LDS window
+#endif
     constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : NEAR_OFF;
     static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : NEAR_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -216,94 +226,97 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 tag[r] = (h32 >> 6) & TAG_MASK;                                     // a filter only: any function of the hash will do
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
-            // ---- far candidates (beyond the LDS window): request their 16 + 4 bytes from the segment now, use them after the near ones
-            U4u fa[G]; uint32_t fm[G];
-            if (FAR) {
+            // ---- candidates: offset (0 = none: empty slot, foreign tag -- a candidate whose tag differs hashed differently, so its first
+            // 6 bytes differ --, position below 4, beyond max_off).  Far candidates (beyond the LDS window) get the 4 bytes before and the
+            // 16 bytes at the candidate requested from the segment now; the other lanes read the segment's first bytes (one line, no
+            // exec masking), which nobody looks at.  A usable candidate lies at position >= 4, so the load never reaches below the segment.
+            uint32_t off[G];
+            U4u fa[G]; uint32_t fb[G];
 #pragma unroll
-                for (int r = 0; r < G; r++) {
-                    const uint32_t c1 = ent[r] >> TAG_BITS, c = c1 - 1, o = q[r] - c;
-                    fa[r].x = fa[r].y = fa[r].z = fa[r].w = 0; fm[r] = 0;
-                    if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r] && o > NEAR && o <= max_off) {
-                        fa[r] = *(const U4u *)(seg + c);
-                        fm[r] = c >= 4 ? *(const u32u *)(seg + c - 4) : (*(const u32u *)seg << ((32u - 8u * c) & 31u));
-                    }
+            for (int r = 0; r < G; r++) {
+                fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = 0;
+                const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
+                off[r] = (c1 > 4 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
+                if (FAR && seg_len > NEAR) {                                        // (uniform) shorter segments have no far candidates
+                    const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
+                    fa[r] = *(const U4u *)(seg + fo);
+                    fb[r] = *(const u32u *)(seg + fo + 16);
                 }
             }
             LZ_STAMP(1);
 
             // ---- match (the inserts of this tile wait behind B3)
-            uint32_t len[G], off[G], flen[G];
-            uint64_t effm[G], cpm[G];                                               // cpm: matches that reached their cap (extended when selected)
+            uint32_t len[G], flen[G];
+            uint64_t effm[G];
             auto do_match = [&](const int r) __attribute__((always_inline)) {
-                uint32_t l = 0, o = 0, bk = 0;
-                bool isfar = false;
-                const uint32_t c1 = ent[r] >> TAG_BITS;
-                // a candidate whose tag differs hashed differently, so its first 6 bytes differ: no match possible
-                if (c1 != 0 && (ent[r] & TAG_MASK) == tag[r]) {
-                    uint32_t c = c1 - 1; o = q[r] - c;
-                    if (o <= max_off) {
-                        isfar = FAR && o > NEAR;
-                        const uint32_t cap = isfar ? CAP_FAR : CAP1;
-                        uint32_t lim = blk_end - q[r]; lim = lim < cap ? lim : cap;
-                        // all 16 bytes at once: in a wave of 64 candidates some lane nearly always needs bytes 8..15, so a
-                        // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
-                        const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
-                        const uint32_t shc = (c & 3) * 8, shq = (q[r] & 3) * 8;
-                        uint32_t w0, w1, w2, w3, bc;                                // 16 bytes at c, the 4 bytes before c
-                        if (isfar) { w0 = fa[r].x; w1 = fa[r].y; w2 = fa[r].z; w3 = fa[r].w; bc = fm[r]; }
-                        else {
-                            const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
-                            w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
-                            w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
-                            bc = __builtin_amdgcn_alignbit(d0, dm, shc);
-                        }
-                        const uint32_t e2 = pq[2], e3 = pq[3], e4 = pq[4];
-                        const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
-                        const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ w2;
-                        const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ w3;
-                        const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
-                        l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
-#pragma unroll
-                        for (uint32_t k16 = 16; k16 < CAP1; k16 += 16) {
-                            if (l == k16 && !isfar) {
-                                // the next 16 bytes, only for the (near) lanes where everything before matched (same alignment as above): most capped
-                                // matches end here, which keeps them off the wave-cooperative extension in the parse loop
-                                const uint32_t *pc2 = win32 + (((c + k16) & (WIN_BYTES - 1)) >> 2), *pq2 = win32 + (((q[r] + k16) & (WIN_BYTES - 1)) >> 2);
-                                const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                                const uint32_t g0 = pq2[0], g1 = pq2[1], g2 = pq2[2], g3 = pq2[3], g4 = pq2[4];
-                                const uint32_t y0 = __builtin_amdgcn_alignbit(g1, g0, shq) ^ __builtin_amdgcn_alignbit(f1, f0, shc);
-                                const uint32_t y1 = __builtin_amdgcn_alignbit(g2, g1, shq) ^ __builtin_amdgcn_alignbit(f2, f1, shc);
-                                const uint32_t y2 = __builtin_amdgcn_alignbit(g3, g2, shq) ^ __builtin_amdgcn_alignbit(f3, f2, shc);
-                                const uint32_t y3 = __builtin_amdgcn_alignbit(g4, g3, shq) ^ __builtin_amdgcn_alignbit(f4, f3, shc);
-                                const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-                                l = k16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
-                            }
-                        }
-                        l = l < lim ? l : lim;
-                        if (l < MIN_MATCH) l = 0;
-                        // bytes before q and c that agree as well (nearest first), at most BACK_CAP and never before the segment start
-                        const uint32_t xk = bq[r] ^ bc;
-                        bk = xk ? (uint32_t)__builtin_clz(xk) >> 3 : 4u;
-                        bk = bk < BACK_CAP ? bk : BACK_CAP; bk = bk < c ? bk : c;
+                uint32_t l = 0, bk4 = 0;                                            // bk4 = 4 x (bytes before q and c that agree as well, <= 3)
+                const uint32_t o = off[r];
+                if (o != 0) {
+                    const uint32_t c = q[r] - o;
+                    const bool isfar = FAR && o > NEAR;
+                    uint32_t lim = blk_end - q[r]; lim = lim < CAP1 ? lim : CAP1;
+                    // all 16 bytes at once: in a wave of 64 candidates some lane nearly always needs bytes 8..15, so a
+                    // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
+                    const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
+                    const uint32_t shc = (c & 3) * 8, shq = (q[r] & 3) * 8;
+                    uint32_t w0, w1, w2, w3, bc;                                    // 16 bytes at c, the 4 bytes before c
+                    if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; }
+                    else {
+                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
+                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
+                        w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                        w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                        bc = __builtin_amdgcn_alignbit(d0, dm, shc);
                     }
+                    const uint32_t e2 = pq[2], e3 = pq[3], e4 = pq[4];
+                    const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
+                    const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ w2;
+                    const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ w3;
+                    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
+                    l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+#pragma unroll
+                    for (uint32_t k16 = 16; k16 < CAP1; k16 += 16) {
+                        if (l == k16) {
+                            // the next 16 bytes, only for the lanes where everything before matched (same alignment as above): most capped
+                            // matches end here, which keeps them off the wave-cooperative extension in the parse loop.  Far candidates
+                            // fetch theirs from the segment now (rare: a few lanes per tile, and the line is usually still in L1 / L2)
+                            const uint32_t *pq2 = win32 + (((q[r] + k16) & (WIN_BYTES - 1)) >> 2);
+                            const uint32_t g0 = pq2[0], g1 = pq2[1], g2 = pq2[2], g3 = pq2[3], g4 = pq2[4];
+                            uint32_t v0, v1, v2, v3;
+                            if (isfar) { const U4u t = *(const U4u *)(seg + c + k16); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+                            else {
+                                const uint32_t *pc2 = win32 + (((c + k16) & (WIN_BYTES - 1)) >> 2);
+                                const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                                v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                                v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
+                            }
+                            const uint32_t y0 = __builtin_amdgcn_alignbit(g1, g0, shq) ^ v0, y1 = __builtin_amdgcn_alignbit(g2, g1, shq) ^ v1;
+                            const uint32_t y2 = __builtin_amdgcn_alignbit(g3, g2, shq) ^ v2, y3 = __builtin_amdgcn_alignbit(g4, g3, shq) ^ v3;
+                            const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
+                            l = k16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+                        }
+                    }
+                    l = l < lim ? l : lim;
+                    if (l < MIN_MATCH) l = 0;
+                    // bytes before q and c that agree as well, nearest first: the low byte forced to differ caps the count at BACK_CAP = 3
+                    bk4 = ((uint32_t)__builtin_clz((bq[r] ^ bc) | 0xFFu) >> 1) & 0xCu;
                 }
-                // ---- backward adoption.  K = len << 5 | far << 4 | back << 2 | lanes the match was moved by
-                uint32_t K = l ? (l << 5) | (isfar ? 16u : 0u) | (bk << 2) : 0u;
+                // ---- backward adoption.  K = len << 5 | back << 2 | lanes the match was moved by.  A lane without a match may carry a stray
+                // back count and adopt "lengths" of 1..3 from such neighbours: they stay below MIN_MATCH and nobody reads them as a match.
+                uint32_t K = (l << 5) | bk4;
+#ifndef LZ_EXP_NOADOPT
                 {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
                     const uint32_t K1 = dpp_next_lane(K), T = K1 + 29u;
-                    const bool ok = K1 >= (MIN_MATCH << 5) && (K1 & 0xCu) != 0 && (T >> 5) > (K >> 5);
-                    K = ok ? T : K;
+                    K = ((K1 & 0xCu) != 0 && T > (K | 31u)) ? T : K;
                 }
                 {   // round 2: the match two lanes to the right (after round 1), two bytes longer
                     const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 58u;
-                    const bool ok = K2 >= (MIN_MATCH << 5) && (K2 & 0x8u) != 0 && (T >> 5) > (K >> 5);
-                    K = ok ? T : K;
+                    K = ((K2 & 0x8u) != 0 && T > (K | 31u)) ? T : K;
                 }
                 l = K >> 5;
-                o = (uint32_t)__shfl((int)o, (int)(lane + (K & 3u)));               // the offset travels with the match
-                len[r] = l; off[r] = o; flen[r] = l;
-                cpm[r] = __ballot(l >= ((K & 16u) ? CAP_FAR : CAP1));
+                off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 3u)));          // the offset travels with the match
+#endif
+                len[r] = l; flen[r] = l;
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)
                 const bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
                 effm[r] = __ballot(eff);
@@ -324,14 +337,18 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint64_t rem = e0 < 64 ? effm[r] & (~(uint64_t)0 << e0) : 0;
                 uint32_t e_last = e0;
                 const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
-                const uint64_t capm = cpm[r];
+                const uint64_t capm = __ballot(len[r] >= CAP1);
                 while (rem) {
                     const uint32_t s = ctz64(rem);
                     uint32_t e = rdlane(endp, s);
                     if ((capm >> s) & 1) {
                         const uint32_t qs = t0 + wbase + 64 * r + s, os = rdlane(off[r], s), L0 = e - s;
                         const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
+                        #ifdef LZ_EXP_NOFAREXT
+                        const uint32_t L = (FAR && os > NEAR) ? L0
+#else
                         const uint32_t L = (FAR && os > NEAR) ? lz_extend<true>(win32, seg, qs, qs - os, L0, xl, lane)
+#endif
                                                               : lz_extend<false>(win32, seg, qs, qs - os, L0, xl, lane);
                         if (lane == s) flen[r] = L;
                         e = s + L;
@@ -349,6 +366,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
                 cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
             };
+            // near candidates of all groups first (LDS), then the far ones + adoption: the far bytes had that long to arrive
             // half of the waves of a SIMD run all matches, then all parses, the other half match / parse group by group:
             // vector-heavy and scalar-heavy stretches of different waves then overlap at the issue port (-3 %)
             if ((wave >> 2) & 1) {
@@ -371,7 +389,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             __syncthreads();                                                        // B3
             // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
 #pragma unroll
-            for (int r = 0; r < G; r++) if (hv[r] && !(lane & 1)) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);   // even positions only
+            for (int r = 0; r < G; r++) if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);   // even positions only
             LZ_STAMP(3);
 
             // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E

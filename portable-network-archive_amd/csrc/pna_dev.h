@@ -30,7 +30,6 @@ constexpr uint32_t LZ_G_ZSTD  = LZ_G_ZSTD_VALUE;          // positions per lane 
 constexpr uint32_t MAX_OFF_G2 = 59392;      // 64 KiB window - 2 tiles of 2 048 - look-ahead - slack
 constexpr uint32_t NEAR_OFF   = LZ_G_ZSTD == 2 ? MAX_OFF_G2 : 65536 - 2 * 1024 * LZ_G_ZSTD - 1024 - 16 - 240;   // candidates at most this far back are verified in the LDS window: 64 KiB - 2 tiles - look-ahead - slack (G = 4: 56 064)
 constexpr uint32_t MAX_OFF    = 1u << 20;   // zstd: any earlier position of the 1 MiB segment; beyond NEAR_OFF the candidate is read from HBM / L2
-constexpr uint32_t CAP_FAR    = 16;         // per-position match length cap of those far candidates
 constexpr uint32_t BACK_CAP   = 3;          // bytes before a match that are known to agree with its candidate (backward adoption)
 #ifndef LZ_CAP1_VALUE
 #define LZ_CAP1_VALUE 32
