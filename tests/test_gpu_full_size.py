@@ -1,0 +1,126 @@
+"""BASELINE.json's configurations at their FULL sizes on one MI355X (run with -m gpu), through size-independent properties plus
+sampled comparisons with the oracle:
+
+  configs[3]  `pna create --solid`, one 8 GiB stream (8 192 x 1 MiB inner entries): the archive is read back through the extract driver
+              (every entry compared with the source), SDAT chunks on both sides of the 4 GiB offset go through an independent decoder;
+  configs[4]  1 000 000 x 4 KiB, Compression::Deflate: offsets partition the output, every entry round-trips on the device, >= 1 000
+              sampled entries equal the oracle's encoder model and inflate with zlib.
+
+Reference behaviour matched: cli/src/command/create.rs:594-623 (solid create), tests/bats/large_file.bats (sizes beyond 4 GiB).
+"""
+import ctypes
+import struct
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_hbm(torch, gib):
+    free, _ = torch.cuda.mem_get_info()
+    assert free >= gib * (1 << 30), f"the full-size case needs {gib} GiB of free HBM, found {free >> 30} GiB: an MI355X has 288 GB"
+
+
+def _chunks(buf):
+    """Walk a .pna image (numpy uint8 array / bytes): yields (type, payload offset, payload length, stored crc)."""
+    pos = 8
+    n = len(buf)
+    while pos < n:
+        ln, = struct.unpack(">I", bytes(buf[pos:pos + 4]))
+        ty = bytes(buf[pos + 4:pos + 8])
+        crc, = struct.unpack(">I", bytes(buf[pos + 8 + ln:pos + 12 + ln]))
+        yield ty, pos + 8, ln, crc
+        pos += 12 + ln
+
+
+def test_solid_8gib_archive_round_trips(gpu_ctx, pna, pf, codec):
+    import numpy as np
+    import torch
+    n, L = 8192, 1 << 20
+    _need_hbm(torch, 120)
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())
+    names = [f"solid/f{i:05d}.txt" for i in range(n)]
+    so, sl = [i * L for i in range(n + 1)], [L] * n
+    cap = pna.solid_archive_bound(pna.ALGO_ZSTD, names, sl)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), so, sl, dst.data_ptr(), cap)
+    arc = dst[:total].cpu().numpy()
+    del dst
+    host_src = src[:n * L].cpu().numpy()
+    del src
+    torch.cuda.empty_cache()
+
+    # ---- structure: signature, AHED, SHED, SDAT*, SEND, AEND; every chunk CRC (the oracle's rule: crc32(type || data))
+    assert bytes(arc[:8]) == bytes.fromhex("89504e410d0a1a0a")
+    kinds, sdat = [], []
+    for ty, off, ln, crc in _chunks(arc):
+        assert zlib.crc32(arc[off:off + ln].tobytes(), zlib.crc32(ty)) == crc, (ty, off)
+        if ty == b"SDAT":
+            sdat.append((off, ln))
+        else:
+            kinds.append(ty)
+    assert kinds == [b"AHED", b"SHED", b"SEND", b"AEND"]
+    rec = len(pf.write_normal_entry(pf.file_entry_header(0, names[0]), [bytes(L)], L))   # bytes of one inner record (names have one length)
+    inner_len = rec * n
+    assert len(sdat) == (inner_len + L - 1) // L                   # one SDAT chunk = one frame = 1 MiB of the inner stream
+    ratio = n * L / sum(ln for _, ln in sdat)
+    assert 2.4 < ratio < 3.2
+
+    # ---- independent decoder on both sides of the 4 GiB offset of the inner stream (u32 wrap), and at the ends
+    def inner_slice(a, b):                                         # bytes [a, b) of the serialised inner stream, from the ORACLE's writer
+        out = bytearray()
+        for e in range(a // rec, min(n, (b - 1) // rec + 1)):
+            data = codec.corpus_file(0, e, L)
+            r = pf.write_normal_entry(pf.file_entry_header(0, names[e]), [data], len(data))    # a STORE entry, lib/src/entry.rs:888-913
+            assert len(r) == rec
+            lo, hi = max(a, e * rec), min(b, (e + 1) * rec)
+            out += r[lo - e * rec:hi - e * rec]
+        return bytes(out)
+    dec = codec.libzstd_decompress_stream if codec.system_libzstd() is not None else codec.zstd_decompress
+    for k in (0, 4095, 4096, 4097, len(sdat) - 1):
+        off, ln = sdat[k]
+        a, b = k * L, min((k + 1) * L, inner_len)
+        assert dec(arc[off:off + ln].tobytes(), b - a) == inner_slice(a, b), k
+        assert codec.zstd_decompress(arc[off:off + ln].tobytes(), b - a) == inner_slice(a, b), k
+
+    # ---- the whole archive through the extract driver (device CRCs, open-size decode, inner FDAT CRCs): every entry == its source
+    seen = []
+
+    def _cb(_u, idx, name, kind, data, ln):
+        ok = (name.decode() == names[idx] and kind == 0 and ln == L and
+              bool(np.array_equal(np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_ubyte)), shape=(ln,)), host_src[idx * L:(idx + 1) * L])))
+        seen.append(idx if ok else -1)
+        return 0
+    cb = pna.ENTRY_FN(_cb)
+    buf = arc.tobytes()
+    gpu_ctx._check(gpu_ctx._L.pna_gpu_extract_archive_host(gpu_ctx._h, buf, len(buf), None, 0, cb, None))
+    assert seen == list(range(n))
+
+
+def test_deflate_one_million_small_entries(gpu_ctx, pna, codec):
+    import torch
+    n, L = 1_000_000, 4096
+    _need_hbm(torch, 40)
+    src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(1, 0, n, L, L, src.data_ptr())
+    cap = n * pna.bound(pna.ALGO_DEFLATE, L) + 64
+    comp = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    so = [i * L for i in range(n + 1)]
+    offs = gpu_ctx.compress_batch_device(src.data_ptr(), so, [L] * n, comp.data_ptr(), cap, algo=pna.ALGO_DEFLATE)
+    assert len(offs) == n + 1 and offs[0] == 0 and all(offs[i] < offs[i + 1] for i in range(n)) and offs[-1] <= cap
+    assert 1.6 < n * L / offs[-1] < 2.2
+    # every entry, every byte: inflated on the device, compared in HBM
+    back = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(comp.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(), so[:n], [L] * n,
+                                    algo=pna.ALGO_DEFLATE)
+    assert torch.equal(back[:n * L], src[:n * L])
+    del back
+    # sampled entries (1 001 of them, first and last included): the oracle's encoder model bit for bit, stdlib zlib reads them
+    host = comp[:offs[-1]].cpu().numpy()
+    for i in list(range(0, n, 1000)) + [n - 1]:
+        want = codec.corpus_file(1, i, L)
+        got = host[offs[i]:offs[i + 1]].tobytes()
+        assert zlib.decompress(got) == want, i
+        assert got == codec.deflate_model_compress(want), i
