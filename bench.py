@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- archive-create throughput of the MI355X compression path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one pass of the hot path over the whole synthetic corpus of this rank, ending with the complete `.pna`
-archive bytes in HBM (LZ -> entropy -> payloads written at their archive offsets -> chunk framing + FDAT CRC-32;
-`--framing none` stops at the packed compressed entries): `--files` enwik-style text files of `--file-mib` MiB each (BASELINE.json configs[1]:
-10 000 x 1 MiB, zstd).  Inputs are generated on the device and are resident in HBM when the timed region starts.
-N > 1: one process per GPU (torch.distributed / RCCL), every rank compresses its own shard of the corpus (weak
-scaling), then the compressed shards are gathered in rank order onto rank 0 over RCCL (the ordered gather of the
-serial PNA stream).  A rank's shard is cut into `--gather-pieces` contiguous pieces (2 when N > 1): piece h of all ranks
-forms the h-th stretch of the archive, so the gather of piece h runs while piece h + 1 is being compressed and only the
-last piece's gather is exposed at the end of a step.  Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path over the whole synthetic corpus, ending with the complete `.pna` archive bytes in HBM
+(LZ -> entropy -> payloads written at their archive offsets -> chunk framing + FDAT CRC-32; `--framing none` stops at the packed
+compressed entries, `--framing solid` is `pna create --solid`).  Default workload = BASELINE.json configs[1]: 10 000 x 1 MiB
+enwik-style text, zstd level 3, one GPU.  Inputs are generated on the device and are resident in HBM when the timed region starts.
+
+N > 1 (configs[2]): one process per GPU (torch.distributed, backend nccl = RCCL).  Default `--scaling strong`: the SAME corpus of
+`--files` entries is sharded over the ranks in contiguous index ranges (cli/src/command/core.rs:496-537 fan-out semantics), every
+rank compresses its shard with no data-path collective, and the compressed shards are gathered in index order onto rank 0 over RCCL
+(the ordered gather of the serial PNA stream).  A rank's shard is cut into `--gather-pieces` contiguous pieces (2 when N > 1): piece h
+of all ranks forms the h-th stretch of the archive, so the gather of piece h runs while piece h + 1 is being compressed and only the
+last piece's gather is exposed.  `--scaling weak` gives every rank `--files` entries of its own.  After the timed region the SURVEY
+§8(e) comparison path is timed as well: every rank copies its pieces D2H straight into a pre-offset page-locked host buffer shared by
+the ranks (`gather_compare`).
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries `roofline` (k_lz against the HBM peak), `cpu_baseline` (the
+reference's pipeline restated on the host cores, for every --algo / --framing), and at N = 1 `end_to_end`: the same corpus from
+PAGEABLE host memory through pna_gpu_create_archive_host to a counting sink (SURVEY §8(d)'s wall-clock metric, PCIe included).
 """
 from __future__ import annotations
 
@@ -27,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ENCODER = ("GPU encoder: 24512-entry LDS hash table over the even positions, look-back = the whole 1 MiB segment (LDS window 56 064 B, "
+           "beyond it candidates are verified in HBM/L2), min_match 6, greedy+lazy1 with backward adoption, 4096-position tiles")
 
 
 def usable_cores() -> int:
@@ -39,6 +49,13 @@ def usable_cores() -> int:
     except Exception:
         pass
     return n
+
+
+def size_label(n: int) -> str:
+    for unit, s in ((1 << 30, "GiB"), (1 << 20, "MiB"), (1 << 10, "KiB")):
+        if n >= unit and n % unit == 0:
+            return f"{n // unit} {s}"
+    return f"{n} B"
 
 
 def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing: str):
@@ -54,45 +71,128 @@ def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing:
     return None
 
 
-def cpu_baseline(sample_files: int, file_len: int) -> dict:
-    """Reference pipeline restated on the host cores (oracle/cpu_baseline.c): one entry per task, libzstd level 3."""
+def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes: int) -> dict:
+    """The reference's create pipeline restated on the host cores (oracle/cpu_baseline.c), bounded sample of the same workload:
+    normal archives = one entry per task on all usable cores (cli/src/command/core.rs:496-537), libzstd level 3 / zlib level 6
+    streaming encoders (lib/src/entry/write.rs:257-262); --solid = ONE encoder on ONE thread (lib/src/archive/write.rs:459-463)."""
     from oracle import codec
     L = codec.lib()
     cores = usable_cores()
-    data = b"".join(codec.corpus_file(0, i, file_len) for i in range(min(sample_files, 64)))
-    n_unique = len(data) // file_len
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    n_unique = max(1, min(64 if file_len >= (1 << 16) else 4096, sample_bytes // max(file_len, 1)))
+    data = b"".join(codec.corpus_file(kind, i, file_len) for i in range(n_unique))
     L.pna_cpu_zstd_version.restype = ctypes.c_uint
-    ver = L.pna_cpu_zstd_version()
-    if ver == 0:
-        # no libzstd on this host: time the oracle's own encoder model instead (single thread) and say so
-        t0 = time.time()
-        out = 0
-        for i in range(min(4, n_unique)):
-            out += len(codec.model_compress(data[i * file_len:(i + 1) * file_len]))
-        dt = time.time() - t0
-        n = min(4, n_unique) * file_len
-        return {"value": n / dt / 2**20, "unit": "MiB/s", "cores": 1, "kind": "port",
-                "sample": f"{min(4, n_unique)} x {file_len} B, oracle model encoder (libzstd absent on this host)",
-                "ratio": n / max(out, 1)}
-    L.pna_cpu_baseline_zstd.restype = ctypes.c_double
-    L.pna_cpu_baseline_zstd.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
-                                        ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
-    # replicate the unique files so that every core gets ~2 s of work (files are re-used: identical CPU cost)
-    reps = max(1, (sample_files + n_unique - 1) // n_unique)
-    buf = data * reps
-    n_files = len(buf) // file_len
+    L.pna_cpu_zlib_version.restype = ctypes.c_char_p
+    zver = L.pna_cpu_zstd_version()
+    lver = (L.pna_cpu_zlib_version() or b"").decode()
+    if algo == "zstd" and zver == 0:
+        raise RuntimeError("libzstd.so.1 is absent on this host: no CPU baseline (BASELINE.md holds the in-container figures)")
+    if algo == "deflate" and not lver:
+        raise RuntimeError("libz.so.1 is absent on this host")
+    codec_txt = (f"host libzstd {zver // 10000}.{zver // 100 % 100}.{zver % 100} level 3 (the reference pins 1.5.7)" if algo == "zstd"
+                 else f"host zlib {lver} level 6 (the reference's flate2 default backend is miniz_oxide; same format and level)")
+    kind_txt = "enwik-style" if kind == 0 else "random-text"
     out = ctypes.c_uint64()
-    secs = L.pna_cpu_baseline_zstd(buf, n_files, file_len, file_len, cores, 3, ctypes.byref(out))
+    if framing == "solid":
+        n_files = max(1, (sample_bytes + file_len - 1) // file_len)
+        buf = data * ((n_files + n_unique - 1) // n_unique)
+        L.pna_cpu_baseline_solid.restype = ctypes.c_double
+        L.pna_cpu_baseline_solid.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                             ctypes.c_int, ctypes.c_int, u64p]
+        secs = L.pna_cpu_baseline_solid(buf, n_files, file_len, file_len, 73, 2 if algo == "zstd" else 1, 3 if algo == "zstd" else 6, ctypes.byref(out))
+        if secs <= 0:
+            raise RuntimeError(f"solid baseline failed ({secs})")
+        return {"value": n_files * file_len / secs / 2**20, "unit": "MiB/s", "cores": 1, "kind": "port",
+                "sample": f"{n_files} x {file_len} B {kind_txt} inner entries ({n_unique} unique) as ONE stream through ONE streaming encoder on one thread "
+                          f"-- the reference's --solid path is single-threaded by construction (lib/src/archive/write.rs:459-463) --, {codec_txt}",
+                "ratio": n_files * file_len / max(out.value, 1)}
+    per_core = sample_bytes // max(file_len, 1)
+    n_files = max(cores, per_core)
+    buf = data * ((n_files + n_unique - 1) // n_unique)
+    n_files = len(buf) // file_len
+    fn = L.pna_cpu_baseline_zstd if algo == "zstd" else L.pna_cpu_baseline_deflate
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, u64p]
+    level = 3 if algo == "zstd" else 6
+    secs = fn(buf, n_files, file_len, file_len, cores, level, ctypes.byref(out))
+    if secs <= 0:
+        raise RuntimeError(f"baseline failed ({secs})")
     out1 = ctypes.c_uint64()
-    n1 = min(n_files, 16)
-    secs1 = L.pna_cpu_baseline_zstd(buf, n1, file_len, file_len, 1, 3, ctypes.byref(out1))
+    n1 = max(1, n_files // max(cores, 1) // 4)
+    secs1 = fn(buf, n1, file_len, file_len, 1, level, ctypes.byref(out1))
     return {"value": n_files * file_len / secs / 2**20, "unit": "MiB/s", "cores": cores, "kind": "port",
-            "sample": f"{n_files} x {file_len} B enwik-style files ({n_unique} unique), host libzstd {ver // 10000}.{ver // 100 % 100}.{ver % 100} "
-                      f"level 3 streaming, one entry per task on {cores} threads (= usable cores: affinity / cgroup cpu.max; "
-                      f"host has {os.cpu_count()} logical CPUs); parallel compression phase only -- the reference's single-threaded "
-                      f"re-order / CRC-32 / write tail (cli/src/command/core.rs:471-493) is not added, which favours the CPU figure",
+            "sample": f"{n_files} x {file_len} B {kind_txt} files ({n_unique} unique), {codec_txt} streaming, one entry per task on {cores} threads "
+                      f"(= usable cores: affinity / cgroup cpu.max; host has {os.cpu_count()} logical CPUs); parallel compression phase only -- the "
+                      f"reference's single-threaded re-order / CRC-32 / write tail (cli/src/command/core.rs:471-493) is not added, which favours the CPU figure",
             "ratio": n_files * file_len / max(out.value, 1),
-            "single_thread_mib_s": n1 * file_len / secs1 / 2**20}
+            "single_thread_mib_s": n1 * file_len / secs1 / 2**20 if secs1 > 0 else None}
+
+
+def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, algo: int, runs: int = 2) -> dict:
+    """wall time from the first input byte in (pageable) host RAM to the last archive byte handed to the sink, through
+    pna_gpu_create_archive_host (bounded window: staging || H2D || kernels || D2H).  The sink counts the bytes."""
+    host = src[:n_files * stride].cpu().numpy()                  # pageable host memory, one entry per pointer
+    base = host.ctypes.data
+    a_names = (ctypes.c_char_p * n_files)(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * n_files)(*[base + i * stride for i in range(n_files)])
+    a_len = (ctypes.c_size_t * n_files)(*[file_len] * n_files)
+    count = [0, 0]
+
+    def _sink(_u, _buf, k):
+        count[0] += k
+        count[1] += 1
+        return 0
+    cb = pna.SINK_FN(_sink)
+    L = pna.load_library()
+    best = None
+    for it in range(runs + 1):                                   # the first run allocates the page-locked staging slots: not timed
+        count[0] = count[1] = 0
+        t0 = time.perf_counter()
+        rc = L.pna_gpu_create_archive_host(ctx._h, algo, pna.LEVEL_DEFAULT, n_files, a_names, a_src, a_len, cb, None)
+        dt = time.perf_counter() - t0
+        if rc:
+            raise RuntimeError(f"pna_gpu_create_archive_host failed: {rc}")
+        if it > 0:
+            best = dt if best is None else min(best, dt)
+    in_bytes = n_files * file_len
+    return {"value": round(in_bytes / best / 2**20, 1), "unit": "MiB/s", "ms": round(best * 1e3, 2), "archive_bytes": count[0], "sink_calls": count[1],
+            "pcie_bytes": in_bytes + count[0], "pcie_GBps": round((in_bytes + count[0]) / best / 1e9, 2), "runs": runs,
+            "path": f"{n_files} x {file_len} B entries in pageable host memory -> pna_gpu_create_archive_host (1 GiB sub-batches: staging into "
+                    f"page-locked slots || H2D || kernels || D2H) -> counting sink; best of {runs} runs after one untimed run"}
+
+
+class HostGather:
+    """SURVEY §8(e) comparison path: every rank copies its compressed pieces D2H straight to their final offsets in ONE page-locked host
+    buffer shared by the ranks of the node (POSIX shared memory registered with the HIP runtime in every process)."""
+
+    def __init__(self, torch, dist, rank: int, world: int, cap: int):
+        from multiprocessing import shared_memory
+        self.torch, self.rank = torch, rank
+        name = f"pna_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid() if world > 1 else os.getpid()}"
+        if rank == 0:
+            self.shm = shared_memory.SharedMemory(name=name, create=True, size=cap)
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            self.shm = shared_memory.SharedMemory(name=name)
+        self.t = torch.frombuffer(self.shm.buf, dtype=torch.uint8)
+        self.registered = int(torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), self.t.numel(), 0)) == 0
+
+    def put(self, dst, total: int, offset: int):
+        self.t[offset:offset + total].copy_(dst[:total], non_blocking=True)
+
+    def close(self, dist, world: int):
+        try:
+            if self.registered:
+                self.torch.cuda.cudart().cudaHostUnregister(self.t.data_ptr())
+            del self.t
+            self.shm.close()
+            if world > 1:
+                dist.barrier()
+            if self.rank == 0:
+                self.shm.unlink()
+        except Exception:
+            pass
 
 
 def main() -> None:
@@ -100,7 +200,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--files", type=int, default=10000)
+    ap.add_argument("--files", type=int, default=10000, help="entries of the corpus (strong scaling: in all; weak scaling: per rank)")
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--algo", choices=["zstd", "deflate"], default="zstd")
     ap.add_argument("--kind", type=int, default=0, help="corpus kind (0 enwik-style text, 1 random-text)")
@@ -109,19 +209,26 @@ def main() -> None:
                          "solid: `pna create --solid` (BASELINE.json configs[3]: one stream, block-split in the kernels)")
     ap.add_argument("--encrypt", choices=["none", "aes-ctr", "aes-cbc", "aes-gcm"], default="none",
                     help="archive framing only: AES-256 cipher stage between compression and chunk CRC (`pna create --aes [ctr|cbc]`)")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="N > 1: strong (default) shards the one corpus of --files entries over the ranks (BASELINE.json configs[2]); weak gives every rank --files entries")
     ap.add_argument("--gather-pieces", type=int, default=0,
                     help="archive framing: cut every rank's shard into this many pieces, each compressed and gathered on its own "
                          "(0 = 2 when N > 1, else 1)")
-    ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive (archive framing)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-files", type=int, default=0, help="0 = 48 files per core")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-sink leg (N = 1, archive framing)")
+    ap.add_argument("--no-gather-compare", action="store_true", help="N > 1: skip the direct-D2H comparison path")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample per core in MiB (0 = 256 zstd / 48 deflate; --solid: 1024 zstd / 192 deflate in all)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: for N > 1 launch one rank per GPU with\n"
+                 f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -133,7 +240,17 @@ def main() -> None:
     pna = importlib.import_module("portable-network-archive_amd")
     ctx = pna.Context(dev.index)
 
-    n_files, file_len = args.files, int(args.file_mib * (1 << 20))
+    scaling = args.scaling if args.scaling != "auto" else "strong"
+    if world == 1:
+        scaling = "weak"                                          # one rank: the two coincide; the contract's default word
+    file_len = int(args.file_mib * (1 << 20))
+    if scaling == "strong" and world > 1:
+        if args.files % world:
+            sys.exit(f"bench.py: --files {args.files} is not a multiple of the {world} ranks")
+        n_files = args.files // world                             # entries of THIS rank
+    else:
+        n_files = args.files
+    files_all = n_files * world
     stride = (file_len + 15) & ~15
     src = torch.empty(n_files * stride + 8192, dtype=torch.uint8, device=dev)
     algo = pna.ALGO_ZSTD if args.algo == "zstd" else pna.ALGO_DEFLATE
@@ -143,8 +260,8 @@ def main() -> None:
     if args.framing != "archive" or pieces < 1 or n_files % pieces:
         pieces = 1
     n_piece = n_files // pieces
-    shard_mod = importlib.import_module("portable-network-archive_amd.shard")
-    first_file = [lo for lo, _ in shard_mod.piece_ranges(rank, world, pieces, n_piece)]
+    shard = importlib.import_module("portable-network-archive_amd.shard")
+    first_file = [lo for lo, _ in shard.piece_ranges(rank, world, pieces, n_piece)]
     for h in range(pieces):
         ctx.corpus_fill_device(args.kind, first_file[h], n_piece, file_len, stride, src.data_ptr() + h * n_piece * stride)
     src_off = [i * stride for i in range(n_files)] + [n_files * stride]
@@ -181,15 +298,18 @@ def main() -> None:
     dsts = [torch.empty(dst_cap, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     arg_cache = [dict() for _ in range(pieces)]
 
-    shard = importlib.import_module("portable-network-archive_amd.shard")
     gather_out = [None] * pieces                              # rank 0: where the pieces h of all ranks land, in rank order
     pending = [None] * nbuf                                   # the gather that still reads dsts[b]
     cur = [0]
+    mode = ["rccl"]                                           # "rccl": ordered gather onto rank 0's HBM; "d2h": direct copies into the shared host buffer
+    host_gather = [None]
+    host_pos = [0]
 
     def finish_gather(b=None):
         for k in (range(nbuf) if b is None else [b]):
             if pending[k] is not None:
-                shard.gather_ordered_wait(pending[k])
+                if pending[k] != "d2h":
+                    shard.gather_ordered_wait(pending[k])
                 torch.cuda.current_stream().synchronize()     # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
                 pending[k] = None
 
@@ -201,6 +321,7 @@ def main() -> None:
 
     def step():
         total_all = 0
+        host_pos[0] = 0
         for h in range(pieces):
             b = cur[0]
             finish_gather(b)                                  # the gather that used this buffer two pieces ago
@@ -215,44 +336,82 @@ def main() -> None:
             tm = ctx.timing()
             lz_acc[0] += tm.ms_lz
             lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
-            if world > 1:
+            if world > 1 and mode[0] == "rccl":
                 if rank == 0 and gather_out[h] is None:
                     gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
                 pending[b] = shard.gather_ordered_start(dst, total, rank, world, out=gather_out[h])
+            elif mode[0] == "d2h":
+                # sizes of piece h of all ranks -> this rank's offset inside the archive image on the host
+                sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
+                if world > 1:
+                    dist.all_gather_into_tensor(sizes_t, torch.tensor([total], dtype=torch.int64, device=dev))
+                else:
+                    sizes_t[0] = total
+                sizes = [int(x) for x in sizes_t.tolist()]
+                host_gather[0].put(dst, total, host_pos[0] + sum(sizes[:rank]))
+                host_pos[0] += sum(sizes)
+                pending[b] = "d2h"
             if nbuf > 1:
                 cur[0] ^= 1
             total_all += total
         return total_all
 
+    def timed(n_steps):
+        finish_gather()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lz_acc[0] = lz_acc[1] = 0.0
+        t0 = time.perf_counter()
+        out = 0
+        for _ in range(n_steps):
+            out = step()
+        finish_gather()                                       # the last piece's gather is inside the timed region
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     for _ in range(args.warmup):
         step()
-    finish_gather()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lz_acc[0] = lz_acc[1] = 0.0
-    t0 = time.perf_counter()
-    out_total = 0
-    for _ in range(args.steps):
-        out_total = step()
-    finish_gather()                                           # the last piece's gather is inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, out_total = timed(args.steps)
     lz_ms, stage_ms = lz_acc
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         o = torch.tensor([out_total], dtype=torch.int64, device=dev)
         dist.all_reduce(o)
         out_all = int(o.item())
     else:
         out_all = out_total
-    # ---- outside the timed region: decode every entry of this rank's last archive on the device and compare with the inputs
+    tm_last = ctx.timing()                                   # stage split of the last timed launch (the checks below run more kernels)
+
+    # ---- outside the timed region: SURVEY §8(e)'s comparison path (N > 1; available at N = 1 with --gather-pieces for rehearsal)
+    gather_compare = None
+    if args.framing == "archive" and not args.no_gather_compare and (world > 1 or args.gather_pieces > 1):
+        try:
+            cap_host = int(out_all * 1.05) + (4 << 20)
+            host_gather[0] = HostGather(torch, dist, rank, world, cap_host)
+            mode[0] = "d2h"
+            step()                                             # untimed: first touch of the shared pages
+            dt2, _ = timed(args.steps)
+            gather_compare = {"rccl_gather_to_rank0_hbm_ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "direct_d2h_to_shared_pinned_host_ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                              "host_buffer_registered": bool(host_gather[0].registered),
+                              "note": "the second path ends with the archive image in HOST memory (where the sink is), the first in rank 0's HBM"}
+        except Exception as e:                                 # never lose the headline number because the comparison leg failed
+            gather_compare = {"error": repr(e)}
+        finally:
+            mode[0] = "rccl"
+            finish_gather()
+            if host_gather[0] is not None:
+                host_gather[0].close(dist, world)
+
+    # ---- decode this rank's last archive on the device and compare with the inputs
     verified = None
-    tm_last = ctx.timing()                                   # stage split of the last timed launch (the check below runs more kernels)
     if args.framing == "archive" and not args.no_verify and args.encrypt in ("none", "aes-ctr"):
         ok = True
         fs = max(1, (file_len.bit_length() + 7) // 8) if file_len else 0          # fSIZ payload: minimal big-endian
@@ -273,8 +432,38 @@ def main() -> None:
                 and (stride != file_len or bool(torch.equal(back[:n_piece * stride], ref)))
         verified = bool(ok)
         del back
+    elif args.framing == "solid" and not args.no_verify:
+        # the archive goes back through the extract driver: SDAT CRCs on the device, frames counted, open-size decode, inner records walked,
+        # inner FDAT CRCs on the device; every name / length is checked, every 64th entry (and the last) byte for byte
+        import numpy as np
+        total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dsts[0].data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0])
+        arc = dsts[0][:total].cpu().numpy().tobytes()
+        good = [0]
+        sample = set(range(0, n_files, 64)) | {n_files - 1}
+
+        def _cb(_u, idx, name, kind, data, ln):
+            ok1 = idx < n_files and name.decode() == names[idx] and kind == 0 and ln == file_len
+            if ok1 and idx in sample and ln:
+                got = np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_ubyte)), shape=(ln,))
+                ok1 = bool(np.array_equal(got, src[src_off[idx]:src_off[idx] + ln].cpu().numpy()))
+            good[0] += 1 if ok1 else 0
+            return 0
+        cbf = pna.ENTRY_FN(_cb)
+        rc = ctx._L.pna_gpu_extract_archive_host(ctx._h, arc, len(arc), None, 0, cbf, None)
+        verified = bool(rc == 0 and good[0] == n_files)
+        del arc
+
     in_rank = n_files * file_len
     in_all = in_rank * world
+    e2e = None
+    if world == 1 and args.framing == "archive" and args.encrypt == "none" and not args.no_end_to_end:
+        try:
+            dsts.clear()
+            gather_out[:] = [None] * pieces
+            torch.cuda.empty_cache()
+            e2e = end_to_end(pna, ctx, src, n_files, file_len, stride, names, algo)
+        except Exception as e:
+            e2e = {"value": None, "error": repr(e)}
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = in_all / (dt / args.steps) / 2**20
@@ -282,17 +471,22 @@ def main() -> None:
         alg_bytes = in_rank + out_total                      # each input byte read once + each output byte written once
         achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
         tm = tm_last
+        level = 3 if args.algo == "zstd" else 6
+        wl = (f"{files_all} x {size_label(file_len)}" if args.framing != "solid" else f"--solid, one {size_label(files_all * file_len)} stream of {files_all} x {size_label(file_len)} entries")
         line = {
-            "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}, 10k x 1MiB corpus",
+            "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}-{level}, {wl} {'enwik-style' if args.kind == 0 else 'random-text'} corpus"
+                      + (f", {args.encrypt}" if args.encrypt != "none" else "") + ("" if args.framing != "none" else ", compressed streams only (no container)"),
             "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"pna create, {n_files} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text per GPU, Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} "
-                                   f"(GPU encoder: 24512-entry LDS hash table, min_match 6, greedy+lazy1, 4096-position tiles), inputs resident in HBM, "
+            "config": {"workload": f"pna create, {files_all} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text"
+                                   + (f" ({n_files} per GPU, contiguous index ranges)" if world > 1 else "")
+                                   + f", Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} level {level} ({ENCODER}), inputs resident in HBM, "
                                    + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
                                       else "--solid: inner STORE records serialised + one compressed stream + SDAT framing, all in HBM" if args.framing == "solid"
-                                      else "output = packed compressed entry streams in HBM"),
-                       "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}",
+                                      else "output = packed compressed entry streams in HBM")
+                                   + ("; compressed shards gathered in index order onto rank 0 over RCCL" if world > 1 else ""),
+                       "entries": files_all, "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}",
                        "gather_pieces": pieces},
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
@@ -310,10 +504,20 @@ def main() -> None:
             line["stages_ms_last_step"]["cipher"] = round(tm.ms_cipher, 3)
             line["cipher"] = {"mode": args.encrypt, "ms": round(tm.ms_cipher, 3),
                               "GB_per_s": round(out_total / pieces / max(tm.ms_cipher, 1e-9) / 1e6, 1)}
-        if world == 1 and not args.no_cpu_baseline and args.algo == "zstd":
+        if gather_compare is not None:
+            line["gather_compare"] = gather_compare
+        if e2e is not None:
+            line["end_to_end"] = e2e
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                sample = args.cpu_sample_files or 64 * usable_cores()
-                line["cpu_baseline"] = cpu_baseline(sample, file_len)
+                cores = usable_cores()
+                if args.framing == "solid":
+                    sample = (args.cpu_sample_mib or (1024 if args.algo == "zstd" else 192)) << 20
+                else:
+                    sample = (args.cpu_sample_mib or (256 if args.algo == "zstd" else 48)) * cores << 20
+                line["cpu_baseline"] = cpu_baseline(args.algo, args.framing, args.kind, file_len, sample)
+                if e2e is not None and e2e.get("value") and line["cpu_baseline"].get("value"):
+                    line["end_to_end"]["vs_cpu_baseline"] = round(e2e["value"] / line["cpu_baseline"]["value"], 2)
             except Exception as e:  # never lose the GPU number because the CPU leg failed
                 line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)

@@ -93,3 +93,119 @@ double pna_cpu_baseline_zstd(const uint8_t *data, size_t n_files, size_t file_le
     if (err) return -2.0;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- Compression::Deflate: flate2's ZlibEncoder::new(w, level 6) (lib/src/entry/write.rs:257-259) == a streaming zlib deflate per entry.
+ * libz is loaded with dlopen like libzstd; the z_stream layout below is zlib's stable ABI (zlib.h, 1.2.x). */
+typedef struct {
+    const unsigned char *next_in; unsigned avail_in; unsigned long total_in;
+    unsigned char *next_out; unsigned avail_out; unsigned long total_out;
+    const char *msg; void *state; void *zalloc; void *zfree; void *opaque; int data_type; unsigned long adler; unsigned long reserved;
+} zstrm;
+typedef int (*fn_dinit)(zstrm *, int, const char *, int);
+typedef int (*fn_deflate)(zstrm *, int);
+typedef int (*fn_dend)(zstrm *);
+typedef const char *(*fn_zver)(void);
+static struct { void *h; fn_dinit init; fn_deflate deflate; fn_dend end; fn_zver ver; } ZL;
+
+static int load_zlib(void) {
+    if (ZL.h) return 0;
+    const char *names[] = {"libz.so.1", "/usr/lib/x86_64-linux-gnu/libz.so.1", "/lib/x86_64-linux-gnu/libz.so.1", 0};
+    for (int i = 0; names[i] && !ZL.h; i++) ZL.h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!ZL.h) return -1;
+    ZL.init = (fn_dinit)dlsym(ZL.h, "deflateInit_"); ZL.deflate = (fn_deflate)dlsym(ZL.h, "deflate");
+    ZL.end = (fn_dend)dlsym(ZL.h, "deflateEnd"); ZL.ver = (fn_zver)dlsym(ZL.h, "zlibVersion");
+    if (!ZL.init || !ZL.deflate || !ZL.end || !ZL.ver) { dlclose(ZL.h); ZL.h = 0; return -1; }
+    return 0;
+}
+const char *pna_cpu_zlib_version(void) { return load_zlib() ? "" : ZL.ver(); }
+
+static void *worker_deflate(void *arg) {
+    job *j = (job *)arg;
+    size_t cap = j->file_len + (j->file_len >> 9) + 1024;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    for (;;) {
+        long i = __sync_fetch_and_add(j->next, 1);
+        if ((size_t)i >= j->n_files) break;
+        zstrm s; memset(&s, 0, sizeof s);                       /* a fresh encoder per entry */
+        if (ZL.init(&s, j->level, ZL.ver(), (int)sizeof s) != 0) { j->err = 1; break; }
+        s.next_in = j->data + (size_t)i * j->stride; s.avail_in = (unsigned)j->file_len;
+        s.next_out = buf; s.avail_out = (unsigned)cap;
+        int r = ZL.deflate(&s, 4 /* Z_FINISH */);
+        if (r != 1 /* Z_STREAM_END */) { ZL.end(&s); j->err = 1; break; }
+        j->out_bytes += s.total_out;
+        ZL.end(&s);
+    }
+    free(buf);
+    return 0;
+}
+
+double pna_cpu_baseline_deflate(const uint8_t *data, size_t n_files, size_t file_len, size_t stride, int threads, int level,
+                                uint64_t *out_total) {
+    if (load_zlib()) return -1.0;
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    pthread_t th[1024]; job jobs[1024];
+    volatile long next = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        job jj = {data, n_files, file_len, stride, level, &next, 0, 0}; jobs[t] = jj;
+        pthread_create(&th[t], 0, worker_deflate, &jobs[t]);
+    }
+    uint64_t total = 0; int err = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], 0); total += jobs[t].out_bytes; err |= jobs[t].err; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (out_total) *out_total = total;
+    if (err) return -2.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* ---- `pna create --solid`: ONE streaming encoder over the serialised inner entries, on ONE thread (lib/src/archive/write.rs:459-463:
+ * into_solid_archive wraps the sink in one compression_writer; cli/src/command/create.rs:594-623 feeds it entry by entry).  The inner
+ * records are `n_files` stored entries of `file_len` bytes; `rec_overhead` bytes of chunk framing per record are fed as zeros-free
+ * filler (taken from the data itself) so that the byte count matches.  algo 2 = zstd, 1 = zlib. */
+double pna_cpu_baseline_solid(const uint8_t *data, size_t n_files, size_t file_len, size_t stride, size_t rec_overhead, int algo, int level,
+                              uint64_t *out_total) {
+    struct timespec t0, t1;
+    uint64_t total = 0;
+    size_t cap = 1u << 20;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    if (algo == 2) {
+        if (load_zstd()) { free(buf); return -1.0; }
+        void *cctx = Z.create();
+        Z.setp(cctx, 100, level);
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (size_t i = 0; i < n_files; i++) {
+            for (int part = 0; part < 2; part++) {
+                zin in = {part ? data + i * stride : data, part ? file_len : rec_overhead, 0};
+                while (in.pos < in.size) {
+                    zout out = {buf, cap, 0};
+                    size_t r = Z.stream2(cctx, &out, &in, 0);
+                    if (Z.iserr(r)) { Z.freec(cctx); free(buf); return -2.0; }
+                    total += out.pos;
+                }
+            }
+        }
+        for (;;) { zin in = {0, 0, 0}; zout out = {buf, cap, 0}; size_t r = Z.stream2(cctx, &out, &in, 2); total += out.pos; if (Z.iserr(r)) { Z.freec(cctx); free(buf); return -2.0; } if (r == 0) break; }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        Z.freec(cctx);
+    } else {
+        if (load_zlib()) { free(buf); return -1.0; }
+        zstrm s; memset(&s, 0, sizeof s);
+        if (ZL.init(&s, level, ZL.ver(), (int)sizeof s) != 0) { free(buf); return -2.0; }
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (size_t i = 0; i < n_files; i++) {
+            for (int part = 0; part < 2; part++) {
+                s.next_in = part ? data + i * stride : data; s.avail_in = (unsigned)(part ? file_len : rec_overhead);
+                while (s.avail_in) { s.next_out = buf; s.avail_out = (unsigned)cap; if (ZL.deflate(&s, 0) != 0) { ZL.end(&s); free(buf); return -2.0; } }
+            }
+        }
+        for (;;) { s.next_out = buf; s.avail_out = (unsigned)cap; int r = ZL.deflate(&s, 4); if (r == 1) break; if (r != 0) { ZL.end(&s); free(buf); return -2.0; } }
+        total = s.total_out;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        ZL.end(&s);
+    }
+    free(buf);
+    if (out_total) *out_total = total;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
