@@ -75,6 +75,19 @@ int  pna_split_archive(const void *archive, size_t len, size_t max_part_bytes, p
 /* The reading side (Archive::read_next_archive): the parts in order -> one archive image for pna_gpu_extract_archive_host. */
 int  pna_join_parts(const void *const *parts, const size_t *part_len, size_t n, pna_sink_fn sink, void *user);
 
+/* ---- `pna append` / `pna update` (cli/src/command/append.rs:504-560, update.rs:620-665): the same entry producer, a different sink.
+ * Archive::seek_to_end (lib/src/archive/read.rs:412-424): after the header, chunks are skipped (skip_chunk: lengths only, no CRC) up to
+ * AEND; *aend_off is the offset of the AEND chunk -- where the appended entries go, overwriting it --, *has_next is 1 when an ANXT chunk
+ * was passed (a multipart archive continues in the next part: append there, append.rs:533-560).  PNA_E_INVAL: not an archive, or
+ * truncated before / inside the AEND chunk (UnexpectedEof in the reference, read.rs:588-604). */
+int  pna_archive_seek_to_end(const void *archive, size_t len, uint64_t *aend_off, int *has_next);
+/* The top-level records of an archive image in order (Archive::raw_entries, lib/src/archive/read.rs:46-66): for each normal entry
+ * (FHED .. FEND) and each solid entry (SHED .. SEND) cb(user, index, name, kind, offset, length) -- `name` is the FHED name as
+ * stored (empty for a solid entry, kind -1), [offset, offset + length) are its bytes in the image, which `pna update` copies unchanged for
+ * entries it keeps (update.rs:620-665) while the changed ones go through pna_gpu_create_archive_part_host. */
+typedef int (*pna_raw_entry_fn)(void *user, size_t index, const char *name, size_t name_len, int kind, uint64_t offset, uint64_t length);
+int  pna_archive_list_entries(const void *archive, size_t len, pna_raw_entry_fn cb, void *user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,9 +235,40 @@ int  pna_gpu_inflate_open_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t s
  * stream, wrong password (GCM key confirmation, CBC padding), authentication failure; PNA_E_UNSUPPORTED: multipart archives, xz,
  * Camellia, CBC / GCM solid streams, solid streams with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND):
  * SDAT CRCs and the inner FDAT CRCs on the device, the stream is decoded without a recorded size (frames counted first). */
+/* `name` is the entry's PATH as the reference's reader exposes it (EntryHeader::path(), lib/src/entry/header.rs:91-94): the FHED name
+ * normalised and reduced to its normal components (EntryName::sanitize, lib/src/entry/name.rs:148-156 -- no root, no "." / ".."), so a
+ * callback that writes files below an output directory cannot be led outside it by a crafted archive.  FHED names that are not valid
+ * UTF-8 (InvalidData in the reference, header.rs:143-146) or that contain a NUL byte (not representable here) fail with PNA_E_INVAL. */
 typedef int (*pna_entry_fn)(void *user, size_t index, const char *name, int kind, const void *data, size_t len);
 int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t archive_len, const void *password, size_t password_len,
                                   pna_entry_fn cb, void *user);
+
+/* pna_gpu_create_archive_host for ONE PART of an archive (PNA_PART_HEAD: signature + AHED first, PNA_PART_TAIL: AEND last): what
+ * `pna append` writes behind the existing entries (PNA_PART_TAIL only) and `pna update` for the entries it re-creates (neither flag). */
+int  pna_gpu_create_archive_part_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                      const void *const *src, const size_t *src_len, uint32_t part_flags, pna_sink_fn sink, void *user);
+/* `pna append` (cli/src/command/append.rs:504-560 run_append_archive: open_archive_then_seek_to_end, add the new entries in order,
+ * finalize): `archive` is the existing image (or its last part); *write_at receives the offset of its AEND chunk, and the sink receives
+ * the bytes that belong there -- the n new entries, compressed on the device, then AEND.  The result, archive[0 .. write_at) followed by
+ * the sink's bytes, equals the archive `pna create` writes from all entries at once. */
+int  pna_gpu_append_archive_host(pna_gpu_ctx *ctx, int algo, int level, const void *archive, size_t archive_len, size_t n,
+                                 const char *const *names, const void *const *src, const size_t *src_len, uint64_t *write_at,
+                                 pna_sink_fn sink, void *user);
+
+/* ---- Archive::write_file / write_stream_entry (lib/src/archive/write.rs:276-299,730-777): an entry written WHILE its data arrives.
+ * The record has no fSIZ (the size is not known when FHED goes out): FHED, the caller's already framed extra + metadata chunks
+ * (`meta`, may be NULL), then the compressed stream as FDAT chunks -- one per burst the encoder hands to the ChunkStreamWriter
+ * (lib/src/chunk/write.rs:32-47: every write() becomes a chunk of at most max_chunk_size bytes; the encoders flush in bursts of at most
+ * 32 KiB, the size of the FDAT / SDAT pieces in the reference's stream-written fixtures) --, then FEND.  begin() emits FHED + meta,
+ * write() buffers like CompressionWriter::write, finish() compresses (group commit with the context's other writers), emits the FDAT
+ * chunks and FEND and frees the writer; abort() frees it without output (the archive is then unusable, as in the reference).
+ * max_chunk_size 0 = u32::MAX.  Thread rules: those of pna_gpu_stream_*. */
+typedef struct pna_gpu_entry_writer pna_gpu_entry_writer;
+int  pna_gpu_stream_entry_begin(pna_gpu_ctx *ctx, int algo, int level, const char *name, const void *meta, size_t meta_len,
+                                uint32_t max_chunk_size, pna_sink_fn sink, void *user, pna_gpu_entry_writer **out);
+int  pna_gpu_stream_entry_write(pna_gpu_entry_writer *w, const void *buf, size_t len);
+int  pna_gpu_stream_entry_finish(pna_gpu_entry_writer *w);
+void pna_gpu_stream_entry_abort(pna_gpu_entry_writer *w);
 
 /* ---- streaming facade with the shape of CompressionWriter<W> (lib/src/compress.rs:32-41,66-75):
  * write() buffers, finish() == try_into_inner(): compresses and pushes the stream into the sink (== W::write).

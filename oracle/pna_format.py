@@ -80,9 +80,22 @@ def fsiz_bytes(raw_size: int) -> bytes:
 
 
 def sanitize_name(name: str) -> str:
-    """EntryName::sanitize: keep Normal components joined by '/' -- lib/src/entry/name.rs:72-80."""
-    parts = [p for p in name.replace("\\", "/").split("/") if p not in ("", ".", "..")]
-    return "/".join(parts)
+    """EntryName::sanitize -- lib/src/entry/name.rs:148-156: normalize_utf8path first (lib/src/util/utf8path.rs:6-33: '.' dropped, '..'
+    pops the preceding normal component, a '..' with nothing to pop is kept for now), then only Normal components survive, joined by '/'.
+    '/' is the only separator off Windows (camino follows std::path)."""
+    rooted = name.startswith("/")
+    buf: List[str] = []
+    for comp in name.split("/"):
+        if comp in ("", "."):
+            continue
+        if comp == "..":
+            if buf and buf[-1] != "..":
+                buf.pop()
+            elif not rooted:
+                buf.append("..")          # Some(ParentDir) | None => push; with a root in front it is dropped
+            continue
+        buf.append(comp)
+    return "/".join(c for c in buf if c != "..")
 
 
 def flatten_writer(writes: Iterable[bytes], max_chunk_size: int = MAX_CHUNK_DATA_LENGTH) -> List[bytes]:
@@ -131,6 +144,41 @@ def write_normal_entry(header: bytes, data_pieces: List[bytes], raw_file_size: O
         out += write_chunk(b"FDAT", d)
     out += write_chunk(b"FEND")
     return bytes(out)
+
+
+def write_stream_entry(header: bytes, bursts: Iterable[bytes], extra: Iterable[Tuple[bytes, bytes]] = (),
+                       facets: Iterable[Tuple[bytes, bytes]] = (), max_chunk_size: Optional[int] = None) -> bytes:
+    """write_stream_entry -- lib/src/archive/write.rs:730-777: FHED, extra*, metadata facets*, then every burst the encoder hands to the
+    ChunkStreamWriter as FDAT chunk(s) of at most max_chunk_size bytes (lib/src/chunk/write.rs:32-47), FEND.  No fSIZ: the size is not
+    known when the header goes out (pinned by archive_write_file_accepts_attributes_without_generating_file_size, write.rs:830-881)."""
+    out = bytearray(write_chunk(b"FHED", header))
+    for ty, d in extra:
+        out += write_chunk(ty, d)
+    for ty, d in facets:
+        out += write_chunk(ty, d)
+    out += chunk_stream_writer(b"FDAT", bursts, max_chunk_size)
+    out += write_chunk(b"FEND")
+    return bytes(out)
+
+
+def seek_to_end(buf: bytes) -> Tuple[int, bool]:
+    """Archive::seek_to_end -- lib/src/archive/read.rs:412-424: skip chunks (no CRC check) up to AEND; returns (offset of the AEND chunk,
+    whether an ANXT chunk was passed)."""
+    if buf[:8] != PNA_SIGNATURE or buf[12:16] != b"AHED":
+        raise ValueError("not a PNA archive")
+    pos, nxt = 8, False
+    while True:
+        if len(buf) - pos < 12:
+            raise ValueError("unexpected end of archive")
+        (length,) = struct.unpack_from(">I", buf, pos)
+        if len(buf) - pos - 12 < length:
+            raise ValueError("unexpected end of archive")
+        ty = bytes(buf[pos + 4:pos + 8])
+        if ty == b"AEND":
+            return pos, nxt
+        if ty == b"ANXT":
+            nxt = True
+        pos += 12 + length
 
 
 def write_encrypted_file_entry(compression: int, encryption: int, cipher_mode: int, name: str, phsf: str, iv: bytes,

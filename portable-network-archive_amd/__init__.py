@@ -92,6 +92,7 @@ class Cipher:
 
 SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 PART_SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t)
+RAW_ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64)
 ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)
 
 _lib = None
@@ -112,6 +113,10 @@ EXPORTS = [
     "pna_crc32", "pna_archive_new", "pna_archive_add_file", "pna_archive_add_dir", "pna_archive_add_solid",
     "pna_archive_inner_entry_bytes", "pna_archive_finalize", "pna_archive_abort", "pna_create_archive",
     "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted", "pna_kdf_argon2", "pna_split_archive", "pna_join_parts",
+    "pna_archive_seek_to_end", "pna_archive_list_entries",
+    # streaming entries, parts, append (include/pna_gpu.h)
+    "pna_gpu_create_archive_part_host", "pna_gpu_append_archive_host", "pna_gpu_stream_entry_begin", "pna_gpu_stream_entry_write",
+    "pna_gpu_stream_entry_finish", "pna_gpu_stream_entry_abort",
 ]
 
 
@@ -239,6 +244,24 @@ def load_library() -> ctypes.CDLL:
     L.pna_create_archive_encrypted.restype = ctypes.c_int
     L.pna_create_archive_encrypted.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                                ctypes.POINTER(sz), ctypes.c_char_p, sz, ctypes.c_int, u32, SINK_FN, vp]
+    L.pna_archive_seek_to_end.restype = ctypes.c_int
+    L.pna_archive_seek_to_end.argtypes = [ctypes.c_char_p, sz, u64p, ctypes.POINTER(ctypes.c_int)]
+    L.pna_archive_list_entries.restype = ctypes.c_int
+    L.pna_archive_list_entries.argtypes = [ctypes.c_char_p, sz, RAW_ENTRY_FN, vp]
+    L.pna_gpu_create_archive_part_host.restype = ctypes.c_int
+    L.pna_gpu_create_archive_part_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                                   ctypes.POINTER(sz), u32, SINK_FN, vp]
+    L.pna_gpu_append_archive_host.restype = ctypes.c_int
+    L.pna_gpu_append_archive_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, sz, ctypes.POINTER(ctypes.c_char_p),
+                                              ctypes.POINTER(vp), ctypes.POINTER(sz), u64p, SINK_FN, vp]
+    L.pna_gpu_stream_entry_begin.restype = ctypes.c_int
+    L.pna_gpu_stream_entry_begin.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, sz, u32, SINK_FN, vp, ctypes.POINTER(vp)]
+    L.pna_gpu_stream_entry_write.restype = ctypes.c_int
+    L.pna_gpu_stream_entry_write.argtypes = [vp, ctypes.c_char_p, sz]
+    L.pna_gpu_stream_entry_finish.restype = ctypes.c_int
+    L.pna_gpu_stream_entry_finish.argtypes = [vp]
+    L.pna_gpu_stream_entry_abort.restype = None
+    L.pna_gpu_stream_entry_abort.argtypes = [vp]
     _lib = L
     return L
 
@@ -728,3 +751,67 @@ def create_archive_with_metadata(ctx: Context, names: Sequence[str], entries: Se
     if rc:
         raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
     return bytes(out)
+
+
+def write_file(ctx: Context, sink, name: str, writes: Sequence[bytes], algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT,
+               meta: bytes = b"", max_chunk_size: int = 0) -> None:
+    """Archive::write_file (lib/src/archive/write.rs:276-299 -> write_stream_entry, :730-777): an entry whose data arrives in `writes`;
+    the record carries no fSIZ and one FDAT chunk per encoder burst.  `sink(bytes)` receives the entry's chunk bytes; `meta` = already
+    framed extra + metadata chunks."""
+    L = load_library()
+
+    def _sink(_u, buf, n):
+        sink(ctypes.string_at(buf, n))
+        return 0
+    cb = SINK_FN(_sink)
+    w = ctypes.c_void_p()
+    ctx._check(L.pna_gpu_stream_entry_begin(ctx._h, algo, level, name.encode(), meta, len(meta), max_chunk_size, cb, None, ctypes.byref(w)))
+    for d in writes:
+        rc = L.pna_gpu_stream_entry_write(w, bytes(d), len(d))
+        if rc:
+            L.pna_gpu_stream_entry_abort(w)
+            ctx._check(rc)
+    ctx._check(L.pna_gpu_stream_entry_finish(w))
+
+
+def seek_to_end(archive: bytes):
+    """Archive::seek_to_end (lib/src/archive/read.rs:412-424): (offset of the AEND chunk, has_next_archive)."""
+    off, nxt = ctypes.c_uint64(), ctypes.c_int()
+    rc = load_library().pna_archive_seek_to_end(bytes(archive), len(archive), ctypes.byref(off), ctypes.byref(nxt))
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return off.value, bool(nxt.value)
+
+
+def list_entries(archive: bytes):
+    """Top-level records of an archive image: [(name bytes, kind (-1 = solid), offset, length)] (pna_archive_list_entries)."""
+    out = []
+
+    def _cb(_u, idx, name, name_len, kind, off, ln):
+        out.append((ctypes.string_at(name, name_len) if name_len else b"", kind, off, ln))
+        return 0
+    cb = RAW_ENTRY_FN(_cb)
+    rc = load_library().pna_archive_list_entries(bytes(archive), len(archive), cb, None)
+    if rc:
+        raise PnaGpuError(rc, load_library().pna_gpu_strerror(rc).decode())
+    return out
+
+
+def append_archive(ctx: Context, archive: bytes, names: Sequence[str], entries: Sequence[bytes], algo: int = ALGO_ZSTD,
+                   level: int = LEVEL_DEFAULT) -> bytes:
+    """`pna append` (cli/src/command/append.rs:504-560): the archive with the new entries behind the old ones."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend(ctypes.string_at(buf, k))
+        return 0
+    cb = SINK_FN(_sink)
+    keep = [bytes(e) for e in entries]
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in keep])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in keep])
+    at = ctypes.c_uint64()
+    ctx._check(L.pna_gpu_append_archive_host(ctx._h, algo, level, bytes(archive), len(archive), n, a_names, a_src, a_len, ctypes.byref(at), cb, None))
+    return bytes(archive[:at.value]) + bytes(out)

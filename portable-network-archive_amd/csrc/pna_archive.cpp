@@ -59,13 +59,28 @@ struct pna_archive {
     }
 };
 
-static std::string sanitize(const char *name) {          // EntryName::sanitize, lib/src/entry/name.rs:72-80
-    std::string out, cur; std::string s(name ? name : "");
-    auto flush = [&]() { if (!cur.empty() && cur != "." && cur != "..") { if (!out.empty()) out += '/'; out += cur; } cur.clear(); };
-    for (char ch : s) { if (ch == '/' || ch == '\\') flush(); else cur += ch; }
-    flush();
+// EntryName::sanitize (lib/src/entry/name.rs:148-156): the path is NORMALISED first (normalize_utf8path, lib/src/util/utf8path.rs:6-33:
+// "." dropped, ".." pops the preceding normal component, "//" collapsed), then only the normal components are kept and joined by '/'.
+// A ".." that finds nothing to pop (or only other ".." / the root) never survives the filter, so a stack of normal components is enough.
+// '/' is the only separator: the reference splits at '\\' on Windows only (camino follows the host's std::path).
+static std::string sanitize_n(const char *name, size_t n) {
+    std::vector<std::pair<size_t, size_t>> st;          // (start, length) of the normal components kept so far
+    size_t i = 0;
+    while (i <= n) {
+        size_t j = i;
+        while (j < n && name[j] != '/') j++;
+        const size_t len = j - i;
+        if (len == 0 || (len == 1 && name[i] == '.')) { /* empty, "." */ }
+        else if (len == 2 && name[i] == '.' && name[i + 1] == '.') { if (!st.empty()) st.pop_back(); }
+        else st.emplace_back(i, len);
+        i = j + 1;
+    }
+    std::string out;
+    for (auto &c : st) { if (!out.empty()) out += '/'; out.append(name + c.first, c.second); }
     return out;
 }
+static std::string sanitize(const char *name) { return sanitize_n(name ? name : "", name ? strlen(name) : 0); }
+namespace pna { std::string pna_sanitize_name(const char *name, size_t n) { return sanitize_n(name, n); } }      // the read side hands out EntryHeader::path(), the sanitised form
 
 static std::vector<uint8_t> fhed(int kind, int compression, int encryption, int cipher_mode, const std::string &name) {
     // EntryHeader::to_bytes, lib/src/entry/header.rs:123-134
@@ -97,13 +112,12 @@ void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number) {
 }
 void frame_archive_tail(std::vector<uint8_t> &o) { put_chunk(o, "AEND", nullptr, 0); }
 // FHED | fSIZ | FDAT length + type: everything of a file entry that precedes its payload (NormalEntry::write_chunks_to, lib/src/entry.rs:895-911)
-// true when EntryName::sanitize would return the name unchanged: relative, '/'-separated, no empty / "." / ".." component, no '\\'
+// true when EntryName::sanitize would return the name unchanged: relative, '/'-separated, no empty / "." / ".." component
 static bool name_is_clean(const char *name, size_t n) {
     if (n == 0 || name[0] == '/' || name[n - 1] == '/') return false;
     size_t comp = 0;
     for (size_t i = 0; i <= n; i++) {
         const char ch = i < n ? name[i] : '/';
-        if (ch == '\\') return false;
         if (ch == '/') {
             if (comp == 0) return false;
             if (comp == 1 && name[i - 1] == '.') return false;
@@ -665,4 +679,49 @@ extern "C" int pna_join_parts(const void *const *parts, const size_t *part_len, 
     }
     uint8_t c[12]; put_be32(c, 0); memcpy(c + 4, "AEND", 4); put_be32(c + 8, pna_crc32(0, "AEND", 4));
     return out(c, 12) ? PNA_OK : PNA_E_SINK;
+}
+
+
+// ---- `pna append` / `pna update` plumbing on the host (include/pna_archive.h)
+static bool pna_image_header_ok(const uint8_t *a, size_t len) {
+    static const uint8_t sig[8] = {0x89, 0x50, 0x4E, 0x41, 0x0D, 0x0A, 0x1A, 0x0A};
+    // signature, then AHED as the first chunk (Archive::read_header, lib/src/archive/read.rs:26-44)
+    return len >= 8 + 12 + 8 && memcmp(a, sig, 8) == 0 && memcmp(a + 12, "AHED", 4) == 0 && a[8] == 0 && a[9] == 0 && a[10] == 0 && a[11] == 8;
+}
+extern "C" int pna_archive_seek_to_end(const void *archive, size_t len, uint64_t *aend_off, int *has_next) {
+    if (!archive || !aend_off) return PNA_E_INVAL;
+    const uint8_t *a = (const uint8_t *)archive;
+    if (!pna_image_header_ok(a, len)) return PNA_E_INVAL;
+    if (has_next) *has_next = 0;
+    size_t pos = 8;
+    for (;;) {
+        if (len - pos < 12) return PNA_E_INVAL;                                   // truncated: UnexpectedEof
+        const uint64_t l = ((uint64_t)a[pos] << 24) | ((uint64_t)a[pos + 1] << 16) | ((uint64_t)a[pos + 2] << 8) | a[pos + 3];
+        if (len - pos - 12 < l) return PNA_E_INVAL;
+        if (memcmp(a + pos + 4, "AEND", 4) == 0) { *aend_off = pos; return PNA_OK; }
+        if (memcmp(a + pos + 4, "ANXT", 4) == 0 && has_next) *has_next = 1;
+        pos += 12 + (size_t)l;
+    }
+}
+extern "C" int pna_archive_list_entries(const void *archive, size_t len, pna_raw_entry_fn cb, void *user) {
+    if (!archive || !cb) return PNA_E_INVAL;
+    const uint8_t *a = (const uint8_t *)archive;
+    if (!pna_image_header_ok(a, len)) return PNA_E_INVAL;
+    size_t pos = 8, idx = 0, start = 0, name_off = 0, name_len = 0;
+    int open = 0, kind = 0;                                                       // 1: inside FHED..FEND, 2: inside SHED..SEND
+    for (;;) {
+        if (len - pos < 12) return PNA_E_INVAL;
+        const uint64_t l = ((uint64_t)a[pos] << 24) | ((uint64_t)a[pos + 1] << 16) | ((uint64_t)a[pos + 2] << 8) | a[pos + 3];
+        if (len - pos - 12 < l) return PNA_E_INVAL;
+        const uint8_t *ty = a + pos + 4;
+        if (!open) {
+            if (memcmp(ty, "AEND", 4) == 0) return PNA_OK;
+            if (memcmp(ty, "FHED", 4) == 0) { if (l < 6) return PNA_E_INVAL; open = 1; start = pos; kind = a[pos + 8 + 2]; name_off = pos + 8 + 6; name_len = (size_t)l - 6; }
+            else if (memcmp(ty, "SHED", 4) == 0) { open = 2; start = pos; kind = -1; name_off = pos; name_len = 0; }
+        } else if ((open == 1 && memcmp(ty, "FEND", 4) == 0) || (open == 2 && memcmp(ty, "SEND", 4) == 0)) {
+            if (cb(user, idx++, (const char *)a + name_off, name_len, kind, start, pos + 12 + l - start) != 0) return PNA_E_SINK;
+            open = 0;
+        }
+        pos += 12 + (size_t)l;
+    }
 }

@@ -58,6 +58,7 @@ void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint
                    void *part, hipStream_t st);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
+std::string pna_sanitize_name(const char *name, size_t n);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
 void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t iv[16]);
@@ -1134,9 +1135,31 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
     return pna_gpu_create_archive_meta_host(c, algo, level, n, names, src, src_len, cipher, nullptr, sink, user);
 }
 
+static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                    const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user);
 extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                 const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                                 const pna_gpu_entry_meta *meta, pna_sink_fn sink, void *user) {
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, cipher, meta, PNA_PART_HEAD | PNA_PART_TAIL, sink, user);
+}
+extern "C" int pna_gpu_create_archive_part_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                const void *const *src, const size_t *src_len, uint32_t part_flags, pna_sink_fn sink, void *user) {
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, part_flags, sink, user);
+}
+// `pna append`: Archive::seek_to_end, then the new entries and AEND where the old AEND stood (cli/src/command/append.rs:504-560)
+extern "C" int pna_gpu_append_archive_host(pna_gpu_ctx *c, int algo, int level, const void *archive, size_t archive_len, size_t n,
+                                           const char *const *names, const void *const *src, const size_t *src_len, uint64_t *write_at,
+                                           pna_sink_fn sink, void *user) {
+    if (!c || !archive || !write_at || !sink) return fail(c, PNA_E_INVAL, "null argument");
+    int has_next = 0;
+    if (pna_archive_seek_to_end(archive, archive_len, write_at, &has_next) != PNA_OK) return fail(c, PNA_E_INVAL, "not a PNA archive, or truncated before its AEND chunk");
+    if (has_next) return fail(c, PNA_E_INVAL, "the archive continues in another part (ANXT): append to its last part");
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, PNA_PART_TAIL, sink, user);
+}
+static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                    const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user) {
     { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
@@ -1151,8 +1174,10 @@ extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int le
         for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)); }
     }
     c->timing = pna_gpu_timing{};
-    std::vector<uint8_t> head, tail; frame_archive_head(head, 0); frame_archive_tail(tail);
-    if (sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    std::vector<uint8_t> head, tail;
+    if (part_flags & PNA_PART_HEAD) frame_archive_head(head, 0);
+    if (part_flags & PNA_PART_TAIL) frame_archive_tail(tail);
+    if (!head.empty() && sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
     // sub-batches of at most SUB input bytes (an entry larger than that is a sub-batch of its own)
     // sub-batch size: the entropy kernels have a fixed latency of a few ms per launch (serial chains), so small sub-batches waste
     // the GPU; 1 GiB keeps the pipeline above the PCIe rate while the in-flight window stays bounded (2 x 1 GiB in, 2 x out)
@@ -1243,7 +1268,7 @@ extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int le
         if (out_len[sl] && sink(user, c->hp_out[sl].p, out_len[sl]) != 0) return fail(c, PNA_E_SINK, "sink failed");
         out_total += out_len[sl];
     }
-    if (sink(user, tail.data(), tail.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    if (!tail.empty() && sink(user, tail.data(), tail.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
     out_total += tail.size();
     c->timing.in_bytes = in_total; c->timing.out_bytes = out_total;
     return PNA_OK;
@@ -1256,6 +1281,30 @@ extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int le
 // mandatory CRC check, lib/src/io.rs:117-149; decrypt_reader / decompress_reader, lib/src/entry/read.rs:59-104,171-190).
 // The chunk walk and the small chunks' CRCs are host work; the data chunks' CRC-32 (k_frame in verify mode), the gather of every
 // entry's data pieces into one stream (k_gather), AES-CTR decryption and the zstd / deflate decoding run on the device.
+// The name an entry is handed out under: EntryHeader::path() (lib/src/entry/header.rs:91-94,143-147) -- the FHED bytes must be UTF-8
+// (InvalidData otherwise), and what callers see is the SANITISED form (EntryName::sanitize: no root, no "." / "..", so a crafted
+// "../../etc/x" or "/abs" cannot leave the extraction directory).  The callback takes a C string, so an embedded NUL is rejected too.
+static bool utf8_ok(const uint8_t *p, size_t n) {
+    for (size_t i = 0; i < n;) {
+        const uint8_t b = p[i];
+        size_t k; uint32_t cp;
+        if (b < 0x80) { i++; continue; }
+        else if ((b & 0xE0) == 0xC0) { k = 1; cp = b & 0x1F; }
+        else if ((b & 0xF0) == 0xE0) { k = 2; cp = b & 0x0F; }
+        else if ((b & 0xF8) == 0xF0) { k = 3; cp = b & 0x07; }
+        else return false;
+        for (size_t j = 1; j <= k; j++) { if (i + j >= n || (p[i + j] & 0xC0) != 0x80) return false; cp = (cp << 6) | (p[i + j] & 0x3F); }
+        if ((k == 1 && cp < 0x80) || (k == 2 && cp < 0x800) || (k == 3 && (cp < 0x10000 || cp > 0x10FFFF)) || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        i += k + 1;
+    }
+    return true;
+}
+static int entry_path(pna_gpu_ctx *c, const std::string &raw, std::string &out) {
+    if (memchr(raw.data(), 0, raw.size())) return fail(c, PNA_E_INVAL, "entry name contains a NUL byte");
+    if (!utf8_ok((const uint8_t *)raw.data(), raw.size())) return fail(c, PNA_E_INVAL, "entry name is not valid UTF-8");
+    out = pna::pna_sanitize_name(raw.data(), raw.size());
+    return PNA_OK;
+}
 namespace {
 struct XPiece { uint64_t off; uint32_t len; };
 struct XEntry {
@@ -1425,7 +1474,13 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
             const std::string prm = phsf.substr(p1, p2 - p1);
             for (size_t q = 0; q < prm.size();) {
                 const size_t e2 = prm.find(',', q); const std::string kv = prm.substr(q, e2 == std::string::npos ? std::string::npos : e2 - q);
-                if (kv.size() > 2 && kv[1] == '=') { const uint32_t v = (uint32_t)strtoul(kv.c_str() + 2, nullptr, 10); if (kv[0] == 'm') m = v; else if (kv[0] == 't') t = v; else if (kv[0] == 'p') lanes = v; }
+                if (kv.size() > 2 && kv[1] == '=') {
+                    char *endp = nullptr; const unsigned long long v = strtoull(kv.c_str() + 2, &endp, 10);
+                    if (!endp || *endp || endp == kv.c_str() + 2) return fail(c, PNA_E_INVAL, "malformed argon2 parameter in PHSF");
+                    // the parameters come from an untrusted archive: refuse costs that only serve to stall / exhaust the host
+                    if ((kv[0] == 'm' && v > (4ull << 20)) || (kv[0] == 't' && v > 64) || (kv[0] == 'p' && v > 256)) return fail(c, PNA_E_UNSUPPORTED, "argon2 cost beyond the accepted maximum (m <= 4 GiB, t <= 64, p <= 256)");
+                    if (kv[0] == 'm') m = (uint32_t)v; else if (kv[0] == 't') t = (uint32_t)v; else if (kv[0] == 'p') lanes = (uint32_t)v;
+                }
                 if (e2 == std::string::npos) break; q = e2 + 1;
             }
             std::vector<uint8_t> salt;
@@ -1443,7 +1498,12 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
         uint32_t rounds = 600000;
         const std::string prm = phsf.substr(p1, p2 - p1);
         const size_t ip = prm.find("i=");
-        if (ip != std::string::npos) rounds = (uint32_t)strtoul(prm.c_str() + ip + 2, nullptr, 10);
+        if (ip != std::string::npos) {
+            char *endp = nullptr; const unsigned long long v = strtoull(prm.c_str() + ip + 2, &endp, 10);
+            if (!endp || (*endp && *endp != ',') || v == 0) return fail(c, PNA_E_INVAL, "malformed pbkdf2 round count in PHSF");
+            if (v > 10000000ull) return fail(c, PNA_E_UNSUPPORTED, "pbkdf2 round count beyond the accepted maximum (10 000 000)");
+            rounds = (uint32_t)v;
+        }
         std::vector<uint8_t> salt;
         std::string sb = phsf.substr(p2 + 1); const size_t p3 = sb.find('$'); if (p3 != std::string::npos) sb.resize(p3);
         if (!b64_decode_nopad(sb, salt) || rounds == 0) return fail(c, PNA_E_INVAL, "malformed PHSF");
@@ -1622,7 +1682,8 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
             rc = key_for(e.phsf, &km); if (rc) return rc;
             uint8_t hd[75]; { uint64_t got = 0; for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < 75; k++) hd[got++] = a[p.off + k]; if (got >= 75) break; } }
             uint8_t kc[32]; hkdf_sha256_32(km, 32, nullptr, 0, "PNA-KC-v1", 9, kc);
-            if (memcmp(kc, hd + 43, 32) != 0) return fail(c, PNA_E_INVAL, "GCM STREAM: key confirmation failed (wrong password)");
+            { uint8_t diff = 0; for (int b = 0; b < 32; b++) diff |= (uint8_t)(kc[b] ^ hd[43 + b]);      // constant time, like the reference's ct_eq
+              if (diff) return fail(c, PNA_E_INVAL, "GCM STREAM: key confirmation failed (wrong password)"); }
             uint8_t info[88], ph[32], ks[32];
             memcpy(info, "PNA-STREAM-v1", 13);
             sha256_bytes("FHED", 4, e.fhed.data(), e.fhed.size(), info + 13);
@@ -1810,7 +1871,8 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
                     const uint8_t *d = D->plain[si].data();
                     if (ie.pieces.size() == 1) d += ie.pieces[0].off;
                     else { joined.clear(); for (const XPiece &p : ie.pieces) joined.insert(joined.end(), d + p.off, d + p.off + p.len); d = joined.data(); }
-                    if (cb(user, idx++, ie.name.c_str(), ie.kind, ie.len ? d : nullptr, (size_t)ie.len) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+                    std::string path; { const int rp = entry_path(c, ie.name, path); if (rp) return rp; }
+                    if (cb(user, idx++, path.c_str(), ie.kind, ie.len ? d : nullptr, (size_t)ie.len) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
                 }
             return PNA_OK;
         };
@@ -1821,7 +1883,8 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
                              : (e.has_size ? raw_host + e.raw_off : D->nosize_data[(size_t)e.raw_off].data());
             const size_t l = e.compression == PNA_ALGO_STORE ? (size_t)e.pay_len : (size_t)e.raw_size;
             if (e.compression == PNA_ALGO_STORE && e.has_size && e.raw_size != e.pay_len) return fail(c, PNA_E_INVAL, "stored entry: fSIZ differs from the data length");
-            if (cb(user, idx++, e.name.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
+            std::string path; { const int rp = entry_path(c, e.name, path); if (rp) return rp; }
+            if (cb(user, idx++, path.c_str(), e.kind, d, l) != 0) return fail(c, PNA_E_SINK, "entry callback failed");
         }
         return deliver_solids(n);
     };
@@ -2291,6 +2354,52 @@ extern "C" int pna_gpu_stream_stats(pna_gpu_ctx *c, uint64_t *batches, uint64_t 
 // Benchmark support: the reference's fan-out restated on host threads (cli/src/command/core.rs:496-537) over the streaming facade --
 // `threads` workers take entries FIFO, each entry = stream_new / write (whole entry in one call, core.rs:900-902) / finish into a
 // counting sink.  Returns the seconds spent; *out_bytes = compressed bytes seen by the sinks.
+// ---- Archive::write_file / write_stream_entry (lib/src/archive/write.rs:276-299,730-777): FHED, extra + metadata chunks, the compressed
+// stream as one FDAT chunk per encoder burst (ChunkStreamWriter::write, lib/src/chunk/write.rs:32-47), FEND; no fSIZ.
+struct pna_gpu_entry_writer { pna_gpu_ctx *ctx; pna_gpu_stream *st; pna_sink_fn sink; void *user; uint32_t max_chunk; };
+static int entry_writer_chunk(pna_gpu_entry_writer *w, const char ty[4], const uint8_t *data, size_t len) {
+    uint8_t head[8] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len, (uint8_t)ty[0], (uint8_t)ty[1], (uint8_t)ty[2], (uint8_t)ty[3]};
+    const uint32_t crc = pna_crc32(pna_crc32(0, ty, 4), data, len);
+    const uint8_t tail[4] = {(uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+    if (w->sink(w->user, head, 8) != 0 || (len && w->sink(w->user, data, len) != 0) || w->sink(w->user, tail, 4) != 0) return 1;
+    return 0;
+}
+static int entry_writer_burst(void *u, const void *buf, size_t len) {       // one encoder burst -> FDAT chunk(s) of at most max_chunk bytes
+    pna_gpu_entry_writer *w = (pna_gpu_entry_writer *)u;
+    const uint8_t *p = (const uint8_t *)buf;
+    while (len) {
+        const size_t k = std::min<size_t>(len, w->max_chunk);
+        if (entry_writer_chunk(w, "FDAT", p, k)) return 1;
+        p += k; len -= k;
+    }
+    return 0;
+}
+extern "C" int pna_gpu_stream_entry_begin(pna_gpu_ctx *c, int algo, int level, const char *name, const void *meta, size_t meta_len,
+                                          uint32_t max_chunk_size, pna_sink_fn sink, void *user, pna_gpu_entry_writer **out) {
+    if (!c || !name || !sink || !out || (meta_len && !meta)) return fail(c, PNA_E_INVAL, "null argument");
+    if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
+    if (meta_len && !meta_blob_ok((const uint8_t *)meta, meta_len)) return fail(c, PNA_E_INVAL, "extra / metadata chunks are not well-formed chunks");
+    pna_gpu_entry_writer *w = new (std::nothrow) pna_gpu_entry_writer{c, nullptr, sink, user, max_chunk_size ? max_chunk_size : 0xFFFFFFFFu};
+    if (!w) return fail(c, PNA_E_NOMEM, "out of memory");
+    int rc = pna_gpu_stream_new(c, algo, level, entry_writer_burst, w, &w->st);
+    if (rc) { delete w; return rc; }
+    const std::vector<uint8_t> fh = frame_fhed_bytes(name, algo, 0, 1);           // cipher_mode CTR (1) when unencrypted, lib/src/entry/options.rs:156-159
+    if (entry_writer_chunk(w, "FHED", fh.data(), fh.size()) || (meta_len && sink(user, meta, meta_len) != 0)) {
+        pna_gpu_stream_abort(w->st); delete w; return fail(c, PNA_E_SINK, "sink failed");
+    }
+    *out = w;
+    return PNA_OK;
+}
+extern "C" int pna_gpu_stream_entry_write(pna_gpu_entry_writer *w, const void *buf, size_t len) { return w ? pna_gpu_stream_write(w->st, buf, len) : PNA_E_INVAL; }
+extern "C" int pna_gpu_stream_entry_finish(pna_gpu_entry_writer *w) {
+    if (!w) return PNA_E_INVAL;
+    int rc = pna_gpu_stream_finish(w->st);                                        // consumes the stream; the bursts went through entry_writer_burst
+    if (rc == PNA_OK && entry_writer_chunk(w, "FEND", nullptr, 0)) rc = fail(w->ctx, PNA_E_SINK, "sink failed");
+    delete w;
+    return rc;
+}
+extern "C" void pna_gpu_stream_entry_abort(pna_gpu_entry_writer *w) { if (w) { pna_gpu_stream_abort(w->st); delete w; } }
+
 static int counting_sink(void *user, const void *, size_t len) { ((std::atomic<uint64_t> *)user)->fetch_add(len, std::memory_order_relaxed); return 0; }
 extern "C" double pna_bench_stream_threads(pna_gpu_ctx *c, int algo, int level, unsigned threads, size_t n, const void *const *src,
                                            const size_t *src_len, uint64_t *out_bytes, int *rc_out) {

@@ -196,3 +196,45 @@ def test_split_archive_equals_the_oracle_and_joins_back(pna, pf, codec):
     assert pna.split_archive(whole, len(p1)) == [p1, p2]
     with pytest.raises(pna.PnaGpuError):
         pna.join_parts([p2, p1])
+
+
+def test_entry_names_are_sanitised_like_the_reference(pna, pf):
+    """EntryName::sanitize (normalise, then keep the normal components) on the writer side: the FHED of an entry written by the product
+    carries the name the reference would write; same vectors as the oracle's test (the reference's name.rs / utf8path.rs)."""
+    from test_oracle_container import SANITIZE_VECTORS
+    for raw, want in SANITIZE_VECTORS:
+        rec = pna.inner_entry_bytes(raw, b"x")
+        body = [d for t, d, _ in pf.read_chunks(rec) if t == b"FHED"][0]
+        assert body[6:].decode() == want, raw
+        assert rec == pf.write_normal_entry(pf.file_entry_header(0, pf.sanitize_name(raw)), [b"x"], 1), raw
+
+
+def test_seek_to_end_and_entry_listing(pna, pf):
+    """Archive::seek_to_end (lib/src/archive/read.rs:412-424, tests :576-604) and the raw-entry walk `pna append` / `pna update` stand on."""
+    arc = golden("zstd.pna")
+    at, nxt = pna.seek_to_end(arc)
+    assert (at, nxt) == pf.seek_to_end(arc) == (len(arc) - 12, False) and arc[at + 4:at + 8] == b"AEND"
+    # an archive that continues in another part: ANXT is seen on the way (seek_to_end_detects_next_archive_marker)
+    p1 = golden("multipart.part1.pna")
+    assert pna.seek_to_end(p1) == pf.seek_to_end(p1) and pna.seek_to_end(p1)[1] is True
+    # truncated inside the tail chunk: UnexpectedEof in the reference (seek_to_end_rejects_archives_truncated_inside_the_tail_chunk)
+    empty = golden("empty.pna")
+    for cut in range(1, 9):
+        with pytest.raises(pna.PnaGpuError):
+            pna.seek_to_end(empty[:-cut])
+        with pytest.raises(ValueError):
+            pf.seek_to_end(empty[:-cut])
+    with pytest.raises(pna.PnaGpuError):
+        pna.seek_to_end(b"not an archive at all, just forty bytes..")
+    # the record list: names, kinds and byte ranges that tile the space between AHED and AEND
+    ents = pna.list_entries(arc)
+    _, items = pf.read_archive(arc)
+    assert [n.decode() for n, _, _, _ in ents] == [it.name for it in items]
+    pos = 28
+    for _, kind, off, ln in ents:
+        assert off == pos and arc[off + 4:off + 8] == b"FHED" and arc[off + ln - 8:off + ln - 4] == b"FEND" and kind in (0, 1, 2, 3)
+        pos += ln
+    assert pos == at
+    solid = golden("solid_zstd.pna")
+    (s,) = pna.list_entries(solid)
+    assert s[1] == -1 and solid[s[2] + 4:s[2] + 8] == b"SHED" and s[2] + s[3] == pna.seek_to_end(solid)[0]

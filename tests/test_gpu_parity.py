@@ -939,3 +939,63 @@ def test_archive_with_metadata_chunks(gpu_ctx, pna, pf, codec):
         with pytest.raises(pna.PnaGpuError) as ei:
             pna.create_archive_with_metadata(gpu_ctx, names, ents, facets=[b] * len(ents))
         assert ei.value.code == -2
+
+
+def test_extract_driver_hands_out_sanitised_names(gpu_ctx, pna, pf, codec):
+    """The read side exposes EntryHeader::path() (lib/src/entry/header.rs:91-94,143-147): names from an untrusted archive are normalised
+    and stripped of root / '.' / '..' before the callback sees them; FHED bytes that are not UTF-8, or carry a NUL, are rejected."""
+    raw_names = ["../../etc/passwd", "/abs/file", "a/../b.txt", "ok/./name", "..", "x//y"]
+    body = b"".join(pf.write_normal_entry(pf.file_entry_header(0, nm), [b"data-%d" % i], 6) for i, nm in enumerate(raw_names))
+    arc = pf.write_archive_header() + body + pf.finalize_archive()
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert [n for n, _, _ in got] == [pf.sanitize_name(n) for n in raw_names] == ["etc/passwd", "abs/file", "b.txt", "ok/name", "", "x/y"]
+    assert [d for _, _, d in got] == [b"data-%d" % i for i in range(len(raw_names))]
+    for bad in (b"bad\xff\xfename", b"nul\x00name", b"\xc0\xafoverlong", b"\xed\xa0\x80surrogate"):
+        hdr = bytes([0, 0, 0, 0, 0, 1]) + bad
+        arc2 = pf.write_archive_header() + pf.write_normal_entry(hdr, [b"x"], 1) + pf.finalize_archive()
+        with pytest.raises(pna.PnaGpuError) as ei:
+            pna.extract_archive(gpu_ctx, arc2)
+        assert ei.value.code == -2, bad
+
+
+def test_write_file_stream_entry(gpu_ctx, pna, pf, codec):
+    """Archive::write_file / write_stream_entry (lib/src/archive/write.rs:276-299,730-777): FHED, extra + metadata chunks, one FDAT per
+    encoder burst (<= 32 KiB; lib/src/chunk/write.rs:32-47), FEND -- and NO fSIZ (write.rs:830-881).  Byte-exact against the oracle's
+    restatement fed with the oracle model's stream; read back by the fixture-pinned reader and by the device extract driver."""
+    data = codec.corpus_file(0, 77, 300000)
+    extra = pf.write_chunk(b"exTr", b"extra")                       # a private ancillary chunk, as in the reference's test
+    fltp = pf.write_chunk(b"fLTP", b"\x01")
+    for algo, comp, model in ((pna.ALGO_ZSTD, 2, lambda d: codec.model_compress(d, _params(codec))), (pna.ALGO_DEFLATE, 1, codec.deflate_model_compress)):
+        for writes, mcs in (([data], 0), ([data[:1000], data[1000:200000], data[200000:]], 0), ([data], 5000), ([b""], 0), ([b"text"], 0)):
+            out = bytearray()
+            pna.write_file(gpu_ctx, out.extend, "dir/../text.txt", writes, algo=algo, meta=extra + fltp, max_chunk_size=mcs)
+            whole = b"".join(writes)
+            stream = model(whole)
+            bursts = [stream[i:i + 32768] for i in range(0, len(stream), 32768)]
+            want = pf.write_stream_entry(pf.file_entry_header(comp, "text.txt"), bursts, extra=[(b"exTr", b"extra")], facets=[(b"fLTP", b"\x01")],
+                                         max_chunk_size=mcs or None)
+            assert bytes(out) == want, (algo, len(writes), mcs)
+            types = [t for t, _, _ in pf.read_chunks(bytes(out))]
+            assert types[:3] == [b"FHED", b"exTr", b"fLTP"] and b"fSIZ" not in types and types[-1] == b"FEND"
+            arc = pf.write_archive_header() + bytes(out) + pf.finalize_archive()
+            (it,) = pf.read_archive(arc)[1]
+            assert it.raw_file_size is None and it.name == "text.txt" and codec.decode_payload(comp, it.data, len(whole) + 64) == whole
+            assert pna.extract_archive(gpu_ctx, arc) == [("text.txt", 0, whole)]      # entries without fSIZ are sized by the decoder
+
+
+def test_append_equals_create(gpu_ctx, pna, pf, codec):
+    """`pna append` (cli/src/command/append.rs:504-560): seek to AEND, add entries, finalize.  Appending k entries to an archive of m gives
+    the very bytes `pna create` writes for all m + k (per-entry streams and framing are position-independent); multipart tails refuse."""
+    ents = [codec.corpus_file(i % 2, 900 + i, n) for i, n in enumerate([300000, 0, 70001, (1 << 20) + 5, 12])]
+    names = [f"ap/{i}.txt" for i in range(len(ents))]
+    for algo in (pna.ALGO_ZSTD, pna.ALGO_DEFLATE):
+        whole = pna.create_archive(gpu_ctx, names, ents, algo=algo)
+        for m in (0, 2, 5):
+            base = pna.create_archive(gpu_ctx, names[:m], ents[:m], algo=algo)
+            got = pna.append_archive(gpu_ctx, base, names[m:], ents[m:], algo=algo)
+            assert got == whole, (algo, m)
+        assert [(it.name, codec.decode_payload(it.compression, it.data, len(e) + 64)) for it, e in zip(pf.read_archive(whole)[1], ents)] == list(zip(names, ents))
+    with pytest.raises(pna.PnaGpuError):
+        pna.append_archive(gpu_ctx, open(os.path.join(GOLDEN, "multipart.part1.pna"), "rb").read(), ["x"], [b"y"])
+    with pytest.raises(pna.PnaGpuError):
+        pna.append_archive(gpu_ctx, whole[:-5], ["x"], [b"y"])

@@ -53,9 +53,24 @@ def test_flatten_writer(pf):
     assert pf.flatten_writer([]) == []
 
 
+# EntryName::sanitize = normalize_utf8path, then only Normal components: the reference's own vectors
+# (lib/src/entry/name.rs:19-23,52-55,143-145,483-490,533-544,593-617; lib/src/util/utf8path.rs:38-58 through the filter)
+SANITIZE_VECTORS = [
+    ("uer/bin", "uer/bin"), ("/user/bin", "user/bin"), ("/user/bin/", "user/bin"), ("../user/bin/", "user/bin"), ("/", ""),
+    ("foo.txt", "foo.txt"), ("/foo.txt", "foo.txt"), ("./foo.txt", "foo.txt"), ("../foo.txt", "foo.txt"),
+    ("/var/../tmp/./log", "tmp/log"), ("/test/test.txt", "test/test.txt"), ("test/", "test"), ("test/test/", "test/test"),
+    ("./test/test.txt", "test/test.txt"), ("../test/test.txt", "test/test.txt"), ("test/../test.txt", "test.txt"),
+    ("test//test.txt", "test/test.txt"), ("test///test.txt", "test/test.txt"), ("///test///test.txt", "test/test.txt"),
+    ("", ""), ("..", ""), (".", ""), ("../../..", ""), ("/../foo", "foo"), ("./foo", "foo"),
+    ("a/b/../../a.txt", "a.txt"), ("a/../../a.txt", "a.txt"), ("a/b/./../a.txt", "a/a.txt"), ("/a//b///", "a/b"), ("a/.", "a"), ("/..", ""),
+    ("日本語/テスト.txt", "日本語/テスト.txt"), ("dir\\file.txt", "dir\\file.txt"),      # '\\' separates on Windows only
+    ("a/../..//b/./c/../d", "b/d"),
+]
+
+
 def test_name_sanitize(pf):
-    assert pf.sanitize_name("/a/./b/../c/") == "a/b/c"   # lib/src/entry/name.rs:72-80 keeps Normal components only
-    assert pf.sanitize_name("corpus/f00000.txt") == "corpus/f00000.txt"
+    for raw, want in SANITIZE_VECTORS:
+        assert pf.sanitize_name(raw) == want, raw
 
 
 @pytest.mark.parametrize("name", ["deflate.pna", "zstd.pna", "zstd_with_raw_file_size.pna"])
