@@ -277,7 +277,8 @@ void pna_gpu_stream_entry_abort(pna_gpu_entry_writer *w);
  * finish() is a group commit: concurrent finishes are collected into one device batch (the thread that finds no batch in flight
  * leads it; finishes arriving meanwhile form the next batch) and every caller receives its own stream through its own sink on
  * its own thread.  Each stream object belongs to one thread; do not mix stream calls with the context's other entry points without
- * external synchronisation.  PNA_STREAM_LINGER_US (environment, default 0) makes a leader wait for stragglers before it submits. */
+ * external synchronisation.  PNA_STREAM_LINGER_US (environment) fixes how long a leader waits for stragglers before it submits; unset: 200 us once more than one
+ * writer has been seen, nothing for a lone writer. */
 typedef struct pna_gpu_stream pna_gpu_stream;
 int  pna_gpu_stream_new(pna_gpu_ctx *ctx, int algo, int level, pna_sink_fn sink, void *user, pna_gpu_stream **out);
 int  pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t len);

@@ -151,7 +151,8 @@ struct pna_gpu_ctx {
     std::vector<pna_gpu_stream *> comb_queue;
     bool comb_leader = false;
     uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0, comb_seq = 0;
-    uint32_t comb_linger_us = 0;           // PNA_STREAM_LINGER_US: the leader waits this long for more finishes before it submits
+    uint32_t comb_linger_us = 0xFFFFFFFFu; // PNA_STREAM_LINGER_US: the leader waits this long for more finishes before it submits (unset: adaptive)
+    size_t comb_last = 0;                  // entries of the previous batch
     // page-locked memory of the streaming facade: write() copies straight into 1 MiB slabs of a pool (no staging copy before the H2D
     // copy), the compressed streams come back into one of two page-locked output slots and the owners drain them from there
     std::mutex pool_mu;
@@ -2314,9 +2315,14 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
             c->comb_leader = true;                                   // s is still queued, so the batch taken below contains it
             const int slot = (int)(c->comb_seq++ & 1);
             while (c->slot_pending[slot]) c->comb_cv.wait(lk);       // the batch before the last one is still being drained from this slot
-            if (c->comb_linger_us) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(c->comb_linger_us)); lk.lock(); }
+            {   // a short linger lets the other writers of the pool reach their finish(): with T writers in flight the batches then hold ~T
+                // entries instead of T / 2 (two alternating cohorts) -- 16 threads: 1.5 -> 2.7 GiB/s, 4: 0.40 -> 0.73, 64: 4.8 -> 5.4.
+                // Adaptive default: 200 us (a few % of a batch's ~5 ms latency) once more than one writer has been seen, none for a lone writer
+                const uint32_t lg = c->comb_linger_us != 0xFFFFFFFFu ? c->comb_linger_us : ((c->comb_last > 1 || c->comb_queue.size() > 1) ? 200u : 0u);
+                if (lg) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(lg)); lk.lock(); }
+            }
             std::vector<pna_gpu_stream *> batch; batch.swap(c->comb_queue);
-            c->slot_pending[slot] = batch.size();
+            c->slot_pending[slot] = batch.size(); c->comb_last = batch.size();
             for (pna_gpu_stream *x : batch) x->slot = slot;
             lk.unlock();
             stream_run_batch(c, batch, slot);

@@ -1,0 +1,84 @@
+// tests/san/device_stub.cpp -- TEST INFRASTRUCTURE: the launch layer of libpna_gpu.so on the CPU for the sanitizer builds.
+// The zstd write path is stubbed with a trivially valid encoder (every segment = one frame of RAW blocks; the empty entry = the
+// reference's 9-byte frame), the framing kernel (prefix + CRC-32 + FEND) is restated bytewise; everything else aborts: the sanitizer
+// driver exercises the HOST code around the kernels, not the codecs (those are checked against the oracle on the GPU).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "pna_dev.h"
+#include "../../include/pna_archive.h"
+
+namespace pna {
+[[noreturn]] static void nostub(const char *what) { fprintf(stderr, "device_stub: %s is not stubbed\n", what); abort(); }
+
+void launch_lz(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, uint32_t, hipStream_t) {}
+void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
+                          uint8_t *, uint8_t *, uint32_t *, uint32_t, hipStream_t, hipEvent_t *) {}
+static uint64_t seg_bytes(const SegDesc &sd) {
+    if (sd.len == 0) return 9;
+    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    return 6 + 3ull * nblk + sd.len;
+}
+void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *, const SegTables *, uint64_t *seg_size, uint64_t *seg_off, uint32_t, hipStream_t) {
+    uint64_t pos = 0;
+    for (uint32_t s = 0; s < nseg; s++) { seg_size[s] = seg_bytes(segs[s]); seg_off[s] = pos; pos += seg_size[s]; }
+    seg_off[nseg] = pos;
+}
+void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *, uint32_t, const BlkInfo *, const SegTables *,
+                  const uint64_t *seg_off, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *dst, hipStream_t) {
+    for (uint32_t s = 0; s < nseg; s++) {
+        const SegDesc &sd = segs[s];
+        uint8_t *o = dst + seg_off[s];
+        if (sd.len == 0) { static const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00}; memcpy(o, e, 9); continue; }
+        static const uint8_t h[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50};
+        memcpy(o, h, 6); o += 6;
+        for (uint32_t b0 = 0; b0 < sd.len; b0 += BLK_SIZE) {
+            const uint32_t bl = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+            const uint32_t hd = (b0 + bl == sd.len ? 1u : 0u) | (bl << 3);          // last | raw (0) << 1 | size << 3
+            o[0] = (uint8_t)hd; o[1] = (uint8_t)(hd >> 8); o[2] = (uint8_t)(hd >> 16);
+            memcpy(o + 3, src + sd.src_off + b0, bl); o += 3 + bl;
+        }
+    }
+}
+void launch_frame(const FrameDesc *fd, uint32_t n, const uint8_t *blob, const CrcTabs *, uint8_t *dst, uint64_t, uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t) {
+    for (uint32_t i = 0; i < n; i++) {
+        const FrameDesc &d = fd[i];
+        memcpy(dst + d.arc_off, blob + d.prefix_off, d.prefix_len);
+        uint8_t *pay = dst + d.arc_off + d.prefix_len;
+        const uint32_t crc = pna_crc32(pna_crc32(0, ty, 4), pay, d.payload_len);
+        uint8_t *q = pay + d.payload_len;
+        q[0] = (uint8_t)(crc >> 24); q[1] = (uint8_t)(crc >> 16); q[2] = (uint8_t)(crc >> 8); q[3] = (uint8_t)crc;
+        if (with_fend && !(d.pad & 2)) {
+            const uint8_t fe[12] = {0, 0, 0, 0, 'F', 'E', 'N', 'D', (uint8_t)(fend_crc >> 24), (uint8_t)(fend_crc >> 16), (uint8_t)(fend_crc >> 8), (uint8_t)fend_crc};
+            memcpy(q + 4, fe, 12);
+        }
+    }
+}
+struct PlaceDesc { uint64_t src_off, dst_off; uint32_t len, pad; };
+void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t) {
+    for (uint32_t i = 0; i < n; i++) { const PlaceDesc &d = ((const PlaceDesc *)pd)[i]; memcpy(dst + d.dst_off, src + d.src_off, d.len); }
+}
+void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) { launch_place(pd, n, src, dst, st); }
+void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); }
+
+void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, const uint4 *, DeflTables *,
+                           uint8_t *, uint64_t *, uint64_t *, hipStream_t, hipEvent_t *, uint32_t) { nostub("deflate"); }
+void launch_deflate_write(const uint8_t *, const SegDesc *, const uint32_t *, uint32_t, const BlkInfo *, const uint64_t *, const uint64_t *, const uint8_t *, const uint32_t *,
+                          uint32_t, uint8_t *, hipStream_t) { nostub("deflate"); }
+void launch_frame_verify(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t) { nostub("frame_verify"); }
+void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, hipStream_t) { nostub("zdec"); }
+void launch_zscan(const ZEntry *, uint32_t, const uint8_t *, ZFrame *, hipStream_t) { nostub("zscan"); }
+void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStream_t) { nostub("zcount"); }
+void launch_zparse(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
+void launch_zstreams(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const void *, ZBlock *, const ZFrame *, const ZTables *, const uint8_t *, uint8_t *, uint64_t *, hipStream_t) { nostub("zstreams"); }
+void launch_inflate(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
+void launch_iadler(ZFrame *, const ZFrameX *, const ZBlock *, uint32_t, const uint32_t *, uint32_t, const uint8_t *, void *, hipStream_t) { nostub("iadler"); }
+void launch_zexec(ZFrame *, const ZFrameX *, uint32_t, ZBlock *, const uint8_t *, const uint8_t *, const uint64_t *, uint8_t *, hipStream_t) { nostub("zexec"); }
+void launch_gcm_tag(const GcmEntry *, uint32_t, uint8_t *, hipStream_t) { nostub("gcm"); }
+void launch_gcm_verify(const GcmEntry *, uint32_t, const uint8_t *, const uint8_t *, uint32_t *, hipStream_t) { nostub("gcm"); }
+void launch_aes_cbc_dec(const CipherUnit *, uint32_t, const uint8_t *, const AesDecTabs *, uint8_t *, const AesKey &, uint32_t *, hipStream_t) { nostub("aes"); }
+void launch_aes_ctr(const CipherUnit *, uint32_t, const uint8_t *, const AesTabs *, uint8_t *, const AesKey &, const AesKey *, hipStream_t) { nostub("aes"); }
+void launch_aes_cbc_enc(const CipherUnit *, uint32_t, const uint8_t *, const AesTabs *, uint8_t *, const AesKey &, hipStream_t) { nostub("aes"); }
+void launch_corpus(int, uint64_t, uint64_t, uint64_t, uint64_t, const uint8_t *, const uint64_t *, const uint32_t *, uint8_t *, hipStream_t) { nostub("corpus"); }
+} // namespace pna
