@@ -338,6 +338,30 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint32_t e_last = e0;
                 const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
                 const uint64_t capm = __ballot(len[r] >= CAP1);
+#ifdef LZ_EXP_VECTORPARSE     // measured: bit-exact, 128 SALU fewer but 132 VALU more per wave and tile, B3 wait 20.6 -> 16.2 %, and 4.8 % SLOWER: the VALU port binds
+                if (rem != 0 && (capm & rem) == 0) {
+                    // No match of the group needs the extension: the greedy walk s -> first usable start at or behind the end of s's match is a
+                    // fixed jump function J, and the chosen starts are the orbit of the first usable start under J.  The orbit is marked by
+                    // pointer doubling -- members push a mark along J (ds_permute), then J := J o J (ds_bpermute) -- in four rounds (a match is
+                    // >= 6 long, so a group holds at most 11 starts <= 1 + 2 + 4 + 8): constant time per group instead of a scalar loop per chosen
+                    // match, which is what made the waves of a tile finish their parse at different times.  J is kept times four (the permute
+                    // address); "no further start" = 256 wraps to lane 0, which no jump can target (J >= 6), and lane 0 ignores what it receives.
+                    const uint64_t shf = endp < 64 ? (effm[r] >> endp) : 0;
+                    uint32_t J4 = shf ? (endp + ctz64(shf)) << 2 : 256u;
+                    const uint32_t s0 = ctz64(rem);
+                    uint32_t m = lane == s0 ? 1u : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(m ? J4 : 0u), 1);
+                        m |= lane ? recv : 0u;
+                        if (k < 3) { const uint32_t J2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)J4, (int)J4); J4 = J4 >= 256u ? 256u : J2; }
+                    }
+                    const uint64_t M = __ballot(m != 0);
+                    sel[r] = M;
+                    e_last = rdlane(endp, 63 - clz64(M));
+                    rem = 0;
+                }
+#endif
                 while (rem) {
                     const uint32_t s = ctz64(rem);
                     uint32_t e = rdlane(endp, s);

@@ -9,7 +9,10 @@
 namespace pna {
 
 constexpr uint32_t SEG_SIZE   = 1u << 20;   // one zstd frame per segment of an entry
-constexpr uint32_t BLK_SIZE   = 1u << 17;   // zstd Block_Maximum_Size
+#ifndef PNA_BLK_LOG
+#define PNA_BLK_LOG 17
+#endif
+constexpr uint32_t BLK_SIZE   = 1u << PNA_BLK_LOG;   // block size of both codecs (<= zstd's Block_Maximum_Size of 128 KiB)
 constexpr uint32_t BLK_PER_SEG = SEG_SIZE / BLK_SIZE;
 
 // LZ stage (k_lz)
@@ -37,7 +40,7 @@ constexpr uint32_t BACK_CAP   = 3;          // bytes before a match that are kno
 constexpr uint32_t CAP1       = LZ_CAP1_VALUE;
 constexpr uint32_t LOOKAHEAD  = 1024;
 constexpr uint32_t WIN_BYTES  = 65536;      // circular look-back window in LDS
-constexpr uint32_t SEQ_CAP    = 22528;      // sequences per block: (BLK_SIZE - 3 * 1024) / MIN_MATCH + one front-cut match (>= 3 bytes) per wave region, rounded up to 256
+constexpr uint32_t SEQ_CAP    = PNA_BLK_LOG == 17 ? 22528 : ((BLK_SIZE / MIN_MATCH + BLK_SIZE / 256 + 256 + 255) & ~255u);      // sequences per block: (BLK_SIZE - 3 * 1024) / MIN_MATCH + one front-cut match (>= 3 bytes) per wave region, rounded up to 256
 
 constexpr uint32_t F_HUF = 1, F_FSE = 2, F_LAZY = 4, F_REP = 8;
 

@@ -144,7 +144,7 @@ struct pna_gpu_ctx {
     std::string err;
     pna_gpu_timing timing = {};
     uint32_t last_nblk = 0;
-    size_t max_blocks = 1u << 17;          // blocks per sub-batch (16 GiB of input)
+    size_t max_blocks = (size_t)(1u << 17) << (17 - PNA_BLK_LOG);   // blocks per sub-batch (16 GiB of input)
     // group commit of the streaming facade (pna_gpu_stream_finish from many host threads -> one device batch)
     std::mutex comb_mu, run_mu;            // comb_mu: queue + leader flag; run_mu: the device batch itself and ctx->err
     std::condition_variable comb_cv;

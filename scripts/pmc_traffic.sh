@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/pmc
 mkdir -p "$OUT"
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$OUT/$(echo $c | tr A-Z a-z | cut -d_ -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o pmc -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline > "$d.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o pmc -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-verify > "$d.log" 2>&1
   tail -1 "$d.log" | cut -c1-200
 done
 python3 scripts/pmc_summarize.py "$OUT" "$FILES" > "$OUT/summary.json"

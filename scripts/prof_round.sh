@@ -7,12 +7,12 @@ TAG=${1:-i}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/kt_default.log" 2>&1
-python3 bench.py --no-cpu-baseline --framing solid --files 8192 > "$OUT/bench_solid.json" 2> "$OUT/bench_solid.err"
-python3 bench.py --no-cpu-baseline --algo deflate --files 2048 > "$OUT/bench_deflate.json" 2> "$OUT/bench_deflate.err"
-python3 bench.py --no-cpu-baseline --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
-python3 bench.py --no-cpu-baseline --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
-python3 bench.py --no-cpu-baseline --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > "$OUT/kt_default.log" 2>&1
+python3 bench.py --framing solid --files 8192 > "$OUT/bench_solid.json" 2> "$OUT/bench_solid.err"
+python3 bench.py --algo deflate --files 2048 > "$OUT/bench_deflate.json" 2> "$OUT/bench_deflate.err"
+python3 bench.py --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
+python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
+python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
 python3 scripts/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head
