@@ -128,7 +128,7 @@ def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes
             "single_thread_mib_s": n1 * file_len / secs1 / 2**20 if secs1 > 0 else None}
 
 
-def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, algo: int, runs: int = 2) -> dict:
+def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, algo: int, level: int, runs: int = 2) -> dict:
     """wall time from the first input byte in (pageable) host RAM to the last archive byte handed to the sink, through
     pna_gpu_create_archive_host (bounded window: staging || H2D || kernels || D2H).  The sink counts the bytes."""
     host = src[:n_files * stride].cpu().numpy()                  # pageable host memory, one entry per pointer
@@ -148,7 +148,7 @@ def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, a
     for it in range(runs + 1):                                   # the first run allocates the page-locked staging slots: not timed
         count[0] = count[1] = 0
         t0 = time.perf_counter()
-        rc = L.pna_gpu_create_archive_host(ctx._h, algo, pna.LEVEL_DEFAULT, n_files, a_names, a_src, a_len, cb, None)
+        rc = L.pna_gpu_create_archive_host(ctx._h, algo, level, n_files, a_names, a_src, a_len, cb, None)
         dt = time.perf_counter() - t0
         if rc:
             raise RuntimeError(f"pna_gpu_create_archive_host failed: {rc}")
@@ -203,6 +203,8 @@ def main() -> None:
     ap.add_argument("--files", type=int, default=10000, help="entries of the corpus (strong scaling: in all; weak scaling: per rank)")
     ap.add_argument("--file-mib", type=float, default=1.0)
     ap.add_argument("--algo", choices=["zstd", "deflate"], default="zstd")
+    ap.add_argument("--level", type=int, default=None, help="compression level on the reference's scale (default: zstd 3 / deflate 6); zstd 1, "
+                    "deflate 0..3 = the fast set, zstd 2 / deflate 4..5 = balanced (no lazy deferral)")
     ap.add_argument("--kind", type=int, default=0, help="corpus kind (0 enwik-style text, 1 random-text)")
     ap.add_argument("--framing", choices=["archive", "none", "solid"], default="archive",
                     help="archive: whole .pna assembled in HBM (default); none: compressed entry streams only; "
@@ -254,6 +256,7 @@ def main() -> None:
     stride = (file_len + 15) & ~15
     src = torch.empty(n_files * stride + 8192, dtype=torch.uint8, device=dev)
     algo = pna.ALGO_ZSTD if args.algo == "zstd" else pna.ALGO_DEFLATE
+    lvl = pna.LEVEL_DEFAULT if args.level is None else args.level
     # pieces: piece h of rank r holds the files [(h * world + r) * n_piece, ... + n_piece) of the corpus -- in archive order all ranks'
     # pieces 0 come first, then all pieces 1, ...: every piece is gathered in rank order as soon as it is compressed
     pieces = args.gather_pieces or (2 if world > 1 else 1)
@@ -328,11 +331,11 @@ def main() -> None:
             dst = dsts[b]
             if args.framing == "archive":
                 total, _ = ctx.create_archive_device(p_names[h], src.data_ptr(), p_off[h], p_len[h], dst.data_ptr(), dst_cap, algo=algo,
-                                                     _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h], want_offsets=False)
+                                                     _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h], want_offsets=False, level=lvl)
             elif args.framing == "solid":
-                total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0])
+                total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0], level=lvl)
             else:
-                total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo)[-1]
+                total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, level=lvl)[-1]
             tm = ctx.timing()
             lz_acc[0] += tm.ms_lz
             lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
@@ -419,7 +422,7 @@ def main() -> None:
         back = torch.empty(n_piece * stride + 64, dtype=torch.uint8, device=dev)
         for h in range(pieces):
             total, eoff = ctx.create_archive_device(p_names[h], src.data_ptr(), p_off[h], p_len[h], dsts[0].data_ptr(), dst_cap, algo=algo,
-                                                    _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h])
+                                                    _cache=arg_cache[h], part=part_flags(h), cipher=p_cipher[h], level=lvl)
             pay_off, pay_len = [], []
             for i in range(n_piece):
                 pre = 12 + 6 + len(p_names[h][i].encode()) + 12 + fs + extra + 8
@@ -436,7 +439,7 @@ def main() -> None:
         # the archive goes back through the extract driver: SDAT CRCs on the device, frames counted, open-size decode, inner records walked,
         # inner FDAT CRCs on the device; every name / length is checked, every 64th entry (and the last) byte for byte
         import numpy as np
-        total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dsts[0].data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0])
+        total = ctx.create_solid_archive_device(names, src.data_ptr(), src_off, src_len, dsts[0].data_ptr(), dst_cap, algo=algo, _cache=arg_cache[0], level=lvl)
         arc = dsts[0][:total].cpu().numpy().tobytes()
         good = [0]
         sample = set(range(0, n_files, 64)) | {n_files - 1}
@@ -461,7 +464,7 @@ def main() -> None:
             dsts.clear()
             gather_out[:] = [None] * pieces
             torch.cuda.empty_cache()
-            e2e = end_to_end(pna, ctx, src, n_files, file_len, stride, names, algo)
+            e2e = end_to_end(pna, ctx, src, n_files, file_len, stride, names, algo, lvl)
         except Exception as e:
             e2e = {"value": None, "error": repr(e)}
     if rank == 0:
@@ -471,7 +474,7 @@ def main() -> None:
         alg_bytes = in_rank + out_total                      # each input byte read once + each output byte written once
         achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
         tm = tm_last
-        level = 3 if args.algo == "zstd" else 6
+        level = pna.clamp_level(algo, lvl)
         wl = (f"{files_all} x {size_label(file_len)}" if args.framing != "solid" else f"--solid, one {size_label(files_all * file_len)} stream of {files_all} x {size_label(file_len)} entries")
         line = {
             "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}-{level}, {wl} {'enwik-style' if args.kind == 0 else 'random-text'} corpus"

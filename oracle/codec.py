@@ -151,11 +151,29 @@ class ZstdParams(ctypes.Structure):
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
+F_FAR, F_ADOPT, F_INS2 = 0x10, 0x20, 0x40       # the product's level-set bits (include/pna_gpu.h); the model takes explicit parameters
 
 
 def default_params() -> ZstdParams:
     p = ZstdParams()
     lib().pna_zstd_default_params(ctypes.byref(p))
+    return p
+
+
+def params_for_flags(flags: int, deflate: bool = False) -> ZstdParams:
+    """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
+    F_ADOPT there is no backward adoption, without F_INS2 every position enters the table."""
+    p = deflate_default_params() if deflate else default_params()
+    p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
+    if not deflate:
+        p.flags &= ~8                     # no repeat codes on the device
+        if not flags & F_FAR:
+            p.max_off = p.near_off
+    if not flags & F_ADOPT:
+        p.rounds = 0
+        p.back_cap = 0
+    if not flags & F_INS2:
+        p.ins_mod = 1
     return p
 
 

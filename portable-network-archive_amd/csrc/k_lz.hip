@@ -33,7 +33,7 @@
 #ifdef LZ_EXP_ALLINS
 #define LZ_INS_COND true
 #else
-#define LZ_INS_COND !(lane & 1)
+#define LZ_INS_COND (ins_all || !(lane & 1))
 #endif
 
 namespace pna {
@@ -149,6 +149,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t lazy = flags & F_LAZY;
+    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);   // (wave-uniform) level sets: pna_host.cpp level_flags()
     const bool force_serial = (flags & FLAG_FORCE_SERIAL) != 0;
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
@@ -237,7 +238,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
                 off[r] = (c1 > 4 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
-                if (FAR && seg_len > NEAR) {                                        // (uniform) shorter segments have no far candidates
+                if (FAR && seg_len > NEAR && max_off > NEAR) {                      // (uniform) shorter segments / near-only levels have no far candidates
                     const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
                     fa[r] = *(const U4u *)(seg + fo);
                     fb[r] = *(const u32u *)(seg + fo + 16);
@@ -305,6 +306,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 // back count and adopt "lengths" of 1..3 from such neighbours: they stay below MIN_MATCH and nobody reads them as a match.
                 uint32_t K = (l << 5) | bk4;
 #ifndef LZ_EXP_NOADOPT
+                if (adopt) {
                 {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
                     const uint32_t K1 = dpp_next_lane(K), T = K1 + 29u;
                     K = ((K1 & 0xCu) != 0 && T > (K | 31u)) ? T : K;
@@ -315,6 +317,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 }
                 l = K >> 5;
                 off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 3u)));          // the offset travels with the match
+                }
 #endif
                 len[r] = l; flen[r] = l;
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)

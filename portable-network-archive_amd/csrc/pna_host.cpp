@@ -191,7 +191,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     if (hipSetDevice(device_id) != hipSuccess) return PNA_E_NODEVICE;
     pna_gpu_ctx *c = new pna_gpu_ctx();
     c->device = device_id;
-    c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY) : (flags & 0xFF);
+    c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
     if (const char *pm = getenv("PNA_STREAM_POOL_MIB")) c->pool_cap = (size_t)std::min<unsigned long>(strtoul(pm, nullptr, 10), 1ul << 20) << 20;
     if (const char *lg = getenv("PNA_STREAM_LINGER_US")) c->comb_linger_us = (uint32_t)std::min<unsigned long>(strtoul(lg, nullptr, 10), 100000ul);
@@ -247,13 +247,18 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
     return 0;
 }
 
-// Two parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
-// lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101): levels below the default (zstd < 3, deflate < 6) take the plain greedy parse,
-// the default and everything above it greedy + one-step lazy deferral (the best this encoder has).  PNA_LEVEL_DEFAULT = the default.
+// Three parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
+// lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101; PNA_LEVEL_DEFAULT and zstd level 0 = the default):
+//   fast      zstd < 0 and 1, deflate 0..3   greedy parse, every position in the table, look-back = the LDS window, no backward adoption
+//   balanced  zstd 2,         deflate 4..5   + even-position table, backward adoption, 1 MiB look-back (zstd); still greedy
+//   default   zstd 0, 3..22,  deflate 6..9   + one-step lazy deferral (the strongest parse this encoder has)
 static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const int lv = pna_gpu_clamp_level(algo, level);
-    const int dflt = algo == PNA_ALGO_DEFLATE ? 6 : 3;
-    return lv < dflt ? (c->flags & ~F_LAZY) : c->flags;
+    const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
+    const bool balanced = algo == PNA_ALGO_DEFLATE ? (lv == 4 || lv == 5) : lv == 2;
+    if (fast) return c->flags & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2);
+    if (balanced) return c->flags & ~F_LAZY;
+    return c->flags;
 }
 
 extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
@@ -535,7 +540,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
-                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | 0x300u)), 32768u, 258u, st);
+                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | 0x300u)), 32768u, 258u, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
@@ -558,7 +563,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
             launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr,
-                      c->call_flags & 0x3FFu, MAX_OFF, 0xFFFFFFFFu, st);
+                      c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st);
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));

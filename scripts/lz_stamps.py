@@ -6,7 +6,7 @@ pna = importlib.import_module("portable-network-archive_amd")
 n, L = 1024, 1 << 20
 import sys as _s
 extra = int(_s.argv[1], 0) if len(_s.argv) > 1 else 0
-ctx = pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | 0x100 | extra)
+ctx = pna.Context(0, flags=pna.F_STD | 0x100 | extra)
 src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
 ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())
 dst = torch.empty(n * (L + 1024), dtype=torch.uint8, device="cuda")

@@ -4,7 +4,7 @@ import torch
 pna = importlib.import_module("portable-network-archive_amd")
 n, L = 1024, 1 << 20
 for extra in (0, 0x400, 0x800, 0xC00):
-    ctx = pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | extra)
+    ctx = pna.Context(0, flags=pna.F_STD | extra)
     src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
     ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())
     dst = torch.empty(n * (L + 1024), dtype=torch.uint8, device="cuda")

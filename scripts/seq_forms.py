@@ -10,7 +10,7 @@ n, L = 10000, 1 << 20
 src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
 dst = torch.empty(n * (L + 1024), dtype=torch.uint8, device="cuda")
 for extra in (0, 0x1000, 0x2000):
-    ctx = pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | extra)
+    ctx = pna.Context(0, flags=pna.F_STD | extra)
     ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())
     best = None
     for it in range(3):

@@ -73,7 +73,7 @@ def test_serial_end_scan_is_identical(pna, codec):
     import torch  # noqa: F401
     cases = _cases(codec)
     names = sorted(cases)
-    with pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | 0x200) as ctx:
+    with pna.Context(0, flags=pna.F_STD | 0x200) as ctx:
         outs = ctx.compress_batch([cases[k] for k in names])
     p = _params(codec)
     for k, o in zip(names, outs):
@@ -87,20 +87,23 @@ def test_both_sequence_coder_forms_are_identical(pna, codec, form):
     import torch  # noqa: F401
     cases = _cases(codec)
     names = sorted(cases)
-    with pna.Context(0, flags=pna.F_HUF | pna.F_FSE | pna.F_LAZY | form) as ctx:
+    with pna.Context(0, flags=pna.F_STD | form) as ctx:
         outs = ctx.compress_batch([cases[k] for k in names])
     p = _params(codec)
     for k, o in zip(names, outs):
         assert o == codec.model_compress(cases[k], p), k
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 0x77, 0x27, 0x67, 0x17, 0x47, 0x37])
 def test_feature_subsets_bit_exact(pna, codec, flags):
+    """Every subset of the encoder's switches -- Huffman / FSE / lazy, and the level-set bits F_FAR (0x10), F_ADOPT (0x20), F_INS2 (0x40) --
+    against the model with the corresponding parameters."""
     import torch  # noqa: F401
-    ents = [codec.corpus_file(0, 21, 300000), codec.corpus_file(1, 22, 5000), bytes(70000), b"", codec.corpus_file(2, 1, 3000)]
+    ents = [codec.corpus_file(0, 21, 300000), codec.corpus_file(1, 22, 5000), bytes(70000), b"", codec.corpus_file(2, 1, 3000),
+            codec.corpus_file(0, 23, 1 << 20)]
     with pna.Context(0, flags=flags) as ctx:
         outs = ctx.compress_batch(ents)
-    p = codec.default_params(); p.flags = flags
+    p = codec.params_for_flags(flags)
     for e, o in zip(ents, outs):
         assert o == codec.model_compress(e, p)
         assert codec.zstd_decompress(o, len(e)) == e
@@ -864,23 +867,27 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
 
 
 def test_levels_select_the_parse(gpu_ctx, pna, codec):
-    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto two parameter sets: below the
-    default (zstd < 3, deflate < 6) the plain greedy parse, from the default upwards greedy + lazy; both bit-exact with the model."""
+    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto three parameter sets -- fast (greedy,
+    LDS-window look-back, every position in the table), balanced (+ even-position table, backward adoption, 1 MiB look-back) and default
+    (+ lazy) --, each bit-exact with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
-    pz = codec.default_params()
-    for level, lazy in ((-5, False), (1, False), (2, False), (3, True), (pna.LEVEL_DEFAULT, True), (19, True), (22, True), (99, True)):
-        pz.flags = codec.F_HUF | codec.F_FSE | (codec.F_LAZY if lazy else 0)
+    std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
+    fast, balanced, dflt = codec.F_HUF | codec.F_FSE, std, std | codec.F_LAZY
+    sizes = {}
+    for level, fl in ((-5, fast), (1, fast), (2, balanced), (0, dflt), (3, dflt), (pna.LEVEL_DEFAULT, dflt), (19, dflt), (22, dflt), (99, dflt)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
+        pz = codec.params_for_flags(fl)
         assert outs == [codec.model_compress(d, pz) for d in data], level
-    pd = codec.deflate_default_params()
-    base = pd.flags
-    for level, lazy in ((0, False), (1, False), (5, False), (6, True), (pna.LEVEL_DEFAULT, True), (9, True)):
-        pd.flags = (base | codec.F_LAZY) if lazy else (base & ~codec.F_LAZY)
+        sizes[level] = sum(map(len, outs))
+    assert sizes[3] < sizes[2] < sizes[1]
+    dstd = codec.F_ADOPT | codec.F_INS2
+    for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd), (5, dstd), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
+        pd = codec.params_for_flags(fl, deflate=True)
         assert outs == [codec.deflate_model_compress(d, pd) for d in data], level
         assert all(codec.zlib_decompress(o) == d for o, d in zip(outs, data))
-    lazy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=3))); greedy_sz = sum(map(len, gpu_ctx.compress_batch(data, level=1)))
-    assert lazy_sz < greedy_sz
+        sizes[("d", level)] = sum(map(len, outs))
+    assert sizes[("d", 6)] < sizes[("d", 4)] < sizes[("d", 1)]
 
 
 def test_extract_driver_windows(gpu_ctx, pna, pf, codec):
