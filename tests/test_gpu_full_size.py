@@ -124,3 +124,77 @@ def test_deflate_one_million_small_entries(gpu_ctx, pna, codec):
         got = host[offs[i]:offs[i + 1]].tobytes()
         assert zlib.decompress(got) == want, i
         assert got == codec.deflate_model_compress(want), i
+
+
+def test_entry_beyond_4gib_round_trips(gpu_ctx, pna, pf, codec):
+    """tests/bats/large_file.bats (a 5 GiB file through create + extract): ONE entry of 5 GiB (+ a small one behind it) -- 64-bit offsets
+    through segment planning, the write kernels, the 1 GiB FDAT cut and the device decoder.  The archive is checked structurally
+    (fSIZ of five bytes, FDAT chunks of at most 1 GiB, every chunk CRC), sampled frames go through an independent decoder, and every byte
+    is decoded on the device and compared in HBM."""
+    import numpy as np
+    import torch
+    n1, L = 5 * 1024, 1 << 20
+    big = n1 * L
+    _need_hbm(torch, 80)
+    src = torch.empty(big + 4096 + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 7000, n1, L, L, src.data_ptr())                # the big entry = 5 120 corpus files back to back
+    gpu_ctx.corpus_fill_device(1, 1, 1, 3000, 3000, src.data_ptr() + big)
+    so, sl = [0, big, big + 3000], [big, 3000]
+    names = ["large/five_gib.bin", "large/small.txt"]
+    cap = pna.archive_bound(pna.ALGO_ZSTD, names, sl)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), so, sl, dst.data_ptr(), cap)
+    assert eoff[0] == 28 and eoff[2] == total - 12 and total > (1 << 30)
+    # ---- structure on the host: chunk walk with CRCs, fSIZ, FDAT sizes
+    arc = dst[:total].cpu().numpy()
+    kinds, fdat = [], []
+    for ty, off, ln, crc in _chunks(arc):
+        assert zlib.crc32(arc[off:off + ln].tobytes(), zlib.crc32(ty)) == crc, (ty, off)
+        kinds.append(ty)
+        if ty == b"FDAT":
+            fdat.append((off, ln))
+        if ty == b"fSIZ" and len(kinds) == 3:
+            assert int.from_bytes(arc[off:off + ln].tobytes(), "big") == big and ln == 5
+    assert kinds[:3] == [b"AHED", b"FHED", b"fSIZ"] and kinds[-1] == b"AEND" and kinds.count(b"FHED") == 2
+    big_fdat = fdat[:-1]
+    assert len(big_fdat) >= 2 and all(ln <= (1 << 30) for _, ln in big_fdat) and 2.4 < big / sum(ln for _, ln in big_fdat) < 3.2
+    # ---- an independent decoder on frames around the 4 GiB mark of the entry (frame k = input bytes [k MiB, (k + 1) MiB))
+    stream = np.concatenate([arc[o:o + ln] for o, ln in big_fdat])
+    pos, k, want_frames = 0, 0, {0, 4095, 4096, 4097, n1 - 1}
+    dec = codec.libzstd_decompress_stream if codec.system_libzstd() is not None else codec.zstd_decompress
+    while pos < len(stream):                                                     # frame walk: header 6 bytes, blocks until the last-block flag
+        assert bytes(stream[pos:pos + 4]) == bytes.fromhex("28b52ffd")
+        q = pos + 6
+        while True:
+            h = int(stream[q]) | (int(stream[q + 1]) << 8) | (int(stream[q + 2]) << 16)
+            q += 3 + (1 if (h >> 1) & 3 == 1 else h >> 3)
+            if h & 1:
+                break
+        if k in want_frames:
+            assert dec(stream[pos:q].tobytes(), L) == codec.corpus_file(0, 7000 + k, L), k
+        pos, k = q, k + 1
+    assert k == n1
+    del stream
+    # ---- every byte: payload offsets from the chunk walk -> device decoder -> compare in HBM
+    back = torch.zeros(big + 4096 + 64, dtype=torch.uint8, device="cuda")
+    # (the device decoder takes one contiguous payload per entry: gather the big entry's FDAT bodies on the device first)
+    packed = torch.cat([dst[o:o + ln] for o, ln in big_fdat])
+    gpu_ctx.decompress_batch_device(packed.data_ptr(), [0], [packed.numel()], back.data_ptr(), [0], [big])
+    assert torch.equal(back[:big], src[:big])
+    o2, l2 = fdat[-1]
+    gpu_ctx.decompress_batch_device(dst.data_ptr(), [o2], [l2], back.data_ptr(), [big], [3000])
+    assert torch.equal(back[big:big + 3000], src[big:big + 3000])
+    # ---- and through the extract driver (`pna extract` of the 5 GiB entry: tests/bats/large_file.bats)
+    del back, packed
+    host_src = src.cpu().numpy()
+    seen = []
+
+    def _cb(_u, idx, name, kind, data, ln):
+        lo = so[idx]
+        got = np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_ubyte)), shape=(ln,))
+        seen.append((name.decode(), ln, bool(np.array_equal(got, host_src[lo:lo + ln]))))
+        return 0
+    cb = pna.ENTRY_FN(_cb)
+    buf = arc.tobytes()
+    gpu_ctx._check(gpu_ctx._L.pna_gpu_extract_archive_host(gpu_ctx._h, buf, len(buf), None, 0, cb, None))
+    assert seen == [(names[0], big, True), (names[1], 3000, True)]
