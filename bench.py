@@ -175,6 +175,11 @@ class HostGather:
             dist.barrier()
         if rank != 0:
             self.shm = shared_memory.SharedMemory(name=name)
+            try:                                               # rank 0 owns (and unlinks) the segment: keep this process' tracker out of it
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:
+                pass
         self.t = torch.frombuffer(self.shm.buf, dtype=torch.uint8)
         self.registered = int(torch.cuda.cudart().cudaHostRegister(self.t.data_ptr(), self.t.numel(), 0)) == 0
 
@@ -231,13 +236,22 @@ def main() -> None:
                  f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     import torch
     import torch.distributed as dist
+    # PNA_BENCH_REHEARSAL=1: the N > 1 control flow on a box with ONE GPU -- every rank uses cuda:0 and the exchange runs over gloo on host
+    # copies (RCCL refuses two ranks on one device).  Timings of such a run mean nothing; it exists to check shard layout, part flags,
+    # the ordered gather and the gathered archive.
+    rehearsal = bool(os.environ.get("PNA_BENCH_REHEARSAL")) and world > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not rehearsal) else 0)
+    xdev = torch.device("cpu") if rehearsal else dev           # where the exchange's tensors live
 
     pna = importlib.import_module("portable-network-archive_amd")
     ctx = pna.Context(dev.index)
@@ -302,6 +316,7 @@ def main() -> None:
     arg_cache = [dict() for _ in range(pieces)]
 
     gather_out = [None] * pieces                              # rank 0: where the pieces h of all ranks land, in rank order
+    piece_sizes = [None] * pieces                             # bytes every rank contributed to piece h (from the last gather of that piece)
     pending = [None] * nbuf                                   # the gather that still reads dsts[b]
     cur = [0]
     mode = ["rccl"]                                           # "rccl": ordered gather onto rank 0's HBM; "d2h": direct copies into the shared host buffer
@@ -312,7 +327,8 @@ def main() -> None:
         for k in (range(nbuf) if b is None else [b]):
             if pending[k] is not None:
                 if pending[k] != "d2h":
-                    shard.gather_ordered_wait(pending[k])
+                    _, sizes_k = shard.gather_ordered_wait(pending[k][0])
+                    piece_sizes[pending[k][1]] = sizes_k
                 torch.cuda.current_stream().synchronize()     # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
                 pending[k] = None
 
@@ -341,13 +357,13 @@ def main() -> None:
             lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
             if world > 1 and mode[0] == "rccl":
                 if rank == 0 and gather_out[h] is None:
-                    gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
-                pending[b] = shard.gather_ordered_start(dst, total, rank, world, out=gather_out[h])
+                    gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=xdev)
+                pending[b] = (shard.gather_ordered_start(dst[:total].cpu() if rehearsal else dst, total, rank, world, out=gather_out[h]), h)
             elif mode[0] == "d2h":
                 # sizes of piece h of all ranks -> this rank's offset inside the archive image on the host
-                sizes_t = torch.zeros(world, dtype=torch.int64, device=dev)
+                sizes_t = torch.zeros(world, dtype=torch.int64, device=xdev)
                 if world > 1:
-                    dist.all_gather_into_tensor(sizes_t, torch.tensor([total], dtype=torch.int64, device=dev))
+                    dist.all_gather_into_tensor(sizes_t, torch.tensor([total], dtype=torch.int64, device=xdev))
                 else:
                     sizes_t[0] = total
                 sizes = [int(x) for x in sizes_t.tolist()]
@@ -375,7 +391,7 @@ def main() -> None:
             dist.barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out
@@ -385,7 +401,7 @@ def main() -> None:
     dt, out_total = timed(args.steps)
     lz_ms, stage_ms = lz_acc
     if world > 1:
-        o = torch.tensor([out_total], dtype=torch.int64, device=dev)
+        o = torch.tensor([out_total], dtype=torch.int64, device=xdev)
         dist.all_reduce(o)
         out_all = int(o.item())
     else:
@@ -412,6 +428,29 @@ def main() -> None:
             finish_gather()
             if host_gather[0] is not None:
                 host_gather[0].close(dist, world)
+
+    # ---- N > 1: the GATHERED archive (all ranks' pieces in index order, as rank 0 holds it) goes through the extract driver: every name in
+    # the corpus order, every length, every 64th entry byte for byte against a freshly generated copy of that corpus file
+    gathered_ok = None
+    if world > 1 and rank == 0 and args.framing == "archive" and args.encrypt == "none" and not args.no_verify and all(x is not None for x in piece_sizes):
+        import numpy as np
+        arc = b"".join(gather_out[h][:sum(piece_sizes[h])].cpu().numpy().tobytes() for h in range(pieces))
+        order = [lo + i for h in range(pieces) for r in range(world) for lo, _ in [shard.piece_ranges(r, world, pieces, n_piece)[h]] for i in range(n_piece)]
+        scratch = torch.empty(stride + 64, dtype=torch.uint8, device=dev)
+        good = [0]
+
+        def _gcb(_u, idx, name, kind, data, ln):
+            ok1 = idx < len(order) and name.decode() == f"enwik/part{order[idx]:07d}.txt" and kind == 0 and ln == file_len
+            if ok1 and idx % 64 == 0 and ln:
+                ctx.corpus_fill_device(args.kind, order[idx], 1, file_len, stride, scratch.data_ptr())
+                got = np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_ubyte)), shape=(ln,))
+                ok1 = bool(np.array_equal(got, scratch[:ln].cpu().numpy()))
+            good[0] += 1 if ok1 else 0
+            return 0
+        gcb = pna.ENTRY_FN(_gcb)
+        rcg = ctx._L.pna_gpu_extract_archive_host(ctx._h, arc, len(arc), None, 0, gcb, None)
+        gathered_ok = bool(rcg == 0 and good[0] == files_all)
+        del arc
 
     # ---- decode this rank's last archive on the device and compare with the inputs
     verified = None
@@ -493,6 +532,7 @@ def main() -> None:
                        "gather_pieces": pieces},
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
+            "gathered_archive_verified": gathered_ok,    # N > 1: the archive gathered on rank 0 read back through the extract driver
             "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing),
