@@ -210,10 +210,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // ---- lookup
             uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G];
             bool hv[G];
+            // (uniform) a tile that lies wholly inside the block and at least 8 bytes before the segment end needs no per-lane range checks
+            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 q[r] = t0 + wbase + 64 * r + lane;
-                hv[r] = (q[r] < t1) && (q[r] + 8 <= seg_len);
+                hv[r] = tile_full || ((q[r] < t1) && (q[r] + 8 <= seg_len));
                 {
                     const uint32_t *p = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);    // p[1], p[2] may lie in the mirror
                     const uint32_t sh = (q[r] & 3) * 8;
@@ -255,7 +257,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 if (o != 0) {
                     const uint32_t c = q[r] - o;
                     const bool isfar = FAR && o > NEAR;
-                    uint32_t lim = blk_end - q[r]; lim = lim < CAP1 ? lim : CAP1;
+                    const bool edge = blk_end - (t0 + wbase + 64u * r) < 64u + CAP1;       // (uniform) only the block's last groups can run into its end
                     // all 16 bytes at once: in a wave of 64 candidates some lane nearly always needs bytes 8..15, so a
                     // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
                     const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
@@ -297,7 +299,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                             l = k16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
                         }
                     }
-                    l = l < lim ? l : lim;
+                    if (edge) { const uint32_t lim = blk_end - q[r]; l = l < lim ? l : lim; }
                     if (l < MIN_MATCH) l = 0;
                     // bytes before q and c that agree as well, nearest first: the low byte forced to differ caps the count at BACK_CAP = 3
                     bk4 = ((uint32_t)__builtin_clz((bq[r] ^ bc) | 0xFFu) >> 1) & 0xCu;
@@ -320,9 +322,11 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 }
 #endif
                 len[r] = l; flen[r] = l;
-                const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0)
-                const bool eff = l >= MIN_MATCH && !(lazy && lane != 63 && (q[r] + 1 < t1) && nl > l);
-                effm[r] = __ballot(eff);
+                const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0, so lane 63 never defers)
+                // lazy deferral: position q waits iff q + 1 is still in the tile and holds a longer match.  nl > l with l < MIN_MATCH is harmless
+                // (the position is no start anyway); q + 1 >= t1 only happens in a block's last, partial tile (nl is 0 there: lanes >= t1 hold no match)
+                const uint64_t longer = lazy ? __ballot(nl > l) : 0;
+                effm[r] = __ballot(l >= MIN_MATCH) & ~longer;
             };
             LZ_STAMP(2);
 

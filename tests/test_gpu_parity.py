@@ -297,6 +297,20 @@ def test_full_size_properties_10k_x_1mib(gpu_ctx, pna, codec):
     back = torch.zeros(n * L + 64, dtype=torch.uint8, device="cuda")
     gpu_ctx.decompress_batch_device(dst.data_ptr(), offs[:n], [offs[i + 1] - offs[i] for i in range(n)], back.data_ptr(), so[:n], sl)
     assert torch.equal(back[:n * L], src[:n * L])
+    del back
+    # ... and ALL 10 000 entries through an INDEPENDENT decoder as well (the system's libzstd, multi-frame streaming decode as zstd-rs does
+    # it, on a pool of host threads), compared with the source copied out of HBM: not one entry rests on this repository's decoder alone
+    if codec.system_libzstd() is not None:
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
+        host_src = src[:n * L].cpu().numpy()
+
+        def check(i):
+            got = np.frombuffer(codec.libzstd_decompress_stream(host[offs[i]:offs[i + 1]], L), dtype=np.uint8)
+            return len(got) == L and bool(np.array_equal(got, host_src[i * L:(i + 1) * L]))
+        with ThreadPoolExecutor(max_workers=min(32, (os.cpu_count() or 8))) as ex:
+            ok = list(ex.map(check, range(n)))
+        assert all(ok), [i for i, v in enumerate(ok) if not v][:8]
 
 
 def test_deflate_bit_exact_and_inflatable(gpu_ctx, pna, codec):
