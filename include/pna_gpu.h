@@ -131,14 +131,14 @@ typedef struct {
     uint8_t key[32];            /* AES-256 key; GCM: K_master, the per-entry stream keys are derived from it (HKDF) */
     const char *phsf;           /* body of the PHSF chunk */
     const uint8_t *ivs;         /* CBC / CTR: n x 16 bytes; GCM: n x 39 bytes (salt[32] || nonce_prefix[7] per entry); or NULL */
-    uint32_t gcm_segment_size;  /* GCM: segment size written into the stream header (0 = 64 MiB, the format's maximum) */
+    uint32_t gcm_segment_size;  /* GCM: segment size written into the stream header (0 = 1 MiB, the reference's DEFAULT_SEGMENT_SIZE; at most 64 MiB) */
 } pna_gpu_cipher;
 /* PNA_MODE_GCM (archive entry points, non-solid): entry record FHED(enc, 2) | fSIZ | PHSF | FDAT(stream header, 75 bytes) |
  * FDAT(ciphertext || tag) | FEND.  The stream key is HKDF(K_master, salt, entry context) with the context bound to the entry's FHED
- * chunk and the PHSF string (derive_stream_key, aead.rs:184-199); every entry is ONE final GCM segment (nonce = prefix || 0 || 1), so
- * an entry whose compressed payload exceeds the segment size is PNA_E_UNSUPPORTED -- with the default 64 MiB that is a > 64 MiB
- * compressed entry.  (The reference's CLI writes 1 MiB segments; the segment size is a field of the stream header and its reader
- * follows it, lib/src/cipher/gcm.rs:146-160.) */
+ * chunk and the PHSF string (derive_stream_key, aead.rs:184-199).  The payload is cut into segments of gcm_segment_size bytes, each
+ * followed by its 16-byte tag (GcmEncryptWriter, lib/src/cipher/gcm.rs:48-100): nonce = prefix || counter || flag, flag 1 on the last
+ * segment (an empty payload is one empty final segment).  An entry whose payload spans several FDAT chunks (> 1 GiB compressed) is
+ * PNA_E_UNSUPPORTED with GCM. */
 size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher);
 /* pna_gpu_create_archive_part_device with a cipher (cipher == NULL or encryption == PNA_ENC_NONE: identical to it). */
 int  pna_gpu_create_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,

@@ -124,6 +124,7 @@ struct pna_gpu_ctx {
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
     hipStream_t x_cp = nullptr; hipEvent_t x_ev[2] = {}, x_done = nullptr;   // extract driver: D2H of window k on x_cp next to window k+1's work
     bool aes_dec_ready = false;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
+    DevBuf ci_spread, ci_spread_desc;                          // GCM entries of several segments: their compact payloads, the pieces to move
     DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
     hipEvent_t ev_ci[2] = {};
@@ -210,7 +211,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -469,6 +470,7 @@ constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR
 
 // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry; cipher + ivs (16 bytes per
 // global entry index): the payloads are encrypted in place before their CRC-32 is taken
+struct PlaceDescH { uint64_t src_off, dst_off; uint32_t len, pad; };   // = PlaceDesc of k_frame.hip (k_place / k_gather)
 struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; const pna_gpu_entry_meta *meta = nullptr; };
 static size_t meta_len(const pna_gpu_entry_meta *m, size_t e) {
     if (!m) return 0;
@@ -583,8 +585,15 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     FrameDesc *fds = nullptr; uint8_t *blob = nullptr; uint64_t *segdst = nullptr; size_t blob_len = 0;
     const bool solid = fj && fj->solid;
     const bool gcm = fj && fj->cipher && fj->cipher->cipher_mode == PNA_MODE_GCM;
-    const uint32_t gcm_seg = gcm ? (fj->cipher->gcm_segment_size ? fj->cipher->gcm_segment_size : (64u << 20)) : 0u;
+    const uint32_t gcm_seg = gcm ? (fj->cipher->gcm_segment_size ? fj->cipher->gcm_segment_size : (1u << 20)) : 0u;   // default = the reference's DEFAULT_SEGMENT_SIZE (1 MiB)
     std::vector<GcmMaterial> gmat; std::vector<GcmEntry> gents;
+    // GCM STREAM segments of this sub-batch, in order (an entry has ceil(payload / segment_size) of them, at least one): counter-mode IV
+    // (nonce || 2) and the entry they belong to; `spread`: pieces of the compact payload that move to their place between the tags
+    struct GcmSeg { uint8_t ctr_iv[16]; uint32_t entry; };
+    std::vector<GcmSeg> gsegs;
+    struct SpreadPiece { uint64_t src, dst; uint32_t len; };
+    std::vector<SpreadPiece> spread; uint64_t spread_bytes = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> spread_copy;     // (archive offset, length) of the compact payloads to save first
     size_t nunit = e1 - e0;                                    // framed units: entries, or the segments of the solid stream
     if (solid) {
         if (e1 - e0 != 1) return fail(c, PNA_E_INVAL, "a solid stream is one entry");
@@ -699,14 +708,37 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                             cunits.push_back(CipherUnit{p0, 0, (uint32_t)plen, (uint32_t)(e - e0)});
                             plen = (plen / 16 + 1) * 16;
                         } else if (gcm) {
-                            // one final GCM segment per entry: ciphertext, then its 16-byte tag (GcmEncryptWriter::finish, gcm.rs:62-66)
-                            if (g1 < s1 || !first || plen > gcm_seg) return fail(c, PNA_E_UNSUPPORTED, "GCM entry beyond one stream segment");
-                            for (uint64_t o = 0; o < plen; o += CTR_UNIT)
-                                cunits.push_back(CipherUnit{p0 + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
-                            GcmEntry ge{p0, (uint32_t)plen, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
-                            memcpy(ge.h, gmat[e - e0].h, 16); memcpy(ge.ej0, gmat[e - e0].ej0, 16);
-                            gents.push_back(ge);
-                            plen += 16;
+                            // GCM STREAM (GcmEncryptWriter, lib/src/cipher/gcm.rs:48-100): the payload in segments of segment_size bytes, every
+                            // segment followed by its 16-byte tag; all but the last carry nonce flag 0, the last one (possibly full, possibly
+                            // empty) flag 1; counters 0, 1, ...  The write kernels have put the payload down compactly: segments k >= 1 move
+                            // forward by 16 k bytes (through a scratch copy) before the cipher runs.
+                            if (g1 < s1 || !first) return fail(c, PNA_E_UNSUPPORTED, "GCM entry beyond one FDAT chunk");
+                            const uint64_t K = plen ? (plen + gcm_seg - 1) / gcm_seg : 1;
+                            if (K > 0xFFFFFFFFull) return fail(c, PNA_E_INVAL, "GCM segment counter overflow");
+                            const GcmMaterial &gm = gmat[e - e0];
+                            if (K > 1) { spread_copy.emplace_back(p0, plen); }
+                            for (uint64_t k = 0; k < K; k++) {
+                                const uint64_t sl = std::min<uint64_t>(gcm_seg, plen - k * gcm_seg), so_ = p0 + k * ((uint64_t)gcm_seg + 16);
+                                const uint32_t si = (uint32_t)gsegs.size();
+                                uint8_t j0[16], eb[16];
+                                memcpy(j0, gm.ctr_iv, 7);                                  // nonce prefix
+                                j0[7] = (uint8_t)(k >> 24); j0[8] = (uint8_t)(k >> 16); j0[9] = (uint8_t)(k >> 8); j0[10] = (uint8_t)k; j0[11] = k + 1 == K ? 1 : 0;
+                                j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+                                aes256_block_host(gm.rk, j0, eb);
+                                GcmSeg gs; memcpy(gs.ctr_iv, j0, 16); gs.ctr_iv[15] = 2; gs.entry = (uint32_t)(e - e0);
+                                gsegs.push_back(gs);
+                                for (uint64_t o = 0; o < sl; o += CTR_UNIT)
+                                    cunits.push_back(CipherUnit{so_ + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, sl - o), si});
+                                GcmEntry ge{so_, (uint32_t)sl, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                                memcpy(ge.h, gm.h, 16);
+                                for (int w = 0; w < 4; w++) ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
+                                gents.push_back(ge);
+                                if (k >= 1)
+                                    for (uint64_t o = 0; o < sl; o += (1u << 20))
+                                        spread.push_back(SpreadPiece{spread_bytes + k * gcm_seg + o, so_ + o, (uint32_t)std::min<uint64_t>(1u << 20, sl - o)});
+                            }
+                            if (K > 1) spread_bytes += (plen + 15) & ~(uint64_t)15;
+                            plen += 16 * K;
                         } else {
                             for (uint64_t o = 0; o < plen; o += CTR_UNIT)
                                 cunits.push_back(CipherUnit{p0 + o, cpos + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
@@ -755,9 +787,20 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         std::vector<uint8_t> giv; std::vector<AesKey> gkeys;
         if (gcm) {
             if (solid) return fail(c, PNA_E_UNSUPPORTED, "GCM on the solid device path");
-            giv.resize((e1 - e0) * 16); gkeys.resize(e1 - e0);
-            for (size_t i = 0; i < e1 - e0; i++) { memcpy(&giv[16 * i], gmat[i].ctr_iv, 16); gkeys[i] = gmat[i].rk; }
-            if (c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) || c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+            giv.resize(gsegs.size() * 16); gkeys.resize(gsegs.size());
+            for (size_t i = 0; i < gsegs.size(); i++) { memcpy(&giv[16 * i], gsegs[i].ctr_iv, 16); gkeys[i] = gmat[gsegs[i].entry].rk; }
+            if (c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) || c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16) || c->ci_ivs.ensure(giv.size() + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+            if (!spread.empty()) {
+                // multi-segment entries: save the compact payloads, then put the segments behind the first one at their places between the tags
+                std::vector<PlaceDescH> pd(spread.size());
+                for (size_t i = 0; i < spread.size(); i++) pd[i] = PlaceDescH{spread[i].src, spread[i].dst, spread[i].len, 0};
+                if (c->ci_spread.ensure(spread_bytes + 64) || c->ci_spread_desc.ensure(pd.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+                uint64_t sp = 0;
+                for (auto &cp : spread_copy) { HIPCHK(c, hipMemcpyAsync((uint8_t *)c->ci_spread.p + sp, d_dst + cp.first, cp.second, hipMemcpyDeviceToDevice, st)); sp += (cp.second + 15) & ~(uint64_t)15; }
+                HIPCHK(c, hipMemcpyAsync(c->ci_spread_desc.p, pd.data(), pd.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
+                launch_gather(c->ci_spread_desc.p, (uint32_t)pd.size(), (const uint8_t *)c->ci_spread.p, d_dst, st);
+                HIPCHK(c, hipStreamSynchronize(st));              // pd goes out of scope
+            }
             HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, giv.data(), giv.size(), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->ci_keys.p, gkeys.data(), gkeys.size() * sizeof(AesKey), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->ci_gcm.p, gents.data(), gents.size() * sizeof(GcmEntry), hipMemcpyHostToDevice, st));
@@ -877,7 +920,13 @@ extern "C" int pna_gpu_create_archive_part_device(pna_gpu_ctx *c, int algo, int 
 
 extern "C" size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher) {
     size_t b = pna_gpu_archive_bound(algo, n, names, src_len);
-    if (cipher && cipher->encryption != PNA_ENC_NONE && cipher->phsf) b += n * (12 + strlen(cipher->phsf) + 12 + 75 + 16);   // PHSF, FDAT(iv | stream header), CBC padding / GCM tag
+    if (cipher && cipher->encryption != PNA_ENC_NONE && cipher->phsf) {
+        b += n * (12 + strlen(cipher->phsf) + 12 + 75 + 16);   // PHSF, FDAT(iv | stream header), CBC padding / the final GCM tag
+        if (cipher->cipher_mode == PNA_MODE_GCM) {               // one more tag per full stream segment of the (bounded) payload
+            const uint64_t seg = cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20);
+            for (size_t i = 0; i < n; i++) b += 16 * (pna_gpu_bound(algo, (size_t)src_len[i]) / seg);
+        }
+    }
     return b;
 }
 
@@ -992,7 +1041,6 @@ extern "C" int pna_gpu_cipher_apply_device(pna_gpu_ctx *c, const pna_gpu_cipher 
 //      one stream in HBM,
 //   2. that stream is compressed as ONE entry (independent 1 MiB frames / zlib blocks inside the kernels),
 //   3. every segment's output becomes one SDAT chunk between SHED and SEND.
-struct PlaceDescH { uint64_t src_off, dst_off; uint32_t len, pad; };
 
 extern "C" size_t pna_gpu_solid_archive_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len) {
     uint64_t plain = 0;
@@ -1199,6 +1247,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
             if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
             off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
             sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
+            if (cipher && cipher->cipher_mode == PNA_MODE_GCM) sb.out_cap += 16 * (pna_gpu_bound(algo, (size_t)l) / (cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20)));   // a tag per full stream segment
             sb.e1++;
         }
         sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;

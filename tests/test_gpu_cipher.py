@@ -274,25 +274,29 @@ def test_gcm_stream_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec,
             src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
     k_master = hashlib.pbkdf2_hmac("sha256", b"password", b"saltsaltsalt", 1000, 32)
     sp = os.urandom(39 * len(lens))
-    seg = 64 << 20
-    ci = pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp)
-    cap = pna.archive_enc_bound(algo, names, lens, ci)
-    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
-    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
-    got = dst[:total].cpu().numpy().tobytes()
-    assert gpu_ctx.timing().ms_cipher > 0
     payloads = gpu_ctx.compress_batch(ents, algo=algo)
-    want = bytearray(pf.write_archive_header())
-    for i, (nm, pl, e) in enumerate(zip(names, payloads, ents)):
-        salt, prefix = sp[39 * i:39 * i + 32], sp[39 * i + 32:39 * i + 39]
-        fhed = pf.entry_header_bytes(pf.KIND_FILE, algo, 1, 2, pf.sanitize_name(nm))
-        ks = codec.derive_stream_key(k_master, salt, prefix, seg, b"FHED", fhed, PHSF.encode())
-        want += pf.write_encrypted_file_entry(algo, 1, 2, pf.sanitize_name(nm), PHSF, codec.stream_header_bytes(salt, prefix, seg, k_master),
-                                              codec.gcm_stream_encrypt(ks, prefix, seg, pl), len(e))
-    want += pf.finalize_archive()
-    assert len(got) == len(want) and got == bytes(want)
-    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
-    _, items = pf.read_archive(got)
+    # segment sizes: the default (1 MiB = the reference's DEFAULT_SEGMENT_SIZE: every payload here is one final segment), 64 KiB and 4 KiB
+    # (payloads of up to several hundred segments, full last segments, tags between the segments: GcmEncryptWriter, gcm.rs:48-100)
+    for seg_arg, seg in ((0, 1 << 20), (65536, 65536), (4096, 4096)):
+        ci = pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp, gcm_segment_size=seg_arg)
+        cap = pna.archive_enc_bound(algo, names, lens, ci)
+        dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+        total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+        got = dst[:total].cpu().numpy().tobytes()
+        assert gpu_ctx.timing().ms_cipher > 0
+        want = bytearray(pf.write_archive_header())
+        for i, (nm, pl, e) in enumerate(zip(names, payloads, ents)):
+            salt, prefix = sp[39 * i:39 * i + 32], sp[39 * i + 32:39 * i + 39]
+            fhed = pf.entry_header_bytes(pf.KIND_FILE, algo, 1, 2, pf.sanitize_name(nm))
+            ks = codec.derive_stream_key(k_master, salt, prefix, seg, b"FHED", fhed, PHSF.encode())
+            want += pf.write_encrypted_file_entry(algo, 1, 2, pf.sanitize_name(nm), PHSF, codec.stream_header_bytes(salt, prefix, seg, k_master),
+                                                  codec.gcm_stream_encrypt(ks, prefix, seg, pl), len(e))
+        want += pf.finalize_archive()
+        assert len(got) == len(want) and got == bytes(want), seg
+        assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+        if seg != 1 << 20:
+            assert max(len(pl) for pl in payloads) > 3 * seg                          # several segments were written
+    _, items = pf.read_archive(got)                                                  # (the 4 KiB-segment archive of the loop's last round)
     for it, e in zip(items, ents):
         assert (it.encryption, it.cipher_mode, it.raw_file_size) == (1, 2, len(e))
         phsf = [d for ty, d in it.chunks if ty == b"PHSF"][0]
@@ -309,11 +313,13 @@ def test_gcm_stream_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec,
     bad = bytearray(items[8].data); bad[100] ^= 1
     with pytest.raises(ValueError, match="authentication"):
         codec.decrypt_payload_gcm(km, bytes(bad), items[8].chunks[0][0], items[8].chunks[0][1], phsf)
-    # an entry beyond one stream segment is refused, not mis-framed
-    with pytest.raises(pna.PnaGpuError) as ei:
-        gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo,
-                                      cipher=pna.Cipher(k_master, PHSF, pna.MODE_GCM, ivs=sp, gcm_segment_size=65536))
-    assert ei.value.code == -7
+    # multi-segment entries through the device read side as well (segment size 64 KiB: tags verified per segment, then decrypt + decode)
+    ci = pna.Cipher(km, phsf.decode(), pna.MODE_GCM, gcm_segment_size=65536)
+    cap = pna.archive_enc_bound(algo, names, lens, ci)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, _ = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+    back = pna.extract_archive(gpu_ctx, dst[:total].cpu().numpy().tobytes(), b"password")
+    assert [d for _, _, d in back] == ents
 
 
 def test_extract_driver_decrypts_ctr_archives(gpu_ctx, pna, codec):
