@@ -14,6 +14,7 @@ namespace pna {
 
 enum { IF_OK = 0, IF_CORRUPT = 1, IF_UNSUPPORTED = 2, IF_DSTSIZE = 3 };          // = ZD_* of k_zdec.hip (ZFrame::status)
 typedef unsigned long long if_u64u __attribute__((aligned(1)));
+typedef uint32_t u32u_i __attribute__((aligned(1)));
 
 constexpr uint32_t IF_LROOT = 11, IF_DROOT = 10;          // bits resolved by the first-level tables
 constexpr uint32_t IF_RING = 512;                          // input ring, dwords (two halves of 256)
@@ -104,7 +105,7 @@ __device__ uint32_t if_build(const uint8_t *lens, uint32_t nsym, uint32_t root, 
 
 __global__ __launch_bounds__(64)
 void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
-               uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs) {
+               uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs, const uint32_t *__restrict__ mode) {
     __shared__ uint16_t lt[1u << IF_LROOT], dt[1u << IF_DROOT];
     __shared__ uint32_t ring[IF_RING];
     __shared__ uint64_t sstage[IF_SEQ_STAGE];
@@ -115,6 +116,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     const uint32_t lane = threadIdx.x, f = blockIdx.x;
     const bool l0 = lane == 0;
     if (IF_U(frames[f].status)) return;
+    if (mode && IF_U(mode[f]) != 1u) return;                               // lane-per-piece decode took this stream (VM_SERIAL = 1)
     const uint64_t src_off = (uint64_t)IF_U((uint32_t)frames[f].src_off) | ((uint64_t)IF_U((uint32_t)(frames[f].src_off >> 32)) << 32);
     const uint64_t dst_off = (uint64_t)IF_U((uint32_t)frames[f].dst_off) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_off >> 32)) << 32);
     const uint32_t src_len = IF_U(frames[f].src_len), dst_len = IF_U(frames[f].dst_len);
@@ -389,17 +391,345 @@ __global__ void k_iadler_fin(ZFrame *__restrict__ frames, const ZFrameX *__restr
         a = (a + pr.x) % IF_ADLER_P;
         left -= len;
     }
-    if ((uint32_t)((b << 16) | a) != blocks[fx[f].blk_base].pad[1]) frames[f].status = IF_CORRUPT;
+    if ((uint32_t)((b << 16) | a) != blocks[fx[f].blk_base + fx[f].nblk - 1].pad[1]) frames[f].status = IF_CORRUPT;   // the trailer was read with the last block
 }
 
-void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, lit_scratch, seqs);
+void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, lit_scratch, seqs, mode);
 }
 void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
                    void *part, hipStream_t st) {
     if (!n) return;
     if (npieces) hipLaunchKernelGGL(k_iadler_part, dim3(npieces), dim3(256), 0, st, (const ZFrame *)frames, cbase, n, dst, (uint2 *)part);
     hipLaunchKernelGGL(k_iadler_fin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, blocks, cbase, (const uint2 *)part, n);
+}
+
+// =====================================================================================================================
+// Lane-per-piece inflate (round 2).  The wave-per-stream walk above keeps ONE scalar unit busy per stream and saturates the chip's 256
+// scalar units at a few thousand streams (11 GiB/s); here every LANE walks a "piece" on the vector units:
+//   * a whole zlib stream whose decoded size is at most BLK_SIZE (small entries: BASELINE configs[4]'s 4 KiB files), or
+//   * one sync-flush delimited piece of a larger stream.  This library's deflate encoder closes every 128 KiB block with a sync flush
+//     (empty stored block: ... 00 00 FF FF), so a stream of raw_len bytes holds ceil(raw_len / BLK_SIZE) byte-aligned pieces of exactly
+//     BLK_SIZE decoded bytes (the last: the rest).  k_imark finds the markers; a stream whose marker count does not fit that pattern, or
+//     whose pieces do not decode to exactly those sizes (a foreign encoder, a chance 00 00 FF FF inside compressed data), is handed to
+//     the wave-per-stream kernel afterwards -- nothing is assumed that is not checked.
+// Decoding is CANONICAL: per lane the symbols of both codes in canonical order in LDS (320 x u16, lane-interleaved: element e of lane l at
+// e * 64 + l), the first code and list position of every code length in registers; a symbol = fifteen compare steps of plain ALU work
+// plus ONE LDS read.  Lookup tables per lane were measured first (9 + 7 bits, 126 KiB of LDS per wave, one wave per CU): with 64
+// independent streams in step some lane misses the table in most rounds, so every round paid the miss path anyway, and the one resident
+// wave left three SIMDs of the CU idle (90 ms per 2 048 x 1 MiB against 171 ms for the scalar walk); 40 KiB per wave puts four waves on
+// a CU.  The code lengths of a dynamic block are decoded TWICE (count, then place) instead of being stored.  Output: the same
+// intermediate form as k_inflate -- literal bytes + (literal run, match length, distance + 3) records, one ZBlock per piece; k_zoff /
+// k_zexec / the Adler kernels run unchanged.
+constexpr uint32_t VI_LDS = 320 * 64 * 2;                               // 40 KiB per wave: four waves (one per SIMD) share a CU
+enum { VM_PIECES = 0, VM_SERIAL = 1 };
+
+struct VPiece { uint32_t frame, j; };
+
+// ---- k_imark: one workgroup per stream: piece boundaries.  pb[blk_base + j] = start of piece j (relative to the stream), pb[... + P] = end.
+__global__ __launch_bounds__(256)
+void k_imark(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint32_t *__restrict__ pb,
+             uint32_t *__restrict__ mode) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const ZFrame fr = frames[f];
+    const uint32_t P = fx[f].blk_cap, base = fx[f].blk_base + f;          // P + 1 boundary slots per stream
+    if (P <= 1) { if (tid == 0) { pb[base] = 0; pb[base + 1] = fr.src_len; mode[f] = VM_PIECES; } return; }
+    const uint8_t *p = src + fr.src_off;
+    const uint32_t n = fr.src_len, per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
+    uint32_t c = 0;
+    for (uint32_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
+    cnt[tid] = c;
+    __syncthreads();
+    if (tid == 0) { uint32_t r = 0; for (uint32_t i = 0; i < 256; i++) { const uint32_t t = cnt[i]; cnt[i] = r; r += t; } mode[f] = r == P - 1 ? VM_PIECES : VM_SERIAL; pb[base] = 0; pb[base + P] = n; }
+    __syncthreads();
+    if (mode[f] != VM_PIECES) return;
+    uint32_t k = cnt[tid];
+    for (uint32_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) { pb[base + 1 + k] = i + 4; k++; }
+}
+
+// ---- k_icount: sync-flush markers per stream (streams of unknown size: the host sizes the piece list from it)
+__global__ __launch_bounds__(256)
+void k_icount(const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint64_t *__restrict__ len, uint32_t *__restrict__ count) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint8_t *p = src + off[f];
+    const uint64_t n = len[f], per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
+    uint32_t c = 0;
+    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
+    cnt[tid] = c;
+    __syncthreads();
+    for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) cnt[tid] += cnt[tid + s2]; __syncthreads(); }
+    if (tid == 0) count[f] = cnt[0];
+}
+void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_icount, dim3(n), dim3(256), 0, st, src, off, len, count);
+}
+
+__global__ __launch_bounds__(64)
+void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const VPiece *__restrict__ pieces, uint32_t npieces,
+                const uint32_t *__restrict__ pb, const uint32_t *__restrict__ mode, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
+                uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t vlds[];
+    uint16_t *lsy = (uint16_t *)vlds;                                        // [320][64]: 0..287 literal / length symbols in canonical order, 288.. distance symbols
+    const uint32_t lane = threadIdx.x, pi = blockIdx.x * 64 + lane;
+    bool live = pi < npieces;
+    VPiece pc = live ? pieces[pi] : VPiece{0, 0};
+    const ZFrame fr = frames[pc.frame];
+    const ZFrameX x = fx[pc.frame];
+    if (live && (fr.status || mode[pc.frame] != VM_PIECES)) live = false;
+    const uint32_t P = x.blk_cap;
+    const uint32_t bslot = x.blk_base + pc.frame;
+    const uint32_t p_start = live ? pb[bslot + pc.j] : 0u, p_end = live ? pb[bslot + pc.j + 1] : 0u;
+    const bool first = pc.j == 0, lastp = pc.j + 1 == P;
+    const bool open = (fr.out_len & ZF_OPEN) != 0;                           // dst_len is a capacity: the last piece's size is found by decoding it
+    const uint64_t room = (uint64_t)fr.dst_len > (uint64_t)pc.j * BLK_SIZE ? (uint64_t)fr.dst_len - (uint64_t)pc.j * BLK_SIZE : 0;
+    const uint32_t expect = lastp ? (uint32_t)(open && room > BLK_SIZE ? BLK_SIZE : room) : BLK_SIZE;
+    const uint8_t *sp = src + fr.src_off;
+    uint8_t *lit_out = lit_scratch + fr.dst_off + (size_t)pc.j * BLK_SIZE;
+    const uint32_t pcap = x.seq_cap / (P ? P : 1);
+    uint64_t *rec_out = seqs + x.seq_base + (size_t)pc.j * pcap;
+#define LS(e)  lsy[(e) * 64 + lane]
+    // bit reader: bytes of [p_start, p_end) of the stream, zeros beyond; the three words after the buffer are always on their way
+    uint32_t pos = p_start;                                                  // first byte not yet in the buffer
+    uint64_t bitbuf = 0; uint32_t bitcnt = 0;
+    auto load4 = [&](uint32_t at) -> uint32_t {
+        if (at + 4 <= p_end) return *(const u32u_i *)(sp + at);
+        uint32_t v = 0; for (uint32_t k = 0; k < 4; k++) if (at + k < p_end) v |= (uint32_t)sp[at + k] << (8 * k); return v;
+    };
+    uint32_t ahead = live ? load4(pos) : 0u, ahead1 = live ? load4(pos + 4) : 0u, ahead2 = live ? load4(pos + 8) : 0u;
+    auto refill = [&]() { if (bitcnt <= 32) { bitbuf |= (uint64_t)ahead << bitcnt; bitcnt += 32; pos += 4; ahead = ahead1; ahead1 = ahead2; ahead2 = load4(pos + 8); } };
+    auto take = [&](uint32_t nb) -> uint32_t { const uint32_t v = (uint32_t)bitbuf & ((1u << nb) - 1u); bitbuf >>= nb; bitcnt -= nb; return v; };
+    auto bytepos = [&]() -> uint32_t { return pos - (bitcnt >> 3); };          // byte position of the next unread bit (when byte-aligned)
+    enum { S_ZHEAD, S_BLOCK, S_TOKENS, S_TRAILER, S_DONE };
+    uint32_t state = live ? (first ? S_ZHEAD : S_BLOCK) : S_DONE, status = IF_OK, lastblk = 0;
+    uint32_t nlit = 0, nseq = 0, ll = 0, adler = 0; uint64_t mtot = 0;
+    uint32_t litw = 0;                                                       // up to 3 literals waiting for a dword store
+    auto put_lit = [&](uint32_t b) {
+        litw |= b << (8 * (nlit & 3)); nlit++;
+        if (!(nlit & 3)) { *(u32u_i *)(lit_out + nlit - 4) = litw; litw = 0; }
+    };
+    // canonical codes, per length L = 1..15: first code (lfc / dfc), position of its first symbol in LS (lbs / dbs; entry 16 = end)
+    uint32_t lfc[16], lbs[17], dfc[16], dbs[17];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { lfc[q] = 0; lbs[q] = 0; dfc[q] = 0; dbs[q] = 288; }
+    lbs[16] = 0; dbs[16] = 288;
+    // counts per length -> first codes and list positions; false for an invalid code set (zlib's inflate_table rules)
+    auto layout = [&](const uint32_t (&cnt)[16], uint32_t (&fc)[16], uint32_t (&bs)[17], uint32_t base) -> bool {
+        int left = 1; uint32_t maxl = 0, code = 0, run = base;
+        fc[0] = 0; bs[0] = base;
+#pragma unroll
+        for (int L = 1; L < 16; L++) { left = (left << 1) - (int)cnt[L]; if (cnt[L]) maxl = (uint32_t)L; fc[L] = code; bs[L] = run; code = (code + cnt[L]) << 1; run += cnt[L]; }
+        bs[16] = run;
+        return !(left < 0 || (left > 0 && maxl > 1));
+    };
+    auto decode = [&](const uint32_t (&fc)[16], const uint32_t (&bs)[17]) -> uint32_t {   // symbol | length << 12, 0 = no code
+        const uint32_t rv = __builtin_bitreverse32((uint32_t)bitbuf);         // the stream's next bits, first bit in the top position
+        uint32_t idx = 0, len = 0;
+#pragma unroll
+        for (int L = 15; L >= 1; L--) { const uint32_t d = (rv >> (32 - L)) - fc[L]; if (d < bs[L + 1] - bs[L]) { idx = bs[L] + d; len = (uint32_t)L; } }
+        return len ? (uint32_t)LS(idx) | (len << 12) : 0u;
+    };
+    auto bump = [&](uint32_t (&a)[16], uint32_t L, uint32_t by) {
+#pragma unroll
+        for (int q = 1; q < 16; q++) a[q] += L == (uint32_t)q ? by : 0u;
+    };
+    for (uint32_t guard = 0; __ballot(state != S_DONE) != 0; guard++) {
+        if (state == S_ZHEAD) {
+            refill();
+            const uint32_t cmf = take(8), flg = take(8);
+            if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0) status = IF_CORRUPT;
+            else if (flg & 0x20) status = IF_UNSUPPORTED;
+            state = status ? S_DONE : S_BLOCK;
+        } else if (state == S_BLOCK) {
+            refill();
+            lastblk = take(1);
+            const uint32_t btype = take(2);
+            if (btype == 0) {
+                (void)take(bitcnt & 7);
+                refill();
+                const uint32_t len = take(16); refill(); const uint32_t nlen = take(16);
+                if ((len ^ nlen) != 0xFFFFu) { status = IF_CORRUPT; state = S_DONE; }
+                else {
+                    uint32_t at = bytepos();
+                    if (at + len > p_end || (uint64_t)nlit + len + mtot > expect) { status = at + len > p_end ? IF_CORRUPT : IF_DSTSIZE; state = S_DONE; }
+                    else {
+                        for (uint32_t k = 0; k < len; k++) put_lit(sp[at + k]);
+                        ll += len; at += len;
+                        pos = at; bitbuf = 0; bitcnt = 0; ahead = load4(pos); ahead1 = load4(pos + 4); ahead2 = load4(pos + 8);
+                        // the empty stored block that closes a piece: the reader stands at the piece's end
+                        if (lastblk) state = S_TRAILER;
+                        else if (!lastp && at == p_end) state = S_DONE;
+                    }
+                }
+            } else if (btype == 1) {
+                // fixed code: lengths 7 (256..279), 8 (0..143, 280..287), 9 (144..255); 32 distance codes of 5 bits
+                uint32_t cl[16], cd[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) { cl[q] = 0; cd[q] = 0; }
+                cl[7] = 24; cl[8] = 152; cl[9] = 112; cd[5] = 32;
+                (void)layout(cl, lfc, lbs, 0); (void)layout(cd, dfc, dbs, 288);
+                for (uint32_t i = 0; i < 24; i++) LS(i) = (uint16_t)(256 + i);
+                for (uint32_t i = 0; i < 144; i++) LS(24 + i) = (uint16_t)i;
+                for (uint32_t i = 0; i < 8; i++) LS(168 + i) = (uint16_t)(280 + i);
+                for (uint32_t i = 0; i < 112; i++) LS(176 + i) = (uint16_t)(144 + i);
+                for (uint32_t i = 0; i < 32; i++) LS(288 + i) = (uint16_t)i;
+                state = S_TOKENS;
+            } else if (btype == 2) {
+                refill();
+                const uint32_t hlit = take(5) + 257, hdist = take(5) + 1, hclen = take(4) + 4;
+                if (hlit > 286 || hdist > 30) { status = IF_CORRUPT; state = S_DONE; }
+                else {
+                    constexpr uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                    uint64_t clp = 0;
+                    for (uint32_t i = 0; i < hclen; i++) { refill(); clp |= (uint64_t)take(3) << (3 * ORDER[i]); }
+                    // the code length code: 19 symbols, lengths <= 7, decoded by matching canonical codes in symbol order
+                    uint32_t ccnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t s2 = 0; s2 < 19; s2++) { const uint32_t L = (uint32_t)(clp >> (3 * s2)) & 7;
+#pragma unroll
+                        for (int q = 1; q < 8; q++) ccnt[q] += L == (uint32_t)q ? 1u : 0u; }
+                    int left = 1; uint32_t cfirst[8]; { uint32_t code = 0;
+#pragma unroll
+                        for (int L = 1; L < 8; L++) { left = (left << 1) - (int)ccnt[L]; cfirst[L] = code; code = (code + ccnt[L]) << 1; } }
+                    if (left != 0) { status = IF_CORRUPT; state = S_DONE; }
+                    else {
+                        const uint32_t total = hlit + hdist;
+                        // the code lengths are walked twice from here: pass 0 counts the lengths, pass 1 places the symbols
+                        const uint32_t s_pos = pos, s_cnt = bitcnt, s_a = ahead, s_a1 = ahead1, s_a2 = ahead2; const uint64_t s_buf = bitbuf;
+                        uint32_t cl[16], cd[16], rl[16], rd[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) { cl[q] = 0; cd[q] = 0; rl[q] = 0; rd[q] = 0; }
+                        bool eob = false;
+                        for (uint32_t pass = 0; pass < 2 && status == IF_OK; pass++) {
+                            if (pass == 1) {
+                                pos = s_pos; bitcnt = s_cnt; ahead = s_a; ahead1 = s_a1; ahead2 = s_a2; bitbuf = s_buf;
+                                if (!eob || !layout(cl, lfc, lbs, 0) || !layout(cd, dfc, dbs, 288)) { status = IF_CORRUPT; break; }
+#pragma unroll
+                                for (int q = 0; q < 16; q++) { rl[q] = lbs[q]; rd[q] = dbs[q]; }
+                            }
+                            uint32_t n = 0, prev = 0;
+                            while (n < total && status == IF_OK) {
+                                refill();
+                                const uint32_t rv = __builtin_bitreverse32((uint32_t)bitbuf);
+                                uint32_t sym = 19, sl = 0, nx[8];
+#pragma unroll
+                                for (int q = 1; q < 8; q++) nx[q] = cfirst[q];
+                                for (uint32_t s2 = 0; s2 < 19 && sym == 19; s2++) {
+                                    const uint32_t L = (uint32_t)(clp >> (3 * s2)) & 7;
+                                    uint32_t cdv = 0;
+#pragma unroll
+                                    for (int q = 1; q < 8; q++) if (L == (uint32_t)q) { cdv = nx[q]; nx[q]++; }
+                                    if (L && (rv >> (32 - L)) == cdv) { sym = s2; sl = L; }
+                                }
+                                if (sym == 19) { status = IF_CORRUPT; break; }
+                                (void)take(sl);
+                                uint32_t rep = 1, val = sym;
+                                if (sym < 16) prev = sym;
+                                else if (sym == 16) { if (n == 0) { status = IF_CORRUPT; break; } rep = 3 + take(2); val = prev; }
+                                else if (sym == 17) { rep = 3 + take(3); val = 0; prev = 0; }
+                                else { rep = 11 + take(7); val = 0; prev = 0; }
+                                if (n + rep > total) { status = IF_CORRUPT; break; }
+                                if (val) {
+                                    const uint32_t a = n < hlit ? (rep < hlit - n ? rep : hlit - n) : 0u;   // how many of the run belong to the literal / length code
+                                    if (pass == 0) {
+                                        bump(cl, val, a); bump(cd, val, rep - a);
+                                        if (n <= 256 && 256 < n + rep) eob = true;
+                                    } else {
+                                        for (uint32_t k = 0; k < rep; k++) {
+                                            const uint32_t sy = n + k; const bool isl = sy < hlit;
+                                            uint32_t at = 0;
+#pragma unroll
+                                            for (int q = 1; q < 16; q++) if (val == (uint32_t)q) { at = isl ? rl[q] : rd[q]; if (isl) rl[q]++; else rd[q]++; }
+                                            LS(at) = (uint16_t)(isl ? sy : sy - hlit);
+                                        }
+                                    }
+                                }
+                                n += rep;
+                            }
+                        }
+                        state = status ? S_DONE : S_TOKENS;
+                    }
+                }
+            } else { status = IF_CORRUPT; state = S_DONE; }
+        } else if (state == S_TOKENS) {
+            // a handful of tokens per visit, so that lanes in other states are not starved and the loop overhead is shared
+            for (uint32_t t = 0; t < 8 && state == S_TOKENS; t++) {
+                refill();
+                const uint32_t e = decode(lfc, lbs);
+                const uint32_t L = e >> 12, sym = e & 0xFFF;
+                if (!L) { status = IF_CORRUPT; state = S_DONE; break; }
+                (void)take(L);
+                if (sym < 256) {
+                    if ((uint64_t)nlit + 1 + mtot > expect) { status = IF_DSTSIZE; state = S_DONE; break; }
+                    put_lit(sym); ll++;
+                    continue;
+                }
+                if (sym == 256) { state = lastblk ? S_TRAILER : S_BLOCK; break; }
+                const uint32_t li = sym - 257;
+                if (li > 28) { status = IF_CORRUPT; state = S_DONE; break; }
+                uint32_t ml;
+                if (li < 8) ml = 3 + li;
+                else if (li == 28) ml = 258;
+                else { const uint32_t eb = (li >> 2) - 1; ml = 3 + ((4 + (li & 3)) << eb) + take(eb); }
+                refill();
+                const uint32_t d = decode(dfc, dbs);
+                const uint32_t dl = d >> 12, ds = d & 0xFFF;
+                if (!dl || ds > 29) { status = IF_CORRUPT; state = S_DONE; break; }
+                (void)take(dl);
+                uint32_t dist;
+                if (ds < 4) dist = 1 + ds;
+                else { const uint32_t eb = (ds >> 1) - 1; refill(); dist = 1 + ((2 + (ds & 1)) << eb) + take(eb); }
+                if (nseq >= pcap || (uint64_t)nlit + mtot + ml > expect) { status = nseq >= pcap ? IF_UNSUPPORTED : IF_DSTSIZE; state = S_DONE; break; }
+                rec_out[nseq++] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)(dist + 3) << 40);
+                mtot += ml; ll = 0;
+            }
+        } else if (state == S_TRAILER) {
+            (void)take(bitcnt & 7);
+            refill();
+            const uint32_t b0 = take(8), b1 = take(8), b2 = take(8), b3 = take(8);
+            adler = (b0 << 24) | (b1 << 16) | (b2 << 8) | b3;
+            if (!lastp || bytepos() != p_end) status = IF_CORRUPT;            // the trailer belongs to the last piece and ends the stream
+            state = S_DONE;
+        }
+        if (state != S_DONE && ((uint64_t)pos * 8 - bitcnt > (uint64_t)p_end * 8 + 64 || guard > (1u << 24))) { status = IF_CORRUPT; state = S_DONE; }
+    }
+    if (!live) return;
+    if (nlit & 3) { for (uint32_t k = 0; k < (nlit & 3); k++) lit_out[(nlit & ~3u) + k] = (uint8_t)(litw >> (8 * k)); }
+    const uint64_t total = (uint64_t)nlit + mtot;
+    if (status == IF_OK && (open && lastp ? total > expect : total != expect)) status = IF_DSTSIZE;
+    ZBlock b;
+    b.body = 0; b.out_off = 0; b.seq_pos = x.seq_base + (uint64_t)pc.j * pcap; b.size = 0; b.type = 2;
+    b.ltype = 2; b.regen = nlit; b.streams = 1; b.lit_off = 0; b.lit_csize = 0; b.lit_pos = pc.j * BLK_SIZE;
+    b.huf_slot = 0xFFFFFFFFu; b.slot[0] = b.slot[1] = b.slot[2] = 0xFFFFFFFFu;
+    b.nseq = nseq; b.seq_off = 0; b.seq_len = 0; b.frame = pc.frame; b.out_len = (uint32_t)total; b.status = status; b.uses_rep = 0;
+    for (int k = 0; k < 7; k++) b.pad[k] = 0;
+    b.pad[1] = adler;
+    blocks[x.blk_base + pc.j] = b;
+#undef LS
+}
+
+// ---- k_vfin: one thread per stream: all pieces fine -> the frame has P blocks; otherwise the wave-per-stream kernel takes the stream
+__global__ void k_vfin(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, uint32_t n, const ZBlock *__restrict__ blocks, uint32_t *__restrict__ mode) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n || frames[f].status) return;
+    if (mode[f] == VM_PIECES) {
+        const uint32_t P = fx[f].blk_cap; uint32_t bad = 0; uint64_t tot = 0;
+        for (uint32_t j = 0; j < P; j++) { bad |= blocks[fx[f].blk_base + j].status; tot += blocks[fx[f].blk_base + j].out_len; }
+        const bool open = (frames[f].out_len & ZF_OPEN) != 0;
+        if (!bad && (open ? tot <= frames[f].dst_len : tot == frames[f].dst_len)) { fx[f].nblk = P; if (!open) frames[f].out_len = (uint32_t)tot; return; }   // (open: k_zoff reports the size)
+        mode[f] = VM_SERIAL;
+    }
+}
+
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint32_t *pb, uint32_t *mode, const uint8_t *src,
+                     ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
+    if (!n) return;
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_vinflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VI_LDS);
+    (void)attr_set;
+    hipLaunchKernelGGL(k_imark, dim3(n), dim3(256), 0, st, (const ZFrame *)frames, (const ZFrameX *)fx, src, pb, mode);
+    hipLaunchKernelGGL(k_vinflate, dim3((npieces + 63) / 64), dim3(64), VI_LDS, st, (const ZFrame *)frames, (const ZFrameX *)fx, (const VPiece *)pieces, npieces,
+                       (const uint32_t *)pb, (const uint32_t *)mode, src, blocks, lit_scratch, seqs);
+    hipLaunchKernelGGL(k_vfin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, n, (const ZBlock *)blocks, mode);
 }
 
 } // namespace pna

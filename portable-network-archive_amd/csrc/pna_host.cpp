@@ -53,7 +53,10 @@ void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, 
                    void *work, hipStream_t st);
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
-void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
+void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st);
+void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, hipStream_t st);
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint32_t *pb, uint32_t *mode, const uint8_t *src,
+                     ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
                    void *part, hipStream_t st);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
@@ -124,6 +127,7 @@ struct pna_gpu_ctx {
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
     hipStream_t x_cp = nullptr; hipEvent_t x_ev[2] = {}, x_done = nullptr;   // extract driver: D2H of window k on x_cp next to window k+1's work
     bool aes_dec_ready = false;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
+    DevBuf z_vp, z_pb, z_mode;                                 // lane-per-piece inflate: piece list, piece boundaries, per-stream mode
     DevBuf ci_spread, ci_spread_desc;                          // GCM entries of several segments: their compact payloads, the pieces to move
     DevBuf aes_tabs, ci_units, ci_ivs, ci_keys, ci_gcm;        // cipher stage: round tables, unit descriptors, IVs; GCM: per-entry round keys, segment descriptors
     bool aes_ready = false;
@@ -211,7 +215,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
@@ -1994,29 +1998,63 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     std::vector<ZFrame> frs(n);
     std::vector<ZFrameX> fxs(n);
     std::vector<uint32_t> cbase(n + 1);
-    uint64_t nseq_cap = 0, out_span = 0, pieces = 0;
+    uint64_t nseq_cap = 0, out_span = 0, pieces = 0, nblk = 0;
+    // Streams of known size go lane-per-piece (k_vinflate): a stream of at most BLK_SIZE decoded bytes is one piece, a larger one is taken
+    // to consist of ceil(raw_len / BLK_SIZE) sync-flush delimited pieces of BLK_SIZE bytes each (what this library's encoder writes) --
+    // k_imark / k_vinflate / k_vfin check that and leave every stream that does not fit to the wave-per-stream kernel.  Streams of
+    // unknown size (`open`) take the wave-per-stream kernel directly.
+    struct VPieceH { uint32_t frame, j; };
+    std::vector<VPieceH> vp;
+    // pieces per stream: from the size when it is known; for streams of unknown size (solid streams, entries without fSIZ) from a count of
+    // the sync-flush markers (one pass + one small read-back): markers + 1 pieces, all but the last holding BLK_SIZE bytes
+    std::vector<uint64_t> npc(n);
+    uint64_t tot_pieces = 0;
+    bool lanes = getenv("PNA_INFLATE_SERIAL") == nullptr;
+    if (lanes && open) {
+        std::vector<uint32_t> cnt(n);
+        if (c->z_pb.ensure(n * 4 + 8) || c->z_vp.ensure(n * 16 + 16)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+        HIPCHK(c, hipMemcpyAsync(c->z_vp.p, src_off, n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_vp.p + n * 8, src_len, n * 8, hipMemcpyHostToDevice, st));
+        launch_icount((const uint8_t *)d_src, (const uint64_t *)c->z_vp.p, (const uint64_t *)((uint8_t *)c->z_vp.p + n * 8), (uint32_t)n, (uint32_t *)c->z_pb.p, st);
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), c->z_pb.p, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; i++) { npc[i] = (uint64_t)cnt[i] + 1; if ((npc[i] - 1) * BLK_SIZE > raw_len[i]) npc[i] = 1; }   // more pieces than the room allows: not this library's layout
+    } else
+        for (size_t i = 0; i < n; i++) npc[i] = std::max<uint64_t>(1, (raw_len[i] + BLK_SIZE - 1) / BLK_SIZE);
+    for (size_t i = 0; i < n; i++) tot_pieces += npc[i];
+    // a handful of pieces is served better by the wave-per-stream walk (a lane needs ~110 ms for a 128 KiB piece, however few there are)
+    if (tot_pieces < 1024) lanes = false;
     for (size_t i = 0; i < n; i++) {
         if (raw_len[i] > 0xFFFFFFFFull || src_len[i] > 0xFFFFFFFFull) return fail(c, PNA_E_UNSUPPORTED, "entries of 4 GiB and more are not decoded on the device");
         frs[i] = ZFrame{src_off[i], dst_off[i], (uint32_t)src_len[i], (uint32_t)raw_len[i], 0, open ? ZF_OPEN : 0u};   // open: raw_len is a capacity
         ZFrameX &x = fxs[i];
-        x.blk_base = (uint32_t)i; x.blk_cap = 1; x.slot_base = 0; x.slot_cap = 0; x.nblk = 0;
-        x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(raw_len[i] / 3 + (raw_len[i] >> 16) + 16, 0x7FFFFFFFu);   // matches are >= 3 bytes; + literal-run splits
+        const uint64_t P = lanes ? npc[i] : 1;
+        const uint64_t pcap = std::min<uint64_t>(raw_len[i], lanes ? BLK_SIZE : raw_len[i]) / 3 + (raw_len[i] >> 16) / P + 16;   // matches are >= 3 bytes; + literal-run splits (serial walk)
+        if (nblk + P > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
+        x.blk_base = (uint32_t)nblk; x.blk_cap = (uint32_t)P; x.slot_base = 0; x.slot_cap = 0; x.nblk = 0;
+        x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(P * pcap, 0x7FFFFFFFu);
         nseq_cap += x.seq_cap;
+        if (lanes) for (uint64_t j = 0; j < P; j++) vp.push_back(VPieceH{(uint32_t)i, (uint32_t)j});
+        nblk += P;
         out_span = std::max<uint64_t>(out_span, dst_off[i] + raw_len[i]);
         cbase[i] = (uint32_t)pieces;
         pieces += (raw_len[i] + 65535) >> 16;
         if (pieces > 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
     }
     cbase[n] = (uint32_t)pieces;
-    if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(n * sizeof(ZBlock)) ||
-        c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8))
+    if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk * sizeof(ZBlock)) ||
+        c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8) ||
+        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 4 + 8) || c->z_mode.ensure(n * 4 + 8))))
         return fail(c, PNA_E_NOMEM, "decoder workspace");
     HIPCHK(c, hipMemcpyAsync(c->z_frames.p, frs.data(), n * sizeof(ZFrame), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), n * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_cbase.p, cbase.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+    if (lanes) HIPCHK(c, hipMemcpyAsync(c->z_vp.p, vp.data(), vp.size() * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (lanes) launch_vinflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, c->z_vp.p, (uint32_t)vp.size(), (uint32_t *)c->z_pb.p, (uint32_t *)c->z_mode.p,
+                               (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
     launch_inflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
-                   (uint64_t *)c->z_seqs.p, st);
+                   (uint64_t *)c->z_seqs.p, lanes ? (const uint32_t *)c->z_mode.p : nullptr, st);
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
                  (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
@@ -2026,6 +2064,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[1], st));
     HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, n * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+    if (lanes) HIPCHK(c, hipStreamSynchronize(st));          // (vp is read by the copy above until then)
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0, ms_h = 0, ms_x = 0;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&ms_h, c->ev[0], c->ev[2]); (void)hipEventElapsedTime(&ms_x, c->ev[2], c->ev[3]);

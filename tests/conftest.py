@@ -45,6 +45,18 @@ def gpu_ctx(pna):
     ctx.close()
 
 
+@pytest.fixture
+def big_ctx(pna):
+    """A context of its own for the full-size cases: their multi-GiB workspaces (decoder scratch, staging) are released with it instead
+    of staying in the session's context, and torch's cached blocks are handed back before and after."""
+    import torch
+    torch.cuda.empty_cache()
+    ctx = pna.Context(0)
+    yield ctx
+    ctx.close()
+    torch.cuda.empty_cache()
+
+
 def golden(name: str) -> bytes:
     with open(os.path.join(GOLDEN, name), "rb") as f:
         return f.read()

@@ -34,7 +34,8 @@ def _chunks(buf):
         pos += 12 + ln
 
 
-def test_solid_8gib_archive_round_trips(gpu_ctx, pna, pf, codec):
+def test_solid_8gib_archive_round_trips(big_ctx, pna, pf, codec):
+    gpu_ctx = big_ctx
     import numpy as np
     import torch
     n, L = 8192, 1 << 20
@@ -99,7 +100,8 @@ def test_solid_8gib_archive_round_trips(gpu_ctx, pna, pf, codec):
     assert seen == list(range(n))
 
 
-def test_deflate_one_million_small_entries(gpu_ctx, pna, codec):
+def test_deflate_one_million_small_entries(big_ctx, pna, codec):
+    gpu_ctx = big_ctx
     import torch
     n, L = 1_000_000, 4096
     _need_hbm(torch, 40)
@@ -126,7 +128,8 @@ def test_deflate_one_million_small_entries(gpu_ctx, pna, codec):
         assert got == codec.deflate_model_compress(want), i
 
 
-def test_entry_beyond_4gib_round_trips(gpu_ctx, pna, pf, codec):
+def test_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
+    gpu_ctx = big_ctx
     """tests/bats/large_file.bats (a 5 GiB file through create + extract): ONE entry of 5 GiB (+ a small one behind it) -- 64-bit offsets
     through segment planning, the write kernels, the 1 GiB FDAT cut and the device decoder.  The archive is checked structurally
     (fSIZ of five bytes, FDAT chunks of at most 1 GiB, every chunk CRC), sampled frames go through an independent decoder, and every byte

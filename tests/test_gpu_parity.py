@@ -262,11 +262,12 @@ def test_device_batch_properties_256mib(gpu_ctx, pna, codec):
     assert 2.3 < n * L / offs[-1] < 3.2
 
 
-def test_full_size_properties_10k_x_1mib(gpu_ctx, pna, codec):
+def test_full_size_properties_10k_x_1mib(big_ctx, pna, codec):
     """BASELINE.json configs[1] at full size through size-independent properties: offsets partition the output,
     the run is reproducible (checksum of the whole stream), sampled entries decode on the host / are bit-exact, and ALL
     entries round-trip through the device decoder."""
     import torch
+    gpu_ctx = big_ctx
     n, L = 10000, 1 << 20
     free, _ = torch.cuda.mem_get_info()
     assert free >= 120 * (1 << 30), f"the headline configuration needs 120 GiB of free HBM, found {free >> 30} GiB (an MI355X has 288 GB)"
@@ -1020,3 +1021,57 @@ def test_append_equals_create(gpu_ctx, pna, pf, codec):
         pna.append_archive(gpu_ctx, open(os.path.join(GOLDEN, "multipart.part1.pna"), "rb").read(), ["x"], [b"y"])
     with pytest.raises(pna.PnaGpuError):
         pna.append_archive(gpu_ctx, whole[:-5], ["x"], [b"y"])
+
+
+def test_device_inflate_lane_per_piece_paths(gpu_ctx, pna, codec):
+    """The lane-per-piece inflate (k_imark / k_vinflate / k_vfin) and its hand-over to the wave-per-stream walk: a batch large enough for
+    the lane path (>= 1 024 pieces) that mixes this library's sync-flushed streams, small foreign zlib streams (one piece each: fixed,
+    dynamic, stored, multi-block), LARGE foreign streams (no sync markers: handed over), a stream with a chance marker pattern in a
+    stored block (marker count does not fit: handed over) and zlib's own Z_SYNC_FLUSH pieces of another size (sizes do not fit: handed
+    over).  PNA_INFLATE_SERIAL=1 must give the same bytes."""
+    import random
+    rnd = random.Random(11)
+    own_raw = [codec.corpus_file(i % 2, 4000 + i, n) for i, n in enumerate([1 << 20, (1 << 20) + 77, 300000, 131072, 131073, 5000, 0, 1] + [200000] * 120)]
+    own = gpu_ctx.compress_batch(own_raw, algo=pna.ALGO_DEFLATE)
+    small_raw = [codec.corpus_file(1, 5000 + i, 100 + 997 * (i % 120)) for i in range(800)]
+    small = [zlib.compress(r, [0, 1, 6, 9][i % 4]) for i, r in enumerate(small_raw)]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED); small_raw.append(small_raw[5]); small.append(co.compress(small_raw[5]) + co.flush())
+    big_raw = [codec.corpus_file(0, 6000 + i, 700000 + i) for i in range(3)]
+    big = [zlib.compress(r, 6) for r in big_raw]
+    tricky_raw = bytes(rnd.getrandbits(8) for _ in range(150000)) + b"\x00\x00\xff\xff" * 5 + bytes(rnd.getrandbits(8) for _ in range(150000))
+    tricky = zlib.compress(tricky_raw, 0)                                   # stored blocks: the pattern appears verbatim in the stream
+    co = zlib.compressobj(6)
+    sf_raw = codec.corpus_file(0, 6100, 400000)
+    sf = b"".join(co.compress(sf_raw[i:i + 50000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 400000, 50000)) + co.flush()
+    raws = own_raw + small_raw + big_raw + [tricky_raw, sf_raw]
+    comps = list(own) + small + big + [tricky, sf]
+    assert sum(max(1, (len(r) + 131071) // 131072) for r in raws) >= 1024
+    got = gpu_ctx.decompress_batch(comps, [len(r) for r in raws], algo=pna.ALGO_DEFLATE)
+    assert got == raws
+    os.environ["PNA_INFLATE_SERIAL"] = "1"
+    try:
+        assert gpu_ctx.decompress_batch(comps, [len(r) for r in raws], algo=pna.ALGO_DEFLATE) == raws
+    finally:
+        del os.environ["PNA_INFLATE_SERIAL"]
+    # corrupt input in a lane batch is refused all the same (after the hand-over): a flipped bit, a wrong size, a bad Adler-32
+    for k, mut in ((3, lambda z: z[:100] + bytes([z[100] ^ 4]) + z[101:]), (200, lambda z: z[:-1] + bytes([z[-1] ^ 1]))):
+        bad = list(comps); bad[k] = mut(bad[k])
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx.decompress_batch(bad, [len(r) for r in raws], algo=pna.ALGO_DEFLATE)
+    with pytest.raises(pna.PnaGpuError):
+        gpu_ctx.decompress_batch(comps, [len(r) for r in raws[:-1]] + [len(raws[-1]) - 1], algo=pna.ALGO_DEFLATE)
+
+
+def test_deflate_solid_stream_decodes_in_pieces(gpu_ctx, pna, pf, codec):
+    """A deflate `--solid` archive is ONE zlib stream of unknown size: its sync-flush markers are counted, the pieces decoded lane-parallel
+    (open size: the last piece reports its length), the inner records walked -- round 1 decoded such a stream on one wave."""
+    n, L = 160, 1 << 20
+    ents = [codec.corpus_file(0, 8000 + i, L) for i in range(n)]
+    names = [f"sd/{i:03d}.txt" for i in range(n)]
+    arc = pna.create_archive(gpu_ctx, names, ents, algo=pna.ALGO_DEFLATE, solid=True)
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert [nm for nm, _, _ in got] == names and all(d == e for (_, _, d), e in zip(got, ents))
+    # the same stream through the oracle's reader and stdlib zlib
+    (so,) = pf.read_archive(arc)[1]
+    inner = pf.read_solid_inner(zlib.decompress(so.data))
+    assert [(e.name, e.data) for e in inner[:3]] == list(zip(names[:3], ents[:3])) and len(inner) == n
