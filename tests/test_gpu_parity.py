@@ -1075,3 +1075,51 @@ def test_deflate_solid_stream_decodes_in_pieces(gpu_ctx, pna, pf, codec):
     (so,) = pf.read_archive(arc)[1]
     inner = pf.read_solid_inner(zlib.decompress(so.data))
     assert [(e.name, e.data) for e in inner[:3]] == list(zip(names[:3], ents[:3])) and len(inner) == n
+
+
+def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
+    """Inputs built to stress round 2's LZ rules: long repeats at distances on both sides of the LDS window limit (56 064) and up to the
+    segment size (far candidates, their 16 + 16 byte steps, the wave-cooperative extension reading the segment from HBM), repeats that start
+    at odd positions and one or two bytes after a table hit (backward adoption, also across the 64-position group border where it must
+    stop), candidates at positions 0..3 (unusable by rule), repeats that run into block and segment ends.  Bit-exact with the model,
+    decodable by libzstd / zlib, for both codecs and the three level sets."""
+    import random
+    rnd = random.Random(2024)
+
+    def rb(n):
+        return bytes(rnd.getrandbits(8) for _ in range(n))
+    cases = {}
+    chunk = rb(5000)
+    # the same 5 000 bytes at growing distances, at odd and even alignments, with random filler in between
+    buf = bytearray()
+    for d in (100, 7000, 33000, 56000, 56064, 56065, 56100, 60001, 131072, 262145, 500003):
+        buf += chunk[:1 + rnd.randrange(3000, 5000)]
+        buf += rb(d % 9973 + 17)
+        while len(buf) % 2 != (d & 1):
+            buf += b"z"
+    cases["repeats"] = bytes(buf)
+    text = codec.corpus_file(0, 4242, 1 << 20)
+    cases["text+far-copy"] = text[:300000] + rb(70000) + text[1000:250000] + rb(1000) + text[123:200123]
+    cases["start-of-segment"] = (text[:40] + rb(200) + text[:40] + rb(60000) + text[:3] + text[1:40] + rb(2000)) * 3
+    cases["block-edge"] = rb(131072 - 50) + text[:100] + rb(70000) + text[:100] + rb(131072 - 70000 - 150) + text[:100]
+    cases["segment-edge"] = rb((1 << 20) - 30) + text[:60] + text[:60] + rb(5000)
+    cases["group-border"] = b"".join(text[i * 61:i * 61 + 61] + bytes([i & 255]) + text[i * 61 + 1:i * 61 + 62] for i in range(3000))
+    cases["long-far-run"] = rb(100000) + bytes(200000) + rb(60000) + bytes(200000)
+    names = sorted(cases)
+    data = [cases[k] for k in names]
+    for level in (1, 2, 3):
+        fl = {1: codec.F_HUF | codec.F_FSE, 2: 0x73, 3: 0x77}[level]
+        outs = gpu_ctx.compress_batch(data, level=level)
+        pz = codec.params_for_flags(fl)
+        for k, d, o in zip(names, data, outs):
+            assert o == codec.model_compress(d, pz), (k, level)
+            assert codec.zstd_decompress(o, len(d)) == d, (k, level)
+            if codec.system_libzstd() is not None:
+                assert codec.libzstd_decompress_stream(o, len(d)) == d, (k, level)
+    assert gpu_ctx.decompress_batch(outs, [len(d) for d in data]) == data
+    for level, fl in ((1, 0), (4, codec.F_ADOPT | codec.F_INS2), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY)):
+        outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
+        pd = codec.params_for_flags(fl, deflate=True)
+        for k, d, o in zip(names, data, outs):
+            assert o == codec.deflate_model_compress(d, pd), (k, level)
+            assert zlib.decompress(o) == d, (k, level)
