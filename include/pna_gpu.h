@@ -250,6 +250,12 @@ int  pna_gpu_extract_archive_host(pna_gpu_ctx *ctx, const void *archive, size_t 
  * `pna append` writes behind the existing entries (PNA_PART_TAIL only) and `pna update` for the entries it re-creates (neither flag). */
 int  pna_gpu_create_archive_part_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                       const void *const *src, const size_t *src_len, uint32_t part_flags, pna_sink_fn sink, void *user);
+/* One process driving several GPUs (SURVEY 8(b) `device_ids, n_devices`): n_ctx contexts (pna_gpu_init per device; they may share a
+ * device), the entries cut into contiguous index ranges balanced by bytes, one range per context on a thread of its own through the bounded
+ * host pipeline, the parts handed to the sink in index order -- the reference's fan-out + ordered drain (cli/src/command/core.rs:496-537,
+ * 471-493) with devices in place of worker threads; no device-to-device traffic.  The archive equals pna_gpu_create_archive_host's. */
+int  pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_t n_ctx, int algo, int level, size_t n, const char *const *names,
+                                       const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 /* `pna append` (cli/src/command/append.rs:504-560 run_append_archive: open_archive_then_seek_to_end, add the new entries in order,
  * finalize): `archive` is the existing image (or its last part); *write_at receives the offset of its AEND chunk, and the sink receives
  * the bytes that belong there -- the n new entries, compressed on the device, then AEND.  The result, archive[0 .. write_at) followed by

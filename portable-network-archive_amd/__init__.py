@@ -117,7 +117,7 @@ EXPORTS = [
     "pna_kdf_pbkdf2_sha256", "pna_create_archive_encrypted", "pna_kdf_argon2", "pna_split_archive", "pna_join_parts",
     "pna_archive_seek_to_end", "pna_archive_list_entries",
     # streaming entries, parts, append (include/pna_gpu.h)
-    "pna_gpu_create_archive_part_host", "pna_gpu_append_archive_host", "pna_gpu_stream_entry_begin", "pna_gpu_stream_entry_write",
+    "pna_gpu_create_archive_part_host", "pna_gpu_create_archive_multi_host", "pna_gpu_append_archive_host", "pna_gpu_stream_entry_begin", "pna_gpu_stream_entry_write",
     "pna_gpu_stream_entry_finish", "pna_gpu_stream_entry_abort",
 ]
 
@@ -253,6 +253,9 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_create_archive_part_host.restype = ctypes.c_int
     L.pna_gpu_create_archive_part_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
                                                    ctypes.POINTER(sz), u32, SINK_FN, vp]
+    L.pna_gpu_create_archive_multi_host.restype = ctypes.c_int
+    L.pna_gpu_create_archive_multi_host.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp),
+                                                    ctypes.POINTER(sz), SINK_FN, vp]
     L.pna_gpu_append_archive_host.restype = ctypes.c_int
     L.pna_gpu_append_archive_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, sz, ctypes.POINTER(ctypes.c_char_p),
                                               ctypes.POINTER(vp), ctypes.POINTER(sz), u64p, SINK_FN, vp]
@@ -817,3 +820,26 @@ def append_archive(ctx: Context, archive: bytes, names: Sequence[str], entries: 
     at = ctypes.c_uint64()
     ctx._check(L.pna_gpu_append_archive_host(ctx._h, algo, level, bytes(archive), len(archive), n, a_names, a_src, a_len, ctypes.byref(at), cb, None))
     return bytes(archive[:at.value]) + bytes(out)
+
+
+def create_archive_multi(ctxs: Sequence[Context], names: Sequence[str], entries: Sequence[bytes], algo: int = ALGO_ZSTD,
+                         level: int = LEVEL_DEFAULT) -> bytes:
+    """`pna create` from ONE process over several contexts / GPUs (pna_gpu_create_archive_multi_host): contiguous index ranges per
+    context, parts written in index order."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend(ctypes.string_at(buf, k))
+        return 0
+    cb = SINK_FN(_sink)
+    keep = [bytes(e) for e in entries]
+    a_ctx = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in keep])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in keep])
+    rc = L.pna_gpu_create_archive_multi_host(a_ctx, len(ctxs), algo, level, n, a_names, a_src, a_len, cb, None)
+    if rc:
+        raise PnaGpuError(rc, L.pna_gpu_last_error(ctxs[0]._h).decode() or L.pna_gpu_strerror(rc).decode())
+    return bytes(out)

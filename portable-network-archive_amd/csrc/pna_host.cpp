@@ -1215,6 +1215,42 @@ extern "C" int pna_gpu_append_archive_host(pna_gpu_ctx *c, int algo, int level, 
     if (has_next) return fail(c, PNA_E_INVAL, "the archive continues in another part (ANXT): append to its last part");
     return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, PNA_PART_TAIL, sink, user);
 }
+// One process, several GPUs (SURVEY §8(b)'s `device_ids, n_devices`; §8(e)'s comparison path in C): the entries are cut into contiguous
+// index ranges balanced by bytes, one per context (= per device), every context runs the bounded host pipeline on its range on a thread of
+// its own (part flags: the first range carries the archive header, the last AEND) into host memory, and the parts reach the sink in index
+// order -- the reference's fan-out + ordered drain (cli/src/command/core.rs:496-537,471-493) with devices in place of rayon workers and no
+// device-to-device traffic at all.  Contexts may share a device (that is how the one-GPU boxes test it).
+extern "C" int pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_t n_ctx, int algo, int level, size_t n, const char *const *names,
+                                                 const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    if (!ctxs || !n_ctx || !sink || (n && (!names || !src || !src_len))) return PNA_E_INVAL;
+    for (size_t r = 0; r < n_ctx; r++) if (!ctxs[r]) return PNA_E_INVAL;
+    if (n_ctx == 1) return pna_gpu_create_archive_host(ctxs[0], algo, level, n, names, src, src_len, sink, user);
+    // contiguous ranges balanced by input bytes (shard.partition_entries)
+    uint64_t total = 0; for (size_t i = 0; i < n; i++) total += src_len[i];
+    std::vector<size_t> lo(n_ctx + 1, n);
+    {   // range r ends where the running byte count passes r + 1 shares of the total (a range may be empty when there are few entries)
+        size_t i = 0; uint64_t acc = 0;
+        for (size_t r = 0; r < n_ctx; r++) {
+            lo[r] = i;
+            const uint64_t target = (uint64_t)((__uint128_t)total * (r + 1) / n_ctx);
+            while (i < n && (r + 1 == n_ctx || acc + src_len[i] <= target)) { acc += src_len[i]; i++; }
+        }
+        lo[n_ctx] = n;
+    }
+    std::vector<std::vector<uint8_t>> parts(n_ctx);
+    std::vector<int> rcs(n_ctx, PNA_OK);
+    auto vec_sink = [](void *u, const void *b, size_t k) -> int { auto *v = (std::vector<uint8_t> *)u; try { v->insert(v->end(), (const uint8_t *)b, (const uint8_t *)b + k); } catch (...) { return 1; } return 0; };
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < n_ctx; r++)
+        th.emplace_back([&, r]() {
+            const uint32_t pf = (r == 0 ? PNA_PART_HEAD : 0u) | (r + 1 == n_ctx ? PNA_PART_TAIL : 0u);
+            rcs[r] = pna_gpu_create_archive_part_host(ctxs[r], algo, level, lo[r + 1] - lo[r], names + lo[r], src + lo[r], src_len + lo[r], pf, vec_sink, &parts[r]);
+        });
+    for (auto &t : th) t.join();
+    for (size_t r = 0; r < n_ctx; r++) if (rcs[r] != PNA_OK) return rcs[r];
+    for (size_t r = 0; r < n_ctx; r++) if (!parts[r].empty() && sink(user, parts[r].data(), parts[r].size()) != 0) return fail(ctxs[0], PNA_E_SINK, "sink failed");
+    return PNA_OK;
+}
 static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                     const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user) {

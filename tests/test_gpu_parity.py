@@ -1123,3 +1123,21 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
         for k, d, o in zip(names, data, outs):
             assert o == codec.deflate_model_compress(d, pd), (k, level)
             assert zlib.decompress(o) == d, (k, level)
+
+
+def test_one_process_several_contexts(gpu_ctx, pna, pf, codec):
+    """pna_gpu_create_archive_multi_host: one process, one context per GPU (here: several contexts on the one GPU), contiguous index
+    ranges balanced by bytes, parts in index order == the archive of a single context, byte for byte."""
+    ents = [codec.corpus_file(i % 2, 1200 + i, n) for i, n in enumerate([300000, 0, 5, (1 << 20) + 3, 70001, 2500000, 12, 1 << 20, 4096, 999999, 1, 65536])]
+    names = [f"mc/{i:02d}.txt" for i in range(len(ents))]
+    want = pna.create_archive(gpu_ctx, names, ents)
+    extra = [pna.Context(0) for _ in range(3)]
+    try:
+        for k in (2, 3, 4):
+            assert pna.create_archive_multi([gpu_ctx] + extra[:k - 1], names, ents) == want, k
+        assert pna.create_archive_multi([gpu_ctx] + extra, names[:2], ents[:2]) == pna.create_archive(gpu_ctx, names[:2], ents[:2])   # more contexts than entries
+        assert pna.create_archive_multi(extra[:2], [], []) == pna.create_archive(gpu_ctx, [], [])
+        assert pna.create_archive_multi(extra[:2], names, ents, algo=pna.ALGO_DEFLATE) == pna.create_archive(gpu_ctx, names, ents, algo=pna.ALGO_DEFLATE)
+    finally:
+        for c in extra:
+            c.close()
