@@ -566,6 +566,7 @@ def main() -> None:
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()                                        # rank 0 may still be reading the gathered archive back
         dist.destroy_process_group()
 
 
