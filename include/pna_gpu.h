@@ -44,6 +44,7 @@ extern "C" {
 #define PNA_F_FAR   0x10u       /* zstd: look-back over the whole 1 MiB segment (candidates beyond the LDS window verified in HBM / L2) */
 #define PNA_F_ADOPT 0x20u       /* backward adoption: a match found late is moved back to its true start */
 #define PNA_F_INS2  0x40u       /* only even positions enter the hash table (with PNA_F_ADOPT) */
+#define PNA_F_STRONG 0x80u      /* third adoption round (up to 7 positions back) + two-step lazy deferral: the set of the high levels */
 #define PNA_F_DEFAULT 0x80000000u   /* let the library choose */
 
 typedef struct pna_gpu_ctx pna_gpu_ctx;

@@ -151,7 +151,7 @@ class ZstdParams(ctypes.Structure):
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
-F_FAR, F_ADOPT, F_INS2 = 0x10, 0x20, 0x40       # the product's level-set bits (include/pna_gpu.h); the model takes explicit parameters
+F_FAR, F_ADOPT, F_INS2, F_STRONG = 0x10, 0x20, 0x40, 0x80       # the product's level-set bits (include/pna_gpu.h); the model takes explicit parameters
 
 
 def default_params() -> ZstdParams:
@@ -169,6 +169,10 @@ def params_for_flags(flags: int, deflate: bool = False) -> ZstdParams:
         p.flags &= ~8                     # no repeat codes on the device
         if not flags & F_FAR:
             p.max_off = p.near_off
+    if flags & F_STRONG and flags & F_ADOPT:   # third adoption round (4 lanes, 7 back bytes) + two-step lazy deferral
+        p.rounds = 0x421
+        p.back_cap = 7
+        p.flags |= 0x80
     if not flags & F_ADOPT:
         p.rounds = 0
         p.back_cap = 0

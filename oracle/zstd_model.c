@@ -53,7 +53,7 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
  * One 128 KiB block.  For each tile of p->tile positions, in this order:
  *   L  every position q with q + 8 <= seg_len looks up cand[q] = table[hash(q)] (value = position+1, 0 = empty);
  *   M  len[q] = length of the common prefix of seg[q..] and seg[c..] (c = cand-1), capped to cap(q) and to the block end;
- *      a candidate is usable iff c >= 4 and q - c <= max_off; len < min_match counts as 0.  cap(q) = cap1 when the offset
+ *      a candidate is usable iff c >= 8 and q - c <= max_off; len < min_match counts as 0.  cap(q) = cap1 when the offset
  *      q - c <= near_off (the candidate lies in the GPU's LDS window) and cap_far otherwise (the candidate is read from
  *      HBM/L2).  For a usable match back[q] = number of equal bytes immediately before q and c, at most back_cap (<= 4);
  *   A  backward adoption, rounds of shift s (the nibbles of p->rounds, lowest first; the GPU's DPP lane shifts): all positions
@@ -65,7 +65,8 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
  *      == atomic max on the GPU; after L for the whole tile, so the positions of one tile do not see each other);
  *   P  region-local greedy parse.  The tile is cut into regions of p->region positions (what one GPU wave owns; region 0
  *      = the whole tile).  Every region is parsed on its own, in ascending q from max(region start, next_free): position q
- *      starts a match iff len[q] >= min_match and not (LAZY and (q & 63) != 63 and q+1 < tile end and len[q+1] > len[q]);
+ *      starts a match iff len[q] >= min_match and not (LAZY and (q & 63) != 63 and q+1 < tile end and len[q+1] > len[q]) and not
+ *      (LAZY2 and (q & 63) < 62 and q+2 < tile end and len[q+2] > len[q] + 1);
  *      a chosen match whose len >= its cap is extended byte-wise up to min(block end, tile end + lookahead) (and max_len);
  *      the region's parse continues at q + len and stops at the region end (its last match may reach beyond it).
  *   F  merge of the regions in ascending order against the running end E of the emitted matches (E = next_free at the
@@ -103,7 +104,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         /* M */
         for (uint32_t q = t0; q < t1; q++) {
             uint32_t c1 = cand[q - t0], l = 0, bk = 0, fr = 0;
-            if (c1 > 4 && q - (c1 - 1) <= p->max_off) {                  /* candidates at positions 0..3 are not used: 4 bytes before a candidate always exist */
+            if (c1 > 8 && q - (c1 - 1) <= p->max_off) {                  /* candidates at positions 0..7 are not used: 8 bytes before a candidate always exist */
                 uint32_t c = c1 - 1, lim = blk_end - q;
                 fr = p->near_off && q - c > p->near_off;
                 uint32_t cap = fr ? p->cap_far : p->cap1;
@@ -136,6 +137,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 uint32_t l = len[q - t0];
                 int take = l >= p->min_match;
                 if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
+                if (take && (p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY2) && (q & 63) < 62 && q + 2 < t1 && len[q + 2 - t0] > l + 1) take = 0;
                 if (!take) { q++; continue; }
                 uint32_t c = cand[q - t0] - 1;
                 if (l >= (far[q - t0] ? p->cap_far : p->cap1)) {

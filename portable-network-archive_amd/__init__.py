@@ -21,7 +21,7 @@ PNA_OK = 0
 ALGO_STORE, ALGO_DEFLATE, ALGO_ZSTD = 0, 1, 2
 LEVEL_DEFAULT = -1000
 F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
-F_FAR, F_ADOPT, F_INS2 = 0x10, 0x20, 0x40
+F_FAR, F_ADOPT, F_INS2, F_STRONG = 0x10, 0x20, 0x40, 0x80
 F_STD = F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2          # what F_DEFAULT selects
 
 SEG_SIZE = 1 << 20

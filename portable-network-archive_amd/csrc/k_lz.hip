@@ -53,7 +53,7 @@ static_assert(sizeof(WPub) == 8, "LDS record size");
 static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
-static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
+static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3 && MIN_MATCH > 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
 static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -123,7 +123,9 @@ __device__ unsigned long long g_lz_stamps[8];
 // G = positions per lane and tile (groups of 64 positions per wave): the wave's G groups are ONE parse region of 64 G positions, a tile is
 // 1024 G positions (zstd: LZ_G_ZSTD, deflate: LZ_G_DEFLATE; the deflate chunk table keeps one entry per 2 KiB).
 // CT: the launch fills the deflate chunk table (a template parameter so that the zstd instance carries none of that code).
-template <bool STAMP, int G, bool CT>
+// STRONG: the parameter set of the high levels (third adoption round over 7 back bytes, two-step lazy deferral) as an instance of its own,
+// so that the default instance carries none of its loads and branches (as run-time switches they cost it 3.3 %).
+template <bool STAMP, int G, bool CT, bool STRONG>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len) {
@@ -149,7 +151,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t lazy = flags & F_LAZY;
-    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);   // (wave-uniform) level sets: pna_host.cpp level_flags()
+    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
+    constexpr bool strong = STRONG;   // (wave-uniform) level sets: pna_host.cpp level_flags()
     const bool force_serial = (flags & FLAG_FORCE_SERIAL) != 0;
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
@@ -208,7 +211,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
 #endif
             // ---- lookup
-            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G];
+            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G], bq2[G];
             bool hv[G];
             // (uniform) a tile that lies wholly inside the block and at least 8 bytes before the segment end needs no per-lane range checks
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
@@ -223,6 +226,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     lo[r] = __builtin_amdgcn_alignbit(d1, d0, sh);
                     hi[r] = __builtin_amdgcn_alignbit(d2, d1, sh);
                     bq[r] = __builtin_amdgcn_alignbit(d0, dm, sh);                  // the 4 bytes before q (q - 1 in the top byte)
+                    bq2[r] = 0;
+                    if (strong) bq2[r] = __builtin_amdgcn_alignbit(dm, win32[((q[r] - 8) & (WIN_BYTES - 1)) >> 2], sh);   // (uniform) and the 4 before those
                 }
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
                 hsh[r] = __umulhi(h32, HASH_ENTRIES);                               // floor(h32 * entries / 2^32): any table size
@@ -230,20 +235,21 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
             }
             // ---- candidates: offset (0 = none: empty slot, foreign tag -- a candidate whose tag differs hashed differently, so its first
-            // 6 bytes differ --, position below 4, beyond max_off).  Far candidates (beyond the LDS window) get the 4 bytes before and the
+            // 6 bytes differ --, position below 8, beyond max_off).  Far candidates (beyond the LDS window) get the 4 bytes before and the
             // 16 bytes at the candidate requested from the segment now; the other lanes read the segment's first bytes (one line, no
-            // exec masking), which nobody looks at.  A usable candidate lies at position >= 4, so the load never reaches below the segment.
+            // exec masking), which nobody looks at.  A usable candidate lies at position >= 8, so the loads never reach below the segment.
             uint32_t off[G];
-            U4u fa[G]; uint32_t fb[G];
+            U4u fa[G]; uint32_t fb[G], fc[G];
 #pragma unroll
             for (int r = 0; r < G; r++) {
-                fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = 0;
+                fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = fc[r] = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
-                off[r] = (c1 > 4 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
+                off[r] = (c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
                 if (FAR && seg_len > NEAR && max_off > NEAR) {                      // (uniform) shorter segments / near-only levels have no far candidates
                     const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
                     fa[r] = *(const U4u *)(seg + fo);
                     fb[r] = *(const u32u *)(seg + fo + 16);
+                    if (strong) fc[r] = *(const u32u *)(seg + (off[r] > NEAR ? fo - 4 : 0u));   // (uniform) bytes c - 8 .. c - 5
                 }
             }
             LZ_STAMP(1);
@@ -252,7 +258,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             uint32_t len[G], flen[G];
             uint64_t effm[G];
             auto do_match = [&](const int r) __attribute__((always_inline)) {
-                uint32_t l = 0, bk4 = 0;                                            // bk4 = 4 x (bytes before q and c that agree as well, <= 3)
+                uint32_t l = 0, bk = 0;                                             // bk = bytes before q and c that agree as well (<= 3; strong set: <= 7)
                 const uint32_t o = off[r];
                 if (o != 0) {
                     const uint32_t c = q[r] - o;
@@ -262,14 +268,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
                     const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
                     const uint32_t shc = (c & 3) * 8, shq = (q[r] & 3) * 8;
-                    uint32_t w0, w1, w2, w3, bc;                                    // 16 bytes at c, the 4 bytes before c
-                    if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; }
+                    uint32_t w0, w1, w2, w3, bc, bc2 = 0;                           // 16 bytes at c, the 4 (strong: 8) bytes before c
+                    if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; bc2 = fc[r]; }
                     else {
                         const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
                         const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
                         w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
                         w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
                         bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                        if (strong) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
                     }
                     const uint32_t e2 = pq[2], e3 = pq[3], e4 = pq[4];
                     const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
@@ -302,30 +309,39 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     if (edge) { const uint32_t lim = blk_end - q[r]; l = l < lim ? l : lim; }
                     if (l < MIN_MATCH) l = 0;
                     // bytes before q and c that agree as well, nearest first: the low byte forced to differ caps the count at BACK_CAP = 3
-                    bk4 = ((uint32_t)__builtin_clz((bq[r] ^ bc) | 0xFFu) >> 1) & 0xCu;
+                    // (strong set: when all four agree, the four before them are counted the same way: at most 7)
+                    const uint32_t xk = bq[r] ^ bc;
+                    bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
+                    if (strong && xk == 0) bk = 4 + ((uint32_t)__builtin_clz((bq2[r] ^ bc2) | 0xFFu) >> 3);
                 }
-                // ---- backward adoption.  K = len << 5 | back << 2 | lanes the match was moved by.  A lane without a match may carry a stray
+                // ---- backward adoption.  K = len << 6 | back << 3 | lanes the match was moved by.  A lane without a match may carry a stray
                 // back count and adopt "lengths" of 1..3 from such neighbours: they stay below MIN_MATCH and nobody reads them as a match.
-                uint32_t K = (l << 5) | bk4;
+                uint32_t K = (l << 6) | (bk << 3);
+                if (STRONG && !l) K = 0;                                            // (three rounds could lift a stray back count to a "length" of 7 >= MIN_MATCH; with two it stays below)
 #ifndef LZ_EXP_NOADOPT
                 if (adopt) {
                 {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
-                    const uint32_t K1 = dpp_next_lane(K), T = K1 + 29u;
-                    K = ((K1 & 0xCu) != 0 && T > (K | 31u)) ? T : K;
+                    const uint32_t K1 = dpp_next_lane(K), T = K1 + 57u;
+                    K = ((K1 & 0x38u) != 0 && T > (K | 63u)) ? T : K;
                 }
                 {   // round 2: the match two lanes to the right (after round 1), two bytes longer
-                    const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 58u;
-                    K = ((K2 & 0x8u) != 0 && T > (K | 31u)) ? T : K;
+                    const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 114u;
+                    K = ((K2 & 0x30u) != 0 && T > (K | 63u)) ? T : K;
                 }
-                l = K >> 5;
-                off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 3u)));          // the offset travels with the match
+                if (strong) {   // (uniform) round 3: four lanes to the right, four bytes longer
+                    const uint32_t K4 = dpp_next_lane(dpp_next_lane(dpp_next_lane(dpp_next_lane(K)))), T = K4 + 228u;
+                    K = ((K4 & 0x20u) != 0 && T > (K | 63u)) ? T : K;
+                }
+                l = K >> 6;
+                off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 7u)));          // the offset travels with the match
                 }
 #endif
                 len[r] = l; flen[r] = l;
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0, so lane 63 never defers)
                 // lazy deferral: position q waits iff q + 1 is still in the tile and holds a longer match.  nl > l with l < MIN_MATCH is harmless
                 // (the position is no start anyway); q + 1 >= t1 only happens in a block's last, partial tile (nl is 0 there: lanes >= t1 hold no match)
-                const uint64_t longer = lazy ? __ballot(nl > l) : 0;
+                uint64_t longer = lazy ? __ballot(nl > l) : 0;
+                if (lazy && strong) longer |= __ballot(dpp_next_lane(nl) > l + 1);     // (uniform) two-step deferral: q + 2 holds a match longer by two or more
                 effm[r] = __ballot(l >= MIN_MATCH) & ~longer;
             };
             LZ_STAMP(2);
@@ -581,22 +597,25 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-template <int G, bool CT>
+template <int G, bool CT, bool STRONG>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true, G, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
-    else hipLaunchKernelGGL((k_lz<false, G, CT>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
-    if (ctab) launch_lz_g<LZ_G_DEFLATE, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
-    else launch_lz_g<LZ_G_ZSTD, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
+    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st); }
+    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
+           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st); }
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

@@ -252,17 +252,20 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
     return 0;
 }
 
-// Three parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
+// Four parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
 // lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101; PNA_LEVEL_DEFAULT and zstd level 0 = the default):
 //   fast      zstd < 0 and 1, deflate 0..3   greedy parse, every position in the table, look-back = the LDS window, no backward adoption
 //   balanced  zstd 2,         deflate 4..5   + even-position table, backward adoption, 1 MiB look-back (zstd); still greedy
-//   default   zstd 0, 3..22,  deflate 6..9   + one-step lazy deferral (the strongest parse this encoder has)
+//   default   zstd 0, 3..9,   deflate 6..8   + one-step lazy deferral
+//   strong    zstd 10..22,    deflate 9      + a third adoption round (matches move back by up to 7 positions) and two-step lazy deferral
 static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const int lv = pna_gpu_clamp_level(algo, level);
     const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
     const bool balanced = algo == PNA_ALGO_DEFLATE ? (lv == 4 || lv == 5) : lv == 2;
-    if (fast) return c->flags & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2);
-    if (balanced) return c->flags & ~F_LAZY;
+    const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : lv >= 10;
+    if (fast) return c->flags & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2 | F_STRONG);
+    if (balanced) return c->flags & ~(F_LAZY | F_STRONG);
+    if (strong && (c->flags & F_ADOPT) && (c->flags & F_LAZY)) return c->flags | F_STRONG;
     return c->flags;
 }
 
@@ -546,7 +549,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
-                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | 0x300u)), 32768u, 258u, st);
+                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,

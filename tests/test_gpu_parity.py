@@ -94,10 +94,10 @@ def test_both_sequence_coder_forms_are_identical(pna, codec, form):
         assert o == codec.model_compress(cases[k], p), k
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 0x77, 0x27, 0x67, 0x17, 0x47, 0x37])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 0x77, 0x27, 0x67, 0x17, 0x47, 0x37, 0xF7, 0xE7, 0xB7])
 def test_feature_subsets_bit_exact(pna, codec, flags):
     """Every subset of the encoder's switches -- Huffman / FSE / lazy, and the level-set bits F_FAR (0x10), F_ADOPT (0x20), F_INS2 (0x40) --
-    against the model with the corresponding parameters."""
+    and F_STRONG (0x80) -- against the model with the corresponding parameters."""
     import torch  # noqa: F401
     ents = [codec.corpus_file(0, 21, 300000), codec.corpus_file(1, 22, 5000), bytes(70000), b"", codec.corpus_file(2, 1, 3000),
             codec.corpus_file(0, 23, 1 << 20)]
@@ -882,27 +882,28 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
 
 
 def test_levels_select_the_parse(gpu_ctx, pna, codec):
-    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto three parameter sets -- fast (greedy,
-    LDS-window look-back, every position in the table), balanced (+ even-position table, backward adoption, 1 MiB look-back) and default
-    (+ lazy) --, each bit-exact with the model; stronger sets compress better."""
+    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto four parameter sets -- fast (greedy,
+    LDS-window look-back, every position in the table), balanced (+ even-position table, backward adoption, 1 MiB look-back), default
+    (+ lazy) and strong (+ third adoption round, two-step lazy) --, each bit-exact with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
     fast, balanced, dflt = codec.F_HUF | codec.F_FSE, std, std | codec.F_LAZY
+    strong = dflt | codec.F_STRONG
     sizes = {}
-    for level, fl in ((-5, fast), (1, fast), (2, balanced), (0, dflt), (3, dflt), (pna.LEVEL_DEFAULT, dflt), (19, dflt), (22, dflt), (99, dflt)):
+    for level, fl in ((-5, fast), (1, fast), (2, balanced), (0, dflt), (3, dflt), (pna.LEVEL_DEFAULT, dflt), (9, dflt), (10, strong), (19, strong), (22, strong), (99, strong)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         pz = codec.params_for_flags(fl)
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
-    assert sizes[3] < sizes[2] < sizes[1]
+    assert sizes[19] < sizes[3] < sizes[2] < sizes[1]
     dstd = codec.F_ADOPT | codec.F_INS2
-    for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd), (5, dstd), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY)):
+    for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd), (5, dstd), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
         pd = codec.params_for_flags(fl, deflate=True)
         assert outs == [codec.deflate_model_compress(d, pd) for d in data], level
         assert all(codec.zlib_decompress(o) == d for o, d in zip(outs, data))
         sizes[("d", level)] = sum(map(len, outs))
-    assert sizes[("d", 6)] < sizes[("d", 4)] < sizes[("d", 1)]
+    assert sizes[("d", 9)] < sizes[("d", 6)] < sizes[("d", 4)] < sizes[("d", 1)]
 
 
 def test_extract_driver_windows(gpu_ctx, pna, pf, codec):
@@ -1082,7 +1083,7 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
     segment size (far candidates, their 16 + 16 byte steps, the wave-cooperative extension reading the segment from HBM), repeats that start
     at odd positions and one or two bytes after a table hit (backward adoption, also across the 64-position group border where it must
     stop), candidates at positions 0..3 (unusable by rule), repeats that run into block and segment ends.  Bit-exact with the model,
-    decodable by libzstd / zlib, for both codecs and the three level sets."""
+    decodable by libzstd / zlib, for both codecs and the four level sets."""
     import random
     rnd = random.Random(2024)
 
@@ -1107,8 +1108,8 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
     cases["long-far-run"] = rb(100000) + bytes(200000) + rb(60000) + bytes(200000)
     names = sorted(cases)
     data = [cases[k] for k in names]
-    for level in (1, 2, 3):
-        fl = {1: codec.F_HUF | codec.F_FSE, 2: 0x73, 3: 0x77}[level]
+    for level in (1, 2, 3, 19):
+        fl = {1: codec.F_HUF | codec.F_FSE, 2: 0x73, 3: 0x77, 19: 0xF7}[level]
         outs = gpu_ctx.compress_batch(data, level=level)
         pz = codec.params_for_flags(fl)
         for k, d, o in zip(names, data, outs):
@@ -1117,7 +1118,7 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
             if codec.system_libzstd() is not None:
                 assert codec.libzstd_decompress_stream(o, len(d)) == d, (k, level)
     assert gpu_ctx.decompress_batch(outs, [len(d) for d in data]) == data
-    for level, fl in ((1, 0), (4, codec.F_ADOPT | codec.F_INS2), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY)):
+    for level, fl in ((1, 0), (4, codec.F_ADOPT | codec.F_INS2), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
         pd = codec.params_for_flags(fl, deflate=True)
         for k, d, o in zip(names, data, outs):
