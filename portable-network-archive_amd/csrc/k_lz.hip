@@ -52,6 +52,7 @@ struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = 
 static_assert(sizeof(WPub) == 8, "LDS record size");
 static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
+constexpr uint32_t FLAG_SPLIT_WAVEPARSE = 0x1000u;   // split form: the parse half as k_lz<MODE = 2> (a wave per region) instead of k_lzp (testing)
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
 static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3 && MIN_MATCH > 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
 static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
@@ -110,6 +111,29 @@ __device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, const uint8
     return L;
 }
 
+// the same with both sides read from the segment in memory (the parse half of the split form has no window)
+__device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t seg_len, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
+    uint32_t L = L0;
+    for (;;) {
+        const uint32_t pos = L + lane * 4;
+        uint32_t nb = 0;
+        const uint32_t room = lim > pos ? lim - pos : 0u;
+        if (room) {                                                                 // q + pos < q + lim <= the block's end: inside the segment
+            if (q + pos + 4 <= seg_len) {
+                const uint32_t x = *(const u32u *)(seg + q + pos) ^ *(const u32u *)(seg + c + pos);
+                nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+            } else {
+                while (nb < room && seg[q + pos + nb] == seg[c + pos + nb]) nb++;
+            }
+            nb = nb < room ? nb : room;
+        }
+        const uint64_t bad = __ballot(nb < 4u);
+        if (bad) { const uint32_t f = ctz64(bad); L += 4 * f + rdlane(nb, f); break; }
+        L += 256;
+    }
+    return L;
+}
+
 __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint32_t seg_len) {
     if (i + 16 <= seg_len) return *(const uint4 *)(seg + i);
     uint32_t w[4] = {0, 0, 0, 0};
@@ -125,10 +149,14 @@ __device__ unsigned long long g_lz_stamps[8];
 // CT: the launch fills the deflate chunk table (a template parameter so that the zstd instance carries none of that code).
 // STRONG: the parameter set of the high levels (third adoption round over 7 back bytes, two-step lazy deferral) as an instance of its own,
 // so that the default instance carries none of its loads and branches (as run-time switches they cost it 3.3 %).
-template <bool STAMP, int G, bool CT, bool STRONG>
-__global__ __launch_bounds__(LZ_THREADS)
+// MODE: 0 = the whole stage in one kernel; 1 / 2 = its two halves as kernels of their own (launch_lz_split): 1 = look-up, match and
+// inserts only -- one word per position (length | offset << 6, after adoption) goes to `pbuf` --, 2 = parse, merge and emission from those
+// words (no window, no table: 192 bytes of LDS, two workgroups per CU).  Same code, same results: the halves only meet in `pbuf`.
+template <bool STAMP, int G, bool CT, bool STRONG, int MODE>
+__global__ __launch_bounds__(LZ_THREADS, MODE == 2 ? 8 : 4)   // (second figure: waves per SIMD the compiler must leave room for)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
-          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len) {
+          uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len,
+          uint32_t *__restrict__ pbuf, uint32_t blk0) {
     constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -142,14 +170,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
-    uint32_t *wend    = (uint32_t *)(lds + L_WEND);
-    WPub     *wpub    = (WPub *)(lds + L_WPUB);
+    uint32_t *wend    = (uint32_t *)(lds + (MODE == 2 ? 0u : L_WEND));
+    WPub     *wpub    = (WPub *)(lds + (MODE == 2 ? 4u * LZ_WAVES : L_WPUB));
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = uni(tid >> 6);                  // tell the compiler it is wave-uniform: keeps the parse walks on the scalar unit
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
+    uint32_t *pb = MODE ? pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
     constexpr bool strong = STRONG;   // (wave-uniform) level sets: pna_host.cpp level_flags()
@@ -157,7 +186,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
 
-    for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 16 bytes per store
+    if (MODE != 2) for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 16 bytes per store
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
@@ -166,12 +195,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
     // positions below t0 + 2 TILE_G + LOOKAHEAD + 16 - 64 Ki <= t0 - max_off, which no match of tile t can reference.
     uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
-    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
+    if (MODE != 2) for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         *(uint4 *)(lds + L_WIN + i) = v;
         if (i == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = v;
     }
-    __syncthreads();
+    if (MODE != 2) __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
 
     const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
@@ -191,7 +220,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
 
             // ---- request the next tile's window chunk (consumed before B3)
-            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
+            if (MODE != 2 && tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
             LZ_STAMP(0);
 
 #ifdef LZ_EXP_PAD
@@ -215,10 +244,18 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             bool hv[G];
             // (uniform) a tile that lies wholly inside the block and at least 8 bytes before the segment end needs no per-lane range checks
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
+            uint32_t pv[G];                                                         // MODE 2: the positions' words
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 q[r] = t0 + wbase + 64 * r + lane;
                 hv[r] = tile_full || ((q[r] < t1) && (q[r] + 8 <= seg_len));
+                if constexpr (MODE == 2) {
+                    const bool in = q[r] < t1;
+                    pv[r] = in ? pb[q[r]] : 0u;
+                    lo[r] = in ? seg[q[r]] : 0u;                                    // the literal byte
+                    hi[r] = hsh[r] = tag[r] = ent[r] = bq[r] = bq2[r] = 0;
+                    continue;
+                }
                 {
                     const uint32_t *p = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);    // p[1], p[2] may lie in the mirror
                     const uint32_t sh = (q[r] & 3) * 8;
@@ -242,6 +279,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             U4u fa[G]; uint32_t fb[G], fc[G];
 #pragma unroll
             for (int r = 0; r < G; r++) {
+                if constexpr (MODE == 2) { off[r] = pv[r] >> 6; continue; }
                 fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = fc[r] = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
                 off[r] = (c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
@@ -260,6 +298,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             auto do_match = [&](const int r) __attribute__((always_inline)) {
                 uint32_t l = 0, bk = 0;                                             // bk = bytes before q and c that agree as well (<= 3; strong set: <= 7)
                 const uint32_t o = off[r];
+                if constexpr (MODE == 2) l = pv[r] & 63u;
+                else {
                 if (o != 0) {
                     const uint32_t c = q[r] - o;
                     const bool isfar = FAR && o > NEAR;
@@ -336,7 +376,9 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 7u)));          // the offset travels with the match
                 }
 #endif
+                }
                 len[r] = l; flen[r] = l;
+                if constexpr (MODE == 1) { effm[r] = 0; return; }
                 const uint32_t nl = dpp_next_lane(l);                               // len of the next position (lane 63: 0, so lane 63 never defers)
                 // lazy deferral: position q waits iff q + 1 is still in the tile and holds a longer match.  nl > l with l < MIN_MATCH is harmless
                 // (the position is no start anyway); q + 1 >= t1 only happens in a block's last, partial tile (nl is 0 there: lanes >= t1 hold no match)
@@ -394,7 +436,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         #ifdef LZ_EXP_NOFAREXT
                         const uint32_t L = (FAR && os > NEAR) ? L0
 #else
-                        const uint32_t L = (FAR && os > NEAR) ? lz_extend<true>(win32, seg, qs, qs - os, L0, xl, lane)
+                        const uint32_t L = MODE == 2 ? lz_extend_mem(seg, seg_len, qs, qs - os, L0, xl, lane)
+                                         : (FAR && os > NEAR) ? lz_extend<true>(win32, seg, qs, qs - os, L0, xl, lane)
 #endif
                                                               : lz_extend<false>(win32, seg, qs, qs - os, L0, xl, lane);
                         if (lane == s) flen[r] = L;
@@ -413,6 +456,23 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t fs = (uint32_t)__shfl((int)flen[r], (int)sl);
                 cov[r] = __ballot((m_le != 0 && lane < sl + fs) || lane < e0);
             };
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < G; r++) do_match(r);
+#pragma unroll
+                for (int r = 0; r < G; r++) if (q[r] < t1) pb[q[r]] = len[r] | (off[r] << 6);
+                if (tid < TILE_G / 16) {
+                    const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
+                    *(uint4 *)(lds + L_WIN + wo) = pf;
+                    if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
+                }
+                loaded_end += TILE_G;
+                __syncthreads();                                                    // every wave has looked up
+#pragma unroll
+                for (int r = 0; r < G; r++) if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+                __syncthreads();                                                    // inserts + window chunk in place
+                continue;
+            }
             // near candidates of all groups first (LDS), then the far ones + adoption: the far bytes had that long to arrive
             // half of the waves of a SIMD run all matches, then all parses, the other half match / parse group by group:
             // vector-heavy and scalar-heavy stretches of different waves then overlap at the issue port (-3 %)
@@ -426,7 +486,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 for (int r = 0; r < G; r++) { do_match(r); do_parse(r); }
             }
             LZ_STAMP(7);
-            if (tid < TILE_G / 16) {
+            if (MODE != 2 && tid < TILE_G / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
@@ -435,8 +495,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             if (lane == 0) wend[wave] = el ? wbase + el : 0u;
             __syncthreads();                                                        // B3
             // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
+            if constexpr (MODE != 2) {
 #pragma unroll
             for (int r = 0; r < G; r++) if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);   // even positions only
+            }
             LZ_STAMP(3);
 
             // ---- merge.  E = running end of the matches of the earlier waves (and the carry): a wave's last match moves E
@@ -592,30 +654,309 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             }
             LZ_STAMP(6);
         } // tiles
-        if (tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
+        if (MODE != 1 && tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
     } // blocks
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
+// ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes of one wave do here with 64-bit vector
+// arithmetic for the sixteen regions of a tile at once.  One workgroup of 4 waves per segment; per tile of 4 096 positions:
+//   0. the tile's words (k_lz<MODE 1>'s output) go from registers (requested one tile ahead) into LDS                       -> barrier
+//   1. position-parallel, 16 groups of 64 per wave: lengths -> start / cap masks of the group (ballots) -> LDS              -> barrier
+//   2. the WALKER wave (blockIdx & 3, so that the walkers of a CU's workgroups sit on different SIMDs), lanes 0..15: greedy walk
+//      over the region's four groups (the word of a chosen start from LDS; a capped match is extended by the whole wave, the
+//      lengths are kept in LDS), merge across the regions = across the lanes (serial form of the scan, DPP row scans for the
+//      counts), selection / literal masks, the region's sequences straight to memory, literal mask + first literal index of every
+//      group to LDS; the block-level state lives in this wave                                                                -> barrier
+//   3. position-parallel again: the literals of 16 groups per wave.
+// Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
+constexpr uint32_t LZP_THREADS = 256, LZP_WAVES = 4;
+template <bool CT, bool STRONG>
+__global__ __launch_bounds__(LZP_THREADS)
+void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
+           BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
+    constexpr uint32_t RW = 256, TG = 4096, GPW = TG / 64 / LZP_WAVES, WPT = TG / LZP_THREADS;   // groups per wave, words per thread
+    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && BLK_SIZE % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
+    __shared__ uint32_t lp[TG];                             // the tile's words
+    __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
+    __shared__ uint4 llit[TG / 64];                         // per group: literal mask, index of its first literal in the block
+    __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = lane & 15;
+    const uint32_t wave = uni(tid >> 6);
+    const bool walker = wave == (blockIdx.x & (LZP_WAVES - 1));
+    const SegDesc sd = segs[blockIdx.x];
+    const uint32_t seg_len = sd.len;
+    const uint8_t *seg = src + sd.src_off;
+    const uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
+    const uint32_t lazy = flags & F_LAZY;
+    const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;
+    const uint32_t wbase = w * RW;
+    const uint32_t ntile = (seg_len + TG - 1) / TG;
+
+    uint32_t pn[WPT];
+#pragma unroll
+    for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = tid + LZP_THREADS * i; pn[i] = p < seg_len ? pb[p] : 0u; }
+    uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (walker wave, uniform)
+    for (uint32_t T = 0; T < ntile; T++) {
+        const uint32_t t0 = T * TG, blk_start = t0 & ~(BLK_SIZE - 1);
+        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
+        const uint32_t t1 = (blk_end - t0 < TG) ? blk_end : t0 + TG;
+        const uint32_t npos = t1 - t0;
+        const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
+        const uint32_t gblk = sd.blk_base + (t0 >> PNA_BLK_LOG);
+        // ---- 0. this tile's words into LDS, the next tile's requested (positions behind the block's end read as "no match")
+#pragma unroll
+        for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = tid + LZP_THREADS * i; lp[p] = p < npos ? pn[i] : 0u; }
+        if (T + 1 < ntile) {
+#pragma unroll
+            for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = t0 + TG + tid + LZP_THREADS * i; pn[i] = p < seg_len ? pb[p] : 0u; }
+        }
+        __syncthreads();
+        // ---- 1. start / cap masks of this wave's groups
+#pragma unroll 4
+        for (uint32_t gi = 0; gi < GPW; gi++) {
+            const uint32_t g = wave * GPW + gi;
+            if (g * 64 >= npos) break;                                              // (uniform)
+            const uint32_t l = lp[g * 64 + lane] & 63u, nl = dpp_next_lane(l);
+            uint64_t longer = lazy ? __ballot(nl > l) : 0;
+            if (lazy && STRONG) longer |= __ballot(dpp_next_lane(nl) > l + 1);
+            const uint64_t em = __ballot(l >= MIN_MATCH) & ~longer, cm = __ballot(l >= CAP1);
+            if (lane == 0) lmask[g] = make_uint4((uint32_t)em, (uint32_t)(em >> 32), (uint32_t)cm, (uint32_t)(cm >> 32));
+        }
+        __syncthreads();
+        if (walker) {
+            if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
+            const bool lv = lane < 16;
+            // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it
+            const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
+            uint64_t sel[4], cov[4], cm[4];
+            uint32_t el = 0, nx = 0;
+            {
+                uint32_t cur = c_in > wbase ? (c_in - wbase < RW ? c_in - wbase : RW) : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    uint4 m = make_uint4(0, 0, 0, 0);
+                    if (lv && (w * 4 + r) * 64 < npos) m = lmask[w * 4 + r];
+                    const uint64_t em = (uint64_t)m.x | ((uint64_t)m.y << 32);
+                    cm[r] = (uint64_t)m.z | ((uint64_t)m.w << 32);
+                    const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;
+                    uint64_t rem = e0 < 64 ? em & (~(uint64_t)0 << e0) : 0;
+                    uint32_t e_last = e0;
+                    uint64_t selr = 0, covr = mlow(e0 < 64 ? e0 : 64u);
+                    while (__ballot(rem != 0)) {
+                        const bool a = rem != 0;
+                        const uint32_t s = a ? ctz64(rem) : 0u;
+                        const uint32_t ps = wbase + 64u * r + s;                    // tile-relative
+                        const uint32_t pwv = a ? lp[ps] : 0u;
+                        uint32_t L = pwv & 63u;
+                        const bool cap = a && ((cm[r] >> s) & 1);
+                        uint64_t need = __ballot(cap);
+                        if (need) {
+                            const uint32_t qs = t0 + ps;
+                            const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
+                            while (need) {
+                                const uint32_t k = ctz64(need); need &= need - 1;
+                                const uint32_t qk = rdlane(qs, k), ok = rdlane(pwv >> 6, k);
+                                const uint32_t Lk = lz_extend_mem(seg, seg_len, qk, qk - ok, rdlane(L, k), rdlane(xl, k), lane);
+                                if (lane == k) L = Lk;
+                            }
+                            if (cap) { xlen[w * 8 + (nx & 7)] = (uint16_t)L; nx++; }
+                        }
+                        if (a) {
+                            const uint32_t e = s + L, ec = e < 64 ? e : 64u;
+                            selr |= (uint64_t)1 << s; e_last = e;
+                            covr |= mlow(ec) & ~mlow(s);
+                            rem = ec < 64 ? rem & (~(uint64_t)0 << ec) : 0;
+                        }
+                    }
+                    sel[r] = selr; cov[r] = covr;
+                    if (selr) el = 64u * r + e_last;
+                    cur = 64u * r + (e_last > 64 ? e_last : 64u);
+                }
+            }
+            uint32_t pc[4];                                 // capped chosen starts in the groups before r = index base into xlen
+            pc[0] = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) pc[r + 1] = pc[r] + (uint32_t)__popcll(sel[r] & cm[r]);
+
+            // ---- merge across the lanes: the serial form of the scan (k_lz takes it only when an end falls 1-2 bytes behind E; it is the definition)
+            uint32_t E = c_in, tile_exit;
+            {
+                const uint32_t wend = el ? wbase + el : 0u;
+                uint32_t x = c_in;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const uint32_t ek = rdlane(wend, k);
+                    if (w == k) E = x;
+                    if (x < k * RW + RW && ek >= x + 3) x = ek;
+                }
+                tile_exit = x;
+            }
+            uint64_t fsel[4], litm[4];
+            uint32_t nselp[5], nlitp[5];
+            uint32_t cut_r = 4, cut_b = 0, cut_len = 0, cut_off = 0;   // the match cut from the front at E, if any
+            {
+                const uint32_t Ew = E > wbase ? (E - wbase < RW ? E - wbase : RW) : 0u;
+                const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;
+                uint64_t K[4], cv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t e = Ew > 64u * r ? Ew - 64u * r : 0u;
+                    K[r] = mlow(e < 64 ? e : 64u); fsel[r] = sel[r] & ~K[r]; cv[r] = cov[r];
+                }
+                if (lv && Ew > 0 && Ew < RW) {
+                    const uint32_t grp = Ew >> 6, b = Ew & 63;
+                    uint64_t cg = cov[0], sg = sel[0];
+#pragma unroll
+                    for (int r = 1; r < 4; r++) if (grp == (uint32_t)r) { cg = cov[r]; sg = sel[r]; }
+                    if (((cg >> b) & 1) && !((sg >> b) & 1)) {
+                        uint64_t below = sg & mlow(b);
+                        uint32_t g2 = grp;
+#pragma unroll
+                        for (int r = 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
+                        const uint32_t s2 = 63 - clz64(below);
+                        const uint32_t pw2 = lp[wbase + 64 * g2 + s2];
+                        uint64_t sc2 = sel[0] & cm[0]; uint32_t pc2 = pc[0];
+#pragma unroll
+                        for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
+                        const uint32_t l2 = ((sc2 >> s2) & 1) ? xlen[w * 8 + ((pc2 + (uint32_t)__popcll(sc2 & mlow(s2))) & 7)] : (pw2 & 63u);
+                        const uint32_t end2 = 64 * g2 + s2 + l2, rmn = end2 - Ew;
+                        if (rmn >= 3) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
+                            cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
+                                const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
+                                cv[r] &= ~(mlow(z0) & ~mlow(a0));
+                            }
+                        }
+                    }
+                }
+                nselp[0] = 0; nlitp[0] = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t ir = in0 > 64u * r ? in0 - 64u * r : 0u;
+                    litm[r] = lv ? mlow(ir < 64 ? ir : 64u) & ~(cv[r] | K[r]) : 0;
+                    if (!lv) fsel[r] = 0;
+                    nselp[r + 1] = nselp[r] + (uint32_t)__popcll(fsel[r]);
+                    nlitp[r + 1] = nlitp[r] + (uint32_t)__popcll(litm[r]);
+                }
+            }
+            uint32_t gl = 0, gf = 0;                        // 1 + the region's literal index at its last / first match, 0 = it has none
+#pragma unroll
+            for (int r = 3; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
+            if (CT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
+            }
+            uint32_t seq_base, lit_base, glast1_before;
+            {
+                const uint32_t cnt = nselp[4] | (nlitp[4] << 16);
+                const uint32_t incl = row_scan_add(cnt), excl = incl - cnt;
+                const uint32_t gabs = gl ? lit_run + (excl >> 16) + gl : 0u;
+                const uint32_t gmax = row_scan_max(gabs);
+                const uint32_t tot = rdlane(incl, 15);
+                seq_base = seq_run + (excl & 0xFFFF); lit_base = lit_run + (excl >> 16);
+                const uint32_t gb = DPP_ROW_SHR(gmax, 1);
+                glast1_before = gb > g_last1 ? gb : g_last1;
+                const uint32_t ga = rdlane(gmax, 15);
+                if (CT) {
+                    constexpr uint32_t CH = TG / TILE, WPC = 16 / CH;
+                    const uint32_t hrow = (uint32_t)__ballot(gl != 0) & 0xFFFFu;
+#pragma unroll
+                    for (uint32_t h = 0; h < CH; h++) {
+                        const uint32_t ex_h = rdlane(excl, h * WPC);
+                        const uint32_t hm_h = hrow & (((1u << WPC) - 1) << (h * WPC));
+                        uint32_t g_first = lit_run + (tot >> 16);
+                        if (hm_h) { const uint32_t j0 = (uint32_t)__builtin_ctz(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + rdlane(gf, j0) - 1; }
+                        if (lane == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
+                    }
+                }
+                g_last1 = ga > g_last1 ? ga : g_last1;
+                seq_run += tot & 0xFFFF; lit_run += tot >> 16;
+                next_free = t0 + rdlane(tile_exit, 0);
+            }
+            // ---- the region's sequences
+            {
+                uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
+                uint32_t idx = seq_base, prev = 0;
+                bool first = true;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    uint64_t rem = fsel[r];
+                    const uint64_t sc = sel[r] & cm[r];
+                    while (rem) {
+                        const uint32_t s = ctz64(rem); rem &= rem - 1;
+                        const uint32_t pwv = lp[wbase + 64u * r + s];
+                        uint32_t ml = pwv & 63u, of = pwv >> 6;
+                        if ((sc >> s) & 1) ml = xlen[w * 8 + ((pc[r] + (uint32_t)__popcll(sc & mlow(s))) & 7)];
+                        if (cut_r == (uint32_t)r && cut_b == s) { ml = cut_len; of = cut_off; }
+                        const uint32_t lidx = nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(s));
+                        const uint32_t ll = first ? lit_base + lidx - (glast1_before - 1) : lidx - prev;
+                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, ml, of);
+                        idx++; prev = lidx; first = false;
+                    }
+                }
+            }
+            if (lv) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) llit[w * 4 + r] = make_uint4((uint32_t)litm[r], (uint32_t)(litm[r] >> 32), lit_base + nlitp[r], 0u);
+            }
+            if (t1 == blk_end && lane == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
+        }
+        __syncthreads();
+        // ---- 3. literals of this wave's groups
+        {
+            uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
+#pragma unroll 4
+            for (uint32_t gi = 0; gi < GPW; gi++) {
+                const uint32_t g = wave * GPW + gi;
+                if (g * 64 >= npos) break;                                          // (uniform)
+                const uint4 m = llit[g];
+                const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
+                if ((lm >> lane) & 1) {
+                    const uint32_t li = m.z + (uint32_t)__popcll(lm & lane_lt);
+                    const uint8_t v = seg[t0 + g * 64 + lane];
+                    if (li < BLK_SIZE) blit[li] = v;
+                }
+            }
+        }
+        // (the next tile's stores into lp / lmask wait behind its first barrier for nobody: lp was last read before the barrier above, lmask before
+        // that; llit is rewritten by the walker only behind the next tile's second barrier, which every wave reaches after these reads)
+    }
+}
+
 template <int G, bool CT, bool STRONG>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
-    if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
-    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len);
+    if (pbuf) {
+        hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+        if (flags & FLAG_SPLIT_WAVEPARSE) hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+        else hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    }
+    else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
+// pbuf != nullptr: the split form (two kernels; pbuf holds one word per position of the launch's blocks, blk0 = the first of them)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
-                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st); }
-    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st);
-           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st); }
+    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0);
+                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0); }
+    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0);
+           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0); }
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

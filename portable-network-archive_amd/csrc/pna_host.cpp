@@ -25,7 +25,7 @@
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st);
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0);
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
@@ -121,7 +121,7 @@ struct pna_gpu_ctx {
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab;
+    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab, pbuf;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
@@ -213,7 +213,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->seg_size,
+    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
@@ -511,6 +511,29 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
     pre.swap(out);
 }
 
+// The LZ stage over segments [s0, s1) of a sub-batch.  Split form (PNA_LZ_SPLIT=1; 2 = with the wave-per-region parse half): match kernel + parse kernel per run of at most
+// `split_blocks` blocks, which meet in c->pbuf (4 bytes per input byte of the run; one run at a time on the stream, so runs share it).
+static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
+                    uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+    static const int split = [] { const char *e = getenv("PNA_LZ_SPLIT"); return e ? atoi(e) : 0; }();
+    static const uint32_t split_blocks = [] { const char *e = getenv("PNA_LZ_SPLIT_BLOCKS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 8 && v <= (1 << 17) ? v : 16384); }();
+    if (!split || (flags & 0x100u)) {
+        launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0);
+        return PNA_OK;
+    }
+    for (uint32_t a = s0; a < s1;) {
+        const uint32_t b0 = segs[a].blk_base;
+        uint32_t b = a + 1;
+        while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
+        const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
+        if (c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
+        launch_lz(d_src, (const SegDesc *)c->segs.p + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (split == 2 ? 0x1000u : 0u), max_off, max_len, st,
+                  (uint32_t *)c->pbuf.p, b0);
+        a = b;
+    }
+    return PNA_OK;
+}
+
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
                         hipStream_t st, bool timed, const FrameJob *fj = nullptr) {
@@ -548,8 +571,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
-        launch_lz(d_src, (const SegDesc *)c->segs.p, nseg, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p,
-                  (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st);
+        { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
@@ -571,8 +593,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr,
-                      c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st);
+            { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st); if (rc) return rc; }
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));

@@ -1,4 +1,5 @@
-"""A/B timing of k_lz between library builds on the SAME box: python scripts/ab.py libA.so libB.so ... (runs each in a child process, alternating)."""
+"""A/B timing of k_lz between library builds on the SAME box: python scripts/ab.py libA.so libB.so ... (runs each in a child process, alternating).
+An argument of the form K=V[,K=V...] runs the default library under that environment instead (e.g. PNA_LZ_SPLIT=1); `default` = no change."""
 import os, subprocess, sys
 child = r'''
 import importlib, os, sys
@@ -19,6 +20,8 @@ print(f"{best:.3f} {offs[-1]}")
 libs = sys.argv[1:]
 for rnd in range(3):
     for lib in libs:
-        env = dict(os.environ, PNA_GPU_LIB=os.path.abspath(lib))
+        if lib == "default": env = dict(os.environ)
+        elif "=" in lib: env = dict(os.environ, **dict(kv.split("=", 1) for kv in lib.split(",")))
+        else: env = dict(os.environ, PNA_GPU_LIB=os.path.abspath(lib))
         out = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True)
         print(rnd, lib, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
