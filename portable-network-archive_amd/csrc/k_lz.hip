@@ -661,44 +661,58 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
-// ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes of one wave do here with 64-bit vector
-// arithmetic for the sixteen regions of a tile at once.  One workgroup of 4 waves per segment; per tile of 4 096 positions:
-//   0. the tile's words (k_lz<MODE 1>'s output) go from registers (requested one tile ahead) into LDS                       -> barrier
-//   1. position-parallel, 16 groups of 64 per wave: lengths -> start / cap masks of the group (ballots) -> LDS              -> barrier
-//   2. the WALKER wave (blockIdx & 3, so that the walkers of a CU's workgroups sit on different SIMDs), lanes 0..15: greedy walk
-//      over the region's four groups (the word of a chosen start from LDS; a capped match is extended by the whole wave, the
-//      lengths are kept in LDS), merge across the regions = across the lanes (serial form of the scan, DPP row scans for the
-//      counts), selection / literal masks, the region's sequences straight to memory, literal mask + first literal index of every
-//      group to LDS; the block-level state lives in this wave                                                                -> barrier
-//   3. position-parallel again: the literals of 16 groups per wave.
+// ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes do here with vector arithmetic for the
+// sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 12.4 KiB of LDS) per segment; per tile of 4 096 positions:
+//   1. the tile's words (k_lz<MODE 1>'s output), 4 consecutive positions per lane and 16-byte load -> their lengths, a byte each, to
+//      LDS; the tile's input bytes go to LDS on the side.  Then one lane per GROUP of 64 positions: start / cap masks of the group
+//      from its 64 length bytes, four at a time inside a register (byte-wise compares by carry-free subtraction, the four
+//      results gathered into a nibble by one multiplication)
+//   2. lanes 0..15: greedy walk over the region's eight half-groups on 32-bit masks (length of a chosen start from LDS; a capped
+//      match is extended by the whole wave, the lengths are kept in LDS), merge across the regions = across the lanes (serial
+//      form of the scan, DPP row scans for the counts), selection / literal masks, one record per group to LDS
+//   3. one lane per group again: the group's sequences (offsets from the words in memory, four requested at a time)
+//   4. the literals, 4 consecutive positions per lane: the lane's literal bytes are packed by v_perm (selector from a 16-entry
+//      table) and stored behind the literals of the positions before it.
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
-constexpr uint32_t LZP_THREADS = 256, LZP_WAVES = 4;
+constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, bool STRONG>
 __global__ __launch_bounds__(LZP_THREADS)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
-    constexpr uint32_t RW = 256, TG = 4096, GPW = TG / 64 / LZP_WAVES, WPT = TG / LZP_THREADS;   // groups per wave, words per thread
+    constexpr uint32_t RW = 256, TG = 4096;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && BLK_SIZE % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
-    __shared__ uint32_t lp[TG];                             // the tile's words
+    __shared__ uint32_t l32[TG / 4];                        // the tile's match lengths, one byte per position
+    __shared__ uint4 sb4[TG / 16];                          // the tile's input bytes (for the literals)
     __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
-    __shared__ uint4 llit[TG / 64];                         // per group: literal mask, index of its first literal in the block
+    __shared__ uint32_t plut[16];                           // v_perm selectors that pack the bytes named by a nibble
+    __shared__ uint4 rec[3][TG / 64];                       // per group: [0] literal mask, first literal index, first sequence index; [1] chosen starts, the capped ones among all chosen;
+                                                            // [2] literal-run base of its first sequence, xlen base, cut position | length << 8, cut offset
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
-    const uint32_t tid = threadIdx.x, lane = tid & 63, w = lane & 15;
-    const uint32_t wave = uni(tid >> 6);
-    const bool walker = wave == (blockIdx.x & (LZP_WAVES - 1));
+    const uint32_t lane = threadIdx.x, w = lane & 15;
+    const uint8_t *len8 = (const uint8_t *)l32; const uint32_t *sb32 = (const uint32_t *)sb4;
     const SegDesc sd = segs[blockIdx.x];
     const uint32_t seg_len = sd.len;
     const uint8_t *seg = src + sd.src_off;
     const uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
     const uint32_t lazy = flags & F_LAZY;
-    const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;
     const uint32_t wbase = w * RW;
     const uint32_t ntile = (seg_len + TG - 1) / TG;
+    const bool lv = lane < 16;
+    if (lv) {                                               // selector of nibble n: the bytes whose bits are set, lowest first
+        uint32_t sel = 0, j = 0;
+        for (uint32_t bit = 0; bit < 4; bit++) if ((lane >> bit) & 1) { sel |= bit << (8 * j); j++; }
+        plut[lane] = sel;
+    }
+    // literals: bits of the group's literal mask below this lane's four positions (lane i of a region: group i / 16, bits 4 (i % 16) ..)
+    const uint64_t lit_below = ((uint64_t)1 << (4 * (lane & 15))) - 1;
+    uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (uniform)
 
-    uint32_t pn[WPT];
-#pragma unroll
-    for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = tid + LZP_THREADS * i; pn[i] = p < seg_len ? pb[p] : 0u; }
-    uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (walker wave, uniform)
+#ifdef LZP_PROF   // diagnostic build (scripts/lzp_stamps.py): s_memtime deltas per phase, summed over all waves
+    unsigned long long pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
+#define LZP_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pa[k] += t_ - pt0; pt0 = t_; } while (0)
+#else
+#define LZP_STAMP(k) do { } while (0)
+#endif
     for (uint32_t T = 0; T < ntile; T++) {
         const uint32_t t0 = T * TG, blk_start = t0 & ~(BLK_SIZE - 1);
         const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
@@ -706,229 +720,293 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         const uint32_t npos = t1 - t0;
         const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
         const uint32_t gblk = sd.blk_base + (t0 >> PNA_BLK_LOG);
-        // ---- 0. this tile's words into LDS, the next tile's requested (positions behind the block's end read as "no match")
+        const uint32_t ng = (npos + 63) >> 6;                                           // groups with positions in them
+        // ---- 1. lengths to LDS (positions behind the block's end count as "no match"; the words of a whole tile lie inside the segment's
+        // share of pbuf, whole blocks, so the loads need no bounds of their own)
+        {
+            uint4 sv[4];                                                                // the tile's input bytes: requested first, stored last
 #pragma unroll
-        for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = tid + LZP_THREADS * i; lp[p] = p < npos ? pn[i] : 0u; }
-        if (T + 1 < ntile) {
+            for (uint32_t i = 0; i < 4; i++) { const uint32_t p = i * 1024 + lane * 16; sv[i] = p < npos ? load_chunk(seg, t0 + p, seg_len) : make_uint4(0, 0, 0, 0); }
+            const uint4 *pt = (const uint4 *)(pb + t0);
+            for (uint32_t wq = 0; wq < 4 && wq * 1024 < npos; wq++) {                   // four regions at a time: their loads go out together
+                uint4 v[4];
 #pragma unroll
-            for (uint32_t i = 0; i < WPT; i++) { const uint32_t p = t0 + TG + tid + LZP_THREADS * i; pn[i] = p < seg_len ? pb[p] : 0u; }
-        }
-        __syncthreads();
-        // ---- 1. start / cap masks of this wave's groups
-#pragma unroll 4
-        for (uint32_t gi = 0; gi < GPW; gi++) {
-            const uint32_t g = wave * GPW + gi;
-            if (g * 64 >= npos) break;                                              // (uniform)
-            const uint32_t l = lp[g * 64 + lane] & 63u, nl = dpp_next_lane(l);
-            uint64_t longer = lazy ? __ballot(nl > l) : 0;
-            if (lazy && STRONG) longer |= __ballot(dpp_next_lane(nl) > l + 1);
-            const uint64_t em = __ballot(l >= MIN_MATCH) & ~longer, cm = __ballot(l >= CAP1);
-            if (lane == 0) lmask[g] = make_uint4((uint32_t)em, (uint32_t)(em >> 32), (uint32_t)cm, (uint32_t)(cm >> 32));
-        }
-        __syncthreads();
-        if (walker) {
-            if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
-            const bool lv = lane < 16;
-            // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it
-            const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
-            uint64_t sel[4], cov[4], cm[4];
-            uint32_t el = 0, nx = 0;
-            {
-                uint32_t cur = c_in > wbase ? (c_in - wbase < RW ? c_in - wbase : RW) : 0u;
+                for (uint32_t i = 0; i < 4; i++) v[i] = pt[(wq * 4 + i) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    uint4 m = make_uint4(0, 0, 0, 0);
-                    if (lv && (w * 4 + r) * 64 < npos) m = lmask[w * 4 + r];
-                    const uint64_t em = (uint64_t)m.x | ((uint64_t)m.y << 32);
-                    cm[r] = (uint64_t)m.z | ((uint64_t)m.w << 32);
-                    const uint32_t e0 = cur > 64u * r ? cur - 64u * r : 0u;
-                    uint64_t rem = e0 < 64 ? em & (~(uint64_t)0 << e0) : 0;
-                    uint32_t e_last = e0;
-                    uint64_t selr = 0, covr = mlow(e0 < 64 ? e0 : 64u);
-                    while (__ballot(rem != 0)) {
-                        const bool a = rem != 0;
-                        const uint32_t s = a ? ctz64(rem) : 0u;
-                        const uint32_t ps = wbase + 64u * r + s;                    // tile-relative
-                        const uint32_t pwv = a ? lp[ps] : 0u;
-                        uint32_t L = pwv & 63u;
-                        const bool cap = a && ((cm[r] >> s) & 1);
-                        uint64_t need = __ballot(cap);
-                        if (need) {
-                            const uint32_t qs = t0 + ps;
-                            const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
-                            while (need) {
-                                const uint32_t k = ctz64(need); need &= need - 1;
-                                const uint32_t qk = rdlane(qs, k), ok = rdlane(pwv >> 6, k);
-                                const uint32_t Lk = lz_extend_mem(seg, seg_len, qk, qk - ok, rdlane(L, k), rdlane(xl, k), lane);
-                                if (lane == k) L = Lk;
-                            }
-                            if (cap) { xlen[w * 8 + (nx & 7)] = (uint16_t)L; nx++; }
-                        }
-                        if (a) {
-                            const uint32_t e = s + L, ec = e < 64 ? e : 64u;
-                            selr |= (uint64_t)1 << s; e_last = e;
-                            covr |= mlow(ec) & ~mlow(s);
-                            rem = ec < 64 ? rem & (~(uint64_t)0 << ec) : 0;
-                        }
-                    }
-                    sel[r] = selr; cov[r] = covr;
-                    if (selr) el = 64u * r + e_last;
-                    cur = 64u * r + (e_last > 64 ? e_last : 64u);
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t p = (wq * 4 + i) * RW + lane * 4;
+                    uint32_t d = (v[i].x & 63u) | ((v[i].y & 63u) << 8) | ((v[i].z & 63u) << 16) | ((v[i].w & 63u) << 24);
+                    if (npos < TG && p + 4 > npos) d = p >= npos ? 0u : d & (0xFFFFFFFFu >> (8 * (p + 4 - npos)));
+                    l32[p >> 2] = d;
                 }
             }
-            uint32_t pc[4];                                 // capped chosen starts in the groups before r = index base into xlen
-            pc[0] = 0;
 #pragma unroll
-            for (int r = 0; r < 3; r++) pc[r + 1] = pc[r] + (uint32_t)__popcll(sel[r] & cm[r]);
+            for (uint32_t i = 0; i < 4; i++) sb4[i * 64 + lane] = sv[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // masks of group `lane` from its 64 length bytes.  Per register of 4 lengths l (all < 64): x = l | 0x80 per byte; x - 6 keeps the top bit iff
+        // l >= 6; x - l' (l' = the next position's length, 0 behind the group) keeps it iff l' <= l, i.e. the position does not defer; no byte
+        // borrows from its neighbour.  The four top bits become a nibble by (y >> 7) * 0x00204081 >> 21.
+        if (lane < ng) {
+            uint32_t d[17];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) { const uint4 t = ((const uint4 *)l32)[lane * 4 + i]; d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w; }
+            d[16] = 0;
+            uint32_t em2[2] = {0, 0}, cm2[2] = {0, 0};
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t x = d[i] | 0x80808080u;
+                uint32_t e = x - 0x06060606u;
+                if (lazy) {
+                    e &= x - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 1);
+                    if (STRONG) e &= x + 0x01010101u - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2);   // ... nor to the position after the next (longer by two or more)
+                }
+                const uint32_t en = ((((e >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
+                const uint32_t cn = ((((d[i] >> 5) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
+                em2[i >> 3] |= en << (4 * (i & 7)); cm2[i >> 3] |= cn << (4 * (i & 7));
+            }
+            lmask[lane] = make_uint4(em2[0], em2[1], cm2[0], cm2[1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        LZP_STAMP(0);
+        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
+        // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it; half-groups of 32 positions: one-register masks
+        const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
+        uint64_t sel[4], cov[4], cm[4];
+        uint32_t el = 0, nx = 0;
+        uint32_t em_lo[4], em_hi[4], cm_lo[4], cm_hi[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint4 m = make_uint4(0, 0, 0, 0);
+            if (lv && w * 4 + r < ng) m = lmask[w * 4 + r];
+            em_lo[r] = m.x; em_hi[r] = m.y; cm_lo[r] = m.z; cm_hi[r] = m.w;
+        }
+        {
+            uint32_t cur = c_in > wbase ? (c_in - wbase < RW ? c_in - wbase : RW) : 0u;
+            uint32_t s32[8], c32[8];
+#pragma unroll
+            for (int hb = 0; hb < 8; hb++) {
+                const uint32_t em32 = (hb & 1) ? em_hi[hb >> 1] : em_lo[hb >> 1], cm32 = (hb & 1) ? cm_hi[hb >> 1] : cm_lo[hb >> 1];
+                const uint32_t e0 = cur > 32u * hb ? cur - 32u * hb : 0u;
+                uint32_t rem = e0 < 32 ? em32 & (0xFFFFFFFFu << e0) : 0u;
+                uint32_t e_last = e0, selr = 0, covr = e0 < 32 ? (1u << e0) - 1 : 0xFFFFFFFFu;
+                while (__ballot(rem != 0)) {
+                    const bool a = rem != 0;
+                    const uint32_t s = a ? (uint32_t)__builtin_ctz(rem) : 0u;
+                    const uint32_t ps = wbase + 32u * hb + s;                       // tile-relative
+                    uint32_t L = a ? len8[ps] : 0u;
+                    const bool cap = a && ((cm32 >> s) & 1);
+                    uint64_t need = __ballot(cap);
+                    if (need) {
+                        const uint32_t qs = t0 + ps;
+                        const uint32_t pwv = cap ? pb[qs] : 0u;                      // (its offset)
+                        const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
+                        while (need) {
+                            const uint32_t k = ctz64(need); need &= need - 1;
+                            const uint32_t qk = rdlane(qs, k), ok = rdlane(pwv >> 6, k);
+                            const uint32_t Lk = lz_extend_mem(seg, seg_len, qk, qk - ok, rdlane(L, k), rdlane(xl, k), lane);
+                            if (lane == k) L = Lk;
+                        }
+                        if (cap) { xlen[w * 8 + (nx & 7)] = (uint16_t)L; nx++; }
+                    }
+                    if (a) {
+                        const uint32_t e = s + L;
+                        const uint32_t me = e < 32 ? (1u << e) - 1 : 0xFFFFFFFFu;   // positions below the match's end
+                        selr |= 1u << s; e_last = e;
+                        covr |= me & ~((1u << s) - 1);
+                        rem &= ~me;
+                    }
+                }
+                s32[hb] = selr; c32[hb] = covr;
+                if (selr) el = 32u * hb + e_last;
+                cur = 32u * hb + (e_last > 32 ? e_last : 32u);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                sel[r] = (uint64_t)s32[2 * r] | ((uint64_t)s32[2 * r + 1] << 32); cov[r] = (uint64_t)c32[2 * r] | ((uint64_t)c32[2 * r + 1] << 32);
+                cm[r] = (uint64_t)cm_lo[r] | ((uint64_t)cm_hi[r] << 32);
+            }
+        }
+        LZP_STAMP(1);
+        uint32_t pc[4];                                     // capped chosen starts in the groups before r = index base into xlen
+        pc[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) pc[r + 1] = pc[r] + (uint32_t)__popcll(sel[r] & cm[r]);
 
-            // ---- merge across the lanes: the serial form of the scan (k_lz takes it only when an end falls 1-2 bytes behind E; it is the definition)
-            uint32_t E = c_in, tile_exit;
-            {
-                const uint32_t wend = el ? wbase + el : 0u;
-                uint32_t x = c_in;
+        // ---- merge across the lanes: the serial form of the scan (k_lz takes it only when an end falls 1-2 bytes behind E; it is the definition)
+        uint32_t E = c_in, tile_exit;
+        {
+            const uint32_t wend = el ? wbase + el : 0u;
+            uint32_t x = c_in;
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) {
-                    const uint32_t ek = rdlane(wend, k);
-                    if (w == k) E = x;
-                    if (x < k * RW + RW && ek >= x + 3) x = ek;
-                }
-                tile_exit = x;
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t ek = rdlane(wend, k);
+                if (w == k) E = x;
+                if (x < k * RW + RW && ek >= x + 3) x = ek;
             }
-            uint64_t fsel[4], litm[4];
-            uint32_t nselp[5], nlitp[5];
-            uint32_t cut_r = 4, cut_b = 0, cut_len = 0, cut_off = 0;   // the match cut from the front at E, if any
-            {
-                const uint32_t Ew = E > wbase ? (E - wbase < RW ? E - wbase : RW) : 0u;
-                const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;
-                uint64_t K[4], cv[4];
+            tile_exit = x;
+        }
+        uint64_t fsel[4], litm[4];
+        uint32_t nselp[5], nlitp[5];
+        uint32_t cut_r = 4, cut_b = 0, cut_len = 0, cut_off = 0;   // the match cut from the front at E, if any
+        {
+            const uint32_t Ew = E > wbase ? (E - wbase < RW ? E - wbase : RW) : 0u;
+            const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;
+            uint64_t K[4], cv[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t e = Ew > 64u * r ? Ew - 64u * r : 0u;
-                    K[r] = mlow(e < 64 ? e : 64u); fsel[r] = sel[r] & ~K[r]; cv[r] = cov[r];
-                }
-                if (lv && Ew > 0 && Ew < RW) {
-                    const uint32_t grp = Ew >> 6, b = Ew & 63;
-                    uint64_t cg = cov[0], sg = sel[0];
+            for (int r = 0; r < 4; r++) {
+                const uint32_t e = Ew > 64u * r ? Ew - 64u * r : 0u;
+                K[r] = mlow(e < 64 ? e : 64u); fsel[r] = sel[r] & ~K[r]; cv[r] = cov[r];
+            }
+            if (lv && Ew > 0 && Ew < RW) {
+                const uint32_t grp = Ew >> 6, b = Ew & 63;
+                uint64_t cg = cov[0], sg = sel[0];
 #pragma unroll
-                    for (int r = 1; r < 4; r++) if (grp == (uint32_t)r) { cg = cov[r]; sg = sel[r]; }
-                    if (((cg >> b) & 1) && !((sg >> b) & 1)) {
-                        uint64_t below = sg & mlow(b);
-                        uint32_t g2 = grp;
+                for (int r = 1; r < 4; r++) if (grp == (uint32_t)r) { cg = cov[r]; sg = sel[r]; }
+                if (((cg >> b) & 1) && !((sg >> b) & 1)) {
+                    uint64_t below = sg & mlow(b);
+                    uint32_t g2 = grp;
 #pragma unroll
-                        for (int r = 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
-                        const uint32_t s2 = 63 - clz64(below);
-                        const uint32_t pw2 = lp[wbase + 64 * g2 + s2];
-                        uint64_t sc2 = sel[0] & cm[0]; uint32_t pc2 = pc[0];
+                    for (int r = 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
+                    const uint32_t s2 = 63 - clz64(below);
+                    const uint32_t pw2 = pb[t0 + wbase + 64 * g2 + s2];
+                    uint64_t sc2 = sel[0] & cm[0]; uint32_t pc2 = pc[0];
 #pragma unroll
-                        for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
-                        const uint32_t l2 = ((sc2 >> s2) & 1) ? xlen[w * 8 + ((pc2 + (uint32_t)__popcll(sc2 & mlow(s2))) & 7)] : (pw2 & 63u);
-                        const uint32_t end2 = 64 * g2 + s2 + l2, rmn = end2 - Ew;
-                        if (rmn >= 3) {
+                    for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
+                    const uint32_t l2 = ((sc2 >> s2) & 1) ? xlen[w * 8 + ((pc2 + (uint32_t)__popcll(sc2 & mlow(s2))) & 7)] : (pw2 & 63u);
+                    const uint32_t end2 = 64 * g2 + s2 + l2, rmn = end2 - Ew;
+                    if (rmn >= 3) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
-                            cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;
-                        } else {
+                        for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
+                        cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;
+                    } else {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
-                                const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
-                                cv[r] &= ~(mlow(z0) & ~mlow(a0));
-                            }
+                        for (int r = 0; r < 4; r++) {
+                            const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
+                            const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
+                            cv[r] &= ~(mlow(z0) & ~mlow(a0));
                         }
                     }
                 }
-                nselp[0] = 0; nlitp[0] = 0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t ir = in0 > 64u * r ? in0 - 64u * r : 0u;
-                    litm[r] = lv ? mlow(ir < 64 ? ir : 64u) & ~(cv[r] | K[r]) : 0;
-                    if (!lv) fsel[r] = 0;
-                    nselp[r + 1] = nselp[r] + (uint32_t)__popcll(fsel[r]);
-                    nlitp[r + 1] = nlitp[r] + (uint32_t)__popcll(litm[r]);
-                }
             }
-            uint32_t gl = 0, gf = 0;                        // 1 + the region's literal index at its last / first match, 0 = it has none
+            nselp[0] = 0; nlitp[0] = 0;
 #pragma unroll
-            for (int r = 3; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ir = in0 > 64u * r ? in0 - 64u * r : 0u;
+                litm[r] = lv ? mlow(ir < 64 ? ir : 64u) & ~(cv[r] | K[r]) : 0;
+                if (!lv) fsel[r] = 0;
+                nselp[r + 1] = nselp[r] + (uint32_t)__popcll(fsel[r]);
+                nlitp[r + 1] = nlitp[r] + (uint32_t)__popcll(litm[r]);
+            }
+        }
+        uint32_t gl = 0, gf = 0;                            // 1 + the region's literal index at its last / first match, 0 = it has none
+#pragma unroll
+        for (int r = 3; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
+        if (CT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
+        }
+        {
+            const uint32_t cnt = nselp[4] | (nlitp[4] << 16);
+            const uint32_t incl = row_scan_add(cnt), excl = incl - cnt;
+            const uint32_t gabs = gl ? lit_run + (excl >> 16) + gl : 0u;
+            const uint32_t gmax = row_scan_max(gabs);
+            const uint32_t tot = rdlane(incl, 15);
+            const uint32_t seq_base = seq_run + (excl & 0xFFFF), lit_base = lit_run + (excl >> 16);
+            const uint32_t gb = DPP_ROW_SHR(gmax, 1);
+            const uint32_t glast1_before = gb > g_last1 ? gb : g_last1;
+            const uint32_t ga = rdlane(gmax, 15);
             if (CT) {
+                constexpr uint32_t CH = TG / TILE, WPC = 16 / CH;
+                const uint32_t hrow = (uint32_t)__ballot(gl != 0) & 0xFFFFu;
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
-            }
-            uint32_t seq_base, lit_base, glast1_before;
-            {
-                const uint32_t cnt = nselp[4] | (nlitp[4] << 16);
-                const uint32_t incl = row_scan_add(cnt), excl = incl - cnt;
-                const uint32_t gabs = gl ? lit_run + (excl >> 16) + gl : 0u;
-                const uint32_t gmax = row_scan_max(gabs);
-                const uint32_t tot = rdlane(incl, 15);
-                seq_base = seq_run + (excl & 0xFFFF); lit_base = lit_run + (excl >> 16);
-                const uint32_t gb = DPP_ROW_SHR(gmax, 1);
-                glast1_before = gb > g_last1 ? gb : g_last1;
-                const uint32_t ga = rdlane(gmax, 15);
-                if (CT) {
-                    constexpr uint32_t CH = TG / TILE, WPC = 16 / CH;
-                    const uint32_t hrow = (uint32_t)__ballot(gl != 0) & 0xFFFFu;
-#pragma unroll
-                    for (uint32_t h = 0; h < CH; h++) {
-                        const uint32_t ex_h = rdlane(excl, h * WPC);
-                        const uint32_t hm_h = hrow & (((1u << WPC) - 1) << (h * WPC));
-                        uint32_t g_first = lit_run + (tot >> 16);
-                        if (hm_h) { const uint32_t j0 = (uint32_t)__builtin_ctz(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + rdlane(gf, j0) - 1; }
-                        if (lane == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
-                    }
+                for (uint32_t h = 0; h < CH; h++) {
+                    const uint32_t ex_h = rdlane(excl, h * WPC);
+                    const uint32_t hm_h = hrow & (((1u << WPC) - 1) << (h * WPC));
+                    uint32_t g_first = lit_run + (tot >> 16);
+                    if (hm_h) { const uint32_t j0 = (uint32_t)__builtin_ctz(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + rdlane(gf, j0) - 1; }
+                    if (lane == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
                 }
-                g_last1 = ga > g_last1 ? ga : g_last1;
-                seq_run += tot & 0xFFFF; lit_run += tot >> 16;
-                next_free = t0 + rdlane(tile_exit, 0);
             }
-            // ---- the region's sequences
-            {
-                uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
-                uint32_t idx = seq_base, prev = 0;
-                bool first = true;
+            g_last1 = ga > g_last1 ? ga : g_last1;
+            seq_run += tot & 0xFFFF; lit_run += tot >> 16;
+            next_free = t0 + rdlane(tile_exit, 0);
+            // one record per group for the lanes that write its sequences and literals
+            if (lv) {
+                uint32_t prevl = 0; bool any = false;       // literal index (region-local) at the region's latest chosen start so far
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    uint64_t rem = fsel[r];
+                    const uint32_t llbase = any ? nlitp[r] - prevl : lit_base + nlitp[r] - (glast1_before - 1);
+                    if (fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); prevl = nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); any = true; }
                     const uint64_t sc = sel[r] & cm[r];
-                    while (rem) {
-                        const uint32_t s = ctz64(rem); rem &= rem - 1;
-                        const uint32_t pwv = lp[wbase + 64u * r + s];
-                        uint32_t ml = pwv & 63u, of = pwv >> 6;
-                        if ((sc >> s) & 1) ml = xlen[w * 8 + ((pc[r] + (uint32_t)__popcll(sc & mlow(s))) & 7)];
-                        if (cut_r == (uint32_t)r && cut_b == s) { ml = cut_len; of = cut_off; }
-                        const uint32_t lidx = nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(s));
-                        const uint32_t ll = first ? lit_base + lidx - (glast1_before - 1) : lidx - prev;
-                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, ml, of);
-                        idx++; prev = lidx; first = false;
-                    }
+                    const uint32_t cutw = cut_r == (uint32_t)r ? cut_b | (cut_len << 8) : 64u;
+                    rec[0][w * 4 + r] = make_uint4((uint32_t)litm[r], (uint32_t)(litm[r] >> 32), lit_base + nlitp[r], seq_base + nselp[r]);
+                    rec[1][w * 4 + r] = make_uint4((uint32_t)fsel[r], (uint32_t)(fsel[r] >> 32), (uint32_t)sc, (uint32_t)(sc >> 32));
+                    rec[2][w * 4 + r] = make_uint4(llbase, w * 8 + pc[r], cutw, cut_off);
                 }
-            }
-            if (lv) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) llit[w * 4 + r] = make_uint4((uint32_t)litm[r], (uint32_t)(litm[r] >> 32), lit_base + nlitp[r], 0u);
             }
             if (t1 == blk_end && lane == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
         }
-        __syncthreads();
-        // ---- 3. literals of this wave's groups
+        __builtin_amdgcn_wave_barrier();
+        LZP_STAMP(2);
+        // ---- 3. the sequences, one lane per group
         {
-            uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
-#pragma unroll 4
-            for (uint32_t gi = 0; gi < GPW; gi++) {
-                const uint32_t g = wave * GPW + gi;
-                if (g * 64 >= npos) break;                                          // (uniform)
-                const uint4 m = llit[g];
-                const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
-                if ((lm >> lane) & 1) {
-                    const uint32_t li = m.z + (uint32_t)__popcll(lm & lane_lt);
-                    const uint8_t v = seg[t0 + g * 64 + lane];
-                    if (li < BLK_SIZE) blit[li] = v;
+            uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
+            const uint4 ra = rec[0][lane], rb = rec[1][lane], rc = rec[2][lane];
+            const uint64_t lm = (uint64_t)ra.x | ((uint64_t)ra.y << 32), sc = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
+            uint64_t rem = lane < ng ? (uint64_t)rb.x | ((uint64_t)rb.y << 32) : 0;
+            uint32_t idx = ra.w, prev = 0;
+            const uint32_t cut_b2 = rc.z & 0xFFu, cut_l2 = rc.z >> 8;
+            bool first = true;
+            const uint32_t *pg = pb + t0 + lane * 64;
+            while (rem) {
+                // four starts at a time: their words (the offsets) are requested together
+                uint32_t sq[4], pw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    sq[u] = rem ? ctz64(rem) : 64u;
+                    pw[u] = rem ? pg[sq[u]] : 0u;
+                    rem &= rem - 1;                                                 // (0 stays 0)
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t s = sq[u];
+                    if (s < 64) {
+                        uint32_t ml = pw[u] & 63u, of = pw[u] >> 6;
+                        if ((sc >> s) & 1) ml = xlen[(rc.y + (uint32_t)__popcll(sc & mlow(s))) & 127];
+                        if (cut_b2 == s) { ml = cut_l2; of = rc.w; }
+                        const uint32_t lq = (uint32_t)__popcll(lm & mlow(s));
+                        const uint32_t ll = first ? rc.x + lq : lq - prev;
+                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, ml, of);
+                        idx++; prev = lq; first = false;
+                    }
                 }
             }
         }
-        // (the next tile's stores into lp / lmask wait behind its first barrier for nobody: lp was last read before the barrier above, lmask before
-        // that; llit is rewritten by the walker only behind the next tile's second barrier, which every wave reaches after these reads)
+        LZP_STAMP(3);
+        // ---- 4. literals, region by region, 4 consecutive positions per lane
+        {
+            uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
+            const uint32_t sh = 4 * (lane & 15);
+            for (uint32_t wr = 0; wr * RW < npos; wr++) {
+                const uint4 m = rec[0][wr * 4 + (lane >> 4)];
+                const uint32_t wd = sb32[wr * 64 + lane];
+                const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
+                const uint32_t nib = (uint32_t)(lm >> sh) & 15u;
+                const uint32_t pk = __builtin_amdgcn_perm(wd, wd, plut[nib]), cnt = (uint32_t)__popc(nib);
+                uint8_t *o = blit + m.z + (uint32_t)__popcll(lm & lit_below);
+                if (cnt > 0) o[0] = (uint8_t)pk;
+                if (cnt > 1) o[1] = (uint8_t)(pk >> 8);
+                if (cnt > 2) o[2] = (uint8_t)(pk >> 16);
+                if (cnt > 3) o[3] = (uint8_t)(pk >> 24);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        LZP_STAMP(4);
     }
+#ifdef LZP_PROF
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], pa[k]);
+#endif
 }
 
 template <int G, bool CT, bool STRONG>

@@ -6,7 +6,7 @@ import importlib, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 pna = importlib.import_module("portable-network-archive_amd")
-n, L = 2048, 1 << 20
+n, L = int(os.environ.get("AB_N", "2048")), 1 << 20
 ctx = pna.Context(0)
 src = torch.empty(n * L + 8192, dtype=torch.uint8, device="cuda")
 ctx.corpus_fill_device(0, 0, n, L, L, src.data_ptr())

@@ -9,7 +9,7 @@ for LIB in "$@"; do
   rm -rf "$OUT"; mkdir -p "$OUT"
   export PNA_GPU_LIB=$PWD/$LIB
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM \
-    --kernel-trace --output-format csv -d "$OUT" -o sq -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline --no-verify > "$OUT.log" 2>&1
+    --kernel-trace --output-format csv -d "$OUT" -o sq -- python3 bench.py --files "$FILES" --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-end-to-end > "$OUT.log" 2>&1
   python3 - "$OUT" "$NAME" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
