@@ -45,6 +45,10 @@ extern "C" {
 #define PNA_F_ADOPT 0x20u       /* backward adoption: a match found late is moved back to its true start */
 #define PNA_F_INS2  0x40u       /* only even positions enter the hash table (with PNA_F_ADOPT) */
 #define PNA_F_STRONG 0x80u      /* third adoption round (up to 7 positions back) + two-step lazy deferral: the set of the high levels */
+#define PNA_F_LZ_WAVEPARSE 0x4000u  /* testing: the split LZ stage with the wave-per-region parse kernel as its second half */
+#define PNA_F_LZ_FUSED 0x8000u     /* the LZ stage as ONE kernel (match + parse in k_lz) instead of the default split form (match kernel ->
+                                     * one word per input byte in a workspace of up to 16 GiB -> parse kernel): same bytes, ~20 % slower,
+                                     * no workspace; the library falls back to it by itself when the workspace cannot be allocated */
 #define PNA_F_DEFAULT 0x80000000u   /* let the library choose */
 
 typedef struct pna_gpu_ctx pna_gpu_ctx;

@@ -22,6 +22,7 @@ ALGO_STORE, ALGO_DEFLATE, ALGO_ZSTD = 0, 1, 2
 LEVEL_DEFAULT = -1000
 F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
 F_FAR, F_ADOPT, F_INS2, F_STRONG = 0x10, 0x20, 0x40, 0x80
+F_LZ_WAVEPARSE, F_LZ_FUSED = 0x4000, 0x8000                      # forms of the LZ stage (default: split, lane-per-region parse); same bytes
 F_STD = F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2          # what F_DEFAULT selects
 
 SEG_SIZE = 1 << 20

@@ -119,6 +119,7 @@ struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
+    uint32_t lz_split_blocks = 0;                   // blocks per run of the split LZ stage once an allocation of pbuf failed (0 = the default)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab, pbuf;
@@ -511,26 +512,34 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
     pre.swap(out);
 }
 
-// The LZ stage over segments [s0, s1) of a sub-batch.  Split form (PNA_LZ_SPLIT=1; 2 = with the wave-per-region parse half): match kernel + parse kernel per run of at most
-// `split_blocks` blocks, which meet in c->pbuf (4 bytes per input byte of the run; one run at a time on the stream, so runs share it).
+// The LZ stage over segments [s0, s1) of a sub-batch.  Default: the split form -- match kernel (k_lz<MODE 1>) + parse kernel (k_lzp) per run
+// of at most `split_blocks` blocks, which meet in c->pbuf (4 bytes per input byte of the run; one run at a time on the stream, so runs
+// share it).  PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0: one kernel (k_lz<MODE 0>), no pbuf; PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form with
+// k_lz<MODE 2> as its parse half.  All forms give the same bytes.  If pbuf cannot be had, the run is halved down to 1 024 blocks, then fused.
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
-    static const int split = [] { const char *e = getenv("PNA_LZ_SPLIT"); return e ? atoi(e) : 0; }();
-    static const uint32_t split_blocks = [] { const char *e = getenv("PNA_LZ_SPLIT_BLOCKS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 8 && v <= (1 << 17) ? v : 16384); }();
-    if (!split || (flags & 0x100u)) {
-        launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0);
-        return PNA_OK;
-    }
-    for (uint32_t a = s0; a < s1;) {
+    // (read per call, not once: the tests switch them inside one process)
+    const int env_split = [] { const char *e = getenv("PNA_LZ_SPLIT"); return e ? atoi(e) : 1; }();
+    const uint32_t env_blocks = [] { const char *e = getenv("PNA_LZ_SPLIT_BLOCKS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 8 && v <= (1 << 17) ? v : 32768); }();
+    const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
+    const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
+    uint32_t split_blocks = c->lz_split_blocks ? c->lz_split_blocks : env_blocks;
+    for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
         while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
         const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
-        if (c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
-        launch_lz(d_src, (const SegDesc *)c->segs.p + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (split == 2 ? 0x1000u : 0u), max_off, max_len, st,
+        if (c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) {
+            (void)hipGetLastError();                                   // (the failed allocation's sticky code)
+            if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; c->lz_split_blocks = split_blocks; continue; }
+            s0 = a; break;                                             // no room for the words: the rest goes through the fused kernel
+        }
+        launch_lz(d_src, (const SegDesc *)c->segs.p + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
                   (uint32_t *)c->pbuf.p, b0);
         a = b;
+        if (a >= s1) return PNA_OK;
     }
+    launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0);
     return PNA_OK;
 }
 

@@ -80,6 +80,57 @@ def test_serial_end_scan_is_identical(pna, codec):
         assert o == codec.model_compress(cases[k], p), k
 
 
+@pytest.mark.parametrize("form", ["fused", "waveparse"])
+def test_lz_stage_forms_are_identical(pna, codec, form):
+    """The LZ stage runs as two kernels by default (k_lz<MODE 1>: look-up / match / inserts -> one word per position in a workspace ->
+    k_lzp: parse with one lane per region); PNA_F_LZ_FUSED runs the one-kernel form (k_lz<MODE 0>), PNA_F_LZ_WAVEPARSE the split form with
+    the wave-per-region parse (k_lz<MODE 2>).  All of them must equal the model, for both codecs and the four level sets, on the cases
+    of the main test and on the inputs that stress far candidates, adoption, block / segment ends and the extension of capped matches."""
+    import random
+    import torch  # noqa: F401
+    rnd = random.Random(77)
+    cases = dict(_cases(codec))
+    text = codec.corpus_file(0, 4343, 1 << 20)
+    rb = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    cases["far"] = text[:300000] + rb(70000) + text[1000:250000] + rb(1000) + text[123:200123]
+    cases["runs"] = rb(100000) + bytes(200000) + rb(60000) + bytes(200000) + b"ab" * 50000
+    cases["ends"] = rb(131072 - 50) + text[:100] + rb(70000) + text[:100] + rb(131072 - 70000 - 150) + text[:100]
+    cases["tail"] = text[:4096 * 3 + 17]
+    cases["3 MiB"] = codec.corpus_file(0, 4344, 3 << 20)
+    names = sorted(cases)
+    data = [cases[k] for k in names]
+    bit = {"fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE}[form]
+    with pna.Context(0, flags=pna.F_STD | bit) as ctx:
+        for level, fl in ((1, codec.F_HUF | codec.F_FSE), (2, 0x73), (3, 0x77), (19, 0xF7)):
+            outs = ctx.compress_batch(data, level=level)
+            pz = codec.params_for_flags(fl)
+            for k, d, o in zip(names, data, outs):
+                assert o == codec.model_compress(d, pz), (k, level)
+        for level, fl in ((1, 0), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
+            outs = ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
+            pd = codec.params_for_flags(fl, deflate=True)
+            for k, d, o in zip(names, data, outs):
+                assert o == codec.deflate_model_compress(d, pd), (k, level)
+
+
+def test_lz_stage_split_runs(pna, codec, monkeypatch):
+    """The split LZ stage works through a sub-batch in runs that share one workspace (PNA_LZ_SPLIT_BLOCKS blocks each, default 32 768 = 4 GiB
+    of input): with 8 blocks per run every 1 MiB segment is a run of its own, entries of several segments span runs, small entries share one."""
+    import torch  # noqa: F401
+    monkeypatch.setenv("PNA_LZ_SPLIT_BLOCKS", "8")
+    ents = [codec.corpus_file(0, 51, (3 << 20) + 4097), b"", codec.corpus_file(1, 52, 5000), codec.corpus_file(0, 53, 1 << 20), bytes(300000),
+            codec.corpus_file(0, 54, 200000), codec.corpus_file(2, 55, 70000), codec.corpus_file(0, 56, (1 << 20) + 1)]
+    with pna.Context(0) as ctx:
+        outs = ctx.compress_batch(ents)
+        p = _params(codec)
+        for e, o in zip(ents, outs):
+            assert o == codec.model_compress(e, p)
+        outs = ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
+        for e, o in zip(ents, outs):
+            assert o == codec.deflate_model_compress(e, codec.params_for_flags(codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY, deflate=True))
+            assert zlib.decompress(o) == e
+
+
 @pytest.mark.parametrize("form", [0x1000, 0x2000])
 def test_both_sequence_coder_forms_are_identical(pna, codec, form):
     """The sequences bitstream has two implementations picked by batch size (k_seqa + k_seqb: short state chain, token-parallel packing;
