@@ -42,7 +42,7 @@ constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 
 // LDS layout (byte offsets into the dynamic shared array)
 constexpr uint32_t L_WIN    = 0;
-constexpr uint32_t WIN_MIRROR = 16;                        // the window's first 16 bytes again behind its end: unaligned reads never wrap
+constexpr uint32_t WIN_MIRROR = 48;                        // the window's first 48 bytes again behind its end: unaligned reads never wrap (k_lz reads 16 past a position, k_lzm 36 past a lane's first)
 constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
 constexpr uint32_t L_WEND   = L_TABLE + 4u * HASH_ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
 constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
@@ -198,7 +198,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (MODE != 2) for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         *(uint4 *)(lds + L_WIN + i) = v;
-        if (i == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = v;
+        if (i < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + i) = v;
     }
     if (MODE != 2) __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
@@ -464,7 +464,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 if (tid < TILE_G / 16) {
                     const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                     *(uint4 *)(lds + L_WIN + wo) = pf;
-                    if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
+                    if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
                 }
                 loaded_end += TILE_G;
                 __syncthreads();                                                    // every wave has looked up
@@ -489,7 +489,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             if (MODE != 2 && tid < TILE_G / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
-                if (wo == 0) *(uint4 *)(lds + L_WIN + WIN_BYTES) = pf;
+                if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
             loaded_end += TILE_G;
             if (lane == 0) wend[wave] = el ? wbase + el : 0u;
@@ -657,6 +657,189 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
         if (MODE != 1 && tid == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
     } // blocks
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_lzm -- the match half of the split form: look-up, match, backward adoption and the tile's inserts, as in k_lz<MODE 1>, but with
+// FOUR CONSECUTIVE POSITIONS PER LANE (lane i of wave w: positions t0 + 256 w + 4 i + j, j = 0..3) instead of one position per lane and
+// group.  Nothing in this half needs a ballot over a group's positions, and with consecutive positions
+//   * the 36 + 4 bytes around a lane's positions are ten aligned dwords, loaded once; the 8 / 16 / 32 bytes at position j are
+//     v_alignbyte with a constant (j = 0: the registers themselves) -- k_lz loads and aligns them per position;
+//   * the right neighbours of the adoption rounds sit in the same lane, except across the lane border (DPP row_shl: a row of
+//     16 lanes is a group of 64 positions, and the zero fill at the row's end is the rule "adoption stops at the group border");
+//     the offset moves along with every adoption instead of one ds_bpermute at the end;
+//   * the four words of a lane go out as one 16-byte store; with even positions only, the inserts are those of j = 0 and 2.
+// Same table, window, tile order and barriers as k_lz, hence the same words (tests/test_gpu_parity.py: forms of the LZ stage).
+#define DPP_ROW_SHL1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xF, 0xF, true))   // value of lane i + 1 inside the row of 16 (0 at its end)
+template <bool DEFL, bool STRONG>
+__global__ __launch_bounds__(LZ_THREADS)
+void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0) {
+    constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
+    constexpr bool FAR = !DEFL;                             // deflate offsets (<= 32 KiB) never leave the LDS window
+    constexpr uint32_t NEAR = NEAR_OFF;
+    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *win32 = (uint32_t *)(lds + L_WIN);
+    uint32_t *table = (uint32_t *)(lds + L_TABLE);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = uni(tid >> 6);
+    const SegDesc sd = segs[blockIdx.x];
+    const uint8_t *seg = src + sd.src_off;
+    const uint32_t seg_len = sd.len;
+    uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
+    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
+
+    for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
+    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
+        const uint4 v = load_chunk(seg, i, seg_len);
+        *(uint4 *)(lds + L_WIN + i) = v;
+        if (i < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + i) = v;
+    }
+    __syncthreads();
+    uint4 pf = make_uint4(0, 0, 0, 0);
+
+    const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
+    for (uint32_t b = 0; b < nblk; b++) {
+        const uint32_t blk_start = b * BLK_SIZE;
+        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
+        for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
+            const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
+            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
+            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
+            const uint32_t q0 = t0 + wave * RW + 4 * lane;
+            // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
+            uint32_t D[9], Dm1, Dm2 = 0;
+            {
+                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..8] may lie in the mirror
+#pragma unroll
+                for (int k = 0; k < 9; k++) D[k] = pq[k];
+                Dm1 = win32[((q0 - 4) & (WIN_BYTES - 1)) >> 2];
+                if (STRONG) Dm2 = win32[((q0 - 8) & (WIN_BYTES - 1)) >> 2];
+            }
+#define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
+            // ---- look-up
+            uint32_t hsh[4], tag[4], ent[4];
+            bool hv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t q = q0 + j;
+                hv[j] = tile_full || ((q < t1) && (q + 8 <= seg_len));
+                const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
+                hsh[j] = __umulhi(h32, HASH_ENTRIES);
+                tag[j] = (h32 >> 6) & TAG_MASK;
+                ent[j] = hv[j] ? table[hsh[j]] : 0u;
+            }
+            // ---- candidates (rules as in k_lz); far ones get their bytes requested from the segment now
+            uint32_t off[4];
+            U4u fa[4]; uint32_t fb[4], fc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                fa[j].x = fa[j].y = fa[j].z = fa[j].w = fb[j] = fc[j] = 0;
+                const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
+                off[j] = (c1 > 8 && (ent[j] & TAG_MASK) == tag[j] && o <= max_off) ? o : 0u;
+                if (FAR && seg_len > NEAR && max_off > NEAR) {
+                    const uint32_t fo = off[j] > NEAR ? c1 - 5 : 0u;
+                    fa[j] = *(const U4u *)(seg + fo);
+                    fb[j] = *(const u32u *)(seg + fo + 16);
+                    if (STRONG) fc[j] = *(const u32u *)(seg + (off[j] > NEAR ? fo - 4 : 0u));
+                }
+            }
+            // ---- match
+            uint32_t K[4];
+            const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t l = 0, bk = 0;
+                const uint32_t o = off[j], q = q0 + j;
+                if (o != 0) {
+                    const uint32_t c = q - o;
+                    const bool isfar = FAR && o > NEAR;
+                    const uint32_t shc = (c & 3) * 8;
+                    uint32_t w0, w1, w2, w3, bc, bc2 = 0;
+                    if (isfar) { bc = fa[j].x; w0 = fa[j].y; w1 = fa[j].z; w2 = fa[j].w; w3 = fb[j]; bc2 = fc[j]; }
+                    else {
+                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
+                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
+                        w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                        w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                        bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                        if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
+                    }
+                    const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
+                    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
+                    l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+                    if (l == 16) {
+                        uint32_t v0, v1, v2, v3;
+                        if (isfar) { const U4u t = *(const U4u *)(seg + c + 16); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+                        else {
+                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
+                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                            v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                            v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
+                        }
+                        const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
+                        const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
+                        l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+                    }
+                    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
+                    if (l < MIN_MATCH) l = 0;
+                    const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
+                    const uint32_t xk = bqj ^ bc;
+                    bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
+                    if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
+                }
+                K[j] = (l << 6) | (bk << 3);
+                if (STRONG && !l) K[j] = 0;
+            }
+            // ---- backward adoption: K = len << 6 | back << 3 | positions moved; the offset goes along
+            if (adopt) {
+                {   // round 1: the right neighbour's match, one byte longer
+                    const uint32_t Kn = DPP_ROW_SHL1(K[0]), on = DPP_ROW_SHL1(off[0]);
+                    uint32_t K1[4] = {K[1], K[2], K[3], Kn}, o1[4] = {off[1], off[2], off[3], on};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t T = K1[j] + 57u;
+                        const bool a = (K1[j] & 0x38u) != 0 && T > (K[j] | 63u);
+                        K[j] = a ? T : K[j]; off[j] = a ? o1[j] : off[j];
+                    }
+                }
+                {   // round 2: the match two positions to the right (after round 1), two bytes longer
+                    const uint32_t Ka = DPP_ROW_SHL1(K[0]), Kb = DPP_ROW_SHL1(K[1]), oa = DPP_ROW_SHL1(off[0]), ob = DPP_ROW_SHL1(off[1]);
+                    uint32_t K2[4] = {K[2], K[3], Ka, Kb}, o2[4] = {off[2], off[3], oa, ob};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t T = K2[j] + 114u;
+                        const bool a = (K2[j] & 0x30u) != 0 && T > (K[j] | 63u);
+                        K[j] = a ? T : K[j]; off[j] = a ? o2[j] : off[j];
+                    }
+                }
+                if (STRONG) {   // round 3: four positions to the right = the same position of the next lane, four bytes longer
+                    uint32_t K4[4], o4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { K4[j] = DPP_ROW_SHL1(K[j]); o4[j] = DPP_ROW_SHL1(off[j]); }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t T = K4[j] + 228u;
+                        const bool a = (K4[j] & 0x20u) != 0 && T > (K[j] | 63u);
+                        K[j] = a ? T : K[j]; off[j] = a ? o4[j] : off[j];
+                    }
+                }
+            }
+            if (q0 < t1) *(uint4 *)(pb + q0) = make_uint4((K[0] >> 6) | (off[0] << 6), (K[1] >> 6) | (off[1] << 6), (K[2] >> 6) | (off[2] << 6), (K[3] >> 6) | (off[3] << 6));
+#undef QW
+            if (tid < TILE_G / 16) {
+                const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
+                *(uint4 *)(lds + L_WIN + wo) = pf;
+                if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
+            }
+            loaded_end += TILE_G;
+            __syncthreads();                                                        // every wave has looked up
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+            __syncthreads();                                                        // inserts + window chunk in place
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1015,13 +1198,18 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lzm<CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
     if (pbuf) {
-        hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
-        if (flags & FLAG_SPLIT_WAVEPARSE) hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
-        else hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+        if (flags & FLAG_SPLIT_WAVEPARSE) {
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            return;
+        }
+        hipLaunchKernelGGL((k_lzm<CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0);
+        hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
     }
     else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
     else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);

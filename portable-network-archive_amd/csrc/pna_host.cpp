@@ -524,11 +524,17 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
     const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
     uint32_t split_blocks = c->lz_split_blocks ? c->lz_split_blocks : env_blocks;
+    const uint32_t s1_all = s1; bool fused_tail = false;
+    // A run of fewer than ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
+    // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
+    // (measured, N x 1 MiB: 256: 2.5 ms fused / 4.9 ms split, 1 024: 9.8 / 9.6, 2 048: 19.5 / 15.5, 3 072: 29.3 / 21.1).
+    const uint32_t min_segs = [] { const char *e = getenv("PNA_LZ_SPLIT_MIN"); const long v = e ? atol(e) : -1; return (uint32_t)(v >= 0 ? v : 1024); }();
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
         while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
         const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
+        if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
         if (c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) {
             (void)hipGetLastError();                                   // (the failed allocation's sticky code)
             if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; c->lz_split_blocks = split_blocks; continue; }
@@ -540,6 +546,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
         if (a >= s1) return PNA_OK;
     }
     launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0);
+    if (fused_tail) return lz_stage(c, d_src, segs, s1, s1_all, nblk, ctab, flags, max_off, max_len, st);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
 

@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _split_lz_stage_for_small_batches(monkeypatch):
+    """The LZ stage sends runs of fewer than 1 024 segments through its one-kernel form (faster for them), so with the library's default
+    the small batches of this suite would never reach the split form's kernels (k_lzm, k_lzp) that the headline workload runs on.  The
+    suite therefore lowers the threshold to zero; the one-kernel form has tests of its own (test_lz_stage_forms_are_identical) and the
+    full-size tests (tests/test_gpu_full_size.py) put the default back."""
+    if "PNA_LZ_SPLIT_MIN" not in os.environ:
+        monkeypatch.setenv("PNA_LZ_SPLIT_MIN", "0")
+
+
 @pytest.fixture(scope="session")
 def codec():
     from oracle import codec as c
@@ -46,10 +56,12 @@ def gpu_ctx(pna):
 
 
 @pytest.fixture
-def big_ctx(pna):
+def big_ctx(pna, monkeypatch):
     """A context of its own for the full-size cases: their multi-GiB workspaces (decoder scratch, staging) are released with it instead
-    of staying in the session's context, and torch's cached blocks are handed back before and after."""
+    of staying in the session's context, and torch's cached blocks are handed back before and after.  The full-size cases run the
+    library's defaults (see _split_lz_stage_for_small_batches)."""
     import torch
+    monkeypatch.delenv("PNA_LZ_SPLIT_MIN", raising=False)
     torch.cuda.empty_cache()
     ctx = pna.Context(0)
     yield ctx

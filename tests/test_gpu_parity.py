@@ -80,8 +80,8 @@ def test_serial_end_scan_is_identical(pna, codec):
         assert o == codec.model_compress(cases[k], p), k
 
 
-@pytest.mark.parametrize("form", ["fused", "waveparse"])
-def test_lz_stage_forms_are_identical(pna, codec, form):
+@pytest.mark.parametrize("form", ["default", "fused", "waveparse"])
+def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     """The LZ stage runs as two kernels by default (k_lz<MODE 1>: look-up / match / inserts -> one word per position in a workspace ->
     k_lzp: parse with one lane per region); PNA_F_LZ_FUSED runs the one-kernel form (k_lz<MODE 0>), PNA_F_LZ_WAVEPARSE the split form with
     the wave-per-region parse (k_lz<MODE 2>).  All of them must equal the model, for both codecs and the four level sets, on the cases
@@ -99,7 +99,9 @@ def test_lz_stage_forms_are_identical(pna, codec, form):
     cases["3 MiB"] = codec.corpus_file(0, 4344, 3 << 20)
     names = sorted(cases)
     data = [cases[k] for k in names]
-    bit = {"fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE}[form]
+    bit = {"default": 0, "fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE}[form]
+    if form == "default":
+        monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: short runs through the one-kernel form (the suite's default is 0)
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
         for level, fl in ((1, codec.F_HUF | codec.F_FSE), (2, 0x73), (3, 0x77), (19, 0xF7)):
             outs = ctx.compress_batch(data, level=level)
