@@ -17,7 +17,8 @@ last piece's gather is exposed.  `--scaling weak` gives every rank `--files` ent
 §8(e) comparison path is timed as well: every rank copies its pieces D2H straight into a pre-offset page-locked host buffer shared by
 the ranks (`gather_compare`).
 
-Rank 0 prints ONE JSON line.  Besides the contract's keys it carries `roofline` (k_lz against the HBM peak), `cpu_baseline` (the
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries `roofline` (the dominant kernel -- k_lzm, the match kernel of the
+split LZ stage, or k_lz when the batch went through the one-kernel form -- against the HBM peak), `cpu_baseline` (the
 reference's pipeline restated on the host cores, for every --algo / --framing), and at N = 1 `end_to_end`: the same corpus from
 PAGEABLE host memory through pna_gpu_create_archive_host to a counting sink (SURVEY §8(d)'s wall-clock metric, PCIe included).
 """
@@ -58,14 +59,15 @@ def size_label(n: int) -> str:
     return f"{n} B"
 
 
-def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing: str):
-    """HBM bytes per k_lz launch from the PMC passes committed under profiles/ (scripts/pmc_traffic.sh); counters cannot be
-    read from inside this process, so the figure is only reported for the exact workload it was measured on, else null."""
+def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing: str, kernel: str):
+    """HBM bytes of the dominant kernel's launches of one step (same span as `algorithmic_bytes`) from the PMC passes committed under
+    profiles/ (scripts/pmc_traffic.sh); counters cannot be read from inside this process, so the figure is only reported for the exact
+    workload and kernel it was measured on, else null."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         w = d["workload"]
         if (w["files"], w["file_bytes"], w["algo"], w["kind"], w["framing"]) == (n_files, file_len, algo, kind, framing):
-            return d["k_lz"]["hbm_bytes_per_launch"]
+            return d[kernel]["hbm_bytes_per_step"]
     except Exception:
         pass
     return None
@@ -336,7 +338,7 @@ def main() -> None:
         # the first piece of rank 0 carries the archive header, the last piece of the last rank AEND: all pieces in order are ONE archive
         return (pna.PART_HEAD if (rank == 0 and h == 0) else 0) | (pna.PART_TAIL if (rank == world - 1 and h == pieces - 1) else 0)
 
-    lz_acc = [0.0, 0.0]
+    lz_acc = [0.0, 0.0, 0.0, 0]                             # LZ stage ms, all stages ms, match-kernel ms, match-kernel launches
 
     def step():
         total_all = 0
@@ -354,6 +356,8 @@ def main() -> None:
                 total = ctx.compress_batch_device(src.data_ptr(), src_off, src_len, dst.data_ptr(), dst_cap, algo=algo, level=lvl)[-1]
             tm = ctx.timing()
             lz_acc[0] += tm.ms_lz
+            lz_acc[2] += tm.ms_lz_match
+            lz_acc[3] += tm.lz_match_launches
             lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
             if world > 1 and mode[0] == "rccl":
                 if rank == 0 and gather_out[h] is None:
@@ -380,7 +384,8 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        lz_acc[0] = lz_acc[1] = 0.0
+        lz_acc[0] = lz_acc[1] = lz_acc[2] = 0.0
+        lz_acc[3] = 0
         t0 = time.perf_counter()
         out = 0
         for _ in range(n_steps):
@@ -399,7 +404,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     dt, out_total = timed(args.steps)
-    lz_ms, stage_ms = lz_acc
+    lz_ms, stage_ms, lzm_ms, lzm_launches = lz_acc
     if world > 1:
         o = torch.tensor([out_total], dtype=torch.int64, device=xdev)
         dist.all_reduce(o)
@@ -509,9 +514,14 @@ def main() -> None:
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = in_all / (dt / args.steps) / 2**20
-        lz_avg_s = lz_ms / args.steps / 1e3
+        # roofline of the dominant kernel.  Split LZ stage (the default for runs of >= 1 024 segments): k_lzm, the match kernel, launched once per
+        # run of <= 4 GiB of input; its launches of a step together see every input byte, so Σ algorithmic bytes / Σ launch time = the step's
+        # algorithmic bytes / the step's k_lzm time.  One-kernel form: k_lz, as before.
         alg_bytes = in_rank + out_total                      # each input byte read once + each output byte written once
-        achieved = alg_bytes / lz_avg_s / 1e9 if lz_avg_s > 0 else 0.0
+        split = lzm_launches > 0 and lzm_ms > 0
+        dom_ms_step = (lzm_ms if split else lz_ms) / args.steps
+        dom_launches = (lzm_launches / args.steps) if split else float(pieces)
+        achieved = alg_bytes / (dom_ms_step / 1e3) / 1e9 if dom_ms_step > 0 else 0.0
         tm = tm_last
         level = pna.clamp_level(algo, lvl)
         wl = (f"{files_all} x {size_label(file_len)}" if args.framing != "solid" else f"--solid, one {size_label(files_all * file_len)} stream of {files_all} x {size_label(file_len)} entries")
@@ -533,11 +543,16 @@ def main() -> None:
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "gathered_archive_verified": gathered_ok,    # N > 1: the archive gathered on rank 0 read back through the extract driver
-            "roofline": {"bound": "hbm", "kernel": "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_lzm" if split else "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing),
-                         "algorithmic_bytes": alg_bytes,
-                         "kernel_ms": round(lz_ms / args.steps, 3), "all_kernels_ms": round(stage_ms / args.steps, 3)},
+                         "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing, "k_lzm" if split else "k_lz"),
+                         "algorithmic_bytes": alg_bytes,                         # per step = over the kernel's launches of one step
+                         "launches_per_step": round(dom_launches, 2),
+                         "kernel_ms": round(dom_ms_step / max(dom_launches, 1e-9), 3),   # average launch duration (HIP events on the launch stream)
+                         "kernel_ms_per_step": round(dom_ms_step, 3),
+                         "lz_stage_ms": round(lz_ms / args.steps, 3),           # match + parse kernels (k_lzm + k_lzp) of a step
+                         "achieved_lz_stage": round(alg_bytes / max(lz_ms / args.steps / 1e3, 1e-12) / 1e9, 2),
+                         "all_kernels_ms": round(stage_ms / args.steps, 3)},
             # the last launch of the last step: with gather_pieces = P that is one piece, 1 / P of a step
             "stages_ms_last_step": {"lz": round(tm.ms_lz, 3), "stats": round(tm.ms_stats, 3), "lit": round(tm.ms_lit, 3),
                                     "seq": round(tm.ms_seq, 3), "pack": round(tm.ms_pack, 3), "frame": round(tm.ms_frame, 3)},

@@ -315,6 +315,8 @@ typedef struct {
     uint64_t in_bytes, out_bytes, n_segments, n_blocks;
     double   ms_frame;                                   /* k_frame (pna_gpu_create_archive_device only)       */
     double   ms_cipher;                                  /* k_aes_* (archives written with a cipher)           */
+    double   ms_lz_match;                                /* of ms_lz: the match kernel (k_lzm) launches of the split LZ stage, summed */
+    uint64_t lz_match_launches;                          /* ... and how many there were (0: the batch went through the one-kernel form) */
 } pna_gpu_timing;
 int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
 

@@ -48,7 +48,8 @@ class Timing(ctypes.Structure):
     _fields_ = [("ms_lz", ctypes.c_double), ("ms_stats", ctypes.c_double), ("ms_lit", ctypes.c_double),
                 ("ms_seq", ctypes.c_double), ("ms_pack", ctypes.c_double), ("in_bytes", ctypes.c_uint64),
                 ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64),
-                ("ms_frame", ctypes.c_double), ("ms_cipher", ctypes.c_double)]
+                ("ms_frame", ctypes.c_double), ("ms_cipher", ctypes.c_double), ("ms_lz_match", ctypes.c_double),
+                ("lz_match_launches", ctypes.c_uint64)]
 
 
 ENC_NONE, ENC_AES, ENC_CAMELLIA = 0, 1, 2          # Encryption::to_byte()

@@ -845,16 +845,16 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
 // ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes do here with vector arithmetic for the
-// sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 12.4 KiB of LDS) per segment; per tile of 4 096 positions:
+// sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 8.4 KiB of LDS) per segment; per tile of 4 096 positions:
 //   1. the tile's words (k_lz<MODE 1>'s output), 4 consecutive positions per lane and 16-byte load -> their lengths, a byte each, to
-//      LDS; the tile's input bytes go to LDS on the side.  Then one lane per GROUP of 64 positions: start / cap masks of the group
+//      LDS; then one lane per GROUP of 64 positions: start / cap masks of the group
 //      from its 64 length bytes, four at a time inside a register (byte-wise compares by carry-free subtraction, the four
 //      results gathered into a nibble by one multiplication)
 //   2. lanes 0..15: greedy walk over the region's eight half-groups on 32-bit masks (length of a chosen start from LDS; a capped
 //      match is extended by the whole wave, the lengths are kept in LDS), merge across the regions = across the lanes (serial
 //      form of the scan, DPP row scans for the counts), selection / literal masks, one record per group to LDS
 //   3. one lane per group again: the group's sequences (offsets from the words in memory, four requested at a time)
-//   4. the literals, 4 consecutive positions per lane: the lane's literal bytes are packed by v_perm (selector from a 16-entry
+//   4. the literals, 4 consecutive positions per lane (their input bytes were requested from memory before step 3): the lane's literal bytes are packed by v_perm (selector from a 16-entry
 //      table) and stored behind the literals of the positions before it.
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
@@ -865,14 +865,13 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     constexpr uint32_t RW = 256, TG = 4096;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && BLK_SIZE % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
     __shared__ uint32_t l32[TG / 4];                        // the tile's match lengths, one byte per position
-    __shared__ uint4 sb4[TG / 16];                          // the tile's input bytes (for the literals)
     __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
     __shared__ uint32_t plut[16];                           // v_perm selectors that pack the bytes named by a nibble
     __shared__ uint4 rec[3][TG / 64];                       // per group: [0] literal mask, first literal index, first sequence index; [1] chosen starts, the capped ones among all chosen;
                                                             // [2] literal-run base of its first sequence, xlen base, cut position | length << 8, cut offset
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
     const uint32_t lane = threadIdx.x, w = lane & 15;
-    const uint8_t *len8 = (const uint8_t *)l32; const uint32_t *sb32 = (const uint32_t *)sb4;
+    const uint8_t *len8 = (const uint8_t *)l32;
     const SegDesc sd = segs[blockIdx.x];
     const uint32_t seg_len = sd.len;
     const uint8_t *seg = src + sd.src_off;
@@ -907,9 +906,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         // ---- 1. lengths to LDS (positions behind the block's end count as "no match"; the words of a whole tile lie inside the segment's
         // share of pbuf, whole blocks, so the loads need no bounds of their own)
         {
-            uint4 sv[4];                                                                // the tile's input bytes: requested first, stored last
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) { const uint32_t p = i * 1024 + lane * 16; sv[i] = p < npos ? load_chunk(seg, t0 + p, seg_len) : make_uint4(0, 0, 0, 0); }
             const uint4 *pt = (const uint4 *)(pb + t0);
             for (uint32_t wq = 0; wq < 4 && wq * 1024 < npos; wq++) {                   // four regions at a time: their loads go out together
                 uint4 v[4];
@@ -923,8 +919,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     l32[p >> 2] = d;
                 }
             }
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) sb4[i * 64 + lane] = sv[i];
         }
         __builtin_amdgcn_wave_barrier();
         // masks of group `lane` from its 64 length bytes.  Per register of 4 lengths l (all < 64): x = l | 0x80 per byte; x - 6 keeps the top bit iff
@@ -1132,6 +1126,15 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         }
         __builtin_amdgcn_wave_barrier();
         LZP_STAMP(2);
+        // the input bytes of the lane's four positions in every region, for the literals: requested now, used behind the sequences
+        uint32_t lw[16];
+#pragma unroll
+        for (uint32_t wr = 0; wr < 16; wr++) {
+            const uint32_t q = t0 + wr * RW + 4 * lane;
+            lw[wr] = 0;
+            if (q + 4 <= seg_len) lw[wr] = *(const uint32_t *)(seg + q);                 // (segments start at multiples of 16)
+            else { for (uint32_t i = 0; i < 3; i++) if (q + i < seg_len) lw[wr] |= (uint32_t)seg[q + i] << (8 * i); }
+        }
         // ---- 3. the sequences, one lane per group
         {
             uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
@@ -1171,9 +1174,11 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         {
             uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
             const uint32_t sh = 4 * (lane & 15);
-            for (uint32_t wr = 0; wr * RW < npos; wr++) {
+#pragma unroll
+            for (uint32_t wr = 0; wr < 16; wr++) {
+                if (wr * RW >= npos) continue;                                      // (uniform)
                 const uint4 m = rec[0][wr * 4 + (lane >> 4)];
-                const uint32_t wd = sb32[wr * 64 + lane];
+                const uint32_t wd = lw[wr];
                 const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
                 const uint32_t nib = (uint32_t)(lm >> sh) & 15u;
                 const uint32_t pk = __builtin_amdgcn_perm(wd, wd, plut[nib]), cnt = (uint32_t)__popc(nib);
@@ -1194,7 +1199,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 
 template <int G, bool CT, bool STRONG>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0) {
+                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
@@ -1205,24 +1210,27 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
     if (pbuf) {
         if (flags & FLAG_SPLIT_WAVEPARSE) {
             hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            if (ev_match) (void)hipEventRecord(ev_match, st);
             hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             return;
         }
         hipLaunchKernelGGL((k_lzm<CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0);
+        if (ev_match) (void)hipEventRecord(ev_match, st);
         hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
     }
     else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
     else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
-// pbuf != nullptr: the split form (two kernels; pbuf holds one word per position of the launch's blocks, blk0 = the first of them)
+// pbuf != nullptr: the split form (two kernels; pbuf holds one word per position of the launch's blocks, blk0 = the first of them;
+// ev_match, if given, is recorded between the two)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0) {
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0);
-                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0); }
-    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0);
-           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0); }
+    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match);
+                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match); }
+    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match);
+           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match); }
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups)

@@ -25,7 +25,7 @@
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0);
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match);
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
@@ -119,6 +119,7 @@ struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
+    std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
     uint32_t lz_split_blocks = 0;                   // blocks per run of the split LZ stage once an allocation of pbuf failed (0 = the default)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -221,6 +222,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     for (auto &e : c->ev_lz) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->lzm_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_ci) if (e) (void)hipEventDestroy(e);
     for (auto &r : c->ev_en) for (auto &e : r) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -517,7 +519,7 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
 // share it).  PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0: one kernel (k_lz<MODE 0>), no pbuf; PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form with
 // k_lz<MODE 2> as its parse half.  All forms give the same bytes.  If pbuf cannot be had, the run is halved down to 1 024 blocks, then fused.
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
-                    uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st) {
+                    uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
     // (read per call, not once: the tests switch them inside one process)
     const int env_split = [] { const char *e = getenv("PNA_LZ_SPLIT"); return e ? atoi(e) : 1; }();
     const uint32_t env_blocks = [] { const char *e = getenv("PNA_LZ_SPLIT_BLOCKS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 8 && v <= (1 << 17) ? v : 32768); }();
@@ -540,13 +542,18 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
             if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; c->lz_split_blocks = split_blocks; continue; }
             s0 = a; break;                                             // no room for the words: the rest goes through the fused kernel
         }
+        hipEvent_t e1 = nullptr;
+        if (timed) {
+            while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
+            HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
+        }
         launch_lz(d_src, (const SegDesc *)c->segs.p + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
-                  (uint32_t *)c->pbuf.p, b0);
+                  (uint32_t *)c->pbuf.p, b0, e1);
         a = b;
         if (a >= s1) return PNA_OK;
     }
-    launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0);
-    if (fused_tail) return lz_stage(c, d_src, segs, s1, s1_all, nblk, ctab, flags, max_off, max_len, st);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
+    launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr);
+    if (fused_tail) return lz_stage(c, d_src, segs, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
 
@@ -582,12 +589,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
     if (nblk) HIPCHK(c, hipMemcpyAsync(c->blk_seg.p, blk_seg.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(c->blk.p, 0, (size_t)(nblk + 1) * sizeof(BlkInfo), st));
+    c->lzm_used = 0;
     const bool defl = algo == PNA_ALGO_DEFLATE;
     if (defl) HIPCHK(c, hipMemcpyAsync(c->entry_seg.p, entry_first_seg.data(), entry_first_seg.size() * 4, hipMemcpyHostToDevice, st));
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
-        { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st); if (rc) return rc; }
+        { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
@@ -609,7 +617,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st); if (rc) return rc; }
+            { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));
@@ -899,6 +907,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         }
         c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
         c->timing.ms_pack += ms[4] + ms[5];
+        for (size_t i = 0; i + 1 < c->lzm_used; i += 2) { float m = 0; (void)hipEventElapsedTime(&m, c->lzm_ev[i], c->lzm_ev[i + 1]); c->timing.ms_lz_match += m; c->timing.lz_match_launches++; }
         c->timing.n_segments += nseg; c->timing.n_blocks += nblk;
     }
     return PNA_OK;
