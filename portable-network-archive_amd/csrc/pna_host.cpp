@@ -526,6 +526,16 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
     const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
     uint32_t split_blocks = c->lz_split_blocks ? c->lz_split_blocks : env_blocks;
+    if (s1 > s0) {
+        // several runs: of about equal size (whole rounds of 256 one-MiB segments) instead of full ones and a short tail -- a tail under the
+        // split form's threshold would fall back to the slower one-kernel form (5 000 segments: 2 560 + 2 440 instead of 4 096 + 904)
+        const uint32_t total = (s1 < segs.size() ? segs[s1].blk_base : nblk) - segs[s0].blk_base;
+        const uint32_t nruns = (total + split_blocks - 1) / split_blocks;
+        if (nruns > 1) {
+            const uint32_t round = 256 * BLK_PER_SEG, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
+            if (even < split_blocks) split_blocks = even;
+        }
+    }
     const uint32_t s1_all = s1; bool fused_tail = false;
     // A run of fewer than ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
     // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
