@@ -547,7 +547,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
         while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
         const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
         if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
-        if (c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) {
+        if (getenv("PNA_LZ_PBUF_FAIL") /* testing: as if the allocation failed */ || c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) {
             (void)hipGetLastError();                                   // (the failed allocation's sticky code)
             if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; c->lz_split_blocks = split_blocks; continue; }
             s0 = a; break;                                             // no room for the words: the rest goes through the fused kernel

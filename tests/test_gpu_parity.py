@@ -133,6 +133,20 @@ def test_lz_stage_split_runs(pna, codec, monkeypatch):
             assert zlib.decompress(o) == e
 
 
+def test_lz_stage_without_workspace_falls_back(pna, codec, monkeypatch):
+    """When the words workspace of the split LZ stage cannot be allocated the library halves the run and finally takes the one-kernel form
+    (PNA_LZ_PBUF_FAIL makes every allocation of it fail): same bytes, and the context remembers the smaller run size."""
+    import torch  # noqa: F401
+    monkeypatch.setenv("PNA_LZ_PBUF_FAIL", "1")
+    ents = [codec.corpus_file(0, 61, (2 << 20) + 5), codec.corpus_file(1, 62, 70000), b"", codec.corpus_file(0, 63, 1 << 20)]
+    with pna.Context(0) as ctx:
+        for _ in range(2):
+            outs = ctx.compress_batch(ents)
+            for e, o in zip(ents, outs):
+                assert o == codec.model_compress(e, _params(codec))
+            assert ctx.timing().lz_match_launches == 0          # nothing went through the match kernel
+
+
 @pytest.mark.parametrize("form", [0x1000, 0x2000])
 def test_both_sequence_coder_forms_are_identical(pna, codec, form):
     """The sequences bitstream has two implementations picked by batch size (k_seqa + k_seqb: short state chain, token-parallel packing;
