@@ -2051,35 +2051,88 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
     if (!c || (n && (!src || !src_len || !dst || !dst_cap || !dst_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented");
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<uint64_t> off(n + 1), len(n), doff(n + 1);
+    std::vector<uint64_t> off(n + 1), len(n), doff(n + 1), obase(n + 1);       // obase: running sum of the entries' bounds
     uint64_t pos = 0, bound = 0;
     for (size_t i = 0; i < n; i++) {
         if (dst_cap[i] < pna_gpu_bound(algo, src_len[i])) return fail(c, PNA_E_DSTSIZE, "dst_cap below pna_gpu_bound");
-        off[i] = pos; len[i] = src_len[i]; pos = (pos + src_len[i] + 15) & ~(uint64_t)15; bound += pna_gpu_bound(algo, src_len[i]);
+        off[i] = pos; len[i] = src_len[i]; pos = (pos + src_len[i] + 15) & ~(uint64_t)15;
+        obase[i] = bound; bound += pna_gpu_bound(algo, src_len[i]);
     }
-    off[n] = pos;
-    // inputs: staged into page-locked memory by several threads, one H2D copy; outputs: one D2H copy, scattered by several threads
-    // (per-entry copies from pageable memory ran at ~1 GiB/s)
-    if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(bound + 64) || c->hp_in[0].ensure(pos + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    off[n] = pos; obase[n] = bound;
+    // Inputs are staged into page-locked memory by several threads and copied H2D, outputs copied D2H and scattered by several threads
+    // (per-entry copies from pageable memory ran at ~1 GiB/s).  A large batch goes through in PIECES of >= 256 MiB (a round of the CUs:
+    // the kernels' fixed latencies stay amortised): piece k + 1 is staged and copied while piece k is on the device, piece k - 1's results
+    // travel back meanwhile -- 512 x 1 MiB: 27.5 -> see profiles/ (PNA_BATCH_PIECE_MIB; 0 = one piece).
+    const uint64_t piece_bytes = [] { const char *e = getenv("PNA_BATCH_PIECE_MIB"); const long v = e ? atol(e) : 256; return (uint64_t)(v <= 0 ? ~0ull >> 1 : (uint64_t)v << 20); }();
+    std::vector<size_t> pe{0};                                   // piece k = entries [pe[k], pe[k + 1])
+    for (size_t i = 0; i < n;) {
+        size_t j = i; uint64_t acc = 0;
+        while (j < n && (j == i || acc + src_len[j] <= piece_bytes)) acc += src_len[j++];
+        pe.push_back(j); i = j;
+    }
+    if (pe.size() > 2 && off[n] - off[pe[pe.size() - 2]] < piece_bytes / 2) pe.erase(pe.end() - 2);   // a short last piece joins its neighbour
+    const size_t K = pe.size() - 1;
+    uint64_t max_in = 0, max_out = 0;
+    std::vector<uint64_t> pbase(K + 1, 0);                       // where piece k's output starts in stage_out (256-byte aligned)
+    for (size_t k = 0; k < K; k++) {
+        max_in = std::max(max_in, off[pe[k + 1]] - off[pe[k]]); max_out = std::max(max_out, obase[pe[k + 1]] - obase[pe[k]]);
+        pbase[k + 1] = (pbase[k] + (obase[pe[k + 1]] - obase[pe[k]]) + 64 + 255) & ~(uint64_t)255;
+    }
+    if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(pbase[K] + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    for (int sl = 0; sl < (K > 1 ? 2 : 1); sl++) if (c->hp_in[sl].ensure(max_in + 64) || c->hp_out[sl].ensure(max_out + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    if (K > 1 && !c->cp_in) {
+        HIPCHK(c, hipStreamCreate(&c->cp_in)); HIPCHK(c, hipStreamCreate(&c->cp_out));
+        for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)); }
+    }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned threads = std::min(8u, std::max(1u, hw / 2));
-    parallel_stage((uint8_t *)c->hp_in[0].p, src, src_len, off.data(), 0, n, threads);
-    if (pos) HIPCHK(c, hipMemcpyAsync(c->stage_in.p, c->hp_in[0].p, pos, hipMemcpyHostToDevice, c->stream));
-    int rc = pna_gpu_compress_batch_device(c, algo, level, n, c->stage_in.p, off.data(), len.data(), c->stage_out.p, bound + 64, doff.data(), nullptr);
-    if (rc) return rc;
-    const uint64_t total = doff[n];
-    if (c->hp_out[0].ensure(total + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
-    if (total) HIPCHK(c, hipMemcpyAsync(c->hp_out[0].p, c->stage_out.p, total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < n; i++) dst_len[i] = (size_t)(doff[i + 1] - doff[i]);
-    {
-        const uint8_t *hb = (const uint8_t *)c->hp_out[0].p;
-        const unsigned T = total < (8u << 20) ? 1u : threads;
+    hipStream_t s_in = K > 1 ? c->cp_in : c->stream, s_out = K > 1 ? c->cp_out : c->stream;
+    auto stage = [&](size_t k) -> int {                          // entries of piece k -> pinned slot -> their place in stage_in
+        const int sl = (int)(k & 1);
+        const uint64_t b0 = off[pe[k]], nb = off[pe[k + 1]] - b0;
+        std::vector<uint64_t> rel(pe[k + 1] - pe[k] + 1);
+        for (size_t i = pe[k]; i <= pe[k + 1]; i++) rel[i - pe[k]] = off[i] - b0;
+        parallel_stage((uint8_t *)c->hp_in[sl].p, src + pe[k], src_len + pe[k], rel.data(), 0, pe[k + 1] - pe[k], threads);
+        if (nb) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->stage_in.p + b0, c->hp_in[sl].p, nb, hipMemcpyHostToDevice, s_in));
+        if (K > 1) HIPCHK(c, hipEventRecord(c->ev_in[sl], s_in));
+        return PNA_OK;
+    };
+    std::vector<uint64_t> ptotal(K);
+    auto scatter = [&](size_t k) -> int {                        // piece k's compressed entries: pinned slot -> the caller's buffers
+        const int sl = (int)(k & 1);
+        if (K > 1) HIPCHK(c, hipEventSynchronize(c->ev_out[sl])); else HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint8_t *hb = (const uint8_t *)c->hp_out[sl].p;
+        const size_t e0 = pe[k], e1 = pe[k + 1];
+        const unsigned T = ptotal[k] < (8u << 20) ? 1u : threads;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < T; t++)
-            th.emplace_back([=, &doff]() { for (size_t i = t; i < n; i += T) if (dst_len[i]) memcpy(dst[i], hb + doff[i], dst_len[i]); });
+            th.emplace_back([=, &doff]() { for (size_t i = e0 + t; i < e1; i += T) if (dst_len[i]) memcpy(dst[i], hb + (doff[i] - doff[e0]), dst_len[i]); });
         for (auto &x : th) x.join();
+        return PNA_OK;
+    };
+    pna_gpu_timing tsum{};
+    int rc = K ? stage(0) : PNA_OK;
+    if (rc) return rc;
+    doff[0] = 0;
+    for (size_t k = 0; k < K; k++) {
+        const int sl = (int)(k & 1);
+        if (k + 1 < K && (rc = stage(k + 1))) return rc;         // (its slot's previous copy, piece k - 1, was waited for by that piece's kernels)
+        if (K > 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[sl], 0));
+        const size_t e0 = pe[k], nk = pe[k + 1] - e0;
+        std::vector<uint64_t> d(nk + 1);
+        uint8_t *ob = (uint8_t *)c->stage_out.p + pbase[k];
+        rc = pna_gpu_compress_batch_device(c, algo, level, nk, c->stage_in.p, off.data() + e0, len.data() + e0, ob, obase[pe[k + 1]] - obase[e0] + 64, d.data(), nullptr);
+        if (rc) return rc;
+        { const pna_gpu_timing &t = c->timing; tsum.ms_lz += t.ms_lz; tsum.ms_stats += t.ms_stats; tsum.ms_lit += t.ms_lit; tsum.ms_seq += t.ms_seq; tsum.ms_pack += t.ms_pack;
+          tsum.in_bytes += t.in_bytes; tsum.out_bytes += t.out_bytes; tsum.n_segments += t.n_segments; tsum.n_blocks += t.n_blocks; tsum.ms_lz_match += t.ms_lz_match; tsum.lz_match_launches += t.lz_match_launches; }
+        for (size_t i = 0; i < nk; i++) { doff[e0 + i + 1] = doff[e0] + d[i + 1]; dst_len[e0 + i] = (size_t)(d[i + 1] - d[i]); }
+        ptotal[k] = d[nk];
+        if (ptotal[k]) HIPCHK(c, hipMemcpyAsync(c->hp_out[sl].p, ob, ptotal[k], hipMemcpyDeviceToHost, s_out));   // (the kernels are done: compress_batch_device returns synchronised)
+        if (K > 1) HIPCHK(c, hipEventRecord(c->ev_out[sl], s_out));
+        if (k >= 1 && (rc = scatter(k - 1))) return rc;
     }
+    if (K && (rc = scatter(K - 1))) return rc;
+    c->timing = tsum;
     return PNA_OK;
 }
 

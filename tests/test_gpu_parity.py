@@ -133,6 +133,25 @@ def test_lz_stage_split_runs(pna, codec, monkeypatch):
             assert zlib.decompress(o) == e
 
 
+def test_compress_batch_in_pieces(pna, codec, monkeypatch):
+    """pna_gpu_compress_batch takes a large batch through in pieces (>= 256 MiB each: staging + H2D of piece k + 1 and the D2H + scatter of
+    piece k - 1 next to piece k's kernels).  With 1 MiB pieces a handful of entries already makes several: every entry must come back in its
+    own buffer, equal to the model, whatever piece it was in (empty entries, entries larger than a piece, a short last piece)."""
+    import torch  # noqa: F401
+    monkeypatch.setenv("PNA_BATCH_PIECE_MIB", "1")
+    ents = [codec.corpus_file(0, 71, 600000), codec.corpus_file(1, 72, 500000), b"", codec.corpus_file(0, 73, (2 << 20) + 77), bytes(100), codec.corpus_file(2, 74, 900000),
+            codec.corpus_file(0, 75, 300000), codec.corpus_file(0, 76, 300001), codec.corpus_file(1, 77, 300002), b"x", codec.corpus_file(0, 78, 1 << 20), codec.corpus_file(0, 79, 5000)]
+    with pna.Context(0) as ctx:
+        outs = ctx.compress_batch(ents)
+        for e, o in zip(ents, outs):
+            assert o == codec.model_compress(e, _params(codec))
+        douts = ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
+        for e, o in zip(ents, douts):
+            assert zlib.decompress(o) == e
+        monkeypatch.setenv("PNA_BATCH_PIECE_MIB", "0")
+        assert ctx.compress_batch(ents) == outs and ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE) == douts
+
+
 def test_lz_stage_without_workspace_falls_back(pna, codec, monkeypatch):
     """When the words workspace of the split LZ stage cannot be allocated the library halves the run and finally takes the one-kernel form
     (PNA_LZ_PBUF_FAIL makes every allocation of it fail): same bytes, and the context remembers the smaller run size."""
