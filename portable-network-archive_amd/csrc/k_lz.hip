@@ -1,4 +1,6 @@
-// k_lz.hip -- LZ77 match finding + greedy parse for gfx950 (CDNA4), one 1024-thread workgroup per segment.
+// k_lz.hip -- LZ77 match finding + greedy parse for gfx950 (CDNA4), one 1024-thread workgroup per segment: the ONE-kernel form of the LZ stage
+// (short runs, PNA_F_LZ_FUSED, fallback without workspace) and, as MODE 1 / 2, its two halves as kernels.  The default for large batches is the
+// split form in k_lz_split.hip (k_lzm + k_lzp); shared pieces live in lz_common.h.
 //
 // Replaces the match finder inside the third-party encoder the reference drives at
 // lib/src/compress.rs:32-41 (CompressionWriter::write -> ZstdEncoder::write).  Integer/byte work, no MFMA.
@@ -27,8 +29,7 @@
 //   two positions late is moved back to its true start by BACKWARD ADOPTION: every match knows how many bytes (<= 3) before it
 //   also agree with its candidate, and two DPP rounds (lane + 1, then lane + 2) let a position take over its right
 //   neighbours' matches, one / two bytes longer.
-#include <hip/hip_runtime.h>
-#include "pna_dev.h"
+#include "lz_common.h"
 
 #ifdef LZ_EXP_ALLINS
 #define LZ_INS_COND true
@@ -38,108 +39,9 @@
 
 namespace pna {
 
-constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
-
-// LDS layout (byte offsets into the dynamic shared array)
-constexpr uint32_t L_WIN    = 0;
-constexpr uint32_t WIN_MIRROR = 48;                        // the window's first 48 bytes again behind its end: unaligned reads never wrap (k_lz reads 16 past a position, k_lzm 36 past a lane's first)
-constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
-constexpr uint32_t L_WEND   = L_TABLE + 4u * HASH_ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
-constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
-constexpr uint32_t L_TOTAL  = L_WPUB + 8 * LZ_WAVES;
-
-struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
-static_assert(sizeof(WPub) == 8, "LDS record size");
-static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
-
-constexpr uint32_t FLAG_SPLIT_WAVEPARSE = 0x1000u;   // split form: the parse half as k_lz<MODE = 2> (a wave per region) instead of k_lzp (testing)
-constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
-static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3 && MIN_MATCH > 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
-static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
-
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
-__device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
-__device__ __forceinline__ uint64_t mlow(uint32_t n) { return n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1); }   // bits [0, n)
-
-// DPP helpers (VALU only): value of lane i-k inside each row of 16 lanes (0 outside), and of lane i+1 of the wave
-#define DPP_ROW_SHR(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (k), 0xF, 0xF, true))
-__device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
-__device__ __forceinline__ uint32_t row_scan_add(uint32_t v) {          // inclusive prefix sum inside a row of 16 lanes
-    v += DPP_ROW_SHR(v, 1); v += DPP_ROW_SHR(v, 2); v += DPP_ROW_SHR(v, 4); v += DPP_ROW_SHR(v, 8); return v;
-}
-__device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
-    uint32_t t;
-    t = DPP_ROW_SHR(v, 1); v = v > t ? v : t; t = DPP_ROW_SHR(v, 2); v = v > t ? v : t;
-    t = DPP_ROW_SHR(v, 4); v = v > t ? v : t; t = DPP_ROW_SHR(v, 8); v = v > t ? v : t; return v;
-}
-
-// 8 / 4 bytes at an arbitrary segment position from the circular window
-__device__ __forceinline__ void fetch8(const uint32_t *win32, uint32_t pos, uint32_t &lo, uint32_t &hi) {
-    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);                    // p[1], p[2] may lie in the mirror
-    const uint32_t sh = (pos & 3) * 8;
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    lo = __builtin_amdgcn_alignbit(d1, d0, sh);
-    hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-}
-__device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) {
-    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);
-    return __builtin_amdgcn_alignbit(p[1], p[0], (pos & 3) * 8);
-}
-
-struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any byte address
-typedef uint32_t u32u __attribute__((aligned(1)));
-
-// Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
-// full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
-// segment in HBM / L2 (c + lim < q, so every address is inside the segment).
-template <bool FARC>
-__device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, const uint8_t *seg, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
-    uint32_t L = L0;
-    for (;;) {
-        uint32_t pos = L + lane * 4;
-        const uint32_t cw = FARC ? *(const u32u *)(seg + c + pos) : fetch4(win32, c + pos);
-        uint32_t x = fetch4(win32, q + pos) ^ cw;
-        uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
-        uint32_t room = lim > pos ? lim - pos : 0u;
-        nb = nb < room ? nb : room;
-        uint64_t bad = __ballot(nb < 4u);
-        if (bad) { uint32_t f = ctz64(bad); L += 4 * f + rdlane(nb, f); break; }
-        L += 256;
-    }
-    return L;
-}
-
-// the same with both sides read from the segment in memory (the parse half of the split form has no window)
-__device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t seg_len, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
-    uint32_t L = L0;
-    for (;;) {
-        const uint32_t pos = L + lane * 4;
-        uint32_t nb = 0;
-        const uint32_t room = lim > pos ? lim - pos : 0u;
-        if (room) {                                                                 // q + pos < q + lim <= the block's end: inside the segment
-            if (q + pos + 4 <= seg_len) {
-                const uint32_t x = *(const u32u *)(seg + q + pos) ^ *(const u32u *)(seg + c + pos);
-                nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
-            } else {
-                while (nb < room && seg[q + pos + nb] == seg[c + pos + nb]) nb++;
-            }
-            nb = nb < room ? nb : room;
-        }
-        const uint64_t bad = __ballot(nb < 4u);
-        if (bad) { const uint32_t f = ctz64(bad); L += 4 * f + rdlane(nb, f); break; }
-        L += 256;
-    }
-    return L;
-}
-
-__device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint32_t seg_len) {
-    if (i + 16 <= seg_len) return *(const uint4 *)(seg + i);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < 16; k++) if (i + k < seg_len) w[k >> 2] |= (uint32_t)seg[i + k] << (8 * (k & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
+void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
+                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match);   // k_lz_split.hip
+void lzp_read_stamps(unsigned long long *out);
 
 // diagnostic build only (STAMP = true): lane 0 of every wave accumulates s_memtime deltas per phase (sums over the 16 waves)
 __device__ unsigned long long g_lz_stamps[8];
@@ -659,551 +561,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_lzm -- the match half of the split form: look-up, match, backward adoption and the tile's inserts, as in k_lz<MODE 1>, but with
-// FOUR CONSECUTIVE POSITIONS PER LANE (lane i of wave w: positions t0 + 256 w + 4 i + j, j = 0..3) instead of one position per lane and
-// group.  Nothing in this half needs a ballot over a group's positions, and with consecutive positions
-//   * the 36 + 4 bytes around a lane's positions are ten aligned dwords, loaded once; the 8 / 16 / 32 bytes at position j are
-//     v_alignbyte with a constant (j = 0: the registers themselves) -- k_lz loads and aligns them per position;
-//   * the right neighbours of the adoption rounds sit in the same lane, except across the lane border (DPP row_shl: a row of
-//     16 lanes is a group of 64 positions, and the zero fill at the row's end is the rule "adoption stops at the group border");
-//     the offset moves along with every adoption instead of one ds_bpermute at the end;
-//   * the four words of a lane go out as one 16-byte store; with even positions only, the inserts are those of j = 0 and 2.
-// Same table, window, tile order and barriers as k_lz, hence the same words (tests/test_gpu_parity.py: forms of the LZ stage).
-#define DPP_ROW_SHL1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xF, 0xF, true))   // value of lane i + 1 inside the row of 16 (0 at its end)
-template <bool DEFL, bool STRONG>
-__global__ __launch_bounds__(LZ_THREADS)
-void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0) {
-    constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
-    constexpr bool FAR = !DEFL;                             // deflate offsets (<= 32 KiB) never leave the LDS window
-    constexpr uint32_t NEAR = NEAR_OFF;
-    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint32_t *win32 = (uint32_t *)(lds + L_WIN);
-    uint32_t *table = (uint32_t *)(lds + L_TABLE);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = uni(tid >> 6);
-    const SegDesc sd = segs[blockIdx.x];
-    const uint8_t *seg = src + sd.src_off;
-    const uint32_t seg_len = sd.len;
-    uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
-    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
-
-    for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
-    uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
-    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
-        const uint4 v = load_chunk(seg, i, seg_len);
-        *(uint4 *)(lds + L_WIN + i) = v;
-        if (i < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + i) = v;
-    }
-    __syncthreads();
-    uint4 pf = make_uint4(0, 0, 0, 0);
-
-    const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
-    for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t blk_start = b * BLK_SIZE;
-        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
-        for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
-            const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
-            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
-            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
-            const uint32_t q0 = t0 + wave * RW + 4 * lane;
-            // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
-            uint32_t D[9], Dm1, Dm2 = 0;
-            {
-                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..8] may lie in the mirror
-#pragma unroll
-                for (int k = 0; k < 9; k++) D[k] = pq[k];
-                Dm1 = win32[((q0 - 4) & (WIN_BYTES - 1)) >> 2];
-                if (STRONG) Dm2 = win32[((q0 - 8) & (WIN_BYTES - 1)) >> 2];
-            }
-#define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
-            // ---- look-up
-            uint32_t hsh[4], tag[4], ent[4];
-            bool hv[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t q = q0 + j;
-                hv[j] = tile_full || ((q < t1) && (q + 8 <= seg_len));
-                const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
-                hsh[j] = __umulhi(h32, HASH_ENTRIES);
-                tag[j] = (h32 >> 6) & TAG_MASK;
-                ent[j] = hv[j] ? table[hsh[j]] : 0u;
-            }
-            // ---- candidates (rules as in k_lz); far ones get their bytes requested from the segment now
-            uint32_t off[4];
-            U4u fa[4]; uint32_t fb[4], fc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                fa[j].x = fa[j].y = fa[j].z = fa[j].w = fb[j] = fc[j] = 0;
-                const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
-                off[j] = (c1 > 8 && (ent[j] & TAG_MASK) == tag[j] && o <= max_off) ? o : 0u;
-                if (FAR && seg_len > NEAR && max_off > NEAR) {
-                    const uint32_t fo = off[j] > NEAR ? c1 - 5 : 0u;
-                    fa[j] = *(const U4u *)(seg + fo);
-                    fb[j] = *(const u32u *)(seg + fo + 16);
-                    if (STRONG) fc[j] = *(const u32u *)(seg + (off[j] > NEAR ? fo - 4 : 0u));
-                }
-            }
-            // ---- match
-            uint32_t K[4];
-            const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t l = 0, bk = 0;
-                const uint32_t o = off[j], q = q0 + j;
-                if (o != 0) {
-                    const uint32_t c = q - o;
-                    const bool isfar = FAR && o > NEAR;
-                    const uint32_t shc = (c & 3) * 8;
-                    uint32_t w0, w1, w2, w3, bc, bc2 = 0;
-                    if (isfar) { bc = fa[j].x; w0 = fa[j].y; w1 = fa[j].z; w2 = fa[j].w; w3 = fb[j]; bc2 = fc[j]; }
-                    else {
-                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
-                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
-                        w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
-                        w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
-                        bc = __builtin_amdgcn_alignbit(d0, dm, shc);
-                        if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
-                    }
-                    const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
-                    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
-                    l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
-                    if (l == 16) {
-                        uint32_t v0, v1, v2, v3;
-                        if (isfar) { const U4u t = *(const U4u *)(seg + c + 16); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
-                        else {
-                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                            v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
-                            v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
-                        }
-                        const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
-                        const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-                        l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
-                    }
-                    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-                    if (l < MIN_MATCH) l = 0;
-                    const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
-                    const uint32_t xk = bqj ^ bc;
-                    bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
-                    if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
-                }
-                K[j] = (l << 6) | (bk << 3);
-                if (STRONG && !l) K[j] = 0;
-            }
-            // ---- backward adoption: K = len << 6 | back << 3 | positions moved; the offset goes along
-            if (adopt) {
-                {   // round 1: the right neighbour's match, one byte longer
-                    const uint32_t Kn = DPP_ROW_SHL1(K[0]), on = DPP_ROW_SHL1(off[0]);
-                    uint32_t K1[4] = {K[1], K[2], K[3], Kn}, o1[4] = {off[1], off[2], off[3], on};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K1[j] + 57u;
-                        const bool a = (K1[j] & 0x38u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o1[j] : off[j];
-                    }
-                }
-                {   // round 2: the match two positions to the right (after round 1), two bytes longer
-                    const uint32_t Ka = DPP_ROW_SHL1(K[0]), Kb = DPP_ROW_SHL1(K[1]), oa = DPP_ROW_SHL1(off[0]), ob = DPP_ROW_SHL1(off[1]);
-                    uint32_t K2[4] = {K[2], K[3], Ka, Kb}, o2[4] = {off[2], off[3], oa, ob};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K2[j] + 114u;
-                        const bool a = (K2[j] & 0x30u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o2[j] : off[j];
-                    }
-                }
-                if (STRONG) {   // round 3: four positions to the right = the same position of the next lane, four bytes longer
-                    uint32_t K4[4], o4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { K4[j] = DPP_ROW_SHL1(K[j]); o4[j] = DPP_ROW_SHL1(off[j]); }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K4[j] + 228u;
-                        const bool a = (K4[j] & 0x20u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o4[j] : off[j];
-                    }
-                }
-            }
-            if (q0 < t1) *(uint4 *)(pb + q0) = make_uint4((K[0] >> 6) | (off[0] << 6), (K[1] >> 6) | (off[1] << 6), (K[2] >> 6) | (off[2] << 6), (K[3] >> 6) | (off[3] << 6));
-#undef QW
-            if (tid < TILE_G / 16) {
-                const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
-                *(uint4 *)(lds + L_WIN + wo) = pf;
-                if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
-            }
-            loaded_end += TILE_G;
-            __syncthreads();                                                        // every wave has looked up
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
-            __syncthreads();                                                        // inserts + window chunk in place
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
-// ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes do here with vector arithmetic for the
-// sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 8.4 KiB of LDS) per segment; per tile of 4 096 positions:
-//   1. the tile's words (k_lz<MODE 1>'s output), 4 consecutive positions per lane and 16-byte load -> their lengths, a byte each, to
-//      LDS; then one lane per GROUP of 64 positions: start / cap masks of the group
-//      from its 64 length bytes, four at a time inside a register (byte-wise compares by carry-free subtraction, the four
-//      results gathered into a nibble by one multiplication)
-//   2. lanes 0..15: greedy walk over the region's eight half-groups on 32-bit masks (length of a chosen start from LDS; a capped
-//      match is extended by the whole wave, the lengths are kept in LDS), merge across the regions = across the lanes (serial
-//      form of the scan, DPP row scans for the counts), selection / literal masks, one record per group to LDS
-//   3. one lane per group again: the group's sequences (offsets from the words in memory, four requested at a time)
-//   4. the literals, 4 consecutive positions per lane (their input bytes were requested from memory before step 3): the lane's literal bytes are packed by v_perm (selector from a 16-entry
-//      table) and stored behind the literals of the positions before it.
-// Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
-constexpr uint32_t LZP_THREADS = 64;
-template <bool CT, bool STRONG>
-__global__ __launch_bounds__(LZP_THREADS)
-void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
-           BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
-    constexpr uint32_t RW = 256, TG = 4096;
-    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && BLK_SIZE % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
-    __shared__ uint32_t l32[TG / 4];                        // the tile's match lengths, one byte per position
-    __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
-    __shared__ uint32_t plut[16];                           // v_perm selectors that pack the bytes named by a nibble
-    __shared__ uint4 rec[3][TG / 64];                       // per group: [0] literal mask, first literal index, first sequence index; [1] chosen starts, the capped ones among all chosen;
-                                                            // [2] literal-run base of its first sequence, xlen base, cut position | length << 8, cut offset
-    __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
-    const uint32_t lane = threadIdx.x, w = lane & 15;
-    const uint8_t *len8 = (const uint8_t *)l32;
-    const SegDesc sd = segs[blockIdx.x];
-    const uint32_t seg_len = sd.len;
-    const uint8_t *seg = src + sd.src_off;
-    const uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
-    const uint32_t lazy = flags & F_LAZY;
-    const uint32_t wbase = w * RW;
-    const uint32_t ntile = (seg_len + TG - 1) / TG;
-    const bool lv = lane < 16;
-    if (lv) {                                               // selector of nibble n: the bytes whose bits are set, lowest first
-        uint32_t sel = 0, j = 0;
-        for (uint32_t bit = 0; bit < 4; bit++) if ((lane >> bit) & 1) { sel |= bit << (8 * j); j++; }
-        plut[lane] = sel;
-    }
-    // literals: bits of the group's literal mask below this lane's four positions (lane i of a region: group i / 16, bits 4 (i % 16) ..)
-    const uint64_t lit_below = ((uint64_t)1 << (4 * (lane & 15))) - 1;
-    uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (uniform)
-
-#ifdef LZP_PROF   // diagnostic build (scripts/lzp_stamps.py): s_memtime deltas per phase, summed over all waves
-    unsigned long long pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
-#define LZP_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pa[k] += t_ - pt0; pt0 = t_; } while (0)
-#else
-#define LZP_STAMP(k) do { } while (0)
-#endif
-    for (uint32_t T = 0; T < ntile; T++) {
-        const uint32_t t0 = T * TG, blk_start = t0 & ~(BLK_SIZE - 1);
-        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
-        const uint32_t t1 = (blk_end - t0 < TG) ? blk_end : t0 + TG;
-        const uint32_t npos = t1 - t0;
-        const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
-        const uint32_t gblk = sd.blk_base + (t0 >> PNA_BLK_LOG);
-        const uint32_t ng = (npos + 63) >> 6;                                           // groups with positions in them
-        // ---- 1. lengths to LDS (positions behind the block's end count as "no match"; the words of a whole tile lie inside the segment's
-        // share of pbuf, whole blocks, so the loads need no bounds of their own)
-        {
-            const uint4 *pt = (const uint4 *)(pb + t0);
-            for (uint32_t wq = 0; wq < 4 && wq * 1024 < npos; wq++) {                   // four regions at a time: their loads go out together
-                uint4 v[4];
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) v[i] = pt[(wq * 4 + i) * 64 + lane];
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) {
-                    const uint32_t p = (wq * 4 + i) * RW + lane * 4;
-                    uint32_t d = (v[i].x & 63u) | ((v[i].y & 63u) << 8) | ((v[i].z & 63u) << 16) | ((v[i].w & 63u) << 24);
-                    if (npos < TG && p + 4 > npos) d = p >= npos ? 0u : d & (0xFFFFFFFFu >> (8 * (p + 4 - npos)));
-                    l32[p >> 2] = d;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // masks of group `lane` from its 64 length bytes.  Per register of 4 lengths l (all < 64): x = l | 0x80 per byte; x - 6 keeps the top bit iff
-        // l >= 6; x - l' (l' = the next position's length, 0 behind the group) keeps it iff l' <= l, i.e. the position does not defer; no byte
-        // borrows from its neighbour.  The four top bits become a nibble by (y >> 7) * 0x00204081 >> 21.
-        if (lane < ng) {
-            uint32_t d[17];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; i++) { const uint4 t = ((const uint4 *)l32)[lane * 4 + i]; d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w; }
-            d[16] = 0;
-            uint32_t em2[2] = {0, 0}, cm2[2] = {0, 0};
-#pragma unroll
-            for (uint32_t i = 0; i < 16; i++) {
-                const uint32_t x = d[i] | 0x80808080u;
-                uint32_t e = x - 0x06060606u;
-                if (lazy) {
-                    e &= x - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 1);
-                    if (STRONG) e &= x + 0x01010101u - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2);   // ... nor to the position after the next (longer by two or more)
-                }
-                const uint32_t en = ((((e >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
-                const uint32_t cn = ((((d[i] >> 5) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
-                em2[i >> 3] |= en << (4 * (i & 7)); cm2[i >> 3] |= cn << (4 * (i & 7));
-            }
-            lmask[lane] = make_uint4(em2[0], em2[1], cm2[0], cm2[1]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        LZP_STAMP(0);
-        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
-        // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it; half-groups of 32 positions: one-register masks
-        const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
-        uint64_t sel[4], cov[4], cm[4];
-        uint32_t el = 0, nx = 0;
-        uint32_t em_lo[4], em_hi[4], cm_lo[4], cm_hi[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            uint4 m = make_uint4(0, 0, 0, 0);
-            if (lv && w * 4 + r < ng) m = lmask[w * 4 + r];
-            em_lo[r] = m.x; em_hi[r] = m.y; cm_lo[r] = m.z; cm_hi[r] = m.w;
-        }
-        {
-            uint32_t cur = c_in > wbase ? (c_in - wbase < RW ? c_in - wbase : RW) : 0u;
-            uint32_t s32[8], c32[8];
-#pragma unroll
-            for (int hb = 0; hb < 8; hb++) {
-                const uint32_t em32 = (hb & 1) ? em_hi[hb >> 1] : em_lo[hb >> 1], cm32 = (hb & 1) ? cm_hi[hb >> 1] : cm_lo[hb >> 1];
-                const uint32_t e0 = cur > 32u * hb ? cur - 32u * hb : 0u;
-                uint32_t rem = e0 < 32 ? em32 & (0xFFFFFFFFu << e0) : 0u;
-                uint32_t e_last = e0, selr = 0, covr = e0 < 32 ? (1u << e0) - 1 : 0xFFFFFFFFu;
-                while (__ballot(rem != 0)) {
-                    const bool a = rem != 0;
-                    const uint32_t s = a ? (uint32_t)__builtin_ctz(rem) : 0u;
-                    const uint32_t ps = wbase + 32u * hb + s;                       // tile-relative
-                    uint32_t L = a ? len8[ps] : 0u;
-                    const bool cap = a && ((cm32 >> s) & 1);
-                    uint64_t need = __ballot(cap);
-                    if (need) {
-                        const uint32_t qs = t0 + ps;
-                        const uint32_t pwv = cap ? pb[qs] : 0u;                      // (its offset)
-                        const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
-                        while (need) {
-                            const uint32_t k = ctz64(need); need &= need - 1;
-                            const uint32_t qk = rdlane(qs, k), ok = rdlane(pwv >> 6, k);
-                            const uint32_t Lk = lz_extend_mem(seg, seg_len, qk, qk - ok, rdlane(L, k), rdlane(xl, k), lane);
-                            if (lane == k) L = Lk;
-                        }
-                        if (cap) { xlen[w * 8 + (nx & 7)] = (uint16_t)L; nx++; }
-                    }
-                    if (a) {
-                        const uint32_t e = s + L;
-                        const uint32_t me = e < 32 ? (1u << e) - 1 : 0xFFFFFFFFu;   // positions below the match's end
-                        selr |= 1u << s; e_last = e;
-                        covr |= me & ~((1u << s) - 1);
-                        rem &= ~me;
-                    }
-                }
-                s32[hb] = selr; c32[hb] = covr;
-                if (selr) el = 32u * hb + e_last;
-                cur = 32u * hb + (e_last > 32 ? e_last : 32u);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                sel[r] = (uint64_t)s32[2 * r] | ((uint64_t)s32[2 * r + 1] << 32); cov[r] = (uint64_t)c32[2 * r] | ((uint64_t)c32[2 * r + 1] << 32);
-                cm[r] = (uint64_t)cm_lo[r] | ((uint64_t)cm_hi[r] << 32);
-            }
-        }
-        LZP_STAMP(1);
-        uint32_t pc[4];                                     // capped chosen starts in the groups before r = index base into xlen
-        pc[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 3; r++) pc[r + 1] = pc[r] + (uint32_t)__popcll(sel[r] & cm[r]);
-
-        // ---- merge across the lanes: the serial form of the scan (k_lz takes it only when an end falls 1-2 bytes behind E; it is the definition)
-        uint32_t E = c_in, tile_exit;
-        {
-            const uint32_t wend = el ? wbase + el : 0u;
-            uint32_t x = c_in;
-#pragma unroll
-            for (uint32_t k = 0; k < 16; k++) {
-                const uint32_t ek = rdlane(wend, k);
-                if (w == k) E = x;
-                if (x < k * RW + RW && ek >= x + 3) x = ek;
-            }
-            tile_exit = x;
-        }
-        uint64_t fsel[4], litm[4];
-        uint32_t nselp[5], nlitp[5];
-        uint32_t cut_r = 4, cut_b = 0, cut_len = 0, cut_off = 0;   // the match cut from the front at E, if any
-        {
-            const uint32_t Ew = E > wbase ? (E - wbase < RW ? E - wbase : RW) : 0u;
-            const uint32_t in0 = t1 > t0 + wbase ? t1 - (t0 + wbase) : 0u;
-            uint64_t K[4], cv[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t e = Ew > 64u * r ? Ew - 64u * r : 0u;
-                K[r] = mlow(e < 64 ? e : 64u); fsel[r] = sel[r] & ~K[r]; cv[r] = cov[r];
-            }
-            if (lv && Ew > 0 && Ew < RW) {
-                const uint32_t grp = Ew >> 6, b = Ew & 63;
-                uint64_t cg = cov[0], sg = sel[0];
-#pragma unroll
-                for (int r = 1; r < 4; r++) if (grp == (uint32_t)r) { cg = cov[r]; sg = sel[r]; }
-                if (((cg >> b) & 1) && !((sg >> b) & 1)) {
-                    uint64_t below = sg & mlow(b);
-                    uint32_t g2 = grp;
-#pragma unroll
-                    for (int r = 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
-                    const uint32_t s2 = 63 - clz64(below);
-                    const uint32_t pw2 = pb[t0 + wbase + 64 * g2 + s2];
-                    uint64_t sc2 = sel[0] & cm[0]; uint32_t pc2 = pc[0];
-#pragma unroll
-                    for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
-                    const uint32_t l2 = ((sc2 >> s2) & 1) ? xlen[w * 8 + ((pc2 + (uint32_t)__popcll(sc2 & mlow(s2))) & 7)] : (pw2 & 63u);
-                    const uint32_t end2 = 64 * g2 + s2 + l2, rmn = end2 - Ew;
-                    if (rmn >= 3) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
-                        cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
-                            const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
-                            cv[r] &= ~(mlow(z0) & ~mlow(a0));
-                        }
-                    }
-                }
-            }
-            nselp[0] = 0; nlitp[0] = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t ir = in0 > 64u * r ? in0 - 64u * r : 0u;
-                litm[r] = lv ? mlow(ir < 64 ? ir : 64u) & ~(cv[r] | K[r]) : 0;
-                if (!lv) fsel[r] = 0;
-                nselp[r + 1] = nselp[r] + (uint32_t)__popcll(fsel[r]);
-                nlitp[r + 1] = nlitp[r] + (uint32_t)__popcll(litm[r]);
-            }
-        }
-        uint32_t gl = 0, gf = 0;                            // 1 + the region's literal index at its last / first match, 0 = it has none
-#pragma unroll
-        for (int r = 3; r >= 0; r--) if (!gl && fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); gl = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
-        if (CT) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) if (!gf && fsel[r]) { const uint32_t sp = ctz64(fsel[r]); gf = 1 + nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); }
-        }
-        {
-            const uint32_t cnt = nselp[4] | (nlitp[4] << 16);
-            const uint32_t incl = row_scan_add(cnt), excl = incl - cnt;
-            const uint32_t gabs = gl ? lit_run + (excl >> 16) + gl : 0u;
-            const uint32_t gmax = row_scan_max(gabs);
-            const uint32_t tot = rdlane(incl, 15);
-            const uint32_t seq_base = seq_run + (excl & 0xFFFF), lit_base = lit_run + (excl >> 16);
-            const uint32_t gb = DPP_ROW_SHR(gmax, 1);
-            const uint32_t glast1_before = gb > g_last1 ? gb : g_last1;
-            const uint32_t ga = rdlane(gmax, 15);
-            if (CT) {
-                constexpr uint32_t CH = TG / TILE, WPC = 16 / CH;
-                const uint32_t hrow = (uint32_t)__ballot(gl != 0) & 0xFFFFu;
-#pragma unroll
-                for (uint32_t h = 0; h < CH; h++) {
-                    const uint32_t ex_h = rdlane(excl, h * WPC);
-                    const uint32_t hm_h = hrow & (((1u << WPC) - 1) << (h * WPC));
-                    uint32_t g_first = lit_run + (tot >> 16);
-                    if (hm_h) { const uint32_t j0 = (uint32_t)__builtin_ctz(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + rdlane(gf, j0) - 1; }
-                    if (lane == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
-                }
-            }
-            g_last1 = ga > g_last1 ? ga : g_last1;
-            seq_run += tot & 0xFFFF; lit_run += tot >> 16;
-            next_free = t0 + rdlane(tile_exit, 0);
-            // one record per group for the lanes that write its sequences and literals
-            if (lv) {
-                uint32_t prevl = 0; bool any = false;       // literal index (region-local) at the region's latest chosen start so far
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t llbase = any ? nlitp[r] - prevl : lit_base + nlitp[r] - (glast1_before - 1);
-                    if (fsel[r]) { const uint32_t sp = 63 - clz64(fsel[r]); prevl = nlitp[r] + (uint32_t)__popcll(litm[r] & mlow(sp)); any = true; }
-                    const uint64_t sc = sel[r] & cm[r];
-                    const uint32_t cutw = cut_r == (uint32_t)r ? cut_b | (cut_len << 8) : 64u;
-                    rec[0][w * 4 + r] = make_uint4((uint32_t)litm[r], (uint32_t)(litm[r] >> 32), lit_base + nlitp[r], seq_base + nselp[r]);
-                    rec[1][w * 4 + r] = make_uint4((uint32_t)fsel[r], (uint32_t)(fsel[r] >> 32), (uint32_t)sc, (uint32_t)(sc >> 32));
-                    rec[2][w * 4 + r] = make_uint4(llbase, w * 8 + pc[r], cutw, cut_off);
-                }
-            }
-            if (t1 == blk_end && lane == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        LZP_STAMP(2);
-        // the input bytes of the lane's four positions in every region, for the literals: requested now, used behind the sequences
-        uint32_t lw[16];
-#pragma unroll
-        for (uint32_t wr = 0; wr < 16; wr++) {
-            const uint32_t q = t0 + wr * RW + 4 * lane;
-            lw[wr] = 0;
-            if (q + 4 <= seg_len) lw[wr] = *(const uint32_t *)(seg + q);                 // (segments start at multiples of 16)
-            else { for (uint32_t i = 0; i < 3; i++) if (q + i < seg_len) lw[wr] |= (uint32_t)seg[q + i] << (8 * i); }
-        }
-        // ---- 3. the sequences, one lane per group
-        {
-            uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
-            const uint4 ra = rec[0][lane], rb = rec[1][lane], rc = rec[2][lane];
-            const uint64_t lm = (uint64_t)ra.x | ((uint64_t)ra.y << 32), sc = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
-            uint64_t rem = lane < ng ? (uint64_t)rb.x | ((uint64_t)rb.y << 32) : 0;
-            uint32_t idx = ra.w, prev = 0;
-            const uint32_t cut_b2 = rc.z & 0xFFu, cut_l2 = rc.z >> 8;
-            bool first = true;
-            const uint32_t *pg = pb + t0 + lane * 64;
-            while (rem) {
-                // four starts at a time: their words (the offsets) are requested together
-                uint32_t sq[4], pw[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    sq[u] = rem ? ctz64(rem) : 64u;
-                    pw[u] = rem ? pg[sq[u]] : 0u;
-                    rem &= rem - 1;                                                 // (0 stays 0)
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t s = sq[u];
-                    if (s < 64) {
-                        uint32_t ml = pw[u] & 63u, of = pw[u] >> 6;
-                        if ((sc >> s) & 1) ml = xlen[(rc.y + (uint32_t)__popcll(sc & mlow(s))) & 127];
-                        if (cut_b2 == s) { ml = cut_l2; of = rc.w; }
-                        const uint32_t lq = (uint32_t)__popcll(lm & mlow(s));
-                        const uint32_t ll = first ? rc.x + lq : lq - prev;
-                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, ml, of);
-                        idx++; prev = lq; first = false;
-                    }
-                }
-            }
-        }
-        LZP_STAMP(3);
-        // ---- 4. literals, region by region, 4 consecutive positions per lane
-        {
-            uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
-            const uint32_t sh = 4 * (lane & 15);
-#pragma unroll
-            for (uint32_t wr = 0; wr < 16; wr++) {
-                if (wr * RW >= npos) continue;                                      // (uniform)
-                const uint4 m = rec[0][wr * 4 + (lane >> 4)];
-                const uint32_t wd = lw[wr];
-                const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
-                const uint32_t nib = (uint32_t)(lm >> sh) & 15u;
-                const uint32_t pk = __builtin_amdgcn_perm(wd, wd, plut[nib]), cnt = (uint32_t)__popc(nib);
-                uint8_t *o = blit + m.z + (uint32_t)__popcll(lm & lit_below);
-                if (cnt > 0) o[0] = (uint8_t)pk;
-                if (cnt > 1) o[1] = (uint8_t)(pk >> 8);
-                if (cnt > 2) o[2] = (uint8_t)(pk >> 16);
-                if (cnt > 3) o[3] = (uint8_t)(pk >> 24);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        LZP_STAMP(4);
-    }
-#ifdef LZP_PROF
-    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], pa[k]);
-#endif
-}
-
 template <int G, bool CT, bool STRONG>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        (void)hipFuncSetAttribute((const void *)k_lzm<CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
         return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
     }();
     (void)attr_set;
@@ -1214,9 +577,7 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
             hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             return;
         }
-        hipLaunchKernelGGL((k_lzm<CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0);
-        if (ev_match) (void)hipEventRecord(ev_match, st);
-        hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+        launch_lz_split(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match);   // k_lzm + k_lzp (k_lz_split.hip)
     }
     else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
     else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
@@ -1233,8 +594,11 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
            else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match); }
 }
 
-// diagnostic: read and clear the phase stamps (cycles summed over workgroups)
+// diagnostic: read and clear the phase stamps (cycles summed over workgroups); a -DLZP_PROF build hands out k_lzp's instead
 void lz_read_stamps(unsigned long long *out) {
+#ifdef LZP_PROF
+    lzp_read_stamps(out); return;
+#endif
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz_stamps), sizeof(unsigned long long) * 8);
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz_stamps), z, sizeof(z));

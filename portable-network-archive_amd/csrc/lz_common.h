@@ -1,0 +1,113 @@
+// lz_common.h -- what the kernels of the LZ stage share: LDS layout of the match finder (window + hash table), flags, cross-lane helpers,
+// the wave-cooperative match extension.  k_lz.hip: the one-kernel form and its two halves as kernels; k_lz_split.hip: k_lzm + k_lzp, the
+// default split form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pna_dev.h"
+
+namespace pna {
+
+constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
+
+// LDS layout (byte offsets into the dynamic shared array)
+constexpr uint32_t L_WIN    = 0;
+constexpr uint32_t WIN_MIRROR = 48;                        // the window's first 48 bytes again behind its end: unaligned reads never wrap (k_lz reads 16 past a position, k_lzm 36 past a lane's first)
+constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
+constexpr uint32_t L_WEND   = L_TABLE + 4u * HASH_ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
+constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
+constexpr uint32_t L_TOTAL  = L_WPUB + 8 * LZ_WAVES;
+
+struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
+static_assert(sizeof(WPub) == 8, "LDS record size");
+static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
+
+constexpr uint32_t FLAG_SPLIT_WAVEPARSE = 0x1000u;   // split form: the parse half as k_lz<MODE = 2> (a wave per region) instead of k_lzp (testing)
+constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
+static_assert(CAP1 >= 16 && CAP1 % 16 == 0 && CAP1 <= 32 && BACK_CAP == 3 && MIN_MATCH > 3, "the match step compares 16 bytes at a time, the next 16 only where all before matched");
+static_assert(GROUPS_PER_WAVE == 2 && TILE == 2048, "TILE / GROUPS_PER_WAVE describe the G = 2 (deflate) form; k_lz itself is generic in G");
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+__device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
+__device__ __forceinline__ uint64_t mlow(uint32_t n) { return n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1); }   // bits [0, n)
+
+// DPP helpers (VALU only): value of lane i-k inside each row of 16 lanes (0 outside), and of lane i+1 of the wave
+#define DPP_ROW_SHR(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (k), 0xF, 0xF, true))
+__device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t row_scan_add(uint32_t v) {          // inclusive prefix sum inside a row of 16 lanes
+    v += DPP_ROW_SHR(v, 1); v += DPP_ROW_SHR(v, 2); v += DPP_ROW_SHR(v, 4); v += DPP_ROW_SHR(v, 8); return v;
+}
+__device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
+    uint32_t t;
+    t = DPP_ROW_SHR(v, 1); v = v > t ? v : t; t = DPP_ROW_SHR(v, 2); v = v > t ? v : t;
+    t = DPP_ROW_SHR(v, 4); v = v > t ? v : t; t = DPP_ROW_SHR(v, 8); v = v > t ? v : t; return v;
+}
+
+// 8 / 4 bytes at an arbitrary segment position from the circular window
+__device__ __forceinline__ void fetch8(const uint32_t *win32, uint32_t pos, uint32_t &lo, uint32_t &hi) {
+    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);                    // p[1], p[2] may lie in the mirror
+    const uint32_t sh = (pos & 3) * 8;
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+}
+__device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) {
+    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);
+    return __builtin_amdgcn_alignbit(p[1], p[0], (pos & 3) * 8);
+}
+
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any byte address
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+// Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
+// full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
+// segment in HBM / L2 (c + lim < q, so every address is inside the segment).
+template <bool FARC>
+__device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, const uint8_t *seg, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
+    uint32_t L = L0;
+    for (;;) {
+        uint32_t pos = L + lane * 4;
+        const uint32_t cw = FARC ? *(const u32u *)(seg + c + pos) : fetch4(win32, c + pos);
+        uint32_t x = fetch4(win32, q + pos) ^ cw;
+        uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+        uint32_t room = lim > pos ? lim - pos : 0u;
+        nb = nb < room ? nb : room;
+        uint64_t bad = __ballot(nb < 4u);
+        if (bad) { uint32_t f = ctz64(bad); L += 4 * f + rdlane(nb, f); break; }
+        L += 256;
+    }
+    return L;
+}
+
+// the same with both sides read from the segment in memory (the parse half of the split form has no window)
+__device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t seg_len, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
+    uint32_t L = L0;
+    for (;;) {
+        const uint32_t pos = L + lane * 4;
+        uint32_t nb = 0;
+        const uint32_t room = lim > pos ? lim - pos : 0u;
+        if (room) {                                                                 // q + pos < q + lim <= the block's end: inside the segment
+            if (q + pos + 4 <= seg_len) {
+                const uint32_t x = *(const u32u *)(seg + q + pos) ^ *(const u32u *)(seg + c + pos);
+                nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+            } else {
+                while (nb < room && seg[q + pos + nb] == seg[c + pos + nb]) nb++;
+            }
+            nb = nb < room ? nb : room;
+        }
+        const uint64_t bad = __ballot(nb < 4u);
+        if (bad) { const uint32_t f = ctz64(bad); L += 4 * f + rdlane(nb, f); break; }
+        L += 256;
+    }
+    return L;
+}
+
+__device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint32_t seg_len) {
+    if (i + 16 <= seg_len) return *(const uint4 *)(seg + i);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16; k++) if (i + k < seg_len) w[k >> 2] |= (uint32_t)seg[i + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+} // namespace pna
