@@ -178,16 +178,16 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // 16 bytes at the candidate requested from the segment now; the other lanes read the segment's first bytes (one line, no
             // exec masking), which nobody looks at.  A usable candidate lies at position >= 8, so the loads never reach below the segment.
             uint32_t off[G];
-            U4u fa[G]; uint32_t fb[G], fc[G];
+            v4u fa[G]; uint32_t fb[G], fc[G];
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 if constexpr (MODE == 2) { off[r] = pv[r] >> 6; continue; }
-                fa[r].x = fa[r].y = fa[r].z = fa[r].w = fb[r] = fc[r] = 0;
+                fa[r] = 0; fb[r] = fc[r] = 0;
                 const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
                 off[r] = (c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
                 if (FAR && seg_len > NEAR && max_off > NEAR) {                      // (uniform) shorter segments / near-only levels have no far candidates
                     const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
-                    fa[r] = *(const U4u *)(seg + fo);
+                    fa[r] = ld16u(seg + fo);
                     fb[r] = *(const u32u *)(seg + fo + 16);
                     if (strong) fc[r] = *(const u32u *)(seg + (off[r] > NEAR ? fo - 4 : 0u));   // (uniform) bytes c - 8 .. c - 5
                 }

@@ -85,17 +85,22 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             }
             // ---- candidates (rules as in k_lz); far ones get their bytes requested from the segment now
             uint32_t off[4];
-            U4u fa[4]; uint32_t fb[4], fc[4];
+            v4u fa[4], fd[4]; uint32_t fb[4], fc[4];           // (register tuples the loads write in place: a struct's components were moved after the load, with a wait)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                fa[j].x = fa[j].y = fa[j].z = fa[j].w = fb[j] = fc[j] = 0;
+                fa[j] = 0; fd[j] = 0; fb[j] = fc[j] = 0;
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
                 off[j] = (c1 > 8 && (ent[j] & TAG_MASK) == tag[j] && o <= max_off) ? o : 0u;
-                if (FAR && seg_len > NEAR && max_off > NEAR) {
-                    const uint32_t fo = off[j] > NEAR ? c1 - 5 : 0u;
-                    fa[j] = *(const U4u *)(seg + fo);
+                if (FAR && off[j] > NEAR) {
+                    // only the lanes that hold one (3 - 4 % of the positions), and ALL the bytes the match step can ask for -- the 4 (8) before the candidate
+                    // and its 32 -- into register tuples the loads write in place.  (Loaded as a struct, the components were moved behind the load, with a
+                    // wait right there: the far candidates then cost 27 % of the kernel instead of 17 %; fetching the second 16 bytes only where the first
+                    // 16 agreed puts a memory round trip into the match step of nearly every wave and position, one far lane in 64 being enough.)
+                    const uint32_t fo = c1 - 5;                                         // byte offset of c - 4 in the segment
+                    fa[j] = ld16u(seg + fo);
                     fb[j] = *(const u32u *)(seg + fo + 16);
-                    if (STRONG) fc[j] = *(const u32u *)(seg + (off[j] > NEAR ? fo - 4 : 0u));
+                    fd[j] = ld16u(seg + fo + 20);
+                    if (STRONG) fc[j] = *(const u32u *)(seg + fo - 4);
                 }
             }
             // ---- match
@@ -124,7 +129,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
                     if (l == 16) {
                         uint32_t v0, v1, v2, v3;
-                        if (isfar) { const U4u t = *(const U4u *)(seg + c + 16); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+                        if (isfar) { v0 = fd[j].x; v1 = fd[j].y; v2 = fd[j].z; v3 = fd[j].w; }
                         else {
                             const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
                             const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];

@@ -59,6 +59,10 @@ __device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) 
 
 struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };   // 16 bytes at any byte address
 typedef uint32_t u32u __attribute__((aligned(1)));
+// 16 bytes at any byte address as ONE register tuple: the load writes it in place (the components of the struct above get moved behind the load,
+// which puts a wait for the load right there)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u ld16u(const uint8_t *p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 
 // Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
 // full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
