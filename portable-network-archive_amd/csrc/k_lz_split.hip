@@ -184,13 +184,15 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     }
                 }
             }
-            if (q0 < t1) *(uint4 *)(pb + q0) = make_uint4((K[0] >> 6) | (off[0] << 6), (K[1] >> 6) | (off[1] << 6), (K[2] >> 6) | (off[2] << 6), (K[3] >> 6) | (off[3] << 6));
-#undef QW
+            // (the window chunk goes to LDS BEFORE the words are stored: the vector memory counter is in order, and waiting for the chunk's load behind the
+            // store would wait for the store's completion as well -- a memory round trip per tile on the four waves that carry the chunk)
             if (tid < TILE_G / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
+            if (q0 < t1) *(uint4 *)(pb + q0) = make_uint4((K[0] >> 6) | (off[0] << 6), (K[1] >> 6) | (off[1] << 6), (K[2] >> 6) | (off[2] << 6), (K[3] >> 6) | (off[3] << 6));
+#undef QW
             loaded_end += TILE_G;
             __syncthreads();                                                        // every wave has looked up
 #pragma unroll
