@@ -539,8 +539,9 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     const uint32_t s1_all = s1; bool fused_tail = false;
     // A run of fewer than ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
     // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
-    // (measured, N x 1 MiB: 256: 2.5 ms fused / 4.9 ms split, 1 024: 9.8 / 9.6, 2 048: 19.5 / 15.5, 3 072: 29.3 / 21.1).
-    const uint32_t min_segs = [] { const char *e = getenv("PNA_LZ_SPLIT_MIN"); const long v = e ? atol(e) : -1; return (uint32_t)(v >= 0 ? v : 1024); }();
+    // (measured on the final kernels, N x 1 MiB, fused / split: 256: 2.4 / 4.7 ms, 1 024 = four full rounds of the CUs: 9.1 / 9.8, 1 152: 11.3 / 11.0,
+    // 2 048: 18.1 / 15.4, 3 072: 27.1 / 21.1): the split form from 1 025 segments on.
+    const uint32_t min_segs = [] { const char *e = getenv("PNA_LZ_SPLIT_MIN"); const long v = e ? atol(e) : -1; return (uint32_t)(v >= 0 ? v : 1025); }();
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;

@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 @pytest.fixture(autouse=True)
 def _split_lz_stage_for_small_batches(monkeypatch):
-    """The LZ stage sends runs of fewer than 1 024 segments through its one-kernel form (faster for them), so with the library's default
+    """The LZ stage sends runs of up to 1 024 segments through its one-kernel form (faster for them), so with the library's default
     the small batches of this suite would never reach the split form's kernels (k_lzm, k_lzp) that the headline workload runs on.  The
     suite therefore lowers the threshold to zero; the one-kernel form has tests of its own (test_lz_stage_forms_are_identical) and the
     full-size tests (tests/test_gpu_full_size.py) put the default back."""
