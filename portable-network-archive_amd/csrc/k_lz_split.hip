@@ -21,7 +21,8 @@ __device__ unsigned long long g_lzp_stamps[8];              // k_lzp's phase sta
 //   * the right neighbours of the adoption rounds sit in the same lane, except across the lane border (DPP row_shl: a row of
 //     16 lanes is a group of 64 positions, and the zero fill at the row's end is the rule "adoption stops at the group border");
 //     the offset moves along with every adoption instead of one ds_bpermute at the end;
-//   * the four words of a lane go out as one 16-byte store; with even positions only, the inserts are those of j = 0 and 2.
+//   * the four words of a lane go out as one 16-byte store; with even positions only, the inserts are those of j = 0 and 2;
+//   * a far candidate's bytes (all 36 the match step can ask for) are requested only on the lanes that hold one, into register tuples.
 // Same table, window, tile order and barriers as k_lz, hence the same words (tests/test_gpu_parity.py: forms of the LZ stage).
 #define DPP_ROW_SHL1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xF, 0xF, true))   // value of lane i + 1 inside the row of 16 (0 at its end)
 template <bool DEFL, bool STRONG>
@@ -206,16 +207,15 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 // k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
 // ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes do here with vector arithmetic for the
 // sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 8.4 KiB of LDS) per segment; per tile of 4 096 positions:
-//   1. the tile's words (k_lz<MODE 1>'s output), 4 consecutive positions per lane and 16-byte load -> their lengths, a byte each, to
-//      LDS; then one lane per GROUP of 64 positions: start / cap masks of the group
-//      from its 64 length bytes, four at a time inside a register (byte-wise compares by carry-free subtraction, the four
-//      results gathered into a nibble by one multiplication)
+//   1. the tile's words (k_lzm's output), 4 consecutive positions per lane and 16-byte load -> their lengths, a byte each, to LDS;
+//      then one lane per GROUP of 64 positions: start / cap masks of the group from its 64 length bytes, four at a time inside a
+//      register (byte-wise compares by carry-free subtraction, the four results gathered into a nibble by one multiplication)
 //   2. lanes 0..15: greedy walk over the region's eight half-groups on 32-bit masks (length of a chosen start from LDS; a capped
 //      match is extended by the whole wave, the lengths are kept in LDS), merge across the regions = across the lanes (serial
 //      form of the scan, DPP row scans for the counts), selection / literal masks, one record per group to LDS
 //   3. one lane per group again: the group's sequences (offsets from the words in memory, four requested at a time)
-//   4. the literals, 4 consecutive positions per lane (their input bytes were requested from memory before step 3): the lane's literal bytes are packed by v_perm (selector from a 16-entry
-//      table) and stored behind the literals of the positions before it.
+//   4. the literals, 4 consecutive positions per lane (their input bytes were requested from memory before step 3): the lane's
+//      literal bytes are packed by v_perm (selector from a 16-entry table) and stored behind the literals of the positions before it.
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, bool STRONG>
