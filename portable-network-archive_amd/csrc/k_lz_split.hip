@@ -537,6 +537,9 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #pragma unroll
             for (uint32_t wr = 0; wr < 16; wr++) {
                 if (wr * RW >= npos) continue;                                      // (uniform)
+#ifdef LZP_EXP_NOLIT   /* timing experiment (no literal bytes written) */
+                if (lw[wr] != 0x12345678u) continue;
+#endif
                 const uint4 m = rec[0][wr * 4 + (lane >> 4)];
                 const uint32_t wd = lw[wr];
                 const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
