@@ -133,6 +133,45 @@ def test_lz_stage_split_runs(pna, codec, monkeypatch):
             assert zlib.decompress(o) == e
 
 
+def test_lz_stage_fuzz_against_model(gpu_ctx, pna, codec):
+    """Seeded structured noise through the split LZ stage (the suite's default) in one batch per codec and level set: entries of 0 .. 400 KB built
+    from random bytes, runs, text and copies of their own earlier fragments at all distances and alignments -- many short and long matches,
+    literals runs of every length, matches across tile / block borders and ends in odd places.  Bit-exact with the model."""
+    import random
+    rnd = random.Random(20260)
+    text = codec.corpus_file(0, 999, 400000)
+    ents = []
+    for i in range(120):
+        target = rnd.choice((0, 1, 7, 100, 4095, 4096, 4097, 20000, 70000, 131072 + rnd.randrange(-3, 4), 250000, 400000)) if i < 40 else rnd.randrange(1, 300000)
+        buf = bytearray()
+        while len(buf) < target:
+            k = rnd.random()
+            if k < 0.25 or not buf:
+                buf += bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 40)))
+            elif k < 0.40:
+                buf += bytes([rnd.getrandbits(8)]) * rnd.randrange(1, 600)
+            elif k < 0.60:
+                o = rnd.randrange(len(text) - 300); buf += text[o:o + rnd.randrange(3, 300)]
+            else:                                                   # copy of an earlier fragment (overlapping copies included)
+                d = rnd.choice((1, 2, 3, 5, 8, 64, 4096, 32768, 56064, 60000, 131072)) if rnd.random() < 0.5 else rnd.randrange(1, len(buf) + 1)
+                d = min(d, len(buf)); n = rnd.randrange(3, 2000)
+                st = len(buf) - d
+                for t in range(n):
+                    buf.append(buf[st + t])
+        ents.append(bytes(buf[:target]))
+    for level, fl in ((3, 0x77), (19, 0xF7), (1, codec.F_HUF | codec.F_FSE)):
+        outs = gpu_ctx.compress_batch(ents, level=level)
+        pz = codec.params_for_flags(fl)
+        for i, (e, o) in enumerate(zip(ents, outs)):
+            assert o == codec.model_compress(e, pz), (i, len(e), level)
+    for level, fl in ((6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
+        outs = gpu_ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE, level=level)
+        pd = codec.params_for_flags(fl, deflate=True)
+        for i, (e, o) in enumerate(zip(ents, outs)):
+            assert o == codec.deflate_model_compress(e, pd), (i, len(e), level)
+            assert zlib.decompress(o) == e
+
+
 def test_compress_batch_in_pieces(pna, codec, monkeypatch):
     """pna_gpu_compress_batch takes a large batch through in pieces (>= 256 MiB each: staging + H2D of piece k + 1 and the D2H + scatter of
     piece k - 1 next to piece k's kernels).  With 1 MiB pieces a handful of entries already makes several: every entry must come back in its
