@@ -488,12 +488,17 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         LZP_STAMP(2);
         // the input bytes of the lane's four positions in every region, for the literals: requested now, used behind the sequences
         uint32_t lw[16];
+        if (t0 + TG <= seg_len) {                           // (uniform) all but a segment's last tile: no end to look out for
 #pragma unroll
-        for (uint32_t wr = 0; wr < 16; wr++) {
-            const uint32_t q = t0 + wr * RW + 4 * lane;
-            lw[wr] = 0;
-            if (q + 4 <= seg_len) lw[wr] = *(const uint32_t *)(seg + q);                 // (segments start at multiples of 16)
-            else { for (uint32_t i = 0; i < 3; i++) if (q + i < seg_len) lw[wr] |= (uint32_t)seg[q + i] << (8 * i); }
+            for (uint32_t wr = 0; wr < 16; wr++) lw[wr] = *(const uint32_t *)(seg + t0 + wr * RW + 4 * lane);      // (segments start at multiples of 16)
+        } else {
+#pragma unroll
+            for (uint32_t wr = 0; wr < 16; wr++) {
+                const uint32_t q = t0 + wr * RW + 4 * lane;
+                lw[wr] = 0;
+                if (q + 4 <= seg_len) lw[wr] = *(const uint32_t *)(seg + q);
+                else { for (uint32_t i = 0; i < 3; i++) if (q + i < seg_len) lw[wr] |= (uint32_t)seg[q + i] << (8 * i); }
+            }
         }
         // ---- 3. the sequences, one lane per group
         {
