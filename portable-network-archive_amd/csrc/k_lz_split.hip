@@ -506,6 +506,9 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const uint4 ra = rec[0][lane], rb = rec[1][lane], rc = rec[2][lane];
             const uint64_t lm = (uint64_t)ra.x | ((uint64_t)ra.y << 32), sc = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
             uint64_t rem = lane < ng ? (uint64_t)rb.x | ((uint64_t)rb.y << 32) : 0;
+#ifdef LZP_EXP_NOSEQ   /* timing experiment (no sequences written) */
+            if (ra.w != 0x12345678u) rem = 0;
+#endif
             uint32_t idx = ra.w, prev = 0;
             const uint32_t cut_b2 = rc.z & 0xFFu, cut_l2 = rc.z >> 8;
             bool first = true;
