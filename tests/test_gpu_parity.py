@@ -137,9 +137,14 @@ def test_lz_stage_fuzz_against_model(gpu_ctx, pna, codec):
     """Seeded structured noise through the split LZ stage (the suite's default) in one batch per codec and level set: entries of 0 .. 400 KB built
     from random bytes, runs, text and copies of their own earlier fragments at all distances and alignments -- many short and long matches,
     literals runs of every length, matches across tile / block borders and ends in odd places.  Bit-exact with the model."""
+    import os
     import random
-    rnd = random.Random(20260)
     text = codec.corpus_file(0, 999, 400000)
+    for seed in range(20260, 20260 + int(os.environ.get("PNA_FUZZ_SEEDS", "1"))):      # (PNA_FUZZ_SEEDS=N: a longer soak, N batches)
+        _fuzz_one(gpu_ctx, pna, codec, text, random.Random(seed))
+
+
+def _fuzz_one(gpu_ctx, pna, codec, text, rnd):
     ents = []
     for i in range(120):
         target = rnd.choice((0, 1, 7, 100, 4095, 4096, 4097, 20000, 70000, 131072 + rnd.randrange(-3, 4), 250000, 400000)) if i < 40 else rnd.randrange(1, 300000)
