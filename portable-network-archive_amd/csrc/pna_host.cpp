@@ -514,10 +514,11 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
     pre.swap(out);
 }
 
-// The LZ stage over segments [s0, s1) of a sub-batch.  Default: the split form -- match kernel (k_lz<MODE 1>) + parse kernel (k_lzp) per run
-// of at most `split_blocks` blocks, which meet in c->pbuf (4 bytes per input byte of the run; one run at a time on the stream, so runs
-// share it).  PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0: one kernel (k_lz<MODE 0>), no pbuf; PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form with
-// k_lz<MODE 2> as its parse half.  All forms give the same bytes.  If pbuf cannot be had, the run is halved down to 1 024 blocks, then fused.
+// The LZ stage over segments [s0, s1) of a sub-batch.  Runs of more than 1 024 segments take the split form -- match kernel (k_lzm) + parse
+// kernel (k_lzp) per run of at most `split_blocks` blocks, which meet in c->pbuf (4 bytes per input byte of the run; one run at a time on the
+// stream, so runs share it) --, shorter ones and PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0 the one-kernel form (k_lz<MODE 0>, no pbuf);
+// PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form as k_lz<MODE 1> + k_lz<MODE 2> (testing).  All forms give the same bytes.  If pbuf
+// cannot be had, the run is halved down to 1 024 blocks, then fused.
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
     // (read per call, not once: the tests switch them inside one process)
@@ -537,7 +538,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
         }
     }
     const uint32_t s1_all = s1; bool fused_tail = false;
-    // A run of fewer than ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
+    // A run of up to ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
     // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
     // (measured on the final kernels, N x 1 MiB, fused / split: 256: 2.4 / 4.7 ms, 1 024 = four full rounds of the CUs: 9.1 / 9.8, 1 152: 11.3 / 11.0,
     // 2 048: 18.1 / 15.4, 3 072: 27.1 / 21.1): the split form from 1 025 segments on.
