@@ -177,6 +177,41 @@ def _fuzz_one(gpu_ctx, pna, codec, text, rnd):
             assert zlib.decompress(o) == e
 
 
+def test_lz_stage_fuzz_large_entries(gpu_ctx, pna, codec):
+    """The same kind of structured noise in entries of 1 - 4 MiB: segments that are not the entry's first, far candidates at every distance up to the
+    segment size, copies across block and segment borders (which the encoder must not follow), tails of odd length."""
+    import random
+    rnd = random.Random(777)
+    text = codec.corpus_file(0, 998, 1 << 20)
+    ents = []
+    for target in ((1 << 20) + 1, (2 << 20) - 7, 3 * (1 << 20) + 4099, (1 << 20) - 4097, (4 << 20), 1500001):
+        buf = bytearray()
+        while len(buf) < target:
+            k = rnd.random()
+            if k < 0.15 or not buf:
+                buf += bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(1, 200)))
+            elif k < 0.25:
+                buf += bytes([rnd.getrandbits(8)]) * rnd.randrange(1, 5000)
+            elif k < 0.55:
+                o = rnd.randrange(len(text) - 4000); buf += text[o:o + rnd.randrange(3, 4000)]
+            else:
+                d = rnd.choice((1, 7, 4096, 51968, 51969, 56064, 56065, 65536, 131072, 500000, (1 << 20) - 1, 1 << 20, (1 << 20) + 1))
+                d = min(d, len(buf)); n = rnd.randrange(3, 20000)
+                buf += (bytes(buf[len(buf) - d:]) * (n // d + 1))[:n]          # an overlapping copy repeats its period
+        ents.append(bytes(buf[:target]))
+    for level, fl in ((3, 0x77), (19, 0xF7)):
+        outs = gpu_ctx.compress_batch(ents, level=level)
+        pz = codec.params_for_flags(fl)
+        for i, (e, o) in enumerate(zip(ents, outs)):
+            assert o == codec.model_compress(e, pz), (i, len(e), level)
+            assert codec.zstd_decompress(o, len(e)) == e
+    outs = gpu_ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
+    pd = codec.params_for_flags(codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY, deflate=True)
+    for i, (e, o) in enumerate(zip(ents, outs)):
+        assert o == codec.deflate_model_compress(e, pd), (i, len(e))
+        assert zlib.decompress(o) == e
+
+
 def test_compress_batch_in_pieces(pna, codec, monkeypatch):
     """pna_gpu_compress_batch takes a large batch through in pieces (>= 256 MiB each: staging + H2D of piece k + 1 and the D2H + scatter of
     piece k - 1 next to piece k's kernels).  With 1 MiB pieces a handful of entries already makes several: every entry must come back in its
