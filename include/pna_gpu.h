@@ -60,6 +60,22 @@ typedef int (*pna_sink_fn)(void *user, const void *buf, size_t len);
 int  pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags);
 void pna_gpu_shutdown(pna_gpu_ctx *ctx);
 const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
+/* Tuning knobs of a context.  Each starts from an environment variable that pna_gpu_init reads ONCE (named in brackets); no entry point
+ * consults the environment afterwards.  PNA_E_INVAL for unknown names and values out of range.
+ *   "blk_log" [PNA_BLK_LOG]               block size of every batch = 1 << value (13..17); 0 = chosen by batch size (default)
+ *   "unit_log" [PNA_LZ_UNIT_LOG]          LZ-stage units of 1 << value bytes (block size..20); 0 = chosen by batch size (default)
+ *   "latency_max_mib" [PNA_LATENCY_MAX_MIB]  batches of at most this many MiB of input run in LATENCY MODE (default 192; 0 = never): smaller
+ *                                         blocks inside the same frames and one LZ workgroup per unit instead of per segment, so that a handful
+ *                                         of entries -- the CompressionWriter seam under the reference's thread pool -- fills the chip.  Same
+ *                                         format, same decoders; ratio -0.1 .. -0.3 % (block headers).  pna_gpu_last_timing reports what was chosen.
+ *   "lz_split" [PNA_LZ_SPLIT]             0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse
+ *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
+ *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 1 025)
+ *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
+ *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "fdat_max_mib" [PNA_FDAT_MAX_MIB], "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],
+ *   "extract_win_mib" [PNA_EXTRACT_WIN_MIB], "batch_piece_mib" [PNA_BATCH_PIECE_MIB], "inflate_serial" [PNA_INFLATE_SERIAL],
+ *   "zdec_serial" [PNA_ZDEC_SERIAL], "stream_pool_mib" [PNA_STREAM_POOL_MIB], "stream_linger_us" [PNA_STREAM_LINGER_US] (-1 = adaptive): DESIGN.md. */
+int  pna_gpu_set_option(pna_gpu_ctx *ctx, const char *name, long value);
 const char *pna_gpu_strerror(int code);
 
 /* Worst-case compressed size of one entry (zstd: ZSTD_compressBound-like; zlib: deflateBound-like). */
@@ -317,6 +333,8 @@ typedef struct {
     double   ms_cipher;                                  /* k_aes_* (archives written with a cipher)           */
     double   ms_lz_match;                                /* of ms_lz: the match kernel (k_lzm) launches of the split LZ stage, summed */
     uint64_t lz_match_launches;                          /* ... and how many there were (0: the batch went through the one-kernel form) */
+    uint32_t blk_log;                                    /* block size of the last (sub-)batch = 1 << blk_log: 17, or 13..16 in latency mode   */
+    uint32_t lz_units;                                   /* latency mode: workgroups (units) of the LZ stage's launch; 0: one per segment       */
 } pna_gpu_timing;
 int  pna_gpu_last_timing(const pna_gpu_ctx *ctx, pna_gpu_timing *out);
 

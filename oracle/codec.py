@@ -147,7 +147,7 @@ class ZstdParams(ctypes.Structure):
                 ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
                 ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32), ("region", ctypes.c_uint32),
                 ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
-                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32)]
+                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
@@ -160,10 +160,12 @@ def default_params() -> ZstdParams:
     return p
 
 
-def params_for_flags(flags: int, deflate: bool = False) -> ZstdParams:
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
-    F_ADOPT there is no backward adoption, without F_INS2 every position enters the table."""
+    F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
+    (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB)."""
     p = deflate_default_params() if deflate else default_params()
+    p.blk_log = blk_log
     p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
     if not deflate:
         p.flags &= ~8                     # no repeat codes on the device
@@ -237,7 +239,7 @@ def model_lz_segment(seg: bytes, params: ZstdParams | None = None):
                                ctypes.POINTER(_Seq), ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
     table = (ctypes.c_uint32 * ((1 << params.hash_log) if params.hash_log <= 31 else params.hash_log))()
     out = []
-    BLK = 1 << 17
+    BLK = (1 << params.blk_log) if 13 <= params.blk_log < 17 else (1 << 17)
     seqs = (_Seq * (BLK // 4))()
     lits = ctypes.create_string_buffer(BLK + 8)
     for b0 in range(0, len(seg), BLK):

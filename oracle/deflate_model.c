@@ -146,8 +146,8 @@ static uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {
 }
 
 size_t pna_deflate_bound(size_t n) {
-    size_t blks = (n + PNA_BLK_SIZE - 1) / PNA_BLK_SIZE; if (!blks) blks = 1;
-    return n + blks * (3 * 5 + 8) + 16;
+    size_t blks = (n + PNA_BLK_MIN - 1) / PNA_BLK_MIN; if (!blks) blks = 1;      /* (the smallest block size a parameter set may name) */
+    return n + blks * 10 + (n >> 17) * 16 + 64;
 }
 
 void pna_deflate_default_params(pna_zstd_params *p) {
@@ -162,34 +162,35 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     dst[op++] = 0x78; dst[op++] = 0x9C;
     const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
-    uint32_t maxblk = PNA_SEG_SIZE / PNA_BLK_SIZE;
-    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (PNA_BLK_SIZE / 4));
+    const uint32_t BS = pna_blk_size(p);
+    uint32_t maxblk = PNA_SEG_SIZE / BS;
+    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (BS / 4));
     uint8_t *lits = (uint8_t *)malloc((size_t)PNA_SEG_SIZE + 8);
-    uint8_t *tmp = (uint8_t *)malloc(PNA_BLK_SIZE * 2 + 4096);
+    uint8_t *tmp = (uint8_t *)malloc(BS * 2 + 4096);
     dtables *t = (dtables *)malloc(sizeof(dtables));
-    uint32_t blk_nseq[PNA_SEG_SIZE / PNA_BLK_SIZE], blk_nlit[PNA_SEG_SIZE / PNA_BLK_SIZE];
+    uint32_t blk_nseq[PNA_SEG_SIZE / PNA_BLK_MIN], blk_nlit[PNA_SEG_SIZE / PNA_BLK_MIN];
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
         memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t nb = 0;
-        for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE, nb++) {
-            uint32_t bl = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
-            blk_nseq[nb] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)nb * (PNA_BLK_SIZE / 4),
-                                        lits + (size_t)nb * PNA_BLK_SIZE, &blk_nlit[nb]);
+        for (uint32_t b0 = 0; b0 < seg_len; b0 += BS, nb++) {
+            uint32_t bl = seg_len - b0 < BS ? seg_len - b0 : BS;
+            blk_nseq[nb] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)nb * (BS / 4),
+                                        lits + (size_t)nb * BS, &blk_nlit[nb]);
         }
         /* segment statistics */
         uint32_t llc[288] = {0}, dc[32] = {0};
         for (uint32_t b = 0; b < nb; b++) {
-            const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE; const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
+            const uint8_t *bl = lits + (size_t)b * BS; const pna_seq *bs = seqs + (size_t)b * (BS / 4);
             for (uint32_t i = 0; i < blk_nlit[b]; i++) llc[bl[i]]++;
             for (uint32_t i = 0; i < blk_nseq[b]; i++) { llc[257 + len_code(bs[i].ml)]++; dc[dist_code(bs[i].off)]++; }
             llc[256]++;
         }
         build_tables(t, llc, dc);
         for (uint32_t b = 0; b < nb; b++) {
-            uint32_t b0 = b * PNA_BLK_SIZE, bl_len = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
-            const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE; const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
+            uint32_t b0 = b * BS, bl_len = seg_len - b0 < BS ? seg_len - b0 : BS;
+            const uint8_t *bl = lits + (size_t)b * BS; const pna_seq *bs = seqs + (size_t)b * (BS / 4);
             int last = (s0 + b0 + bl_len >= n);
             dbw w; dw_init(&w, tmp);
             dw_add(&w, (uint32_t)last, 1); dw_add(&w, 2, 2);
@@ -206,7 +207,7 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
             if (!last) dw_add(&w, 0, 3);                   /* header of the empty stored block (sync flush), then align */
             size_t dyn = dw_align(&w);
             size_t stored = (size_t)bl_len + 5 * (((size_t)bl_len + 65534) / 65535);
-            if (dyn >= stored || dyn > PNA_BLK_SIZE) {       /* second clause: the device's per-block scratch is one block */
+            if (dyn >= stored || dyn > BS) {       /* second clause: the device's per-block scratch is one block */
                 for (uint32_t o = 0; o < bl_len; o += 65535) {
                     uint32_t k = bl_len - o < 65535 ? bl_len - o : 65535;
                     dst[op++] = (uint8_t)((last && o + k >= bl_len) ? 1 : 0);

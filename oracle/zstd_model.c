@@ -8,7 +8,7 @@
  *                   reference's streaming frames `28 B5 2F FD 00 58` except for the smaller window).  n == 0
  *                   gives the reference's empty frame 28B52FFD 20 00 01 00 00 (tests/golden/zstd.pna,
  *                   raw/empty.txt).  Frames are concatenated (zstd-rs Decoder reads all of them).
- * SEGMENT -> BLOCKS 128 KiB blocks; the hash table persists across the blocks of a segment, so matches reach
+ * SEGMENT -> BLOCKS 128 KiB blocks (p->blk_log: 8 - 64 KiB in the device's latency mode); the hash table persists across the blocks of a segment, so matches reach
  *                   back into earlier blocks (<= max_off bytes).
  * LZ STAGE          tile-synchronous hash matching, see pna_lz_block().
  * ENTROPY STAGE     literals: raw / RLE / Huffman (<= 11 bits, 1 or 4 streams); sequences: predefined / RLE /
@@ -25,11 +25,18 @@ void pna_zstd_default_params(pna_zstd_params *p) {
     p->hash_log = 24512; p->min_match = 6; p->tile = 4096; p->max_off = 1u << 20; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 56064; p->cap_far = 32;
+    p->blk_log = 0;
+}
+
+/* block size of a parameter set: 128 KiB unless blk_log names a smaller power of two (the device's latency mode: small batches are cut
+ * into 8 - 64 KiB blocks so that the per-block serial chains are short) */
+uint32_t pna_blk_size(const pna_zstd_params *p) {
+    return (p->blk_log >= PNA_BLK_LOG_MIN && p->blk_log < 17) ? 1u << p->blk_log : PNA_BLK_SIZE;
 }
 
 size_t pna_zstd_bound(size_t n) {
     size_t segs = (n + PNA_SEG_SIZE - 1) / PNA_SEG_SIZE; if (segs == 0) segs = 1;
-    size_t blks = (n + PNA_BLK_SIZE - 1) / PNA_BLK_SIZE + segs;
+    size_t blks = (n + PNA_BLK_MIN - 1) / PNA_BLK_MIN + segs;      /* (the smallest block size a parameter set may name) */
     return n + segs * 6 + blks * 3 + 16;
 }
 
@@ -520,19 +527,20 @@ static size_t put_raw_lit_header(uint8_t *dst, int type, uint32_t nlit) {
  * the block's input offset scaled: seqs at index b*(BLK/4), lits at byte b*BLK).  Returns frame bytes.
  */
 size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_seq *seqs, const uint8_t *lits,
-                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint8_t *dst) {
-    uint32_t nblk = (seg_len + PNA_BLK_SIZE - 1) / PNA_BLK_SIZE;
+                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint32_t blk_size, uint8_t *dst) {
+    const uint32_t BS = blk_size;
+    uint32_t nblk = (seg_len + BS - 1) / BS;
     static const uint8_t fh[6] = {0x28,0xB5,0x2F,0xFD,0x00,0x50};
     size_t op = 0;
     memcpy(dst, fh, 6); op = 6;
     /* segment statistics */
     uint32_t lcount[256] = {0}, scount[3][64]; memset(scount, 0, sizeof(scount));
     uint32_t nseq_seg = 0;
-    uint32_t *ofb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nblk * (PNA_BLK_SIZE / 4));
+    uint32_t *ofb = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nblk * (BS / 4));
     for (uint32_t b = 0; b < nblk; b++) {
-        const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE;
-        const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
-        uint32_t *bo = ofb + (size_t)b * (PNA_BLK_SIZE / 4);
+        const uint8_t *bl = lits + (size_t)b * BS;
+        const pna_seq *bs = seqs + (size_t)b * (BS / 4);
+        uint32_t *bo = ofb + (size_t)b * (BS / 4);
         for (uint32_t i = 0; i < blk_nlit[b]; i++) lcount[bl[i]]++;
         block_offbase(bs, blk_nseq[b], flags, bo);
         for (uint32_t i = 0; i < blk_nseq[b]; i++) {
@@ -550,12 +558,12 @@ size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_s
     }
     /* blocks, in order; have_huf / have_seq record whether a previous block of the frame carried the tables */
     int have_huf = 0, have_seq = 0;
-    uint8_t *tmpblk = (uint8_t *)malloc(PNA_BLK_SIZE * 2 + 1024);
-    uint8_t *hbody = (uint8_t *)malloc(PNA_BLK_SIZE * 2 + 64), *sbits = (uint8_t *)malloc((size_t)(PNA_BLK_SIZE / 4) * 12 + 64);
+    uint8_t *tmpblk = (uint8_t *)malloc(BS * 2 + 1024);
+    uint8_t *hbody = (uint8_t *)malloc(BS * 2 + 64), *sbits = (uint8_t *)malloc((size_t)(BS / 4) * 12 + 64);
     for (uint32_t b = 0; b < nblk; b++) {
-        uint32_t b0 = b * PNA_BLK_SIZE, bl_len = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
-        const uint8_t *bl = lits + (size_t)b * PNA_BLK_SIZE;
-        const pna_seq *bs = seqs + (size_t)b * (PNA_BLK_SIZE / 4);
+        uint32_t b0 = b * BS, bl_len = seg_len - b0 < BS ? seg_len - b0 : BS;
+        const uint8_t *bl = lits + (size_t)b * BS;
+        const pna_seq *bs = seqs + (size_t)b * (BS / 4);
         uint32_t nlit = blk_nlit[b], nseq = blk_nseq[b];
         int last = (b + 1 == nblk);
         uint8_t *out = tmpblk; size_t csz = 0, sb = 0; int ok = seq_ok || nseq == 0;
@@ -589,7 +597,7 @@ size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_s
                 for (int k = 0; k < 3; k++) m[k] = t->mode[k] == 0 ? 0 : (have_seq ? 3 : t->mode[k]);
                 out[csz++] = (uint8_t)((m[0] << 6) | (m[1] << 4) | (m[2] << 2));
                 if (!have_seq) for (int k = 0; k < 3; k++) { memcpy(out + csz, t->desc[k], t->desc_len[k]); csz += t->desc_len[k]; }
-                sb = block_seq_bits(t, bs, ofb + (size_t)b * (PNA_BLK_SIZE / 4), nseq, sbits);
+                sb = block_seq_bits(t, bs, ofb + (size_t)b * (BS / 4), nseq, sbits);
             }
         }
         uint32_t hdr;
@@ -615,21 +623,22 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     if (n == 0) { static const uint8_t e[9] = {0x28,0xB5,0x2F,0xFD,0x20,0x00,0x01,0x00,0x00}; memcpy(dst, e, 9); return 9; }
     const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
-    uint32_t maxblk = PNA_SEG_SIZE / PNA_BLK_SIZE;
-    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (PNA_BLK_SIZE / 4));
+    const uint32_t BS = pna_blk_size(p);
+    uint32_t maxblk = PNA_SEG_SIZE / BS;
+    pna_seq *seqs = (pna_seq *)malloc(sizeof(pna_seq) * (size_t)maxblk * (BS / 4));
     uint8_t *lits = (uint8_t *)malloc((size_t)PNA_SEG_SIZE + 8);
-    uint32_t blk_nseq[PNA_SEG_SIZE / PNA_BLK_SIZE], blk_nlit[PNA_SEG_SIZE / PNA_BLK_SIZE];
+    uint32_t blk_nseq[PNA_SEG_SIZE / PNA_BLK_MIN], blk_nlit[PNA_SEG_SIZE / PNA_BLK_MIN];
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
         memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t b = 0;
-        for (uint32_t b0 = 0; b0 < seg_len; b0 += PNA_BLK_SIZE, b++) {
-            uint32_t bl = seg_len - b0 < PNA_BLK_SIZE ? seg_len - b0 : PNA_BLK_SIZE;
-            blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)b * (PNA_BLK_SIZE / 4),
-                                       lits + (size_t)b * PNA_BLK_SIZE, &blk_nlit[b]);
+        for (uint32_t b0 = 0; b0 < seg_len; b0 += BS, b++) {
+            uint32_t bl = seg_len - b0 < BS ? seg_len - b0 : BS;
+            blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)b * (BS / 4),
+                                       lits + (size_t)b * BS, &blk_nlit[b]);
         }
-        op += pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, dst + op);
+        op += pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, BS, dst + op);
     }
     free(table); free(seqs); free(lits);
     return op;

@@ -16,7 +16,9 @@
 #include <stddef.h>
 
 #define PNA_SEG_SIZE   (1u << 20)   /* one zstd frame per 1 MiB segment of an entry            */
-#define PNA_BLK_SIZE   (1u << 17)   /* zstd Block_Maximum_Size                                  */
+#define PNA_BLK_SIZE   (1u << 17)   /* zstd Block_Maximum_Size: the default block size          */
+#define PNA_BLK_LOG_MIN 13          /* smallest block a parameter set may ask for (blk_log)     */
+#define PNA_BLK_MIN    (1u << PNA_BLK_LOG_MIN)
 
 #define PNA_F_HUF      1u           /* Huffman-compressed literals allowed                      */
 #define PNA_F_FSE      2u           /* FSE_Compressed sequence tables allowed (else predefined) */
@@ -39,6 +41,7 @@ typedef struct {
     uint32_t rounds;      /* backward adoption rounds: nibbles = lane shifts, lowest first (0x21 = shift 1, then shift 2)   */
     uint32_t near_off;    /* offsets above it are "far" (outside the GPU's LDS window): per-position cap cap_far; 0 = none  */
     uint32_t cap_far;     /* per-position match length cap of far candidates                                                */
+    uint32_t blk_log;     /* block size = 1 << blk_log for 13..16 (latency mode of the device: short per-block chains); anything else: 128 KiB */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */
@@ -55,7 +58,8 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                       uint32_t *table, const pna_zstd_params *p,
                       pna_seq *seqs, uint8_t *lits, uint32_t *nlit_out);
 /* entropy + framing for one segment (= one frame) from the LZ stage's per-block outputs; seqs of block b start at
- * index b*(PNA_BLK_SIZE/4), its literals at byte b*PNA_BLK_SIZE.  Returns the frame size. */
+ * index b*(blk_size/4), its literals at byte b*blk_size.  Returns the frame size. */
 size_t pna_zstd_encode_segment(const uint8_t *seg, uint32_t seg_len, const pna_seq *seqs, const uint8_t *lits,
-                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint8_t *dst);
+                               const uint32_t *blk_nseq, const uint32_t *blk_nlit, uint32_t flags, uint32_t blk_size, uint8_t *dst);
+uint32_t pna_blk_size(const pna_zstd_params *p);
 #endif

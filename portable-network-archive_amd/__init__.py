@@ -49,7 +49,7 @@ class Timing(ctypes.Structure):
                 ("ms_seq", ctypes.c_double), ("ms_pack", ctypes.c_double), ("in_bytes", ctypes.c_uint64),
                 ("out_bytes", ctypes.c_uint64), ("n_segments", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64),
                 ("ms_frame", ctypes.c_double), ("ms_cipher", ctypes.c_double), ("ms_lz_match", ctypes.c_double),
-                ("lz_match_launches", ctypes.c_uint64)]
+                ("lz_match_launches", ctypes.c_uint64), ("blk_log", ctypes.c_uint32), ("lz_units", ctypes.c_uint32)]
 
 
 ENC_NONE, ENC_AES, ENC_CAMELLIA = 0, 1, 2          # Encryption::to_byte()
@@ -102,7 +102,7 @@ ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctyp
 _lib = None
 
 EXPORTS = [
-    "pna_gpu_init", "pna_gpu_shutdown", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
@@ -431,6 +431,26 @@ class Context:
         self._check(self._L.pna_gpu_decompress_batch_device(self._h, algo, n, ctypes.c_void_p(d_src), mk(src_off), mk(src_len),
                                                             ctypes.c_void_p(d_dst), mk(dst_off), mk(raw_len),
                                                             ctypes.c_void_p(stream) if stream else None))
+
+    def set_option(self, name: str, value: int) -> None:
+        """pna_gpu_set_option: tuning knobs of the context (include/pna_gpu.h lists them)."""
+        self._L.pna_gpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]
+        self._check(self._L.pna_gpu_set_option(self._h, name.encode(), value))
+
+    def options(self, **kw):
+        """Context manager: set options for the duration of a block, then put the given previous values back (tests: `with ctx.options(sub_mib=(128, 1024))`
+        -- value, value to restore)."""
+        ctx = self
+
+        class _O:
+            def __enter__(self_):
+                for k, (v, _) in kw.items():
+                    ctx.set_option(k, v)
+
+            def __exit__(self_, *a):
+                for k, (_, r) in kw.items():
+                    ctx.set_option(k, r)
+        return _O()
 
     def timing(self) -> Timing:
         t = Timing()

@@ -177,7 +177,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     DeflTables *T = tabs + blockIdx.x;
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd);
     for (uint32_t i = tid; i < 8 * 256; i += DS_THREADS) (&h_lit[0][0])[i] = 0;
     if (tid < 128) { (&h_len[0][0])[tid] = 0; (&h_dist[0][0])[tid] = 0; }
     __syncthreads();
@@ -342,7 +342,7 @@ void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     __shared__ unsigned long long r1[256], r2[256];
     const uint32_t tid = threadIdx.x, g = blockIdx.x;
     const SegDesc sd = segs[blk_seg[g]];
-    const uint32_t b0 = (g - sd.blk_base) * BLK_SIZE, n = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const uint32_t bsz = 1u << sd.blk_log, b0 = (g - sd.blk_base) * bsz, n = sd.len - b0 < bsz ? sd.len - b0 : bsz;
     const uint8_t *p = src + sd.src_off + b0;
     unsigned long long s1 = 0, s2 = 0;
     // S1 = sum d_i ; S2 = sum (n - i) d_i   (16-byte vector loads; src offsets are 16-byte aligned)
@@ -419,8 +419,8 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     if (tid < 32) t_d[tid] = T->d_code[tid];
     for (uint32_t i = tid; i < DB_STAGE; i += DB_THREADS) stage[i] = 0;
     for (uint32_t i = tid; i < TILE + 8; i += DB_THREADS) wm[i] = 0;
-    const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
-    const uint32_t bl_len = sd.len - b * BLK_SIZE < BLK_SIZE ? sd.len - b * BLK_SIZE : BLK_SIZE;
+    const uint32_t b = g - sd.blk_base, nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
+    const uint32_t bl_len = sd.len - b * bsz < bsz ? sd.len - b * bsz : bsz;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     const uint32_t ntile = (bl_len + TILE - 1) / TILE;
     const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
@@ -558,15 +558,15 @@ __global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
     if (sd.len == 0) { seg_size[sidx] = 8; return; }        // empty entry: 78 9C 03 00 00 00 00 01
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
     uint64_t off = (sd.first & 1) ? 2 : 0;                  // zlib header in front of the entry's first segment
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t g = sd.blk_base + b;
-        const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+        const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
         const bool last = (sd.first & 2) && (b + 1 == nblk);
         const uint32_t dyn = blk[g].lit_body, stored = bl_len + 5 * ((bl_len + 65534) / 65535);
         uint32_t sz, plan;
-        if (dyn >= stored || dyn > BLK_SIZE) { plan = 0; sz = stored + (last ? 0 : 5); }   // same rule in the model
+        if (dyn >= stored || dyn > bsz) { plan = 0; sz = stored + (last ? 0 : 5); }   // same rule in the model
         else { plan = 1; sz = dyn + (last ? 0 : 4); }
         blk[g].plan = plan; blk[g].out_size = sz; blk[g].out_off = off;
         off += sz;
@@ -584,8 +584,8 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
     const uint32_t sidx = blk_seg[g];
     const SegDesc sd = segs[sidx];
     const BlkInfo bi = blk[g];
-    const uint32_t b = g - sd.blk_base, nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
-    const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const uint32_t b = g - sd.blk_base, nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
+    const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     uint8_t *out = dst + seg_off[sidx] + bi.out_off;
     if (bi.plan & 1) {
@@ -622,10 +622,10 @@ __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__res
     unsigned long long A = 1, B = 0;
     for (uint32_t s = s0; s < s1; s++) {
         const SegDesc sd = segs[s];
-        const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+        const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
         for (uint32_t b = 0; b < nblk; b++) {
             const BlkInfo bi = blk[sd.blk_base + b];
-            const uint32_t n = sd.len - b * BLK_SIZE < BLK_SIZE ? sd.len - b * BLK_SIZE : BLK_SIZE;
+            const uint32_t n = sd.len - b * bsz < bsz ? sd.len - b * bsz : bsz;
             B = (B + bi.adler_b + (unsigned long long)(n % ADLER_P) * ((A + ADLER_P - 1) % ADLER_P)) % ADLER_P;
             A = (A + bi.adler_a + ADLER_P - 1) % ADLER_P;
         }

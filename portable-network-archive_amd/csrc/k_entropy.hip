@@ -274,7 +274,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     SegTables *T = tabs + blockIdx.x;
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd);
 
     for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
     for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
@@ -495,31 +495,34 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
 // (one workgroup per block) then assembles the bitstream token-parallel: 256 sequences per round, field lengths -> workgroup scan ->
 // 64-bit ORs into an LDS stage -> coalesced stores.  The chain is ~3x shorter than with the bit packing inside it (it was ~350
 // dependent instructions per sequence), and the chain's latency is what bounds this stage -- for one entry as for ten thousand.
-constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // 8 segments x 8 blocks = 64 lanes
+constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // 8 segments x 8 blocks = 64 lanes (blocks of BLK_SIZE; in latency mode a segment has 16 .. 128 smaller
+                                                          // blocks, a wave then carries 4, 2, 1 or half a segment: bps_log = log2(blocks per full segment))
 constexpr uint32_t SEQ_TWO_PHASE_MAX_BLOCKS = 40960;    // 640 chain waves: at most one per SIMD with room to spare (256 CUs x 4 SIMDs)
 static_assert(SEQ_MAX_LOG <= 8, "k_seqa packs three state flushes into 24 bits and the final states into 3 x 8 bits");
 
 __global__ __launch_bounds__(64)
 void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
-            const SegTables *__restrict__ tabs, uint32_t *__restrict__ seqw) {
+            const SegTables *__restrict__ tabs, uint32_t *__restrict__ seqw, uint32_t bps_log) {
     __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
     __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 (small values only)
     const uint32_t lane = threadIdx.x;
-    const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    const uint32_t seg0 = (blockIdx.x * 64u) >> bps_log;
+    const uint32_t segs_wg = bps_log >= 6 ? 1u : 64u >> bps_log;
     for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
     { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8); }
     for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8); }
-    for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
+    for (uint32_t s = 0; s < segs_wg && seg0 + s < nseg; s++) {
         const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
         uint32_t *dstw = (uint32_t *)&tab[s][0];
         for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
     }
     __syncthreads();
-    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
+    const uint32_t vb = blockIdx.x * 64u + lane;                       // lane -> (segment, block): block slot vb of the launch, 1 << bps_log slots per segment
+    const uint32_t sidx = vb >> bps_log, sl = sidx - seg0, b = vb & ((1u << bps_log) - 1);
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd);
     if (b >= nblk) return;
     const uint32_t g = sd.blk_base + b;
     const SegTables *T = tabs + sidx;
@@ -589,25 +592,27 @@ void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__r
 // traffic per sequence (10 000 x 1 MiB: 6.4 ms against 4.7 + 2.4 ms; 1 GiB sub-batches and single entries: 3.4 ms against 1.9 + 0.2 ms).
 __global__ __launch_bounds__(64)
 void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
-           const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc) {
+           const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t bps_log) {
     __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
     __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 | base << 16 (small values only)
     const uint32_t lane = threadIdx.x;
-    const uint32_t seg0 = blockIdx.x * SEQ_SEGS_PER_WG;
+    const uint32_t seg0 = (blockIdx.x * 64u) >> bps_log;
+    const uint32_t segs_wg = bps_log >= 6 ? 1u : 64u >> bps_log;
     for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
     { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8) | (C_LL_BASE[c] << 16); }
     for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8) | (C_ML_BASE[c] << 16); }
-    for (uint32_t s = 0; s < SEQ_SEGS_PER_WG && seg0 + s < nseg; s++) {
+    for (uint32_t s = 0; s < segs_wg && seg0 + s < nseg; s++) {
         const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
         uint32_t *dstw = (uint32_t *)&tab[s][0];
         for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
     }
     __syncthreads();
-    const uint32_t sl = lane / BLK_PER_SEG, b = lane % BLK_PER_SEG, sidx = seg0 + sl;
+    const uint32_t vb = blockIdx.x * 64u + lane;                       // lane -> (segment, block): block slot vb of the launch, 1 << bps_log slots per segment
+    const uint32_t sidx = vb >> bps_log, sl = sidx - seg0, b = vb & ((1u << bps_log) - 1);
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd);
     if (b >= nblk) return;
     const uint32_t g = sd.blk_base + b;
     const SegTables *T = tabs + sidx;
@@ -785,14 +790,14 @@ __global__ void k_plan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo 
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
     const SegTables *T = tabs + sidx;
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
     const uint32_t desc_total = T->desc_len[0] + T->desc_len[1] + T->desc_len[2];
     bool have_huf = false, have_seq = false;
     uint64_t off = 6;
     if (sd.len == 0) { seg_size[sidx] = 9; return; }           // empty entry: the reference's 9-byte empty frame
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t g = sd.blk_base + b;
-        const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+        const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         const bool ok = T->seq_ok || nseq == 0;
         uint32_t plan = 0, csz = 0;
@@ -851,8 +856,8 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     const SegTables *T = tabs + sidx;
     const BlkInfo bi = blk[g];
     const uint32_t b = g - sd.blk_base;
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
-    const uint32_t b0 = b * BLK_SIZE, bl_len = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+    const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
+    const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
     const uint32_t last = (b + 1 == nblk) ? 1u : 0u;
     uint8_t *fr = dst + seg_off[sidx];
     uint8_t *out = fr + bi.out_off;
@@ -935,17 +940,19 @@ void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st
 // sequence streams.  `tabs`, `segs` are the arrays of the whole batch.
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
+                          uint32_t flags, uint32_t blk_log, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
+    const uint32_t bps_log = 20u - blk_log;                                 // blocks per full segment (SEG_SIZE = 1 MiB)
+    const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     hipLaunchKernelGGL(k_stats, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0);
     if (ev) (void)hipEventRecord(ev[1], st);
     // two phases (short chain, parallel packing) while the chain waves fit the SIMDs, the one-kernel form beyond (see k_seq)
     if (!(flags & 0x1000u) && (nb <= SEQ_TWO_PHASE_MAX_BLOCKS || (flags & 0x2000u))) {
-        hipLaunchKernelGGL(k_seqa, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqw);
+        hipLaunchKernelGGL(k_seqa, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqw, bps_log);
         if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, seqw, blk, tabs, seqc, g0);
     } else {
-        hipLaunchKernelGGL(k_seq, dim3((ns + SEQ_SEGS_PER_WG - 1) / SEQ_SEGS_PER_WG), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc);
+        hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
 }

@@ -80,7 +80,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
-    uint32_t *pb = MODE ? pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE : nullptr;   // the segment's words (split form)
+    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;   // block size of the batch (BLK_SIZE, or less in latency mode); the per-block arrays keep BLK_SIZE strides
+    uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
     constexpr bool strong = STRONG;   // (wave-uniform) level sets: pna_host.cpp level_flags()
@@ -96,19 +97,25 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     // initial window fill [0, TILE_G + LOOKAHEAD + 16); afterwards one tile-sized chunk per tile: requested at the top of
     // tile t, stored into LDS before tile t's B3, first read after B4 (tile t+1's lookups).  The slots it overwrites hold
     // positions below t0 + 2 TILE_G + LOOKAHEAD + 16 - 64 Ki <= t0 - max_off, which no match of tile t can reference.
-    uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
-    if (MODE != 2) for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
-        const uint4 v = load_chunk(seg, i, seg_len);
-        *(uint4 *)(lds + L_WIN + i) = v;
-        if (i < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + i) = v;
+    // A unit that starts inside the segment (latency mode): the window holds the 64 KiB that end where the first tile's chunk ends, the table is
+    // pre-warmed with the positions before the unit (lz_common.h) -- the state the segment-long walk would have here.
+    uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
+    if (MODE != 2) {
+        __syncthreads();                                                            // (the table is zero before the pre-warm's inserts)
+        if (sd.u0) lz_prewarm(table, seg, seg_len, sd.u0, ins_all, tid);
+        for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
+            const uint4 v = load_chunk(seg, i, seg_len);
+            const uint32_t wo = i & (WIN_BYTES - 1);
+            *(uint4 *)(lds + L_WIN + wo) = v;
+            if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = v;
+        }
+        __syncthreads();
     }
-    if (MODE != 2) __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
 
-    const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
-    for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t blk_start = b * BLK_SIZE;
-        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
+    for (uint32_t blk_start = sd.u0; blk_start < sd.u1; blk_start += bsz) {
+        const uint32_t b = blk_start >> blk_log;
+        const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         const uint32_t gblk = sd.blk_base + b;
         uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
         uint8_t  *blit = lits + (size_t)gblk * BLK_SIZE;

@@ -40,23 +40,26 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
-    uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
+    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
+    uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
 
     for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
-    uint32_t loaded_end = TILE_G + LOOKAHEAD + 16;
-    for (uint32_t i = tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
+    // a unit that starts inside the segment (latency mode): window and table as the segment-long walk has them there (k_lz.hip, lz_common.h)
+    uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
+    __syncthreads();
+    if (sd.u0) lz_prewarm(table, seg, seg_len, sd.u0, ins_all, tid);
+    for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
-        *(uint4 *)(lds + L_WIN + i) = v;
-        if (i < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + i) = v;
+        const uint32_t wo = i & (WIN_BYTES - 1);
+        *(uint4 *)(lds + L_WIN + wo) = v;
+        if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = v;
     }
     __syncthreads();
     uint4 pf = make_uint4(0, 0, 0, 0);
 
-    const uint32_t nblk = (seg_len + BLK_SIZE - 1) / BLK_SIZE;
-    for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t blk_start = b * BLK_SIZE;
-        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
+    for (uint32_t blk_start = sd.u0; blk_start < sd.u1; blk_start += bsz) {
+        const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
             const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
             if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(LZP_THREADS)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
     constexpr uint32_t RW = 256, TG = 4096;
-    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && BLK_SIZE % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
+    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && (1u << BLK_LOG_MIN) % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
     __shared__ uint32_t l32[TG / 4];                        // the tile's match lengths, one byte per position
     __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
     __shared__ uint32_t plut[16];                           // v_perm selectors that pack the bytes named by a nibble
@@ -235,10 +238,11 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const SegDesc sd = segs[blockIdx.x];
     const uint32_t seg_len = sd.len;
     const uint8_t *seg = src + sd.src_off;
-    const uint32_t *pb = pbuf + (size_t)(sd.blk_base - blk0) * BLK_SIZE;
+    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
+    const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     const uint32_t lazy = flags & F_LAZY;
     const uint32_t wbase = w * RW;
-    const uint32_t ntile = (seg_len + TG - 1) / TG;
+    const uint32_t tile0 = sd.u0 / TG, ntile = (sd.u1 + TG - 1) / TG;      // the unit's tiles (a whole segment unless the batch runs in latency mode)
     const bool lv = lane < 16;
     if (lv) {                                               // selector of nibble n: the bytes whose bits are set, lowest first
         uint32_t sel = 0, j = 0;
@@ -255,13 +259,13 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #else
 #define LZP_STAMP(k) do { } while (0)
 #endif
-    for (uint32_t T = 0; T < ntile; T++) {
-        const uint32_t t0 = T * TG, blk_start = t0 & ~(BLK_SIZE - 1);
-        const uint32_t blk_end = (seg_len - blk_start < BLK_SIZE) ? seg_len : blk_start + BLK_SIZE;
+    for (uint32_t T = tile0; T < ntile; T++) {
+        const uint32_t t0 = T * TG, blk_start = t0 & ~(bsz - 1);
+        const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         const uint32_t t1 = (blk_end - t0 < TG) ? blk_end : t0 + TG;
         const uint32_t npos = t1 - t0;
         const uint32_t ext_lim = (t1 + LOOKAHEAD < blk_end) ? t1 + LOOKAHEAD : blk_end;
-        const uint32_t gblk = sd.blk_base + (t0 >> PNA_BLK_LOG);
+        const uint32_t gblk = sd.blk_base + (t0 >> blk_log);
         const uint32_t ng = (npos + 63) >> 6;                                           // groups with positions in them
         // ---- 1. lengths to LDS (positions behind the block's end count as "no match"; the words of a whole tile lie inside the segment's
         // share of pbuf, whole blocks, so the loads need no bounds of their own)

@@ -64,6 +64,12 @@ typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4u ld16u(const uint8_t *p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 
+__device__ __forceinline__ uint4 load_chunk_tail(const uint8_t *seg, uint32_t i, uint32_t seg_len) {    // 16 bytes at i, zeros behind the segment's end
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16; k++) if (i + k < seg_len) w[k >> 2] |= (uint32_t)seg[i + k] << (8 * (k & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
 // full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
 // segment in HBM / L2 (c + lim < q, so every address is inside the segment).
@@ -105,6 +111,29 @@ __device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t s
         L += 256;
     }
     return L;
+}
+
+// Pre-warm of a UNIT's hash table (latency mode: a segment is cut into units, one workgroup each, so that a small batch fills the chip): the table
+// gets the state the segment-long walk has when it reaches position `end` -- every position q < end with q + 8 <= seg_len (with even_only: every
+// second one) entered, the latest position of a slot wins.  Inserts are ds_max_u32, so their order does not matter and the bytes can come straight
+// from memory, eight consecutive positions per lane and 16-byte load, without the window and without barriers.  The unit's matches are therefore
+// those of the segment-long walk, bit for bit.
+__device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, uint32_t seg_len, uint32_t end, bool ins_all, uint32_t tid) {
+#pragma unroll 2
+    for (uint32_t p = tid * 8; p < end; p += LZ_THREADS * 8) {
+        uint32_t w[4];
+        if (p + 16 <= seg_len) { const uint2 a = *(const uint2 *)(seg + p), b = *(const uint2 *)(seg + p + 8); w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; }
+        else { const uint4 v = load_chunk_tail(seg, p, seg_len); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!ins_all && (j & 1)) continue;
+            const uint32_t q = p + j;
+            const uint32_t lo = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], j & 3) : w[j >> 2];
+            const uint32_t hi = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 2 < 4 ? (j >> 2) + 2 : 3], w[(j >> 2) + 1], j & 3) : w[(j >> 2) + 1];
+            const uint32_t h32 = lo * 0x9E3779B1u + (hi & 0xFFFFu) * 0x85EBCA6Bu;
+            if (q < end && q + 8 <= seg_len) atomicMax(&table[__umulhi(h32, HASH_ENTRIES)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
+        }
+    }
 }
 
 __device__ __forceinline__ uint4 load_chunk(const uint8_t *seg, uint32_t i, uint32_t seg_len) {

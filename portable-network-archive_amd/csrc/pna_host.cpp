@@ -34,7 +34,7 @@ void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_
                           uint8_t *dst, hipStream_t st);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, hipStream_t st, hipEvent_t *ev);
+                          uint32_t flags, uint32_t blk_log, hipStream_t st, hipEvent_t *ev);
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st);
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
@@ -114,13 +114,46 @@ struct PinBuf {                                  // page-locked host staging: as
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// Tuning knobs of a context (pna_gpu_set_option; include/pna_gpu.h lists them).  Each starts from the environment variable of the same
+// purpose, read ONCE in pna_gpu_init -- no entry point consults the environment afterwards.
+struct Tuning {
+    long lz_split = 1;               // PNA_LZ_SPLIT: 0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse kernel
+    long lz_split_blocks = 32768;    // PNA_LZ_SPLIT_BLOCKS: blocks per run of the split form (the words workspace holds one run)
+    long lz_split_min = 1025;        // PNA_LZ_SPLIT_MIN: shortest run (segments) that takes the split form
+    long lz_pbuf_fail = 0;           // PNA_LZ_PBUF_FAIL: testing -- behave as if the words workspace could not be allocated
+    long pipeline_chunks = 1;        // PNA_PIPELINE_CHUNKS: zstd entropy stage of chunk k next to the LZ stage of chunk k + 1 (measured: slower)
+    long fdat_max_mib = 1024;        // PNA_FDAT_MAX_MIB: largest FDAT chunk the device paths write when the caller names no max_chunk_size
+    long sub_mib = 1024;             // PNA_SUB_MIB: input bytes per sub-batch of the bounded host pipeline
+    long stage_threads = 0;          // PNA_STAGE_THREADS: host threads that stage entries into page-locked memory (0: min(8, cores / 2))
+    long extract_win_mib = 1024;     // PNA_EXTRACT_WIN_MIB: archive bytes per window of the extract driver
+    long batch_piece_mib = 256;      // PNA_BATCH_PIECE_MIB: pna_gpu_compress_batch takes a large batch through in pieces of this size (0: one piece)
+    long inflate_serial = 0;         // PNA_INFLATE_SERIAL: deflate decoding on the wave-per-stream walk only
+    long zdec_serial = 0;            // PNA_ZDEC_SERIAL: zstd decoding with one workgroup per frame only
+    long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
+    long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
+    long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+};
+struct TuningName { const char *name, *env; long Tuning::*field; long lo, hi; };
+static const TuningName TUNING_NAMES[] = {
+    {"lz_split", "PNA_LZ_SPLIT", &Tuning::lz_split, 0, 2}, {"lz_split_blocks", "PNA_LZ_SPLIT_BLOCKS", &Tuning::lz_split_blocks, 8, 1 << 17},
+    {"lz_split_min", "PNA_LZ_SPLIT_MIN", &Tuning::lz_split_min, 0, 1 << 30}, {"lz_pbuf_fail", "PNA_LZ_PBUF_FAIL", &Tuning::lz_pbuf_fail, 0, 1},
+    {"pipeline_chunks", "PNA_PIPELINE_CHUNKS", &Tuning::pipeline_chunks, 1, 8}, {"fdat_max_mib", "PNA_FDAT_MAX_MIB", &Tuning::fdat_max_mib, 1, 2047},
+    {"sub_mib", "PNA_SUB_MIB", &Tuning::sub_mib, 16, 16384}, {"stage_threads", "PNA_STAGE_THREADS", &Tuning::stage_threads, 0, 64},
+    {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20},
+    {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
+    {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
+    {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20},
+};
+
 struct pna_gpu_stream;
 struct pna_gpu_ctx {
+    Tuning tun;
+    DevBuf units;                                   // latency mode: the LZ stage's units (pieces of segments, one workgroup each)
+    uint32_t last_blk_log = PNA_BLK_LOG, last_units = 0;
     int device = 0;
     uint32_t flags = 0;
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
-    uint32_t lz_split_blocks = 0;                   // blocks per run of the split LZ stage once an allocation of pbuf failed (0 = the default)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab, pbuf;
@@ -200,9 +233,12 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->device = device_id;
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
+    for (const TuningName &t : TUNING_NAMES)
+        if (const char *e = getenv(t.env)) { const long v = atol(e); if (v >= t.lo && v <= t.hi) c->tun.*(t.field) = v; }
     if (const char *pm = getenv("PNA_STREAM_POOL_MIB")) c->pool_cap = (size_t)std::min<unsigned long>(strtoul(pm, nullptr, 10), 1ul << 20) << 20;
     if (const char *lg = getenv("PNA_STREAM_LINGER_US")) c->comb_linger_us = (uint32_t)std::min<unsigned long>(strtoul(lg, nullptr, 10), 100000ul);
     if (!(flags & PNA_F_DEFAULT)) c->flags |= flags & 0x3F00u;  // diagnostics: 0x100 phase stamps, 0x200 force the serial fallback in k_lz, 0x1000 / 0x2000 force the one-kernel / two-phase sequence coder
+    c->flags |= flags & (PNA_F_LZ_FUSED | PNA_F_LZ_WAVEPARSE);  // the form of the LZ stage: honoured next to PNA_F_DEFAULT as well
     c->call_flags = c->flags;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
@@ -210,12 +246,25 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     return PNA_OK;
 }
 
+extern "C" int pna_gpu_set_option(pna_gpu_ctx *c, const char *name, long value) {
+    if (!c || !name) return PNA_E_INVAL;
+    if (!strcmp(name, "stream_pool_mib")) { if (value < 0) return PNA_E_INVAL; c->pool_cap = (size_t)std::min<long>(value, 1l << 20) << 20; return PNA_OK; }
+    if (!strcmp(name, "stream_linger_us")) { c->comb_linger_us = value < 0 ? 0xFFFFFFFFu : (uint32_t)std::min<long>(value, 100000); return PNA_OK; }
+    for (const TuningName &t : TUNING_NAMES)
+        if (!strcmp(name, t.name)) {
+            if (value < t.lo || value > t.hi) return fail(c, PNA_E_INVAL, "option value out of range");
+            if (t.field == &Tuning::blk_log && value != 0 && value < (long)BLK_LOG_MIN) return fail(c, PNA_E_INVAL, "blk_log: 0 or 13..17");
+            c->tun.*(t.field) = value; return PNA_OK;
+        }
+    return fail(c, PNA_E_INVAL, "unknown option");
+}
+
 extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     if (c) { for (void *a : c->pool_arenas) (void)hipHostFree(a); c->pool_arenas.clear(); c->pool_free.clear(); c->s_out[0].release(); c->s_out[1].release(); }
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
+    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->units, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
@@ -236,9 +285,12 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
 
 extern "C" size_t pna_gpu_bound(int algo, size_t n) {
     if (algo == PNA_ALGO_STORE) return n;
-    if (algo == PNA_ALGO_DEFLATE) { size_t b = (n + BLK_SIZE - 1) / BLK_SIZE; if (!b) b = 1; return n + b * 23 + 16; }
+    // (per block of the SMALLEST size a batch may be cut into -- latency mode, BLK_LOG_MIN --: deflate 5 bytes of stored-block header + 5 of sync flush,
+    // zstd 3 bytes of block header; per segment / 128 KiB the older, coarser allowances)
+    constexpr size_t BMIN = (size_t)1 << BLK_LOG_MIN;
+    if (algo == PNA_ALGO_DEFLATE) { size_t b = (n + BMIN - 1) / BMIN; if (!b) b = 1; return n + b * 10 + (n >> PNA_BLK_LOG) * 16 + 64; }
     size_t segs = (n + SEG_SIZE - 1) / SEG_SIZE; if (segs == 0) segs = 1;
-    size_t blks = (n + BLK_SIZE - 1) / BLK_SIZE + segs;
+    size_t blks = (n + BMIN - 1) / BMIN + segs;
     return n + segs * 6 + blks * 3 + 16;
 }
 
@@ -250,7 +302,8 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
     }
     if (algo == PNA_ALGO_DEFLATE) {         // lib/src/compress/deflate.rs:33-38,89-101
         if (level == PNA_LEVEL_DEFAULT) return 6;
-        return level < 0 ? 0 : (level > 9 ? 9 : level);
+        // Custom(n) => Compression::new((n as u32).clamp(0, 9)): a negative n wraps to a large u32 and clamps to 9 (deflate.rs:89-101)
+        return (uint32_t)level > 9u ? 9 : level;
     }
     return 0;
 }
@@ -272,9 +325,15 @@ static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     return c->flags;
 }
 
+// blocks an entry of `len` bytes takes in the per-block workspace (sub-batches are cut by block count); a forced block size counts as such
+static size_t plan_blocks(const pna_gpu_ctx *c, uint64_t len) {
+    const uint32_t lg = c->tun.blk_log ? (uint32_t)c->tun.blk_log : (uint32_t)PNA_BLK_LOG;
+    return (size_t)((len + ((uint64_t)1 << lg) - 1) >> lg);
+}
+
 extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
     if (!c || !out) return PNA_E_INVAL;
-    *out = c->timing; return PNA_OK;
+    *out = c->timing; out->blk_log = c->last_blk_log; out->lz_units = c->last_units; return PNA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -521,12 +580,11 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
 // cannot be had, the run is halved down to 1 024 blocks, then fused.
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
-    // (read per call, not once: the tests switch them inside one process)
-    const int env_split = [] { const char *e = getenv("PNA_LZ_SPLIT"); return e ? atoi(e) : 1; }();
-    const uint32_t env_blocks = [] { const char *e = getenv("PNA_LZ_SPLIT_BLOCKS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 8 && v <= (1 << 17) ? v : 32768); }();
+    const int env_split = (int)c->tun.lz_split;
+    const uint32_t env_blocks = (uint32_t)c->tun.lz_split_blocks;
     const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
     const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
-    uint32_t split_blocks = c->lz_split_blocks ? c->lz_split_blocks : env_blocks;
+    uint32_t split_blocks = env_blocks;
     if (s1 > s0) {
         // several runs: of about equal size (whole rounds of 256 one-MiB segments) instead of full ones and a short tail -- a tail under the
         // split form's threshold would fall back to the slower one-kernel form (5 000 segments: 2 560 + 2 440 instead of 4 096 + 904)
@@ -542,16 +600,16 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
     // (measured on the final kernels, N x 1 MiB, fused / split: 256: 2.4 / 4.7 ms, 1 024 = four full rounds of the CUs: 9.1 / 9.8, 1 152: 11.3 / 11.0,
     // 2 048: 18.1 / 15.4, 3 072: 27.1 / 21.1): the split form from 1 025 segments on.
-    const uint32_t min_segs = [] { const char *e = getenv("PNA_LZ_SPLIT_MIN"); const long v = e ? atol(e) : -1; return (uint32_t)(v >= 0 ? v : 1025); }();
+    const uint32_t min_segs = (uint32_t)c->tun.lz_split_min;
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
         while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
         const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
         if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
-        if (getenv("PNA_LZ_PBUF_FAIL") /* testing: as if the allocation failed */ || c->pbuf.ensure((size_t)std::max<uint32_t>(b1 - b0, 1) * BLK_SIZE * 4)) {
+        if (c->tun.lz_pbuf_fail /* testing: as if the allocation failed */ || c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4)) {
             (void)hipGetLastError();                                   // (the failed allocation's sticky code)
-            if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; c->lz_split_blocks = split_blocks; continue; }
+            if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; continue; }                    // (for this call only: the next one tries the full run again)
             s0 = a; break;                                             // no room for the words: the rest goes through the fused kernel
         }
         hipEvent_t e1 = nullptr;
@@ -574,22 +632,50 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                         hipStream_t st, bool timed, const FrameJob *fj = nullptr) {
     std::vector<SegDesc> segs; std::vector<uint32_t> blk_seg; std::vector<uint32_t> entry_first_seg;
     uint32_t nblk = 0;
+    // LATENCY MODE: a small batch -- the CompressionWriter seam with a handful of writers in flight, one entry of
+    // `pna_gpu_compress_batch` -- has fewer segments than the chip has CUs, and its time is the length of the per-segment and per-block serial
+    // chains (one workgroup walks a segment's 256 tiles; one lane codes a block's sequences).  Such a batch is cut finer: blocks of 8 .. 64 KiB
+    // inside the same frames (blk_log), and the LZ stage runs one workgroup per UNIT of 1 << unit_log bytes whose table is pre-warmed with
+    // everything before it (lz_prewarm), which gives the very matches of the segment-long walk.  Both follow from the batch's size alone
+    // (and pna_gpu_set_option), are reported by pna_gpu_last_timing, and are parameters of the oracle's model.
+    uint64_t in_total = 0, nseg_est = 0;
+    for (size_t e = e0; e < e1; e++) { in_total += src_len[e]; nseg_est += src_len[e] ? (src_len[e] + SEG_SIZE - 1) / SEG_SIZE : 1; }
+    const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
+    uint32_t blk_log = PNA_BLK_LOG, unit_log = 20;
+    if (latency) {
+        // blocks: 16 KiB up to 16 MiB of input (a block's sequence chain then is ~1 000 steps), then growing with the batch so that the
+        // block count -- per-block fixed costs of the entropy kernels -- stays near 1 024 .. 2 048
+        blk_log = 14;
+        while (blk_log < PNA_BLK_LOG && (in_total >> blk_log) > 2048) blk_log++;
+        // units: about one per CU (256), never smaller than a block
+        unit_log = blk_log;
+        while (unit_log < 20 && (in_total >> unit_log) > 384) unit_log++;
+    }
+    if (c->tun.blk_log) blk_log = (uint32_t)c->tun.blk_log;
+    if (c->tun.unit_log) unit_log = (uint32_t)std::max<long>(c->tun.unit_log, blk_log);
+    if (unit_log < blk_log) unit_log = blk_log;
+    const uint32_t bsz = 1u << blk_log;
+    std::vector<SegDesc> units;
     for (size_t e = e0; e < e1; e++) {
         entry_first_seg.push_back((uint32_t)segs.size());
         uint64_t len = src_len[e], off = src_off[e];
         if (off & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
-        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3}; segs.push_back(s); continue; }
+        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3, 0, 0, blk_log, 0}; segs.push_back(s); continue; }
         for (uint64_t p = 0; p < len; p += SEG_SIZE) {
             uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
-            SegDesc s{off + p, sl, nblk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u)};
-            uint32_t nb = (sl + BLK_SIZE - 1) / BLK_SIZE;
+            SegDesc s{off + p, sl, nblk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u), 0, sl, blk_log, 0};
+            uint32_t nb = (sl + bsz - 1) >> blk_log;
             for (uint32_t b = 0; b < nb; b++) blk_seg.push_back((uint32_t)segs.size());
             nblk += nb; segs.push_back(s);
+            if (unit_log < 20)
+                for (uint32_t u = 0; u < sl; u += 1u << unit_log) { SegDesc us = s; us.u0 = u; us.u1 = std::min<uint32_t>(sl, u + (1u << unit_log)); units.push_back(us); }
         }
     }
     entry_first_seg.push_back((uint32_t)segs.size());
     const uint32_t nseg = (uint32_t)segs.size();
     if (nseg == 0) return PNA_OK;
+    const bool unit_mode = unit_log < 20 && !units.empty();
+    c->last_blk_log = blk_log; c->last_units = unit_mode ? (uint32_t)units.size() : 0;
     if (c->segs.ensure(nseg * sizeof(SegDesc)) || c->blk_seg.ensure((size_t)(nblk + 1) * 4) ||
         c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
         c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) || (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
@@ -599,6 +685,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
         return fail(c, PNA_E_NOMEM, "workspace allocation failed");
     HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+    if (unit_mode) {
+        if (c->units.ensure(units.size() * sizeof(SegDesc))) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
+        HIPCHK(c, hipMemcpyAsync(c->units.p, units.data(), units.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+    }
     if (nblk) HIPCHK(c, hipMemcpyAsync(c->blk_seg.p, blk_seg.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(c->blk.p, 0, (size_t)(nblk + 1) * sizeof(BlkInfo), st));
     c->lzm_used = 0;
@@ -607,7 +697,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
-        { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)), 32768u, 258u, st, timed); if (rc) return rc; }
+        const uint32_t dfl = c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u);
+        if (unit_mode) launch_lz(d_src, (const SegDesc *)c->units.p, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
+        else { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
@@ -624,18 +716,20 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         // Measured (10 000 x 1 MiB): 4 chunks 111.8 ms vs 108.9 ms unchunked -- k_seq's duration is set by the length of one
         // block's tANS chain, not by the number of blocks, so every chunk pays it in full and the co-resident waves slow k_lz
         // by 12 %.  The chunked form therefore stays off unless PNA_PIPELINE_CHUNKS asks for it.
-        { const char *e = getenv("PNA_PIPELINE_CHUNKS"); nch = e ? atoi(e) : 1; if (nch < 1) nch = 1; if (nch > pna_gpu_ctx::MAXCH) nch = pna_gpu_ctx::MAXCH; if ((uint32_t)nch > nseg) nch = 1; }
+        nch = (int)c->tun.pipeline_chunks; if (nch < 1) nch = 1; if (nch > pna_gpu_ctx::MAXCH) nch = pna_gpu_ctx::MAXCH; if ((uint32_t)nch > nseg || latency) nch = 1;
         HIPCHK(c, hipEventRecord(c->ev_lz[0], st));
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            if (unit_mode) launch_lz(d_src, (const SegDesc *)c->units.p, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
+                                     (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, nullptr, 0, nullptr);       // (nch == 1: one launch over all units)
+            else { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
             HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));
             launch_entropy_chunk((const SegDesc *)c->segs.p, s0, s1 - s0, (const uint32_t *)c->blk_seg.p, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
-                                 (uint32_t *)c->seqw.p, c->call_flags, c->aux, &c->ev_en[k][1]);
+                                 (uint32_t *)c->seqw.p, c->call_flags, blk_log, c->aux, &c->ev_en[k][1]);
         }
         HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -748,8 +842,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         } else {
             // FlattenWriter cuts an entry's stream into FDAT chunks of at most max_chunk_size (lib/src/util/io.rs:60-77); here the
             // cut points are segment boundaries and the limit is 1 GiB (PNA_FDAT_MAX_MIB for tests)
-            uint64_t fdat_max = 1024ull << 20;
-            if (const char *ev = getenv("PNA_FDAT_MAX_MIB")) { const long v = atol(ev); if (v >= 1 && v <= 2047) fdat_max = (uint64_t)v << 20; }
+            uint64_t fdat_max = (uint64_t)c->tun.fdat_max_mib << 20;
             std::vector<FrameDesc> units; units.reserve(e1 - e0);
             const bool cbc = fj->cipher && fj->cipher->cipher_mode == PNA_MODE_CBC;
             for (size_t e = e0; e < e1; e++) {
@@ -940,7 +1033,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
     while (e < n) {
         size_t e1 = e; size_t blocks = 0;
         while (e1 < n) {
-            size_t nb = (size_t)((src_len[e1] + BLK_SIZE - 1) / BLK_SIZE);
+            size_t nb = plan_blocks(c, src_len[e1]);
             if (e1 > e && blocks + nb > c->max_blocks) break;
             blocks += nb; in_total += src_len[e1]; e1++;
         }
@@ -1045,7 +1138,7 @@ extern "C" int pna_gpu_create_archive_meta_device(pna_gpu_ctx *c, int algo, int 
     while (e < n) {
         size_t e1 = e, blocks = 0;
         while (e1 < n) {
-            size_t nb = (size_t)((src_len[e1] + BLK_SIZE - 1) / BLK_SIZE);
+            size_t nb = plan_blocks(c, src_len[e1]);
             if (e1 > e && blocks + nb > c->max_blocks) break;
             blocks += nb; in_total += src_len[e1]; e1++;
         }
@@ -1336,15 +1429,14 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     // sub-batches of at most SUB input bytes (an entry larger than that is a sub-batch of its own)
     // sub-batch size: the entropy kernels have a fixed latency of a few ms per launch (serial chains), so small sub-batches waste
     // the GPU; 1 GiB keeps the pipeline above the PCIe rate while the in-flight window stays bounded (2 x 1 GiB in, 2 x out)
-    uint64_t SUB = 1024ull << 20;
-    if (const char *e = getenv("PNA_SUB_MIB")) { const long v = atol(e); if (v >= 16 && v <= 16384) SUB = (uint64_t)v << 20; }
+    const uint64_t SUB = (uint64_t)c->tun.sub_mib << 20;
     struct Sub { size_t e0, e1; uint64_t in_bytes, out_cap; };
     std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
     for (size_t e = 0; e < n;) {
         Sub sb{e, e, 0, 64}; uint64_t pos = 0; size_t blocks = 0;
         while (sb.e1 < n) {
             const size_t i = sb.e1; const uint64_t l = src_len[i];
-            const size_t nb = (size_t)((l + BLK_SIZE - 1) / BLK_SIZE);
+            const size_t nb = plan_blocks(c, l);
             if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
             off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
             sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
@@ -1355,7 +1447,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
-    if (const char *e = getenv("PNA_STAGE_THREADS")) { const int t = atoi(e); if (t >= 1 && t <= 64) threads = (unsigned)t; }
+    if (c->tun.stage_threads) threads = (unsigned)c->tun.stage_threads;
     FrameJob fj{names, 0, cipher, ivs, meta};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
@@ -1552,8 +1644,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
     // device at a time (an archive of any size in host memory against a bounded footprint in HBM); a solid entry is a window of its own
     XKeys keys; size_t index = 0, si = 0, w0 = 0;
     const size_t n_all = ents.size();
-    uint64_t WIN = 1ull << 30;                                  // 1 GiB of archive (and at most 3 GiB decoded) per window: small enough to pipeline, large enough for the kernels
-    if (const char *ev = getenv("PNA_EXTRACT_WIN_MIB")) { const long v = atol(ev); if (v >= 1 && v <= (1 << 20)) WIN = (uint64_t)v << 20; }
+    const uint64_t WIN = (uint64_t)c->tun.extract_win_mib << 20;  // 1 GiB of archive (and at most 3 GiB decoded) per window by default: small enough to pipeline, large enough for the kernels
     auto rebase_run = [&](size_t e0, size_t e1, std::vector<XEntry> &we, std::vector<FrameDesc> &wd, uint64_t base) {
         we.assign(std::make_move_iterator(ents.begin() + e0), std::make_move_iterator(ents.begin() + e1));
         wd.assign(dchunks.begin() + we.front().d0, dchunks.begin() + we.back().d1);
@@ -2065,7 +2156,7 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
     // (per-entry copies from pageable memory ran at ~1 GiB/s).  A large batch goes through in PIECES of >= 256 MiB (a round of the CUs:
     // the kernels' fixed latencies stay amortised): piece k + 1 is staged and copied while piece k is on the device, piece k - 1's results
     // travel back meanwhile -- 512 x 1 MiB: 27.5 -> see profiles/ (PNA_BATCH_PIECE_MIB; 0 = one piece).
-    const uint64_t piece_bytes = [] { const char *e = getenv("PNA_BATCH_PIECE_MIB"); const long v = e ? atol(e) : 256; return (uint64_t)(v <= 0 ? ~0ull >> 1 : (uint64_t)v << 20); }();
+    const uint64_t piece_bytes = c->tun.batch_piece_mib <= 0 ? ~0ull >> 1 : (uint64_t)c->tun.batch_piece_mib << 20;
     std::vector<size_t> pe{0};                                   // piece k = entries [pe[k], pe[k + 1])
     for (size_t i = 0; i < n;) {
         size_t j = i; uint64_t acc = 0;
@@ -2159,7 +2250,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     // the sync-flush markers (one pass + one small read-back): markers + 1 pieces, all but the last holding BLK_SIZE bytes
     std::vector<uint64_t> npc(n);
     uint64_t tot_pieces = 0;
-    bool lanes = getenv("PNA_INFLATE_SERIAL") == nullptr;
+    bool lanes = !c->tun.inflate_serial;
     if (lanes && open) {
         std::vector<uint32_t> cnt(n);
         if (c->z_pb.ensure(n * 4 + 8) || c->z_vp.ensure(n * 16 + 16)) return fail(c, PNA_E_NOMEM, "decoder workspace");
@@ -2308,7 +2399,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
             if (nblk_cap > 0x3FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
         }
     }
-    const bool serial_only = getenv("PNA_ZDEC_SERIAL") != nullptr;     // diagnostics: one workgroup per frame for everything
+    const bool serial_only = c->tun.zdec_serial != 0;                  // diagnostics: one workgroup per frame for everything
     if (c->z_ents.ensure(n * sizeof(ZEntry)) || c->z_frames.ensure(nfr * sizeof(ZFrame)) || c->z_lit.ensure(out_span + 64) ||
         c->z_fx.ensure(nfr * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk_cap * sizeof(ZBlock)) || c->z_tabs.ensure(nslot * sizeof(ZTables)) ||
         c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_hlist.ensure(nblk_cap * 16 + 16) || c->z_slist.ensure(nblk_cap * 4 + 16) || c->z_work.ensure(64))

@@ -22,6 +22,11 @@ def _split_lz_stage_for_small_batches(monkeypatch):
     full-size tests (tests/test_gpu_full_size.py) put the default back."""
     if "PNA_LZ_SPLIT_MIN" not in os.environ:
         monkeypatch.setenv("PNA_LZ_SPLIT_MIN", "0")
+    # For the same reason the suite switches the LATENCY MODE off (small batches cut into small blocks and LZ units: other kernels' paths, other
+    # model parameters): the headline path is what most tests pin; tests/test_gpu_latency.py covers the mode itself and the library's default.
+    if "PNA_LATENCY_MAX_MIB" not in os.environ:
+        monkeypatch.setenv("PNA_LATENCY_MAX_MIB", "0")
+    # (pna_gpu_init reads both once: contexts are created inside the tests, after this fixture)
 
 
 @pytest.fixture(scope="session")
@@ -62,6 +67,7 @@ def big_ctx(pna, monkeypatch):
     library's defaults (see _split_lz_stage_for_small_batches)."""
     import torch
     monkeypatch.delenv("PNA_LZ_SPLIT_MIN", raising=False)
+    monkeypatch.delenv("PNA_LATENCY_MAX_MIB", raising=False)
     torch.cuda.empty_cache()
     ctx = pna.Context(0)
     yield ctx

@@ -14,11 +14,10 @@ namespace pna {
 
 void launch_lz(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, hipEvent_t) {}
 void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
-                          uint8_t *, uint8_t *, uint32_t *, uint32_t, hipStream_t, hipEvent_t *) {}
+                          uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, hipStream_t, hipEvent_t *) {}
 static uint64_t seg_bytes(const SegDesc &sd) {
     if (sd.len == 0) return 9;
-    const uint32_t nblk = (sd.len + BLK_SIZE - 1) / BLK_SIZE;
-    return 6 + 3ull * nblk + sd.len;
+    return 6 + 3ull * seg_nblk(sd) + sd.len;
 }
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *, const SegTables *, uint64_t *seg_size, uint64_t *seg_off, uint32_t, hipStream_t) {
     uint64_t pos = 0;
@@ -33,8 +32,9 @@ void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const 
         if (sd.len == 0) { static const uint8_t e[9] = {0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00}; memcpy(o, e, 9); continue; }
         static const uint8_t h[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50};
         memcpy(o, h, 6); o += 6;
-        for (uint32_t b0 = 0; b0 < sd.len; b0 += BLK_SIZE) {
-            const uint32_t bl = sd.len - b0 < BLK_SIZE ? sd.len - b0 : BLK_SIZE;
+        const uint32_t bsz = 1u << sd.blk_log;                                      // (small batches run on smaller blocks: latency mode)
+        for (uint32_t b0 = 0; b0 < sd.len; b0 += bsz) {
+            const uint32_t bl = sd.len - b0 < bsz ? sd.len - b0 : bsz;
             const uint32_t hd = (b0 + bl == sd.len ? 1u : 0u) | (bl << 3);          // last | raw (0) << 1 | size << 3
             o[0] = (uint8_t)hd; o[1] = (uint8_t)(hd >> 8); o[2] = (uint8_t)(hd >> 16);
             memcpy(o + 3, src + sd.src_off + b0, bl); o += 3 + bl;

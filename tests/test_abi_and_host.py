@@ -41,7 +41,10 @@ def test_bound_and_levels(pna):
         assert pna.bound(pna.ALGO_ZSTD, n) >= n + 6 * ((n + (1 << 20) - 1) >> 20) + 3 * ((n + (1 << 17) - 1) >> 17)
     # lib/src/compress/zstandard.rs:91-146 and lib/src/compress/deflate.rs:128-187
     assert pna.clamp_level(pna.ALGO_ZSTD) == 3 and pna.clamp_level(pna.ALGO_ZSTD, 100) == 22 and pna.clamp_level(pna.ALGO_ZSTD, 7) == 7
-    assert pna.clamp_level(pna.ALGO_DEFLATE) == 6 and pna.clamp_level(pna.ALGO_DEFLATE, 100) == 9 and pna.clamp_level(pna.ALGO_DEFLATE, -5) == 0
+    assert pna.clamp_level(pna.ALGO_DEFLATE) == 6 and pna.clamp_level(pna.ALGO_DEFLATE, 100) == 9
+    # a negative custom level goes through `value as u32` and clamps to NINE (lib/src/compress/deflate.rs:89-101), 0 stays 0
+    assert pna.clamp_level(pna.ALGO_DEFLATE, -5) == 9 and pna.clamp_level(pna.ALGO_DEFLATE, -1) == 9 and pna.clamp_level(pna.ALGO_DEFLATE, 0) == 0
+    assert pna.clamp_level(pna.ALGO_ZSTD, -5) == -5 and pna.clamp_level(pna.ALGO_ZSTD, -(1 << 20)) == -131072      # zstd min_c_level (zstandard.rs:43-57)
 
 
 def test_crc_and_empty_archive(pna):

@@ -173,11 +173,8 @@ def test_create_archive_encrypted_from_host_memory(gpu_ctx, pna, pf, codec, mode
     mode = pna.MODE_CTR if mode_name == "ctr" else pna.MODE_CBC
     ents = [codec.corpus_file(0, 300 + i, n) for i, n in enumerate([1 << 20, 70000, 0, 3, (1 << 20) + 17, 65536, 250000, 999])] * 3
     names = [f"h/{i:03d}.txt" for i in range(len(ents))]
-    os.environ["PNA_SUB_MIB"] = "16"
-    try:
+    with gpu_ctx.options(sub_mib=(16, 1024)):
         arc = pna.create_archive_encrypted(gpu_ctx, names, ents, b"password", mode=mode, rounds=1000)
-    finally:
-        del os.environ["PNA_SUB_MIB"]
     _, items = pf.read_archive(arc)
     assert [it.name for it in items] == names
     phsfs = {[d for ty, d in it.chunks if ty == b"PHSF"][0] for it in items}

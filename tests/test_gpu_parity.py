@@ -80,7 +80,7 @@ def test_serial_end_scan_is_identical(pna, codec):
         assert o == codec.model_compress(cases[k], p), k
 
 
-@pytest.mark.parametrize("form", ["default", "fused", "waveparse"])
+@pytest.mark.parametrize("form", ["default", "fused", "waveparse", "split"])
 def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     """The LZ stage runs as two kernels by default (k_lz<MODE 1>: look-up / match / inserts -> one word per position in a workspace ->
     k_lzp: parse with one lane per region); PNA_F_LZ_FUSED runs the one-kernel form (k_lz<MODE 0>), PNA_F_LZ_WAVEPARSE the split form with
@@ -99,12 +99,14 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     cases["3 MiB"] = codec.corpus_file(0, 4344, 3 << 20)
     names = sorted(cases)
     data = [cases[k] for k in names]
-    bit = {"default": 0, "fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE}[form]
+    bit = {"default": 0, "fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE, "split": 0}[form]      # ("split": k_lzm + k_lzp, the suite's setting)
     if form == "default":
         monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: short runs through the one-kernel form (the suite's default is 0)
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
         for level, fl in ((1, codec.F_HUF | codec.F_FSE), (2, 0x73), (3, 0x77), (19, 0xF7)):
             outs = ctx.compress_batch(data, level=level)
+            # the form actually taken: the one-kernel form launches no match kernel, the split forms do
+            assert (ctx.timing().lz_match_launches == 0) == (form in ("default", "fused")), form
             pz = codec.params_for_flags(fl)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
@@ -227,13 +229,13 @@ def test_compress_batch_in_pieces(pna, codec, monkeypatch):
         douts = ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
         for e, o in zip(ents, douts):
             assert zlib.decompress(o) == e
-        monkeypatch.setenv("PNA_BATCH_PIECE_MIB", "0")
+        ctx.set_option("batch_piece_mib", 0)
         assert ctx.compress_batch(ents) == outs and ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE) == douts
 
 
 def test_lz_stage_without_workspace_falls_back(pna, codec, monkeypatch):
     """When the words workspace of the split LZ stage cannot be allocated the library halves the run and finally takes the one-kernel form
-    (PNA_LZ_PBUF_FAIL makes every allocation of it fail): same bytes, and the context remembers the smaller run size."""
+    (option lz_pbuf_fail makes every allocation of it fail): same bytes; with the option off again the next call is back on the split form."""
     import torch  # noqa: F401
     monkeypatch.setenv("PNA_LZ_PBUF_FAIL", "1")
     ents = [codec.corpus_file(0, 61, (2 << 20) + 5), codec.corpus_file(1, 62, 70000), b"", codec.corpus_file(0, 63, 1 << 20)]
@@ -243,6 +245,8 @@ def test_lz_stage_without_workspace_falls_back(pna, codec, monkeypatch):
             for e, o in zip(ents, outs):
                 assert o == codec.model_compress(e, _params(codec))
             assert ctx.timing().lz_match_launches == 0          # nothing went through the match kernel
+        ctx.set_option("lz_pbuf_fail", 0)
+        assert ctx.compress_batch(ents) == outs and ctx.timing().lz_match_launches > 0     # a failed allocation is not remembered
 
 
 @pytest.mark.parametrize("form", [0x1000, 0x2000])
@@ -594,11 +598,8 @@ def test_host_pipeline_many_sub_batches(gpu_ctx, pna, pf, codec):
     ents = [host[i * L:(i + 1) * L].tobytes() for i in range(n)]
     ents[5] = b""; ents[6] = ents[6][:12345]
     names = [f"p/{i:04d}" for i in range(n)]
-    os.environ["PNA_SUB_MIB"] = "128"                      # several sub-batches (the default window is 1 GiB per slot)
-    try:
+    with gpu_ctx.options(sub_mib=(128, 1024)):           # several sub-batches (the default window is 1 GiB per slot)
         arc = pna.create_archive(gpu_ctx, names, ents)
-    finally:
-        del os.environ["PNA_SUB_MIB"]
     _, items = pf.read_archive(arc)
     assert [it.name for it in items] == names and [it.raw_file_size for it in items] == [len(e) for e in ents]
     for i in (0, 5, 6, 255, 256, 257, 511, 512, 699):
@@ -791,11 +792,8 @@ def test_large_payload_is_cut_into_several_fdat_chunks(gpu_ctx, pna, pf, codec):
             src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
     cap = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
     dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    os.environ["PNA_FDAT_MAX_MIB"] = "1"
-    try:
+    with gpu_ctx.options(fdat_max_mib=(1, 1024)):
         total, _ = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap)
-    finally:
-        del os.environ["PNA_FDAT_MAX_MIB"]
     got = dst[:total].cpu().numpy().tobytes()
     # expected: frames of the 1 MiB segments, grouped greedily while the group stays within 1 MiB (at least one segment per group)
     want = pf.write_archive_header()
@@ -1084,12 +1082,8 @@ def test_extract_driver_windows(gpu_ctx, pna, pf, codec):
     mixed = pf.write_archive_header() + b"".join(pf.write_chunk(t, d) for t, d in chunks[:cut] + so_chunks + chunks[cut:]) + pf.finalize_archive()
     want = [(n, d) for n, d in zip(names[:4], ents[:4])] + [("s/a", ents[0]), ("s/b", ents[4])] + [(n, d) for n, d in zip(names[4:], ents[4:])]
     for win in (None, "1", "3"):
-        if win:
-            os.environ["PNA_EXTRACT_WIN_MIB"] = win
-        try:
+        with gpu_ctx.options(extract_win_mib=(int(win) if win else 1024, 1024)):
             got = pna.extract_archive(gpu_ctx, mixed)
-        finally:
-            os.environ.pop("PNA_EXTRACT_WIN_MIB", None)
         assert [(n, d) for n, _, d in got] == want, win
 
 
@@ -1214,11 +1208,8 @@ def test_device_inflate_lane_per_piece_paths(gpu_ctx, pna, codec):
     assert sum(max(1, (len(r) + 131071) // 131072) for r in raws) >= 1024
     got = gpu_ctx.decompress_batch(comps, [len(r) for r in raws], algo=pna.ALGO_DEFLATE)
     assert got == raws
-    os.environ["PNA_INFLATE_SERIAL"] = "1"
-    try:
+    with gpu_ctx.options(inflate_serial=(1, 0)):
         assert gpu_ctx.decompress_batch(comps, [len(r) for r in raws], algo=pna.ALGO_DEFLATE) == raws
-    finally:
-        del os.environ["PNA_INFLATE_SERIAL"]
     # corrupt input in a lane batch is refused all the same (after the hand-over): a flipped bit, a wrong size, a bad Adler-32
     for k, mut in ((3, lambda z: z[:100] + bytes([z[100] ^ 4]) + z[101:]), (200, lambda z: z[:-1] + bytes([z[-1] ^ 1]))):
         bad = list(comps); bad[k] = mut(bad[k])
