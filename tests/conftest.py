@@ -56,6 +56,11 @@ def pna():
 def gpu_ctx(pna):
     import torch  # noqa: F401  (shares its HIP runtime with the extension)
     ctx = pna.Context(0)
+    # (a session fixture is set up before the function-scoped one above has touched the environment: say it here)
+    if "PNA_LZ_SPLIT_MIN" not in os.environ or os.environ["PNA_LZ_SPLIT_MIN"] == "0":
+        ctx.set_option("lz_split_min", 0)
+    if "PNA_LATENCY_MAX_MIB" not in os.environ or os.environ["PNA_LATENCY_MAX_MIB"] == "0":
+        ctx.set_option("latency_max_mib", 0)
     yield ctx
     ctx.close()
 
