@@ -68,6 +68,8 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *                                         blocks inside the same frames and one LZ workgroup per unit instead of per segment, so that a handful
  *                                         of entries -- the CompressionWriter seam under the reference's thread pool -- fills the chip.  Same
  *                                         format, same decoders; ratio -0.1 .. -0.3 % (block headers).  pna_gpu_last_timing reports what was chosen.
+ *   "hist_by_block" [PNA_HIST_BY_BLOCK]   zstd entropy stage with statistics per block and three-lane state chains (1) or per segment and the one-kernel
+ *                                         sequence coder (0); -1 (default): the first up to 40 960 blocks per sub-batch.  Same bytes either way.
  *   "lz_split" [PNA_LZ_SPLIT]             0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 1 025)

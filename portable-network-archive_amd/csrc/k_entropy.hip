@@ -3,11 +3,13 @@
 //            Huffman code (<= 11 bits) + tree description and the three FSE tables + descriptions.
 //   k_lit    one workgroup per block: RLE test and 1- or 4-stream Huffman bit packing (one wave per stream,
 //            wave scan of bit lengths, 32-bit atomic OR into the zeroed body).
-//   k_seqa   one LANE per block, the lanes of one segment sharing the segment's tables in LDS: the serial tANS
-//            state chain of the sequences bitstream -- states only: per sequence the three state flushes as one field.
+//   k_hist   one workgroup per block (batches of up to 40 960 blocks): the histograms of k_stats gathered per block into per-segment
+//            counters, and every sequence's three codes for k_seqa.
+//   k_seqa   three LANES per block, one per FSE stream: the serial tANS state chain -- states only: per sequence and stream the
+//            state flush.
 //   k_seqb   one workgroup per block: the sequences bitstream assembled token-parallel from those fields and the
 //            extra bits (prefix sums of the field lengths, 64-bit ORs into an LDS stage, coalesced stores).
-//   k_plan   one thread per segment: block types, which block carries the table descriptions, sizes.
+//   k_plan   one wave per segment, a lane per block: block types, which block carries the table descriptions, sizes.
 //   k_scan   exclusive scan of segment sizes -> output offsets.
 //   k_write  one workgroup per block: frame/block/section headers + payload into the packed output.
 // Replaces libzstd's HUF_compress4X / ZSTD_encodeSequences / block+frame assembly behind
@@ -253,9 +255,61 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
     return true;
 }
 
+// k_hist: the histograms of k_stats with one workgroup per BLOCK, added into the segment's 448 counters in memory (256 literal bytes, 3 x 64
+// codes) -- for batches whose segments are few and cut into many blocks (latency mode) the statistics of a segment are then gathered by up to
+// 128 workgroups instead of one; k_stats<true> builds the tables from the counters.
+constexpr uint32_t HIST_WORDS = 256 + 3 * 64;
+__global__ __launch_bounds__(ST_THREADS)
+void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
+            const BlkInfo *__restrict__ blk, uint32_t *__restrict__ hist, uint16_t *__restrict__ seqw, uint32_t g0) {
+    __shared__ uint32_t h_lit[8][256];
+    __shared__ uint32_t h_seq[3][4][64];
+    __shared__ uint8_t s_llc[64], s_mlc[128], s_llb[64], s_mlb[128];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x + g0;
+    const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
+    for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
+    if (tid < 64) { s_llc[tid] = C_LL_CODE[tid]; s_llb[tid] = C_LL_BITS[C_LL_CODE[tid]]; }
+    if (tid < 128) { s_mlc[tid] = C_ML_CODE[tid]; s_mlb[tid] = C_ML_BITS[C_ML_CODE[tid]]; }
+    __syncthreads();
+    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    uint32_t *hl = h_lit[tid & 7];
+    const uint32_t n16 = nlit >> 4;
+    for (uint32_t i = tid; i < n16; i += ST_THREADS) {
+        uint4 v = ((const uint4 *)bl)[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(&hl[w[k] & 0xFF], 1u); atomicAdd(&hl[(w[k] >> 8) & 0xFF], 1u);
+            atomicAdd(&hl[(w[k] >> 16) & 0xFF], 1u); atomicAdd(&hl[w[k] >> 24], 1u);
+        }
+    }
+    for (uint32_t j = (n16 << 4) + tid; j < nlit; j += ST_THREADS) atomicAdd(&hl[bl[j]], 1u);
+    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+    uint16_t *bw = seqw + (size_t)g * SEQ_CAP * 4;                      // three arrays of SEQ_CAP u16: LL, OF, ML
+    for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
+        const uint64_t s = bs[i];
+        const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
+        const uint32_t lc = llv < 64 ? (uint32_t)s_llc[llv] : hb(llv) + 19, lx = llv < 64 ? (uint32_t)s_llb[llv] : hb(llv);
+        const uint32_t oc = hb(seq_off(s) + 3);
+        const uint32_t mc = mb < 128 ? (uint32_t)s_mlc[mb] : hb(mb) + 36, mx = mb < 128 ? (uint32_t)s_mlb[mb] : hb(mb);
+        atomicAdd(&h_seq[0][tid & 3][lc], 1u);
+        atomicAdd(&h_seq[1][tid & 3][oc], 1u);
+        atomicAdd(&h_seq[2][tid & 3][mc], 1u);
+        // for the chain kernel (k_seqa): per stream the sequence's code and its number of extra bits, a u16; k_seqa puts its state flushes in their place
+        bw[i] = (uint16_t)(lc | (lx << 8)); bw[SEQ_CAP + i] = (uint16_t)(oc | (oc << 8)); bw[2 * SEQ_CAP + i] = (uint16_t)(mc | (mx << 8));
+    }
+    __syncthreads();
+    uint32_t *hs = hist + (size_t)blk_seg[g] * HIST_WORDS;
+    { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; if (c) atomicAdd(&hs[tid], c); }
+    if (tid < 192) { const uint32_t w = tid >> 6, s = tid & 63, c = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; if (c) atomicAdd(&hs[256 + tid], c); }
+}
+
+// PRE: the histograms were gathered by k_hist (`hist`, 448 counters per segment); otherwise this workgroup walks the segment's blocks itself
+template <bool PRE>
 __global__ __launch_bounds__(ST_THREADS)
 void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
-             const BlkInfo *__restrict__ blk, SegTables *__restrict__ tabs, uint32_t flags) {
+             const BlkInfo *__restrict__ blk, SegTables *__restrict__ tabs, uint32_t flags, const uint32_t *__restrict__ hist) {
     __shared__ uint32_t h_lit[8][256];
     __shared__ uint32_t h_seq[3][4][64];
     __shared__ uint32_t count[256];
@@ -287,7 +341,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     }
     __syncthreads();
     uint32_t nseq_seg = 0;
-    for (uint32_t b = 0; b < nblk; b++) {
+    for (uint32_t b = 0; b < (PRE ? 0u : nblk); b++) {
         const uint32_t g = sd.blk_base + b;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         nseq_seg += nseq;
@@ -314,8 +368,16 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         }
     }
     __syncthreads();
-    { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; count[tid] = c; }
-    if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63; scount[w][s] = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; }
+    if (PRE) {
+        const uint32_t *hs = hist + (size_t)blockIdx.x * HIST_WORDS;
+        count[tid] = hs[tid];
+        if (tid < 192) scount[tid >> 6][tid & 63] = hs[256 + tid];
+        __syncthreads();
+        for (uint32_t s = 0; s < 36; s++) nseq_seg += scount[0][s];             // every sequence has one literal-length code
+    } else {
+        { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; count[tid] = c; }
+        if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63; scount[w][s] = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; }
+    }
     __syncthreads();
     // ---- tables: wave 0 builds the literal code, lane 0 of waves 1..3 one sequence table each (LL, OF, ML), concurrently
     const uint32_t wave = tid >> 6, lane = tid & 63;
@@ -488,102 +550,90 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
 }
 
 // ------------------------------------------------------------------ k_seqa / k_seqb : sequence bitstreams in two phases
-// The FSE states of a block form one serial chain (each sequence's state depends on the next one's), but only the STATES do: the
-// extra bits of the literal length / match length / offset and the position of every field follow from prefix sums.  So the chain
-// kernel k_seqa (one LANE per block, the lanes of a segment sharing its tables in LDS) walks the sequences last to first and records,
-// per sequence, just the three state flushes as one field (<= 24 bits + its length, one u32) and counts the stream's bits; k_seqb
-// (one workgroup per block) then assembles the bitstream token-parallel: 256 sequences per round, field lengths -> workgroup scan ->
-// 64-bit ORs into an LDS stage -> coalesced stores.  The chain is ~3x shorter than with the bit packing inside it (it was ~350
-// dependent instructions per sequence), and the chain's latency is what bounds this stage -- for one entry as for ten thousand.
-constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // 8 segments x 8 blocks = 64 lanes (blocks of BLK_SIZE; in latency mode a segment has 16 .. 128 smaller
+// The FSE states of a block form serial chains (each sequence's state depends on the next one's), but only the STATES do: the extra
+// bits of the literal length / match length / offset and the position of every field follow from prefix sums, and the three streams'
+// states do not depend on each other.  So the chain kernel k_seqa (three lanes per block, one per stream) walks the sequences last to
+// first and records per sequence and stream just the state flush (<= 8 bits + their count, a u16); k_seqb (one workgroup per block)
+// then assembles the bitstream token-parallel: 256 sequences per round, field lengths -> workgroup scan -> 64-bit ORs into an LDS
+// stage -> coalesced stores.  History: one lane per block with the bit packing inside the chain ~350 instructions per sequence (k_seq,
+// still the form for the largest batches: it touches the sequences once), states only ~95, one stream per lane with the codes prepared
+// by k_hist ~20 -- and the chain's length times its instructions is what bounds this stage, for one entry as for ten thousand.
+constexpr uint32_t SEQ_SEGS_PER_WG = 64 / BLK_PER_SEG;   // k_seq: 8 segments x 8 blocks = 64 lanes (blocks of BLK_SIZE; in latency mode a segment has 16 .. 128 smaller
                                                           // blocks, a wave then carries 4, 2, 1 or half a segment: bps_log = log2(blocks per full segment))
-constexpr uint32_t SEQ_TWO_PHASE_MAX_BLOCKS = 40960;    // 640 chain waves: at most one per SIMD with room to spare (256 CUs x 4 SIMDs)
-static_assert(SEQ_MAX_LOG <= 8, "k_seqa packs three state flushes into 24 bits and the final states into 3 x 8 bits");
+static_assert(SEQ_MAX_LOG <= 8, "k_seqa: a state flush is at most 8 bits (12 are kept), the final states go into 3 x 8 bits");
 
+// k_seqa: THREE lanes per block, one per FSE stream (literal lengths, offsets, match lengths: their state chains are independent of each other), 21
+// blocks per wave.  A lane's step per sequence is what is serial about the stream -- nb = (state + delta_nb) >> 16, the flushed bits, the next state
+// from the table in LDS -- and nothing else: the code and the count of extra bits of every sequence were put down by k_hist (token-parallel), and the
+// lane writes its flush (bits | count << 12, a u16) in their place for k_seqb.  A wave issues one instruction every few cycles whatever its lanes do, so
+// the time of this kernel is (instructions per step) x (sequences per block): ~20 x 1 000 in latency mode, where it was ~95 x 1 000 with one lane
+// doing all three streams and the code look-ups.
+constexpr uint32_t SEQA_BLKS = 21, SEQA_MAXSEG = 5;         // blocks per wave; segments those can span (>= 8 block slots per segment: 21 slots touch at most 4)
 __global__ __launch_bounds__(64)
-void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
-            const SegTables *__restrict__ tabs, uint32_t *__restrict__ seqw, uint32_t bps_log) {
-    __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
-    __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
-    __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 (small values only)
+void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs,
+            uint16_t *__restrict__ seqw, uint32_t bps_log) {
+    __shared__ SeqTable tab[SEQA_MAXSEG][3];
+    __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to (0 bits per step, the state stays 0)
     const uint32_t lane = threadIdx.x;
-    const uint32_t seg0 = (blockIdx.x * 64u) >> bps_log;
-    const uint32_t segs_wg = bps_log >= 6 ? 1u : 64u >> bps_log;
+    const uint32_t vb0 = blockIdx.x * SEQA_BLKS;
+    const uint32_t seg0 = vb0 >> bps_log, seg1 = (vb0 + SEQA_BLKS - 1) >> bps_log;
     for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
-    { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8); }
-    for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8); }
-    for (uint32_t s = 0; s < segs_wg && seg0 + s < nseg; s++) {
-        const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
-        uint32_t *dstw = (uint32_t *)&tab[s][0];
+    for (uint32_t s = seg0; s <= seg1 && s < nseg && s - seg0 < SEQA_MAXSEG; s++) {
+        const uint32_t *srcw = (const uint32_t *)&tabs[s].tab[0];
+        uint32_t *dstw = (uint32_t *)&tab[s - seg0][0];
         for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
     }
     __syncthreads();
-    const uint32_t vb = blockIdx.x * 64u + lane;                       // lane -> (segment, block): block slot vb of the launch, 1 << bps_log slots per segment
-    const uint32_t sidx = vb >> bps_log, sl = sidx - seg0, b = vb & ((1u << bps_log) - 1);
-    if (sidx >= nseg) return;
+    const uint32_t slot = lane / 3, st = lane - 3 * slot;              // st: 0 literal lengths, 1 offsets, 2 match lengths (the order of SegTables::tab)
+    const uint32_t vb = vb0 + slot;
+    const uint32_t sidx = vb >> bps_log, b = vb & ((1u << bps_log) - 1);
+    if (lane >= 3 * SEQA_BLKS || sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
-    const uint32_t nblk = seg_nblk(sd);
-    if (b >= nblk) return;
+    if (b >= seg_nblk(sd)) return;
     const uint32_t g = sd.blk_base + b;
     const SegTables *T = tabs + sidx;
     const uint32_t nseq = blk[g].nseq;
-    if (nseq == 0 || !T->seq_ok) { blk[g].seq_bits = 0; return; }
-    const uint32_t mll = T->mode[0], mof = T->mode[1], mml = T->mode[2];
-    const uint32_t tl_ll = T->tlog[0], tl_of = T->tlog[1], tl_ml = T->tlog[2];
-    // RLE mode (one symbol, no state bits) runs through the same code on an all-zero table: delta_nb = 0 gives 0 bits, state[0] = 0
-    // keeps the state at 0 -- no per-sequence branch on the mode
-    const SeqTable *tll = mll == 1 ? &ztab : &tab[sl][0], *tof = mof == 1 ? &ztab : &tab[sl][1], *tml = mml == 1 ? &ztab : &tab[sl][2];
-    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    uint4 *w4 = (uint4 *)(seqw + (size_t)g * SEQ_CAP);
-    // Sequences are consumed last-to-first in 32-byte chunks (4 sequences, two 16-byte loads per lane); the next chunk is
-    // requested before the current one is walked so the HBM/L2 latency overlaps the chain.
-    uint32_t st_ml = 0, st_of = 0, st_ll = 0, bits_total = 0;
-    const uint32_t top = nseq - 1;
-    uint32_t k = top >> 2;
-    const uint4 *bs4 = (const uint4 *)bs;
-    uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
+    if (nseq == 0 || !T->seq_ok) { if (st == 0) blk[g].seq_bits = 0; return; }
+    const uint32_t mode = T->mode[st], tlog = T->tlog[st];
+    const SeqTable *tb = mode == 1 ? &ztab : &tab[sidx - seg0][st];
+    uint16_t *w = seqw + (size_t)g * SEQ_CAP * 4 + (size_t)st * SEQ_CAP;   // this stream's u16 per sequence (k_hist: code | extra bits << 8)
+    uint32_t state = 0, bits = 0;
+    // Sequences last to first in groups of eight (one 16-byte load, one 16-byte store); the next group is requested before the current one is walked.
+    // The block's last sequence only sets the initial state.
+    uint4 *w8 = (uint4 *)w;
+    int32_t j = (int32_t)((nseq - 1) >> 3);
+    uint4 cur = w8[j];
     bool first = true;
-    for (;;) {
-        uint4 n0 = a0, n1 = a1;
-        if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
-        const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
-                                (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
-        uint32_t rec[4] = {0, 0, 0, 0};
+    for (; j >= 0; j--) {
+        uint4 nxt = cur;
+        if (j > 0) nxt = w8[j - 1];
+        const uint32_t cw32[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t out[4] = {0, 0, 0, 0};
+        const int32_t top = (int32_t)(nseq - 1) - 8 * j;                // highest sequence of the group that exists (7 but in the top group)
 #pragma unroll
-        for (int j = 3; j >= 0; j--) {
-            if (4 * k + (uint32_t)j > top) continue;
-            const uint32_t llv = seq_ll(sq[j]), mb = seq_ml(sq[j]) - 3, ofb = seq_off(sq[j]) + 3;
-            // code and extra-bit count: LDS LUT for small values, arithmetic above (code = highbit + 19 / 36), selected without a branch
-            const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
-            const uint32_t lc = llv < 64 ? (tl & 0xFF) : hl + 19, lbits = llv < 64 ? (tl >> 8) : hl;
-            const uint32_t tm = lut_ml[mb < 128 ? mb : 127u], hm = hb(mb | 1u);
-            const uint32_t mc = mb < 128 ? (tm & 0xFF) : hm + 36, mbits = mb < 128 ? (tm >> 8) : hm;
-            const uint32_t oc = hb(ofb);
-            const SeqSym yo = tof->sym[oc], ym = tml->sym[mc], yl = tll->sym[lc];
-            uint32_t nst = 0;
-            if (first) {                                       // the last sequence of the block only sets the initial states
-                st_ml = ym.first_state; st_of = yo.first_state; st_ll = yl.first_state;
-                first = false;
-            } else {
-                // the three state flushes (<= 8 bits each) as one field: offset state lowest, then match length, then literal length
-                const uint32_t no = (st_of + yo.delta_nb) >> 16, nm = (st_ml + ym.delta_nb) >> 16, nl = (st_ll + yl.delta_nb) >> 16;
-                const uint32_t fv = (st_of & ((1u << no) - 1)) | ((st_ml & ((1u << nm) - 1)) << no) | ((st_ll & ((1u << nl) - 1)) << (no + nm));
-                st_of = tof->state[(int)(st_of >> no) + yo.delta_find];
-                st_ml = tml->state[(int)(st_ml >> nm) + ym.delta_find];
-                st_ll = tll->state[(int)(st_ll >> nl) + yl.delta_find];
-                nst = no + nm + nl;
-                rec[j] = fv | (nst << 24);
+        for (int k = 7; k >= 0; k--) {
+            if (k > top) continue;
+            const uint32_t cw = (cw32[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            const SeqSym y = tb->sym[cw & 0xFF];
+            uint32_t rec = 0;
+            if (first) { state = y.first_state; first = false; }
+            else {
+                const uint32_t nb = (state + y.delta_nb) >> 16;
+                rec = (state & ((1u << nb) - 1)) | (nb << 12);
+                state = tb->state[(int)(state >> nb) + y.delta_find];
+                bits += nb;
             }
-            bits_total += nst + lbits + mbits + oc;
+            bits += cw >> 8;
+            out[k >> 1] |= rec << (16 * (k & 1));
         }
-        w4[k] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-        if (k == 0) break;
-        k--; a0 = n0; a1 = n1;
+        w8[j] = make_uint4(out[0], out[1], out[2], out[3]);
+        cur = nxt;
     }
-    // the final states and the closing 1-bit are appended by k_seqb
-    bits_total += (mml != 1 ? tl_ml : 0u) + (mof != 1 ? tl_of : 0u) + (mll != 1 ? tl_ll : 0u) + 1u;
-    blk[g].pad = (st_ml & ((1u << tl_ml) - 1)) | ((st_of & ((1u << tl_of) - 1)) << 8) | ((st_ll & ((1u << tl_ll) - 1)) << 16);
-    blk[g].seq_bits = (bits_total + 7) >> 3;
+    // the block's bit count: the three streams' sums + the final states + the closing bit; the final states go to BlkInfo::pad (zero so far), ML | OF << 8 | LL << 16
+    bits += mode != 1 ? tlog : 0u;
+    const uint32_t b1 = (uint32_t)__shfl((int)bits, (int)(3 * slot + 1)), b2 = (uint32_t)__shfl((int)bits, (int)(3 * slot + 2));
+    atomicOr(&blk[g].pad, (state & ((1u << tlog) - 1)) << (st == 2 ? 0 : (st == 1 ? 8 : 16)));
+    if (st == 0) blk[g].seq_bits = (bits + b1 + b2 + 1 + 7) >> 3;
 }
 
 // The one-kernel form: the same chain with the bit packing inside it (~350 instructions per sequence instead of ~95).  Slower per
@@ -696,7 +746,7 @@ constexpr uint32_t SB_THREADS = 256;
 constexpr uint32_t SB_STAGE_Q = 320;                    // 256 sequences x <= 76 bits = 304 qwords, + the carried partial one
 
 __global__ __launch_bounds__(SB_THREADS)
-void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint32_t *__restrict__ seqw,
+void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint16_t *__restrict__ seqw,
             const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t g0) {
     __shared__ unsigned long long st[SB_STAGE_Q];
     __shared__ uint32_t wtot[SB_THREADS / 64];
@@ -713,7 +763,7 @@ void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
     __syncthreads();
     unsigned long long *out64 = (unsigned long long *)(seqc + (size_t)g * BLK_SIZE);
     const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    const uint32_t *w = seqw + (size_t)g * SEQ_CAP;
+    const uint16_t *w = seqw + (size_t)g * SEQ_CAP * 4;              // k_seqa's flushes (bits | count << 12): arrays LL, OF, ML
     uint32_t pos = 0, qfl = 0;                                          // next free bit of the stream; st[0] holds stream qword qfl
     for (uint32_t hi = n; hi > 0; hi = hi > SB_THREADS ? hi - SB_THREADS : 0u) {
         // thread t takes sequence hi - 1 - t: later sequences lie at lower bit positions
@@ -721,15 +771,17 @@ void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
         if (tid < hi) {
             const uint32_t i = hi - 1 - tid;
             const uint64_t s = bs[i];
-            const uint32_t rec = w[i];
+            const uint32_t rl = w[i], ro = w[SEQ_CAP + i], rm = w[2 * SEQ_CAP + i];
             const uint32_t llv = seq_ll(s), mlv = seq_ml(s), mb = mlv - 3, ofb = seq_off(s) + 3;
             const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
             const uint32_t lbits = llv < 64 ? (tl & 0xFF) : hl, lbase = llv < 64 ? (tl >> 8) : (1u << hl);
             const uint32_t tm = lut_ml[mb < 128 ? mb : 127u], hm = hb(mb | 1u);
             const uint32_t mbits = mb < 128 ? (tm & 0xFF) : hm, mbase = mb < 128 ? (tm >> 8) : ((1u << hm) + 3);
             oc = hb(ofb); oval = ofb - (1u << oc);
-            const uint32_t nst = rec >> 24;
-            lo64 = (unsigned long long)(rec & 0xFFFFFFu) | ((unsigned long long)(llv - lbase) << nst) | ((unsigned long long)(mlv - mbase) << (nst + lbits));
+            const uint32_t no = ro >> 12, nm = rm >> 12, nl = rl >> 12, nst = no + nm + nl;
+            // the three state flushes as one field: offset state lowest, then match length, then literal length
+            const uint32_t fv = (ro & 0xFFFu) | ((rm & 0xFFFu) << no) | ((rl & 0xFFFu) << (no + nm));
+            lo64 = (unsigned long long)fv | ((unsigned long long)(llv - lbase) << nst) | ((unsigned long long)(mlv - mbase) << (nst + lbits));
             nlo = nst + lbits + mbits;                                  // <= 24 + 16 + 16
         }
         const uint32_t tot = nlo + oc;
@@ -780,62 +832,97 @@ void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
     }
 }
 
-// ------------------------------------------------------------------ k_plan : one thread per segment
+// ------------------------------------------------------------------ k_plan
 __device__ __forceinline__ uint32_t raw_lit_hdr(uint32_t nlit) { return nlit < 32 ? 1u : (nlit < 4096 ? 2u : 3u); }
 __device__ __forceinline__ uint32_t nseq_hdr(uint32_t nseq) { return nseq < 128 ? 1u : (nseq < 0x7F00 ? 2u : 3u); }
 
-__global__ void k_plan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk,
-                       const SegTables *__restrict__ tabs, uint64_t *__restrict__ seg_size, uint32_t flags) {
-    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per segment, a lane per block (64 at a time).  Which block carries the segment's Huffman tree / FSE table descriptions is a serial rule --
+// the first block that uses them --, but the state (tree seen, tables seen) changes at most twice along a segment: every lane evaluates its block
+// under the current state, the first lane whose block changes the state settles everything up to itself, and the rest is evaluated again; sizes by a
+// wave scan.  (One thread per segment walked up to 128 blocks with dependent loads: 40 us for a single segment in latency mode.)
+constexpr uint32_t PLAN_THREADS = 256;
+__global__ __launch_bounds__(PLAN_THREADS)
+void k_plan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk,
+            const SegTables *__restrict__ tabs, uint64_t *__restrict__ seg_size, uint32_t flags) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t sidx = blockIdx.x * (PLAN_THREADS / 64) + (threadIdx.x >> 6);
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
     const SegTables *T = tabs + sidx;
     const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
+    if (sd.len == 0) { if (lane == 0) seg_size[sidx] = 9; return; }     // empty entry: the reference's 9-byte empty frame
     const uint32_t desc_total = T->desc_len[0] + T->desc_len[1] + T->desc_len[2];
-    bool have_huf = false, have_seq = false;
+    const uint32_t seq_ok = T->seq_ok, huf_ok = T->huf_ok, tree_len = T->tree_len;
+    bool have_huf = false, have_seq = false;                            // (uniform)
     uint64_t off = 6;
-    if (sd.len == 0) { seg_size[sidx] = 9; return; }           // empty entry: the reference's 9-byte empty frame
-    for (uint32_t b = 0; b < nblk; b++) {
-        const uint32_t g = sd.blk_base + b;
-        const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
-        const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
-        const bool ok = T->seq_ok || nseq == 0;
+    for (uint32_t c0 = 0; c0 < nblk; c0 += 64) {
+        const uint32_t b = c0 + lane, n = nblk - c0 < 64 ? nblk - c0 : 64u;
+        const bool in = lane < n;
+        const uint32_t g = sd.blk_base + (in ? b : c0);
+        const uint32_t b0 = (in ? b : c0) * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
+        const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq, lit_rle = blk[g].lit_rle, lit_body = blk[g].lit_body, seq_bits = blk[g].seq_bits;
         uint32_t plan = 0, csz = 0;
-        if (ok) {
-            const uint32_t raw_h = raw_lit_hdr(nlit);
-            const bool rle = (flags & F_HUF) && nlit >= 64 && blk[g].lit_rle;
-            if (rle) { csz = raw_h + 1; plan |= 16; }
-            else {
-                const uint32_t hs = (T->huf_ok && nlit >= 64) ? blk[g].lit_body : 0;
-                const uint32_t lh = 3 + (nlit >= 1024) + (nlit >= 16384), ts = have_huf ? 0 : T->tree_len;
-                if (hs && lh + ts + hs < raw_h + nlit) { csz = lh + ts + hs; plan |= 2; if (!have_huf) plan |= 4; }
-                else csz = raw_h + nlit;
+        uint32_t pos = 0;                                               // lanes below it are settled
+        for (;;) {
+            const bool ok = seq_ok || nseq == 0;
+            uint32_t p = 0, cs = 0;
+            if (ok) {
+                const uint32_t raw_h = raw_lit_hdr(nlit);
+                const bool rle = (flags & F_HUF) && nlit >= 64 && lit_rle;
+                if (rle) { cs = raw_h + 1; p |= 16; }
+                else {
+                    const uint32_t hs = (huf_ok && nlit >= 64) ? lit_body : 0;
+                    const uint32_t lh = 3 + (nlit >= 1024) + (nlit >= 16384), ts = have_huf ? 0 : tree_len;
+                    if (hs && lh + ts + hs < raw_h + nlit) { cs = lh + ts + hs; p |= 2; if (!have_huf) p |= 4; }
+                    else cs = raw_h + nlit;
+                }
+                cs += nseq_hdr(nseq);
+                if (nseq) { cs += 1 + (have_seq ? 0 : desc_total) + seq_bits; if (!have_seq) p |= 8; }
             }
-            csz += nseq_hdr(nseq);
-            if (nseq) { csz += 1 + (have_seq ? 0 : desc_total) + blk[g].seq_bits; if (!have_seq) plan |= 8; }
+            bool comp = true;
+            if (!ok || cs >= bl_len) { p = 0; cs = bl_len; comp = false; } else p |= 1;
+            const bool s_huf = comp && (p & 2) && !have_huf, s_seq = comp && nseq && !have_seq;
+            const uint64_t m = __ballot((s_huf || s_seq) && in && lane >= pos);
+            const uint32_t f = m ? (uint32_t)__builtin_ctzll(m) : 63u;
+            if (lane >= pos && lane <= f) { plan = p; csz = cs; }
+            if (!m) break;
+            have_huf = have_huf || ((__ballot(s_huf) >> f) & 1);
+            have_seq = have_seq || ((__ballot(s_seq) >> f) & 1);
+            pos = f + 1;
+            if (pos >= n) break;
         }
-        if (!ok || csz >= bl_len) { plan = 0; csz = bl_len; }
-        else { plan |= 1; if (plan & 2) have_huf = true; if (nseq) have_seq = true; }
-        blk[g].plan = plan; blk[g].out_size = 3 + csz; blk[g].out_off = off;
-        off += 3 + csz;
+        const uint32_t sz = in ? 3 + csz : 0u;
+        uint32_t incl = sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += t; }
+        if (in) { blk[g].plan = plan; blk[g].out_size = sz; blk[g].out_off = off + (incl - sz); }
+        off += (uint32_t)__shfl((int)incl, 63);
     }
-    seg_size[sidx] = off;
+    if (lane == 0) seg_size[sidx] = off;
 }
 
 // ------------------------------------------------------------------ k_scan : exclusive scan (single workgroup)
 __global__ __launch_bounds__(1024)
 void k_scan(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n) {
-    __shared__ uint64_t part[1024];
+    __shared__ uint64_t part[2][1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023) / 1024;
     const uint32_t a = tid * per, e = a + per < n ? a + per : n;
     uint64_t s = 0;
     for (uint32_t i = a; i < e; i++) s += in[i];
-    part[tid] = s;
+    // inclusive scan of the 1 024 partial sums in LDS (log steps, two buffers)
+    uint32_t cur = 0;
+    part[0][tid] = s;
     __syncthreads();
-    if (tid == 0) { uint64_t r = 0; for (uint32_t i = 0; i < 1024; i++) { uint64_t t = part[i]; part[i] = r; r += t; } out[n] = r; }
-    __syncthreads();
-    uint64_t r = part[tid];
+    const uint32_t nact = per ? (n + per - 1) / per : 0;                // threads that hold anything
+    for (uint32_t d = 1; d < 1024 && d < nact; d <<= 1) {
+        const uint64_t v = part[cur][tid] + (tid >= d ? part[cur][tid - d] : 0ull);
+        part[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    uint64_t r = part[cur][tid] - s;
+    if (tid == 0) out[n] = nact ? part[cur][nact - 1] : 0ull;           // (threads from nact on hold nothing and were not scanned to the end)
     for (uint32_t i = a; i < e; i++) { out[i] = r; r += in[i]; }
 }
 
@@ -940,17 +1027,23 @@ void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st
 // sequence streams.  `tabs`, `segs` are the arrays of the whole batch.
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, uint32_t blk_log, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
+                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
     const uint32_t bps_log = 20u - blk_log;                                 // blocks per full segment (SEG_SIZE = 1 MiB)
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
-    hipLaunchKernelGGL(k_stats, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags);
+    if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
+        if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0);
+        hipLaunchKernelGGL(k_stats<true>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
+    } else
+        hipLaunchKernelGGL(k_stats<false>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0);
     if (ev) (void)hipEventRecord(ev[1], st);
-    // two phases (short chain, parallel packing) while the chain waves fit the SIMDs, the one-kernel form beyond (see k_seq)
-    if (!(flags & 0x1000u) && (nb <= SEQ_TWO_PHASE_MAX_BLOCKS || (flags & 0x2000u))) {
-        hipLaunchKernelGGL(k_seqa, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqw, bps_log);
-        if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, seqw, blk, tabs, seqc, g0);
+    // two phases (short chains on three lanes per block, parallel packing) for the batches whose statistics were gathered per block (the host
+    // picks them: few enough blocks that the chain waves fit the SIMDs), the one-kernel form otherwise (see k_seq)
+    if (hist) {
+        const uint32_t wgs = (uint32_t)((((uint64_t)ns << bps_log) + SEQA_BLKS - 1) / SEQA_BLKS);
+        hipLaunchKernelGGL(k_seqa, dim3(wgs), dim3(64), 0, st, segs + s0, ns, blk, tabs + s0, (uint16_t *)seqw, bps_log);
+        if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, (const uint16_t *)seqw, blk, tabs, seqc, g0);
     } else {
         hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }
@@ -959,13 +1052,13 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
 // sizes of all segments -> offsets
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st) {
-    hipLaunchKernelGGL(k_plan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, tabs, seg_size, flags);
+    hipLaunchKernelGGL(k_plan, dim3((nseg + PLAN_THREADS / 64 - 1) / (PLAN_THREADS / 64)), dim3(PLAN_THREADS), 0, st, segs, nseg, blk, tabs, seg_size, flags);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, seg_size, seg_off, nseg);
 }
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
-                  const uint8_t *seqc, uint8_t *dst, hipStream_t st) {
-    hipLaunchKernelGGL(k_empty, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, seg_off, dst);
+                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st) {
+    if (any_empty) hipLaunchKernelGGL(k_empty, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, seg_off, dst);
     if (nblk) hipLaunchKernelGGL(k_write, dim3(nblk), dim3(WR_THREADS), 0, st, src, segs, blk_seg, blk, tabs, seg_off, lits, litc, seqc, dst);
 }
 

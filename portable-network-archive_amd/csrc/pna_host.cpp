@@ -34,12 +34,12 @@ void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_
                           uint8_t *dst, hipStream_t st);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, uint32_t blk_log, hipStream_t st, hipEvent_t *ev);
+                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev);
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st);
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
-                  const uint8_t *seqc, uint8_t *dst, hipStream_t st);
+                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st);
 void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
@@ -132,6 +132,7 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long hist_by_block = -1;         // PNA_HIST_BY_BLOCK: zstd entropy stage in its per-block form (1: k_hist, k_seqa, k_seqb) or its per-segment form (0: k_stats, k_seq); -1: by batch size
 };
 struct TuningName { const char *name, *env; long Tuning::*field; long lo, hi; };
 static const TuningName TUNING_NAMES[] = {
@@ -142,13 +143,16 @@ static const TuningName TUNING_NAMES[] = {
     {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20},
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
-    {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20},
+    {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
 };
 
 struct pna_gpu_stream;
 struct pna_gpu_ctx {
     Tuning tun;
-    DevBuf units;                                   // latency mode: the LZ stage's units (pieces of segments, one workgroup each)
+    // the plan of a sub-batch -- segment descriptors, LZ units (latency mode: pieces of segments, one workgroup each), block -> segment, entry -> first
+    // segment -- is staged in ONE page-locked blob and travels in one copy; the per-segment histograms of k_hist lie behind the BlkInfo array (one memset)
+    DevBuf plan; PinBuf h_plan;
+    SegDesc *d_segs = nullptr, *d_units = nullptr; uint32_t *d_blk_seg = nullptr, *d_entry_seg = nullptr, *d_hist = nullptr;
     uint32_t last_blk_log = PNA_BLK_LOG, last_units = 0;
     int device = 0;
     uint32_t flags = 0;
@@ -156,7 +160,7 @@ struct pna_gpu_ctx {
     std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    DevBuf segs, blk_seg, blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, entry_seg, ctab, pbuf;
+    DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
@@ -264,10 +268,10 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->segs, &c->blk_seg, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->units, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->entry_seg, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
+    for (DevBuf *b : {&c->plan, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
-    for (PinBuf *b : {&c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
+    for (PinBuf *b : {&c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
     for (auto &e : c->ev_lz) if (e) (void)hipEventDestroy(e);
@@ -617,12 +621,12 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
             while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
         }
-        launch_lz(d_src, (const SegDesc *)c->segs.p + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
+        launch_lz(d_src, c->d_segs + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
                   (uint32_t *)c->pbuf.p, b0, e1);
         a = b;
         if (a >= s1) return PNA_OK;
     }
-    launch_lz(d_src, (const SegDesc *)c->segs.p + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr);
+    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr);
     if (fused_tail) return lz_stage(c, d_src, segs, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
@@ -655,12 +659,12 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (c->tun.unit_log) unit_log = (uint32_t)std::max<long>(c->tun.unit_log, blk_log);
     if (unit_log < blk_log) unit_log = blk_log;
     const uint32_t bsz = 1u << blk_log;
-    std::vector<SegDesc> units;
+    std::vector<SegDesc> units; bool any_empty = false;
     for (size_t e = e0; e < e1; e++) {
         entry_first_seg.push_back((uint32_t)segs.size());
         uint64_t len = src_len[e], off = src_off[e];
         if (off & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
-        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3, 0, 0, blk_log, 0}; segs.push_back(s); continue; }
+        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3, 0, 0, blk_log, 0}; segs.push_back(s); any_empty = true; continue; }
         for (uint64_t p = 0; p < len; p += SEG_SIZE) {
             uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
             SegDesc s{off + p, sl, nblk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u), 0, sl, blk_log, 0};
@@ -676,32 +680,43 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (nseg == 0) return PNA_OK;
     const bool unit_mode = unit_log < 20 && !units.empty();
     c->last_blk_log = blk_log; c->last_units = unit_mode ? (uint32_t)units.size() : 0;
-    if (c->segs.ensure(nseg * sizeof(SegDesc)) || c->blk_seg.ensure((size_t)(nblk + 1) * 4) ||
-        c->blk.ensure((size_t)(nblk + 1) * sizeof(BlkInfo)) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
-        c->entry_seg.ensure((entry_first_seg.size() + 1) * 4) || (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
+    // zstd entropy stage, two forms: statistics per block (k_hist) + tables + three-lane state chains (k_seqa) + token-parallel packing (k_seqb) while
+    // the chain waves fit the chip's SIMDs (<= 40 960 blocks); beyond, statistics per segment inside k_stats and the one-kernel coder k_seq.  Flags
+    // 0x1000 / 0x2000 and option hist_by_block force one.
+    const bool hist_on = algo == PNA_ALGO_ZSTD && !(c->call_flags & 0x1000u) &&
+                         ((c->call_flags & 0x2000u) || (c->tun.hist_by_block < 0 ? nblk <= 40960u : c->tun.hist_by_block != 0));
+    const size_t o_units = ((size_t)nseg * sizeof(SegDesc) + 15) & ~(size_t)15, o_blkseg = (o_units + units.size() * sizeof(SegDesc) + 15) & ~(size_t)15,
+                 o_entry = (o_blkseg + (size_t)(nblk + 1) * 4 + 15) & ~(size_t)15, plan_bytes = o_entry + (entry_first_seg.size() + 1) * 4;
+    const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + (hist_on ? (size_t)nseg * 448 * 4 : 0);
+    if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes) ||
+        c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
+        (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
         c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
         c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
-        (algo == PNA_ALGO_ZSTD && c->seqw.ensure((size_t)(nblk + 1) * SEQ_CAP * 4)) ||
+        (algo == PNA_ALGO_ZSTD && c->seqw.ensure(hist_on ? (size_t)(nblk + 1) * SEQ_CAP * 8 : 64)) ||
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
         return fail(c, PNA_E_NOMEM, "workspace allocation failed");
-    HIPCHK(c, hipMemcpyAsync(c->segs.p, segs.data(), nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
-    if (unit_mode) {
-        if (c->units.ensure(units.size() * sizeof(SegDesc))) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
-        HIPCHK(c, hipMemcpyAsync(c->units.p, units.data(), units.size() * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+    {
+        uint8_t *hp = (uint8_t *)c->h_plan.p, *dp = (uint8_t *)c->plan.p;          // (the previous sub-batch has been waited for: the staging is free)
+        memcpy(hp, segs.data(), (size_t)nseg * sizeof(SegDesc));
+        if (!units.empty()) memcpy(hp + o_units, units.data(), units.size() * sizeof(SegDesc));
+        if (nblk) memcpy(hp + o_blkseg, blk_seg.data(), (size_t)nblk * 4);
+        memcpy(hp + o_entry, entry_first_seg.data(), entry_first_seg.size() * 4);
+        c->d_segs = (SegDesc *)dp; c->d_units = (SegDesc *)(dp + o_units); c->d_blk_seg = (uint32_t *)(dp + o_blkseg); c->d_entry_seg = (uint32_t *)(dp + o_entry);
+        c->d_hist = (uint32_t *)((uint8_t *)c->blk.p + o_hist);
+        HIPCHK(c, hipMemcpyAsync(dp, hp, plan_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(c->blk.p, 0, blk_bytes, st));                     // BlkInfo of every block and, behind them, the segments' histogram counters
     }
-    if (nblk) HIPCHK(c, hipMemcpyAsync(c->blk_seg.p, blk_seg.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(c->blk.p, 0, (size_t)(nblk + 1) * sizeof(BlkInfo), st));
     c->lzm_used = 0;
     const bool defl = algo == PNA_ALGO_DEFLATE;
-    if (defl) HIPCHK(c, hipMemcpyAsync(c->entry_seg.p, entry_first_seg.data(), entry_first_seg.size() * 4, hipMemcpyHostToDevice, st));
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
         const uint32_t dfl = c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u);
-        if (unit_mode) launch_lz(d_src, (const SegDesc *)c->units.p, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
+        if (unit_mode) launch_lz(d_src, c->d_units, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
         else { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
-        launch_deflate_stage1(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const uint64_t *)c->seqs.p,
+        launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
                               (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags);
     } else {
@@ -721,20 +736,21 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            if (unit_mode) launch_lz(d_src, (const SegDesc *)c->units.p, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
+            if (unit_mode) launch_lz(d_src, c->d_units, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
                                      (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, nullptr, 0, nullptr);       // (nch == 1: one launch over all units)
             else { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
+            hipStream_t est = nch > 1 ? c->aux : st;
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
-            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
-            HIPCHK(c, hipEventRecord(c->ev_en[k][0], c->aux));
-            launch_entropy_chunk((const SegDesc *)c->segs.p, s0, s1 - s0, (const uint32_t *)c->blk_seg.p, g0, g1 - g0, (const uint64_t *)c->seqs.p,
+            if (nch > 1) HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_lz[k + 1], 0));
+            HIPCHK(c, hipEventRecord(c->ev_en[k][0], est));
+            launch_entropy_chunk(c->d_segs, s0, s1 - s0, c->d_blk_seg, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
-                                 (uint32_t *)c->seqw.p, c->call_flags, blk_log, c->aux, &c->ev_en[k][1]);
+                                 (uint32_t *)c->seqw.p, c->call_flags, blk_log, hist_on ? c->d_hist : nullptr, est, &c->ev_en[k][1]);
         }
-        HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        if (nch > 1) { HIPCHK(c, hipEventRecord(c->ev_join, c->aux)); HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0)); }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[4], st));
-        launch_plan((const SegDesc *)c->segs.p, nseg, (BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (uint64_t *)c->seg_size.p,
+        launch_plan(c->d_segs, nseg, (BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (uint64_t *)c->seg_size.p,
                     (uint64_t *)c->seg_off.p, c->call_flags, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[5], st));
     }
@@ -813,9 +829,15 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     // the output offsets are needed on the host before the write pass can be bounds-checked
     if (c->h_segoff.ensure((size_t)(nseg + 1) * 8)) return fail(c, PNA_E_NOMEM, "offset staging");
     const uint64_t *seg_off = (const uint64_t *)c->h_segoff.p;
-    HIPCHK(c, hipMemcpyAsync(c->h_segoff.p, c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    uint64_t total = seg_off[nseg];
+    // (plain batches whose destination holds the worst case of every entry need no check against the sizes found: the write kernels go out
+    // at once, the offsets travel behind them and the one wait is the call's last -- a wait in the middle of a small batch is a tenth of it)
+    bool early_write = !fj;
+    if (early_write) { uint64_t need = out_base; for (size_t e = e0; e < e1; e++) need += pna_gpu_bound(algo, (size_t)src_len[e]); early_write = need <= dst_cap; }
+    if (!early_write) {
+        HIPCHK(c, hipMemcpyAsync(c->h_segoff.p, c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    uint64_t total = early_write ? 0 : seg_off[nseg];
     std::vector<CipherUnit> cunits;
     const uint64_t *d_segdst = (const uint64_t *)c->seg_off.p;
     uint8_t *wbase = d_dst + out_base;
@@ -928,13 +950,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         HIPCHK(c, hipMemcpyAsync(c->fr_blob.p, blob, blob_len, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->fr_segdst.p, segdst, (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, st));
         d_segdst = (const uint64_t *)c->fr_segdst.p; wbase = d_dst;
-    } else if (out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
-    if (defl) launch_deflate_write(d_src, (const SegDesc *)c->segs.p, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
-                                   d_segdst, (const uint64_t *)c->seg_size.p, (const uint8_t *)c->litc.p, (const uint32_t *)c->entry_seg.p,
+    } else if (!early_write && out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
+    if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
+                                   d_segdst, (const uint64_t *)c->seg_size.p, (const uint8_t *)c->litc.p, c->d_entry_seg,
                                    (uint32_t)(e1 - e0), wbase, st);
-    else launch_write(d_src, (const SegDesc *)c->segs.p, nseg, (const uint32_t *)c->blk_seg.p, nblk, (const BlkInfo *)c->blk.p,
+    else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
-                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, st);
+                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st);
     if (fj && fj->cipher) {
         if (solid && fj->cipher->cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "solid archives: only CTR on the device path (CBC is one serial chain)");
         int rc = ensure_aes(c); if (rc) return rc;
@@ -978,6 +1000,11 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                          d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), solid ? "SDAT" : "FDAT", !solid, st);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
     HIPCHK(c, hipGetLastError());
+    if (early_write) {
+        HIPCHK(c, hipMemcpyAsync(c->h_segoff.p, c->seg_off.p, (size_t)(nseg + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        total = seg_off[nseg];
+    }
     if (!fj) for (size_t e = e0; e < e1; e++) dst_off[e] = out_base + seg_off[entry_first_seg[e - e0]];
     dst_off[e1] = out_base + total;
     c->last_nblk = nblk;

@@ -14,7 +14,7 @@ namespace pna {
 
 void launch_lz(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, hipEvent_t) {}
 void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
-                          uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, hipStream_t, hipEvent_t *) {}
+                          uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t, hipEvent_t *) {}
 static uint64_t seg_bytes(const SegDesc &sd) {
     if (sd.len == 0) return 9;
     return 6 + 3ull * seg_nblk(sd) + sd.len;
@@ -25,7 +25,7 @@ void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *, const SegTables 
     seg_off[nseg] = pos;
 }
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *, uint32_t, const BlkInfo *, const SegTables *,
-                  const uint64_t *seg_off, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *dst, hipStream_t) {
+                  const uint64_t *seg_off, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *dst, bool, hipStream_t) {
     for (uint32_t s = 0; s < nseg; s++) {
         const SegDesc &sd = segs[s];
         uint8_t *o = dst + seg_off[s];
