@@ -159,8 +159,10 @@ def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, a
     in_bytes = n_files * file_len
     return {"value": round(in_bytes / best / 2**20, 1), "unit": "MiB/s", "ms": round(best * 1e3, 2), "archive_bytes": count[0], "sink_calls": count[1],
             "pcie_bytes": in_bytes + count[0], "pcie_GBps": round((in_bytes + count[0]) / best / 1e9, 2), "runs": runs,
-            "path": f"{n_files} x {file_len} B entries in pageable host memory -> pna_gpu_create_archive_host (1 GiB sub-batches: staging into "
-                    f"page-locked slots || H2D || kernels || D2H) -> counting sink; best of {runs} runs after one untimed run"}
+            "h2d_GBps": round(in_bytes / best / 1e9, 2),
+            "path": f"{n_files} x {file_len} B entries in pageable host memory -> pna_gpu_create_archive_host (sub-batches of 64 .. 256 MiB over a ring of four "
+                    f"page-locked slots: staging || H2D copy engine || kernels || D2H by a throttled copy kernel) -> counting sink; best of {runs} runs after one "
+                    f"untimed run.  Bound: the H2D direction of the host link (56.8 GB/s page-locked -> HBM on these boxes, profiles/r03_c_link_duplex.txt)"}
 
 
 class HostGather:
@@ -528,7 +530,9 @@ def main() -> None:
         line = {
             "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}-{level}, {wl} {'enwik-style' if args.kind == 0 else 'random-text'} corpus"
                       + (f", {args.encrypt}" if args.encrypt != "none" else "") + ("" if args.framing != "none" else ", compressed streams only (no container)"),
-            "value": round(value, 1), "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "value_kind": "hbm_resident (inputs in HBM when the timed region starts, archive bytes left in HBM; the host-RAM-to-sink rate of "
+                                                    "SURVEY 8(d) is `end_to_end`)",
+            "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"pna create, {files_all} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text"

@@ -182,6 +182,19 @@ void k_gather(const PlaceDesc *__restrict__ pd, const uint8_t *__restrict__ src,
     const uint32_t done = n16 << 4;
     if (threadIdx.x < d.len - done) o[done + threadIdx.x] = s[done + threadIdx.x];
 }
+// ------------------------------------------------------------------ k_link_copy : a sub-batch's archive bytes from HBM into page-locked host memory
+// A plain 16-byte copy on FEW workgroups: the number of workgroups sets the rate (4: 26 GB/s, 8: 36 GB/s of stores over the link), and that is the
+// point -- next to it the H2D copy engine keeps its 57 GB/s, where the runtime's D2H copy (a blit kernel at full tilt, 51 GB/s) took 30 % off it
+// (experiments/link_duplex.hip).  src, dst: 16-byte aligned.
+__global__ __launch_bounds__(256)
+void k_link_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, const uint8_t *__restrict__ src8, uint8_t *__restrict__ dst8, uint32_t tail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail) dst8[(n16 << 4) + threadIdx.x] = src8[(n16 << 4) + threadIdx.x];
+}
+void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_link_copy, dim3(wgs ? wgs : 1), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n >> 4, src, dst, (uint32_t)(n & 15));
+}
+
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_gather, dim3(n), dim3(256), 0, st, (const PlaceDesc *)pd, src, dst);
 }

@@ -45,6 +45,7 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
+void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
@@ -123,7 +124,8 @@ struct Tuning {
     long lz_pbuf_fail = 0;           // PNA_LZ_PBUF_FAIL: testing -- behave as if the words workspace could not be allocated
     long pipeline_chunks = 1;        // PNA_PIPELINE_CHUNKS: zstd entropy stage of chunk k next to the LZ stage of chunk k + 1 (measured: slower)
     long fdat_max_mib = 1024;        // PNA_FDAT_MAX_MIB: largest FDAT chunk the device paths write when the caller names no max_chunk_size
-    long sub_mib = 1024;             // PNA_SUB_MIB: input bytes per sub-batch of the bounded host pipeline
+    long sub_mib = 256;              // PNA_SUB_MIB: largest sub-batch (input bytes) of the bounded host pipeline
+    long sub_ramp_down = 0;          // PNA_SUB_RAMP_DOWN: sub-batches shrink towards the end of the input (measured: no gain)
     long stage_threads = 0;          // PNA_STAGE_THREADS: host threads that stage entries into page-locked memory (0: min(8, cores / 2))
     long extract_win_mib = 1024;     // PNA_EXTRACT_WIN_MIB: archive bytes per window of the extract driver
     long batch_piece_mib = 256;      // PNA_BATCH_PIECE_MIB: pna_gpu_compress_batch takes a large batch through in pieces of this size (0: one piece)
@@ -132,6 +134,8 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long trace = 0;                  // PNA_TRACE: phase times of the host pipelines on stderr
+    long d2h_wgs = 6;                // PNA_D2H_WGS: workgroups of the kernel that carries a sub-batch's archive bytes to the host (0: the copy engine / runtime's choice)
     long hist_by_block = -1;         // PNA_HIST_BY_BLOCK: zstd entropy stage in its per-block form (1: k_hist, k_seqa, k_seqb) or its per-segment form (0: k_stats, k_seq); -1: by batch size
 };
 struct TuningName { const char *name, *env; long Tuning::*field; long lo, hi; };
@@ -144,6 +148,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -176,13 +181,13 @@ struct pna_gpu_ctx {
     DevBuf z_fx, z_blocks, z_tabs, z_seqs, z_hlist, z_slist, z_work, z_fb, z_cbase, z_apart;   // lane-parallel decoder workspace
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
-    PinBuf hp_in[2], hp_out[2];
-    DevBuf dp_in[2], dp_out[2];
+    PinBuf hp_in[4], hp_out[2];
+    DevBuf dp_in[4], dp_out[2];
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipStream_t aux = nullptr;                        // entropy stage of chunk c runs here while k_lz works on chunk c+1
     static constexpr int MAXCH = 8;
     hipEvent_t ev_lz[MAXCH + 1] = {}, ev_en[MAXCH][4] = {}, ev_join = nullptr;
-    hipEvent_t ev_in[2] = {}, ev_out[2] = {};
+    hipEvent_t ev_in[4] = {}, ev_out[2] = {};
     bool crc_ready = false;
     bool corpus_ready = false;
     std::string err;
@@ -271,9 +276,10 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (DevBuf *b : {&c->plan, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
-    for (PinBuf *b : {&c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_out[0], &c->hp_out[1]}) b->release();
-    for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_out[0], &c->dp_out[1]}) b->release();
-    for (int i = 0; i < 2; i++) { if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]); if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]); }
+    for (PinBuf *b : {&c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
+    for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_in[2], &c->dp_in[3], &c->dp_out[0], &c->dp_out[1]}) b->release();
+    for (auto &e : c->ev_in) if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_out) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_lz) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->lzm_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_ci) if (e) (void)hipEventDestroy(e);
@@ -1446,105 +1452,149 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->cp_in) {
         HIPCHK(c, hipStreamCreate(&c->cp_in)); HIPCHK(c, hipStreamCreate(&c->cp_out));
-        for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)); }
+        for (auto &e : c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_out) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     c->timing = pna_gpu_timing{};
     std::vector<uint8_t> head, tail;
     if (part_flags & PNA_PART_HEAD) frame_archive_head(head, 0);
     if (part_flags & PNA_PART_TAIL) frame_archive_tail(tail);
     if (!head.empty() && sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
-    // sub-batches of at most SUB input bytes (an entry larger than that is a sub-batch of its own)
-    // sub-batch size: the entropy kernels have a fixed latency of a few ms per launch (serial chains), so small sub-batches waste
-    // the GPU; 1 GiB keeps the pipeline above the PCIe rate while the in-flight window stays bounded (2 x 1 GiB in, 2 x out)
-    const uint64_t SUB = (uint64_t)c->tun.sub_mib << 20;
+    // Sub-batches.  What bounds this path is the host link in the H2D direction (page-locked memory -> HBM: 56.8 GB/s on the MI355X boxes;
+    // experiments/link_duplex.hip, profiles/r03_c_link_duplex.txt) -- the kernels take a sixth of that time, the archive bytes going back a third of the
+    // volume and the link is full duplex.  So the pipeline is built around ONE rule: the H2D copy engine never waits.
+    //   * a stager thread runs ahead through all sub-batches over a ring of four input slots (page-locked staging + device buffer): it copies
+    //     the entries of a sub-batch into the slot's page-locked buffer (several threads, groups of ~128 MiB) and issues each group's H2D copy
+    //     right behind it; it blocks only while all four slots are in use (a slot is free again when its sub-batch's kernels are done);
+    //   * the main thread takes the sub-batches in order: kernels on the context's stream, then the archive bytes of the sub-batch travel to
+    //     the host next to the following sub-batch's kernels and copies -- by a small copy KERNEL that stores into the page-locked buffer
+    //     (d2h_wgs workgroups: ~30 GB/s, which leaves the H2D engine its full rate; the runtime's own D2H copy ran as a blit kernel at 51 GB/s
+    //     and took 30 % off the H2D copies next to it) --, and are handed to the sink one sub-batch later;
+    //   * sub-batch sizes grow from 64 MiB to `sub_mib` (default 256 MiB) at the start: the first kernels start after 2 ms instead of 20, and
+    //     what is left to do when the last input byte has arrived is the work of one sub-batch.  256 MiB is the smallest size whose kernels
+    //     (1.2 ms of fixed costs + 1 ms per 85 MiB) keep up with its H2D copy (1 ms per 53 MiB); shrinking sizes at the end only makes the
+    //     kernels fall behind the copies (measured: option sub_ramp_down).
+    const uint64_t SUBMAX = (uint64_t)c->tun.sub_mib << 20, SUBMIN = std::min<uint64_t>(64ull << 20, SUBMAX);
     struct Sub { size_t e0, e1; uint64_t in_bytes, out_cap; };
     std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
-    for (size_t e = 0; e < n;) {
-        Sub sb{e, e, 0, 64}; uint64_t pos = 0; size_t blocks = 0;
-        while (sb.e1 < n) {
-            const size_t i = sb.e1; const uint64_t l = src_len[i];
-            const size_t nb = plan_blocks(c, l);
-            if (i > sb.e0 && (pos + l > SUB || blocks + nb > c->max_blocks)) break;
-            off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
-            sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
-            if (cipher && cipher->cipher_mode == PNA_MODE_GCM) sb.out_cap += 16 * (pna_gpu_bound(algo, (size_t)l) / (cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20)));   // a tag per full stream segment
-            sb.e1++;
+    uint64_t in_total = 0;
+    for (size_t e = 0; e < n; e++) in_total += src_len[e];
+    {
+        uint64_t done = 0, target = SUBMIN;
+        for (size_t e = 0; e < n;) {
+            const uint64_t rest = in_total - done;
+            uint64_t want = std::min(target, SUBMAX);
+            if (c->tun.sub_ramp_down && rest < 2 * want) want = std::max(SUBMIN, rest / 2);   // (option) ramp down: half of what is left, not below the minimum
+            (void)rest;
+            Sub sb{e, e, 0, 64}; uint64_t pos = 0; size_t blocks = 0;
+            while (sb.e1 < n) {
+                const size_t i = sb.e1; const uint64_t l = src_len[i];
+                const size_t nb = plan_blocks(c, l);
+                if (i > sb.e0 && (pos + l > want || blocks + nb > c->max_blocks)) break;
+                off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
+                sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
+                if (cipher && cipher->cipher_mode == PNA_MODE_GCM) sb.out_cap += 16 * (pna_gpu_bound(algo, (size_t)l) / (cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20)));   // a tag per full stream segment
+                done += l; sb.e1++;
+            }
+            sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
+            target = std::min(SUBMAX, target * 2);
         }
-        sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (c->tun.stage_threads) threads = (unsigned)c->tun.stage_threads;
     FrameJob fj{names, 0, cipher, ivs, meta};
     std::vector<uint64_t> eoff(n + 1);
-    uint64_t out_len[2] = {0, 0}, in_total = 0, out_total = head.size();
-    for (size_t e = 0; e < n; e++) in_total += src_len[e];
-    auto ensure_slot = [&](size_t k) -> int {
-        const Sub &sb = subs[k]; const int sl = (int)(k & 1);
-        if (c->hp_in[sl].ensure(sb.in_bytes + 8192) || c->dp_in[sl].ensure(sb.in_bytes + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
-        return PNA_OK;
-    };
+    uint64_t out_len[2] = {0, 0}, out_total = head.size();
+    constexpr int NS = 4;
+    {   // slots sized once for the largest sub-batch (allocation of page-locked memory is slow: not inside the pipeline)
+        uint64_t max_in = 0, max_out = 0;
+        for (const Sub &sb : subs) { max_in = std::max(max_in, sb.in_bytes); max_out = std::max(max_out, sb.out_cap); }
+        for (int s = 0; s < NS && s < (int)subs.size(); s++)
+            if (c->hp_in[s].ensure(max_in + 8192) || c->dp_in[s].ensure(max_in + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+        for (int s = 0; s < 2 && s < (int)subs.size(); s++)
+            if (c->dp_out[s].ensure(max_out + 64) || c->hp_out[s].ensure(max_out + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    }
     int rc = PNA_OK;
-    std::thread stager; int stager_rc = PNA_OK;
-    // staging of one sub-batch in groups of ~128 MiB; every group's H2D copy is issued right behind it, so the copy engine
-    // works while the next group is still being staged (runs on the stager thread: its own hipSetDevice)
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what, size_t k) { if (c->tun.trace) fprintf(stderr, "[pna create] %8.3f ms  %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), what, k); };
+    trace("planned, slots ready; sub-batches:", subs.size());
+    // the stager: sub-batch k into slot k % NS as soon as sub-batch k - NS has left the device
+    std::mutex mu; std::condition_variable cv;
+    size_t staged = 0, freed = 0; int stager_rc = PNA_OK; bool stop = false;      // sub-batches staged (copies issued) / sub-batches whose kernels are done
     const int dev_id = c->device;
     hipStream_t cp_in = c->cp_in;
-    auto stage_and_copy = [=, &off](const Sub nx, uint8_t *hb, uint8_t *db, hipEvent_t ev) -> int {
-        if (hipSetDevice(dev_id) != hipSuccess) return PNA_E_HIP;
-        size_t g0 = nx.e0;
-        while (g0 < nx.e1) {
-            size_t g1 = g0; uint64_t acc = 0;
-            while (g1 < nx.e1 && acc < (128ull << 20)) acc += src_len[g1++];
-            parallel_stage(hb, src, src_len, off.data(), g0, g1, threads);
-            const uint64_t b0 = off[g0], b1 = g1 < nx.e1 ? off[g1] : nx.in_bytes;
-            if (b1 > b0 && hipMemcpyAsync(db + b0, hb + b0, b1 - b0, hipMemcpyHostToDevice, cp_in) != hipSuccess) return PNA_E_HIP;
-            g0 = g1;
-        }
-        return hipEventRecord(ev, cp_in) == hipSuccess ? PNA_OK : PNA_E_HIP;
-    };
-    if (!subs.empty()) {
-        rc = ensure_slot(0); if (rc) return rc;
-        if (stage_and_copy(subs[0], (uint8_t *)c->hp_in[0].p, (uint8_t *)c->dp_in[0].p, c->ev_in[0]) != PNA_OK) return fail(c, PNA_E_HIP, "H2D copy failed");
-    }
-    for (size_t k = 0; k < subs.size() && rc == PNA_OK; k++) {
-        const Sub &sb = subs[k]; const int sl = (int)(k & 1);
-        if (k + 1 < subs.size()) {                               // stage the next sub-batch while the GPU works on this one
-            stager_rc = ensure_slot(k + 1);
-            if (stager_rc == PNA_OK) {
-                const Sub nx = subs[k + 1]; uint8_t *hb = (uint8_t *)c->hp_in[sl ^ 1].p, *db = (uint8_t *)c->dp_in[sl ^ 1].p;
-                hipEvent_t evn = c->ev_in[sl ^ 1];
-                stager = std::thread([=, &stager_rc]() { stager_rc = stage_and_copy(nx, hb, db, evn); });
+    std::thread stager([&]() {
+        try {
+            if (hipSetDevice(dev_id) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); stager_rc = PNA_E_HIP; staged = subs.size(); cv.notify_all(); return; }
+            for (size_t k = 0; k < subs.size(); k++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || k < freed + NS; });
+                    if (stop) return;
+                }
+                const Sub &nx = subs[k]; const int sl = (int)(k % NS);
+                uint8_t *hb = (uint8_t *)c->hp_in[sl].p, *db = (uint8_t *)c->dp_in[sl].p;
+                int r = PNA_OK;
+                size_t g0 = nx.e0;
+                while (g0 < nx.e1 && r == PNA_OK) {
+                    size_t g1 = g0; uint64_t acc = 0;
+                    while (g1 < nx.e1 && acc < (128ull << 20)) acc += src_len[g1++];
+                    parallel_stage(hb, src, src_len, off.data(), g0, g1, threads);
+                    const uint64_t b0 = off[g0], b1 = g1 < nx.e1 ? off[g1] : nx.in_bytes;
+                    if (b1 > b0 && hipMemcpyAsync(db + b0, hb + b0, b1 - b0, hipMemcpyHostToDevice, cp_in) != hipSuccess) r = PNA_E_HIP;
+                    g0 = g1;
+                }
+                if (r == PNA_OK && hipEventRecord(c->ev_in[sl], cp_in) != hipSuccess) r = PNA_E_HIP;
+                trace("staged + H2D issued", k);
+                std::lock_guard<std::mutex> lk(mu);
+                if (r != PNA_OK) { stager_rc = r; staged = subs.size(); cv.notify_all(); return; }
+                staged = k + 1; cv.notify_all();
             }
+        } catch (...) { std::lock_guard<std::mutex> lk(mu); stager_rc = PNA_E_NOMEM; staged = subs.size(); cv.notify_all(); }
+    });
+    uint8_t *hp_out_dev[2] = {nullptr, nullptr};                 // device views of the page-locked output slots (the copy kernel's destination)
+    const uint32_t d2h_wgs = (uint32_t)c->tun.d2h_wgs;
+    for (size_t k = 0; k < subs.size() && rc == PNA_OK; k++) {
+        const Sub &sb = subs[k]; const int sl = (int)(k % NS), so = (int)(k & 1);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return staged > k; });
+            if (stager_rc != PNA_OK) { rc = fail(c, stager_rc, "staging / H2D copy failed"); break; }
         }
-        if (c->dp_out[sl].ensure(sb.out_cap + 64) || c->hp_out[sl].ensure(sb.out_cap + 64)) rc = fail(c, PNA_E_NOMEM, "staging allocation failed");
-        if (rc == PNA_OK && hipEventSynchronize(c->ev_in[sl]) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
-        if (rc == PNA_OK)
-            rc = run_subbatch(c, algo, (const uint8_t *)c->dp_in[sl].p, off.data(), len64.data(), sb.e0, sb.e1, (uint8_t *)c->dp_out[sl].p,
-                              sb.out_cap + 64, 0, eoff.data(), c->stream, true, &fj);
+        if (hipEventSynchronize(c->ev_in[sl]) != hipSuccess) { rc = fail(c, PNA_E_HIP, "H2D copy failed"); break; }
+        trace("H2D done, kernels start", k);
+        rc = run_subbatch(c, algo, (const uint8_t *)c->dp_in[sl].p, off.data(), len64.data(), sb.e0, sb.e1, (uint8_t *)c->dp_out[so].p,
+                          sb.out_cap + 64, 0, eoff.data(), c->stream, true, &fj);
+        { std::lock_guard<std::mutex> lk(mu); freed = k + 1; cv.notify_all(); }       // (run_subbatch has waited for its kernels: the input slot is free)
+        trace("kernels done", k);
         if (rc == PNA_OK) {
-            out_len[sl] = eoff[sb.e1];
-            if (hipMemcpyAsync(c->hp_out[sl].p, c->dp_out[sl].p, out_len[sl], hipMemcpyDeviceToHost, c->cp_out) != hipSuccess ||
-                hipEventRecord(c->ev_out[sl], c->cp_out) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+            out_len[so] = eoff[sb.e1];
+            bool ok = true;
+            if (d2h_wgs && !hp_out_dev[so]) ok = hipHostGetDevicePointer((void **)&hp_out_dev[so], c->hp_out[so].p, 0) == hipSuccess;
+            if (ok && d2h_wgs) { launch_link_copy((const uint8_t *)c->dp_out[so].p, hp_out_dev[so], out_len[so], d2h_wgs, c->cp_out); ok = hipGetLastError() == hipSuccess; }
+            else if (ok) ok = hipMemcpyAsync(c->hp_out[so].p, c->dp_out[so].p, out_len[so], hipMemcpyDeviceToHost, c->cp_out) == hipSuccess;
+            if (!ok || hipEventRecord(c->ev_out[so], c->cp_out) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
         }
-        if (stager.joinable()) stager.join();
-        if (rc == PNA_OK && stager_rc != PNA_OK) rc = fail(c, stager_rc, "staging / H2D copy failed");
         if (rc == PNA_OK && k > 0) {                             // archive bytes of the previous sub-batch -> sink
-            if (hipEventSynchronize(c->ev_out[sl ^ 1]) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
-            else if (out_len[sl ^ 1] && sink(user, c->hp_out[sl ^ 1].p, out_len[sl ^ 1]) != 0) rc = fail(c, PNA_E_SINK, "sink failed");
-            out_total += out_len[sl ^ 1];
+            if (hipEventSynchronize(c->ev_out[so ^ 1]) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+            else if (out_len[so ^ 1] && sink(user, c->hp_out[so ^ 1].p, out_len[so ^ 1]) != 0) rc = fail(c, PNA_E_SINK, "sink failed");
+            out_total += out_len[so ^ 1];
         }
     }
-    if (stager.joinable()) stager.join();
+    { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+    stager.join();
+    trace("loop done", 0);
     if (rc != PNA_OK) { (void)hipDeviceSynchronize(); return rc; }
     if (!subs.empty()) {
-        const int sl = (int)((subs.size() - 1) & 1);
-        HIPCHK(c, hipEventSynchronize(c->ev_out[sl]));
-        if (out_len[sl] && sink(user, c->hp_out[sl].p, out_len[sl]) != 0) return fail(c, PNA_E_SINK, "sink failed");
-        out_total += out_len[sl];
+        const int so = (int)((subs.size() - 1) & 1);
+        HIPCHK(c, hipEventSynchronize(c->ev_out[so]));
+        if (out_len[so] && sink(user, c->hp_out[so].p, out_len[so]) != 0) return fail(c, PNA_E_SINK, "sink failed");
+        out_total += out_len[so];
     }
     if (!tail.empty() && sink(user, tail.data(), tail.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
     out_total += tail.size();
+    trace("all bytes handed to the sink", 0);
     c->timing.in_bytes = in_total; c->timing.out_bytes = out_total;
     return PNA_OK;
 }
@@ -2202,7 +2252,8 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
     for (int sl = 0; sl < (K > 1 ? 2 : 1); sl++) if (c->hp_in[sl].ensure(max_in + 64) || c->hp_out[sl].ensure(max_out + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
     if (K > 1 && !c->cp_in) {
         HIPCHK(c, hipStreamCreate(&c->cp_in)); HIPCHK(c, hipStreamCreate(&c->cp_out));
-        for (int i = 0; i < 2; i++) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming)); }
+        for (auto &e : c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_out) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned threads = std::min(8u, std::max(1u, hw / 2));

@@ -60,6 +60,7 @@ void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, 
     for (uint32_t i = 0; i < n; i++) { const PlaceDesc &d = ((const PlaceDesc *)pd)[i]; memcpy(dst + d.dst_off, src + d.src_off, d.len); }
 }
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) { launch_place(pd, n, src, dst, st); }
+void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t, hipStream_t) { memcpy(dst, src, n); }
 void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); }
 
 void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, const uint4 *, DeflTables *,
