@@ -74,7 +74,7 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 1 025)
  *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
- *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "fdat_max_mib" [PNA_FDAT_MAX_MIB], "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],
+ *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "max_chunk_size" [PNA_MAX_CHUNK_SIZE] (FDAT chunk size of the entry points without such a parameter), "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],
  *   "extract_win_mib" [PNA_EXTRACT_WIN_MIB], "batch_piece_mib" [PNA_BATCH_PIECE_MIB], "inflate_serial" [PNA_INFLATE_SERIAL],
  *   "zdec_serial" [PNA_ZDEC_SERIAL], "stream_pool_mib" [PNA_STREAM_POOL_MIB], "stream_linger_us" [PNA_STREAM_LINGER_US] (-1 = adaptive): DESIGN.md. */
 int  pna_gpu_set_option(pna_gpu_ctx *ctx, const char *name, long value);
@@ -162,7 +162,7 @@ typedef struct {
  * FDAT(ciphertext || tag) | FEND.  The stream key is HKDF(K_master, salt, entry context) with the context bound to the entry's FHED
  * chunk and the PHSF string (derive_stream_key, aead.rs:184-199).  The payload is cut into segments of gcm_segment_size bytes, each
  * followed by its 16-byte tag (GcmEncryptWriter, lib/src/cipher/gcm.rs:48-100): nonce = prefix || counter || flag, flag 1 on the last
- * segment (an empty payload is one empty final segment).  An entry whose payload spans several FDAT chunks (> 1 GiB compressed) is
+ * segment (an empty payload is one empty final segment).  An entry whose payload spans several FDAT chunks (beyond max_chunk_size) is
  * PNA_E_UNSUPPORTED with GCM. */
 size_t pna_gpu_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher);
 /* pna_gpu_create_archive_part_device with a cipher (cipher == NULL or encryption == PNA_ENC_NONE: identical to it). */
@@ -186,6 +186,21 @@ int  pna_gpu_create_archive_meta_device(pna_gpu_ctx *ctx, int algo, int level, s
 int  pna_gpu_create_archive_meta_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                       const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                       const pna_gpu_entry_meta *meta, pna_sink_fn sink, void *user);
+/* FlattenWriter::max_chunk_size (lib/src/util/io.rs:60-77; FileEntryBuilder::max_chunk_size, lib/src/entry/builder/file.rs:105-112; default u32::MAX,
+ * lib/src/chunk.rs:28): an entry's stream -- after the cipher -- is cut into FDAT chunks of exactly max_chunk_size bytes, the last one holding the rest
+ * (an IV / stream header stays the data piece of its own that prepend_data_prefix makes it).  The general forms of the archive entry points take it as a
+ * parameter (0 = u32::MAX); the entry points above and below without one use the context's option "max_chunk_size" (pna_gpu_set_option, default 0).
+ * Byte-identical to the reference's chunking up to chunks of 2^32 - 5 bytes (the device CRC takes type + data as one message below 2^32 bytes: an entry
+ * whose compressed payload exceeds 4 GiB - 5 bytes is cut 4 bytes earlier than the reference would).  CBC and GCM entries must fit one chunk
+ * (PNA_E_UNSUPPORTED otherwise; CTR -- the CLI's default -- has no such limit).  Bound: pna_gpu_archive_chunked_bound (+ the meta blobs' lengths). */
+size_t pna_gpu_archive_chunked_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher, uint32_t max_chunk_size);
+int  pna_gpu_create_archive_chunked_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                           const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                           const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, uint32_t max_chunk_size, void *d_dst, size_t dst_cap,
+                                           uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
+int  pna_gpu_create_archive_chunked_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
+                                         const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                         const pna_gpu_entry_meta *meta, uint32_t max_chunk_size, uint32_t part_flags, pna_sink_fn sink, void *user);
 /* pna_gpu_create_archive_host (bounded in-flight window from host memory) with the cipher stage. */
 int  pna_gpu_create_archive_enc_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                      const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,

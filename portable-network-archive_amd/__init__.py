@@ -102,7 +102,8 @@ ENTRY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctyp
 _lib = None
 
 EXPORTS = [
-    "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_archive_chunked_bound", "pna_gpu_create_archive_chunked_device",
+    "pna_gpu_create_archive_chunked_host", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
@@ -432,6 +433,24 @@ class Context:
                                                             ctypes.c_void_p(d_dst), mk(dst_off), mk(raw_len),
                                                             ctypes.c_void_p(stream) if stream else None))
 
+    def create_archive_chunked_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int, dst_cap: int,
+                                      max_chunk_size: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, cipher: Optional[Cipher] = None,
+                                      part: int = PART_HEAD | PART_TAIL):
+        """pna_gpu_create_archive_chunked_device: the archive in HBM with FDAT chunks of at most max_chunk_size bytes.  Returns (archive_len, entry_off)."""
+        n = len(src_len)
+        a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+        a_off = (ctypes.c_uint64 * (n + 1))(*(list(src_off)[:n] + [0]))
+        a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+        a_out = (ctypes.c_uint64 * (n + 1))()
+        total = ctypes.c_uint64()
+        cs = cipher.struct(n) if cipher is not None else None
+        f = self._L.pna_gpu_create_archive_chunked_device
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        self._check(f(self._h, algo, level, n, a_names, ctypes.c_void_p(d_src), a_off, a_len, ctypes.byref(cs) if cs is not None else None, None,
+                      max_chunk_size, ctypes.c_void_p(d_dst), dst_cap, a_out, ctypes.byref(total), part, None))
+        return total.value, list(a_out)
+
     def set_option(self, name: str, value: int) -> None:
         """pna_gpu_set_option: tuning knobs of the context (include/pna_gpu.h lists them)."""
         self._L.pna_gpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_long]
@@ -607,6 +626,42 @@ def archive_enc_bound(algo: int, names: Sequence[str], src_len: Sequence[int], c
     a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
     cs = cipher.struct(0) if cipher is not None and cipher.ivs is None else (cipher.struct(n) if cipher is not None else None)
     return load_library().pna_gpu_archive_enc_bound(algo, n, a_names, a_len, ctypes.byref(cs) if cs is not None else None)
+
+
+def archive_chunked_bound(algo: int, names: Sequence[str], src_len: Sequence[int], max_chunk_size: int, cipher: Optional[Cipher] = None) -> int:
+    n = len(src_len)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+    cs = cipher.struct(0) if cipher is not None and cipher.ivs is None else (cipher.struct(n) if cipher is not None else None)
+    L = load_library()
+    L.pna_gpu_archive_chunked_bound.restype = ctypes.c_size_t
+    L.pna_gpu_archive_chunked_bound.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    return L.pna_gpu_archive_chunked_bound(algo, n, a_names, a_len, ctypes.byref(cs) if cs is not None else None, max_chunk_size)
+
+
+def create_archive_chunked(ctx: "Context", names: Sequence[str], entries: Sequence[bytes], max_chunk_size: int, algo: int = ALGO_ZSTD,
+                           level: int = LEVEL_DEFAULT, cipher: Optional[Cipher] = None, part: int = PART_HEAD | PART_TAIL) -> bytes:
+    """pna_gpu_create_archive_chunked_host: the bounded host pipeline with FlattenWriter::max_chunk_size (lib/src/util/io.rs:60-77)."""
+    L = load_library()
+    n = len(entries)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend((ctypes.c_char * k).from_address(buf))
+        return 0
+    cb = SINK_FN(_sink)
+    bufs = [e if isinstance(e, bytes) else bytes(e) for e in entries]
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
+    a_len = (ctypes.c_size_t * max(n, 1))(*[len(e) for e in entries])
+    cs = cipher.struct(n) if cipher is not None else None
+    L.pna_gpu_create_archive_chunked_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, SINK_FN, ctypes.c_void_p]
+    rc = L.pna_gpu_create_archive_chunked_host(ctx._h, algo, level, n, a_names, a_src, a_len, ctypes.byref(cs) if cs is not None else None, None,
+                                               max_chunk_size, part, cb, None)
+    if rc:
+        raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
+    return bytes(out)
 
 
 def solid_archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> int:

@@ -123,7 +123,7 @@ struct Tuning {
     long lz_split_min = 1025;        // PNA_LZ_SPLIT_MIN: shortest run (segments) that takes the split form
     long lz_pbuf_fail = 0;           // PNA_LZ_PBUF_FAIL: testing -- behave as if the words workspace could not be allocated
     long pipeline_chunks = 1;        // PNA_PIPELINE_CHUNKS: zstd entropy stage of chunk k next to the LZ stage of chunk k + 1 (measured: slower)
-    long fdat_max_mib = 1024;        // PNA_FDAT_MAX_MIB: largest FDAT chunk the device paths write when the caller names no max_chunk_size
+    long max_chunk_size = 0;         // PNA_MAX_CHUNK_SIZE: FlattenWriter::max_chunk_size of the archive entry points without such a parameter (0 = the reference's default, u32::MAX)
     long sub_mib = 256;              // PNA_SUB_MIB: largest sub-batch (input bytes) of the bounded host pipeline
     long sub_ramp_down = 0;          // PNA_SUB_RAMP_DOWN: sub-batches shrink towards the end of the input (measured: no gain)
     long stage_threads = 0;          // PNA_STAGE_THREADS: host threads that stage entries into page-locked memory (0: min(8, cores / 2))
@@ -142,7 +142,7 @@ struct TuningName { const char *name, *env; long Tuning::*field; long lo, hi; };
 static const TuningName TUNING_NAMES[] = {
     {"lz_split", "PNA_LZ_SPLIT", &Tuning::lz_split, 0, 2}, {"lz_split_blocks", "PNA_LZ_SPLIT_BLOCKS", &Tuning::lz_split_blocks, 8, 1 << 17},
     {"lz_split_min", "PNA_LZ_SPLIT_MIN", &Tuning::lz_split_min, 0, 1 << 30}, {"lz_pbuf_fail", "PNA_LZ_PBUF_FAIL", &Tuning::lz_pbuf_fail, 0, 1},
-    {"pipeline_chunks", "PNA_PIPELINE_CHUNKS", &Tuning::pipeline_chunks, 1, 8}, {"fdat_max_mib", "PNA_FDAT_MAX_MIB", &Tuning::fdat_max_mib, 1, 2047},
+    {"pipeline_chunks", "PNA_PIPELINE_CHUNKS", &Tuning::pipeline_chunks, 1, 8}, {"max_chunk_size", "PNA_MAX_CHUNK_SIZE", &Tuning::max_chunk_size, 0, 0xFFFFFFFFl},
     {"sub_mib", "PNA_SUB_MIB", &Tuning::sub_mib, 16, 16384}, {"stage_threads", "PNA_STAGE_THREADS", &Tuning::stage_threads, 0, 64},
     {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20},
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
@@ -550,7 +550,11 @@ constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR
 // names[e] for the batch's global entry index e; solid: one SDAT chunk per segment of the (single) entry; cipher + ivs (16 bytes per
 // global entry index): the payloads are encrypted in place before their CRC-32 is taken
 struct PlaceDescH { uint64_t src_off, dst_off; uint32_t len, pad; };   // = PlaceDesc of k_frame.hip (k_place / k_gather)
-struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; const pna_gpu_entry_meta *meta = nullptr; };
+struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; const pna_gpu_entry_meta *meta = nullptr;
+                  uint32_t max_chunk = 0; };   // FDAT chunks of at most this many bytes (FlattenWriter::max_chunk_size; 0 = the reference's default u32::MAX)
+// largest FDAT chunk the device paths write: the CRC kernel takes "FDAT" || data as one message of at most 2^32 - 1 bytes (the reference's default cuts
+// at u32::MAX: the same chunks unless an entry's compressed payload exceeds 4 GiB - 5 bytes)
+static uint64_t chunk_limit(uint32_t max_chunk) { return max_chunk ? std::min<uint64_t>(max_chunk, 0xFFFFFFFBull) : 0xFFFFFFFBull; }
 static size_t meta_len(const pna_gpu_entry_meta *m, size_t e) {
     if (!m) return 0;
     return (m->extra && m->extra_len ? m->extra_len[e] : 0) + (m->facets && m->facets_len ? m->facets_len[e] : 0);
@@ -785,9 +789,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         std::vector<uint8_t> tmp;
         size_t bound = 0;
         for (size_t e = e0; e < e1; e++) bound += (fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e])) + meta_len(fj->meta, e);
-        // (a payload beyond the FDAT limit is cut into several FDAT chunks at segment boundaries: room for one more descriptor and
-        // 8 more prefix bytes per segment)
-        if (c->h_desc.ensure(((e1 - e0) + nseg) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * (size_t)nseg + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
+        // (every FDAT chunk behind an entry's first needs a descriptor and 8 prefix bytes: at most one per max_chunk_size bytes of the worst-case output)
+        size_t extra_chunks = 0;
+        { const uint64_t CHb = chunk_limit(fj->max_chunk); for (size_t e = e0; e < e1; e++) extra_chunks += (size_t)((pna_gpu_bound(algo, (size_t)src_len[e]) + 64 + 16 * (src_len[e] >> 12)) / CHb); }
+        if (c->h_desc.ensure(((e1 - e0) + extra_chunks + 1) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * extra_chunks + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing staging");
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
         if (gcm) {
@@ -868,80 +873,80 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             }
             blob_len = 8 * (size_t)nseg;
         } else {
-            // FlattenWriter cuts an entry's stream into FDAT chunks of at most max_chunk_size (lib/src/util/io.rs:60-77); here the
-            // cut points are segment boundaries and the limit is 1 GiB (PNA_FDAT_MAX_MIB for tests)
-            uint64_t fdat_max = (uint64_t)c->tun.fdat_max_mib << 20;
+            // FlattenWriter cuts an entry's stream into FDAT chunks of max_chunk_size bytes, the last one holding the rest (lib/src/util/io.rs:60-77:
+            // the open chunk is topped up before a new one starts; FileEntryBuilder::max_chunk_size, lib/src/entry/builder/file.rs:105-112; default
+            // u32::MAX, lib/src/chunk.rs:28).  The write kernels put an entry's payload down in one piece behind the first FDAT header; for an entry of
+            // K > 1 chunks the payload is saved to a scratch buffer and chunks 1 .. K - 1 move forward by 12 k bytes (CRC of the chunk before +
+            // their own length / type), k_frame then takes one descriptor per chunk.  The same pass serves the GCM STREAM layout below.
+            const uint64_t CH = chunk_limit(fj->max_chunk);
             std::vector<FrameDesc> units; units.reserve(e1 - e0);
             const bool cbc = fj->cipher && fj->cipher->cipher_mode == PNA_MODE_CBC;
+            const bool ctr = fj->cipher && !cbc && !gcm;
             for (size_t e = e0; e < e1; e++) {
                 const uint32_t s0 = entry_first_seg[e - e0], s1 = entry_first_seg[e - e0 + 1];
-                const FrameDesc f0 = fds[e - e0];                  // prefix of the entry: FHED | fSIZ | first FDAT header
+                const FrameDesc f0 = fds[e - e0];                  // prefix of the entry: FHED | fSIZ | ... | first FDAT header
                 dst_off[e] = pos;
-                uint32_t g0 = s0;
-                bool first = true;
-                uint64_t cpos = 0;                                 // position in the entry's cipher stream
-                do {
-                    uint32_t g1 = g0 + 1;
-                    while (g1 < s1 && seg_off[g1 + 1] - seg_off[g0] <= fdat_max) g1++;
-                    uint64_t plen = seg_off[g1] - seg_off[g0];
-                    if (fj->cipher) {
-                        // the payload is encrypted where it stands: CTR keeps its length and may be cut anywhere; CBC chains the whole
-                        // entry (one lane) and appends the PKCS#7 padding block
-                        const uint64_t p0 = pos + (first ? f0.prefix_len : 8);
-                        if (cbc) {
-                            if (g1 < s1 || !first) return fail(c, PNA_E_UNSUPPORTED, "CBC entry beyond one FDAT chunk");
-                            cunits.push_back(CipherUnit{p0, 0, (uint32_t)plen, (uint32_t)(e - e0)});
-                            plen = (plen / 16 + 1) * 16;
-                        } else if (gcm) {
-                            // GCM STREAM (GcmEncryptWriter, lib/src/cipher/gcm.rs:48-100): the payload in segments of segment_size bytes, every
-                            // segment followed by its 16-byte tag; all but the last carry nonce flag 0, the last one (possibly full, possibly
-                            // empty) flag 1; counters 0, 1, ...  The write kernels have put the payload down compactly: segments k >= 1 move
-                            // forward by 16 k bytes (through a scratch copy) before the cipher runs.
-                            if (g1 < s1 || !first) return fail(c, PNA_E_UNSUPPORTED, "GCM entry beyond one FDAT chunk");
-                            const uint64_t K = plen ? (plen + gcm_seg - 1) / gcm_seg : 1;
-                            if (K > 0xFFFFFFFFull) return fail(c, PNA_E_INVAL, "GCM segment counter overflow");
-                            const GcmMaterial &gm = gmat[e - e0];
-                            if (K > 1) { spread_copy.emplace_back(p0, plen); }
-                            for (uint64_t k = 0; k < K; k++) {
-                                const uint64_t sl = std::min<uint64_t>(gcm_seg, plen - k * gcm_seg), so_ = p0 + k * ((uint64_t)gcm_seg + 16);
-                                const uint32_t si = (uint32_t)gsegs.size();
-                                uint8_t j0[16], eb[16];
-                                memcpy(j0, gm.ctr_iv, 7);                                  // nonce prefix
-                                j0[7] = (uint8_t)(k >> 24); j0[8] = (uint8_t)(k >> 16); j0[9] = (uint8_t)(k >> 8); j0[10] = (uint8_t)k; j0[11] = k + 1 == K ? 1 : 0;
-                                j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
-                                aes256_block_host(gm.rk, j0, eb);
-                                GcmSeg gs; memcpy(gs.ctr_iv, j0, 16); gs.ctr_iv[15] = 2; gs.entry = (uint32_t)(e - e0);
-                                gsegs.push_back(gs);
-                                for (uint64_t o = 0; o < sl; o += CTR_UNIT)
-                                    cunits.push_back(CipherUnit{so_ + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, sl - o), si});
-                                GcmEntry ge{so_, (uint32_t)sl, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
-                                memcpy(ge.h, gm.h, 16);
-                                for (int w = 0; w < 4; w++) ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
-                                gents.push_back(ge);
-                                if (k >= 1)
-                                    for (uint64_t o = 0; o < sl; o += (1u << 20))
-                                        spread.push_back(SpreadPiece{spread_bytes + k * gcm_seg + o, so_ + o, (uint32_t)std::min<uint64_t>(1u << 20, sl - o)});
-                            }
-                            if (K > 1) spread_bytes += (plen + 15) & ~(uint64_t)15;
-                            plen += 16 * K;
-                        } else {
-                            for (uint64_t o = 0; o < plen; o += CTR_UNIT)
-                                cunits.push_back(CipherUnit{p0 + o, cpos + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, plen - o), (uint32_t)(e - e0)});
-                            cpos += plen;
-                        }
+                const uint64_t p0 = pos + f0.prefix_len;           // where the payload starts
+                uint64_t plen = seg_off[s1] - seg_off[s0];         // the entry's compressed stream, then what the cipher makes of it
+                for (uint32_t sg = s0; sg < s1; sg++) segdst[sg] = p0 + (seg_off[sg] - seg_off[s0]);
+                if (cbc) {
+                    // CBC chains the whole entry (one lane) and appends the PKCS#7 padding block, in place
+                    cunits.push_back(CipherUnit{p0, 0, (uint32_t)plen, (uint32_t)(e - e0)});
+                    plen = (plen / 16 + 1) * 16;
+                    if (plen > CH) return fail(c, PNA_E_UNSUPPORTED, "CBC entry beyond one FDAT chunk");
+                } else if (gcm) {
+                    // GCM STREAM (GcmEncryptWriter, lib/src/cipher/gcm.rs:48-100): the payload in segments of segment_size bytes, every
+                    // segment followed by its 16-byte tag; all but the last carry nonce flag 0, the last one (possibly full, possibly
+                    // empty) flag 1; counters 0, 1, ...  Segments k >= 1 move forward by 16 k bytes before the cipher runs.
+                    const uint64_t K = plen ? (plen + gcm_seg - 1) / gcm_seg : 1;
+                    if (K > 0xFFFFFFFFull) return fail(c, PNA_E_INVAL, "GCM segment counter overflow");
+                    if (plen + 16 * K > CH) return fail(c, PNA_E_UNSUPPORTED, "GCM entry beyond one FDAT chunk");
+                    const GcmMaterial &gm = gmat[e - e0];
+                    if (K > 1) { spread_copy.emplace_back(p0, plen); }
+                    for (uint64_t k = 0; k < K; k++) {
+                        const uint64_t sl = std::min<uint64_t>(gcm_seg, plen - k * gcm_seg), so_ = p0 + k * ((uint64_t)gcm_seg + 16);
+                        const uint32_t si = (uint32_t)gsegs.size();
+                        uint8_t j0[16], eb[16];
+                        memcpy(j0, gm.ctr_iv, 7);                                  // nonce prefix
+                        j0[7] = (uint8_t)(k >> 24); j0[8] = (uint8_t)(k >> 16); j0[9] = (uint8_t)(k >> 8); j0[10] = (uint8_t)k; j0[11] = k + 1 == K ? 1 : 0;
+                        j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+                        aes256_block_host(gm.rk, j0, eb);
+                        GcmSeg gs; memcpy(gs.ctr_iv, j0, 16); gs.ctr_iv[15] = 2; gs.entry = (uint32_t)(e - e0);
+                        gsegs.push_back(gs);
+                        for (uint64_t o = 0; o < sl; o += CTR_UNIT)
+                            cunits.push_back(CipherUnit{so_ + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, sl - o), si});
+                        GcmEntry ge{so_, (uint32_t)sl, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                        memcpy(ge.h, gm.h, 16);
+                        for (int w = 0; w < 4; w++) ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
+                        gents.push_back(ge);
+                        if (k >= 1)
+                            for (uint64_t o = 0; o < sl; o += (1u << 20))
+                                spread.push_back(SpreadPiece{spread_bytes + k * gcm_seg + o, so_ + o, (uint32_t)std::min<uint64_t>(1u << 20, sl - o)});
                     }
-                    if (plen >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "segment group too large for one FDAT chunk");
+                    if (K > 1) spread_bytes += (plen + 15) & ~(uint64_t)15;
+                    plen += 16 * K;
+                }
+                // the FDAT chunks: CH bytes each, the last one the rest (an empty payload is one empty chunk)
+                const uint64_t K = plen ? (plen + CH - 1) / CH : 1;
+                if (K > 1) spread_copy.emplace_back(p0, plen);
+                for (uint64_t k = 0; k < K; k++) {
+                    const uint64_t cl = std::min<uint64_t>(CH, plen - k * CH), cstart = p0 + k * (CH + 12);   // the chunk's data in the archive
                     FrameDesc u;
-                    if (first) u = f0;
-                    else { u.prefix_off = (uint32_t)blob_len; u.prefix_len = 8; memcpy(blob + blob_len + 4, "FDAT", 4); blob_len += 8; }
+                    if (k == 0) { u = f0; u.arc_off = pos; }
+                    else { u.prefix_off = (uint32_t)blob_len; u.prefix_len = 8; u.arc_off = cstart - 8; memcpy(blob + blob_len + 4, "FDAT", 4); blob_len += 8; }
                     uint8_t *lenf = &blob[u.prefix_off + u.prefix_len - 8];  // FDAT chunk length, big-endian
-                    lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
-                    u.arc_off = pos; u.payload_len = (uint32_t)plen; u.pad = g1 < s1 ? 2u : 0u;
-                    for (uint32_t sg = g0; sg < g1; sg++) segdst[sg] = pos + u.prefix_len + (seg_off[sg] - seg_off[g0]);
-                    pos += u.prefix_len + plen + 4 + (g1 < s1 ? 0 : 12);
+                    lenf[0] = (uint8_t)(cl >> 24); lenf[1] = (uint8_t)(cl >> 16); lenf[2] = (uint8_t)(cl >> 8); lenf[3] = (uint8_t)cl;
+                    u.payload_len = (uint32_t)cl; u.pad = k + 1 < K ? 2u : 0u;
                     units.push_back(u);
-                    g0 = g1; first = false;
-                } while (g0 < s1);
+                    if (k >= 1)
+                        for (uint64_t o = 0; o < cl; o += (1u << 20))
+                            spread.push_back(SpreadPiece{spread_bytes + k * CH + o, cstart + o, (uint32_t)std::min<uint64_t>(1u << 20, cl - o)});
+                    if (ctr)                                       // CTR keeps the length and may be cut anywhere: the keystream position runs on over the chunks
+                        for (uint64_t o = 0; o < cl; o += CTR_UNIT)
+                            cunits.push_back(CipherUnit{cstart + o, k * CH + o, (uint32_t)std::min<uint64_t>(CTR_UNIT, cl - o), (uint32_t)(e - e0)});
+                }
+                if (K > 1) spread_bytes += (plen + 15) & ~(uint64_t)15;
+                pos += f0.prefix_len + plen + 12 * (K - 1) + 4 + 12;
             }
             nunit = units.size();
             memcpy(fds, units.data(), nunit * sizeof(FrameDesc));
@@ -963,6 +968,17 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st);
+    if (!spread.empty()) {
+        // entries of several FDAT chunks / GCM segments: save the compact payloads, then put the pieces behind the first one at their places
+        std::vector<PlaceDescH> pd(spread.size());
+        for (size_t i = 0; i < spread.size(); i++) pd[i] = PlaceDescH{spread[i].src, spread[i].dst, spread[i].len, 0};
+        if (c->ci_spread.ensure(spread_bytes + 64) || c->ci_spread_desc.ensure(pd.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "chunk workspace");
+        uint64_t sp = 0;
+        for (auto &cp : spread_copy) { HIPCHK(c, hipMemcpyAsync((uint8_t *)c->ci_spread.p + sp, d_dst + cp.first, cp.second, hipMemcpyDeviceToDevice, st)); sp += (cp.second + 15) & ~(uint64_t)15; }
+        HIPCHK(c, hipMemcpyAsync(c->ci_spread_desc.p, pd.data(), pd.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
+        launch_gather(c->ci_spread_desc.p, (uint32_t)pd.size(), (const uint8_t *)c->ci_spread.p, d_dst, st);
+        HIPCHK(c, hipStreamSynchronize(st));                      // pd goes out of scope
+    }
     if (fj && fj->cipher) {
         if (solid && fj->cipher->cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "solid archives: only CTR on the device path (CBC is one serial chain)");
         int rc = ensure_aes(c); if (rc) return rc;
@@ -975,17 +991,6 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             giv.resize(gsegs.size() * 16); gkeys.resize(gsegs.size());
             for (size_t i = 0; i < gsegs.size(); i++) { memcpy(&giv[16 * i], gsegs[i].ctr_iv, 16); gkeys[i] = gmat[gsegs[i].entry].rk; }
             if (c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) || c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16) || c->ci_ivs.ensure(giv.size() + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
-            if (!spread.empty()) {
-                // multi-segment entries: save the compact payloads, then put the segments behind the first one at their places between the tags
-                std::vector<PlaceDescH> pd(spread.size());
-                for (size_t i = 0; i < spread.size(); i++) pd[i] = PlaceDescH{spread[i].src, spread[i].dst, spread[i].len, 0};
-                if (c->ci_spread.ensure(spread_bytes + 64) || c->ci_spread_desc.ensure(pd.size() * sizeof(PlaceDescH) + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
-                uint64_t sp = 0;
-                for (auto &cp : spread_copy) { HIPCHK(c, hipMemcpyAsync((uint8_t *)c->ci_spread.p + sp, d_dst + cp.first, cp.second, hipMemcpyDeviceToDevice, st)); sp += (cp.second + 15) & ~(uint64_t)15; }
-                HIPCHK(c, hipMemcpyAsync(c->ci_spread_desc.p, pd.data(), pd.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
-                launch_gather(c->ci_spread_desc.p, (uint32_t)pd.size(), (const uint8_t *)c->ci_spread.p, d_dst, st);
-                HIPCHK(c, hipStreamSynchronize(st));              // pd goes out of scope
-            }
             HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, giv.data(), giv.size(), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->ci_keys.p, gkeys.data(), gkeys.size() * sizeof(AesKey), hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->ci_gcm.p, gents.data(), gents.size() * sizeof(GcmEntry), hipMemcpyHostToDevice, st));
@@ -1143,10 +1148,32 @@ static int check_meta(pna_gpu_ctx *c, const pna_gpu_entry_meta *meta, size_t n) 
 
 // ... and with per-entry metadata: chunks the host has already framed (timestamps, permissions, owner, xattr: try_for_each_metadata_facet,
 // lib/src/entry.rs:124-180; user-defined extra chunks) are placed where NormalEntry::write_chunks_to puts them.
+static int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                      const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                      const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, uint32_t max_chunk, void *d_dst, size_t dst_cap,
+                                      uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream);
 extern "C" int pna_gpu_create_archive_meta_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                   const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                                   const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, void *d_dst, size_t dst_cap,
                                                   uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
+    return create_archive_device_impl(c, algo, level, n, names, d_src, src_off, src_len, cipher, meta, c ? (uint32_t)c->tun.max_chunk_size : 0u, d_dst, dst_cap, entry_off, archive_len, part_flags, hip_stream);
+}
+extern "C" int pna_gpu_create_archive_chunked_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                     const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                                     const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, uint32_t max_chunk_size, void *d_dst, size_t dst_cap,
+                                                     uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
+    return create_archive_device_impl(c, algo, level, n, names, d_src, src_off, src_len, cipher, meta, max_chunk_size, d_dst, dst_cap, entry_off, archive_len, part_flags, hip_stream);
+}
+extern "C" size_t pna_gpu_archive_chunked_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher, uint32_t max_chunk_size) {
+    size_t b = cipher && cipher->encryption != PNA_ENC_NONE ? pna_gpu_archive_enc_bound(algo, n, names, src_len, cipher) : pna_gpu_archive_bound(algo, n, names, src_len);
+    const uint64_t CH = chunk_limit(max_chunk_size);
+    for (size_t i = 0; i < n; i++) b += 12 * (size_t)((pna_gpu_bound(algo, (size_t)src_len[i]) + 64 + 16 * (src_len[i] >> 12)) / CH + 1);   // a CRC + a header per further chunk
+    return b;
+}
+static int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                      const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
+                                      const pna_gpu_cipher *cipher, const pna_gpu_entry_meta *meta, uint32_t max_chunk, void *d_dst, size_t dst_cap,
+                                      uint64_t *entry_off, uint64_t *archive_len, uint32_t part_flags, void *hip_stream) {
     { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
@@ -1166,7 +1193,7 @@ extern "C" int pna_gpu_create_archive_meta_device(pna_gpu_ctx *c, int algo, int 
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    FrameJob fj{names, 0, cipher, ivs, meta};
+    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk};
     size_t e = 0;
     while (e < n) {
         size_t e1 = e, blocks = 0;
@@ -1382,15 +1409,20 @@ extern "C" int pna_gpu_create_archive_enc_host(pna_gpu_ctx *c, int algo, int lev
 
 static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
-                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user);
+                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user, uint32_t max_chunk);
 extern "C" int pna_gpu_create_archive_meta_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                 const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                                 const pna_gpu_entry_meta *meta, pna_sink_fn sink, void *user) {
-    return create_archive_host_impl(c, algo, level, n, names, src, src_len, cipher, meta, PNA_PART_HEAD | PNA_PART_TAIL, sink, user);
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, cipher, meta, PNA_PART_HEAD | PNA_PART_TAIL, sink, user, c ? (uint32_t)c->tun.max_chunk_size : 0u);
+}
+extern "C" int pna_gpu_create_archive_chunked_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
+                                                   const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
+                                                   const pna_gpu_entry_meta *meta, uint32_t max_chunk_size, uint32_t part_flags, pna_sink_fn sink, void *user) {
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, cipher, meta, part_flags, sink, user, max_chunk_size);
 }
 extern "C" int pna_gpu_create_archive_part_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                 const void *const *src, const size_t *src_len, uint32_t part_flags, pna_sink_fn sink, void *user) {
-    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, part_flags, sink, user);
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, part_flags, sink, user, c ? (uint32_t)c->tun.max_chunk_size : 0u);
 }
 // `pna append`: Archive::seek_to_end, then the new entries and AEND where the old AEND stood (cli/src/command/append.rs:504-560)
 extern "C" int pna_gpu_append_archive_host(pna_gpu_ctx *c, int algo, int level, const void *archive, size_t archive_len, size_t n,
@@ -1400,7 +1432,7 @@ extern "C" int pna_gpu_append_archive_host(pna_gpu_ctx *c, int algo, int level, 
     int has_next = 0;
     if (pna_archive_seek_to_end(archive, archive_len, write_at, &has_next) != PNA_OK) return fail(c, PNA_E_INVAL, "not a PNA archive, or truncated before its AEND chunk");
     if (has_next) return fail(c, PNA_E_INVAL, "the archive continues in another part (ANXT): append to its last part");
-    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, PNA_PART_TAIL, sink, user);
+    return create_archive_host_impl(c, algo, level, n, names, src, src_len, nullptr, nullptr, PNA_PART_TAIL, sink, user, (uint32_t)c->tun.max_chunk_size);
 }
 // One process, several GPUs (SURVEY §8(b)'s `device_ids, n_devices`; §8(e)'s comparison path in C): the entries are cut into contiguous
 // index ranges balanced by bytes, one per context (= per device), every context runs the bounded host pipeline on its range on a thread of
@@ -1440,7 +1472,7 @@ extern "C" int pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_
 }
 static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
-                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user) {
+                                    const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user, uint32_t max_chunk) {
     { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
@@ -1503,7 +1535,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (c->tun.stage_threads) threads = (unsigned)c->tun.stage_threads;
-    FrameJob fj{names, 0, cipher, ivs, meta};
+    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, out_total = head.size();
     constexpr int NS = 4;

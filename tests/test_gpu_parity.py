@@ -776,11 +776,14 @@ def test_error_codes_at_the_boundary(gpu_ctx, pna, codec):
     assert gpu_ctx.compress_batch([d])[0] == codec.model_compress(d, _params(codec))
 
 
-def test_large_payload_is_cut_into_several_fdat_chunks(gpu_ctx, pna, pf, codec):
-    """FlattenWriter semantics (lib/src/util/io.rs:60-77) on the device path: a payload beyond the FDAT limit becomes several
-    FDAT chunks, cut at segment boundaries (limit lowered to 1 MiB here; 1 GiB by default)."""
+@pytest.mark.parametrize("mcs", [1000, 4097, 65536, (1 << 20) + 1, 0])
+def test_max_chunk_size_cuts_fdat_like_flatten_writer(gpu_ctx, pna, pf, codec, mcs):
+    """FlattenWriter (lib/src/util/io.rs:60-77; FileEntryBuilder::max_chunk_size, lib/src/entry/builder/file.rs:105-112): an entry's stream becomes FDAT
+    chunks of exactly max_chunk_size bytes, the last one the rest; 0 = u32::MAX.  The archive assembled in HBM (pna_gpu_create_archive_chunked_device),
+    the bounded host pipeline (..._chunked_host) and the context option "max_chunk_size" behind the plain entry points must all give the bytes of the
+    oracle's writer fed with the same streams -- plain and with AES-CTR (one keystream over all chunks, the IV a data piece of its own)."""
     import torch
-    lens = [(3 << 20) + 4567, 1000, (5 << 20), 0]
+    lens = [(3 << 20) + 4567, 1000, (2 << 20), 0, 999, 1001, 65537]
     ents = [codec.corpus_file(2 if i == 2 else 0, 600 + i, n) if n else b"" for i, n in enumerate(lens)]   # entry 2 is incompressible
     names = [f"big/{i}" for i in range(len(lens))]
     offs, pos = [], 0
@@ -790,29 +793,41 @@ def test_large_payload_is_cut_into_several_fdat_chunks(gpu_ctx, pna, pf, codec):
     for o, e in zip(offs, ents):
         if e:
             src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
-    cap = pna.archive_bound(pna.ALGO_ZSTD, names, lens)
-    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    with gpu_ctx.options(fdat_max_mib=(1, 1024)):
-        total, _ = gpu_ctx.create_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap)
+    payloads = gpu_ctx.compress_batch(ents)
+    big = pf.MAX_CHUNK_DATA_LENGTH
+    want = pf.write_archive_header() + b"".join(
+        pf.write_normal_entry(pf.file_entry_header(2, nm), pf.flatten_writer([pl], mcs or big) or [b""], len(e)) for nm, pl, e in zip(names, payloads, ents)
+    ) + pf.finalize_archive()
+    cap = pna.archive_chunked_bound(pna.ALGO_ZSTD, names, lens, mcs)
+    dst = torch.full((cap + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    total, _ = gpu_ctx.create_archive_chunked_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, mcs)
     got = dst[:total].cpu().numpy().tobytes()
-    # expected: frames of the 1 MiB segments, grouped greedily while the group stays within 1 MiB (at least one segment per group)
-    want = pf.write_archive_header()
-    for nm, e in zip(names, ents):
-        segs = [e[i:i + (1 << 20)] for i in range(0, len(e), 1 << 20)] or [b""]
-        frames = gpu_ctx.compress_batch(segs)
-        pieces, cur = [], b""
-        for fr in frames:
-            if cur and len(cur) + len(fr) > (1 << 20):
-                pieces.append(cur); cur = b""
-            cur += fr
-        pieces.append(cur)
-        want += pf.write_normal_entry(pf.file_entry_header(2, nm), pieces, len(e))
-    want += pf.finalize_archive()
     assert got == want
+    assert bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+    assert pna.create_archive_chunked(gpu_ctx, names, ents, mcs) == want
+    with gpu_ctx.options(max_chunk_size=(mcs, 0)):
+        assert pna.create_archive(gpu_ctx, names, ents) == want                     # the entry points without the parameter follow the option
     _, items = pf.read_archive(got)
     assert [codec.decode_payload(2, it.data, len(e) + 64) for it, e in zip(items, ents)] == ents
-    assert sum(1 for t, _ in items[2].chunks if t == b"FDAT") >= 5
-
+    if mcs:
+        assert sum(1 for t, _ in items[0].chunks if t == b"FDAT") == -(-len(payloads[0]) // mcs)
+    assert [(n, d) for n, _, d in pna.extract_archive(gpu_ctx, got)] == list(zip(names, ents))
+    # AES-256-CTR: FDAT(iv) then the ciphertext in chunks of max_chunk_size
+    key, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
+    ivs = bytes((7 * i) & 0xFF for i in range(16 * len(ents)))
+    ci = pna.Cipher(key, phsf, pna.MODE_CTR, ivs=ivs)
+    ewant = pf.write_archive_header() + b"".join(
+        pf.write_encrypted_file_entry(2, 1, 1, nm, phsf, ivs[16 * i:16 * i + 16], codec.aes_ctr(key, ivs[16 * i:16 * i + 16], pl), len(e), mcs or big)
+        for i, (nm, pl, e) in enumerate(zip(names, payloads, ents))) + pf.finalize_archive()
+    ecap = pna.archive_chunked_bound(pna.ALGO_ZSTD, names, lens, mcs, cipher=ci)
+    edst = torch.zeros(ecap + 64, dtype=torch.uint8, device="cuda")
+    etotal, _ = gpu_ctx.create_archive_chunked_device(names, src.data_ptr(), offs, lens, edst.data_ptr(), ecap, mcs, cipher=ci)
+    assert edst[:etotal].cpu().numpy().tobytes() == ewant
+    assert pna.create_archive_chunked(gpu_ctx, names, ents, mcs, cipher=ci) == ewant
+    if mcs and mcs < 100000:
+        # CBC chains the whole entry and GCM authenticates whole segments: entries beyond one chunk are refused, not written differently
+        with pytest.raises(pna.PnaGpuError):
+            pna.create_archive_chunked(gpu_ctx, names, ents, mcs, cipher=pna.Cipher(key, phsf, pna.MODE_CBC, ivs=ivs))
 
 # ---------------------------------------------------------------------------------------------------------
 # Device inflate (k_inflate -> k_zoff / k_zexec -> k_iadler): flate2::read::ZlibDecoder behind decompress_reader
