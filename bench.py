@@ -225,6 +225,9 @@ def main() -> None:
     ap.add_argument("--gather-pieces", type=int, default=0,
                     help="archive framing: cut every rank's shard into this many pieces, each compressed and gathered on its own "
                          "(0 = 2 when N > 1, else 1)")
+    ap.add_argument("--gather", choices=["torch", "lib"], default="torch",
+                    help="N > 1: the ordered gather through torch.distributed (nccl = RCCL; overlapped with the next piece's compression) or through the "
+                         "library's own pna_gpu_gather_ordered (RCCL behind the C ABI, include/pna_gpu.h; synchronous per piece)")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-sink leg (N = 1, archive framing)")
@@ -319,6 +322,11 @@ def main() -> None:
     dsts = [torch.empty(dst_cap, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     arg_cache = [dict() for _ in range(pieces)]
 
+    lib_comm = None
+    if world > 1 and args.gather == "lib" and not rehearsal:
+        uid = [pna.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        lib_comm = pna.Comm(dev.index, uid[0], world, rank)
     gather_out = [None] * pieces                              # rank 0: where the pieces h of all ranks land, in rank order
     piece_sizes = [None] * pieces                             # bytes every rank contributed to piece h (from the last gather of that piece)
     pending = [None] * nbuf                                   # the gather that still reads dsts[b]
@@ -331,8 +339,10 @@ def main() -> None:
         for k in (range(nbuf) if b is None else [b]):
             if pending[k] is not None:
                 if pending[k] != "d2h":
-                    _, sizes_k = shard.gather_ordered_wait(pending[k][0])
+                    out_k, sizes_k = shard.gather_ordered_wait(pending[k][0])
                     piece_sizes[pending[k][1]] = sizes_k
+                    if rank == 0 and out_k is not None:
+                        gather_out[pending[k][1]] = out_k         # (the gather allocates a larger buffer when the ranks' pieces outgrow the one it was offered)
                 torch.cuda.current_stream().synchronize()     # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
                 pending[k] = None
 
@@ -361,7 +371,13 @@ def main() -> None:
             lz_acc[2] += tm.ms_lz_match
             lz_acc[3] += tm.lz_match_launches
             lz_acc[1] += tm.ms_lz + tm.ms_stats + tm.ms_lit + tm.ms_seq + tm.ms_pack + tm.ms_frame + tm.ms_cipher
-            if world > 1 and mode[0] == "rccl":
+            if world > 1 and mode[0] == "rccl" and lib_comm is not None:
+                # the library's gather: a worst-case destination (every rank's piece is below the archive bound of its entries), one call
+                if rank == 0 and gather_out[h] is None:
+                    gather_out[h] = torch.empty(dst_cap * world, dtype=torch.uint8, device=dev)
+                sizes_h, _ = lib_comm.gather_ordered(dst.data_ptr(), total, gather_out[h].data_ptr() if rank == 0 else 0, dst_cap * world if rank == 0 else 0)
+                piece_sizes[h] = sizes_h
+            elif world > 1 and mode[0] == "rccl":
                 if rank == 0 and gather_out[h] is None:
                     gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=xdev)
                 pending[b] = (shard.gather_ordered_start(dst[:total].cpu() if rehearsal else dst, total, rank, world, out=gather_out[h]), h)

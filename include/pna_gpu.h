@@ -304,6 +304,26 @@ int  pna_gpu_append_archive_host(pna_gpu_ctx *ctx, int algo, int level, const vo
                                  const char *const *names, const void *const *src, const size_t *src_len, uint64_t *write_at,
                                  pna_sink_fn sink, void *user);
 
+/* ---- several GPUs, one process per GPU: rank r compresses the contiguous index range r of the entries into an archive PART in its HBM
+ * (pna_gpu_create_archive_part_device: PNA_PART_HEAD on the first rank, PNA_PART_TAIL on the last), and the parts in rank order are the archive -- the
+ * fan-out and ordered drain of cli/src/command/core.rs:496-537,471-493 with GPUs in place of worker threads.  The one exchange step is the ordered
+ * gather: an all-gather of the parts' sizes (8 bytes per rank), then every rank sends its part to `root` (ncclSend / ncclRecv in one group: a link per
+ * peer over xGMI), which receives them at the prefix sums of the sizes.  RCCL is loaded with dlopen at the first call (PNA_E_UNSUPPORTED when the
+ * host has none).  Bootstrap as with NCCL: rank 0 calls pna_gpu_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the
+ * host has (the reference has none: it is a single process), every rank calls pna_gpu_comm_init.  All calls are collective.
+ *   sizes  (host, nranks values, may be NULL) receives every part's length on every rank; *total their sum;
+ *   d_out / out_cap matter on `root` only: PNA_E_DSTSIZE when the parts do not fit. */
+#define PNA_COMM_ID_BYTES 128
+typedef struct pna_gpu_comm pna_gpu_comm;
+int  pna_gpu_comm_unique_id(void *id128);
+int  pna_gpu_comm_init(int device_id, const void *id128, int nranks, int rank, pna_gpu_comm **out);
+void pna_gpu_comm_destroy(pna_gpu_comm *comm);
+const char *pna_gpu_comm_last_error(const pna_gpu_comm *comm);
+int  pna_gpu_gather_ordered(pna_gpu_comm *comm, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
+                            uint64_t *sizes, uint64_t *total, void *hip_stream);
+/* offs[r] = where rank r's part starts in the gathered stream, offs[nranks] = the total (host arithmetic; what the gather above uses) */
+int  pna_gather_offsets(const uint64_t *sizes, int nranks, uint64_t *offs);
+
 /* ---- Archive::write_file / write_stream_entry (lib/src/archive/write.rs:276-299,730-777): an entry written WHILE its data arrives.
  * The record has no fSIZ (the size is not known when FHED goes out): FHED, the caller's already framed extra + metadata chunks
  * (`meta`, may be NULL), then the compressed stream as FDAT chunks -- one per burst the encoder hands to the ChunkStreamWriter

@@ -103,7 +103,8 @@ _lib = None
 
 EXPORTS = [
     "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_archive_chunked_bound", "pna_gpu_create_archive_chunked_device",
-    "pna_gpu_create_archive_chunked_host", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_create_archive_chunked_host", "pna_gpu_comm_unique_id", "pna_gpu_comm_init", "pna_gpu_comm_destroy", "pna_gpu_comm_last_error",
+    "pna_gpu_gather_ordered", "pna_gather_offsets", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
@@ -662,6 +663,56 @@ def create_archive_chunked(ctx: "Context", names: Sequence[str], entries: Sequen
     if rc:
         raise PnaGpuError(rc, L.pna_gpu_last_error(ctx._h).decode() or L.pna_gpu_strerror(rc).decode())
     return bytes(out)
+
+
+def gather_offsets(sizes: Sequence[int]) -> List[int]:
+    """pna_gather_offsets: where every rank's part starts in the gathered stream (+ the total)."""
+    n = len(sizes)
+    a = (ctypes.c_uint64 * max(n, 1))(*sizes)
+    o = (ctypes.c_uint64 * (n + 1))()
+    rc = load_library().pna_gather_offsets(a, n, o)
+    if rc:
+        raise PnaGpuError(rc, "pna_gather_offsets")
+    return list(o)
+
+
+class Comm:
+    """pna_gpu_comm: the RCCL communicator of the ordered gather (one process per GPU).  `Comm.unique_id()` on rank 0, the 128 bytes to all ranks."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = load_library().pna_gpu_comm_unique_id(buf)
+        if rc:
+            raise PnaGpuError(rc, "pna_gpu_comm_unique_id (is RCCL installed?)")
+        return buf.raw
+
+    def __init__(self, device: int, uid: bytes, nranks: int, rank: int):
+        self._L = load_library()
+        self._L.pna_gpu_comm_last_error.restype = ctypes.c_char_p
+        self._L.pna_gpu_comm_last_error.argtypes = [ctypes.c_void_p]
+        h = ctypes.c_void_p()
+        rc = self._L.pna_gpu_comm_init(device, bytes(uid), nranks, rank, ctypes.byref(h))
+        if rc:
+            raise PnaGpuError(rc, "pna_gpu_comm_init")
+        self._h, self.nranks, self.rank = h, nranks, rank
+
+    def gather_ordered(self, d_local: int, local_len: int, d_out: int = 0, out_cap: int = 0, root: int = 0, stream: int = 0):
+        """Returns (sizes of all ranks' parts, total); on `root` the parts lie in d_out in rank order."""
+        sizes = (ctypes.c_uint64 * self.nranks)()
+        total = ctypes.c_uint64()
+        f = self._L.pna_gpu_gather_ordered
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(self._h, ctypes.c_void_p(d_local), local_len, root, ctypes.c_void_p(d_out), out_cap, sizes, ctypes.byref(total), ctypes.c_void_p(stream) if stream else None)
+        if rc:
+            raise PnaGpuError(rc, self._L.pna_gpu_comm_last_error(self._h).decode())
+        return list(sizes), total.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pna_gpu_comm_destroy.argtypes = [ctypes.c_void_p]
+            self._L.pna_gpu_comm_destroy(self._h)
+            self._h = None
 
 
 def solid_archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int]) -> int:

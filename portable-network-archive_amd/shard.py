@@ -89,13 +89,14 @@ def gather_ordered_start(local, local_bytes: int, rank: int, world: int, out=Non
             if sizes[r]:
                 ops.append(dist.P2POp(dist.irecv, out[pos:pos + sizes[r]], r))
             pos += sizes[r]
-        return {"works": dist.batch_isend_irecv(ops) if ops else [], "out": out[:need], "sizes": sizes}
+        return {"works": dist.batch_isend_irecv(ops) if ops else [], "out": out, "sizes": sizes}      # `out`: the buffer in use -- the caller's, or a larger one allocated here
     works = dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]) if local_bytes else []
     return {"works": works, "out": None, "sizes": sizes}
 
 
 def gather_ordered_wait(handle):
-    """Completes a gather_ordered_start(); returns (tensor on rank 0 / None elsewhere, sizes)."""
+    """Completes a gather_ordered_start(); returns (buffer on rank 0 / None elsewhere, sizes): the gathered bytes are buffer[:sum(sizes)], and the buffer
+    is the one to offer as `out` next time (it is not the caller's own when that was too small)."""
     for w in handle["works"]:
         w.wait()
     return handle["out"], handle["sizes"]

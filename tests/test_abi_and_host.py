@@ -241,3 +241,12 @@ def test_seek_to_end_and_entry_listing(pna, pf):
     solid = golden("solid_zstd.pna")
     (s,) = pna.list_entries(solid)
     assert s[1] == -1 and solid[s[2] + 4:s[2] + 8] == b"SHED" and s[2] + s[3] == pna.seek_to_end(solid)[0]
+
+
+def test_gather_offsets(pna):
+    """The ordered gather places rank r's part at the prefix sum of the earlier parts' sizes (the order of ReorderByIndex,
+    cli/src/command/core/iter.rs:21-80): pinned here on the CPU, used by pna_gpu_gather_ordered and by bench.py's direct-D2H comparison path."""
+    assert pna.gather_offsets([5]) == [0, 5]
+    assert pna.gather_offsets([3, 0, 7, 1 << 40, 2]) == [0, 3, 3, 10, 10 + (1 << 40), 12 + (1 << 40)]
+    with pytest.raises(pna.PnaGpuError):
+        pna.gather_offsets([1 << 63, 1 << 63])

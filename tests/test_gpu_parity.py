@@ -1313,3 +1313,25 @@ def test_one_process_several_contexts(gpu_ctx, pna, pf, codec):
     finally:
         for c in extra:
             c.close()
+
+
+def test_ordered_gather_over_rccl_single_rank(gpu_ctx, pna, pf, codec):
+    """pna_gpu_gather_ordered on a communicator of ONE rank (RCCL initialises on a single device; the N-GPU run is the driver's): the all-gather of
+    the sizes and the root's own copy run for real, the archive part arrives unchanged and reads back."""
+    import torch
+    ents = [codec.corpus_file(0, 3100 + i, 200000 + 1000 * i) for i in range(6)]
+    names = [f"g/{i}" for i in range(len(ents))]
+    arc = pna.create_archive(gpu_ctx, names, ents)
+    local = torch.frombuffer(bytearray(arc), dtype=torch.uint8).cuda()
+    out = torch.zeros(len(arc) + 64, dtype=torch.uint8, device="cuda")
+    comm = pna.Comm(0, pna.Comm.unique_id(), 1, 0)
+    try:
+        sizes, total = comm.gather_ordered(local.data_ptr(), len(arc), out.data_ptr(), out.numel())
+        assert sizes == [len(arc)] and total == len(arc)
+        assert out[:total].cpu().numpy().tobytes() == arc and int(out[total:].sum()) == 0
+        assert [(n, d) for n, _, d in pna.extract_archive(gpu_ctx, out[:total].cpu().numpy().tobytes())] == list(zip(names, ents))
+        with pytest.raises(pna.PnaGpuError):
+            comm.gather_ordered(local.data_ptr(), len(arc), out.data_ptr(), 100)          # destination too small
+        assert comm.gather_ordered(0, 0, out.data_ptr(), out.numel()) == ([0], 0)          # an empty part
+    finally:
+        comm.close()

@@ -38,6 +38,10 @@ def _worker(rank, world, port, q):
     h = shard.gather_ordered_start(blob, sum(len(m) for m in mine), rank, world)
     got2, shard_bytes2 = shard.gather_ordered_wait(h)
     assert shard_bytes2 == shard_bytes and (rank != 0 or bytes(got2.numpy().tobytes()) == bytes(got.numpy().tobytes()))
+    # a destination that is too small is replaced, and the handle hands the buffer in use back (bench.py keeps it for the read-back and the next step)
+    h3 = shard.gather_ordered_start(blob, sum(len(m) for m in mine), rank, world, out=torch.empty(10, dtype=torch.uint8) if rank == 0 else None)
+    got3, sb3 = shard.gather_ordered_wait(h3)
+    assert sb3 == shard_bytes and (rank != 0 or (got3.numel() >= sum(sb3) and bytes(got3[:sum(sb3)].numpy().tobytes()) == bytes(got.numpy().tobytes())))
     # two gathers in flight at once, each into its own destination -- what bench.py does with --gather-pieces 2 (piece 0 travels while
     # piece 1 is compressed into the other buffer)
     half = len(mine) // 2
