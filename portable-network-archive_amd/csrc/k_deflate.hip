@@ -184,7 +184,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t g = sd.blk_base + b;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
-        const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+        const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
         uint32_t *hl = h_lit[tid & 7];
         const uint32_t n16 = nlit >> 4;
         for (uint32_t i = tid; i < n16; i += DS_THREADS) {
@@ -197,7 +197,7 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
             }
         }
         for (uint32_t i = (n16 << 4) + tid; i < nlit; i += DS_THREADS) atomicAdd(&hl[bl[i]], 1u);
-        const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+        const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
         for (uint32_t i = tid; i < nseq; i += DS_THREADS) {
             const uint64_t s = bs[i];
             uint32_t c, eb, ev;
@@ -424,9 +424,9 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     const uint32_t ntile = (bl_len + TILE - 1) / TILE;
     const uint32_t nseq = blk[g].nseq, nlit = blk[g].nlit;
-    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
-    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    unsigned long long *out64 = (unsigned long long *)(outc + (size_t)g * BLK_SIZE);
+    const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
+    const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
+    unsigned long long *out64 = (unsigned long long *)(outc + ((size_t)g << sd.blk_log));
     const uint32_t hdr_bits = T->hdr_bits;
     __syncthreads();
 
@@ -443,7 +443,7 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     auto flush = [&](uint32_t nslots) {
         __syncthreads();
         const uint32_t nfull = (bitpos >> 6) - flushed;
-        for (uint32_t i = tid; i < nfull; i += DB_THREADS) if (flushed + i < BLK_SIZE / 8) out64[flushed + i] = stage[i];
+        for (uint32_t i = tid; i < nfull; i += DB_THREADS) if (flushed + i < bsz / 8) out64[flushed + i] = stage[i];
         const unsigned long long carry = stage[nfull];
         __syncthreads();
         for (uint32_t i = tid; i <= nfull + 1 && i < DB_STAGE; i += DB_THREADS) stage[i] = i == 0 ? carry : 0ull;
@@ -454,10 +454,10 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     flush(0);
 
     for (uint32_t t = 0; t < ntile; t++) {
-        const uint4 c = ctab[(size_t)g * (BLK_SIZE / TILE) + t];
+        const uint4 c = ctab[((size_t)g << (sd.blk_log - 11)) + t];
         const uint32_t s0 = c.x, l0 = c.y;
         uint32_t s1 = nseq, l1 = nlit;
-        if (t + 1 < ntile) { const uint4 cn = ctab[(size_t)g * (BLK_SIZE / TILE) + t + 1]; s1 = cn.x; l1 = cn.y; }
+        if (t + 1 < ntile) { const uint4 cn = ctab[((size_t)g << (sd.blk_log - 11)) + t + 1]; s1 = cn.x; l1 = cn.y; }
         const uint32_t ns = s1 - s0, nl = l1 - l0;
         const uint32_t gf = (ns ? c.z : l1) - l0;            // slot of the tile's first match
         const uint32_t base = bitpos - (flushed << 6);      // staging bit offset of the tile's first token
@@ -548,7 +548,7 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     __syncthreads();
     const uint32_t bytes = (bitpos + 7) / 8;
     const uint32_t nun = (bitpos + 63) / 64 - flushed;
-    for (uint32_t i = tid; i < nun; i += DB_THREADS) if (flushed + i < BLK_SIZE / 8) out64[flushed + i] = stage[i];
+    for (uint32_t i = tid; i < nun; i += DB_THREADS) if (flushed + i < bsz / 8) out64[flushed + i] = stage[i];
     if (tid == 0) blk[g].lit_body = bytes;
 }
 
@@ -589,7 +589,7 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     uint8_t *out = dst + seg_off[sidx] + bi.out_off;
     if (bi.plan & 1) {
-        const uint8_t *p = outc + (size_t)g * BLK_SIZE;
+        const uint8_t *p = outc + ((size_t)g << sd.blk_log);
         for (uint32_t i = tid; i < bi.lit_body; i += 256) out[i] = p[i];
         if (!last && tid < 4) out[bi.lit_body + tid] = (tid < 2) ? 0x00 : 0xFF;
     } else {

@@ -261,7 +261,8 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
 constexpr uint32_t HIST_WORDS = 256 + 3 * 64;
 __global__ __launch_bounds__(ST_THREADS)
 void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
-            const BlkInfo *__restrict__ blk, uint32_t *__restrict__ hist, uint16_t *__restrict__ seqw, uint32_t g0) {
+            const BlkInfo *__restrict__ blk, uint32_t *__restrict__ hist, uint16_t *__restrict__ seqw, uint32_t g0, uint32_t blk_log) {
+    const uint32_t SC = seq_cap_of(blk_log);
     __shared__ uint32_t h_lit[8][256];
     __shared__ uint32_t h_seq[3][4][64];
     __shared__ uint8_t s_llc[64], s_mlc[128], s_llb[64], s_mlb[128];
@@ -272,7 +273,7 @@ void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
     if (tid < 64) { s_llc[tid] = C_LL_CODE[tid]; s_llb[tid] = C_LL_BITS[C_LL_CODE[tid]]; }
     if (tid < 128) { s_mlc[tid] = C_ML_CODE[tid]; s_mlb[tid] = C_ML_BITS[C_ML_CODE[tid]]; }
     __syncthreads();
-    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    const uint8_t *bl = lits + ((size_t)g << blk_log);
     uint32_t *hl = h_lit[tid & 7];
     const uint32_t n16 = nlit >> 4;
     for (uint32_t i = tid; i < n16; i += ST_THREADS) {
@@ -285,8 +286,8 @@ void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
         }
     }
     for (uint32_t j = (n16 << 4) + tid; j < nlit; j += ST_THREADS) atomicAdd(&hl[bl[j]], 1u);
-    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    uint16_t *bw = seqw + (size_t)g * SEQ_CAP * 4;                      // three arrays of SEQ_CAP u16: LL, OF, ML
+    const uint64_t *bs = seqs + (size_t)g * SC;
+    uint16_t *bw = seqw + (size_t)g * SC * 4;                           // three arrays of SC u16: LL, OF, ML
     for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
         const uint64_t s = bs[i];
         const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
@@ -297,7 +298,7 @@ void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
         atomicAdd(&h_seq[1][tid & 3][oc], 1u);
         atomicAdd(&h_seq[2][tid & 3][mc], 1u);
         // for the chain kernel (k_seqa): per stream the sequence's code and its number of extra bits, a u16; k_seqa puts its state flushes in their place
-        bw[i] = (uint16_t)(lc | (lx << 8)); bw[SEQ_CAP + i] = (uint16_t)(oc | (oc << 8)); bw[2 * SEQ_CAP + i] = (uint16_t)(mc | (mx << 8));
+        bw[i] = (uint16_t)(lc | (lx << 8)); bw[SC + i] = (uint16_t)(oc | (oc << 8)); bw[2 * SC + i] = (uint16_t)(mc | (mx << 8));
     }
     __syncthreads();
     uint32_t *hs = hist + (size_t)blk_seg[g] * HIST_WORDS;
@@ -345,7 +346,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         const uint32_t g = sd.blk_base + b;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         nseq_seg += nseq;
-        const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+        const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
         uint32_t *hl = h_lit[tid & 7];
         const uint32_t n16 = nlit >> 4;
         for (uint32_t i = tid; i < n16; i += ST_THREADS) {
@@ -358,7 +359,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
             }
         }
         for (uint32_t j = (n16 << 4) + tid; j < nlit; j += ST_THREADS) atomicAdd(&hl[bl[j]], 1u);
-        const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
+        const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
         for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
             const uint64_t s = bs[i];
             const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
@@ -435,7 +436,7 @@ constexpr uint32_t LIT_STAGE_Q = 184;            // qwords of staging per wave: 
 
 __global__ __launch_bounds__(LIT_THREADS)
 void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint8_t *__restrict__ lits,
-           BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags, uint32_t g0) {
+           BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ litc, uint32_t flags, uint32_t g0, uint32_t blk_log) {
     __shared__ uint32_t code[256];
     __shared__ uint32_t sbits[4];
     __shared__ unsigned long long stage[4][LIT_STAGE_Q];
@@ -443,9 +444,9 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     const uint32_t g = blockIdx.x + g0;                          // g0: first block of the chunk of segments this launch covers
     const SegTables *T = tabs + blk_seg[g];
     const uint32_t nlit = blk[g].nlit;
-    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    const uint8_t *bl = lits + ((size_t)g << blk_log);
     const uint4 *bl16 = (const uint4 *)bl;
-    unsigned long long *out64 = (unsigned long long *)(litc + (size_t)g * BLK_SIZE);
+    unsigned long long *out64 = (unsigned long long *)(litc + ((size_t)g << blk_log));
     if (!(flags & F_HUF) || nlit < 64) { if (tid == 0) { blk[g].lit_body = 0; blk[g].lit_rle = 0; } return; }
     if (!T->huf_ok) {
         // no Huffman code for this segment: only the RLE test is left (coalesced)
@@ -490,7 +491,7 @@ void k_lit(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_se
     uint32_t sz[4], off[4], body = nstreams == 4 ? 6u : 0u;
     for (uint32_t k = 0; k < 4; k++) { sz[k] = k < nstreams ? (sbits[k] >> 3) + 1 : 0; off[k] = body; body += sz[k]; }
     if (tid == 0) { blk[g].lit_body = body; blk[g].lit_rle = 0; }
-    if (body >= nlit || body > BLK_SIZE) return;                   // Huffman cannot win: k_plan picks raw literals
+    if (body >= nlit || body > (1u << blk_log)) return;                   // Huffman cannot win: k_plan picks raw literals
     for (uint32_t i = tid; i < (body + 7) / 8; i += LIT_THREADS) out64[i] = 0;
     for (uint32_t i = lane; i < LIT_STAGE_Q; i += 64) stage[wave][i] = 0;
     __builtin_amdgcn_s_waitcnt(0);
@@ -596,7 +597,8 @@ void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict
     if (nseq == 0 || !T->seq_ok) { if (st == 0) blk[g].seq_bits = 0; return; }
     const uint32_t mode = T->mode[st], tlog = T->tlog[st];
     const SeqTable *tb = mode == 1 ? &ztab : &tab[sidx - seg0][st];
-    uint16_t *w = seqw + (size_t)g * SEQ_CAP * 4 + (size_t)st * SEQ_CAP;   // this stream's u16 per sequence (k_hist: code | extra bits << 8)
+    const uint32_t SC = seq_cap_of(sd.blk_log);
+    uint16_t *w = seqw + (size_t)g * SC * 4 + (size_t)st * SC;   // this stream's u16 per sequence (k_hist: code | extra bits << 8)
     uint32_t state = 0, bits = 0;
     // Sequences last to first in groups of eight (one 16-byte load, one 16-byte store); the next group is requested before the current one is walked.
     // The block's last sequence only sets the initial state.
@@ -673,9 +675,9 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     // RLE mode (one symbol, no state bits) runs through the same code on an all-zero table: delta_nb = 0 gives 0 bits, state[0] = 0
     // keeps the state at 0 -- no per-sequence branch on the mode
     const SeqTable *tll = mll == 1 ? &ztab : &tab[sl][0], *tof = mof == 1 ? &ztab : &tab[sl][1], *tml = mml == 1 ? &ztab : &tab[sl][2];
-    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    uint32_t *out32 = (uint32_t *)(seqc + (size_t)g * BLK_SIZE);
-    const uint32_t cap_words = BLK_SIZE / 4;
+    const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
+    uint32_t *out32 = (uint32_t *)(seqc + ((size_t)g << sd.blk_log));
+    const uint32_t cap_words = (1u << sd.blk_log) / 4;
     uint64_t acc = 0; uint32_t nb = 0, widx = 0;
     auto put = [&](uint32_t v, uint32_t n) {               // n <= 32, v < 2^n (the accumulator holds < 32 bits before)
         acc |= (uint64_t)v << nb; nb += n;
@@ -747,7 +749,8 @@ constexpr uint32_t SB_STAGE_Q = 320;                    // 256 sequences x <= 76
 
 __global__ __launch_bounds__(SB_THREADS)
 void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs, const uint16_t *__restrict__ seqw,
-            const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t g0) {
+            const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t g0, uint32_t blk_log) {
+    const uint32_t SC = seq_cap_of(blk_log);
     __shared__ unsigned long long st[SB_STAGE_Q];
     __shared__ uint32_t wtot[SB_THREADS / 64];
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // extra bits | base << 8 (small values only)
@@ -756,14 +759,14 @@ void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
     const BlkInfo bi = blk[g];
     const SegTables *T = tabs + blk_seg[g];
     const uint32_t n = bi.nseq;
-    if (n == 0 || !T->seq_ok || bi.seq_bits >= BLK_SIZE) return;       // nothing to encode / cannot beat a raw block (k_plan)
+    if (n == 0 || !T->seq_ok || bi.seq_bits >= (1u << blk_log)) return;       // nothing to encode / cannot beat a raw block (k_plan)
     if (tid < 64) { const uint32_t c = C_LL_CODE[tid]; lut_ll[tid] = (uint32_t)C_LL_BITS[c] | (C_LL_BASE[c] << 8); }
     if (tid < 128) { const uint32_t c = C_ML_CODE[tid]; lut_ml[tid] = (uint32_t)C_ML_BITS[c] | (C_ML_BASE[c] << 8); }
     for (uint32_t i = tid; i < SB_STAGE_Q; i += SB_THREADS) st[i] = 0;
     __syncthreads();
-    unsigned long long *out64 = (unsigned long long *)(seqc + (size_t)g * BLK_SIZE);
-    const uint64_t *bs = seqs + (size_t)g * SEQ_CAP;
-    const uint16_t *w = seqw + (size_t)g * SEQ_CAP * 4;              // k_seqa's flushes (bits | count << 12): arrays LL, OF, ML
+    unsigned long long *out64 = (unsigned long long *)(seqc + ((size_t)g << blk_log));
+    const uint64_t *bs = seqs + (size_t)g * SC;
+    const uint16_t *w = seqw + (size_t)g * SC * 4;              // k_seqa's flushes (bits | count << 12): arrays LL, OF, ML
     uint32_t pos = 0, qfl = 0;                                          // next free bit of the stream; st[0] holds stream qword qfl
     for (uint32_t hi = n; hi > 0; hi = hi > SB_THREADS ? hi - SB_THREADS : 0u) {
         // thread t takes sequence hi - 1 - t: later sequences lie at lower bit positions
@@ -771,7 +774,7 @@ void k_seqb(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
         if (tid < hi) {
             const uint32_t i = hi - 1 - tid;
             const uint64_t s = bs[i];
-            const uint32_t rl = w[i], ro = w[SEQ_CAP + i], rm = w[2 * SEQ_CAP + i];
+            const uint32_t rl = w[i], ro = w[SC + i], rm = w[2 * SC + i];
             const uint32_t llv = seq_ll(s), mlv = seq_ml(s), mb = mlv - 3, ofb = seq_off(s) + 3;
             const uint32_t tl = lut_ll[llv < 64 ? llv : 63u], hl = hb(llv | 1u);
             const uint32_t lbits = llv < 64 ? (tl & 0xFF) : hl, lbase = llv < 64 ? (tl >> 8) : (1u << hl);
@@ -954,7 +957,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     out += 3;
     if (!(bi.plan & 1)) { copy_bytes(out, src + sd.src_off + b0, bl_len, tid); return; }
     const uint32_t nlit = bi.nlit, nseq = bi.nseq;
-    const uint8_t *bl = lits + (size_t)g * BLK_SIZE;
+    const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
     uint32_t pos = 0;
     // literals section
     if (bi.plan & 16) {
@@ -976,7 +979,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
             for (uint32_t i = 0; i < lh; i++) out[i] = (uint8_t)(h >> (8 * i));
         }
         copy_bytes(out + lh, T->tree, ts, tid);
-        copy_bytes(out + lh + ts, litc + (size_t)g * BLK_SIZE, hs, tid);
+        copy_bytes(out + lh + ts, litc + ((size_t)g << sd.blk_log), hs, tid);
         pos = lh + ts + hs;
     } else {
         uint32_t h = raw_lit_hdr(nlit);
@@ -1005,7 +1008,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
         }
         pos += 1;
         if (carry) for (int k = 0; k < 3; k++) { copy_bytes(out + pos, T->desc[k], T->desc_len[k], tid); pos += T->desc_len[k]; }
-        copy_bytes(out + pos, seqc + (size_t)g * BLK_SIZE, bi.seq_bits, tid);
+        copy_bytes(out + pos, seqc + ((size_t)g << sd.blk_log), bi.seq_bits, tid);
     }
 }
 
@@ -1031,19 +1034,19 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
     const uint32_t bps_log = 20u - blk_log;                                 // blocks per full segment (SEG_SIZE = 1 MiB)
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
-        if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0);
+        if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0, blk_log);
         hipLaunchKernelGGL(k_stats<true>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
     } else
         hipLaunchKernelGGL(k_stats<false>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0);
+    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
     if (ev) (void)hipEventRecord(ev[1], st);
     // two phases (short chains on three lanes per block, parallel packing) for the batches whose statistics were gathered per block (the host
     // picks them: few enough blocks that the chain waves fit the SIMDs), the one-kernel form otherwise (see k_seq)
     if (hist) {
         const uint32_t wgs = (uint32_t)((((uint64_t)ns << bps_log) + SEQA_BLKS - 1) / SEQA_BLKS);
         hipLaunchKernelGGL(k_seqa, dim3(wgs), dim3(64), 0, st, segs + s0, ns, blk, tabs + s0, (uint16_t *)seqw, bps_log);
-        if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, (const uint16_t *)seqw, blk, tabs, seqc, g0);
+        if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, (const uint16_t *)seqw, blk, tabs, seqc, g0, blk_log);
     } else {
         hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }

@@ -80,7 +80,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
-    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;   // block size of the batch (BLK_SIZE, or less in latency mode); the per-block arrays keep BLK_SIZE strides
+    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);   // block size of the batch = stride of the per-block arrays
     uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
@@ -117,8 +117,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
         const uint32_t b = blk_start >> blk_log;
         const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         const uint32_t gblk = sd.blk_base + b;
-        uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
-        uint8_t  *blit = lits + (size_t)gblk * BLK_SIZE;
+        uint64_t *bseq = seqs + (size_t)gblk * SC;
+        uint8_t  *blit = lits + ((size_t)gblk << blk_log);
         // block-level parse state, uniform across the workgroup
         uint32_t next_free = blk_start;      // first position not covered by an emitted match
         uint32_t seq_run = 0, lit_run = 0;   // sequences / literals emitted so far
@@ -526,7 +526,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         const uint64_t hm_h = hm & (mlow(WPC) << (h * WPC));
                         uint32_t g_first = lit_run + (tot >> 16);
                         if (hm_h) { const uint32_t j0 = ctz64(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + (rdlane(pl.gl, j0) >> 16) - 1; }
-                        if (tid == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
+                        if (tid == 0) ctab[((size_t)gblk << (blk_log - 11)) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
                     }
                 }
                 seq_run += tot & 0xFFFF; lit_run += tot >> 16;
@@ -556,9 +556,9 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         else if (since[r] != NONE) ll = since[r] + lq;
                         else ll = lit_base + lb - (glast1_before - 1);
                         const uint32_t idx = seq_base + nselp[r] + (uint32_t)__popcll(pm);
-                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, flen[r], off[r]);
+                        if (idx < SC) bseq[idx] = seq_pack(ll, flen[r], off[r]);
                     }
-                    if ((litm[r] >> lane) & 1) { const uint32_t li = lit_base + lb; if (li < BLK_SIZE) blit[li] = (uint8_t)lo[r]; }
+                    if ((litm[r] >> lane) & 1) { const uint32_t li = lit_base + lb; if (li < bsz) blit[li] = (uint8_t)lo[r]; }
                 }
             }
             LZ_STAMP(6);

@@ -238,7 +238,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const SegDesc sd = segs[blockIdx.x];
     const uint32_t seg_len = sd.len;
     const uint8_t *seg = src + sd.src_off;
-    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
+    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);
     const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     const uint32_t lazy = flags & F_LAZY;
     const uint32_t wbase = w * RW;
@@ -466,7 +466,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     const uint32_t hm_h = hrow & (((1u << WPC) - 1) << (h * WPC));
                     uint32_t g_first = lit_run + (tot >> 16);
                     if (hm_h) { const uint32_t j0 = (uint32_t)__builtin_ctz(hm_h); g_first = lit_run + (rdlane(excl, j0) >> 16) + rdlane(gf, j0) - 1; }
-                    if (lane == 0) ctab[(size_t)gblk * (BLK_SIZE / TILE) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
+                    if (lane == 0) ctab[((size_t)gblk << (blk_log - 11)) + (t0 - blk_start) / TILE + h] = make_uint4(seq_run + (ex_h & 0xFFFF), lit_run + (ex_h >> 16), g_first, 0u);
                 }
             }
             g_last1 = ga > g_last1 ? ga : g_last1;
@@ -506,7 +506,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         }
         // ---- 3. the sequences, one lane per group
         {
-            uint64_t *bseq = seqs + (size_t)gblk * SEQ_CAP;
+            uint64_t *bseq = seqs + (size_t)gblk * SC;
             const uint4 ra = rec[0][lane], rb = rec[1][lane], rc = rec[2][lane];
             const uint64_t lm = (uint64_t)ra.x | ((uint64_t)ra.y << 32), sc = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
             uint64_t rem = lane < ng ? (uint64_t)rb.x | ((uint64_t)rb.y << 32) : 0;
@@ -535,7 +535,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                         if (cut_b2 == s) { ml = cut_l2; of = rc.w; }
                         const uint32_t lq = (uint32_t)__popcll(lm & mlow(s));
                         const uint32_t ll = first ? rc.x + lq : lq - prev;
-                        if (idx < SEQ_CAP) bseq[idx] = seq_pack(ll, ml, of);
+                        if (idx < SC) bseq[idx] = seq_pack(ll, ml, of);
                         idx++; prev = lq; first = false;
                     }
                 }
@@ -544,7 +544,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         LZP_STAMP(3);
         // ---- 4. literals, region by region, 4 consecutive positions per lane
         {
-            uint8_t *blit = lits + (size_t)gblk * BLK_SIZE;
+            uint8_t *blit = lits + ((size_t)gblk << blk_log);
             const uint32_t sh = 4 * (lane & 15);
 #pragma unroll
             for (uint32_t wr = 0; wr < 16; wr++) {

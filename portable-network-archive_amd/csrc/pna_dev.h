@@ -61,11 +61,16 @@ struct SegDesc {
     uint32_t first;       // bit0: entry's first segment, bit1: entry's last segment
     uint32_t u0, u1;      // LZ stage: the part of the segment one workgroup parses, [u0, u1): whole blocks (u1: or the segment's end).  The segment's own
                           // descriptor has [0, len); in latency mode (small batches) the LZ kernels run over UNITS, copies of it with a piece each
-    uint32_t blk_log;     // block size of the batch = 1 << blk_log: 17 (BLK_SIZE), or BLK_LOG_MIN..16 in latency mode.  The per-block arrays keep the stride of a full block.
+    uint32_t blk_log;     // block size of the batch = 1 << blk_log: 17 (BLK_SIZE), or BLK_LOG_MIN..16 (latency mode; batches of small entries).  It is also the
+                          // stride of the per-block arrays: literals, bitstreams 1 << blk_log bytes, sequences seq_cap_of(blk_log) slots, chunk table 1 << (blk_log - 11).
     uint32_t pad;
 };
 constexpr uint32_t BLK_LOG_MIN = 13;   // smallest block of the latency mode (bounds: pna_gpu_bound)
 static_assert(sizeof(SegDesc) == 40, "SegDesc layout");
+// sequences a block of 1 << blk_log bytes can hold: a match is >= MIN_MATCH bytes but for one front-cut match (>= 3 bytes) per 256-position parse region
+__host__ __device__ inline uint32_t seq_cap_of(uint32_t blk_log) {
+    return blk_log >= PNA_BLK_LOG ? SEQ_CAP : ((((1u << blk_log) / MIN_MATCH + ((1u << blk_log) >> 8) + 256 + 255)) & ~255u);
+}
 __host__ __device__ inline uint32_t seg_nblk(const SegDesc &sd) { return (sd.len + (1u << sd.blk_log) - 1) >> sd.blk_log; }
 
 // per-segment entropy tables (k_stats output; 4 KiB-ish, read by k_lit / k_seq / k_pack)

@@ -46,6 +46,8 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st);
+void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
+                   uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
@@ -134,6 +136,7 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long dev_layout = 1;             // PNA_DEV_LAYOUT: archive layout of plain one-chunk entries on the device (k_layout); 0: on the host, after a wait for the sizes
     long trace = 0;                  // PNA_TRACE: phase times of the host pipelines on stderr
     long d2h_wgs = 6;                // PNA_D2H_WGS: workgroups of the kernel that carries a sub-batch's archive bytes to the host (0: the copy engine / runtime's choice)
     long hist_by_block = -1;         // PNA_HIST_BY_BLOCK: zstd entropy stage in its per-block form (1: k_hist, k_seqa, k_seqb) or its per-segment form (0: k_stats, k_seq); -1: by batch size
@@ -148,7 +151,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -167,7 +170,8 @@ struct pna_gpu_ctx {
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
     DevBuf c_vocab, c_cum, c_phr;
-    DevBuf fr_desc, fr_blob, fr_segdst, crc_tabs;
+    DevBuf fr_desc, fr_blob, fr_segdst, fr_entoff, crc_tabs;
+    PinBuf h_entoff;
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
     hipStream_t x_cp = nullptr; hipEvent_t x_ev[2] = {}, x_done = nullptr;   // extract driver: D2H of window k on x_cp next to window k+1's work
     bool aes_dec_ready = false;        // read side (pna_gpu_extract_archive_host): archive image, packed payloads, decoded entries
@@ -193,7 +197,8 @@ struct pna_gpu_ctx {
     std::string err;
     pna_gpu_timing timing = {};
     uint32_t last_nblk = 0;
-    size_t max_blocks = (size_t)(1u << 17) << (17 - PNA_BLK_LOG);   // blocks per sub-batch (16 GiB of input)
+    uint32_t plan_log = PNA_BLK_LOG;                // block size the current call's sub-batches are planned with (plan_call)
+    size_t max_blocks = (size_t)1 << 17;            // blocks per sub-batch: what ~96 GiB of per-block workspace hold at that block size (16 GiB of input at 128 KiB)
     // group commit of the streaming facade (pna_gpu_stream_finish from many host threads -> one device batch)
     std::mutex comb_mu, run_mu;            // comb_mu: queue + leader flag; run_mu: the device batch itself and ctx->err
     std::condition_variable comb_cv;
@@ -275,8 +280,8 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->plan, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
-    for (PinBuf *b : {&c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
+                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+    for (PinBuf *b : {&c->h_entoff, &c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_in[2], &c->dp_in[3], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (auto &e : c->ev_in) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_out) if (e) (void)hipEventDestroy(e);
@@ -337,8 +342,27 @@ static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
 
 // blocks an entry of `len` bytes takes in the per-block workspace (sub-batches are cut by block count); a forced block size counts as such
 static size_t plan_blocks(const pna_gpu_ctx *c, uint64_t len) {
-    const uint32_t lg = c->tun.blk_log ? (uint32_t)c->tun.blk_log : (uint32_t)PNA_BLK_LOG;
-    return (size_t)((len + ((uint64_t)1 << lg) - 1) >> lg);
+    return (size_t)((len + ((uint64_t)1 << c->plan_log) - 1) >> c->plan_log);
+}
+// Block size of a batch whose entries are all small: the per-block arrays have the block size as their stride, so a batch of 4 KiB entries on 128 KiB
+// blocks would spend 32 times the memory (and a sub-batch per 131 072 entries) that 8 KiB blocks need.  Entries of up to 64 KiB: the power of two that
+// holds the largest (>= 8 KiB); anything larger: 128 KiB.  (Latency mode, for small batches of large entries, chooses on top of this in run_subbatch.)
+template <class L>
+static uint32_t small_entry_blk_log(const pna_gpu_ctx *c, const L *src_len, size_t e0, size_t e1) {
+    if (c->tun.blk_log) return (uint32_t)c->tun.blk_log;
+    uint64_t mx = 0;
+    for (size_t e = e0; e < e1; e++) mx = std::max<uint64_t>(mx, src_len[e]);
+    if (mx > 65536) return PNA_BLK_LOG;
+    uint32_t lg = BLK_LOG_MIN;
+    while (((uint64_t)1 << lg) < mx) lg++;
+    return lg;
+}
+// per call: the block size the sub-batches are cut with and how many blocks fit the workspace budget
+template <class L>
+static void plan_call(pna_gpu_ctx *c, const L *src_len, size_t n) {
+    c->plan_log = small_entry_blk_log(c, src_len, 0, n);
+    const uint64_t per_block = (uint64_t)seq_cap_of(c->plan_log) * 16 + ((uint64_t)3 << c->plan_log) + 64;
+    c->max_blocks = (size_t)std::max<uint64_t>(1024, (96ull << 30) / per_block);
 }
 
 extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
@@ -551,7 +575,7 @@ constexpr uint64_t CTR_UNIT = 256u << 10;                    // bytes of one CTR
 // global entry index): the payloads are encrypted in place before their CRC-32 is taken
 struct PlaceDescH { uint64_t src_off, dst_off; uint32_t len, pad; };   // = PlaceDesc of k_frame.hip (k_place / k_gather)
 struct FrameJob { const char *const *names; int solid; const pna_gpu_cipher *cipher = nullptr; const uint8_t *ivs = nullptr; const pna_gpu_entry_meta *meta = nullptr;
-                  uint32_t max_chunk = 0; };   // FDAT chunks of at most this many bytes (FlattenWriter::max_chunk_size; 0 = the reference's default u32::MAX)
+                  uint32_t max_chunk = 0; bool want_offsets = true; };   // FDAT chunks of at most this many bytes (FlattenWriter::max_chunk_size; 0 = the reference's default u32::MAX)
 // largest FDAT chunk the device paths write: the CRC kernel takes "FDAT" || data as one message of at most 2^32 - 1 bytes (the reference's default cuts
 // at u32::MAX: the same chunks unless an entry's compressed payload exceeds 4 GiB - 5 bytes)
 static uint64_t chunk_limit(uint32_t max_chunk) { return max_chunk ? std::min<uint64_t>(max_chunk, 0xFFFFFFFBull) : 0xFFFFFFFBull; }
@@ -641,6 +665,41 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     return PNA_OK;
 }
 
+// stage times of a finished sub-batch from its events (the stream has been waited for)
+static int collect_timing(pna_gpu_ctx *c, bool defl, int nch, uint32_t nseg, uint32_t nblk, bool with_cipher) {
+    float ms[6] = {0, 0, 0, 0, 0, 0}, msf = 0;
+    (void)hipEventElapsedTime(&msf, c->ev[6], c->ev[7]);
+    c->timing.ms_frame += msf;
+    float mc = 0;                                             // the cipher kernels run inside the "pack" interval: report them apart
+    if (with_cipher) { (void)hipEventElapsedTime(&mc, c->ev_ci[0], c->ev_ci[1]); c->timing.ms_cipher += mc; c->timing.ms_pack -= mc; }
+    if (defl) {
+        (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&ms[3], c->ev[3], c->ev[4]);
+        (void)hipEventElapsedTime(&ms[4], c->ev[4], c->ev[5]);
+        (void)hipEventElapsedTime(&ms[5], c->ev[5], c->ev[6]);
+    } else {
+        // k_lz: first launch to last completion on the main stream; the entropy stages are summed over the chunks on the
+        // auxiliary stream (with more than one chunk they overlap k_lz and add up to more than the wall time); "pack" = from the
+        // end of the last chunk's entropy stage to the end of the write kernels (plan + scan + layout + write)
+        (void)hipEventElapsedTime(&ms[0], c->ev_lz[0], c->ev_lz[nch]);
+        for (int k = 0; k < nch; k++) {
+            float a = 0, b2 = 0, d = 0;
+            (void)hipEventElapsedTime(&a, c->ev_en[k][0], c->ev_en[k][1]);
+            (void)hipEventElapsedTime(&b2, c->ev_en[k][1], c->ev_en[k][2]);
+            (void)hipEventElapsedTime(&d, c->ev_en[k][2], c->ev_en[k][3]);
+            ms[1] += a; ms[2] += b2; ms[3] += d;
+        }
+        (void)hipEventElapsedTime(&ms[4], c->ev_en[nch - 1][3], c->ev[6]);
+    }
+    c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
+    c->timing.ms_pack += ms[4] + ms[5];
+    for (size_t i = 0; i + 1 < c->lzm_used; i += 2) { float m = 0; (void)hipEventElapsedTime(&m, c->lzm_ev[i], c->lzm_ev[i + 1]); c->timing.ms_lz_match += m; c->timing.lz_match_launches++; }
+    c->timing.n_segments += nseg; c->timing.n_blocks += nblk;
+    return PNA_OK;
+}
+
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
                         hipStream_t st, bool timed, const FrameJob *fj = nullptr) {
@@ -655,8 +714,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     uint64_t in_total = 0, nseg_est = 0;
     for (size_t e = e0; e < e1; e++) { in_total += src_len[e]; nseg_est += src_len[e] ? (src_len[e] + SEG_SIZE - 1) / SEG_SIZE : 1; }
     const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
-    uint32_t blk_log = PNA_BLK_LOG, unit_log = 20;
-    if (latency) {
+    uint32_t blk_log = small_entry_blk_log(c, src_len, e0, e1), unit_log = 20;
+    if (latency && blk_log == PNA_BLK_LOG) {
         // blocks: 16 KiB up to 16 MiB of input (a block's sequence chain then is ~1 000 steps), then growing with the batch so that the
         // block count -- per-block fixed costs of the entropy kernels -- stays near 1 024 .. 2 048
         blk_log = 14;
@@ -665,7 +724,6 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         unit_log = blk_log;
         while (unit_log < 20 && (in_total >> unit_log) > 384) unit_log++;
     }
-    if (c->tun.blk_log) blk_log = (uint32_t)c->tun.blk_log;
     if (c->tun.unit_log) unit_log = (uint32_t)std::max<long>(c->tun.unit_log, blk_log);
     if (unit_log < blk_log) unit_log = blk_log;
     const uint32_t bsz = 1u << blk_log;
@@ -700,10 +758,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + (hist_on ? (size_t)nseg * 448 * 4 : 0);
     if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes) ||
         c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
-        (algo == PNA_ALGO_DEFLATE && c->ctab.ensure((size_t)(nblk + 1) * (BLK_SIZE / TILE) * 16)) ||
-        c->seqs.ensure((size_t)(nblk + 1) * SEQ_CAP * 8) || c->lits.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
-        c->litc.ensure((size_t)(nblk + 1) * BLK_SIZE) || c->seqc.ensure((size_t)(nblk + 1) * BLK_SIZE) ||
-        (algo == PNA_ALGO_ZSTD && c->seqw.ensure(hist_on ? (size_t)(nblk + 1) * SEQ_CAP * 8 : 64)) ||
+        (algo == PNA_ALGO_DEFLATE && c->ctab.ensure(((size_t)(nblk + 1) << (blk_log - 11)) * 16)) ||
+        c->seqs.ensure((size_t)(nblk + 1) * seq_cap_of(blk_log) * 8) || c->lits.ensure((size_t)(nblk + 1) << blk_log) ||
+        c->litc.ensure((size_t)(nblk + 1) << blk_log) || (algo == PNA_ALGO_ZSTD && c->seqc.ensure((size_t)(nblk + 1) << blk_log)) ||
+        (algo == PNA_ALGO_ZSTD && c->seqw.ensure(hist_on ? (size_t)(nblk + 1) * seq_cap_of(blk_log) * 8 : 64)) ||
         c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
         return fail(c, PNA_E_NOMEM, "workspace allocation failed");
     {
@@ -836,6 +894,52 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             fds[e - e0] = FrameDesc{0, 0, (uint32_t)blob_len, (uint32_t)tmp.size(), 0};
             blob_len += tmp.size();
         }
+    }
+    // Plain file entries of one FDAT chunk each (no cipher; the worst case of every payload below the chunk limit and of the whole sub-batch below the
+    // destination's capacity): the archive layout is computed on the device (k_layout) and the host never waits in the middle of the sub-batch.
+    bool dev_layout = fj && !solid && !fj->cipher && c->tun.dev_layout != 0;
+    if (dev_layout) {
+        const uint64_t CH = chunk_limit(fj->max_chunk);
+        uint64_t need = out_base;
+        for (size_t e = e0; e < e1 && dev_layout; e++) {
+            const uint64_t b = pna_gpu_bound(algo, (size_t)src_len[e]);
+            if (b > CH) dev_layout = false;
+            need += fds[e - e0].prefix_len + b + 16;
+        }
+        if (need + 16 > dst_cap) dev_layout = false;
+    }
+    if (dev_layout) {
+        const size_t ne = e1 - e0;
+        if (c->fr_desc.ensure(ne * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8) ||
+            c->fr_entoff.ensure((ne + 2) * 8) || c->h_entoff.ensure((ne + 2) * 8)) return fail(c, PNA_E_NOMEM, "framing workspace");
+        int rcc = ensure_crc(c); if (rcc) return rcc;
+        HIPCHK(c, hipMemcpyAsync(c->fr_desc.p, fds, ne * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->fr_blob.p, blob, blob_len, hipMemcpyHostToDevice, st));
+        uint64_t *d_ent = (uint64_t *)c->fr_entoff.p;
+        launch_layout((FrameDesc *)c->fr_desc.p, (uint8_t *)c->fr_blob.p, c->d_entry_seg, (const uint64_t *)c->seg_off.p, (uint32_t)ne, nseg, out_base,
+                      (uint64_t *)c->fr_segdst.p, d_ent, d_ent + ne + 1, st);
+        if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const uint64_t *)c->fr_segdst.p, (const uint64_t *)c->seg_size.p,
+                                       (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st);
+        else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (const uint64_t *)c->fr_segdst.p,
+                          (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st);
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
+        launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)ne, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
+                     d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st);
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
+        // the entry offsets (when the caller wants them) and the sub-batch's length travel back behind the kernels: the call's one wait
+        uint64_t *h_ent = (uint64_t *)c->h_entoff.p;
+        if (fj->want_offsets) HIPCHK(c, hipMemcpyAsync(h_ent, d_ent, (ne + 2) * 8, hipMemcpyDeviceToHost, st));
+        else HIPCHK(c, hipMemcpyAsync(h_ent + ne, d_ent + ne, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError());
+        if (fj->want_offsets) memcpy(dst_off + e0, h_ent, ne * 8);
+        dst_off[e1] = h_ent[ne];
+        c->last_nblk = nblk;
+        if (timed) {
+            int rct = collect_timing(c, defl, nch, nseg, nblk, false);
+            if (rct) return rct;
+        }
+        return PNA_OK;
     }
     // the output offsets are needed on the host before the write pass can be bounds-checked
     if (c->h_segoff.ensure((size_t)(nseg + 1) * 8)) return fail(c, PNA_E_NOMEM, "offset staging");
@@ -1022,36 +1126,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (fj && !timed) HIPCHK(c, hipStreamSynchronize(st));        // the staging buffers are reused by the next sub-batch
     if (timed) {
         HIPCHK(c, hipStreamSynchronize(st));
-        float ms[6] = {0, 0, 0, 0, 0, 0}, msf = 0;
-        (void)hipEventElapsedTime(&msf, c->ev[6], c->ev[7]);
-        c->timing.ms_frame += msf;
-        float mc = 0;                                             // the cipher kernels run inside the "pack" interval: report them apart
-        if (fj && fj->cipher) { (void)hipEventElapsedTime(&mc, c->ev_ci[0], c->ev_ci[1]); c->timing.ms_cipher += mc; c->timing.ms_pack -= mc; }
-        if (defl) {
-            (void)hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
-            (void)hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
-            (void)hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
-            (void)hipEventElapsedTime(&ms[3], c->ev[3], c->ev[4]);
-            (void)hipEventElapsedTime(&ms[4], c->ev[4], c->ev[5]);
-            (void)hipEventElapsedTime(&ms[5], c->ev[5], c->ev[6]);
-        } else {
-            // k_lz: first launch to last completion on the main stream; the entropy stages are summed over the chunks on the
-            // auxiliary stream (with more than one chunk they overlap k_lz and add up to more than the wall time); "pack" = from the
-            // end of the last chunk's entropy stage to the end of the write kernels (plan + scan + offsets to the host + write)
-            (void)hipEventElapsedTime(&ms[0], c->ev_lz[0], c->ev_lz[nch]);
-            for (int k = 0; k < nch; k++) {
-                float a = 0, b2 = 0, d = 0;
-                (void)hipEventElapsedTime(&a, c->ev_en[k][0], c->ev_en[k][1]);
-                (void)hipEventElapsedTime(&b2, c->ev_en[k][1], c->ev_en[k][2]);
-                (void)hipEventElapsedTime(&d, c->ev_en[k][2], c->ev_en[k][3]);
-                ms[1] += a; ms[2] += b2; ms[3] += d;
-            }
-            (void)hipEventElapsedTime(&ms[4], c->ev_en[nch - 1][3], c->ev[6]);
-        }
-        c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
-        c->timing.ms_pack += ms[4] + ms[5];
-        for (size_t i = 0; i + 1 < c->lzm_used; i += 2) { float m = 0; (void)hipEventElapsedTime(&m, c->lzm_ev[i], c->lzm_ev[i + 1]); c->timing.ms_lz_match += m; c->timing.lz_match_launches++; }
-        c->timing.n_segments += nseg; c->timing.n_blocks += nblk;
+        int rct = collect_timing(c, defl, nch, nseg, nblk, fj && fj->cipher);
+        if (rct) return rct;
     }
     return PNA_OK;
 }
@@ -1068,6 +1144,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
     dst_off[0] = 0;
     uint64_t out_base = 0, in_total = 0;
     size_t e = 0;
+    plan_call(c, src_len, n);
     while (e < n) {
         size_t e1 = e; size_t blocks = 0;
         while (e1 < n) {
@@ -1193,8 +1270,9 @@ static int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk};
+    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, entry_off != nullptr};
     size_t e = 0;
+    plan_call(c, src_len, n);
     while (e < n) {
         size_t e1 = e, blocks = 0;
         while (e1 < n) {
@@ -1511,6 +1589,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
     uint64_t in_total = 0;
     for (size_t e = 0; e < n; e++) in_total += src_len[e];
+    plan_call(c, src_len, n);
     {
         uint64_t done = 0, target = SUBMIN;
         for (size_t e = 0; e < n;) {
@@ -1535,7 +1614,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (c->tun.stage_threads) threads = (unsigned)c->tun.stage_threads;
-    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk};
+    FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, false};
     std::vector<uint64_t> eoff(n + 1);
     uint64_t out_len[2] = {0, 0}, out_total = head.size();
     constexpr int NS = 4;
@@ -2895,8 +2974,8 @@ extern "C" int pna_gpu_debug_block(pna_gpu_ctx *c, uint32_t block, uint64_t *seq
     HIPCHK(c, hipMemcpy(&bi, (BlkInfo *)c->blk.p + block, sizeof(bi), hipMemcpyDeviceToHost));
     if (nseq) *nseq = bi.nseq;
     if (nlit) *nlit = bi.nlit;
-    if (seqs) HIPCHK(c, hipMemcpy(seqs, (uint64_t *)c->seqs.p + (size_t)block * SEQ_CAP, (size_t)std::min(cap_seqs, bi.nseq) * 8, hipMemcpyDeviceToHost));
-    if (lits) HIPCHK(c, hipMemcpy(lits, (uint8_t *)c->lits.p + (size_t)block * BLK_SIZE, std::min(cap_lits, bi.nlit), hipMemcpyDeviceToHost));
+    if (seqs) HIPCHK(c, hipMemcpy(seqs, (uint64_t *)c->seqs.p + (size_t)block * seq_cap_of(c->last_blk_log), (size_t)std::min(cap_seqs, bi.nseq) * 8, hipMemcpyDeviceToHost));
+    if (lits) HIPCHK(c, hipMemcpy(lits, (uint8_t *)c->lits.p + ((size_t)block << c->last_blk_log), std::min(cap_lits, bi.nlit), hipMemcpyDeviceToHost));
     return PNA_OK;
 }
 

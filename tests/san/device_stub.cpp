@@ -60,6 +60,21 @@ void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, 
     for (uint32_t i = 0; i < n; i++) { const PlaceDesc &d = ((const PlaceDesc *)pd)[i]; memcpy(dst + d.dst_off, src + d.src_off, d.len); }
 }
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) { launch_place(pd, n, src, dst, st); }
+void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
+                   uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t) {
+    uint64_t pos = out_base;
+    for (uint32_t i = 0; i < nentry; i++) {
+        const uint32_t s0 = entry_seg[i], s1 = entry_seg[i + 1];
+        const uint64_t base = seg_off[s0], plen = seg_off[s1] - base;
+        fd[i].arc_off = pos; fd[i].payload_len = (uint32_t)plen;
+        uint8_t *lenf = blob + fd[i].prefix_off + fd[i].prefix_len - 8;
+        lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
+        for (uint32_t sg = s0; sg < s1; sg++) segdst[sg] = pos + fd[i].prefix_len + (seg_off[sg] - base);
+        ent_off[i] = pos;
+        pos += fd[i].prefix_len + plen + 16;
+    }
+    segdst[nseg] = pos; ent_off[nentry] = pos; *total = pos - out_base;
+}
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t, hipStream_t) { memcpy(dst, src, n); }
 void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); }
 

@@ -131,8 +131,8 @@ def test_deflate_one_million_small_entries(big_ctx, pna, codec):
 def test_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
     gpu_ctx = big_ctx
     """tests/bats/large_file.bats (a 5 GiB file through create + extract): ONE entry of 5 GiB (+ a small one behind it) -- 64-bit offsets
-    through segment planning, the write kernels, the 1 GiB FDAT cut and the device decoder.  The archive is checked structurally
-    (fSIZ of five bytes, FDAT chunks of at most 1 GiB, every chunk CRC), sampled frames go through an independent decoder, and every byte
+    through segment planning, the write kernels, the FDAT cut (max_chunk_size 1 GiB: FlattenWriter chunks of exactly that size, lib/src/util/io.rs:60-77)
+    and the device decoder.  The archive is checked structurally (fSIZ of five bytes, FDAT chunks of exactly 1 GiB but the last, every chunk CRC), sampled frames go through an independent decoder, and every byte
     is decoded on the device and compared in HBM."""
     import numpy as np
     import torch
@@ -144,9 +144,9 @@ def test_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
     gpu_ctx.corpus_fill_device(1, 1, 1, 3000, 3000, src.data_ptr() + big)
     so, sl = [0, big, big + 3000], [big, 3000]
     names = ["large/five_gib.bin", "large/small.txt"]
-    cap = pna.archive_bound(pna.ALGO_ZSTD, names, sl)
+    cap = pna.archive_chunked_bound(pna.ALGO_ZSTD, names, sl, 1 << 30)
     dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    total, eoff = gpu_ctx.create_archive_device(names, src.data_ptr(), so, sl, dst.data_ptr(), cap)
+    total, eoff = gpu_ctx.create_archive_chunked_device(names, src.data_ptr(), so, sl, dst.data_ptr(), cap, 1 << 30)
     assert eoff[0] == 28 and eoff[2] == total - 12 and total > (1 << 30)
     # ---- structure on the host: chunk walk with CRCs, fSIZ, FDAT sizes
     arc = dst[:total].cpu().numpy()
@@ -160,7 +160,7 @@ def test_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
             assert int.from_bytes(arc[off:off + ln].tobytes(), "big") == big and ln == 5
     assert kinds[:3] == [b"AHED", b"FHED", b"fSIZ"] and kinds[-1] == b"AEND" and kinds.count(b"FHED") == 2
     big_fdat = fdat[:-1]
-    assert len(big_fdat) >= 2 and all(ln <= (1 << 30) for _, ln in big_fdat) and 2.4 < big / sum(ln for _, ln in big_fdat) < 3.2
+    assert len(big_fdat) >= 2 and all(ln == (1 << 30) for _, ln in big_fdat[:-1]) and 0 < big_fdat[-1][1] <= (1 << 30) and 2.4 < big / sum(ln for _, ln in big_fdat) < 3.2
     # ---- an independent decoder on frames around the 4 GiB mark of the entry (frame k = input bytes [k MiB, (k + 1) MiB))
     stream = np.concatenate([arc[o:o + ln] for o, ln in big_fdat])
     pos, k, want_frames = 0, 0, {0, 4095, 4096, 4097, n1 - 1}
