@@ -634,7 +634,7 @@ __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__res
     t[0] = (uint8_t)(B >> 8); t[1] = (uint8_t)B; t[2] = (uint8_t)(A >> 8); t[3] = (uint8_t)A;
 }
 
-void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st);
+void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st);
 
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
@@ -646,7 +646,7 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
     if (nblk) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(DB_THREADS), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
     if (ev) (void)hipEventRecord(ev[2], st);
     hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size);
-    k_scan_launch(seg_size, seg_off, nseg, st);
+    k_scan_launch_big(seg_size, seg_off, nseg, st);
     if (ev) (void)hipEventRecord(ev[3], st);
 }
 

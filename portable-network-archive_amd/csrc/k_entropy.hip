@@ -1022,8 +1022,46 @@ __global__ void k_empty(const SegDesc *__restrict__ segs, uint32_t nseg, const u
 }
 
 // ------------------------------------------------------------------ launchers
+// large n (10^5 .. 10^6 small entries): chunks of 4 096 values scanned by a workgroup each, the chunk sums by k_scan, then added back
+__global__ __launch_bounds__(1024)
+void k_scan_a(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n, uint64_t *__restrict__ chunk_sum) {
+    __shared__ uint64_t part[2][1024];
+    const uint32_t tid = threadIdx.x, i0 = blockIdx.x * 4096 + tid * 4;
+    uint64_t v[4], s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0ull; s += v[k]; }
+    uint32_t cur = 0;
+    part[0][tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        part[cur ^ 1][tid] = part[cur][tid] + (tid >= d ? part[cur][tid - d] : 0ull);
+        cur ^= 1;
+        __syncthreads();
+    }
+    uint64_t r = part[cur][tid] - s;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = r; r += v[k]; }
+    if (tid == 1023) chunk_sum[blockIdx.x] = part[cur][1023];
+}
+__global__ __launch_bounds__(1024)
+void k_scan_c(uint64_t *__restrict__ out, uint32_t n, const uint64_t *__restrict__ chunk_off, uint32_t nchunk) {
+    const uint32_t i0 = blockIdx.x * 4096 + threadIdx.x * 4;
+    const uint64_t o = chunk_off[blockIdx.x];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) if (i0 + k < n) out[i0 + k] += o;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = chunk_off[nchunk];
+}
+// (scratch of the hierarchical form: the caller's `out` must have room for n + 1 + 2 * (n / 4096 + 2) values)
 void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st) {
+    if (n <= 65536) { k_scan_launch(in, out, n, st); return; }
+    const uint32_t nchunk = (n + 4095) / 4096;
+    uint64_t *chunk_sum = out + n + 1, *chunk_off = chunk_sum + nchunk + 1;
+    hipLaunchKernelGGL(k_scan_a, dim3(nchunk), dim3(1024), 0, st, in, out, n, chunk_sum);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, chunk_sum, chunk_off, nchunk);
+    hipLaunchKernelGGL(k_scan_c, dim3(nchunk), dim3(1024), 0, st, out, n, chunk_off, nchunk);
 }
 
 // Entropy stage of the segments [s0, s0 + ns) whose blocks are [g0, g0 + nb): statistics + tables, literal streams,
@@ -1056,7 +1094,7 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st) {
     hipLaunchKernelGGL(k_plan, dim3((nseg + PLAN_THREADS / 64 - 1) / (PLAN_THREADS / 64)), dim3(PLAN_THREADS), 0, st, segs, nseg, blk, tabs, seg_size, flags);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, seg_size, seg_off, nseg);
+    k_scan_launch_big(seg_size, seg_off, nseg, st);
 }
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,

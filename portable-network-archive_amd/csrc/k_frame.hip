@@ -37,16 +37,20 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
 
 __global__ __launch_bounds__(FR_THREADS)
 void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct,
-             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t *__restrict__ verify) {
+             uint8_t *__restrict__ dst, uint64_t cap16, uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t *__restrict__ verify,
+             uint32_t nent, uint32_t epw) {
     __shared__ uint32_t sT[4][256], sZ[4][256];
     __shared__ uint32_t tile[FR_TILE_DW + FR_TILE_DW / 16 + 8];
     __shared__ uint32_t part[FR_THREADS];
     const uint32_t tid = threadIdx.x;
-    const FrameDesc d = fd[blockIdx.x];
     for (uint32_t i = tid; i < 1024; i += FR_THREADS) { (&sT[0][0])[i] = (&ct->T[0][0])[i]; (&sZ[0][0])[i] = (&ct->Z[0][0])[i]; }
+    // `epw` consecutive descriptors per workgroup: with 10^5 .. 10^6 small entries the 8 KiB of tables are then loaded once per epw entries
+    for (uint32_t ent = blockIdx.x * epw; ent < nent && ent < (blockIdx.x + 1) * epw; ent++) {
+    __syncthreads();                                                 // (the previous entry's `part` and `tile` are done with)
+    const FrameDesc d = fd[ent];
     // verify != NULL: read side (read_chunk, lib/src/io.rs:117-149) -- nothing is written, the CRC is compared with the stored one
     if (!verify) for (uint32_t i = tid; i < d.prefix_len; i += FR_THREADS) dst[d.arc_off + i] = blob[d.prefix_off + i];
-    if (d.pad & 1) return;                                           // record without a data chunk: the prefix is all of it
+    if (d.pad & 1) continue;                                         // record without a data chunk: the prefix is all of it
 
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
     const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
@@ -109,9 +113,9 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         if (tid == 0) {
             const uint8_t *q = dst + pay + d.payload_len;
             const uint32_t stored = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
-            if (stored != ~part[0]) { atomicAdd(&verify[0], 1u); atomicMin(&verify[1], blockIdx.x); }
+            if (stored != ~part[0]) { atomicAdd(&verify[0], 1u); atomicMin(&verify[1], ent); }
         }
-        return;
+        continue;
     }
     if (tid < ((with_fend && !(d.pad & 2)) ? 16u : 4u)) {                // pad bit 1: another data chunk of the same entry follows, no FEND yet
         const uint32_t crc = ~part[0];
@@ -123,6 +127,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         else if (tid < 12) v = (uint8_t)(fe >> (8 * (tid - 8)));
         else v = (uint8_t)(fend_crc >> (24 - 8 * (tid - 12)));
         dst[pay + d.payload_len + tid] = v;
+    }
     }
 }
 
@@ -159,13 +164,15 @@ void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, 
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
-    if (nentry) hipLaunchKernelGGL(k_frame, dim3(nentry), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u, (uint32_t *)nullptr);
+    const uint32_t epw = 1u;                                    // (4 entries per workgroup measured SLOWER for 10^6 small entries: 9.1 vs 8.0 ms -- more workgroups in flight hide the per-entry chain better)
+    if (nentry) hipLaunchKernelGGL(k_frame, dim3((nentry + epw - 1) / epw), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u, (uint32_t *)nullptr, nentry, epw);
 }
 // Read side: CRC-32 of n data chunks of type `ty` where they stand in buf (FrameDesc: arc_off = chunk start, prefix_len = 8,
 // payload_len = chunk length); verify[0] counts mismatches, verify[1] keeps the lowest failing descriptor index.
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
-    if (n) hipLaunchKernelGGL(k_frame, dim3(n), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, verify);
+    const uint32_t epw = 1u;
+    if (n) hipLaunchKernelGGL(k_frame, dim3((n + epw - 1) / epw), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, verify, n, epw);
 }
 
 // ------------------------------------------------------------------ k_gather : byte ranges from arbitrary offsets to 16-byte aligned ones
@@ -185,29 +192,45 @@ void k_gather(const PlaceDesc *__restrict__ pd, const uint8_t *__restrict__ src,
 // ------------------------------------------------------------------ k_layout : the archive layout of a sub-batch, on the device
 // For plain file entries (one FDAT chunk each) the record of entry e is  prefix_e | payload_e | crc | FEND : its place follows from the prefix
 // lengths (host: they depend on names and sizes only) and the compressed sizes (device: the segments' offsets in the packed stream, k_scan).  One
-// workgroup: every thread sums a contiguous run of entries, a log-step scan over the 1 024 partial sums, a second walk fills in what the write
-// kernels and k_frame need -- FrameDesc::arc_off / payload_len, the FDAT length inside the prefix bytes, every segment's destination.  The host
+// entry per thread: sizes and a scan inside each workgroup of 1 024 entries (k_layout_a), a scan over the workgroups' sums (k_scan), then every
+// thread fills in what the write kernels and k_frame need (k_layout_c) -- FrameDesc::arc_off / payload_len, the FDAT length inside the prefix bytes, every segment's destination.  The host
 // reads back one number (the sub-batch's length) at the END of the call instead of all segment sizes in the middle of it; for 125 000 entries of
 // 4 KiB that wait and the layout loop behind it were a third of the sub-batch's time.
-__global__ __launch_bounds__(1024)
-void k_layout(FrameDesc *__restrict__ fd, uint8_t *__restrict__ blob, const uint32_t *__restrict__ entry_seg, const uint64_t *__restrict__ seg_off,
-              uint32_t nentry, uint32_t nseg, uint64_t out_base, uint64_t *__restrict__ segdst, uint64_t *__restrict__ ent_off, uint64_t *__restrict__ total) {
-    __shared__ uint64_t part[2][1024];
+// workgroup-wide inclusive scan of one u64 per thread (1 024 threads, log steps over two LDS buffers); returns the inclusive value, *wg_total the sum
+__device__ __forceinline__ uint64_t wg_scan_1024(uint64_t v, uint64_t (*part)[1024], uint64_t *wg_total) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (nentry + 1023) / 1024;
-    const uint32_t a = tid * per < nentry ? tid * per : nentry, e = a + per < nentry ? a + per : nentry;
-    uint64_t s = 0;
-    for (uint32_t i = a; i < e; i++) s += (uint64_t)fd[i].prefix_len + (seg_off[entry_seg[i + 1]] - seg_off[entry_seg[i]]) + 16;
     uint32_t cur = 0;
-    part[0][tid] = s;
+    part[0][tid] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         part[cur ^ 1][tid] = part[cur][tid] + (tid >= d ? part[cur][tid - d] : 0ull);
         cur ^= 1;
         __syncthreads();
     }
-    uint64_t pos = out_base + part[cur][tid] - s;
-    for (uint32_t i = a; i < e; i++) {
+    *wg_total = part[cur][1023];
+    return part[cur][tid];
+}
+// phase A: one entry per thread; its record's size -> offset inside the workgroup's 1 024 entries (ent_off), the workgroup's total (wg_sum)
+__global__ __launch_bounds__(1024)
+void k_layout_a(const FrameDesc *__restrict__ fd, const uint32_t *__restrict__ entry_seg, const uint64_t *__restrict__ seg_off, uint32_t nentry,
+                uint64_t *__restrict__ ent_off, uint64_t *__restrict__ wg_sum) {
+    __shared__ uint64_t part[2][1024];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    uint64_t s = 0;
+    if (i < nentry) s = (uint64_t)fd[i].prefix_len + (seg_off[entry_seg[i + 1]] - seg_off[entry_seg[i]]) + 16;
+    uint64_t tot;
+    const uint64_t incl = wg_scan_1024(s, part, &tot);
+    if (i < nentry) ent_off[i] = incl - s;
+    if (threadIdx.x == 0) wg_sum[blockIdx.x] = tot;
+}
+// phase C (behind a scan of wg_sum -> wg_off): the final places
+__global__ __launch_bounds__(1024)
+void k_layout_c(FrameDesc *__restrict__ fd, uint8_t *__restrict__ blob, const uint32_t *__restrict__ entry_seg, const uint64_t *__restrict__ seg_off,
+                uint32_t nentry, uint32_t nseg, uint64_t out_base, const uint64_t *__restrict__ wg_off, uint32_t nwg,
+                uint64_t *__restrict__ segdst, uint64_t *__restrict__ ent_off, uint64_t *__restrict__ total) {
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nentry) {
+        const uint64_t pos = out_base + wg_off[blockIdx.x] + ent_off[i];
         const uint32_t s0 = entry_seg[i], s1 = entry_seg[i + 1];
         const uint64_t base = seg_off[s0], plen = seg_off[s1] - base;
         FrameDesc d = fd[i];
@@ -217,13 +240,18 @@ void k_layout(FrameDesc *__restrict__ fd, uint8_t *__restrict__ blob, const uint
         lenf[0] = (uint8_t)(plen >> 24); lenf[1] = (uint8_t)(plen >> 16); lenf[2] = (uint8_t)(plen >> 8); lenf[3] = (uint8_t)plen;
         for (uint32_t sg = s0; sg < s1; sg++) segdst[sg] = pos + d.prefix_len + (seg_off[sg] - base);
         ent_off[i] = pos;
-        pos += d.prefix_len + plen + 16;
     }
-    if (tid == 1023) { const uint64_t end = out_base + part[cur][1023]; segdst[nseg] = end; ent_off[nentry] = end; *total = end - out_base; }
+    if (i == 0) { const uint64_t end = out_base + wg_off[nwg]; segdst[nseg] = end; ent_off[nentry] = end; *total = end - out_base; }
 }
+void k_scan_launch(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_t st);   // k_entropy.hip
+// scratch: 2 x (ceil(nentry / 1024) + 1) u64 behind the entry offsets (the caller's ent_off has nentry + 2 + that many slots)
 void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st) {
-    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, fd, blob, entry_seg, seg_off, nentry, nseg, out_base, segdst, ent_off, total);
+    const uint32_t nwg = (nentry + 1023) / 1024;
+    uint64_t *wg_sum = ent_off + nentry + 2, *wg_off = wg_sum + nwg + 1;
+    hipLaunchKernelGGL(k_layout_a, dim3(nwg), dim3(1024), 0, st, fd, entry_seg, seg_off, nentry, ent_off, wg_sum);
+    k_scan_launch(wg_sum, wg_off, nwg, st);
+    hipLaunchKernelGGL(k_layout_c, dim3(nwg), dim3(1024), 0, st, fd, blob, entry_seg, seg_off, nentry, nseg, out_base, wg_off, nwg, segdst, ent_off, total);
 }
 
 // ------------------------------------------------------------------ k_link_copy : a sub-batch's archive bytes from HBM into page-locked host memory

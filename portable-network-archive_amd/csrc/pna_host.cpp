@@ -616,20 +616,22 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
 // stream, so runs share it) --, shorter ones and PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0 the one-kernel form (k_lz<MODE 0>, no pbuf);
 // PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form as k_lz<MODE 1> + k_lz<MODE 2> (testing).  All forms give the same bytes.  If pbuf
 // cannot be had, the run is halved down to 1 024 blocks, then fused.
-static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegDesc> &segs, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
+static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, uint32_t nseg_all, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
     const int env_split = (int)c->tun.lz_split;
-    const uint32_t env_blocks = (uint32_t)c->tun.lz_split_blocks;
+    // (the option counts blocks of 128 KiB: a run is that many BYTES of input whatever the batch's block size)
+    const uint32_t env_blocks = (uint32_t)std::min<uint64_t>((uint64_t)c->tun.lz_split_blocks << (PNA_BLK_LOG - segs[s0].blk_log), 1u << 30);
+    const uint32_t bps = 1u << (20 - segs[s0].blk_log);          // blocks of a full segment
     const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
     const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
     uint32_t split_blocks = env_blocks;
     if (s1 > s0) {
         // several runs: of about equal size (whole rounds of 256 one-MiB segments) instead of full ones and a short tail -- a tail under the
         // split form's threshold would fall back to the slower one-kernel form (5 000 segments: 2 560 + 2 440 instead of 4 096 + 904)
-        const uint32_t total = (s1 < segs.size() ? segs[s1].blk_base : nblk) - segs[s0].blk_base;
+        const uint32_t total = (s1 < nseg_all ? segs[s1].blk_base : nblk) - segs[s0].blk_base;
         const uint32_t nruns = (total + split_blocks - 1) / split_blocks;
         if (nruns > 1) {
-            const uint32_t round = 256 * BLK_PER_SEG, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
+            const uint32_t round = 256 * bps, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
             if (even < split_blocks) split_blocks = even;
         }
     }
@@ -642,8 +644,8 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
-        while (b < s1 && (b < segs.size() ? segs[b].blk_base : nblk) - b0 + BLK_PER_SEG <= split_blocks) b++;
-        const uint32_t b1 = b < segs.size() ? segs[b].blk_base : nblk;
+        while (b < s1 && (b < nseg_all ? segs[b].blk_base : nblk) - b0 + bps <= split_blocks) b++;
+        const uint32_t b1 = b < nseg_all ? segs[b].blk_base : nblk;
         if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
         if (c->tun.lz_pbuf_fail /* testing: as if the allocation failed */ || c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4)) {
             (void)hipGetLastError();                                   // (the failed allocation's sticky code)
@@ -661,7 +663,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const std::vector<SegD
         if (a >= s1) return PNA_OK;
     }
     launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr);
-    if (fused_tail) return lz_stage(c, d_src, segs, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
+    if (fused_tail) return lz_stage(c, d_src, segs, nseg_all, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
 
@@ -703,8 +705,6 @@ static int collect_timing(pna_gpu_ctx *c, bool defl, int nch, uint32_t nseg, uin
 static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t *src_off, const uint64_t *src_len,
                         size_t e0, size_t e1, uint8_t *d_dst, size_t dst_cap, uint64_t out_base, uint64_t *dst_off,
                         hipStream_t st, bool timed, const FrameJob *fj = nullptr) {
-    std::vector<SegDesc> segs; std::vector<uint32_t> blk_seg; std::vector<uint32_t> entry_first_seg;
-    uint32_t nblk = 0;
     // LATENCY MODE: a small batch -- the CompressionWriter seam with a handful of writers in flight, one entry of
     // `pna_gpu_compress_batch` -- has fewer segments than the chip has CUs, and its time is the length of the per-segment and per-block serial
     // chains (one workgroup walks a segment's 256 tiles; one lane codes a block's sequences).  Such a batch is cut finer: blocks of 8 .. 64 KiB
@@ -727,49 +727,72 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (c->tun.unit_log) unit_log = (uint32_t)std::max<long>(c->tun.unit_log, blk_log);
     if (unit_log < blk_log) unit_log = blk_log;
     const uint32_t bsz = 1u << blk_log;
-    std::vector<SegDesc> units; bool any_empty = false;
-    for (size_t e = e0; e < e1; e++) {
-        entry_first_seg.push_back((uint32_t)segs.size());
-        uint64_t len = src_len[e], off = src_off[e];
-        if (off & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
-        if (len == 0) { SegDesc s{off, 0, nblk, (uint32_t)e, 3, 0, 0, blk_log, 0}; segs.push_back(s); any_empty = true; continue; }
-        for (uint64_t p = 0; p < len; p += SEG_SIZE) {
-            uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
-            SegDesc s{off + p, sl, nblk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u), 0, sl, blk_log, 0};
-            uint32_t nb = (sl + bsz - 1) >> blk_log;
-            for (uint32_t b = 0; b < nb; b++) blk_seg.push_back((uint32_t)segs.size());
-            nblk += nb; segs.push_back(s);
-            if (unit_log < 20)
-                for (uint32_t u = 0; u < sl; u += 1u << unit_log) { SegDesc us = s; us.u0 = u; us.u1 = std::min<uint32_t>(sl, u + (1u << unit_log)); units.push_back(us); }
+    // The plan: counted first, then written straight into the page-locked blob that travels to the device in one copy (several threads for the
+    // batches of 10^5 .. 10^6 small entries, where this loop is a tenth of the call).  Layout: [segs | units | blk_seg | entry_first_seg].
+    const size_t ne_all = e1 - e0;
+    std::vector<uint32_t> efs_v(ne_all + 1), efb_v(ne_all + 1), efu_v(ne_all + 1);     // first segment / block / unit of every entry
+    bool any_empty = false;
+    {
+        uint32_t sg = 0, bk = 0, un = 0;
+        for (size_t e = e0; e < e1; e++) {
+            efs_v[e - e0] = sg; efb_v[e - e0] = bk; efu_v[e - e0] = un;
+            const uint64_t len = src_len[e];
+            if (src_off[e] & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
+            if (len == 0) { sg++; any_empty = true; continue; }
+            const uint64_t full = len >> 20, rest = len & (SEG_SIZE - 1);
+            sg += (uint32_t)(full + (rest ? 1 : 0));
+            bk += (uint32_t)((full << (20 - blk_log)) + ((rest + bsz - 1) >> blk_log));
+            if (unit_log < 20) un += (uint32_t)((full << (20 - unit_log)) + ((rest + (1u << unit_log) - 1) >> unit_log));
         }
+        efs_v[ne_all] = sg; efb_v[ne_all] = bk; efu_v[ne_all] = un;
     }
-    entry_first_seg.push_back((uint32_t)segs.size());
-    const uint32_t nseg = (uint32_t)segs.size();
+    const uint32_t nseg = efs_v[ne_all], nblk = efb_v[ne_all], nunits = efu_v[ne_all];
     if (nseg == 0) return PNA_OK;
-    const bool unit_mode = unit_log < 20 && !units.empty();
-    c->last_blk_log = blk_log; c->last_units = unit_mode ? (uint32_t)units.size() : 0;
+    const size_t o_units = ((size_t)nseg * sizeof(SegDesc) + 15) & ~(size_t)15, o_blkseg = (o_units + (size_t)nunits * sizeof(SegDesc) + 15) & ~(size_t)15,
+                 o_entry = (o_blkseg + (size_t)(nblk + 1) * 4 + 15) & ~(size_t)15, plan_bytes = o_entry + (ne_all + 2) * 4;
+    if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes)) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
+    SegDesc *segs = (SegDesc *)c->h_plan.p, *units = (SegDesc *)((uint8_t *)c->h_plan.p + o_units);   // (the previous sub-batch has been waited for: the staging is free)
+    uint32_t *blk_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_blkseg), *entry_first_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_entry);
+    {
+        auto fill = [&](size_t a, size_t b) {
+            for (size_t e = a; e < b; e++) {
+                uint32_t sg = efs_v[e - e0], bk = efb_v[e - e0], un = efu_v[e - e0];
+                entry_first_seg[e - e0] = sg;
+                const uint64_t len = src_len[e], off = src_off[e];
+                if (len == 0) { segs[sg] = SegDesc{off, 0, bk, (uint32_t)e, 3, 0, 0, blk_log, 0}; continue; }
+                for (uint64_t p = 0; p < len; p += SEG_SIZE) {
+                    const uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
+                    const SegDesc s{off + p, sl, bk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u), 0, sl, blk_log, 0};
+                    const uint32_t nb = (sl + bsz - 1) >> blk_log;
+                    for (uint32_t b2 = 0; b2 < nb; b2++) blk_seg[bk + b2] = sg;
+                    bk += nb; segs[sg++] = s;
+                    if (unit_log < 20)
+                        for (uint32_t u = 0; u < sl; u += 1u << unit_log) { SegDesc us = s; us.u0 = u; us.u1 = std::min<uint32_t>(sl, u + (1u << unit_log)); units[un++] = us; }
+                }
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, ne_all / 32768));
+        if (nt > 1) { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(fill, e0 + ne_all * t / nt, e0 + ne_all * (t + 1) / nt); for (auto &x : th) x.join(); }
+        else fill(e0, e1);
+        entry_first_seg[ne_all] = nseg;
+    }
+    const bool unit_mode = unit_log < 20 && nunits > 0;
+    c->last_blk_log = blk_log; c->last_units = unit_mode ? nunits : 0;
     // zstd entropy stage, two forms: statistics per block (k_hist) + tables + three-lane state chains (k_seqa) + token-parallel packing (k_seqb) while
     // the chain waves fit the chip's SIMDs (<= 40 960 blocks); beyond, statistics per segment inside k_stats and the one-kernel coder k_seq.  Flags
     // 0x1000 / 0x2000 and option hist_by_block force one.
     const bool hist_on = algo == PNA_ALGO_ZSTD && !(c->call_flags & 0x1000u) &&
                          ((c->call_flags & 0x2000u) || (c->tun.hist_by_block < 0 ? nblk <= 40960u : c->tun.hist_by_block != 0));
-    const size_t o_units = ((size_t)nseg * sizeof(SegDesc) + 15) & ~(size_t)15, o_blkseg = (o_units + units.size() * sizeof(SegDesc) + 15) & ~(size_t)15,
-                 o_entry = (o_blkseg + (size_t)(nblk + 1) * 4 + 15) & ~(size_t)15, plan_bytes = o_entry + (entry_first_seg.size() + 1) * 4;
     const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + (hist_on ? (size_t)nseg * 448 * 4 : 0);
-    if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes) ||
-        c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
+    if (c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
         (algo == PNA_ALGO_DEFLATE && c->ctab.ensure(((size_t)(nblk + 1) << (blk_log - 11)) * 16)) ||
         c->seqs.ensure((size_t)(nblk + 1) * seq_cap_of(blk_log) * 8) || c->lits.ensure((size_t)(nblk + 1) << blk_log) ||
         c->litc.ensure((size_t)(nblk + 1) << blk_log) || (algo == PNA_ALGO_ZSTD && c->seqc.ensure((size_t)(nblk + 1) << blk_log)) ||
         (algo == PNA_ALGO_ZSTD && c->seqw.ensure(hist_on ? (size_t)(nblk + 1) * seq_cap_of(blk_log) * 8 : 64)) ||
-        c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure((size_t)(nseg + 1) * 8))
+        c->seg_size.ensure((size_t)nseg * 8) || c->seg_off.ensure(((size_t)nseg + 1 + 2 * ((size_t)nseg / 4096 + 2)) * 8))       // (+ the scratch of the hierarchical scan)
         return fail(c, PNA_E_NOMEM, "workspace allocation failed");
     {
-        uint8_t *hp = (uint8_t *)c->h_plan.p, *dp = (uint8_t *)c->plan.p;          // (the previous sub-batch has been waited for: the staging is free)
-        memcpy(hp, segs.data(), (size_t)nseg * sizeof(SegDesc));
-        if (!units.empty()) memcpy(hp + o_units, units.data(), units.size() * sizeof(SegDesc));
-        if (nblk) memcpy(hp + o_blkseg, blk_seg.data(), (size_t)nblk * 4);
-        memcpy(hp + o_entry, entry_first_seg.data(), entry_first_seg.size() * 4);
+        uint8_t *hp = (uint8_t *)c->h_plan.p, *dp = (uint8_t *)c->plan.p;
         c->d_segs = (SegDesc *)dp; c->d_units = (SegDesc *)(dp + o_units); c->d_blk_seg = (uint32_t *)(dp + o_blkseg); c->d_entry_seg = (uint32_t *)(dp + o_entry);
         c->d_hist = (uint32_t *)((uint8_t *)c->blk.p + o_hist);
         HIPCHK(c, hipMemcpyAsync(dp, hp, plan_bytes, hipMemcpyHostToDevice, st));
@@ -781,8 +804,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         const uint32_t dfl = c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u);
-        if (unit_mode) launch_lz(d_src, c->d_units, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
-        else { const int rc = lz_stage(c, d_src, segs, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
+        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
+        else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
@@ -804,9 +827,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            if (unit_mode) launch_lz(d_src, c->d_units, (uint32_t)units.size(), (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
+            if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
                                      (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, nullptr, 0, nullptr);       // (nch == 1: one launch over all units)
-            else { const int rc = lz_stage(c, d_src, segs, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
             hipStream_t est = nch > 1 ? c->aux : st;
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
@@ -911,7 +934,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (dev_layout) {
         const size_t ne = e1 - e0;
         if (c->fr_desc.ensure(ne * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8) ||
-            c->fr_entoff.ensure((ne + 2) * 8) || c->h_entoff.ensure((ne + 2) * 8)) return fail(c, PNA_E_NOMEM, "framing workspace");
+            c->fr_entoff.ensure((ne + 2 + 2 * (ne / 1024 + 2)) * 8) || c->h_entoff.ensure((ne + 2) * 8)) return fail(c, PNA_E_NOMEM, "framing workspace");
         int rcc = ensure_crc(c); if (rcc) return rcc;
         HIPCHK(c, hipMemcpyAsync(c->fr_desc.p, fds, ne * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->fr_blob.p, blob, blob_len, hipMemcpyHostToDevice, st));

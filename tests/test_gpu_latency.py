@@ -135,7 +135,7 @@ def test_compression_writers_in_latency_mode(pna, codec, monkeypatch):
         th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
         for x in th: x.start()
         for x in th: x.join()
-        assert ctx.timing().blk_log == 14
+        assert ctx.timing().blk_log in (13, 14)      # (13: a last batch of the two small entries only -- every entry of up to 64 KiB is one block whatever the block size)
     pz = codec.params_for_flags(0x77, blk_log=14)
     for e, r in zip(ents, results):
         assert r == codec.model_compress(e, pz)
