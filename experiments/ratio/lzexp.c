@@ -8,7 +8,7 @@
 typedef struct {
     uint32_t entries, min_match, tile, max_off, cap1, lookahead, lazy, lazy2, region, ins_mod, back_cap, rounds, look_mod, ways, hash_bytes, blk;
     uint32_t rep;      /* estimate repeat-offset codes */
-    uint32_t prefer_near; /* 2-way: on equal length prefer the nearer candidate */
+    uint32_t prefer_near; uint32_t gran; /* gran: entries hold 1 << gran byte granules, the position inside is found by comparing the hashed bytes */
 } P;
 static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint32_t hashf(const uint8_t *p, const P *pr) {
@@ -24,6 +24,7 @@ typedef struct { uint32_t ll, ml, off; } seq;
 static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 /* one block; table: ways x entries */
+static uint64_t g_cand[8];   /* candidates looked at: total, offset > 8K, > 16K, > 23K, > 39K, > 56K */
 static uint32_t lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, uint32_t blk_len, uint32_t *table, const P *p, seq *seqs, uint8_t *lits, uint32_t *nlit_out) {
     uint32_t blk_end = blk_start + blk_len, nseq = 0, nlit = 0, next_free = blk_start, lit_start = blk_start, T = p->tile;
     uint32_t *cand = malloc(4 * T), *cand0 = malloc(4 * T); uint16_t *len = malloc(2 * (T + 1)), *len0 = malloc(2 * (T + 1));
@@ -39,8 +40,18 @@ static uint32_t lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_star
                 uint32_t h = hashf(seg + q, p);
                 for (uint32_t w = 0; w < W; w++) {
                     uint32_t c1 = table[w * E + h], l = 0, bk = 0;
+                    if (p->gran && c1) {                                  /* granule -> the highest (even) position in it whose hashed bytes equal those at q */
+                        uint32_t g0 = (c1 - 1) << p->gran, found = 0;
+                        for (int32_t pp = (int32_t)(g0 + (1u << p->gran) - 1); pp >= (int32_t)g0; pp--) {
+                            if (p->ins_mod > 1 && (pp % p->ins_mod)) continue;
+                            if ((uint32_t)pp >= t0 || (uint32_t)pp + 8 > seg_len) continue;
+                            if (!memcmp(seg + pp, seg + q, p->hash_bytes)) { found = (uint32_t)pp + 1; break; }
+                        }
+                        c1 = found;
+                    }
                     if (c1 > 8 && q - (c1 - 1) <= p->max_off) {
                         uint32_t c = c1 - 1, lim = blk_end - q;
+                        { uint32_t o = q - c; g_cand[0]++; if (o > 8192) g_cand[1]++; if (o > 16384) g_cand[2]++; if (o > 23000) g_cand[3]++; if (o > 39000) g_cand[4]++; if (o > 56064) g_cand[5]++; }
                         if (lim > p->cap1) lim = p->cap1;
                         while (l < lim && seg[q + l] == seg[c + l]) l++;
                         if (l < p->min_match) l = 0;
@@ -57,7 +68,8 @@ static uint32_t lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_star
             if (q + 8 <= seg_len && q % (p->ins_mod ? p->ins_mod : 1) == 0) {
                 uint32_t h = hashf(seg + q, p);
                 uint32_t old = table[h];
-                if (old < q + 1) { if (W > 1 && old < t0 + 1 && old) table[E + h] = old; table[h] = q + 1; }
+                uint32_t nv = p->gran ? (q >> p->gran) + 1 : q + 1, tl = p->gran ? (t0 >> p->gran) + 1 : t0 + 1;
+                if (old < nv) { if (W > 1 && old < tl && old) table[E + h] = old; table[h] = nv; }
             }
         /* A */
         for (uint32_t rr = p->rounds; rr; rr >>= 4) {
@@ -107,14 +119,14 @@ static const uint8_t MLB[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
 static double ent(const uint32_t *c, int n) { double t = 0, e = 0; for (int i = 0; i < n; i++) t += c[i]; for (int i = 0; i < n; i++) if (c[i]) e -= c[i] * log2(c[i] / t); return e; }
 
 int main(int argc, char **argv) {
-    P p = {24512, 6, 4096, 1u << 20, 32, 1024, 1, 0, 256, 2, 3, 0x21, 1, 1, 6, 1u << 17, 0, 1};
+    P p = {24512, 6, 4096, 1u << 20, 32, 1024, 1, 0, 256, 2, 3, 0x21, 1, 1, 6, 1u << 17, 0, 1, 0};
     const char *files = NULL;
     for (int i = 1; i < argc; i++) {
         char *eq = strchr(argv[i], '=');
         if (!eq) { files = argv[i]; continue; }
         *eq = 0; uint32_t v = (uint32_t)strtoul(eq + 1, NULL, 0);
 #define K(n) if (!strcmp(argv[i], #n)) p.n = v;
-        K(entries) K(min_match) K(tile) K(max_off) K(cap1) K(lookahead) K(lazy) K(lazy2) K(region) K(ins_mod) K(back_cap) K(rounds) K(look_mod) K(ways) K(hash_bytes) K(blk) K(rep)
+        K(entries) K(min_match) K(tile) K(max_off) K(cap1) K(lookahead) K(lazy) K(lazy2) K(region) K(ins_mod) K(back_cap) K(rounds) K(look_mod) K(ways) K(hash_bytes) K(blk) K(rep) K(gran)
     }
     FILE *f = fopen(files, "rb"); if (!f) { perror("open"); return 1; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
@@ -150,6 +162,7 @@ int main(int argc, char **argv) {
         (void)ns_seg;
         bits_total += ent(lc, 256) + ent(llc, 36) + ent(mlc, 53) + ent(ofc, 32) + extra + 8 * 200;
     }
+    printf("candidates %.1f%% of positions; of them beyond 8K %.1f%%, 16K %.1f%%, 23K %.1f%%, 39K %.1f%%, 56K %.1f%%\n", 100.0 * g_cand[0] / n, 100.0 * g_cand[1] / g_cand[0], 100.0 * g_cand[2] / g_cand[0], 100.0 * g_cand[3] / g_cand[0], 100.0 * g_cand[4] / g_cand[0], 100.0 * g_cand[5] / g_cand[0]);
     printf("est ratio %.4f  (est bytes %.0f of %ld; %llu seqs, %llu lits, mean ml %.2f)\n", n / (bits_total / 8), bits_total / 8, n, (unsigned long long)nseq_total, (unsigned long long)nlit_total, nseq_total ? (double)mlsum / nseq_total : 0.0);
     return 0;
 }

@@ -141,6 +141,30 @@ def libzstd_compress(data: bytes, level: int = 3) -> bytes:
     return buf.raw[:n]
 
 
+def libzstd_compress_checksum(data: bytes, level: int = 3) -> bytes:
+    """One frame WITH Content_Checksum (XXH64 low 32 bits behind the last block) from the system libzstd: test input for the device decoder's check."""
+    Z = system_libzstd()
+    Z.ZSTD_createCCtx.restype = ctypes.c_void_p
+    Z.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
+    Z.ZSTD_CCtx_setParameter.restype = ctypes.c_size_t
+    Z.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    Z.ZSTD_compress2.restype = ctypes.c_size_t
+    Z.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    cctx = Z.ZSTD_createCCtx()
+    try:
+        for prm, v in ((100, level), (201, 1)):                # ZSTD_c_compressionLevel, ZSTD_c_checksumFlag
+            if Z.ZSTD_isError(Z.ZSTD_CCtx_setParameter(cctx, prm, v)):
+                raise ValueError("libzstd: parameter refused")
+        cap = Z.ZSTD_compressBound(len(data))
+        buf = ctypes.create_string_buffer(cap)
+        n = Z.ZSTD_compress2(cctx, buf, cap, bytes(data), len(data))
+        if Z.ZSTD_isError(n):
+            raise ValueError("libzstd compress error")
+        return buf.raw[:n]
+    finally:
+        Z.ZSTD_freeCCtx(cctx)
+
+
 class ZstdParams(ctypes.Structure):
     """Mirror of pna_zstd_params (oracle/zstd_model.h)."""
     _fields_ = [("hash_log", ctypes.c_uint32), ("min_match", ctypes.c_uint32), ("tile", ctypes.c_uint32),

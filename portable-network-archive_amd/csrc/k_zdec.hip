@@ -204,7 +204,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                     if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
-                if ((fhd >> 2) & 1) { /* content checksum: 4 bytes after the last block, not verified */ }
+                if ((fhd >> 2) & 1) { /* content checksum: 4 bytes after the last block, verified by k_zxxh once the content is there */ }
             }
         }
     }
@@ -1244,6 +1244,55 @@ void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t 
 
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_zscan, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, frames);
+}
+
+// ------------------------------------------------------------------ k_zxxh : Content_Checksum (RFC 8878 3.1.1: the low 32 bits of XXH64(content, seed 0))
+// Frames written with a checksum -- this library and the reference's writer set none (lib/src/entry/write.rs:260-262: the encoder's defaults), other
+// zstd writers may -- are verified after decoding: a frame whose decoded bytes do not hash to the stored value is corrupt, as zstd::stream::read::Decoder
+// reports it (decompress_reader, lib/src/entry/read.rs:171-190).  XXH64 runs four independent accumulator chains over 32-byte stripes: four lanes per
+// frame, sixteen frames per wave; frames without the flag cost one byte read.
+__device__ __forceinline__ uint64_t xxh_rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xxh_rd64(const uint8_t *p) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i); return v; }
+__global__ __launch_bounds__(64)
+void k_zxxh(ZFrame *__restrict__ frames, uint32_t n, const uint8_t *__restrict__ src, const uint8_t *__restrict__ dst) {
+    constexpr uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull, P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+    const uint32_t lane = threadIdx.x, f = blockIdx.x * 16 + (lane >> 2), k = lane & 3;
+    bool act = f < n;
+    ZFrame fr; fr.status = 1; fr.src_len = 0; fr.dst_len = 0; fr.src_off = 0; fr.dst_off = 0;
+    if (act) fr = frames[f];
+    act = act && fr.status == 0 && fr.src_len >= 10 && ((src[fr.src_off + 4] >> 2) & 1);
+    const uint8_t *p = dst + fr.dst_off;
+    const uint64_t len = act ? fr.dst_len : 0;
+    uint64_t acc = k == 0 ? P1 + P2 : (k == 1 ? P2 : (k == 2 ? 0ull : 0ull - P1));
+    const uint64_t nstripe = len >> 5;
+    for (uint64_t s = 0; s < nstripe; s++) {
+        uint64_t w;
+        const uint8_t *q = p + 32 * s + 8 * k;
+        if ((((uintptr_t)q) & 7) == 0) w = *(const uint64_t *)q; else w = xxh_rd64(q);
+        acc = xxh_rotl(acc + w * P2, 31) * P1;
+    }
+    // the four accumulators meet in lane 0 of the frame's group
+    const uint32_t g0 = lane & ~3u;
+    uint64_t v[4];
+    for (int j = 0; j < 4; j++) { const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)acc, (int)(g0 + j)), hi = (uint32_t)__shfl((int)(uint32_t)(acc >> 32), (int)(g0 + j)); v[j] = ((uint64_t)hi << 32) | lo; }
+    if (!act || k != 0) return;
+    uint64_t h;
+    if (len >= 32) {
+        h = xxh_rotl(v[0], 1) + xxh_rotl(v[1], 7) + xxh_rotl(v[2], 12) + xxh_rotl(v[3], 18);
+        for (int j = 0; j < 4; j++) { const uint64_t r = xxh_rotl(v[j] * P2, 31) * P1; h = (h ^ r) * P1 + P4; }
+    } else h = P5;
+    h += len;
+    const uint8_t *q = p + (nstripe << 5), *e = p + len;
+    for (; q + 8 <= e; q += 8) { const uint64_t r = xxh_rotl(xxh_rd64(q) * P2, 31) * P1; h = xxh_rotl(h ^ r, 27) * P1 + P4; }
+    if (q + 4 <= e) { const uint64_t w = (uint64_t)q[0] | ((uint64_t)q[1] << 8) | ((uint64_t)q[2] << 16) | ((uint64_t)q[3] << 24); h = xxh_rotl(h ^ (w * P1), 23) * P2 + P3; q += 4; }
+    for (; q < e; q++) h = xxh_rotl(h ^ ((uint64_t)*q * P5), 11) * P1;
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    const uint8_t *c4 = src + fr.src_off + fr.src_len - 4;
+    const uint32_t stored = (uint32_t)c4[0] | ((uint32_t)c4[1] << 8) | ((uint32_t)c4[2] << 16) | ((uint32_t)c4[3] << 24);
+    if (stored != (uint32_t)h) frames[f].status = 1;                   // corrupt: the content does not match its checksum
+}
+void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zxxh, dim3((n + 15) / 16), dim3(64), 0, st, frames, n, src, dst);
 }
 
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st) {

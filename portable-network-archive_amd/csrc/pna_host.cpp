@@ -50,6 +50,7 @@ void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, cons
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
+void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
 void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st);
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
@@ -1557,19 +1558,37 @@ extern "C" int pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_
         }
         lo[n_ctx] = n;
     }
-    std::vector<std::vector<uint8_t>> parts(n_ctx);
-    std::vector<int> rcs(n_ctx, PNA_OK);
+    // Every range runs the bounded pipeline on a thread of its own; range 0 hands its pieces to the caller's sink as they come, the ranges behind it keep
+    // theirs in memory until every range before them has finished (the sink sees the archive in index order, on the calling thread only).  An exception
+    // inside a worker (allocation) is that range's PNA_E_NOMEM, not a terminate; the first failing range's code is returned and its message copied to
+    // ctxs[0] (what pna_gpu_last_error of the first context reports).
+    struct Part { std::vector<uint8_t> buf; int rc = PNA_OK; bool done = false; };
+    std::vector<Part> parts(n_ctx);
+    std::mutex mu; std::condition_variable cv;
     auto vec_sink = [](void *u, const void *b, size_t k) -> int { auto *v = (std::vector<uint8_t> *)u; try { v->insert(v->end(), (const uint8_t *)b, (const uint8_t *)b + k); } catch (...) { return 1; } return 0; };
     std::vector<std::thread> th;
-    for (size_t r = 0; r < n_ctx; r++)
+    for (size_t r = 1; r < n_ctx; r++)
         th.emplace_back([&, r]() {
-            const uint32_t pf = (r == 0 ? PNA_PART_HEAD : 0u) | (r + 1 == n_ctx ? PNA_PART_TAIL : 0u);
-            rcs[r] = pna_gpu_create_archive_part_host(ctxs[r], algo, level, lo[r + 1] - lo[r], names + lo[r], src + lo[r], src_len + lo[r], pf, vec_sink, &parts[r]);
+            int rc;
+            try {
+                const uint32_t pf = r + 1 == n_ctx ? PNA_PART_TAIL : 0u;
+                rc = pna_gpu_create_archive_part_host(ctxs[r], algo, level, lo[r + 1] - lo[r], names + lo[r], src + lo[r], src_len + lo[r], pf, vec_sink, &parts[r].buf);
+            } catch (...) { rc = PNA_E_NOMEM; }
+            std::lock_guard<std::mutex> lk(mu);
+            parts[r].rc = rc; parts[r].done = true; cv.notify_all();
         });
+    int rc0;
+    try { rc0 = pna_gpu_create_archive_part_host(ctxs[0], algo, level, lo[1] - lo[0], names + lo[0], src + lo[0], src_len + lo[0], PNA_PART_HEAD, sink, user); }
+    catch (...) { rc0 = fail(ctxs[0], PNA_E_NOMEM, "out of memory"); }
+    int rc = rc0;
+    for (size_t r = 1; r < n_ctx; r++) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return parts[r].done; }); }
+        if (rc == PNA_OK && parts[r].rc != PNA_OK) { rc = parts[r].rc; const std::string msg = std::string("range ") + std::to_string(r) + ": " + pna_gpu_last_error(ctxs[r]); (void)fail(ctxs[0], rc, msg.c_str()); }
+        if (rc == PNA_OK && !parts[r].buf.empty() && sink(user, parts[r].buf.data(), parts[r].buf.size()) != 0) rc = fail(ctxs[0], PNA_E_SINK, "sink failed");
+        std::vector<uint8_t>().swap(parts[r].buf);                // handed on (or abandoned): the memory goes back at once
+    }
     for (auto &t : th) t.join();
-    for (size_t r = 0; r < n_ctx; r++) if (rcs[r] != PNA_OK) return rcs[r];
-    for (size_t r = 0; r < n_ctx; r++) if (!parts[r].empty() && sink(user, parts[r].data(), parts[r].size()) != 0) return fail(ctxs[0], PNA_E_SINK, "sink failed");
-    return PNA_OK;
+    return rc;
 }
 static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
@@ -2633,6 +2652,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
                         (const ZFrame *)c->z_frames.p, (const ZTables *)c->z_tabs.p, (const uint8_t *)d_src, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
         launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)nfr, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
                      (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+        launch_zxxh((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (const uint8_t *)d_dst, st);   // frames that carry a content checksum
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -2657,6 +2677,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
             return fail(c, PNA_E_NOMEM, "decoder workspace");
         HIPCHK(c, hipMemcpyAsync(c->z_fb.p, sub.data(), sub.size() * sizeof(ZFrame), hipMemcpyHostToDevice, st));
         launch_zdec((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, st);
+        launch_zxxh((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (const uint8_t *)d_dst, st);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(sub.data(), c->z_fb.p, sub.size() * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));

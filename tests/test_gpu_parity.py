@@ -1335,3 +1335,26 @@ def test_ordered_gather_over_rccl_single_rank(gpu_ctx, pna, pf, codec):
         assert comm.gather_ordered(0, 0, out.data_ptr(), out.numel()) == ([0], 0)          # an empty part
     finally:
         comm.close()
+
+
+def test_zstd_content_checksum_is_verified(gpu_ctx, pna, codec):
+    """Frames with a Content_Checksum (RFC 8878 3.1.1; the reference's own writer sets none, other zstd writers may): the device decoder checks the
+    XXH64 of what it decoded, as zstd::stream::read::Decoder does behind decompress_reader (lib/src/entry/read.rs:171-190) -- good frames decode,
+    a frame whose stored checksum is off by a bit is refused, whichever decode path takes it (lane-parallel; one workgroup per frame)."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frames) is absent")
+    raws = [codec.corpus_file(0, 8100, 300000), b"", b"abc", codec.corpus_file(1, 8101, 31), codec.corpus_file(2, 8102, 70001), codec.corpus_file(0, 8103, (1 << 20) + 33),
+            bytes(100000), codec.corpus_file(0, 8104, 32), codec.corpus_file(0, 8105, 4 << 20)]
+    comps = [codec.libzstd_compress_checksum(r, 3 + (i % 3)) for i, r in enumerate(raws)]
+    assert all((c[4] >> 2) & 1 for c in comps)                                   # the frames do carry the flag
+    lens = [len(r) for r in raws]
+    assert gpu_ctx.decompress_batch(comps, lens) == raws
+    with gpu_ctx.options(zdec_serial=(1, 0)):
+        assert gpu_ctx.decompress_batch(comps, lens) == raws
+    for k in (0, 3, 5, 8):
+        bad = list(comps); bad[k] = bad[k][:-1] + bytes([bad[k][-1] ^ 0x10])
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx.decompress_batch(bad, lens)
+        with gpu_ctx.options(zdec_serial=(1, 0)):
+            with pytest.raises(pna.PnaGpuError):
+                gpu_ctx.decompress_batch(bad, lens)
