@@ -199,6 +199,8 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0) -> Zst
         p.rounds = 0x421
         p.back_cap = 7
         p.flags |= 0x80
+        if not deflate:
+            p.hash_log = 19            # zstd levels 10 .. 22: the match kernel's table lies in global memory, 2^19 slots per segment (index = the hash's top bits)
     if not flags & F_ADOPT:
         p.rounds = 0
         p.back_cap = 0

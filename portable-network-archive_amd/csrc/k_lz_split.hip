@@ -25,16 +25,23 @@ __device__ unsigned long long g_lzp_stamps[8];              // k_lzp's phase sta
 //   * a far candidate's bytes (all 36 the match step can ask for) are requested only on the lanes that hold one, into register tuples.
 // Same table, window, tile order and barriers as k_lz, hence the same words (tests/test_gpu_parity.py: forms of the LZ stage).
 #define DPP_ROW_SHL1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xF, 0xF, true))   // value of lane i + 1 inside the row of 16 (0 at its end)
-template <bool DEFL, bool STRONG>
+// GLOG != 0: the hash table of this workgroup lies in GLOBAL memory, 1 << GLOG slots (gtab + blockIdx.x << GLOG): the zstd levels 10 .. 22.  What a
+// 1 MiB segment's match finder can remember is what sets the ratio on text (24 512 slots in LDS 2.70, 2^19 slots 2.96), and LDS
+// cannot hold more; the high levels trade speed for it, as the reference's do.  Look-ups are loads that bypass the CU's L1 (agent-scope atomic loads:
+// the table is only ever modified by atomics, which execute in L2), inserts are global atomics, and a tile's inserts are waited for (vmcnt) before
+// the barrier that lets the next tile's look-ups go.
+constexpr uint32_t GTAB_LOG = 19;
+template <bool DEFL, bool STRONG, uint32_t GLOG>
 __global__ __launch_bounds__(LZ_THREADS)
-void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0) {
+void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
+           uint32_t *__restrict__ gtab) {
     constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
     constexpr bool FAR = !DEFL;                             // deflate offsets (<= 32 KiB) never leave the LDS window
     constexpr uint32_t NEAR = NEAR_OFF;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32 = (uint32_t *)(lds + L_WIN);
-    uint32_t *table = (uint32_t *)(lds + L_TABLE);
+    uint32_t *table = GLOG ? gtab + ((size_t)blockIdx.x << GLOG) : (uint32_t *)(lds + L_TABLE);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = uni(tid >> 6);
     const SegDesc sd = segs[blockIdx.x];
@@ -44,11 +51,12 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
 
-    for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < (GLOG ? (1u << GLOG) : HASH_ENTRIES) / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the zeros are in L2 before the pre-warm's atomics and the first look-ups)
     // a unit that starts inside the segment (latency mode): window and table as the segment-long walk has them there (k_lz.hip, lz_common.h)
     uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
     __syncthreads();
-    if (sd.u0) lz_prewarm(table, seg, seg_len, sd.u0, ins_all, tid);
+    if (sd.u0) { lz_prewarm<GLOG>(table, seg, seg_len, sd.u0, ins_all, tid); if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         const uint32_t wo = i & (WIN_BYTES - 1);
@@ -83,9 +91,10 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 const uint32_t q = q0 + j;
                 hv[j] = tile_full || ((q < t1) && (q + 8 <= seg_len));
                 const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
-                hsh[j] = __umulhi(h32, HASH_ENTRIES);
+                hsh[j] = lz_slot<GLOG>(h32);
                 tag[j] = (h32 >> 6) & TAG_MASK;
-                ent[j] = hv[j] ? table[hsh[j]] : 0u;
+                if (GLOG) ent[j] = hv[j] ? __hip_atomic_load(&table[hsh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                else ent[j] = hv[j] ? table[hsh[j]] : 0u;
             }
             // ---- candidates (rules as in k_lz); far ones get their bytes requested from the segment now
             uint32_t off[4];
@@ -201,6 +210,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             __syncthreads();                                                        // every wave has looked up
 #pragma unroll
             for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+            if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the atomics have reached L2)
             __syncthreads();                                                        // inserts + window chunk in place
         }
     }
@@ -572,25 +582,28 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #endif
 }
 
-template <bool CT, bool STRONG>
+template <bool CT, bool STRONG, uint32_t GLOG>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                           uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match) {
-    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);   // once per process, thread-safe
+                           uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<CT, STRONG>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0);
+    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG>), dim3(nseg), dim3(LZ_THREADS), GLOG ? L_TABLE : L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
 // match kernel + parse kernel over `nseg` segments; pbuf holds one word per position of the launch's blocks, blk0 = the first of them; ctab != nullptr:
 // a deflate launch (chunk table, look-back inside the LDS window); ev_match, if given, is recorded between the two kernels
+// gtab != nullptr (zstd, strong set): the match kernel's hash tables in global memory, nseg << GTAB_LOG words
 void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match) {
+                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_split_g<true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match);
-                else launch_split_g<true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match); }
-    else { if (strong) launch_split_g<false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match);
-           else launch_split_g<false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match); }
+    if (ctab) { if (strong) launch_split_g<true, true, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+                else launch_split_g<true, false, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
+    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+    else { if (strong) launch_split_g<false, true, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+           else launch_split_g<false, false, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
 }
+uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {
 #ifdef LZP_PROF
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzp_stamps), sizeof(unsigned long long) * 8);

@@ -118,6 +118,11 @@ __device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t s
 // second one) entered, the latest position of a slot wins.  Inserts are ds_max_u32, so their order does not matter and the bytes can come straight
 // from memory, eight consecutive positions per lane and 16-byte load, without the window and without barriers.  The unit's matches are therefore
 // those of the segment-long walk, bit for bit.
+// GLOG: 0 = the LDS table of HASH_ENTRIES slots (slot = mulhi(hash, entries)); otherwise the table lies in global memory and has 1 << GLOG slots
+// (slot = the hash's top bits): the strong level set of the zstd encoder (k_lz_split.hip)
+template <uint32_t GLOG>
+__device__ __forceinline__ uint32_t lz_slot(uint32_t h32) { return GLOG ? h32 >> (32 - (GLOG ? GLOG : 1)) : __umulhi(h32, HASH_ENTRIES); }
+template <uint32_t GLOG = 0>
 __device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, uint32_t seg_len, uint32_t end, bool ins_all, uint32_t tid) {
 #pragma unroll 2
     for (uint32_t p = tid * 8; p < end; p += LZ_THREADS * 8) {
@@ -131,7 +136,7 @@ __device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, 
             const uint32_t lo = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], j & 3) : w[j >> 2];
             const uint32_t hi = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 2 < 4 ? (j >> 2) + 2 : 3], w[(j >> 2) + 1], j & 3) : w[(j >> 2) + 1];
             const uint32_t h32 = lo * 0x9E3779B1u + (hi & 0xFFFFu) * 0x85EBCA6Bu;
-            if (q < end && q + 8 <= seg_len) atomicMax(&table[__umulhi(h32, HASH_ENTRIES)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
+            if (q < end && q + 8 <= seg_len) atomicMax(&table[lz_slot<GLOG>(h32)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
         }
     }
 }

@@ -25,7 +25,8 @@
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match);
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab);
+uint32_t lz_gtab_log();
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
@@ -137,6 +138,7 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long strong_gtab = 1;            // PNA_STRONG_GTAB: zstd levels 10 .. 22 with the match kernel's hash tables in global memory (2^19 slots per segment); 0: the LDS table
     long dev_layout = 1;             // PNA_DEV_LAYOUT: archive layout of plain one-chunk entries on the device (k_layout); 0: on the host, after a wait for the sizes
     long trace = 0;                  // PNA_TRACE: phase times of the host pipelines on stderr
     long d2h_wgs = 6;                // PNA_D2H_WGS: workgroups of the kernel that carries a sub-batch's archive bytes to the host (0: the copy engine / runtime's choice)
@@ -152,7 +154,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -171,6 +173,7 @@ struct pna_gpu_ctx {
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
     DevBuf c_vocab, c_cum, c_phr;
+    DevBuf gtab;                                    // hash tables of the strong level set's match kernel (global memory)
     DevBuf fr_desc, fr_blob, fr_segdst, fr_entoff, crc_tabs;
     PinBuf h_entoff;
     DevBuf x_arc, x_pk, x_raw[2], x_desc, x_place, x_flag, x_tags, x_plen, aes_dtabs;
@@ -281,7 +284,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->plan, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
-                      &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+                      &c->gtab, &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (PinBuf *b : {&c->h_entoff, &c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_in[2], &c->dp_in[3], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (auto &e : c->ev_in) if (e) (void)hipEventDestroy(e);
@@ -623,8 +626,11 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
     // (the option counts blocks of 128 KiB: a run is that many BYTES of input whatever the batch's block size)
     const uint32_t env_blocks = (uint32_t)std::min<uint64_t>((uint64_t)c->tun.lz_split_blocks << (PNA_BLK_LOG - segs[s0].blk_log), 1u << 30);
     const uint32_t bps = 1u << (20 - segs[s0].blk_log);          // blocks of a full segment
-    const bool fused = (c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u);   // (0x100: the phase stamps live in the fused kernel)
-    const bool waveparse = (c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2;
+    // zstd levels 10 .. 22 (the strong set): the match kernel's hash tables lie in global memory (2^19 slots per segment instead of the 24 512 LDS
+    // holds; k_lz_split.hip) -- only k_lzm has that form, so those levels always take the split form, whatever the run's length
+    const bool gt = !ctab && (flags & F_STRONG) && (flags & F_ADOPT) && c->tun.strong_gtab != 0;
+    const bool fused = !gt && ((c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u));   // (0x100: the phase stamps live in the fused kernel)
+    const bool waveparse = !gt && ((c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2);
     uint32_t split_blocks = env_blocks;
     if (s1 > s0) {
         // several runs: of about equal size (whole rounds of 256 one-MiB segments) instead of full ones and a short tail -- a tail under the
@@ -641,16 +647,18 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
     // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
     // (measured on the final kernels, N x 1 MiB, fused / split: 256: 2.4 / 4.7 ms, 1 024 = four full rounds of the CUs: 9.1 / 9.8, 1 152: 11.3 / 11.0,
     // 2 048: 18.1 / 15.4, 3 072: 27.1 / 21.1): the split form from 1 025 segments on.
-    const uint32_t min_segs = (uint32_t)c->tun.lz_split_min;
+    const uint32_t min_segs = gt ? 0u : (uint32_t)c->tun.lz_split_min;
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
         while (b < s1 && (b < nseg_all ? segs[b].blk_base : nblk) - b0 + bps <= split_blocks) b++;
         const uint32_t b1 = b < nseg_all ? segs[b].blk_base : nblk;
         if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
-        if (c->tun.lz_pbuf_fail /* testing: as if the allocation failed */ || c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4)) {
+        if ((c->tun.lz_pbuf_fail && !gt) /* testing: as if the allocation failed */ || c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4) ||
+            (gt && c->gtab.ensure((size_t)(b - a) << (lz_gtab_log() + 2)))) {
             (void)hipGetLastError();                                   // (the failed allocation's sticky code)
             if (split_blocks > 1024 && b - a > 1) { split_blocks /= 2; continue; }                    // (for this call only: the next one tries the full run again)
+            if (gt) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");    // (the one-kernel form has LDS tables: other bytes)
             s0 = a; break;                                             // no room for the words: the rest goes through the fused kernel
         }
         hipEvent_t e1 = nullptr;
@@ -659,11 +667,11 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
             HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
         }
         launch_lz(d_src, c->d_segs + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
-                  (uint32_t *)c->pbuf.p, b0, e1);
+                  (uint32_t *)c->pbuf.p, b0, e1, gt ? (uint32_t *)c->gtab.p : nullptr);
         a = b;
         if (a >= s1) return PNA_OK;
     }
-    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr);
+    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr);
     if (fused_tail) return lz_stage(c, d_src, segs, nseg_all, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
@@ -805,7 +813,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         const uint32_t dfl = c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u);
-        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr);
+        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr);
         else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
@@ -828,8 +836,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
-                                     (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, nullptr, 0, nullptr);       // (nch == 1: one launch over all units)
+            if (unit_mode) {
+                // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
+                const bool gt = (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong_gtab != 0;
+                if (gt && (c->pbuf.ensure(((size_t)nblk << blk_log) * 4) || c->gtab.ensure((size_t)nunits << (lz_gtab_log() + 2)))) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");
+                launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
+                          (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr);
+            }
             else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
             hipStream_t est = nch > 1 ? c->aux : st;

@@ -106,7 +106,8 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
         for level, fl in ((1, codec.F_HUF | codec.F_FSE), (2, 0x73), (3, 0x77), (19, 0xF7)):
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
-            assert (ctx.timing().lz_match_launches == 0) == (form in ("default", "fused")), form
+            # (levels 10 .. 22 always take the split form: only the match kernel k_lzm has the global-memory hash table of the strong set)
+            assert (ctx.timing().lz_match_launches == 0) == (form in ("default", "fused") and level < 10), (form, level)
             pz = codec.params_for_flags(fl)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
