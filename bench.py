@@ -566,6 +566,8 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": "k_lzm" if split else "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing, "k_lzm" if split else "k_lz"),
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on this build's LZ kernels "
+                                           "(scripts/pmc_traffic.sh); not measured inside this run -- counters cannot be read from within the process",
                          "algorithmic_bytes": alg_bytes,                         # per step = over the kernel's launches of one step
                          "launches_per_step": round(dom_launches, 2),
                          "kernel_ms": round(dom_ms_step / max(dom_launches, 1e-9), 3),   # average launch duration (HIP events on the launch stream)

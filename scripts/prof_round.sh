@@ -7,12 +7,24 @@ TAG=${1:-i}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+echo default done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > "$OUT/kt_default.log" 2>&1
+echo trace done
 python3 bench.py --framing solid --files 8192 > "$OUT/bench_solid.json" 2> "$OUT/bench_solid.err"
 python3 bench.py --algo deflate --files 2048 > "$OUT/bench_deflate.json" 2> "$OUT/bench_deflate.err"
+echo solid deflate done
 python3 bench.py --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
+python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k_1m.json" 2> "$OUT/bench_deflate_4k_1m.err"
+echo small done
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
+for lv in 1 2 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
+echo levels done
 python3 scripts/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
+python3 scripts/batch_rate.py > "$OUT/batch_rate.txt" 2>&1
+PNA_TRACE=1 python3 scripts/host_rate.py 10000 > "$OUT/host_rate.txt" 2> "$OUT/host_rate_trace.txt"
+echo seam done
+bash scripts/pmc_traffic.sh 10000 > "$OUT/pmc_traffic.log" 2>&1
+cp gpurun_out/pmc/summary.json "$OUT/pmc_summary_raw.json" 2>/dev/null
 find "$OUT" -name "*kernel_stats.csv" | head
