@@ -184,12 +184,43 @@ def default_params() -> ZstdParams:
     return p
 
 
-def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0) -> ZstdParams:
+def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = None):
+    """(flags, gtab): the level sets behind the reference's level scale as the product maps them (pna_host.cpp level_flags / set_call_level):
+    zstd < 0, 1 fast; 2 balanced; 0, 3..5 default; 6..9 high (+ F_STRONG); 10..22 max (+ the hash table in global memory) -- deflate 0..3, 4..5,
+    6..8, 9.  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
+    base = ctx_flags if ctx_flags is not None else ((F_ADOPT | F_INS2 | F_LAZY) if deflate else (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2))
+    if deflate:
+        lv = 6 if level is None or level == -1000 else (9 if level < 0 or level > 9 else level)      # (PNA_LEVEL_DEFAULT; a negative Custom(n) wraps and clamps to 9)
+        fast, balanced, strong = lv <= 3, lv in (4, 5), lv >= 9
+    else:
+        lv = 3 if level is None or level == -1000 else min(level, 22)
+        fast, balanced, strong = lv < 0 or lv == 1, lv == 2, lv >= 6
+    if fast:
+        fl = base & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2 | F_STRONG)
+    elif balanced:
+        fl = base & ~(F_LAZY | F_STRONG)
+    elif strong and base & F_ADOPT and base & F_LAZY:
+        fl = base | F_STRONG
+    else:
+        fl = base
+    return fl, bool(not deflate and lv >= 10 and fl & F_STRONG and fl & F_ADOPT)
+
+
+def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None) -> "ZstdParams":
+    fl, gtab = product_level_flags(level, deflate, ctx_flags)
+    return params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab)
+
+
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: bool = True) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
     F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
-    (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB)."""
+    (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB).  gtab: the match kernel's table lies in global
+    memory (zstd levels 10..22).  The zstd sets with far candidates and lazy deferral run the 32 KiB-window geometry of the match finder (32 704
+    table slots) unless the table is global or the context's option win32k is 0; everything else the 64 KiB one (24 512)."""
     p = deflate_default_params() if deflate else default_params()
     p.blk_log = blk_log
+    if not deflate and not (flags & F_FAR and flags & F_LAZY and not gtab and win32k):
+        p.hash_log, p.near_off = 24512, 56064
     p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
     if not deflate:
         p.flags &= ~8                     # no repeat codes on the device
@@ -199,8 +230,8 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0) -> Zst
         p.rounds = 0x421
         p.back_cap = 7
         p.flags |= 0x80
-        if not deflate:
-            p.hash_log = 19            # zstd levels 10 .. 22: the match kernel's table lies in global memory, 2^19 slots per segment (index = the hash's top bits)
+    if gtab:
+        p.hash_log = 19                # zstd levels 10 .. 22: the match kernel's table lies in global memory, 2^19 slots per segment (index = the hash's top bits)
     if not flags & F_ADOPT:
         p.rounds = 0
         p.back_cap = 0

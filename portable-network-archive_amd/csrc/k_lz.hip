@@ -54,7 +54,7 @@ __device__ unsigned long long g_lz_stamps[8];
 // MODE: 0 = the whole stage in one kernel; 1 / 2 = its two halves as kernels of their own (launch_lz_split): 1 = look-up, match and
 // inserts only -- one word per position (length | offset << 6, after adoption) goes to `pbuf` --, 2 = parse, merge and emission from those
 // words (no window, no table: 192 bytes of LDS, two workgroups per CU).  Same code, same results: the halves only meet in `pbuf`.
-template <bool STAMP, int G, bool CT, bool STRONG, int MODE>
+template <bool STAMP, int G, bool CT, bool STRONG, int MODE, uint32_t WLOG>
 __global__ __launch_bounds__(LZ_THREADS, MODE == 2 ? 8 : 4)   // (second figure: waves per SIMD the compiler must leave room for)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len,
@@ -67,8 +67,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 #else
     constexpr bool FAR = !CT;                               // deflate offsets (<= 32 KiB) never leave the LDS window
 #endif
-    constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : NEAR_OFF;
-    static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + (G == 2 ? MAX_OFF_G2 : NEAR_OFF), "window: look-back + this tile + look-ahead + the chunk in flight");
+    using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
+    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, L_WEND = GEO::L_WEND, L_WPUB = GEO::L_WPUB;
+    constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : GEO::NEAR;
+    static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!CT || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
@@ -102,7 +104,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
     if (MODE != 2) {
         __syncthreads();                                                            // (the table is zero before the pre-warm's inserts)
-        if (sd.u0) lz_prewarm(table, seg, seg_len, sd.u0, ins_all, tid);
+        if (sd.u0) lz_prewarm<0, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid);
         for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
             const uint4 v = load_chunk(seg, i, seg_len);
             const uint32_t wo = i & (WIN_BYTES - 1);
@@ -346,9 +348,9 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         const uint32_t L = (FAR && os > NEAR) ? L0
 #else
                         const uint32_t L = MODE == 2 ? lz_extend_mem(seg, seg_len, qs, qs - os, L0, xl, lane)
-                                         : (FAR && os > NEAR) ? lz_extend<true>(win32, seg, qs, qs - os, L0, xl, lane)
+                                         : (FAR && os > NEAR) ? lz_extend<true, WIN_BYTES>(win32, seg, qs, qs - os, L0, xl, lane)
 #endif
-                                                              : lz_extend<false>(win32, seg, qs, qs - os, L0, xl, lane);
+                                                              : lz_extend<false, WIN_BYTES>(win32, seg, qs, qs - os, L0, xl, lane);
                         if (lane == s) flen[r] = L;
                         e = s + L;
                     }
@@ -568,26 +570,26 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-template <int G, bool CT, bool STRONG>
+template <int G, bool CT, bool STRONG, uint32_t WLOG>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
+        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
     }();
     (void)attr_set;
     if (pbuf) {
         if (flags & FLAG_SPLIT_WAVEPARSE) {
-            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             if (ev_match) (void)hipEventRecord(ev_match, st);
-            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2, WLOG>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             return;
         }
         launch_lz_split(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);   // k_lzm + k_lzp (k_lz_split.hip)
     }
-    else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0>), dim3(nseg), dim3(LZ_THREADS), L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+    else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
 // pbuf != nullptr: the split form (two kernels; pbuf holds one word per position of the launch's blocks, blk0 = the first of them;
@@ -595,10 +597,13 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
-                else launch_lz_g<LZ_G_DEFLATE, true, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab); }
-    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
-           else launch_lz_g<LZ_G_ZSTD, false, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab); }
+    if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+                else launch_lz_g<LZ_G_DEFLATE, true, false, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab); }
+    else if (flags & FLAG_W32) {
+           if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+           else launch_lz_g<LZ_G_ZSTD, false, false, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab); }
+    else { if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+           else launch_lz_g<LZ_G_ZSTD, false, false, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab); }
 }
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups); a -DLZP_PROF build hands out k_lzp's instead

@@ -31,13 +31,15 @@ __device__ unsigned long long g_lzp_stamps[8];              // k_lzp's phase sta
 // the table is only ever modified by atomics, which execute in L2), inserts are global atomics, and a tile's inserts are waited for (vmcnt) before
 // the barrier that lets the next tile's look-ups go.
 constexpr uint32_t GTAB_LOG = 19;
-template <bool DEFL, bool STRONG, uint32_t GLOG>
+template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
            uint32_t *__restrict__ gtab) {
     constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
     constexpr bool FAR = !DEFL;                             // deflate offsets (<= 32 KiB) never leave the LDS window
-    constexpr uint32_t NEAR = NEAR_OFF;
+    using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
+    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR;
+    static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!DEFL || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32 = (uint32_t *)(lds + L_WIN);
@@ -56,7 +58,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     // a unit that starts inside the segment (latency mode): window and table as the segment-long walk has them there (k_lz.hip, lz_common.h)
     uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
     __syncthreads();
-    if (sd.u0) { lz_prewarm<GLOG>(table, seg, seg_len, sd.u0, ins_all, tid); if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (sd.u0) { lz_prewarm<GLOG, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid); if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         const uint32_t wo = i & (WIN_BYTES - 1);
@@ -91,7 +93,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 const uint32_t q = q0 + j;
                 hv[j] = tile_full || ((q < t1) && (q + 8 <= seg_len));
                 const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
-                hsh[j] = lz_slot<GLOG>(h32);
+                hsh[j] = lz_slot<GLOG, HASH_ENTRIES>(h32);
                 tag[j] = (h32 >> 6) & TAG_MASK;
                 if (GLOG) ent[j] = hv[j] ? __hip_atomic_load(&table[hsh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 else ent[j] = hv[j] ? table[hsh[j]] : 0u;
@@ -204,7 +206,11 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
-            if (q0 < t1) *(uint4 *)(pb + q0) = make_uint4((K[0] >> 6) | (off[0] << 6), (K[1] >> 6) | (off[1] << 6), (K[2] >> 6) | (off[2] << 6), (K[3] >> 6) | (off[3] << 6));
+            if (q0 < t1) {
+                v4u wv; wv.x = (K[0] >> 6) | (off[0] << 6); wv.y = (K[1] >> 6) | (off[1] << 6); wv.z = (K[2] >> 6) | (off[2] << 6); wv.w = (K[3] >> 6) | (off[3] << 6);
+                __builtin_nontemporal_store(wv, (v4u *)(pb + q0));       // (streamed: the parse kernel reads the words, this one never; without the hint they push the
+                                                                         // segment's recent bytes -- where most far candidates lie -- out of L2: k_lzm + 1.5 %)
+            }
 #undef QW
             loaded_end += TILE_G;
             __syncthreads();                                                        // every wave has looked up
@@ -582,12 +588,12 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #endif
 }
 
-template <bool CT, bool STRONG, uint32_t GLOG>
+template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                            uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
-    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L_TOTAL);   // once per process, thread-safe
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG>), dim3(nseg), dim3(LZ_THREADS), GLOG ? L_TABLE : L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
+    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
@@ -597,11 +603,14 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
 void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                      uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_split_g<true, true, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-                else launch_split_g<true, false, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
-    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
-    else { if (strong) launch_split_g<false, true, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-           else launch_split_g<false, false, 0>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
+    if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+                else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
+    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+    else if (flags & FLAG_W32) {
+           if (strong) launch_split_g<false, true, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+           else launch_split_g<false, false, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
+    else { if (strong) launch_split_g<false, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+           else launch_split_g<false, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {

@@ -12,14 +12,24 @@ constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
 // LDS layout (byte offsets into the dynamic shared array)
 constexpr uint32_t L_WIN    = 0;
 constexpr uint32_t WIN_MIRROR = 48;                        // the window's first 48 bytes again behind its end: unaligned reads never wrap (k_lz reads 16 past a position, k_lzm 36 past a lane's first)
-constexpr uint32_t L_TABLE  = L_WIN + WIN_BYTES + WIN_MIRROR;
-constexpr uint32_t L_WEND   = L_TABLE + 4u * HASH_ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
-constexpr uint32_t L_WPUB   = L_WEND + 4 * LZ_WAVES;        // 16 x 8 B
-constexpr uint32_t L_TOTAL  = L_WPUB + 8 * LZ_WAVES;
+// Two geometries share the CU's 160 KiB (WLOG = log2 of the window): 64 KiB window + 24 512-slot table (deflate, whose 32 KiB look-back must lie in
+// the window; the zstd sets without far candidates, whose look-back IS the window), and 32 KiB window + 32 704-slot table (the zstd sets with far
+// candidates: a third more slots are worth +1.6 % of ratio on text, and what the window no longer holds -- candidates more than NEAR bytes back -- is
+// verified against the segment in HBM / L2 like everything beyond the window before)
+template <uint32_t WLOG> struct LzGeo {
+    static_assert(WLOG == 15 || WLOG == 16, "window of 32 or 64 KiB");
+    static constexpr uint32_t WIN     = 1u << WLOG;
+    static constexpr uint32_t L_TABLE = L_WIN + WIN + WIN_MIRROR;
+    static constexpr uint32_t ENTRIES = WLOG == 16 ? HASH_ENTRIES : ((160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 4 & ~63u);   // 32 704
+    static constexpr uint32_t L_WEND  = L_TABLE + 4u * ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
+    static constexpr uint32_t L_WPUB  = L_WEND + 4 * LZ_WAVES;    // 16 x 8 B
+    static constexpr uint32_t L_TOTAL = L_WPUB + 8 * LZ_WAVES;
+    static constexpr uint32_t NEAR    = WLOG == 16 ? NEAR_OFF : WIN - 2 * 1024 * LZ_G_ZSTD - LOOKAHEAD - 16 - 240;   // candidates at most this far back are verified in the window (32 KiB: 23 296)
+    static_assert(L_TOTAL <= 160 * 1024 && ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
+};
 
 struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
 static_assert(sizeof(WPub) == 8, "LDS record size");
-static_assert(L_TOTAL <= 160 * 1024 && HASH_ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 
 constexpr uint32_t FLAG_SPLIT_WAVEPARSE = 0x1000u;   // split form: the parse half as k_lz<MODE = 2> (a wave per region) instead of k_lzp (testing)
 constexpr uint32_t FLAG_STAMP = 0x100u, FLAG_FORCE_SERIAL = 0x200u;   // 0x200: always take the serial form of the end scan (testing)
@@ -45,15 +55,17 @@ __device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
 }
 
 // 8 / 4 bytes at an arbitrary segment position from the circular window
+template <uint32_t WB>
 __device__ __forceinline__ void fetch8(const uint32_t *win32, uint32_t pos, uint32_t &lo, uint32_t &hi) {
-    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);                    // p[1], p[2] may lie in the mirror
+    const uint32_t *p = win32 + ((pos & (WB - 1)) >> 2);                    // p[1], p[2] may lie in the mirror
     const uint32_t sh = (pos & 3) * 8;
     const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
     lo = __builtin_amdgcn_alignbit(d1, d0, sh);
     hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 }
+template <uint32_t WB>
 __device__ __forceinline__ uint32_t fetch4(const uint32_t *win32, uint32_t pos) {
-    const uint32_t *p = win32 + ((pos & (WIN_BYTES - 1)) >> 2);
+    const uint32_t *p = win32 + ((pos & (WB - 1)) >> 2);
     return __builtin_amdgcn_alignbit(p[1], p[0], (pos & 3) * 8);
 }
 
@@ -73,13 +85,13 @@ __device__ __forceinline__ uint4 load_chunk_tail(const uint8_t *seg, uint32_t i,
 // Wave-cooperative extension of a match whose first L0 bytes are known to agree: q, c, L0, lim are wave-uniform; returns the
 // full length (<= lim).  64 lanes x 4 bytes per step.  FARC: the candidate lies outside the LDS window, its bytes come from the
 // segment in HBM / L2 (c + lim < q, so every address is inside the segment).
-template <bool FARC>
+template <bool FARC, uint32_t WB>
 __device__ __forceinline__ uint32_t lz_extend(const uint32_t *win32, const uint8_t *seg, uint32_t q, uint32_t c, uint32_t L0, uint32_t lim, uint32_t lane) {
     uint32_t L = L0;
     for (;;) {
         uint32_t pos = L + lane * 4;
-        const uint32_t cw = FARC ? *(const u32u *)(seg + c + pos) : fetch4(win32, c + pos);
-        uint32_t x = fetch4(win32, q + pos) ^ cw;
+        const uint32_t cw = FARC ? *(const u32u *)(seg + c + pos) : fetch4<WB>(win32, c + pos);
+        uint32_t x = fetch4<WB>(win32, q + pos) ^ cw;
         uint32_t nb = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
         uint32_t room = lim > pos ? lim - pos : 0u;
         nb = nb < room ? nb : room;
@@ -118,11 +130,11 @@ __device__ __forceinline__ uint32_t lz_extend_mem(const uint8_t *seg, uint32_t s
 // second one) entered, the latest position of a slot wins.  Inserts are ds_max_u32, so their order does not matter and the bytes can come straight
 // from memory, eight consecutive positions per lane and 16-byte load, without the window and without barriers.  The unit's matches are therefore
 // those of the segment-long walk, bit for bit.
-// GLOG: 0 = the LDS table of HASH_ENTRIES slots (slot = mulhi(hash, entries)); otherwise the table lies in global memory and has 1 << GLOG slots
+// GLOG: 0 = the LDS table of ENT slots (slot = mulhi(hash, entries)); otherwise the table lies in global memory and has 1 << GLOG slots
 // (slot = the hash's top bits): the strong level set of the zstd encoder (k_lz_split.hip)
-template <uint32_t GLOG>
-__device__ __forceinline__ uint32_t lz_slot(uint32_t h32) { return GLOG ? h32 >> (32 - (GLOG ? GLOG : 1)) : __umulhi(h32, HASH_ENTRIES); }
-template <uint32_t GLOG = 0>
+template <uint32_t GLOG, uint32_t ENT>
+__device__ __forceinline__ uint32_t lz_slot(uint32_t h32) { return GLOG ? h32 >> (32 - (GLOG ? GLOG : 1)) : __umulhi(h32, ENT); }
+template <uint32_t GLOG, uint32_t ENT>
 __device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, uint32_t seg_len, uint32_t end, bool ins_all, uint32_t tid) {
 #pragma unroll 2
     for (uint32_t p = tid * 8; p < end; p += LZ_THREADS * 8) {
@@ -136,7 +148,7 @@ __device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, 
             const uint32_t lo = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 1], w[j >> 2], j & 3) : w[j >> 2];
             const uint32_t hi = (j & 3) ? __builtin_amdgcn_alignbyte(w[(j >> 2) + 2 < 4 ? (j >> 2) + 2 : 3], w[(j >> 2) + 1], j & 3) : w[(j >> 2) + 1];
             const uint32_t h32 = lo * 0x9E3779B1u + (hi & 0xFFFFu) * 0x85EBCA6Bu;
-            if (q < end && q + 8 <= seg_len) atomicMax(&table[lz_slot<GLOG>(h32)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
+            if (q < end && q + 8 <= seg_len) atomicMax(&table[lz_slot<GLOG, ENT>(h32)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
         }
     }
 }

@@ -138,6 +138,7 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long win32k = 1;                 // PNA_WIN32K: zstd default / high level sets on the 32 KiB-window geometry of the match finder (32 704 table slots); 0: 64 KiB / 24 512
     long strong_gtab = 1;            // PNA_STRONG_GTAB: zstd levels 10 .. 22 with the match kernel's hash tables in global memory (2^19 slots per segment); 0: the LDS table
     long dev_layout = 1;             // PNA_DEV_LAYOUT: archive layout of plain one-chunk entries on the device (k_layout); 0: on the host, after a wait for the sizes
     long trace = 0;                  // PNA_TRACE: phase times of the host pipelines on stderr
@@ -154,7 +155,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -168,6 +169,7 @@ struct pna_gpu_ctx {
     int device = 0;
     uint32_t flags = 0;
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
+    bool call_gtab = false, call_w32 = false;       // ... and where the match finder's table lies / its LDS geometry (set_call_level)
     std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -331,17 +333,26 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
 // lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101; PNA_LEVEL_DEFAULT and zstd level 0 = the default):
 //   fast      zstd < 0 and 1, deflate 0..3   greedy parse, every position in the table, look-back = the LDS window, no backward adoption
 //   balanced  zstd 2,         deflate 4..5   + even-position table, backward adoption, 1 MiB look-back (zstd); still greedy
-//   default   zstd 0, 3..9,   deflate 6..8   + one-step lazy deferral
-//   strong    zstd 10..22,    deflate 9      + a third adoption round (matches move back by up to 7 positions) and two-step lazy deferral
+//   default   zstd 0, 3..5,   deflate 6..8   + one-step lazy deferral
+//   high      zstd 6..9,      deflate 9      + a third adoption round (matches move back by up to 7 positions) and two-step lazy deferral
+//   max       zstd 10..22                    + the match kernel's hash table in global memory: 2^19 slots per segment instead of what LDS holds
+// zstd default and high run the match finder's 32 KiB-window geometry (32 704 table slots instead of 24 512; lz_common.h LzGeo), the others and
+// deflate the 64 KiB one.
 static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const int lv = pna_gpu_clamp_level(algo, level);
     const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
     const bool balanced = algo == PNA_ALGO_DEFLATE ? (lv == 4 || lv == 5) : lv == 2;
-    const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : lv >= 10;
+    const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : lv >= 6;
     if (fast) return c->flags & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2 | F_STRONG);
     if (balanced) return c->flags & ~(F_LAZY | F_STRONG);
     if (strong && (c->flags & F_ADOPT) && (c->flags & F_LAZY)) return c->flags | F_STRONG;
     return c->flags;
+}
+static void set_call_level(pna_gpu_ctx *c, int algo, int level) {
+    c->call_flags = level_flags(c, algo, level);
+    const bool zstd = algo != PNA_ALGO_DEFLATE;
+    c->call_gtab = zstd && pna_gpu_clamp_level(algo, level) >= 10 && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong_gtab != 0;
+    c->call_w32 = zstd && !c->call_gtab && (c->call_flags & F_FAR) && (c->call_flags & F_LAZY) && c->tun.win32k != 0;
 }
 
 // blocks an entry of `len` bytes takes in the per-block workspace (sub-batches are cut by block count); a forced block size counts as such
@@ -628,7 +639,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
     const uint32_t bps = 1u << (20 - segs[s0].blk_log);          // blocks of a full segment
     // zstd levels 10 .. 22 (the strong set): the match kernel's hash tables lie in global memory (2^19 slots per segment instead of the 24 512 LDS
     // holds; k_lz_split.hip) -- only k_lzm has that form, so those levels always take the split form, whatever the run's length
-    const bool gt = !ctab && (flags & F_STRONG) && (flags & F_ADOPT) && c->tun.strong_gtab != 0;
+    const bool gt = !ctab && c->call_gtab;
     const bool fused = !gt && ((c->call_flags & PNA_F_LZ_FUSED) || env_split == 0 || (flags & 0x100u));   // (0x100: the phase stamps live in the fused kernel)
     const bool waveparse = !gt && ((c->call_flags & PNA_F_LZ_WAVEPARSE) || env_split == 2);
     uint32_t split_blocks = env_blocks;
@@ -836,14 +847,15 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
+            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? FLAG_W32 : 0u);
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
-                const bool gt = (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong_gtab != 0;
+                const bool gt = c->call_gtab;
                 if (gt && (c->pbuf.ensure(((size_t)nblk << blk_log) * 4) || c->gtab.ensure((size_t)nunits << (lz_gtab_log() + 2)))) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");
-                launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, c->call_flags & 0x3FFu,
+                launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, zfl,
                           (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr);
             }
-            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, c->call_flags & 0x3FFu, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
             hipStream_t est = nch > 1 ? c->aux : st;
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
@@ -1174,7 +1186,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
                                              uint64_t *dst_off, void *hip_stream) {
     if (!c || !src_off || !src_len || !dst_off || (!d_src && n) || (!d_dst && n)) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
-    c->call_flags = level_flags(c, algo, level);
+    set_call_level(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->timing = pna_gpu_timing{};
@@ -1296,7 +1308,7 @@ static int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
     if (cipher) { int rc = resolve_ivs(c, cipher, n, own_ivs, &ivs); if (rc) return rc; }
-    c->call_flags = level_flags(c, algo, level);
+    set_call_level(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->timing = pna_gpu_timing{};
@@ -1403,7 +1415,7 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
-    c->call_flags = level_flags(c, algo, level);
+    set_call_level(c, algo, level);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // ---- 1. layout of the serialised inner entries (all sizes are known up front)
@@ -1609,7 +1621,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
-    c->call_flags = level_flags(c, algo, level);
+    set_call_level(c, algo, level);
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LEVELS_Z = ((1, 0x03), (2, 0x73), (3, 0x77), (19, 0xF7))            # level -> the product's flag bits (codec.params_for_flags)
+LEVELS_Z = (1, 2, 3, 7, 19)            # one level of each zstd set: fast, balanced, default, high, max (codec.product_level_flags)
 
 
 def _ents(codec):
@@ -46,11 +46,11 @@ def test_latency_mode_equals_the_model(pna, codec, blk_log, unit_log):
     with pna.Context(0) as ctx:
         ctx.set_option("blk_log", blk_log)
         ctx.set_option("unit_log", unit_log)
-        for level, fl in LEVELS_Z:
+        for level in LEVELS_Z:
             outs = ctx.compress_batch(data, level=level)
             t = ctx.timing()
             assert t.blk_log == blk_log and (t.lz_units > 0) == (unit_log < 20), (t.blk_log, t.lz_units)
-            pz = codec.params_for_flags(fl, blk_log=blk_log)
+            pz = codec.params_for_level(level, blk_log=blk_log)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
                 assert len(o) <= ctx._L.pna_gpu_bound(2, len(d)), k

@@ -84,7 +84,7 @@ def test_serial_end_scan_is_identical(pna, codec):
 def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     """The LZ stage runs as two kernels by default (k_lz<MODE 1>: look-up / match / inserts -> one word per position in a workspace ->
     k_lzp: parse with one lane per region); PNA_F_LZ_FUSED runs the one-kernel form (k_lz<MODE 0>), PNA_F_LZ_WAVEPARSE the split form with
-    the wave-per-region parse (k_lz<MODE 2>).  All of them must equal the model, for both codecs and the four level sets, on the cases
+    the wave-per-region parse (k_lz<MODE 2>).  All of them must equal the model, for both codecs and every level set, on the cases
     of the main test and on the inputs that stress far candidates, adoption, block / segment ends and the extension of capped matches."""
     import random
     import torch  # noqa: F401
@@ -103,12 +103,12 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     if form == "default":
         monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: short runs through the one-kernel form (the suite's default is 0)
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
-        for level, fl in ((1, codec.F_HUF | codec.F_FSE), (2, 0x73), (3, 0x77), (19, 0xF7)):
+        for level in (1, 2, 3, 7, 19):              # the five zstd level sets: fast, balanced, default, high, max (codec.product_level_flags)
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
             # (levels 10 .. 22 always take the split form: only the match kernel k_lzm has the global-memory hash table of the strong set)
             assert (ctx.timing().lz_match_launches == 0) == (form in ("default", "fused") and level < 10), (form, level)
-            pz = codec.params_for_flags(fl)
+            pz = codec.params_for_level(level)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
         for level, fl in ((1, 0), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
@@ -167,9 +167,9 @@ def _fuzz_one(gpu_ctx, pna, codec, text, rnd):
                 for t in range(n):
                     buf.append(buf[st + t])
         ents.append(bytes(buf[:target]))
-    for level, fl in ((3, 0x77), (19, 0xF7), (1, codec.F_HUF | codec.F_FSE)):
+    for level in (3, 7, 19, 1):
         outs = gpu_ctx.compress_batch(ents, level=level)
-        pz = codec.params_for_flags(fl)
+        pz = codec.params_for_level(level)
         for i, (e, o) in enumerate(zip(ents, outs)):
             assert o == codec.model_compress(e, pz), (i, len(e), level)
     for level, fl in ((6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
@@ -202,9 +202,9 @@ def test_lz_stage_fuzz_large_entries(gpu_ctx, pna, codec):
                 d = min(d, len(buf)); n = rnd.randrange(3, 20000)
                 buf += (bytes(buf[len(buf) - d:]) * (n // d + 1))[:n]          # an overlapping copy repeats its period
         ents.append(bytes(buf[:target]))
-    for level, fl in ((3, 0x77), (19, 0xF7)):
+    for level in (3, 7, 19):
         outs = gpu_ctx.compress_batch(ents, level=level)
-        pz = codec.params_for_flags(fl)
+        pz = codec.params_for_level(level)
         for i, (e, o) in enumerate(zip(ents, outs)):
             assert o == codec.model_compress(e, pz), (i, len(e), level)
             assert codec.zstd_decompress(o, len(e)) == e
@@ -273,7 +273,7 @@ def test_feature_subsets_bit_exact(pna, codec, flags):
             codec.corpus_file(0, 23, 1 << 20)]
     with pna.Context(0, flags=flags) as ctx:
         outs = ctx.compress_batch(ents)
-    p = codec.params_for_flags(flags)
+    p = codec.params_for_level(3, ctx_flags=flags)           # (the default level keeps the context's bits as they are)
     for e, o in zip(ents, outs):
         assert o == codec.model_compress(e, p)
         assert codec.zstd_decompress(o, len(e)) == e
@@ -1061,20 +1061,23 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
 
 
 def test_levels_select_the_parse(gpu_ctx, pna, codec):
-    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto four parameter sets -- fast (greedy,
+    """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto parameter sets -- fast (greedy,
     LDS-window look-back, every position in the table), balanced (+ even-position table, backward adoption, 1 MiB look-back), default
-    (+ lazy) and strong (+ third adoption round, two-step lazy) --, each bit-exact with the model; stronger sets compress better."""
+    (+ lazy; zstd: the match finder's 32 KiB-window geometry with 32 704 table slots), high (+ third adoption round, two-step lazy) and, zstd
+    only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
     fast, balanced, dflt = codec.F_HUF | codec.F_FSE, std, std | codec.F_LAZY
     strong = dflt | codec.F_STRONG
     sizes = {}
-    for level, fl in ((-5, fast), (1, fast), (2, balanced), (0, dflt), (3, dflt), (pna.LEVEL_DEFAULT, dflt), (9, dflt), (10, strong), (19, strong), (22, strong), (99, strong)):
+    for level, fl, gtab in ((-5, fast, 0), (1, fast, 0), (2, balanced, 0), (0, dflt, 0), (3, dflt, 0), (pna.LEVEL_DEFAULT, dflt, 0), (5, dflt, 0), (6, strong, 0), (9, strong, 0),
+                            (10, strong, 1), (19, strong, 1), (22, strong, 1), (99, strong, 1)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
-        pz = codec.params_for_flags(fl)
+        assert codec.product_level_flags(level) == (fl, bool(gtab)), level
+        pz = codec.params_for_flags(fl, gtab=bool(gtab))
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
-    assert sizes[19] < sizes[3] < sizes[2] < sizes[1]
+    assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1]
     dstd = codec.F_ADOPT | codec.F_INS2
     for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd), (5, dstd), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
@@ -1255,7 +1258,7 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
     segment size (far candidates, their 16 + 16 byte steps, the wave-cooperative extension reading the segment from HBM), repeats that start
     at odd positions and one or two bytes after a table hit (backward adoption, also across the 64-position group border where it must
     stop), candidates at positions 0..3 (unusable by rule), repeats that run into block and segment ends.  Bit-exact with the model,
-    decodable by libzstd / zlib, for both codecs and the four level sets."""
+    decodable by libzstd / zlib, for both codecs and every level set."""
     import random
     rnd = random.Random(2024)
 
@@ -1280,10 +1283,9 @@ def test_far_candidates_and_adoption_edge_cases(gpu_ctx, pna, codec):
     cases["long-far-run"] = rb(100000) + bytes(200000) + rb(60000) + bytes(200000)
     names = sorted(cases)
     data = [cases[k] for k in names]
-    for level in (1, 2, 3, 19):
-        fl = {1: codec.F_HUF | codec.F_FSE, 2: 0x73, 3: 0x77, 19: 0xF7}[level]
+    for level in (1, 2, 3, 7, 19):
         outs = gpu_ctx.compress_batch(data, level=level)
-        pz = codec.params_for_flags(fl)
+        pz = codec.params_for_level(level)
         for k, d, o in zip(names, data, outs):
             assert o == codec.model_compress(d, pz), (k, level)
             assert codec.zstd_decompress(o, len(d)) == d, (k, level)
