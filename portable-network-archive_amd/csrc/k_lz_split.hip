@@ -31,12 +31,75 @@ __device__ unsigned long long g_lzp_stamps[8];              // k_lzp's phase sta
 // the table is only ever modified by atomics, which execute in L2), inserts are global atomics, and a tile's inserts are waited for (vmcnt) before
 // the barrier that lets the next tile's look-ups go.
 constexpr uint32_t GTAB_LOG = 19;
-template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG>
+// ---- k_lzm's far candidates (see the kernel): pair s of the wave's far (lane, j) pairs hands position and offset to lane s - r0 (lane 63: the others' pushes)
+// (one word: owner lane | j << 6 | offset << 8 -- offsets are at most 2^20; the position follows from lane and j, q0w = the wave's first position of the tile)
+__device__ __forceinline__ void far_push(const bool (&farj)[4], const uint32_t (&idx)[4], uint32_t r0, uint32_t q0w, uint32_t lane, const uint32_t (&off)[4], uint32_t &sq, uint32_t &so) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t d = idx[j] - r0;
+        const int dst = (int)((farj[j] && d < 63u) ? d : 63u) * 4;
+        w |= (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)(lane | (uint32_t)j << 6 | off[j] << 8));   // (a lane is the target of at most one pair; lanes nobody writes to get 0)
+    }
+    sq = q0w + 4 * (w & 63u) + ((w >> 6) & 3u); so = w >> 8;
+}
+// the candidate's bytes c - 4 .. c + 32 (STRONG: from c - 8) from the segment in HBM / L2
+template <bool ON, bool STRONG>
+__device__ __forceinline__ void far_load(const uint8_t *seg, uint32_t c, v4u &fa, uint32_t &fb, v4u &fd, uint32_t &fc) {
+    if (!ON) { fa = 0; fd = 0; fb = fc = 0; return; }
+#ifdef LZM_EXP_FARHOT
+    const uint8_t *pc = seg + ((c - 4) & 0xFFFu) + 8;                              // timing experiment: bytes that stay in the caches (wrong matches)
+#else
+    const uint8_t *pc = seg + c - 4;
+#endif
+    fa = ld16u(pc); fb = *(const u32u *)(pc + 16); fd = ld16u(pc + 20);
+    fc = 0;
+    if (STRONG) fc = *(const u32u *)(pc - 4);
+}
+// the owners take their results from the lanes that computed them
+__device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (&idx)[4], uint32_t r0, uint32_t Kf, uint32_t (&K)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t d = idx[j] - r0;
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d < 63u ? d : 63u) * 4), (int)Kf);
+        if (farj[j] && d < 63u) K[j] = got;
+    }
+}
+// the match step of position q against those bytes: K = len << 6 | back << 3, exactly as for a candidate inside the window
+template <bool STRONG, uint32_t WB>
+__device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q, v4u fa, uint32_t fb, v4u fd, uint32_t fc, bool edge, uint32_t blk_end) {
+    const uint32_t *pq = win32 + (((q - 4) & (WB - 1)) >> 2);                      // the position's bytes q - 4 .. q + 32: aligned words + shift; pq[1..9] may lie in the mirror
+    const uint32_t shq = ((q - 4) & 3) * 8;
+    uint32_t E[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) E[k] = pq[k];
+#define EW(k) __builtin_amdgcn_alignbit(E[(k) + 1], E[k], shq)                     /* bytes q - 4 + 4 k .. + 3 */
+    const uint32_t x0 = EW(1) ^ fa.y, x1 = EW(2) ^ fa.z, x2 = EW(3) ^ fa.w, x3 = EW(4) ^ fb;
+    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
+    uint32_t l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+    if (l == 16) {
+        const uint32_t y0 = EW(5) ^ fd.x, y1 = EW(6) ^ fd.y, y2 = EW(7) ^ fd.z, y3 = EW(8) ^ fd.w;
+        const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
+        l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+    }
+    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
+    if (l < MIN_MATCH) l = 0;
+    const uint32_t xk = EW(0) ^ fa.x;
+    uint32_t bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
+    if (STRONG && xk == 0) {
+        const uint32_t em = win32[((q - 8) & (WB - 1)) >> 2];
+        bk = 4 + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], em, shq) ^ fc) | 0xFFu) >> 3);
+    }
+#undef EW
+    return (STRONG && !l) ? 0u : (l << 6) | (bk << 3);
+}
+
+template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
            uint32_t *__restrict__ gtab) {
     constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
-    constexpr bool FAR = !DEFL;                             // deflate offsets (<= 32 KiB) never leave the LDS window
+    constexpr bool FAR = !DEFL && FARP;                     // deflate offsets (<= 32 KiB) never leave the LDS window; FARP = false: a zstd launch whose look-back ends with the window (the fast set)
     using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
     constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR;
     static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!DEFL || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
@@ -72,7 +135,9 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
             const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
+#ifndef LZM_EXP_PFLATE
             if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
+#endif
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
             // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
@@ -98,40 +163,55 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 if (GLOG) ent[j] = hv[j] ? __hip_atomic_load(&table[hsh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 else ent[j] = hv[j] ? table[hsh[j]] : 0u;
             }
-            // ---- candidates (rules as in k_lz); far ones get their bytes requested from the segment now
+            // ---- candidates (rules as in k_lz)
             uint32_t off[4];
-            v4u fa[4], fd[4]; uint32_t fb[4], fc[4];           // (register tuples the loads write in place: a struct's components were moved after the load, with a wait)
+            bool farj[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                fa[j] = 0; fd[j] = 0; fb[j] = fc[j] = 0;
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
                 off[j] = (c1 > 8 && (ent[j] & TAG_MASK) == tag[j] && o <= max_off) ? o : 0u;
-                if (FAR && off[j] > NEAR) {
-                    // only the lanes that hold one (3 - 4 % of the positions), and ALL the bytes the match step can ask for -- the 4 (8) before the candidate
-                    // and its 32 -- into register tuples the loads write in place.  (Loaded as a struct, the components were moved behind the load, with a
-                    // wait right there: the far candidates then cost 27 % of the kernel instead of 17 %; fetching the second 16 bytes only where the first
-                    // 16 agreed puts a memory round trip into the match step of nearly every wave and position, one far lane in 64 being enough.)
-                    const uint32_t fo = c1 - 5;                                         // byte offset of c - 4 in the segment
-                    fa[j] = ld16u(seg + fo);
-                    fb[j] = *(const u32u *)(seg + fo + 16);
-                    fd[j] = ld16u(seg + fo + 20);
-                    if (STRONG) fc[j] = *(const u32u *)(seg + fo - 4);
-                }
+                farj[j] = FAR && off[j] > NEAR;
             }
-            // ---- match
+            // ---- the far candidates (more than NEAR bytes back: outside the window) are handled COMPACTED.  A vector load costs the CU's address unit 16
+            // cycles per instruction whatever the number of active lanes, and nearly every wave and position j holds a far lane or two (3 - 6 % of the
+            // positions): loaded in place, 12 loads per wave and tile were 22 % of the kernel.  So the wave's far pairs (lane, j) are numbered (ballot +
+            // mbcnt), pair s hands its position and offset to lane s (ds_permute), lane s requests the candidate's 4 (8) + 32 bytes from the segment --
+            // three loads per wave and tile, in flight during the match step of the near candidates --, then reads the position's bytes from the window,
+            // runs the same match step on them, and the owner pulls the result (ds_bpermute).  63 pairs per round (lane 63 takes the pushes of the
+            // lanes without a pair); more than 63: further rounds behind the first.
+            // (The first round's loads are issued whether the wave holds a far pair or not -- nearly every wave does --, lanes without a pair reading the
+            // segment's first bytes: a load under a branch makes the compiler copy the loaded tuple behind the branch, with a wait for it right there.)
+            uint32_t idx[4] = {0, 0, 0, 0}, npair = 0, sq = 0, so = 0;
+            if (FAR) {
+                uint64_t fm[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) fm[j] = __ballot(farj[j]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    idx[j] = npair + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm[j], 0u));
+                    npair += (uint32_t)__builtin_popcountll(fm[j]);
+                }
+                npair = uni(npair);
+                far_push(farj, idx, 0u, t0 + wave * RW, lane, off, sq, so);
+            }
+            const bool slot0 = FAR && lane < 63u && lane < npair;
+            v4u ffa, ffd; uint32_t ffb, ffc;
+            far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
+#ifdef LZM_EXP_PFLATE
+            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
+#endif
+            // ---- match: the candidates inside the window
             uint32_t K[4];
             const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t l = 0, bk = 0;
-                const uint32_t o = off[j], q = q0 + j;
+                const uint32_t o = farj[j] ? 0u : off[j], q = q0 + j;
                 if (o != 0) {
                     const uint32_t c = q - o;
-                    const bool isfar = FAR && o > NEAR;
                     const uint32_t shc = (c & 3) * 8;
                     uint32_t w0, w1, w2, w3, bc, bc2 = 0;
-                    if (isfar) { bc = fa[j].x; w0 = fa[j].y; w1 = fa[j].z; w2 = fa[j].w; w3 = fb[j]; bc2 = fc[j]; }
-                    else {
+                    {
                         const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
                         const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
                         w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
@@ -144,8 +224,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
                     if (l == 16) {
                         uint32_t v0, v1, v2, v3;
-                        if (isfar) { v0 = fd[j].x; v1 = fd[j].y; v2 = fd[j].z; v3 = fd[j].w; }
-                        else {
+                        {
                             const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
                             const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
                             v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
@@ -164,6 +243,24 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 }
                 K[j] = (l << 6) | (bk << 3);
                 if (STRONG && !l) K[j] = 0;
+            }
+            // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)
+            if (FAR && npair) {
+                {
+                    uint32_t Kf = 0;
+                    if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, ffa, ffb, ffd, ffc, edge, blk_end);
+                    far_pull(farj, idx, 0u, Kf, K);
+                }
+                for (uint32_t r0 = 63; r0 < npair; r0 += 63) {                         // (more than 63 far pairs in 256 positions: rare)
+                    uint32_t sq2, so2, Kf = 0;
+                    far_push(farj, idx, r0, t0 + wave * RW, lane, off, sq2, so2);
+                    if (lane < 63u && lane < npair - r0) {
+                        v4u ga, gd; uint32_t gb, gc;
+                        far_load<true, STRONG>(seg, sq2 - so2, ga, gb, gd, gc);
+                        Kf = far_match<STRONG, WIN_BYTES>(win32, sq2, ga, gb, gd, gc, edge, blk_end);
+                    }
+                    far_pull(farj, idx, r0, Kf, K);
+                }
             }
             // ---- backward adoption: K = len << 6 | back << 3 | positions moved; the offset goes along
             if (adopt) {
@@ -588,12 +685,12 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #endif
 }
 
-template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG>
+template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                            uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
-    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);   // once per process, thread-safe
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG, FARP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
+    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
@@ -610,6 +707,7 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
            if (strong) launch_split_g<false, true, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
            else launch_split_g<false, false, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
     else { if (strong) launch_split_g<false, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
+           else if (max_off <= NEAR_OFF) launch_split_g<false, false, 0, 16, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
            else launch_split_g<false, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
