@@ -222,9 +222,15 @@ int  pna_gpu_create_solid_archive_device(pna_gpu_ctx *ctx, int algo, int level, 
                                          const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                          void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream);
 
-/* With a cipher (CTR only: CBC would be one serial chain over the whole stream): SHED(encryption, cipher_mode) | PHSF | SDAT(iv) |
- * SDAT(ciphertext)* | SEND, one cipher stream over all SDAT bodies (into_solid_archive, lib/src/archive/write.rs:443-470).
- * cipher->ivs is ONE 16-byte IV or NULL; pna_gpu_archive_enc_bound-style slack: add 64 + strlen(phsf) bytes to the plain bound. */
+/* With a cipher: one cipher stream over all SDAT bodies (into_solid_archive takes any cipher, lib/src/archive/write.rs:443-470).
+ *   CTR: SHED(encryption, cipher_mode) | PHSF | SDAT(iv) | SDAT(ciphertext)* | SEND; cipher->ivs is ONE 16-byte IV or NULL.
+ *   GCM: SHED | PHSF | SDAT(stream header, 75 bytes) | SDAT(segment ciphertext || tag)* | SEND -- the GCM STREAM layout of
+ *        pna_gpu_create_archive_enc_device over the compressed solid stream, the stream key bound to the SHED chunk (entry_context,
+ *        lib/src/cipher/aead.rs:167-190); cipher->ivs is ONE salt(32) || nonce_prefix(7) or NULL.
+ *   CBC encryption would be one serial chain over the whole stream: PNA_E_UNSUPPORTED (the extract driver decrypts CBC solid streams,
+ *   which is parallel).
+ * pna_gpu_solid_archive_enc_bound: the destination capacity to offer (cipher == NULL: the plain bound). */
+size_t pna_gpu_solid_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher);
 int  pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                              const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                              const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *archive_len,
@@ -277,7 +283,7 @@ int  pna_gpu_inflate_open_device(pna_gpu_ctx *ctx, const void *d_src, uint64_t s
  * and zstd / deflate / store decoding run on the device; entries without fSIZ are sized by the decoder.  cb is called once per entry in archive order (kind =
  * DataKind::to_byte(): 0 file, 1 directory, ...); `data` is valid during the call.  PNA_E_INVAL: structural damage, CRC mismatch, corrupt
  * stream, wrong password (GCM key confirmation, CBC padding), authentication failure; PNA_E_UNSUPPORTED: multipart archives, xz,
- * Camellia, CBC / GCM solid streams, solid streams with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND):
+ * Camellia, solid streams with inner entries that are not stored.  Solid entries (SHED [PHSF] SDAT* SEND; plain or AES CTR / CBC / GCM):
  * SDAT CRCs and the inner FDAT CRCs on the device, the stream is decoded without a recorded size (frames counted first). */
 /* `name` is the entry's PATH as the reference's reader exposes it (EntryHeader::path(), lib/src/entry/header.rs:91-94): the FHED name
  * normalised and reduced to its normal components (EntryName::sanitize, lib/src/entry/name.rs:148-156 -- no root, no "." / ".."), so a

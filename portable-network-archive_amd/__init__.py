@@ -109,7 +109,7 @@ EXPORTS = [
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
     "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
-    "pna_gpu_solid_archive_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
+    "pna_gpu_solid_archive_bound", "pna_gpu_solid_archive_enc_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",
     "pna_gpu_create_solid_archive_enc_device", "pna_gpu_extract_archive_host", "pna_gpu_zstd_stream_frames_device",
@@ -178,6 +178,8 @@ def load_library() -> ctypes.CDLL:
     L.pna_gpu_decompress_batch_device.argtypes = [vp, ctypes.c_int, sz, vp, u64p, u64p, vp, u64p, u64p, vp]
     L.pna_gpu_solid_archive_bound.restype = sz
     L.pna_gpu_solid_archive_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p]
+    L.pna_gpu_solid_archive_enc_bound.restype = sz
+    L.pna_gpu_solid_archive_enc_bound.argtypes = [ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), u64p, ctypes.POINTER(CipherStruct)]
     L.pna_gpu_create_solid_archive_device.restype = ctypes.c_int
     L.pna_gpu_create_solid_archive_device.argtypes = [vp, ctypes.c_int, ctypes.c_int, sz, ctypes.POINTER(ctypes.c_char_p), vp, u64p, u64p,
                                                       vp, sz, u64p, vp]
@@ -395,7 +397,7 @@ class Context:
     def create_solid_archive_device(self, names: Sequence[str], d_src: int, src_off: Sequence[int], src_len: Sequence[int], d_dst: int,
                                     dst_cap: int, algo: int = ALGO_ZSTD, level: int = LEVEL_DEFAULT, stream: int = 0,
                                     _cache: Optional[dict] = None, cipher: Optional[Cipher] = None) -> int:
-        """`pna create --solid` assembled in HBM (pna_gpu_create_solid_archive_enc_device; `cipher`: CTR, one IV).
+        """`pna create --solid` assembled in HBM (pna_gpu_create_solid_archive_enc_device; `cipher`: CTR with one IV, or GCM with one salt || nonce prefix).
         Returns the archive length."""
         n = len(src_len)
         if _cache is not None and "a" in _cache:
@@ -722,6 +724,14 @@ def solid_archive_bound(algo: int, names: Sequence[str], src_len: Sequence[int])
     return load_library().pna_gpu_solid_archive_bound(algo, n, a_names, a_len)
 
 
+def solid_archive_enc_bound(algo: int, names: Sequence[str], src_len: Sequence[int], cipher: Optional[Cipher]) -> int:
+    n = len(src_len)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_len = (ctypes.c_uint64 * max(n, 1))(*src_len)
+    cs = cipher.struct(1) if cipher is not None else None
+    return load_library().pna_gpu_solid_archive_enc_bound(algo, n, a_names, a_len, ctypes.byref(cs) if cs is not None else None)
+
+
 def crc_schedule(payload: bytes) -> int:
     """crc32(b"FDAT" + payload) computed by the host walk through k_frame's lane schedule (table self-check)."""
     return load_library().pna_gpu_debug_crc_schedule(payload, len(payload))
@@ -791,7 +801,7 @@ def create_archive_encrypted(ctx: Context, names: Sequence[str], entries: Sequen
 
 def extract_archive(ctx: Context, archive: bytes, password: Optional[bytes] = None):
     """`pna extract` for a non-solid archive (pna_gpu_extract_archive_host): returns [(name, kind, data)] in archive order; chunk CRCs
-    are verified (data chunks on the device), entries are decrypted (AES-CTR) and decoded on the device."""
+    are verified (data chunks on the device), entries and solid streams are decrypted (AES CTR / CBC / GCM STREAM) and decoded on the device."""
     out = []
 
     def _cb(_u, idx, name, kind, data, n):

@@ -180,11 +180,11 @@ void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name) {
 // SHED chunk of an unencrypted solid entry -- lib/src/entry/header.rs:274-282; SEND -- lib/src/archive/write.rs:716-727
 void frame_solid_head(std::vector<uint8_t> &o, int compression) { const uint8_t shed[5] = {0, 0, (uint8_t)compression, 0, 1}; put_chunk(o, "SHED", shed, 5); }
 // SHED | PHSF | SDAT(iv) of a solid entry written with a cipher -- into_solid_archive, lib/src/archive/write.rs:443-470
-void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t iv[16]) {
+void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t *prefix, size_t prefix_len) {
     const uint8_t shed[5] = {0, 0, (uint8_t)compression, (uint8_t)encryption, (uint8_t)cipher_mode};
     put_chunk(o, "SHED", shed, 5);
     put_chunk(o, "PHSF", (const uint8_t *)phsf, strlen(phsf));
-    put_chunk(o, "SDAT", iv, 16);
+    put_chunk(o, "SDAT", prefix, prefix_len);                       // CTR: the IV; GCM STREAM: the stream header
 }
 void frame_solid_tail(std::vector<uint8_t> &o) { put_chunk(o, "SEND", nullptr, 0); }
 size_t frame_entry_prefix_bound(const char *name) { return 12 + 6 + (name ? strlen(name) : 0) + 12 + 16 + 8; }

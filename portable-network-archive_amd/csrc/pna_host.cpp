@@ -69,7 +69,7 @@ void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks,
 std::string pna_sanitize_name(const char *name, size_t n);
 void frame_inner_entry_empty(std::vector<uint8_t> &o, const char *name);
 void frame_solid_head(std::vector<uint8_t> &o, int compression);
-void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t iv[16]);
+void frame_solid_head_enc(std::vector<uint8_t> &o, int compression, int encryption, int cipher_mode, const char *phsf, const uint8_t *prefix, size_t prefix_len);
 void frame_solid_tail(std::vector<uint8_t> &o);
 void frame_archive_head(std::vector<uint8_t> &o, uint32_t archive_number);
 void frame_archive_tail(std::vector<uint8_t> &o);
@@ -542,15 +542,18 @@ static void aes256_block_host(const AesKey &k, const uint8_t in[16], uint8_t out
 // GCM STREAM material of one entry (lib/src/entry/write.rs:81-107 to_hashed; lib/src/cipher/aead.rs): stream header, stream key bound to
 // the FHED chunk and the PHSF string, round keys, hash subkey, E(K, J0) of the (single, final) segment 0 and its first counter block.
 struct GcmMaterial { uint8_t header[75]; AesKey rk; uint32_t h[4], ej0[4]; uint8_t ctr_iv[16]; };
+// (the stream key is bound to the header chunk of the entry that carries the stream: FHED of a normal entry, SHED of a solid one -- entry_context,
+// lib/src/cipher/aead.rs:167-190; name == nullptr: the solid entry's SHED)
 static void gcm_entry_material(const pna_gpu_cipher *ci, const uint8_t kc[32], const uint8_t phsf_hash[32], const uint8_t salt_prefix[39],
                                uint32_t seg_size, const char *name, int compression, GcmMaterial &m) {
     memcpy(m.header, salt_prefix, 39);
     m.header[39] = (uint8_t)(seg_size >> 24); m.header[40] = (uint8_t)(seg_size >> 16); m.header[41] = (uint8_t)(seg_size >> 8); m.header[42] = (uint8_t)seg_size;
     memcpy(m.header + 43, kc, 32);
-    const std::vector<uint8_t> fh = frame_fhed_bytes(name, compression, ci->encryption, PNA_MODE_GCM);
+    const std::vector<uint8_t> fh = name ? frame_fhed_bytes(name, compression, ci->encryption, PNA_MODE_GCM)
+                                         : std::vector<uint8_t>{0, 0, (uint8_t)compression, (uint8_t)ci->encryption, (uint8_t)PNA_MODE_GCM};
     uint8_t info[88];
     memcpy(info, "PNA-STREAM-v1", 13);
-    sha256_bytes("FHED", 4, fh.data(), fh.size(), info + 13);
+    sha256_bytes(name ? "FHED" : "SHED", 4, fh.data(), fh.size(), info + 13);
     memcpy(info + 45, phsf_hash, 32);
     memcpy(info + 77, salt_prefix + 32, 7);
     memcpy(info + 84, m.header + 39, 4);
@@ -889,9 +892,18 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (solid) {
         if (e1 - e0 != 1) return fail(c, PNA_E_INVAL, "a solid stream is one entry");
         nunit = nseg;
-        if (c->h_desc.ensure(nunit * sizeof(FrameDesc)) || c->h_blob.ensure(nunit * 8 + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
+        // (GCM: one SDAT chunk per GCM segment of the compressed stream -- at most the worst-case output / segment size + 1 of them)
+        const size_t ucap = gcm ? (size_t)(pna_gpu_bound(algo, (size_t)src_len[e0]) / gcm_seg) + 2 : nunit;
+        if (c->h_desc.ensure(ucap * sizeof(FrameDesc)) || c->h_blob.ensure(ucap * 8 + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing staging");
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
+        if (gcm) {
+            gmat.resize(1);
+            uint8_t kc[32], ph[32];
+            hkdf_sha256_32(fj->cipher->key, 32, nullptr, 0, "PNA-KC-v1", 9, kc);
+            sha256_bytes(fj->cipher->phsf, strlen(fj->cipher->phsf), nullptr, 0, ph);
+            gcm_entry_material(fj->cipher, kc, ph, fj->ivs, gcm_seg, nullptr, algo, gmat[0]);
+        }
     } else if (fj) {
         std::vector<uint8_t> tmp;
         size_t bound = 0;
@@ -1012,6 +1024,46 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         if (solid) {
             // solid stream: one SDAT chunk per segment (= per zstd frame / per run of deflate blocks): [len "SDAT" | payload | crc]
             dst_off[e0] = pos;
+            if (gcm) {
+                // GCM STREAM over the solid stream (into_solid_archive takes any cipher, lib/src/archive/write.rs:443-470; GcmEncryptWriter, lib/src/cipher/
+                // gcm.rs:48-100): the head carries the stream header as its first SDAT chunk; here one SDAT chunk per GCM segment, ciphertext || tag.  The
+                // write kernels put the compressed stream down in one piece behind the first chunk header, segments k >= 1 then move forward by 28 k
+                // bytes (tag and CRC of the chunk before + their own chunk header), as a GCM entry of several segments does.
+                const uint64_t P = seg_off[nseg] - seg_off[0], G = gcm_seg;
+                const uint64_t K = P ? (P + G - 1) / G : 1;
+                if (K > 0xFFFFFFFFull) return fail(c, PNA_E_INVAL, "GCM segment counter overflow");
+                const uint64_t B = pos + 8;
+                for (uint32_t sg = 0; sg < nseg; sg++) segdst[sg] = B + (seg_off[sg] - seg_off[0]);
+                if (K > 1) spread_copy.emplace_back(B, P);
+                const GcmMaterial &gm = gmat[0];
+                for (uint64_t k = 0; k < K; k++) {
+                    const uint64_t sl = std::min<uint64_t>(G, P - k * G), hk = pos + k * (G + 28), so_ = hk + 8;
+                    uint8_t *pf = blob + 8 * (size_t)k;
+                    const uint64_t cl = sl + 16;
+                    pf[0] = (uint8_t)(cl >> 24); pf[1] = (uint8_t)(cl >> 16); pf[2] = (uint8_t)(cl >> 8); pf[3] = (uint8_t)cl;
+                    memcpy(pf + 4, "SDAT", 4);
+                    fds[k] = FrameDesc{hk, (uint32_t)cl, (uint32_t)(8 * k), 8u, 0};
+                    const uint32_t si = (uint32_t)gsegs.size();
+                    uint8_t j0[16], eb[16];
+                    memcpy(j0, gm.ctr_iv, 7);
+                    j0[7] = (uint8_t)(k >> 24); j0[8] = (uint8_t)(k >> 16); j0[9] = (uint8_t)(k >> 8); j0[10] = (uint8_t)k; j0[11] = k + 1 == K ? 1 : 0;
+                    j0[12] = 0; j0[13] = 0; j0[14] = 0; j0[15] = 1;
+                    aes256_block_host(gm.rk, j0, eb);
+                    GcmSeg gs; memcpy(gs.ctr_iv, j0, 16); gs.ctr_iv[15] = 2; gs.entry = 0;
+                    gsegs.push_back(gs);
+                    for (uint64_t o = 0; o < sl; o += CTR_UNIT) cunits.push_back(CipherUnit{so_ + o, o, (uint32_t)std::min<uint64_t>(CTR_UNIT, sl - o), si});
+                    GcmEntry ge{so_, (uint32_t)sl, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                    memcpy(ge.h, gm.h, 16);
+                    for (int w = 0; w < 4; w++) ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
+                    gents.push_back(ge);
+                    if (k >= 1)
+                        for (uint64_t o = 0; o < sl; o += (1u << 20))
+                            spread.push_back(SpreadPiece{spread_bytes + k * G + o, so_ + o, (uint32_t)std::min<uint64_t>(1u << 20, sl - o)});
+                }
+                if (K > 1) spread_bytes += (P + 15) & ~(uint64_t)15;
+                pos += P + 28 * K;
+                nunit = (size_t)K; blob_len = 8 * (size_t)K;
+            } else {
             for (uint32_t sg = 0; sg < nseg; sg++) {
                 const uint64_t plen = seg_off[sg + 1] - seg_off[sg];
                 uint8_t *pf = blob + 8 * (size_t)sg;
@@ -1025,6 +1077,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 pos += 8 + plen + 4;
             }
             blob_len = 8 * (size_t)nseg;
+            }
         } else {
             // FlattenWriter cuts an entry's stream into FDAT chunks of max_chunk_size bytes, the last one holding the rest (lib/src/util/io.rs:60-77:
             // the open chunk is topped up before a new one starts; FileEntryBuilder::max_chunk_size, lib/src/entry/builder/file.rs:105-112; default
@@ -1133,14 +1186,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         HIPCHK(c, hipStreamSynchronize(st));                      // pd goes out of scope
     }
     if (fj && fj->cipher) {
-        if (solid && fj->cipher->cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "solid archives: only CTR on the device path (CBC is one serial chain)");
+        if (solid && fj->cipher->cipher_mode == PNA_MODE_CBC) return fail(c, PNA_E_UNSUPPORTED, "solid archives: CTR and GCM on the device path (CBC encryption is one serial chain over the whole stream)");
         int rc = ensure_aes(c); if (rc) return rc;
         if (c->ci_units.ensure(cunits.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure((e1 - e0) * 16 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
         AesKey key; aes256_expand(fj->cipher->key, key);
         HIPCHK(c, hipMemcpyAsync(c->ci_units.p, cunits.data(), cunits.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
         std::vector<uint8_t> giv; std::vector<AesKey> gkeys;
         if (gcm) {
-            if (solid) return fail(c, PNA_E_UNSUPPORTED, "GCM on the solid device path");
             giv.resize(gsegs.size() * 16); gkeys.resize(gsegs.size());
             for (size_t i = 0; i < gsegs.size(); i++) { memcpy(&giv[16 * i], gsegs[i].ctr_iv, 16); gkeys[i] = gmat[gsegs[i].entry].rk; }
             if (c->ci_keys.ensure(gkeys.size() * sizeof(AesKey) + 16) || c->ci_gcm.ensure(gents.size() * sizeof(GcmEntry) + 16) || c->ci_ivs.ensure(giv.size() + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
@@ -1394,6 +1446,17 @@ extern "C" size_t pna_gpu_solid_archive_bound(int algo, size_t n, const char *co
     return 28 + 17 + pna_gpu_bound(algo, (size_t)plain) + 12 * segs + 12 + 12 + 64;
 }
 
+extern "C" size_t pna_gpu_solid_archive_enc_bound(int algo, size_t n, const char *const *names, const uint64_t *src_len, const pna_gpu_cipher *cipher) {
+    size_t b = pna_gpu_solid_archive_bound(algo, n, names, src_len);
+    if (!cipher || cipher->encryption == PNA_ENC_NONE) return b;
+    b += 12 + (cipher->phsf ? strlen(cipher->phsf) : 0) + 12 + 75 + 64;          // PHSF chunk, the chunk of the IV / stream header
+    if (cipher->cipher_mode == PNA_MODE_GCM) {
+        const uint64_t seg = cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20);
+        b += 28 * (size_t)(b / seg + 2);                                            // tag + chunk framing per GCM segment
+    }
+    return b;
+}
+
 extern "C" int pna_gpu_create_solid_archive_device(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                    const void *d_src, const uint64_t *src_off, const uint64_t *src_len,
                                                    void *d_dst, size_t dst_cap, uint64_t *archive_len, void *hip_stream) {
@@ -1410,8 +1473,8 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
-    if (cipher && cipher->cipher_mode == PNA_MODE_GCM) return fail(c, PNA_E_UNSUPPORTED, "GCM on the solid device path");
     if (cipher) { int rc0 = resolve_ivs(c, cipher, 1, own_ivs, &ivs); if (rc0) return rc0; }
+    if (cipher && cipher->cipher_mode == PNA_MODE_CBC) return fail(c, PNA_E_UNSUPPORTED, "solid archives: CTR and GCM on the device path (CBC encryption is one serial chain over the whole stream)");
     if (!c || !archive_len || (n && (!names || !src_off || !src_len || !d_src)) || !d_dst) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
@@ -1456,7 +1519,14 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     c->timing = pna_gpu_timing{};
     std::vector<uint8_t> head, tail;
     frame_archive_head(head, 0);
-    if (cipher) frame_solid_head_enc(head, algo, cipher->encryption, cipher->cipher_mode, cipher->phsf, ivs); else frame_solid_head(head, algo);
+    if (cipher && cipher->cipher_mode == PNA_MODE_GCM) {
+        // the stream header (salt || nonce prefix || segment size || key confirmation: 75 bytes) is the stream's first write, a chunk of its own
+        GcmMaterial gm; uint8_t kc[32], ph[32];
+        hkdf_sha256_32(cipher->key, 32, nullptr, 0, "PNA-KC-v1", 9, kc);
+        sha256_bytes(cipher->phsf, strlen(cipher->phsf), nullptr, 0, ph);
+        gcm_entry_material(cipher, kc, ph, ivs, cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20), nullptr, algo, gm);
+        frame_solid_head_enc(head, algo, cipher->encryption, cipher->cipher_mode, cipher->phsf, gm.header, 75);
+    } else if (cipher) frame_solid_head_enc(head, algo, cipher->encryption, cipher->cipher_mode, cipher->phsf, ivs, 16); else frame_solid_head(head, algo);
     frame_solid_tail(tail); frame_archive_tail(tail);
     if (head.size() + tail.size() + 64 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
@@ -1826,8 +1896,15 @@ struct XSolid {                                                // SHED [PHSF] SD
     std::vector<XPiece> pieces; uint64_t stream_len = 0;
     size_t order = 0;                                          // number of normal entries in front of it
     uint64_t pk_off = 0, pay_len = 0;
+    std::vector<uint8_t> shed;                                 // SHED body: the GCM stream key is bound to it (entry_context, lib/src/cipher/aead.rs:167-190)
+    uint32_t gcm_seg = 0;
     size_t s0 = 0, s1 = 0;                                     // its SDAT chunks in the descriptor list
     uint64_t lo = 0, hi = 0;
+};
+// an encrypted data stream of the archive, a normal entry's or a solid entry's: what the cipher stage needs of either
+struct XCipherStream {
+    const std::string *phsf; int mode; const std::vector<XPiece> *pieces; uint64_t stream_len, pk_off; uint64_t *pay_len; uint32_t gcm_seg;
+    const char *htype; const std::vector<uint8_t> *hdr; uint8_t iv[16];
 };
 uint32_t rd_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 int b64_val(char ch) {
@@ -1874,7 +1951,7 @@ extern "C" int pna_gpu_extract_archive_host(pna_gpu_ctx *c, const void *archive,
         else if (memcmp(ty, "SHED", 4) == 0) {
             if (in_entry || in_solid || len != 5 || data[0] != 0 || data[1] != 0) return fail(c, PNA_E_INVAL, "bad solid header");
             scur = XSolid(); in_solid = true; scur.order = ents.size(); scur.s0 = schunks.size(); scur.lo = pos;
-            scur.compression = data[2]; scur.encryption = data[3]; scur.cipher_mode = data[4];
+            scur.compression = data[2]; scur.encryption = data[3]; scur.cipher_mode = data[4]; scur.shed.assign(data, data + len);
         } else if (in_solid) {
             if (memcmp(ty, "SDAT", 4) == 0) { scur.pieces.push_back(XPiece{pos + 8, len}); scur.stream_len += len; }
             else if (memcmp(ty, "PHSF", 4) == 0) scur.phsf.assign((const char *)data, len);
@@ -2016,54 +2093,60 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
         return PNA_OK;
     };
     uint64_t pk_total = 0, raw_total = 0;
-    std::vector<PlaceDescH> places; std::vector<uint8_t> ivs; std::vector<size_t> enc_idx, gcm_idx, nosize_idx;
+    std::vector<PlaceDescH> places; std::vector<XCipherStream> enc_list, gcm_list; std::vector<size_t> nosize_idx;
     std::vector<std::vector<uint8_t>> nosize_data;
-    for (size_t i = 0; i < n; i++) {
-        XEntry &e = ents[i];
-        uint64_t prefix = 0;
-        // bytes [lo, hi) of the entry's data stream (the concatenated FDAT bodies) -> host buffer / gather descriptors
-        auto stream_read = [&](uint64_t lo, uint64_t n2, uint8_t *out) {
+    // A data stream (the concatenated FDAT / SDAT bodies) is laid into the packed buffer at pk_off with its cipher prefix stripped: CTR / CBC lose the
+    // IV, a GCM STREAM its header and the segments' tags (only the ciphertext is gathered).  Sets pay_len (and gcm_seg) and registers the stream
+    // with the cipher stage.
+    auto plan_stream = [&](const std::vector<XPiece> &pieces, uint64_t stream_len, int encryption, int cipher_mode, const std::string &phsf,
+                           const char *htype, const std::vector<uint8_t> &hdr, uint64_t pk_off, uint64_t &pay_len, uint32_t &gcm_seg) -> int {
+        auto stream_read = [&](uint64_t lo, uint64_t n2, uint8_t *out) {        // (the prefix may span data pieces: prepend_data_prefix makes it a piece of its own)
             uint64_t at2 = 0, got = 0;
-            for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < n2; k++) if (at2 + k >= lo) out[got++] = a[p.off + k]; at2 += p.len; if (got >= n2) break; }
+            for (const XPiece &p : pieces) { for (uint32_t k = 0; k < p.len && got < n2; k++) if (at2 + k >= lo) out[got++] = a[p.off + k]; at2 += p.len; if (got >= n2) break; }
         };
         auto stream_place = [&](uint64_t lo, uint64_t hi, uint64_t dst) {
             uint64_t at2 = 0;
-            for (const XPiece &p : e.pieces) {
+            for (const XPiece &p : pieces) {
                 const uint64_t s0 = std::max<uint64_t>(lo, at2), s1 = std::min<uint64_t>(hi, at2 + p.len);
                 for (uint64_t k = s0; k < s1; k += (1u << 20)) places.push_back(PlaceDescH{p.off + (k - at2), dst + (k - lo), (uint32_t)std::min<uint64_t>(1u << 20, s1 - k), 0});
                 at2 += p.len;
             }
         };
+        if (encryption == PNA_ENC_NONE) { pay_len = stream_len; stream_place(0, stream_len, pk_off); return PNA_OK; }
+        if (encryption != PNA_ENC_AES) return fail(c, PNA_E_UNSUPPORTED, "only AES entries are decrypted by this driver");
+        if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
+        if (phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
+        XCipherStream cs{&phsf, cipher_mode, &pieces, stream_len, pk_off, &pay_len, 0, htype, &hdr, {0}};
+        if (cipher_mode == PNA_MODE_CTR || cipher_mode == PNA_MODE_CBC) {
+            if (stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
+            stream_read(0, 16, cs.iv);
+            pay_len = stream_len - 16;
+            stream_place(16, stream_len, pk_off);
+            enc_list.push_back(cs);
+        } else if (cipher_mode == PNA_MODE_GCM) {
+            // stream header, then segments of (segment size + 16-byte tag), the last one shorter: only the ciphertext is gathered
+            if (stream_len < 75 + 16) return fail(c, PNA_E_INVAL, "datastream shorter than the stream header");
+            uint8_t hd[75]; stream_read(0, 75, hd);
+            gcm_seg = rd_be32(hd + 39);
+            if (gcm_seg == 0 || gcm_seg > (64u << 20)) return fail(c, PNA_E_INVAL, "GCM segment size out of range");
+            cs.gcm_seg = gcm_seg;
+            uint64_t rest = stream_len - 75, at2 = 75, outp = pk_off;
+            while (rest) {
+                const uint64_t segl = std::min<uint64_t>(rest, (uint64_t)gcm_seg + 16);
+                if (segl < 16) return fail(c, PNA_E_INVAL, "GCM segment shorter than a tag");
+                stream_place(at2, at2 + segl - 16, outp);
+                outp += segl - 16; at2 += segl; rest -= segl;
+            }
+            pay_len = outp - pk_off;
+            gcm_list.push_back(cs);
+        } else return fail(c, PNA_E_UNSUPPORTED, "unknown cipher mode");
+        return PNA_OK;
+    };
+    for (size_t i = 0; i < n; i++) {
+        XEntry &e = ents[i];
         if (e.compression != PNA_ALGO_STORE && e.compression != PNA_ALGO_ZSTD && e.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "compression method not decoded on the device (xz)");
         e.pk_off = pk_total;
-        if (e.encryption != PNA_ENC_NONE) {
-            if (e.encryption != PNA_ENC_AES) return fail(c, PNA_E_UNSUPPORTED, "only AES entries are decrypted by this driver");
-            if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
-            if (e.phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
-            if (e.cipher_mode == PNA_MODE_CTR || e.cipher_mode == PNA_MODE_CBC) {
-                if (e.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
-                prefix = 16;
-                uint8_t iv[16]; stream_read(0, 16, iv);          // the IV may span data pieces (prepend_data_prefix makes it a piece of its own)
-                ivs.insert(ivs.end(), iv, iv + 16); enc_idx.push_back(i);
-                e.pay_len = e.stream_len - prefix;
-                stream_place(prefix, e.stream_len, e.pk_off);
-            } else if (e.cipher_mode == PNA_MODE_GCM) {
-                // stream header, then segments of (segment size + 16-byte tag), the last one shorter: only the ciphertext is gathered
-                if (e.stream_len < 75 + 16) return fail(c, PNA_E_INVAL, "datastream shorter than the stream header");
-                uint8_t hd[75]; stream_read(0, 75, hd);
-                e.gcm_seg = rd_be32(hd + 39);
-                if (e.gcm_seg == 0 || e.gcm_seg > (64u << 20)) return fail(c, PNA_E_INVAL, "GCM segment size out of range");
-                gcm_idx.push_back(i);
-                uint64_t rest = e.stream_len - 75, at2 = 75, outp = e.pk_off;
-                while (rest) {
-                    const uint64_t segl = std::min<uint64_t>(rest, (uint64_t)e.gcm_seg + 16);
-                    if (segl < 16) return fail(c, PNA_E_INVAL, "GCM segment shorter than a tag");
-                    stream_place(at2, at2 + segl - 16, outp);
-                    outp += segl - 16; at2 += segl; rest -= segl;
-                }
-                e.pay_len = outp - e.pk_off;
-            } else return fail(c, PNA_E_UNSUPPORTED, "unknown cipher mode");
-        } else { e.pay_len = e.stream_len; stream_place(0, e.stream_len, e.pk_off); }
+        { const int r = plan_stream(e.pieces, e.stream_len, e.encryption, e.cipher_mode, e.phsf, "FHED", e.fhed, e.pk_off, e.pay_len, e.gcm_seg); if (r) return r; }
         pk_total = (pk_total + e.pay_len + 15) & ~(uint64_t)15;
         if (e.compression != PNA_ALGO_STORE) {
             // fSIZ is optional (older writers omit it): the payload is then decoded like a solid stream, its size found by the decoder
@@ -2078,23 +2161,9 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
         }
     }
     for (XSolid &so : solids) {
-        uint64_t prefix = 0;
-        if (so.encryption != PNA_ENC_NONE) {
-            if (so.encryption != PNA_ENC_AES || so.cipher_mode != PNA_MODE_CTR) return fail(c, PNA_E_UNSUPPORTED, "only AES-CTR entries are decrypted by this driver");
-            if (!password) return fail(c, PNA_E_INVAL, "encrypted entry and no password");
-            if (so.phsf.empty()) return fail(c, PNA_E_INVAL, "`PHSF` chunk not found");
-            if (so.stream_len < 16) return fail(c, PNA_E_INVAL, "data stream shorter than the IV");
-            prefix = 16;
-        }
         if (so.compression != PNA_ALGO_STORE && so.compression != PNA_ALGO_ZSTD && so.compression != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "solid stream: compression method not decoded on the device (xz)");
-        so.pk_off = pk_total; so.pay_len = so.stream_len - prefix;
-        uint64_t skip = prefix, at = so.pk_off;
-        for (const XPiece &p : so.pieces) {
-            uint64_t o = p.off, l = p.len;
-            if (skip) { const uint64_t sk = std::min<uint64_t>(skip, l); o += sk; l -= sk; skip -= sk; }
-            for (uint64_t k = 0; k < l; k += (1u << 20)) places.push_back(PlaceDescH{o + k, at + k, (uint32_t)std::min<uint64_t>(1u << 20, l - k), 0});
-            at += l;
-        }
+        so.pk_off = pk_total;
+        { const int r = plan_stream(so.pieces, so.stream_len, so.encryption, so.cipher_mode, so.phsf, "SHED", so.shed, so.pk_off, so.pay_len, so.gcm_seg); if (r) return r; }
         pk_total = (pk_total + so.pay_len + 15) & ~(uint64_t)15;
     }
     // ---- 3. device: upload, data-chunk CRCs, gather, decrypt, decode
@@ -2134,62 +2203,78 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
     // as one after the other -- and the kernels would again run with the link idle.)
     if (prev && *prev && !prev->issued) { prev->issued = true; const int r = prev->issue(); if (r) return r; }
     if (flag[0]) { c->err = "data chunk CRC mismatch (" + std::to_string(flag[0]) + " FDAT / SDAT chunks)"; return PNA_E_INVAL; }
-    if (!enc_idx.empty()) {
-        // entries sharing a PHSF string and a mode share the key: one cipher call per group
-        std::vector<bool> done(enc_idx.size(), false);
-        for (size_t j = 0; j < enc_idx.size(); j++) {
+    if (!enc_list.empty()) {
+        // streams sharing a PHSF string and a mode share the key: one cipher call per group
+        std::vector<bool> done(enc_list.size(), false);
+        for (size_t j = 0; j < enc_list.size(); j++) {
             if (done[j]) continue;
-            const XEntry &e0 = ents[enc_idx[j]];
+            const XCipherStream &e0 = enc_list[j];
             const uint8_t *key = nullptr;
-            rc = key_for(e0.phsf, &key); if (rc) return rc;
+            rc = key_for(*e0.phsf, &key); if (rc) return rc;
             std::vector<uint64_t> off, len; std::vector<uint8_t> iv2; std::vector<size_t> who;
-            for (size_t k = j; k < enc_idx.size(); k++)
-                if (!done[k] && ents[enc_idx[k]].phsf == e0.phsf && ents[enc_idx[k]].cipher_mode == e0.cipher_mode) {
-                    done[k] = true; off.push_back(ents[enc_idx[k]].pk_off); len.push_back(ents[enc_idx[k]].pay_len); who.push_back(enc_idx[k]);
-                    iv2.insert(iv2.end(), ivs.begin() + 16 * k, ivs.begin() + 16 * k + 16);
+            for (size_t k = j; k < enc_list.size(); k++)
+                if (!done[k] && *enc_list[k].phsf == *e0.phsf && enc_list[k].mode == e0.mode) {
+                    done[k] = true; off.push_back(enc_list[k].pk_off); len.push_back(*enc_list[k].pay_len); who.push_back(k);
+                    iv2.insert(iv2.end(), enc_list[k].iv, enc_list[k].iv + 16);
                 }
-            if (e0.cipher_mode == PNA_MODE_CTR) {
+            if (e0.mode == PNA_MODE_CTR) {
                 pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv2.data();
                 rc = pna_gpu_cipher_apply_device(c, &ci, 1, off.size(), c->x_pk.p, off.data(), len.data(), st);
                 if (rc) return rc;
             } else {                                              // CBC: DecryptCbcAes256Reader, lib/src/entry/read.rs:77-82
                 rc = ensure_aes_dec(c); if (rc) return rc;
-                std::vector<CipherUnit> units(off.size());
-                for (size_t q = 0; q < off.size(); q++) { if (len[q] >= 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "cipher range too long"); units[q] = CipherUnit{off[q], 0, (uint32_t)len[q], (uint32_t)q}; }
-                if (c->ci_units.ensure(units.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure(iv2.size() + 16) || c->x_plen.ensure(units.size() * 4 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+                // (a block's plaintext needs its own and the previous ciphertext block only: a long stream -- a solid one -- is cut into units of 16 MiB whose
+                // IV is the ciphertext block in front; the padding is read at the end of the stream's last unit)
+                constexpr uint64_t CBC_UNIT = 16u << 20;
+                std::vector<CipherUnit> units; std::vector<uint8_t> uiv; std::vector<size_t> last_unit(off.size());
+                for (size_t q = 0; q < off.size(); q++) {
+                    if (len[q] == 0 || (len[q] & 15)) return fail(c, PNA_E_INVAL, "CBC: bad length or padding (wrong password or damaged data)");
+                    for (uint64_t o = 0; o < len[q]; o += CBC_UNIT) {
+                        units.push_back(CipherUnit{off[q] + o, 0, (uint32_t)std::min<uint64_t>(CBC_UNIT, len[q] - o), (uint32_t)units.size()});
+                        last_unit[q] = units.size() - 1;
+                    }
+                }
+                if (c->ci_units.ensure(units.size() * sizeof(CipherUnit) + 16) || c->ci_ivs.ensure(units.size() * 16 + 16) || c->x_plen.ensure(units.size() * 4 + 16)) return fail(c, PNA_E_NOMEM, "cipher workspace");
+                // the units' IVs: the stream's own for its first unit, else the 16 ciphertext bytes in front of the unit (copied on the device BEFORE the
+                // kernel overwrites them: the decryption is in place)
+                { size_t u = 0;
+                  for (size_t q = 0; q < off.size(); q++)
+                      for (uint64_t o = 0; o < len[q]; o += CBC_UNIT, u++) {
+                          if (o == 0) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->ci_ivs.p + 16 * u, iv2.data() + 16 * q, 16, hipMemcpyHostToDevice, st));
+                          else HIPCHK(c, hipMemcpyAsync((uint8_t *)c->ci_ivs.p + 16 * u, (const uint8_t *)c->x_pk.p + off[q] + o - 16, 16, hipMemcpyDeviceToDevice, st));
+                      } }
                 AesKey ek, dk; aes256_expand(key, ek); aes256_dec_key(ek, dk);
                 std::vector<uint32_t> plen(units.size());
                 HIPCHK(c, hipMemcpyAsync(c->ci_units.p, units.data(), units.size() * sizeof(CipherUnit), hipMemcpyHostToDevice, st));
-                HIPCHK(c, hipMemcpyAsync(c->ci_ivs.p, iv2.data(), iv2.size(), hipMemcpyHostToDevice, st));
                 launch_aes_cbc_dec((const CipherUnit *)c->ci_units.p, (uint32_t)units.size(), (const uint8_t *)c->ci_ivs.p, (const AesDecTabs *)c->aes_dtabs.p,
                                    (uint8_t *)c->x_pk.p, dk, (uint32_t *)c->x_plen.p, st);
                 HIPCHK(c, hipMemcpyAsync(plen.data(), c->x_plen.p, units.size() * 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipStreamSynchronize(st));
                 for (size_t q = 0; q < who.size(); q++) {
-                    if (plen[q] == 0xFFFFFFFFu) return fail(c, PNA_E_INVAL, "CBC: bad length or padding (wrong password or damaged data)");
-                    ents[who[q]].pay_len = plen[q];
+                    const uint32_t pl = plen[last_unit[q]];
+                    if (pl == 0xFFFFFFFFu) return fail(c, PNA_E_INVAL, "CBC: bad length or padding (wrong password or damaged data)");
+                    *enc_list[who[q]].pay_len = (len[q] - 1) / CBC_UNIT * CBC_UNIT + pl;
                 }
             }
         }
     }
-    if (!gcm_idx.empty()) {
+    if (!gcm_list.empty()) {
         // cipher mode 2 (decrypt_reader, (_, CipherMode::GCM): lib/src/entry/read.rs:105-140): key confirmation first -- a wrong password is
         // told apart from tampering --, then every segment's tag (k_gcm_tag in verify mode), then the CTR keystream with the stream keys
         rc = ensure_aes(c); if (rc) return rc;
         std::vector<GcmEntry> gents; std::vector<uint8_t> tags, giv; std::vector<AesKey> gkeys; std::vector<CipherUnit> units;
-        for (size_t gi : gcm_idx) {
-            XEntry &e = ents[gi];
+        for (const XCipherStream &e : gcm_list) {
             const uint8_t *km = nullptr;
-            rc = key_for(e.phsf, &km); if (rc) return rc;
-            uint8_t hd[75]; { uint64_t got = 0; for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < 75; k++) hd[got++] = a[p.off + k]; if (got >= 75) break; } }
+            rc = key_for(*e.phsf, &km); if (rc) return rc;
+            uint8_t hd[75]; { uint64_t got = 0; for (const XPiece &p : *e.pieces) { for (uint32_t k = 0; k < p.len && got < 75; k++) hd[got++] = a[p.off + k]; if (got >= 75) break; } }
             uint8_t kc[32]; hkdf_sha256_32(km, 32, nullptr, 0, "PNA-KC-v1", 9, kc);
             { uint8_t diff = 0; for (int b = 0; b < 32; b++) diff |= (uint8_t)(kc[b] ^ hd[43 + b]);      // constant time, like the reference's ct_eq
               if (diff) return fail(c, PNA_E_INVAL, "GCM STREAM: key confirmation failed (wrong password)"); }
             uint8_t info[88], ph[32], ks[32];
             memcpy(info, "PNA-STREAM-v1", 13);
-            sha256_bytes("FHED", 4, e.fhed.data(), e.fhed.size(), info + 13);
-            sha256_bytes(e.phsf.data(), e.phsf.size(), nullptr, 0, ph); memcpy(info + 45, ph, 32);
+            sha256_bytes(e.htype, 4, e.hdr->data(), e.hdr->size(), info + 13);      // (entry_context: the header chunk's type and body, FHED or SHED -- lib/src/cipher/aead.rs:167-190)
+            sha256_bytes(e.phsf->data(), e.phsf->size(), nullptr, 0, ph); memcpy(info + 45, ph, 32);
             memcpy(info + 77, hd + 32, 7); memcpy(info + 84, hd + 39, 4);
             hkdf_sha256_32(km, 32, hd, 32, info, 88, ks);
             AesKey rk; aes256_expand(ks, rk);
@@ -2208,7 +2293,7 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
                     ge.ej0[w] = ((uint32_t)eb[4 * w] << 24) | ((uint32_t)eb[4 * w + 1] << 16) | ((uint32_t)eb[4 * w + 2] << 8) | eb[4 * w + 3];
                 }
                 { uint64_t p2 = 0, got = 0; const uint64_t lo = at2 + ctl;      // the stored tag, wherever the chunk boundaries fall
-                  for (const XPiece &p : e.pieces) { for (uint32_t k = 0; k < p.len && got < 16; k++) if (p2 + k >= lo) tag[got++] = a[p.off + k]; p2 += p.len; if (got >= 16) break; } }
+                  for (const XPiece &p : *e.pieces) { for (uint32_t k = 0; k < p.len && got < 16; k++) if (p2 + k >= lo) tag[got++] = a[p.off + k]; p2 += p.len; if (got >= 16) break; } }
                 const uint32_t idx = (uint32_t)gents.size();
                 gents.push_back(ge); tags.insert(tags.end(), tag, tag + 16); gkeys.push_back(rk);
                 j0[15] = 2; giv.insert(giv.end(), j0, j0 + 16);
@@ -2255,21 +2340,13 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
         if (got) HIPCHK(c, hipMemcpy(nosize_data.back().data(), c->solid_plain.p, got, hipMemcpyDeviceToHost));
         e.raw_size = got; e.raw_off = nosize_data.size() - 1;      // index into nosize_data
     }
-    // ---- solid entries: decrypt (CTR), decode a stream of unknown size, walk the inner records
+    // ---- solid entries: decode a stream of unknown size, walk the inner records
     struct Inner { std::string name; int kind; std::vector<XPiece> pieces; uint64_t len; };
     std::vector<std::vector<Inner>> inner(solids.size());
     std::vector<std::vector<uint8_t>> plain(solids.size());
     for (size_t si = 0; si < solids.size(); si++) {
         XSolid &so = solids[si];
-        if (so.encryption != PNA_ENC_NONE) {
-            const uint8_t *key = nullptr;
-            rc = key_for(so.phsf, &key); if (rc) return rc;
-            uint8_t iv[16]; uint64_t got = 0;
-            for (const XPiece &p : so.pieces) for (uint32_t k = 0; k < p.len && got < 16; k++) iv[got++] = a[p.off + k];
-            pna_gpu_cipher ci{}; ci.encryption = PNA_ENC_AES; ci.cipher_mode = PNA_MODE_CTR; memcpy(ci.key, key, 32); ci.phsf = ""; ci.ivs = iv;
-            rc = pna_gpu_cipher_apply_device(c, &ci, 1, 1, c->x_pk.p, &so.pk_off, &so.pay_len, st);
-            if (rc) return rc;
-        }
+        // (an encrypted stream has been decrypted in place by the cipher stage above, with the normal entries' streams)
         uint64_t plen = so.pay_len; const void *d_plain = (const uint8_t *)c->x_pk.p + so.pk_off;
         if (so.compression != PNA_ALGO_STORE) {
             uint32_t nfr = 1;

@@ -1,6 +1,7 @@
 """The cipher stage on the device (k_cipher.hip) against the oracle's cipher layer (oracle/cipher_model.c), through the C ABI.
 Integer work: bit-exact."""
 import hashlib
+import zlib
 import os
 
 import pytest
@@ -251,6 +252,55 @@ def test_encrypted_solid_archive_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
         assert [n for n, _, _ in back] == names and [d for _, _, d in back] == ents
 
 
+@pytest.mark.parametrize("seg_arg,seg", [(0, 1 << 20), (65536, 65536), (1 << 18, 1 << 18)])
+def test_gcm_solid_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec, seg_arg, seg):
+    """pna create --solid --aes gcm in HBM: SHED | PHSF | SDAT(stream header) | SDAT(segment ciphertext || tag)* | SEND -- ONE GCM STREAM over the
+    compressed solid stream, its key bound to the SHED chunk (entry_context, lib/src/cipher/aead.rs:167-190).  Byte-exact against the plain solid
+    archive's SDAT bodies run through the oracle's GcmEncryptWriter; read back the reference's way and by the extract driver."""
+    import torch
+    algo = pna.ALGO_ZSTD
+    lens = [300000, 0, 5, (1 << 20) + 3, 70001, 2500000, 12, 3 << 20]
+    ents = [codec.corpus_file(i % 2, 500 + i, n) if n else b"" for i, n in enumerate(lens)]
+    ents[7] = codec.corpus_file(2, 9, lens[7])                 # incompressible: the compressed stream spans several 1 MiB GCM segments
+    names = [f"s/{i}.txt" for i in range(len(lens))]
+    offs, pos = [], 0
+    for e in ents:
+        offs.append(pos); pos = (pos + len(e) + 15) & ~15
+    src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+    for o, e in zip(offs, ents):
+        if e:
+            src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    k_master, phsf = pna.kdf_pbkdf2_sha256(b"password", bytes(range(16)), 1000)
+    sp = os.urandom(39)
+    ci = pna.Cipher(k_master, phsf, pna.MODE_GCM, ivs=sp, gcm_segment_size=seg_arg)
+    cap = pna.solid_archive_enc_bound(algo, names, lens, ci)
+    dst = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=algo, cipher=ci)
+    got = dst[:total].cpu().numpy().tobytes()
+    assert gpu_ctx.timing().ms_cipher > 0 and bytes(dst[total:total + 16].cpu().numpy()) == b"\xA5" * 16
+    dst2 = torch.full((cap,), 0xA5, dtype=torch.uint8, device="cuda")
+    total2 = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst2.data_ptr(), cap, algo=algo)
+    (plain_solid,) = pf.read_archive(dst2[:total2].cpu().numpy().tobytes())[1]
+    stream = b"".join(d for ty, d in plain_solid.chunks if ty == b"SDAT")
+    salt, prefix = sp[:32], sp[32:]
+    shed = pf.solid_header_bytes(algo, 1, 2)
+    ks = codec.derive_stream_key(k_master, salt, prefix, seg, b"SHED", shed, phsf.encode())
+    ct = codec.gcm_stream_encrypt(ks, prefix, seg, stream)
+    want = pf.write_archive_header() + pf.write_chunk(b"SHED", shed) + pf.write_chunk(b"PHSF", phsf.encode())
+    want += pf.write_chunk(b"SDAT", codec.stream_header_bytes(salt, prefix, seg, k_master))
+    for p in range(0, len(ct), seg + 16):
+        want += pf.write_chunk(b"SDAT", ct[p:p + seg + 16])
+    want += pf.write_chunk(b"SEND") + pf.finalize_archive()
+    assert len(stream) > 3 * seg and got == want
+    # the reference's read path, then the extract driver
+    (so,) = pf.read_archive(got)[1]
+    assert (so.encryption, so.cipher_mode) == (1, 2)
+    inner = pf.read_solid_inner(codec.decode_payload(algo, codec.decrypt_payload_gcm(k_master, so.data, b"SHED", shed, phsf.encode()), sum(lens) + 4096))
+    assert [e.name for e in inner] == names and [e.data for e in inner] == ents
+    back = pna.extract_archive(gpu_ctx, got, b"password")
+    assert [n for n, _, _ in back] == names and [d for _, _, d in back] == ents
+
+
 @pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
 def test_gcm_stream_archive_in_hbm_equals_oracle_writer(gpu_ctx, pna, pf, codec, algo_name):
     """Cipher mode 2 (GCM STREAM) in HBM: per-entry stream header + HKDF stream key on the host, CTR keystream and GHASH + tag on the
@@ -390,18 +440,42 @@ def test_extract_driver_round_trips_cbc_and_gcm(gpu_ctx, pna, pf, codec, mode_na
         assert ei.value.code == -2 and "authentication" in str(ei.value)
 
 
-def test_extract_driver_opens_the_reference_encrypted_solid_archive(gpu_ctx, pna, pf, codec):
-    """solid_zstd_aes_ctr.pna: SHED | PHSF (Argon2id) | SDAT* (IV first) | SEND, one zstd frame, inner entries stored."""
-    arc = open(os.path.join(os.path.dirname(__file__), "golden", "solid_zstd_aes_ctr.pna"), "rb").read()
+@pytest.mark.parametrize("fixture", ["solid_zstd_aes_ctr.pna", "solid_zstd_aes_cbc.pna", "solid_zstd_aes_gcm.pna"])
+def test_extract_driver_opens_the_reference_encrypted_solid_archives(gpu_ctx, pna, pf, codec, fixture):
+    """The reference's encrypted solid fixtures (lib/tests/extract_solid_compatibility.rs): SHED | PHSF (Argon2id) | SDAT* | SEND, one cipher
+    stream over the SDAT bodies -- CTR / CBC: IV first; GCM STREAM: header, segments with tags, the stream key bound to the SHED chunk
+    (entry_context, lib/src/cipher/aead.rs:167-190) --, one zstd frame, inner entries stored."""
+    arc = open(os.path.join(os.path.dirname(__file__), "golden", fixture), "rb").read()
     (so,) = pf.read_archive(arc)[1]
-    phsf = [d for ty, d in so.chunks if ty == b"PHSF"][0].decode()
-    km = codec.derive_key_from_phsf(phsf, b"password")
-    inner = pf.read_solid_inner(codec.decode_payload(so.compression, codec.decrypt_payload(so.encryption, so.cipher_mode, km, so.data), 16 << 20))
+    phsf = [d for ty, d in so.chunks if ty == b"PHSF"][0]
+    km = codec.derive_key_from_phsf(phsf.decode(), b"password")
+    comp = (codec.decrypt_payload_gcm(km, so.data, so.chunks[0][0], so.chunks[0][1], phsf) if so.cipher_mode == 2
+            else codec.decrypt_payload(so.encryption, so.cipher_mode, km, so.data))
+    inner = pf.read_solid_inner(codec.decode_payload(so.compression, comp, 16 << 20))
     got = pna.extract_archive(gpu_ctx, arc, b"password")
     assert [(n, d) for n, _, d in got] == [(e.name, e.data) for e in inner] and len(got) == 9
-    with pytest.raises(pna.PnaGpuError) as ei:                  # CBC over a solid stream stays with the reference's reader
-        pna.extract_archive(gpu_ctx, open(os.path.join(os.path.dirname(__file__), "golden", "solid_zstd_aes_cbc.pna"), "rb").read(), b"password")
-    assert ei.value.code == -7
+    with pytest.raises(pna.PnaGpuError) as ei:
+        pna.extract_archive(gpu_ctx, arc, b"passw0rd")
+    assert ei.value.code == -2
+    if so.cipher_mode == 2:                                       # a flipped ciphertext bit (chunk CRC repaired): the segment's tag says so
+        body = [d for ty, d in so.chunks if ty == b"SDAT"][-1]
+        at = arc.index(body)
+        bad = bytearray(arc); bad[at + len(body) // 2] ^= 1
+        bad[at + len(body):at + len(body) + 4] = (zlib.crc32(bytes(bad[at:at + len(body)]), zlib.crc32(b"SDAT")) & 0xFFFFFFFF).to_bytes(4, "big")
+        with pytest.raises(pna.PnaGpuError) as ei:
+            pna.extract_archive(gpu_ctx, bytes(bad), b"password")
+        assert ei.value.code == -2 and "authentication" in str(ei.value)
+
+
+def test_cbc_stream_in_units(gpu_ctx, pna, pf, codec):
+    """A CBC stream longer than the decryption's unit (16 MiB: a unit's IV is the ciphertext block in front of it) -- an entry of incompressible
+    bytes, written by this library, read back by the extract driver."""
+    import torch  # noqa: F401
+    data = [codec.corpus_file(2, 5, (40 << 20) + 12345), codec.corpus_file(2, 6, (16 << 20) - 7), codec.corpus_file(0, 7, 100000)]
+    names = ["big.bin", "unit.bin", "small.txt"]
+    arc = pna.create_archive_encrypted(gpu_ctx, names, data, b"password", mode=pna.MODE_CBC, rounds=1000)
+    got = pna.extract_archive(gpu_ctx, arc, b"password")
+    assert [n for n, _, _ in got] == names and [d for _, _, d in got] == data
 
 
 @pytest.mark.parametrize("mode_name", ["ctr", "cbc", "gcm"])
