@@ -336,7 +336,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, bool STRONG>
 __global__ __launch_bounds__(LZP_THREADS)
-void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
+void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
     constexpr uint32_t RW = 256, TG = 4096;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && (1u << BLK_LOG_MIN) % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
@@ -348,14 +348,17 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
     const uint32_t lane = threadIdx.x, w = lane & 15;
     const uint8_t *len8 = (const uint8_t *)l32;
-    const SegDesc sd = segs[blockIdx.x];
+    // one wave per block: block blk0 + blockIdx.x of the sub-batch, its segment from the block -> segment map (segs: all segments of the sub-batch)
+    const uint32_t gb = blk0 + blockIdx.x;
+    const SegDesc sd = segs[blk_seg[gb]];
     const uint32_t seg_len = sd.len;
     const uint8_t *seg = src + sd.src_off;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);
     const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     const uint32_t lazy = flags & F_LAZY;
     const uint32_t wbase = w * RW;
-    const uint32_t tile0 = sd.u0 / TG, ntile = (sd.u1 + TG - 1) / TG;      // the unit's tiles (a whole segment unless the batch runs in latency mode)
+    const uint32_t bs0 = (gb - sd.blk_base) << blk_log, bs1 = seg_len - bs0 < bsz ? seg_len : bs0 + bsz;    // (an empty segment's only block: no tiles)
+    const uint32_t tile0 = bs0 / TG, ntile = bs0 < seg_len ? (bs1 + TG - 1) / TG : tile0;
     const bool lv = lane < 16;
     if (lv) {                                               // selector of nibble n: the bytes whose bits are set, lowest first
         uint32_t sel = 0, j = 0;
@@ -687,28 +690,29 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 
 template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                           uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
+                           uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
     static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG, FARP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
     hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
-    hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(nseg), dim3(LZP_THREADS), 0, st, src, segs, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    if (pg->nb == 0) return;                                   // (a run of empty entries has segments and no blocks)
+    hipLaunchKernelGGL((k_lzp<CT, STRONG>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
 // match kernel + parse kernel over `nseg` segments; pbuf holds one word per position of the launch's blocks, blk0 = the first of them; ctab != nullptr:
 // a deflate launch (chunk table, look-back inside the LDS window); ev_match, if given, is recorded between the two kernels
 // gtab != nullptr (zstd, strong set): the match kernel's hash tables in global memory, nseg << GTAB_LOG words
 void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab) {
+                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-                else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
-    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab);
+    if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+                else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
+    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
     else if (flags & FLAG_W32) {
-           if (strong) launch_split_g<false, true, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-           else launch_split_g<false, false, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
-    else { if (strong) launch_split_g<false, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-           else if (max_off <= NEAR_OFF) launch_split_g<false, false, 0, 16, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr);
-           else launch_split_g<false, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr); }
+           if (strong) launch_split_g<false, true, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else launch_split_g<false, false, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
+    else { if (strong) launch_split_g<false, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else if (max_off <= NEAR_OFF) launch_split_g<false, false, 0, 16, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else launch_split_g<false, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {

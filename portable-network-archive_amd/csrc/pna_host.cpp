@@ -25,7 +25,7 @@
 
 namespace pna {
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
-               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab);
+               uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg);
 uint32_t lz_gtab_log();
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
@@ -124,7 +124,7 @@ struct PinBuf {                                  // page-locked host staging: as
 struct Tuning {
     long lz_split = 1;               // PNA_LZ_SPLIT: 0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse kernel
     long lz_split_blocks = 32768;    // PNA_LZ_SPLIT_BLOCKS: blocks per run of the split form (the words workspace holds one run)
-    long lz_split_min = 1025;        // PNA_LZ_SPLIT_MIN: shortest run (segments) that takes the split form
+    long lz_split_min = 0;           // PNA_LZ_SPLIT_MIN: shortest run (segments) that takes the split form (0: every run; shorter ones take the one-kernel form)
     long lz_pbuf_fail = 0;           // PNA_LZ_PBUF_FAIL: testing -- behave as if the words workspace could not be allocated
     long pipeline_chunks = 1;        // PNA_PIPELINE_CHUNKS: zstd entropy stage of chunk k next to the LZ stage of chunk k + 1 (measured: slower)
     long max_chunk_size = 0;         // PNA_MAX_CHUNK_SIZE: FlattenWriter::max_chunk_size of the archive entry points without such a parameter (0 = the reference's default, u32::MAX)
@@ -657,10 +657,10 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         }
     }
     const uint32_t s1_all = s1; bool fused_tail = false;
-    // A run of up to ~1 000 segments is faster through the fused kernel: the parse kernel walks a segment's tiles one after the other in ONE
-    // wave (3.4 ms per MiB of segment whatever the batch), which only pays once the match kernel's saving (1.1 ms per 256 segments) exceeds it
-    // (measured on the final kernels, N x 1 MiB, fused / split: 256: 2.4 / 4.7 ms, 1 024 = four full rounds of the CUs: 9.1 / 9.8, 1 152: 11.3 / 11.0,
-    // 2 048: 18.1 / 15.4, 3 072: 27.1 / 21.1): the split form from 1 025 segments on.
+    // The split form at every size: its parse kernel runs one wave per BLOCK (a block's parse depends on nothing outside the block), so a short run no
+    // longer waits for one wave's walk over a whole segment (N x 1 MiB, one-kernel / split: 32: 2.3 / 1.6 ms, 256: 2.4 / 1.8, 1 024: 9.3 / 6.3,
+    // 2 048: 18.6 / 12.3; scripts/lz_forms.py).  The one-kernel form remains for PNA_F_LZ_FUSED, for a workspace that cannot be allocated and for the
+    // units of the latency mode; lz_split_min restores a threshold.
     const uint32_t min_segs = gt ? 0u : (uint32_t)c->tun.lz_split_min;
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
@@ -680,12 +680,13 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
             while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
         }
+        const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};            // the parse kernel: one wave per block of the run
         launch_lz(d_src, c->d_segs + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
-                  (uint32_t *)c->pbuf.p, b0, e1, gt ? (uint32_t *)c->gtab.p : nullptr);
+                  (uint32_t *)c->pbuf.p, b0, e1, gt ? (uint32_t *)c->gtab.p : nullptr, &pg);
         a = b;
         if (a >= s1) return PNA_OK;
     }
-    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr);
+    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr, nullptr);
     if (fused_tail) return lz_stage(c, d_src, segs, nseg_all, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
@@ -827,7 +828,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         const uint32_t dfl = c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u);
-        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr);
+        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
         else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
@@ -854,9 +855,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
                 const bool gt = c->call_gtab;
+                const LzParseGrid pgu{c->d_segs, c->d_blk_seg, nblk};
                 if (gt && (c->pbuf.ensure(((size_t)nblk << blk_log) * 4) || c->gtab.ensure((size_t)nunits << (lz_gtab_log() + 2)))) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");
                 launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, zfl,
-                          (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr);
+                          (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr, gt ? &pgu : nullptr);
             }
             else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)

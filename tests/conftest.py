@@ -16,13 +16,12 @@ def pytest_configure(config):
 
 @pytest.fixture(autouse=True)
 def _split_lz_stage_for_small_batches(monkeypatch):
-    """The LZ stage sends runs of up to 1 024 segments through its one-kernel form (faster for them), so with the library's default
-    the small batches of this suite would never reach the split form's kernels (k_lzm, k_lzp) that the headline workload runs on.  The
-    suite therefore lowers the threshold to zero; the one-kernel form has tests of its own (test_lz_stage_forms_are_identical) and the
-    full-size tests (tests/test_gpu_full_size.py) put the default back."""
+    """The suite pins the split form of the LZ stage (k_lzm + k_lzp: the library's default for every run since the parse kernel runs one wave per
+    block; the option only matters if a threshold is configured); the one-kernel form has tests of its own (test_lz_stage_forms_are_identical,
+    the latency mode's units)."""
     if "PNA_LZ_SPLIT_MIN" not in os.environ:
         monkeypatch.setenv("PNA_LZ_SPLIT_MIN", "0")
-    # For the same reason the suite switches the LATENCY MODE off (small batches cut into small blocks and LZ units: other kernels' paths, other
+    # The suite switches the LATENCY MODE off (small batches cut into small blocks and LZ units: other kernels' paths, other
     # model parameters): the headline path is what most tests pin; tests/test_gpu_latency.py covers the mode itself and the library's default.
     if "PNA_LATENCY_MAX_MIB" not in os.environ:
         monkeypatch.setenv("PNA_LATENCY_MAX_MIB", "0")

@@ -101,13 +101,13 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     data = [cases[k] for k in names]
     bit = {"default": 0, "fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE, "split": 0}[form]      # ("split": k_lzm + k_lzp, the suite's setting)
     if form == "default":
-        monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: short runs through the one-kernel form (the suite's default is 0)
+        monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: the split form at every size
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
         for level in (1, 2, 3, 7, 19):              # the five zstd level sets: fast, balanced, default, high, max (codec.product_level_flags)
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
             # (levels 10 .. 22 always take the split form: only the match kernel k_lzm has the global-memory hash table of the strong set)
-            assert (ctx.timing().lz_match_launches == 0) == (form in ("default", "fused") and level < 10), (form, level)
+            assert (ctx.timing().lz_match_launches == 0) == (form == "fused" and level < 10), (form, level)
             pz = codec.params_for_level(level)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
