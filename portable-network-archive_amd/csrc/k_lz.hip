@@ -233,8 +233,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
                     const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ w2;
                     const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ w3;
-                    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
-                    l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+                    l = first_diff16(x0, x1, x2, x3);
 #pragma unroll
                     for (uint32_t k16 = 16; k16 < CAP1; k16 += 16) {
                         if (l == k16) {
@@ -253,8 +252,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                             }
                             const uint32_t y0 = __builtin_amdgcn_alignbit(g1, g0, shq) ^ v0, y1 = __builtin_amdgcn_alignbit(g2, g1, shq) ^ v1;
                             const uint32_t y2 = __builtin_amdgcn_alignbit(g3, g2, shq) ^ v2, y3 = __builtin_amdgcn_alignbit(g4, g3, shq) ^ v3;
-                            const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-                            l = k16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+                            l = k16 + first_diff16(y0, y1, y2, y3);
                         }
                     }
                     if (edge) { const uint32_t lim = blk_end - q[r]; l = l < lim ? l : lim; }

@@ -75,12 +75,10 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
     for (int k = 0; k < 10; k++) E[k] = pq[k];
 #define EW(k) __builtin_amdgcn_alignbit(E[(k) + 1], E[k], shq)                     /* bytes q - 4 + 4 k .. + 3 */
     const uint32_t x0 = EW(1) ^ fa.y, x1 = EW(2) ^ fa.z, x2 = EW(3) ^ fa.w, x3 = EW(4) ^ fb;
-    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
-    uint32_t l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+    uint32_t l = first_diff16(x0, x1, x2, x3);
     if (l == 16) {
         const uint32_t y0 = EW(5) ^ fd.x, y1 = EW(6) ^ fd.y, y2 = EW(7) ^ fd.z, y3 = EW(8) ^ fd.w;
-        const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-        l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+        l = 16 + first_diff16(y0, y1, y2, y3);
     }
     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
     if (l < MIN_MATCH) l = 0;
@@ -161,7 +159,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 hsh[j] = lz_slot<GLOG, HASH_ENTRIES>(h32);
                 tag[j] = (h32 >> 6) & TAG_MASK;
                 if (GLOG) ent[j] = hv[j] ? __hip_atomic_load(&table[hsh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                else ent[j] = hv[j] ? table[hsh[j]] : 0u;
+                else { const uint32_t e = table[hsh[j]]; ent[j] = hv[j] ? e : 0u; }     // (the LDS read goes out for every lane -- any slot is readable --, a select instead of an exec-masked region)
             }
             // ---- candidates (rules as in k_lz)
             uint32_t off[4];
@@ -169,7 +167,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
-                off[j] = (c1 > 8 && (ent[j] & TAG_MASK) == tag[j] && o <= max_off) ? o : 0u;
+                off[j] = ((c1 > 8) & ((ent[j] & TAG_MASK) == tag[j]) & (o <= max_off)) ? o : 0u;      // (& not &&: no short-circuit branches)
                 farj[j] = FAR && off[j] > NEAR;
             }
             // ---- the far candidates (more than NEAR bytes back: outside the window) are handled COMPACTED.  A vector load costs the CU's address unit 16
@@ -220,8 +218,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                         if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
                     }
                     const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
-                    const uint64_t xa = (uint64_t)x0 | ((uint64_t)x1 << 32), xb = (uint64_t)x2 | ((uint64_t)x3 << 32);
-                    l = xa ? ctz64(xa) >> 3 : (xb ? 8 + (ctz64(xb) >> 3) : 16);
+                    l = first_diff16(x0, x1, x2, x3);
                     if (l == 16) {
                         uint32_t v0, v1, v2, v3;
                         {
@@ -231,8 +228,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                             v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
                         }
                         const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
-                        const uint64_t ya = (uint64_t)y0 | ((uint64_t)y1 << 32), yb = (uint64_t)y2 | ((uint64_t)y3 << 32);
-                        l = 16 + (ya ? ctz64(ya) >> 3 : (yb ? 8 + (ctz64(yb) >> 3) : 16));
+                        l = 16 + first_diff16(y0, y1, y2, y3);
                     }
                     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
                     if (l < MIN_MATCH) l = 0;
@@ -311,8 +307,13 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #undef QW
             loaded_end += TILE_G;
             __syncthreads();                                                        // every wave has looked up
+            if (tile_full) {                                                        // (uniform: all but a block's last tile -- every position valid, no exec masks)
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+                for (int j = 0; j < 4; j++) if (ins_all || !(j & 1)) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+            }
             if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the atomics have reached L2)
             __syncthreads();                                                        // inserts + window chunk in place
         }

@@ -40,6 +40,17 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) { return (uin
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 __device__ __forceinline__ uint32_t clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
+// Index of the first nonzero byte among the 16 of four XOR words (16: none), branch-free: v_ffbl_b32 yields 0xFFFFFFFF for a zero word, the saturating
+// adds keep it there, two min3 / min pick the lowest bit index.  (Written as `xa ? ctz64(xa) >> 3 : (xb ? ... : 16)` the compiler built two nested
+// exec-masked branches per compare: ~22 vector + 10 scalar instructions instead of 11.)
+__device__ __forceinline__ uint32_t ffbl_hw(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t first_diff16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const uint32_t f0 = ffbl_hw(x0), f1 = __builtin_elementwise_add_sat(ffbl_hw(x1), 32u), f2 = __builtin_elementwise_add_sat(ffbl_hw(x2), 64u),
+                   f3 = __builtin_elementwise_add_sat(ffbl_hw(x3), 96u);
+    uint32_t m = f0 < f1 ? f0 : f1; const uint32_t n = f2 < f3 ? f2 : f3; m = m < n ? m : n;
+    m >>= 3;
+    return m < 16u ? m : 16u;
+}
 __device__ __forceinline__ uint64_t mlow(uint32_t n) { return n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1); }   // bits [0, n)
 
 // DPP helpers (VALU only): value of lane i-k inside each row of 16 lanes (0 outside), and of lane i+1 of the wave
