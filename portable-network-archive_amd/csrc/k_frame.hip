@@ -131,6 +131,82 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     }
 }
 
+// ------------------------------------------------------------------ k_frame_wave : the same for SMALL payloads, one WAVE per entry
+// With 10^5 .. 10^6 entries of a few KiB the workgroup form above spends its time on what does not depend on the payload: 8 KiB of tables per
+// workgroup, a 16 KiB tile of which 7/8 are padding, eight fold steps with a barrier and a 32-step multiply each.  Here a workgroup's four waves
+// take an entry each (the slice-by-4 table is loaded once per workgroup).  The message "type || payload" (n bytes) is anchored at its END: lane t
+// owns the 64 m bytes that end 64 m (63 - t) bytes before the message's end (m = ceil(n / 4096) pieces of 64 bytes per lane; positions in front of
+// the message are zero bytes, which are free -- identity (2) above), reads them straight from memory (16-byte loads at any byte address), and its
+// state is folded in by ONE multiplication with x^(8 * 64 m (63 - t)) from a table (m <= 4: payloads up to 16 380 bytes; beyond that the power
+// is computed on the spot -- correct, slow, and not what the host sends here) and an XOR across the wave.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u ld16u(const uint8_t *p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }   // 16 bytes at any byte address
+__device__ __forceinline__ uint32_t gf2_xpow_dev(uint64_t e) {
+    uint32_t r = 0x80000000u, base = 0x40000000u;
+    while (e) { if (e & 1) r = gf2_mulmod(base, r); base = gf2_mulmod(base, base); e >>= 1; }
+    return r;
+}
+__global__ __launch_bounds__(256)
+void k_frame_wave(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct, uint8_t *__restrict__ dst,
+                  uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t nent) {
+    __shared__ uint32_t sT[4][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t i = tid; i < 1024; i += 256) (&sT[0][0])[i] = (&ct->T[0][0])[i];
+    __syncthreads();
+    const uint32_t ent = blockIdx.x * 4 + (tid >> 6);
+    if (ent >= nent) return;
+    const FrameDesc d = fd[ent];
+    for (uint32_t i = lane; i < d.prefix_len; i += 64) dst[d.arc_off + i] = blob[d.prefix_off + i];
+    if (d.pad & 1) return;                                           // record without a data chunk: the prefix is all of it
+    const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
+    const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload
+    const uint32_t m = (n + 4095) >> 12;                             // pieces of 64 bytes per lane (uniform)
+    const int64_t s0 = (int64_t)n - (int64_t)64 * m * (64 - lane);   // message position of the lane's first byte (negative: in front of the message)
+    const uint8_t *msg = dst + pay - 4;                              // address of message position 0 (the type bytes come from ty_x, not from memory)
+    uint32_t state = 0;
+    for (uint32_t i = 0; i < m; i++) {
+        const int64_t P0 = s0 + (int64_t)64 * i;
+        if (P0 + 64 <= 0) continue;                                  // all zero, and the state still is
+        uint32_t w[16];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            v4u v = 0;
+            if (P0 + 16 * g + 16 > 0) v = ld16u(msg + P0 + 16 * g);     // (a group that straddles position 0 reads up to 15 bytes in front of the type bytes: inside the entry's prefix / the chunk before)
+            w[4 * g] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+        }
+        if (P0 < 4) {                                                // the dwords that hold positions below 4: zero in front of the message, the type bytes (already XORed with the CRC's initial value) at 0 .. 3
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int32_t P = (int32_t)P0 + 4 * j;               // (P0 > -64 here)
+                if (P >= 4) continue;
+                const uint32_t k = P > 0 ? (uint32_t)P : 0u;          // payload bytes in the dword: its top k
+                const uint32_t keep = k ? 0xFFFFFFFFu << (8 * (4 - k)) : 0u;
+                const uint32_t tyw = P >= 0 ? ty_x >> (8 * P) : (P > -4 ? ty_x << (8 * -P) : 0u);
+                w[j] = (w[j] & keep) | tyw;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t c = state ^ w[j];
+            state = sT[3][c & 0xFF] ^ sT[2][(c >> 8) & 0xFF] ^ sT[1][(c >> 16) & 0xFF] ^ sT[0][c >> 24];
+        }
+    }
+    uint32_t x = 0;
+    if (state) x = gf2_mulmod(m <= 4 ? ct->pw[m - 1][63 - lane] : gf2_xpow_dev((uint64_t)8 * 64 * m * (63 - lane)), state);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x ^= (uint32_t)__shfl_xor((int)x, o);
+    if (lane < ((with_fend && !(d.pad & 2)) ? 16u : 4u)) {             // pad bit 1: another data chunk of the same entry follows, no FEND yet
+        const uint32_t crc = ~x;
+        const uint32_t fe = 0x444E4546u;                              // "FEND" little-endian
+        uint8_t v;
+        if (lane < 4) v = (uint8_t)(crc >> (24 - 8 * lane));
+        else if (lane < 8) v = 0;
+        else if (lane < 12) v = (uint8_t)(fe >> (8 * (lane - 8)));
+        else v = (uint8_t)(fend_crc >> (24 - 8 * (lane - 12)));
+        dst[pay + d.payload_len + lane] = v;
+    }
+}
+
 // ------------------------------------------------------------------ k_place : byte ranges to arbitrary offsets
 // One workgroup per piece (<= 1 MiB) of an entry: dst[dst_off .. +len) = src[src_off .. +len).  src_off is 16-byte aligned,
 // dst_off is not: whole destination dwords are assembled from two aligned source dwords, the <= 3 bytes at either end are
@@ -161,9 +237,14 @@ void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, 
 }
 
 // ty: chunk type as it stands in the file (e.g. "FDAT"); with_fend: append an FEND chunk behind the data chunk's CRC
+// max_payload: an upper bound of the launch's payload lengths if the host knows one that is small (0: none) -- up to 16 380 bytes the wave-per-entry form runs
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
-                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st) {
+                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st, uint32_t max_payload) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
+    if (nentry && max_payload && max_payload <= 16380u) {
+        hipLaunchKernelGGL(k_frame_wave, dim3((nentry + 3) / 4), dim3(256), 0, st, fd, blob, ct, dst, fend_crc, ~ty_le, with_fend ? 1u : 0u, nentry);
+        return;
+    }
     const uint32_t epw = 1u;                                    // (4 entries per workgroup measured SLOWER for 10^6 small entries: 9.1 vs 8.0 ms -- more workgroups in flight hide the per-entry chain better)
     if (nentry) hipLaunchKernelGGL(k_frame, dim3((nentry + epw - 1) / epw), dim3(FR_THREADS), 0, st, fd, blob, ct, dst, cap16, fend_crc, ~ty_le, with_fend ? 1u : 0u, (uint32_t *)nullptr, nentry, epw);
 }

@@ -124,6 +124,7 @@ struct CrcTabs {
     uint32_t T[4][256];      // slice-by-4 tables of the reflected CRC-32
     uint32_t Z[4][256];      // "append 16320 zero bytes" as four byte-indexed tables
     uint32_t sh[8];          // x^(8 * 64 * 2^j) mod P, j = 0..7
+    uint32_t pw[4][64];      // k_frame_wave: x^(8 * 64 m * k) mod P for m = 1..4 pieces per lane, k = 0..63 lanes behind
 };
 
 // cipher stage (k_cipher.hip)

@@ -43,7 +43,7 @@ void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const 
                   const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st);
 void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
-                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st);
+                  uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st, uint32_t max_payload);
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st);
@@ -404,6 +404,7 @@ static void build_crc_tabs(CrcTabs &t) {
     const uint32_t z = gf2_xpow(8ull * 16320);
     for (int j = 0; j < 4; j++) for (uint32_t b = 0; b < 256; b++) t.Z[j][b] = gf2_mulmod(z, b << (8 * j));
     for (int j = 0; j < 8; j++) t.sh[j] = gf2_xpow(8ull * 64 << j);
+    for (int m = 1; m <= 4; m++) for (uint32_t k = 0; k < 64; k++) t.pw[m - 1][k] = gf2_xpow(8ull * 64 * m * k);
 }
 static int ensure_crc(pna_gpu_ctx *c) {
     if (c->crc_ready) return PNA_OK;
@@ -735,8 +736,10 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     // inside the same frames (blk_log), and the LZ stage runs one workgroup per UNIT of 1 << unit_log bytes whose table is pre-warmed with
     // everything before it (lz_prewarm), which gives the very matches of the segment-long walk.  Both follow from the batch's size alone
     // (and pna_gpu_set_option), are reported by pna_gpu_last_timing, and are parameters of the oracle's model.
-    uint64_t in_total = 0, nseg_est = 0;
-    for (size_t e = e0; e < e1; e++) { in_total += src_len[e]; nseg_est += src_len[e] ? (src_len[e] + SEG_SIZE - 1) / SEG_SIZE : 1; }
+    uint64_t in_total = 0, nseg_est = 0, max_len = 0;
+    for (size_t e = e0; e < e1; e++) { in_total += src_len[e]; nseg_est += src_len[e] ? (src_len[e] + SEG_SIZE - 1) / SEG_SIZE : 1; max_len = std::max<uint64_t>(max_len, src_len[e]); }
+    // an upper bound of every payload of the sub-batch when the entries are small and plain (k_frame's wave-per-entry form takes those; 0: no such bound)
+    const uint32_t frame_max_payload = (fj && !fj->solid && !fj->cipher && max_len <= 16384) ? (uint32_t)std::min<size_t>(pna_gpu_bound(algo, (size_t)max_len), 0xFFFFFFFFu) : 0u;
     const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
     uint32_t blk_log = small_entry_blk_log(c, src_len, e0, e1), unit_log = 20;
     if (latency && blk_log == PNA_BLK_LOG) {
@@ -987,7 +990,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                           (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
         launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)ne, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
-                     d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st);
+                     d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st, frame_max_payload);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
         // the entry offsets (when the caller wants them) and the sub-batch's length travel back behind the kernels: the call's one wait
         uint64_t *h_ent = (uint64_t *)c->h_entoff.p;
@@ -1215,7 +1218,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     }
     if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
     if (fj) launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)nunit, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
-                         d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), solid ? "SDAT" : "FDAT", !solid, st);
+                         d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), solid ? "SDAT" : "FDAT", !solid, st, frame_max_payload);
     if (timed) HIPCHK(c, hipEventRecord(c->ev[7], st));
     HIPCHK(c, hipGetLastError());
     if (early_write) {
@@ -1485,7 +1488,9 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     // ---- 1. layout of the serialised inner entries (all sizes are known up front)
     std::vector<FrameDesc> fds(n); std::vector<uint8_t> blob; std::vector<PlaceDescH> places;
-    uint64_t pos = 0;
+    uint64_t pos = 0, max_inner = 0;
+    for (size_t i = 0; i < n; i++) max_inner = std::max<uint64_t>(max_inner, src_len[i]);
+    const uint32_t solid_max_inner = max_inner <= 16380 ? (uint32_t)std::max<uint64_t>(max_inner, 1) : 0u;      // (stored inner entries: the FDAT payload is the entry; small ones take k_frame's wave-per-entry form)
     for (size_t i = 0; i < n; i++) {
         if (src_off[i] & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
         if (src_len[i] >= 0x7FFF0000ull) return fail(c, PNA_E_INVAL, "inner entry too large for one FDAT chunk");
@@ -1513,7 +1518,7 @@ extern "C" int pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *c, int algo,
         if (!places.empty()) HIPCHK(c, hipMemcpyAsync(c->solid_place.p, places.data(), places.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
         launch_place(c->solid_place.p, (uint32_t)places.size(), (const uint8_t *)d_src, (uint8_t *)c->solid_plain.p, st);
         launch_frame((const FrameDesc *)c->solid_desc.p, (uint32_t)n, (const uint8_t *)c->solid_blob.p, (const CrcTabs *)c->crc_tabs.p,
-                     (uint8_t *)c->solid_plain.p, (uint64_t)c->solid_plain.cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st);
+                     (uint8_t *)c->solid_plain.p, (uint64_t)c->solid_plain.cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st, solid_max_inner);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(st));                     // the host vectors above are read by the async copies
     }

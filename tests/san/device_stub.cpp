@@ -42,7 +42,7 @@ void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const 
         }
     }
 }
-void launch_frame(const FrameDesc *fd, uint32_t n, const uint8_t *blob, const CrcTabs *, uint8_t *dst, uint64_t, uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t) {
+void launch_frame(const FrameDesc *fd, uint32_t n, const uint8_t *blob, const CrcTabs *, uint8_t *dst, uint64_t, uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t, uint32_t) {
     for (uint32_t i = 0; i < n; i++) {
         const FrameDesc &d = fd[i];
         memcpy(dst + d.arc_off, blob + d.prefix_off, d.prefix_len);
