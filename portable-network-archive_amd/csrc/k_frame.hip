@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t gf2_xpow_dev(uint64_t e) {
 }
 __global__ __launch_bounds__(256)
 void k_frame_wave(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob, const CrcTabs *__restrict__ ct, uint8_t *__restrict__ dst,
-                  uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t nent) {
+                  uint32_t fend_crc, uint32_t ty_x, uint32_t with_fend, uint32_t nent, uint32_t *__restrict__ verify) {
     __shared__ uint32_t sT[4][256];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     for (uint32_t i = tid; i < 1024; i += 256) (&sT[0][0])[i] = (&ct->T[0][0])[i];
@@ -156,7 +156,8 @@ void k_frame_wave(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ 
     const uint32_t ent = blockIdx.x * 4 + (tid >> 6);
     if (ent >= nent) return;
     const FrameDesc d = fd[ent];
-    for (uint32_t i = lane; i < d.prefix_len; i += 64) dst[d.arc_off + i] = blob[d.prefix_off + i];
+    // verify != NULL: read side (read_chunk, lib/src/io.rs:117-149) -- nothing is written, the CRC is compared with the stored one
+    if (!verify) for (uint32_t i = lane; i < d.prefix_len; i += 64) dst[d.arc_off + i] = blob[d.prefix_off + i];
     if (d.pad & 1) return;                                           // record without a data chunk: the prefix is all of it
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
     const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload
@@ -195,6 +196,14 @@ void k_frame_wave(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ 
     if (state) x = gf2_mulmod(m <= 4 ? ct->pw[m - 1][63 - lane] : gf2_xpow_dev((uint64_t)8 * 64 * m * (63 - lane)), state);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x ^= (uint32_t)__shfl_xor((int)x, o);
+    if (verify) {
+        if (lane == 0) {
+            const uint8_t *q = dst + pay + d.payload_len;
+            const uint32_t stored = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+            if (stored != ~x) { atomicAdd(&verify[0], 1u); atomicMin(&verify[1], ent); }
+        }
+        return;
+    }
     if (lane < ((with_fend && !(d.pad & 2)) ? 16u : 4u)) {             // pad bit 1: another data chunk of the same entry follows, no FEND yet
         const uint32_t crc = ~x;
         const uint32_t fe = 0x444E4546u;                              // "FEND" little-endian
@@ -242,7 +251,7 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st, uint32_t max_payload) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
     if (nentry && max_payload && max_payload <= 16380u) {
-        hipLaunchKernelGGL(k_frame_wave, dim3((nentry + 3) / 4), dim3(256), 0, st, fd, blob, ct, dst, fend_crc, ~ty_le, with_fend ? 1u : 0u, nentry);
+        hipLaunchKernelGGL(k_frame_wave, dim3((nentry + 3) / 4), dim3(256), 0, st, fd, blob, ct, dst, fend_crc, ~ty_le, with_fend ? 1u : 0u, nentry, (uint32_t *)nullptr);
         return;
     }
     const uint32_t epw = 1u;                                    // (4 entries per workgroup measured SLOWER for 10^6 small entries: 9.1 vs 8.0 ms -- more workgroups in flight hide the per-entry chain better)
@@ -250,8 +259,12 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
 }
 // Read side: CRC-32 of n data chunks of type `ty` where they stand in buf (FrameDesc: arc_off = chunk start, prefix_len = 8,
 // payload_len = chunk length); verify[0] counts mismatches, verify[1] keeps the lowest failing descriptor index.
-void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st) {
+void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st, uint32_t max_payload) {
     const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
+    if (n && max_payload && max_payload <= 16380u) {               // many small chunks: a wave per chunk
+        hipLaunchKernelGGL(k_frame_wave, dim3((n + 3) / 4), dim3(256), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), 0u, ~ty_le, 0u, n, verify);
+        return;
+    }
     const uint32_t epw = 1u;
     if (n) hipLaunchKernelGGL(k_frame, dim3((n + epw - 1) / epw), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, verify, n, epw);
 }

@@ -49,7 +49,7 @@ void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst,
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st);
 void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
-void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st);
+void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st, uint32_t max_payload);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
 void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st);
@@ -1898,6 +1898,11 @@ struct XEntry {
     uint64_t lo = 0, hi = 0;                                   // archive bytes [lo, hi) that hold its data chunks
 };
 typedef std::vector<std::pair<std::string, std::vector<uint8_t>>> XKeys;
+static uint32_t max_chunk_len(const std::vector<FrameDesc> &v) {       // the longest data chunk of a list (0: none below 16 380 bytes, the wave-per-chunk CRC kernel's limit)
+    uint32_t m = 1;
+    for (const FrameDesc &d : v) { if (d.payload_len > 16380u) return 0u; m = std::max(m, d.payload_len); }
+    return m;
+}
 struct XSolid {                                                // SHED [PHSF] SDAT* SEND -- lib/src/entry.rs:465-484,567-583
     int compression = 0, encryption = 0, cipher_mode = 0; std::string phsf;
     std::vector<XPiece> pieces; uint64_t stream_len = 0;
@@ -2188,13 +2193,13 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
     if (!dchunks.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->x_desc.p, dchunks.data(), dchunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         launch_frame_verify((const FrameDesc *)c->x_desc.p, (uint32_t)dchunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)c->x_arc.p,
-                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st);
+                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st, max_chunk_len(dchunks));
     }
     if (!schunks.empty()) {
         if (c->solid_desc.ensure(schunks.size() * sizeof(FrameDesc) + 16)) return fail(c, PNA_E_NOMEM, "extract workspace");
         HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, schunks.data(), schunks.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
         launch_frame_verify((const FrameDesc *)c->solid_desc.p, (uint32_t)schunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)c->x_arc.p,
-                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "SDAT", (uint32_t *)c->x_flag.p, st);
+                            (uint64_t)c->x_arc.cap & ~(uint64_t)15, "SDAT", (uint32_t *)c->x_flag.p, st, max_chunk_len(schunks));
     }
     if (!places.empty()) {
         HIPCHK(c, hipMemcpyAsync(c->x_place.p, places.data(), places.size() * sizeof(PlaceDescH), hipMemcpyHostToDevice, st));
@@ -2401,7 +2406,7 @@ static int extract_window(pna_gpu_ctx *c, const uint8_t *a, size_t archive_len, 
                 HIPCHK(c, hipMemcpyAsync(c->solid_desc.p, adj.data(), adj.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
             }
             launch_frame_verify((const FrameDesc *)c->solid_desc.p, (uint32_t)ichunks.size(), (const CrcTabs *)c->crc_tabs.p, (const uint8_t *)pb.p,
-                                (uint64_t)pb.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st);
+                                (uint64_t)pb.cap & ~(uint64_t)15, "FDAT", (uint32_t *)c->x_flag.p, st, max_chunk_len(ichunks));
             HIPCHK(c, hipMemcpyAsync(flag, c->x_flag.p, 8, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipStreamSynchronize(st));
