@@ -133,30 +133,45 @@ constexpr int HUF_MAX = 11;
 __device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent, uint32_t *sh, uint32_t lane) {
     if (lane == 0) { sh[0] = 0; sh[1] = 0; sh[2] = 0; }
     __builtin_amdgcn_wave_barrier();
-    uint32_t mine = 0;
+    // the symbols that occur (text: ~100 of the 256): the rank sort only walks these.  (`parent` is free until the merge: it holds the list.)
+    uint16_t *used = parent;
     for (int s = (int)lane; s < 256; s += 64) {
         lens[s] = 0;
-        const uint32_t c = count[s];
-        if (!c) continue;
-        uint32_t rank = 0;
-        for (int o = 0; o < 256; o++) { const uint32_t co = count[o]; rank += (co != 0 && (co < c || (co == c && o < s))) ? 1u : 0u; }   // sort by (count asc, symbol asc)
-        order[rank] = (uint16_t)s;
-        mine++;
+        if (count[s]) used[atomicAdd(&sh[0], 1u)] = (uint16_t)s;
     }
-    if (mine) atomicAdd(&sh[0], mine);
     __builtin_amdgcn_wave_barrier();
     const int n = (int)sh[0];
     if (n < 2) return n;
+    for (int k = (int)lane; k < n; k += 64) {
+        const int s = used[k];
+        const uint32_t c = count[s];
+        uint32_t rank = 0;
+        for (int j = 0; j < n; j++) { const int o = used[j]; const uint32_t co = count[o]; rank += (co < c || (co == c && o < s)) ? 1u : 0u; }   // sort by (count asc, symbol asc)
+        order[rank] = (uint16_t)s;
+    }
+    __builtin_amdgcn_wave_barrier();
     for (int i = (int)lane; i < n; i += 64) wt[i] = count[order[i]];
     __builtin_amdgcn_wave_barrier();
     const int nn = 2 * n - 1;
     if (lane == 0) {
+        // two-queue Huffman, leaves win ties; n - 1 dependent steps on one lane.  The two heads of each queue are kept in registers (the leaf queue is
+        // read one element ahead, a new internal node enters the head registers directly when the queue is that short), so no step waits for an LDS
+        // round trip (k_deflate.hip's d_build_lens has the same form); weights are < 2^31, INF marks an exhausted / not yet filled head.  Same picks,
+        // same order as `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
+        constexpr uint32_t INF = 0xFFFFFFFFu;
         int lq = 0, iq = n, m = n;
-        while (m < nn) {                               // two-queue Huffman, leaves win ties
-            int a, b;
-            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) a = lq++; else a = iq++;
-            if (lq < n && (iq >= m || wt[lq] <= wt[iq])) b = lq++; else b = iq++;
-            wt[m] = wt[a] + wt[b]; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; m++;
+        uint32_t l0 = wt[0], l1 = n > 1 ? wt[1] : INF, i0 = INF, i1 = INF;
+        auto take = [&](uint32_t &w) -> int {
+            if (l0 != INF && l0 <= i0) { w = l0; const int a = lq++; l0 = l1; l1 = (lq + 1 < n) ? wt[lq + 1] : INF; return a; }
+            w = i0; const int a = iq++; i0 = i1; i1 = (iq + 1 < m) ? wt[iq + 1] : INF; return a;
+        };
+        while (m < nn) {
+            uint32_t wa, wb;
+            const int a = take(wa), b = take(wb);
+            const uint32_t sum = wa + wb;
+            wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m;
+            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum;      // the new node is (or follows) the head of the internal queue
+            m++;
         }
     }
     __builtin_amdgcn_wave_barrier();
