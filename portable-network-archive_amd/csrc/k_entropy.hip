@@ -209,7 +209,9 @@ __device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sy
     for (int s = 0; s < nw; s++) wts[s] = lens[s] ? (uint8_t)(maxbits + 1 - lens[s]) : 0;
     uint32_t fse_size = 0;
     {
-        uint32_t cnt[16]; for (int i = 0; i < 16; i++) cnt[i] = 0;
+        // (cnt and norm live in LDS, behind the 128 halfwords fse_build_table uses of tmp192: as local arrays with run-time indices they would be
+        // private memory, i.e. a trip to L2 / HBM per access on this one lane)
+        uint32_t *cnt = (uint32_t *)(tmp192 + 144); for (int i = 0; i < 16; i++) cnt[i] = 0;
         int maxw = 0, distinct = 0; uint32_t maxc = 0;
         for (int i = 0; i < nw; i++) { cnt[wts[i]]++; if (wts[i] > maxw) maxw = wts[i]; }
         for (int v = 0; v <= maxw; v++) { if (cnt[v]) distinct++; if (cnt[v] > maxc) maxc = cnt[v]; }
@@ -218,7 +220,7 @@ __device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sy
             while ((1 << minlog) < distinct) minlog++;
             if (tlog < minlog) tlog = minlog;
             if (tlog > 6) tlog = 6;
-            int16_t norm[16];
+            int16_t *norm = (int16_t *)(tmp192 + 128);
             fse_normalize(cnt, maxw + 1, (uint32_t)nw, tlog, norm);
             uint32_t hs = fse_write_ncount(tmp + 1, norm, maxw + 1, tlog);
             fse_build_table(scratch_tab, norm, maxw + 1, tlog, cell, tmp192);
@@ -262,7 +264,7 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
     while ((1 << minlog) < distinct) minlog++;
     if (tlog < minlog) tlog = minlog;
     if (tlog > (int)SEQ_MAX_LOG) tlog = (int)SEQ_MAX_LOG;
-    int16_t norm[64];
+    int16_t *norm = (int16_t *)(tmp192 + 128);      // (LDS, not a local array: see huf_write_tree)
     fse_normalize(count, maxs + 1, nseq, tlog, norm);
     T->desc_len[which] = fse_write_ncount(T->desc[which], norm, maxs + 1, tlog);
     fse_build_table(&T->tab[which], norm, maxs + 1, tlog, cell, tmp192);
@@ -337,8 +339,8 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     __shared__ uint8_t  wts[256];
     __shared__ uint8_t  tmp[320];
     __shared__ uint8_t  cell[4][256];            // one scratch set per table-building task (waves 0..3)
-    __shared__ uint16_t tmp192[4][192];
-    __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2];
+    __shared__ __attribute__((aligned(16))) uint16_t tmp192[4][192];
+    __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2], cntw_s[HUF_MAX + 2], crun_s[HUF_MAX + 2];
     __shared__ SeqTable wtab;
     __shared__ uint8_t s_llc[64], s_mlc[128];
     const uint32_t tid = threadIdx.x;
@@ -411,26 +413,38 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     if (np < 2) return;
     // canonical codes: weight-1 symbols first (ascending symbol), code = cell index >> (weight-1); symbol s sits behind all
     // symbols of smaller weight and the lower-numbered ones of its own weight
+    // (all of this on the wave's lanes: the highest symbol and the longest code by a reduction, the symbols per weight by LDS atomics, a symbol's rank
+    // among the lower-numbered symbols of its length by one ballot per length and round -- each was a loop on one lane before)
+    uint32_t ms = 0, mb = 0;
+    for (int s2 = (int)lane; s2 < 256; s2 += 64) { if (count[s2]) ms = (uint32_t)s2; const uint32_t l = lens[s2]; mb = l > mb ? l : mb; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t a2 = (uint32_t)__shfl_xor((int)ms, o), b2 = (uint32_t)__shfl_xor((int)mb, o); ms = a2 > ms ? a2 : ms; mb = b2 > mb ? b2 : mb; }
+    const int max_sym = (int)ms, maxbits = (int)mb;
+    if (lane < HUF_MAX + 2) { cntw_s[lane] = 0; crun_s[lane] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    for (int s2 = (int)lane; s2 < 256; s2 += 64) { const uint32_t l = lens[s2]; if (l && s2 <= max_sym) atomicAdd(&cntw_s[(uint32_t)maxbits + 1 - l], 1u); }
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        int max_sym = 0, maxbits = 0;
-        for (int s2 = 0; s2 < 256; s2++) if (count[s2]) max_sym = s2;
-        for (int s2 = 0; s2 <= max_sym; s2++) if (lens[s2] > maxbits) maxbits = lens[s2];
-        uint32_t cntw[HUF_MAX + 2];
-        for (int w = 0; w <= HUF_MAX + 1; w++) cntw[w] = 0;
-        for (int s2 = 0; s2 <= max_sym; s2++) if (lens[s2]) cntw[maxbits + 1 - lens[s2]]++;
         uint32_t pos = 0;
-        for (int w = 1; w <= maxbits; w++) { wbase_s[w] = pos; pos += cntw[w] << (w - 1); }
+        for (int w = 1; w <= maxbits; w++) { wbase_s[w] = pos; pos += cntw_s[w] << (w - 1); }
         hsh[3] = (uint32_t)max_sym; hsh[4] = (uint32_t)maxbits;
     }
     __builtin_amdgcn_wave_barrier();
-    const int max_sym = (int)hsh[3], maxbits = (int)hsh[4];
-    for (int s2 = (int)lane; s2 < 256; s2 += 64) {
+    const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;
+    for (int r = 0; r < 4; r++) {
+        const int s2 = 64 * r + (int)lane;
+        const uint32_t l = (s2 <= max_sym) ? (uint32_t)lens[s2] : 0u;
+        uint32_t before = 0;
+        for (uint32_t L = 1; L <= (uint32_t)maxbits; L++) {
+            const uint64_t m = __ballot(l == L);
+            if (l == L) before = crun_s[L] + (uint32_t)__popcll(m & lane_lt);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0 && m) crun_s[L] += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+        }
         uint32_t v = 0;
-        const uint32_t l = lens[s2];
-        if (l && s2 <= max_sym) {
+        if (l) {
             const uint32_t w = (uint32_t)maxbits + 1 - l;
-            uint32_t before = 0;
-            for (int o = 0; o < s2; o++) before += lens[o] == l ? 1u : 0u;
             v = ((wbase_s[w] + (before << (w - 1))) >> (w - 1)) | (l << 16);
         }
         T->huf_code[s2] = v;
