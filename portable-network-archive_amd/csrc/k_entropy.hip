@@ -123,6 +123,83 @@ __device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int 
     for (int u = 0; u < size; u++) { const int s = cell[u]; t->state[fill[s]++] = (uint16_t)(size + u); }
 }
 
+// The same table built by a whole WAVE (all 64 lanes call it; norm, cell, tmp192 in LDS -- tmp192[0 .. 127] is scratch here --; nsym <= 64, tlog <= 8).
+// Same cells, same states as the serial form above, which walks the table three times on one lane:
+//   * the low-probability symbols (norm = -1) take the top cells in symbol order: a ballot and a rank;
+//   * spread: position i of the walk is p_i = (i * step) & mask -- a permutation of the cells --, the walk skips the cells above `high`, so the k-th
+//     cell it fills is the k-th i with p_i <= high, and it belongs to the symbol whose run of norm[s] cells contains k: a prefix count over the lanes
+//     per round of 64 i's, a binary search in the symbols' cumulative counts (the LAST symbol whose count of cells before it is <= k: symbols
+//     without walk cells share that count with the next symbol that has some);
+//   * the state table lists a symbol's cells in ascending order behind those of the lower symbols: per round of 64 cells one ballot per distinct
+//     symbol of the round gives a cell's rank among its symbol's cells, a running count per symbol carries it over the rounds; a symbol's first
+//     cell (first_state = table size + cell) is the lowest lane of its first ballot.
+__device__ void fse_build_table_wave(SeqTable *t, const int16_t *norm, int nsym, int tlog, uint8_t *cell, uint16_t *tmp192, uint32_t lane) {
+    const int size = 1 << tlog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint16_t *cum = tmp192, *run = tmp192 + 64;
+    const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;
+    const int nrm = (int)lane < nsym ? (int)norm[lane] : 0;
+    const int n_walk = nrm > 0 ? nrm : 0, n_all = nrm == -1 ? 1 : n_walk;
+    // low-probability symbols: the top cells, in symbol order
+    const uint64_t lowm = __ballot(nrm == -1);
+    const int high = size - 1 - (int)__popcll(lowm);
+    if (nrm == -1) cell[size - 1 - (int)__popcll(lowm & lane_lt)] = (uint8_t)lane;
+    // inclusive scans over the symbols: the walk's cells, all cells
+    int pc = n_walk, ac = n_all;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int a2 = __shfl_up(pc, o), b2 = __shfl_up(ac, o); if ((int)lane >= o) { pc += a2; ac += b2; } }
+    cum[lane] = (uint16_t)(pc - n_walk);
+    __builtin_amdgcn_wave_barrier();
+    // spread
+    int kbase = 0;
+    for (int i0 = 0; i0 < size; i0 += 64) {
+        const int i = i0 + (int)lane, pi = (i * step) & mask;
+        const bool valid = i < size && pi <= high;
+        const uint64_t vm = __ballot(valid);
+        if (valid) {
+            const int k = kbase + (int)__popcll(vm & lane_lt);
+            int lo = 0, hi = nsym - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)cum[mid] <= k) lo = mid; else hi = mid - 1; }
+            cell[pi] = (uint8_t)lo;
+        }
+        kbase += (int)__popcll(vm);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // state table, and every symbol's first cell on the way
+    cum[lane] = (uint16_t)(ac - n_all);                          // from here on: the symbol's first state slot
+    run[lane] = 0;
+    uint32_t first_cell = 0;                                    // (kept by the symbol's own lane)
+    __builtin_amdgcn_wave_barrier();
+    for (int u0 = 0; u0 < size; u0 += 64) {
+        const int u = u0 + (int)lane;
+        const bool in = u < size;
+        const int sy = in ? (int)cell[u] : -1;
+        uint64_t todo = __ballot(in);
+        while (todo) {
+            const int l0 = (int)__builtin_ctzll(todo);         // the lowest lane not yet served: the lowest lane of its symbol
+            const int sx = __shfl(sy, l0);
+            const uint64_t m = __ballot(sy == sx);
+            const int before = (int)run[sx];
+            if (sy == sx) t->state[(int)cum[sx] + before + (int)__popcll(m & lane_lt)] = (uint16_t)(size + u);
+            if ((int)lane == sx && before == 0) first_cell = (uint32_t)(size + u0 + l0);
+            __builtin_amdgcn_wave_barrier();
+            if ((int)lane == l0) run[sx] = (uint16_t)(before + (int)__popcll(m));
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~m;
+        }
+    }
+    // symbol entries
+    if ((int)lane < nsym) {
+        SeqSym y; y.delta_nb = 0; y.delta_find = 0; y.first_state = 0;
+        if (n_all > 0) {
+            const int maxbits = (n_all == 1) ? tlog : tlog - (int)hb((uint32_t)(n_all - 1));
+            y.delta_nb = (uint32_t)((maxbits << 16) - (n_all << maxbits));
+            y.delta_find = (int16_t)((ac - n_all) - n_all);
+            y.first_state = (uint16_t)first_cell;
+        }
+        t->sym[lane] = y;
+    }
+}
+
 // ------------------------------------------------------------------ k_stats
 constexpr uint32_t ST_THREADS = 256;
 constexpr int HUF_MAX = 11;
@@ -272,6 +349,41 @@ __device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32
     return true;
 }
 
+// seq_build by a whole wave: lane 0 decides the mode, normalises and writes the description (short loops over <= 53 symbols), the encoder table is
+// then built by all lanes (fse_build_table_wave).  sh: four LDS words of the wave.
+__device__ bool seq_build_wave(SegTables *T, int which, const uint32_t *count, uint32_t nseq, int alphabet,
+                               const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *cell, uint16_t *tmp192, uint32_t *sh, uint32_t lane) {
+    int16_t *norm = (int16_t *)(tmp192 + 128);
+    if (lane == 0) {
+        int kind = 0, nsym = 0, tl = 0, ok = 1;                 // kind: 0 no table to build, 1 the predefined distribution, 2 norm
+        int maxs = 0, distinct = 0;
+        for (int s = 0; s < alphabet; s++) if (count[s]) { maxs = s; distinct++; }
+        T->desc_len[which] = 0;
+        if (distinct == 1 && nseq > 2) { T->desc[which][0] = (uint8_t)maxs; T->desc_len[which] = 1; T->tlog[which] = 0; T->mode[which] = 1; }
+        else {
+            const bool def_ok = maxs < def_n;
+            if (!(flags & F_FSE) || (nseq < 64 && def_ok)) {
+                if (!def_ok) ok = 0;
+                else { kind = 1; nsym = def_n; tl = def_log; T->tlog[which] = (uint32_t)def_log; T->mode[which] = 0; }
+            } else {
+                int tlog = (int)hb(nseq - 1) - 2, minlog = 5;
+                while ((1 << minlog) < distinct) minlog++;
+                if (tlog < minlog) tlog = minlog;
+                if (tlog > (int)SEQ_MAX_LOG) tlog = (int)SEQ_MAX_LOG;
+                fse_normalize(count, maxs + 1, nseq, tlog, norm);
+                T->desc_len[which] = fse_write_ncount(T->desc[which], norm, maxs + 1, tlog);
+                kind = 2; nsym = maxs + 1; tl = tlog; T->tlog[which] = (uint32_t)tlog; T->mode[which] = 2;
+            }
+        }
+        sh[0] = (uint32_t)kind; sh[1] = (uint32_t)nsym; sh[2] = (uint32_t)tl; sh[3] = (uint32_t)ok;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int kind = (int)sh[0], nsym = (int)sh[1], tl = (int)sh[2];
+    if (kind == 1) { if ((int)lane < nsym) norm[lane] = def[lane]; __builtin_amdgcn_wave_barrier(); }
+    if (kind) fse_build_table_wave(&T->tab[which], norm, nsym, tl, cell, tmp192, lane);
+    return sh[3] != 0;
+}
+
 // k_hist: the histograms of k_stats with one workgroup per BLOCK, added into the segment's 448 counters in memory (256 literal bytes, 3 x 64
 // codes) -- for batches whose segments are few and cut into many blocks (latency mode) the statistics of a segment are then gathered by up to
 // 128 workgroups instead of one; k_stats<true> builds the tables from the counters.
@@ -340,7 +452,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     __shared__ uint8_t  tmp[320];
     __shared__ uint8_t  cell[4][256];            // one scratch set per table-building task (waves 0..3)
     __shared__ __attribute__((aligned(16))) uint16_t tmp192[4][192];
-    __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2], cntw_s[HUF_MAX + 2], crun_s[HUF_MAX + 2];
+    __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2], cntw_s[HUF_MAX + 2], crun_s[HUF_MAX + 2], sq_sh[4][4];
     __shared__ SeqTable wtab;
     __shared__ uint8_t s_llc[64], s_mlc[128];
     const uint32_t tid = threadIdx.x;
@@ -400,12 +512,12 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     // ---- tables: wave 0 builds the literal code, lane 0 of waves 1..3 one sequence table each (LL, OF, ML), concurrently
     const uint32_t wave = tid >> 6, lane = tid & 63;
     if (wave != 0) {
-        if (lane != 0 || !nseq_seg) return;
+        if (!nseq_seg) return;
         bool ok;
-        if (wave == 1) ok = seq_build(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell[1], tmp192[1]);
-        else if (wave == 2) ok = seq_build(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell[2], tmp192[2]);
-        else ok = seq_build(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell[3], tmp192[3]);
-        if (!ok) atomicAnd(&T->seq_ok, 0u);
+        if (wave == 1) ok = seq_build_wave(T, 0, scount[0], nseq_seg, 36, C_LL_DEF, 36, 6, flags, cell[1], tmp192[1], sq_sh[1], lane);
+        else if (wave == 2) ok = seq_build_wave(T, 1, scount[1], nseq_seg, 32, C_OF_DEF, 29, 5, flags, cell[2], tmp192[2], sq_sh[2], lane);
+        else ok = seq_build_wave(T, 2, scount[2], nseq_seg, 53, C_ML_DEF, 53, 6, flags, cell[3], tmp192[3], sq_sh[3], lane);
+        if (!ok && lane == 0) atomicAnd(&T->seq_ok, 0u);
         return;
     }
     if (!(flags & F_HUF)) return;
