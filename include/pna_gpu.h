@@ -74,6 +74,10 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 0: every run)
  *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
+ *   "win32k" [PNA_WIN32K]                 zstd default / high level sets on the match finder's 32 KiB-window geometry with 32 704 table slots (1, default)
+ *                                         or on the 64 KiB / 24 512 one (0): other bytes (ratio 2.742 / 2.699 on text), same format
+ *   "strong_gtab" [PNA_STRONG_GTAB]       zstd levels 10..22 with the hash table in global memory (1, default) or in LDS (0)
+ *   "lit_beside_seq" [PNA_LIT_BESIDE_SEQ] large zstd batches: the literal coder on a second stream next to the sequence coder (1, default)
  *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "max_chunk_size" [PNA_MAX_CHUNK_SIZE] (FDAT chunk size of the entry points without such a parameter), "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],
  *   "extract_win_mib" [PNA_EXTRACT_WIN_MIB], "batch_piece_mib" [PNA_BATCH_PIECE_MIB], "inflate_serial" [PNA_INFLATE_SERIAL],
  *   "zdec_serial" [PNA_ZDEC_SERIAL], "stream_pool_mib" [PNA_STREAM_POOL_MIB], "stream_linger_us" [PNA_STREAM_LINGER_US] (-1 = adaptive): DESIGN.md. */
@@ -371,7 +375,8 @@ int  pna_gpu_compress_solid(pna_gpu_ctx *ctx, int algo, int level, const void *s
 
 /* ---- introspection used by tests and the benchmark */
 typedef struct {
-    double   ms_lz, ms_stats, ms_lit, ms_seq, ms_pack;   /* HIP-event time of each stage of the last batch     */
+    double   ms_lz, ms_stats, ms_lit, ms_seq, ms_pack;   /* HIP-event time of each stage of the last batch (large zstd batches run the literal coder
+                                                          * beside the sequence coder on a second stream: ms_lit is then ~0 and ms_seq covers both) */
     uint64_t in_bytes, out_bytes, n_segments, n_blocks;
     double   ms_frame;                                   /* k_frame (pna_gpu_create_archive_device only)       */
     double   ms_cipher;                                  /* k_aes_* (archives written with a cipher)           */

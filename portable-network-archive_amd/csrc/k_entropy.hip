@@ -820,9 +820,17 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     uint32_t *out32 = (uint32_t *)(seqc + ((size_t)g << sd.blk_log));
     const uint32_t cap_words = (1u << sd.blk_log) / 4;
     uint64_t acc = 0; uint32_t nb = 0, widx = 0;
+    // Finished dwords are collected four at a time and leave as ONE 16-byte store: every lane writes a stream of its own, and a 4-byte store per lane
+    // reached HBM as a masked 32-byte write each (WRITE_SIZE 12.5 GB per step for 1.5 GB of bitstreams -- the kernel's time was that traffic).
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
     auto put = [&](uint32_t v, uint32_t n) {               // n <= 32, v < 2^n (the accumulator holds < 32 bits before)
         acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) { if (widx < cap_words) out32[widx] = (uint32_t)acc; widx++; acc >>= 32; nb -= 32; }
+        if (nb >= 32) {
+            const uint32_t w = (uint32_t)acc, k = widx & 3u;
+            if (k == 3u) { if (widx < cap_words) *(uint4 *)(out32 + (widx - 3u)) = make_uint4(w0, w1, w2, w); }     // (cap_words is a multiple of 4: a group lies inside or outside as a whole)
+            else { w0 = k == 0u ? w : w0; w1 = k == 1u ? w : w1; w2 = k == 2u ? w : w2; }
+            widx++; acc >>= 32; nb -= 32;
+        }
     };
     // code / extra-bit count / base of a literal length and a match length: LDS LUT for small values, arithmetic above (code = highbit +
     // 19 / 36), both computed and selected (no divergent branch)
@@ -881,7 +889,15 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     if (mll != 1) put(st_ll & ((1u << tl_ll) - 1), tl_ll);
     put(1, 1);
     uint32_t bytes = widx * 4 + (nb + 7) / 8;
-    if (nb && widx < cap_words) out32[widx] = (uint32_t)acc;
+    {   // the dwords of the last, incomplete group, then the accumulator's rest
+        const uint32_t k = widx & 3u, gb = widx - k;
+        if (gb < cap_words) {
+            if (k > 0) out32[gb] = w0;
+            if (k > 1) out32[gb + 1] = w1;
+            if (k > 2) out32[gb + 2] = w2;
+            if (nb) out32[widx] = (uint32_t)acc;
+        }
+    }
     blk[g].seq_bits = bytes;
 }
 
@@ -1209,7 +1225,10 @@ void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_
 // sequence streams.  `tabs`, `segs` are the arrays of the whole batch.
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */) {
+                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */,
+                          hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+    // side != null (large batches, the one-kernel sequence coder): the literal coder runs on a second stream NEXT TO the sequence coder -- both only
+    // need the tables; k_seq is a few long chains per SIMD (1 250 waves of 64 chains on 1 024 SIMDs: issue slots to spare), k_lit streams memory
     const uint32_t bps_log = 20u - blk_log;                                 // blocks per full segment (SEG_SIZE = 1 MiB)
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
@@ -1218,8 +1237,12 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
     } else
         hipLaunchKernelGGL(k_stats<false>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
-    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
-    if (ev) (void)hipEventRecord(ev[1], st);
+    const bool forked = side && !hist && nb;
+    hipStream_t lst = forked ? side : st;
+    if (forked) { (void)hipEventRecord(fork, st); (void)hipStreamWaitEvent(side, fork, 0); }
+    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, lst, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
+    if (ev) (void)hipEventRecord(ev[1], st);                                   // (forked: the "literals" interval is empty and the "sequences" interval covers both kernels)
+    if (forked) (void)hipEventRecord(join, side);
     // two phases (short chains on three lanes per block, parallel packing) for the batches whose statistics were gathered per block (the host
     // picks them: few enough blocks that the chain waves fit the SIMDs), the one-kernel form otherwise (see k_seq)
     if (hist) {
@@ -1229,6 +1252,7 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
     } else {
         hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }
+    if (forked) (void)hipStreamWaitEvent(st, join, 0);
     if (ev) (void)hipEventRecord(ev[2], st);
 }
 // sizes of all segments -> offsets

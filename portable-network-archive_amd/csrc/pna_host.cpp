@@ -35,7 +35,7 @@ void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_
                           uint8_t *dst, hipStream_t st);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev);
+                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t fork, hipEvent_t join);
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st);
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
@@ -139,6 +139,7 @@ struct Tuning {
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
     long win32k = 1;                 // PNA_WIN32K: zstd default / high level sets on the 32 KiB-window geometry of the match finder (32 704 table slots); 0: 64 KiB / 24 512
+    long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
     long strong_gtab = 1;            // PNA_STRONG_GTAB: zstd levels 10 .. 22 with the match kernel's hash tables in global memory (2^19 slots per segment); 0: the LDS table
     long dev_layout = 1;             // PNA_DEV_LAYOUT: archive layout of plain one-chunk entries on the device (k_layout); 0: on the host, after a wait for the sizes
     long trace = 0;                  // PNA_TRACE: phase times of the host pipelines on stderr
@@ -155,7 +156,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -196,7 +197,7 @@ struct pna_gpu_ctx {
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipStream_t aux = nullptr;                        // entropy stage of chunk c runs here while k_lz works on chunk c+1
     static constexpr int MAXCH = 8;
-    hipEvent_t ev_lz[MAXCH + 1] = {}, ev_en[MAXCH][4] = {}, ev_join = nullptr;
+    hipEvent_t ev_lz[MAXCH + 1] = {}, ev_en[MAXCH][4] = {}, ev_join = nullptr, ev_fork = nullptr;
     hipEvent_t ev_in[4] = {}, ev_out[2] = {};
     bool crc_ready = false;
     bool corpus_ready = false;
@@ -296,6 +297,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (auto &e : c->ev_ci) if (e) (void)hipEventDestroy(e);
     for (auto &r : c->ev_en) for (auto &e : r) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->cp_in) (void)hipStreamDestroy(c->cp_in);
     if (c->cp_out) (void)hipStreamDestroy(c->cp_out);
@@ -845,6 +847,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             for (auto &e : c->ev_lz) HIPCHK(c, hipEventCreate(&e));
             for (auto &r : c->ev_en) for (auto &e : r) HIPCHK(c, hipEventCreate(&e));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         }
         // Measured (10 000 x 1 MiB): 4 chunks 111.8 ms vs 108.9 ms unchunked -- k_seq's duration is set by the length of one
         // block's tANS chain, not by the number of blocks, so every chunk pays it in full and the co-resident waves slow k_lz
@@ -871,7 +874,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
             HIPCHK(c, hipEventRecord(c->ev_en[k][0], est));
             launch_entropy_chunk(c->d_segs, s0, s1 - s0, c->d_blk_seg, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
-                                 (uint32_t *)c->seqw.p, c->call_flags, blk_log, hist_on ? c->d_hist : nullptr, est, &c->ev_en[k][1]);
+                                 (uint32_t *)c->seqw.p, c->call_flags, blk_log, hist_on ? c->d_hist : nullptr, est, &c->ev_en[k][1],
+                                 (nch == 1 && c->tun.lit_beside_seq) ? c->aux : nullptr, c->ev_fork, c->ev_join);
         }
         if (nch > 1) { HIPCHK(c, hipEventRecord(c->ev_join, c->aux)); HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0)); }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[4], st));
