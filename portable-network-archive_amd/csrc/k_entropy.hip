@@ -1238,11 +1238,22 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
         hipLaunchKernelGGL(k_stats<false>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
     const bool forked = side && !hist && nb;
-    hipStream_t lst = forked ? side : st;
-    if (forked) { (void)hipEventRecord(fork, st); (void)hipStreamWaitEvent(side, fork, 0); }
-    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, lst, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
-    if (ev) (void)hipEventRecord(ev[1], st);                                   // (forked: the "literals" interval is empty and the "sequences" interval covers both kernels)
-    if (forked) (void)hipEventRecord(join, side);
+    if (forked) {
+        // The sequence coder goes FIRST: its 1 250 long-running waves must hold their SIMD slots before the literal coder's 80 000 workgroups flood the
+        // dispatcher (with k_lit ahead -- even by the few microseconds of an event marker between the two launches -- the pair took 11 ms instead of 7).
+        // The "literals" interval of the timing is empty then, the "sequences" interval covers both kernels.
+        if (ev) (void)hipEventRecord(ev[1], st);
+        (void)hipEventRecord(fork, st);
+        hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, side, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
+        (void)hipEventRecord(join, side);
+        (void)hipStreamWaitEvent(st, join, 0);
+        if (ev) (void)hipEventRecord(ev[2], st);
+        return;
+    }
+    if (nb) hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, st, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
+    if (ev) (void)hipEventRecord(ev[1], st);
     // two phases (short chains on three lanes per block, parallel packing) for the batches whose statistics were gathered per block (the host
     // picks them: few enough blocks that the chain waves fit the SIMDs), the one-kernel form otherwise (see k_seq)
     if (hist) {
@@ -1252,7 +1263,6 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
     } else {
         hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }
-    if (forked) (void)hipStreamWaitEvent(st, join, 0);
     if (ev) (void)hipEventRecord(ev[2], st);
 }
 // sizes of all segments -> offsets

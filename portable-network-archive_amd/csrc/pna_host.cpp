@@ -843,7 +843,8 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         // zstd: the segments go through k_lz in chunks on `st`; the entropy stage of a finished chunk runs on the auxiliary
         // stream next to the following chunk's k_lz (latency-bound kernels hide in the issue slots k_lz leaves free)
         if (!c->aux) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+            { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (lowest priority: what runs here fills in beside the main stream's kernels)
+              HIPCHK(c, hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo)); }
             for (auto &e : c->ev_lz) HIPCHK(c, hipEventCreate(&e));
             for (auto &r : c->ev_en) for (auto &e : r) HIPCHK(c, hipEventCreate(&e));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
