@@ -23,9 +23,7 @@ def _raw(rel):
 
 
 def _params(codec):
-    p = codec.default_params()
-    p.flags = codec.F_HUF | codec.F_FSE | codec.F_LAZY        # what the device build produces (no repeat codes)
-    return p
+    return codec.params_for_level(3)        # the product's default level set (no repeat codes, two-step lazy deferral, the 32 KiB-window geometry)
 
 
 def _cases(codec):
