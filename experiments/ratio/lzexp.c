@@ -8,7 +8,7 @@
 typedef struct {
     uint32_t entries, min_match, tile, max_off, cap1, lookahead, lazy, lazy2, region, ins_mod, back_cap, rounds, look_mod, ways, hash_bytes, blk;
     uint32_t rep;      /* estimate repeat-offset codes */
-    uint32_t prefer_near; uint32_t gran; /* gran: entries hold 1 << gran byte granules, the position inside is found by comparing the hashed bytes */
+    uint32_t prefer_near; uint32_t gran; uint32_t lazy3, far_min, far_thr, min2, thr2; /* gran: entries hold 1 << gran byte granules, the position inside is found by comparing the hashed bytes */
 } P;
 static uint32_t rd32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint32_t hashf(const uint8_t *p, const P *pr) {
@@ -90,6 +90,9 @@ static uint32_t lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_star
                 int take = l >= p->min_match;
                 if (take && p->lazy && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
                 if (take && p->lazy && p->lazy2 && (q & 63) < 62 && q + 2 < t1 && len[q + 2 - t0] > l + 1) take = 0;
+                if (take && p->lazy && p->lazy3 && (q & 63) < 61 && q + 3 < t1 && len[q + 3 - t0] > l + 2) take = 0;
+                if (take && p->far_min && (q - (cand[q - t0] - 1)) > p->far_thr && l < p->far_min) take = 0;
+                if (take && p->min2 && (q - (cand[q - t0] - 1)) > p->thr2 && l < p->min2) take = 0;
                 if (!take) { q++; continue; }
                 uint32_t c = cand[q - t0] - 1;
                 if (l >= p->cap1) { uint32_t el = ext_lim; while (q + l < el && seg[q + l] == seg[c + l]) l++; }
@@ -119,14 +122,14 @@ static const uint8_t MLB[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
 static double ent(const uint32_t *c, int n) { double t = 0, e = 0; for (int i = 0; i < n; i++) t += c[i]; for (int i = 0; i < n; i++) if (c[i]) e -= c[i] * log2(c[i] / t); return e; }
 
 int main(int argc, char **argv) {
-    P p = {24512, 6, 4096, 1u << 20, 32, 1024, 1, 0, 256, 2, 3, 0x21, 1, 1, 6, 1u << 17, 0, 1, 0};
+    P p = {24512, 6, 4096, 1u << 20, 32, 1024, 1, 0, 256, 2, 3, 0x21, 1, 1, 6, 1u << 17, 0, 1, 0, 0, 0, 0, 0, 0};
     const char *files = NULL;
     for (int i = 1; i < argc; i++) {
         char *eq = strchr(argv[i], '=');
         if (!eq) { files = argv[i]; continue; }
         *eq = 0; uint32_t v = (uint32_t)strtoul(eq + 1, NULL, 0);
 #define K(n) if (!strcmp(argv[i], #n)) p.n = v;
-        K(entries) K(min_match) K(tile) K(max_off) K(cap1) K(lookahead) K(lazy) K(lazy2) K(region) K(ins_mod) K(back_cap) K(rounds) K(look_mod) K(ways) K(hash_bytes) K(blk) K(rep) K(gran)
+        K(entries) K(min_match) K(tile) K(max_off) K(cap1) K(lookahead) K(lazy) K(lazy2) K(region) K(ins_mod) K(back_cap) K(rounds) K(look_mod) K(ways) K(hash_bytes) K(blk) K(rep) K(gran) K(lazy3) K(far_min) K(far_thr) K(min2) K(thr2)
     }
     FILE *f = fopen(files, "rb"); if (!f) { perror("open"); return 1; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);

@@ -152,7 +152,7 @@ size_t pna_deflate_bound(size_t n) {
 
 void pna_deflate_default_params(pna_zstd_params *p) {
     pna_zstd_default_params(p);
-    p->max_off = 32768; p->max_len = 258; p->flags = PNA_F_LAZY | PNA_F_LAZY2;
+    p->max_off = 32768; p->max_len = 258; p->flags = PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3;
     p->hash_log = 24512; p->near_off = 56064;      /* the 64 KiB-window geometry: the whole look-back lies in the window */
 }
 

@@ -26,7 +26,7 @@ static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; 
  * (oracle/codec.py params_for_flags sets those). */
 void pna_zstd_default_params(pna_zstd_params *p) {
     p->hash_log = 32704; p->min_match = 6; p->tile = 4096; p->max_off = 1u << 20; p->cap1 = 32;
-    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_REP; p->max_len = 0; p->region = 256;
+    p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3 | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
     p->blk_log = 0;
 }
@@ -148,6 +148,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 int take = l >= p->min_match;
                 if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
                 if (take && (p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY2) && (q & 63) < 62 && q + 2 < t1 && len[q + 2 - t0] > l + 1) take = 0;
+                if (take && (p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY3) && (q & 63) < 61 && q + 3 < t1 && len[q + 3 - t0] > l + 2) take = 0;
                 if (!take) { q++; continue; }
                 uint32_t c = cand[q - t0] - 1;
                 if (l >= (far[q - t0] ? p->cap_far : p->cap1)) {

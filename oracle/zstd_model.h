@@ -24,6 +24,7 @@
 #define PNA_F_FSE      2u           /* FSE_Compressed sequence tables allowed (else predefined) */
 #define PNA_F_LAZY     4u           /* one-step lazy deferral inside a 64-position group        */
 #define PNA_F_REP      8u           /* repeat-offset codes (block-local history)                */
+#define PNA_F_LAZY3    0x100u       /* with PNA_F_LAZY2: also defer to a match at q + 3 that is longer by three or more */
 #define PNA_F_LAZY2    0x80u        /* with PNA_F_LAZY: also defer to a match at q + 2 that is longer by two or more (strong set) */
 
 typedef struct {

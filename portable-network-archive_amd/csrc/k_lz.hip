@@ -293,6 +293,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 // (the position is no start anyway); q + 1 >= t1 only happens in a block's last, partial tile (nl is 0 there: lanes >= t1 hold no match)
                 uint64_t longer = lazy ? __ballot(nl > l) : 0;
                 if (lazy && (flags & FLAG_LAZY2)) longer |= __ballot(dpp_next_lane(nl) > l + 1);     // (uniform) two-step deferral: q + 2 holds a match longer by two or more
+                if (lazy && (flags & FLAG_LAZY3)) longer |= __ballot(dpp_next_lane(dpp_next_lane(nl)) > l + 2);   // (uniform) three-step: q + 3, longer by three or more
                 effm[r] = __ballot(l >= MIN_MATCH) & ~longer;
             };
             LZ_STAMP(2);

@@ -335,7 +335,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 //      literal bytes are packed by v_perm (selector from a 16-entry table) and stored behind the literals of the positions before it.
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
-template <bool CT, bool LAZY2>
+template <bool CT, int LZD>   // LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
 __global__ __launch_bounds__(LZP_THREADS)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
@@ -417,7 +417,8 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                 uint32_t e = x - 0x06060606u;
                 if (lazy) {
                     e &= x - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 1);
-                    if (LAZY2) e &= x + 0x01010101u - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2);   // ... nor to the position after the next (longer by two or more)
+                    if (LZD >= 2) e &= x + 0x01010101u - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2);   // ... nor to the position after the next (longer by two or more)
+                    if (LZD >= 3) e &= x + 0x02020202u - __builtin_amdgcn_alignbyte(d[i + 1], d[i], 3);   // ... nor to the one after that (longer by three or more)
                 }
                 const uint32_t en = ((((e >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
                 const uint32_t cn = ((((d[i] >> 5) & 0x01010101u) * 0x00204081u) >> 21) & 15u;
@@ -697,8 +698,9 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
     hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (pg->nb == 0) return;                                   // (a run of empty entries has segments and no blocks)
-    if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lzp<CT, false>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    else hipLaunchKernelGGL((k_lzp<CT, 1>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
 // match kernel + parse kernel over `nseg` segments; pbuf holds one word per position of the launch's blocks, blk0 = the first of them; ctab != nullptr:
 // a deflate launch (chunk table, look-back inside the LDS window); ev_match, if given, is recorded between the two kernels
