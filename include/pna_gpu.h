@@ -74,8 +74,10 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 0: every run)
  *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
- *   "win32k" [PNA_WIN32K]                 zstd default / high level sets on the match finder's 32 KiB-window geometry with 32 704 table slots (1, default)
- *                                         or on the 64 KiB / 24 512 one (0): other bytes (ratio 2.742 / 2.699 on text), same format
+ *   "win32k" [PNA_WIN32K]                 LDS geometry of the zstd match finder: 1 (default) the default level set on a 32 KiB window with 32 704 table
+ *                                         slots, the high set on a 16 KiB window with 36 800; 0: both on 64 KiB / 24 512; 2: both on 16 KiB.  Other bytes
+ *                                         (ratio 2.70 / 2.76 / 2.78 on text at the default level), same format
+ *   "lazy2" [PNA_LAZY2]                   how far a start looks ahead before it is taken, beyond the next position: 2 (default), 1, 0
  *   "strong_gtab" [PNA_STRONG_GTAB]       zstd levels 10..22 with the hash table in global memory (1, default) or in LDS (0)
  *   "lit_beside_seq" [PNA_LIT_BESIDE_SEQ] large zstd batches: the literal coder on a second stream next to the sequence coder (1, default)
  *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "max_chunk_size" [PNA_MAX_CHUNK_SIZE] (FDAT chunk size of the entry points without such a parameter), "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],

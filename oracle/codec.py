@@ -211,7 +211,7 @@ def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: 
     return params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab)
 
 
-def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: bool = True, lazy2: int = 2) -> ZstdParams:
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
     F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
     (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB).  gtab: the match kernel's table lies in global
@@ -221,6 +221,8 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
     p.blk_log = blk_log
     if not deflate and not (flags & F_FAR and flags & F_LAZY and not gtab and win32k):
         p.hash_log, p.near_off = 24512, 56064
+    elif not deflate and (win32k >= 2 or (flags & F_STRONG and flags & F_ADOPT)):
+        p.hash_log, p.near_off = 36800, 6912       # the 16 KiB window: the high set (and, with the product's option win32k = 2, the default set)
     p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
     p.flags &= ~0x180                      # two- and three-step lazy deferral go with F_LAZY (the product's option lazy2 = 2 / 1 / 0: both, the first, none -- the high sets keep the first)
     if flags & F_LAZY and (lazy2 or flags & F_STRONG):

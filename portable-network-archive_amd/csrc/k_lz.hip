@@ -598,6 +598,9 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
     if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
                 else launch_lz_g<LZ_G_DEFLATE, true, false, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
+    else if (flags & FLAG_W16) {
+           if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+           else launch_lz_g<LZ_G_ZSTD, false, false, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
     else if (flags & FLAG_W32) {
            if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
            else launch_lz_g<LZ_G_ZSTD, false, false, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }

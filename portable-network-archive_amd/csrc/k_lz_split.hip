@@ -711,6 +711,9 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
     if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
                 else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
     else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+    else if (flags & FLAG_W16) {
+           if (strong) launch_split_g<false, true, 0, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else launch_split_g<false, false, 0, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
     else if (flags & FLAG_W32) {
            if (strong) launch_split_g<false, true, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
            else launch_split_g<false, false, 0, 15>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }

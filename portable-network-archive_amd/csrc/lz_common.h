@@ -17,14 +17,14 @@ constexpr uint32_t WIN_MIRROR = 48;                        // the window's first
 // candidates: a third more slots are worth +1.6 % of ratio on text, and what the window no longer holds -- candidates more than NEAR bytes back -- is
 // verified against the segment in HBM / L2 like everything beyond the window before)
 template <uint32_t WLOG> struct LzGeo {
-    static_assert(WLOG == 15 || WLOG == 16, "window of 32 or 64 KiB");
+    static_assert(WLOG >= 14 && WLOG <= 16, "window of 16, 32 or 64 KiB");
     static constexpr uint32_t WIN     = 1u << WLOG;
     static constexpr uint32_t L_TABLE = L_WIN + WIN + WIN_MIRROR;
-    static constexpr uint32_t ENTRIES = WLOG == 16 ? HASH_ENTRIES : ((160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 4 & ~63u);   // 32 704
+    static constexpr uint32_t ENTRIES = WLOG == 16 ? HASH_ENTRIES : ((160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 4 & ~63u);   // 32 704 (32 KiB window), 36 800 (16 KiB)
     static constexpr uint32_t L_WEND  = L_TABLE + 4u * ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
     static constexpr uint32_t L_WPUB  = L_WEND + 4 * LZ_WAVES;    // 16 x 8 B
     static constexpr uint32_t L_TOTAL = L_WPUB + 8 * LZ_WAVES;
-    static constexpr uint32_t NEAR    = WLOG == 16 ? NEAR_OFF : WIN - 2 * 1024 * LZ_G_ZSTD - LOOKAHEAD - 16 - 240;   // candidates at most this far back are verified in the window (32 KiB: 23 296)
+    static constexpr uint32_t NEAR    = WLOG == 16 ? NEAR_OFF : WIN - 2 * 1024 * LZ_G_ZSTD - LOOKAHEAD - 16 - 240;   // candidates at most this far back are verified in the window (32 KiB: 23 296; 16 KiB: 6 912)
     static_assert(L_TOTAL <= 160 * 1024 && ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 };
 

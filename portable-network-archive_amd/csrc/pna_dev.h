@@ -45,6 +45,7 @@ constexpr uint32_t SEQ_CAP    = PNA_BLK_LOG == 17 ? 22528 : ((BLK_SIZE / MIN_MAT
 constexpr uint32_t F_HUF = 1, F_FSE = 2, F_LAZY = 4, F_REP = 8;
 constexpr uint32_t FLAG_LAZY2 = 0x400u;   // launch flag of the LZ kernels (with F_LAZY): two-step lazy deferral -- a start also waits for a match at q + 2 that is longer by two or more
 constexpr uint32_t FLAG_LAZY3 = 0x800u;   // (with FLAG_LAZY2) three-step deferral: ... and for a match at q + 3 that is longer by three or more
+constexpr uint32_t FLAG_W16 = 0x4000u;   // ... the 16 KiB-window geometry (36 800 table slots)
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy
 

@@ -277,6 +277,32 @@ def test_feature_subsets_bit_exact(pna, codec, flags):
         assert codec.zstd_decompress(o, len(e)) == e
 
 
+@pytest.mark.parametrize("form", ["split", "one-kernel"])
+def test_lds_geometries_equal_the_model(pna, codec, form):
+    """The match finder shares a CU's 160 KiB of LDS between window and hash table in one of three geometries (lz_common.h LzGeo): 64 KiB + 24 512 slots,
+    32 KiB + 32 704 (the zstd default set), 16 KiB + 36 800 (the high set); option win32k = 0 / 1 / 2 puts both sets on the first / leaves the choice /
+    puts both on the last.  What the window does not hold is read from the segment (far candidates): same rules, other table -- every combination must
+    equal the model with that table size, in both forms of the LZ stage, and a smaller window must not compress worse."""
+    import torch  # noqa: F401
+    ents = [codec.corpus_file(0, 1, 300000), codec.corpus_file(0, 2, (1 << 20) + 77), codec.corpus_file(1, 3, 65536), b"", codec.corpus_file(0, 5, 2500000)]
+    size = {}
+    with pna.Context(0) as ctx:
+        ctx.set_option("latency_max_mib", 0)
+        ctx.set_option("lz_split_min", 0 if form == "split" else 1 << 20)
+        for w in (0, 1, 2):
+            ctx.set_option("win32k", w)
+            for lvl in (3, 7):
+                outs = ctx.compress_batch(ents, level=lvl)
+                assert (ctx.timing().lz_match_launches > 0) == (form == "split")
+                fl, gt = codec.product_level_flags(lvl)
+                p = codec.params_for_flags(fl, gtab=gt, win32k=w)
+                assert p.hash_log == {(0, 3): 24512, (0, 7): 24512, (1, 3): 32704, (1, 7): 36800, (2, 3): 36800, (2, 7): 36800}[(w, lvl)]
+                for e, o in zip(ents, outs):
+                    assert o == codec.model_compress(e, p), (w, lvl, len(e))
+                size[(w, lvl)] = sum(map(len, outs))
+    assert size[(2, 3)] < size[(1, 3)] < size[(0, 3)] and size[(1, 7)] < size[(0, 7)] and size[(1, 7)] < size[(1, 3)]
+
+
 def test_lz_stage_equals_model(gpu_ctx, codec):
     d = codec.corpus_file(0, 31, 700000)
     gpu_ctx.compress_batch([d])
