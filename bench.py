@@ -39,16 +39,16 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def encoder_text(algo: str, level: int) -> str:
     """The level set behind the (clamped) `level` in words (pna_host.cpp level_flags / set_call_level)."""
     defl = algo == "deflate"
-    fast, balanced = (level <= 3, level in (4, 5)) if defl else (level < 0 or level == 1, level == 2)
+    fast, balanced = (level <= 3, level in (4, 5)) if defl else (level < 0 or level == 1, False)
     high, gtab = (level >= 9 if defl else level >= 6), (not defl and level >= 10)
     w32 = not defl and not fast and not balanced and not gtab
-    table = ("2^19-slot hash table per segment in global memory" if gtab else ("32704" if w32 else "24512") + "-entry LDS hash table") \
+    table = ("2^19-slot hash table per segment in global memory" if gtab else ("36800" if (w32 and high) else "32704" if w32 else "24512") + "-entry LDS hash table") \
         + ("" if fast else " over the even positions")
     look = ("look-back 32 KiB (inside the 64 KiB LDS window)" if defl else
             "look-back = the LDS window (56 064 B)" if fast else
-            "look-back = the whole 1 MiB segment (LDS window %s B, beyond it candidates are verified in HBM/L2)" % ("23 296" if w32 else "56 064"))
+            "look-back = the whole 1 MiB segment (LDS window %s B, beyond it candidates are verified in HBM/L2)" % ("6 912" if (w32 and high) else "23 296" if w32 else "56 064"))
     parse = "greedy" if fast else "greedy with backward adoption" if balanced else \
-        "greedy+lazy2 with backward adoption (3 rounds)" if high else "greedy+lazy1 with backward adoption"
+        "greedy+lazy3 with backward adoption (3 rounds)" if high else "greedy+lazy3 with backward adoption"
     return f"GPU encoder: {table}, {look}, min_match 6, {parse}, 4096-position tiles"
 
 

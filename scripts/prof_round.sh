@@ -18,7 +18,7 @@ python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 >
 echo small done
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
-for lv in 1 2 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
+for lv in 1 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
 echo levels done
 python3 scripts/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1

@@ -101,7 +101,7 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     if form == "default":
         monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: the split form at every size
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
-        for level in (1, 2, 3, 7, 19):              # the five zstd level sets: fast, balanced, default, high, max (codec.product_level_flags)
+        for level in (1, 2, 3, 7, 19):              # the zstd level sets: fast, default (2 and 3), high, max (codec.product_level_flags)
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
             # (levels 10 .. 22 always take the split form: only the match kernel k_lzm has the global-memory hash table of the strong set)
@@ -1086,22 +1086,23 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
 
 def test_levels_select_the_parse(gpu_ctx, pna, codec):
     """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto parameter sets -- fast (greedy,
-    LDS-window look-back, every position in the table), balanced (+ even-position table, backward adoption, 1 MiB look-back), default
-    (+ lazy; zstd: the match finder's 32 KiB-window geometry with 32 704 table slots), high (+ third adoption round, two-step lazy) and, zstd
-    only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact with the model; stronger sets compress better."""
+    LDS-window look-back, every position in the table), balanced (deflate only: + even-position table, backward adoption), default
+    (+ 1 MiB look-back, lazy deferral over three positions; zstd: the match finder's 32 KiB-window geometry with 32 704 table slots), high (+ third
+    adoption round; zstd: 16 KiB window, 36 800 slots) and, zstd only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact
+    with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
     fast, balanced, dflt = codec.F_HUF | codec.F_FSE, std, std | codec.F_LAZY
     strong = dflt | codec.F_STRONG
     sizes = {}
-    for level, fl, gtab in ((-5, fast, 0), (1, fast, 0), (2, balanced, 0), (0, dflt, 0), (3, dflt, 0), (pna.LEVEL_DEFAULT, dflt, 0), (5, dflt, 0), (6, strong, 0), (9, strong, 0),
+    for level, fl, gtab in ((-5, fast, 0), (1, fast, 0), (2, dflt, 0), (0, dflt, 0), (3, dflt, 0), (pna.LEVEL_DEFAULT, dflt, 0), (5, dflt, 0), (6, strong, 0), (9, strong, 0),
                             (10, strong, 1), (19, strong, 1), (22, strong, 1), (99, strong, 1)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         assert codec.product_level_flags(level) == (fl, bool(gtab)), level
         pz = codec.params_for_flags(fl, gtab=bool(gtab))
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
-    assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1]
+    assert sizes[19] < sizes[6] < sizes[3] == sizes[2] < sizes[1]
     dstd = codec.F_ADOPT | codec.F_INS2
     for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd), (5, dstd), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
