@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def encoder_text(algo: str, level: int) -> str:
     """The level set behind the (clamped) `level` in words (pna_host.cpp level_flags / set_call_level)."""
     defl = algo == "deflate"
-    fast, balanced = (level <= 3, level in (4, 5)) if defl else (level < 0 or level == 1, False)
+    fast, balanced = (level <= 3, False) if defl else (level < 0 or level == 1, False)
     high, gtab = (level >= 9 if defl else level >= 6), (not defl and level >= 10)
     w32 = not defl and not fast and not balanced and not gtab
     table = ("2^19-slot hash table per segment in global memory" if gtab else ("36800" if (w32 and high) else "32704" if w32 else "24512") + "-entry LDS hash table") \

@@ -186,12 +186,11 @@ def default_params() -> ZstdParams:
 
 def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = None):
     """(flags, gtab): the level sets behind the reference's level scale as the product maps them (pna_host.cpp level_flags / set_call_level):
-    zstd < 0, 1 fast; 0, 2..5 default; 6..9 high (+ F_STRONG); 10..22 max (+ the hash table in global memory) -- deflate 0..3, 4..5,
-    6..8, 9.  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
+    zstd < 0, 1 fast; 0, 2..5 default; 6..9 high (+ F_STRONG); 10..22 max (+ the hash table in global memory) -- deflate 0..3, 4..8, 9.  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
     base = ctx_flags if ctx_flags is not None else ((F_ADOPT | F_INS2 | F_LAZY) if deflate else (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2))
     if deflate:
         lv = 6 if level is None or level == -1000 else (9 if level < 0 or level > 9 else level)      # (PNA_LEVEL_DEFAULT; a negative Custom(n) wraps and clamps to 9)
-        fast, balanced, strong = lv <= 3, lv in (4, 5), lv >= 9
+        fast, balanced, strong = lv <= 3, False, lv >= 9                    # (deflate 4..5 = the default set)
     else:
         lv = 3 if level is None or level == -1000 else min(level, 22)
         fast, balanced, strong = lv < 0 or lv == 1, False, lv >= 6          # (zstd 2 = the default set)
