@@ -47,7 +47,7 @@ def encoder_text(algo: str, level: int) -> str:
     look = ("look-back 32 KiB (inside the 64 KiB LDS window)" if defl else
             "look-back = the LDS window (56 064 B)" if fast else
             "look-back = the whole 1 MiB segment (LDS window %s B, beyond it candidates are verified in HBM/L2)" % ("6 912" if (w32 and high) else "23 296" if w32 else "56 064"))
-    parse = "greedy" if fast else "greedy with backward adoption" if balanced else \
+    parse = "greedy+lazy3" if fast else "greedy with backward adoption" if balanced else \
         "greedy+lazy3 with backward adoption (3 rounds)" if high else "greedy+lazy3 with backward adoption"
     return f"GPU encoder: {table}, {look}, min_match 6, {parse}, 4096-position tiles"
 

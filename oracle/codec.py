@@ -195,7 +195,7 @@ def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = No
         lv = 3 if level is None or level == -1000 else min(level, 22)
         fast, balanced, strong = lv < 0 or lv == 1, False, lv >= 6          # (zstd 2 = the default set)
     if fast:
-        fl = base & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2 | F_STRONG)
+        fl = base & ~(F_FAR | F_ADOPT | F_INS2 | F_STRONG)                    # (lazy deferral stays)
     elif balanced:
         fl = base & ~(F_LAZY | F_STRONG)
     elif strong and base & F_ADOPT and base & F_LAZY:

@@ -336,7 +336,7 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
 
 // Four parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
 // lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101; PNA_LEVEL_DEFAULT and zstd level 0 = the default):
-//   fast      zstd < 0 and 1, deflate 0..3   greedy parse, every position in the table, look-back = the LDS window, no backward adoption
+//   fast      zstd < 0 and 1, deflate 0..3   every position in the table, look-back = the LDS window, no backward adoption; lazy deferral as below
 //   default   zstd 0, 2..5,   deflate 4..8   + even-position table, backward adoption, 1 MiB look-back (zstd), lazy deferral over three positions
 //   high      zstd 6..9,      deflate 9      + a third adoption round (matches move back by up to 7 positions) and two-step lazy deferral
 //   max       zstd 10..22                    + the match kernel's hash table in global memory: 2^19 slots per segment instead of what LDS holds
@@ -347,7 +347,7 @@ static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
     const bool balanced = false;   // (the set without lazy deferral -- zstd 2, deflate 4..5 until round 3 -- is as fast as the default set since the parse kernel looks ahead for free; the levels take the default set, the bits remain)
     const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : lv >= 6;
-    if (fast) return c->flags & ~(F_LAZY | F_FAR | F_ADOPT | F_INS2 | F_STRONG);
+    if (fast) return c->flags & ~(F_FAR | F_ADOPT | F_INS2 | F_STRONG);      // (lazy deferral stays: the parse kernel does it for free -- zstd-1 2.510 -> 2.54 at the same speed)
     if (balanced) return c->flags & ~(F_LAZY | F_STRONG);
     if (strong && (c->flags & F_ADOPT) && (c->flags & F_LAZY)) return c->flags | F_STRONG;
     return c->flags;

@@ -109,7 +109,7 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
             pz = codec.params_for_level(level)
             for k, d, o in zip(names, data, outs):
                 assert o == codec.model_compress(d, pz), (k, level)
-        for level, fl in ((1, 0), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
+        for level, fl in ((1, codec.F_LAZY), (6, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY), (9, codec.F_ADOPT | codec.F_INS2 | codec.F_LAZY | codec.F_STRONG)):
             outs = ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
             pd = codec.params_for_flags(fl, deflate=True)
             for k, d, o in zip(names, data, outs):
@@ -1092,7 +1092,7 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
     with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
-    fast, balanced, dflt = codec.F_HUF | codec.F_FSE, std, std | codec.F_LAZY
+    fast, balanced, dflt = codec.F_HUF | codec.F_FSE | codec.F_LAZY, std, std | codec.F_LAZY
     strong = dflt | codec.F_STRONG
     sizes = {}
     for level, fl, gtab in ((-5, fast, 0), (1, fast, 0), (2, dflt, 0), (0, dflt, 0), (3, dflt, 0), (pna.LEVEL_DEFAULT, dflt, 0), (5, dflt, 0), (6, strong, 0), (9, strong, 0),
@@ -1104,7 +1104,7 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
         sizes[level] = sum(map(len, outs))
     assert sizes[19] < sizes[6] < sizes[3] == sizes[2] < sizes[1]
     dstd = codec.F_ADOPT | codec.F_INS2
-    for level, fl in ((0, 0), (1, 0), (3, 0), (4, dstd | codec.F_LAZY), (5, dstd | codec.F_LAZY), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
+    for level, fl in ((0, codec.F_LAZY), (1, codec.F_LAZY), (3, codec.F_LAZY), (4, dstd | codec.F_LAZY), (5, dstd | codec.F_LAZY), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
         pd = codec.params_for_flags(fl, deflate=True)
         assert outs == [codec.deflate_model_compress(d, pd) for d in data], level
