@@ -336,16 +336,19 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, int LZD>   // LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
-__global__ __launch_bounds__(LZP_THREADS)
+__global__ __launch_bounds__(LZP_THREADS)   // (88 registers: 5 waves per SIMD; asked for 6 / 7 the allocator spills 4 / 9 registers and the kernel is no faster / 2 % slower)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
     constexpr uint32_t RW = 256, TG = 4096;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && (1u << BLK_LOG_MIN) % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
-    __shared__ uint32_t l32[TG / 4];                        // the tile's match lengths, one byte per position
+    __shared__ __attribute__((aligned(16))) uint32_t l32[TG / 4];   // the tile's match lengths, one byte per position; from the end of step 2 on: the records (below)
     __shared__ uint4 lmask[TG / 64];                        // per group: start mask, cap mask
     __shared__ uint32_t plut[16];                           // v_perm selectors that pack the bytes named by a nibble
-    __shared__ uint4 rec[3][TG / 64];                       // per group: [0] literal mask, first literal index, first sequence index; [1] chosen starts, the capped ones among all chosen;
-                                                            // [2] literal-run base of its first sequence, xlen base, cut position | length << 8, cut offset
+    // per group: [0] literal mask, first literal index, first sequence index; [1] chosen starts, the capped ones among all chosen; [2] literal-run base of
+    // its first sequence, xlen base, cut position | length << 8, cut offset.  The records are written when the walk is through with the lengths and live
+    // until the tile's literals are out: they take the lengths' place (3 of its 4 KiB) -- 5.4 KiB of LDS per wave instead of 8.4, so that the registers,
+    // not LDS, bound the waves per CU (the kernel hides its memory latency by occupancy: 13 instead of 19 waves per CU cost it 12 %, 9 waves 36 %; above 20 nothing more is gained).
+    uint4 (*rec)[TG / 64] = (uint4 (*)[TG / 64])l32;
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
     const uint32_t lane = threadIdx.x, w = lane & 15;
     const uint8_t *len8 = (const uint8_t *)l32;
@@ -591,6 +594,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             seq_run += tot & 0xFFFF; lit_run += tot >> 16;
             next_free = t0 + rdlane(tile_exit, 0);
             // one record per group for the lanes that write its sequences and literals
+            asm volatile("" ::: "memory");                 // (the records overwrite the lengths: every read of those stays in front)
             if (lv) {
                 uint32_t prevl = 0; bool any = false;       // literal index (region-local) at the region's latest chosen start so far
 #pragma unroll
@@ -683,6 +687,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             }
         }
         __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");                     // (the next tile's lengths overwrite the records)
         LZP_STAMP(4);
     }
 #ifdef LZP_PROF
