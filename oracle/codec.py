@@ -171,7 +171,7 @@ class ZstdParams(ctypes.Structure):
                 ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
                 ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32), ("region", ctypes.c_uint32),
                 ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
-                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32)]
+                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32), ("len_word_max", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
@@ -238,6 +238,8 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
         p.flags |= 0x80
     if gtab:
         p.hash_log = 19                # zstd levels 10 .. 22: the match kernel's table lies in global memory, 2^19 slots per segment (index = the hash's top bits)
+        p.max_off = 1 << 20            # ... and its words keep 4 bytes per position: the whole segment as look-back, no clamp of the adopted lengths
+        p.len_word_max = 0
     if not flags & F_ADOPT:
         p.rounds = 0
         p.back_cap = 0

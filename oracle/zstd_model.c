@@ -25,10 +25,10 @@ static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; 
  * "far").  The fast / balanced sets, the sets with the table in global memory and deflate run the 64 KiB geometry: 24 512 slots, far beyond 56 064
  * (oracle/codec.py params_for_flags sets those). */
 void pna_zstd_default_params(pna_zstd_params *p) {
-    p->hash_log = 32704; p->min_match = 6; p->tile = 4096; p->max_off = 1u << 20; p->cap1 = 32;
+    p->hash_log = 32704; p->min_match = 6; p->tile = 4096; p->max_off = (1u << 19) - 1; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3 | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
-    p->blk_log = 0;
+    p->blk_log = 0; p->len_word_max = 36;
 }
 
 /* block size of a parameter set: 128 KiB unless blk_log names a smaller power of two (the device's latency mode: small batches are cut
@@ -137,6 +137,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 back[q - t0] = (uint8_t)(back0[j] - sft); far[q - t0] = far0[j];
             }
         }
+        if (p->len_word_max) for (uint32_t i = 0; i < t1 - t0; i++) if (len[i] > p->len_word_max) len[i] = (uint16_t)p->len_word_max;
         /* P */
         uint32_t ext_lim = t1 + p->lookahead < blk_end ? t1 + p->lookahead : blk_end;
         uint32_t R = p->region ? p->region : T;

@@ -43,6 +43,7 @@ typedef struct {
     uint32_t near_off;    /* offsets above it are "far" (outside the GPU's LDS window): per-position cap cap_far; 0 = none  */
     uint32_t cap_far;     /* per-position match length cap of far candidates                                                */
     uint32_t blk_log;     /* block size = 1 << blk_log for 13..16 (latency mode of the device: short per-block chains); anything else: 128 KiB */
+    uint32_t len_word_max; /* adopted lengths are clamped to it (0 = no clamp): the device's 3-byte words keep lengths up to 36 (plus 19 bits of offset: max_off 524 287) */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */

@@ -282,6 +282,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     K = ((K4 & 0x20u) != 0 && T > (K | 63u)) ? T : K;
                 }
                 l = K >> 6;
+                if (flags & FLAG_LEN36) l = l < 36u ? l : 36u;                      // (uniform) what the split form's 3-byte words keep
                 off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 7u)));          // the offset travels with the match
                 }
 #endif

@@ -111,7 +111,12 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
+    // The words: one per position, length | offset.  With the table in LDS (GLOG = 0) they take THREE bytes -- 5 bits for the length (0, or length - 5
+    // for 6 .. 36: adopted lengths beyond 36 are clamped, FLAG_LEN36 tells the one-kernel form to do the same) and 19 for the offset (MAX_OFF_W3) --:
+    // the parse kernel's time is the time to stream them (42 GB per step at 4 bytes).  With the table in global memory: 4 bytes, 6 + 20 bits.
+    constexpr bool W3 = GLOG == 0;
     uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
+    uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
 
     for (uint32_t i = tid; i < (GLOG ? (1u << GLOG) : HASH_ENTRIES) / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
@@ -299,7 +304,20 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
-            if (q0 < t1) {
+            if (W3) {
+                if (q0 < t1) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t l = K[j] >> 6, lc = l < 5u ? 5u : (l > 36u ? 36u : l);       // (v_med3_u32: lengths below MIN_MATCH are strays of the adoption, nobody's match)
+                        ww[j] = (lc - 5u) | (off[j] << 5);
+                    }
+                    W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);                              // (q0 is a multiple of 4: the 12 bytes are dword-aligned)
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);   // bytes 0 1 2 of word 0, byte 0 of word 1
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);   // bytes 1 2 of word 1, bytes 0 1 of word 2
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);   // byte 2 of word 2, bytes 0 1 2 of word 3
+                }
+            } else if (q0 < t1) {
                 v4u wv; wv.x = (K[0] >> 6) | (off[0] << 6); wv.y = (K[1] >> 6) | (off[1] << 6); wv.z = (K[2] >> 6) | (off[2] << 6); wv.w = (K[3] >> 6) | (off[3] << 6);
                 __builtin_nontemporal_store(wv, (v4u *)(pb + q0));       // (streamed: the parse kernel reads the words, this one never; without the hint they push the
                                                                          // segment's recent bytes -- where most far candidates lie -- out of L2: k_lzm + 1.5 %)
@@ -335,7 +353,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 //      literal bytes are packed by v_perm (selector from a 16-entry table) and stored behind the literals of the positions before it.
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
-template <bool CT, int LZD>   // LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
+template <bool CT, int LZD, bool W3>   // W3: the words take three bytes (k_lzm); LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
 __global__ __launch_bounds__(LZP_THREADS)   // (88 registers: 5 waves per SIMD; asked for 6 / 7 the allocator spills 4 / 9 registers and the kernel is no faster / 2 % slower)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
@@ -359,6 +377,13 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     const uint8_t *seg = src + sd.src_off;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);
     const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
+    const uint8_t *pb8 = (const uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
+    // the word of position `pos` of the segment in the 4-byte form (length | offset << 6), whichever way it is stored
+    auto word_at = [&](uint32_t pos) -> uint32_t {
+        if (!W3) return pb[pos];
+        const uint32_t x = *(const u32u *)(pb8 + 3 * (size_t)pos) & 0xFFFFFFu, e = x & 31u;
+        return (e ? e + 5u : 0u) | ((x >> 5) << 6);
+    };
     const uint32_t lazy = flags & F_LAZY;
     const uint32_t wbase = w * RW;
     const uint32_t bs0 = (gb - sd.blk_base) << blk_log, bs1 = seg_len - bs0 < bsz ? seg_len : bs0 + bsz;    // (an empty segment's only block: no tiles)
@@ -391,14 +416,21 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
         // share of pbuf, whole blocks, so the loads need no bounds of their own)
         {
             const uint4 *pt = (const uint4 *)(pb + t0);
+            const W12 *pt3 = (const W12 *)(pb8 + 3 * (size_t)t0);
             for (uint32_t wq = 0; wq < 4 && wq * 1024 < npos; wq++) {                   // four regions at a time: their loads go out together
-                uint4 v[4];
+                uint4 v[4]; W12 v3[4];
 #pragma unroll
-                for (uint32_t i = 0; i < 4; i++) v[i] = pt[(wq * 4 + i) * 64 + lane];
+                for (uint32_t i = 0; i < 4; i++) { if (W3) v3[i] = pt3[(wq * 4 + i) * 64 + lane]; else v[i] = pt[(wq * 4 + i) * 64 + lane]; }
 #pragma unroll
                 for (uint32_t i = 0; i < 4; i++) {
                     const uint32_t p = (wq * 4 + i) * RW + lane * 4;
-                    uint32_t d = (v[i].x & 63u) | ((v[i].y & 63u) << 8) | ((v[i].z & 63u) << 16) | ((v[i].w & 63u) << 24);
+                    uint32_t d;
+                    if (W3) {
+                        // the four 5-bit fields (bytes 0, 3, 6, 9 of the lane's 12) as bytes; length = field + 5 where the field is not 0
+                        const uint32_t E = (v3[i].x & 31u) | (((v3[i].x >> 24) & 31u) << 8) | (((v3[i].y >> 16) & 31u) << 16) | (((v3[i].z >> 8) & 31u) << 24);
+                        const uint32_t nz = ((E + 0x1F1F1F1Fu) >> 5) & 0x01010101u;
+                        d = E + nz * 5u;
+                    } else d = (v[i].x & 63u) | ((v[i].y & 63u) << 8) | ((v[i].z & 63u) << 16) | ((v[i].w & 63u) << 24);
                     if (npos < TG && p + 4 > npos) d = p >= npos ? 0u : d & (0xFFFFFFFFu >> (8 * (p + 4 - npos)));
                     l32[p >> 2] = d;
                 }
@@ -461,7 +493,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                     uint64_t need = __ballot(cap);
                     if (need) {
                         const uint32_t qs = t0 + ps;
-                        const uint32_t pwv = cap ? pb[qs] : 0u;                      // (its offset)
+                        const uint32_t pwv = cap ? word_at(qs) : 0u;                 // (its offset)
                         const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
                         while (need) {
                             const uint32_t k = ctz64(need); need &= need - 1;
@@ -531,7 +563,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
 #pragma unroll
                     for (int r = 2; r >= 0; r--) if (!below && (uint32_t)r < grp && sel[r]) { below = sel[r]; g2 = (uint32_t)r; }
                     const uint32_t s2 = 63 - clz64(below);
-                    const uint32_t pw2 = pb[t0 + wbase + 64 * g2 + s2];
+                    const uint32_t pw2 = word_at(t0 + wbase + 64 * g2 + s2);
                     uint64_t sc2 = sel[0] & cm[0]; uint32_t pc2 = pc[0];
 #pragma unroll
                     for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
@@ -638,14 +670,14 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             uint32_t idx = ra.w, prev = 0;
             const uint32_t cut_b2 = rc.z & 0xFFu, cut_l2 = rc.z >> 8;
             bool first = true;
-            const uint32_t *pg = pb + t0 + lane * 64;
+            const uint32_t pg0 = t0 + lane * 64;
             while (rem) {
                 // four starts at a time: their words (the offsets) are requested together
                 uint32_t sq[4], pw[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     sq[u] = rem ? ctz64(rem) : 64u;
-                    pw[u] = rem ? pg[sq[u]] : 0u;
+                    pw[u] = rem ? word_at(pg0 + sq[u]) : 0u;
                     rem &= rem - 1;                                                 // (0 stays 0)
                 }
 #pragma unroll
@@ -703,9 +735,10 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
     hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (pg->nb == 0) return;                                   // (a run of empty entries has segments and no blocks)
-    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
-    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lzp<CT, 1>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    constexpr bool W3 = GLOG == 0;
+    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    else hipLaunchKernelGGL((k_lzp<CT, 1, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
 }
 // match kernel + parse kernel over `nseg` segments; pbuf holds one word per position of the launch's blocks, blk0 = the first of them; ctab != nullptr:
 // a deflate launch (chunk table, look-back inside the LDS window); ev_match, if given, is recorded between the two kernels

@@ -836,7 +836,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
-        const uint32_t dfl = (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u);
+        const uint32_t dfl = (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | FLAG_LEN36;
         if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
         else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
@@ -862,16 +862,17 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? ((c->tun.win32k >= 2 || ((c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT))) ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u);
+            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? ((c->tun.win32k >= 2 || ((c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT))) ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36);
+            const uint32_t zmax = (c->call_flags & F_FAR) ? (c->call_gtab ? MAX_OFF : MAX_OFF_W3) : NEAR_OFF;   // (3-byte words keep 19 bits of offset)
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
                 const bool gt = c->call_gtab;
                 const LzParseGrid pgu{c->d_segs, c->d_blk_seg, nblk};
                 if (gt && (c->pbuf.ensure(((size_t)nblk << blk_log) * 4) || c->gtab.ensure((size_t)nunits << (lz_gtab_log() + 2)))) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");
                 launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, zfl,
-                          (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr, gt ? &pgu : nullptr);
+                          zmax, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr, gt ? &pgu : nullptr);
             }
-            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, (c->call_flags & F_FAR) ? MAX_OFF : NEAR_OFF, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, zmax, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
             hipStream_t est = nch > 1 ? c->aux : st;
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
