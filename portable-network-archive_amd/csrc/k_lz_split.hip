@@ -734,7 +734,7 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
     (void)attr_set;
     hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
-    if (pg->nb == 0) return;                                   // (a run of empty entries has segments and no blocks)
+    if (!pg || pg->nb == 0) return;                            // (no grid: the caller wants the match kernel alone; a run of empty entries has segments and no blocks)
     constexpr bool W3 = GLOG == 0;
     if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
     else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);

@@ -138,6 +138,7 @@ struct Tuning {
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
+    long tail_units = 1;             // PNA_TAIL_UNITS: the segments behind a run's last full round of the CUs go through the match kernel in units of one block
     long lazy2 = 2;                  // PNA_LAZY2: how far the lazy level sets look ahead beyond the next position: 2 = two more positions (default), 1 = one more, 0 = none (the high sets: one)
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
@@ -157,7 +158,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -166,6 +167,7 @@ struct pna_gpu_ctx {
     // the plan of a sub-batch -- segment descriptors, LZ units (latency mode: pieces of segments, one workgroup each), block -> segment, entry -> first
     // segment -- is staged in ONE page-locked blob and travels in one copy; the per-segment histograms of k_hist lie behind the BlkInfo array (one memset)
     DevBuf plan; PinBuf h_plan;
+    DevBuf d_tail; PinBuf h_tail; size_t tail_used = 0;     // unit descriptors of the segments behind a run's last full round of workgroups (lz_stage)
     SegDesc *d_segs = nullptr, *d_units = nullptr; uint32_t *d_blk_seg = nullptr, *d_entry_seg = nullptr, *d_hist = nullptr;
     uint32_t last_blk_log = PNA_BLK_LOG, last_units = 0;
     int device = 0;
@@ -288,10 +290,10 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->plan, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
+    for (DevBuf *b : {&c->plan, &c->d_tail, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->gtab, &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
-    for (PinBuf *b : {&c->h_entoff, &c->h_plan, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
+    for (PinBuf *b : {&c->h_entoff, &c->h_plan, &c->h_tail, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_in[2], &c->dp_in[3], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (auto &e : c->ev_in) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_out) if (e) (void)hipEventDestroy(e);
@@ -688,6 +690,31 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
             HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
         }
         const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};            // the parse kernel: one wave per block of the run
+        // The match kernel runs one workgroup per segment and CU, all of equal length: a run of 3 334 segments is 13 full rounds of the 256 CUs and a 14th for
+        // 6 of them.  The segments behind the last full round are therefore cut into UNITS of one block each (table pre-warmed: the same words, SS4a), a launch
+        // of their own behind the full rounds: R x 8 short workgroups instead of R long ones next to 256 - R idle CUs.
+        uint32_t R = (!gt && !waveparse && c->tun.tail_units && b - a >= 512) ? (b - a) % 256 : 0;
+        if (R > 96) R = 0;
+        if (R) {
+            const uint32_t bl = segs[a].blk_log, bs = 1u << bl;
+            size_t nu = 0;
+            for (uint32_t sgi = b - R; sgi < b; sgi++) nu += std::max<uint32_t>(1, (segs[sgi].len + bs - 1) >> bl);
+            constexpr size_t TAIL_CAP = 16 * 96 * 128;                 // (allocated once at this size: a buffer that grew would move under the launches already queued)
+            if (c->tail_used + nu > TAIL_CAP || c->h_tail.ensure(TAIL_CAP * sizeof(SegDesc)) || c->d_tail.ensure(TAIL_CAP * sizeof(SegDesc))) R = 0;
+            else {
+                SegDesc *hu = (SegDesc *)c->h_tail.p + c->tail_used; SegDesc *du = (SegDesc *)c->d_tail.p + c->tail_used;
+                size_t k = 0;
+                for (uint32_t sgi = b - R; sgi < b; sgi++)
+                    for (uint32_t u = 0; u < std::max<uint32_t>(segs[sgi].len, 1); u += bs) { SegDesc us = segs[sgi]; us.u0 = u; us.u1 = std::min<uint32_t>(segs[sgi].len, u + bs); hu[k++] = us; }
+                HIPCHK(c, hipMemcpyAsync(du, hu, nu * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+                launch_lz(d_src, c->d_segs + a, b - a - R, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st,
+                          (uint32_t *)c->pbuf.p, b0, nullptr, nullptr, nullptr);                        // the full rounds: match kernel only
+                launch_lz(d_src, du, (uint32_t)nu, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st,
+                          (uint32_t *)c->pbuf.p, b0, e1, nullptr, &pg);                                 // the rest in units, then the parse kernel over the whole run
+                c->tail_used += nu;
+            }
+        }
+        if (!R)
         launch_lz(d_src, c->d_segs + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags | (waveparse ? 0x1000u : 0u), max_off, max_len, st,
                   (uint32_t *)c->pbuf.p, b0, e1, gt ? (uint32_t *)c->gtab.p : nullptr, &pg);
         a = b;
@@ -785,6 +812,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                  o_entry = (o_blkseg + (size_t)(nblk + 1) * 4 + 15) & ~(size_t)15, plan_bytes = o_entry + (ne_all + 2) * 4;
     if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes)) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
     SegDesc *segs = (SegDesc *)c->h_plan.p, *units = (SegDesc *)((uint8_t *)c->h_plan.p + o_units);   // (the previous sub-batch has been waited for: the staging is free)
+    c->tail_used = 0;
     uint32_t *blk_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_blkseg), *entry_first_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_entry);
     {
         auto fill = [&](size_t a, size_t b) {
