@@ -789,6 +789,7 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
     __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 | base << 16 (small values only)
+    __shared__ uint32_t ring[8][64];                   // per lane (column) the bitstream's last dwords: see put()
     const uint32_t lane = threadIdx.x;
     const uint32_t seg0 = (blockIdx.x * 64u) >> bps_log;
     const uint32_t segs_wg = bps_log >= 6 ? 1u : 64u >> bps_log;
@@ -819,17 +820,25 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
     uint32_t *out32 = (uint32_t *)(seqc + ((size_t)g << sd.blk_log));
     const uint32_t cap_words = (1u << sd.blk_log) / 4;
-    uint64_t acc = 0; uint32_t nb = 0, widx = 0;
-    // Finished dwords are collected four at a time and leave as ONE 16-byte store: every lane writes a stream of its own, and a 4-byte store per lane
-    // reached HBM as a masked 32-byte write each (WRITE_SIZE 12.5 GB per step for 1.5 GB of bitstreams -- the kernel's time was that traffic).
-    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    uint32_t acc = 0, nb = 0, widx = 0, gdone = 0;
+    // Finished dwords leave four at a time as ONE 16-byte store: every lane writes a stream of its own, and a 4-byte store per lane reached HBM as a
+    // masked 32-byte write each (WRITE_SIZE 12.5 GB per step for 1.5 GB of bitstreams -- the kernel's time was that traffic).  The group is collected
+    // in the lane's column of an LDS ring of eight dwords: put() writes the accumulator's low dword to slot widx & 7 WHETHER OR NOT it is complete (a
+    // later put overwrites it with more bits; the slots ahead belong to the group that left before), so a put is a shift, an OR, a store and three
+    // selects -- with the group held in registers it was twenty instructions, a third of the kernel's, and the kernel is bound by issue (PMC: VALU
+    // active half of the wave cycles at one wave per SIMD).  A sequence appends < 3 dwords, so one look per sequence finds a finished group.
     auto put = [&](uint32_t v, uint32_t n) {               // n <= 32, v < 2^n (the accumulator holds < 32 bits before)
-        acc |= (uint64_t)v << nb; nb += n;
-        if (nb >= 32) {
-            const uint32_t w = (uint32_t)acc, k = widx & 3u;
-            if (k == 3u) { if (widx < cap_words) *(uint4 *)(out32 + (widx - 3u)) = make_uint4(w0, w1, w2, w); }     // (cap_words is a multiple of 4: a group lies inside or outside as a whole)
-            else { w0 = k == 0u ? w : w0; w1 = k == 1u ? w : w1; w2 = k == 2u ? w : w2; }
-            widx++; acc >>= 32; nb -= 32;
+        const uint64_t y = (uint64_t)acc | ((uint64_t)v << nb);
+        ring[widx & 7u][lane] = (uint32_t)y;
+        nb += n;
+        const bool full = nb >= 32;
+        widx += full ? 1u : 0u; acc = full ? (uint32_t)(y >> 32) : (uint32_t)y; nb &= 31u;
+    };
+    auto flush = [&]() {
+        if ((widx >> 2) != gdone) {                      // group gdone is complete (cap_words is a multiple of 4: a group lies inside or outside as a whole)
+            const uint32_t h = (gdone & 1u) * 4u;
+            if (4 * gdone < cap_words) *(uint4 *)(out32 + 4 * gdone) = make_uint4(ring[h][lane], ring[h + 1][lane], ring[h + 2][lane], ring[h + 3][lane]);
+            gdone++;
         }
     };
     // code / extra-bit count / base of a literal length and a match length: LDS LUT for small values, arithmetic above (code = highbit +
@@ -880,6 +889,7 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
             // literal-length and match-length extra bits (<= 16 + 16) as one field, then the offset's
             put((llv - lbase) | ((mlv - mbase) << lbits), lbits + mbits);
             put(ofb - (1u << oc), oc);
+            flush();
         }
         if (k == 0) break;
         k--; a0 = n0; a1 = n1;
@@ -888,14 +898,15 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     if (mof != 1) put(st_of & ((1u << tl_of) - 1), tl_of);
     if (mll != 1) put(st_ll & ((1u << tl_ll) - 1), tl_ll);
     put(1, 1);
+    flush();
     uint32_t bytes = widx * 4 + (nb + 7) / 8;
     {   // the dwords of the last, incomplete group, then the accumulator's rest
-        const uint32_t k = widx & 3u, gb = widx - k;
+        const uint32_t k = widx & 3u, gb = widx - k, h = (gdone & 1u) * 4u;
         if (gb < cap_words) {
-            if (k > 0) out32[gb] = w0;
-            if (k > 1) out32[gb + 1] = w1;
-            if (k > 2) out32[gb + 2] = w2;
-            if (nb) out32[widx] = (uint32_t)acc;
+            if (k > 0) out32[gb] = ring[h][lane];
+            if (k > 1) out32[gb + 1] = ring[h + 1][lane];
+            if (k > 2) out32[gb + 2] = ring[h + 2][lane];
+            if (nb) out32[widx] = acc;
         }
     }
     blk[g].seq_bits = bytes;
