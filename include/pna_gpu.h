@@ -260,8 +260,9 @@ int  pna_gpu_create_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n
  *   PNA_ALGO_ZSTD: one or more RFC 8878 frames without dictionary; a multi-frame payload must follow this library's
  *     segmentation (every frame but the last holds 1 MiB) because frames carry no content size -- single-frame payloads, which
  *     is what the reference writes, always work.
- *   PNA_ALGO_DEFLATE: one RFC 1950 zlib stream (any block types, sync-flush markers, window <= 32 KiB); Adler-32 is verified;
- *     entries below 4 GiB.
+ *   PNA_ALGO_DEFLATE: one RFC 1950 zlib stream (any block types, sync-flush markers, window <= 32 KiB); Adler-32 is verified.
+ *     Streams of 4 GiB and more (compressed or decoded) are decoded by their sync-flush delimited pieces -- what this library
+ *     writes; a stream of that size without them is PNA_E_UNSUPPORTED (the wave-per-stream walk counts in 32 bits).
  * Errors: PNA_E_INVAL for corrupt / mismatching streams (pna_gpu_last_error names the entry), PNA_E_UNSUPPORTED for
  * dictionaries and other algorithms. */
 int  pna_gpu_decompress_batch(pna_gpu_ctx *ctx, int algo, size_t n, const void *const *src, const size_t *src_len,

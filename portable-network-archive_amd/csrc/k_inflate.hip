@@ -119,7 +119,11 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     if (mode && IF_U(mode[f]) != 1u) return;                               // lane-per-piece decode took this stream (VM_SERIAL = 1)
     const uint64_t src_off = (uint64_t)IF_U((uint32_t)frames[f].src_off) | ((uint64_t)IF_U((uint32_t)(frames[f].src_off >> 32)) << 32);
     const uint64_t dst_off = (uint64_t)IF_U((uint32_t)frames[f].dst_off) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_off >> 32)) << 32);
-    const uint32_t src_len = IF_U(frames[f].src_len), dst_len = IF_U(frames[f].dst_len);
+    if (IF_U((uint32_t)(frames[f].src_len >> 32)) | IF_U((uint32_t)(frames[f].dst_len >> 32))) {      // this walk counts in 32 bits: streams of 4 GiB and more are decoded by pieces or not at all
+        if (l0) { frames[f].status = IF_UNSUPPORTED; fx[f].nblk = 0; }
+        return;
+    }
+    const uint32_t src_len = IF_U((uint32_t)frames[f].src_len), dst_len = IF_U((uint32_t)frames[f].dst_len);
     const bool open = (IF_U(frames[f].out_len) & ZF_OPEN) != 0;        // dst_len is a capacity: the stream's size is reported back
     const uint64_t seq_base = (uint64_t)IF_U((uint32_t)fx[f].seq_base) | ((uint64_t)IF_U((uint32_t)(fx[f].seq_base >> 32)) << 32);
     const uint32_t seq_cap = IF_U(fx[f].seq_cap), blk_base = IF_U(fx[f].blk_base), blk_cap = IF_U(fx[f].blk_cap);
@@ -348,7 +352,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
         fx[f].nblk = status == IF_OK ? 1u : 0u;
         frames[f].status = status;
         frames[f].out_len = (uint32_t)total;
-        if (open && status == IF_OK) frames[f].dst_len = (uint32_t)total;
+        if (open && status == IF_OK) frames[f].dst_len = total;
     }
 }
 
@@ -426,9 +430,9 @@ enum { VM_PIECES = 0, VM_SERIAL = 1 };
 
 struct VPiece { uint32_t frame, j; };
 
-// ---- k_imark: one workgroup per stream: piece boundaries.  pb[blk_base + j] = start of piece j (relative to the stream), pb[... + P] = end.
+// ---- k_imark: one workgroup per stream: piece boundaries.  pb[blk_base + f + j] = start of piece j (relative to the stream, 64 bits), pb[... + P] = end.
 __global__ __launch_bounds__(256)
-void k_imark(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint32_t *__restrict__ pb,
+void k_imark(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint64_t *__restrict__ pb,
              uint32_t *__restrict__ mode) {
     __shared__ uint32_t cnt[256];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -436,16 +440,16 @@ void k_imark(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, 
     const uint32_t P = fx[f].blk_cap, base = fx[f].blk_base + f;          // P + 1 boundary slots per stream
     if (P <= 1) { if (tid == 0) { pb[base] = 0; pb[base + 1] = fr.src_len; mode[f] = VM_PIECES; } return; }
     const uint8_t *p = src + fr.src_off;
-    const uint32_t n = fr.src_len, per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
+    const uint64_t n = fr.src_len, per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
     uint32_t c = 0;
-    for (uint32_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
+    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
     cnt[tid] = c;
     __syncthreads();
     if (tid == 0) { uint32_t r = 0; for (uint32_t i = 0; i < 256; i++) { const uint32_t t = cnt[i]; cnt[i] = r; r += t; } mode[f] = r == P - 1 ? VM_PIECES : VM_SERIAL; pb[base] = 0; pb[base + P] = n; }
     __syncthreads();
     if (mode[f] != VM_PIECES) return;
     uint32_t k = cnt[tid];
-    for (uint32_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) { pb[base + 1 + k] = i + 4; k++; }
+    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) { pb[base + 1 + k] = i + 4; k++; }
 }
 
 // ---- k_icount: sync-flush markers per stream (streams of unknown size: the host sizes the piece list from it)
@@ -468,7 +472,7 @@ void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len,
 
 __global__ __launch_bounds__(64)
 void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const VPiece *__restrict__ pieces, uint32_t npieces,
-                const uint32_t *__restrict__ pb, const uint32_t *__restrict__ mode, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
+                const uint64_t *__restrict__ pb, const uint32_t *__restrict__ mode, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
                 uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t vlds[];
     uint16_t *lsy = (uint16_t *)vlds;                                        // [320][64]: 0..287 literal / length symbols in canonical order, 288.. distance symbols
@@ -480,18 +484,20 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
     if (live && (fr.status || mode[pc.frame] != VM_PIECES)) live = false;
     const uint32_t P = x.blk_cap;
     const uint32_t bslot = x.blk_base + pc.frame;
-    const uint32_t p_start = live ? pb[bslot + pc.j] : 0u, p_end = live ? pb[bslot + pc.j + 1] : 0u;
+    // the piece's bytes: positions below are relative to its start (the stream may be longer than 32 bits count, a piece is not)
+    const uint64_t p_start = live ? pb[bslot + pc.j] : 0u, p_stop = live ? pb[bslot + pc.j + 1] : 0u;
+    const uint32_t p_end = (uint32_t)(p_stop - p_start < 0xFFFFFFF0ull ? p_stop - p_start : 0xFFFFFFF0ull);
     const bool first = pc.j == 0, lastp = pc.j + 1 == P;
     const bool open = (fr.out_len & ZF_OPEN) != 0;                           // dst_len is a capacity: the last piece's size is found by decoding it
     const uint64_t room = (uint64_t)fr.dst_len > (uint64_t)pc.j * BLK_SIZE ? (uint64_t)fr.dst_len - (uint64_t)pc.j * BLK_SIZE : 0;
     const uint32_t expect = lastp ? (uint32_t)(open && room > BLK_SIZE ? BLK_SIZE : room) : BLK_SIZE;
-    const uint8_t *sp = src + fr.src_off;
+    const uint8_t *sp = src + fr.src_off + p_start;
     uint8_t *lit_out = lit_scratch + fr.dst_off + (size_t)pc.j * BLK_SIZE;
-    const uint32_t pcap = x.seq_cap / (P ? P : 1);
+    const uint32_t pcap = x.pcap;
     uint64_t *rec_out = seqs + x.seq_base + (size_t)pc.j * pcap;
 #define LS(e)  lsy[(e) * 64 + lane]
-    // bit reader: bytes of [p_start, p_end) of the stream, zeros beyond; the three words after the buffer are always on their way
-    uint32_t pos = p_start;                                                  // first byte not yet in the buffer
+    // bit reader: bytes [0, p_end) of the piece, zeros beyond; the three words after the buffer are always on their way
+    uint32_t pos = 0;                                                        // first byte not yet in the buffer
     uint64_t bitbuf = 0; uint32_t bitcnt = 0;
     auto load4 = [&](uint32_t at) -> uint32_t {
         if (at + 4 <= p_end) return *(const u32u_i *)(sp + at);
@@ -699,11 +705,11 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
     if (status == IF_OK && (open && lastp ? total > expect : total != expect)) status = IF_DSTSIZE;
     ZBlock b;
     b.body = 0; b.out_off = 0; b.seq_pos = x.seq_base + (uint64_t)pc.j * pcap; b.size = 0; b.type = 2;
-    b.ltype = 2; b.regen = nlit; b.streams = 1; b.lit_off = 0; b.lit_csize = 0; b.lit_pos = pc.j * BLK_SIZE;
+    b.ltype = 2; b.regen = nlit; b.streams = 1; b.lit_off = 0; b.lit_csize = 0; b.lit_pos = (uint32_t)((uint64_t)pc.j * BLK_SIZE);
     b.huf_slot = 0xFFFFFFFFu; b.slot[0] = b.slot[1] = b.slot[2] = 0xFFFFFFFFu;
     b.nseq = nseq; b.seq_off = 0; b.seq_len = 0; b.frame = pc.frame; b.out_len = (uint32_t)total; b.status = status; b.uses_rep = 0;
     for (int k = 0; k < 7; k++) b.pad[k] = 0;
-    b.pad[1] = adler;
+    b.pad[1] = adler; b.pad[2] = (uint32_t)(((uint64_t)pc.j * BLK_SIZE) >> 32);
     blocks[x.blk_base + pc.j] = b;
 #undef LS
 }
@@ -716,19 +722,19 @@ __global__ void k_vfin(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, ui
         const uint32_t P = fx[f].blk_cap; uint32_t bad = 0; uint64_t tot = 0;
         for (uint32_t j = 0; j < P; j++) { bad |= blocks[fx[f].blk_base + j].status; tot += blocks[fx[f].blk_base + j].out_len; }
         const bool open = (frames[f].out_len & ZF_OPEN) != 0;
-        if (!bad && (open ? tot <= frames[f].dst_len : tot == frames[f].dst_len)) { fx[f].nblk = P; if (!open) frames[f].out_len = (uint32_t)tot; return; }   // (open: k_zoff reports the size)
+        if (!bad && (open ? tot <= frames[f].dst_len : tot == frames[f].dst_len)) { fx[f].nblk = P; if (!open) frames[f].out_len = (uint32_t)(tot < 0xFFFFFFFFull ? tot : 0xFFFFFFFFull); return; }   // (open: k_zoff reports the size)
         mode[f] = VM_SERIAL;
     }
 }
 
-void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint32_t *pb, uint32_t *mode, const uint8_t *src,
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, const uint8_t *src,
                      ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
     if (!n) return;
     static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_vinflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VI_LDS);
     (void)attr_set;
     hipLaunchKernelGGL(k_imark, dim3(n), dim3(256), 0, st, (const ZFrame *)frames, (const ZFrameX *)fx, src, pb, mode);
     hipLaunchKernelGGL(k_vinflate, dim3((npieces + 63) / 64), dim3(64), VI_LDS, st, (const ZFrame *)frames, (const ZFrameX *)fx, (const VPiece *)pieces, npieces,
-                       (const uint32_t *)pb, (const uint32_t *)mode, src, blocks, lit_scratch, seqs);
+                       (const uint64_t *)pb, (const uint32_t *)mode, src, blocks, lit_scratch, seqs);
     hipLaunchKernelGGL(k_vfin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, n, (const ZBlock *)blocks, mode);
 }
 

@@ -175,7 +175,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     ZFrame fr = frames[blockIdx.x];
     const uint8_t *in = src + fr.src_off;
     uint8_t *out = dst + fr.dst_off;
-    const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;      // (zstd frames of 4 GiB and more never get here: k_zscan)
     const bool open = (fr.out_len & ZF_OPEN) != 0;                     // cap is only a capacity
     uint32_t ip = 0, op = 0;
     uint32_t status = ZD_OK;
@@ -585,7 +585,7 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
     ZFrame fr = frames[f];
     ZFrameX x = fx[f];
     const uint8_t *in = src + fr.src_off;
-    const uint32_t in_len = fr.src_len, cap = fr.dst_len;
+    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;
     const bool open = (fr.out_len & ZF_OPEN) != 0;
     uint32_t status = fr.status, ip = 0;
     // ---- frame header
@@ -1023,7 +1023,7 @@ __global__ void k_zoff(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ 
         b->out_off = off + total; total += b->out_len; st |= b->status;
     }
     if (st) frames[f].status = ZD_CORRUPT;
-    else if (frames[f].out_len & ZF_OPEN) { if (total > frames[f].dst_len) frames[f].status = ZD_DSTSIZE; else frames[f].dst_len = (uint32_t)total; }
+    else if (frames[f].out_len & ZF_OPEN) { if (total > frames[f].dst_len) frames[f].status = ZD_DSTSIZE; else frames[f].dst_len = total; }
     else if (total != frames[f].dst_len) frames[f].status = ZD_DSTSIZE;
 }
 
@@ -1035,13 +1035,17 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
     const ZFrame fr = frames[f];
     if (fr.status) return;
     const ZFrameX x = fx[f];
-    uint8_t *out = dst + fr.dst_off;                                  // frame-relative positions below
-    const uint32_t cap = fr.dst_len;
+    // Positions below count in 32 bits from `out`.  For frames below 2 GiB that is the frame's start; further on the base follows the blocks
+    // 2 GiB behind (a block is at most 128 KiB, a reference reaches back less than 2^24: both stay in range, and the test `offset > o0 + ll`
+    // cannot fail there, as it must not).  Frames of 4 GiB and more: zlib streams decoded by pieces (k_vinflate).
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool okq = true;
     for (uint32_t k = 0; k < x.nblk && okq; k++) {
         const ZBlock b = blocks[x.blk_base + k];
-        uint32_t op = (uint32_t)(b.out_off - fr.dst_off);
+        const uint64_t bpos = b.out_off - fr.dst_off, rebase = bpos > (1ull << 31) ? bpos - (1ull << 31) : 0;
+        uint8_t *out = dst + fr.dst_off + rebase;
+        const uint64_t cap = fr.dst_len - rebase;
+        uint32_t op = (uint32_t)(bpos - rebase);
         const uint8_t *body = src + b.body;
         if (b.type < 2) {
             const uint32_t rle = body[0];
@@ -1049,7 +1053,7 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
             continue;
         }
         const uint8_t *lit_raw = body + b.lit_off;
-        const uint8_t *lit_dec = lit_scratch + fr.dst_off + b.lit_pos;
+        const uint8_t *lit_dec = lit_scratch + fr.dst_off + ((uint64_t)b.lit_pos | ((uint64_t)b.pad[2] << 32));
         auto LIT = [&](uint32_t i) -> uint8_t { return b.ltype == 0 ? lit_raw[i] : (b.ltype == 1 ? lit_raw[0] : lit_dec[i]); };
         const uint64_t *rec = seqs + b.seq_pos;
         uint32_t litpos = 0;
@@ -1200,8 +1204,8 @@ __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8
     // gets all of raw_len and goes to the one-workgroup-per-frame kernel (the bounded per-frame resources are sized for SEG_SIZE);
     // the other frame slots planned for the entry are void
     if (nfr > 1 && zscan_frame_end(p, 0, len) == len) {
-        ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = (uint32_t)len; fr.out_len = en.open ? ZF_OPEN : 0u;
-        fr.dst_len = (uint32_t)en.raw_len; fr.status = (en.raw_len > 0xFFFFFFFFull || len > 0xFFFFFFFFull) ? 1u : 2u;
+        ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = len; fr.out_len = en.open ? ZF_OPEN : 0u;
+        fr.dst_len = en.raw_len; fr.status = (en.raw_len > 0xFFFFFFFFull || len > 0xFFFFFFFFull) ? 1u : 2u;
         frames[en.first_frame] = fr;
         fr.src_len = 0; fr.dst_len = 0; fr.status = 4;              // ZD_VOID
         for (uint32_t g = 1; g < nfr; g++) frames[en.first_frame + g] = fr;

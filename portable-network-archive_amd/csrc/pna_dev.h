@@ -154,19 +154,21 @@ struct GcmEntry {            // k_gcm_tag: one GCM segment (this library writes 
 struct ZFrame {
     uint64_t src_off;        // frame start in the compressed buffer
     uint64_t dst_off;        // where its content goes
-    uint32_t src_len;        // bytes of the frame
-    uint32_t dst_len;        // bytes of content it must produce
+    uint64_t src_len;        // bytes of the frame          } 64 bits for zlib streams that are decoded by pieces (k_vinflate); zstd frames and the
+    uint64_t dst_len;        // bytes of content it must produce } wave-per-stream inflate walk take what fits 32 bits (status 2 otherwise)
     uint32_t status;         // out: 0 ok, 1 corrupt, 2 unsupported, 3 size mismatch
-    uint32_t out_len;        // out: bytes produced
+    uint32_t out_len;        // in: flags (ZF_OPEN); out: bytes produced, saturated at 2^32 - 1 (diagnostics)
 };
+static_assert(sizeof(ZFrame) == 40, "ZFrame layout");
 
 // ---- lane-parallel decoder (k_zparse / k_zhuf / k_zfse / k_zoff / k_zexec)
 struct ZFrameX {             // per frame: where its blocks, table slots and sequence records live
     uint64_t seq_base;       // first record of the frame in the sequence scratch
     uint32_t blk_base, blk_cap;      // its region of the block array
     uint32_t slot_base, slot_cap;    // its table slots
-    uint32_t seq_cap;                // records available
+    uint32_t seq_cap;                // records available (saturated at 2^31 - 1)
     uint32_t nblk;                   // out
+    uint32_t pcap, pad;              // k_vinflate: records available to each piece (piece j's start at seq_base + j * pcap)
 };
 struct ZBlock {
     uint64_t body;           // offset of the block body in the compressed buffer
@@ -174,11 +176,11 @@ struct ZBlock {
     uint64_t seq_pos;        // first sequence record (absolute index into the scratch)
     uint32_t size, type;     // body bytes; 0 raw, 1 RLE, 2 compressed
     uint32_t ltype, regen, streams, lit_off, lit_csize;    // literals: section payload (body-relative) behind the tree description
-    uint32_t lit_pos;        // where the block's decoded literals go in the frame's literal scratch (frame-relative)
+    uint32_t lit_pos;        // where the block's decoded literals go in the frame's literal scratch (frame-relative; bits 32.. in pad[2])
     uint32_t huf_slot, slot[3];      // table slots that apply (Huffman; LL, OF, ML)
     uint32_t nseq, seq_off, seq_len; // sequence bitstream (body-relative)
     uint32_t frame, out_len, status, uses_rep;
-    uint32_t pad[7];
+    uint32_t pad[7];         // [0] zstd: last-block bit; [1] inflate: the Adler-32 trailer read with the stream's last piece; [2] lit_pos >> 32
 };
 static_assert(sizeof(ZBlock) == 128, "ZBlock layout");
 struct ZTables {             // one slot

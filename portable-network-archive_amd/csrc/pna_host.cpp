@@ -60,7 +60,7 @@ void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, c
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st);
 void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, hipStream_t st);
-void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint32_t *pb, uint32_t *mode, const uint8_t *src,
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, const uint8_t *src,
                      ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
                    void *part, hipStream_t st);
@@ -2649,15 +2649,16 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     // a handful of pieces is served better by the wave-per-stream walk (a lane needs ~110 ms for a 128 KiB piece, however few there are)
     if (tot_pieces < 1024) lanes = false;
     for (size_t i = 0; i < n; i++) {
-        if (raw_len[i] > 0xFFFFFFFFull || src_len[i] > 0xFFFFFFFFull) return fail(c, PNA_E_UNSUPPORTED, "entries of 4 GiB and more are not decoded on the device");
-        frs[i] = ZFrame{src_off[i], dst_off[i], (uint32_t)src_len[i], (uint32_t)raw_len[i], 0, open ? ZF_OPEN : 0u};   // open: raw_len is a capacity
+        // streams of 4 GiB and more: decoded by pieces (this library's layout: a sync flush behind every 128 KiB); the wave-per-stream walk counts in 32 bits
+        if ((raw_len[i] > 0xFFFFFFFFull || src_len[i] > 0xFFFFFFFFull) && !lanes) return fail(c, PNA_E_UNSUPPORTED, "zlib streams of 4 GiB and more are decoded by sync-flush delimited pieces only");
+        frs[i] = ZFrame{src_off[i], dst_off[i], src_len[i], raw_len[i], 0, open ? ZF_OPEN : 0u};   // open: raw_len is a capacity
         ZFrameX &x = fxs[i];
         const uint64_t P = lanes ? npc[i] : 1;
         const uint64_t pcap = std::min<uint64_t>(raw_len[i], lanes ? BLK_SIZE : raw_len[i]) / 3 + (raw_len[i] >> 16) / P + 16;   // matches are >= 3 bytes; + literal-run splits (serial walk)
         if (nblk + P > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
         x.blk_base = (uint32_t)nblk; x.blk_cap = (uint32_t)P; x.slot_base = 0; x.slot_cap = 0; x.nblk = 0;
-        x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(P * pcap, 0x7FFFFFFFu);
-        nseq_cap += x.seq_cap;
+        x.seq_base = nseq_cap; x.seq_cap = (uint32_t)std::min<uint64_t>(P * pcap, 0x7FFFFFFFu); x.pcap = (uint32_t)std::min<uint64_t>(pcap, 0x7FFFFFFFu); x.pad = 0;
+        nseq_cap += P * pcap;
         if (lanes) for (uint64_t j = 0; j < P; j++) vp.push_back(VPieceH{(uint32_t)i, (uint32_t)j});
         nblk += P;
         out_span = std::max<uint64_t>(out_span, dst_off[i] + raw_len[i]);
@@ -2668,14 +2669,14 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     cbase[n] = (uint32_t)pieces;
     if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk * sizeof(ZBlock)) ||
         c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8) ||
-        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 4 + 8) || c->z_mode.ensure(n * 4 + 8))))
+        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 8 + 8) || c->z_mode.ensure(n * 4 + 8))))
         return fail(c, PNA_E_NOMEM, "decoder workspace");
     HIPCHK(c, hipMemcpyAsync(c->z_frames.p, frs.data(), n * sizeof(ZFrame), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), n * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_cbase.p, cbase.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
     if (lanes) HIPCHK(c, hipMemcpyAsync(c->z_vp.p, vp.data(), vp.size() * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
-    if (lanes) launch_vinflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, c->z_vp.p, (uint32_t)vp.size(), (uint32_t *)c->z_pb.p, (uint32_t *)c->z_mode.p,
+    if (lanes) launch_vinflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, c->z_vp.p, (uint32_t)vp.size(), (uint64_t *)c->z_pb.p, (uint32_t *)c->z_mode.p,
                                (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
     launch_inflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
                    (uint64_t *)c->z_seqs.p, lanes ? (const uint32_t *)c->z_mode.p : nullptr, st);
@@ -2696,8 +2697,8 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     for (size_t i = 0; i < n; i++)
         if (frs[i].status) {
             char msg[160];
-            snprintf(msg, sizeof msg, "entry %zu: %s (produced %u of %u bytes)", i,
-                     frs[i].status == 2 ? "unsupported stream" : (frs[i].status == 3 ? "size mismatch" : "corrupt stream"), frs[i].out_len, frs[i].dst_len);
+            snprintf(msg, sizeof msg, "entry %zu: %s (produced %u of %llu bytes)", i,
+                     frs[i].status == 2 ? "unsupported stream" : (frs[i].status == 3 ? "size mismatch" : "corrupt stream"), frs[i].out_len, (unsigned long long)frs[i].dst_len);
             return fail(c, frs[i].status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
         }
     if (open && raw_out) for (size_t i = 0; i < n; i++) raw_out[i] = frs[i].dst_len;
@@ -2711,7 +2712,6 @@ extern "C" int pna_gpu_inflate_open_device(pna_gpu_ctx *c, const void *d_src, ui
     if (!c || !d_src || !d_dst || !raw_len) return fail(c, PNA_E_INVAL, "null argument");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if (dst_cap > 0xFFFFFFFFull) dst_cap = 0xFFFFFFFFull;
     return inflate_batch_device(c, 1, d_src, &src_off, &src_len, d_dst, &dst_off, &dst_cap, st, true, raw_len);
 }
 
@@ -2844,8 +2844,8 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
             const ZFrame &fr = frs[ents[i].first_frame + f];
             if (fr.status && fr.status != 4) {                    // 4: void slot behind a single frame that holds the whole entry
                 char msg[160];
-                snprintf(msg, sizeof msg, "entry %zu frame %u: %s (produced %u of %u bytes)", i, f,
-                         fr.status == 2 ? "unsupported stream" : (fr.status == 3 ? "size mismatch (foreign multi-frame stream?)" : "corrupt stream"), fr.out_len, fr.dst_len);
+                snprintf(msg, sizeof msg, "entry %zu frame %u: %s (produced %u of %llu bytes)", i, f,
+                         fr.status == 2 ? "unsupported stream" : (fr.status == 3 ? "size mismatch (foreign multi-frame stream?)" : "corrupt stream"), fr.out_len, (unsigned long long)fr.dst_len);
                 return fail(c, fr.status == 2 ? PNA_E_UNSUPPORTED : PNA_E_INVAL, msg);
             }
         }

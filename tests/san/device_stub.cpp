@@ -92,7 +92,7 @@ void launch_zparse(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTa
 void launch_zstreams(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const void *, ZBlock *, const ZFrame *, const ZTables *, const uint8_t *, uint8_t *, uint64_t *, hipStream_t) { nostub("zstreams"); }
 void launch_inflate(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, const uint32_t *, hipStream_t) { nostub("inflate"); }
 void launch_icount(const uint8_t *, const uint64_t *, const uint64_t *, uint32_t, uint32_t *, hipStream_t) { nostub("inflate"); }
-void launch_vinflate(ZFrame *, ZFrameX *, uint32_t, const void *, uint32_t, uint32_t *, uint32_t *, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
+void launch_vinflate(ZFrame *, ZFrameX *, uint32_t, const void *, uint32_t, uint64_t *, uint32_t *, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
 void launch_iadler(ZFrame *, const ZFrameX *, const ZBlock *, uint32_t, const uint32_t *, uint32_t, const uint8_t *, void *, hipStream_t) { nostub("iadler"); }
 void launch_zexec(ZFrame *, const ZFrameX *, uint32_t, ZBlock *, const uint8_t *, const uint8_t *, const uint64_t *, uint8_t *, hipStream_t) { nostub("zexec"); }
 void launch_gcm_tag(const GcmEntry *, uint32_t, uint8_t *, hipStream_t) { nostub("gcm"); }

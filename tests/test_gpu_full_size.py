@@ -201,3 +201,71 @@ def test_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
     buf = arc.tobytes()
     gpu_ctx._check(gpu_ctx._L.pna_gpu_extract_archive_host(gpu_ctx._h, buf, len(buf), None, 0, cb, None))
     assert seen == [(names[0], big, True), (names[1], 3000, True)]
+
+
+@pytest.mark.gpu
+def test_deflate_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
+    """The same file as Compression::Deflate (tests/bats/large_file.bats; flate2::read::ZlibDecoder, lib/src/entry/read.rs:178-179): ONE zlib
+    stream that decodes to more than 4 GiB.  The device decoder takes it by its sync-flush delimited pieces (64-bit stream positions and sizes,
+    the execution pass's 32-bit positions re-based as it goes); Adler-32 over all of it on the device; zlib (the C library) decodes the same
+    stream on the host piece by piece as the independent reader."""
+    gpu_ctx = big_ctx
+    import numpy as np
+    import torch
+    n1, L = 4 * 1024 + 160, 1 << 20
+    big = n1 * L
+    assert big > 1 << 32
+    _need_hbm(torch, 80)
+    src = torch.empty(big + 4096 + 8192, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 9000, n1, L, L, src.data_ptr())
+    gpu_ctx.corpus_fill_device(1, 1, 1, 3000, 3000, src.data_ptr() + big)
+    so, sl = [0, big, big + 3000], [big, 3000]
+    names = ["large/four_gib_and_more.bin", "large/small.txt"]
+    cap = pna.archive_chunked_bound(pna.ALGO_DEFLATE, names, sl, 1 << 30)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    total, eoff = gpu_ctx.create_archive_chunked_device(names, src.data_ptr(), so, sl, dst.data_ptr(), cap, 1 << 30, algo=pna.ALGO_DEFLATE)
+    arc = dst[:total].cpu().numpy()
+    kinds, fdat = [], []
+    for ty, off, ln, crc in _chunks(arc):
+        assert zlib.crc32(arc[off:off + ln].tobytes(), zlib.crc32(ty)) == crc, (ty, off)
+        kinds.append(ty)
+        if ty == b"FDAT":
+            fdat.append((off, ln))
+        if ty == b"fSIZ" and len(kinds) == 3:
+            assert int.from_bytes(arc[off:off + ln].tobytes(), "big") == big and ln == 5
+    assert kinds[:3] == [b"AHED", b"FHED", b"fSIZ"] and kinds[-1] == b"AEND" and kinds.count(b"FHED") == 2
+    big_fdat = fdat[:-1]
+    assert len(big_fdat) >= 2 and all(ln == (1 << 30) for _, ln in big_fdat[:-1]) and 2.2 < big / sum(ln for _, ln in big_fdat) < 3.0
+    # ---- the independent reader: zlib over the whole stream, compared as it comes
+    host_src = src.cpu().numpy()
+    d, pos = zlib.decompressobj(), 0
+    for o, ln in big_fdat:
+        for a in range(o, o + ln, 64 << 20):
+            out = d.decompress(arc[a:min(a + (64 << 20), o + ln)].tobytes())
+            assert np.array_equal(np.frombuffer(out, dtype=np.uint8), host_src[pos:pos + len(out)]), pos
+            pos += len(out)
+    out = d.flush()
+    assert np.array_equal(np.frombuffer(out, dtype=np.uint8), host_src[pos:pos + len(out)]) and pos + len(out) == big and d.eof
+    # ---- the device decoder: every byte, compared in HBM
+    back = torch.zeros(big + 4096 + 64, dtype=torch.uint8, device="cuda")
+    packed = torch.cat([dst[o:o + ln] for o, ln in big_fdat])
+    gpu_ctx.decompress_batch_device(packed.data_ptr(), [0], [packed.numel()], back.data_ptr(), [0], [big], algo=pna.ALGO_DEFLATE)
+    assert torch.equal(back[:big], src[:big])
+    # a damaged byte far behind the 4 GiB mark is found (Adler-32 / the piece's own checks)
+    bad = packed.clone()
+    bad[packed.numel() - 5000] ^= 0x10
+    with pytest.raises(pna.PnaGpuError):
+        gpu_ctx.decompress_batch_device(bad.data_ptr(), [0], [bad.numel()], back.data_ptr(), [0], [big], algo=pna.ALGO_DEFLATE)
+    del back, packed, bad
+    # ---- and through the extract driver
+    seen = []
+
+    def _cb(_u, idx, name, kind, data, ln):
+        lo = so[idx]
+        got = np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_ubyte)), shape=(ln,))
+        seen.append((name.decode(), ln, bool(np.array_equal(got, host_src[lo:lo + ln]))))
+        return 0
+    cb = pna.ENTRY_FN(_cb)
+    buf = arc.tobytes()
+    gpu_ctx._check(gpu_ctx._L.pna_gpu_extract_archive_host(gpu_ctx._h, buf, len(buf), None, 0, cb, None))
+    assert seen == [(names[0], big, True), (names[1], 3000, True)]
