@@ -257,7 +257,7 @@ int  pna_gpu_create_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n
 /* ---- read side (extract / verify): replaces decompress_reader() -> zstd::stream::read::Decoder / flate2::read::ZlibDecoder
  * (lib/src/entry/read.rs:171-190; callers cli/src/command/extract.rs:594-640, verify.rs:140-188).  Entry i's payload (the
  * concatenated FDAT bodies) is decoded to raw_len[i] bytes (the entry's fSIZ).
- *   PNA_ALGO_ZSTD: one or more RFC 8878 frames without dictionary; a multi-frame payload must follow this library's
+ *   PNA_ALGO_ZSTD: one or more RFC 8878 frames without dictionary, offsets up to 2^28 - 4 (windows up to 128 MiB: every libzstd level without --long); a multi-frame payload must follow this library's
  *     segmentation (every frame but the last holds 1 MiB) because frames carry no content size -- single-frame payloads, which
  *     is what the reference writes, always work.
  *   PNA_ALGO_DEFLATE: one RFC 1950 zlib stream (any block types, sync-flush markers, window <= 32 KiB); Adler-32 is verified.

@@ -141,8 +141,9 @@ def libzstd_compress(data: bytes, level: int = 3) -> bytes:
     return buf.raw[:n]
 
 
-def libzstd_compress_checksum(data: bytes, level: int = 3) -> bytes:
-    """One frame WITH Content_Checksum (XXH64 low 32 bits behind the last block) from the system libzstd: test input for the device decoder's check."""
+def libzstd_compress_checksum(data: bytes, level: int = 3, extra=()) -> bytes:
+    """One frame WITH Content_Checksum (XXH64 low 32 bits behind the last block) from the system libzstd: test input for the device decoder's check.
+    `extra`: further (ZSTD_cParameter, value) pairs, e.g. (101, 26) = ZSTD_c_windowLog, (160, 1) = ZSTD_c_enableLongDistanceMatching."""
     Z = system_libzstd()
     Z.ZSTD_createCCtx.restype = ctypes.c_void_p
     Z.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
@@ -152,7 +153,7 @@ def libzstd_compress_checksum(data: bytes, level: int = 3) -> bytes:
     Z.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
     cctx = Z.ZSTD_createCCtx()
     try:
-        for prm, v in ((100, level), (201, 1)):                # ZSTD_c_compressionLevel, ZSTD_c_checksumFlag
+        for prm, v in ((100, level), (201, 1)) + tuple(extra):  # ZSTD_c_compressionLevel, ZSTD_c_checksumFlag
             if Z.ZSTD_isError(Z.ZSTD_CCtx_setParameter(cctx, prm, v)):
                 raise ValueError("libzstd: parameter refused")
         cap = Z.ZSTD_compressBound(len(data))

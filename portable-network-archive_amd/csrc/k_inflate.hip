@@ -22,7 +22,7 @@ constexpr uint32_t IF_HALF = 256;
 constexpr uint32_t IF_PHASE_TOKENS = 128;                  // tokens per phase: at most 48 bits each, 768 bytes < one ring half
 constexpr uint32_t IF_SEQ_STAGE = IF_PHASE_TOKENS, IF_LIT_STAGE = IF_PHASE_TOKENS;
 constexpr uint32_t IF_LSUB = 143, IF_DSUB = 15;            // second-level tables (16 / 32 cells each): a complete code has at most this many long prefixes
-constexpr uint32_t IF_LL_SPLIT = 0x80000;                  // literal runs are cut into records of at most this many bytes (20-bit field)
+constexpr uint32_t IF_LL_SPLIT = 0x20000;                  // literal runs are cut into records of at most this many bytes (18-bit field: zrec_pack)
 constexpr uint32_t IF_ADLER_PIECE = 65536, IF_ADLER_P = 65521;
 
 enum { IST_ZHEAD = 0, IST_BLOCK = 1, IST_CODES = 2, IST_TRAILER = 3, IST_DONE = 4 };
@@ -251,7 +251,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
                 if (sym < 256) {
                     if (l0) lstage[nl] = (uint8_t)sym;
                     nl++;
-                    if (++ll == IF_LL_SPLIT) { if (l0) sstage[nq] = (uint64_t)IF_LL_SPLIT | (4ull << 40); nq++; ll = 0; }
+                    if (++ll == IF_LL_SPLIT) { if (l0) sstage[nq] = zrec_pack(IF_LL_SPLIT, 0, 4); nq++; ll = 0; }
                     if (bitcnt <= 32) { bitbuf |= (uint64_t)w << bitcnt; bitcnt += 32; wi++; }
                     continue;
                 }
@@ -274,7 +274,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
                 uint32_t dist;
                 if (ds < 4) dist = 1 + ds;
                 else { const uint32_t eb = (ds >> 1) - 1; dist = 1 + ((2 + (ds & 1)) << eb) + take(eb); }
-                if (l0) sstage[nq] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)(dist + 3) << 40);
+                if (l0) sstage[nq] = zrec_pack(ll, ml, dist + 3);
                 nq++; mtot += ml; ll = 0;
                 if (bitcnt <= 32) { bitbuf |= (uint64_t)w2 << bitcnt; bitcnt += 32; wi++; }
             }
@@ -310,7 +310,7 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
             nlit_tot += len; ll += len;
             if (ll >= IF_LL_SPLIT) {
                 if (nseq_tot + 1 > seq_cap) { status = IF_UNSUPPORTED; break; }
-                if (l0) rec_out[nseq_tot] = (uint64_t)IF_LL_SPLIT | (4ull << 40);
+                if (l0) rec_out[nseq_tot] = zrec_pack(IF_LL_SPLIT, 0, 4);
                 nseq_tot++; ll -= IF_LL_SPLIT;
             }
             // re-seat the reader behind the stored bytes
@@ -686,7 +686,7 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
                 if (ds < 4) dist = 1 + ds;
                 else { const uint32_t eb = (ds >> 1) - 1; refill(); dist = 1 + ((2 + (ds & 1)) << eb) + take(eb); }
                 if (nseq >= pcap || (uint64_t)nlit + mtot + ml > expect) { status = nseq >= pcap ? IF_UNSUPPORTED : IF_DSTSIZE; state = S_DONE; break; }
-                rec_out[nseq++] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)(dist + 3) << 40);
+                rec_out[nseq++] = zrec_pack(ll, ml, dist + 3);
                 mtot += ml; ll = 0;
             }
         } else if (state == S_TRAILER) {

@@ -166,7 +166,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     __shared__ int16_t  norm[256];
     __shared__ uint16_t nexts[256];
     __shared__ ZdBlk    B;
-    __shared__ uint64_t sq[ZD_BATCH];                  // ll | ml << 20 | resolved offset << 40
+    __shared__ uint64_t sq[ZD_BATCH];                  // zrec_pack(ll, ml, resolved offset)
     __shared__ uint32_t wtab[64];                      // weight-decoding table (alog <= 6)
     __shared__ uint64_t stage64[ZD_STAGE_W];           // LDS copy of the stream(s) being decoded (8-byte aligned starts)
     __shared__ uint32_t s_nb, s_ok[3], s_alog[3], s_huf_ok, s_hufbits, s_err, s_op, s_rep[3];
@@ -461,7 +461,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                         const uint64_t ofv = ((uint64_t)1 << ofc) + zd_wread(bw, fq, ofc);
                         const uint32_t ml = ZD_ML_BASE[mlc] + (uint32_t)zd_wread(bw, fq, ZD_ML_BITS[mlc]);
                         const uint32_t ll = ZD_LL_BASE[llc] + (uint32_t)zd_wread(bw, fq, ZD_LL_BITS[llc]);
-                        if (bw.off < 0 || ofv > 0xFFFFFFu) { okq = false; break; }
+                        if (bw.off < 0 || ofv > ZREC_OF_MAX) { okq = false; break; }
                         if (base + i + 1 < b.nseq) {
                             sll = (cl >> 16) + (uint32_t)zd_wread(bw, fq, (cl >> 8) & 0xFF);
                             sml = (cm >> 16) + (uint32_t)zd_wread(bw, fq, (cm >> 8) & 0xFF);
@@ -480,7 +480,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                                 rep1 = rep0; rep0 = offset;
                             }
                         }
-                        sq[i] = (uint64_t)ll | ((uint64_t)ml << 20) | ((uint64_t)offset << 40);
+                        sq[i] = zrec_pack(ll, ml, offset);
                     }
                     if (okq && base + nb == b.nseq && bw.off != 0) okq = false;
                     s_nb = okq ? 1u : 0u;
@@ -491,7 +491,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                 if (dbg & 1) continue;
                 const bool act = lane < nb;
                 const uint64_t sv = act ? sq[lane] : 0;
-                const uint32_t ll = (uint32_t)(sv & 0xFFFFF), ml = (uint32_t)((sv >> 20) & 0xFFFFF), offset = (uint32_t)(sv >> 40);
+                const uint32_t ll = zrec_ll(sv), ml = zrec_ml(sv), offset = zrec_of(sv);
                 uint32_t incl = ll + ml, lincl = ll;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
@@ -985,7 +985,7 @@ void k_zfse(const uint32_t *__restrict__ seq_list, const ZWork *__restrict__ wor
                 const uint32_t e2 = (uint32_t)zd_wread(bw, fetch, nm + nl);
                 const uint32_t ml = t_mlb[mlc] + (e2 >> nl);
                 const uint32_t ll = t_llb[llc] + (e2 & ((1u << nl) - 1));
-                if (bw.off < 0 || ofv > 0xFFFFFFu) { ok = false; break; }
+                if (bw.off < 0 || ofv > ZREC_OF_MAX) { ok = false; break; }
                 if (k + 1 < b.nseq) {
                     const uint32_t bl = (cl >> 8) & 0xFF, bm = (cm >> 8) & 0xFF, bo = (co >> 8) & 0xFF;
                     const uint32_t e3 = (uint32_t)zd_wread(bw, fetch, bl + bm + bo);
@@ -995,7 +995,7 @@ void k_zfse(const uint32_t *__restrict__ seq_list, const ZWork *__restrict__ wor
                     if (bw.off < 0) { ok = false; break; }
                 }
                 if (ofv <= 3) uses_rep = 1;
-                rbuf[lane][k & 7] = (uint64_t)ll | ((uint64_t)ml << 20) | (ofv << 40);
+                rbuf[lane][k & 7] = zrec_pack(ll, ml, ofv);
                 total += ml;
                 if ((k & 7) == 7 || k + 1 == b.nseq) {
                     const uint32_t k0 = k & ~7u;
@@ -1036,7 +1036,7 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
     if (fr.status) return;
     const ZFrameX x = fx[f];
     // Positions below count in 32 bits from `out`.  For frames below 2 GiB that is the frame's start; further on the base follows the blocks
-    // 2 GiB behind (a block is at most 128 KiB, a reference reaches back less than 2^24: both stay in range, and the test `offset > o0 + ll`
+    // 2 GiB behind (a block is at most 128 KiB, a reference reaches back less than 2^28: both stay in range, and the test `offset > o0 + ll`
     // cannot fail there, as it must not).  Frames of 4 GiB and more: zlib streams decoded by pieces (k_vinflate).
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool okq = true;
@@ -1061,7 +1061,7 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
             const uint32_t nb = b.nseq - base < 64 ? b.nseq - base : 64u;
             const bool act = lane < nb;
             const uint64_t sv = act ? rec[base + lane] : 0;
-            const uint32_t ll = (uint32_t)(sv & 0xFFFFF), ml = (uint32_t)((sv >> 20) & 0xFFFFF), ofv = (uint32_t)(sv >> 40);
+            const uint32_t ll = zrec_ll(sv), ml = zrec_ml(sv), ofv = zrec_of(sv);
             // ---- offsets: without repeat codes in the batch every offset is its own value - 3 and the history is simply
             // the last three offsets; otherwise lane order has to be walked
             uint32_t offset = ofv - 3;

@@ -195,6 +195,14 @@ struct ZEntry {              // k_zscan input: one compressed entry
     uint32_t first_frame, n_frames;
     uint32_t open, pad;          // open != 0: raw_len is only a capacity -- the last frame's size is found by decoding (streams without fSIZ: solid)
 };
+// Decoder records (k_zfse / k_zdec / k_inflate / k_vinflate -> k_zexec): literal run (18 bits: a zstd block and an inflate piece hold at most 128 KiB) |
+// match length << 18 (18 bits: zstd's longest is 131 074) | offset value << 36 (28 bits: offset + 3 -- 1 .. 3 are zstd's repeat codes --; libzstd's
+// largest window without --long, level 22's 128 MiB, fits).
+constexpr uint64_t ZREC_OF_MAX = 0xFFFFFFFull;
+__host__ __device__ inline uint64_t zrec_pack(uint32_t ll, uint32_t ml, uint64_t ofv) { return (uint64_t)ll | ((uint64_t)ml << 18) | (ofv << 36); }
+__host__ __device__ inline uint32_t zrec_ll(uint64_t s) { return (uint32_t)(s & 0x3FFFF); }
+__host__ __device__ inline uint32_t zrec_ml(uint64_t s) { return (uint32_t)((s >> 18) & 0x3FFFF); }
+__host__ __device__ inline uint32_t zrec_of(uint64_t s) { return (uint32_t)(s >> 36); }
 constexpr uint32_t ZF_OPEN = 0x80000000u;   // ZFrame.out_len on input: dst_len is a capacity, the decoder writes the size it found back to dst_len
 
 } // namespace pna

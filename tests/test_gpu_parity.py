@@ -1386,3 +1386,23 @@ def test_zstd_content_checksum_is_verified(gpu_ctx, pna, codec):
         with gpu_ctx.options(zdec_serial=(1, 0)):
             with pytest.raises(pna.PnaGpuError):
                 gpu_ctx.decompress_batch(bad, lens)
+
+
+def test_zstd_frames_with_offsets_beyond_16_mib(gpu_ctx, pna, codec):
+    """A foreign frame whose matches reach further back than 16 MiB (libzstd with a 64 MiB window and long-distance matching; the reference's
+    `--zstd 20..22` on large entries: lib/src/compress/zstandard.rs:43-57 passes the level through, ultra levels take windows of 32 - 128 MiB):
+    the decoder's records hold offsets of 28 bits.  Both decode paths; the frame is checked to hold such an offset by decoding it with a
+    window of 16 MiB in the model decoder's terms: the second copy of the first 2 MiB lies 40 MiB behind the first."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frame) is absent")
+    import numpy as np
+    rng = np.random.default_rng(77)
+    head = rng.integers(0, 256, size=40 << 20, dtype=np.uint8).tobytes()
+    raw = head + head[:2 << 20] + codec.corpus_file(0, 8200, 100000)
+    comp = codec.libzstd_compress_checksum(raw, 3, extra=((101, 26), (160, 1)))
+    assert len(comp) < len(head) + (1 << 20)                                     # the repeat was found: it costs a few hundred bytes, not 2 MiB
+    assert codec.libzstd_decompress_stream(comp, len(raw)) == raw
+    assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
+    with gpu_ctx.options(zdec_serial=(1, 0)):
+        assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
+
