@@ -175,9 +175,15 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     ZFrame fr = frames[blockIdx.x];
     const uint8_t *in = src + fr.src_off;
     uint8_t *out = dst + fr.dst_off;
-    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;      // (zstd frames of 4 GiB and more never get here: k_zscan)
+    // Positions (ip, op) count in 32 bits from `in` / `out`; for a frame of 4 GiB and more (one frame per entry is what the reference writes,
+    // whatever the entry's size: tests/bats/large_file.bats) both bases move along at block boundaries -- the input's to the block, the output's
+    // to 2 GiB behind it (offsets are below 2^28) --, in_len and cap are what is left from there, saturated.
+    uint64_t in_left = fr.src_len, cap_left = fr.dst_len, out_base = 0;
+    uint32_t in_len = (uint32_t)(in_left < 0xFFFFFFFFull ? in_left : 0xFFFFFFFFull), cap = (uint32_t)(cap_left < 0xFFFFFFFFull ? cap_left : 0xFFFFFFFFull);
     const bool open = (fr.out_len & ZF_OPEN) != 0;                     // cap is only a capacity
     uint32_t ip = 0, op = 0;
+    // (dbg & 8: the bases move every few MiB instead of every few GiB, for frames with windows of at most 8 MiB -- the test of this logic)
+    const uint32_t rb_in = (dbg & 8) ? (1u << 16) : (1u << 30), rb_hi = (dbg & 8) ? (3u << 22) : (3u << 30), rb_keep = (dbg & 8) ? (1u << 23) : (1u << 31);
     uint32_t status = ZD_OK;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     if (tid == 0) { s_ok[0] = s_ok[1] = s_ok[2] = 0; s_huf_ok = 0; s_err = 0; }
@@ -201,7 +207,7 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
                     uint64_t fcs = 0;
                     for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
                     if (fsz == 2) fcs += 256;
-                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
+                    if (fsz && (open ? fcs > fr.dst_len : fcs != fr.dst_len)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
                 if ((fhd >> 2) & 1) { /* content checksum: 4 bytes after the last block, verified by k_zxxh once the content is there */ }
@@ -213,6 +219,11 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
     if (fr.status) status = fr.status;                                 // set by the scan
     bool done = status != ZD_OK;
     while (!done) {
+        if (ip > rb_in) { in += ip; in_left -= ip; ip = 0; in_len = (uint32_t)(in_left < 0xFFFFFFFFull ? in_left : 0xFFFFFFFFull); }
+        if (op > rb_hi) {
+            const uint32_t shift = op - rb_keep;
+            out += shift; out_base += shift; cap_left -= shift; op -= shift; cap = (uint32_t)(cap_left < 0xFFFFFFFFull ? cap_left : 0xFFFFFFFFull);
+        }
         // ================= thread 0: headers, weights, distributions
         if (tid == 0) {
             ZdBlk b; b.status = ZD_OK; b.new_tree = 0; b.nseq = 0; b.regen = 0; b.ltype = 0; b.streams = 1; b.lit_off = 0; b.lit_csize = 0;
@@ -554,8 +565,12 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
         __syncthreads();
         if (b.last) break;
     }
-    if (status == ZD_OK && op != cap && !dbg && !open) status = ZD_DSTSIZE;
-    if (tid == 0) { frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = op; if (open && status == ZD_OK) frames[blockIdx.x].dst_len = op; }
+    const uint64_t produced = out_base + op;
+    if (status == ZD_OK && produced != fr.dst_len && !(dbg & 7) && !open) status = ZD_DSTSIZE;
+    if (tid == 0) {
+        frames[blockIdx.x].status = status; frames[blockIdx.x].out_len = (uint32_t)(produced < 0xFFFFFFFFull ? produced : 0xFFFFFFFFull);
+        if (open && status == ZD_OK) frames[blockIdx.x].dst_len = produced;
+    }
 }
 
 // =====================================================================================================================
@@ -1193,19 +1208,30 @@ __device__ uint64_t zscan_frame_end(const uint8_t *p, uint64_t ip, uint64_t len)
     return q > len ? 0 : q;
 }
 
-__global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8_t *__restrict__ src, ZFrame *__restrict__ frames) {
+__global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8_t *__restrict__ src, ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const ZEntry en = ents[e];
     const uint8_t *p = src + en.src_off;
     const uint64_t len = en.src_len;
     const uint32_t nfr = en.n_frames;
-    // ONE frame that holds the whole entry, however large (what the reference writes: libzstd streaming, one frame per entry): it
-    // gets all of raw_len and goes to the one-workgroup-per-frame kernel (the bounded per-frame resources are sized for SEG_SIZE);
-    // the other frame slots planned for the entry are void
+    // ONE frame that holds the whole entry, however large (what the reference writes: libzstd streaming, one frame per entry): it gets all of
+    // raw_len and -- below 4 GiB -- all the block descriptors, table slots and sequence records planned for the entry's frames (their regions are
+    // contiguous), so that its blocks are decoded side by side like those of many small frames (k_zparse .. k_zexec: a 64 MiB frame 10.7 MiB/s on
+    // the one-workgroup kernel).  A frame of 4 GiB and more, or one that still does not fit (k_zparse finds out), goes to that kernel.  The other
+    // frame slots planned for the entry are void.
     if (nfr > 1 && zscan_frame_end(p, 0, len) == len) {
         ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = len; fr.out_len = en.open ? ZF_OPEN : 0u;
-        fr.dst_len = en.raw_len; fr.status = (en.raw_len > 0xFFFFFFFFull || len > 0xFFFFFFFFull) ? 1u : 2u;
+        fr.dst_len = en.raw_len; fr.status = 2u;
+        if (len <= 0xFFFFFFFFull && en.raw_len <= 0xFFFFFFFFull && fx) {
+            ZFrameX x = fx[en.first_frame];
+            uint64_t nb = 0, ns = 0, nq = 0;
+            for (uint32_t g = 0; g < nfr; g++) { const ZFrameX y = fx[en.first_frame + g]; nb += y.blk_cap; ns += y.slot_cap; nq += y.seq_cap; }
+            x.blk_cap = (uint32_t)(nb < 0x7FFFFFFFull ? nb : 0x7FFFFFFFull); x.slot_cap = (uint32_t)(ns < 0x7FFFFFFFull ? ns : 0x7FFFFFFFull);
+            x.seq_cap = (uint32_t)(nq < 0x7FFFFFFFull ? nq : 0x7FFFFFFFull);
+            fx[en.first_frame] = x;
+            fr.status = 0u;
+        }
         frames[en.first_frame] = fr;
         fr.src_len = 0; fr.dst_len = 0; fr.status = 4;              // ZD_VOID
         for (uint32_t g = 1; g < nfr; g++) frames[en.first_frame + g] = fr;
@@ -1246,8 +1272,8 @@ void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t 
     if (n) hipLaunchKernelGGL(k_zcount, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, counts);
 }
 
-void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_zscan, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, frames);
+void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, ZFrameX *fx, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zscan, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, frames, fx);
 }
 
 // ------------------------------------------------------------------ k_zxxh : Content_Checksum (RFC 8878 3.1.1: the low 32 bits of XXH64(content, seed 0))
@@ -1300,7 +1326,7 @@ void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *
 }
 
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st) {
-    const char *e = getenv("PNA_ZDEC_DBG");                     // diagnostics: 1 skip execution, 2 skip sequences, 4 skip Huffman streams
+    const char *e = getenv("PNA_ZDEC_DBG");                     // diagnostics: 1 skip execution, 2 skip sequences, 4 skip Huffman streams, 8 small re-base distances
     if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst, lit_scratch, e ? (uint32_t)atoi(e) : 0u);
 }
 

@@ -9,6 +9,7 @@ sampled comparisons with the oracle:
 Reference behaviour matched: cli/src/command/create.rs:594-623 (solid create), tests/bats/large_file.bats (sizes beyond 4 GiB).
 """
 import ctypes
+import os
 import struct
 import zlib
 
@@ -269,3 +270,49 @@ def test_deflate_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
     buf = arc.tobytes()
     gpu_ctx._check(gpu_ctx._L.pna_gpu_extract_archive_host(gpu_ctx._h, buf, len(buf), None, 0, cb, None))
     assert seen == [(names[0], big, True), (names[1], 3000, True)]
+
+
+@pytest.mark.gpu
+def test_one_foreign_zstd_frame_beyond_4gib(big_ctx, pna, pf, codec):
+    """What the reference writes for a file of more than 4 GiB (tests/bats/large_file.bats; zstd::stream::write::Encoder, lib/src/compress.rs:32-41):
+    ONE zstd frame, however large the entry.  The writer here is the system libzstd (one ZSTD_compress call: a single frame with an 8-byte
+    Frame_Content_Size); the device decoder takes the frame on one workgroup, its 32-bit positions re-based as it goes, and every byte is compared
+    in HBM; a flipped bit behind the 4 GiB mark of the content is found."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frame) is absent")
+    if os.environ.get("PNA_TEST_HUGE_FRAME") != "1":
+        pytest.skip("one workgroup decodes the 4 GiB frame at ~11 MiB/s (6 - 7 minutes): run with PNA_TEST_HUGE_FRAME=1; the moving bases are covered by "
+                    "test_one_workgroup_decoder_moves_its_bases, frames below 4 GiB by test_one_large_foreign_zstd_frame")
+    gpu_ctx = big_ctx
+    import numpy as np
+    import torch
+    n1, L = 4 * 1024 + 48, 1 << 20
+    big = n1 * L
+    assert big > 1 << 32
+    _need_hbm(torch, 40)
+    src = torch.empty(big + 4096, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 9500, n1, L, L, src.data_ptr())
+    Z = codec.system_libzstd()
+    host = src[:big].cpu().numpy()
+    cap = Z.ZSTD_compressBound(big)
+    buf = np.empty(cap, dtype=np.uint8)
+    n = Z.ZSTD_compress(buf.ctypes.data, cap, ctypes.c_char_p(host.ctypes.data), big, 1)
+    assert not Z.ZSTD_isError(n) and n < big // 2
+    fhd = int(buf[4])
+    assert (fhd >> 6) == 3                                                       # Frame_Content_Size of 8 bytes (behind the window descriptor, if any)
+    fcs_at = 5 + (0 if (fhd >> 5) & 1 else 1)
+    assert int.from_bytes(buf[fcs_at:fcs_at + 8].tobytes(), "little") == big
+    del host
+    comp = torch.from_numpy(buf[:n]).cuda()
+    back = torch.zeros(big + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(comp.data_ptr(), [0], [n], back.data_ptr(), [0], [big])
+    assert torch.equal(back[:big], src[:big])
+    bad = comp.clone()
+    bad[n - 70000] ^= 0x04
+    back.zero_()
+    try:
+        gpu_ctx.decompress_batch_device(bad.data_ptr(), [0], [n], back.data_ptr(), [0], [big])
+        same = torch.equal(back[:big], src[:big])                                # (a flipped literal bit may still decode: then the content differs)
+    except pna.PnaGpuError:
+        same = False
+    assert not same

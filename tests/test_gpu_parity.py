@@ -1406,3 +1406,52 @@ def test_zstd_frames_with_offsets_beyond_16_mib(gpu_ctx, pna, codec):
     with gpu_ctx.options(zdec_serial=(1, 0)):
         assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
 
+
+
+def _libzstd_one_frame(codec, raw, level=3):
+    import numpy as np
+    Z = codec.system_libzstd()
+    host = np.frombuffer(raw, dtype=np.uint8)
+    cap = Z.ZSTD_compressBound(host.size)
+    buf = np.empty(cap, dtype=np.uint8)
+    n = Z.ZSTD_compress(buf.ctypes.data, cap, raw, host.size, level)
+    assert not Z.ZSTD_isError(n)
+    return buf[:n].tobytes()
+
+
+def test_one_large_foreign_zstd_frame(gpu_ctx, pna, codec):
+    """What the reference writes for a large file: ONE frame (zstd::stream::write::Encoder, lib/src/compress.rs:32-41) -- here 96 MiB from the
+    system libzstd.  The frame gets the descriptors, table slots and record space planned for the entry (k_zscan) and its 768 blocks are decoded
+    side by side (k_zparse .. k_zexec); the one-workgroup kernel decodes the same frame when asked to (zdec_serial)."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frame) is absent")
+    raw = b"".join(codec.corpus_file(i % 3, 8300 + i, 1 << 20) for i in range(96))
+    comp = _libzstd_one_frame(codec, raw)
+    assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
+    t = gpu_ctx.timing()
+    small = codec.corpus_file(0, 8299, 70000)
+    assert gpu_ctx.decompress_batch([comp, _libzstd_one_frame(codec, small)], [len(raw), len(small)]) == [raw, small]
+    bad = bytearray(comp); bad[len(bad) // 2] ^= 0x40
+    try:
+        assert gpu_ctx.decompress_batch([bytes(bad)], [len(raw)]) != [raw]
+    except pna.PnaGpuError:
+        pass
+    assert t is not None
+
+
+def test_one_workgroup_decoder_moves_its_bases(gpu_ctx, pna, codec, monkeypatch):
+    """k_zdec counts positions in 32 bits from bases that follow the frame (frames of 4 GiB and more: test_one_foreign_zstd_frame_beyond_4gib,
+    minutes at one workgroup's speed).  PNA_ZDEC_DBG=8 moves the bases every few MiB instead of every few GiB: a 24 MiB libzstd frame (window
+    2 MiB) crosses them a dozen times and decodes to the same bytes."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frame) is absent")
+    raw = b"".join(codec.corpus_file(i % 3, 8400 + i, 1 << 20) for i in range(24))
+    comp = _libzstd_one_frame(codec, raw)
+    monkeypatch.setenv("PNA_ZDEC_DBG", "8")
+    with gpu_ctx.options(zdec_serial=(1, 0)):
+        assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
+        bad = bytearray(comp); bad[-3000] ^= 0x01
+        try:
+            assert gpu_ctx.decompress_batch([bytes(bad)], [len(raw)]) != [raw]
+        except pna.PnaGpuError:
+            pass
