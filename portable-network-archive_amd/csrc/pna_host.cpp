@@ -177,6 +177,7 @@ struct pna_gpu_ctx {
     bool call_lazy2 = false;                         // two-step lazy deferral (FLAG_LAZY2 of the LZ kernels)
     bool call_gtab = false, call_w32 = false;       // ... and where the match finder's table lies / its LDS geometry (set_call_level)
     std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
+    std::vector<uint8_t> lzm_nl;                            // launches inside each pair (2 where a run's last segments go in units)
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
@@ -687,7 +688,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         hipEvent_t e1 = nullptr;
         if (timed) {
             while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
-            HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2;
+            HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2; c->lzm_nl.push_back(1);
         }
         const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};            // the parse kernel: one wave per block of the run
         // The match kernel runs one workgroup per segment and CU, all of equal length: a run of 3 334 segments is 13 full rounds of the 256 CUs and a 14th for
@@ -712,6 +713,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
                 launch_lz(d_src, du, (uint32_t)nu, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st,
                           (uint32_t *)c->pbuf.p, b0, e1, nullptr, &pg);                                 // the rest in units, then the parse kernel over the whole run
                 c->tail_used += nu;
+                if (timed) c->lzm_nl.back() = 2;                               // (the pair of events spans both launches of the match kernel)
             }
         }
         if (!R)
@@ -755,7 +757,7 @@ static int collect_timing(pna_gpu_ctx *c, bool defl, int nch, uint32_t nseg, uin
     }
     c->timing.ms_lz += ms[0]; c->timing.ms_stats += ms[1]; c->timing.ms_lit += ms[2]; c->timing.ms_seq += ms[3];
     c->timing.ms_pack += ms[4] + ms[5];
-    for (size_t i = 0; i + 1 < c->lzm_used; i += 2) { float m = 0; (void)hipEventElapsedTime(&m, c->lzm_ev[i], c->lzm_ev[i + 1]); c->timing.ms_lz_match += m; c->timing.lz_match_launches++; }
+    for (size_t i = 0; i + 1 < c->lzm_used; i += 2) { float m = 0; (void)hipEventElapsedTime(&m, c->lzm_ev[i], c->lzm_ev[i + 1]); c->timing.ms_lz_match += m; c->timing.lz_match_launches += i / 2 < c->lzm_nl.size() ? c->lzm_nl[i / 2] : 1u; }
     c->timing.n_segments += nseg; c->timing.n_blocks += nblk;
     return PNA_OK;
 }
@@ -859,7 +861,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         HIPCHK(c, hipMemcpyAsync(dp, hp, plan_bytes, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->blk.p, 0, blk_bytes, st));                     // BlkInfo of every block and, behind them, the segments' histogram counters
     }
-    c->lzm_used = 0;
+    c->lzm_used = 0; c->lzm_nl.clear();
     const bool defl = algo == PNA_ALGO_DEFLATE;
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
