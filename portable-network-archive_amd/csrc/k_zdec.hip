@@ -1042,6 +1042,15 @@ __global__ void k_zoff(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ 
     else if (total != frames[f].dst_len) frames[f].status = ZD_DSTSIZE;
 }
 
+// the low n (0 .. 8 and more = 8) bytes of v to p: one 8-byte store, or 4 + 2 + 1 (unaligned accesses)
+typedef uint32_t __attribute__((aligned(1))) zd_u32u;
+typedef uint16_t __attribute__((aligned(1))) zd_u16u;
+__device__ __forceinline__ void zx_store_upto8(uint8_t *p, uint64_t v, uint32_t n) {
+    if (n >= 8) { *(zd_u64u *)p = v; return; }
+    if (n & 4) { *(zd_u32u *)p = (uint32_t)v; p += 4; v >>= 32; }
+    if (n & 2) { *(zd_u16u *)p = (uint16_t)v; p += 2; v >>= 16; }
+    if (n & 1) *p = (uint8_t)v;
+}
 // ------------------------------------------------------------------ k_zexec : one wave per frame, blocks in order
 __global__ __launch_bounds__(64)
 void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src,
@@ -1112,12 +1121,21 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
                 const uint32_t ls = ll < 32 ? ll : 32u;
                 if (b.ltype == 1) { for (uint32_t i = 0; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = lit_raw[0]; }
                 else {
-                    // eight bytes per step while eight remain (unaligned 64-bit accesses), single bytes for the rest
+                    // All the loads, then the stores: up to four 8-byte pieces (unaligned 64-bit accesses), the last, partial one read whole where the
+                    // block's literals reach that far (byte by byte at their very end) and stored as 4 + 2 + 1 bytes.  A load waited for per piece and per
+                    // tail byte, as before, was what a batch of 64 sequences took its ~10 us for: one wave sees the memory latency undiluted.
                     const uint8_t *ls_src = (b.ltype == 0 ? lit_raw : lit_dec) + l0;
-                    uint32_t i = 0;
-                    for (; __ballot(i + 8 <= ls); i += 8) if (i + 8 <= ls) *(zd_u64u *)(out + o0 + i) = *(const zd_u64u *)(ls_src + i);
-                    i = ls & ~7u;
-                    for (; __ballot(i < ls); i++) if (i < ls) out[o0 + i] = ls_src[i];
+                    uint64_t q[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        q[k] = 0;
+                        if (8 * k < ls) {
+                            if (l0 + 8 * k + 8 <= b.regen) q[k] = *(const zd_u64u *)(ls_src + 8 * k);
+                            else for (uint32_t t = 0; t < 8 && 8 * k + t < ls; t++) q[k] |= (uint64_t)ls_src[8 * k + t] << (8 * t);
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) zx_store_upto8(out + o0 + 8 * k, q[k], ls > 8 * k ? ls - 8 * k : 0u);
                 }
                 uint64_t longm = __ballot(ll > 32);
                 while (longm) {
@@ -1137,12 +1155,28 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
                 const bool ready = pending && src_end <= frontier;
                 const bool shortr = ready && ml <= 32;
                 {
-                    // distance >= 8: eight bytes per step; closer matches copy byte by byte (they read what they just wrote)
-                    const bool wide = shortr && offset >= 8;
+                    // source and destination apart (offset >= length: most matches): all the loads, then the stores, as for the literals (bytes behind the
+                    // source's end may be in the making: they are read and dropped; the read stays inside the frame)
+                    const bool apart = shortr && offset >= ml;
+                    if (__ballot(apart)) {
+                        uint64_t q[4];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            q[k] = 0;
+                            if (apart && 8 * k < ml) {
+                                if ((uint64_t)m0 + 8 * k + 8 <= cap) q[k] = *(const zd_u64u *)(out + m0 + 8 * k);
+                                else for (uint32_t t = 0; t < 8 && 8 * k + t < ml; t++) q[k] |= (uint64_t)out[m0 + 8 * k + t] << (8 * t);
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) zx_store_upto8(out + dstp + 8 * k, q[k], apart && ml > 8 * k ? ml - 8 * k : 0u);
+                    }
+                    // overlapping: distance >= 8: eight bytes per step; closer matches copy byte by byte (they read what they just wrote)
+                    const bool lap = shortr && !apart, wide = lap && offset >= 8;
                     uint32_t i = 0;
                     for (; __ballot(wide && i + 8 <= ml); i += 8) if (wide && i + 8 <= ml) *(zd_u64u *)(out + dstp + i) = *(const zd_u64u *)(out + m0 + i);
                     i = wide ? (ml & ~7u) : 0u;
-                    for (; __ballot(shortr && i < ml); i++) if (shortr && i < ml) out[dstp + i] = out[m0 + i];
+                    for (; __ballot(lap && i < ml); i++) if (lap && i < ml) out[dstp + i] = out[m0 + i];
                 }
                 uint64_t longm = __ballot(ready && ml > 32);
                 while (longm) {
