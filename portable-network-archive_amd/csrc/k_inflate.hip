@@ -430,44 +430,73 @@ enum { VM_PIECES = 0, VM_SERIAL = 1 };
 
 struct VPiece { uint32_t frame, j; };
 
-// ---- k_imark: one workgroup per stream: piece boundaries.  pb[blk_base + f + j] = start of piece j (relative to the stream, 64 bits), pb[... + P] = end.
+// ---- k_imark_*: piece boundaries.  pb[blk_base + f + j] = start of piece j (relative to the stream, 64 bits), pb[... + P] = end.  G workgroups per
+// stream (G from the batch's longest stream: one workgroup scanned a 1 GiB stream's 400 MB for 1.27 s), each over its share of the bytes: a counting pass,
+// then -- every workgroup sums the counts in front of it -- the placing pass.
+__device__ __forceinline__ bool if_marker(const uint8_t *p, uint64_t i, uint64_t n) { return i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF; }
 __global__ __launch_bounds__(256)
-void k_imark(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint64_t *__restrict__ pb,
-             uint32_t *__restrict__ mode) {
+void k_imark_count(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint32_t *__restrict__ cntg, uint32_t G) {
     __shared__ uint32_t cnt[256];
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    if (fx[f].blk_cap <= 1) return;
     const ZFrame fr = frames[f];
-    const uint32_t P = fx[f].blk_cap, base = fx[f].blk_base + f;          // P + 1 boundary slots per stream
-    if (P <= 1) { if (tid == 0) { pb[base] = 0; pb[base + 1] = fr.src_len; mode[f] = VM_PIECES; } return; }
     const uint8_t *p = src + fr.src_off;
-    const uint64_t n = fr.src_len, per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
+    const uint64_t n = fr.src_len, per_g = (n + G - 1) / G, g0 = per_g * g < n ? per_g * g : n, g1 = g0 + per_g < n ? g0 + per_g : n;
+    const uint64_t per = (g1 - g0 + 255) / 256, a = g0 + tid * per < g1 ? g0 + tid * per : g1, e = a + per < g1 ? a + per : g1;
     uint32_t c = 0;
-    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
-    cnt[tid] = c;
-    __syncthreads();
-    if (tid == 0) { uint32_t r = 0; for (uint32_t i = 0; i < 256; i++) { const uint32_t t = cnt[i]; cnt[i] = r; r += t; } mode[f] = r == P - 1 ? VM_PIECES : VM_SERIAL; pb[base] = 0; pb[base + P] = n; }
-    __syncthreads();
-    if (mode[f] != VM_PIECES) return;
-    uint32_t k = cnt[tid];
-    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) { pb[base + 1 + k] = i + 4; k++; }
-}
-
-// ---- k_icount: sync-flush markers per stream (streams of unknown size: the host sizes the piece list from it)
-__global__ __launch_bounds__(256)
-void k_icount(const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint64_t *__restrict__ len, uint32_t *__restrict__ count) {
-    __shared__ uint32_t cnt[256];
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    const uint8_t *p = src + off[f];
-    const uint64_t n = len[f], per = (n + 255) / 256, a = tid * per, e = a + per < n ? a + per : n;
-    uint32_t c = 0;
-    for (uint64_t i = a; i < e; i++) if (i + 4 <= n && p[i] == 0 && p[i + 1] == 0 && p[i + 2] == 0xFF && p[i + 3] == 0xFF) c++;
+    for (uint64_t i = a; i < e; i++) if (if_marker(p, i, n)) c++;
     cnt[tid] = c;
     __syncthreads();
     for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) cnt[tid] += cnt[tid + s2]; __syncthreads(); }
-    if (tid == 0) count[f] = cnt[0];
+    if (tid == 0) cntg[(size_t)f * G + g] = cnt[0];
 }
-void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_icount, dim3(n), dim3(256), 0, st, src, off, len, count);
+__global__ __launch_bounds__(256)
+void k_imark_place(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, uint64_t *__restrict__ pb,
+                   uint32_t *__restrict__ mode, const uint32_t *__restrict__ cntg, uint32_t G) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t s_before, s_total;
+    const uint32_t f = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const ZFrame fr = frames[f];
+    const uint32_t P = fx[f].blk_cap, base = fx[f].blk_base + f;          // P + 1 boundary slots per stream
+    if (P <= 1) { if (g == 0 && tid == 0) { pb[base] = 0; pb[base + 1] = fr.src_len; mode[f] = VM_PIECES; } return; }
+    if (tid == 0) { uint32_t b = 0, t = 0; for (uint32_t h = 0; h < G; h++) { const uint32_t c = cntg[(size_t)f * G + h]; if (h < g) b += c; t += c; } s_before = b; s_total = t; }
+    __syncthreads();
+    const uint64_t n = fr.src_len;
+    const bool pieces = s_total == P - 1;
+    if (g == 0 && tid == 0) { mode[f] = pieces ? VM_PIECES : VM_SERIAL; pb[base] = 0; pb[base + P] = n; }
+    if (!pieces) return;
+    const uint8_t *p = src + fr.src_off;
+    const uint64_t per_g = (n + G - 1) / G, g0 = per_g * g < n ? per_g * g : n, g1 = g0 + per_g < n ? g0 + per_g : n;
+    const uint64_t per = (g1 - g0 + 255) / 256, a = g0 + tid * per < g1 ? g0 + tid * per : g1, e = a + per < g1 ? a + per : g1;
+    uint32_t c = 0;
+    for (uint64_t i = a; i < e; i++) if (if_marker(p, i, n)) c++;
+    cnt[tid] = c;
+    __syncthreads();
+    if (tid == 0) { uint32_t r = s_before; for (uint32_t i = 0; i < 256; i++) { const uint32_t t = cnt[i]; cnt[i] = r; r += t; } }
+    __syncthreads();
+    uint32_t k = cnt[tid];
+    for (uint64_t i = a; i < e; i++) if (if_marker(p, i, n)) { pb[base + 1 + k] = i + 4; k++; }
+}
+
+// ---- k_icount: sync-flush markers per stream (streams of unknown size: the host sizes the piece list from it); G workgroups per stream add up in count[f] (zeroed before)
+__global__ __launch_bounds__(256)
+void k_icount(const uint8_t *__restrict__ src, const uint64_t *__restrict__ off, const uint64_t *__restrict__ len, uint32_t *__restrict__ count, uint32_t G) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t f = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const uint8_t *p = src + off[f];
+    const uint64_t n = len[f], per_g = (n + G - 1) / G, g0 = per_g * g < n ? per_g * g : n, g1 = g0 + per_g < n ? g0 + per_g : n;
+    const uint64_t per = (g1 - g0 + 255) / 256, a = g0 + tid * per < g1 ? g0 + tid * per : g1, e = a + per < g1 ? a + per : g1;
+    uint32_t c = 0;
+    for (uint64_t i = a; i < e; i++) if (if_marker(p, i, n)) c++;
+    cnt[tid] = c;
+    __syncthreads();
+    for (uint32_t s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) cnt[tid] += cnt[tid + s2]; __syncthreads(); }
+    if (tid == 0 && cnt[0]) atomicAdd(&count[f], cnt[0]);
+}
+void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, uint32_t G, hipStream_t st) {
+    if (!n) return;
+    (void)hipMemsetAsync(count, 0, (size_t)n * 4, st);
+    hipLaunchKernelGGL(k_icount, dim3(n, G), dim3(256), 0, st, src, off, len, count, G);
 }
 
 __global__ __launch_bounds__(64)
@@ -510,6 +539,7 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
     enum { S_ZHEAD, S_BLOCK, S_TOKENS, S_TRAILER, S_DONE };
     uint32_t state = live ? (first ? S_ZHEAD : S_BLOCK) : S_DONE, status = IF_OK, lastblk = 0;
     uint32_t nlit = 0, nseq = 0, ll = 0, adler = 0; uint64_t mtot = 0;
+    int64_t minsrc = 0;                                                      // the earliest byte a match of this piece copies from
     uint32_t litw = 0;                                                       // up to 3 literals waiting for a dword store
     auto put_lit = [&](uint32_t b) {
         litw |= b << (8 * (nlit & 3)); nlit++;
@@ -687,6 +717,7 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
                 else { const uint32_t eb = (ds >> 1) - 1; refill(); dist = 1 + ((2 + (ds & 1)) << eb) + take(eb); }
                 if (nseq >= pcap || (uint64_t)nlit + mtot + ml > expect) { status = nseq >= pcap ? IF_UNSUPPORTED : IF_DSTSIZE; state = S_DONE; break; }
                 rec_out[nseq++] = zrec_pack(ll, ml, dist + 3);
+                { const int64_t sp0 = (int64_t)((uint64_t)nlit + mtot) - (int64_t)dist; minsrc = sp0 < minsrc ? sp0 : minsrc; }   // (piece-relative; negative: an earlier piece)
                 mtot += ml; ll = 0;
             }
         } else if (state == S_TRAILER) {
@@ -710,32 +741,46 @@ void k_vinflate(const ZFrame *__restrict__ frames, const ZFrameX *__restrict__ f
     b.nseq = nseq; b.seq_off = 0; b.seq_len = 0; b.frame = pc.frame; b.out_len = (uint32_t)total; b.status = status; b.uses_rep = 0;
     for (int k = 0; k < 7; k++) b.pad[k] = 0;
     b.pad[1] = adler; b.pad[2] = (uint32_t)(((uint64_t)pc.j * BLK_SIZE) >> 32);
+    { const int64_t r = (int64_t)((uint64_t)pc.j * BLK_SIZE) + minsrc; const uint64_t ru = r < 0 ? 0ull : (uint64_t)r; b.pad[3] = (uint32_t)ru; b.pad[4] = (uint32_t)(ru >> 32); }   // how far back the piece reaches (stream position): k_vfin
     blocks[x.blk_base + pc.j] = b;
 #undef LS
 }
 
-// ---- k_vfin: one thread per stream: all pieces fine -> the frame has P blocks; otherwise the wave-per-stream kernel takes the stream
-__global__ void k_vfin(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, uint32_t n, const ZBlock *__restrict__ blocks, uint32_t *__restrict__ mode) {
+// ---- k_vfin: one thread per stream: all pieces fine -> the frame has P blocks; otherwise the wave-per-stream kernel takes the stream.
+// Execution groups: piece j starts one iff no piece k >= j copies from in front of piece j's start (pad[5] = 1) -- the groups of a stream are
+// executed side by side (k_zexec_groups).  What this library writes: a group per 1 MiB segment (its matches never leave the segment), so an entry of
+// N MiB is executed by N waves instead of one (4 GiB: 40 s on one wave).
+__global__ void k_vfin(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, uint32_t n, ZBlock *__restrict__ blocks, uint32_t *__restrict__ mode) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n || frames[f].status) return;
     if (mode[f] == VM_PIECES) {
         const uint32_t P = fx[f].blk_cap; uint32_t bad = 0; uint64_t tot = 0;
         for (uint32_t j = 0; j < P; j++) { bad |= blocks[fx[f].blk_base + j].status; tot += blocks[fx[f].blk_base + j].out_len; }
         const bool open = (frames[f].out_len & ZF_OPEN) != 0;
-        if (!bad && (open ? tot <= frames[f].dst_len : tot == frames[f].dst_len)) { fx[f].nblk = P; if (!open) frames[f].out_len = (uint32_t)(tot < 0xFFFFFFFFull ? tot : 0xFFFFFFFFull); return; }   // (open: k_zoff reports the size)
+        if (!bad && (open ? tot <= frames[f].dst_len : tot == frames[f].dst_len)) {
+            uint64_t sufmin = ~0ull;
+            for (uint32_t j = P; j-- > 0;) {
+                ZBlock *b = blocks + fx[f].blk_base + j;
+                const uint64_t reach = (uint64_t)b->pad[3] | ((uint64_t)b->pad[4] << 32);
+                sufmin = reach < sufmin ? reach : sufmin;
+                b->pad[5] = sufmin >= (uint64_t)j * BLK_SIZE ? 1u : 0u;
+            }
+            fx[f].nblk = P; if (!open) frames[f].out_len = (uint32_t)(tot < 0xFFFFFFFFull ? tot : 0xFFFFFFFFull); return;   // (open: k_zoff reports the size)
+        }
         mode[f] = VM_SERIAL;
     }
 }
 
-void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, const uint8_t *src,
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, uint32_t *cntg, uint32_t G, const uint8_t *src,
                      ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
     if (!n) return;
     static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_vinflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VI_LDS);
     (void)attr_set;
-    hipLaunchKernelGGL(k_imark, dim3(n), dim3(256), 0, st, (const ZFrame *)frames, (const ZFrameX *)fx, src, pb, mode);
+    hipLaunchKernelGGL(k_imark_count, dim3(n, G), dim3(256), 0, st, (const ZFrame *)frames, (const ZFrameX *)fx, src, cntg, G);
+    hipLaunchKernelGGL(k_imark_place, dim3(n, G), dim3(256), 0, st, (const ZFrame *)frames, (const ZFrameX *)fx, src, pb, mode, (const uint32_t *)cntg, G);
     hipLaunchKernelGGL(k_vinflate, dim3((npieces + 63) / 64), dim3(64), VI_LDS, st, (const ZFrame *)frames, (const ZFrameX *)fx, (const VPiece *)pieces, npieces,
                        (const uint64_t *)pb, (const uint32_t *)mode, src, blocks, lit_scratch, seqs);
-    hipLaunchKernelGGL(k_vfin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, n, (const ZBlock *)blocks, mode);
+    hipLaunchKernelGGL(k_vfin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, n, blocks, mode);
 }
 
 } // namespace pna

@@ -1052,19 +1052,15 @@ __device__ __forceinline__ void zx_store_upto8(uint8_t *p, uint64_t v, uint32_t 
     if (n & 1) *p = (uint8_t)v;
 }
 // ------------------------------------------------------------------ k_zexec : one wave per frame, blocks in order
-__global__ __launch_bounds__(64)
-void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src,
-             const uint8_t *__restrict__ lit_scratch, const uint64_t *__restrict__ seqs, uint8_t *__restrict__ dst) {
-    const uint32_t lane = threadIdx.x, f = blockIdx.x;
-    const ZFrame fr = frames[f];
-    if (fr.status) return;
-    const ZFrameX x = fx[f];
+// (zexec_blocks: blocks [k0, k1) of a frame on the calling wave; k_zexec_groups runs the execution groups of inflated streams side by side)
+__device__ __forceinline__ bool zexec_blocks(const ZFrame &fr, const ZFrameX &x, uint32_t k0, uint32_t k1, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src,
+                                             const uint8_t *__restrict__ lit_scratch, const uint64_t *__restrict__ seqs, uint8_t *__restrict__ dst, uint32_t lane) {
     // Positions below count in 32 bits from `out`.  For frames below 2 GiB that is the frame's start; further on the base follows the blocks
     // 2 GiB behind (a block is at most 128 KiB, a reference reaches back less than 2^28: both stay in range, and the test `offset > o0 + ll`
     // cannot fail there, as it must not).  Frames of 4 GiB and more: zlib streams decoded by pieces (k_vinflate).
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool okq = true;
-    for (uint32_t k = 0; k < x.nblk && okq; k++) {
+    for (uint32_t k = k0; k < k1 && okq; k++) {
         const ZBlock b = blocks[x.blk_base + k];
         const uint64_t bpos = b.out_off - fr.dst_off, rebase = bpos > (1ull << 31) ? bpos - (1ull << 31) : 0;
         uint8_t *out = dst + fr.dst_off + rebase;
@@ -1197,6 +1193,36 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
         }
         __threadfence_block();
     }
+    return okq;
+}
+
+__global__ __launch_bounds__(64)
+void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src,
+             const uint8_t *__restrict__ lit_scratch, const uint64_t *__restrict__ seqs, uint8_t *__restrict__ dst) {
+    const uint32_t lane = threadIdx.x, f = blockIdx.x;
+    const ZFrame fr = frames[f];
+    if (fr.status) return;
+    const ZFrameX x = fx[f];
+    const bool okq = zexec_blocks(fr, x, 0, x.nblk, blocks, src, lit_scratch, seqs, dst, lane);
+    if (!okq && lane == 0) frames[f].status = ZD_CORRUPT;
+}
+
+// One wave per PIECE slot of the inflated streams (the list k_vinflate ran on): the wave of a piece that starts an execution group (pad[5], k_vfin;
+// block 0 always does) executes the group's blocks in order, the others leave at once.  A stream the wave-per-stream walk took has one block.
+__global__ __launch_bounds__(64)
+void k_zexec_groups(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const ZBlock *__restrict__ blocks, const uint2 *__restrict__ pieces, uint32_t npieces,
+                    const uint8_t *__restrict__ src, const uint8_t *__restrict__ lit_scratch, const uint64_t *__restrict__ seqs, uint8_t *__restrict__ dst) {
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= npieces) return;
+    const uint2 pc = pieces[blockIdx.x];                               // (frame, piece)
+    const uint32_t f = pc.x, j = pc.y;
+    const ZFrame fr = frames[f];
+    if (fr.status) return;
+    const ZFrameX x = fx[f];
+    if (j >= x.nblk || (j && !blocks[x.blk_base + j].pad[5])) return;
+    uint32_t k1 = j + 1;
+    while (k1 < x.nblk && !blocks[x.blk_base + k1].pad[5]) k1++;
+    const bool okq = zexec_blocks(fr, x, j, k1, blocks, src, lit_scratch, seqs, dst, lane);
     if (!okq && lane == 0) frames[f].status = ZD_CORRUPT;
 }
 
@@ -1214,6 +1240,12 @@ void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks,
     if (!n) return;
     hipLaunchKernelGGL(k_zoff, dim3((n + 63) / 64), dim3(64), 0, st, frames, fx, n, blocks);
     hipLaunchKernelGGL(k_zexec, dim3(n), dim3(64), 0, st, frames, fx, blocks, src, lit_scratch, seqs, dst);
+}
+void launch_zexec_groups(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const void *pieces, uint32_t npieces, const uint8_t *src, const uint8_t *lit_scratch,
+                         const uint64_t *seqs, uint8_t *dst, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_zoff, dim3((n + 63) / 64), dim3(64), 0, st, frames, fx, n, blocks);
+    if (npieces) hipLaunchKernelGGL(k_zexec_groups, dim3(npieces), dim3(64), 0, st, frames, fx, (const ZBlock *)blocks, (const uint2 *)pieces, npieces, src, lit_scratch, seqs, dst);
 }
 
 // ------------------------------------------------------------------ k_zscan : one thread per entry

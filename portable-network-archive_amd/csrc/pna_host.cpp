@@ -59,11 +59,13 @@ void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, 
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st);
-void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, hipStream_t st);
-void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, const uint8_t *src,
+void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, uint32_t G, hipStream_t st);
+void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, uint32_t *cntg, uint32_t G, const uint8_t *src,
                      ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
                    void *part, hipStream_t st);
+void launch_zexec_groups(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const void *pieces, uint32_t npieces, const uint8_t *src, const uint8_t *lit_scratch,
+                         const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 std::string pna_sanitize_name(const char *name, size_t n);
@@ -2636,12 +2638,16 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     std::vector<uint64_t> npc(n);
     uint64_t tot_pieces = 0;
     bool lanes = !c->tun.inflate_serial;
+    // workgroups per stream for the marker scans: one per 256 KiB of the batch's longest stream (n x G bounded)
+    uint64_t max_src = 0;
+    for (size_t i = 0; i < n; i++) max_src = std::max<uint64_t>(max_src, src_len[i]);
+    const uint32_t scan_g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(max_src >> 18, 1024), (1ull << 24) / std::max<size_t>(n, 1)));
     if (lanes && open) {
         std::vector<uint32_t> cnt(n);
         if (c->z_pb.ensure(n * 4 + 8) || c->z_vp.ensure(n * 16 + 16)) return fail(c, PNA_E_NOMEM, "decoder workspace");
         HIPCHK(c, hipMemcpyAsync(c->z_vp.p, src_off, n * 8, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_vp.p + n * 8, src_len, n * 8, hipMemcpyHostToDevice, st));
-        launch_icount((const uint8_t *)d_src, (const uint64_t *)c->z_vp.p, (const uint64_t *)((uint8_t *)c->z_vp.p + n * 8), (uint32_t)n, (uint32_t *)c->z_pb.p, st);
+        launch_icount((const uint8_t *)d_src, (const uint64_t *)c->z_vp.p, (const uint64_t *)((uint8_t *)c->z_vp.p + n * 8), (uint32_t)n, (uint32_t *)c->z_pb.p, scan_g, st);
         HIPCHK(c, hipMemcpyAsync(cnt.data(), c->z_pb.p, n * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         for (size_t i = 0; i < n; i++) { npc[i] = (uint64_t)cnt[i] + 1; if ((npc[i] - 1) * BLK_SIZE > raw_len[i]) npc[i] = 1; }   // more pieces than the room allows: not this library's layout
@@ -2671,7 +2677,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     cbase[n] = (uint32_t)pieces;
     if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk * sizeof(ZBlock)) ||
         c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8) ||
-        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 8 + 8) || c->z_mode.ensure(n * 4 + 8))))
+        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 8 + 8) || c->z_mode.ensure(n * 4 + 8 + (size_t)n * scan_g * 4))))
         return fail(c, PNA_E_NOMEM, "decoder workspace");
     HIPCHK(c, hipMemcpyAsync(c->z_frames.p, frs.data(), n * sizeof(ZFrame), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), n * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
@@ -2679,12 +2685,14 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     if (lanes) HIPCHK(c, hipMemcpyAsync(c->z_vp.p, vp.data(), vp.size() * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (lanes) launch_vinflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, c->z_vp.p, (uint32_t)vp.size(), (uint64_t *)c->z_pb.p, (uint32_t *)c->z_mode.p,
-                               (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
+                               (uint32_t *)c->z_mode.p + n + 2, scan_g, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
     launch_inflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
                    (uint64_t *)c->z_seqs.p, lanes ? (const uint32_t *)c->z_mode.p : nullptr, st);
     HIPCHK(c, hipEventRecord(c->ev[2], st));
-    launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
-                 (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+    if (lanes) launch_zexec_groups((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, c->z_vp.p, (uint32_t)vp.size(), (const uint8_t *)d_src,
+                                   (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);   // execution groups side by side (k_vfin)
+    else launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
+                      (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
     HIPCHK(c, hipEventRecord(c->ev[3], st));
     launch_iadler((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (const ZBlock *)c->z_blocks.p, (uint32_t)n, (const uint32_t *)c->z_cbase.p,
                   (uint32_t)pieces, (const uint8_t *)d_dst, c->z_apart.p, st);

@@ -91,10 +91,11 @@ void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStr
 void launch_zparse(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
 void launch_zstreams(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const void *, ZBlock *, const ZFrame *, const ZTables *, const uint8_t *, uint8_t *, uint64_t *, hipStream_t) { nostub("zstreams"); }
 void launch_inflate(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, const uint32_t *, hipStream_t) { nostub("inflate"); }
-void launch_icount(const uint8_t *, const uint64_t *, const uint64_t *, uint32_t, uint32_t *, hipStream_t) { nostub("inflate"); }
-void launch_vinflate(ZFrame *, ZFrameX *, uint32_t, const void *, uint32_t, uint64_t *, uint32_t *, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
+void launch_icount(const uint8_t *, const uint64_t *, const uint64_t *, uint32_t, uint32_t *, uint32_t, hipStream_t) { nostub("inflate"); }
+void launch_vinflate(ZFrame *, ZFrameX *, uint32_t, const void *, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
 void launch_iadler(ZFrame *, const ZFrameX *, const ZBlock *, uint32_t, const uint32_t *, uint32_t, const uint8_t *, void *, hipStream_t) { nostub("iadler"); }
 void launch_zexec(ZFrame *, const ZFrameX *, uint32_t, ZBlock *, const uint8_t *, const uint8_t *, const uint64_t *, uint8_t *, hipStream_t) { nostub("zexec"); }
+void launch_zexec_groups(ZFrame *, const ZFrameX *, uint32_t, ZBlock *, const void *, uint32_t, const uint8_t *, const uint8_t *, const uint64_t *, uint8_t *, hipStream_t) { nostub("zexec"); }
 void launch_gcm_tag(const GcmEntry *, uint32_t, uint8_t *, hipStream_t) { nostub("gcm"); }
 void launch_gcm_verify(const GcmEntry *, uint32_t, const uint8_t *, const uint8_t *, uint32_t *, hipStream_t) { nostub("gcm"); }
 void launch_aes_cbc_dec(const CipherUnit *, uint32_t, const uint8_t *, const AesDecTabs *, uint8_t *, const AesKey &, uint32_t *, hipStream_t) { nostub("aes"); }
