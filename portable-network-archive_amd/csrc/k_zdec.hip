@@ -1091,17 +1091,29 @@ __device__ __forceinline__ bool zexec_blocks(const ZFrame &fr, const ZFrameX &x,
                 else if (nb == 2) { rep2 = rep0; rep1 = (uint32_t)__shfl((int)offset, 0); rep0 = (uint32_t)__shfl((int)offset, 1); }
                 else { rep2 = rep1; rep1 = rep0; rep0 = (uint32_t)__shfl((int)offset, 0); }
             } else {
-                for (uint32_t j = 0; j < nb; j++) {
-                    const uint32_t vj = (uint32_t)__shfl((int)ofv, (int)j), lj = (uint32_t)__shfl((int)ll, (int)j);
+                // Only the repeat codes are walked (libzstd's frames hold some in nearly every batch; walking all 64 lanes was most of the kernel's
+                // instructions for them): the history in front of a repeat code = the history behind the previous one, pushed down by the up to three
+                // plain offsets in between -- read from their lanes (uniform lane numbers: v_readlane).
+                auto lane_of = [&](uint32_t v, uint32_t j) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)j)); };
+                auto advance = [&](uint32_t cur, uint32_t j) {             // plain offsets of lanes [cur, j) enter the history
+                    const uint32_t c = j - cur;
+                    if (c >= 3) { rep0 = lane_of(offset, j - 1); rep1 = lane_of(offset, j - 2); rep2 = lane_of(offset, j - 3); }
+                    else if (c == 2) { rep2 = rep0; rep0 = lane_of(offset, j - 1); rep1 = lane_of(offset, j - 2); }
+                    else if (c == 1) { rep2 = rep1; rep1 = rep0; rep0 = lane_of(offset, j - 1); }
+                };
+                uint32_t cur = 0;
+                for (uint64_t m = repm; m; m &= m - 1) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                    advance(cur, j);
+                    const uint32_t vj = lane_of(ofv, j), lj = lane_of(ll, j);
+                    const uint32_t idx = vj - 1 + (lj == 0 ? 1u : 0u);
                     uint32_t o;
-                    if (vj > 3) { o = vj - 3; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                    else {
-                        const uint32_t idx = vj - 1 + (lj == 0 ? 1u : 0u);
-                        if (idx == 0) o = rep0;
-                        else { o = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1); if (idx > 1) rep2 = rep1; rep1 = rep0; rep0 = o; }
-                    }
+                    if (idx == 0) o = rep0;
+                    else { o = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - 1); if (idx > 1) rep2 = rep1; rep1 = rep0; rep0 = o; }
                     if (lane == j) offset = o;
+                    cur = j + 1;
                 }
+                advance(cur, nb);
             }
             uint32_t incl = ll + ml, lincl = ll;
 #pragma unroll
