@@ -82,7 +82,7 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lit_beside_seq" [PNA_LIT_BESIDE_SEQ] large zstd batches: the literal coder on a second stream next to the sequence coder (1, default)
  *   "pipeline_chunks" [PNA_PIPELINE_CHUNKS], "max_chunk_size" [PNA_MAX_CHUNK_SIZE] (FDAT chunk size of the entry points without such a parameter), "sub_mib" [PNA_SUB_MIB], "stage_threads" [PNA_STAGE_THREADS],
  *   "extract_win_mib" [PNA_EXTRACT_WIN_MIB], "batch_piece_mib" [PNA_BATCH_PIECE_MIB], "inflate_serial" [PNA_INFLATE_SERIAL],
- *   "zdec_serial" [PNA_ZDEC_SERIAL], "stream_pool_mib" [PNA_STREAM_POOL_MIB], "stream_linger_us" [PNA_STREAM_LINGER_US] (-1 = adaptive): DESIGN.md. */
+ *   "zdec_serial" [PNA_ZDEC_SERIAL], "zdec_dbg" [PNA_ZDEC_DBG] (diagnostics of the one-workgroup zstd decoder: bit 8 = small re-base distances, for its test), "stream_pool_mib" [PNA_STREAM_POOL_MIB], "stream_linger_us" [PNA_STREAM_LINGER_US] (-1 = adaptive): DESIGN.md. */
 int  pna_gpu_set_option(pna_gpu_ctx *ctx, const char *name, long value);
 const char *pna_gpu_strerror(int code);
 

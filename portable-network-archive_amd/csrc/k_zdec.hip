@@ -1403,9 +1403,9 @@ void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *
     if (n) hipLaunchKernelGGL(k_zxxh, dim3((n + 15) / 16), dim3(64), 0, st, frames, n, src, dst);
 }
 
-void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st) {
-    const char *e = getenv("PNA_ZDEC_DBG");                     // diagnostics: 1 skip execution, 2 skip sequences, 4 skip Huffman streams, 8 small re-base distances
-    if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst, lit_scratch, e ? (uint32_t)atoi(e) : 0u);
+// dbg (option "zdec_dbg"): diagnostics: 1 skip execution, 2 skip sequences, 4 skip Huffman streams, 8 small re-base distances
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, uint32_t dbg, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_zdec, dim3(n), dim3(ZD_THREADS), 0, st, frames, src, dst, lit_scratch, dbg);
 }
 
 } // namespace pna

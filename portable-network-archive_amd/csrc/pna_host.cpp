@@ -50,7 +50,7 @@ void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, 
 void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st, uint32_t max_payload);
-void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, hipStream_t st);
+void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, uint32_t dbg, hipStream_t st);
 void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, ZFrameX *fx, hipStream_t st);
 void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st);
@@ -137,6 +137,7 @@ struct Tuning {
     long batch_piece_mib = 256;      // PNA_BATCH_PIECE_MIB: pna_gpu_compress_batch takes a large batch through in pieces of this size (0: one piece)
     long inflate_serial = 0;         // PNA_INFLATE_SERIAL: deflate decoding on the wave-per-stream walk only
     long zdec_serial = 0;            // PNA_ZDEC_SERIAL: zstd decoding with one workgroup per frame only
+    long zdec_dbg = 0;               // PNA_ZDEC_DBG: the one-workgroup kernel's diagnostics (1 skip execution, 2 skip sequences, 4 skip Huffman streams, 8 small re-base distances)
     long blk_log = 0;                // PNA_BLK_LOG: block size of every batch = 1 << blk_log (13..17); 0 = by batch size (latency mode)
     long unit_log = 0;               // PNA_LZ_UNIT_LOG: LZ units of 1 << unit_log bytes (>= the block size, <= 20); 0 = by batch size
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
@@ -157,7 +158,7 @@ static const TuningName TUNING_NAMES[] = {
     {"pipeline_chunks", "PNA_PIPELINE_CHUNKS", &Tuning::pipeline_chunks, 1, 8}, {"max_chunk_size", "PNA_MAX_CHUNK_SIZE", &Tuning::max_chunk_size, 0, 0xFFFFFFFFl},
     {"sub_mib", "PNA_SUB_MIB", &Tuning::sub_mib, 16, 16384}, {"stage_threads", "PNA_STAGE_THREADS", &Tuning::stage_threads, 0, 64},
     {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20},
-    {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1},
+    {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
     {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
@@ -2838,7 +2839,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
         if (c->z_fb.ensure(sub.size() * sizeof(ZFrame)) || c->z_lit.ensure(std::max<uint64_t>(out_span + 64, sub.size() * (uint64_t)(128u << 10) + 64)))
             return fail(c, PNA_E_NOMEM, "decoder workspace");
         HIPCHK(c, hipMemcpyAsync(c->z_fb.p, sub.data(), sub.size() * sizeof(ZFrame), hipMemcpyHostToDevice, st));
-        launch_zdec((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, st);
+        launch_zdec((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (uint8_t *)d_dst, (uint8_t *)c->z_lit.p, (uint32_t)c->tun.zdec_dbg, st);
         launch_zxxh((ZFrame *)c->z_fb.p, (uint32_t)sub.size(), (const uint8_t *)d_src, (const uint8_t *)d_dst, st);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(sub.data(), c->z_fb.p, sub.size() * sizeof(ZFrame), hipMemcpyDeviceToHost, st));

@@ -84,7 +84,7 @@ void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uin
 void launch_deflate_write(const uint8_t *, const SegDesc *, const uint32_t *, uint32_t, const BlkInfo *, const uint64_t *, const uint64_t *, const uint8_t *, const uint32_t *,
                           uint32_t, uint8_t *, hipStream_t) { nostub("deflate"); }
 void launch_frame_verify(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t, uint32_t) { nostub("frame_verify"); }
-void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, hipStream_t) { nostub("zdec"); }
+void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, hipStream_t) { nostub("zdec"); }
 void launch_zxxh(ZFrame *, uint32_t, const uint8_t *, const uint8_t *, hipStream_t) { nostub("zxxh"); }
 void launch_zscan(const ZEntry *, uint32_t, const uint8_t *, ZFrame *, ZFrameX *, hipStream_t) { nostub("zscan"); }
 void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStream_t) { nostub("zcount"); }

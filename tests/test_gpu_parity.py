@@ -1439,16 +1439,15 @@ def test_one_large_foreign_zstd_frame(gpu_ctx, pna, codec):
     assert t is not None
 
 
-def test_one_workgroup_decoder_moves_its_bases(gpu_ctx, pna, codec, monkeypatch):
+def test_one_workgroup_decoder_moves_its_bases(gpu_ctx, pna, codec):
     """k_zdec counts positions in 32 bits from bases that follow the frame (frames of 4 GiB and more: test_one_foreign_zstd_frame_beyond_4gib,
-    minutes at one workgroup's speed).  PNA_ZDEC_DBG=8 moves the bases every few MiB instead of every few GiB: a 24 MiB libzstd frame (window
+    minutes at one workgroup's speed).  The option zdec_dbg = 8 moves the bases every few MiB instead of every few GiB: a 24 MiB libzstd frame (window
     2 MiB) crosses them a dozen times and decodes to the same bytes."""
     if codec.system_libzstd() is None:
         pytest.skip("system libzstd (the writer of the test frame) is absent")
     raw = b"".join(codec.corpus_file(i % 3, 8400 + i, 1 << 20) for i in range(24))
     comp = _libzstd_one_frame(codec, raw)
-    monkeypatch.setenv("PNA_ZDEC_DBG", "8")
-    with gpu_ctx.options(zdec_serial=(1, 0)):
+    with gpu_ctx.options(zdec_serial=(1, 0), zdec_dbg=(8, 0)):
         assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw]
         bad = bytearray(comp); bad[-3000] ^= 0x01
         try:
