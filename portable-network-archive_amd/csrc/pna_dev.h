@@ -180,7 +180,8 @@ struct ZBlock {
     uint32_t huf_slot, slot[3];      // table slots that apply (Huffman; LL, OF, ML)
     uint32_t nseq, seq_off, seq_len; // sequence bitstream (body-relative)
     uint32_t frame, out_len, status, uses_rep;
-    uint32_t pad[7];         // [0] zstd: last-block bit; [1] inflate: the Adler-32 trailer read with the stream's last piece; [2] lit_pos >> 32
+    uint32_t pad[7];         // [0] zstd: last-block bit; [1] inflate: the Adler-32 trailer read with the stream's last piece; [2] lit_pos >> 32;
+                             // inflate pieces: [3], [4] the earliest stream position a match of the piece copies from (k_vinflate), [5] the piece starts an execution group (k_vfin)
 };
 static_assert(sizeof(ZBlock) == 128, "ZBlock layout");
 struct ZTables {             // one slot
