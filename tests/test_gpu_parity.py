@@ -1462,7 +1462,6 @@ def test_damaged_large_streams_are_refused_or_differ(gpu_ctx, pna, codec):
     structure, sizes, Adler-32, Content_Checksum) or decodes to different bytes; none hangs or reads outside its buffers (flate2 / zstd-rs return
     io::Error for the same inputs, lib/src/entry/read.rs:171-190)."""
     import random
-    rng = random.Random(2026)
     raw_d = b"".join(codec.corpus_file(i % 3, 8500 + i, 1 << 20) for i in range(6))
     comp_d = gpu_ctx.compress_batch([raw_d], algo=pna.ALGO_DEFLATE)[0]
     assert gpu_ctx.decompress_batch([comp_d] * 24, [len(raw_d)] * 24, algo=pna.ALGO_DEFLATE) == [raw_d] * 24       # (24 x 48 pieces: the lane-per-piece path)
@@ -1470,21 +1469,24 @@ def test_damaged_large_streams_are_refused_or_differ(gpu_ctx, pna, codec):
     if codec.system_libzstd() is not None:
         raw_z = b"".join(codec.corpus_file(i % 3, 8600 + i, 1 << 20) for i in range(12))
         cases.append((codec.libzstd_compress_checksum(raw_z, 3), raw_z, pna.ALGO_ZSTD))
+    seeds = range(2026, 2026 + int(os.environ.get("PNA_DAMAGE_SEEDS", "1")))       # (PNA_DAMAGE_SEEDS=N: a longer soak)
     for comp, raw, algo in cases:
-        for trial in range(12):
-            bad = bytearray(comp)
-            kind = trial % 4
-            if kind == 0:
-                bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
-            elif kind == 1:
-                a = rng.randrange(len(bad) - 64); bad[a:a + 16] = bytes(rng.randrange(256) for _ in range(16))
-            elif kind == 2:
-                bad = bad[:rng.randrange(len(bad) // 2, len(bad) - 1)]
-            else:
-                a = rng.randrange(len(bad) - 4096); del bad[a:a + rng.randrange(1, 4096)]
-            streams = [bytes(bad)] + ([comp] * 23 if algo == pna.ALGO_DEFLATE else [])
-            try:
-                out = gpu_ctx.decompress_batch(streams, [len(raw)] * len(streams), algo=algo)
-                assert out[0] != raw, (algo, trial)
-            except pna.PnaGpuError:
-                pass
+        for seed in seeds:
+            rng = random.Random(seed * 7 + algo)
+            for trial in range(12):
+                bad = bytearray(comp)
+                kind = trial % 4
+                if kind == 0:
+                    bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+                elif kind == 1:
+                    a = rng.randrange(len(bad) - 64); bad[a:a + 16] = bytes(rng.randrange(256) for _ in range(16))
+                elif kind == 2:
+                    bad = bad[:rng.randrange(len(bad) // 2, len(bad) - 1)]
+                else:
+                    a = rng.randrange(len(bad) - 4096); del bad[a:a + rng.randrange(1, 4096)]
+                streams = [bytes(bad)] + ([comp] * 23 if algo == pna.ALGO_DEFLATE else [])
+                try:
+                    out = gpu_ctx.decompress_batch(streams, [len(raw)] * len(streams), algo=algo)
+                    assert out[0] != raw, (algo, seed, trial)
+                except pna.PnaGpuError:
+                    pass
