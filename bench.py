@@ -216,6 +216,46 @@ class HostGather:
             pass
 
 
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks as children of this process through torch.distributed.run (the very command the
+    driver uses), on a free port of 127.0.0.1.  Nothing here touches the GPU -- a process that has initialised HIP must not exec or fork GPU users --;
+    the children's stdout / stderr are inherited, so rank 0's one JSON line is this process' stdout, and the launcher's exit code is returned
+    (non-zero as soon as one rank fails: torch.distributed.run ends the others)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                      # (what torchrun would set, without its warning on stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(rank: int, world: int, fail_rank: int) -> int:
+    """--launch-check: the launch mechanics alone (no GPU): rendezvous over gloo, every rank reports in, rank 0 prints one JSON line.  tests/ run the
+    plain command line through this on CPU-only hosts; --launch-check-fail-rank R makes rank R exit 3 to show the exit code travels."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = os.getpid()
+    if world > 1:
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "ranks_seen": int((seen != 0).sum().item()),
+                          "distinct_processes": len(set(seen.tolist())), "launcher": "torch.distributed.run"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 3 if rank == fail_rank else 0
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,22 +277,30 @@ def main() -> None:
     ap.add_argument("--gather-pieces", type=int, default=0,
                     help="archive framing: cut every rank's shard into this many pieces, each compressed and gathered on its own "
                          "(0 = 2 when N > 1, else 1)")
-    ap.add_argument("--gather", choices=["torch", "lib"], default="torch",
-                    help="N > 1: the ordered gather through torch.distributed (nccl = RCCL; overlapped with the next piece's compression) or through the "
-                         "library's own pna_gpu_gather_ordered (RCCL behind the C ABI, include/pna_gpu.h; synchronous per piece)")
+    ap.add_argument("--gather", choices=["lib", "torch"], default="lib",
+                    help="N > 1: the ordered gather through the library's own pna_gpu_gather_ordered_start / _wait (RCCL behind the C ABI, include/pna_gpu.h: "
+                         "the default) or through torch.distributed (nccl = RCCL); either way piece h travels while piece h + 1 is compressed")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-sink leg (N = 1, archive framing)")
     ap.add_argument("--no-gather-compare", action="store_true", help="N > 1: skip the direct-D2H comparison path")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)         # launch mechanics only (tests; no GPU)
+    ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-mib", type=int, default=0, help="CPU baseline sample per core in MiB (0 = 256 zstd / 48 deflate; --solid: 1024 zstd / 192 deflate in all)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # the plain command line (`python bench.py --gpus N ...`, no launcher around it): this process becomes the launcher -- it has not
+        # touched the GPU (torch is not even imported yet) -- and runs the N ranks as children; rank 0's JSON line is its stdout
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: for N > 1 launch one rank per GPU with\n"
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch it plainly (python bench.py --gpus {args.gpus} ...: it starts its own ranks) or with\n"
                  f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    if args.launch_check:
+        sys.exit(launch_check(rank, world, args.launch_check_fail_rank))
     import torch
     import torch.distributed as dist
     # PNA_BENCH_REHEARSAL=1: the N > 1 control flow on a box with ONE GPU -- every rank uses cuda:0 and the exchange runs over gloo on host
@@ -350,11 +398,13 @@ def main() -> None:
     def finish_gather(b=None):
         for k in (range(nbuf) if b is None else [b]):
             if pending[k] is not None:
-                if pending[k] != "d2h":
-                    out_k, sizes_k = shard.gather_ordered_wait(pending[k][0])
+                if isinstance(pending[k], tuple) and pending[k][0] == "lib":
+                    lib_comm.gather_wait(pending[k][1])       # (the gather that read this buffer; a later one may still be travelling)
+                elif pending[k] != "d2h":
+                    _, buf_k, sizes_k = shard.gather_ordered_wait(pending[k][0])
                     piece_sizes[pending[k][1]] = sizes_k
-                    if rank == 0 and out_k is not None:
-                        gather_out[pending[k][1]] = out_k         # (the gather allocates a larger buffer when the ranks' pieces outgrow the one it was offered)
+                    if rank == 0 and buf_k is not None:
+                        gather_out[pending[k][1]] = buf_k         # (the gather allocates a larger buffer when the ranks' pieces outgrow the one it was offered)
                 torch.cuda.current_stream().synchronize()     # RCCL work.wait() only orders streams: the buffers are reused by the host-launched kernels
                 pending[k] = None
 
@@ -387,8 +437,10 @@ def main() -> None:
                 # the library's gather: a worst-case destination (every rank's piece is below the archive bound of its entries), one call
                 if rank == 0 and gather_out[h] is None:
                     gather_out[h] = torch.empty(dst_cap * world, dtype=torch.uint8, device=dev)
-                sizes_h, _ = lib_comm.gather_ordered(dst.data_ptr(), total, gather_out[h].data_ptr() if rank == 0 else 0, dst_cap * world if rank == 0 else 0)
+                sizes_h, _ = lib_comm.gather_ordered_start(dst.data_ptr(), total, gather_out[h].data_ptr() if rank == 0 else 0, dst_cap * world if rank == 0 else 0,
+                                                           stream=torch.cuda.current_stream().cuda_stream)
                 piece_sizes[h] = sizes_h
+                pending[b] = ("lib", lib_comm.ticket())       # the transfer runs on the communicator's stream while the next piece is compressed
             elif world > 1 and mode[0] == "rccl":
                 if rank == 0 and gather_out[h] is None:
                     gather_out[h] = torch.empty(int(total * world * 1.02) + (1 << 20), dtype=torch.uint8, device=xdev)

@@ -326,7 +326,16 @@ int  pna_gpu_append_archive_host(pna_gpu_ctx *ctx, int algo, int level, const vo
  * host has none).  Bootstrap as with NCCL: rank 0 calls pna_gpu_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the
  * host has (the reference has none: it is a single process), every rank calls pna_gpu_comm_init.  All calls are collective.
  *   sizes  (host, nranks values, may be NULL) receives every part's length on every rank; *total their sum;
- *   d_out / out_cap matter on `root` only: PNA_E_DSTSIZE when the parts do not fit. */
+ *   d_out / out_cap matter on `root` only.  The root's capacity travels with the sizes, so the verdict is COLLECTIVE: when the parts do not fit, every
+ *   rank returns PNA_E_DSTSIZE and no rank has sent anything (the communicator stays usable; sizes / total are filled in, so the host can retry with
+ *   a larger destination).
+ * pna_gpu_gather_ordered_start posts the gather and returns: the only thing it waits for is the 16-bytes-per-rank size exchange on the communicator's own
+ * stream; the transfers are ordered behind the work already queued on `hip_stream` (the producer of d_local) and run on the communicator's stream, so
+ * they overlap whatever the host launches next (the next piece's compression into another buffer).  pna_gpu_gather_wait blocks until the posted
+ * gathers are done; d_local and d_out belong to the gather until then.  pna_gpu_gather_ticket = how many gathers the communicator has posted (the
+ * latest one's ticket), pna_gpu_gather_wait_for(ticket) waits for the gathers up to that one only -- the double-buffering host waits for the gather
+ * that used a buffer two pieces ago while the latest still travels.  pna_gpu_gather_ordered = start + wait.
+ * pna_gather_verdict is the host arithmetic every rank runs on the gathered (size, capacity) pairs (exported: the CPU tests pin it). */
 #define PNA_COMM_ID_BYTES 128
 typedef struct pna_gpu_comm pna_gpu_comm;
 int  pna_gpu_comm_unique_id(void *id128);
@@ -335,6 +344,12 @@ void pna_gpu_comm_destroy(pna_gpu_comm *comm);
 const char *pna_gpu_comm_last_error(const pna_gpu_comm *comm);
 int  pna_gpu_gather_ordered(pna_gpu_comm *comm, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
                             uint64_t *sizes, uint64_t *total, void *hip_stream);
+int  pna_gpu_gather_ordered_start(pna_gpu_comm *comm, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
+                                  uint64_t *sizes, uint64_t *total, void *hip_stream);
+int  pna_gpu_gather_wait(pna_gpu_comm *comm);
+uint64_t pna_gpu_gather_ticket(const pna_gpu_comm *comm);
+int  pna_gpu_gather_wait_for(pna_gpu_comm *comm, uint64_t ticket);
+int  pna_gather_verdict(const uint64_t *pairs, int nranks, int root, uint64_t *sizes, uint64_t *offs);
 /* offs[r] = where rank r's part starts in the gathered stream, offs[nranks] = the total (host arithmetic; what the gather above uses) */
 int  pna_gather_offsets(const uint64_t *sizes, int nranks, uint64_t *offs);
 

@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get("PNA_GPU_LIB") or os.path.join(_HERE, "libpna_gpu.so")
 PNA_OK = 0
 ALGO_STORE, ALGO_DEFLATE, ALGO_ZSTD = 0, 1, 2
 LEVEL_DEFAULT = -1000
+# error codes of include/pna_gpu.h
+E_NODEVICE, E_INVAL, E_NOMEM, E_DSTSIZE, E_HIP, E_SINK, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6, -7
 F_HUF, F_FSE, F_LAZY, F_REP, F_DEFAULT = 1, 2, 4, 8, 0x80000000
 F_FAR, F_ADOPT, F_INS2, F_STRONG = 0x10, 0x20, 0x40, 0x80
 F_LZ_WAVEPARSE, F_LZ_FUSED = 0x4000, 0x8000                      # forms of the LZ stage (default: split, lane-per-region parse); same bytes
@@ -104,7 +106,7 @@ _lib = None
 EXPORTS = [
     "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_archive_chunked_bound", "pna_gpu_create_archive_chunked_device",
     "pna_gpu_create_archive_chunked_host", "pna_gpu_comm_unique_id", "pna_gpu_comm_init", "pna_gpu_comm_destroy", "pna_gpu_comm_last_error",
-    "pna_gpu_gather_ordered", "pna_gather_offsets", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_gather_ordered", "pna_gpu_gather_ordered_start", "pna_gpu_gather_wait", "pna_gpu_gather_ticket", "pna_gpu_gather_wait_for", "pna_gather_verdict", "pna_gather_offsets", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
@@ -667,6 +669,18 @@ def create_archive_chunked(ctx: "Context", names: Sequence[str], entries: Sequen
     return bytes(out)
 
 
+def gather_verdict(sizes: Sequence[int], caps: Sequence[int], root: int = 0):
+    """pna_gather_verdict: what every rank decides from the all-gathered (size, capacity) pairs -- (rc, offsets); rc = PNA_E_DSTSIZE when the parts
+    do not fit the root's capacity (the same answer on every rank, so an overflow is an error everywhere and never a hang)."""
+    n = len(sizes)
+    pairs = (ctypes.c_uint64 * (2 * n))(*[v for sc in zip(sizes, caps) for v in sc])
+    o = (ctypes.c_uint64 * (n + 1))()
+    L = load_library()
+    L.pna_gather_verdict.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.pna_gather_verdict(pairs, n, root, None, o)
+    return rc, list(o)
+
+
 def gather_offsets(sizes: Sequence[int]) -> List[int]:
     """pna_gather_offsets: where every rank's part starts in the gathered stream (+ the total)."""
     n = len(sizes)
@@ -709,6 +723,31 @@ class Comm:
         if rc:
             raise PnaGpuError(rc, self._L.pna_gpu_comm_last_error(self._h).decode())
         return list(sizes), total.value
+
+    def gather_ordered_start(self, d_local: int, local_len: int, d_out: int = 0, out_cap: int = 0, root: int = 0, stream: int = 0):
+        """Posts the gather behind the work queued on `stream` and returns (sizes, total) as soon as the size exchange is through; the transfers run on the
+        communicator's own stream until gather_wait().  PnaGpuError(PNA_E_DSTSIZE) is raised on EVERY rank when the parts do not fit the root's d_out."""
+        sizes = (ctypes.c_uint64 * self.nranks)()
+        total = ctypes.c_uint64()
+        f = self._L.pna_gpu_gather_ordered_start
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(self._h, ctypes.c_void_p(d_local), local_len, root, ctypes.c_void_p(d_out), out_cap, sizes, ctypes.byref(total), ctypes.c_void_p(stream) if stream else None)
+        if rc:
+            raise PnaGpuError(rc, self._L.pna_gpu_comm_last_error(self._h).decode())
+        return list(sizes), total.value
+
+    def ticket(self) -> int:
+        """The latest posted gather's ticket (= how many this communicator has posted)."""
+        self._L.pna_gpu_gather_ticket.argtypes = [ctypes.c_void_p]
+        self._L.pna_gpu_gather_ticket.restype = ctypes.c_uint64
+        return int(self._L.pna_gpu_gather_ticket(self._h))
+
+    def gather_wait(self, ticket: int = 0):
+        """Blocks until the gathers up to `ticket` are done (0: all posted ones)."""
+        self._L.pna_gpu_gather_wait_for.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        rc = self._L.pna_gpu_gather_wait_for(self._h, ticket)
+        if rc:
+            raise PnaGpuError(rc, self._L.pna_gpu_comm_last_error(self._h).decode())
 
     def close(self):
         if getattr(self, "_h", None):

@@ -31,11 +31,7 @@
 //   neighbours' matches, one / two bytes longer.
 #include "lz_common.h"
 
-#ifdef LZ_EXP_ALLINS
-#define LZ_INS_COND true
-#else
 #define LZ_INS_COND (ins_all || !(lane & 1))
-#endif
 
 namespace pna {
 
@@ -62,11 +58,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     constexpr uint32_t RW = 64u * G;                       // positions one wave owns = the parse region
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-#ifdef LZ_EXP_NOFAR
-    constexpr bool FAR = false; max_off = max_off < NEAR_OFF ? max_off : NEAR_OFF;   // timing experiment: no look-back beyond the LDS window
-#else
     constexpr bool FAR = !CT;                               // deflate offsets (<= 32 KiB) never leave the LDS window
-#endif
     using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
     constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, L_WEND = GEO::L_WEND, L_WPUB = GEO::L_WPUB;
     constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : GEO::NEAR;
@@ -134,22 +126,6 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             if (MODE != 2 && tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
             LZ_STAMP(0);
 
-#ifdef LZ_EXP_PAD
-            // issue-model experiment: 128 extra independent SALU (flag 0x400) or VALU (flag 0x800) instructions per wave and tile
-            if (flags & 0x400u) {
-                uint32_t a0 = tid, a1 = 1, a2 = 2, a3 = 3;
-                a0 = uni(a0);
-#pragma unroll
-                for (int k = 0; k < 32; k++) asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1" : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3) :: "scc");
-                if (a0 + a1 + a2 + a3 == 0x7FFFFFF0u) lits[0] = 1;
-            }
-            if (flags & 0x800u) {
-                uint32_t a0 = tid, a1 = 1, a2 = 2, a3 = 3;
-#pragma unroll
-                for (int k = 0; k < 32; k++) asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-                if (a0 + a1 + a2 + a3 == 0x7FFFFFF0u) lits[0] = 1;
-            }
-#endif
             // ---- lookup
             uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G], bq2[G];
             bool hv[G];
@@ -267,7 +243,6 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 // back count and adopt "lengths" of 1..3 from such neighbours: they stay below MIN_MATCH and nobody reads them as a match.
                 uint32_t K = (l << 6) | (bk << 3);
                 if (STRONG && !l) K = 0;                                            // (three rounds could lift a stray back count to a "length" of 7 >= MIN_MATCH; with two it stays below)
-#ifndef LZ_EXP_NOADOPT
                 if (adopt) {
                 {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
                     const uint32_t K1 = dpp_next_lane(K), T = K1 + 57u;
@@ -285,7 +260,6 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 if (flags & FLAG_LEN36) l = l < 36u ? l : 36u;                      // (uniform) what the split form's 3-byte words keep
                 off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 7u)));          // the offset travels with the match
                 }
-#endif
                 }
                 len[r] = l; flen[r] = l;
                 if constexpr (MODE == 1) { effm[r] = 0; return; }
@@ -314,42 +288,14 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint32_t e_last = e0;
                 const uint32_t endp = lane + len[r];                                // group-relative end of this position's match
                 const uint64_t capm = __ballot(len[r] >= CAP1);
-#ifdef LZ_EXP_VECTORPARSE     // measured: bit-exact, 128 SALU fewer but 132 VALU more per wave and tile, B3 wait 20.6 -> 16.2 %, and 4.8 % SLOWER: the VALU port binds
-                if (rem != 0 && (capm & rem) == 0) {
-                    // No match of the group needs the extension: the greedy walk s -> first usable start at or behind the end of s's match is a
-                    // fixed jump function J, and the chosen starts are the orbit of the first usable start under J.  The orbit is marked by
-                    // pointer doubling -- members push a mark along J (ds_permute), then J := J o J (ds_bpermute) -- in four rounds (a match is
-                    // >= 6 long, so a group holds at most 11 starts <= 1 + 2 + 4 + 8): constant time per group instead of a scalar loop per chosen
-                    // match, which is what made the waves of a tile finish their parse at different times.  J is kept times four (the permute
-                    // address); "no further start" = 256 wraps to lane 0, which no jump can target (J >= 6), and lane 0 ignores what it receives.
-                    const uint64_t shf = endp < 64 ? (effm[r] >> endp) : 0;
-                    uint32_t J4 = shf ? (endp + ctz64(shf)) << 2 : 256u;
-                    const uint32_t s0 = ctz64(rem);
-                    uint32_t m = lane == s0 ? 1u : 0u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_permute((int)(m ? J4 : 0u), 1);
-                        m |= lane ? recv : 0u;
-                        if (k < 3) { const uint32_t J2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)J4, (int)J4); J4 = J4 >= 256u ? 256u : J2; }
-                    }
-                    const uint64_t M = __ballot(m != 0);
-                    sel[r] = M;
-                    e_last = rdlane(endp, 63 - clz64(M));
-                    rem = 0;
-                }
-#endif
                 while (rem) {
                     const uint32_t s = ctz64(rem);
                     uint32_t e = rdlane(endp, s);
                     if ((capm >> s) & 1) {
                         const uint32_t qs = t0 + wbase + 64 * r + s, os = rdlane(off[r], s), L0 = e - s;
                         const uint32_t xl = ext_lim - qs < max_len ? ext_lim - qs : max_len;
-                        #ifdef LZ_EXP_NOFAREXT
-                        const uint32_t L = (FAR && os > NEAR) ? L0
-#else
                         const uint32_t L = MODE == 2 ? lz_extend_mem(seg, seg_len, qs, qs - os, L0, xl, lane)
                                          : (FAR && os > NEAR) ? lz_extend<true, WIN_BYTES>(win32, seg, qs, qs - os, L0, xl, lane)
-#endif
                                                               : lz_extend<false, WIN_BYTES>(win32, seg, qs, qs - os, L0, xl, lane);
                         if (lane == s) flen[r] = L;
                         e = s + L;
@@ -611,9 +557,6 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
 
 // diagnostic: read and clear the phase stamps (cycles summed over workgroups); a -DLZP_PROF build hands out k_lzp's instead
 void lz_read_stamps(unsigned long long *out) {
-#ifdef LZP_PROF
-    lzp_read_stamps(out); return;
-#endif
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz_stamps), sizeof(unsigned long long) * 8);
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz_stamps), z, sizeof(z));

@@ -8,9 +8,6 @@
 
 namespace pna {
 
-#ifdef LZP_PROF
-__device__ unsigned long long g_lzp_stamps[8];              // k_lzp's phase stamps (scripts/lzp_stamps.py)
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // k_lzm -- the match half of the split form: look-up, match, backward adoption and the tile's inserts, as in k_lz<MODE 1>, but with
@@ -47,11 +44,7 @@ __device__ __forceinline__ void far_push(const bool (&farj)[4], const uint32_t (
 template <bool ON, bool STRONG>
 __device__ __forceinline__ void far_load(const uint8_t *seg, uint32_t c, v4u &fa, uint32_t &fb, v4u &fd, uint32_t &fc) {
     if (!ON) { fa = 0; fd = 0; fb = fc = 0; return; }
-#ifdef LZM_EXP_FARHOT
-    const uint8_t *pc = seg + ((c - 4) & 0xFFFu) + 8;                              // timing experiment: bytes that stay in the caches (wrong matches)
-#else
     const uint8_t *pc = seg + c - 4;
-#endif
     fa = ld16u(pc); fb = *(const u32u *)(pc + 16); fd = ld16u(pc + 20);
     fc = 0;
     if (STRONG) fc = *(const u32u *)(pc - 4);
@@ -138,9 +131,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
         for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
             const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
-#ifndef LZM_EXP_PFLATE
             if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
-#endif
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
             // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
@@ -200,9 +191,6 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool slot0 = FAR && lane < 63u && lane < npair;
             v4u ffa, ffd; uint32_t ffb, ffc;
             far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
-#ifdef LZM_EXP_PFLATE
-            if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
-#endif
             // ---- match: the candidates inside the window
             uint32_t K[4];
             const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
@@ -398,12 +386,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     const uint64_t lit_below = ((uint64_t)1 << (4 * (lane & 15))) - 1;
     uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (uniform)
 
-#ifdef LZP_PROF   // diagnostic build (scripts/lzp_stamps.py): s_memtime deltas per phase, summed over all waves
-    unsigned long long pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = __builtin_amdgcn_s_memtime();
-#define LZP_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pa[k] += t_ - pt0; pt0 = t_; } while (0)
-#else
-#define LZP_STAMP(k) do { } while (0)
-#endif
     for (uint32_t T = tile0; T < ntile; T++) {
         const uint32_t t0 = T * TG, blk_start = t0 & ~(bsz - 1);
         const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
@@ -462,7 +444,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             lmask[lane] = make_uint4(em2[0], em2[1], cm2[0], cm2[1]);
         }
         __builtin_amdgcn_wave_barrier();
-        LZP_STAMP(0);
         if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
         // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it; half-groups of 32 positions: one-register masks
         const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
@@ -521,7 +502,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                 cm[r] = (uint64_t)cm_lo[r] | ((uint64_t)cm_hi[r] << 32);
             }
         }
-        LZP_STAMP(1);
         uint32_t pc[4];                                     // capped chosen starts in the groups before r = index base into xlen
         pc[0] = 0;
 #pragma unroll
@@ -643,7 +623,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             if (t1 == blk_end && lane == 0) { blk[gblk].nseq = seq_run; blk[gblk].nlit = lit_run; }
         }
         __builtin_amdgcn_wave_barrier();
-        LZP_STAMP(2);
         // the input bytes of the lane's four positions in every region, for the literals: requested now, used behind the sequences
         uint32_t lw[16];
         if (t0 + TG <= seg_len) {                           // (uniform) all but a segment's last tile: no end to look out for
@@ -664,9 +643,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             const uint4 ra = rec[0][lane], rb = rec[1][lane], rc = rec[2][lane];
             const uint64_t lm = (uint64_t)ra.x | ((uint64_t)ra.y << 32), sc = (uint64_t)rb.z | ((uint64_t)rb.w << 32);
             uint64_t rem = lane < ng ? (uint64_t)rb.x | ((uint64_t)rb.y << 32) : 0;
-#ifdef LZP_EXP_NOSEQ   /* timing experiment (no sequences written) */
-            if (ra.w != 0x12345678u) rem = 0;
-#endif
             uint32_t idx = ra.w, prev = 0;
             const uint32_t cut_b2 = rc.z & 0xFFu, cut_l2 = rc.z >> 8;
             bool first = true;
@@ -695,7 +671,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                 }
             }
         }
-        LZP_STAMP(3);
         // ---- 4. literals, region by region, 4 consecutive positions per lane
         {
             uint8_t *blit = lits + ((size_t)gblk << blk_log);
@@ -703,9 +678,6 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
 #pragma unroll
             for (uint32_t wr = 0; wr < 16; wr++) {
                 if (wr * RW >= npos) continue;                                      // (uniform)
-#ifdef LZP_EXP_NOLIT   /* timing experiment (no literal bytes written) */
-                if (lw[wr] != 0x12345678u) continue;
-#endif
                 const uint4 m = rec[0][wr * 4 + (lane >> 4)];
                 const uint32_t wd = lw[wr];
                 const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
@@ -720,11 +692,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");                     // (the next tile's lengths overwrite the records)
-        LZP_STAMP(4);
     }
-#ifdef LZP_PROF
-    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lzp_stamps[k], pa[k]);
-#endif
 }
 
 template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT>
@@ -761,13 +729,7 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {
-#ifdef LZP_PROF
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzp_stamps), sizeof(unsigned long long) * 8);
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzp_stamps), z, sizeof(z));
-#else
     for (int k = 0; k < 8; k++) out[k] = 0;
-#endif
 }
 
 } // namespace pna

@@ -1,8 +1,8 @@
 // pna_comm.cpp -- the one exchange step of the multi-GPU path behind the C ABI (BASELINE.json north_star: "RCCL over xGMI only for
 // the final ordered gather of compressed chunks into the serial PNA stream").  One process per GPU; rank r has compressed the contiguous index range
 // r of the entries (the fan-out of cli/src/command/core.rs:496-537 with GPUs in place of worker threads) into an archive PART in its HBM; the parts in
-// rank order are the archive (the ordered drain of drain_entry_results, core.rs:471-493).  pna_gpu_gather_ordered: ncclAllGather of the parts' sizes,
-// then grouped ncclSend / ncclRecv -- every sending rank has its own xGMI link to the root, so the seven transfers of an 8-GPU node run side by side.
+// rank order are the archive (the ordered drain of drain_entry_results, core.rs:471-493).  pna_gpu_gather_ordered: ncclAllGather of the parts' sizes
+// and the root's capacity (one verdict for all ranks), then grouped ncclSend / ncclRecv -- every sending rank has its own xGMI link to the root, so the seven transfers of an 8-GPU node run side by side.
 // RCCL is taken with dlopen("librccl.so.1") at the first call: libpna_gpu.so itself links only the HIP runtime, and a process that never gathers never
 // loads RCCL (nor a second copy next to the one PyTorch brings along).
 #include <hip/hip_runtime.h>
@@ -44,7 +44,13 @@ Rccl *rccl() {
 struct pna_gpu_comm {
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0, device = 0;
-    uint64_t *d_sizes = nullptr;         // nranks + 1 words in HBM: the all-gathered sizes, then this rank's own
+    uint64_t *d_sizes = nullptr;         // 2 (nranks + 1) words in HBM: the all-gathered (size, capacity) pairs, then this rank's own
+    uint64_t *h_pairs = nullptr;         // page-locked: this rank's pair, then the gathered pairs
+    hipStream_t st = nullptr;            // the communicator's stream: every RCCL call of this communicator is issued here
+    hipEvent_t ev = nullptr;             // orders a gather behind the caller's stream
+    static constexpr int RING = 8;
+    hipEvent_t done[RING] = {};          // done[t % RING]: recorded behind the t-th gather posted (tickets count from 1)
+    uint64_t posted = 0;
     std::string err;
 };
 
@@ -60,6 +66,7 @@ extern "C" int pna_gpu_comm_unique_id(void *id128) {
     return PNA_OK;
 }
 
+extern "C" void pna_gpu_comm_destroy(pna_gpu_comm *m);
 extern "C" int pna_gpu_comm_init(int device_id, const void *id128, int nranks, int rank, pna_gpu_comm **out) {
     if (!out) return PNA_E_INVAL;
     *out = nullptr;
@@ -70,10 +77,13 @@ extern "C" int pna_gpu_comm_init(int device_id, const void *id128, int nranks, i
     pna_gpu_comm *m = new pna_gpu_comm();
     m->nranks = nranks; m->rank = rank; m->device = device_id;
     ncclUniqueId id; memcpy(&id, id128, sizeof(id));
-    if (R->CommInitRank(&m->comm, nranks, id, rank) != ncclSuccess || hipMalloc((void **)&m->d_sizes, (size_t)(nranks + 1) * 8) != hipSuccess) {
-        if (m->comm) (void)R->CommDestroy(m->comm);
-        delete m; return PNA_E_HIP;
+    if (R->CommInitRank(&m->comm, nranks, id, rank) != ncclSuccess || hipMalloc((void **)&m->d_sizes, (size_t)(nranks + 1) * 16) != hipSuccess ||
+        hipHostMalloc((void **)&m->h_pairs, (size_t)(nranks + 1) * 16, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess) {
+        pna_gpu_comm_destroy(m); return PNA_E_HIP;
     }
+    for (int i = 0; i < pna_gpu_comm::RING; i++)
+        if (hipEventCreateWithFlags(&m->done[i], hipEventDisableTiming) != hipSuccess) { pna_gpu_comm_destroy(m); return PNA_E_HIP; }
     *out = m;
     return PNA_OK;
 }
@@ -81,9 +91,14 @@ extern "C" int pna_gpu_comm_init(int device_id, const void *id128, int nranks, i
 extern "C" void pna_gpu_comm_destroy(pna_gpu_comm *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    if (m->d_sizes) (void)hipFree(m->d_sizes);
+    if (m->st) { (void)hipStreamSynchronize(m->st); }
     Rccl *R = rccl();
     if (R && m->comm) (void)R->CommDestroy(m->comm);
+    if (m->d_sizes) (void)hipFree(m->d_sizes);
+    if (m->h_pairs) (void)hipHostFree(m->h_pairs);
+    if (m->ev) (void)hipEventDestroy(m->ev);
+    for (int i = 0; i < pna_gpu_comm::RING; i++) if (m->done[i]) (void)hipEventDestroy(m->done[i]);
+    if (m->st) (void)hipStreamDestroy(m->st);
     delete m;
 }
 
@@ -97,36 +112,83 @@ extern "C" int pna_gather_offsets(const uint64_t *sizes, int nranks, uint64_t *o
     return PNA_OK;
 }
 
-extern "C" int pna_gpu_gather_ordered(pna_gpu_comm *m, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
-                                      uint64_t *sizes, uint64_t *total, void *hip_stream) {
+// What every rank decides from the all-gathered (size, capacity) pairs -- the SAME verdict on every rank, so nobody is left inside a send whose receive is
+// never posted: PNA_OK and the offsets, PNA_E_INVAL when the sizes overflow 64 bits, PNA_E_DSTSIZE when the parts do not fit the root's destination.
+// pairs[2 r] = rank r's part length, pairs[2 r + 1] = the capacity rank r offers (only the root's counts).  Host arithmetic, exported for the CPU tests.
+extern "C" int pna_gather_verdict(const uint64_t *pairs, int nranks, int root, uint64_t *sizes, uint64_t *offs) {
+    if (!pairs || nranks < 1 || root < 0 || root >= nranks) return PNA_E_INVAL;
+    std::vector<uint64_t> sz((size_t)nranks), of((size_t)nranks + 1);
+    for (int r = 0; r < nranks; r++) sz[(size_t)r] = pairs[2 * r];
+    if (pna_gather_offsets(sz.data(), nranks, of.data()) != PNA_OK) return PNA_E_INVAL;
+    if (sizes) memcpy(sizes, sz.data(), (size_t)nranks * 8);
+    if (offs) memcpy(offs, of.data(), ((size_t)nranks + 1) * 8);
+    return of[(size_t)nranks] > pairs[2 * root + 1] ? PNA_E_DSTSIZE : PNA_OK;
+}
+
+// The gather, posted: the size exchange (16 bytes per rank) runs on the communicator's OWN stream and is the only thing this call waits for; the parts'
+// transfers are queued on that stream behind an event recorded on `hip_stream` (the stream whose work produced d_local) and the call returns.
+// pna_gpu_gather_wait() blocks until they are done; until then d_local and d_out belong to the gather.  So a host that compresses piece k + 1 into a
+// second buffer after this call overlaps it with piece k's transfer -- one RCCL stream per communicator, no RCCL call ever issued on the caller's stream.
+extern "C" int pna_gpu_gather_ordered_start(pna_gpu_comm *m, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
+                                            uint64_t *sizes, uint64_t *total, void *hip_stream) {
     Rccl *R = rccl();
     if (!m || !R) return PNA_E_INVAL;
     auto bad = [&](int code, const char *what, ncclResult_t nr = ncclSuccess) { m->err = what; if (nr != ncclSuccess && R->GetErrorString) { m->err += ": "; m->err += R->GetErrorString(nr); } return code; };
     if (root < 0 || root >= m->nranks || (local_len && !d_local)) return bad(PNA_E_INVAL, "bad argument");
     if (hipSetDevice(m->device) != hipSuccess) return bad(PNA_E_HIP, "hipSetDevice failed");
-    hipStream_t st = (hipStream_t)hip_stream;
-    // (1) everybody learns every part's size: 8 bytes per rank
-    uint64_t *d_mine = m->d_sizes + m->nranks;
-    if (hipMemcpyAsync(d_mine, &local_len, 8, hipMemcpyHostToDevice, st) != hipSuccess) return bad(PNA_E_HIP, "size upload failed");
-    ncclResult_t nr = R->AllGather(d_mine, m->d_sizes, 1, ncclUint64, m->comm, st);
+    hipStream_t cs = m->st;
+    // (1) everybody learns every part's size and the root's capacity: two words per rank.  (A root without a destination offers capacity 0.)
+    m->h_pairs[0] = local_len;
+    m->h_pairs[1] = (m->rank == root && d_out) ? out_cap : 0;
+    uint64_t *d_mine = m->d_sizes + 2 * (size_t)m->nranks;
+    if (hipMemcpyAsync(d_mine, m->h_pairs, 16, hipMemcpyHostToDevice, cs) != hipSuccess) return bad(PNA_E_HIP, "size upload failed");
+    ncclResult_t nr = R->AllGather(d_mine, m->d_sizes, 2, ncclUint64, m->comm, cs);
     if (nr != ncclSuccess) return bad(PNA_E_HIP, "ncclAllGather", nr);
-    std::vector<uint64_t> sz((size_t)m->nranks), offs((size_t)m->nranks + 1);
-    if (hipMemcpyAsync(sz.data(), m->d_sizes, (size_t)m->nranks * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    uint64_t *pairs = m->h_pairs + 2;
+    if (hipMemcpyAsync(pairs, m->d_sizes, (size_t)m->nranks * 16, hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess)
         return bad(PNA_E_HIP, "size download failed");
-    if (pna_gather_offsets(sz.data(), m->nranks, offs.data()) != PNA_OK) return bad(PNA_E_INVAL, "sizes overflow");
+    std::vector<uint64_t> sz((size_t)m->nranks), offs((size_t)m->nranks + 1);
+    const int verdict = pna_gather_verdict(pairs, m->nranks, root, sz.data(), offs.data());
+    if (verdict == PNA_E_INVAL) return bad(PNA_E_INVAL, "sizes overflow");
     if (sizes) memcpy(sizes, sz.data(), (size_t)m->nranks * 8);
-    if (total) *total = offs[m->nranks];
-    // (2) the parts travel to the root, each over its own link; the root's own part is a device copy
+    if (total) *total = offs[(size_t)m->nranks];
+    // every rank has the same pairs, hence the same verdict: on an overflow NOBODY sends and every rank returns the error
+    if (verdict == PNA_E_DSTSIZE) return bad(PNA_E_DSTSIZE, "gather destination too small (no part was sent; every rank returns this)");
+    // (2) the parts travel to the root, each over its own link, once the caller's stream has produced them; the root's own part is a device copy
+    if (hipEventRecord(m->ev, (hipStream_t)hip_stream) != hipSuccess || hipStreamWaitEvent(cs, m->ev, 0) != hipSuccess) return bad(PNA_E_HIP, "stream order failed");
     if (m->rank == root) {
-        if (offs[m->nranks] > out_cap || (offs[m->nranks] && !d_out)) return bad(PNA_E_DSTSIZE, "gather destination too small");   // (the senders' data then stays unsent: the caller aborts the job)
-        if (local_len && hipMemcpyAsync((uint8_t *)d_out + offs[root], d_local, local_len, hipMemcpyDeviceToDevice, st) != hipSuccess) return bad(PNA_E_HIP, "local copy failed");
+        if (local_len && hipMemcpyAsync((uint8_t *)d_out + offs[(size_t)root], d_local, local_len, hipMemcpyDeviceToDevice, cs) != hipSuccess) return bad(PNA_E_HIP, "local copy failed");
         if ((nr = R->GroupStart()) != ncclSuccess) return bad(PNA_E_HIP, "ncclGroupStart", nr);
         for (int r = 0; r < m->nranks; r++)
-            if (r != root && sz[r] && (nr = R->Recv((uint8_t *)d_out + offs[r], sz[r], ncclUint8, r, m->comm, st)) != ncclSuccess) { (void)R->GroupEnd(); return bad(PNA_E_HIP, "ncclRecv", nr); }
+            if (r != root && sz[(size_t)r] && (nr = R->Recv((uint8_t *)d_out + offs[(size_t)r], sz[(size_t)r], ncclUint8, r, m->comm, cs)) != ncclSuccess) { (void)R->GroupEnd(); return bad(PNA_E_HIP, "ncclRecv", nr); }
         if ((nr = R->GroupEnd()) != ncclSuccess) return bad(PNA_E_HIP, "ncclGroupEnd", nr);
     } else if (local_len) {
-        if ((nr = R->Send(d_local, local_len, ncclUint8, root, m->comm, st)) != ncclSuccess) return bad(PNA_E_HIP, "ncclSend", nr);
+        if ((nr = R->Send(d_local, local_len, ncclUint8, root, m->comm, cs)) != ncclSuccess) return bad(PNA_E_HIP, "ncclSend", nr);
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return bad(PNA_E_HIP, "gather failed");
+    m->posted++;
+    if (hipEventRecord(m->done[m->posted % pna_gpu_comm::RING], cs) != hipSuccess) return bad(PNA_E_HIP, "event record failed");
     return PNA_OK;
+}
+
+// the number of gathers this communicator has posted = the ticket of the latest one
+extern "C" uint64_t pna_gpu_gather_ticket(const pna_gpu_comm *m) { return m ? m->posted : 0; }
+
+// Blocks until the gathers up to `ticket` are done (0 or a ticket out of the ring's reach: all of them).  A host that double-buffers waits for the
+// gather that used a buffer two pieces ago while the latest one is still travelling.
+extern "C" int pna_gpu_gather_wait_for(pna_gpu_comm *m, uint64_t ticket) {
+    if (!m) return PNA_E_INVAL;
+    if (hipSetDevice(m->device) != hipSuccess) { m->err = "hipSetDevice failed"; return PNA_E_HIP; }
+    hipError_t e;
+    if (ticket == 0 || ticket > m->posted || m->posted - ticket >= (uint64_t)pna_gpu_comm::RING) e = hipStreamSynchronize(m->st);
+    else e = hipEventSynchronize(m->done[ticket % pna_gpu_comm::RING]);
+    if (e != hipSuccess) { m->err = "gather failed"; return PNA_E_HIP; }
+    return PNA_OK;
+}
+extern "C" int pna_gpu_gather_wait(pna_gpu_comm *m) { return pna_gpu_gather_wait_for(m, 0); }
+
+// the synchronous form: start + wait
+extern "C" int pna_gpu_gather_ordered(pna_gpu_comm *m, const void *d_local, uint64_t local_len, int root, void *d_out, uint64_t out_cap,
+                                      uint64_t *sizes, uint64_t *total, void *hip_stream) {
+    const int rc = pna_gpu_gather_ordered_start(m, d_local, local_len, root, d_out, out_cap, sizes, total, hip_stream);
+    return rc != PNA_OK ? rc : pna_gpu_gather_wait(m);
 }

@@ -1792,6 +1792,9 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
                 off[i] = pos; len64[i] = l; pos = (pos + l + 15) & ~(uint64_t)15; blocks += nb;
                 sb.out_cap += (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + pna_gpu_bound(algo, (size_t)l) + 16;
                 if (cipher && cipher->cipher_mode == PNA_MODE_GCM) sb.out_cap += 16 * (pna_gpu_bound(algo, (size_t)l) / (cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20)));   // a tag per full stream segment
+                // a CRC + a header per further FDAT chunk once max_chunk_size cuts the payload (the term of pna_gpu_archive_chunked_bound: without it data
+                // that does not compress overran the sub-batch's device buffer by 12 bytes per chunk -- PNA_E_DSTSIZE for a 2 MiB random entry at mcs = 1000)
+                sb.out_cap += 12 * (uint64_t)((pna_gpu_bound(algo, (size_t)l) + 64 + 16 * (l >> 12)) / chunk_limit(max_chunk) + 1);
                 done += l; sb.e1++;
             }
             sb.in_bytes = pos; subs.push_back(sb); e = sb.e1;

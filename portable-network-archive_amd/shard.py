@@ -36,51 +36,51 @@ def piece_ranges(rank: int, world: int, pieces: int, per_piece: int) -> List[Tup
     return [((h * world + rank) * per_piece, (h * world + rank + 1) * per_piece) for h in range(pieces)]
 
 
-def gather_ordered(local, local_bytes: int, rank: int, world: int, out=None):
+class GatherOverflow(RuntimeError):
+    """The parts do not fit the destination rank 0 offered (and growing it was not allowed).  Raised on EVERY rank -- the capacity travels with the sizes --
+    before anything is sent, so the job sees an error, never a hang (pna_gpu_gather_ordered's PNA_E_DSTSIZE; include/pna_gpu.h)."""
+
+    def __init__(self, need: int, cap: int, sizes):
+        super().__init__(f"ordered gather: {need} bytes do not fit the {cap} offered on rank 0")
+        self.need, self.cap, self.sizes = need, cap, sizes
+
+
+def _exchange_sizes(local, local_bytes: int, rank: int, world: int, out, grow: bool):
+    """All-gather of (part size, capacity offered): every rank gets the same pairs, hence the same verdict.  Capacity -1 = rank 0 may allocate."""
+    import torch
+    import torch.distributed as dist
+    cap = -1 if (grow or rank != 0) else (out.numel() if out is not None else 0)
+    pairs = torch.zeros(2 * world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(pairs, torch.tensor([local_bytes, cap], dtype=torch.int64, device=local.device))
+    pl = [int(x) for x in pairs.tolist()]
+    sizes, cap0 = pl[0::2], pl[1]
+    need = sum(sizes)
+    if cap0 >= 0 and need > cap0:
+        raise GatherOverflow(need, cap0, sizes)
+    return sizes, need
+
+
+def gather_ordered(local, local_bytes: int, rank: int, world: int, out=None, grow: bool = True):
     """Gather every rank's first `local_bytes` bytes of the uint8 tensor `local` onto rank 0, in rank order.
 
-    Returns (tensor, sizes) on rank 0 and (None, sizes) elsewhere.  Works for CUDA tensors over the nccl (=RCCL)
-    backend and CPU tensors over gloo."""
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return local[:local_bytes], [local_bytes]
-    sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
-    dist.all_gather_into_tensor(sizes_t, torch.tensor([local_bytes], dtype=torch.int64, device=local.device))
-    sizes = [int(x) for x in sizes_t.tolist()]
-    if rank == 0:
-        need = sum(sizes)
-        if out is None or out.numel() < need:
-            out = torch.empty(need, dtype=torch.uint8, device=local.device)
-        out[:sizes[0]].copy_(local[:sizes[0]])
-        ops, pos = [], sizes[0]
-        for r in range(1, world):
-            if sizes[r]:
-                ops.append(dist.P2POp(dist.irecv, out[pos:pos + sizes[r]], r))
-            pos += sizes[r]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return out[:need], sizes
-    if local_bytes:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]):
-            w.wait()
-    return None, sizes
+    Returns (gathered bytes, sizes) on rank 0 and (None, sizes) elsewhere.  Works for CUDA tensors over the nccl (=RCCL)
+    backend and CPU tensors over gloo.  The synchronous form of gather_ordered_start / gather_ordered_wait."""
+    return gather_ordered_wait(gather_ordered_start(local, local_bytes, rank, world, out=out, grow=grow))[::2]
 
 
-def gather_ordered_start(local, local_bytes: int, rank: int, world: int, out=None):
+def gather_ordered_start(local, local_bytes: int, rank: int, world: int, out=None, grow: bool = True):
     """Asynchronous form of gather_ordered: posts the size exchange and the sends / receives and returns a handle for
     gather_ordered_wait().  `local` (and `out` on rank 0) must stay untouched until the wait returns -- callers that keep
-    producing double-buffer `local`, so the gather of shard k overlaps the compression of shard k+1."""
+    producing double-buffer `local`, so the gather of shard k overlaps the compression of shard k+1.
+    `out` (rank 0): a destination to reuse; when it is too small a larger one is allocated if `grow`, else GatherOverflow is raised on every rank."""
     import torch
     import torch.distributed as dist
     if world == 1:
-        return {"works": [], "out": local[:local_bytes], "sizes": [local_bytes]}
-    sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
-    dist.all_gather_into_tensor(sizes_t, torch.tensor([local_bytes], dtype=torch.int64, device=local.device))
-    sizes = [int(x) for x in sizes_t.tolist()]
+        if out is not None and not grow and out.numel() < local_bytes:
+            raise GatherOverflow(local_bytes, out.numel(), [local_bytes])
+        return {"works": [], "out": local[:local_bytes], "buf": local, "sizes": [local_bytes]}
+    sizes, need = _exchange_sizes(local, local_bytes, rank, world, out, grow)
     if rank == 0:
-        need = sum(sizes)
         if out is None or out.numel() < need:
             out = torch.empty(need, dtype=torch.uint8, device=local.device)
         out[:sizes[0]].copy_(local[:sizes[0]], non_blocking=True)
@@ -89,14 +89,14 @@ def gather_ordered_start(local, local_bytes: int, rank: int, world: int, out=Non
             if sizes[r]:
                 ops.append(dist.P2POp(dist.irecv, out[pos:pos + sizes[r]], r))
             pos += sizes[r]
-        return {"works": dist.batch_isend_irecv(ops) if ops else [], "out": out, "sizes": sizes}      # `out`: the buffer in use -- the caller's, or a larger one allocated here
+        return {"works": dist.batch_isend_irecv(ops) if ops else [], "out": out[:need], "buf": out, "sizes": sizes}
     works = dist.batch_isend_irecv([dist.P2POp(dist.isend, local[:local_bytes], 0)]) if local_bytes else []
-    return {"works": works, "out": None, "sizes": sizes}
+    return {"works": works, "out": None, "buf": None, "sizes": sizes}
 
 
 def gather_ordered_wait(handle):
-    """Completes a gather_ordered_start(); returns (buffer on rank 0 / None elsewhere, sizes): the gathered bytes are buffer[:sum(sizes)], and the buffer
-    is the one to offer as `out` next time (it is not the caller's own when that was too small)."""
+    """Completes a gather_ordered_start(); returns (gathered, buffer, sizes): `gathered` = exactly the gathered bytes (rank 0; None elsewhere) -- the same
+    on every path --, `buffer` = the tensor behind it, to offer as `out` next time (not the caller's own when that was too small)."""
     for w in handle["works"]:
         w.wait()
-    return handle["out"], handle["sizes"]
+    return handle["out"], handle["buf"], handle["sizes"]

@@ -854,6 +854,22 @@ def test_max_chunk_size_cuts_fdat_like_flatten_writer(gpu_ctx, pna, pf, codec, m
         with pytest.raises(pna.PnaGpuError):
             pna.create_archive_chunked(gpu_ctx, names, ents, mcs, cipher=pna.Cipher(key, phsf, pna.MODE_CBC, ivs=ivs))
 
+def test_max_chunk_size_host_pipeline_with_incompressible_entries_only(gpu_ctx, pna, pf, codec):
+    """The bounded host pipeline sizes a sub-batch's device buffer per entry; with max_chunk_size set every further FDAT chunk costs a CRC + a header
+    (12 bytes) on top of pna_gpu_bound.  Entries that do not compress at all leave no slack to borrow: two 2 MiB random entries at chunks of 1 000 bytes
+    need ~25 KB of chunk framing each (the round-3 advisor's case: PNA_E_DSTSIZE before the term was added to the host path as well)."""
+    ents = [codec.corpus_file(2, 900 + i, 2 << 20) for i in range(2)]
+    names = [f"rnd/{i}" for i in range(len(ents))]
+    payloads = gpu_ctx.compress_batch(ents)
+    assert all(len(p) >= len(e) for p, e in zip(payloads, ents))                       # really incompressible: raw blocks
+    for mcs in (1000, 4096):
+        want = pf.write_archive_header() + b"".join(
+            pf.write_normal_entry(pf.file_entry_header(2, nm), pf.flatten_writer([pl], mcs), len(e)) for nm, pl, e in zip(names, payloads, ents)) + pf.finalize_archive()
+        assert pna.create_archive_chunked(gpu_ctx, names, ents, mcs) == want
+        with gpu_ctx.options(max_chunk_size=(mcs, 0)):
+            assert pna.create_archive(gpu_ctx, names, ents) == want
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Device inflate (k_inflate -> k_zoff / k_zexec -> k_iadler): flate2::read::ZlibDecoder behind decompress_reader
 def _zlib_streams(codec):
@@ -1358,9 +1374,23 @@ def test_ordered_gather_over_rccl_single_rank(gpu_ctx, pna, pf, codec):
         assert sizes == [len(arc)] and total == len(arc)
         assert out[:total].cpu().numpy().tobytes() == arc and int(out[total:].sum()) == 0
         assert [(n, d) for n, _, d in pna.extract_archive(gpu_ctx, out[:total].cpu().numpy().tobytes())] == list(zip(names, ents))
-        with pytest.raises(pna.PnaGpuError):
-            comm.gather_ordered(local.data_ptr(), len(arc), out.data_ptr(), 100)          # destination too small
-        assert comm.gather_ordered(0, 0, out.data_ptr(), out.numel()) == ([0], 0)          # an empty part
+        with pytest.raises(pna.PnaGpuError) as ei:
+            comm.gather_ordered(local.data_ptr(), len(arc), out.data_ptr(), 100)          # destination too small: the collective verdict, nothing sent
+        assert ei.value.code == pna.E_DSTSIZE
+        assert comm.gather_ordered(0, 0, out.data_ptr(), out.numel()) == ([0], 0)          # an empty part; the communicator is still in step
+        # the posted form: two gathers in flight on the communicator's stream, each behind the stream that produced its part; tickets say which is done
+        side = torch.cuda.Stream()
+        out2 = torch.zeros_like(out)
+        with torch.cuda.stream(side):
+            local2 = local.flip(0).contiguous()                                               # (produced on `side`: the gather must wait for it)
+        t0 = comm.ticket()
+        assert comm.gather_ordered_start(local.data_ptr(), len(arc), out.data_ptr(), out.numel()) == ([len(arc)], len(arc))
+        assert comm.gather_ordered_start(local2.data_ptr(), len(arc), out2.data_ptr(), out2.numel(), stream=side.cuda_stream) == ([len(arc)], len(arc))
+        assert comm.ticket() == t0 + 2
+        comm.gather_wait(t0 + 1)
+        assert out[:total].cpu().numpy().tobytes() == arc
+        comm.gather_wait()
+        assert out2[:total].cpu().numpy().tobytes() == arc[::-1]
     finally:
         comm.close()
 
