@@ -92,7 +92,7 @@ size_t pna_gpu_bound(int algo, size_t src_len);
 /* Level mapping of the reference, restated so callers can pass CompressionLevel values through unchanged:
  * lib/src/compress/zstandard.rs:43-57 (Default -> 3, clamp to min..max) and lib/src/compress/deflate.rs:89-101
  * (Default -> 6, clamp 0..9).  `level` < 0 with level == PNA_LEVEL_DEFAULT means default. */
-/* The encoder has these parameter sets behind that scale: fast (zstd < 0 and 1, deflate 0..3: every position in the table, lazy deferral,
+/* The encoder has these parameter sets behind that scale: stored (deflate 0 = Compression::none(): stored blocks only), fast (zstd < 0 and 1, deflate 1..3: every position in the table, lazy deferral,
  * look-back = the LDS window), default
  * (zstd 0 and 2..5, deflate 4..8: + even-position table, backward adoption, 1 MiB look-back (zstd), lazy deferral over three positions; zstd: a third more table slots next to a 32 KiB window), high (zstd 6..9,
  * deflate 9: + a third adoption round and two-step lazy deferral) and, zstd only, max (10..22: + the hash table in global memory, 2^19

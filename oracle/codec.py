@@ -172,7 +172,8 @@ class ZstdParams(ctypes.Structure):
                 ("max_off", ctypes.c_uint32), ("cap1", ctypes.c_uint32), ("lookahead", ctypes.c_uint32),
                 ("flags", ctypes.c_uint32), ("max_len", ctypes.c_uint32), ("region", ctypes.c_uint32),
                 ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
-                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32), ("len_word_max", ctypes.c_uint32)]
+                ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32), ("len_word_max", ctypes.c_uint32),
+                ("tab3", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
@@ -187,14 +188,14 @@ def default_params() -> ZstdParams:
 
 def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = None):
     """(flags, gtab): the level sets behind the reference's level scale as the product maps them (pna_host.cpp level_flags / set_call_level):
-    zstd < 0, 1 fast; 0, 2..5 default; 6..9 high (+ F_STRONG); 10..22 max (+ the hash table in global memory) -- deflate 0..3, 4..8, 9.  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
+    zstd < 0, 1 fast; 2 light; 0, 3..5 default (+ F_STRONG, round 4); 6..9 high (the 16 KiB window: level_win32k); 10..22 max (+ the hash table in global memory) -- deflate 1..3, 4..8, 9 (deflate 0: stored blocks only, params_for_level).  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
     base = ctx_flags if ctx_flags is not None else ((F_ADOPT | F_INS2 | F_LAZY) if deflate else (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2))
     if deflate:
         lv = 6 if level is None or level == -1000 else (9 if level < 0 or level > 9 else level)      # (PNA_LEVEL_DEFAULT; a negative Custom(n) wraps and clamps to 9)
         fast, balanced, strong = lv <= 3, False, lv >= 9                    # (deflate 4..5 = the default set)
     else:
         lv = 3 if level is None or level == -1000 else min(level, 22)
-        fast, balanced, strong = lv < 0 or lv == 1, False, lv >= 6          # (zstd 2 = the default set)
+        fast, balanced, strong = lv < 0 or lv == 1, False, (lv >= 3 or lv == 0)          # (zstd 2 = the light set: two adoption rounds; 0 = the default = 3)
     if fast:
         fl = base & ~(F_FAR | F_ADOPT | F_INS2 | F_STRONG)                    # (lazy deferral stays)
     elif balanced:
@@ -206,12 +207,21 @@ def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = No
     return fl, bool(not deflate and lv >= 10 and fl & F_STRONG and fl & F_ADOPT)
 
 
-def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None) -> "ZstdParams":
+def level_win32k(level, deflate: bool = False, win32k: int = 1) -> int:
+    """The window geometry a zstd level runs with the context's option win32k (1 by default): levels 6..9 take the 16 KiB window (2), the others the option's."""
+    lv = 3 if level is None or level == -1000 else min(level, 22)
+    return 2 if (not deflate and win32k and lv >= 6) else win32k
+
+
+def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1) -> "ZstdParams":
     fl, gtab = product_level_flags(level, deflate, ctx_flags)
-    return params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab)
+    p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3)
+    if deflate and level == 0:
+        p.flags |= 0x200               # PNA_F_STORED: deflate level 0 = Compression::none(), stored blocks only (lib/src/compress/deflate.rs:89-101)
+    return p
 
 
-def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2) -> ZstdParams:
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2, tab3: int = 1) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
     F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
     (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB).  gtab: the match kernel's table lies in global
@@ -219,10 +229,16 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
     table slots) unless the table is global or the context's option win32k is 0; everything else the 64 KiB one (24 512)."""
     p = deflate_default_params() if deflate else default_params()
     p.blk_log = blk_log
+    # the packed table (three 21-bit entries per 64-bit LDS word; the product's option tab3, default on): the sets on the 32 / 16 KiB geometries with
+    # even-position inserts and backward adoption -- 49 062 / 55 206 slots instead of 32 704 / 36 800
+    packed = bool(tab3 and flags & F_INS2 and flags & F_ADOPT)
+    p.tab3 = 0
     if not deflate and not (flags & F_FAR and flags & F_LAZY and not gtab and win32k):
         p.hash_log, p.near_off = 24512, 56064
-    elif not deflate and (win32k >= 2 or (flags & F_STRONG and flags & F_ADOPT)):
-        p.hash_log, p.near_off = 36800, 6912       # the 16 KiB window: the high set (and, with the product's option win32k = 2, the default set)
+    elif not deflate and win32k >= 2:
+        p.hash_log, p.near_off, p.tab3 = (55206 if packed else 36800), 6912, int(packed)       # the 16 KiB window: the high set (and, with the product's option win32k = 2, the default set)
+    elif not deflate:
+        p.hash_log, p.near_off, p.tab3 = (49062 if packed else 32704), 23296, int(packed)
     p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
     p.flags &= ~0x180                      # two- and three-step lazy deferral go with F_LAZY (the product's option lazy2 = 2 / 1 / 0: both, the first, none -- the high sets keep the first)
     if flags & F_LAZY and (lazy2 or flags & F_STRONG):

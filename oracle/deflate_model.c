@@ -153,14 +153,18 @@ size_t pna_deflate_bound(size_t n) {
 void pna_deflate_default_params(pna_zstd_params *p) {
     pna_zstd_default_params(p);
     p->max_off = 32768; p->max_len = 258; p->flags = PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3;
-    p->hash_log = 24512; p->near_off = 56064;      /* the 64 KiB-window geometry: the whole look-back lies in the window */
+    p->hash_log = 24512; p->near_off = 56064; p->tab3 = 0;      /* the 64 KiB-window geometry: the whole look-back lies in the window; 32-bit table entries */
 }
 
 size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const pna_zstd_params *p) {
     if (cap < pna_deflate_bound(n)) return 0;
+    /* level 0 = Compression::none() (lib/src/compress/deflate.rs:89-101): stored blocks only -- header 78 01 (FLEVEL 0), per block of the block size
+     * the stored pieces (<= 65 535 bytes each), the sync flush between blocks as everywhere, an empty entry = one empty final stored block */
+    const int stored_only = (p->flags & PNA_F_STORED) != 0;
+    if (n == 0 && stored_only) { static const uint8_t e[11] = {0x78,0x01,0x01,0x00,0x00,0xFF,0xFF,0x00,0x00,0x00,0x01}; memcpy(dst, e, 11); return 11; }
     if (n == 0) { static const uint8_t e[8] = {0x78,0x9C,0x03,0x00,0x00,0x00,0x00,0x01}; memcpy(dst, e, 8); return 8; }
     size_t op = 0;
-    dst[op++] = 0x78; dst[op++] = 0x9C;
+    dst[op++] = 0x78; dst[op++] = stored_only ? 0x01 : 0x9C;
     const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     const uint32_t BS = pna_blk_size(p);
@@ -208,7 +212,7 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
             if (!last) dw_add(&w, 0, 3);                   /* header of the empty stored block (sync flush), then align */
             size_t dyn = dw_align(&w);
             size_t stored = (size_t)bl_len + 5 * (((size_t)bl_len + 65534) / 65535);
-            if (dyn >= stored || dyn > BS) {       /* second clause: the device's per-block scratch is one block */
+            if (stored_only || dyn >= stored || dyn > BS) {       /* second clause: the device's per-block scratch is one block */
                 for (uint32_t o = 0; o < bl_len; o += 65535) {
                     uint32_t k = bl_len - o < 65535 ? bl_len - o : 65535;
                     dst[op++] = (uint8_t)((last && o + k >= bl_len) ? 1 : 0);

@@ -21,14 +21,14 @@
 
 static int hb32(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
-/* The default level set of the product: its match finder's 32 KiB-window geometry (32 704 table slots; candidates more than 23 296 bytes back count as
- * "far").  The fast / balanced sets, the sets with the table in global memory and deflate run the 64 KiB geometry: 24 512 slots, far beyond 56 064
+/* The default level set of the product: its match finder's 32 KiB-window geometry with the PACKED table (49 062 slots in words of three, round 4; with
+ * 32-bit entries 32 704; candidates more than 23 296 bytes back count as "far").  The fast / balanced sets, the sets with the table in global memory and deflate run the 64 KiB geometry: 24 512 slots, far beyond 56 064
  * (oracle/codec.py params_for_flags sets those). */
 void pna_zstd_default_params(pna_zstd_params *p) {
-    p->hash_log = 32704; p->min_match = 6; p->tile = 4096; p->max_off = (1u << 19) - 1; p->cap1 = 32;
+    p->hash_log = 49062; p->min_match = 6; p->tile = 4096; p->max_off = (1u << 19) - 1; p->cap1 = 32;
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3 | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
-    p->blk_log = 0; p->len_word_max = 36;
+    p->blk_log = 0; p->len_word_max = 36; p->tab3 = 1;
 }
 
 /* block size of a parameter set: 128 KiB unless blk_log names a smaller power of two (the device's latency mode: small batches are cut
@@ -57,6 +57,15 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
     /* hash_log <= 31: a table of 2^hash_log entries, index = the top bits; larger values ARE the entry count (any size that fits the
      * LDS): index = floor(h * count / 2^32) */
     return hash_log <= 31 ? h >> (32 - hash_log) : (uint32_t)(((uint64_t)h * hash_log) >> 32);
+}
+/* the packed table (tab3): slot = 3 * word + field; the word from the hash's top bits, the field from its low 16 */
+static uint32_t lz_hash3(const uint8_t *p, uint32_t min_match, uint32_t slots) {
+    uint32_t lo = rd32(p);
+    uint32_t hi = 0;
+    if (min_match >= 5) hi = p[4];
+    if (min_match >= 6) hi |= (uint32_t)p[5] << 8;
+    uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA6Bu;
+    return 3u * (uint32_t)(((uint64_t)h * (slots / 3)) >> 32) + (((h & 0xFFFFu) * 3u) >> 16);
 }
 
 /*
@@ -100,12 +109,30 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     uint8_t *back0 = (uint8_t *)malloc(2 * (T + 1)), *far0 = back0 + T + 1;
     const uint32_t ins_mod = p->ins_mod ? p->ins_mod : 1;
     uint32_t *mq = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1) * 4), *ml = mq + T + 1, *mc = ml + T + 1, *mr = mc + T + 1;
+    uint32_t *wbest = p->tab3 ? (uint32_t *)calloc(p->hash_log / 3 + 1, sizeof(uint32_t)) : NULL, *wlist = p->tab3 ? (uint32_t *)malloc(sizeof(uint32_t) * (T + 1)) : NULL;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
         uint32_t t1 = t0 + T < blk_end ? t0 + T : blk_end;
         /* L */
         for (uint32_t q = t0; q < t1; q++)
-            cand[q - t0] = (q + 8 <= seg_len) ? table[lz_hash(seg + q, p->min_match, p->hash_log)] : 0;
+            cand[q - t0] = (q + 8 > seg_len) ? 0 : table[p->tab3 ? lz_hash3(seg + q, p->min_match, p->hash_log) : lz_hash(seg + q, p->min_match, p->hash_log)];
         /* I */
+        if (p->tab3) {
+            /* per word of three slots, ONE of the tile's inserts is stored: the contender with the highest (field, position) -- the device's single
+             * 64-bit maximum of "the word as the look-ups saw it, my field replaced".  (Position 0 is never stored: its entry is the empty one.) */
+            uint32_t nw = 0;
+            for (uint32_t q = t0; q < t1; q++) {
+                if (q + 8 > seg_len || q % ins_mod || q == 0) continue;
+                const uint32_t s3 = lz_hash3(seg + q, p->min_match, p->hash_log), w = s3 / 3;
+                const uint32_t key = ((s3 % 3 + 1) << 24) | (q - t0);               /* (field + 1, position): 0 = no contender yet */
+                if (!wbest[w]) wlist[nw++] = w;
+                if (key > wbest[w]) wbest[w] = key;
+            }
+            for (uint32_t i = 0; i < nw; i++) {
+                const uint32_t w = wlist[i], key = wbest[w];
+                wbest[w] = 0;
+                table[3 * w + (key >> 24) - 1] = t0 + (key & 0xFFFFFFu) + 1;
+            }
+        } else
         for (uint32_t q = t0; q < t1; q++)
             if (q + 8 <= seg_len) {
                 uint32_t h = lz_hash(seg + q, p->min_match, p->hash_log);
@@ -176,7 +203,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         }
     }
     memcpy(lits + nlit, seg + lit_start, blk_end - lit_start); nlit += blk_end - lit_start;
-    free(cand); free(len); free(mq); free(back); free(len0); free(cand0); free(back0);
+    free(cand); free(len); free(mq); free(back); free(len0); free(cand0); free(back0); free(wbest); free(wlist);
     *nlit_out = nlit;
     return nseq;
 }

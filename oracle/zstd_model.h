@@ -25,6 +25,7 @@
 #define PNA_F_LAZY     4u           /* one-step lazy deferral inside a 64-position group        */
 #define PNA_F_REP      8u           /* repeat-offset codes (block-local history)                */
 #define PNA_F_LAZY3    0x100u       /* with PNA_F_LAZY2: also defer to a match at q + 3 that is longer by three or more */
+#define PNA_F_STORED   0x200u       /* deflate model only: level 0 (Compression::none()): every block a stored block, header 78 01 */
 #define PNA_F_LAZY2    0x80u        /* with PNA_F_LAZY: also defer to a match at q + 2 that is longer by two or more (strong set) */
 
 typedef struct {
@@ -44,6 +45,11 @@ typedef struct {
     uint32_t cap_far;     /* per-position match length cap of far candidates                                                */
     uint32_t blk_log;     /* block size = 1 << blk_log for 13..16 (latency mode of the device: short per-block chains); anything else: 128 KiB */
     uint32_t len_word_max; /* adopted lengths are clamped to it (0 = no clamp): the device's 3-byte words keep lengths up to 36 (plus 19 bits of offset: max_off 524 287) */
+    uint32_t tab3;        /* 1: the PACKED table of the device's default / high zstd sets -- hash_log (> 31, a multiple of 3) slots in words of THREE: word =
+                           * floor(h * (slots / 3) / 2^32), field = ((h & 0xFFFF) * 3) >> 16, slot = 3 * word + field (on the device a 64-bit LDS word of three
+                           * 21-bit entries: 19 bits of even position, 2 of tag).  A tile's inserts into one word are ONE 64-bit maximum of "the word as it was,
+                           * my field replaced": of a tile's contenders for a word only the one with the highest (field, position) is stored, the others are
+                           * lost (4 - 8 % of the inserts; the estimator: -0.1 % of ratio for a half more slots in the same LDS).  Needs ins_mod = 2. */
 } pna_zstd_params;
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */

@@ -553,11 +553,12 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
 }
 
 // ------------------------------------------------------------------ k_dplan : one thread per segment
-__global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk, uint64_t *__restrict__ seg_size) {
+// stored != 0: deflate level 0 (Compression::none(), lib/src/compress/deflate.rs:89-101): every block a stored block, no dynamic block was built
+__global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict__ blk, uint64_t *__restrict__ seg_size, uint32_t stored_only) {
     const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= nseg) return;
     const SegDesc sd = segs[sidx];
-    if (sd.len == 0) { seg_size[sidx] = 8; return; }        // empty entry: 78 9C 03 00 00 00 00 01
+    if (sd.len == 0) { seg_size[sidx] = stored_only ? 11 : 8; return; }        // empty entry: 78 9C 03 00 00 00 00 01 (level 0: 78 01 + an empty final stored block + Adler-32)
     const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
     uint64_t off = (sd.first & 1) ? 2 : 0;                  // zlib header in front of the entry's first segment
     for (uint32_t b = 0; b < nblk; b++) {
@@ -566,7 +567,7 @@ __global__ void k_dplan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo
         const bool last = (sd.first & 2) && (b + 1 == nblk);
         const uint32_t dyn = blk[g].lit_body, stored = bl_len + 5 * ((bl_len + 65534) / 65535);
         uint32_t sz, plan;
-        if (dyn >= stored || dyn > bsz) { plan = 0; sz = stored + (last ? 0 : 5); }   // same rule in the model
+        if (stored_only || dyn >= stored || dyn > bsz) { plan = 0; sz = stored + (last ? 0 : 5); }   // same rule in the model
         else { plan = 1; sz = dyn + (last ? 0 : 4); }
         blk[g].plan = plan; blk[g].out_size = sz; blk[g].out_off = off;
         off += sz;
@@ -611,13 +612,16 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
 // ------------------------------------------------------------------ k_dfinal : one thread per entry
 __global__ void k_dfinal(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ entry_seg, uint32_t nentry,
                          const BlkInfo *__restrict__ blk, const uint64_t *__restrict__ seg_off, const uint64_t *__restrict__ seg_size,
-                         uint8_t *__restrict__ dst) {
+                         uint8_t *__restrict__ dst, uint32_t stored_only) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nentry) return;
     const uint32_t s0 = entry_seg[e], s1 = entry_seg[e + 1];
     uint8_t *o = dst + seg_off[s0];
-    if (segs[s0].len == 0) { const uint8_t z[8] = {0x78, 0x9C, 0x03, 0x00, 0x00, 0x00, 0x00, 0x01}; for (int i = 0; i < 8; i++) o[i] = z[i]; return; }
-    o[0] = 0x78; o[1] = 0x9C;
+    if (segs[s0].len == 0) {
+        if (stored_only) { const uint8_t z[11] = {0x78, 0x01, 0x01, 0x00, 0x00, 0xFF, 0xFF, 0x00, 0x00, 0x00, 0x01}; for (int i = 0; i < 11; i++) o[i] = z[i]; return; }
+        const uint8_t z[8] = {0x78, 0x9C, 0x03, 0x00, 0x00, 0x00, 0x00, 0x01}; for (int i = 0; i < 8; i++) o[i] = z[i]; return;
+    }
+    o[0] = 0x78; o[1] = stored_only ? 0x01 : 0x9C;          // FLEVEL 0 = "fastest", what a level-0 zlib stream says (FCHECK makes 0x7801 a multiple of 31)
     // adler(X || Y): A = A_x + A_y - 1, B = B_x + B_y + len_y * (A_x - 1)   (mod 65521)
     unsigned long long A = 1, B = 0;
     for (uint32_t s = s0; s < s1; s++) {
@@ -638,23 +642,23 @@ void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_
 
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg) {
-    hipLaunchKernelGGL(k_dstats, dim3(nseg), dim3(DS_THREADS), 0, st, segs, seqs, lits, blk, tabs);
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only) {
+    if (!stored_only) hipLaunchKernelGGL(k_dstats, dim3(nseg), dim3(DS_THREADS), 0, st, segs, seqs, lits, blk, tabs);
     if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (ev) (void)hipEventRecord(ev[1], st);
-    if (nblk) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(DB_THREADS), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
+    if (nblk && !stored_only) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(DB_THREADS), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
     if (ev) (void)hipEventRecord(ev[2], st);
-    hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size);
+    hipLaunchKernelGGL(k_dplan, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, blk, seg_size, stored_only ? 1u : 0u);
     k_scan_launch_big(seg_size, seg_off, nseg, st);
     if (ev) (void)hipEventRecord(ev[3], st);
 }
 
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
-                          uint8_t *dst, hipStream_t st) {
+                          uint8_t *dst, hipStream_t st, bool stored_only) {
     if (nblk) hipLaunchKernelGGL(k_dwrite, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk, seg_off, outc, dst);
-    hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, seg_size, dst);
+    hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, seg_size, dst, stored_only ? 1u : 0u);
 }
 
 } // namespace pna

@@ -50,7 +50,7 @@ __device__ unsigned long long g_lz_stamps[8];
 // MODE: 0 = the whole stage in one kernel; 1 / 2 = its two halves as kernels of their own (launch_lz_split): 1 = look-up, match and
 // inserts only -- one word per position (length | offset << 6, after adoption) goes to `pbuf` --, 2 = parse, merge and emission from those
 // words (no window, no table: 192 bytes of LDS, two workgroups per CU).  Same code, same results: the halves only meet in `pbuf`.
-template <bool STAMP, int G, bool CT, bool STRONG, int MODE, uint32_t WLOG>
+template <bool STAMP, int G, bool CT, bool STRONG, int MODE, uint32_t WLOG, bool TAB3 = false>   // TAB3: the packed table (lz_common.h)
 __global__ __launch_bounds__(LZ_THREADS, MODE == 2 ? 8 : 4)   // (second figure: waves per SIMD the compiler must leave room for)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len,
@@ -59,13 +59,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     constexpr uint32_t TILE_G = RW * LZ_WAVES;             // positions per synchronous step
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     constexpr bool FAR = !CT;                               // deflate offsets (<= 32 KiB) never leave the LDS window
-    using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
-    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, L_WEND = GEO::L_WEND, L_WPUB = GEO::L_WPUB;
+    using GEO = LzGeo<WLOG, TAB3>;                          // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
+    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, L_WEND = GEO::L_WEND, L_WPUB = GEO::L_WPUB, NW3 = GEO::WORDS3;
+    static_assert(!TAB3 || (!CT && G == 4), "the packed table: zstd launches");
     constexpr uint32_t NEAR = G == 2 ? MAX_OFF_G2 : GEO::NEAR;
     static_assert(TILE_G % TILE == 0 && WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!CT || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32   = (uint32_t *)(lds + L_WIN);
     uint32_t *table   = (uint32_t *)(lds + L_TABLE);
+    uint64_t *table64 = (uint64_t *)(lds + L_TABLE);      // TAB3
     uint32_t *wend    = (uint32_t *)(lds + (MODE == 2 ? 0u : L_WEND));
     WPub     *wpub    = (WPub *)(lds + (MODE == 2 ? 4u * LZ_WAVES : L_WPUB));
 
@@ -83,7 +85,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
 
-    if (MODE != 2) for (uint32_t i = tid; i < HASH_ENTRIES / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 16 bytes per store
+    if (MODE != 2) for (uint32_t i = tid; i < GEO::TABLE_BYTES / 16; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);   // 16 bytes per store
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
     if (STAMP && lane == 0) st_prev = __builtin_amdgcn_s_memtime();
 #define LZ_STAMP(k) do { if (STAMP && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_prev; st_prev = t_; } } while (0)
@@ -96,7 +98,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
     if (MODE != 2) {
         __syncthreads();                                                            // (the table is zero before the pre-warm's inserts)
-        if (sd.u0) lz_prewarm<0, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid);
+        if (sd.u0) { if constexpr (TAB3) lz_prewarm3<NW3>(table64, seg, seg_len, sd.u0, tid); else lz_prewarm<0, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid); }
         for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
             const uint4 v = load_chunk(seg, i, seg_len);
             const uint32_t wo = i & (WIN_BYTES - 1);
@@ -128,6 +130,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 
             // ---- lookup
             uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G], bq2[G];
+            uint32_t sh3[G]; uint64_t w3[G];                                         // TAB3: the field's bit position and the word as the look-up saw it
             bool hv[G];
             // (uniform) a tile that lies wholly inside the block and at least 8 bytes before the segment end needs no per-lane range checks
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
@@ -154,9 +157,17 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     if (strong) bq2[r] = __builtin_amdgcn_alignbit(dm, win32[((q[r] - 8) & (WIN_BYTES - 1)) >> 2], sh);   // (uniform) and the 4 before those
                 }
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
+                sh3[r] = 0; w3[r] = 0;
+                if constexpr (TAB3) {
+                    t3_slot<NW3>(h32, hsh[r], sh3[r]);
+                    tag[r] = t3_tag(h32);
+                    w3[r] = table64[hsh[r]];
+                    ent[r] = hv[r] ? t3_field(w3[r], sh3[r]) : 0u;
+                } else {
                 hsh[r] = __umulhi(h32, HASH_ENTRIES);                               // floor(h32 * entries / 2^32): any table size
                 tag[r] = (h32 >> 6) & TAG_MASK;                                     // a filter only: any function of the hash will do
                 ent[r] = hv[r] ? table[hsh[r]] : 0u;
+                }
             }
             // ---- candidates: offset (0 = none: empty slot, foreign tag -- a candidate whose tag differs hashed differently, so its first
             // 6 bytes differ --, position below 8, beyond max_off).  Far candidates (beyond the LDS window) get the 4 bytes before and the
@@ -168,8 +179,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             for (int r = 0; r < G; r++) {
                 if constexpr (MODE == 2) { off[r] = pv[r] >> 6; continue; }
                 fa[r] = 0; fb[r] = fc[r] = 0;
-                const uint32_t c1 = ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
-                off[r] = (c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u;
+                // (TAB3: an entry = (position / 2) << 2 | tag, usable from position 8 on: entry >= 16)
+                const uint32_t c1 = TAB3 ? t3_pos(ent[r]) + 1 : ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
+                off[r] = TAB3 ? ((ent[r] >= 16u && (ent[r] & 3u) == tag[r] && o <= max_off) ? o : 0u)
+                              : ((c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u);
                 if (FAR && seg_len > NEAR && max_off > NEAR) {                      // (uniform) shorter segments / near-only levels have no far candidates
                     const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
                     fa[r] = ld16u(seg + fo);
@@ -326,7 +339,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 loaded_end += TILE_G;
                 __syncthreads();                                                    // every wave has looked up
 #pragma unroll
-                for (int r = 0; r < G; r++) if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+                for (int r = 0; r < G; r++) {
+                    if constexpr (TAB3) { if (hv[r] && !(lane & 1) && q[r] != 0) t3_max(&table64[hsh[r]], t3_put(w3[r], sh3[r], t3_field(w3[r], sh3[r]), t3_entry(q[r], tag[r]))); }
+                    else if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+                }
                 __syncthreads();                                                    // inserts + window chunk in place
                 continue;
             }
@@ -354,7 +370,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // every wave has finished its lookups: the tile's inserts go here (all of them land before B4, i.e. before the next lookups)
             if constexpr (MODE != 2) {
 #pragma unroll
-            for (int r = 0; r < G; r++) if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);   // even positions only
+            for (int r = 0; r < G; r++) {                                            // even positions only
+                if constexpr (TAB3) { if (hv[r] && !(lane & 1) && q[r] != 0) t3_max(&table64[hsh[r]], t3_put(w3[r], sh3[r], t3_field(w3[r], sh3[r]), t3_entry(q[r], tag[r]))); }
+                else if (hv[r] && LZ_INS_COND) atomicMax(&table[hsh[r]], ((q[r] + 1) << TAG_BITS) | tag[r]);
+            }
             }
             LZ_STAMP(3);
 
@@ -516,26 +535,27 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-template <int G, bool CT, bool STRONG, uint32_t WLOG>
+template <int G, bool CT, bool STRONG, uint32_t WLOG, bool TAB3 = false>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
+    static constexpr uint32_t LT = LzGeo<WLOG, TAB3>::L_TOTAL;
     static const hipError_t attr_set = [] {                    // once per process, thread-safe (contexts may be created on several threads)
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
-        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
-        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0, WLOG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 0, WLOG, TAB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT);
+        (void)hipFuncSetAttribute((const void *)k_lz<false, G, CT, STRONG, 1, WLOG, TAB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT);
+        return hipFuncSetAttribute((const void *)k_lz<true, G, CT, STRONG, 0, WLOG, TAB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT);
     }();
     (void)attr_set;
     if (pbuf) {
         if (flags & FLAG_SPLIT_WAVEPARSE) {
-            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             if (ev_match) (void)hipEventRecord(ev_match, st);
-            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2, WLOG>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             return;
         }
         launch_lz_split(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);   // k_lzm + k_lzp (k_lz_split.hip)
     }
-    else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0, WLOG>), dim3(nseg), dim3(LZ_THREADS), LzGeo<WLOG>::L_TOTAL, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+    else if (flags & FLAG_STAMP) hipLaunchKernelGGL((k_lz<true, G, CT, STRONG, 0, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+    else hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 0, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
 }
 // zstd launches (no chunk table) run LZ_G_ZSTD positions per lane and tile, deflate launches LZ_G_DEFLATE (k_dblock walks the 2 KiB chunks of the table)
 // pbuf != nullptr: the split form (two kernels; pbuf holds one word per position of the launch's blocks, blk0 = the first of them;
@@ -545,6 +565,12 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
     if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
                 else launch_lz_g<LZ_G_DEFLATE, true, false, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
+    else if ((flags & FLAG_TAB3) && (flags & FLAG_W16)) {
+           if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+           else launch_lz_g<LZ_G_ZSTD, false, false, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
+    else if ((flags & FLAG_TAB3) && (flags & FLAG_W32)) {
+           if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 15, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+           else launch_lz_g<LZ_G_ZSTD, false, false, 15, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
     else if (flags & FLAG_W16) {
            if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
            else launch_lz_g<LZ_G_ZSTD, false, false, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }

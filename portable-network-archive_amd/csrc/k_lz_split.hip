@@ -4,6 +4,7 @@
 // Replaces, together, the match finder + parser inside the third-party encoder the reference drives at lib/src/compress.rs:32-41
 // (CompressionWriter::write -> ZstdEncoder::write / ZlibEncoder::write).  Same results as k_lz (k_lz.hip), which stays as the one-kernel
 // form for short runs; DESIGN.md section 5 "Round 2, second half" has the measurements.  Integer / byte work, no MFMA.
+#include <type_traits>
 #include "lz_common.h"
 
 namespace pna {
@@ -85,19 +86,21 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
     return (STRONG && !l) ? 0u : (l << 6) | (bk << 3);
 }
 
-template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP>
+template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
            uint32_t *__restrict__ gtab) {
     constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
     constexpr bool FAR = !DEFL && FARP;                     // deflate offsets (<= 32 KiB) never leave the LDS window; FARP = false: a zstd launch whose look-back ends with the window (the fast set)
-    using GEO = LzGeo<WLOG>;                                // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
-    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR;
+    using GEO = LzGeo<WLOG, TAB3>;                          // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
+    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR, NW3 = GEO::WORDS3;
     static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!DEFL || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
-    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
+    static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
+    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 44, "k_lzm: four positions per lane, 40 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32 = (uint32_t *)(lds + L_WIN);
     uint32_t *table = GLOG ? gtab + ((size_t)blockIdx.x << GLOG) : (uint32_t *)(lds + L_TABLE);
+    uint64_t *table64 = (uint64_t *)(lds + L_TABLE);        // TAB3: the packed table, three 21-bit entries per word (lz_common.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = uni(tid >> 6);
     const SegDesc sd = segs[blockIdx.x];
@@ -112,12 +115,15 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
 
-    for (uint32_t i = tid; i < (GLOG ? (1u << GLOG) : HASH_ENTRIES) / 4; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < (GLOG ? (4u << GLOG) : GEO::TABLE_BYTES) / 16; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
     if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the zeros are in L2 before the pre-warm's atomics and the first look-ups)
     // a unit that starts inside the segment (latency mode): window and table as the segment-long walk has them there (k_lz.hip, lz_common.h)
     uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
     __syncthreads();
-    if (sd.u0) { lz_prewarm<GLOG, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid); if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    if (sd.u0) {
+        if constexpr (TAB3) lz_prewarm3<NW3>(table64, seg, seg_len, sd.u0, tid);
+        else { lz_prewarm<GLOG, HASH_ENTRIES>(table, seg, seg_len, sd.u0, ins_all, tid); if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
     for (uint32_t i = (loaded_end > WIN_BYTES ? loaded_end - WIN_BYTES : 0u) + tid * 16; i < loaded_end; i += LZ_THREADS * 16) {
         const uint4 v = load_chunk(seg, i, seg_len);
         const uint32_t wo = i & (WIN_BYTES - 1);
@@ -133,37 +139,59 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
             if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
             const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
+            // The tile's work is instantiated twice: FULL = every position of the tile is inside the block and at least 8 bytes before the segment's end (all
+            // tiles but a block's / segment's last, and never tile 0 with the packed table: position 0 is not stored) -- no validity masks, no selects, no
+            // bounds on the stores --, and the general form.  (uniform branch; round 4: 12 vector + 10 scalar instructions of the 630 per wave and tile)
+            auto tile_body = [&](auto full_t) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_t)::value;
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
             // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
-            uint32_t D[9], Dm1, Dm2 = 0;
+            uint32_t D[10], Dm1, Dm2 = 0;
             {
-                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..8] may lie in the mirror
+                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..9] may lie in the mirror
 #pragma unroll
-                for (int k = 0; k < 9; k++) D[k] = pq[k];
+                for (int k = 0; k < 10; k++) D[k] = pq[k];
                 Dm1 = win32[((q0 - 4) & (WIN_BYTES - 1)) >> 2];
                 if (STRONG) Dm2 = win32[((q0 - 8) & (WIN_BYTES - 1)) >> 2];
             }
 #define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
             // ---- look-up
             uint32_t hsh[4], tag[4], ent[4];
+            uint32_t sh3[4] = {0, 0, 0, 0}; uint64_t w3a = 0, w3b = 0;                  // TAB3: the fields' bit positions; the words of positions 0 and 2 as the look-ups saw them
             bool hv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t q = q0 + j;
-                hv[j] = tile_full || ((q < t1) && (q + 8 <= seg_len));
+                hv[j] = FULL || ((q < t1) && (q + 8 <= seg_len));
                 const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
+                if constexpr (TAB3) {
+                    t3_slot<NW3>(h32, hsh[j], sh3[j]);
+                    tag[j] = t3_tag(h32);
+                    const uint64_t w = table64[hsh[j]];
+                    if (j == 0) w3a = w;
+                    if (j == 2) w3b = w;
+                    const uint32_t e = t3_field(w, sh3[j]);
+                    ent[j] = hv[j] ? e : 0u;
+                } else {
                 hsh[j] = lz_slot<GLOG, HASH_ENTRIES>(h32);
                 tag[j] = (h32 >> 6) & TAG_MASK;
                 if (GLOG) ent[j] = hv[j] ? __hip_atomic_load(&table[hsh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 else { const uint32_t e = table[hsh[j]]; ent[j] = hv[j] ? e : 0u; }     // (the LDS read goes out for every lane -- any slot is readable --, a select instead of an exec-masked region)
+                }
             }
             // ---- candidates (rules as in k_lz)
             uint32_t off[4];
             bool farj[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                if constexpr (TAB3) {
+                    // an entry = (position / 2) << 2 | tag: usable iff its position is >= 8 (entry >= 16: the empty entry 0 included), the tag agrees, the offset fits
+                    const uint32_t o = q0 + j - t3_pos(ent[j]);
+                    off[j] = ((ent[j] >= 16u) & ((ent[j] & 3u) == tag[j]) & (o <= max_off)) ? o : 0u;
+                } else {
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
                 off[j] = ((c1 > 8) & ((ent[j] & TAG_MASK) == tag[j]) & (o <= max_off)) ? o : 0u;      // (& not &&: no short-circuit branches)
+                }
                 farj[j] = FAR && off[j] > NEAR;
             }
             // ---- the far candidates (more than NEAR bytes back: outside the window) are handled COMPACTED.  A vector load costs the CU's address unit 16
@@ -191,8 +219,8 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool slot0 = FAR && lane < 63u && lane < npair;
             v4u ffa, ffd; uint32_t ffb, ffc;
             far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
-            // ---- match: the candidates inside the window
-            uint32_t K[4];
+            // ---- match: the candidates inside the window.  First the 16 bytes at every position; the next 16 are compared ONCE per lane and offset (below).
+            uint32_t K[4], L1[4], BK[4];
             const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -212,25 +240,50 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     }
                     const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
                     l = first_diff16(x0, x1, x2, x3);
-                    if (l == 16) {
-                        uint32_t v0, v1, v2, v3;
-                        {
-                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                            v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
-                            v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
-                        }
-                        const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
-                        l = 16 + first_diff16(y0, y1, y2, y3);
-                    }
-                    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-                    if (l < MIN_MATCH) l = 0;
                     const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
                     const uint32_t xk = bqj ^ bc;
                     bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
                     if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
                 }
-                K[j] = (l << 6) | (bk << 3);
+                L1[j] = l; BK[j] = bk;
+            }
+            // Bytes 16 .. of the matches whose first 16 agree (5 % of the positions, but nearly every wave holds some at every j: compared in place they were
+            // a fifth of the kernel).  Inside a long match a lane's positions share the offset, and position j's length is position A's less j - A: so the
+            // lane compares 20 more bytes for its FIRST such position A (length up to 36) and hands min(36 - (j - A), 32) ... exactly what the capped
+            // compare at j would find ... to its later positions with the same offset; positions with another offset take another turn of the loop (rare).
+            {
+                uint32_t need = (L1[0] == 16u ? 1u : 0u) | (L1[1] == 16u ? 2u : 0u) | (L1[2] == 16u ? 4u : 0u) | (L1[3] == 16u ? 8u : 0u);
+                while (__ballot(need != 0)) {
+                    if (need) {
+                        const uint32_t jA = (uint32_t)__builtin_ctz(need);
+                        const uint32_t oA = jA == 0 ? off[0] : (jA == 1 ? off[1] : (jA == 2 ? off[2] : off[3]));
+                        const uint32_t cA = q0 + jA - oA + 16u, shc = (cA & 3) * 8;
+                        const uint32_t *pc2 = win32 + ((cA & (WIN_BYTES - 1)) >> 2);
+                        const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4], f5 = pc2[5];
+                        const uint32_t y0 = __builtin_amdgcn_alignbyte(D[5], D[4], jA) ^ __builtin_amdgcn_alignbit(f1, f0, shc);
+                        const uint32_t y1 = __builtin_amdgcn_alignbyte(D[6], D[5], jA) ^ __builtin_amdgcn_alignbit(f2, f1, shc);
+                        const uint32_t y2 = __builtin_amdgcn_alignbyte(D[7], D[6], jA) ^ __builtin_amdgcn_alignbit(f3, f2, shc);
+                        const uint32_t y3 = __builtin_amdgcn_alignbyte(D[8], D[7], jA) ^ __builtin_amdgcn_alignbit(f4, f3, shc);
+                        const uint32_t y4 = __builtin_amdgcn_alignbyte(D[9], D[8], jA) ^ __builtin_amdgcn_alignbit(f5, f4, shc);
+                        uint32_t fd = first_diff16(y0, y1, y2, y3);
+                        if (fd == 16u) fd = 16u + (ffbl_hw(y4) >> 3 < 4u ? ffbl_hw(y4) >> 3 : 4u);
+                        const uint32_t E = 16u + fd + jA;                                 // position A's length (<= 36) + A
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const bool same = ((need >> j) & 1u) && off[j] == oA;
+                            const uint32_t lj = E - (uint32_t)j;
+                            L1[j] = same ? (lj < 32u ? lj : 32u) : L1[j];
+                            need = same ? need & ~(1u << j) : need;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t l = L1[j];
+                if (edge) { const uint32_t lim = blk_end - (q0 + j); l = l < lim ? l : lim; }
+                if (l < MIN_MATCH) l = 0;
+                K[j] = (l << 6) | (BK[j] << 3);
                 if (STRONG && !l) K[j] = 0;
             }
             // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)
@@ -293,7 +346,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
             if (W3) {
-                if (q0 < t1) {
+                if (FULL || q0 < t1) {
                     uint32_t ww[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -305,7 +358,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);   // bytes 1 2 of word 1, bytes 0 1 of word 2
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);   // byte 2 of word 2, bytes 0 1 2 of word 3
                 }
-            } else if (q0 < t1) {
+            } else if (FULL || q0 < t1) {
                 v4u wv; wv.x = (K[0] >> 6) | (off[0] << 6); wv.y = (K[1] >> 6) | (off[1] << 6); wv.z = (K[2] >> 6) | (off[2] << 6); wv.w = (K[3] >> 6) | (off[3] << 6);
                 __builtin_nontemporal_store(wv, (v4u *)(pb + q0));       // (streamed: the parse kernel reads the words, this one never; without the hint they push the
                                                                          // segment's recent bytes -- where most far candidates lie -- out of L2: k_lzm + 1.5 %)
@@ -313,7 +366,12 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #undef QW
             loaded_end += TILE_G;
             __syncthreads();                                                        // every wave has looked up
-            if (tile_full) {                                                        // (uniform: all but a block's last tile -- every position valid, no exec masks)
+            if constexpr (TAB3) {
+                // one 64-bit maximum per even position: the word as the look-up saw it with this position's field replaced (position 0 is never stored:
+                // its entry could be the empty one)
+                if (FULL || (hv[0] && q0 != 0)) t3_max(&table64[hsh[0]], t3_put(w3a, sh3[0], t3_field(w3a, sh3[0]), t3_entry(q0, tag[0])));
+                if (FULL || hv[2]) t3_max(&table64[hsh[2]], t3_put(w3b, sh3[2], t3_field(w3b, sh3[2]), t3_entry(q0 + 2, tag[2])));
+            } else if (FULL) {                                                      // (all but a block's last tile -- every position valid, no exec masks)
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (ins_all || !(j & 1)) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
             } else {
@@ -322,6 +380,8 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             }
             if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the atomics have reached L2)
             __syncthreads();                                                        // inserts + window chunk in place
+            };
+            if (tile_full && !(TAB3 && t0 == 0)) tile_body(std::true_type{}); else tile_body(std::false_type{});
         }
     }
 }
@@ -695,12 +755,13 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     }
 }
 
-template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT>
+template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT, bool TAB3 = false>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                            uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
-    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG, FARP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG>::L_TOTAL);   // once per process, thread-safe
+    constexpr uint32_t LT = GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG, TAB3>::L_TOTAL;
+    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG, TAB3>::L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP>), dim3(nseg), dim3(LZ_THREADS), GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG>::L_TOTAL, st, src, segs, flags, max_off, pbuf, blk0, gtab);
+    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, flags, max_off, pbuf, blk0, gtab);
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (!pg || pg->nb == 0) return;                            // (no grid: the caller wants the match kernel alone; a run of empty entries has segments and no blocks)
     constexpr bool W3 = GLOG == 0;
@@ -717,6 +778,12 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
     if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
                 else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
     else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+    else if ((flags & FLAG_TAB3) && (flags & FLAG_W16)) {
+           if (strong) launch_split_g<false, true, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else launch_split_g<false, false, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
+    else if ((flags & FLAG_TAB3) && (flags & FLAG_W32)) {
+           if (strong) launch_split_g<false, true, 0, 15, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else launch_split_g<false, false, 0, 15, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
     else if (flags & FLAG_W16) {
            if (strong) launch_split_g<false, true, 0, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
            else launch_split_g<false, false, 0, 14>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }

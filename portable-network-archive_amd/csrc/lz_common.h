@@ -16,17 +16,40 @@ constexpr uint32_t WIN_MIRROR = 48;                        // the window's first
 // the window; the zstd sets without far candidates, whose look-back IS the window), and 32 KiB window + 32 704-slot table (the zstd sets with far
 // candidates: a third more slots are worth +1.6 % of ratio on text, and what the window no longer holds -- candidates more than NEAR bytes back -- is
 // verified against the segment in HBM / L2 like everything beyond the window before)
-template <uint32_t WLOG> struct LzGeo {
+// TAB3 (round 4): the PACKED table of the zstd default / high sets.  What the table remembers sets the ratio on text (LAB_LOG.md 3.3: 32 704 slots 2.759,
+// 49 152: 2.83, 65 536: 2.86), and LDS holds no more 32-bit entries; an entry needs 19 bits of (even) position and tolerates a 2-bit tag -- a false
+// candidate only costs a compare that fails --, so THREE entries of 21 bits share a 64-bit LDS word: 49 062 slots next to the 32 KiB window, 55 206 next to the
+// 16 KiB one.  slot -> word = mulhi(hash, words), field = ((hash & 0xFFFF) * 3) >> 16.  A tile's inserts are ONE ds_max_u64 each of "the word as my look-up
+// saw it, my field replaced": every contender's value exceeds the old word (positions only grow), among a tile's contenders for one word the highest
+// (field, position) wins and the others are LOST (4 - 8 % of the inserts, -0.1 % of ratio in the model -- oracle/zstd_model.c does exactly this), no CAS loop.
+template <uint32_t WLOG, bool TAB3 = false> struct LzGeo {
     static_assert(WLOG >= 14 && WLOG <= 16, "window of 16, 32 or 64 KiB");
+    static_assert(!TAB3 || WLOG < 16, "the packed table belongs to the zstd sets with far candidates");
     static constexpr uint32_t WIN     = 1u << WLOG;
     static constexpr uint32_t L_TABLE = L_WIN + WIN + WIN_MIRROR;
-    static constexpr uint32_t ENTRIES = WLOG == 16 ? HASH_ENTRIES : ((160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 4 & ~63u);   // 32 704 (32 KiB window), 36 800 (16 KiB)
-    static constexpr uint32_t L_WEND  = L_TABLE + 4u * ENTRIES;   // 16 x u32: tile-relative end of each wave's last match (0 = none)
+    static constexpr uint32_t WORDS3  = (160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 8 & ~1u;           // 64-bit words of the packed table: 16 354 (32 KiB window), 18 402 (16 KiB)
+    static constexpr uint32_t ENTRIES = TAB3 ? 3 * WORDS3 : (WLOG == 16 ? HASH_ENTRIES : ((160u * 1024 - 12 * LZ_WAVES - L_TABLE) / 4 & ~63u));   // 32 704 (32 KiB window), 36 800 (16 KiB); packed: 49 062, 55 206
+    static constexpr uint32_t TABLE_BYTES = TAB3 ? 8u * WORDS3 : 4u * ENTRIES;
+    static constexpr uint32_t L_WEND  = L_TABLE + TABLE_BYTES;    // 16 x u32: tile-relative end of each wave's last match (0 = none)
     static constexpr uint32_t L_WPUB  = L_WEND + 4 * LZ_WAVES;    // 16 x 8 B
     static constexpr uint32_t L_TOTAL = L_WPUB + 8 * LZ_WAVES;
     static constexpr uint32_t NEAR    = WLOG == 16 ? NEAR_OFF : WIN - 2 * 1024 * LZ_G_ZSTD - LOOKAHEAD - 16 - 240;   // candidates at most this far back are verified in the window (32 KiB: 23 296; 16 KiB: 6 912)
-    static_assert(L_TOTAL <= 160 * 1024 && ENTRIES % 4 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
+    static_assert(L_TOTAL <= 160 * 1024 && TABLE_BYTES % 16 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 };
+// the packed table's arithmetic: (word, bit position of the field) of a hash; the 21-bit entry of an even position; the word with a field replaced
+constexpr uint32_t T3_MASK = 0x1FFFFFu;
+template <uint32_t NW> __device__ __forceinline__ void t3_slot(uint32_t h32, uint32_t &widx, uint32_t &sh) { widx = __umulhi(h32, NW); sh = (((h32 & 0xFFFFu) * 3u) >> 16) * 21u; }
+__device__ __forceinline__ uint32_t t3_tag(uint32_t h32) { return (h32 >> 16) & 3u; }
+// field at bit 0, 21 or 42 of the word WITHOUT a 64-bit shift (a quarter-rate instruction): v_alignbit_b32 takes the shift modulo 32 -- 0, 21, 10 -- over
+// {hi, lo} for the first two fields and over {hi, hi} for the third
+__device__ __forceinline__ uint32_t t3_field(uint64_t w, uint32_t sh) {
+    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    return __builtin_amdgcn_alignbit(hi, sh == 42u ? hi : lo, sh) & T3_MASK;
+}
+__device__ __forceinline__ uint32_t t3_entry(uint32_t q_even, uint32_t tag2) { return (q_even << 1) | tag2; }     // (q / 2) << 2 | tag
+__device__ __forceinline__ uint32_t t3_pos(uint32_t fld) { return (fld >> 1) & ~1u; }                             // the position an entry names
+__device__ __forceinline__ uint64_t t3_put(uint64_t w, uint32_t sh, uint32_t fld, uint32_t v) { return w ^ ((uint64_t)(fld ^ v) << sh); }
+__device__ __forceinline__ void t3_max(uint64_t *p, uint64_t v) { (void)__hip_atomic_fetch_max((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct WPub  { uint32_t cnt; uint32_t gl; };   // cnt = nsel | nlit << 16; gl = (local literal index of the LAST match + 1) | (same for the FIRST match) << 16, 0 = no match
 static_assert(sizeof(WPub) == 8, "LDS record size");
@@ -162,6 +185,40 @@ __device__ __forceinline__ void lz_prewarm(uint32_t *table, const uint8_t *seg, 
             const uint32_t h32 = lo * 0x9E3779B1u + (hi & 0xFFFFu) * 0x85EBCA6Bu;
             if (q < end && q + 8 <= seg_len) atomicMax(&table[lz_slot<GLOG, ENT>(h32)], ((q + 1) << TAG_BITS) | ((h32 >> 6) & TAG_MASK));
         }
+    }
+}
+
+// The same for the PACKED table.  Its inserts are not order-free -- of a tile's contenders for one word only one is stored --, so the pre-warm replays
+// the walk's tiles (aligned 4 096 positions: blocks are multiples of that) one by one: every thread reads the words of its two even positions, barrier,
+// one ds_max_u64 each, barrier.  The next tile's bytes are requested before the current tile is stored (two tiles in flight): ~0.3 us per tile.
+template <uint32_t NW>
+__device__ __forceinline__ void lz_prewarm3(uint64_t *table64, const uint8_t *seg, uint32_t seg_len, uint32_t end, uint32_t tid) {
+    auto fetch = [&](uint32_t t0, uint32_t (&w)[3]) {
+        const uint32_t p = t0 + 4 * tid;                                              // positions p and p + 2: bytes p .. p + 9
+        w[0] = w[1] = w[2] = 0;
+        if (p + 12 <= seg_len) { w[0] = *(const uint32_t *)(seg + p); w[1] = *(const uint32_t *)(seg + p + 4); w[2] = *(const uint32_t *)(seg + p + 8); }
+        else if (p < seg_len) { const uint4 v = load_chunk_tail(seg, p, seg_len); w[0] = v.x; w[1] = v.y; w[2] = v.z; }
+    };
+    uint32_t wa[3], wb[3];
+    fetch(0, wa);
+    for (uint32_t t0 = 0; t0 < end; t0 += 4 * LZ_THREADS) {
+        if (t0 + 4 * LZ_THREADS < end) fetch(t0 + 4 * LZ_THREADS, wb);
+        uint32_t widx[2], sh[2], v[2]; uint64_t w64[2]; bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t q = t0 + 4 * tid + 2 * k;
+            const uint32_t lo = k ? __builtin_amdgcn_alignbyte(wa[1], wa[0], 2) : wa[0], hi = k ? __builtin_amdgcn_alignbyte(wa[2], wa[1], 2) : wa[1];
+            const uint32_t h32 = lo * 0x9E3779B1u + (hi & 0xFFFFu) * 0x85EBCA6Bu;
+            t3_slot<NW>(h32, widx[k], sh[k]);
+            ok[k] = q < end && q + 8 <= seg_len && q != 0;
+            v[k] = t3_entry(q, t3_tag(h32));
+            w64[k] = table64[widx[k]];
+        }
+        __syncthreads();                                                                // every thread has read the words as the tile's look-ups see them
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (ok[k]) t3_max(&table64[widx[k]], t3_put(w64[k], sh[k], t3_field(w64[k], sh[k]), v[k]));
+        __syncthreads();
+        wa[0] = wb[0]; wa[1] = wb[1]; wa[2] = wb[2];
     }
 }
 

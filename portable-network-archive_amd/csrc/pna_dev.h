@@ -48,6 +48,7 @@ constexpr uint32_t FLAG_LAZY3 = 0x800u;   // (with FLAG_LAZY2) three-step deferr
 constexpr uint32_t FLAG_W16 = 0x4000u;   // ... the 16 KiB-window geometry (36 800 table slots)
 constexpr uint32_t FLAG_LEN36 = 0x8000u;  // adopted lengths clamped to 36: what the 3-byte words of the split form keep (5 bits: 0 or length - 5) next to 19 bits of offset
 constexpr uint32_t MAX_OFF_W3 = (1u << 19) - 1;   // ... so the look-back of the sets with an LDS table ends there (the estimator: 2.7761 -> 2.7759; 2^18: 2.7678)
+constexpr uint32_t FLAG_TAB3 = 0x10000u;  // (with FLAG_W32 / FLAG_W16, even inserts) the packed table: three 21-bit entries per 64-bit LDS word, 49 062 / 55 206 slots (lz_common.h)
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy
 

@@ -29,10 +29,10 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
 uint32_t lz_gtab_log();
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg);
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only);
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
-                          uint8_t *dst, hipStream_t st);
+                          uint8_t *dst, hipStream_t st, bool stored_only);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t fork, hipEvent_t join);
@@ -143,6 +143,7 @@ struct Tuning {
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
     long tail_units = 1;             // PNA_TAIL_UNITS: the segments behind a run's last full round of the CUs go through the match kernel in units of one block
     long lazy2 = 2;                  // PNA_LAZY2: how far the lazy level sets look ahead beyond the next position: 2 = two more positions (default), 1 = one more, 0 = none (the high sets: one)
+    long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
     long strong_gtab = 1;            // PNA_STRONG_GTAB: zstd levels 10 .. 22 with the match kernel's hash tables in global memory (2^19 slots per segment); 0: the LDS table
@@ -161,7 +162,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -178,6 +179,9 @@ struct pna_gpu_ctx {
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     bool call_lazy3 = false;
     bool call_lazy2 = false;                         // two-step lazy deferral (FLAG_LAZY2 of the LZ kernels)
+    bool call_stored = false;                       // deflate level 0: stored blocks only (Compression::none())
+    bool call_tab3 = false;                         // ... its table packed (lz_common.h TAB3)
+    bool call_w16 = false;                          // ... the 16 KiB window (zstd 6..9)
     bool call_gtab = false, call_w32 = false;       // ... and where the match finder's table lies / its LDS geometry (set_call_level)
     std::vector<hipEvent_t> lzm_ev; size_t lzm_used = 0;   // event pairs around the match kernel launches of the current sub-batch (timed calls)
     std::vector<uint8_t> lzm_nl;                            // launches inside each pair (2 where a run's last segments go in units)
@@ -340,19 +344,21 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
     return 0;
 }
 
-// Four parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
+// Parameter sets behind the reference's level scale (CompressionLevel -> ZstdCompressionLevel / flate2::Compression,
 // lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101; PNA_LEVEL_DEFAULT and zstd level 0 = the default):
-//   fast      zstd < 0 and 1, deflate 0..3   every position in the table, look-back = the LDS window, no backward adoption; lazy deferral as below
-//   default   zstd 0, 2..5,   deflate 4..8   + even-position table, backward adoption, 1 MiB look-back (zstd), lazy deferral over three positions
-//   high      zstd 6..9,      deflate 9      + a third adoption round (matches move back by up to 7 positions) and two-step lazy deferral
+//   stored    deflate 0                      Compression::none(): stored blocks only (no match finder, header 78 01)
+//   fast      zstd < 0 and 1, deflate 1..3   every position in the table, look-back = the LDS window, no backward adoption; lazy deferral as below
+//   light     zstd 2,         deflate 4..8   + even-position table, backward adoption (two rounds), 1 MiB look-back (zstd), lazy deferral over three positions
+//   default   zstd 0, 3..5                   + a third adoption round (matches move back by up to 7 positions): ratio at the reference's default level (round 4)
+//   high      zstd 6..9,      deflate 9      the default set on the 16 KiB-window geometry (more table slots, more candidates verified in HBM / L2); deflate: + third round
 //   max       zstd 10..22                    + the match kernel's hash table in global memory: 2^19 slots per segment instead of what LDS holds
-// zstd default and high run the match finder's 32 KiB-window geometry (32 704 table slots instead of 24 512; lz_common.h LzGeo), the others and
-// deflate the 64 KiB one.
+// zstd light / default run the match finder's 32 KiB-window geometry, high the 16 KiB one (lz_common.h LzGeo), both with the PACKED table (three 21-bit
+// entries per 64-bit LDS word: 49 062 / 55 206 slots; option tab3 = 0: 32-bit entries, 32 704 / 36 800); the others and deflate the 64 KiB geometry (24 512).
 static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const int lv = pna_gpu_clamp_level(algo, level);
     const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
     const bool balanced = false;   // (the set without lazy deferral -- zstd 2, deflate 4..5 until round 3 -- is as fast as the default set since the parse kernel looks ahead for free; the levels take the default set, the bits remain)
-    const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : lv >= 6;
+    const bool strong = algo == PNA_ALGO_DEFLATE ? lv >= 9 : (lv >= 3 || lv == 0);      // (zstd 0 = the default = 3; round 4: the third adoption round from the default level on)
     if (fast) return c->flags & ~(F_FAR | F_ADOPT | F_INS2 | F_STRONG);      // (lazy deferral stays: the parse kernel does it for free -- zstd-1 2.510 -> 2.54 at the same speed)
     if (balanced) return c->flags & ~(F_LAZY | F_STRONG);
     if (strong && (c->flags & F_ADOPT) && (c->flags & F_LAZY)) return c->flags | F_STRONG;
@@ -363,6 +369,9 @@ static void set_call_level(pna_gpu_ctx *c, int algo, int level) {
     const bool zstd = algo != PNA_ALGO_DEFLATE;
     c->call_gtab = zstd && pna_gpu_clamp_level(algo, level) >= 10 && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong_gtab != 0;
     c->call_w32 = zstd && !c->call_gtab && (c->call_flags & F_FAR) && (c->call_flags & F_LAZY) && c->tun.win32k != 0;
+    c->call_w16 = c->call_w32 && (c->tun.win32k >= 2 || pna_gpu_clamp_level(algo, level) >= 6);          // the high set's geometry (round 4: chosen by the level, no longer by F_STRONG)
+    c->call_stored = !zstd && pna_gpu_clamp_level(algo, level) == 0;
+    c->call_tab3 = c->call_w32 && (c->call_flags & F_INS2) && (c->call_flags & F_ADOPT) && c->tun.tab3 != 0;
     c->call_lazy2 = (c->call_flags & F_LAZY) && (c->tun.lazy2 != 0 || (c->call_flags & F_STRONG));   // every lazy set defers over two positions (the high sets always did)
     c->call_lazy3 = c->call_lazy2 && c->tun.lazy2 >= 2;                                               // ... and over three (option lazy2 = 2, the default)
 }
@@ -870,12 +879,13 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     int nch = 1;
     if (defl) {
         const uint32_t dfl = (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | FLAG_LEN36;
-        if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
+        if (c->call_stored) { }                                // deflate level 0 = Compression::none(): stored blocks only, no match finder, no codes
+        else if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
         else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
-                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags);
+                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags, c->call_stored);
     } else {
         // zstd: the segments go through k_lz in chunks on `st`; the entropy stage of a finished chunk runs on the auxiliary
         // stream next to the following chunk's k_lz (latency-bound kernels hide in the issue slots k_lz leaves free)
@@ -895,7 +905,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? ((c->tun.win32k >= 2 || ((c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT))) ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36);
+            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? (c->call_w16 ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36) | (c->call_tab3 ? FLAG_TAB3 : 0u);
             const uint32_t zmax = (c->call_flags & F_FAR) ? (c->call_gtab ? MAX_OFF : MAX_OFF_W3) : NEAR_OFF;   // (3-byte words keep 19 bits of offset)
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
@@ -1028,7 +1038,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
         launch_layout((FrameDesc *)c->fr_desc.p, (uint8_t *)c->fr_blob.p, c->d_entry_seg, (const uint64_t *)c->seg_off.p, (uint32_t)ne, nseg, out_base,
                       (uint64_t *)c->fr_segdst.p, d_ent, d_ent + ne + 1, st);
         if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const uint64_t *)c->fr_segdst.p, (const uint64_t *)c->seg_size.p,
-                                       (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st);
+                                       (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st, c->call_stored);
         else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (const uint64_t *)c->fr_segdst.p,
                           (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -1218,7 +1228,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     } else if (!early_write && out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                                    d_segdst, (const uint64_t *)c->seg_size.p, (const uint8_t *)c->litc.p, c->d_entry_seg,
-                                   (uint32_t)(e1 - e0), wbase, st);
+                                   (uint32_t)(e1 - e0), wbase, st, c->call_stored);
     else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st);

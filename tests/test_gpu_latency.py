@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LEVELS_Z = (1, 2, 3, 7, 19)            # zstd levels of every set: fast, default (2, 3), high, max (codec.product_level_flags)
+LEVELS_Z = (1, 2, 3, 7, 19)            # zstd levels of every set: fast, light, default, high, max (codec.product_level_flags)
 
 
 def _ents(codec):
@@ -96,19 +96,19 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
         (o,) = ctx.compress_batch([one])
         t = ctx.timing()
         assert (t.blk_log, t.lz_units) == (14, 64)
-        assert o == codec.model_compress(one, codec.params_for_flags(0x77, blk_log=14))
+        assert o == codec.model_compress(one, codec.params_for_level(3, blk_log=14))
         ents = [codec.corpus_file(0, 701 + i, 1 << 20) for i in range(40)]
         outs = ctx.compress_batch(ents)
         t = ctx.timing()
         assert 14 < t.blk_log <= 17 and 0 < t.lz_units <= 640, (t.blk_log, t.lz_units)
-        pz = codec.params_for_flags(0x77, blk_log=t.blk_log)
+        pz = codec.params_for_level(3, blk_log=t.blk_log)
         for e, o in zip(ents[:4], outs[:4]):
             assert o == codec.model_compress(e, pz)
         ctx.set_option("latency_max_mib", 8)
         outs2 = ctx.compress_batch(ents[:12])
         t = ctx.timing()
         assert (t.blk_log, t.lz_units) == (17, 0)
-        assert outs2[0] == codec.model_compress(ents[0], codec.params_for_flags(0x77))
+        assert outs2[0] == codec.model_compress(ents[0], codec.params_for_level(3))
 
 
 def test_compression_writers_in_latency_mode(pna, codec, monkeypatch):
@@ -136,7 +136,7 @@ def test_compression_writers_in_latency_mode(pna, codec, monkeypatch):
         for x in th: x.start()
         for x in th: x.join()
         assert ctx.timing().blk_log in (13, 14)      # (13: a last batch of the two small entries only -- every entry of up to 64 KiB is one block whatever the block size)
-    pz = codec.params_for_flags(0x77, blk_log=14)
+    pz = codec.params_for_level(3, blk_log=14)
     for e, r in zip(ents, results):
         assert r == codec.model_compress(e, pz)
         assert codec.zstd_decompress(r, len(e)) == e

@@ -101,7 +101,7 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     if form == "default":
         monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: the split form at every size
     with pna.Context(0, flags=pna.F_STD | bit) as ctx:
-        for level in (1, 2, 3, 7, 19):              # the zstd level sets: fast, default (2 and 3), high, max (codec.product_level_flags)
+        for level in (1, 2, 3, 7, 19):              # the zstd level sets: fast, light, default, high, max (codec.product_level_flags)
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
             # (levels 10 .. 22 always take the split form: only the match kernel k_lzm has the global-memory hash table of the strong set)
@@ -271,36 +271,48 @@ def test_feature_subsets_bit_exact(pna, codec, flags):
             codec.corpus_file(0, 23, 1 << 20)]
     with pna.Context(0, flags=flags) as ctx:
         outs = ctx.compress_batch(ents)
-    p = codec.params_for_level(3, ctx_flags=flags)           # (the default level keeps the context's bits as they are)
-    for e, o in zip(ents, outs):
+        outs2 = ctx.compress_batch(ents, level=2)
+    # level 2 (the light set) keeps the context's bits as they are; the default level adds the third adoption round (F_STRONG) where the bits allow it
+    p = codec.params_for_level(3, ctx_flags=flags)
+    p2 = codec.params_for_level(2, ctx_flags=flags)
+    assert (p.rounds == 0x421) == bool(flags & 0x20 and flags & 4) and p2.rounds == (0x421 if flags & 0x80 and flags & 0x20 else 0x21 if flags & 0x20 else 0)
+    for e, o, o2 in zip(ents, outs, outs2):
         assert o == codec.model_compress(e, p)
+        assert o2 == codec.model_compress(e, p2)
         assert codec.zstd_decompress(o, len(e)) == e
 
 
 @pytest.mark.parametrize("form", ["split", "one-kernel"])
 def test_lds_geometries_equal_the_model(pna, codec, form):
     """The match finder shares a CU's 160 KiB of LDS between window and hash table in one of three geometries (lz_common.h LzGeo): 64 KiB + 24 512 slots,
-    32 KiB + 32 704 (the zstd default set), 16 KiB + 36 800 (the high set); option win32k = 0 / 1 / 2 puts both sets on the first / leaves the choice /
-    puts both on the last.  What the window does not hold is read from the segment (far candidates): same rules, other table -- every combination must
-    equal the model with that table size, in both forms of the LZ stage, and a smaller window must not compress worse."""
+    32 KiB (the zstd default set), 16 KiB (the high set); option win32k = 0 / 1 / 2 puts both sets on the first / leaves the choice / puts both on the
+    last.  On the two small windows the table is PACKED (option tab3, default 1: three 21-bit entries per 64-bit LDS word -- 49 062 / 55 206 slots, of a
+    tile's inserts into one word only the highest (field, position) is stored) or holds 32-bit entries (tab3 = 0: 32 704 / 36 800 slots).  What the window
+    does not hold is read from the segment (far candidates): same rules, other table -- every combination must equal the model with that table, in both
+    forms of the LZ stage, and more slots must not compress worse."""
     import torch  # noqa: F401
     ents = [codec.corpus_file(0, 1, 300000), codec.corpus_file(0, 2, (1 << 20) + 77), codec.corpus_file(1, 3, 65536), b"", codec.corpus_file(0, 5, 2500000)]
     size = {}
     with pna.Context(0) as ctx:
         ctx.set_option("latency_max_mib", 0)
         ctx.set_option("lz_split_min", 0 if form == "split" else 1 << 20)
-        for w in (0, 1, 2):
-            ctx.set_option("win32k", w)
-            for lvl in (3, 7):
-                outs = ctx.compress_batch(ents, level=lvl)
-                assert (ctx.timing().lz_match_launches > 0) == (form == "split")
-                fl, gt = codec.product_level_flags(lvl)
-                p = codec.params_for_flags(fl, gtab=gt, win32k=w)
-                assert p.hash_log == {(0, 3): 24512, (0, 7): 24512, (1, 3): 32704, (1, 7): 36800, (2, 3): 36800, (2, 7): 36800}[(w, lvl)]
-                for e, o in zip(ents, outs):
-                    assert o == codec.model_compress(e, p), (w, lvl, len(e))
-                size[(w, lvl)] = sum(map(len, outs))
-    assert size[(2, 3)] < size[(1, 3)] < size[(0, 3)] and size[(1, 7)] < size[(0, 7)] and size[(1, 7)] < size[(1, 3)]
+        for t3 in (1, 0):
+            ctx.set_option("tab3", t3)
+            for w in (0, 1, 2):
+                ctx.set_option("win32k", w)
+                for lvl in (3, 7):
+                    outs = ctx.compress_batch(ents, level=lvl)
+                    assert (ctx.timing().lz_match_launches > 0) == (form == "split")
+                    p = codec.params_for_level(lvl, win32k=w, tab3=t3)
+                    want = {(0, 3): 24512, (0, 7): 24512, (1, 3): 32704, (1, 7): 36800, (2, 3): 36800, (2, 7): 36800} if not t3 else \
+                           {(0, 3): 24512, (0, 7): 24512, (1, 3): 49062, (1, 7): 55206, (2, 3): 55206, (2, 7): 55206}
+                    assert p.hash_log == want[(w, lvl)] and p.tab3 == (1 if (t3 and w) else 0)
+                    for e, o in zip(ents, outs):
+                        assert o == codec.model_compress(e, p), (t3, w, lvl, len(e))
+                    size[(t3, w, lvl)] = sum(map(len, outs))
+    for t3 in (0, 1):
+        assert size[(t3, 2, 3)] < size[(t3, 1, 3)] < size[(t3, 0, 3)] and size[(t3, 1, 7)] < size[(t3, 0, 7)] and size[(t3, 1, 7)] < size[(t3, 1, 3)]
+    assert size[(1, 1, 3)] < size[(0, 1, 3)] and size[(1, 1, 7)] < size[(0, 1, 7)]        # the packed table remembers more
 
 
 def test_lz_stage_equals_model(gpu_ctx, codec):
@@ -1111,16 +1123,22 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
     fast, balanced, dflt = codec.F_HUF | codec.F_FSE | codec.F_LAZY, std, std | codec.F_LAZY
     strong = dflt | codec.F_STRONG
     sizes = {}
-    for level, fl, gtab in ((-5, fast, 0), (1, fast, 0), (2, dflt, 0), (0, dflt, 0), (3, dflt, 0), (pna.LEVEL_DEFAULT, dflt, 0), (5, dflt, 0), (6, strong, 0), (9, strong, 0),
-                            (10, strong, 1), (19, strong, 1), (22, strong, 1), (99, strong, 1)):
+    for level, fl, gtab, slots in ((-5, fast, 0, 24512), (1, fast, 0, 24512), (2, dflt, 0, 49062), (0, strong, 0, 49062), (3, strong, 0, 49062), (pna.LEVEL_DEFAULT, strong, 0, 49062),
+                                   (5, strong, 0, 49062), (6, strong, 0, 55206), (9, strong, 0, 55206), (10, strong, 1, 19), (19, strong, 1, 19), (22, strong, 1, 19), (99, strong, 1, 19)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         assert codec.product_level_flags(level) == (fl, bool(gtab)), level
-        pz = codec.params_for_flags(fl, gtab=bool(gtab))
+        pz = codec.params_for_level(level)
+        assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else 0x421 if fl == strong else 0x21), level
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
-    assert sizes[19] < sizes[6] < sizes[3] == sizes[2] < sizes[1]
+    assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1] and sizes[0] == sizes[3] == sizes[pna.LEVEL_DEFAULT]
     dstd = codec.F_ADOPT | codec.F_INS2
-    for level, fl in ((0, codec.F_LAZY), (1, codec.F_LAZY), (3, codec.F_LAZY), (4, dstd | codec.F_LAZY), (5, dstd | codec.F_LAZY), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
+    # deflate level 0 is Compression::none() (lib/src/compress/deflate.rs:89-101): stored blocks only, header 78 01 -- not the fast set
+    outs0 = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=0)
+    assert outs0 == [codec.deflate_model_compress(d, codec.params_for_level(0, deflate=True)) for d in data]
+    assert all(codec.zlib_decompress(o) == d for o, d in zip(outs0, data)) and all(o[:2] == b"\x78\x01" for o in outs0)
+    assert all(len(o) > len(d) for o, d in zip(outs0, data)) and len(outs0[2]) == 11
+    for level, fl in ((1, codec.F_LAZY), (3, codec.F_LAZY), (4, dstd | codec.F_LAZY), (5, dstd | codec.F_LAZY), (6, dstd | codec.F_LAZY), (pna.LEVEL_DEFAULT, dstd | codec.F_LAZY), (8, dstd | codec.F_LAZY), (9, dstd | codec.F_LAZY | codec.F_STRONG)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
         pd = codec.params_for_flags(fl, deflate=True)
         assert outs == [codec.deflate_model_compress(d, pd) for d in data], level
