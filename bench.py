@@ -169,7 +169,32 @@ def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, a
         if it > 0:
             best = dt if best is None else min(best, dt)
     in_bytes = n_files * file_len
+    # the same with the entries in page-locked slots of the library (pna_gpu_host_alloc: the host reads its files straight into them): no staging copy,
+    # one host thread issues the copies
+    slots = None
+    try:
+        import numpy as np
+        slot = pna.HostSlot(ctx, n_files * stride + 64)
+        np.frombuffer(slot.view, dtype=np.uint8)[:n_files * stride] = host[:n_files * stride]
+        s_src = (ctypes.c_void_p * n_files)(*[slot.ptr + i * stride for i in range(n_files)])
+        sbest = None
+        for it in range(runs + 1):
+            count[0] = count[1] = 0
+            t0 = time.perf_counter()
+            rc = L.pna_gpu_create_archive_host(ctx._h, algo, level, n_files, a_names, s_src, a_len, cb, None)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError(f"pna_gpu_create_archive_host (slots) failed: {rc}")
+            if it > 0:
+                sbest = dt if sbest is None else min(sbest, dt)
+        slot.free()
+        slots = {"value": round(in_bytes / sbest / 2**20, 1), "unit": "MiB/s", "ms": round(sbest * 1e3, 2), "h2d_GBps": round(in_bytes / sbest / 1e9, 2),
+                 "path": "the same entries in page-locked slots of pna_gpu_host_alloc (a host that reads its files straight into them): no staging copy, "
+                         "one host thread issues the H2D copies"}
+    except Exception as e:
+        slots = {"value": None, "error": repr(e)}
     return {"value": round(in_bytes / best / 2**20, 1), "unit": "MiB/s", "ms": round(best * 1e3, 2), "archive_bytes": count[0], "sink_calls": count[1],
+            "from_host_slots": slots,
             "pcie_bytes": in_bytes + count[0], "pcie_GBps": round((in_bytes + count[0]) / best / 1e9, 2), "runs": runs,
             "h2d_GBps": round(in_bytes / best / 1e9, 2),
             "path": f"{n_files} x {file_len} B entries in pageable host memory -> pna_gpu_create_archive_host (sub-batches of 64 .. 256 MiB over a ring of four "

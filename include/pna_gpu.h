@@ -310,6 +310,16 @@ int  pna_gpu_create_archive_part_host(pna_gpu_ctx *ctx, int algo, int level, siz
  * 471-493) with devices in place of worker threads; no device-to-device traffic.  The archive equals pna_gpu_create_archive_host's. */
 int  pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_t n_ctx, int algo, int level, size_t n, const char *const *names,
                                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
+/* Zero-staging input.  The reference reads every file into memory of its own (fs::read, cli/src/command/core.rs:889-913 write_from_path) before the
+ * encoder sees it; a device needs the bytes in PAGE-LOCKED memory to copy them at the link's rate.  pna_gpu_host_alloc hands the host such a buffer to
+ * read its files into (read_exact into the slot instead of fs::read into a Vec): the host-memory create entry points (pna_gpu_create_archive_host and its
+ * _enc / _meta / _chunked / _part forms, pna_gpu_append_archive_host) send a batch whose entries all lie in buffers of this call to the device straight
+ * from there -- no pageable -> page-locked copy, one host thread instead of eight --; runs of entries that are contiguous at a 16-byte stride travel as
+ * one copy.  A batch with an entry elsewhere is staged as before.  A buffer must stay untouched until the create call that reads it has returned;
+ * pna_gpu_host_free gives it back (pna_gpu_destroy frees what is left). */
+int  pna_gpu_host_alloc(pna_gpu_ctx *ctx, size_t bytes, void **out);
+int  pna_gpu_host_free(pna_gpu_ctx *ctx, void *buf);
+
 /* `pna append` (cli/src/command/append.rs:504-560 run_append_archive: open_archive_then_seek_to_end, add the new entries in order,
  * finalize): `archive` is the existing image (or its last part); *write_at receives the offset of its AEND chunk, and the sink receives
  * the bytes that belong there -- the n new entries, compressed on the device, then AEND.  The result, archive[0 .. write_at) followed by

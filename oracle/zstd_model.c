@@ -670,7 +670,21 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
             blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)b * (BS / 4),
                                        lits + (size_t)b * BS, &blk_nlit[b]);
         }
-        op += pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, BS, dst + op);
+        size_t fs = pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, BS, dst + op);
+        if (p->flags & PNA_F_SINGLE_FRAME) {
+            /* the entry as ONE frame: the segments' blocks as they are, the 6-byte frame header in front of the first segment only, the last-block bit on
+             * the entry's last block only (the product's option single_frame; SURVEY 8 a14's fallback for a reader that refuses concatenated frames) */
+            if (s0 + seg_len < n) {                                      /* not the entry's last segment: clear its last block's bit */
+                size_t q = 6;
+                for (;;) {
+                    uint32_t h = dst[op + q] | (dst[op + q + 1] << 8) | ((uint32_t)dst[op + q + 2] << 16);
+                    if (h & 1) { dst[op + q] &= (uint8_t)~1u; break; }
+                    q += 3 + (((h >> 1) & 3) == 1 ? 1 : (h >> 3));
+                }
+            }
+            if (s0 > 0) { memmove(dst + op, dst + op + 6, fs - 6); fs -= 6; }
+        }
+        op += fs;
     }
     free(table); free(seqs); free(lits);
     return op;

@@ -25,6 +25,7 @@
 #define PNA_F_LAZY     4u           /* one-step lazy deferral inside a 64-position group        */
 #define PNA_F_REP      8u           /* repeat-offset codes (block-local history)                */
 #define PNA_F_LAZY3    0x100u       /* with PNA_F_LAZY2: also defer to a match at q + 3 that is longer by three or more */
+#define PNA_F_SINGLE_FRAME 0x400u   /* zstd model: an entry is ONE frame (header once, last-block bit once) instead of a frame per 1 MiB segment */
 #define PNA_F_STORED   0x200u       /* deflate model only: level 0 (Compression::none()): every block a stored block, header 78 01 */
 #define PNA_F_LAZY2    0x80u        /* with PNA_F_LAZY: also defer to a match at q + 2 that is longer by two or more (strong set) */
 

@@ -106,7 +106,7 @@ _lib = None
 EXPORTS = [
     "pna_gpu_init", "pna_gpu_set_option", "pna_gpu_shutdown", "pna_gpu_archive_chunked_bound", "pna_gpu_create_archive_chunked_device",
     "pna_gpu_create_archive_chunked_host", "pna_gpu_comm_unique_id", "pna_gpu_comm_init", "pna_gpu_comm_destroy", "pna_gpu_comm_last_error",
-    "pna_gpu_gather_ordered", "pna_gpu_gather_ordered_start", "pna_gpu_gather_wait", "pna_gpu_gather_ticket", "pna_gpu_gather_wait_for", "pna_gather_verdict", "pna_gather_offsets", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
+    "pna_gpu_host_alloc", "pna_gpu_host_free", "pna_gpu_gather_ordered", "pna_gpu_gather_ordered_start", "pna_gpu_gather_wait", "pna_gpu_gather_ticket", "pna_gpu_gather_wait_for", "pna_gather_verdict", "pna_gather_offsets", "pna_gpu_last_error", "pna_gpu_strerror", "pna_gpu_bound", "pna_gpu_clamp_level",
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
@@ -778,6 +778,46 @@ def crc_schedule(payload: bytes) -> int:
 
 def crc32(data: bytes, crc: int = 0) -> int:
     return load_library().pna_crc32(crc, bytes(data), len(data))
+
+
+class HostSlot:
+    """pna_gpu_host_alloc: a page-locked buffer the host reads its files into (read_exact into the slot instead of fs::read into a Vec,
+    cli/src/command/core.rs:889-913); entries that lie in one go to the device straight from there -- no staging copy.  `view` is a writable
+    memoryview of the buffer, `ptr` its address."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self._ctx, self.nbytes = ctx, nbytes
+        p = ctypes.c_void_p()
+        L = ctx._L
+        L.pna_gpu_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        ctx._check(L.pna_gpu_host_alloc(ctx._h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        self.view = memoryview((ctypes.c_ubyte * nbytes).from_address(self.ptr)).cast("B")
+
+    def free(self):
+        if self.ptr:
+            self.view.release()
+            self._ctx._L.pna_gpu_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            self._ctx._check(self._ctx._L.pna_gpu_host_free(self._ctx._h, ctypes.c_void_p(self.ptr)))
+            self.ptr = 0
+
+
+def create_archive_from_slot(ctx: "Context", names: Sequence[str], slot: HostSlot, offsets: Sequence[int], lengths: Sequence[int], algo: int = ALGO_ZSTD,
+                             level: int = LEVEL_DEFAULT) -> bytes:
+    """pna_gpu_create_archive_host over entries that lie in a HostSlot (entry i = slot bytes [offsets[i], offsets[i] + lengths[i])): the zero-staging path."""
+    L = load_library()
+    n = len(lengths)
+    out = bytearray()
+
+    def _sink(_u, buf, k):
+        out.extend((ctypes.c_char * k).from_address(buf))
+        return 0
+    cb = SINK_FN(_sink)
+    a_names = (ctypes.c_char_p * max(n, 1))(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * max(n, 1))(*[slot.ptr + o for o in offsets])
+    a_len = (ctypes.c_size_t * max(n, 1))(*lengths)
+    ctx._check(L.pna_gpu_create_archive_host(ctx._h, algo, level, n, a_names, a_src, a_len, cb, None))
+    return bytes(out)
 
 
 def create_archive(ctx: Optional[Context], names: Sequence[str], entries: Sequence[bytes], algo: int = ALGO_ZSTD,

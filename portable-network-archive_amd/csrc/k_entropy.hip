@@ -1025,7 +1025,7 @@ void k_plan(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict
     const uint32_t desc_total = T->desc_len[0] + T->desc_len[1] + T->desc_len[2];
     const uint32_t seq_ok = T->seq_ok, huf_ok = T->huf_ok, tree_len = T->tree_len;
     bool have_huf = false, have_seq = false;                            // (uniform)
-    uint64_t off = 6;
+    uint64_t off = ((sd.first & 4) && !(sd.first & 1)) ? 0 : 6;          // (single-frame entries: the frame header stands in front of the entry's first segment only)
     for (uint32_t c0 = 0; c0 < nblk; c0 += 64) {
         const uint32_t b = c0 + lane, n = nblk - c0 < 64 ? nblk - c0 : 64u;
         const bool in = lane < n;
@@ -1116,10 +1116,11 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     const uint32_t b = g - sd.blk_base;
     const uint32_t nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
     const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
-    const uint32_t last = (b + 1 == nblk) ? 1u : 0u;
+    const bool single = (sd.first & 4) != 0;                            // the entry is ONE frame: header at its first segment, last-block bit at its last block
+    const uint32_t last = (b + 1 == nblk && (!single || (sd.first & 2))) ? 1u : 0u;
     uint8_t *fr = dst + seg_off[sidx];
     uint8_t *out = fr + bi.out_off;
-    if (b == 0 && tid < 6) { const uint8_t fh[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50}; fr[tid] = fh[tid]; }
+    if (b == 0 && tid < 6 && (!single || (sd.first & 1))) { const uint8_t fh[6] = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x50}; fr[tid] = fh[tid]; }
     const uint32_t csz = bi.out_size - 3;
     if (tid < 3) { uint32_t hdr = last | ((bi.plan & 1 ? 2u : 0u) << 1) | (csz << 3); out[tid] = (uint8_t)(hdr >> (8 * tid)); }
     out += 3;

@@ -96,7 +96,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR, NW3 = GEO::WORDS3;
     static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!DEFL || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
     static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
-    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 44, "k_lzm: four positions per lane, 40 bytes read behind a lane's first position");
+    static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32 = (uint32_t *)(lds + L_WIN);
     uint32_t *table = GLOG ? gtab + ((size_t)blockIdx.x << GLOG) : (uint32_t *)(lds + L_TABLE);
@@ -146,11 +146,11 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             constexpr bool FULL = decltype(full_t)::value;
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
             // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
-            uint32_t D[10], Dm1, Dm2 = 0;
+            uint32_t D[9], Dm1, Dm2 = 0;
             {
-                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..9] may lie in the mirror
+                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..8] may lie in the mirror
 #pragma unroll
-                for (int k = 0; k < 10; k++) D[k] = pq[k];
+                for (int k = 0; k < 9; k++) D[k] = pq[k];
                 Dm1 = win32[((q0 - 4) & (WIN_BYTES - 1)) >> 2];
                 if (STRONG) Dm2 = win32[((q0 - 8) & (WIN_BYTES - 1)) >> 2];
             }
@@ -219,8 +219,11 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool slot0 = FAR && lane < 63u && lane < npair;
             v4u ffa, ffd; uint32_t ffb, ffc;
             far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
-            // ---- match: the candidates inside the window.  First the 16 bytes at every position; the next 16 are compared ONCE per lane and offset (below).
-            uint32_t K[4], L1[4], BK[4];
+            // ---- match: the candidates inside the window
+            // (Round 4, measured and dropped: the bytes 16 .. 35 compared ONCE per lane and offset in a wave-uniform loop -- a lane's positions inside a long
+            // match share the offset, position j's length is position A's less j - A --: bit-exact, and 11 % SLOWER than the four in-place compares below;
+            // the loop's dynamic selects and its second and third turns cost more than the 80 instructions it saves.)
+            uint32_t K[4];
             const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -240,50 +243,25 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     }
                     const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
                     l = first_diff16(x0, x1, x2, x3);
+                    if (l == 16) {
+                        uint32_t v0, v1, v2, v3;
+                        {
+                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
+                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                            v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                            v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
+                        }
+                        const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
+                        l = 16 + first_diff16(y0, y1, y2, y3);
+                    }
+                    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
+                    if (l < MIN_MATCH) l = 0;
                     const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
                     const uint32_t xk = bqj ^ bc;
                     bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
                     if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
                 }
-                L1[j] = l; BK[j] = bk;
-            }
-            // Bytes 16 .. of the matches whose first 16 agree (5 % of the positions, but nearly every wave holds some at every j: compared in place they were
-            // a fifth of the kernel).  Inside a long match a lane's positions share the offset, and position j's length is position A's less j - A: so the
-            // lane compares 20 more bytes for its FIRST such position A (length up to 36) and hands min(36 - (j - A), 32) ... exactly what the capped
-            // compare at j would find ... to its later positions with the same offset; positions with another offset take another turn of the loop (rare).
-            {
-                uint32_t need = (L1[0] == 16u ? 1u : 0u) | (L1[1] == 16u ? 2u : 0u) | (L1[2] == 16u ? 4u : 0u) | (L1[3] == 16u ? 8u : 0u);
-                while (__ballot(need != 0)) {
-                    if (need) {
-                        const uint32_t jA = (uint32_t)__builtin_ctz(need);
-                        const uint32_t oA = jA == 0 ? off[0] : (jA == 1 ? off[1] : (jA == 2 ? off[2] : off[3]));
-                        const uint32_t cA = q0 + jA - oA + 16u, shc = (cA & 3) * 8;
-                        const uint32_t *pc2 = win32 + ((cA & (WIN_BYTES - 1)) >> 2);
-                        const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4], f5 = pc2[5];
-                        const uint32_t y0 = __builtin_amdgcn_alignbyte(D[5], D[4], jA) ^ __builtin_amdgcn_alignbit(f1, f0, shc);
-                        const uint32_t y1 = __builtin_amdgcn_alignbyte(D[6], D[5], jA) ^ __builtin_amdgcn_alignbit(f2, f1, shc);
-                        const uint32_t y2 = __builtin_amdgcn_alignbyte(D[7], D[6], jA) ^ __builtin_amdgcn_alignbit(f3, f2, shc);
-                        const uint32_t y3 = __builtin_amdgcn_alignbyte(D[8], D[7], jA) ^ __builtin_amdgcn_alignbit(f4, f3, shc);
-                        const uint32_t y4 = __builtin_amdgcn_alignbyte(D[9], D[8], jA) ^ __builtin_amdgcn_alignbit(f5, f4, shc);
-                        uint32_t fd = first_diff16(y0, y1, y2, y3);
-                        if (fd == 16u) fd = 16u + (ffbl_hw(y4) >> 3 < 4u ? ffbl_hw(y4) >> 3 : 4u);
-                        const uint32_t E = 16u + fd + jA;                                 // position A's length (<= 36) + A
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const bool same = ((need >> j) & 1u) && off[j] == oA;
-                            const uint32_t lj = E - (uint32_t)j;
-                            L1[j] = same ? (lj < 32u ? lj : 32u) : L1[j];
-                            need = same ? need & ~(1u << j) : need;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                uint32_t l = L1[j];
-                if (edge) { const uint32_t lim = blk_end - (q0 + j); l = l < lim ? l : lim; }
-                if (l < MIN_MATCH) l = 0;
-                K[j] = (l << 6) | (BK[j] << 3);
+                K[j] = (l << 6) | (bk << 3);
                 if (STRONG && !l) K[j] = 0;
             }
             // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)

@@ -143,6 +143,8 @@ struct Tuning {
     long latency_max_mib = 192;      // PNA_LATENCY_MAX_MIB: batches of at most this many MiB of input run in latency mode (0: never)
     long tail_units = 1;             // PNA_TAIL_UNITS: the segments behind a run's last full round of the CUs go through the match kernel in units of one block
     long lazy2 = 2;                  // PNA_LAZY2: how far the lazy level sets look ahead beyond the next position: 2 = two more positions (default), 1 = one more, 0 = none (the high sets: one)
+    long single_frame = 0;           // PNA_SINGLE_FRAME: 1: a zstd entry is ONE frame whatever its size (header once, last-block bit once; SURVEY 8 a14's fallback for a reader that would
+                                     // not take concatenated frames -- zstd's own Decoder, which the reference uses, does); 0 (default): one frame per 1 MiB segment
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
@@ -162,7 +164,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -179,6 +181,7 @@ struct pna_gpu_ctx {
     uint32_t call_flags = 0;                        // flags of the current call: the level picks the parse (level_flags)
     bool call_lazy3 = false;
     bool call_lazy2 = false;                         // two-step lazy deferral (FLAG_LAZY2 of the LZ kernels)
+    uint32_t n_cus = 256;                           // compute units of the device (hipDeviceProp_t::multiProcessorCount): a full round of one-workgroup-per-CU kernels
     bool call_stored = false;                       // deflate level 0: stored blocks only (Compression::none())
     bool call_tab3 = false;                         // ... its table packed (lz_common.h TAB3)
     bool call_w16 = false;                          // ... the 16 KiB window (zstd 6..9)
@@ -206,6 +209,8 @@ struct pna_gpu_ctx {
     PinBuf h_desc, h_blob, h_segdst, h_segoff;
     // pipelined host path (pna_gpu_create_archive_host): two slots of staging
     PinBuf hp_in[4], hp_out[2];
+    // page-locked buffers handed to the host (pna_gpu_host_alloc): entries that live in one go to the device straight from there (no staging copy)
+    std::mutex lent_mu; std::vector<std::pair<const uint8_t *, size_t>> lent;
     DevBuf dp_in[4], dp_out[2];
     hipStream_t cp_in = nullptr, cp_out = nullptr;
     hipStream_t aux = nullptr;                        // entropy stage of chunk c runs here while k_lz works on chunk c+1
@@ -265,6 +270,7 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     if (hipSetDevice(device_id) != hipSuccess) return PNA_E_NODEVICE;
     pna_gpu_ctx *c = new pna_gpu_ctx();
     c->device = device_id;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus; }
     c->flags = (flags & PNA_F_DEFAULT) ? (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2) : (flags & 0xFF);
     c->flags &= ~F_REP;                    // repeat-offset codes are not produced by this build
     for (const TuningName &t : TUNING_NAMES)
@@ -301,6 +307,8 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (DevBuf *b : {&c->plan, &c->d_tail, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
                       &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->gtab, &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
+    for (auto &b : c->lent) (void)hipHostFree((void *)b.first);          // (buffers the host never gave back)
+    c->lent.clear();
     for (PinBuf *b : {&c->h_entoff, &c->h_plan, &c->h_tail, &c->h_desc, &c->h_blob, &c->h_segdst, &c->h_segoff, &c->hp_in[0], &c->hp_in[1], &c->hp_in[2], &c->hp_in[3], &c->hp_out[0], &c->hp_out[1]}) b->release();
     for (DevBuf *b : {&c->dp_in[0], &c->dp_in[1], &c->dp_in[2], &c->dp_in[3], &c->dp_out[0], &c->dp_out[1]}) b->release();
     for (auto &e : c->ev_in) if (e) (void)hipEventDestroy(e);
@@ -674,7 +682,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         const uint32_t total = (s1 < nseg_all ? segs[s1].blk_base : nblk) - segs[s0].blk_base;
         const uint32_t nruns = (total + split_blocks - 1) / split_blocks;
         if (nruns > 1) {
-            const uint32_t round = 256 * bps, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
+            const uint32_t round = c->n_cus * bps, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
             if (even < split_blocks) split_blocks = even;
         }
     }
@@ -706,8 +714,8 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         // The match kernel runs one workgroup per segment and CU, all of equal length: a run of 3 334 segments is 13 full rounds of the 256 CUs and a 14th for
         // 6 of them.  The segments behind the last full round are therefore cut into UNITS of one block each (table pre-warmed: the same words, SS4a), a launch
         // of their own behind the full rounds: R x 8 short workgroups instead of R long ones next to 256 - R idle CUs.
-        uint32_t R = (!gt && !waveparse && c->tun.tail_units && b - a >= 512) ? (b - a) % 256 : 0;
-        if (R > 96) R = 0;
+        uint32_t R = (!gt && !waveparse && c->tun.tail_units && b - a >= 2 * c->n_cus) ? (b - a) % c->n_cus : 0;     // (n_cus: the device's compute units, 256 on an MI355X)
+        if (R > 3 * c->n_cus / 8) R = 0;
         if (R) {
             const uint32_t bl = segs[a].blk_log, bs = 1u << bl;
             size_t nu = 0;
@@ -828,6 +836,9 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
     SegDesc *segs = (SegDesc *)c->h_plan.p, *units = (SegDesc *)((uint8_t *)c->h_plan.p + o_units);   // (the previous sub-batch has been waited for: the staging is free)
     c->tail_used = 0;
     uint32_t *blk_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_blkseg), *entry_first_seg = (uint32_t *)((uint8_t *)c->h_plan.p + o_entry);
+    // option single_frame (zstd): an entry's segments form ONE frame -- the frame header in front of the first segment only, the last-block bit on the entry's
+    // last block only (SegDesc::first bit 2 tells k_plan / k_write); the blocks are what they are in the frame-per-segment form
+    const uint32_t sf_bit = (algo == PNA_ALGO_ZSTD && c->tun.single_frame) ? 4u : 0u;
     {
         auto fill = [&](size_t a, size_t b) {
             for (size_t e = a; e < b; e++) {
@@ -837,7 +848,7 @@ static int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const ui
                 if (len == 0) { segs[sg] = SegDesc{off, 0, bk, (uint32_t)e, 3, 0, 0, blk_log, 0}; continue; }
                 for (uint64_t p = 0; p < len; p += SEG_SIZE) {
                     const uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
-                    const SegDesc s{off + p, sl, bk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u), 0, sl, blk_log, 0};
+                    const SegDesc s{off + p, sl, bk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u) | sf_bit, 0, sl, blk_log, 0};
                     const uint32_t nb = (sl + bsz - 1) >> blk_log;
                     for (uint32_t b2 = 0; b2 < nb; b2++) blk_seg[bk + b2] = sg;
                     bk += nb; segs[sg++] = s;
@@ -1638,6 +1649,49 @@ extern "C" int pna_gpu_create_solid_archive_host(pna_gpu_ctx *c, int algo, int l
 // page-locked memory and its H2D copy runs on a second stream; the archive bytes of sub-batch k-1 travel back on a
 // third stream and are handed to the sink in one piece.  Replaces the reference's "every compressed entry in RAM until
 // the scope ends" (cli/src/command/core.rs:496-537, create.rs:575-635) with a fixed in-flight window.
+// ---- zero-staging input (round 4).  cli/src/command/core.rs:889-913 write_from_path reads every file into memory the library could own: with
+// pna_gpu_host_alloc the host gets PAGE-LOCKED buffers to read its files into (read_exact into the slot instead of fs::read into a Vec), and the create
+// entry points send entries that lie in such a buffer to the device straight from there -- the pageable -> page-locked copy on eight host threads is gone,
+// one thread issues the copies.  Any mix works: a batch with an entry elsewhere is staged as before.
+extern "C" int pna_gpu_host_alloc(pna_gpu_ctx *c, size_t bytes, void **out) {
+    if (!c || !out || !bytes) return fail(c, PNA_E_INVAL, "null argument");
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(c, PNA_E_NOMEM, "page-locked allocation failed");
+    { std::lock_guard<std::mutex> lk(c->lent_mu); c->lent.emplace_back((const uint8_t *)p, bytes); }
+    *out = p;
+    return PNA_OK;
+}
+extern "C" int pna_gpu_host_free(pna_gpu_ctx *c, void *p) {
+    if (!c || !p) return fail(c, PNA_E_INVAL, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->lent_mu);
+        auto it = std::find_if(c->lent.begin(), c->lent.end(), [&](const std::pair<const uint8_t *, size_t> &b) { return b.first == (const uint8_t *)p; });
+        if (it == c->lent.end()) return fail(c, PNA_E_INVAL, "not a buffer of pna_gpu_host_alloc");
+        c->lent.erase(it);
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipHostFree(p);
+    return PNA_OK;
+}
+static bool entries_all_lent(pna_gpu_ctx *c, const void *const *src, const size_t *src_len, size_t n) {
+    std::lock_guard<std::mutex> lk(c->lent_mu);
+    if (c->lent.empty() || !n) return false;
+    size_t hint = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!src_len[i]) continue;
+        const uint8_t *p = (const uint8_t *)src[i];
+        bool in = false;
+        for (size_t k = 0; k < c->lent.size() && !in; k++) {                            // (entries of one call mostly share a buffer: start with the last hit)
+            const auto &b = c->lent[(hint + k) % c->lent.size()];
+            if (p >= b.first && p + src_len[i] <= b.first + b.second) { in = true; hint = (hint + k) % c->lent.size(); }
+        }
+        if (!in) return false;
+    }
+    return true;
+}
+
 static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *src_len, const uint64_t *off, size_t e0, size_t e1, unsigned threads) {
     uint64_t total = 0;
     for (size_t e = e0; e < e1; e++) total += src_len[e];
@@ -1821,8 +1875,9 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     {   // slots sized once for the largest sub-batch (allocation of page-locked memory is slow: not inside the pipeline)
         uint64_t max_in = 0, max_out = 0;
         for (const Sub &sb : subs) { max_in = std::max(max_in, sb.in_bytes); max_out = std::max(max_out, sb.out_cap); }
+        const bool lent0 = entries_all_lent(c, src, src_len, n);                    // (then no page-locked staging of the library's own is needed)
         for (int s = 0; s < NS && s < (int)subs.size(); s++)
-            if (c->hp_in[s].ensure(max_in + 8192) || c->dp_in[s].ensure(max_in + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+            if ((!lent0 && c->hp_in[s].ensure(max_in + 8192)) || c->dp_in[s].ensure(max_in + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
         for (int s = 0; s < 2 && s < (int)subs.size(); s++)
             if (c->dp_out[s].ensure(max_out + 64) || c->hp_out[s].ensure(max_out + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
     }
@@ -1835,6 +1890,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     size_t staged = 0, freed = 0; int stager_rc = PNA_OK; bool stop = false;      // sub-batches staged (copies issued) / sub-batches whose kernels are done
     const int dev_id = c->device;
     hipStream_t cp_in = c->cp_in;
+    const bool all_lent = entries_all_lent(c, src, src_len, n);
     std::thread stager([&]() {
         try {
             if (hipSetDevice(dev_id) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); stager_rc = PNA_E_HIP; staged = subs.size(); cv.notify_all(); return; }
@@ -1848,6 +1904,18 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
                 uint8_t *hb = (uint8_t *)c->hp_in[sl].p, *db = (uint8_t *)c->dp_in[sl].p;
                 int r = PNA_OK;
                 size_t g0 = nx.e0;
+                if (all_lent) {
+                    // every entry lies in page-locked memory the library lent out (pna_gpu_host_alloc): no staging copy, the copy engine reads the host's
+                    // buffers themselves -- runs of entries that are contiguous there and here (16-byte stride) travel as ONE copy
+                    while (g0 < nx.e1 && r == PNA_OK) {
+                        size_t g1 = g0 + 1;
+                        while (g1 < nx.e1 && (const uint8_t *)src[g1] == (const uint8_t *)src[g0] + (off[g1] - off[g0])) g1++;
+                        const uint64_t bytes = (g1 < nx.e1 ? off[g1] : off[g1 - 1] + src_len[g1 - 1]) - off[g0];
+                        const uint64_t k = std::min<uint64_t>(bytes, (const uint8_t *)src[g1 - 1] + src_len[g1 - 1] - (const uint8_t *)src[g0]);
+                        if (k && hipMemcpyAsync(db + off[g0], src[g0], k, hipMemcpyHostToDevice, cp_in) != hipSuccess) r = PNA_E_HIP;
+                        g0 = g1;
+                    }
+                }
                 while (g0 < nx.e1 && r == PNA_OK) {
                     size_t g1 = g0; uint64_t acc = 0;
                     while (g1 < nx.e1 && acc < (128ull << 20)) acc += src_len[g1++];

@@ -8,6 +8,7 @@ import hashlib
 import importlib
 import io
 import os
+import ctypes
 import zlib
 
 import pytest
@@ -865,6 +866,68 @@ def test_max_chunk_size_cuts_fdat_like_flatten_writer(gpu_ctx, pna, pf, codec, m
         # CBC chains the whole entry and GCM authenticates whole segments: entries beyond one chunk are refused, not written differently
         with pytest.raises(pna.PnaGpuError):
             pna.create_archive_chunked(gpu_ctx, names, ents, mcs, cipher=pna.Cipher(key, phsf, pna.MODE_CBC, ivs=ivs))
+
+def test_single_frame_option(pna, pf, codec):
+    """Option single_frame: a zstd entry is ONE frame whatever its size -- the blocks of the frame-per-segment form, the frame header in front of the first
+    segment only and the last-block bit on the entry's last block only (SURVEY 8 a14's fallback should a reader ever refuse concatenated frames; the
+    reference's own reader takes both: zstd::Decoder::with_buffer, lib/src/entry/read.rs:181).  Equal to the model with PNA_F_SINGLE_FRAME, exactly
+    6 bytes per further segment shorter than the default form, one frame for every decoder -- the oracle's, libzstd, the device's --, in a batch call,
+    in an archive assembled in HBM and read back by the extract driver, and for the solid stream."""
+    import torch  # noqa: F401
+    ents = [codec.corpus_file(0, 4500, (3 << 20) + 12345), b"", codec.corpus_file(1, 4501, 70000), codec.corpus_file(0, 4502, 1 << 20), codec.corpus_file(2, 4503, (1 << 20) + 1),
+            codec.corpus_file(0, 4504, (2 << 20))]
+    names = [f"sf/{i}" for i in range(len(ents))]
+    with pna.Context(0) as ctx:
+        ctx.set_option("latency_max_mib", 0)
+        multi = ctx.compress_batch(ents)
+        ctx.set_option("single_frame", 1)
+        outs = ctx.compress_batch(ents)
+        p = codec.params_for_level(3)
+        p.flags |= 0x400
+        for e, o, m in zip(ents, outs, multi):
+            assert o == codec.model_compress(e, p)
+            assert len(m) - len(o) == 6 * (max(1, -(-len(e) >> 20)) - 1)
+            assert codec.zstd_frame_count(o, len(e) + 64) == 1
+            assert codec.zstd_decompress(o, len(e)) == e
+            if codec.system_libzstd() is not None:
+                assert codec.libzstd_decompress_stream(o, len(e)) == e
+        assert ctx.decompress_batch(outs, [len(e) for e in ents]) == ents
+        arc = pna.create_archive(ctx, names, ents)
+        _, items = pf.read_archive(arc)
+        assert [it.data for it in items] == outs
+        assert [(n, d) for n, _, d in pna.extract_archive(ctx, arc)] == list(zip(names, ents))
+        solid = pna.create_archive(ctx, names, ents, solid=True)
+        assert [(n, d) for n, _, d in pna.extract_archive(ctx, solid)] == list(zip(names, ents))
+        ctx.set_option("latency_max_mib", 192)                     # the small-batch mode (smaller blocks, LZ units): same rule
+        (o1,) = ctx.compress_batch([ents[0]])
+        p1 = codec.params_for_level(3, blk_log=ctx.timing().blk_log)
+        p1.flags |= 0x400
+        assert o1 == codec.model_compress(ents[0], p1) and codec.zstd_frame_count(o1, len(ents[0]) + 64) == 1
+
+
+def test_zero_staging_host_slots(gpu_ctx, pna, pf, codec):
+    """pna_gpu_host_alloc: entries the host placed in a page-locked buffer of the library go to the device straight from there (no pageable ->
+    page-locked staging copy; cli/src/command/core.rs:889-913 reads into memory the library could own).  Same archive, byte for byte, as from ordinary
+    memory -- contiguous at a 16-byte stride (one copy per run), scattered with gaps, with empty entries in between, and mixed with an entry that lives
+    elsewhere (the whole batch is staged then)."""
+    ents = [codec.corpus_file(0, 4400 + i, n) for i, n in enumerate([300000, 0, 5, (1 << 20) + 3, 70001, 0, 999])]
+    names = [f"slot/{i}" for i in range(len(ents))]
+    want = pna.create_archive(gpu_ctx, names, ents)
+    slot = pna.HostSlot(gpu_ctx, 4 << 20)
+    try:
+        for gap in (0, 4096 + 5):                                     # packed at the pipeline's own stride / scattered
+            offs, pos = [], 0
+            for e in ents:
+                offs.append(pos)
+                slot.view[pos:pos + len(e)] = e
+                pos = ((pos + len(e) + 15) & ~15) + gap
+            assert pna.create_archive_from_slot(gpu_ctx, names, slot, offs, [len(e) for e in ents]) == want
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx._check(gpu_ctx._L.pna_gpu_host_free(gpu_ctx._h, ctypes.c_void_p(slot.ptr + 16)))      # not a buffer of host_alloc
+    finally:
+        slot.free()
+    assert pna.create_archive(gpu_ctx, names, ents) == want           # (and the ordinary path is what it was)
+
 
 def test_max_chunk_size_host_pipeline_with_incompressible_entries_only(gpu_ctx, pna, pf, codec):
     """The bounded host pipeline sizes a sub-batch's device buffer per entry; with max_chunk_size set every further FDAT chunk costs a CRC + a header
