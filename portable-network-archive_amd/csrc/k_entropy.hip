@@ -745,11 +745,16 @@ void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict
     // The block's last sequence only sets the initial state.
     uint4 *w8 = (uint4 *)w;
     int32_t j = (int32_t)((nseq - 1) >> 3);
-    uint4 cur = w8[j];
+    // (four groups in flight: a group's eight steps are ~0.3 us of the lane's chain, a load under this kernel's traffic takes ~2 us -- with one group
+    // ahead the kernel waited for memory 80 % of its cycles, PMC round 4)
+    uint4 cur = w8[j], r1 = cur, r2 = cur, r3 = cur;
+    if (j > 0) r1 = w8[j - 1];
+    if (j > 1) r2 = w8[j - 2];
+    if (j > 2) r3 = w8[j - 3];
     bool first = true;
     for (; j >= 0; j--) {
-        uint4 nxt = cur;
-        if (j > 0) nxt = w8[j - 1];
+        uint4 r4 = r3;
+        if (j > 3) r4 = w8[j - 4];
         const uint32_t cw32[4] = {cur.x, cur.y, cur.z, cur.w};
         uint32_t out[4] = {0, 0, 0, 0};
         const int32_t top = (int32_t)(nseq - 1) - 8 * j;                // highest sequence of the group that exists (7 but in the top group)
@@ -770,7 +775,7 @@ void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict
             out[k >> 1] |= rec << (16 * (k & 1));
         }
         w8[j] = make_uint4(out[0], out[1], out[2], out[3]);
-        cur = nxt;
+        cur = r1; r1 = r2; r2 = r3; r3 = r4;
     }
     // the block's bit count: the three streams' sums + the final states + the closing bit; the final states go to BlkInfo::pad (zero so far), ML | OF << 8 | LL << 16
     bits += mode != 1 ? tlog : 0u;
@@ -861,11 +866,15 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     const uint32_t top = nseq - 1;
     uint32_t k = top >> 2;
     const uint4 *bs4 = (const uint4 *)bs;
+    // (two chunks ahead: a chunk's four sequences are ~800 instructions = 1.6 us of one wave, about what a load takes under the stage's traffic -- with one
+    // chunk in flight a third of the kernel's cycles were waits for it)
     uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
+    uint4 n0 = a0, n1 = a1;
+    if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
     bool first = true;
     for (;;) {
-        uint4 n0 = a0, n1 = a1;
-        if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
+        uint4 m0 = n0, m1 = n1;
+        if (k > 1) { m0 = bs4[2 * (k - 2)]; m1 = bs4[2 * (k - 2) + 1]; }
         const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
                                 (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
 #pragma unroll
@@ -892,7 +901,7 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
             flush();
         }
         if (k == 0) break;
-        k--; a0 = n0; a1 = n1;
+        k--; a0 = n0; a1 = n1; n0 = m0; n1 = m1;
     }
     if (mml != 1) put(st_ml & ((1u << tl_ml) - 1), tl_ml);
     if (mof != 1) put(st_of & ((1u << tl_of) - 1), tl_of);

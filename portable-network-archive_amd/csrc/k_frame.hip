@@ -361,6 +361,31 @@ void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, 
     if (n) hipLaunchKernelGGL(k_link_copy, dim3(wgs ? wgs : 1), dim3(256), 0, st, (const uint4 *)src, (uint4 *)dst, n >> 4, src, dst, (uint32_t)(n & 15));
 }
 
+// ------------------------------------------------------------------ k_link_gather : many small page-locked host buffers -> one device buffer
+// The streaming facade's writers fill 1 MiB page-locked slabs; as one hipMemcpyAsync each they took ~30 us apiece on the copy engine (33 GB/s for a
+// batch of 256: the copy-in stage bound the facade's pipeline).  One kernel reads them through their device mapping instead -- workgroup w takes the
+// segments w, w + W, ..., 16 bytes per lane and step --; the list of segments lies in page-locked memory as well.  len: multiples of 16 but for a
+// stream's last slab (its tail bytes go one by one).
+struct LinkSeg { const uint8_t *src; uint8_t *dst; uint64_t len; };
+__global__ __launch_bounds__(256)
+void k_link_gather(const LinkSeg *__restrict__ segs, uint32_t nseg) {
+    for (uint32_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const LinkSeg g = segs[s];
+        const uint4 *src = (const uint4 *)g.src; uint4 *dst = (uint4 *)g.dst;
+        const size_t n16 = g.len >> 4;
+        size_t i = threadIdx.x;
+        for (; i + 768 < n16; i += 1024) {                                   // four loads in flight per lane: the link's latency is what a lane waits for
+            const uint4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+            dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+        }
+        for (; i < n16; i += 256) dst[i] = src[i];
+        if (threadIdx.x < (g.len & 15)) g.dst[(n16 << 4) + threadIdx.x] = g.src[(n16 << 4) + threadIdx.x];
+    }
+}
+void launch_link_gather(const void *segs, uint32_t nseg, uint32_t wgs, hipStream_t st) {
+    if (nseg) hipLaunchKernelGGL(k_link_gather, dim3(wgs < nseg ? wgs : nseg), dim3(256), 0, st, (const LinkSeg *)segs, nseg);
+}
+
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_gather, dim3(n), dim3(256), 0, st, (const PlaceDesc *)pd, src, dst);
 }

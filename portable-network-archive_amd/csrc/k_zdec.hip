@@ -586,9 +586,13 @@ void k_zdec(ZFrame *__restrict__ frames, const uint8_t *__restrict__ src, uint8_
 // go through k_zdec.
 struct ZWork { uint32_t n_huf, n_seq, pad0, pad1; };
 
+// ONE (round 4): the frame's blocks were laid out by k_zparse_a (a serial walk of the headers only: positions, sizes, table slots) and every wave of this
+// launch parses ONE of them -- blockIdx.x = index into `one_list` of block numbers --: what took the single wave of a 2 048-block frame 0.6 s (0.29 ms of
+// weight decoding and table building per block on lane 0) runs side by side.  Same code, the running state comes from the block's descriptor.
+template <bool ONE>
 __global__ __launch_bounds__(64)
 void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
-              ZTables *__restrict__ tabs, uint32_t *__restrict__ huf_list, uint32_t *__restrict__ seq_list, ZWork *__restrict__ work) {
+              ZTables *__restrict__ tabs, uint32_t *__restrict__ huf_list, uint32_t *__restrict__ seq_list, ZWork *__restrict__ work, const uint32_t *__restrict__ one_list) {
     __shared__ uint16_t huf_tab[1 << ZD_HUF_MAX];
     __shared__ uint32_t fse_tab[512];
     __shared__ uint8_t  weights[256];
@@ -596,15 +600,19 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
     __shared__ uint16_t nexts[256];
     __shared__ uint32_t wtab[64];
     __shared__ uint32_t s_cmd[8];          // lane 0 -> wave: [0] what to flush (1 huffman, 2 fse), [1] slot, [2] which, [3] maxbits / alog, [4] nweights
-    const uint32_t lane = threadIdx.x, f = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    ZBlock pre;                                                         // ONE: what k_zparse_a put down for this wave's block
+    if (ONE) pre = blocks[one_list[blockIdx.x]];
+    const uint32_t f = ONE ? pre.frame : blockIdx.x;
     ZFrame fr = frames[f];
     ZFrameX x = fx[f];
+    if (!ONE && x.pad) return;                                          // a large frame: k_zparse_a + k_zparse<true> take it
     const uint8_t *in = src + fr.src_off;
     const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;
     const bool open = (fr.out_len & ZF_OPEN) != 0;
     uint32_t status = fr.status, ip = 0;
     // ---- frame header
-    if (status == ZD_OK) {
+    if (!ONE && status == ZD_OK) {
         if (in_len < 6) status = ZD_CORRUPT;
         else {
             const uint32_t magic = in[0] | (in[1] << 8) | (in[2] << 16) | ((uint32_t)in[3] << 24);
@@ -628,6 +636,11 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
     }
     uint32_t nblk = 0, next_slot = 0, huf_slot = 0xFFFFFFFFu, slot3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     uint32_t lit_pos = 0; uint64_t seq_pos = 0;
+    if (ONE) {                                                          // the walk's state in front of this block
+        nblk = one_list[blockIdx.x] - x.blk_base; next_slot = pre.pad[3]; huf_slot = pre.huf_slot; slot3[0] = pre.slot[0]; slot3[1] = pre.slot[1]; slot3[2] = pre.slot[2];
+        lit_pos = pre.lit_pos; seq_pos = pre.seq_pos - x.seq_base; ip = (uint32_t)(pre.body - 3 - fr.src_off);
+        if (status != ZD_OK) return;
+    }
     bool last = status != ZD_OK;
     while (!last) {
         // lane 0 parses one block; whenever a table is complete in LDS the whole wave copies it out
@@ -834,8 +847,111 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
         if (s_cmd[3] == 2) { lit_pos += s_cmd[4]; seq_pos += s_cmd[6]; }
         nblk++;
         __builtin_amdgcn_wave_barrier();
+        if (ONE) break;
     }
+    if (ONE) { if (status != ZD_OK && lane == 0) atomicMax(&frames[f].status, status); return; }
     if (lane == 0) { fx[f].nblk = nblk; frames[f].status = status; }
+}
+
+// ------------------------------------------------------------------ k_zparse_a : the header walk of a LARGE frame, one lane per frame of the list
+// Per block only what the walk itself needs: the 3-byte block header, the literals section's header (<= 5 bytes: sizes) and the sequences section's
+// (count + modes) -- which tables the block DEFINES follows from those, so the slots can be handed out without decoding anything.  Every block gets its
+// descriptor with the walk's state in front of it (k_zparse<true> starts from there); a few dependent loads per block: ~10 ms for 2 048 blocks.
+__global__ void k_zparse_a(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint32_t *__restrict__ big_list, uint32_t nbig, const uint8_t *__restrict__ src,
+                           ZBlock *__restrict__ blocks, uint32_t *__restrict__ one_list, uint32_t *__restrict__ one_count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbig) return;
+    const uint32_t f = big_list[t];
+    ZFrame fr = frames[f];
+    const ZFrameX x = fx[f];
+    const uint8_t *in = src + fr.src_off;
+    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;
+    const bool open = (fr.out_len & ZF_OPEN) != 0;
+    uint32_t status = fr.status, ip = 0;
+    if (status == ZD_OK) {
+        if (in_len < 6) status = ZD_CORRUPT;
+        else {
+            const uint32_t magic = in[0] | (in[1] << 8) | (in[2] << 16) | ((uint32_t)in[3] << 24);
+            const uint32_t fhd = in[4];
+            const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+            if (magic != 0xFD2FB528u || (fhd & 0x08)) status = ZD_CORRUPT;
+            else if (dict) status = ZD_UNSUPPORTED;
+            else {
+                ip = 5 + (single ? 0 : 1);
+                const uint32_t fsz = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+                if (ip + fsz > in_len) status = ZD_CORRUPT;
+                else {
+                    uint64_t fcs = 0;
+                    for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
+                    if (fsz == 2) fcs += 256;
+                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
+                    ip += fsz;
+                }
+            }
+        }
+    }
+    uint32_t nblk = 0, next_slot = 0, huf_slot = 0xFFFFFFFFu, slot3[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t lit_pos = 0; uint64_t seq_pos = 0;
+    bool last = status != ZD_OK;
+    while (!last) {
+        if (nblk >= x.blk_cap) { status = ZD_UNSUPPORTED; break; }
+        if (ip + 3 > in_len) { status = ZD_CORRUPT; break; }
+        const uint32_t bh = in[ip] | (in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
+        const uint32_t type = (bh >> 1) & 3, size = bh >> 3;
+        if (type == 3 || size > (128u << 10)) { status = ZD_CORRUPT; break; }
+        if (type == 1 ? ip + 4 > in_len : ip + 3 + size > in_len) { status = ZD_CORRUPT; break; }
+        ZBlock b;
+        b.body = fr.src_off + ip + 3; b.out_off = 0; b.seq_pos = x.seq_base + seq_pos; b.size = size; b.type = type; b.ltype = 0; b.regen = 0; b.streams = 1; b.lit_off = 0; b.lit_csize = 0;
+        b.lit_pos = lit_pos; b.huf_slot = huf_slot; b.slot[0] = slot3[0]; b.slot[1] = slot3[1]; b.slot[2] = slot3[2];
+        b.nseq = 0; b.seq_off = 0; b.seq_len = 0; b.frame = f; b.out_len = type < 2 ? size : 0; b.status = 0; b.uses_rep = 0;
+        for (int i = 0; i < 7; i++) b.pad[i] = 0;
+        b.pad[0] = bh & 1; b.pad[3] = next_slot;
+        uint32_t regen = 0, nseq = 0;
+        if (type == 2) {
+            const uint8_t *p = in + ip + 3; const uint32_t len = size;
+            if (len < 1) { status = ZD_CORRUPT; break; }
+            const uint32_t ltype = p[0] & 3, sf = (p[0] >> 2) & 3;
+            uint32_t comp = 0, hdr;
+            if (ltype < 2) {
+                if (sf == 0 || sf == 2) { regen = p[0] >> 3; hdr = 1; }
+                else if (sf == 1) { if (len < 2) { status = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4); hdr = 2; }
+                else { if (len < 3) { status = ZD_CORRUPT; break; } regen = (p[0] >> 4) + ((uint32_t)p[1] << 4) + ((uint32_t)p[2] << 12); hdr = 3; }
+            } else {
+                if (len < 5) { status = ZD_CORRUPT; break; }
+                uint64_t v = 0; for (int i = 0; i < 5; i++) v |= (uint64_t)p[i] << (8 * i);
+                if (sf == 0) { hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                else if (sf == 1) { hdr = 3; regen = (v >> 4) & 0x3FF; comp = (v >> 14) & 0x3FF; }
+                else if (sf == 2) { hdr = 4; regen = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; }
+                else { hdr = 5; regen = (v >> 4) & 0x3FFFF; comp = (v >> 22) & 0x3FFFF; }
+            }
+            if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { status = regen > (128u << 10) ? ZD_CORRUPT : ZD_DSTSIZE; break; }
+            uint32_t pos = hdr + (ltype == 0 ? regen : (ltype == 1 ? 1u : comp));
+            if (pos >= len) { status = ZD_CORRUPT; break; }                 // (the sequences section holds at least its count)
+            const uint32_t b0 = p[pos++];
+            if (b0 < 128) nseq = b0;
+            else if (b0 < 255) { if (pos >= len) { status = ZD_CORRUPT; break; } nseq = ((b0 - 128) << 8) + p[pos++]; }
+            else { if (pos + 2 > len) { status = ZD_CORRUPT; break; } nseq = p[pos] + ((uint32_t)p[pos + 1] << 8) + 0x7F00; pos += 2; }
+            uint32_t modes = 0xFF;                                          // (no sequences: nothing is defined)
+            if (nseq) { if (pos >= len) { status = ZD_CORRUPT; break; } modes = p[pos]; }
+            if (seq_pos + nseq > x.seq_cap) { status = ZD_UNSUPPORTED; break; }
+            const bool def_tree = ltype == 2;
+            bool own = def_tree;
+            for (int k = 0; k < 3; k++) if (nseq && ((modes >> (6 - 2 * k)) & 3) != 3) own = true;
+            if (own && next_slot >= x.slot_cap) { status = ZD_UNSUPPORTED; break; }
+            if (ltype == 3 && huf_slot == 0xFFFFFFFFu) { status = ZD_CORRUPT; break; }
+            if (def_tree) huf_slot = x.slot_base + next_slot;
+            for (int k = 0; k < 3; k++) if (nseq && ((modes >> (6 - 2 * k)) & 3) != 3) slot3[k] = x.slot_base + next_slot;
+            if (own) next_slot++;
+        }
+        const uint32_t bi = x.blk_base + nblk;
+        blocks[bi] = b;
+        one_list[atomicAdd(one_count, 1u)] = bi;
+        last = (bh & 1) != 0;
+        ip += 3 + (type == 1 ? 1 : size);
+        if (type == 2) { lit_pos += regen; seq_pos += nseq; }
+        nblk++;
+    }
+    fx[f].nblk = nblk; frames[f].status = status;
 }
 
 // ------------------------------------------------------------------ k_zhuf : one lane per Huffman stream
@@ -1215,6 +1331,7 @@ void k_zexec(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx, const 
     const ZFrame fr = frames[f];
     if (fr.status) return;
     const ZFrameX x = fx[f];
+    if (x.pad) return;                                                  // a large frame: executed in parallel (k_zexec_par.hip)
     const bool okq = zexec_blocks(fr, x, 0, x.nblk, blocks, src, lit_scratch, seqs, dst, lane);
     if (!okq && lane == 0) frames[f].status = ZD_CORRUPT;
 }
@@ -1240,7 +1357,16 @@ void k_zexec_groups(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx,
 
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
                    void *work, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_zparse, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, tabs, huf_list, seq_list, (ZWork *)work);
+    if (n) hipLaunchKernelGGL(k_zparse<false>, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, tabs, huf_list, seq_list, (ZWork *)work, (const uint32_t *)nullptr);
+}
+// large frames (ZFrameX::pad set, listed in big_list): the header walk; one_list receives their blocks, work[2] their number
+void launch_zparse_big_a(ZFrame *frames, ZFrameX *fx, const uint32_t *big_list, uint32_t nbig, const uint8_t *src, ZBlock *blocks, uint32_t *one_list, void *work, hipStream_t st) {
+    if (nbig) hipLaunchKernelGGL(k_zparse_a, dim3((nbig + 63) / 64), dim3(64), 0, st, frames, fx, big_list, nbig, src, blocks, one_list, &((ZWork *)work)->pad0);
+}
+// ... and the blocks' tables, one wave per block
+void launch_zparse_big_b(ZFrame *frames, ZFrameX *fx, uint32_t nblocks, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
+                         void *work, const uint32_t *one_list, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_zparse<true>, dim3(nblocks), dim3(64), 0, st, frames, fx, src, blocks, tabs, huf_list, seq_list, (ZWork *)work, one_list);
 }
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {

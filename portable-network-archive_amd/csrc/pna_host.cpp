@@ -47,6 +47,7 @@ void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, con
 void launch_place(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_gather(const void *pd, uint32_t n, const uint8_t *src, uint8_t *dst, hipStream_t st);
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, hipStream_t st);
+void launch_link_gather(const void *segs, uint32_t nseg, uint32_t wgs, hipStream_t st);   // k_frame.hip: {src, dst, len} x nseg, page-locked sources
 void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st, uint32_t max_payload);
@@ -56,6 +57,9 @@ void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *fr
 void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st);
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
                    void *work, hipStream_t st);
+void launch_zparse_big_a(ZFrame *frames, ZFrameX *fx, const uint32_t *big_list, uint32_t nbig, const uint8_t *src, ZBlock *blocks, uint32_t *one_list, void *work, hipStream_t st);
+void launch_zparse_big_b(ZFrame *frames, ZFrameX *fx, uint32_t nblocks, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
+                         void *work, const uint32_t *one_list, hipStream_t st);
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st);
@@ -66,6 +70,9 @@ void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint
                    void *part, hipStream_t st);
 void launch_zexec_groups(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const void *pieces, uint32_t npieces, const uint8_t *src, const uint8_t *lit_scratch,
                          const uint64_t *seqs, uint8_t *dst, hipStream_t st);
+struct ZxFrame { uint64_t dst_off, dst_len; uint32_t blk_base, nblk, status, unresolved; };      // k_zexec_par.hip
+int launch_zexec_par(ZxFrame *zf, const ZxFrame &h, const ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch, uint64_t *seqs, uint32_t *rep_scratch,
+                     uint32_t *words, uint8_t *dst, uint32_t *status_out, uint32_t *rounds_out, hipStream_t st);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 std::string pna_sanitize_name(const char *name, size_t n);
@@ -145,6 +152,10 @@ struct Tuning {
     long lazy2 = 2;                  // PNA_LAZY2: how far the lazy level sets look ahead beyond the next position: 2 = two more positions (default), 1 = one more, 0 = none (the high sets: one)
     long single_frame = 0;           // PNA_SINGLE_FRAME: 1: a zstd entry is ONE frame whatever its size (header once, last-block bit once; SURVEY 8 a14's fallback for a reader that would
                                      // not take concatenated frames -- zstd's own Decoder, which the reference uses, does); 0 (default): one frame per 1 MiB segment
+    long stream_gather_wgs = 48;     // PNA_STREAM_GATHER_WGS: workgroups of the kernel that copies a batch's page-locked slabs to the device (0: one hipMemcpyAsync per slab, ~30 us each)
+    long stream_overlap_mib = 64;    // PNA_STREAM_OVERLAP_MIB: while a batch runs on the device the next one is taken (and copied in beside it) only once the queue holds this much
+    long stream_batch_mib = 256;     // PNA_STREAM_BATCH_MIB: input bytes one batch of the streaming facade takes at most (the queue's rest is the next batch, which is copied in meanwhile)
+    long zexec_par_min_mib = 8;      // PNA_ZEXEC_PAR_MIN_MIB: zstd frames whose content takes this many MiB and more are executed in parallel by pointer jumping (0: never)
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
@@ -164,7 +175,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 struct pna_gpu_stream;
@@ -191,6 +202,9 @@ struct pna_gpu_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
+    DevBuf z_big, z_one;                            // large zstd frames: their numbers, their blocks (k_zparse_a -> k_zparse<true>)
+    DevBuf z_words, z_rep, z_zxf;                   // the parallel executor of large zstd frames (k_zexec_par.hip): a word per output byte, histories per block
+    uint32_t zexec_par_rounds = 0;                  // pointer-jumping rounds of the latest large frame (diagnostics)
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf gtab;                                    // hash tables of the strong level set's match kernel (global memory)
     DevBuf fr_desc, fr_blob, fr_segdst, fr_entoff, crc_tabs;
@@ -226,7 +240,7 @@ struct pna_gpu_ctx {
     size_t max_blocks = (size_t)1 << 17;            // blocks per sub-batch: what ~96 GiB of per-block workspace hold at that block size (16 GiB of input at 128 KiB)
     // group commit of the streaming facade (pna_gpu_stream_finish from many host threads -> one device batch)
     std::mutex comb_mu, run_mu;            // comb_mu: queue + leader flag; run_mu: the device batch itself and ctx->err
-    std::condition_variable comb_cv;
+    std::condition_variable comb_cv, gate_cv;   // gate_cv: the ONE leader waiting for its slot / the device / a larger queue (every push signals it: not the hundreds of writers on comb_cv)
     std::vector<pna_gpu_stream *> comb_queue;
     bool comb_leader = false;
     uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0, comb_seq = 0;
@@ -236,8 +250,23 @@ struct pna_gpu_ctx {
     // copy), the compressed streams come back into one of two page-locked output slots and the owners drain them from there
     std::mutex pool_mu;
     std::vector<void *> pool_arenas; std::vector<uint8_t *> pool_free; size_t pool_bytes = 0, pool_cap = 4096ull << 20;
-    PinBuf s_out[2];
-    uint64_t slot_pending[2] = {0, 0};     // streams of the slot's last batch that have not been drained yet (under comb_mu)
+    // Round 4: the batches of the facade form a PIPELINE of three stages over three slots -- (1) the H2D copies of batch k + 1 from the writers' slabs, (2) the
+    // device batch k, (3) the D2H copy of batch k - 1's streams -- each on a stream of its own; a leader holds `comb_leader` only while it takes its batch
+    // and copies it in, `run_mu` only for the device batch.  A batch takes at most stream_batch_mib of input (what fills the chip), the rest of the queue
+    // is the next leader's.
+    static constexpr int S_SLOTS = 3;
+    PinBuf s_out[S_SLOTS];
+    DevBuf st_in[S_SLOTS], st_out[S_SLOTS];
+    PinBuf s_segs[S_SLOTS];                 // the copy-in kernel's segment list of the slot's batch
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t s_ev[S_SLOTS] = {nullptr, nullptr, nullptr};
+    uint64_t slot_pending[S_SLOTS] = {0, 0, 0};     // streams of the slot's last batch that have not been drained yet (under comb_mu)
+    bool device_busy = false;              // a batch of the facade holds the device (under comb_mu).  While it does, a new leader keeps collecting until the queue holds
+                                           // stream_overlap_mib -- enough to be worth copying in beside the running batch --; few writers therefore still form ONE batch per
+                                           // device turn (the fixed ~0.7 ms of a batch is shared by all of them), many writers fill the pipeline
+    uint32_t staged_waiting = 0;           // batches copied in and waiting for the device (under comb_mu): a new leader takes its batch only when there is none --
+                                           // while the device is busy the queue keeps growing, so few writers still share batches (4 writers: batches of 2 - 3, not 1)
+    std::mutex err_mu;                     // ctx->err from the pipeline's copy stages (the device batch sets it under run_mu as every entry point does)
 };
 
 static int fail(pna_gpu_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
@@ -300,12 +329,13 @@ extern "C" int pna_gpu_set_option(pna_gpu_ctx *c, const char *name, long value) 
 }
 
 extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
-    if (c) { for (void *a : c->pool_arenas) (void)hipHostFree(a); c->pool_arenas.clear(); c->pool_free.clear(); c->s_out[0].release(); c->s_out[1].release(); }
+    if (c) { for (void *a : c->pool_arenas) (void)hipHostFree(a); c->pool_arenas.clear(); c->pool_free.clear(); for (auto &b : c->s_out) b.release(); for (auto &b : c->st_in) b.release(); for (auto &b : c->st_out) b.release(); for (auto &b : c->s_segs) b.release();
+             if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d); if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h); for (auto &e : c->s_ev) if (e) (void)hipEventDestroy(e); }
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->plan, &c->d_tail, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->z_words, &c->z_rep, &c->z_zxf, &c->z_big, &c->z_one, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->gtab, &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (auto &b : c->lent) (void)hipHostFree((void *)b.first);          // (buffers the host never gave back)
     c->lent.clear();
@@ -2886,16 +2916,67 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     std::vector<ZFrame> frs(nfr);
     if (!serial_only) {
+        // Large frames (the reference writes ONE frame per entry whatever its size): k_zscan has found them -- a frame whose content takes zexec_par_min_mib
+        // and more (below 2 GiB: the parallel executor's words hold 31-bit positions).  Their blocks are PARSED side by side (k_zparse_a: the header walk,
+        // k_zparse<true>: a wave per block for the tables) and their sequences EXECUTED in parallel by pointer jumping (k_zexec_par.hip) instead of by one
+        // wave each; the per-frame kernels skip them (ZFrameX::pad).
+        std::vector<uint32_t> big;
+        std::vector<ZFrameX> fxd;
+        const uint64_t big_min = (uint64_t)c->tun.zexec_par_min_mib << 20;
+        if (c->tun.zexec_par_min_mib > 0) {
+            bool any = false;
+            for (size_t i = 0; i < n && !any; i++) any = raw_len[i] >= big_min;
+            if (any) {
+                HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                for (uint64_t f = 0; f < nfr; f++)
+                    if (frs[f].status == 0 && frs[f].dst_len >= big_min && frs[f].dst_len < (1ull << 31) - 4096) big.push_back((uint32_t)f);
+                if (!big.empty()) {
+                    if (c->z_big.ensure(big.size() * 4 + 64) || c->z_one.ensure(nblk_cap * 4 + 64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+                    const uint32_t one = 1;
+                    for (uint32_t f : big) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_fx.p + (size_t)f * sizeof(ZFrameX) + offsetof(ZFrameX, pad), &one, 4, hipMemcpyHostToDevice, st));
+                    HIPCHK(c, hipMemcpyAsync(c->z_big.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
+                }
+            }
+        }
         // sequence records of frame f start at seq_base: k_zparse adds it to the block's running count
         launch_zparse((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)nfr, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (ZTables *)c->z_tabs.p,
                       (uint32_t *)c->z_hlist.p, (uint32_t *)c->z_slist.p, c->z_work.p, st);
         uint32_t work[4] = {0, 0, 0, 0};
+        if (!big.empty()) {
+            launch_zparse_big_a((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (const uint32_t *)c->z_big.p, (uint32_t)big.size(), (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p,
+                                (uint32_t *)c->z_one.p, c->z_work.p, st);
+            fxd.resize(nfr);
+            HIPCHK(c, hipMemcpyAsync(work, c->z_work.p, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(fxd.data(), c->z_fx.p, nfr * sizeof(ZFrameX), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            launch_zparse_big_b((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, work[2], (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (ZTables *)c->z_tabs.p,
+                                (uint32_t *)c->z_hlist.p, (uint32_t *)c->z_slist.p, c->z_work.p, (const uint32_t *)c->z_one.p, st);
+        }
         HIPCHK(c, hipMemcpyAsync(work, c->z_work.p, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         launch_zstreams(work[0], work[1], (const uint32_t *)c->z_hlist.p, (const uint32_t *)c->z_slist.p, c->z_work.p, (ZBlock *)c->z_blocks.p,
                         (const ZFrame *)c->z_frames.p, (const ZTables *)c->z_tabs.p, (const uint8_t *)d_src, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
         launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)nfr, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
                      (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+        if (!big.empty()) {
+            HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));      // (k_zoff has fixed the sizes of open frames)
+            HIPCHK(c, hipStreamSynchronize(st));
+            for (uint32_t f : big) {
+                if (frs[f].status) continue;
+                ZxFrame h{frs[f].dst_off, frs[f].dst_len, fxd[f].blk_base, fxd[f].nblk, 0, 0};
+                if (c->z_words.ensure(h.dst_len * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+                HIPCHK(c, hipMemcpyAsync(c->z_zxf.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+                uint32_t zst = 0, rounds = 0;
+                if (launch_zexec_par((ZxFrame *)c->z_zxf.p, h, (const ZBlock *)c->z_blocks.p, (const uint8_t *)d_src, (const uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p,
+                                     (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st) != 0) return fail(c, PNA_E_HIP, "parallel frame execution failed");
+                c->zexec_par_rounds = rounds;
+                if (zst) {                                            // 2: the serial kernel takes the frame (it decodes from the source again); 3: corrupt
+                    const uint32_t code = zst == 2 ? 2u : 1u;
+                    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)f * sizeof(ZFrame) + offsetof(ZFrame, status), &code, 4, hipMemcpyHostToDevice, st));
+                }
+            }
+        }
         launch_zxxh((ZFrame *)c->z_frames.p, (uint32_t)nfr, (const uint8_t *)d_src, (const uint8_t *)d_dst, st);   // frames that carry a content checksum
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
@@ -2993,7 +3074,7 @@ struct pna_gpu_stream {
     pna_gpu_ctx *ctx; int algo, level; pna_sink_fn sink; void *user;
     std::vector<uint8_t *> slabs; size_t slab_len = 0;      // page-locked mode: bytes [k * S_SLAB, ...) live in slabs[k]
     bool pageable = false; std::vector<uint8_t> buf;        // pageable mode (pool exhausted / very large stream): everything in buf
-    const uint8_t *out = nullptr; size_t out_len = 0; int rc = PNA_OK, slot = 0; bool done = false;
+    const uint8_t *out = nullptr; size_t out_len = 0; int rc = PNA_OK, slot = 0; bool done = false, queued = false;
     size_t total() const { return pageable ? buf.size() : slab_len; }
 };
 
@@ -3051,67 +3132,113 @@ extern "C" int pna_gpu_stream_write(pna_gpu_stream *s, const void *buf, size_t l
 extern "C" int pna_gpu_stream_flush(pna_gpu_stream *s) { return s ? PNA_OK : PNA_E_INVAL; }
 extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { if (s) { pool_put(s->ctx, s->slabs); delete s; } }
 
-// One device batch per (algo, level) group of the streams the leader took: H2D copies straight from the streams' page-locked slabs
-// (pageable streams are staged first), the device batch, ONE D2H copy of the group's streams into the slot's page-locked output.
-static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch, int slot) {
-    std::lock_guard<std::mutex> run(c->run_mu);
+// One batch of the facade = the streams a leader took, per (algo, level) group: (1) H2D copies straight from the streams' page-locked slabs (pageable
+// streams are staged first) on the copy-in stream; `in_done()` then hands the leader's role on, and the next batch is copied in while this one runs;
+// (2) the device batch under run_mu; (3) ONE D2H copy of the group's streams into the slot's page-locked output on the copy-out stream.
+static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch, int slot, const std::function<void()> &in_done, const std::function<void()> &on_device,
+                             const std::function<void()> &off_device) {
+    auto set_err = [&](int code, const char *what) { std::lock_guard<std::mutex> lk(c->err_mu); return fail(c, code, what); };
     auto fail_all = [&](int rc) { for (pna_gpu_stream *x : batch) if (x->rc == PNA_OK && !x->out) { x->rc = rc; x->out_len = 0; } };
-    if (hipSetDevice(c->device) != hipSuccess) { fail_all(fail(c, PNA_E_HIP, "hipSetDevice failed")); return; }
-    uint64_t out_cap = 64, page_bytes = 0;
-    for (pna_gpu_stream *x : batch) { out_cap += pna_gpu_bound(x->algo, x->total()) + 16; if (x->pageable) page_bytes += (x->buf.size() + 15) & ~(size_t)15; }
-    if (c->s_out[slot].ensure(out_cap) || (page_bytes && c->hp_in[0].ensure(page_bytes + 64))) { fail_all(fail(c, PNA_E_NOMEM, "staging allocation failed")); return; }
-    uint64_t out_base = 0;
-    std::vector<char> taken(batch.size(), 0);
-    for (size_t i = 0; i < batch.size(); i++) {
-        if (taken[i]) continue;
-        std::vector<pna_gpu_stream *> grp;
-        for (size_t j = i; j < batch.size(); j++)
-            if (!taken[j] && batch[j]->algo == batch[i]->algo && batch[j]->level == batch[i]->level) { taken[j] = 1; grp.push_back(batch[j]); }
-        const size_t n = grp.size();
-        std::vector<uint64_t> off(n + 1), len(n), doff(n + 1);
-        uint64_t pos = 0, bound = 0;
-        for (size_t k = 0; k < n; k++) { off[k] = pos; len[k] = grp[k]->total(); pos = (pos + len[k] + 15) & ~(uint64_t)15; bound += pna_gpu_bound(grp[k]->algo, (size_t)len[k]); }
-        off[n] = pos;
-        int rc = PNA_OK;
-        static const bool trace = getenv("PNA_STREAM_TRACE") != nullptr;     // per-batch phase times on stderr
-        const auto t0 = std::chrono::steady_clock::now();
-        if (c->stage_in.ensure(pos + 8192) || c->stage_out.ensure(bound + 64)) rc = fail(c, PNA_E_NOMEM, "staging allocation failed");
+    struct Grp { std::vector<pna_gpu_stream *> st; std::vector<uint64_t> off, len, doff; uint64_t in_base = 0, in_bytes = 0, bound = 0, out_base = 0; int rc = PNA_OK; };
+    std::vector<Grp> groups;
+    static const bool trace = getenv("PNA_STREAM_TRACE") != nullptr;         // per-batch phase times on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    // ---- stage 1: plan + copy in (the leader still holds comb_leader: one batch at a time in this stage)
+    int rc0 = PNA_OK;
+    {
+        if (hipSetDevice(c->device) != hipSuccess) rc0 = set_err(PNA_E_HIP, "hipSetDevice failed");
+        if (rc0 == PNA_OK && !c->s_h2d) {
+            if (hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) != hipSuccess) rc0 = set_err(PNA_E_HIP, "stream creation failed");
+            for (auto &e : c->s_ev) if (rc0 == PNA_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc0 = set_err(PNA_E_HIP, "event creation failed");
+        }
+        std::vector<char> taken(batch.size(), 0);
+        uint64_t in_total = 0, bound_total = 0, out_cap = 64, page_bytes = 0;
+        for (size_t i = 0; i < batch.size(); i++) {
+            if (taken[i]) continue;
+            Grp g;
+            for (size_t q = i; q < batch.size(); q++)
+                if (!taken[q] && batch[q]->algo == batch[i]->algo && batch[q]->level == batch[i]->level) { taken[q] = 1; g.st.push_back(batch[q]); }
+            const size_t n = g.st.size();
+            g.off.resize(n + 1); g.len.resize(n); g.doff.resize(n + 1);
+            uint64_t pos = 0;
+            for (size_t k = 0; k < n; k++) { g.off[k] = pos; g.len[k] = g.st[k]->total(); pos = (pos + g.len[k] + 15) & ~(uint64_t)15; g.bound += pna_gpu_bound(g.st[k]->algo, (size_t)g.len[k]) + 16; }
+            g.off[n] = pos; g.in_bytes = pos;
+            g.in_base = in_total; in_total += (pos + 8192 + 255) & ~(uint64_t)255;
+            g.out_base = bound_total; bound_total += (g.bound + 64 + 255) & ~(uint64_t)255;
+            groups.push_back(std::move(g));
+        }
+        for (pna_gpu_stream *x : batch) { out_cap += pna_gpu_bound(x->algo, x->total()) + 32; if (x->pageable) page_bytes += (x->buf.size() + 15) & ~(size_t)15; }
+        // (buffers of a slot are sized for a full batch at once: growing them batch by batch cost the first seconds of a run 10 - 20 ms of page-locking each)
+        const uint64_t capb = ((uint64_t)c->tun.stream_batch_mib << 20), cap_out = pna_gpu_bound(PNA_ALGO_DEFLATE, (size_t)capb) + (capb >> 12) + (1u << 20);
+        size_t nsl = 0;
+        for (pna_gpu_stream *x : batch) nsl += x->slabs.size() + 1;
+        if (rc0 == PNA_OK && (c->s_out[slot].ensure(std::max<uint64_t>(out_cap + 256 * groups.size(), cap_out)) || c->st_in[slot].ensure(std::max<uint64_t>(in_total + 64, capb + (1u << 20))) ||
+                              c->st_out[slot].ensure(std::max<uint64_t>(bound_total + 64, cap_out)) || c->s_segs[slot].ensure(std::max<size_t>(nsl, 4096) * 24) ||
+                              (page_bytes && c->hp_in[0].ensure(page_bytes + 64)))) rc0 = set_err(PNA_E_NOMEM, "staging allocation failed");
+        struct LinkSegH { const uint8_t *src; uint8_t *dst; uint64_t len; };
+        LinkSegH *lsg = (LinkSegH *)c->s_segs[slot].p; uint32_t nlsg = 0;
         uint64_t ppos = 0;
-        for (size_t k = 0; k < n && rc == PNA_OK; k++) {
-            pna_gpu_stream *x = grp[k];
-            uint8_t *d = (uint8_t *)c->stage_in.p + off[k];
-            if (x->pageable) {
-                if (!x->buf.empty()) {
-                    big_memcpy((uint8_t *)c->hp_in[0].p + ppos, x->buf.data(), x->buf.size());
-                    if (hipMemcpyAsync(d, (uint8_t *)c->hp_in[0].p + ppos, x->buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
-                    ppos += (x->buf.size() + 15) & ~(size_t)15;
-                }
-            } else {
-                for (size_t b = 0; b < x->slabs.size() && rc == PNA_OK; b++) {
-                    const size_t nb = std::min(S_SLAB, x->slab_len - b * S_SLAB);
-                    if (hipMemcpyAsync(d + b * S_SLAB, x->slabs[b], nb, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "H2D copy failed");
+        for (Grp &g : groups) {
+            for (size_t k = 0; k < g.st.size() && rc0 == PNA_OK; k++) {
+                pna_gpu_stream *x = g.st[k];
+                uint8_t *d = (uint8_t *)c->st_in[slot].p + g.in_base + g.off[k];
+                if (x->pageable) {
+                    if (!x->buf.empty()) {
+                        big_memcpy((uint8_t *)c->hp_in[0].p + ppos, x->buf.data(), x->buf.size());
+                        if (hipMemcpyAsync(d, (uint8_t *)c->hp_in[0].p + ppos, x->buf.size(), hipMemcpyHostToDevice, c->s_h2d) != hipSuccess) rc0 = set_err(PNA_E_HIP, "H2D copy failed");
+                        ppos += (x->buf.size() + 15) & ~(size_t)15;
+                    }
+                } else {
+                    for (size_t b = 0; b < x->slabs.size() && rc0 == PNA_OK; b++) {
+                        const size_t nb = std::min(S_SLAB, x->slab_len - b * S_SLAB);
+                        lsg[nlsg++] = LinkSegH{x->slabs[b], d + b * S_SLAB, nb};       // (the slabs are page-locked and device-mapped: one kernel reads them all)
+                    }
                 }
             }
         }
-        const auto t1 = std::chrono::steady_clock::now();
-        if (trace) (void)hipStreamSynchronize(c->stream);
-        const auto t2 = std::chrono::steady_clock::now();
-        if (rc == PNA_OK) rc = pna_gpu_compress_batch_device(c, grp[0]->algo, grp[0]->level, n, c->stage_in.p, off.data(), len.data(), c->stage_out.p, bound + 64, doff.data(), nullptr);
-        const auto t3 = std::chrono::steady_clock::now();
-        if (rc == PNA_OK && doff[n] && hipMemcpyAsync((uint8_t *)c->s_out[slot].p + out_base, c->stage_out.p, doff[n], hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
-        if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PNA_OK) rc = fail(c, PNA_E_HIP, "device batch failed");
-        if (trace) {
-            const auto t4 = std::chrono::steady_clock::now();
-            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "[pna stream batch] %zu entries, %.1f MiB in: issue H2D %.2f ms, H2D done +%.2f ms, device batch %.2f ms, D2H %.2f ms\n",
-                    n, pos / 1048576.0, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
+        if (rc0 == PNA_OK && nlsg) {
+            if (c->tun.stream_gather_wgs) { launch_link_gather(lsg, nlsg, (uint32_t)c->tun.stream_gather_wgs, c->s_h2d); if (hipGetLastError() != hipSuccess) rc0 = set_err(PNA_E_HIP, "copy-in kernel failed"); }
+            else for (uint32_t q = 0; q < nlsg && rc0 == PNA_OK; q++)
+                if (hipMemcpyAsync(lsg[q].dst, lsg[q].src, lsg[q].len, hipMemcpyHostToDevice, c->s_h2d) != hipSuccess) rc0 = set_err(PNA_E_HIP, "H2D copy failed");
         }
+        if (rc0 == PNA_OK && hipStreamSynchronize(c->s_h2d) != hipSuccess) rc0 = set_err(PNA_E_HIP, "H2D copy failed");
+    }
+    in_done();                                                           // the leader's role is free (the next batch is taken once this one is on the device)
+    if (rc0 != PNA_OK) { on_device(); off_device(); fail_all(rc0); return; }
+    const auto t1 = std::chrono::steady_clock::now();
+    // ---- stage 2: the device batch (the context's kernels and workspaces: one at a time)
+    auto t2 = t1;
+    {
+        std::lock_guard<std::mutex> run(c->run_mu);
+        on_device();                                                     // the next leader may take its batch and copy it in beside this one's kernels
+        t2 = std::chrono::steady_clock::now();
+        (void)hipSetDevice(c->device);
+        for (Grp &g : groups)
+            g.rc = pna_gpu_compress_batch_device(c, g.st[0]->algo, g.st[0]->level, g.st.size(), (uint8_t *)c->st_in[slot].p + g.in_base, g.off.data(), g.len.data(),
+                                                 (uint8_t *)c->st_out[slot].p + g.out_base, g.bound + 64, g.doff.data(), nullptr);
+        off_device();
+    }
+    const auto t3 = std::chrono::steady_clock::now();
+    // ---- stage 3: the streams travel back (the next batch's kernels are running by now)
+    uint64_t hpos = 0;
+    for (Grp &g : groups) {
+        const size_t n = g.st.size();
+        if (g.rc == PNA_OK && g.doff[n] && hipMemcpyAsync((uint8_t *)c->s_out[slot].p + hpos, (uint8_t *)c->st_out[slot].p + g.out_base, g.doff[n], hipMemcpyDeviceToHost, c->s_d2h) != hipSuccess)
+            g.rc = set_err(PNA_E_HIP, "D2H copy failed");
         for (size_t k = 0; k < n; k++) {
-            grp[k]->rc = rc;
-            grp[k]->out = (const uint8_t *)c->s_out[slot].p + out_base + (rc == PNA_OK ? doff[k] : 0);
-            grp[k]->out_len = rc == PNA_OK ? (size_t)(doff[k + 1] - doff[k]) : 0;
+            g.st[k]->out = (const uint8_t *)c->s_out[slot].p + hpos + (g.rc == PNA_OK ? g.doff[k] : 0);
+            g.st[k]->out_len = g.rc == PNA_OK ? (size_t)(g.doff[k + 1] - g.doff[k]) : 0;
         }
-        if (rc == PNA_OK) out_base += (doff[n] + 15) & ~(uint64_t)15;
+        if (g.rc == PNA_OK) hpos += (g.doff[n] + 255) & ~(uint64_t)255;
+    }
+    bool ok = hipEventRecord(c->s_ev[slot], c->s_d2h) == hipSuccess && hipEventSynchronize(c->s_ev[slot]) == hipSuccess;
+    for (Grp &g : groups) { if (!ok && g.rc == PNA_OK) g.rc = set_err(PNA_E_HIP, "device batch failed"); for (pna_gpu_stream *x : g.st) { x->rc = g.rc; if (g.rc != PNA_OK) x->out_len = 0; } }
+    if (trace) {
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        uint64_t inb = 0; for (Grp &g : groups) inb += g.in_bytes;
+        fprintf(stderr, "[pna stream batch] slot %d, %zu entries, %.1f MiB in: copy in %.2f ms, wait for the device %.2f ms, device batch %.2f ms, copy out %.2f ms\n",
+                slot, batch.size(), inb / 1048576.0, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
     }
 }
 
@@ -3120,26 +3247,48 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
     pna_gpu_ctx *c = s->ctx;
     {
         std::unique_lock<std::mutex> lk(c->comb_mu);
-        c->comb_queue.push_back(s);
+        c->comb_queue.push_back(s); s->queued = true;
+        c->gate_cv.notify_one();                                     // (the leader may be waiting for the queue to grow)
         while (!s->done) {
-            if (c->comb_leader) { c->comb_cv.wait(lk); continue; }
+            // (a stream the current leader left in the queue -- its batch was full -- waits for the leader's role like a new one)
+            if (c->comb_leader || !s->queued) { c->comb_cv.wait(lk); continue; }
             c->comb_leader = true;                                   // s is still queued, so the batch taken below contains it
-            const int slot = (int)(c->comb_seq++ & 1);
-            while (c->slot_pending[slot]) c->comb_cv.wait(lk);       // the batch before the last one is still being drained from this slot
+            const int slot = (int)(c->comb_seq++ % pna_gpu_ctx::S_SLOTS);
+            // the batch three before this one is still being drained from this slot; a batch is copied in and waits for the device; the device is busy and
+            // the queue is still small
+            for (;;) {
+                uint64_t qb = 0;
+                for (pna_gpu_stream *x : c->comb_queue) qb += x->total();
+                if (!c->slot_pending[slot] && !c->staged_waiting && (!c->device_busy || qb >= ((uint64_t)c->tun.stream_overlap_mib << 20))) break;
+                c->gate_cv.wait(lk);
+            }
             {   // a short linger lets the other writers of the pool reach their finish(): with T writers in flight the batches then hold ~T
                 // entries instead of T / 2 (two alternating cohorts) -- 16 threads: 1.5 -> 2.7 GiB/s, 4: 0.40 -> 0.73, 64: 4.8 -> 5.4.
-                // Adaptive default: 200 us (a few % of a batch's ~5 ms latency) once more than one writer has been seen, none for a lone writer
+                // Adaptive default: 200 us (a few % of a batch's latency) once more than one writer has been seen, none for a lone writer
                 const uint32_t lg = c->comb_linger_us != 0xFFFFFFFFu ? c->comb_linger_us : ((c->comb_last > 1 || c->comb_queue.size() > 1) ? 200u : 0u);
                 if (lg) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(lg)); lk.lock(); }
             }
-            std::vector<pna_gpu_stream *> batch; batch.swap(c->comb_queue);
+            // the batch: the queue's streams in arrival order up to stream_batch_mib of input -- s itself always (it may be anywhere in the queue)
+            std::vector<pna_gpu_stream *> batch, rest;
+            {
+                const uint64_t cap = (uint64_t)c->tun.stream_batch_mib << 20;
+                uint64_t bytes = s->total();
+                batch.push_back(s);
+                for (pna_gpu_stream *x : c->comb_queue) {
+                    if (x == s) continue;
+                    if (bytes + x->total() <= cap) { batch.push_back(x); bytes += x->total(); } else rest.push_back(x);
+                }
+                c->comb_queue.swap(rest);
+            }
             c->slot_pending[slot] = batch.size(); c->comb_last = batch.size();
-            for (pna_gpu_stream *x : batch) x->slot = slot;
+            for (pna_gpu_stream *x : batch) { x->slot = slot; x->queued = false; }
             lk.unlock();
-            stream_run_batch(c, batch, slot);
+            stream_run_batch(c, batch, slot, [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->comb_leader = false; c->staged_waiting++; c->comb_cv.notify_all(); },
+                             [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->staged_waiting--; c->device_busy = true; c->gate_cv.notify_one(); },
+                             [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->device_busy = false; c->gate_cv.notify_one(); });
             lk.lock();
             for (pna_gpu_stream *x : batch) x->done = true;          // owners may free their streams as soon as the lock is released
-            c->comb_leader = false; c->comb_batches++; c->comb_entries += batch.size(); c->comb_max = std::max<uint64_t>(c->comb_max, batch.size());
+            c->comb_batches++; c->comb_entries += batch.size(); c->comb_max = std::max<uint64_t>(c->comb_max, batch.size());
             c->comb_cv.notify_all();
         }
     }
@@ -3149,12 +3298,12 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
         // the reference's zstd writer drains in bursts of at most 32 KiB (zio::Writer); keep that shape
         for (size_t p = 0; p < s->out_len && rc == PNA_OK; p += 32768) {
             const size_t k = std::min<size_t>(32768, s->out_len - p);
-            if (s->sink(s->user, s->out + p, k) != 0) { std::lock_guard<std::mutex> run(c->run_mu); rc = fail(c, PNA_E_SINK, "sink failed"); }
+            if (s->sink(s->user, s->out + p, k) != 0) { std::lock_guard<std::mutex> run(c->err_mu); rc = fail(c, PNA_E_SINK, "sink failed"); }
         }
     }
     {
         std::lock_guard<std::mutex> lk(c->comb_mu);
-        if (--c->slot_pending[s->slot] == 0) c->comb_cv.notify_all();
+        if (--c->slot_pending[s->slot] == 0) c->gate_cv.notify_one();
     }
     delete s;
     return rc;

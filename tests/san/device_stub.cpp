@@ -77,6 +77,10 @@ void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, cons
     segdst[nseg] = pos; ent_off[nentry] = pos; *total = pos - out_base;
 }
 void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t, hipStream_t) { memcpy(dst, src, n); }
+void launch_link_gather(const void *segs, uint32_t nseg, uint32_t, hipStream_t) {
+    struct Seg { const uint8_t *src; uint8_t *dst; uint64_t len; };
+    for (uint32_t i = 0; i < nseg; i++) memcpy(((const Seg *)segs)[i].dst, ((const Seg *)segs)[i].src, ((const Seg *)segs)[i].len);
+}
 void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); }
 
 void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, const uint4 *, DeflTables *,
@@ -85,6 +89,10 @@ void launch_deflate_write(const uint8_t *, const SegDesc *, const uint32_t *, ui
                           uint32_t, uint8_t *, hipStream_t, bool) { nostub("deflate"); }
 void launch_frame_verify(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t, uint32_t) { nostub("frame_verify"); }
 void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, hipStream_t) { nostub("zdec"); }
+void launch_zparse_big_a(ZFrame *, ZFrameX *, const uint32_t *, uint32_t, const uint8_t *, ZBlock *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
+void launch_zparse_big_b(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, const uint32_t *, hipStream_t) { nostub("zparse"); }
+struct ZxFrame;
+int launch_zexec_par(ZxFrame *, const ZxFrame &, const ZBlock *, const uint8_t *, const uint8_t *, uint64_t *, uint32_t *, uint32_t *, uint8_t *, uint32_t *, uint32_t *, hipStream_t) { nostub("zexec_par"); return -1; }
 void launch_zxxh(ZFrame *, uint32_t, const uint8_t *, const uint8_t *, hipStream_t) { nostub("zxxh"); }
 void launch_zscan(const ZEntry *, uint32_t, const uint8_t *, ZFrame *, ZFrameX *, hipStream_t) { nostub("zscan"); }
 void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStream_t) { nostub("zcount"); }

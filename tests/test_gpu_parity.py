@@ -1550,6 +1550,47 @@ def test_one_large_foreign_zstd_frame(gpu_ctx, pna, codec):
     assert t is not None
 
 
+def test_large_frames_are_executed_in_parallel(gpu_ctx, pna, codec):
+    """k_zexec_par.hip: a large frame's sequences are executed by pointer jumping (repeat-offset codes resolved per block from a symbolic start history,
+    one word per output byte, word[p] = word[word[p]] until every word holds a byte) instead of by one wave in order.  Same bytes as the serial
+    executor (option zexec_par_min_mib = 0) for libzstd frames of several levels -- text (short matches, repeat codes in nearly every batch), long runs
+    and periodic data (copy chains thousands deep: offsets 1, 2, 7, 64 KiB), incompressible stretches (raw blocks), RLE blocks --, with a content checksum,
+    next to small frames in the same call; damage is refused or decodes differently."""
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd (the writer of the test frames) is absent")
+    import random
+    rnd = random.Random(5)
+    text = b"".join(codec.corpus_file(i % 2, 8600 + i, 1 << 20) for i in range(12))
+    runs = bytearray()
+    while len(runs) < (10 << 20):
+        k = rnd.randrange(6)
+        if k == 0: runs += bytes([rnd.randrange(256)]) * rnd.randrange(1, 300000)
+        elif k == 1: runs += bytes(rnd.randrange(256) for _ in range(rnd.randrange(2, 9))) * rnd.randrange(10, 40000)
+        elif k == 2: runs += text[rnd.randrange(len(text) - 70000):][:rnd.randrange(10, 70000)]
+        elif k == 3: runs += codec.corpus_file(2, rnd.randrange(1000), rnd.randrange(1, 200000))
+        elif k == 4: blk = bytes(runs[-65536:]); runs += blk * rnd.randrange(1, 4)
+        else: runs += bytes(300000)
+    cases = [("text-l1", text, 1), ("text-l3", text, 3), ("text-l19", text[:9 << 20], 19), ("runs-l3", bytes(runs), 3), ("runs-l1", bytes(runs), 1),
+             ("zeros", bytes(20 << 20), 3), ("mixed-l5", bytes(runs[:5 << 20]) + text[:4 << 20], 5)]
+    small = codec.corpus_file(0, 8599, 70000)
+    for name, raw, lvl in cases:
+        comp = codec.libzstd_compress(raw, lvl)
+        assert codec.zstd_frame_count(comp, len(raw) + 64) == 1, name
+        with gpu_ctx.options(zexec_par_min_mib=(0, 8)):
+            want = gpu_ctx.decompress_batch([comp], [len(raw)])
+        assert want == [raw], name
+        assert gpu_ctx.decompress_batch([comp], [len(raw)]) == [raw], name
+        assert gpu_ctx.decompress_batch([codec.libzstd_compress(small, 3), comp, comp[:]], [len(small), len(raw), len(raw)]) == [small, raw, raw], name
+    comp = codec.libzstd_compress_checksum(text, 3)
+    assert gpu_ctx.decompress_batch([comp], [len(text)]) == [text]
+    for k in range(6):
+        bad = bytearray(comp); bad[rnd.randrange(16, len(bad))] ^= 1 << rnd.randrange(8)
+        try:
+            assert gpu_ctx.decompress_batch([bytes(bad)], [len(text)]) != [text]
+        except pna.PnaGpuError:
+            pass
+
+
 def test_one_workgroup_decoder_moves_its_bases(gpu_ctx, pna, codec):
     """k_zdec counts positions in 32 bits from bases that follow the frame (frames of 4 GiB and more: test_one_foreign_zstd_frame_beyond_4gib,
     minutes at one workgroup's speed).  The option zdec_dbg = 8 moves the bases every few MiB instead of every few GiB: a 24 MiB libzstd frame (window
