@@ -18,13 +18,22 @@ python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 >
 echo small done
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
-for lv in 1 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
+for lv in 1 2 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
+python3 bench.py --algo zstd --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_zstd_4k.json" 2> "$OUT/bench_zstd_4k.err"
+for lv in 1 9; do python3 bench.py --algo deflate --files 2048 --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_deflate_level$lv.json" 2> "$OUT/bench_deflate_level$lv.err"; done
 echo levels done
-python3 scripts/stream_rate.py > "$OUT/stream_rate.txt" 2>&1
+python3 scripts/stream_rate.py 4096 > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
 python3 scripts/batch_rate.py > "$OUT/batch_rate.txt" 2>&1
 PNA_TRACE=1 python3 scripts/host_rate.py 10000 > "$OUT/host_rate.txt" 2> "$OUT/host_rate_trace.txt"
 echo seam done
+python3 scripts/zdec_one_frame_rate.py 256 > "$OUT/zdec_one_frame.txt" 2>&1
+python3 scripts/zdec_one_frame_rate.py 1024 >> "$OUT/zdec_one_frame.txt" 2>&1
+python3 scripts/decode_rate_foreign.py 2048 > "$OUT/decode_foreign_frames.txt" 2>&1
+python3 scripts/inflate_one_entry_rate.py 1024 > "$OUT/inflate_one_entry.txt" 2>&1
+echo decode done
+bash scripts/pmc_insts.sh 4096 > "$OUT/sq_counters.txt" 2>&1
+bash scripts/pmc_sq.sh 4096 >> "$OUT/sq_counters.txt" 2>&1
 bash scripts/pmc_traffic.sh 10000 > "$OUT/pmc_traffic.log" 2>&1
 cp gpurun_out/pmc/summary.json "$OUT/pmc_summary_raw.json" 2>/dev/null
 find "$OUT" -name "*kernel_stats.csv" | head

@@ -14,18 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(autouse=True)
-def _split_lz_stage_for_small_batches(monkeypatch):
-    """The suite pins the split form of the LZ stage (k_lzm + k_lzp: the library's default for every run since the parse kernel runs one wave per
-    block; the option only matters if a threshold is configured); the one-kernel form has tests of its own (test_lz_stage_forms_are_identical,
-    the latency mode's units)."""
-    if "PNA_LZ_SPLIT_MIN" not in os.environ:
-        monkeypatch.setenv("PNA_LZ_SPLIT_MIN", "0")
-    # The suite switches the LATENCY MODE off (small batches cut into small blocks and LZ units: other kernels' paths, other
-    # model parameters): the headline path is what most tests pin; tests/test_gpu_latency.py covers the mode itself and the library's default.
-    if "PNA_LATENCY_MAX_MIB" not in os.environ:
-        monkeypatch.setenv("PNA_LATENCY_MAX_MIB", "0")
-    # (pna_gpu_init reads both once: contexts are created inside the tests, after this fixture)
+def headline_context(pna, flags=None, device=0):
+    """A context PINNED to the headline form of the encoder -- 128 KiB blocks, whole segments per workgroup, i.e. the library's latency mode for small
+    batches switched off --: what most parity tests compare with the model at its default block size.  Tests OPT IN by calling this (or taking the
+    `gpu_ctx` fixture, which is such a context); a test that creates `pna.Context(0)` itself runs the library's defaults, latency mode included
+    (tests/test_gpu_latency.py, the full-size cases, the seam).  (Until round 4 an autouse fixture pinned this through the environment for every test.)"""
+    ctx = pna.Context(device) if flags is None else pna.Context(device, flags=flags)
+    ctx.set_option("latency_max_mib", 0)
+    return ctx
 
 
 @pytest.fixture(scope="session")
@@ -54,12 +50,7 @@ def pna():
 @pytest.fixture(scope="session")
 def gpu_ctx(pna):
     import torch  # noqa: F401  (shares its HIP runtime with the extension)
-    ctx = pna.Context(0)
-    # (a session fixture is set up before the function-scoped one above has touched the environment: say it here)
-    if "PNA_LZ_SPLIT_MIN" not in os.environ or os.environ["PNA_LZ_SPLIT_MIN"] == "0":
-        ctx.set_option("lz_split_min", 0)
-    if "PNA_LATENCY_MAX_MIB" not in os.environ or os.environ["PNA_LATENCY_MAX_MIB"] == "0":
-        ctx.set_option("latency_max_mib", 0)
+    ctx = headline_context(pna)
     yield ctx
     ctx.close()
 
@@ -68,10 +59,8 @@ def gpu_ctx(pna):
 def big_ctx(pna, monkeypatch):
     """A context of its own for the full-size cases: their multi-GiB workspaces (decoder scratch, staging) are released with it instead
     of staying in the session's context, and torch's cached blocks are handed back before and after.  The full-size cases run the
-    library's defaults (see _split_lz_stage_for_small_batches)."""
+    library's defaults."""
     import torch
-    monkeypatch.delenv("PNA_LZ_SPLIT_MIN", raising=False)
-    monkeypatch.delenv("PNA_LATENCY_MAX_MIB", raising=False)
     torch.cuda.empty_cache()
     ctx = pna.Context(0)
     yield ctx

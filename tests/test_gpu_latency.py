@@ -90,7 +90,6 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
     """The default context: one 1 MiB entry runs in 64 units of 16 KiB blocks, a batch of 40 MiB in coarser ones, a batch beyond the mode's
     limit in whole segments and 128 KiB blocks; the model with the reported block size reproduces each."""
     import torch  # noqa: F401
-    monkeypatch.delenv("PNA_LATENCY_MAX_MIB", raising=False)
     one = codec.corpus_file(0, 700, 1 << 20)
     with pna.Context(0) as ctx:
         (o,) = ctx.compress_batch([one])
@@ -116,7 +115,6 @@ def test_compression_writers_in_latency_mode(pna, codec, monkeypatch):
     settings: 16 writer threads, each stream must equal the model at the block size of the batch that carried it -- a batch of up to 16 MiB
     runs on 16 KiB blocks, so that is the only candidate here -- and decode."""
     import torch  # noqa: F401
-    monkeypatch.delenv("PNA_LATENCY_MAX_MIB", raising=False)
     ents = [codec.corpus_file(0, 900 + i, (1 << 20) - 1000 * (i % 5)) for i in range(32)] + [b"", b"x" * 100]
     results = [None] * len(ents)
 

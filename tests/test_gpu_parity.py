@@ -13,7 +13,7 @@ import zlib
 
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, headline_context
 
 pytestmark = pytest.mark.gpu
 
@@ -72,7 +72,7 @@ def test_serial_end_scan_is_identical(pna, codec):
     import torch  # noqa: F401
     cases = _cases(codec)
     names = sorted(cases)
-    with pna.Context(0, flags=pna.F_STD | 0x200) as ctx:
+    with headline_context(pna, flags=pna.F_STD | 0x200) as ctx:
         outs = ctx.compress_batch([cases[k] for k in names])
     p = _params(codec)
     for k, o in zip(names, outs):
@@ -99,9 +99,9 @@ def test_lz_stage_forms_are_identical(pna, codec, form, monkeypatch):
     names = sorted(cases)
     data = [cases[k] for k in names]
     bit = {"default": 0, "fused": pna.F_LZ_FUSED, "waveparse": pna.F_LZ_WAVEPARSE, "split": 0}[form]      # ("split": k_lzm + k_lzp, the suite's setting)
-    if form == "default":
-        monkeypatch.delenv("PNA_LZ_SPLIT_MIN")       # the library's own choice: the split form at every size
-    with pna.Context(0, flags=pna.F_STD | bit) as ctx:
+    with headline_context(pna, flags=pna.F_STD | bit) as ctx:
+        if form == "split":
+            ctx.set_option("lz_split_min", 0)            # (what the library chooses by itself as well: the split form at every size)
         for level in (1, 2, 3, 7, 19):              # the zstd level sets: fast, light, default, high, max (codec.product_level_flags)
             outs = ctx.compress_batch(data, level=level)
             # the form actually taken: the one-kernel form launches no match kernel, the split forms do
@@ -124,7 +124,7 @@ def test_lz_stage_split_runs(pna, codec, monkeypatch):
     monkeypatch.setenv("PNA_LZ_SPLIT_BLOCKS", "8")
     ents = [codec.corpus_file(0, 51, (3 << 20) + 4097), b"", codec.corpus_file(1, 52, 5000), codec.corpus_file(0, 53, 1 << 20), bytes(300000),
             codec.corpus_file(0, 54, 200000), codec.corpus_file(2, 55, 70000), codec.corpus_file(0, 56, (1 << 20) + 1)]
-    with pna.Context(0) as ctx:
+    with headline_context(pna) as ctx:
         outs = ctx.compress_batch(ents)
         p = _params(codec)
         for e, o in zip(ents, outs):
@@ -222,7 +222,7 @@ def test_compress_batch_in_pieces(pna, codec, monkeypatch):
     monkeypatch.setenv("PNA_BATCH_PIECE_MIB", "1")
     ents = [codec.corpus_file(0, 71, 600000), codec.corpus_file(1, 72, 500000), b"", codec.corpus_file(0, 73, (2 << 20) + 77), bytes(100), codec.corpus_file(2, 74, 900000),
             codec.corpus_file(0, 75, 300000), codec.corpus_file(0, 76, 300001), codec.corpus_file(1, 77, 300002), b"x", codec.corpus_file(0, 78, 1 << 20), codec.corpus_file(0, 79, 5000)]
-    with pna.Context(0) as ctx:
+    with headline_context(pna) as ctx:
         outs = ctx.compress_batch(ents)
         for e, o in zip(ents, outs):
             assert o == codec.model_compress(e, _params(codec))
@@ -239,7 +239,7 @@ def test_lz_stage_without_workspace_falls_back(pna, codec, monkeypatch):
     import torch  # noqa: F401
     monkeypatch.setenv("PNA_LZ_PBUF_FAIL", "1")
     ents = [codec.corpus_file(0, 61, (2 << 20) + 5), codec.corpus_file(1, 62, 70000), b"", codec.corpus_file(0, 63, 1 << 20)]
-    with pna.Context(0) as ctx:
+    with headline_context(pna) as ctx:
         for _ in range(2):
             outs = ctx.compress_batch(ents)
             for e, o in zip(ents, outs):
@@ -256,7 +256,7 @@ def test_both_sequence_coder_forms_are_identical(pna, codec, form):
     import torch  # noqa: F401
     cases = _cases(codec)
     names = sorted(cases)
-    with pna.Context(0, flags=pna.F_STD | form) as ctx:
+    with headline_context(pna, flags=pna.F_STD | form) as ctx:
         outs = ctx.compress_batch([cases[k] for k in names])
     p = _params(codec)
     for k, o in zip(names, outs):
@@ -270,7 +270,7 @@ def test_feature_subsets_bit_exact(pna, codec, flags):
     import torch  # noqa: F401
     ents = [codec.corpus_file(0, 21, 300000), codec.corpus_file(1, 22, 5000), bytes(70000), b"", codec.corpus_file(2, 1, 3000),
             codec.corpus_file(0, 23, 1 << 20)]
-    with pna.Context(0, flags=flags) as ctx:
+    with headline_context(pna, flags=flags) as ctx:
         outs = ctx.compress_batch(ents)
         outs2 = ctx.compress_batch(ents, level=2)
     # level 2 (the light set) keeps the context's bits as they are; the default level adds the third adoption round (F_STRONG) where the bits allow it
@@ -347,7 +347,7 @@ def test_compression_writers_on_many_threads_are_batched(pna, codec):
     on its own thread; the finishes were carried by fewer device batches than there are entries (group commit)."""
     import threading
     import torch  # noqa: F401
-    ctx = pna.Context(0)
+    ctx = headline_context(pna)
     try:
         sizes = [0, 1, 777, 4096, 65536, 200000, 300001, 1 << 20]
         n_threads, per = 24, 4
@@ -395,7 +395,7 @@ def test_stream_spills_to_pageable_memory(pna, codec, monkeypatch):
     pageable memory (and a second writer finds the pool empty from its first byte) -- the streams stay equal to the oracle's."""
     import torch  # noqa: F401
     monkeypatch.setenv("PNA_STREAM_POOL_MIB", "64")
-    ctx = pna.Context(0)
+    ctx = headline_context(pna)
     try:
         big = b"".join(codec.corpus_file(0, 500 + i, 1 << 20) for i in range(6)) * 11          # 66 MiB
 
@@ -1428,7 +1428,7 @@ def test_one_process_several_contexts(gpu_ctx, pna, pf, codec):
     ents = [codec.corpus_file(i % 2, 1200 + i, n) for i, n in enumerate([300000, 0, 5, (1 << 20) + 3, 70001, 2500000, 12, 1 << 20, 4096, 999999, 1, 65536])]
     names = [f"mc/{i:02d}.txt" for i in range(len(ents))]
     want = pna.create_archive(gpu_ctx, names, ents)
-    extra = [pna.Context(0) for _ in range(3)]
+    extra = [headline_context(pna) for _ in range(3)]
     try:
         for k in (2, 3, 4):
             assert pna.create_archive_multi([gpu_ctx] + extra[:k - 1], names, ents) == want, k
