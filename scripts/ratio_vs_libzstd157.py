@@ -35,9 +35,12 @@ for name, path in libs.items():
     out = [stream_compress(Z, f, 3) for f in files]
     assert codec.zstd_decompress(out[0], 1 << 20) == files[0]
     print(f"libzstd {Z.ZSTD_versionNumber()} [{name}] level 3 streaming: ratio {tot / sum(map(len, out)):.4f}, header {out[0][:6].hex()}")
-for nm, fl in (("fast (zstd 1)", 0x03), ("balanced (zstd 2)", 0x73), ("default (zstd 3)", 0x77)):
-    p = codec.params_for_flags(fl)
-    print(f"encoder model, {nm}: ratio {tot / sum(len(codec.model_compress(f, p)) for f in files):.4f}")
+    if name.startswith("1.5.7"):
+        for lv in (1, 2, 5, 7, 9):
+            print(f"    ... level {lv}: ratio {tot / sum(len(stream_compress(Z, f, lv)) for f in files):.4f}")
+for lv, nm in ((1, "fast"), (2, "light"), (3, "default"), (7, "high"), (19, "max")):
+    p = codec.params_for_level(lv)
+    print(f"encoder model, zstd {lv} ({nm}: {p.hash_log} slots{' packed' if p.tab3 else ''}, rounds {p.rounds:#x}): ratio {tot / sum(len(codec.model_compress(f, p)) for f in files):.4f}")
 import zlib
 d = [codec.deflate_model_compress(f) for f in files]
 print(f"deflate model (level 6): ratio {tot / sum(map(len, d)):.4f}; zlib {zlib.ZLIB_VERSION} level 6: {tot / sum(len(zlib.compress(f, 6)) for f in files):.4f}")
