@@ -39,16 +39,24 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def encoder_text(algo: str, level: int) -> str:
     """The level set behind the (clamped) `level` in words (pna_host.cpp level_flags / set_call_level)."""
     defl = algo == "deflate"
-    fast, balanced = (level <= 3, False) if defl else (level < 0 or level == 1, False)
-    high, gtab = (level >= 9 if defl else level >= 6), (not defl and level >= 10)
-    w32 = not defl and not fast and not balanced and not gtab
-    table = ("2^19-slot hash table per segment in global memory" if gtab else ("36800" if (w32 and high) else "32704" if w32 else "24512") + "-entry LDS hash table") \
-        + ("" if fast else " over the even positions")
+    if defl and level == 0:
+        return "GPU encoder: level 0 = Compression::none(): stored blocks only"
+    fast = level <= 3 if defl else (level < 0 or level == 1)
+    gtab = not defl and level >= 10
+    strong = level >= 9 if defl else (level >= 3 or level == 0)
+    w16 = not defl and not fast and not gtab and level >= 6
+    packed = not defl and not fast and not gtab
+    if gtab:
+        table = "2^19-slot hash table per segment in global memory over the even positions"
+    elif packed:
+        table = ("55206" if w16 else "49062") + "-slot PACKED LDS hash table (three 21-bit entries per 64-bit word) over the even positions"
+    else:
+        table = "24512-entry LDS hash table" + ("" if fast else " over the even positions")
     look = ("look-back 32 KiB (inside the 64 KiB LDS window)" if defl else
             "look-back = the LDS window (56 064 B)" if fast else
-            "look-back = the whole 1 MiB segment (LDS window %s B, beyond it candidates are verified in HBM/L2)" % ("6 912" if (w32 and high) else "23 296" if w32 else "56 064"))
-    parse = "greedy+lazy3" if fast else "greedy with backward adoption" if balanced else \
-        "greedy+lazy3 with backward adoption (3 rounds)" if high else "greedy+lazy3 with backward adoption"
+            "look-back = the whole 1 MiB segment (LDS window 56 064 B, beyond it candidates are verified in HBM/L2)" if gtab else
+            "look-back 512 KiB of the segment (LDS window %s B, beyond it candidates are verified in HBM/L2)" % ("6 912" if w16 else "23 296"))
+    parse = "greedy+lazy3" if fast else ("greedy+lazy3 with backward adoption (3 rounds, 7 back bytes)" if strong else "greedy+lazy3 with backward adoption (2 rounds)")
     return f"GPU encoder: {table}, {look}, min_match 6, {parse}, 4096-position tiles"
 
 

@@ -6,7 +6,9 @@ export TMPDIR=/tmp
 TAG=${1:-i}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+PART=${2:-all}
+if [ "$PART" = all ] || [ "$PART" = a ]; then
+python3 bench.py --steps 10 --warmup 3 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo default done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > "$OUT/kt_default.log" 2>&1
 echo trace done
@@ -22,6 +24,8 @@ for lv in 1 2 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --leve
 python3 bench.py --algo zstd --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_zstd_4k.json" 2> "$OUT/bench_zstd_4k.err"
 for lv in 1 9; do python3 bench.py --algo deflate --files 2048 --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_deflate_level$lv.json" 2> "$OUT/bench_deflate_level$lv.err"; done
 echo levels done
+fi
+if [ "$PART" = all ] || [ "$PART" = b ]; then
 python3 scripts/stream_rate.py 4096 > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
 python3 scripts/batch_rate.py > "$OUT/batch_rate.txt" 2>&1
@@ -37,3 +41,4 @@ bash scripts/pmc_sq.sh 4096 >> "$OUT/sq_counters.txt" 2>&1
 bash scripts/pmc_traffic.sh 10000 > "$OUT/pmc_traffic.log" 2>&1
 cp gpurun_out/pmc/summary.json "$OUT/pmc_summary_raw.json" 2>/dev/null
 find "$OUT" -name "*kernel_stats.csv" | head
+fi

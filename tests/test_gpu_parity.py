@@ -1324,6 +1324,41 @@ def test_append_equals_create(gpu_ctx, pna, pf, codec):
         pna.append_archive(gpu_ctx, whole[:-5], ["x"], [b"y"])
 
 
+def test_update_composed_from_listing_and_parts(gpu_ctx, pna, pf, codec):
+    """`pna update` (cli/src/command/update.rs:611-665): walk the old archive's entries -- an entry whose file did not change is copied as it stands, one
+    whose file is newer is (with --sync) dropped or (without: bsdtar's append-only -u) kept --, then the changed and the new files are compressed and
+    added behind them in argument order.  Composed here from the library's pieces, as a host would: pna_archive_list_entries for the records'
+    places, the kept records byte for byte, pna_gpu_create_archive_part_host (no head, no tail) for the compressed ones, AEND -- against the oracle's
+    writer fed with the model's streams, for both codecs and both --sync settings; the result reads back through the oracle reader and the extract
+    driver (later record of a name wins on extraction)."""
+    old_ents = [codec.corpus_file(i % 2, 9100 + i, n) for i, n in enumerate([300000, 0, 70001, (1 << 20) + 5, 12, 4096])]
+    old_names = [f"up/{i}.txt" for i in range(len(old_ents))]
+    changed = {1: codec.corpus_file(0, 9201, 50000), 3: codec.corpus_file(1, 9203, 2 << 20)}        # newer on disk than in the archive
+    added = [("up/new-a.txt", codec.corpus_file(0, 9300, 123457)), ("up/new-b.txt", b"")]
+    for algo in (pna.ALGO_ZSTD, pna.ALGO_DEFLATE):
+        base = pna.create_archive(gpu_ctx, old_names, old_ents, algo=algo)
+        recs = pna.list_entries(base)
+        assert [r[0].decode() for r in recs] == old_names and all(r[1] == 0 for r in recs)
+        assert recs[0][2] == len(pf.write_archive_header()) and recs[-1][2] + recs[-1][3] == pna.seek_to_end(base)[0]
+        new_names = [old_names[i] for i in sorted(changed)] + [n for n, _ in added]
+        new_ents = [changed[i] for i in sorted(changed)] + [d for _, d in added]
+        part = pna.create_archive_chunked(gpu_ctx, new_names, new_ents, 0, algo=algo, part=0)            # the records alone: neither header nor AEND
+        model = (lambda d: codec.model_compress(d, codec.params_for_level(3))) if algo == pna.ALGO_ZSTD else (lambda d: codec.deflate_model_compress(d))
+        want_part = b"".join(pf.write_normal_entry(pf.file_entry_header(2 if algo == pna.ALGO_ZSTD else 1, nm), [model(d)], len(d)) for nm, d in zip(new_names, new_ents))
+        assert part == want_part
+        for sync in (False, True):
+            kept = [base[o:o + ln] for k, (_, _, o, ln) in enumerate(recs) if not (sync and k in changed)]
+            got = pf.write_archive_header() + b"".join(kept) + part + pf.finalize_archive()
+            _, items = pf.read_archive(got)
+            names_out = [it.name for it in items]
+            assert names_out == [n for k, n in enumerate(old_names) if not (sync and k in changed)] + new_names
+            latest = {}
+            for n, _, d in pna.extract_archive(gpu_ctx, got):
+                latest[n] = d                                                                            # later wins
+            want_latest = dict(zip(old_names, old_ents)); want_latest.update({old_names[i]: d for i, d in changed.items()}); want_latest.update(dict(added))
+            assert latest == want_latest, (algo, sync)
+
+
 def test_device_inflate_lane_per_piece_paths(gpu_ctx, pna, codec):
     """The lane-per-piece inflate (k_imark / k_vinflate / k_vfin) and its hand-over to the wave-per-stream walk: a batch large enough for
     the lane path (>= 1 024 pieces) that mixes this library's sync-flushed streams, small foreign zlib streams (one piece each: fixed,
