@@ -74,9 +74,19 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 32 768 = 4 GiB of input, 16 GiB of workspace)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 0: every run)
  *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
- *   "win32k" [PNA_WIN32K]                 LDS geometry of the zstd match finder: 1 (default) the default level set on a 32 KiB window with 32 704 table
- *                                         slots, the high set on a 16 KiB window with 36 800; 0: both on 64 KiB / 24 512; 2: both on 16 KiB.  Other bytes
- *                                         (ratio 2.70 / 2.76 / 2.78 on text at the default level), same format
+ *   "win32k" [PNA_WIN32K]                 LDS geometry of the zstd match finder: 1 (default) the light and default level sets on a 32 KiB window, the high set on
+ *                                         a 16 KiB window; 0: both on 64 KiB; 2: both on 16 KiB.  Other bytes, same format
+ *   "tab3" [PNA_TAB3]                     the hash table of the zstd light / default / high sets: 1 (default) PACKED, three 21-bit entries (even position + 2-bit tag) per
+ *                                         64-bit LDS word -- 49 062 slots next to the 32 KiB window, 55 206 next to the 16 KiB one; 0: one 32-bit entry per slot
+ *                                         (32 704 / 36 800: round 3's table).  Other bytes (ratio 2.847 against 2.759 on text at the default level), same format
+ *   "single_frame" [PNA_SINGLE_FRAME]     zstd: 1 = an entry's payload is ONE frame (one frame header, the 1 MiB segments' blocks behind each other, matches never
+ *                                         cross a segment start) as the reference's encoder writes (lib/src/compress/zstandard.rs: one Encoder per entry);
+ *                                         0 (default) = a frame per 1 MiB segment, which this library's decoder takes in parallel.  3 + 0..2 bytes per segment apart
+ *   "zexec_par_min_mib" [PNA_ZEXEC_PAR_MIN_MIB]  decoder: single zstd frames of at least this many MiB (default 8, below 2 GiB) take the header walk +
+ *                                         wave-per-block parse + pointer-jumping execution; 0 = never
+ *   "stream_batch_mib" [PNA_STREAM_BATCH_MIB] (256), "stream_overlap_mib" [PNA_STREAM_OVERLAP_MIB] (64), "stream_gather_wgs" [PNA_STREAM_GATHER_WGS] (48): the streaming
+ *                                         facade's pipeline -- largest device batch, how much may queue before a second batch is cut while one is on the device,
+ *                                         workgroups of the copy-in kernel
  *   "lazy2" [PNA_LAZY2]                   how far a start looks ahead before it is taken, beyond the next position: 2 (default), 1, 0
  *   "strong_gtab" [PNA_STRONG_GTAB]       zstd levels 10..22 with the hash table in global memory (1, default) or in LDS (0)
  *   "lit_beside_seq" [PNA_LIT_BESIDE_SEQ] large zstd batches: the literal coder on a second stream next to the sequence coder (1, default)
@@ -92,11 +102,14 @@ size_t pna_gpu_bound(int algo, size_t src_len);
 /* Level mapping of the reference, restated so callers can pass CompressionLevel values through unchanged:
  * lib/src/compress/zstandard.rs:43-57 (Default -> 3, clamp to min..max) and lib/src/compress/deflate.rs:89-101
  * (Default -> 6, clamp 0..9).  `level` < 0 with level == PNA_LEVEL_DEFAULT means default. */
-/* The encoder has these parameter sets behind that scale: stored (deflate 0 = Compression::none(): stored blocks only), fast (zstd < 0 and 1, deflate 1..3: every position in the table, lazy deferral,
- * look-back = the LDS window), default
- * (zstd 0 and 2..5, deflate 4..8: + even-position table, backward adoption, 1 MiB look-back (zstd), lazy deferral over three positions; zstd: a third more table slots next to a 32 KiB window), high (zstd 6..9,
- * deflate 9: + a third adoption round and two-step lazy deferral) and, zstd only, max (10..22: + the hash table in global memory, 2^19
- * slots per segment); DESIGN.md section 4. */
+/* The encoder has these parameter sets behind that scale ("Level sets"):
+ *   stored   deflate 0 = Compression::none(): stored blocks only (zlib header 78 01)
+ *   fast     zstd < 0 and 1, deflate 1..3: every position in the table, lazy deferral, look-back = the LDS window
+ *   light    zstd 2: even-position PACKED table next to a 32 KiB window, backward adoption (two rounds), 1 MiB look-back, lazy deferral over three positions
+ *   default  zstd 0 and 3..5: light + a third adoption round (up to 7 positions back) and two-step lazy deferral;  deflate 4..8: even-position table,
+ *            adoption, lazy deferral over three positions
+ *   high     zstd 6..9: default on a 16 KiB window with 55 206 slots;  deflate 9: + the third adoption round and two-step lazy deferral
+ *   max      zstd 10..22: + the hash table in global memory, 2^19 slots per segment */
 #define PNA_LEVEL_DEFAULT  (-1000)
 int  pna_gpu_clamp_level(int algo, int level);
 
