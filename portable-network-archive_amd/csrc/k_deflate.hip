@@ -39,57 +39,72 @@ __device__ __forceinline__ void dw_add(DBitW &w, uint32_t v, uint32_t n) {
     while (w.nb >= 8) { w.p[w.pos++] = (uint8_t)w.acc; w.acc >>= 8; w.nb -= 8; }
 }
 
-// code lengths <= maxlen (two-queue Huffman + Kraft repair; identical procedure to the zstd literal code), executed by the
-// whole workgroup: stable rank sort by count and the leaf depths are parallel, the two-queue merge (n - 1 dependent steps)
-// and the rare Kraft repair stay on thread 0.  Every thread of the workgroup must call it; returns the number of used symbols.
+// Code construction of one segment on T threads: T = 256, a workgroup per segment, or T = 64, ONE WAVE per segment -- the form for batches of many small
+// entries, where four waves per entry spent most of their instructions and three quarters of their time in barriers next to the one-lane sections
+// (10^6 x 4 KiB: 14.8 ms of a 56 ms step).  Same procedure, same picks, same bytes for either T.
+//
+// code lengths <= maxlen (two-queue Huffman + Kraft repair; identical procedure to the zstd literal code): the stable rank sort by count and the leaf
+// depths are parallel, the two-queue merge (n - 1 dependent steps) and the rare Kraft repair stay on thread 0.  Every thread must call it; returns the
+// number of used symbols.  wt: [580] words, 16-byte aligned -- the sort keys of the symbols live in its upper part (wt + 288: nsym + 4 words) until
+// the sorted weights are in its lower part; the merge then overwrites them with the inner nodes.
+__device__ __forceinline__ uint32_t d_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <uint32_t T>
 __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t *lens, uint16_t *order, uint32_t *wt, uint16_t *parent,
-                            uint32_t *sh /* [2] scratch */, uint16_t *used /* [nsym]: the symbols that occur, in no particular order */,
-                            uint32_t tid, uint32_t nthr) {
+                            uint32_t *sh /* [2] scratch */, uint32_t tid) {
+    uint32_t *keys = wt + 288;
     if (tid == 0) { sh[0] = 0; sh[1] = 0; }
+    for (int s = (int)tid; s < nsym + 4; s += (int)T) keys[s] = 0xFFFFFFFFu;
     __syncthreads();
-    // the symbols that occur (a 4 KiB entry uses ~70 of the 286): the rank sort below and the code assignment only walk these
-    for (int s = (int)tid; s < nsym; s += (int)nthr) {
+    // the symbols that occur (a 4 KiB entry uses ~70 of the 286), as keys count << 9 | symbol in no particular order: a symbol's place in the order
+    // by (count, symbol) is the number of smaller keys (counts are < 2^21: a segment has at most 2^20 literals)
+    for (int s = (int)tid; s < nsym; s += (int)T) {
         lens[s] = 0;
-        if (count[s]) used[atomicAdd(&sh[0], 1u)] = (uint16_t)s;
+        const uint32_t c = count[s];
+        if (c) keys[atomicAdd(&sh[0], 1u)] = (c << 9) | (uint32_t)s;
     }
     __syncthreads();
     const int n = (int)sh[0];
-    for (int k = (int)tid; k < n; k += (int)nthr) {
-        const int s = used[k];
-        const uint32_t c = count[s];
+    for (int k = (int)tid; k < n; k += (int)T) {
+        const uint32_t key = keys[k];
         uint32_t rank = 0;
-        for (int j = 0; j < n; j++) { const int o = used[j]; const uint32_t co = count[o]; rank += (co < c || (co == c && o < s)) ? 1u : 0u; }
-        order[rank] = (uint16_t)s;
+        for (int j = 0; j < n; j += 4) {                                  // the list is padded with 0xFFFFFFFF
+            const uint4 v = *(const uint4 *)(keys + j);
+            rank += (v.x < key ? 1u : 0u) + (v.y < key ? 1u : 0u) + (v.z < key ? 1u : 0u) + (v.w < key ? 1u : 0u);
+        }
+        order[rank] = (uint16_t)(key & 511u); wt[rank] = key >> 9;
     }
     __syncthreads();
     if (n == 0) return 0;
     if (n == 1) { if (tid == 0) lens[order[0]] = 1; __syncthreads(); return 1; }
-    for (int i = (int)tid; i < n; i += (int)nthr) wt[i] = count[order[i]];
-    __syncthreads();
     const int nn = 2 * n - 1;
-    if (tid == 0) {
-        // two-queue merge, n - 1 dependent steps on one lane.  The two heads of each queue are kept in registers (the leaf queue is read
-        // one element ahead, a new internal node enters the head registers directly when the queue is that short), so no step waits for
-        // an LDS round trip; weights are < 2^31, INF marks an exhausted / not yet filled head.  Same picks, same order as
-        // `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
+    if (tid < 64) {
+        // two-queue merge, n - 1 dependent steps, executed by the first wave IN SCALAR REGISTERS: every value of the loop is wave-uniform (what comes
+        // from LDS through readfirstlane), so compares, selects and counters are SALU work and only the LDS traffic -- the queues' next elements, the
+        // new node's weight, two parent links -- goes through the vector unit.  Both queues keep two heads in scalar registers and a third element in
+        // flight in a vector register (requested when the one before it moved up, read a take later), so no step waits for an LDS round trip; a new
+        // node enters whichever of the three places of the internal queue it belongs to directly.  Weights are < 2^31, INF marks an exhausted / not
+        // yet filled place.  Same picks, same order as `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
         constexpr uint32_t INF = 0xFFFFFFFFu;
         int lq = 0, iq = n, m = n;
-        uint32_t l0 = wt[0], l1 = n > 1 ? wt[1] : INF, i0 = INF, i1 = INF;
+        uint32_t l0 = d_rfl(wt[0]), l1 = d_rfl(wt[1]), i0 = INF, i1 = INF;
+        uint32_t l2v = n > 2 ? wt[2] : INF, i2v = INF;
         auto take = [&](uint32_t &w) -> int {
-            if (l0 != INF && l0 <= i0) { w = l0; const int a = lq++; l0 = l1; l1 = (lq + 1 < n) ? wt[lq + 1] : INF; return a; }
-            w = i0; const int a = iq++; i0 = i1; i1 = (iq + 1 < m) ? wt[iq + 1] : INF; return a;
+            if (l0 != INF && l0 <= i0) {
+                w = l0; const int a = lq++; l0 = l1; l1 = d_rfl(l2v); l2v = (lq + 2 < n) ? wt[lq + 2] : INF; return a;
+            }
+            w = i0; const int a = iq++; i0 = i1; i1 = d_rfl(i2v); i2v = (iq + 2 < m) ? wt[iq + 2] : INF; return a;
         };
         while (m < nn) {
             uint32_t wa, wb;
             const int a = take(wa), b = take(wb);
             const uint32_t sum = wa + wb;
-            wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m;
-            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum;      // the new node is (or follows) the head of the internal queue
+            if (tid == 0) { wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; }
+            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum; else if (iq + 2 == m) i2v = sum;   // the new node's place among the three heads
             m++;
         }
     }
     __syncthreads();
-    for (int i = (int)tid; i < n; i += (int)nthr) {
+    for (int i = (int)tid; i < n; i += (int)T) {
         int d = 0, q = i;
         while (q != nn - 1) { q = parent[q]; d++; }
         if (d > maxlen) { d = maxlen; sh[1] = 1; }
@@ -115,28 +130,40 @@ __device__ int d_build_lens(const uint32_t *count, int nsym, int maxlen, uint8_t
     __syncthreads();
     return n;
 }
-// canonical codes, bit-reversed; out[s] = code | len << 16.  Workgroup-wide (256 threads, symbol s on thread s mod 256 of round s / 256):
+// canonical codes, bit-reversed; out[s] = code | len << 16 (out may be global memory).  Symbol s sits on thread s mod T of round s / T:
 // code of s = first code of its length + number of lower-numbered symbols of the same length.  That rank comes from one ballot per code
-// length -- lanes below in the wave, plus the counts of the earlier waves / rounds from LDS -- instead of every symbol looping over all
-// others.  cntw: 9 x 16 words of scratch.
+// length THAT OCCURS in the wave's 64 symbols -- lanes below in the wave, plus the counts of the earlier waves / rounds from LDS -- instead of every
+// symbol looping over all others.  cntw: 9 x 16 words of scratch (a slot of 16 per wave and round: at most 8).
+template <uint32_t T>
 __device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t *first /* [16] scratch */, uint32_t *cntw, uint32_t tid) {
+    constexpr uint32_t NW = T / 64, MAXR = (288 + T - 1) / T;
+    static_assert(NW * MAXR <= 8, "cntw holds eight slots");
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
-    uint32_t myl[2], myrank[2];
+    const uint32_t nr = ((uint32_t)nsym + T - 1) / T, nslot = nr * NW;
+    for (uint32_t i = tid; i < nslot * 16; i += T) cntw[i] = 0;
+    __syncthreads();
+    uint32_t myl[MAXR], myrank[MAXR];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int sy = r * 256 + (int)tid;
-        const uint32_t l = sy < nsym ? (uint32_t)lens[sy] : 0u;
-        myl[r] = l; uint32_t rk = 0;
-        for (uint32_t L = 1; L <= 15; L++) {
-            const uint64_t m = __ballot(l == L);
-            if (l == L) rk = (uint32_t)__popcll(m & lt);
-            if (lane == 0) cntw[(r * 4 + wv) * 16 + L] = (uint32_t)__popcll(m);
+    for (uint32_t r = 0; r < MAXR; r++) {
+        myl[r] = 0; myrank[r] = 0;
+        if (r < nr) {
+            const int sy = (int)(r * T + tid);
+            const uint32_t l = sy < nsym ? (uint32_t)lens[sy] : 0u;
+            uint32_t rk = 0;
+            uint64_t rem = __ballot(l != 0);
+            while (rem) {
+                const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)l, (int)__builtin_ctzll(rem));
+                const uint64_t m = __ballot(l == L);
+                if (l == L) rk = (uint32_t)__popcll(m & lt);
+                if (lane == 0) cntw[(r * NW + wv) * 16 + L] = (uint32_t)__popcll(m);
+                rem &= ~m;
+            }
+            myl[r] = l; myrank[r] = rk;
         }
-        myrank[r] = rk;
     }
     __syncthreads();
-    if (tid >= 1 && tid < 16) { uint32_t c = 0; for (int k = 0; k < 8; k++) c += cntw[k * 16 + tid]; cntw[8 * 16 + tid] = c; }   // symbols per length
+    if (tid >= 1 && tid < 16) { uint32_t c = 0; for (uint32_t k = 0; k < nslot; k++) c += cntw[k * 16 + tid]; cntw[8 * 16 + tid] = c; }   // symbols per length
     __syncthreads();
     if (tid == 0) {
         uint32_t code = 0; first[0] = 0;
@@ -144,14 +171,14 @@ __device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t 
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int sy = r * 256 + (int)tid;
-        if (sy < nsym) {
+    for (uint32_t r = 0; r < MAXR; r++) {
+        const int sy = (int)(r * T + tid);
+        if (r < nr && sy < nsym) {
             const uint32_t l = myl[r];
             uint32_t v = 0;
             if (l) {
                 uint32_t c = first[l] + myrank[r];
-                for (uint32_t k = 0; k < (uint32_t)r * 4 + wv; k++) c += cntw[k * 16 + l];
+                for (uint32_t k = 0; k < r * NW + wv; k++) c += cntw[k * 16 + l];
                 v = (__builtin_bitreverse32(c) >> (32 - l)) | (l << 16);
             }
             out[sy] = v;
@@ -160,34 +187,41 @@ __device__ void d_assign(const uint8_t *lens, int nsym, uint32_t *out, uint32_t 
     __syncthreads();
 }
 
-constexpr uint32_t DS_THREADS = 256;
-__global__ __launch_bounds__(DS_THREADS)
+template <uint32_t T>
+__global__ __launch_bounds__(T)
 void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
               const BlkInfo *__restrict__ blk, DeflTables *__restrict__ tabs) {
-    __shared__ uint32_t h_lit[8][256];
-    __shared__ uint32_t h_len[4][32], h_dist[4][32];
-    __shared__ uint32_t llc[288], dc[32], clc[19];
-    __shared__ uint16_t order[288]; __shared__ uint32_t wt[576]; __shared__ uint16_t parent[576];
-    __shared__ uint8_t ll_len[288], d_len[32], cl_len[19], seq[320], sym[320], ext[320];
-    __shared__ uint32_t cl_code[19];
-    __shared__ uint32_t ll_code_s[288], d_code_s[32], first_s[16], sh2[2], hsh[3];
-    __shared__ uint16_t used_ll[288], used_d[32], used_cl[20];
-    __shared__ uint32_t hbuf[104], wsum[8], wsum2[8], cntw_s[9 * 16];
-    static_assert(DS_THREADS == 256, "d_assign lays 2 x 256 symbols over the workgroup");
+    constexpr uint32_t NW = T / 64, HL = T == 256 ? 8 : 2;              // waves; copies of the literal histogram (32 lanes share one)
+    constexpr uint32_t RND = (320 + T - 1) / T, NSLOT = RND * NW;       // rounds of T over the <= 316 code lengths of the table description
+    // LDS by phase (the wave-per-segment form lives on occupancy: 6.7 KiB instead of 13): region 1 holds the histograms, then the scratch of the code
+    // builds (sorted weights + inner nodes + sort keys, parent links, symbol order); region 2 the symbol counts, then the table description's arrays
+    constexpr uint32_t HC = T == 256 ? 4 : 1;                           // copies of the length / distance histograms
+    constexpr uint32_t A_BYTES = HL * 1024 + 2 * HC * 128, C_BYTES = 580 * 4 + 576 * 2 + 288 * 2;
+    __shared__ __attribute__((aligned(16))) uint8_t r1[A_BYTES > C_BYTES ? A_BYTES : C_BYTES];
+    __shared__ __attribute__((aligned(16))) uint32_t r2[344];
+    uint32_t (*h_lit)[256] = (uint32_t (*)[256])r1;
+    uint32_t *h_len = (uint32_t *)(r1 + HL * 1024), *h_dist = h_len + HC * 32;
+    uint32_t *wt = (uint32_t *)r1; uint16_t *parent = (uint16_t *)(r1 + 580 * 4), *order = parent + 576;
+    uint32_t *llc = r2, *dc = r2 + 288;
+    uint8_t *seq = (uint8_t *)r2, *sym = seq + 320, *ext = sym + 320; uint32_t *hbuf = r2 + 240;
+    __shared__ uint8_t ll_len[288], d_len[32], cl_len[20];
+    __shared__ uint32_t clc[19], cl_code[19];
+    __shared__ uint32_t first_s[16], sh2[2], hsh[3];
+    __shared__ uint32_t wsum[8], wsum2[8], cntw_s[9 * 16];
     const uint32_t tid = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
-    DeflTables *T = tabs + blockIdx.x;
+    DeflTables *T_ = tabs + blockIdx.x;
     const uint32_t nblk = seg_nblk(sd);
-    for (uint32_t i = tid; i < 8 * 256; i += DS_THREADS) (&h_lit[0][0])[i] = 0;
-    if (tid < 128) { (&h_len[0][0])[tid] = 0; (&h_dist[0][0])[tid] = 0; }
+    for (uint32_t i = tid; i < HL * 256; i += T) (&h_lit[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 2 * HC * 32; i += T) h_len[i] = 0;       // both histograms, all copies
     __syncthreads();
     for (uint32_t b = 0; b < nblk; b++) {
         const uint32_t g = sd.blk_base + b;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
-        uint32_t *hl = h_lit[tid & 7];
+        uint32_t *hl = h_lit[tid & (HL - 1)];
         const uint32_t n16 = nlit >> 4;
-        for (uint32_t i = tid; i < n16; i += DS_THREADS) {
+        for (uint32_t i = tid; i < n16; i += T) {
             uint4 v = ((const uint4 *)bl)[i];
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -196,75 +230,77 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
                 atomicAdd(&hl[(w[k] >> 16) & 0xFF], 1u); atomicAdd(&hl[w[k] >> 24], 1u);
             }
         }
-        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += DS_THREADS) atomicAdd(&hl[bl[i]], 1u);
+        for (uint32_t i = (n16 << 4) + tid; i < nlit; i += T) atomicAdd(&hl[bl[i]], 1u);
         const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
-        for (uint32_t i = tid; i < nseq; i += DS_THREADS) {
+        for (uint32_t i = tid; i < nseq; i += T) {
             const uint64_t s = bs[i];
             uint32_t c, eb, ev;
-            len_sym(seq_ml(s), c, eb, ev); atomicAdd(&h_len[tid & 3][c], 1u);
-            dist_sym(seq_off(s), c, eb, ev); atomicAdd(&h_dist[tid & 3][c], 1u);
+            len_sym(seq_ml(s), c, eb, ev); atomicAdd(&h_len[(tid & (HC - 1)) * 32 + c], 1u);
+            dist_sym(seq_off(s), c, eb, ev); atomicAdd(&h_dist[(tid & (HC - 1)) * 32 + c], 1u);
         }
     }
     __syncthreads();
-    { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; llc[tid] = c; }
+    for (uint32_t i = tid; i < 256; i += T) { uint32_t c = 0; for (uint32_t k = 0; k < HL; k++) c += h_lit[k][i]; llc[i] = c; }
     if (tid < 32) {
-        llc[256 + tid] = tid == 0 ? nblk : (tid <= 29 ? h_len[0][tid - 1] + h_len[1][tid - 1] + h_len[2][tid - 1] + h_len[3][tid - 1] : 0u);
-        dc[tid] = tid < 30 ? h_dist[0][tid] + h_dist[1][tid] + h_dist[2][tid] + h_dist[3][tid] : 0u;
+        uint32_t cl = 0, cd = 0;
+        for (uint32_t k = 0; k < HC; k++) { cl += tid >= 1 && tid <= 29 ? h_len[k * 32 + tid - 1] : 0u; cd += tid < 30 ? h_dist[k * 32 + tid] : 0u; }
+        llc[256 + tid] = tid == 0 ? nblk : cl;
+        dc[tid] = cd;
     }
     __syncthreads();
-    (void)d_build_lens(llc, 286, 15, ll_len, order, wt, parent, sh2, used_ll, tid, DS_THREADS);
-    (void)d_build_lens(dc, 30, 15, d_len, order, wt, parent, sh2, used_d, tid, DS_THREADS);
-    d_assign(ll_len, 286, ll_code_s, first_s, cntw_s, tid);
-    d_assign(d_len, 30, d_code_s, first_s, cntw_s, tid);
-    for (uint32_t i = tid; i < 288; i += DS_THREADS) T->ll_code[i] = i < 286 ? ll_code_s[i] : 0u;
-    if (tid < 32) T->d_code[tid] = tid < 30 ? d_code_s[tid] : 0u;
-    // table description: run-length tokens of the code lengths, their 19-symbol code, the header bits -- all of it on the whole
-    // workgroup (for 4 KiB entries this used to be one lane walking ~300 lengths and ~150 tokens: the largest per-entry cost)
+    (void)d_build_lens<T>(llc, 286, 15, ll_len, order, wt, parent, sh2, tid);
+    (void)d_build_lens<T>(dc, 30, 15, d_len, order, wt, parent, sh2, tid);
+    d_assign<T>(ll_len, 286, T_->ll_code, first_s, cntw_s, tid);       // straight to the tables in global memory
+    d_assign<T>(d_len, 30, T_->d_code, first_s, cntw_s, tid);
+    if (tid < 2) { T_->ll_code[286 + tid] = 0; T_->d_code[30 + tid] = 0; }
+    // table description: run-length tokens of the code lengths, their 19-symbol code, the header bits -- all of it on all threads
+    // (for 4 KiB entries this used to be one lane walking ~300 lengths and ~150 tokens: the largest per-entry cost)
     const uint32_t lane = tid & 63, wv = tid >> 6;
     if (tid == 0) { hsh[0] = 257; hsh[1] = 1; }
     if (tid < 19) clc[tid] = 0;
-    for (uint32_t i = tid; i < 104; i += DS_THREADS) hbuf[i] = 0;
+    for (uint32_t i = tid; i < 104; i += T) hbuf[i] = 0;
     __syncthreads();
-    for (uint32_t s2 = 257 + tid; s2 < 286; s2 += DS_THREADS) if (ll_len[s2]) atomicMax(&hsh[0], s2 + 1);
+    for (uint32_t s2 = 257 + tid; s2 < 286; s2 += T) if (ll_len[s2]) atomicMax(&hsh[0], s2 + 1);
     if (tid >= 1 && tid < 30 && d_len[tid]) atomicMax(&hsh[1], tid + 1);
     __syncthreads();
     const uint32_t nll = hsh[0], nd = hsh[1], n = nll + nd;
-    for (uint32_t i = tid; i < n; i += DS_THREADS) seq[i] = i < nll ? ll_len[i] : d_len[i - nll];
+    for (uint32_t i = tid; i < n; i += T) seq[i] = i < nll ? ll_len[i] : d_len[i - nll];
     __syncthreads();
     // token starts: a non-zero length is its own token; a run of R zeros is R / 138 tokens "18 x 138", then one "18" (rest >= 11), one
     // "17" (rest >= 3) or the rest as literal zeros -- what the greedy left-to-right scan produces
-    uint32_t tsym[2] = {0, 0}, text[2] = {0, 0}, tidx[2] = {0, 0}; bool tst[2] = {false, false};
+    uint32_t tsym[RND], text[RND], tidx[RND]; bool tst[RND];
     // the zero runs' ends come from ballots instead of walks along the run (a 4 KiB entry leaves runs of a hundred zeros and more, and every
     // lane of a run walked all of it): per (round, wave) the first / last position that is non-zero -- or beyond n, which ends a run too
     __shared__ int16_t nz_first[8], nz_last[8];
-    uint32_t vv[2]; uint64_t nzm[2];
+    uint32_t vv[RND]; uint64_t nzm[RND];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; c2++) {
-        const uint32_t i = (uint32_t)c2 * DS_THREADS + tid;
+    for (uint32_t c2 = 0; c2 < RND; c2++) {
+        const uint32_t i = c2 * T + tid;
+        tsym[c2] = 0; text[c2] = 0; tidx[c2] = 0; tst[c2] = false;
         vv[c2] = i < n ? (uint32_t)seq[i] : 1u;
         nzm[c2] = __ballot(vv[c2] != 0);
         if (lane == 0) {
-            const int base = c2 * (int)DS_THREADS + (int)wv * 64;
-            nz_first[c2 * 4 + wv] = nzm[c2] ? (int16_t)(base + __builtin_ctzll(nzm[c2])) : (int16_t)-1;
-            nz_last[c2 * 4 + wv] = nzm[c2] ? (int16_t)(base + 63 - __builtin_clzll(nzm[c2])) : (int16_t)-1;
+            const int base = (int)(c2 * T + wv * 64);
+            nz_first[c2 * NW + wv] = nzm[c2] ? (int16_t)(base + __builtin_ctzll(nzm[c2])) : (int16_t)-1;
+            nz_last[c2 * NW + wv] = nzm[c2] ? (int16_t)(base + 63 - __builtin_clzll(nzm[c2])) : (int16_t)-1;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int c2 = 0; c2 < 2; c2++) {
-        const uint32_t i = (uint32_t)c2 * DS_THREADS + tid;
+    for (uint32_t c2 = 0; c2 < RND; c2++) {
+        const uint32_t i = c2 * T + tid;
         if (i < n) {
             const uint32_t v = vv[c2];
             if (v) { tst[c2] = true; tsym[c2] = v; }
             else {
-                const int slot = c2 * 4 + (int)wv, base = c2 * (int)DS_THREADS + (int)wv * 64;
+                const int slot = (int)(c2 * NW + wv), base = (int)(c2 * T + wv * 64);
                 const uint64_t lt = ((uint64_t)1 << lane) - 1;
                 const uint64_t below = nzm[c2] & lt, above = nzm[c2] & ~(lt | ((uint64_t)1 << lane));
                 int pb = -1, pa = (int)n;                                  // nearest run-ending position below / above (position n always ends a run)
                 if (below) pb = base + 63 - __builtin_clzll(below);
                 else for (int s2 = slot - 1; s2 >= 0; s2--) if (nz_last[s2] >= 0) { pb = nz_last[s2]; break; }
                 if (above) pa = base + __builtin_ctzll(above);
-                else for (int s2 = slot + 1; s2 < 8; s2++) if (nz_first[s2] >= 0) { pa = nz_first[s2]; break; }
+                else for (int s2 = slot + 1; s2 < (int)NSLOT; s2++) if (nz_first[s2] >= 0) { pa = nz_first[s2]; break; }
                 const uint32_t a = (uint32_t)(pb + 1), e = (uint32_t)(pa - 1);
                 const uint32_t R = e - a + 1, o = i - a, q = R / 138, rem = R - q * 138;
                 if (o < q * 138) { tst[c2] = (o % 138) == 0; tsym[c2] = 18; text[c2] = 138 - 11; }
@@ -275,40 +311,41 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
         }
         const uint64_t m = __ballot(tst[c2]);
         tidx[c2] = (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1));
-        if (lane == 0) wsum[c2 * 4 + wv] = (uint32_t)__popcll(m);
+        if (lane == 0) wsum[c2 * NW + wv] = (uint32_t)__popcll(m);
     }
     __syncthreads();
     uint32_t ns = 0;
-    for (int k = 0; k < 8; k++) ns += wsum[k];
+    for (uint32_t k = 0; k < NSLOT; k++) ns += wsum[k];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; c2++)
+    for (uint32_t c2 = 0; c2 < RND; c2++)
         if (tst[c2]) {
             uint32_t base = 0;
-            for (uint32_t k = 0; k < (uint32_t)c2 * 4 + wv; k++) base += wsum[k];
+            for (uint32_t k = 0; k < c2 * NW + wv; k++) base += wsum[k];
             sym[base + tidx[c2]] = (uint8_t)tsym[c2]; ext[base + tidx[c2]] = (uint8_t)text[c2];
             atomicAdd(&clc[tsym[c2]], 1u);
         }
     __syncthreads();
-    int n_cl = d_build_lens(clc, 19, 7, cl_len, order, wt, parent, sh2, used_cl, tid, DS_THREADS);
+    int n_cl = d_build_lens<T>(clc, 19, 7, cl_len, order, wt, parent, sh2, tid);
     if (n_cl == 1) {
-        if (tid == 0) for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; used_cl[1] = (uint16_t)k; break; }
+        if (tid == 0) for (int k = 0; k < 19; k++) if (!cl_len[k]) { cl_len[k] = 1; break; }
         n_cl = 2;
         __syncthreads();
     }
-    d_assign(cl_len, 19, cl_code, first_s, cntw_s, tid);
+    d_assign<T>(cl_len, 19, cl_code, first_s, cntw_s, tid);
     int ncl = 19; while (ncl > 4 && cl_len[D_CL_ORDER[ncl - 1]] == 0) ncl--;
-    // bit lengths of the tokens -> positions (two packed scans of 256) -> ORed into the header image in LDS
+    // bit lengths of the tokens -> positions (packed scans over the waves) -> ORed into the header image in LDS
     auto put_bits = [&](uint32_t pos, uint32_t v, uint32_t nb2) {       // nb2 <= 14: at most two words
         if (!nb2) return;
         const uint32_t w2 = pos >> 5, sh = pos & 31;
         atomicOr(&hbuf[w2], v << sh);
         if (sh + nb2 > 32) atomicOr(&hbuf[w2 + 1], v >> (32 - sh));
     };
-    uint32_t tl[2] = {0, 0}, tv[2] = {0, 0}, tp[2] = {0, 0};
+    uint32_t tl[RND], tv[RND], tp[RND];
     __syncthreads();
 #pragma unroll
-    for (int c2 = 0; c2 < 2; c2++) {
-        const uint32_t k = (uint32_t)c2 * DS_THREADS + tid;
+    for (uint32_t c2 = 0; c2 < RND; c2++) {
+        const uint32_t k = c2 * T + tid;
+        tl[c2] = 0; tv[c2] = 0;
         if (k < ns) {
             const uint32_t sy = sym[k], cc = cl_code[sy], cl = cc >> 16, eb = sy == 17 ? 3u : (sy == 18 ? 7u : 0u);
             tl[c2] = cl + eb; tv[c2] = (cc & 0xFFFF) | ((uint32_t)ext[k] << cl);
@@ -317,23 +354,23 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)lane >= d) x += y; }
         tp[c2] = x - tl[c2];
-        if (lane == 63) wsum2[c2 * 4 + wv] = x;
+        if (lane == 63) wsum2[c2 * NW + wv] = x;
     }
     __syncthreads();
     const uint32_t hbits = 14 + 3 * (uint32_t)ncl;
     uint32_t total = hbits;
-    for (int k = 0; k < 8; k++) total += wsum2[k];
+    for (uint32_t k = 0; k < NSLOT; k++) total += wsum2[k];
 #pragma unroll
-    for (int c2 = 0; c2 < 2; c2++)
+    for (uint32_t c2 = 0; c2 < RND; c2++)
         if (tl[c2]) {
             uint32_t base = hbits;
-            for (uint32_t k = 0; k < (uint32_t)c2 * 4 + wv; k++) base += wsum2[k];
+            for (uint32_t k = 0; k < c2 * NW + wv; k++) base += wsum2[k];
             put_bits(base + tp[c2], tv[c2], tl[c2]);
         }
-    if (tid == 0) { put_bits(0, nll - 257, 5); put_bits(5, nd - 1, 5); put_bits(10, (uint32_t)(ncl - 4), 4); T->hdr_bits = total; }
+    if (tid == 0) { put_bits(0, nll - 257, 5); put_bits(5, nd - 1, 5); put_bits(10, (uint32_t)(ncl - 4), 4); T_->hdr_bits = total; }
     if (tid < (uint32_t)ncl) put_bits(14 + 3 * tid, cl_len[D_CL_ORDER[tid]], 3);
     __syncthreads();
-    for (uint32_t i = tid; i < 100; i += DS_THREADS) ((uint32_t *)T->hdr)[i] = hbuf[i];
+    for (uint32_t i = tid; i < 100; i += T) ((uint32_t *)T_->hdr)[i] = hbuf[i];
 }
 
 // ------------------------------------------------------------------ Adler-32 halves of one block's input
@@ -642,8 +679,11 @@ void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_
 
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only) {
-    if (!stored_only) hipLaunchKernelGGL(k_dstats, dim3(nseg), dim3(DS_THREADS), 0, st, segs, seqs, lits, blk, tabs);
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only, bool wave_per_seg) {
+    if (!stored_only) {
+        if (wave_per_seg) hipLaunchKernelGGL(k_dstats<64>, dim3(nseg), dim3(64), 0, st, segs, seqs, lits, blk, tabs);
+        else hipLaunchKernelGGL(k_dstats<256>, dim3(nseg), dim3(256), 0, st, segs, seqs, lits, blk, tabs);
+    }
     if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (ev) (void)hipEventRecord(ev[1], st);

@@ -30,7 +30,7 @@ void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t 
 uint32_t lz_gtab_log();
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
-                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only);
+                           uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only, bool wave_per_seg);
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
                           uint8_t *dst, hipStream_t st, bool stored_only);
@@ -279,15 +279,33 @@ inline size_t plan_blocks(const pna_gpu_ctx *c, uint64_t len) {
 // Block size of a batch whose entries are all small: the per-block arrays have the block size as their stride, so a batch of 4 KiB entries on 128 KiB
 // blocks would spend 32 times the memory (and a sub-batch per 131 072 entries) that 8 KiB blocks need.  Entries of up to 64 KiB: the power of two that
 // holds the largest (>= 8 KiB); anything larger: 128 KiB.  (Latency mode, for small batches of large entries, chooses on top of this in run_subbatch.)
+inline uint32_t blk_log_for_longest(const pna_gpu_ctx *c, uint64_t mx) {
+    if (c->tun.blk_log) return (uint32_t)c->tun.blk_log;
+    if (mx > 65536) return PNA_BLK_LOG;
+    uint32_t lg = BLK_LOG_MIN;
+    while (((uint64_t)1 << lg) < mx) lg++;
+    return lg;
+}
 template <class L>
 inline uint32_t small_entry_blk_log(const pna_gpu_ctx *c, const L *src_len, size_t e0, size_t e1) {
     if (c->tun.blk_log) return (uint32_t)c->tun.blk_log;
     uint64_t mx = 0;
     for (size_t e = e0; e < e1; e++) mx = std::max<uint64_t>(mx, src_len[e]);
-    if (mx > 65536) return PNA_BLK_LOG;
-    uint32_t lg = BLK_LOG_MIN;
-    while (((uint64_t)1 << lg) < mx) lg++;
-    return lg;
+    return blk_log_for_longest(c, mx);
+}
+// The per-entry host loops of a sub-batch of 10^5 .. 10^6 small entries (plan, bounds, record prefixes) run on several threads over CONTIGUOUS index
+// ranges: fn(t, a, b) for thread t and its range [a, b) of [0, n); the caller's thread takes the first range.
+inline unsigned host_loop_threads(size_t n) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::min<size_t>(std::min<unsigned>(16u, hw), std::max<size_t>(1, n / 16384));
+}
+template <class F>
+inline void par_ranges(size_t n, unsigned nt, F &&fn) {
+    if (nt <= 1) { fn(0u, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back([&fn, n, nt, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
+    fn(0u, (size_t)0, n / nt);
+    for (auto &x : th) x.join();
 }
 // per call: the block size the sub-batches are cut with and how many blocks fit the workspace budget
 template <class L>

@@ -531,12 +531,34 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     // inside the same frames (blk_log), and the LZ stage runs one workgroup per UNIT of 1 << unit_log bytes whose table is pre-warmed with
     // everything before it (lz_prewarm), which gives the very matches of the segment-long walk.  Both follow from the batch's size alone
     // (and pna_gpu_set_option), are reported by pna_gpu_last_timing, and are parameters of the oracle's model.
+    // option trace: the HOST's time line of the sub-batch (what it does before and next to the kernels), printed when the call ends
+    const auto t_host0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char *, double>> host_marks;
+    auto mark = [&](const char *what) { if (c->tun.trace) host_marks.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count()); };
+    auto print_marks = [&]() { if (c->tun.trace && !host_marks.empty()) { fprintf(stderr, "[pna sub-batch] %zu entries, host:", e1 - e0); for (auto &m : host_marks) fprintf(stderr, "  %s %.2f", m.first, m.second); fprintf(stderr, " ms\n"); } };
+    const size_t ne_all = e1 - e0;
+    const unsigned host_nt = host_loop_threads(ne_all);
+    struct PlanPart { uint64_t in_total = 0, nseg_est = 0, max_len = 0; uint32_t sg = 0, bk = 0, un = 0; bool misaligned = false, any_empty = false; };
+    std::vector<PlanPart> pp(host_nt);
+    par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
+        PlanPart q;
+        for (size_t e = e0 + a; e < e0 + b; e++) {
+            const uint64_t len = src_len[e];
+            q.in_total += len; q.nseg_est += len ? (len + SEG_SIZE - 1) / SEG_SIZE : 1; q.max_len = std::max<uint64_t>(q.max_len, len);
+            q.misaligned |= (src_off[e] & 15) != 0; q.any_empty |= len == 0;
+        }
+        pp[t] = q;
+    });
     uint64_t in_total = 0, nseg_est = 0, max_len = 0;
-    for (size_t e = e0; e < e1; e++) { in_total += src_len[e]; nseg_est += src_len[e] ? (src_len[e] + SEG_SIZE - 1) / SEG_SIZE : 1; max_len = std::max<uint64_t>(max_len, src_len[e]); }
+    bool any_empty = false;
+    for (const PlanPart &q : pp) {
+        in_total += q.in_total; nseg_est += q.nseg_est; max_len = std::max(max_len, q.max_len); any_empty |= q.any_empty;
+        if (q.misaligned) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
+    }
     // an upper bound of every payload of the sub-batch when the entries are small and plain (k_frame's wave-per-entry form takes those; 0: no such bound)
     const uint32_t frame_max_payload = (fj && !fj->solid && !fj->cipher && max_len <= 16384) ? (uint32_t)std::min<size_t>(pna_gpu_bound(algo, (size_t)max_len), 0xFFFFFFFFu) : 0u;
     const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
-    uint32_t blk_log = small_entry_blk_log(c, src_len, e0, e1), unit_log = 20;
+    uint32_t blk_log = blk_log_for_longest(c, max_len), unit_log = 20;
     if (latency && blk_log == PNA_BLK_LOG) {
         // blocks: 16 KiB up to 16 MiB of input (a block's sequence chain then is ~1 000 steps), then growing with the batch so that the
         // block count -- per-block fixed costs of the entropy kernels -- stays near 1 024 .. 2 048
@@ -551,25 +573,24 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     const uint32_t bsz = 1u << blk_log;
     // The plan: counted first, then written straight into the page-locked blob that travels to the device in one copy (several threads for the
     // batches of 10^5 .. 10^6 small entries, where this loop is a tenth of the call).  Layout: [segs | units | blk_seg | entry_first_seg].
-    const size_t ne_all = e1 - e0;
-    std::vector<uint32_t> efs_v(ne_all + 1), efb_v(ne_all + 1), efu_v(ne_all + 1);     // first segment / block / unit of every entry
-    bool any_empty = false;
-    {
+    // first segment / block / unit of every range of entries (the ranges of par_ranges): counted per range, then a prefix sum over the ranges
+    par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
         uint32_t sg = 0, bk = 0, un = 0;
-        for (size_t e = e0; e < e1; e++) {
-            efs_v[e - e0] = sg; efb_v[e - e0] = bk; efu_v[e - e0] = un;
+        for (size_t e = e0 + a; e < e0 + b; e++) {
             const uint64_t len = src_len[e];
-            if (src_off[e] & 15) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
-            if (len == 0) { sg++; any_empty = true; continue; }
+            if (len == 0) { sg++; continue; }
             const uint64_t full = len >> 20, rest = len & (SEG_SIZE - 1);
             sg += (uint32_t)(full + (rest ? 1 : 0));
             bk += (uint32_t)((full << (20 - blk_log)) + ((rest + bsz - 1) >> blk_log));
             if (unit_log < 20) un += (uint32_t)((full << (20 - unit_log)) + ((rest + (1u << unit_log) - 1) >> unit_log));
         }
-        efs_v[ne_all] = sg; efb_v[ne_all] = bk; efu_v[ne_all] = un;
-    }
-    const uint32_t nseg = efs_v[ne_all], nblk = efb_v[ne_all], nunits = efu_v[ne_all];
+        pp[t].sg = sg; pp[t].bk = bk; pp[t].un = un;
+    });
+    uint32_t nseg = 0, nblk = 0, nunits = 0;
+    for (PlanPart &q : pp) { const uint32_t a = q.sg, b = q.bk, u = q.un; q.sg = nseg; q.bk = nblk; q.un = nunits; nseg += a; nblk += b; nunits += u; }
+
     if (nseg == 0) return PNA_OK;
+    mark("counted");
     const size_t o_units = ((size_t)nseg * sizeof(SegDesc) + 15) & ~(size_t)15, o_blkseg = (o_units + (size_t)nunits * sizeof(SegDesc) + 15) & ~(size_t)15,
                  o_entry = (o_blkseg + (size_t)(nblk + 1) * 4 + 15) & ~(size_t)15, plan_bytes = o_entry + (ne_all + 2) * 4;
     if (c->plan.ensure(plan_bytes) || c->h_plan.ensure(plan_bytes)) return fail(c, PNA_E_NOMEM, "workspace allocation failed");
@@ -580,12 +601,12 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     // last block only (SegDesc::first bit 2 tells k_plan / k_write); the blocks are what they are in the frame-per-segment form
     const uint32_t sf_bit = (algo == PNA_ALGO_ZSTD && c->tun.single_frame) ? 4u : 0u;
     {
-        auto fill = [&](size_t a, size_t b) {
-            for (size_t e = a; e < b; e++) {
-                uint32_t sg = efs_v[e - e0], bk = efb_v[e - e0], un = efu_v[e - e0];
+        auto fill = [&](unsigned t, size_t a, size_t b) {
+            uint32_t sg = pp[t].sg, bk = pp[t].bk, un = pp[t].un;
+            for (size_t e = e0 + a; e < e0 + b; e++) {
                 entry_first_seg[e - e0] = sg;
                 const uint64_t len = src_len[e], off = src_off[e];
-                if (len == 0) { segs[sg] = SegDesc{off, 0, bk, (uint32_t)e, 3, 0, 0, blk_log, 0}; continue; }
+                if (len == 0) { segs[sg++] = SegDesc{off, 0, bk, (uint32_t)e, 3, 0, 0, blk_log, 0}; continue; }
                 for (uint64_t p = 0; p < len; p += SEG_SIZE) {
                     const uint32_t sl = (uint32_t)std::min<uint64_t>(SEG_SIZE, len - p);
                     const SegDesc s{off + p, sl, bk, (uint32_t)e, (p == 0 ? 1u : 0u) | (p + SEG_SIZE >= len ? 2u : 0u) | sf_bit, 0, sl, blk_log, 0};
@@ -597,9 +618,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
                 }
             }
         };
-        const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, ne_all / 32768));
-        if (nt > 1) { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(fill, e0 + ne_all * t / nt, e0 + ne_all * (t + 1) / nt); for (auto &x : th) x.join(); }
-        else fill(e0, e1);
+        par_ranges(ne_all, host_nt, fill);
         entry_first_seg[ne_all] = nseg;
     }
     const bool unit_mode = unit_log < 20 && nunits > 0;
@@ -626,6 +645,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     }
     c->lzm_used = 0; c->lzm_nl.clear();
     const bool defl = algo == PNA_ALGO_DEFLATE;
+    mark("plan queued");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
@@ -636,7 +656,8 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
                               (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (const uint4 *)c->ctab.p, (DeflTables *)c->tabs.p, (uint8_t *)c->litc.p,
-                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags, c->call_stored);
+                              (uint64_t *)c->seg_size.p, (uint64_t *)c->seg_off.p, st, timed ? &c->ev[2] : nullptr, c->call_flags, c->call_stored,
+                              /* a wave per segment: many small entries */ max_len <= 32768 && nseg >= 4096);
     } else {
         // zstd: the segments go through k_lz in chunks on `st`; the entropy stage of a finished chunk runs on the auxiliary
         // stream next to the following chunk's k_lz (latency-bound kernels hide in the issue slots k_lz leaves free)
@@ -685,6 +706,8 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     }
     HIPCHK(c, hipGetLastError());
     // while the kernels run: the name-dependent part of every entry record (FHED and fSIZ chunks with their CRCs)
+    mark("kernels queued");
+    uint64_t layout_need = 0; bool layout_over = false;         // the sub-batch's worst-case size with its prefixes; an entry whose worst case exceeds one FDAT chunk
     FrameDesc *fds = nullptr; uint8_t *blob = nullptr; uint64_t *segdst = nullptr; size_t blob_len = 0;
     const bool solid = fj && fj->solid;
     const bool gcm = fj && fj->cipher && fj->cipher->cipher_mode == PNA_MODE_GCM;
@@ -715,11 +738,24 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         }
     } else if (fj) {
         std::vector<uint8_t> tmp;
-        size_t bound = 0;
-        for (size_t e = e0; e < e1; e++) bound += (fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e])) + meta_len(fj->meta, e);
-        // (every FDAT chunk behind an entry's first needs a descriptor and 8 prefix bytes: at most one per max_chunk_size bytes of the worst-case output)
-        size_t extra_chunks = 0;
-        { const uint64_t CHb = chunk_limit(fj->max_chunk); for (size_t e = e0; e < e1; e++) extra_chunks += (size_t)((pna_gpu_bound(algo, (size_t)src_len[e]) + 64 + 16 * (src_len[e] >> 12)) / CHb); }
+        // bounds, one pass over the entries on the host-loop threads: the prefixes' worst case per range of entries (a range's prefixes are written
+        // from its bound offset on, so the ranges need no compaction pass afterwards), the extra FDAT chunks (every chunk behind an entry's first needs a
+        // descriptor and 8 prefix bytes: at most one per max_chunk_size bytes of the worst-case output), and what the device-side layout must know --
+        // whether every worst-case payload fits one chunk, and the worst-case size of the sub-batch
+        struct FramePart { size_t bound = 0, extra = 0; uint64_t need = 0; bool over = false; };
+        std::vector<FramePart> fp(host_nt);
+        const uint64_t CHb = chunk_limit(fj->max_chunk);
+        par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
+            FramePart q;
+            for (size_t e = e0 + a; e < e0 + b; e++) {
+                const size_t pb = (fj->cipher ? frame_entry_prefix_enc_bound(fj->names[e], fj->cipher->phsf) : frame_entry_prefix_bound(fj->names[e])) + meta_len(fj->meta, e);
+                const uint64_t wb = pna_gpu_bound(algo, (size_t)src_len[e]);
+                q.bound += pb; q.extra += (size_t)((wb + 64 + 16 * (src_len[e] >> 12)) / CHb); q.need += pb + wb + 16; q.over |= wb > CHb;
+            }
+            fp[t] = q;
+        });
+        size_t bound = 0, extra_chunks = 0;
+        for (FramePart &q : fp) { const size_t b = q.bound; q.bound = bound; bound += b; extra_chunks += q.extra; layout_need += q.need; layout_over |= q.over; }
         if (c->h_desc.ensure(((e1 - e0) + extra_chunks + 1) * sizeof(FrameDesc)) || c->h_blob.ensure(bound + 8 * extra_chunks + 16) || c->h_segdst.ensure((size_t)(nseg + 1) * 8))
             return fail(c, PNA_E_NOMEM, "framing staging");
         fds = (FrameDesc *)c->h_desc.p; blob = (uint8_t *)c->h_blob.p; segdst = (uint64_t *)c->h_segdst.p;
@@ -740,19 +776,17 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
             for (auto &x : th) x.join();
         }
         if (!fj->cipher && !fj->meta) {
-            // plain entries: the prefixes are written straight into the staging blob; with many entries several threads share them
-            // (each thread fills the slots of its range at the bound offsets, a compaction pass closes the gaps)
-            const size_t ne = e1 - e0;
-            const unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, ne / 8192));
-            std::vector<uint32_t> plen(ne); std::vector<size_t> slot(ne + 1); slot[0] = 0;
-            for (size_t i = 0; i < ne; i++) slot[i + 1] = slot[i] + frame_entry_prefix_bound(fj->names[e0 + i]);
-            auto work = [&](unsigned t) { for (size_t i = t; i < ne; i += nt) plen[i] = (uint32_t)frame_entry_prefix_into(blob + slot[i], fj->names[e0 + i], algo, src_len[e0 + i]); };
-            if (nt > 1) { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); } else work(0);
-            for (size_t i = 0; i < ne; i++) {
-                if (blob_len != slot[i]) memmove(blob + blob_len, blob + slot[i], plen[i]);
-                fds[i] = FrameDesc{0, 0, (uint32_t)blob_len, plen[i], 0};
-                blob_len += plen[i];
-            }
+            // plain entries: the prefixes are written straight into the staging blob, every range of entries back to back from the range's bound offset
+            // (the few unused bytes between two ranges travel with the blob; nothing refers to them)
+            par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
+                size_t at = fp[t].bound;
+                for (size_t i = a; i < b; i++) {
+                    const size_t pl = frame_entry_prefix_into(blob + at, fj->names[e0 + i], algo, src_len[e0 + i]);
+                    fds[i] = FrameDesc{0, 0, (uint32_t)at, (uint32_t)pl, 0};
+                    at += pl;
+                }
+            });
+            blob_len = bound;
         } else
         for (size_t e = e0; e < e1; e++) {
             tmp.clear();
@@ -767,17 +801,8 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     }
     // Plain file entries of one FDAT chunk each (no cipher; the worst case of every payload below the chunk limit and of the whole sub-batch below the
     // destination's capacity): the archive layout is computed on the device (k_layout) and the host never waits in the middle of the sub-batch.
-    bool dev_layout = fj && !solid && !fj->cipher && c->tun.dev_layout != 0;
-    if (dev_layout) {
-        const uint64_t CH = chunk_limit(fj->max_chunk);
-        uint64_t need = out_base;
-        for (size_t e = e0; e < e1 && dev_layout; e++) {
-            const uint64_t b = pna_gpu_bound(algo, (size_t)src_len[e]);
-            if (b > CH) dev_layout = false;
-            need += fds[e - e0].prefix_len + b + 16;
-        }
-        if (need + 16 > dst_cap) dev_layout = false;
-    }
+    mark("prefixes built");
+    const bool dev_layout = fj && !solid && !fj->cipher && c->tun.dev_layout != 0 && !layout_over && out_base + layout_need + 16 <= dst_cap;
     if (dev_layout) {
         const size_t ne = e1 - e0;
         if (c->fr_desc.ensure(ne * sizeof(FrameDesc)) || c->fr_blob.ensure(blob_len + 16) || c->fr_segdst.ensure((size_t)(nseg + 1) * 8) ||
@@ -800,7 +825,9 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         uint64_t *h_ent = (uint64_t *)c->h_entoff.p;
         if (fj->want_offsets) HIPCHK(c, hipMemcpyAsync(h_ent, d_ent, (ne + 2) * 8, hipMemcpyDeviceToHost, st));
         else HIPCHK(c, hipMemcpyAsync(h_ent + ne, d_ent + ne, 16, hipMemcpyDeviceToHost, st));
+        mark("framing queued");
         HIPCHK(c, hipStreamSynchronize(st));
+        mark("device done"); print_marks();
         HIPCHK(c, hipGetLastError());
         if (fj->want_offsets) memcpy(dst_off + e0, h_ent, ne * 8);
         dst_off[e1] = h_ent[ne];

@@ -84,7 +84,7 @@ void launch_link_gather(const void *segs, uint32_t nseg, uint32_t, hipStream_t) 
 void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); }
 
 void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, const uint4 *, DeflTables *,
-                           uint8_t *, uint64_t *, uint64_t *, hipStream_t, hipEvent_t *, uint32_t, bool) { nostub("deflate"); }
+                           uint8_t *, uint64_t *, uint64_t *, hipStream_t, hipEvent_t *, uint32_t, bool, bool) { nostub("deflate"); }
 void launch_deflate_write(const uint8_t *, const SegDesc *, const uint32_t *, uint32_t, const BlkInfo *, const uint64_t *, const uint64_t *, const uint8_t *, const uint32_t *,
                           uint32_t, uint8_t *, hipStream_t, bool) { nostub("deflate"); }
 void launch_frame_verify(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t, uint32_t) { nostub("frame_verify"); }

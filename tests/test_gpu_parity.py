@@ -562,6 +562,25 @@ def test_deflate_many_small_entries(gpu_ctx, pna, codec):
     assert all(zlib.decompress(o) == e for o, e in zip(outs[:200], ents[:200]))
 
 
+def test_deflate_wave_per_entry_form_equals_the_model(gpu_ctx, pna, codec):
+    """Batches of >= 4 096 entries of at most 32 KiB build their Huffman codes with ONE WAVE per entry (k_dstats<64>) instead of a workgroup: every
+    stream must still be the model's, for ragged sizes -- empty, a few bytes, one symbol only, 32 KiB of text and of noise -- in one batch."""
+    import random
+    rnd = random.Random(5)
+    sizes = [0, 1, 2, 3, 7, 64, 257, 4095, 4096, 4097, 16384, 32768, 32767] + [rnd.choice((rnd.randrange(1, 600), rnd.randrange(600, 9000), 4096)) for _ in range(4200)]
+    ents = []
+    for i, n in enumerate(sizes):
+        k = i % 5
+        if k == 3: ents.append(bytes([65 + i % 7]) * n)                          # one symbol: the single-code corner of all three code builds
+        elif k == 4: ents.append(rnd.randbytes(n))                                # noise: every literal occurs, no matches, stored blocks
+        else: ents.append(codec.corpus_file(k & 1, 300 + i, n) if n else b"")
+    outs = gpu_ctx.compress_batch(ents, algo=pna.ALGO_DEFLATE)
+    assert len(outs) == len(ents)
+    bad = [i for i, (o, e) in enumerate(zip(outs, ents)) if o != codec.deflate_model_compress(e)]
+    assert not bad, (bad[:8], [sizes[i] for i in bad[:8]])
+    assert all(zlib.decompress(o) == e for o, e in zip(outs[::9], ents[::9]))
+
+
 @pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
 def test_archive_assembled_in_hbm_equals_host_framing(gpu_ctx, pna, pf, codec, algo_name):
     """pna_gpu_create_archive_device: payloads written at their archive offsets + k_frame (prefix, FDAT CRC, FEND) must give
