@@ -165,7 +165,8 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     if (n == 0) { static const uint8_t e[8] = {0x78,0x9C,0x03,0x00,0x00,0x00,0x00,0x01}; memcpy(dst, e, 8); return 8; }
     size_t op = 0;
     dst[op++] = 0x78; dst[op++] = stored_only ? 0x01 : 0x9C;
-    const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    if (table_entries < p->small_slots) table_entries = p->small_slots;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     const uint32_t BS = pna_blk_size(p);
     uint32_t maxblk = PNA_SEG_SIZE / BS;
@@ -177,11 +178,13 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
+        pna_zstd_params small;
+        const pna_zstd_params *ps = pna_seg_params(p, seg_len, &small);           /* a short segment: the small geometry (zstd_model.h) */
         memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t nb = 0;
         for (uint32_t b0 = 0; b0 < seg_len; b0 += BS, nb++) {
             uint32_t bl = seg_len - b0 < BS ? seg_len - b0 : BS;
-            blk_nseq[nb] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)nb * (BS / 4),
+            blk_nseq[nb] = pna_lz_block(seg, seg_len, b0, bl, table, ps, seqs + (size_t)nb * (BS / 4),
                                         lits + (size_t)nb * BS, &blk_nlit[nb]);
         }
         /* segment statistics */

@@ -29,6 +29,12 @@ void pna_zstd_default_params(pna_zstd_params *p) {
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3 | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
     p->blk_log = 0; p->len_word_max = 36; p->tab3 = 1;
+    p->mtile = 0; p->small_seg = 4096; p->small_slots = 2048; p->small_tile = 256;
+}
+const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp) {
+    if (!p->small_seg || seg_len > p->small_seg) return p;
+    *tmp = *p; tmp->hash_log = p->small_slots; tmp->tab3 = 0; tmp->mtile = p->small_tile;
+    return tmp;
 }
 
 /* block size of a parameter set: 128 KiB unless blk_log names a smaller power of two (the device's latency mode: small batches are cut
@@ -112,15 +118,18 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     uint32_t *wbest = p->tab3 ? (uint32_t *)calloc(p->hash_log / 3 + 1, sizeof(uint32_t)) : NULL, *wlist = p->tab3 ? (uint32_t *)malloc(sizeof(uint32_t) * (T + 1)) : NULL;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
         uint32_t t1 = t0 + T < blk_end ? t0 + T : blk_end;
-        /* L */
-        for (uint32_t q = t0; q < t1; q++)
+        /* L, I: per sub-tile of MT positions (the whole tile unless p->mtile says otherwise) */
+        const uint32_t MT = p->mtile ? p->mtile : T;
+        for (uint32_t m0 = t0; m0 < t1; m0 += MT) {
+        const uint32_t m1 = m0 + MT < t1 ? m0 + MT : t1;
+        for (uint32_t q = m0; q < m1; q++)
             cand[q - t0] = (q + 8 > seg_len) ? 0 : table[p->tab3 ? lz_hash3(seg + q, p->min_match, p->hash_log) : lz_hash(seg + q, p->min_match, p->hash_log)];
         /* I */
         if (p->tab3) {
             /* per word of three slots, ONE of the tile's inserts is stored: the contender with the highest (field, position) -- the device's single
              * 64-bit maximum of "the word as the look-ups saw it, my field replaced".  (Position 0 is never stored: its entry is the empty one.) */
             uint32_t nw = 0;
-            for (uint32_t q = t0; q < t1; q++) {
+            for (uint32_t q = m0; q < m1; q++) {
                 if (q + 8 > seg_len || q % ins_mod || q == 0) continue;
                 const uint32_t s3 = lz_hash3(seg + q, p->min_match, p->hash_log), w = s3 / 3;
                 const uint32_t key = ((s3 % 3 + 1) << 24) | (q - t0);               /* (field + 1, position): 0 = no contender yet */
@@ -133,11 +142,12 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 table[3 * w + (key >> 24) - 1] = t0 + (key & 0xFFFFFFu) + 1;
             }
         } else
-        for (uint32_t q = t0; q < t1; q++)
+        for (uint32_t q = m0; q < m1; q++)
             if (q + 8 <= seg_len) {
                 uint32_t h = lz_hash(seg + q, p->min_match, p->hash_log);
                 if (q % ins_mod == 0 && table[h] < q + 1) table[h] = q + 1;
             }
+        }
         /* M */
         for (uint32_t q = t0; q < t1; q++) {
             uint32_t c1 = cand[q - t0], l = 0, bk = 0, fr = 0;
@@ -653,7 +663,8 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     if (cap < pna_zstd_bound(n)) return 0;
     size_t op = 0;
     if (n == 0) { static const uint8_t e[9] = {0x28,0xB5,0x2F,0xFD,0x20,0x00,0x01,0x00,0x00}; memcpy(dst, e, 9); return 9; }
-    const size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
+    if (table_entries < p->small_slots) table_entries = p->small_slots;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     const uint32_t BS = pna_blk_size(p);
     uint32_t maxblk = PNA_SEG_SIZE / BS;
@@ -663,11 +674,13 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     for (size_t s0 = 0; s0 < n; s0 += PNA_SEG_SIZE) {
         uint32_t seg_len = (uint32_t)(n - s0 < PNA_SEG_SIZE ? n - s0 : PNA_SEG_SIZE);
         const uint8_t *seg = src + s0;
+        pna_zstd_params small;
+        const pna_zstd_params *ps = pna_seg_params(p, seg_len, &small);           /* a short segment: the small geometry */
         memset(table, 0, sizeof(uint32_t) * table_entries);
         uint32_t b = 0;
         for (uint32_t b0 = 0; b0 < seg_len; b0 += BS, b++) {
             uint32_t bl = seg_len - b0 < BS ? seg_len - b0 : BS;
-            blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, p, seqs + (size_t)b * (BS / 4),
+            blk_nseq[b] = pna_lz_block(seg, seg_len, b0, bl, table, ps, seqs + (size_t)b * (BS / 4),
                                        lits + (size_t)b * BS, &blk_nlit[b]);
         }
         size_t fs = pna_zstd_encode_segment(seg, seg_len, seqs, lits, blk_nseq, blk_nlit, p->flags, BS, dst + op);

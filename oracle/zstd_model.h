@@ -51,7 +51,15 @@ typedef struct {
                            * 21-bit entries: 19 bits of even position, 2 of tag).  A tile's inserts into one word are ONE 64-bit maximum of "the word as it was,
                            * my field replaced": of a tile's contenders for a word only the one with the highest (field, position) is stored, the others are
                            * lost (4 - 8 % of the inserts; the estimator: -0.1 % of ratio for a half more slots in the same LDS).  Needs ins_mod = 2. */
+    uint32_t mtile;       /* look-ups and inserts alternate per SUB-TILE of mtile positions inside a tile (0 = the whole tile): the positions of a sub-tile see the
+                           * inserts of the sub-tiles before it.  Parse, lazy deferral and extension keep the tile. */
+    uint32_t small_seg;   /* segments of at most this many bytes (0 = none) run the SMALL geometry of the device -- one wave per segment instead of a workgroup:
+                           * table of small_slots 32-bit entries (not packed), sub-tiles of small_tile positions (one wave's 256).  With the large geometry a
+                           * segment of one tile never finds a match (its positions do not see each other): 4 KiB text entries 1.77 -> 2.07 (zlib -6: 2.02). */
+    uint32_t small_slots, small_tile;
 } pna_zstd_params;
+/* the parameters segment `seg_len` bytes long runs with: p itself, or *tmp = p with the small geometry */
+const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp);
 
 typedef struct { uint32_t ll, ml, off; } pna_seq;   /* literal run, match length, offset (>=1) */
 

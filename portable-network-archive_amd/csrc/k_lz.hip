@@ -38,6 +38,8 @@ namespace pna {
 void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                      uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg);   // k_lz_split.hip
 void lzp_read_stamps(unsigned long long *out);
+void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
+                     uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, const LzParseGrid *pg, bool w3);   // k_lz_split.hip
 
 // diagnostic build only (STAMP = true): lane 0 of every wave accumulates s_memtime deltas per phase (sums over the 16 waves)
 __device__ unsigned long long g_lz_stamps[8];
@@ -77,6 +79,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);   // block size of the batch = stride of the per-block arrays
+    if (MODE != 2 && (flags & FLAG_HAS_SMALL) && seg_len <= SMALL_SEG) return;         // (uniform) a short segment: k_lzms's (pna_dev.h; MODE 2 parses its words like any)
     uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
@@ -548,6 +551,7 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
     if (pbuf) {
         if (flags & FLAG_SPLIT_WAVEPARSE) {
             hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 1, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
+            if (flags & FLAG_HAS_SMALL) launch_lz_small(src, segs, nseg, seqs, lits, blk, ctab, flags, max_len, st, pbuf, blk0, nullptr, false);   // (match kernel only; this form's words take four bytes)
             if (ev_match) (void)hipEventRecord(ev_match, st);
             hipLaunchKernelGGL((k_lz<false, G, CT, STRONG, 2, WLOG, TAB3>), dim3(nseg), dim3(LZ_THREADS), 4 * LZ_WAVES + 8 * LZ_WAVES, st, src, segs, seqs, lits, blk, ctab, flags, max_off, max_len, pbuf, blk0);
             return;

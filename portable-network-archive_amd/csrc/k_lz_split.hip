@@ -106,6 +106,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
+    if ((flags & FLAG_HAS_SMALL) && seg_len <= SMALL_SEG) return;     // (uniform) a short segment: k_lzms's
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
     // The words: one per position, length | offset.  With the table in LDS (GLOG = 0) they take THREE bytes -- 5 bits for the length (0, or length - 5
     // for 6 .. 36: adopted lengths beyond 36 are clamped, FLAG_LEN36 tells the one-kernel form to do the same) and 19 for the offset (MAX_OFF_W3) --:
@@ -365,6 +366,159 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// k_lzms -- the match half for SHORT segments (pna_dev.h: at most SMALL_SEG = 4 096 bytes).  k_lzm's tile is 4 096 positions whose look-ups all come before
+// its inserts, so a segment of one tile finds nothing, and its workgroup of 16 waves with 160 KiB of LDS per CU spends its time being launched and
+// clearing the table (10^6 entries of 4 KiB: 13.7 ms for no match at all).  Here ONE WAVE owns the segment: the whole of it in LDS (no circular window, no far
+// candidates: every offset is inside), a table of SMALL_SLOTS 32-bit entries, and the walk in sub-tiles of 256 positions -- four per lane, as in k_lzm --
+// whose look-ups see the inserts of the sub-tiles before them: 12.4 KiB of LDS, twelve segments per CU.  Same hash, entries, match step, adoption rounds
+// and words as k_lzm (the parse kernel does not know the difference); oracle/zstd_model.c: mtile / small_seg.  4 KiB text entries: ratio 1.77 -> 2.07.
+template <bool STRONG, bool W3>
+__global__ __launch_bounds__(64)
+void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t *__restrict__ pbuf, uint32_t blk0) {
+    constexpr uint32_t RW = 256, PAD = 64;
+    __shared__ __attribute__((aligned(16))) uint8_t winb[PAD + SMALL_SEG + 64];     // 64 bytes in front of the segment (read, never used), the segment, zeros behind it
+    __shared__ __attribute__((aligned(16))) uint32_t table[SMALL_SLOTS];
+    const uint32_t lane = threadIdx.x;
+    const SegDesc sd = segs[blockIdx.x];
+    const uint32_t seg_len = sd.len;
+    if (seg_len == 0 || seg_len > SMALL_SEG) return;
+    const uint8_t *seg = src + sd.src_off;
+    const uint32_t blk_log = sd.blk_log;
+    uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
+    uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
+    const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
+    const uint32_t *win32 = (const uint32_t *)(winb + PAD);
+    for (uint32_t i = lane; i < SMALL_SLOTS / 4; i += 64) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    if (lane < PAD / 16) ((uint4 *)winb)[lane] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16; i < SMALL_SEG + 64; i += 64 * 16) *(uint4 *)(winb + PAD + i) = i < seg_len ? load_chunk(seg, i, seg_len) : make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < seg_len; t0 += RW) {
+        const uint32_t t1 = seg_len - t0 < RW ? seg_len : t0 + RW;
+        const uint32_t q0 = t0 + 4 * lane;
+        uint32_t D[9], Dm1, Dm2 = 0;
+        {
+            const uint32_t *pq = win32 + (q0 >> 2);
+#pragma unroll
+            for (int k = 0; k < 9; k++) D[k] = pq[k];
+            Dm1 = pq[-1];
+            if (STRONG) Dm2 = pq[-2];
+        }
+#define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
+        uint32_t hsh[4], tag[4], off[4], K[4];
+        bool hv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t q = q0 + j;
+            hv[j] = (q < t1) && (q + 8 <= seg_len);
+            const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
+            hsh[j] = __umulhi(h32, SMALL_SLOTS);
+            tag[j] = (h32 >> 6) & TAG_MASK;
+            const uint32_t e = table[hsh[j]], ent = hv[j] ? e : 0u;
+            const uint32_t c1 = ent >> TAG_BITS;
+            off[j] = ((c1 > 8) & ((ent & TAG_MASK) == tag[j])) ? q + 1 - c1 : 0u;
+        }
+        const bool edge = seg_len - t0 < RW + CAP1;                                 // (uniform) only the last sub-tiles can run into the segment's end
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t l = 0, bk = 0;
+            const uint32_t o = off[j], q = q0 + j;
+            if (o != 0) {
+                const uint32_t c = q - o;
+                const uint32_t shc = (c & 3) * 8;
+                uint32_t w0, w1, w2, w3, bc, bc2 = 0;
+                {
+                    const uint32_t *pc = win32 + (c >> 2);
+                    const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = pc[-1];
+                    w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                    w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                    bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                    if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, pc[-2], shc);
+                }
+                const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
+                l = first_diff16(x0, x1, x2, x3);
+                if (l == 16) {
+                    uint32_t v0, v1, v2, v3;
+                    {
+                        const uint32_t *pc2 = win32 + ((c + 16) >> 2);
+                        const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                        v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                        v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
+                    }
+                    const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
+                    l = 16 + first_diff16(y0, y1, y2, y3);
+                }
+                if (edge) { const uint32_t lim = seg_len - q; l = l < lim ? l : lim; }
+                if (l < MIN_MATCH) l = 0;
+                const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;           // the 4 bytes before q (q - 1 in the top byte)
+                const uint32_t xk = bqj ^ bc;
+                bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
+                if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
+            }
+            K[j] = (l << 6) | (bk << 3);
+            if (STRONG && !l) K[j] = 0;
+        }
+        if (adopt) {        // backward adoption, the rounds of k_lzm
+            {
+                const uint32_t Kn = DPP_ROW_SHL1(K[0]), on = DPP_ROW_SHL1(off[0]);
+                uint32_t K1[4] = {K[1], K[2], K[3], Kn}, o1[4] = {off[1], off[2], off[3], on};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t T = K1[j] + 57u;
+                    const bool a = (K1[j] & 0x38u) != 0 && T > (K[j] | 63u);
+                    K[j] = a ? T : K[j]; off[j] = a ? o1[j] : off[j];
+                }
+            }
+            {
+                const uint32_t Ka = DPP_ROW_SHL1(K[0]), Kb = DPP_ROW_SHL1(K[1]), oa = DPP_ROW_SHL1(off[0]), ob = DPP_ROW_SHL1(off[1]);
+                uint32_t K2[4] = {K[2], K[3], Ka, Kb}, o2[4] = {off[2], off[3], oa, ob};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t T = K2[j] + 114u;
+                    const bool a = (K2[j] & 0x30u) != 0 && T > (K[j] | 63u);
+                    K[j] = a ? T : K[j]; off[j] = a ? o2[j] : off[j];
+                }
+            }
+            if (STRONG) {
+                uint32_t K4[4], o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { K4[j] = DPP_ROW_SHL1(K[j]); o4[j] = DPP_ROW_SHL1(off[j]); }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t T = K4[j] + 228u;
+                    const bool a = (K4[j] & 0x20u) != 0 && T > (K[j] | 63u);
+                    K[j] = a ? T : K[j]; off[j] = a ? o4[j] : off[j];
+                }
+            }
+        }
+        if (q0 < t1) {
+            if (W3) {
+                uint32_t ww[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t l = K[j] >> 6, lc = l < 5u ? 5u : (l > 36u ? 36u : l);
+                    ww[j] = (lc - 5u) | (off[j] << 5);
+                }
+                W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);
+                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);
+            } else {
+                const uint32_t lmax = (flags & FLAG_LEN36) ? 36u : 63u;            // (four-byte words behind the one-kernel form's match half keep the clamp of the three-byte ones)
+                uint32_t l4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const uint32_t l = K[j] >> 6; l4[j] = l < lmax ? l : lmax; }
+                v4u wv; wv.x = l4[0] | (off[0] << 6); wv.y = l4[1] | (off[1] << 6); wv.z = l4[2] | (off[2] << 6); wv.w = l4[3] | (off[3] << 6);
+                __builtin_nontemporal_store(wv, (v4u *)(pb + q0));
+            }
+        }
+#undef QW
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
+        __syncthreads();                                                            // (one wave: the next sub-tile's look-ups come behind these inserts)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // k_lzp -- the parse half of the split form with one LANE per parse region.  What a whole wave does in k_lz with scalar loops on
 // ballot masks (an SALU instruction takes an issue slot like a vector one), sixteen lanes do here with vector arithmetic for the
 // sixteen regions of a tile at once.  One wave (= one workgroup: no barriers, 8.4 KiB of LDS) per segment; per tile of 4 096 positions:
@@ -400,6 +554,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     const uint32_t gb = blk0 + blockIdx.x;
     const SegDesc sd = segs[blk_seg[gb]];
     const uint32_t seg_len = sd.len;
+    if ((flags & FLAG_SMALL_ONLY) && seg_len > SMALL_SEG) return;     // (uniform) the pass over the short segments behind a one-kernel launch
     const uint8_t *seg = src + sd.src_off;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);
     const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
@@ -739,10 +894,11 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
     constexpr uint32_t LT = GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG, TAB3>::L_TOTAL;
     static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LzGeo<WLOG, TAB3>::L_TOTAL);   // once per process, thread-safe
     (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, flags, max_off, pbuf, blk0, gtab);
+    constexpr bool W3 = GLOG == 0;
+    if (!(flags & FLAG_ALL_SMALL)) hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, flags, max_off, pbuf, blk0, gtab);
+    if (flags & FLAG_HAS_SMALL) hipLaunchKernelGGL((k_lzms<STRONG, W3>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);     // the short segments, which k_lzm skipped
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (!pg || pg->nb == 0) return;                            // (no grid: the caller wants the match kernel alone; a run of empty entries has segments and no blocks)
-    constexpr bool W3 = GLOG == 0;
     if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
     else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
     else hipLaunchKernelGGL((k_lzp<CT, 1, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
@@ -771,6 +927,23 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
     else { if (strong) launch_split_g<false, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
            else if (max_off <= NEAR_OFF) launch_split_g<false, false, 0, 16, false>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
            else launch_split_g<false, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
+}
+// The short segments of a launch that took the one-kernel form (which skips them: FLAG_HAS_SMALL): k_lzms + the parse kernel over their blocks only.  w3: words of
+// three bytes (the caller's choice: every launch but the zstd levels with the table in global memory takes them, as in the split form).
+void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
+                     uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, const LzParseGrid *pg, bool w3) {
+    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
+    if (strong) { if (w3) hipLaunchKernelGGL((k_lzms<true, true>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);
+                  else hipLaunchKernelGGL((k_lzms<true, false>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0); }
+    else { if (w3) hipLaunchKernelGGL((k_lzms<false, true>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);
+           else hipLaunchKernelGGL((k_lzms<false, false>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0); }
+    if (!pg || pg->nb == 0) return;
+    const uint32_t pf = flags | FLAG_SMALL_ONLY;
+#define LZP_SMALL(CT_, LZD_) do { if (w3) hipLaunchKernelGGL((k_lzp<CT_, LZD_, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0); \
+                                  else hipLaunchKernelGGL((k_lzp<CT_, LZD_, false>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0); } while (0)
+    if (ctab) { if (flags & FLAG_LAZY3) LZP_SMALL(true, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(true, 2); else LZP_SMALL(true, 1); }
+    else { if (flags & FLAG_LAZY3) LZP_SMALL(false, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(false, 2); else LZP_SMALL(false, 1); }
+#undef LZP_SMALL
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {

@@ -49,6 +49,13 @@ constexpr uint32_t FLAG_W16 = 0x4000u;   // ... the 16 KiB-window geometry (36 8
 constexpr uint32_t FLAG_LEN36 = 0x8000u;  // adopted lengths clamped to 36: what the 3-byte words of the split form keep (5 bits: 0 or length - 5) next to 19 bits of offset
 constexpr uint32_t MAX_OFF_W3 = (1u << 19) - 1;   // ... so the look-back of the sets with an LDS table ends there (the estimator: 2.7761 -> 2.7759; 2^18: 2.7678)
 constexpr uint32_t FLAG_TAB3 = 0x10000u;  // (with FLAG_W32 / FLAG_W16, even inserts) the packed table: three 21-bit entries per 64-bit LDS word, 49 062 / 55 206 slots (lz_common.h)
+// SHORT segments (at most SMALL_SEG bytes: less than one tile of the match finder, whose positions do not see each other's inserts -- such a segment would never
+// find a match) run the SMALL geometry: one wave per segment (k_lzms, k_lz_split.hip), a table of SMALL_SLOTS 32-bit entries, look-ups and inserts alternating per
+// 256 positions; the parse is the common one.  oracle/zstd_model.h: small_seg, small_slots, small_tile.
+constexpr uint32_t SMALL_SEG = 4096, SMALL_SLOTS = 2048;
+constexpr uint32_t FLAG_HAS_SMALL = 0x20000u;   // launch flag of the LZ kernels: the launch may hold short segments -- k_lzms takes them, the other match kernels skip them
+constexpr uint32_t FLAG_SMALL_ONLY = 0x40000u;  // (k_lzp) parse the blocks of short segments only: the pass behind a one-kernel launch, which skipped them
+constexpr uint32_t FLAG_ALL_SMALL = 0x80000u;   // every segment of the launch is short (or empty): the large geometry's kernels are not launched at all
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy
 

@@ -11,7 +11,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 extern "C" const char *pna_gpu_strerror(int code) {
@@ -404,6 +404,30 @@ static void splice_meta(std::vector<uint8_t> &pre, const pna_gpu_entry_meta *m, 
 // stream, so runs share it) --, shorter ones and PNA_F_LZ_FUSED / PNA_LZ_SPLIT=0 the one-kernel form (k_lz<MODE 0>, no pbuf);
 // PNA_F_LZ_WAVEPARSE / PNA_LZ_SPLIT=2: the split form as k_lz<MODE 1> + k_lz<MODE 2> (testing).  All forms give the same bytes.  If pbuf
 // cannot be had, the run is halved down to 1 024 blocks, then fused.
+// The SHORT segments among [s0, s1) behind a launch of the one-kernel form, which skips them (pna_dev.h SMALL_SEG): k_lzms + the parse kernel over their blocks, through
+// the words workspace, in runs of blocks as the split form's
+static int lz_small_pass(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, uint32_t nseg_all, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
+                         uint32_t flags, uint32_t max_len, hipStream_t st) {
+    uint32_t run_blocks = (uint32_t)std::min<uint64_t>((uint64_t)c->tun.lz_split_blocks << (PNA_BLK_LOG - segs[s0].blk_log), 1u << 30);
+    const uint32_t bps = 1u << (20 - segs[s0].blk_log);
+    for (uint32_t a = s0; a < s1;) {
+        const uint32_t b0 = segs[a].blk_base;
+        uint32_t b = a + 1;
+        while (b < s1 && (b < nseg_all ? segs[b].blk_base : nblk) - b0 + bps <= run_blocks) b++;
+        const uint32_t b1 = b < nseg_all ? segs[b].blk_base : nblk;
+        if (c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4)) {
+            (void)hipGetLastError();
+            if (run_blocks > 1024 && b - a > 1) { run_blocks /= 2; continue; }
+            return fail(c, PNA_E_NOMEM, "no room for the short segments' words");
+        }
+        const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};
+        launch_lz_small(d_src, c->d_segs + a, b - a, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_len, st, (uint32_t *)c->pbuf.p, b0, &pg,
+                        (flags & FLAG_LEN36) != 0);
+        a = b;
+    }
+    return PNA_OK;
+}
+
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, uint32_t nseg_all, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
     const int env_split = (int)c->tun.lz_split;
@@ -455,7 +479,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         // 6 of them.  The segments behind the last full round are therefore cut into UNITS of one block each (table pre-warmed: the same words, SS4a), a launch
         // of their own behind the full rounds: R x 8 short workgroups instead of R long ones next to 256 - R idle CUs.
         uint32_t R = (!gt && !waveparse && c->tun.tail_units && b - a >= 2 * c->n_cus) ? (b - a) % c->n_cus : 0;     // (n_cus: the device's compute units, 256 on an MI355X)
-        if (R > 3 * c->n_cus / 8) R = 0;
+        if (R > 3 * c->n_cus / 8 || (flags & FLAG_ALL_SMALL)) R = 0;
         if (R) {
             const uint32_t bl = segs[a].blk_log, bs = 1u << bl;
             size_t nu = 0;
@@ -482,7 +506,8 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         a = b;
         if (a >= s1) return PNA_OK;
     }
-    launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr, nullptr);
+    if (!(flags & FLAG_ALL_SMALL)) launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr, nullptr);
+    if (flags & FLAG_HAS_SMALL) { const int rc = lz_small_pass(c, d_src, segs, nseg_all, s0, s1, nblk, ctab, flags, max_len, st); if (rc) return rc; }   // (the one-kernel form skips the short segments)
     if (fused_tail) return lz_stage(c, d_src, segs, nseg_all, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
     return PNA_OK;
 }
@@ -538,7 +563,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     auto print_marks = [&]() { if (c->tun.trace && !host_marks.empty()) { fprintf(stderr, "[pna sub-batch] %zu entries, host:", e1 - e0); for (auto &m : host_marks) fprintf(stderr, "  %s %.2f", m.first, m.second); fprintf(stderr, " ms\n"); } };
     const size_t ne_all = e1 - e0;
     const unsigned host_nt = host_loop_threads(ne_all);
-    struct PlanPart { uint64_t in_total = 0, nseg_est = 0, max_len = 0; uint32_t sg = 0, bk = 0, un = 0; bool misaligned = false, any_empty = false; };
+    struct PlanPart { uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0; uint32_t sg = 0, bk = 0, un = 0; bool misaligned = false, any_empty = false; };
     std::vector<PlanPart> pp(host_nt);
     par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
         PlanPart q;
@@ -546,13 +571,15 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
             const uint64_t len = src_len[e];
             q.in_total += len; q.nseg_est += len ? (len + SEG_SIZE - 1) / SEG_SIZE : 1; q.max_len = std::max<uint64_t>(q.max_len, len);
             q.misaligned |= (src_off[e] & 15) != 0; q.any_empty |= len == 0;
+            // SHORT segments (pna_dev.h SMALL_SEG): an entry of at most that many bytes, or the last segment of a longer one
+            q.n_short += (len > 0 && (((len - 1) & (SEG_SIZE - 1)) + 1) <= SMALL_SEG) ? 1u : 0u;
         }
         pp[t] = q;
     });
-    uint64_t in_total = 0, nseg_est = 0, max_len = 0;
+    uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0;
     bool any_empty = false;
     for (const PlanPart &q : pp) {
-        in_total += q.in_total; nseg_est += q.nseg_est; max_len = std::max(max_len, q.max_len); any_empty |= q.any_empty;
+        in_total += q.in_total; nseg_est += q.nseg_est; max_len = std::max(max_len, q.max_len); any_empty |= q.any_empty; n_short += q.n_short;
         if (q.misaligned) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
     }
     // an upper bound of every payload of the sub-batch when the entries are small and plain (k_frame's wave-per-entry form takes those; 0: no such bound)
@@ -645,13 +672,18 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     }
     c->lzm_used = 0; c->lzm_nl.clear();
     const bool defl = algo == PNA_ALGO_DEFLATE;
+    // the short segments' geometry (k_lzms): a launch flag tells the large geometry's kernels to skip them; a sub-batch of short segments only launches none of those
+    const uint32_t small_fl = (c->tun.small_geometry && n_short) ? (FLAG_HAS_SMALL | (max_len <= SMALL_SEG ? FLAG_ALL_SMALL : 0u)) : 0u;
     mark("plan queued");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;
     if (defl) {
-        const uint32_t dfl = (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | FLAG_LEN36;
+        const uint32_t dfl = (c->call_flags & (F_LAZY | F_ADOPT | F_INS2 | F_STRONG | 0x300u)) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | FLAG_LEN36 | small_fl;
         if (c->call_stored) { }                                // deflate level 0 = Compression::none(): stored blocks only, no match finder, no codes
-        else if (unit_mode) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
+        else if (unit_mode) {
+            if (!(dfl & FLAG_ALL_SMALL)) launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, nullptr, 0, nullptr, nullptr, nullptr);
+            if (dfl & FLAG_HAS_SMALL) { const int rc = lz_small_pass(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 258u, st); if (rc) return rc; }
+        }
         else { const int rc = lz_stage(c, d_src, segs, nseg, 0, nseg, nblk, (uint4 *)c->ctab.p, dfl, 32768u, 258u, st, timed); if (rc) return rc; }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
         launch_deflate_stage1(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const uint64_t *)c->seqs.p,
@@ -677,15 +709,17 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? (c->call_w16 ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36) | (c->call_tab3 ? FLAG_TAB3 : 0u);
+            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? (c->call_w16 ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36) | (c->call_tab3 ? FLAG_TAB3 : 0u) | small_fl;
             const uint32_t zmax = (c->call_flags & F_FAR) ? (c->call_gtab ? MAX_OFF : MAX_OFF_W3) : NEAR_OFF;   // (3-byte words keep 19 bits of offset)
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)
                 const bool gt = c->call_gtab;
                 const LzParseGrid pgu{c->d_segs, c->d_blk_seg, nblk};
                 if (gt && (c->pbuf.ensure(((size_t)nblk << blk_log) * 4) || c->gtab.ensure((size_t)nunits << (lz_gtab_log() + 2)))) return fail(c, PNA_E_NOMEM, "no room for the strong level set's hash tables");
+                if (gt || !(zfl & FLAG_ALL_SMALL))
                 launch_lz(d_src, c->d_units, nunits, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, nullptr, zfl,
                           zmax, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr, gt ? &pgu : nullptr);
+                if (!gt && (zfl & FLAG_HAS_SMALL)) { const int rc = lz_small_pass(c, d_src, segs, nseg, 0, nseg, nblk, nullptr, zfl, 0xFFFFFFFFu, st); if (rc) return rc; }   // (the split form above takes them itself)
             }
             else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, zmax, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)

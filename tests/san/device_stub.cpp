@@ -13,6 +13,7 @@ namespace pna {
 [[noreturn]] static void nostub(const char *what) { fprintf(stderr, "device_stub: %s is not stubbed\n", what); abort(); }
 
 void launch_lz(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, hipEvent_t, uint32_t *, const LzParseGrid *) {}
+void launch_lz_small(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, const LzParseGrid *, bool) {}
 uint32_t lz_gtab_log() { return 19; }
 void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
                           uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t, hipEvent_t *, hipStream_t, hipEvent_t, hipEvent_t) {}

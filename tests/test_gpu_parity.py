@@ -562,6 +562,53 @@ def test_deflate_many_small_entries(gpu_ctx, pna, codec):
     assert all(zlib.decompress(o) == e for o, e in zip(outs[:200], ents[:200]))
 
 
+def _short_cases(codec):
+    """Entries whose segments are SHORT (at most 4 096 bytes: the small geometry of the match finder, k_lzms) around the threshold, entries whose LAST
+    segment is short behind long ones, and ordinary ones in between -- one batch, so that both geometries' kernels run side by side."""
+    t = codec.corpus_file(0, 77, (1 << 20) + 5000)
+    cases = {"empty": b"", "one": b"z", "seven": b"abcdefg", "eight": b"abcdefgh", "nine": b"abcdefghi", "t255": t[:255], "t256": t[:256], "t257": t[:257],
+             "t511": t[100:611], "t1000": t[:1000], "t4095": t[:4095], "t4096": t[:4096], "t4097": t[:4097], "t5000": t[:5000], "t70000": t[:70000],
+             "seg+100": t[:(1 << 20) + 100], "seg+4096": t[:(1 << 20) + 4096], "seg+4097": t[:(1 << 20) + 4097],
+             "rep4096": (t[:300] * 14)[:4096], "zeros4096": bytes(4096), "noise3000": codec.corpus_file(2, 5, 3000), "words4096": codec.corpus_file(1, 8, 4096),
+             "ab": b"ab" * 2000, "period7": bytes((i * 37) & 0xFF for i in range(7)) * 500}
+    for i in range(40):
+        cases[f"mix{i:02d}"] = codec.corpus_file(i & 1, 500 + i, 37 + 97 * i)
+    return cases
+
+
+@pytest.mark.parametrize("form", ["split", "one_kernel", "wave_parse", "no_workspace"])
+def test_short_segments_take_the_small_geometry(pna, codec, form):
+    """Segments of at most 4 096 bytes are matched by one wave each in sub-tiles of 256 positions (with k_lzm's tile of 4 096 they would find nothing);
+    whatever form the LZ stage takes for the rest of the batch -- split, one kernel, the wave-per-region parse, no words workspace for the long segments --
+    every stream is the model's (oracle: small_seg / mtile), for every level set of both codecs, and the short text entries now do hold matches."""
+    cases = _short_cases(codec)
+    names = sorted(cases)
+    data = [cases[k] for k in names]
+    with headline_context(pna) as ctx:
+        if form == "one_kernel": ctx.set_option("lz_split", 0)
+        if form == "wave_parse": ctx.set_option("lz_split", 2)
+        if form == "no_workspace": ctx.set_option("lz_pbuf_fail", 1)
+        for level in (1, 2, 3, 7, 19):
+            outs = ctx.compress_batch(data, level=level)
+            pz = codec.params_for_level(level)
+            bad = [k for k, d, o in zip(names, data, outs) if o != codec.model_compress(d, pz)]
+            assert not bad, (form, level, bad[:6])
+            assert all(codec.zstd_decompress(o, len(d)) == d for d, o in zip(data, outs))
+        for level in (1, 6, 9):
+            outs = ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=level)
+            pd = codec.params_for_level(level, deflate=True)
+            bad = [k for k, d, o in zip(names, data, outs) if o != codec.deflate_model_compress(d, pd)]
+            assert not bad, (form, "deflate", level, bad[:6])
+            assert all(zlib.decompress(o) == d for d, o in zip(data, outs))
+        d = cases["t4096"]
+        o6 = ctx.compress_batch([d], algo=pna.ALGO_DEFLATE)[0]
+        assert len(o6) < len(zlib.compress(d, 6)) + 40 and len(o6) < 0.56 * len(d)       # matches inside a 4 KiB entry: without them Huffman alone gives ~0.58
+        # the option that switches the small geometry off: the model without it
+        ctx.set_option("small_geometry", 0)
+        p0 = codec.params_for_level(3); p0.small_seg = 0
+        assert ctx.compress_batch(data[:24], level=3) == [codec.model_compress(x, p0) for x in data[:24]]
+
+
 def test_deflate_wave_per_entry_form_equals_the_model(gpu_ctx, pna, codec):
     """Batches of >= 4 096 entries of at most 32 KiB build their Huffman codes with ONE WAVE per entry (k_dstats<64>) instead of a workgroup: every
     stream must still be the model's, for ragged sizes -- empty, a few bytes, one symbol only, 32 KiB of text and of noise -- in one batch."""
