@@ -58,7 +58,9 @@ __device__ void fse_normalize(const uint32_t *count, int nsym, uint32_t total, i
     int size = 1 << tlog, sum = 0, best = 0;
     for (int s = 0; s < nsym; s++) {
         if (count[s] == 0) { norm[s] = 0; continue; }
-        uint32_t q = (uint32_t)(((uint64_t)count[s] << tlog) / total);
+        // (counts are below 2^20 -- a segment holds at most 2^20 / 3 sequences, a Huffman tree 256 weights -- and tlog <= 9: the product fits 32 bits, and a 32-bit
+        // division is a fifth of the instructions of a 64-bit one, which was a third of this kernel's work for 4 KiB entries)
+        uint32_t q = (count[s] << tlog) / total;
         if (q == 0) q = 1;
         norm[s] = (int16_t)q; sum += (int)q;
         if (count[s] > count[best]) best = s;
@@ -230,24 +232,28 @@ __device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *or
     for (int i = (int)lane; i < n; i += 64) wt[i] = count[order[i]];
     __builtin_amdgcn_wave_barrier();
     const int nn = 2 * n - 1;
-    if (lane == 0) {
-        // two-queue Huffman, leaves win ties; n - 1 dependent steps on one lane.  The two heads of each queue are kept in registers (the leaf queue is
-        // read one element ahead, a new internal node enters the head registers directly when the queue is that short), so no step waits for an LDS
-        // round trip (k_deflate.hip's d_build_lens has the same form); weights are < 2^31, INF marks an exhausted / not yet filled head.  Same picks,
-        // same order as `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
+    {
+        // two-queue Huffman, leaves win ties; n - 1 dependent steps, executed by the whole wave IN SCALAR REGISTERS (k_deflate.hip's d_build_lens has the
+        // same form): every value of the loop is wave-uniform (what comes from LDS through readfirstlane), so compares, selects and counters are SALU work and
+        // only the LDS traffic goes through the vector unit.  Both queues keep two heads in scalar registers and a third element in flight in a vector
+        // register, so no step waits for an LDS round trip; a new node enters whichever of the internal queue's three places it belongs to directly.
+        // Weights are < 2^31, INF marks an exhausted / not yet filled place.  Same picks, same order as
+        // `if (lq < n && (iq >= m || wt[lq] <= wt[iq])) leaf else internal`.
         constexpr uint32_t INF = 0xFFFFFFFFu;
+        auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         int lq = 0, iq = n, m = n;
-        uint32_t l0 = wt[0], l1 = n > 1 ? wt[1] : INF, i0 = INF, i1 = INF;
+        uint32_t l0 = rfl(wt[0]), l1 = rfl(wt[1]), i0 = INF, i1 = INF;
+        uint32_t l2v = n > 2 ? wt[2] : INF, i2v = INF;
         auto take = [&](uint32_t &w) -> int {
-            if (l0 != INF && l0 <= i0) { w = l0; const int a = lq++; l0 = l1; l1 = (lq + 1 < n) ? wt[lq + 1] : INF; return a; }
-            w = i0; const int a = iq++; i0 = i1; i1 = (iq + 1 < m) ? wt[iq + 1] : INF; return a;
+            if (l0 != INF && l0 <= i0) { w = l0; const int a = lq++; l0 = l1; l1 = rfl(l2v); l2v = (lq + 2 < n) ? wt[lq + 2] : INF; return a; }
+            w = i0; const int a = iq++; i0 = i1; i1 = rfl(i2v); i2v = (iq + 2 < m) ? wt[iq + 2] : INF; return a;
         };
         while (m < nn) {
             uint32_t wa, wb;
             const int a = take(wa), b = take(wb);
             const uint32_t sum = wa + wb;
-            wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m;
-            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum;      // the new node is (or follows) the head of the internal queue
+            if (lane == 0) { wt[m] = sum; parent[a] = (uint16_t)m; parent[b] = (uint16_t)m; }
+            if (iq == m) i0 = sum; else if (iq + 1 == m) i1 = sum; else if (iq + 2 == m) i2v = sum;   // the new node's place among the three heads
             m++;
         }
     }
@@ -788,10 +794,14 @@ void k_seqa(const SegDesc *__restrict__ segs, uint32_t nseg, BlkInfo *__restrict
 // chain, but it touches the sequences once and writes nothing in between; it wins when the launch has more chain waves than the
 // chip has SIMDs, where k_seqa's time is set by 4-cycle VALU issue on the SIMDs that hold two waves and k_seqb's by its 12 bytes of
 // traffic per sequence (10 000 x 1 MiB: 6.4 ms against 4.7 + 2.4 ms; 1 GiB sub-batches and single entries: 3.4 ms against 1.9 + 0.2 ms).
+// GT (batches whose segments hold ONE block each: entries of at most a block -- the many-small-files case): a lane per SEGMENT (bps_log = 0) with the tables
+// read where k_stats left them, in global memory.  With the block slots of a full segment per segment, a 4 KiB entry kept one lane of two waves busy, and
+// both waves copied its three tables to LDS first: 26 ns per entry, the stage's largest cost; its chain is short, and 64 of them per wave hide the loads.
+template <bool GT>
 __global__ __launch_bounds__(64)
 void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__restrict__ seqs, BlkInfo *__restrict__ blk,
            const SegTables *__restrict__ tabs, uint8_t *__restrict__ seqc, uint32_t bps_log) {
-    __shared__ SeqTable tab[SEQ_SEGS_PER_WG][3];
+    __shared__ SeqTable tab[GT ? 1 : SEQ_SEGS_PER_WG][3];
     __shared__ SeqTable ztab;                           // all zero: what an RLE-mode table amounts to
     __shared__ uint32_t lut_ll[64], lut_ml[128];       // code | extra bits << 8 | base << 16 (small values only)
     __shared__ uint32_t ring[8][64];                   // per lane (column) the bitstream's last dwords: see put()
@@ -801,7 +811,7 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&ztab)[i] = 0;
     { uint32_t c = C_LL_CODE[lane]; lut_ll[lane] = c | ((uint32_t)C_LL_BITS[c] << 8) | (C_LL_BASE[c] << 16); }
     for (uint32_t i = lane; i < 128; i += 64) { uint32_t c = C_ML_CODE[i]; lut_ml[i] = c | ((uint32_t)C_ML_BITS[c] << 8) | (C_ML_BASE[c] << 16); }
-    for (uint32_t s = 0; s < segs_wg && seg0 + s < nseg; s++) {
+    for (uint32_t s = 0; !GT && s < segs_wg && seg0 + s < nseg; s++) {
         const uint32_t *srcw = (const uint32_t *)&tabs[seg0 + s].tab[0];
         uint32_t *dstw = (uint32_t *)&tab[s][0];
         for (uint32_t i = lane; i < 3 * sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
@@ -821,7 +831,8 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     const uint32_t tl_ll = T->tlog[0], tl_of = T->tlog[1], tl_ml = T->tlog[2];
     // RLE mode (one symbol, no state bits) runs through the same code on an all-zero table: delta_nb = 0 gives 0 bits, state[0] = 0
     // keeps the state at 0 -- no per-sequence branch on the mode
-    const SeqTable *tll = mll == 1 ? &ztab : &tab[sl][0], *tof = mof == 1 ? &ztab : &tab[sl][1], *tml = mml == 1 ? &ztab : &tab[sl][2];
+    const SeqTable *tll = mll == 1 ? &ztab : (GT ? &T->tab[0] : &tab[sl][0]), *tof = mof == 1 ? &ztab : (GT ? &T->tab[1] : &tab[sl][1]),
+                   *tml = mml == 1 ? &ztab : (GT ? &T->tab[2] : &tab[sl][2]);
     const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
     uint32_t *out32 = (uint32_t *)(seqc + ((size_t)g << sd.blk_log));
     const uint32_t cap_words = (1u << sd.blk_log) / 4;
@@ -1247,10 +1258,10 @@ void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */,
-                          hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+                          hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block /* no segment of the chunk holds more than one block */) {
     // side != null (large batches, the one-kernel sequence coder): the literal coder runs on a second stream NEXT TO the sequence coder -- both only
     // need the tables; k_seq is a few long chains per SIMD (1 250 waves of 64 chains on 1 024 SIMDs: issue slots to spare), k_lit streams memory
-    const uint32_t bps_log = 20u - blk_log;                                 // blocks per full segment (SEG_SIZE = 1 MiB)
+    const uint32_t bps_log = single_block ? 0u : 20u - blk_log;             // block slots per segment: the blocks of a full one (SEG_SIZE = 1 MiB), or the one block every segment has
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
         if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0, blk_log);
@@ -1265,7 +1276,8 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
         // The "literals" interval of the timing is empty then, the "sequences" interval covers both kernels.
         if (ev) (void)hipEventRecord(ev[1], st);
         (void)hipEventRecord(fork, st);
-        hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
+        if (single_block) hipLaunchKernelGGL(k_seq<true>, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
+        else hipLaunchKernelGGL(k_seq<false>, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
         (void)hipStreamWaitEvent(side, fork, 0);
         hipLaunchKernelGGL(k_lit, dim3(nb), dim3(LIT_THREADS), 0, side, segs, blk_seg, lits, blk, tabs, litc, flags, g0, blk_log);
         (void)hipEventRecord(join, side);
@@ -1281,8 +1293,10 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
         const uint32_t wgs = (uint32_t)((((uint64_t)ns << bps_log) + SEQA_BLKS - 1) / SEQA_BLKS);
         hipLaunchKernelGGL(k_seqa, dim3(wgs), dim3(64), 0, st, segs + s0, ns, blk, tabs + s0, (uint16_t *)seqw, bps_log);
         if (nb) hipLaunchKernelGGL(k_seqb, dim3(nb), dim3(SB_THREADS), 0, st, blk_seg, seqs, (const uint16_t *)seqw, blk, tabs, seqc, g0, blk_log);
+    } else if (single_block) {
+        hipLaunchKernelGGL(k_seq<true>, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     } else {
-        hipLaunchKernelGGL(k_seq, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
+        hipLaunchKernelGGL(k_seq<false>, dim3(seq_wgs), dim3(64), 0, st, segs + s0, ns, seqs, blk, tabs + s0, seqc, bps_log);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
 }

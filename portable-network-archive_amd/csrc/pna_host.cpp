@@ -653,7 +653,9 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     // zstd entropy stage, two forms: statistics per block (k_hist) + tables + three-lane state chains (k_seqa) + token-parallel packing (k_seqb) while
     // the chain waves fit the chip's SIMDs (<= 40 960 blocks); beyond, statistics per segment inside k_stats and the one-kernel coder k_seq.  Flags
     // 0x1000 / 0x2000 and option hist_by_block force one.
-    const bool hist_on = algo == PNA_ALGO_ZSTD && !(c->call_flags & 0x1000u) &&
+    // (batches whose segments hold one block each -- entries of at most a block --: statistics per segment and the sequence coder with a lane per segment)
+    const bool single_block = max_len <= bsz;
+    const bool hist_on = algo == PNA_ALGO_ZSTD && !(c->call_flags & 0x1000u) && !single_block &&
                          ((c->call_flags & 0x2000u) || (c->tun.hist_by_block < 0 ? nblk <= 40960u : c->tun.hist_by_block != 0));
     const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + (hist_on ? (size_t)nseg * 448 * 4 : 0);
     if (c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
@@ -730,7 +732,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
             launch_entropy_chunk(c->d_segs, s0, s1 - s0, c->d_blk_seg, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
                                  (uint32_t *)c->seqw.p, c->call_flags, blk_log, hist_on ? c->d_hist : nullptr, est, &c->ev_en[k][1],
-                                 (nch == 1 && c->tun.lit_beside_seq) ? c->aux : nullptr, c->ev_fork, c->ev_join);
+                                 (nch == 1 && c->tun.lit_beside_seq) ? c->aux : nullptr, c->ev_fork, c->ev_join, single_block);
         }
         if (nch > 1) { HIPCHK(c, hipEventRecord(c->ev_join, c->aux)); HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0)); }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[4], st));
