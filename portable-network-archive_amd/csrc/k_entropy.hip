@@ -96,35 +96,6 @@ __device__ uint32_t fse_write_ncount(uint8_t *dst, const int16_t *norm, int nsym
     return bw_close(w, false);
 }
 
-// encoder table from normalised counts; `cell` is scratch of 1 << tlog bytes
-__device__ void fse_build_table(SeqTable *t, const int16_t *norm, int nsym, int tlog, uint8_t *cell, uint16_t *tmp192) {
-    int size = 1 << tlog, high = size - 1;
-    for (int s = 0; s < nsym; s++) if (norm[s] == -1) cell[high--] = (uint8_t)s;
-    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
-    for (int s = 0; s < nsym; s++)
-        for (int i = 0; i < norm[s]; i++) { cell[pos] = (uint8_t)s; do { pos = (pos + step) & mask; } while (pos > high); }
-    // one pass over the cells in ascending order fills state[cum[s] .. cum[s]+n_s)
-    uint16_t *fill = tmp192, *first = tmp192 + 64;
-    // first cell (lowest index) of every symbol
-    for (int s = 0; s < nsym; s++) first[s] = 0xFFFF;
-    for (int u = size - 1; u >= 0; u--) first[cell[u]] = (uint16_t)(size + u);
-    int cum = 0;
-    for (int s = 0; s < nsym; s++) {
-        int n = norm[s] == -1 ? 1 : norm[s];
-        SeqSym y; y.delta_nb = 0; y.delta_find = 0; y.first_state = 0;
-        if (n > 0) {
-            int maxbits = (n == 1) ? tlog : tlog - (int)hb((uint32_t)(n - 1));
-            y.delta_nb = (uint32_t)((maxbits << 16) - (n << maxbits));
-            y.delta_find = (int16_t)(cum - n);
-            y.first_state = first[s];
-        }
-        t->sym[s] = y;
-        fill[s] = (uint16_t)cum;
-        cum += n;
-    }
-    for (int u = 0; u < size; u++) { const int s = cell[u]; t->state[fill[s]++] = (uint16_t)(size + u); }
-}
-
 // The same table built by a whole WAVE (all 64 lanes call it; norm, cell, tmp192 in LDS -- tmp192[0 .. 127] is scratch here --; nsym <= 64, tlog <= 8).
 // Same cells, same states as the serial form above, which walks the table three times on one lane:
 //   * the low-probability symbols (norm = -1) take the top cells in symbol order: a ballot and a rank;
@@ -285,74 +256,104 @@ __device__ int huf_build_lens(const uint32_t *count, uint8_t *lens, uint16_t *or
     return sh[2] ? -1 : n;
 }
 
-// Huffman tree description (direct 4-bit weights or FSE-compressed weights); returns bytes (0 = not representable)
-__device__ uint32_t huf_write_tree(uint8_t *dst, const uint8_t *lens, int max_sym, int maxbits, uint8_t *wts, uint8_t *tmp,
-                                   SeqTable *scratch_tab, uint8_t *cell, uint16_t *tmp192) {
-    int nw = max_sym;
-    for (int s = 0; s < nw; s++) wts[s] = lens[s] ? (uint8_t)(maxbits + 1 - lens[s]) : 0;
-    uint32_t fse_size = 0;
-    {
-        // (cnt and norm live in LDS, behind the 128 halfwords fse_build_table uses of tmp192: as local arrays with run-time indices they would be
-        // private memory, i.e. a trip to L2 / HBM per access on this one lane)
-        uint32_t *cnt = (uint32_t *)(tmp192 + 144); for (int i = 0; i < 16; i++) cnt[i] = 0;
-        int maxw = 0, distinct = 0; uint32_t maxc = 0;
-        for (int i = 0; i < nw; i++) { cnt[wts[i]]++; if (wts[i] > maxw) maxw = wts[i]; }
-        for (int v = 0; v <= maxw; v++) { if (cnt[v]) distinct++; if (cnt[v] > maxc) maxc = cnt[v]; }
+// Huffman tree description (direct 4-bit weights or FSE-compressed weights) BY A WHOLE WAVE; returns its length (0 = not representable) on every lane.
+// On one lane this was the longest serial chain of k_stats (4 KiB entries: 5 of the kernel's 8 ms): the weights' table built cell by cell and ~120 tANS
+// steps of two dependent LDS reads each.  Here the lanes compute the weights and count them; lane 0 normalises and writes the table's description
+// (<= 13 symbols); fse_build_table_wave builds the table; then the TWO interleaved tANS chains (even / odd weight indices, from the last weight down) run in
+// scalar registers -- the symbols' entries and the state table (<= 64 states) sit on the lanes, one value each, and a step is a handful of v_readlane /
+// SALU instructions instead of LDS round trips; every step leaves (bits, count) on the lane of its weight; a suffix sum over the counts places them
+// and the lanes OR them into the stream.  Same bytes as the serial form (oracle/zstd_model.c huf_write_tree).
+__device__ __forceinline__ uint32_t huf_write_tree_wave(uint8_t *dst, const uint8_t *lens, int max_sym_v, int maxbits_v, uint8_t *wts, uint8_t *tmp /* 320 bytes, 4-byte aligned */,
+                                        SeqTable *tab, uint8_t *cell, uint16_t *tmp192, uint32_t *sh /* 4 words */, uint32_t lane) {
+    // (wave-uniform values are told to be: the chains below then run on the scalar unit -- as vector loops under exec masks they were a third of the kernel)
+    const int nw = __builtin_amdgcn_readfirstlane(max_sym_v), maxbits = __builtin_amdgcn_readfirstlane(maxbits_v);
+    // (cnt and norm live in LDS, behind the 128 halfwords fse_build_table_wave uses of tmp192)
+    uint32_t *cnt = (uint32_t *)(tmp192 + 144);
+    int16_t *norm = (int16_t *)(tmp192 + 128);
+    uint32_t *tmp32 = (uint32_t *)tmp;
+    if (lane < 16) cnt[lane] = 0;
+    for (uint32_t i = lane; i < 80; i += 64) tmp32[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t wv[4];                                             // the weight of symbol 64 r + lane (0 from nw on)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int sy = 64 * r + (int)lane;
+        const uint32_t l = sy < nw ? (uint32_t)lens[sy] : 0u;
+        wv[r] = l ? (uint32_t)maxbits + 1u - l : 0u;
+        if (sy < nw) { wts[sy] = (uint8_t)wv[r]; atomicAdd(&cnt[wv[r]], 1u); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int maxw = 0, distinct = 0; uint32_t maxc = 0, kind = 0, hs = 0; int tlog = 0;
+        for (int v = 0; v < 16; v++) if (cnt[v]) { maxw = v; distinct++; if (cnt[v] > maxc) maxc = cnt[v]; }
         if (distinct >= 2 && nw >= 2 && maxc > 1) {
-            int tlog = (int)hb((uint32_t)(nw - 1)) - 2, minlog = 5;
+            int minlog = 5;
+            tlog = (int)hb((uint32_t)(nw - 1)) - 2;
             while ((1 << minlog) < distinct) minlog++;
             if (tlog < minlog) tlog = minlog;
             if (tlog > 6) tlog = 6;
-            int16_t *norm = (int16_t *)(tmp192 + 128);
             fse_normalize(cnt, maxw + 1, (uint32_t)nw, tlog, norm);
-            uint32_t hs = fse_write_ncount(tmp + 1, norm, maxw + 1, tlog);
-            fse_build_table(scratch_tab, norm, maxw + 1, tlog, cell, tmp192);
-            BitW w; bw_init(w, tmp + 1 + hs);
-            int i = nw; uint32_t s1, s2;
-            auto enc = [&](uint32_t st, int sy) -> uint32_t {
-                const SeqSym y = scratch_tab->sym[sy];
-                uint32_t nb = (st + y.delta_nb) >> 16;
-                bw_add(w, st, nb);
-                return scratch_tab->state[(int)(st >> nb) + y.delta_find];
-            };
-            if (nw & 1) { s1 = scratch_tab->sym[wts[--i]].first_state; s2 = scratch_tab->sym[wts[--i]].first_state; s1 = enc(s1, wts[--i]); }
-            else { s2 = scratch_tab->sym[wts[--i]].first_state; s1 = scratch_tab->sym[wts[--i]].first_state; }
-            while (i > 0) { s2 = enc(s2, wts[--i]); s1 = enc(s1, wts[--i]); }
-            bw_add(w, s2, (uint32_t)tlog); bw_add(w, s1, (uint32_t)tlog);
-            uint32_t bs = bw_close(w, true);
-            if (hs + bs < 128) { fse_size = hs + bs; tmp[0] = (uint8_t)fse_size; }
+            hs = fse_write_ncount(tmp + 1, norm, maxw + 1, tlog);
+            kind = 1;
         }
+        sh[0] = kind; sh[1] = (uint32_t)tlog; sh[2] = hs; sh[3] = (uint32_t)(maxw + 1);
     }
-    uint32_t direct = (nw <= 128) ? (uint32_t)(nw + 1) / 2 : 0;
-    if (fse_size && (!direct || fse_size < direct)) { for (uint32_t i = 0; i < 1 + fse_size; i++) dst[i] = tmp[i]; return 1 + fse_size; }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[0]), tlog = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[1]),
+                   hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh[2]);
+    const int nsym = __builtin_amdgcn_readfirstlane((int)sh[3]);
+    uint32_t fse_size = 0;
+    if (kind) {
+        fse_build_table_wave(tab, norm, nsym, (int)tlog, cell, tmp192, lane);
+        __builtin_amdgcn_wave_barrier();
+        const SeqSym y = tab->sym[(int)lane < nsym ? lane : 0u];
+        const uint32_t Ydnb = y.delta_nb, Ydf = (uint32_t)(uint16_t)y.delta_find | ((uint32_t)y.first_state << 16);
+        const uint32_t ST = tab->state[lane & ((1u << tlog) - 1u)];
+        // The two chains, from the last weight down: odd indices carry state s2, even ones s1 (whatever nw's parity: the serial form's start-up amounts to
+        // that); each chain's first symbol only sets its state.  Everything is wave-uniform: the weight, its symbol's entry and the next state come through
+        // v_readlane, the bits are shifted into a 64-bit scalar accumulator and leave 32 at a time for the stream (lane 0's store) -- ~25 instructions a
+        // step, against ~80 with the bits parked on the weights' lanes and placed by a scan afterwards.
+        uint32_t s1 = 0, s2 = 0;
+        uint64_t acc = 0; uint32_t nacc = 0, wout = (8u * (1u + hs)) >> 5;                 // (the stream starts at byte 1 + hs of tmp: accumulate from that byte's word on)
+        { const uint32_t b0 = (8u * (1u + hs)) & 31u; acc = (uint64_t)(tmp32[wout] & ((1u << b0) - 1u)); nacc = b0; }      // the header bytes sharing the first word
+        auto emit = [&](uint32_t v, uint32_t n) {
+            acc |= (uint64_t)v << nacc; nacc += n;
+            if (nacc >= 32u) { if (lane == 0) tmp32[wout] = (uint32_t)acc; wout++; acc >>= 32; nacc -= 32u; }
+        };
+        auto wgt = [&](int i) -> uint32_t {                          // (i is uniform: one of the four reads executes)
+            if (i < 64) return (uint32_t)__builtin_amdgcn_readlane((int)wv[0], i);
+            if (i < 128) return (uint32_t)__builtin_amdgcn_readlane((int)wv[1], i - 64);
+            if (i < 192) return (uint32_t)__builtin_amdgcn_readlane((int)wv[2], i - 128);
+            return (uint32_t)__builtin_amdgcn_readlane((int)wv[3], i - 192);
+        };
+        auto step = [&](int i, uint32_t &sc) {
+            const uint32_t w = wgt(i);
+            const uint32_t dnb = (uint32_t)__builtin_amdgcn_readlane((int)Ydnb, (int)w), df = (uint32_t)__builtin_amdgcn_readlane((int)Ydf, (int)w);
+            const uint32_t nb = (sc + dnb) >> 16;
+            emit(sc & ((1u << nb) - 1u), nb);
+            sc = (uint32_t)__builtin_amdgcn_readlane((int)ST, (int)(sc >> nb) + (int)(int16_t)(df & 0xFFFFu));
+        };
+        auto first = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)Ydf, (int)wgt(i)) >> 16; };
+        int i = nw - 1;
+        if (i & 1) { s2 = first(i); s1 = first(i - 1); } else { s1 = first(i); s2 = first(i - 1); }
+        i -= 2;
+        if (i >= 0 && !(i & 1)) { step(i, s1); i--; }              // (down to an odd index: pairs from here)
+        for (; i >= 1; i -= 2) { step(i, s2); step(i - 1, s1); }
+        const uint32_t m = (1u << tlog) - 1u;
+        emit(s2 & m, tlog); emit(s1 & m, tlog); emit(1u, 1u);
+        if (lane == 0 && nacc) tmp32[wout] = (uint32_t)acc;
+        const uint32_t tbits = (wout << 5) + nacc - 8u * (1u + hs);                         // bits of the stream, the closing one included
+        const uint32_t bs = (tbits + 7u) >> 3;
+        __builtin_amdgcn_wave_barrier();
+        if (hs + bs < 128) { fse_size = hs + bs; if (lane == 0) tmp[0] = (uint8_t)fse_size; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t direct = (nw <= 128) ? (uint32_t)(nw + 1) / 2 : 0;
+    if (fse_size && (!direct || fse_size < direct)) { for (uint32_t i = lane; i < 1 + fse_size; i += 64) dst[i] = tmp[i]; return 1 + fse_size; }
     if (!direct) return 0;
-    dst[0] = (uint8_t)(127 + nw);
-    for (int i = 0; i < nw; i += 2) dst[1 + i / 2] = (uint8_t)((wts[i] << 4) | (i + 1 < nw ? wts[i + 1] : 0));
+    if (lane == 0) dst[0] = (uint8_t)(127 + nw);
+    for (int i = 2 * (int)lane; i < nw; i += 128) dst[1 + i / 2] = (uint8_t)((wts[i] << 4) | (i + 1 < nw ? wts[i + 1] : 0));
     return 1 + direct;
-}
-
-// one of LL / OF / ML: mode + description + encoder table; returns false when no valid table exists
-__device__ bool seq_build(SegTables *T, int which, const uint32_t *count, uint32_t nseq, int alphabet,
-                          const int16_t *def, int def_n, int def_log, uint32_t flags, uint8_t *cell, uint16_t *tmp192) {
-    int maxs = 0, distinct = 0;
-    for (int s = 0; s < alphabet; s++) if (count[s]) { maxs = s; distinct++; }
-    T->desc_len[which] = 0;
-    if (distinct == 1 && nseq > 2) { T->desc[which][0] = (uint8_t)maxs; T->desc_len[which] = 1; T->tlog[which] = 0; T->mode[which] = 1; return true; }
-    bool def_ok = maxs < def_n;
-    if (!(flags & F_FSE) || (nseq < 64 && def_ok)) {
-        if (!def_ok) return false;
-        fse_build_table(&T->tab[which], def, def_n, def_log, cell, tmp192); T->tlog[which] = (uint32_t)def_log; T->mode[which] = 0; return true;
-    }
-    int tlog = (int)hb(nseq - 1) - 2, minlog = 5;
-    while ((1 << minlog) < distinct) minlog++;
-    if (tlog < minlog) tlog = minlog;
-    if (tlog > (int)SEQ_MAX_LOG) tlog = (int)SEQ_MAX_LOG;
-    int16_t *norm = (int16_t *)(tmp192 + 128);      // (LDS, not a local array: see huf_write_tree)
-    fse_normalize(count, maxs + 1, nseq, tlog, norm);
-    T->desc_len[which] = fse_write_ncount(T->desc[which], norm, maxs + 1, tlog);
-    fse_build_table(&T->tab[which], norm, maxs + 1, tlog, cell, tmp192);
-    T->tlog[which] = (uint32_t)tlog; T->mode[which] = 2;
-    return true;
 }
 
 // seq_build by a whole wave: lane 0 decides the mode, normalises and writes the description (short loops over <= 53 symbols), the encoder table is
@@ -455,7 +456,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     __shared__ uint16_t parent[512];
     __shared__ uint8_t  lens[256];
     __shared__ uint8_t  wts[256];
-    __shared__ uint8_t  tmp[320];
+    __shared__ __attribute__((aligned(4))) uint8_t tmp[320];
     __shared__ uint8_t  cell[4][256];            // one scratch set per table-building task (waves 0..3)
     __shared__ __attribute__((aligned(16))) uint16_t tmp192[4][192];
     __shared__ uint32_t hsh[8], wbase_s[HUF_MAX + 2], cntw_s[HUF_MAX + 2], crun_s[HUF_MAX + 2], sq_sh[4][4];
@@ -567,9 +568,9 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         }
         T->huf_code[s2] = v;
     }
-    if (lane != 0) return;
-    const uint32_t tl = huf_write_tree(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell[0], tmp192[0]);
-    T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tl = huf_write_tree_wave(T->tree, lens, max_sym, maxbits, wts, tmp, &wtab, cell[0], tmp192[0], sq_sh[0], lane);
+    if (lane == 0) { T->tree_len = tl; T->max_sym = (uint32_t)max_sym; T->maxbits = (uint32_t)maxbits; T->huf_ok = tl > 0; }
 }
 
 // ------------------------------------------------------------------ k_lit
