@@ -356,6 +356,25 @@ __device__ __forceinline__ uint32_t huf_write_tree_wave(uint8_t *dst, const uint
     return 1 + direct;
 }
 
+// The three PREDEFINED tables (RFC 8878 3.1.1.3.2.2) are the same for every segment that takes them -- with fewer than 64 sequences, i.e. nearly every small
+// entry --: built once per device (launch_default_tables, from pna_gpu_init) and COPIED into a segment's tables (240 words by the wave) instead of built there
+// again (10^5 .. 10^6 small entries: three table builds per entry were most of what k_stats did besides the literal code).
+__device__ SeqTable g_def_tab[3];
+__global__ __launch_bounds__(192)
+void k_deftab() {
+    __shared__ uint8_t cell[3][256];
+    __shared__ __attribute__((aligned(16))) uint16_t tmp192[3][192];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int16_t *def = wave == 0 ? C_LL_DEF : (wave == 1 ? C_OF_DEF : C_ML_DEF);
+    const int n = wave == 0 ? 36 : (wave == 1 ? 29 : 53), lg = wave == 1 ? 5 : 6;
+    int16_t *norm = (int16_t *)(tmp192[wave] + 128);
+    if ((int)lane < n) norm[lane] = def[lane];
+    for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) ((uint32_t *)&g_def_tab[wave])[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    fse_build_table_wave(&g_def_tab[wave], norm, n, lg, cell[wave], tmp192[wave], lane);
+}
+void launch_default_tables(hipStream_t st) { hipLaunchKernelGGL(k_deftab, dim3(1), dim3(192), 0, st); }
+
 // seq_build by a whole wave: lane 0 decides the mode, normalises and writes the description (short loops over <= 53 symbols), the encoder table is
 // then built by all lanes (fse_build_table_wave).  sh: four LDS words of the wave.
 __device__ bool seq_build_wave(SegTables *T, int which, const uint32_t *count, uint32_t nseq, int alphabet,
@@ -386,8 +405,12 @@ __device__ bool seq_build_wave(SegTables *T, int which, const uint32_t *count, u
     }
     __builtin_amdgcn_wave_barrier();
     const int kind = (int)sh[0], nsym = (int)sh[1], tl = (int)sh[2];
-    if (kind == 1) { if ((int)lane < nsym) norm[lane] = def[lane]; __builtin_amdgcn_wave_barrier(); }
-    if (kind) fse_build_table_wave(&T->tab[which], norm, nsym, tl, cell, tmp192, lane);
+    if (kind == 1) {                                            // the predefined table: a copy of the device's (which = LL, OF, ML in g_def_tab's order)
+        const uint32_t *srcw = (const uint32_t *)&g_def_tab[which];
+        uint32_t *dstw = (uint32_t *)&T->tab[which];
+        for (uint32_t i = lane; i < sizeof(SeqTable) / 4; i += 64) dstw[i] = srcw[i];
+    } else if (kind) fse_build_table_wave(&T->tab[which], norm, nsym, tl, cell, tmp192, lane);
+    (void)def;
     return sh[3] != 0;
 }
 
@@ -443,12 +466,15 @@ void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
 }
 
 // PRE: the histograms were gathered by k_hist (`hist`, 448 counters per segment); otherwise this workgroup walks the segment's blocks itself
-template <bool PRE>
+// LEAN (batches of single-block segments, i.e. many small entries): two copies of the literal histogram and one of the code histograms instead of eight and
+// four -- 13 KiB of LDS instead of 22, eleven workgroups per CU instead of seven; the kernel's time there is wave 0's chain of dependent steps x the entries in flight.
+template <bool PRE, bool LEAN>
 __global__ __launch_bounds__(ST_THREADS)
 void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
              const BlkInfo *__restrict__ blk, SegTables *__restrict__ tabs, uint32_t flags, const uint32_t *__restrict__ hist) {
-    __shared__ uint32_t h_lit[8][256];
-    __shared__ uint32_t h_seq[3][4][64];
+    constexpr uint32_t HL = LEAN ? 2 : 8, HS = LEAN ? 1 : 4;
+    __shared__ uint32_t h_lit[HL][256];
+    __shared__ uint32_t h_seq[3][HS][64];
     __shared__ uint32_t count[256];
     __shared__ uint32_t scount[3][64];
     __shared__ uint16_t order[256];
@@ -467,8 +493,8 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     SegTables *T = tabs + blockIdx.x;
     const uint32_t nblk = seg_nblk(sd);
 
-    for (uint32_t i = tid; i < 8 * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
-    for (uint32_t i = tid; i < 3 * 4 * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
+    for (uint32_t i = tid; i < HL * 256; i += ST_THREADS) (&h_lit[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 3 * HS * 64; i += ST_THREADS) (&h_seq[0][0][0])[i] = 0;
     // code look-ups of the small literal / match lengths from LDS (a per-lane index into __constant__ memory is a global load)
     if (tid < 64) s_llc[tid] = C_LL_CODE[tid];
     if (tid < 128) s_mlc[tid] = C_ML_CODE[tid];
@@ -483,7 +509,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         nseq_seg += nseq;
         const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
-        uint32_t *hl = h_lit[tid & 7];
+        uint32_t *hl = h_lit[tid & (HL - 1)];
         const uint32_t n16 = nlit >> 4;
         for (uint32_t i = tid; i < n16; i += ST_THREADS) {
             uint4 v = ((const uint4 *)bl)[i];
@@ -499,9 +525,9 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
             const uint64_t s = bs[i];
             const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
-            atomicAdd(&h_seq[0][tid & 3][llv < 64 ? (uint32_t)s_llc[llv] : hb(llv) + 19], 1u);
-            atomicAdd(&h_seq[1][tid & 3][hb(seq_off(s) + 3)], 1u);
-            atomicAdd(&h_seq[2][tid & 3][mb < 128 ? (uint32_t)s_mlc[mb] : hb(mb) + 36], 1u);
+            atomicAdd(&h_seq[0][tid & (HS - 1)][llv < 64 ? (uint32_t)s_llc[llv] : hb(llv) + 19], 1u);
+            atomicAdd(&h_seq[1][tid & (HS - 1)][hb(seq_off(s) + 3)], 1u);
+            atomicAdd(&h_seq[2][tid & (HS - 1)][mb < 128 ? (uint32_t)s_mlc[mb] : hb(mb) + 36], 1u);
         }
     }
     __syncthreads();
@@ -512,8 +538,8 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         __syncthreads();
         for (uint32_t s = 0; s < 36; s++) nseq_seg += scount[0][s];             // every sequence has one literal-length code
     } else {
-        { uint32_t c = 0; for (int k = 0; k < 8; k++) c += h_lit[k][tid]; count[tid] = c; }
-        if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63; scount[w][s] = h_seq[w][0][s] + h_seq[w][1][s] + h_seq[w][2][s] + h_seq[w][3][s]; }
+        { uint32_t c = 0; for (uint32_t k = 0; k < HL; k++) c += h_lit[k][tid]; count[tid] = c; }
+        if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63, c = 0; for (uint32_t k = 0; k < HS; k++) c += h_seq[w][k][s]; scount[w][s] = c; }
     }
     __syncthreads();
     // ---- tables: wave 0 builds the literal code, lane 0 of waves 1..3 one sequence table each (LL, OF, ML), concurrently
@@ -1266,9 +1292,11 @@ void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const u
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
         if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0, blk_log);
-        hipLaunchKernelGGL(k_stats<true>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
-    } else
-        hipLaunchKernelGGL(k_stats<false>, dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_stats<true, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
+    } else if (single_block)
+        hipLaunchKernelGGL((k_stats<false, true>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((k_stats<false, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
     const bool forked = side && !hist && nb;
     if (forked) {

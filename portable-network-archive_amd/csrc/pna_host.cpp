@@ -50,6 +50,15 @@ extern "C" int pna_gpu_init(pna_gpu_ctx **out, int device_id, uint32_t flags) {
     c->call_flags = c->flags;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
     for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return PNA_E_NODEVICE; }
+    {   // the predefined sequence tables of this device (k_entropy.hip g_def_tab): built by the first context on it
+        static std::mutex mu; static bool built[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        if (device_id >= 0 && device_id < 64 && !built[device_id]) {
+            launch_default_tables(c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { delete c; return PNA_E_HIP; }
+            built[device_id] = true;
+        }
+    }
     *out = c;
     return PNA_OK;
 }

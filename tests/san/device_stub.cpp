@@ -14,6 +14,7 @@ namespace pna {
 
 void launch_lz(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, hipEvent_t, uint32_t *, const LzParseGrid *) {}
 void launch_lz_small(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uint8_t *, BlkInfo *, uint4 *, uint32_t, uint32_t, hipStream_t, uint32_t *, uint32_t, const LzParseGrid *, bool) {}
+void launch_default_tables(hipStream_t) {}
 uint32_t lz_gtab_log() { return 19; }
 void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
                           uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t, hipEvent_t *, hipStream_t, hipEvent_t, hipEvent_t, bool) {}
