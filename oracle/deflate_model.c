@@ -167,6 +167,7 @@ size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, si
     dst[op++] = 0x78; dst[op++] = stored_only ? 0x01 : 0x9C;
     size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
     if (table_entries < p->small_slots) table_entries = p->small_slots;
+    if (table_entries < p->mid_slots) table_entries = p->mid_slots;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     const uint32_t BS = pna_blk_size(p);
     uint32_t maxblk = PNA_SEG_SIZE / BS;

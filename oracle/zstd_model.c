@@ -29,11 +29,14 @@ void pna_zstd_default_params(pna_zstd_params *p) {
     p->lookahead = 1024; p->flags = PNA_F_HUF | PNA_F_FSE | PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3 | PNA_F_REP; p->max_len = 0; p->region = 256;
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
     p->blk_log = 0; p->len_word_max = 36; p->tab3 = 1;
-    p->mtile = 0; p->small_seg = 4096; p->small_slots = 2048; p->small_tile = 256;
+    p->mtile = 0; p->small_seg = 4096; p->small_slots = 2048; p->small_tile = 256; p->mid_seg = 16384; p->mid_slots = 2048;
 }
 const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp) {
-    if (!p->small_seg || seg_len > p->small_seg) return p;
-    *tmp = *p; tmp->hash_log = p->small_slots; tmp->tab3 = 0; tmp->mtile = p->small_tile;
+    uint32_t slots = 0;
+    if (p->small_seg && seg_len <= p->small_seg) slots = p->small_slots;
+    else if (p->small_seg && p->mid_seg && seg_len <= p->mid_seg) slots = p->mid_slots;
+    if (!slots) return p;
+    *tmp = *p; tmp->hash_log = slots; tmp->tab3 = 0; tmp->mtile = p->small_tile;
     return tmp;
 }
 
@@ -665,6 +668,7 @@ size_t pna_zstd_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_
     if (n == 0) { static const uint8_t e[9] = {0x28,0xB5,0x2F,0xFD,0x20,0x00,0x01,0x00,0x00}; memcpy(dst, e, 9); return 9; }
     size_t table_entries = p->hash_log <= 31 ? (size_t)1 << p->hash_log : p->hash_log;
     if (table_entries < p->small_slots) table_entries = p->small_slots;
+    if (table_entries < p->mid_slots) table_entries = p->mid_slots;
     uint32_t *table = (uint32_t *)malloc(sizeof(uint32_t) * table_entries);
     const uint32_t BS = pna_blk_size(p);
     uint32_t maxblk = PNA_SEG_SIZE / BS;

@@ -57,6 +57,8 @@ typedef struct {
                            * table of small_slots 32-bit entries (not packed), sub-tiles of small_tile positions (one wave's 256).  With the large geometry a
                            * segment of one tile never finds a match (its positions do not see each other): 4 KiB text entries 1.77 -> 2.07 (zlib -6: 2.02). */
     uint32_t small_slots, small_tile;
+    uint32_t mid_seg, mid_slots;   /* a second tier of the same geometry: segments above small_seg and of at most mid_seg bytes (0 = none) with a table of mid_slots entries
+                                    * (the device gives both tiers the same table and sizes the window by the tier: 8 KiB text entries 1.97 -> 2.16, 16 KiB 2.16 -> 2.24; zlib -6: 2.12 / 2.22) */
 } pna_zstd_params;
 /* the parameters segment `seg_len` bytes long runs with: p itself, or *tmp = p with the small geometry */
 const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp);

@@ -79,7 +79,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);   // block size of the batch = stride of the per-block arrays
-    if (MODE != 2 && (flags & FLAG_HAS_SMALL) && seg_len <= SMALL_SEG) return;         // (uniform) a short segment: k_lzms's (pna_dev.h; MODE 2 parses its words like any)
+    if (MODE != 2 && (flags & FLAG_HAS_SMALL) && seg_len <= MID_SEG) return;         // (uniform) a short segment: k_lzms's (pna_dev.h; MODE 2 parses its words like any)
     uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);

@@ -106,7 +106,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
-    if ((flags & FLAG_HAS_SMALL) && seg_len <= SMALL_SEG) return;     // (uniform) a short segment: k_lzms's
+    if ((flags & FLAG_HAS_SMALL) && seg_len <= MID_SEG) return;       // (uniform) a short segment: k_lzms's
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
     // The words: one per position, length | offset.  With the table in LDS (GLOG = 0) they take THREE bytes -- 5 bits for the length (0, or length - 5
     // for 6 .. 36: adopted lengths beyond 36 are clamped, FLAG_LEN36 tells the one-kernel form to do the same) and 19 for the offset (MAX_OFF_W3) --:
@@ -372,28 +372,35 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 // candidates: every offset is inside), a table of SMALL_SLOTS 32-bit entries, and the walk in sub-tiles of 256 positions -- four per lane, as in k_lzm --
 // whose look-ups see the inserts of the sub-tiles before them: 12.4 KiB of LDS, twelve segments per CU.  Same hash, entries, match step, adoption rounds
 // and words as k_lzm (the parse kernel does not know the difference); oracle/zstd_model.c: mtile / small_seg.  4 KiB text entries: ratio 1.77 -> 2.07.
+// Two tiers (pna_dev.h), two launches: segments of at most SMALL_SEG bytes, and those of SMALL_SEG + 1 .. MID_SEG bytes; a launch takes the segments of
+// (seg_min, seg_max] and has LDS for the table and a window of seg_max bytes (dynamic: 12.4 KiB per wave for the first tier, 16.5 .. 24.5 for the second).
+constexpr uint32_t LZMS_PAD = 64;
+__host__ __device__ constexpr uint32_t lzms_lds(uint32_t seg_max) { return SMALL_SLOTS * 4 + LZMS_PAD + ((seg_max + 255u) & ~255u) + 64; }
 template <bool STRONG, bool W3>
 __global__ __launch_bounds__(64)
-void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t *__restrict__ pbuf, uint32_t blk0) {
-    constexpr uint32_t RW = 256, PAD = 64;
-    __shared__ __attribute__((aligned(16))) uint8_t winb[PAD + SMALL_SEG + 64];     // 64 bytes in front of the segment (read, never used), the segment, zeros behind it
-    __shared__ __attribute__((aligned(16))) uint32_t table[SMALL_SLOTS];
+void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t *__restrict__ pbuf, uint32_t blk0, uint32_t seg_min, uint32_t seg_max) {
+    constexpr uint32_t RW = 256, PAD = LZMS_PAD, SLOTS = SMALL_SLOTS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *table = (uint32_t *)lds;
+    uint8_t *winb = lds + SLOTS * 4;                            // 64 bytes in front of the segment (read, never used), the segment, zeros behind it
     const uint32_t lane = threadIdx.x;
     const SegDesc sd = segs[blockIdx.x];
     const uint32_t seg_len = sd.len;
-    if (seg_len == 0 || seg_len > SMALL_SEG) return;
+    if (seg_len <= seg_min || seg_len > seg_max) return;
     const uint8_t *seg = src + sd.src_off;
     const uint32_t blk_log = sd.blk_log;
     uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
     const uint32_t *win32 = (const uint32_t *)(winb + PAD);
-    for (uint32_t i = lane; i < SMALL_SLOTS / 4; i += 64) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane; i < SLOTS / 4; i += 64) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
     if (lane < PAD / 16) ((uint4 *)winb)[lane] = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lane * 16; i < SMALL_SEG + 64; i += 64 * 16) *(uint4 *)(winb + PAD + i) = i < seg_len ? load_chunk(seg, i, seg_len) : make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane * 16; i < ((seg_len + 15u) & ~15u) + 64; i += 64 * 16) *(uint4 *)(winb + PAD + i) = i < seg_len ? load_chunk(seg, i, seg_len) : make_uint4(0, 0, 0, 0);
     __syncthreads();
+    const uint32_t bsz = 1u << blk_log;                                             // (a segment of the second tier may span two blocks of the smallest size: matches end with their block)
     for (uint32_t t0 = 0; t0 < seg_len; t0 += RW) {
-        const uint32_t t1 = seg_len - t0 < RW ? seg_len : t0 + RW;
+        const uint32_t blk_end = ((t0 & ~(bsz - 1)) + bsz < seg_len) ? (t0 & ~(bsz - 1)) + bsz : seg_len;
+        const uint32_t t1 = blk_end - t0 < RW ? blk_end : t0 + RW;
         const uint32_t q0 = t0 + 4 * lane;
         uint32_t D[9], Dm1, Dm2 = 0;
         {
@@ -411,13 +418,13 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
             const uint32_t q = q0 + j;
             hv[j] = (q < t1) && (q + 8 <= seg_len);
             const uint32_t h32 = QW(0, j) * 0x9E3779B1u + (QW(1, j) & 0xFFFFu) * 0x85EBCA6Bu;
-            hsh[j] = __umulhi(h32, SMALL_SLOTS);
+            hsh[j] = __umulhi(h32, SLOTS);
             tag[j] = (h32 >> 6) & TAG_MASK;
             const uint32_t e = table[hsh[j]], ent = hv[j] ? e : 0u;
             const uint32_t c1 = ent >> TAG_BITS;
             off[j] = ((c1 > 8) & ((ent & TAG_MASK) == tag[j])) ? q + 1 - c1 : 0u;
         }
-        const bool edge = seg_len - t0 < RW + CAP1;                                 // (uniform) only the last sub-tiles can run into the segment's end
+        const bool edge = blk_end - t0 < RW + CAP1;                                 // (uniform) only a block's last sub-tiles can run into its end
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t l = 0, bk = 0;
@@ -447,7 +454,7 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
                     const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
                     l = 16 + first_diff16(y0, y1, y2, y3);
                 }
-                if (edge) { const uint32_t lim = seg_len - q; l = l < lim ? l : lim; }
+                if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
                 if (l < MIN_MATCH) l = 0;
                 const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;           // the 4 bytes before q (q - 1 in the top byte)
                 const uint32_t xk = bqj ^ bc;
@@ -554,7 +561,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     const uint32_t gb = blk0 + blockIdx.x;
     const SegDesc sd = segs[blk_seg[gb]];
     const uint32_t seg_len = sd.len;
-    if ((flags & FLAG_SMALL_ONLY) && seg_len > SMALL_SEG) return;     // (uniform) the pass over the short segments behind a one-kernel launch
+    if ((flags & FLAG_SMALL_ONLY) && seg_len > MID_SEG) return;       // (uniform) the pass over the short segments behind a one-kernel launch
     const uint8_t *seg = src + sd.src_off;
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);
     const uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
@@ -896,7 +903,9 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
     (void)attr_set;
     constexpr bool W3 = GLOG == 0;
     if (!(flags & FLAG_ALL_SMALL)) hipLaunchKernelGGL((k_lzm<CT, STRONG, GLOG, WLOG, FARP, TAB3>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, flags, max_off, pbuf, blk0, gtab);
-    if (flags & FLAG_HAS_SMALL) hipLaunchKernelGGL((k_lzms<STRONG, W3>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);     // the short segments, which k_lzm skipped
+    if (flags & FLAG_TIER1) hipLaunchKernelGGL((k_lzms<STRONG, W3>), dim3(nseg), dim3(64), lzms_lds(SMALL_SEG), st, src, segs, flags, pbuf, blk0, 0u, SMALL_SEG);     // the short segments, which k_lzm skipped
+    if (flags & FLAG_TIER2) { const uint32_t mx = 8192u + 4096u * ((flags >> FLAG_T2_SHIFT) & 3u);
+                              hipLaunchKernelGGL((k_lzms<STRONG, W3>), dim3(nseg), dim3(64), lzms_lds(mx), st, src, segs, flags, pbuf, blk0, SMALL_SEG, mx); }
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (!pg || pg->nb == 0) return;                            // (no grid: the caller wants the match kernel alone; a run of empty entries has segments and no blocks)
     if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
@@ -933,10 +942,13 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
 void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                      uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, const LzParseGrid *pg, bool w3) {
     const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
-    if (strong) { if (w3) hipLaunchKernelGGL((k_lzms<true, true>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);
-                  else hipLaunchKernelGGL((k_lzms<true, false>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0); }
-    else { if (w3) hipLaunchKernelGGL((k_lzms<false, true>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0);
-           else hipLaunchKernelGGL((k_lzms<false, false>), dim3(nseg), dim3(64), 0, st, src, segs, flags, pbuf, blk0); }
+#define LZMS(ST_, W3_) do { \
+        if (flags & FLAG_TIER1) hipLaunchKernelGGL((k_lzms<ST_, W3_>), dim3(nseg), dim3(64), lzms_lds(SMALL_SEG), st, src, segs, flags, pbuf, blk0, 0u, SMALL_SEG); \
+        if (flags & FLAG_TIER2) { const uint32_t mx = 8192u + 4096u * ((flags >> FLAG_T2_SHIFT) & 3u); \
+                                  hipLaunchKernelGGL((k_lzms<ST_, W3_>), dim3(nseg), dim3(64), lzms_lds(mx), st, src, segs, flags, pbuf, blk0, SMALL_SEG, mx); } } while (0)
+    if (strong) { if (w3) LZMS(true, true); else LZMS(true, false); }
+    else { if (w3) LZMS(false, true); else LZMS(false, false); }
+#undef LZMS
     if (!pg || pg->nb == 0) return;
     const uint32_t pf = flags | FLAG_SMALL_ONLY;
 #define LZP_SMALL(CT_, LZD_) do { if (w3) hipLaunchKernelGGL((k_lzp<CT_, LZD_, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0); \

@@ -53,8 +53,14 @@ constexpr uint32_t FLAG_TAB3 = 0x10000u;  // (with FLAG_W32 / FLAG_W16, even ins
 // find a match) run the SMALL geometry: one wave per segment (k_lzms, k_lz_split.hip), a table of SMALL_SLOTS 32-bit entries, look-ups and inserts alternating per
 // 256 positions; the parse is the common one.  oracle/zstd_model.h: small_seg, small_slots, small_tile.
 constexpr uint32_t SMALL_SEG = 4096, SMALL_SLOTS = 2048;
-constexpr uint32_t FLAG_HAS_SMALL = 0x20000u;   // launch flag of the LZ kernels: the launch may hold short segments -- k_lzms takes them, the other match kernels skip them
+// ... and a second tier of it: segments of 4 097 .. MID_SEG bytes -- a segment of two to four of the large geometry's tiles finds nothing in its first one (8 KiB text
+// entries 1.93 -> 2.12, 16 KiB 2.14 -> 2.24; above 16 KiB the large table wins).  Same table size (4 096 slots were + 1 % of ratio for half the waves per CU); the tiers
+// differ in the LDS their window takes, which a launch sizes by its longest segment of the tier (FLAG_T2_SHIFT: 8, 12 or 16 KiB).  oracle: mid_seg, mid_slots.
+constexpr uint32_t MID_SEG = 16384, MID_SLOTS = SMALL_SLOTS;
+constexpr uint32_t FLAG_T2_SHIFT = 22;          // two bits: the second tier's longest segment is at most 8 / 12 / 16 KiB (0, 1, 2)
+constexpr uint32_t FLAG_HAS_SMALL = 0x20000u;   // launch flag of the LZ kernels: the launch may hold short segments (at most MID_SEG bytes) -- k_lzms takes them, the other match kernels skip them
 constexpr uint32_t FLAG_SMALL_ONLY = 0x40000u;  // (k_lzp) parse the blocks of short segments only: the pass behind a one-kernel launch, which skipped them
+constexpr uint32_t FLAG_TIER1 = 0x100000u, FLAG_TIER2 = 0x200000u;   // (with FLAG_HAS_SMALL) the launch holds segments of the first / second tier: which of k_lzms's two forms to launch
 constexpr uint32_t FLAG_ALL_SMALL = 0x80000u;   // every segment of the launch is short (or empty): the large geometry's kernels are not launched at all
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy

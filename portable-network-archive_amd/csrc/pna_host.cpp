@@ -572,7 +572,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     auto print_marks = [&]() { if (c->tun.trace && !host_marks.empty()) { fprintf(stderr, "[pna sub-batch] %zu entries, host:", e1 - e0); for (auto &m : host_marks) fprintf(stderr, "  %s %.2f", m.first, m.second); fprintf(stderr, " ms\n"); } };
     const size_t ne_all = e1 - e0;
     const unsigned host_nt = host_loop_threads(ne_all);
-    struct PlanPart { uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0; uint32_t sg = 0, bk = 0, un = 0; bool misaligned = false, any_empty = false; };
+    struct PlanPart { uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0, n_mid = 0, max_mid = 0; uint32_t sg = 0, bk = 0, un = 0; bool misaligned = false, any_empty = false; };
     std::vector<PlanPart> pp(host_nt);
     par_ranges(ne_all, host_nt, [&](unsigned t, size_t a, size_t b) {
         PlanPart q;
@@ -581,14 +581,15 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
             q.in_total += len; q.nseg_est += len ? (len + SEG_SIZE - 1) / SEG_SIZE : 1; q.max_len = std::max<uint64_t>(q.max_len, len);
             q.misaligned |= (src_off[e] & 15) != 0; q.any_empty |= len == 0;
             // SHORT segments (pna_dev.h SMALL_SEG): an entry of at most that many bytes, or the last segment of a longer one
-            q.n_short += (len > 0 && (((len - 1) & (SEG_SIZE - 1)) + 1) <= SMALL_SEG) ? 1u : 0u;
+            const uint64_t last = len ? ((len - 1) & (SEG_SIZE - 1)) + 1 : 0;
+            q.n_short += (last > 0 && last <= SMALL_SEG) ? 1u : 0u; if (last > SMALL_SEG && last <= MID_SEG) { q.n_mid++; q.max_mid = std::max(q.max_mid, last); }
         }
         pp[t] = q;
     });
-    uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0;
+    uint64_t in_total = 0, nseg_est = 0, max_len = 0, n_short = 0, n_mid = 0, max_mid = 0;
     bool any_empty = false;
     for (const PlanPart &q : pp) {
-        in_total += q.in_total; nseg_est += q.nseg_est; max_len = std::max(max_len, q.max_len); any_empty |= q.any_empty; n_short += q.n_short;
+        in_total += q.in_total; nseg_est += q.nseg_est; max_len = std::max(max_len, q.max_len); any_empty |= q.any_empty; n_short += q.n_short; n_mid += q.n_mid; max_mid = std::max(max_mid, q.max_mid);
         if (q.misaligned) return fail(c, PNA_E_INVAL, "entry offset not 16-byte aligned");
     }
     // an upper bound of every payload of the sub-batch when the entries are small and plain (k_frame's wave-per-entry form takes those; 0: no such bound)
@@ -684,7 +685,8 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     c->lzm_used = 0; c->lzm_nl.clear();
     const bool defl = algo == PNA_ALGO_DEFLATE;
     // the short segments' geometry (k_lzms): a launch flag tells the large geometry's kernels to skip them; a sub-batch of short segments only launches none of those
-    const uint32_t small_fl = (c->tun.small_geometry && n_short) ? (FLAG_HAS_SMALL | (max_len <= SMALL_SEG ? FLAG_ALL_SMALL : 0u)) : 0u;
+    const uint32_t small_fl = (c->tun.small_geometry && (n_short || n_mid))
+        ? (FLAG_HAS_SMALL | (n_short ? FLAG_TIER1 : 0u) | (n_mid ? FLAG_TIER2 | ((max_mid <= 8192 ? 0u : (max_mid <= 12288 ? 1u : 2u)) << FLAG_T2_SHIFT) : 0u) | (max_len <= MID_SEG ? FLAG_ALL_SMALL : 0u)) : 0u;
     mark("plan queued");
     if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     int nch = 1;

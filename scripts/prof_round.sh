@@ -15,15 +15,25 @@ echo trace done
 python3 bench.py --framing solid --files 8192 > "$OUT/bench_solid.json" 2> "$OUT/bench_solid.err"
 python3 bench.py --algo deflate --files 2048 > "$OUT/bench_deflate.json" 2> "$OUT/bench_deflate.err"
 echo solid deflate done
-python3 bench.py --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
-python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k_1m.json" 2> "$OUT/bench_deflate_4k_1m.err"
-echo small done
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-ctr > "$OUT/bench_aes_ctr.json" 2> "$OUT/bench_aes_ctr.err"
 python3 bench.py --no-cpu-baseline --no-end-to-end --encrypt aes-gcm > "$OUT/bench_aes_gcm.json" 2> "$OUT/bench_aes_gcm.err"
 for lv in 1 2 7 19; do python3 bench.py --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_level$lv.json" 2> "$OUT/bench_level$lv.err"; done
-python3 bench.py --algo zstd --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_zstd_4k.json" 2> "$OUT/bench_zstd_4k.err"
 for lv in 1 9; do python3 bench.py --algo deflate --files 2048 --no-cpu-baseline --no-end-to-end --level $lv > "$OUT/bench_deflate_level$lv.json" 2> "$OUT/bench_deflate_level$lv.err"; done
 echo levels done
+fi
+if [ "$PART" = all ] || [ "$PART" = c ]; then
+# many small entries (BASELINE.json configs[4]'s shape and its zstd counterpart; kind 1 = random-text, kind 0 = enwik-style text)
+python3 bench.py --algo deflate --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k.json" 2> "$OUT/bench_deflate_4k.err"
+python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 > "$OUT/bench_deflate_4k_1m.json" 2> "$OUT/bench_deflate_4k_1m.err"
+python3 bench.py --algo deflate --files 262144 --file-mib 0.00390625 --kind 0 --no-cpu-baseline --no-end-to-end > "$OUT/bench_deflate_4k_text.json" 2> "$OUT/bench_deflate_4k_text.err"
+echo deflate small done
+python3 bench.py --algo zstd --files 262144 --file-mib 0.00390625 --kind 1 > "$OUT/bench_zstd_4k.json" 2> "$OUT/bench_zstd_4k.err"
+python3 bench.py --algo zstd --files 1000000 --file-mib 0.00390625 --kind 1 > "$OUT/bench_zstd_4k_1m.json" 2> "$OUT/bench_zstd_4k_1m.err"
+python3 bench.py --algo zstd --files 262144 --file-mib 0.00390625 --kind 0 --no-cpu-baseline --no-end-to-end > "$OUT/bench_zstd_4k_text.json" 2> "$OUT/bench_zstd_4k_text.err"
+echo zstd small done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_deflate_4k_1m" -o kt -- python3 bench.py --algo deflate --files 1000000 --file-mib 0.00390625 --kind 1 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-verify > "$OUT/kt_deflate_4k_1m.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_zstd_4k" -o kt -- python3 bench.py --files 262144 --file-mib 0.00390625 --kind 1 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-verify > "$OUT/kt_zstd_4k.log" 2>&1
+echo small traces done
 fi
 if [ "$PART" = all ] || [ "$PART" = b ]; then
 python3 scripts/stream_rate.py 4096 > "$OUT/stream_rate.txt" 2>&1

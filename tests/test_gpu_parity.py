@@ -563,14 +563,17 @@ def test_deflate_many_small_entries(gpu_ctx, pna, codec):
 
 
 def _short_cases(codec):
-    """Entries whose segments are SHORT (at most 4 096 bytes: the small geometry of the match finder, k_lzms) around the threshold, entries whose LAST
-    segment is short behind long ones, and ordinary ones in between -- one batch, so that both geometries' kernels run side by side."""
+    """Entries whose segments are SHORT (at most 4 096 bytes, and 4 097 .. 16 384: the two tiers of the small geometry of the match finder, k_lzms) around the
+    thresholds, entries whose LAST segment is short behind long ones, and ordinary ones in between -- one batch, so that all geometries' kernels run side by side."""
     t = codec.corpus_file(0, 77, (1 << 20) + 5000)
     cases = {"empty": b"", "one": b"z", "seven": b"abcdefg", "eight": b"abcdefgh", "nine": b"abcdefghi", "t255": t[:255], "t256": t[:256], "t257": t[:257],
              "t511": t[100:611], "t1000": t[:1000], "t4095": t[:4095], "t4096": t[:4096], "t4097": t[:4097], "t5000": t[:5000], "t70000": t[:70000],
              "seg+100": t[:(1 << 20) + 100], "seg+4096": t[:(1 << 20) + 4096], "seg+4097": t[:(1 << 20) + 4097],
              "rep4096": (t[:300] * 14)[:4096], "zeros4096": bytes(4096), "noise3000": codec.corpus_file(2, 5, 3000), "words4096": codec.corpus_file(1, 8, 4096),
-             "ab": b"ab" * 2000, "period7": bytes((i * 37) & 0xFF for i in range(7)) * 500}
+             "ab": b"ab" * 2000, "period7": bytes((i * 37) & 0xFF for i in range(7)) * 500,
+             # the second tier (4 097 .. 16 384 bytes) and its upper edge
+             "t8191": t[:8191], "t8192": t[:8192], "t8193": t[:8193], "t12000": t[300:12300], "t16383": t[:16383], "t16384": t[:16384], "t16385": t[:16385],
+             "seg+9000": t[:(1 << 20) + 9000], "rep16384": (t[:700] * 24)[:16384], "noise9000": codec.corpus_file(2, 6, 9000), "zeros16384": bytes(16384)}
     for i in range(40):
         cases[f"mix{i:02d}"] = codec.corpus_file(i & 1, 500 + i, 37 + 97 * i)
     return cases
