@@ -36,9 +36,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-def encoder_text(algo: str, level: int) -> str:
+def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
     """The level set behind the (clamped) `level` in words (pna_host.cpp level_flags / set_call_level)."""
     defl = algo == "deflate"
+    if not (defl and level == 0) and entry_bytes <= 16384:
+        # segments of at most 16 KiB: the short-segment geometry (DESIGN.md 4-short), whatever the level's table
+        strong = level >= 9 if defl else (level >= 3 or level == 0)
+        fast = level <= 3 if defl else (level < 0 or level == 1)
+        parse = "greedy+lazy3" if fast else ("greedy+lazy3 with backward adoption (3 rounds, 7 back bytes)" if strong else "greedy+lazy3 with backward adoption (2 rounds)")
+        return (f"GPU encoder, short-segment geometry: one wave per entry, 2048-entry LDS hash table" + ("" if fast else " over the even positions") +
+                f", the whole entry as look-back, look-ups and inserts alternating per 256 positions, min_match 6, {parse}, 4096-position parse tiles")
     if defl and level == 0:
         return "GPU encoder: level 0 = Compression::none(): stored blocks only"
     fast = level <= 3 if defl else (level < 0 or level == 1)
@@ -650,7 +657,7 @@ def main() -> None:
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"pna create, {files_all} x {file_len} B synthetic {'enwik-style' if args.kind == 0 else 'random'} text"
                                    + (f" ({n_files} per GPU, contiguous index ranges)" if world > 1 else "")
-                                   + f", Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} level {level} ({encoder_text(args.algo, level)}), inputs resident in HBM, "
+                                   + f", Compression::{'ZStandard' if args.algo == 'zstd' else 'Deflate'} level {level} ({encoder_text(args.algo, level, file_len if args.framing != 'solid' else 1 << 20)}), inputs resident in HBM, "
                                    + ("output = complete .pna archive bytes in HBM (chunk framing + CRC-32 on device)" if args.framing == "archive"
                                       else "--solid: inner STORE records serialised + one compressed stream + SDAT framing, all in HBM" if args.framing == "solid"
                                       else "output = packed compressed entry streams in HBM")
@@ -660,7 +667,8 @@ def main() -> None:
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "gathered_archive_verified": gathered_ok,    # N > 1: the archive gathered on rank 0 read back through the extract driver
-            "roofline": {"bound": "hbm", "kernel": "k_lzm" if split else "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # (entries of at most 16 KiB: the match kernel of the short-segment geometry, k_lzms, takes every segment)
+            "roofline": {"bound": "hbm", "kernel": ("k_lzms" if (file_len <= 16384 and args.framing != "solid") else "k_lzm") if split else "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing, "k_lzm" if split else "k_lz"),
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on this build's LZ kernels "

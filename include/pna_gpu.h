@@ -79,6 +79,9 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "tab3" [PNA_TAB3]                     the hash table of the zstd light / default / high sets: 1 (default) PACKED, three 21-bit entries (even position + 2-bit tag) per
  *                                         64-bit LDS word -- 49 062 slots next to the 32 KiB window, 55 206 next to the 16 KiB one; 0: one 32-bit entry per slot
  *                                         (32 704 / 36 800: round 3's table).  Other bytes (ratio 2.847 against 2.759 on text at the default level), same format
+ *   "small_geometry" [PNA_SMALL_GEOMETRY] 1 (default): segments of at most 16 KiB -- small entries, the tail of longer ones -- are matched by one wave each with look-ups and inserts
+ *                                         alternating per 256 positions (k_lzms) instead of by a workgroup per 4 096: such a segment's first tile finds nothing in the large
+ *                                         geometry (4 KiB text entries: ratio 1.77 -> 2.04, libzstd -3: 2.05).  0: the large geometry for every segment.  Other bytes, same format
  *   "single_frame" [PNA_SINGLE_FRAME]     zstd: 1 = an entry's payload is ONE frame (one frame header, the 1 MiB segments' blocks behind each other, matches never
  *                                         cross a segment start) as the reference's encoder writes (lib/src/compress/zstandard.rs: one Encoder per entry);
  *                                         0 (default) = a frame per 1 MiB segment, which this library's decoder takes in parallel.  3 + 0..2 bytes per segment apart
