@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ v4u ld16u(const uint8_t *p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }   // 16 bytes at any byte address
+
 namespace pna {
 
 __constant__ uint16_t D_LEN_BASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
@@ -374,16 +377,19 @@ void k_dstats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seq
 }
 
 // ------------------------------------------------------------------ Adler-32 halves of one block's input
-__global__ __launch_bounds__(256)
+// T = 256: a workgroup per block; T = 64 (batches of many small entries: blocks of a few KiB): a wave per block, the sums reduced by lane shuffles -- no LDS,
+// no barriers (the workgroup form spends eight barriers on a 4 KiB block's 256 partial sums)
+template <uint32_t T>
+__global__ __launch_bounds__(T)
 void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, BlkInfo *__restrict__ blk) {
-    __shared__ unsigned long long r1[256], r2[256];
+    __shared__ unsigned long long r1[T == 64 ? 1 : T], r2[T == 64 ? 1 : T];
     const uint32_t tid = threadIdx.x, g = blockIdx.x;
     const SegDesc sd = segs[blk_seg[g]];
     const uint32_t bsz = 1u << sd.blk_log, b0 = (g - sd.blk_base) * bsz, n = sd.len - b0 < bsz ? sd.len - b0 : bsz;
     const uint8_t *p = src + sd.src_off + b0;
     unsigned long long s1 = 0, s2 = 0;
     // S1 = sum d_i ; S2 = sum (n - i) d_i   (16-byte vector loads; src offsets are 16-byte aligned)
-    for (uint32_t i = tid * 16; i < n; i += 256 * 16) {
+    for (uint32_t i = tid * 16; i < n; i += T * 16) {
         if (i + 16 <= n) {
             const uint4 v = *(const uint4 *)(p + i);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -391,9 +397,18 @@ void k_adler(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
             for (uint32_t k = 0; k < 16; k++) { const uint32_t d = (w[k >> 2] >> (8 * (k & 3))) & 0xFF; s1 += d; s2 += (unsigned long long)(n - i - k) * d; }
         } else for (uint32_t k = i; k < n; k++) { const uint32_t d = p[k]; s1 += d; s2 += (unsigned long long)(n - k) * d; }
     }
+    if (T == 64) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(s1 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)s1, o);
+            s2 += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(s2 >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)s2, o);
+        }
+        if (tid == 0) { blk[g].adler_a = (uint32_t)((1 + s1) % ADLER_P); blk[g].adler_b = (uint32_t)((n + s2) % ADLER_P); }
+        return;
+    }
     r1[tid] = s1; r2[tid] = s2;
     __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) { if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; } __syncthreads(); }
+    for (uint32_t s = T / 2; s > 0; s >>= 1) { if (tid < s) { r1[tid] += r1[tid + s]; r2[tid] += r2[tid + s]; } __syncthreads(); }
     if (tid == 0) { blk[g].adler_a = (uint32_t)((1 + r1[0]) % ADLER_P); blk[g].adler_b = (uint32_t)((n + r2[0]) % ADLER_P); }
 }
 
@@ -626,9 +641,17 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
     const uint32_t b0 = b * bsz, bl_len = sd.len - b0 < bsz ? sd.len - b0 : bsz;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
     uint8_t *out = dst + seg_off[sidx] + bi.out_off;
+    const uint32_t T = blockDim.x;                               // 256, or 64 for the batches of many small blocks (a wave per block: four times the blocks in flight)
+    // n bytes from p to o: the destination's unaligned head and tail byte by byte, its aligned middle as 16-byte stores of unaligned 16-byte loads
+    auto copy = [&](uint8_t *o, const uint8_t *p, uint32_t n) {
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u), h = head < n ? head : n, mid = (n - h) >> 4;
+        if (tid < h) o[tid] = p[tid];
+        for (uint32_t i = tid; i < mid; i += T) *(v4u *)(o + h + 16 * i) = ld16u(p + h + 16 * i);
+        for (uint32_t i = h + 16 * mid + tid; i < n; i += T) o[i] = p[i];
+    };
     if (bi.plan & 1) {
         const uint8_t *p = outc + ((size_t)g << sd.blk_log);
-        for (uint32_t i = tid; i < bi.lit_body; i += 256) out[i] = p[i];
+        copy(out, p, bi.lit_body);
         if (!last && tid < 4) out[bi.lit_body + tid] = (tid < 2) ? 0x00 : 0xFF;
     } else {
         const uint8_t *p = src + sd.src_off + b0;
@@ -639,7 +662,7 @@ void k_dwrite(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs,
                 out[pos] = (last && o + k >= bl_len) ? 1 : 0;
                 out[pos + 1] = (uint8_t)k; out[pos + 2] = (uint8_t)(k >> 8); out[pos + 3] = (uint8_t)~k; out[pos + 4] = (uint8_t)(~k >> 8);
             }
-            for (uint32_t i = tid; i < k; i += 256) out[pos + 5 + i] = p[o + i];
+            copy(out + pos + 5, p + o, k);
             pos += 5 + k;
         }
         if (!last && tid < 5) out[pos + tid] = (tid < 3) ? 0x00 : 0xFF;
@@ -684,7 +707,8 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
         if (wave_per_seg) hipLaunchKernelGGL(k_dstats<64>, dim3(nseg), dim3(64), 0, st, segs, seqs, lits, blk, tabs);
         else hipLaunchKernelGGL(k_dstats<256>, dim3(nseg), dim3(256), 0, st, segs, seqs, lits, blk, tabs);
     }
-    if (nblk) hipLaunchKernelGGL(k_adler, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
+    if (nblk && wave_per_seg) hipLaunchKernelGGL(k_adler<64>, dim3(nblk), dim3(64), 0, st, src, segs, blk_seg, blk);
+    else if (nblk) hipLaunchKernelGGL(k_adler<256>, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (ev) (void)hipEventRecord(ev[1], st);
     if (nblk && !stored_only) hipLaunchKernelGGL(k_dblock, dim3(nblk), dim3(DB_THREADS), 0, st, segs, blk_seg, seqs, lits, blk, ctab, tabs, outc, dbg);
@@ -696,8 +720,8 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
 
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
-                          uint8_t *dst, hipStream_t st, bool stored_only) {
-    if (nblk) hipLaunchKernelGGL(k_dwrite, dim3(nblk), dim3(256), 0, st, src, segs, blk_seg, blk, seg_off, outc, dst);
+                          uint8_t *dst, hipStream_t st, bool stored_only, bool small_blocks) {
+    if (nblk) hipLaunchKernelGGL(k_dwrite, dim3(nblk), dim3(small_blocks ? 64 : 256), 0, st, src, segs, blk_seg, blk, seg_off, outc, dst);
     hipLaunchKernelGGL(k_dfinal, dim3((nentry + 255) / 256), dim3(256), 0, st, segs, entry_seg, nentry, blk, seg_off, seg_size, dst, stored_only ? 1u : 0u);
 }
 

@@ -35,7 +35,7 @@ void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nse
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only, bool wave_per_seg);
 void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                           const uint64_t *seg_off, const uint64_t *seg_size, const uint8_t *outc, const uint32_t *entry_seg, uint32_t nentry,
-                          uint8_t *dst, hipStream_t st, bool stored_only);
+                          uint8_t *dst, hipStream_t st, bool stored_only, bool small_blocks);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block);

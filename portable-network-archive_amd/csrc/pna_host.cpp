@@ -861,7 +861,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         launch_layout((FrameDesc *)c->fr_desc.p, (uint8_t *)c->fr_blob.p, c->d_entry_seg, (const uint64_t *)c->seg_off.p, (uint32_t)ne, nseg, out_base,
                       (uint64_t *)c->fr_segdst.p, d_ent, d_ent + ne + 1, st);
         if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const uint64_t *)c->fr_segdst.p, (const uint64_t *)c->seg_size.p,
-                                       (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st, c->call_stored);
+                                       (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st, c->call_stored, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
         else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (const uint64_t *)c->fr_segdst.p,
                           (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
@@ -1053,7 +1053,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     } else if (!early_write && out_base + total > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                                    d_segdst, (const uint64_t *)c->seg_size.p, (const uint8_t *)c->litc.p, c->d_entry_seg,
-                                   (uint32_t)(e1 - e0), wbase, st, c->call_stored);
+                                   (uint32_t)(e1 - e0), wbase, st, c->call_stored, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
     else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
                  (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st);

@@ -88,7 +88,7 @@ void lz_read_stamps(unsigned long long *out) { memset(out, 0, 8 * sizeof *out); 
 void launch_deflate_stage1(const uint8_t *, const SegDesc *, uint32_t, const uint32_t *, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, const uint4 *, DeflTables *,
                            uint8_t *, uint64_t *, uint64_t *, hipStream_t, hipEvent_t *, uint32_t, bool, bool) { nostub("deflate"); }
 void launch_deflate_write(const uint8_t *, const SegDesc *, const uint32_t *, uint32_t, const BlkInfo *, const uint64_t *, const uint64_t *, const uint8_t *, const uint32_t *,
-                          uint32_t, uint8_t *, hipStream_t, bool) { nostub("deflate"); }
+                          uint32_t, uint8_t *, hipStream_t, bool, bool) { nostub("deflate"); }
 void launch_frame_verify(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t, uint32_t) { nostub("frame_verify"); }
 void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint32_t, hipStream_t) { nostub("zdec"); }
 void launch_zparse_big_a(ZFrame *, ZFrameX *, const uint32_t *, uint32_t, const uint8_t *, ZBlock *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
