@@ -1146,8 +1146,14 @@ void k_scan(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_
 
 // ------------------------------------------------------------------ k_write : one workgroup per block
 constexpr uint32_t WR_THREADS = 256;
-__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t tid) {
-    for (uint32_t i = tid; i < n; i += WR_THREADS) dst[i] = src[i];
+// n bytes by the workgroup's T threads: the destination's unaligned head and tail byte by byte, its aligned middle as 16-byte stores of unaligned 16-byte loads
+// (byte by byte a wave moved 64 bytes per instruction; the streams of a 128 KiB block are 10 .. 40 KiB)
+typedef uint32_t wr_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t tid, uint32_t T) {
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u), h = head < n ? head : n, mid = (n - h) >> 4;
+    if (tid < h) dst[tid] = src[tid];
+    for (uint32_t i = tid; i < mid; i += T) { wr_v4u v; __builtin_memcpy(&v, src + h + 16 * i, 16); *(wr_v4u *)(dst + h + 16 * i) = v; }
+    for (uint32_t i = h + 16 * mid + tid; i < n; i += T) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(WR_THREADS)
@@ -1155,7 +1161,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
              const BlkInfo *__restrict__ blk, const SegTables *__restrict__ tabs, const uint64_t *__restrict__ seg_off,
              const uint8_t *__restrict__ lits, const uint8_t *__restrict__ litc, const uint8_t *__restrict__ seqc,
              uint8_t *__restrict__ dst) {
-    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x, NT = blockDim.x;   // 256 threads, or 64 for batches of many small blocks (a wave per block: four times the blocks in flight)
     const uint32_t sidx = blk_seg[g];
     const SegDesc sd = segs[sidx];
     const SegTables *T = tabs + sidx;
@@ -1171,7 +1177,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
     const uint32_t csz = bi.out_size - 3;
     if (tid < 3) { uint32_t hdr = last | ((bi.plan & 1 ? 2u : 0u) << 1) | (csz << 3); out[tid] = (uint8_t)(hdr >> (8 * tid)); }
     out += 3;
-    if (!(bi.plan & 1)) { copy_bytes(out, src + sd.src_off + b0, bl_len, tid); return; }
+    if (!(bi.plan & 1)) { copy_bytes(out, src + sd.src_off + b0, bl_len, tid, NT); return; }
     const uint32_t nlit = bi.nlit, nseq = bi.nseq;
     const uint8_t *bl = lits + ((size_t)g << sd.blk_log);
     uint32_t pos = 0;
@@ -1194,8 +1200,8 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
             else h = type | (3u << 2) | ((uint64_t)nlit << 4) | (comp << 22);
             for (uint32_t i = 0; i < lh; i++) out[i] = (uint8_t)(h >> (8 * i));
         }
-        copy_bytes(out + lh, T->tree, ts, tid);
-        copy_bytes(out + lh + ts, litc + ((size_t)g << sd.blk_log), hs, tid);
+        copy_bytes(out + lh, T->tree, ts, tid, NT);
+        copy_bytes(out + lh + ts, litc + ((size_t)g << sd.blk_log), hs, tid, NT);
         pos = lh + ts + hs;
     } else {
         uint32_t h = raw_lit_hdr(nlit);
@@ -1204,7 +1210,7 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
             else if (h == 2) { out[0] = (uint8_t)((1 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); }
             else { out[0] = (uint8_t)((3 << 2) | ((nlit & 15) << 4)); out[1] = (uint8_t)(nlit >> 4); out[2] = (uint8_t)(nlit >> 12); }
         }
-        copy_bytes(out + h, bl, nlit, tid);
+        copy_bytes(out + h, bl, nlit, tid, NT);
         pos = h + nlit;
     }
     // sequences section
@@ -1223,8 +1229,8 @@ void k_write(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, 
             out[pos] = (uint8_t)((m[0] << 6) | (m[1] << 4) | (m[2] << 2));
         }
         pos += 1;
-        if (carry) for (int k = 0; k < 3; k++) { copy_bytes(out + pos, T->desc[k], T->desc_len[k], tid); pos += T->desc_len[k]; }
-        copy_bytes(out + pos, seqc + ((size_t)g << sd.blk_log), bi.seq_bits, tid);
+        if (carry) for (int k = 0; k < 3; k++) { copy_bytes(out + pos, T->desc[k], T->desc_len[k], tid, NT); pos += T->desc_len[k]; }
+        copy_bytes(out + pos, seqc + ((size_t)g << sd.blk_log), bi.seq_bits, tid, NT);
     }
 }
 
@@ -1337,9 +1343,9 @@ void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTabl
 }
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
-                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st) {
+                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st, bool small_blocks) {
     if (any_empty) hipLaunchKernelGGL(k_empty, dim3((nseg + 255) / 256), dim3(256), 0, st, segs, nseg, seg_off, dst);
-    if (nblk) hipLaunchKernelGGL(k_write, dim3(nblk), dim3(WR_THREADS), 0, st, src, segs, blk_seg, blk, tabs, seg_off, lits, litc, seqc, dst);
+    if (nblk) hipLaunchKernelGGL(k_write, dim3(nblk), dim3(small_blocks ? 64 : WR_THREADS), 0, st, src, segs, blk_seg, blk, tabs, seg_off, lits, litc, seqc, dst);
 }
 
 } // namespace pna

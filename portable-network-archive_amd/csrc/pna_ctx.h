@@ -44,7 +44,7 @@ void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTabl
                  uint32_t flags, hipStream_t st);
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk, const BlkInfo *blk,
                   const SegTables *tabs, const uint64_t *seg_off, const uint8_t *lits, const uint8_t *litc,
-                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st);
+                  const uint8_t *seqc, uint8_t *dst, bool any_empty, hipStream_t st, bool small_blocks);
 void lz_read_stamps(unsigned long long *out);
 void launch_frame(const FrameDesc *fd, uint32_t nentry, const uint8_t *blob, const CrcTabs *ct, uint8_t *dst, uint64_t cap16,
                   uint32_t fend_crc, const char ty[4], bool with_fend, hipStream_t st, uint32_t max_payload);

@@ -863,7 +863,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         if (defl) launch_deflate_write(d_src, c->d_segs, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const uint64_t *)c->fr_segdst.p, (const uint64_t *)c->seg_size.p,
                                        (const uint8_t *)c->litc.p, c->d_entry_seg, (uint32_t)ne, d_dst, st, c->call_stored, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
         else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p, (const SegTables *)c->tabs.p, (const uint64_t *)c->fr_segdst.p,
-                          (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st);
+                          (const uint8_t *)c->lits.p, (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, d_dst, any_empty, st, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
         if (timed) HIPCHK(c, hipEventRecord(c->ev[6], st));
         launch_frame((const FrameDesc *)c->fr_desc.p, (uint32_t)ne, (const uint8_t *)c->fr_blob.p, (const CrcTabs *)c->crc_tabs.p,
                      d_dst, (uint64_t)dst_cap & ~(uint64_t)15, frame_fend_crc(), "FDAT", true, st, frame_max_payload);
@@ -1056,7 +1056,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
                                    (uint32_t)(e1 - e0), wbase, st, c->call_stored, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
     else launch_write(d_src, c->d_segs, nseg, c->d_blk_seg, nblk, (const BlkInfo *)c->blk.p,
                  (const SegTables *)c->tabs.p, d_segdst, (const uint8_t *)c->lits.p,
-                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st);
+                 (const uint8_t *)c->litc.p, (const uint8_t *)c->seqc.p, wbase, any_empty, st, /* a wave per block */ max_len <= 32768 && nseg >= 4096);
     if (!spread.empty()) {
         // entries of several FDAT chunks / GCM segments: save the compact payloads, then put the pieces behind the first one at their places
         std::vector<PlaceDescH> pd(spread.size());

@@ -28,7 +28,7 @@ void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *, const SegTables 
     seg_off[nseg] = pos;
 }
 void launch_write(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *, uint32_t, const BlkInfo *, const SegTables *,
-                  const uint64_t *seg_off, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *dst, bool, hipStream_t) {
+                  const uint64_t *seg_off, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *dst, bool, hipStream_t, bool) {
     for (uint32_t s = 0; s < nseg; s++) {
         const SegDesc &sd = segs[s];
         uint8_t *o = dst + seg_off[s];
