@@ -631,6 +631,28 @@ def test_deflate_wave_per_entry_form_equals_the_model(gpu_ctx, pna, codec):
     assert all(zlib.decompress(o) == e for o, e in zip(outs[::9], ents[::9]))
 
 
+def test_zstd_many_small_entries_equal_the_model(gpu_ctx, pna, codec):
+    """Batches of >= 4 096 entries of at most 32 KiB take the small-entry forms of the zstd path together: the short-segment match kernel, k_stats with lean
+    histograms and the wave-built tree description, predefined tables copied from the device's, the sequence coder with a lane per segment, the write kernel
+    with a wave per block.  Every stream must be the model's -- ragged sizes, one-symbol entries (RLE literals), noise (raw blocks), text -- and decode."""
+    import random
+    rnd = random.Random(11)
+    sizes = [0, 1, 2, 5, 8, 9, 63, 64, 255, 256, 257, 1000, 4095, 4096, 4097, 8192, 16384, 16385, 32768] + [rnd.choice((rnd.randrange(1, 700), rnd.randrange(700, 9000), 4096, 12000)) for _ in range(4200)]
+    ents = []
+    for i, n in enumerate(sizes):
+        k = i % 5
+        if k == 3: ents.append(bytes([97 + i % 5]) * n)
+        elif k == 4: ents.append(rnd.randbytes(n))
+        else: ents.append(codec.corpus_file(k & 1, 900 + i, n) if n else b"")
+    for level in (3, 1):
+        outs = gpu_ctx.compress_batch(ents, level=level)
+        p = codec.params_for_level(level)
+        bad = [i for i, (o, e) in enumerate(zip(outs, ents)) if o != codec.model_compress(e, p)]
+        assert not bad, (level, bad[:8], [sizes[i] for i in bad[:8]])
+        assert all(codec.zstd_decompress(o, len(e)) == e for o, e in zip(outs[::7], ents[::7]))
+    assert gpu_ctx.decompress_batch(outs[:600], [len(e) for e in ents[:600]]) == ents[:600]
+
+
 @pytest.mark.parametrize("algo_name", ["zstd", "deflate"])
 def test_archive_assembled_in_hbm_equals_host_framing(gpu_ctx, pna, pf, codec, algo_name):
     """pna_gpu_create_archive_device: payloads written at their archive offsets + k_frame (prefix, FDAT CRC, FEND) must give
