@@ -422,7 +422,10 @@ static int lz_small_pass(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *se
     for (uint32_t a = s0; a < s1;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
-        while (b < s1 && (b < nseg_all ? segs[b].blk_base : nblk) - b0 + bps <= run_blocks) b++;
+        {   // the first segment behind `a` whose blocks no longer fit the run (block bases grow with the index: a binary search -- 10^6 small entries made the linear walk a millisecond)
+            uint32_t hi = s1;
+            while (b < hi) { const uint32_t mid = b + (hi - b) / 2; if ((mid < nseg_all ? segs[mid].blk_base : nblk) - b0 + bps <= run_blocks) b = mid + 1; else hi = mid; }
+        }
         const uint32_t b1 = b < nseg_all ? segs[b].blk_base : nblk;
         if (c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4)) {
             (void)hipGetLastError();
@@ -468,7 +471,10 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
     for (uint32_t a = s0; a < s1 && !fused;) {
         const uint32_t b0 = segs[a].blk_base;
         uint32_t b = a + 1;
-        while (b < s1 && (b < nseg_all ? segs[b].blk_base : nblk) - b0 + bps <= split_blocks) b++;
+        {   // the first segment behind `a` whose blocks no longer fit the run (block bases grow with the index: a binary search -- 10^6 small entries made the linear walk a millisecond)
+            uint32_t hi = s1;
+            while (b < hi) { const uint32_t mid = b + (hi - b) / 2; if ((mid < nseg_all ? segs[mid].blk_base : nblk) - b0 + bps <= split_blocks) b = mid + 1; else hi = mid; }
+        }
         const uint32_t b1 = b < nseg_all ? segs[b].blk_base : nblk;
         if (b - a < min_segs && !waveparse) { s0 = a; s1 = b; fused_tail = b < s1_all; break; }
         if ((c->tun.lz_pbuf_fail && !gt) /* testing: as if the allocation failed */ || c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << segs[a].blk_log) * 4) ||
