@@ -425,7 +425,8 @@ typedef struct {
     double   ms_frame;                                   /* k_frame (pna_gpu_create_archive_device only)       */
     double   ms_cipher;                                  /* k_aes_* (archives written with a cipher)           */
     double   ms_lz_match;                                /* of ms_lz: the match kernel (k_lzm) launches of the split LZ stage, summed */
-    uint64_t lz_match_launches;                          /* ... and how many there were (0: the batch went through the one-kernel form) */
+    uint64_t lz_match_launches;                          /* ... and how many there were (0: the batch went through the one-kernel form).  After a DEFLATE DECODE call: the large foreign
+                                                          * streams that were decoded in chunks between block starts found by trial (the others of that size took one wave's walk) */
     uint32_t blk_log;                                    /* block size of the last (sub-)batch = 1 << blk_log: 17, or 13..16 in latency mode   */
     uint32_t lz_units;                                   /* latency mode: workgroups (units) of the LZ stage's launch; 0: one per segment       */
 } pna_gpu_timing;

@@ -103,9 +103,25 @@ __device__ uint32_t if_build(const uint8_t *lens, uint32_t nsym, uint32_t root, 
 // instruction per step instead of a 64-lane vector operation with one live lane.  Only LDS / global stores are lane-guarded.
 #define IF_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
+// CHUNK MODE (chunks != nullptr; round 4): one LARGE stream of a foreign encoder -- no sync-flush markers to cut it at, one wave's walk is a few MiB/s -- is walked by
+// one wave per CHUNK: [start_bit, end_bit) of the stream's bits, block starts that k_ispec found by testing every bit position for a well-formed dynamic block header
+// (complete code-length code, complete literal / length and distance codes, an end-of-block code: the chance of a false one is negligible, and a false one breaks the
+// chain -- a chunk must end exactly where the next begins -- which sends the stream to the serial walk).  The records need no window (matches are only recorded), so a
+// chunk starts from nothing.  Two passes: COUNT (sizes of every chunk's literals, records and output), then -- prefix sums on the host -- EMIT into the stream's regions,
+// one ZBlock per chunk; k_zexec_par executes them.
+struct ISChunk {
+    uint64_t start_bit, end_bit;                          // end_bit = ~0: up to the stream's trailer
+    uint64_t lit_base, out_base, rec_base;                // EMIT: the chunk's first literal / output byte / record, relative to the stream's
+    uint64_t end_found, mtot;                             // out: the bit position behind the chunk's last block (behind the trailer for the last chunk); bytes produced by matches
+    uint32_t nlit, nrec, status, adler;                   // out
+};
+static_assert(sizeof(ISChunk) == 72, "ISChunk layout");
+enum { IF_CHAIN = 4 };                                    // chunk mode: the walk passed its end_bit (the next chunk's start was not a block start)
+
 __global__ __launch_bounds__(64)
 void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8_t *__restrict__ src, ZBlock *__restrict__ blocks,
-               uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs, const uint32_t *__restrict__ mode) {
+               uint8_t *__restrict__ lit_scratch, uint64_t *__restrict__ seqs, const uint32_t *__restrict__ mode,
+               ISChunk *__restrict__ chunks, uint32_t chunk_frame, uint32_t emit) {
     __shared__ uint16_t lt[1u << IF_LROOT], dt[1u << IF_DROOT];
     __shared__ uint32_t ring[IF_RING];
     __shared__ uint64_t sstage[IF_SEQ_STAGE];
@@ -113,10 +129,10 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     __shared__ uint8_t lens[320 + 8];
     __shared__ uint8_t cltab[128];
     __shared__ uint16_t lt2[IF_LSUB << (15 - IF_LROOT)], dt2[IF_DSUB << (15 - IF_DROOT)], fst[16];
-    const uint32_t lane = threadIdx.x, f = blockIdx.x;
-    const bool l0 = lane == 0;
+    const uint32_t lane = threadIdx.x, f = chunks ? chunk_frame : blockIdx.x, ck = blockIdx.x;
+    const bool l0 = lane == 0, emit_on = !chunks || emit != 0;
     if (IF_U(frames[f].status)) return;
-    if (mode && IF_U(mode[f]) != 1u) return;                               // lane-per-piece decode took this stream (VM_SERIAL = 1)
+    if (!chunks && mode && IF_U(mode[f]) != 1u) return;                    // lane-per-piece decode (or the chunk mode) took this stream (VM_SERIAL = 1)
     const uint64_t src_off = (uint64_t)IF_U((uint32_t)frames[f].src_off) | ((uint64_t)IF_U((uint32_t)(frames[f].src_off >> 32)) << 32);
     const uint64_t dst_off = (uint64_t)IF_U((uint32_t)frames[f].dst_off) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_off >> 32)) << 32);
     if (IF_U((uint32_t)(frames[f].src_len >> 32)) | IF_U((uint32_t)(frames[f].dst_len >> 32))) {      // this walk counts in 32 bits: streams of 4 GiB and more are decoded by pieces or not at all
@@ -133,18 +149,24 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     const uint32_t nwords = (uint32_t)((end_bytes + 3) >> 2);
     const uint32_t *gsrc = (const uint32_t *)(src + a0);
     auto gload = [&](uint32_t w) -> uint32_t { return w < nwords ? gsrc[w] : 0u; };
-    uint8_t *lit_out = lit_scratch + dst_off;
-    uint64_t *rec_out = seqs + seq_base;
+    auto u64u = [&](const uint64_t &v) -> uint64_t { return (uint64_t)IF_U((uint32_t)v) | ((uint64_t)IF_U((uint32_t)(v >> 32)) << 32); };
+    const uint64_t sbit = chunks ? u64u(chunks[ck].start_bit) : 0, ebit = chunks ? u64u(chunks[ck].end_bit) : ~0ull;
+    const uint64_t lit_base = chunks ? u64u(chunks[ck].lit_base) : 0, rec_base = chunks ? u64u(chunks[ck].rec_base) : 0, out_base = chunks ? u64u(chunks[ck].out_base) : 0;
+    uint8_t *lit_out = lit_scratch + dst_off + lit_base;
+    uint64_t *rec_out = seqs + seq_base + rec_base;
 
-    uint32_t rbase = 0;
+    // the reader starts at bit `sbit` of the stream (0 but for the chunks of a large stream)
+    const uint64_t abit = (uint64_t)mis * 8 + sbit;
+    const uint32_t wi0 = (uint32_t)(abit >> 5), boff = (uint32_t)abit & 31u;
+    uint32_t rbase = wi0 & ~(IF_HALF - 1);
     uint32_t pend[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) ring[lane + 64 * k] = gload(lane + 64 * (uint32_t)k);
+    for (int k = 0; k < 8; k++) { const uint32_t w = rbase + lane + 64 * (uint32_t)k; ring[w & (IF_RING - 1)] = gload(w); }
 #pragma unroll
-    for (int k = 0; k < 4; k++) pend[k] = gload(IF_RING + lane + 64 * (uint32_t)k);
-    uint32_t wi = 1, bitcnt = 32 - 8 * mis;
-    uint64_t bitbuf = (uint64_t)(IF_U(gload(0)) >> (8 * mis));
-    uint32_t state = IST_ZHEAD, last = 0, ll = 0, status = IF_OK, adler = 0;
+    for (int k = 0; k < 4; k++) pend[k] = gload(rbase + IF_RING + lane + 64 * (uint32_t)k);
+    uint32_t wi = wi0 + 1, bitcnt = 32 - boff;
+    uint64_t bitbuf = (uint64_t)(IF_U(gload(wi0)) >> boff);
+    uint32_t state = sbit ? IST_BLOCK : IST_ZHEAD, last = 0, ll = 0, status = IF_OK, adler = 0;
     uint32_t nseq_tot = 0, nlit_tot = 0;
     uint64_t mtot = 0;                                                      // bytes produced by matches
     __builtin_amdgcn_wave_barrier();
@@ -165,6 +187,11 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
         wi = IF_U(wi); bitcnt = IF_U(bitcnt); bitbuf = (uint64_t)IF_U((uint32_t)bitbuf) | ((uint64_t)IF_U((uint32_t)(bitbuf >> 32)) << 32);
         state = IF_U(state); last = IF_U(last); ll = IF_U(ll); status = IF_U(status); nseq_tot = IF_U(nseq_tot); nlit_tot = IF_U(nlit_tot); rbase = IF_U(rbase);
         mtot = (uint64_t)IF_U((uint32_t)mtot) | ((uint64_t)IF_U((uint32_t)(mtot >> 32)) << 32);
+        if (chunks && state == IST_BLOCK) {                                 // a chunk ends at the block start that is the next chunk's first bit
+            const uint64_t bp = (uint64_t)wi * 32 - bitcnt - (uint64_t)mis * 8;
+            if (bp > ebit) status = IF_CHAIN;
+            if (bp >= ebit) break;
+        }
         uint32_t nq = 0, nl = 0, act = IACT_NONE, p0 = 0, p1 = 0;
         if (state == IST_ZHEAD) {
             // RFC 1950: CMF, FLG.  Deflate with a window of at most 32 KiB, header check, no preset dictionary.
@@ -287,11 +314,13 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
         }
         __builtin_amdgcn_wave_barrier();
         // ---- flush what the phase staged
-        if ((uint64_t)nlit_tot + nl + mtot > dst_len) { if (status == IF_OK) status = IF_DSTSIZE; }
-        else if (nseq_tot + nq > seq_cap) { if (status == IF_OK) status = IF_UNSUPPORTED; }
+        if (out_base + nlit_tot + nl + mtot > dst_len) { if (status == IF_OK) status = IF_DSTSIZE; }
+        else if (rec_base + nseq_tot + nq > seq_cap) { if (status == IF_OK) status = IF_UNSUPPORTED; }
         else {
-            for (uint32_t k = lane; k < nq; k += 64) rec_out[nseq_tot + k] = sstage[k];
-            for (uint32_t k = lane; k < nl; k += 64) lit_out[nlit_tot + k] = lstage[k];
+            if (emit_on) {
+                for (uint32_t k = lane; k < nq; k += 64) rec_out[nseq_tot + k] = sstage[k];
+                for (uint32_t k = lane; k < nl; k += 64) lit_out[nlit_tot + k] = lstage[k];
+            }
             nseq_tot += nq; nlit_tot += nl;
         }
         // every consumed bit must lie inside the stream
@@ -300,17 +329,17 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
         if (act == IACT_STORED) {
             const uint32_t len = p0;
             if ((uint64_t)p1 + len > end_bytes) { status = IF_CORRUPT; break; }
-            if ((uint64_t)nlit_tot + len + mtot > dst_len) { status = IF_DSTSIZE; break; }
+            if (out_base + nlit_tot + len + mtot > dst_len) { status = IF_DSTSIZE; break; }
             const uint8_t *sp = src + a0 + p1;
             uint8_t *dp = lit_out + nlit_tot;
-            for (uint32_t i = lane * 8; i < len; i += 512) {
+            if (emit_on) for (uint32_t i = lane * 8; i < len; i += 512) {
                 if (i + 8 <= len) *(if_u64u *)(dp + i) = *(const if_u64u *)(sp + i);
                 else for (uint32_t k = i; k < len; k++) dp[k] = sp[k];
             }
             nlit_tot += len; ll += len;
             if (ll >= IF_LL_SPLIT) {
-                if (nseq_tot + 1 > seq_cap) { status = IF_UNSUPPORTED; break; }
-                if (l0) rec_out[nseq_tot] = zrec_pack(IF_LL_SPLIT, 0, 4);
+                if (rec_base + nseq_tot + 1 > seq_cap) { status = IF_UNSUPPORTED; break; }
+                if (l0 && emit_on) rec_out[nseq_tot] = zrec_pack(IF_LL_SPLIT, 0, 4);
                 nseq_tot++; ll -= IF_LL_SPLIT;
             }
             // re-seat the reader behind the stored bytes
@@ -339,6 +368,25 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     }
     // ---- one block record for k_zoff / k_zexec
     const uint64_t total = (uint64_t)nlit_tot + mtot;
+    if (chunks) {
+        if (status == IF_OK && state != IST_DONE && state != IST_BLOCK) status = IF_CORRUPT;
+        if (status == IF_OK && total > 0xFFFFFFFFull) status = IF_UNSUPPORTED;
+        if (l0) {
+            ISChunk &cr = chunks[ck];
+            cr.end_found = (uint64_t)wi * 32 - bitcnt - (uint64_t)mis * 8; cr.mtot = mtot; cr.nlit = nlit_tot; cr.nrec = nseq_tot; cr.status = status; cr.adler = adler;
+            if (emit && status == IF_OK && ck < blk_cap) {
+                ZBlock b;
+                b.body = 0; b.out_off = dst_off + out_base; b.seq_pos = seq_base + rec_base; b.size = 0; b.type = 2;
+                b.ltype = 2; b.regen = nlit_tot; b.streams = 1; b.lit_off = 0; b.lit_csize = 0; b.lit_pos = (uint32_t)lit_base;
+                b.huf_slot = 0xFFFFFFFFu; b.slot[0] = b.slot[1] = b.slot[2] = 0xFFFFFFFFu;
+                b.nseq = nseq_tot; b.seq_off = 0; b.seq_len = 0; b.frame = f; b.out_len = (uint32_t)total; b.status = 0; b.uses_rep = 0;
+                for (int k = 0; k < 7; k++) b.pad[k] = 0;
+                b.pad[1] = adler; b.pad[2] = (uint32_t)(lit_base >> 32);
+                blocks[blk_base + ck] = b;
+            }
+        }
+        return;
+    }
     if (status == IF_OK && (open ? total > dst_len : total != dst_len)) status = IF_DSTSIZE;
     if (l0) {
         ZBlock b;
@@ -399,13 +447,107 @@ __global__ void k_iadler_fin(ZFrame *__restrict__ frames, const ZFrameX *__restr
 }
 
 void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, lit_scratch, seqs, mode);
+    if (n) hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, frames, fx, src, blocks, lit_scratch, seqs, mode, (ISChunk *)nullptr, 0u, 0u);
+}
+// chunk mode: the `nchunks` chunks (device array of ISChunk, 72 bytes each) of stream `frame`; emit = 0: count only
+void launch_inflate_chunks(ZFrame *frames, ZFrameX *fx, uint32_t frame, void *chunks, uint32_t nchunks, uint32_t emit, const uint8_t *src, ZBlock *blocks,
+                           uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st) {
+    if (nchunks) hipLaunchKernelGGL(k_inflate, dim3(nchunks), dim3(64), 0, st, frames, fx, src, blocks, lit_scratch, seqs, (const uint32_t *)nullptr, (ISChunk *)chunks, frame, emit);
 }
 void launch_iadler(ZFrame *frames, const ZFrameX *fx, const ZBlock *blocks, uint32_t n, const uint32_t *cbase, uint32_t npieces, const uint8_t *dst,
                    void *part, hipStream_t st) {
     if (!n) return;
     if (npieces) hipLaunchKernelGGL(k_iadler_part, dim3(npieces), dim3(256), 0, st, (const ZFrame *)frames, cbase, n, dst, (uint2 *)part);
     hipLaunchKernelGGL(k_iadler_fin, dim3((n + 255) / 256), dim3(256), 0, st, frames, fx, blocks, cbase, (const uint2 *)part, n);
+}
+
+// ------------------------------------------------------------------ k_ispec: block starts of a large foreign stream, by trial
+// One workgroup per chunk of `cbytes` compressed bytes: the first bit position in the chunk at which a DYNAMIC block with BFINAL = 0 can start -- BTYPE 2, HLIT / HDIST
+// in range, a complete code-length code, and the HLIT + HDIST lengths it codes forming complete literal / length and distance codes (or a single one-bit code, as
+// zlib's inflate_table accepts) with an end-of-block code.  256 bit positions per round, one per thread: the three-bit lengths' Kraft sum is the cheap filter (a few in
+// a thousand positions pass), the lengths are then decoded canonically on the lane (puff's scheme: counts per length and the symbols in canonical order, held in
+// registers).  start[c] = the bit position relative to the stream, or ~0 (none: the chunk before simply runs on through this one).
+__device__ __forceinline__ uint64_t isp_bits(const uint8_t *s, uint64_t bit) { return *(const if_u64u *)(s + (bit >> 3)) >> (bit & 7); }     // >= 57 valid bits
+__device__ bool isp_header_ok(const uint8_t *s, uint64_t p, uint64_t nbits) {
+    if (p + 17 + 57 + 64 > nbits) return false;                                  // (headers in the stream's last bytes are not needed as chunk starts)
+    const uint64_t h = isp_bits(s, p);
+    if ((h & 7u) != 4u) return false;                                            // BFINAL = 0, BTYPE = 2 (LSB first: 0, then 01b -> value 2)
+    const uint32_t hlit = (uint32_t)(h >> 3) & 31u, hdist = (uint32_t)(h >> 8) & 31u, hclen = ((uint32_t)(h >> 13) & 15u) + 4u;
+    if (hlit > 29u || hdist > 29u) return false;
+    // the code-length code's lengths, by symbol (3 bits each)
+    constexpr uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    const uint64_t c0 = isp_bits(s, p + 17);                                     // 19 x 3 = 57 bits: all of them
+    uint64_t cl = 0, cntp = 0;                                                   // lengths: 3 bits per symbol; symbols per length: 5 bits per length (registers, no indexed arrays)
+    uint32_t kraft = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 19; i++) {
+        const uint32_t v = i < hclen ? (uint32_t)(c0 >> (3 * i)) & 7u : 0u;
+        cl |= (uint64_t)v << (3 * ORDER[i]);
+        if (v) { kraft += 128u >> v; cntp += 1ull << (5 * v); }
+    }
+    if (kraft != 128u) return false;
+    // symbols in canonical order (by length, then value): 19 x 5 bits
+    uint64_t so0 = 0, so1 = 0; uint32_t ns = 0;
+    for (uint32_t l = 1; l < 8; l++)
+        for (uint32_t sy = 0; sy < 19; sy++)
+            if (((uint32_t)(cl >> (3 * sy)) & 7u) == l) { if (ns < 12) so0 |= (uint64_t)sy << (5 * ns); else so1 |= (uint64_t)sy << (5 * (ns - 12)); ns++; }
+    // the HLIT + HDIST code lengths
+    const uint32_t nll = hlit + 257u, total = nll + hdist + 1u;
+    uint64_t bp = p + 17 + 3ull * hclen;
+    uint32_t n = 0, prev = 0, kll = 0, kd = 0, maxll = 0, maxd = 0, eob = 0;
+    auto add = [&](uint32_t len, uint32_t times) {                                // `times` symbols of length `len` from position n on
+        for (uint32_t t = 0; t < times; t++, n++) {
+            if (!len) continue;
+            if (n < nll) { kll += 32768u >> len; if (len > maxll) maxll = len; if (n == 256) eob = len; }
+            else { kd += 32768u >> len; if (len > maxd) maxd = len; }
+        }
+    };
+    while (n < total) {
+        if (bp + 64 > nbits) return false;
+        uint64_t bb = isp_bits(s, bp);
+        uint32_t code = 0, first = 0, index = 0, sym = 99, used = 0;
+        for (uint32_t l = 1; l < 8; l++) {
+            code |= (uint32_t)bb & 1u; bb >>= 1; used++;
+            const uint32_t c = (uint32_t)(cntp >> (5 * l)) & 31u;
+            if (code - first < c) { const uint32_t k = index + (code - first); sym = k < 12 ? (uint32_t)(so0 >> (5 * k)) & 31u : (uint32_t)(so1 >> (5 * (k - 12))) & 31u; break; }
+            index += c; first = (first + c) << 1; code <<= 1;
+        }
+        if (sym == 99) return false;
+        uint32_t rep = 1, val = sym;
+        if (sym < 16) prev = sym;
+        else if (sym == 16) { if (n == 0) return false; rep = 3 + ((uint32_t)bb & 3u); used += 2; val = prev; }
+        else if (sym == 17) { rep = 3 + ((uint32_t)bb & 7u); used += 3; val = 0; prev = 0; }
+        else { rep = 11 + ((uint32_t)bb & 127u); used += 7; val = 0; prev = 0; }
+        if (n + rep > total) return false;
+        add(val, rep);
+        bp += used;
+    }
+    if (!eob) return false;
+    if (kll != 32768u && !(kll < 32768u && maxll <= 1)) return false;
+    if (kd != 32768u && !(kd < 32768u && maxd <= 1)) return false;
+    return true;
+}
+__global__ __launch_bounds__(256)
+void k_ispec(const uint8_t *__restrict__ src, uint64_t src_off, uint64_t src_len, uint32_t cbytes, uint32_t nchunks, uint64_t *__restrict__ start) {
+    __shared__ unsigned long long best;
+    const uint32_t tid = threadIdx.x, c = blockIdx.x;
+    if (c >= nchunks) return;
+    if (c == 0) { if (tid == 0) start[0] = 0; return; }                          // the stream's first chunk starts with the zlib header
+    if (tid == 0) best = ~0ull;
+    __syncthreads();
+    const uint8_t *s = src + src_off;
+    const uint64_t nbits = src_len * 8, b0 = (uint64_t)c * cbytes * 8, b1 = (uint64_t)(c + 1) * cbytes * 8 < nbits ? (uint64_t)(c + 1) * cbytes * 8 : nbits;
+    for (uint64_t base = b0; base < b1; base += 256) {
+        const uint64_t p = base + tid;
+        if (p < b1 && isp_header_ok(s, p, nbits)) atomicMin(&best, (unsigned long long)p);
+        __syncthreads();
+        if (best != ~0ull) break;
+        __syncthreads();
+    }
+    if (tid == 0) start[c] = best;
+}
+void launch_ispec(const uint8_t *src, uint64_t src_off, uint64_t src_len, uint32_t cbytes, uint32_t nchunks, uint64_t *start, hipStream_t st) {
+    if (nchunks) hipLaunchKernelGGL(k_ispec, dim3(nchunks), dim3(256), 0, st, src, src_off, src_len, cbytes, nchunks, start);
 }
 
 // =====================================================================================================================

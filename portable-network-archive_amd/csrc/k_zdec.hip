@@ -1348,6 +1348,7 @@ void k_zexec_groups(ZFrame *__restrict__ frames, const ZFrameX *__restrict__ fx,
     const ZFrame fr = frames[f];
     if (fr.status) return;
     const ZFrameX x = fx[f];
+    if (x.pad) return;                                                  // a large foreign stream: its chunks are executed in parallel (k_zexec_par.hip)
     if (j >= x.nblk || (j && !blocks[x.blk_base + j].pad[5])) return;
     uint32_t k1 = j + 1;
     while (k1 < x.nblk && !blocks[x.blk_base + k1].pad[5]) k1++;

@@ -66,6 +66,11 @@ void launch_zparse_big_b(ZFrame *frames, ZFrameX *fx, uint32_t nblocks, const ui
                          void *work, const uint32_t *one_list, hipStream_t st);
 void launch_zstreams(uint32_t n_huf, uint32_t n_seq, const uint32_t *huf_list, const uint32_t *seq_list, const void *work, ZBlock *blocks,
                      const ZFrame *frames, const ZTables *tabs, const uint8_t *src, uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
+struct ISChunkH { uint64_t start_bit, end_bit, lit_base, out_base, rec_base, end_found, mtot; uint32_t nlit, nrec, status, adler; };   // = ISChunk of k_inflate.hip
+static_assert(sizeof(ISChunkH) == 72, "ISChunk layout");
+void launch_ispec(const uint8_t *src, uint64_t src_off, uint64_t src_len, uint32_t cbytes, uint32_t nchunks, uint64_t *start, hipStream_t st);
+void launch_inflate_chunks(ZFrame *frames, ZFrameX *fx, uint32_t frame, void *chunks, uint32_t nchunks, uint32_t emit, const uint8_t *src, ZBlock *blocks,
+                           uint8_t *lit_scratch, uint64_t *seqs, hipStream_t st);
 void launch_inflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, uint8_t *lit_scratch, uint64_t *seqs, const uint32_t *mode, hipStream_t st);
 void launch_icount(const uint8_t *src, const uint64_t *off, const uint64_t *len, uint32_t n, uint32_t *count, uint32_t G, hipStream_t st);
 void launch_vinflate(ZFrame *frames, ZFrameX *fx, uint32_t n, const void *pieces, uint32_t npieces, uint64_t *pb, uint32_t *mode, uint32_t *cntg, uint32_t G, const uint8_t *src,
@@ -197,8 +202,10 @@ struct pna_gpu_ctx {
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
     DevBuf z_big, z_one;                            // large zstd frames: their numbers, their blocks (k_zparse_a -> k_zparse<true>)
+    DevBuf z_spec;                                  // large foreign zlib streams: chunk starts + chunk descriptors (k_ispec, k_inflate's chunk mode)
     DevBuf z_words, z_rep, z_zxf;                   // the parallel executor of large zstd frames (k_zexec_par.hip): a word per output byte, histories per block
     uint32_t zexec_par_rounds = 0;                  // pointer-jumping rounds of the latest large frame (diagnostics)
+    uint32_t inflate_spec_streams = 0;              // streams of the latest inflate call that went through the speculative chunk decoder (diagnostics)
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf gtab;                                    // hash tables of the strong level set's match kernel (global memory)
     DevBuf fr_desc, fr_blob, fr_segdst, fr_entoff, crc_tabs;

@@ -4,6 +4,72 @@
 // Read side, Compression::Deflate: one zlib stream per entry (flate2::read::ZlibDecoder, lib/src/entry/read.rs:178-179).
 // k_inflate turns each stream into literals + (run, length, distance) records, k_zoff / k_zexec execute them, k_iadler_* check
 // the Adler-32 trailer.
+// A LARGE stream the lane-per-piece decoder cannot take (a foreign encoder's: no sync flush behind every 128 KiB -- what the reference itself writes for a large
+// deflate entry): block starts found by trial (k_ispec), one wave per chunk between two of them (k_inflate's chunk mode: COUNT, prefix sums here, EMIT), one ZBlock per
+// chunk.  *ok = false: something did not fit (no chunk starts found, a chunk's walk did not end where the next begins, sizes that do not add up) -- the serial walk
+// takes the stream, nothing is lost but time.  The records are executed by k_zexec_par afterwards (the caller).
+static constexpr uint32_t SPEC_CHUNK = 16384;
+static int inflate_spec_stream(pna_gpu_ctx *c, uint32_t f, const ZFrame &fr, const ZFrameX &x, const void *d_src, hipStream_t st, uint32_t *nblk_out, bool *ok,
+                               bool open, uint64_t *out_len) {
+    *ok = false;
+    const uint32_t nch = (uint32_t)((fr.src_len + SPEC_CHUNK - 1) / SPEC_CHUNK);
+    if (nch < 4 || nch > x.blk_cap) return PNA_OK;
+    if (c->z_spec.ensure((size_t)nch * (8 + sizeof(ISChunkH)) + 64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+    uint64_t *d_start = (uint64_t *)c->z_spec.p;
+    ISChunkH *d_chunks = (ISChunkH *)((uint8_t *)c->z_spec.p + (size_t)nch * 8);
+    std::vector<uint64_t> start(nch);
+    launch_ispec((const uint8_t *)d_src, fr.src_off, fr.src_len, SPEC_CHUNK, nch, d_start, st);
+    HIPCHK(c, hipMemcpyAsync(start.data(), d_start, (size_t)nch * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<ISChunkH> ch;
+    for (uint32_t k = 0; k < nch; k++)
+        if (start[k] != ~0ull) { ISChunkH h{}; h.start_bit = start[k]; h.end_bit = ~0ull; if (!ch.empty()) ch.back().end_bit = start[k]; ch.push_back(h); }
+    uint32_t m = (uint32_t)ch.size();
+    auto why = [&](const char *what, uint64_t a, uint64_t b) { if (c->tun.trace) fprintf(stderr, "[pna inflate] stream %u of %llu B not decoded in chunks: %s (%llu, %llu)\n", f, (unsigned long long)fr.src_len, what, (unsigned long long)a, (unsigned long long)b); };
+    if (m < 4) { why("too few block starts found", m, nch); return PNA_OK; }                                      // (stored data, or blocks of more than a chunk each: not worth the two passes)
+    auto run = [&](uint32_t emit) -> int {
+        HIPCHK(c, hipMemcpyAsync(d_chunks, ch.data(), (size_t)m * sizeof(ISChunkH), hipMemcpyHostToDevice, st));
+        launch_inflate_chunks((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, f, d_chunks, m, emit, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
+                              (uint64_t *)c->z_seqs.p, st);
+        HIPCHK(c, hipMemcpyAsync(ch.data(), d_chunks, (size_t)m * sizeof(ISChunkH), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        return PNA_OK;
+    };
+    // A walk that runs past its chunk's end says the NEXT chunk's start was not a block start (a well-formed header by chance: one in a few 10^9 bit positions --
+    // seen in a 445 MB stream): that chunk is dropped, its predecessor runs on to the start behind it, and the count is taken again.
+    int rc = PNA_OK;
+    for (int round = 0;; round++) {
+        rc = run(0); if (rc) return rc;
+        std::vector<ISChunkH> keep;
+        bool dropped = false;
+        for (uint32_t k = 0; k < m; k++) {
+            if (k > 0 && ch[k - 1].status == 4u /* IF_CHAIN */ && !dropped) { dropped = true; continue; }      // (one per round: the predecessor's next end decides about the one behind)
+            keep.push_back(ch[k]);
+        }
+        if (!dropped) break;
+        if (round >= 16) { why("too many false block starts", m, round); return PNA_OK; }
+        for (size_t k = 0; k < keep.size(); k++) keep[k].end_bit = k + 1 < keep.size() ? keep[k + 1].start_bit : ~0ull;
+        ch.swap(keep); m = (uint32_t)ch.size();
+    }
+    uint64_t lit = 0, out = 0, rec = 0;
+    for (uint32_t k = 0; k < m; k++) {
+        const ISChunkH &h = ch[k];
+        if (h.status) { why("a chunk's walk failed: chunk, status", k, h.status); return PNA_OK; }
+        if (k + 1 < m && h.end_found != ch[k + 1].start_bit) { why("the chain is broken behind chunk: end found, next start", h.end_found, ch[k + 1].start_bit); return PNA_OK; }   // a false start, or a stream this scheme does not fit
+        lit += h.nlit; out += (uint64_t)h.nlit + h.mtot; rec += h.nrec;
+    }
+    if (open ? out > fr.dst_len : out != fr.dst_len) { why("sizes do not add up: output, expected", out, fr.dst_len); return PNA_OK; }   // (open: dst_len is the room)
+    *out_len = out;
+    if (rec > x.seq_cap) { why("more records than room: records, room", rec, x.seq_cap); return PNA_OK; }
+    if ((ch[m - 1].end_found + 7) / 8 != fr.src_len) { why("the last chunk does not end with the stream: end bit, stream bytes", ch[m - 1].end_found, fr.src_len); return PNA_OK; }
+    lit = out = rec = 0;
+    for (uint32_t k = 0; k < m; k++) { ISChunkH &h = ch[k]; h.lit_base = lit; h.out_base = out; h.rec_base = rec; lit += h.nlit; out += (uint64_t)h.nlit + h.mtot; rec += h.nrec; }
+    rc = run(1); if (rc) return rc;
+    for (uint32_t k = 0; k < m; k++) if (ch[k].status) { why("a chunk's second walk failed: chunk, status", k, ch[k].status); return PNA_OK; }
+    *nblk_out = m; *ok = true;
+    return PNA_OK;
+}
+
 static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
                                 const uint64_t *dst_off, const uint64_t *raw_len, hipStream_t st, bool open = false, uint64_t *raw_out = nullptr) {
     if (n > 0x3FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
@@ -26,6 +92,9 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     uint64_t max_src = 0;
     for (size_t i = 0; i < n; i++) max_src = std::max<uint64_t>(max_src, src_len[i]);
     const uint32_t scan_g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(max_src >> 18, 1024), (1ull << 24) / std::max<size_t>(n, 1)));
+    // large streams that may turn out to be a foreign encoder's (inflate_spec_stream): candidates by size; their chunks' blocks live behind the batch's own
+    const uint64_t spec_min = (uint64_t)c->tun.zexec_par_min_mib << 20;
+    std::vector<uint32_t> cand; std::vector<uint64_t> cand_base;
     if (lanes && open) {
         std::vector<uint32_t> cnt(n);
         if (c->z_pb.ensure(n * 4 + 8) || c->z_vp.ensure(n * 16 + 16)) return fail(c, PNA_E_NOMEM, "decoder workspace");
@@ -57,12 +126,18 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
         cbase[i] = (uint32_t)pieces;
         pieces += (raw_len[i] + 65535) >> 16;
         if (pieces > 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
+        // (open: raw_len is the room, the size comes out of the count; the stream must be worth it by its compressed size then)
+        if (spec_min && (open ? src_len[i] >= spec_min / 4 : raw_len[i] >= spec_min) && raw_len[i] < (1ull << 31) && src_len[i] < (1ull << 32) && src_len[i] >= 8ull * SPEC_CHUNK) cand.push_back((uint32_t)i);
     }
     cbase[n] = (uint32_t)pieces;
+    for (uint32_t i : cand) { cand_base.push_back(nblk); nblk += (src_len[i] + SPEC_CHUNK - 1) / SPEC_CHUNK; if (nblk > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call"); }
     if (c->z_frames.ensure(n * sizeof(ZFrame)) || c->z_fx.ensure(n * sizeof(ZFrameX)) || c->z_blocks.ensure(nblk * sizeof(ZBlock)) ||
         c->z_lit.ensure(out_span + 64) || c->z_seqs.ensure(nseq_cap * 8 + 64) || c->z_cbase.ensure((n + 1) * 4) || c->z_apart.ensure(pieces * 8 + 8) ||
-        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 8 + 8) || c->z_mode.ensure(n * 4 + 8 + (size_t)n * scan_g * 4))))
+        c->z_mode.ensure(n * 4 + 8 + (lanes ? (size_t)n * scan_g * 4 : 0)) ||
+        (lanes && (c->z_vp.ensure(vp.size() * 8 + 8) || c->z_pb.ensure((nblk + n) * 8 + 8))))
         return fail(c, PNA_E_NOMEM, "decoder workspace");
+    std::vector<uint32_t> modes(n, 1u);                            // 1 = the wave-per-stream walk's (VM_SERIAL); the lane-per-piece decoder decides for itself when it runs
+    if (!lanes) HIPCHK(c, hipMemcpyAsync(c->z_mode.p, modes.data(), n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_frames.p, frs.data(), n * sizeof(ZFrame), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_fx.p, fxs.data(), n * sizeof(ZFrameX), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->z_cbase.p, cbase.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
@@ -70,13 +145,53 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (lanes) launch_vinflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, c->z_vp.p, (uint32_t)vp.size(), (uint64_t *)c->z_pb.p, (uint32_t *)c->z_mode.p,
                                (uint32_t *)c->z_mode.p + n + 2, scan_g, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p, st);
+    // ---- large foreign streams: chunks between block starts found by trial, walked side by side; what does not fit stays with the serial walk below
+    std::vector<std::pair<uint32_t, ZFrameX>> spec; std::vector<uint64_t> spec_len;
+    if (!cand.empty()) {
+        if (lanes) { HIPCHK(c, hipMemcpyAsync(modes.data(), c->z_mode.p, n * 4, hipMemcpyDeviceToHost, st)); HIPCHK(c, hipStreamSynchronize(st)); }
+        for (size_t k = 0; k < cand.size(); k++) {
+            const uint32_t i = cand[k];
+            if (modes[i] != 1u) continue;                              // this library's layout: the lane-per-piece decoder has it
+            ZFrameX xs = fxs[i];
+            xs.blk_base = (uint32_t)cand_base[k]; xs.blk_cap = (uint32_t)((src_len[i] + SPEC_CHUNK - 1) / SPEC_CHUNK); xs.nblk = 0; xs.pad = 0;
+            HIPCHK(c, hipMemcpyAsync((ZFrameX *)c->z_fx.p + i, &xs, sizeof xs, hipMemcpyHostToDevice, st));
+            bool ok = false; uint32_t m = 0; uint64_t olen = 0;
+            const int rcs = inflate_spec_stream(c, i, frs[i], xs, d_src, st, &m, &ok, open, &olen);
+            if (rcs) return rcs;
+            static const uint32_t three = 3u;                           // (not 1: the serial walk leaves the stream alone)
+            if (ok) {
+                xs.nblk = m; xs.pad = 1; HIPCHK(c, hipMemcpyAsync((uint32_t *)c->z_mode.p + i, &three, 4, hipMemcpyHostToDevice, st));
+                if (open) {                                             // the size found: what the serial walk reports through ZFrame::dst_len
+                    frs[i].dst_len = olen;
+                    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)i * sizeof(ZFrame) + offsetof(ZFrame, dst_len), &frs[i].dst_len, 8, hipMemcpyHostToDevice, st));
+                }
+            }
+            else xs = fxs[i];
+            HIPCHK(c, hipMemcpyAsync((ZFrameX *)c->z_fx.p + i, &xs, sizeof xs, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));                        // (xs is read by the copy until then)
+            if (ok) { spec.emplace_back(i, xs); spec_len.push_back(olen); }
+        }
+    }
     launch_inflate((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, (uint32_t)n, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
-                   (uint64_t *)c->z_seqs.p, lanes ? (const uint32_t *)c->z_mode.p : nullptr, st);
+                   (uint64_t *)c->z_seqs.p, (const uint32_t *)c->z_mode.p, st);
     HIPCHK(c, hipEventRecord(c->ev[2], st));
     if (lanes) launch_zexec_groups((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, c->z_vp.p, (uint32_t)vp.size(), (const uint8_t *)d_src,
                                    (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);   // execution groups side by side (k_vfin)
     else launch_zexec((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (uint32_t)n, (ZBlock *)c->z_blocks.p, (const uint8_t *)d_src,
                       (const uint8_t *)c->z_lit.p, (const uint64_t *)c->z_seqs.p, (uint8_t *)d_dst, st);
+    for (size_t si = 0; si < spec.size(); si++) {                        // their chunks' records: pointer jumping over the stream's output positions (k_zexec_par.hip)
+        auto &sp = spec[si];
+        const uint32_t i = sp.first;
+        ZxFrame h{frs[i].dst_off, spec_len[si], sp.second.blk_base, sp.second.nblk, 0, 0};
+        if (c->z_words.ensure(h.dst_len * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+        HIPCHK(c, hipMemcpyAsync(c->z_zxf.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+        uint32_t zst = 0, rounds = 0;
+        if (launch_zexec_par((ZxFrame *)c->z_zxf.p, h, (const ZBlock *)c->z_blocks.p, (const uint8_t *)d_src, (const uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p,
+                             (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st) != 0) return fail(c, PNA_E_HIP, "parallel stream execution failed");
+        c->zexec_par_rounds = rounds;
+        if (zst) { static const uint32_t corrupt = 1u; HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)i * sizeof(ZFrame) + offsetof(ZFrame, status), &corrupt, 4, hipMemcpyHostToDevice, st)); }
+    }
+    c->inflate_spec_streams = (uint32_t)spec.size();
     HIPCHK(c, hipEventRecord(c->ev[3], st));
     launch_iadler((ZFrame *)c->z_frames.p, (const ZFrameX *)c->z_fx.p, (const ZBlock *)c->z_blocks.p, (uint32_t)n, (const uint32_t *)c->z_cbase.p,
                   (uint32_t)pieces, (const uint8_t *)d_dst, c->z_apart.p, st);
@@ -88,6 +203,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
     float ms = 0, ms_h = 0, ms_x = 0;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&ms_h, c->ev[0], c->ev[2]); (void)hipEventElapsedTime(&ms_x, c->ev[2], c->ev[3]);
     c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms; c->timing.ms_stats = ms_h; c->timing.ms_lit = ms_x;   // total, Huffman walk, execution
+    c->timing.lz_match_launches = spec.size();                      // (decode calls: the large foreign streams that went through the chunk decoder)
     for (size_t i = 0; i < n; i++)
         if (frs[i].status) {
             char msg[160];

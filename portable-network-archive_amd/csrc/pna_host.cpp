@@ -83,7 +83,7 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->plan, &c->d_tail, &c->blk, &c->tabs, &c->seqs, &c->lits, &c->litc, &c->seqc, &c->seqw, &c->pbuf, &c->seg_size,
-                      &c->seg_off, &c->stage_in, &c->stage_out, &c->z_words, &c->z_rep, &c->z_zxf, &c->z_big, &c->z_one, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
+                      &c->seg_off, &c->stage_in, &c->stage_out, &c->z_words, &c->z_rep, &c->z_zxf, &c->z_spec, &c->z_big, &c->z_one, &c->ctab, &c->c_vocab, &c->c_cum, &c->c_phr,
                       &c->gtab, &c->fr_desc, &c->fr_blob, &c->fr_segdst, &c->fr_entoff, &c->crc_tabs, &c->aes_tabs, &c->ci_units, &c->ci_ivs, &c->ci_keys, &c->ci_gcm, &c->ci_spread, &c->ci_spread_desc, &c->z_vp, &c->z_pb, &c->z_mode, &c->x_arc, &c->x_pk, &c->x_raw[0], &c->x_raw[1], &c->x_desc, &c->x_place, &c->x_flag, &c->x_tags, &c->x_plen, &c->aes_dtabs, &c->solid_plain, &c->solid_desc, &c->solid_blob, &c->solid_place, &c->z_ents, &c->z_frames, &c->z_lit, &c->z_fx, &c->z_blocks, &c->z_tabs, &c->z_seqs, &c->z_hlist, &c->z_slist, &c->z_work, &c->z_fb, &c->z_cbase, &c->z_apart}) b->release();
     for (auto &b : c->lent) (void)hipHostFree((void *)b.first);          // (buffers the host never gave back)
     c->lent.clear();

@@ -1676,6 +1676,69 @@ def test_one_large_foreign_zstd_frame(gpu_ctx, pna, codec):
     assert t is not None
 
 
+def test_large_foreign_zlib_streams_are_decoded_in_chunks(gpu_ctx, pna, codec):
+    """One LARGE zlib stream of a foreign encoder (stdlib zlib: no sync flush every 128 KiB -- what the reference's flate2 writes for a large deflate entry) has no
+    markers to cut it at: block starts are found by trial (k_ispec), the chunks between them walked side by side (k_inflate's chunk mode, count + emit), the records
+    executed by pointer jumping.  Same bytes as the wave-per-stream walk (option zexec_par_min_mib = 0) for several levels and kinds of data; streams the scheme does not
+    fit (stored blocks: incompressible data) fall back and still decode; damage is refused or decodes differently; small entries beside it are untouched."""
+    import random
+    rnd = random.Random(17)
+    text = b"".join(codec.corpus_file(i % 2, 9100 + i, 1 << 20) for i in range(24))
+    runs = bytearray()
+    while len(runs) < (12 << 20):
+        k = rnd.randrange(5)
+        if k == 0: runs += bytes([rnd.randrange(256)]) * rnd.randrange(1, 200000)
+        elif k == 1: runs += bytes(rnd.randrange(256) for _ in range(rnd.randrange(2, 9))) * rnd.randrange(10, 30000)
+        elif k == 2: runs += text[rnd.randrange(len(text) - 70000):][:rnd.randrange(10, 70000)]
+        elif k == 3: blk = bytes(runs[-32768:]); runs += blk * rnd.randrange(1, 4)
+        else: runs += bytes(200000)
+    noise = codec.corpus_file(2, 77, 3 << 20)
+    cases = [("text-6", text, 6, True), ("text-1", text[:16 << 20], 1, True), ("text-9", text[:12 << 20], 9, True), ("runs-6", bytes(runs), 6, None),
+             ("text+noise-6", text[:6 << 20] + noise + text[6 << 20:12 << 20], 6, None), ("noise-6", noise * 3, 6, None)]
+    small = codec.corpus_file(0, 9099, 50000)
+    for name, raw, lvl, must in cases:
+        comp = zlib.compress(raw, lvl)
+        got = gpu_ctx.decompress_batch([comp], [len(raw)], algo=pna.ALGO_DEFLATE)
+        chunks = gpu_ctx.timing().lz_match_launches
+        assert got == [raw], name
+        if must: assert chunks == 1, (name, chunks)
+        with gpu_ctx.options(zexec_par_min_mib=(0, 8)):
+            if len(raw) <= (12 << 20):                                   # (the serial walk: ~0.1 s per MiB)
+                assert gpu_ctx.decompress_batch([comp], [len(raw)], algo=pna.ALGO_DEFLATE) == [raw], name
+                assert gpu_ctx.timing().lz_match_launches == 0
+        assert gpu_ctx.decompress_batch([zlib.compress(small, 6), comp], [len(small), len(raw)], algo=pna.ALGO_DEFLATE) == [small, raw], name
+    raw = text[:12 << 20]; comp = zlib.compress(raw, 6)
+    for k in range(6):
+        bad = bytearray(comp); bad[rnd.randrange(16, len(bad) - 8)] ^= 1 << rnd.randrange(8)
+        try:
+            assert gpu_ctx.decompress_batch([bytes(bad)], [len(raw)], algo=pna.ALGO_DEFLATE) != [raw]
+        except pna.PnaGpuError:
+            pass
+    for cut in (len(comp) - 1, len(comp) - 5, len(comp) // 2):
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx.decompress_batch([comp[:cut]], [len(raw)], algo=pna.ALGO_DEFLATE)
+
+
+def test_foreign_solid_deflate_archive_is_extracted_in_chunks(gpu_ctx, pna, pf, codec):
+    """What `pna create --solid --deflate` of the REFERENCE writes: the inner STORE records as ONE zlib stream of a foreign encoder, its decoded size recorded nowhere
+    (built here with the oracle's writer and stdlib zlib).  The extract driver decodes it through the chunk decoder (open size: the count pass yields it) and walks the
+    inner records; entries written by a foreign encoder as ordinary large deflate entries (fSIZ known) come out the same way."""
+    n = 40
+    ents = [codec.corpus_file(i % 2, 9300 + i, (1 << 20) - 7 * i) for i in range(n)]
+    names = [f"fs/{i:03d}.txt" for i in range(n)]
+    inner = b"".join(pf.write_normal_entry(pf.file_entry_header(pf.COMPRESSION_NO, nm), [d], len(d)) for nm, d in zip(names, ents))
+    stream = zlib.compress(inner, 6)
+    arc = pf.write_archive_header() + pf.write_solid_entry(pf.COMPRESSION_DEFLATE, pf.flatten_writer([stream])) + pf.finalize_archive()
+    got = pna.extract_archive(gpu_ctx, arc)
+    assert gpu_ctx.timing().lz_match_launches == 1
+    assert [nm for nm, _, _ in got] == names and all(d == e for (_, _, d), e in zip(got, ents))
+    big = b"".join(ents[:24])
+    arc2 = (pf.write_archive_header() + pf.write_normal_entry(pf.file_entry_header(pf.COMPRESSION_DEFLATE, "big/one.txt"), pf.flatten_writer([zlib.compress(big, 6)]), len(big))
+            + pf.write_normal_entry(pf.file_entry_header(pf.COMPRESSION_DEFLATE, "small.txt"), [zlib.compress(ents[30], 9)], len(ents[30])) + pf.finalize_archive())
+    got2 = pna.extract_archive(gpu_ctx, arc2)
+    assert [(nm, d) for nm, _, d in got2] == [("big/one.txt", big), ("small.txt", ents[30])]
+
+
 def test_large_frames_are_executed_in_parallel(gpu_ctx, pna, codec):
     """k_zexec_par.hip: a large frame's sequences are executed by pointer jumping (repeat-offset codes resolved per block from a symbolic start history,
     one word per output byte, word[p] = word[word[p]] until every word holds a byte) instead of by one wave in order.  Same bytes as the serial
