@@ -1798,8 +1798,8 @@ def test_one_workgroup_decoder_moves_its_bases(gpu_ctx, pna, codec):
 
 
 def test_damaged_large_streams_are_refused_or_differ(gpu_ctx, pna, codec):
-    """Random damage to the streams the round's decoder paths take -- a 6 MiB deflate entry of this library's (48 pieces, execution groups, marker scans on
-    several workgroups) and a 12 MiB libzstd frame (pooled per-entry resources) --: every damaged stream is either refused (PNA_E_INVAL / UNSUPPORTED:
+    """Random damage to the streams the decoder's large-stream paths take -- a 6 MiB deflate entry of this library's (48 pieces, execution groups, marker scans on
+    several workgroups), a 12 MiB libzstd frame (pooled per-entry resources) and a 10 MiB stdlib-zlib stream (the chunk decoder) --: every damaged stream is either refused (PNA_E_INVAL / UNSUPPORTED:
     structure, sizes, Adler-32, Content_Checksum) or decodes to different bytes; none hangs or reads outside its buffers (flate2 / zstd-rs return
     io::Error for the same inputs, lib/src/entry/read.rs:171-190)."""
     import random
@@ -1810,6 +1810,8 @@ def test_damaged_large_streams_are_refused_or_differ(gpu_ctx, pna, codec):
     if codec.system_libzstd() is not None:
         raw_z = b"".join(codec.corpus_file(i % 3, 8600 + i, 1 << 20) for i in range(12))
         cases.append((codec.libzstd_compress_checksum(raw_z, 3), raw_z, pna.ALGO_ZSTD))
+    raw_f = b"".join(codec.corpus_file(i % 2, 8700 + i, 1 << 20) for i in range(10))
+    cases.append((zlib.compress(raw_f, 6), raw_f, pna.ALGO_DEFLATE + 100))           # (+ 100: a FOREIGN zlib stream, alone in its call: the chunk decoder of round 4 -- trial block starts, chain check, fallback)
     seeds = range(2026, 2026 + int(os.environ.get("PNA_DAMAGE_SEEDS", "1")))       # (PNA_DAMAGE_SEEDS=N: a longer soak)
     for comp, raw, algo in cases:
         for seed in seeds:
@@ -1827,7 +1829,7 @@ def test_damaged_large_streams_are_refused_or_differ(gpu_ctx, pna, codec):
                     a = rng.randrange(len(bad) - 4096); del bad[a:a + rng.randrange(1, 4096)]
                 streams = [bytes(bad)] + ([comp] * 23 if algo == pna.ALGO_DEFLATE else [])
                 try:
-                    out = gpu_ctx.decompress_batch(streams, [len(raw)] * len(streams), algo=algo)
+                    out = gpu_ctx.decompress_batch(streams, [len(raw)] * len(streams), algo=algo % 100)
                     assert out[0] != raw, (algo, seed, trial)
                 except pna.PnaGpuError:
                     pass
