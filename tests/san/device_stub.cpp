@@ -101,6 +101,8 @@ void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStr
 void launch_zparse(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
 void launch_zstreams(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const void *, ZBlock *, const ZFrame *, const ZTables *, const uint8_t *, uint8_t *, uint64_t *, hipStream_t) { nostub("zstreams"); }
 void launch_inflate(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, const uint32_t *, hipStream_t) { nostub("inflate"); }
+void launch_ispec(const uint8_t *, uint64_t, uint64_t, uint32_t, uint32_t, uint64_t *, hipStream_t) { nostub("inflate (chunk starts)"); }
+void launch_inflate_chunks(ZFrame *, ZFrameX *, uint32_t, void *, uint32_t, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate (chunks)"); }
 void launch_icount(const uint8_t *, const uint64_t *, const uint64_t *, uint32_t, uint32_t *, uint32_t, hipStream_t) { nostub("inflate"); }
 void launch_vinflate(ZFrame *, ZFrameX *, uint32_t, const void *, uint32_t, uint64_t *, uint32_t *, uint32_t *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, hipStream_t) { nostub("inflate"); }
 void launch_iadler(ZFrame *, const ZFrameX *, const ZBlock *, uint32_t, const uint32_t *, uint32_t, const uint8_t *, void *, hipStream_t) { nostub("iadler"); }
