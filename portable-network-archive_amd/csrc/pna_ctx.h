@@ -205,6 +205,7 @@ struct pna_gpu_ctx {
     DevBuf z_spec;                                  // large foreign zlib streams: chunk starts + chunk descriptors (k_ispec, k_inflate's chunk mode)
     DevBuf z_words, z_rep, z_zxf;                   // the parallel executor of large zstd frames (k_zexec_par.hip): a word per output byte, histories per block
     uint32_t zexec_par_rounds = 0;                  // pointer-jumping rounds of the latest large frame (diagnostics)
+    std::vector<uint64_t> pl_off, pl_len, pl_cap, pl_eoff;   // the host pipeline's per-entry plan (staging offsets, lengths, capacity terms), kept between calls
     uint32_t inflate_spec_streams = 0;              // streams of the latest inflate call that went through the speculative chunk decoder (diagnostics)
     DevBuf c_vocab, c_cum, c_phr;
     DevBuf gtab;                                    // hash tables of the strong level set's match kernel (global memory)
@@ -319,6 +320,11 @@ inline void par_ranges(size_t n, unsigned nt, F &&fn) {
     for (auto &x : th) x.join();
 }
 // per call: the block size the sub-batches are cut with and how many blocks fit the workspace budget
+inline void plan_call_longest(pna_gpu_ctx *c, uint64_t longest) {           // plan_call for a caller that knows the longest entry already
+    c->plan_log = blk_log_for_longest(c, longest);
+    const uint64_t per_block = (uint64_t)seq_cap_of(c->plan_log) * 16 + ((uint64_t)3 << c->plan_log) + 64;
+    c->max_blocks = (size_t)std::max<uint64_t>(1024, (96ull << 30) / per_block);
+}
 template <class L>
 inline void plan_call(pna_gpu_ctx *c, const L *src_len, size_t n) {
     c->plan_log = small_entry_blk_log(c, src_len, 0, n);

@@ -66,17 +66,23 @@ extern "C" int pna_gpu_host_free(pna_gpu_ctx *c, void *p) {
 static bool entries_all_lent(pna_gpu_ctx *c, const void *const *src, const size_t *src_len, size_t n) {
     std::lock_guard<std::mutex> lk(c->lent_mu);
     if (c->lent.empty() || !n) return false;
-    size_t hint = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (!src_len[i]) continue;
-        const uint8_t *p = (const uint8_t *)src[i];
-        bool in = false;
-        for (size_t k = 0; k < c->lent.size() && !in; k++) {                            // (entries of one call mostly share a buffer: start with the last hit)
-            const auto &b = c->lent[(hint + k) % c->lent.size()];
-            if (p >= b.first && p + src_len[i] <= b.first + b.second) { in = true; hint = (hint + k) % c->lent.size(); }
+    // (on the host-loop threads: 10^6 entries against the registry were 4 ms on one; the registry does not change while the lock is held)
+    const unsigned nt = host_loop_threads(n);
+    std::vector<char> ok(nt, 1);
+    par_ranges(n, nt, [&](unsigned t, size_t a, size_t b) {
+        size_t hint = 0;
+        for (size_t i = a; i < b; i++) {
+            if (!src_len[i]) continue;
+            const uint8_t *p = (const uint8_t *)src[i];
+            bool in = false;
+            for (size_t k = 0; k < c->lent.size() && !in; k++) {                        // (entries of one call mostly share a buffer: start with the last hit)
+                const auto &bf = c->lent[(hint + k) % c->lent.size()];
+                if (p >= bf.first && p + src_len[i] <= bf.first + bf.second) { in = true; hint = (hint + k) % c->lent.size(); }
+            }
+            if (!in) { ok[t] = 0; return; }
         }
-        if (!in) return false;
-    }
+    });
+    for (char v : ok) if (!v) return false;
     return true;
 }
 
@@ -190,6 +196,7 @@ extern "C" int pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_
 static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                     const void *const *src, const size_t *src_len, const pna_gpu_cipher *cipher,
                                     const pna_gpu_entry_meta *meta, uint32_t part_flags, pna_sink_fn sink, void *user, uint32_t max_chunk) {
+    const auto t_entry = std::chrono::steady_clock::now();
     { int rcm = check_meta(c, meta, n); if (rcm) return rcm; }
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
@@ -225,16 +232,20 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
     //     kernels fall behind the copies (measured: option sub_ramp_down).
     const uint64_t SUBMAX = (uint64_t)c->tun.sub_mib << 20, SUBMIN = std::min<uint64_t>(64ull << 20, SUBMAX);
     struct Sub { size_t e0, e1; uint64_t in_bytes, out_cap; };
-    std::vector<Sub> subs; std::vector<uint64_t> off(n + 1), len64(n);
-    uint64_t in_total = 0;
-    for (size_t e = 0; e < n; e++) in_total += src_len[e];
-    plan_call(c, src_len, n);
+    std::vector<Sub> subs;
+    // (the context keeps these arrays between calls: 10^6 entries are 24 MB, and fresh memory costs a page fault per 4 KiB -- milliseconds in front of the pipeline)
+    if (c->pl_off.size() < n + 1) { c->pl_off.resize(n + 1); c->pl_len.resize(n + 1); c->pl_cap.resize(n + 1); }
+    uint64_t *off = c->pl_off.data(), *len64 = c->pl_len.data(), *ecap = c->pl_cap.data();
+    uint64_t in_total = 0, longest = 0;
     // every entry's share of its sub-batch's output capacity (name length, worst-case payload, chunk framing): on the host-loop threads -- for 10^5 .. 10^6 small
     // entries this loop, on one thread, was 8 .. 40 ms in front of the pipeline (a third of the end-to-end time of 10^6 x 4 KiB)
-    std::vector<uint64_t> ecap(n);
-    par_ranges(n, host_loop_threads(n), [&](unsigned, size_t a, size_t b) {
+    const unsigned plan_nt = host_loop_threads(n);
+    std::vector<std::pair<uint64_t, uint64_t>> psum(plan_nt, {0, 0});         // (bytes, longest entry) per thread
+    par_ranges(n, plan_nt, [&](unsigned t, size_t a, size_t b) {
+        uint64_t tot = 0, mx = 0;
         for (size_t i = a; i < b; i++) {
             const uint64_t l = src_len[i], wb = pna_gpu_bound(algo, (size_t)l);
+            tot += l; mx = std::max(mx, l);
             uint64_t cap = (cipher ? frame_entry_prefix_enc_bound(names[i], cipher->phsf) + 16 : frame_entry_prefix_bound(names[i])) + meta_len(meta, i) + wb + 16;
             if (cipher && cipher->cipher_mode == PNA_MODE_GCM) cap += 16 * (wb / (cipher->gcm_segment_size ? cipher->gcm_segment_size : (1u << 20)));   // a tag per full stream segment
             // a CRC + a header per further FDAT chunk once max_chunk_size cuts the payload (the term of pna_gpu_archive_chunked_bound: without it data
@@ -242,7 +253,11 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
             cap += 12 * (uint64_t)((wb + 64 + 16 * (l >> 12)) / chunk_limit(max_chunk) + 1);
             ecap[i] = cap;
         }
+        psum[t] = {tot, mx};
     });
+    for (auto &q : psum) { in_total += q.first; longest = std::max(longest, q.second); }
+    plan_call_longest(c, longest);
+    const auto t_caps = std::chrono::steady_clock::now();
     {
         uint64_t done = 0, target = SUBMIN;
         for (size_t e = 0; e < n;) {
@@ -263,32 +278,35 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
             target = std::min(SUBMAX, target * 2);
         }
     }
+    const auto t_cut = std::chrono::steady_clock::now();
+    const bool all_lent = entries_all_lent(c, src, src_len, n);                     // (then no page-locked staging of the library's own is needed, and no staging copy)
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     unsigned threads = std::min(8u, std::max(1u, hw / 2));
     if (c->tun.stage_threads) threads = (unsigned)c->tun.stage_threads;
     FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, false};
-    std::vector<uint64_t> eoff(n + 1);
+    if (c->pl_eoff.size() < n + 1) c->pl_eoff.resize(n + 1);
+    uint64_t *eoff = c->pl_eoff.data();
     uint64_t out_len[2] = {0, 0}, out_total = head.size();
     constexpr int NS = 4;
     {   // slots sized once for the largest sub-batch (allocation of page-locked memory is slow: not inside the pipeline)
         uint64_t max_in = 0, max_out = 0;
         for (const Sub &sb : subs) { max_in = std::max(max_in, sb.in_bytes); max_out = std::max(max_out, sb.out_cap); }
-        const bool lent0 = entries_all_lent(c, src, src_len, n);                    // (then no page-locked staging of the library's own is needed)
         for (int s = 0; s < NS && s < (int)subs.size(); s++)
-            if ((!lent0 && c->hp_in[s].ensure(max_in + 8192)) || c->dp_in[s].ensure(max_in + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+            if ((!all_lent && c->hp_in[s].ensure(max_in + 8192)) || c->dp_in[s].ensure(max_in + 8192)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
         for (int s = 0; s < 2 && s < (int)subs.size(); s++)
             if (c->dp_out[s].ensure(max_out + 64) || c->hp_out[s].ensure(max_out + 64)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
     }
     int rc = PNA_OK;
     const auto tr0 = std::chrono::steady_clock::now();
     auto trace = [&](const char *what, size_t k) { if (c->tun.trace) fprintf(stderr, "[pna create] %8.3f ms  %s %zu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), what, k); };
+    if (c->tun.trace) fprintf(stderr, "[pna create] planning took %.3f ms (capacity terms at %.3f, sub-batches cut at %.3f)\n", std::chrono::duration<double, std::milli>(tr0 - t_entry).count(),
+                              std::chrono::duration<double, std::milli>(t_caps - t_entry).count(), std::chrono::duration<double, std::milli>(t_cut - t_entry).count());
     trace("planned, slots ready; sub-batches:", subs.size());
     // the stager: sub-batch k into slot k % NS as soon as sub-batch k - NS has left the device
     std::mutex mu; std::condition_variable cv;
     size_t staged = 0, freed = 0; int stager_rc = PNA_OK; bool stop = false;      // sub-batches staged (copies issued) / sub-batches whose kernels are done
     const int dev_id = c->device;
     hipStream_t cp_in = c->cp_in;
-    const bool all_lent = entries_all_lent(c, src, src_len, n);
     std::thread stager([&]() {
         try {
             if (hipSetDevice(dev_id) != hipSuccess) { std::lock_guard<std::mutex> lk(mu); stager_rc = PNA_E_HIP; staged = subs.size(); cv.notify_all(); return; }
@@ -317,7 +335,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
                 while (g0 < nx.e1 && r == PNA_OK) {
                     size_t g1 = g0; uint64_t acc = 0;
                     while (g1 < nx.e1 && acc < (128ull << 20)) acc += src_len[g1++];
-                    parallel_stage(hb, src, src_len, off.data(), g0, g1, threads);
+                    parallel_stage(hb, src, src_len, off, g0, g1, threads);
                     const uint64_t b0 = off[g0], b1 = g1 < nx.e1 ? off[g1] : nx.in_bytes;
                     if (b1 > b0 && hipMemcpyAsync(db + b0, hb + b0, b1 - b0, hipMemcpyHostToDevice, cp_in) != hipSuccess) r = PNA_E_HIP;
                     g0 = g1;
@@ -341,8 +359,8 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
         }
         if (hipEventSynchronize(c->ev_in[sl]) != hipSuccess) { rc = fail(c, PNA_E_HIP, "H2D copy failed"); break; }
         trace("H2D done, kernels start", k);
-        rc = run_subbatch(c, algo, (const uint8_t *)c->dp_in[sl].p, off.data(), len64.data(), sb.e0, sb.e1, (uint8_t *)c->dp_out[so].p,
-                          sb.out_cap + 64, 0, eoff.data(), c->stream, true, &fj);
+        rc = run_subbatch(c, algo, (const uint8_t *)c->dp_in[sl].p, off, len64, sb.e0, sb.e1, (uint8_t *)c->dp_out[so].p,
+                          sb.out_cap + 64, 0, eoff, c->stream, true, &fj);
         { std::lock_guard<std::mutex> lk(mu); freed = k + 1; cv.notify_all(); }       // (run_subbatch has waited for its kernels: the input slot is free)
         trace("kernels done", k);
         if (rc == PNA_OK) {
