@@ -423,10 +423,30 @@ def main() -> None:
     arg_cache = [dict() for _ in range(pieces)]
 
     lib_comm = None
+    gather_note = None
     if world > 1 and args.gather == "lib" and not rehearsal:
-        uid = [pna.Comm.unique_id() if rank == 0 else None]
+        # the library's communicator (RCCL behind the C ABI).  Should it not come up on some rank (no librccl to dlopen, an init error), every rank learns of it
+        # and the run goes on with the same gather over torch.distributed instead of dying at N > 1 -- the line then says so.
+        err = None
+        try:
+            uid = [pna.Comm.unique_id() if rank == 0 else None]
+        except Exception as e:                                  # noqa: BLE001
+            uid, err = [None], repr(e)
         dist.broadcast_object_list(uid, src=0)
-        lib_comm = pna.Comm(dev.index, uid[0], world, rank)
+        if uid[0] is not None:
+            try:
+                lib_comm = pna.Comm(dev.index, uid[0], world, rank)
+            except Exception as e:                              # noqa: BLE001
+                err = repr(e)
+        ok = torch.tensor([1 if lib_comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if lib_comm is not None:
+                lib_comm.close()
+                lib_comm = None
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            gather_note = "torch.distributed (the library's communicator did not come up: %s)" % next((e for e in errs if e), "unknown")
     gather_out = [None] * pieces                              # rank 0: where the pieces h of all ranks land, in rank order
     piece_sizes = [None] * pieces                             # bytes every rank contributed to piece h (from the last gather of that piece)
     pending = [None] * nbuf                                   # the gather that still reads dsts[b]
@@ -663,7 +683,8 @@ def main() -> None:
                                       else "output = packed compressed entry streams in HBM")
                                    + ("; compressed shards gathered in index order onto rank 0 over RCCL" if world > 1 else ""),
                        "entries": files_all, "entries_per_gpu": n_files, "entry_bytes": file_len, "parallelism": f"entry-sharded x{world}",
-                       "gather_pieces": pieces},
+                       "gather_pieces": pieces,
+                       "gather": (gather_note or ("library (RCCL behind the C ABI: pna_gpu_gather_ordered_start / _wait)" if lib_comm is not None else "torch.distributed")) if world > 1 else None},
             "ratio": round(in_all / max(out_all, 1), 4),
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "gathered_archive_verified": gathered_ok,    # N > 1: the archive gathered on rank 0 read back through the extract driver
