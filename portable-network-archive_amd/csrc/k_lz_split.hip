@@ -23,6 +23,23 @@ namespace pna {
 //   * a far candidate's bytes (all 36 the match step can ask for) are requested only on the lanes that hold one, into register tuples.
 // Same table, window, tile order and barriers as k_lz, hence the same words (tests/test_gpu_parity.py: forms of the LZ stage).
 #define DPP_ROW_SHL1(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x101, 0xF, 0xF, true))   // value of lane i + 1 inside the row of 16 (0 at its end)
+// The match key of k_lzm: length << 26 | offset << 6 | back << 3 in ONE register (offsets < 2^20, lengths <= 36 + 7, back <= 7), so that an adoption round
+// moves one value per position (one DPP, one select) instead of key and offset: taking over the match of position q + s is + (s << 26) - (s << 3), and
+// "strictly longer" is a compare against the own key with everything below the length set.
+constexpr uint32_t PK_LEN = 26, PK_OFF = 6, PK_LOW = (1u << PK_LEN) - 1;
+__device__ __forceinline__ uint32_t pk_make(uint32_t l, uint32_t off, uint32_t bk3) { return (l << PK_LEN) | ((off << PK_OFF) | bk3); }
+template <uint32_t S>
+__device__ __forceinline__ uint32_t pk_adopt(uint32_t P, uint32_t Pn) {            // Pn: the key of position q + S
+    const uint32_t T = Pn + ((S << PK_LEN) - (S << 3));
+    const bool a = (Pn & (0x38u & ~((S - 1) << 3))) != 0 && T > (P | PK_LOW);       // back >= S (S = 1, 2, 4: a test of the upper back bits)
+    return a ? T : P;
+}
+// A window word by its LDS BYTE ADDRESS.  The kernels of this file have no static __shared__ variables, so their dynamic LDS starts at address 0 and the window (L_WIN = 0)
+// with it (checked once per workgroup: lds_base_is_zero); through the `lds` symbol every address computation ends in an add of the symbol's (zero) address that the
+// compiler cannot fold -- three v_add_u32 v, 0, v per match step.
+typedef const __attribute__((address_space(3))) uint32_t lds_cu32;
+__device__ __forceinline__ lds_cu32 *lds_word(uint32_t byte_addr) { return (lds_cu32 *)(uintptr_t)byte_addr; }
+__device__ __forceinline__ bool lds_base_is_zero(const uint8_t *dyn) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)dyn == 0u; }
 // GLOG != 0: the hash table of this workgroup lies in GLOBAL memory, 1 << GLOG slots (gtab + blockIdx.x << GLOG): the zstd levels 10 .. 22.  What a
 // 1 MiB segment's match finder can remember is what sets the ratio on text (24 512 slots in LDS 2.70, 2^19 slots 2.96), and LDS
 // cannot hold more; the high levels trade speed for it, as the reference's do.  Look-ups are loads that bypass the CU's L1 (agent-scope atomic loads:
@@ -51,7 +68,7 @@ __device__ __forceinline__ void far_load(const uint8_t *seg, uint32_t c, v4u &fa
     if (STRONG) fc = *(const u32u *)(pc - 4);
 }
 // the owners take their results from the lanes that computed them
-__device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (&idx)[4], uint32_t r0, uint32_t Kf, uint32_t (&K)[4]) {
+__device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (&idx)[4], uint32_t r0, uint32_t Kf, uint32_t (&K)[4]) {   // K: packed keys (pk_make)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t d = idx[j] - r0;
@@ -59,14 +76,16 @@ __device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (
         if (farj[j] && d < 63u) K[j] = got;
     }
 }
-// the match step of position q against those bytes: K = len << 6 | back << 3, exactly as for a candidate inside the window
+// the match step of position q against those bytes: the packed key (pk_make) with the offset so, exactly as for a candidate inside the window
 template <bool STRONG, uint32_t WB>
-__device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q, v4u fa, uint32_t fb, v4u fd, uint32_t fc, bool edge, uint32_t blk_end) {
-    const uint32_t *pq = win32 + (((q - 4) & (WB - 1)) >> 2);                      // the position's bytes q - 4 .. q + 32: aligned words + shift; pq[1..9] may lie in the mirror
-    const uint32_t shq = ((q - 4) & 3) * 8;
+__device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q, uint32_t so, v4u fa, uint32_t fb, v4u fd, uint32_t fc, bool edge, uint32_t blk_end) {
+    // the position's bytes q - 8 .. q + 36 from ONE base address (the dword that holds q - 8; what lies behind the window's end is its mirror):
+    // pq[0] = q - 8 .., pq[1] = q - 4 .., pq[2 ..] = q ..
+    lds_cu32 *pq = lds_word(L_WIN + ((q - 8) & (WB - 4)));
+    const uint32_t shq = q << 3;                                                    // (v_alignbit takes the shift modulo 32)
     uint32_t E[10];
 #pragma unroll
-    for (int k = 0; k < 10; k++) E[k] = pq[k];
+    for (int k = 0; k < 10; k++) E[k] = pq[k + 1];
 #define EW(k) __builtin_amdgcn_alignbit(E[(k) + 1], E[k], shq)                     /* bytes q - 4 + 4 k .. + 3 */
     const uint32_t x0 = EW(1) ^ fa.y, x1 = EW(2) ^ fa.z, x2 = EW(3) ^ fa.w, x3 = EW(4) ^ fb;
     uint32_t l = first_diff16(x0, x1, x2, x3);
@@ -77,13 +96,10 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
     if (l < MIN_MATCH) l = 0;
     const uint32_t xk = EW(0) ^ fa.x;
-    uint32_t bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
-    if (STRONG && xk == 0) {
-        const uint32_t em = win32[((q - 8) & (WB - 1)) >> 2];
-        bk = 4 + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], em, shq) ^ fc) | 0xFFu) >> 3);
-    }
+    uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                      // back << 3
+    if (STRONG && xk == 0) bk3 = 32u + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], pq[0], shq) ^ fc) | 0xFFu) & 24u);
 #undef EW
-    return (STRONG && !l) ? 0u : (l << 6) | (bk << 3);
+    return (STRONG && !l) ? 0u : pk_make(l, so, bk3);
 }
 
 template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>
@@ -93,8 +109,11 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
     constexpr bool FAR = !DEFL && FARP;                     // deflate offsets (<= 32 KiB) never leave the LDS window; FARP = false: a zstd launch whose look-back ends with the window (the fast set)
     using GEO = LzGeo<WLOG, TAB3>;                          // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
-    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NEAR = GEO::NEAR, NW3 = GEO::WORDS3;
-    static_assert(WIN_BYTES >= 2 * TILE_G + LOOKAHEAD + 16 + NEAR && (!DEFL || NEAR >= 32768), "window: look-back + this tile + look-ahead + the chunk in flight");
+    constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NW3 = GEO::WORDS3;
+    // candidates at most NEAR back are verified in the window: the window gives way to the next chunk only BEHIND the tile's first barrier (round 4), so its look-back is a tile
+    // longer than the one-kernel form's (GEO::NEAR): 27 392 bytes with the 32 KiB window (far pairs per wave and tile 56.9 -> 52.6; same results -- NEAR only says where the bytes come from)
+    constexpr uint32_t NEAR = GEO::NEAR + TILE_G;
+    static_assert(WIN_BYTES >= TILE_G + LOOKAHEAD + 16 + NEAR + 8 + 200 && (!DEFL || NEAR >= 32768), "window: look-back (+ 8 back bytes) + this tile + look-ahead");
     static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -107,6 +126,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
     if ((flags & FLAG_HAS_SMALL) && seg_len <= MID_SEG) return;       // (uniform) a short segment: k_lzms's
+    if (!lds_base_is_zero(lds)) __builtin_trap();                     // (lds_word: the window's words are addressed from 0)
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
     // The words: one per position, length | offset.  With the table in LDS (GLOG = 0) they take THREE bytes -- 5 bits for the length (0, or length - 5
     // for 6 .. 36: adopted lengths beyond 36 are clamped, FLAG_LEN36 tells the one-kernel form to do the same) and 19 for the offset (MAX_OFF_W3) --:
@@ -139,21 +159,22 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
         for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
             const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
             if (tid < TILE_G / 16) { pf = (loaded_end + tid * 16 < seg_len) ? load_chunk(seg, loaded_end + tid * 16, seg_len) : make_uint4(0, 0, 0, 0); }
-            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len);
-            // The tile's work is instantiated twice: FULL = every position of the tile is inside the block and at least 8 bytes before the segment's end (all
-            // tiles but a block's / segment's last, and never tile 0 with the packed table: position 0 is not stored) -- no validity masks, no selects, no
-            // bounds on the stores --, and the general form.  (uniform branch; round 4: 12 vector + 10 scalar instructions of the 630 per wave and tile)
+            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len) && (blk_end - t0 >= TILE_G + CAP1);
+            // The tile's work is instantiated twice: FULL = every position of the tile is inside the block, at least 8 bytes before the segment's end and far enough
+            // from the block's end that no match step can reach it (all tiles but a block's / segment's last, and never tile 0 with the packed table: position 0 is
+            // not stored) -- no validity masks, no selects, no bounds on the stores, no clamp at the block's end --, and the general form.  (uniform branch)
             auto tile_body = [&](auto full_t) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_t)::value;
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
-            // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0
+            // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0.  ONE base address (the dword of q0 - 8): what
+            // lies behind the window's end is its mirror (48 bytes: the base + 44)
             uint32_t D[9], Dm1, Dm2 = 0;
             {
-                const uint32_t *pq = win32 + ((q0 & (WIN_BYTES - 1)) >> 2);            // pq[1..8] may lie in the mirror
+                lds_cu32 *pq = lds_word(L_WIN + ((q0 - 8) & (WIN_BYTES - 1)));
 #pragma unroll
-                for (int k = 0; k < 9; k++) D[k] = pq[k];
-                Dm1 = win32[((q0 - 4) & (WIN_BYTES - 1)) >> 2];
-                if (STRONG) Dm2 = win32[((q0 - 8) & (WIN_BYTES - 1)) >> 2];
+                for (int k = 0; k < 9; k++) D[k] = pq[k + 2];
+                Dm1 = pq[1];
+                if (STRONG) Dm2 = pq[0];
             }
 #define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
             // ---- look-up
@@ -220,38 +241,35 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool slot0 = FAR && lane < 63u && lane < npair;
             v4u ffa, ffd; uint32_t ffb, ffc;
             far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
-            // ---- match: the candidates inside the window
+            // ---- match: the candidates inside the window.  P[j] = the packed key (pk_make): length, offset, back bytes
             // (Round 4, measured and dropped: the bytes 16 .. 35 compared ONCE per lane and offset in a wave-uniform loop -- a lane's positions inside a long
             // match share the offset, position j's length is position A's less j - A --: bit-exact, and 11 % SLOWER than the four in-place compares below;
             // the loop's dynamic selects and its second and third turns cost more than the 80 instructions it saves.)
-            uint32_t K[4];
-            const bool edge = blk_end - (t0 + wave * RW) < RW + CAP1;                   // (uniform) only the block's last waves can run into its end
+            uint32_t P[4];
+            const uint32_t q8[4] = {q0 - 8, q0 - 7, q0 - 6, q0 - 5};
+            const bool edge = !FULL && blk_end - (t0 + wave * RW) < RW + CAP1;          // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t l = 0, bk = 0;
+                uint32_t l = 0, bk3 = 0;
                 const uint32_t o = farj[j] ? 0u : off[j], q = q0 + j;
                 if (o != 0) {
-                    const uint32_t c = q - o;
-                    const uint32_t shc = (c & 3) * 8;
-                    uint32_t w0, w1, w2, w3, bc, bc2 = 0;
-                    {
-                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
-                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
-                        w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
-                        w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
-                        bc = __builtin_amdgcn_alignbit(d0, dm, shc);
-                        if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
-                    }
+                    // the candidate's bytes c - 8 .. c + 36 from ONE base address (the dword of c - 8; the mirror behind the window's end covers the base + 44):
+                    // pc[0] = c - 8 .., pc[1] = c - 4 .., pc[2 .. 6] the first 16 (+ 4) bytes, pc[6 .. 10] the second
+                    const uint32_t c8 = q8[j] - o;                                      // c - 8
+                    const uint32_t shc = c8 << 3;                                       // (v_alignbit takes the shift modulo 32: that of c)
+                    lds_cu32 *pc = lds_word(L_WIN + (c8 & (WIN_BYTES - 4)));
+                    const uint32_t dm = pc[1], d0 = pc[2], d1 = pc[3], d2 = pc[4], d3 = pc[5], d4 = pc[6];
+                    const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, shc), w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                    const uint32_t w2 = __builtin_amdgcn_alignbit(d3, d2, shc), w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                    const uint32_t bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                    uint32_t bc2 = 0;
+                    if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, pc[0], shc);
                     const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
                     l = first_diff16(x0, x1, x2, x3);
                     if (l == 16) {
-                        uint32_t v0, v1, v2, v3;
-                        {
-                            const uint32_t *pc2 = win32 + (((c + 16) & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                            v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
-                            v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
-                        }
+                        const uint32_t f1 = pc[7], f2 = pc[8], f3 = pc[9], f4 = pc[10];
+                        const uint32_t v0 = __builtin_amdgcn_alignbit(f1, d4, shc), v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                        const uint32_t v2 = __builtin_amdgcn_alignbit(f3, f2, shc), v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
                         const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
                         l = 16 + first_diff16(y0, y1, y2, y3);
                     }
@@ -259,92 +277,61 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     if (l < MIN_MATCH) l = 0;
                     const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
                     const uint32_t xk = bqj ^ bc;
-                    bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
-                    if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
+                    bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                               // back << 3
+                    if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
                 }
-                K[j] = (l << 6) | (bk << 3);
-                if (STRONG && !l) K[j] = 0;
+                P[j] = pk_make(l, o, bk3);
+                if (STRONG && !l) P[j] = 0;
             }
             // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)
             if (FAR && npair) {
                 {
                     uint32_t Kf = 0;
-                    if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, ffa, ffb, ffd, ffc, edge, blk_end);
-                    far_pull(farj, idx, 0u, Kf, K);
+                    if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, so, ffa, ffb, ffd, ffc, edge, blk_end);
+                    far_pull(farj, idx, 0u, Kf, P);
                 }
-                for (uint32_t r0 = 63; r0 < npair; r0 += 63) {                         // (more than 63 far pairs in 256 positions: rare)
+                for (uint32_t r0 = 63; r0 < npair; r0 += 63) {                         // (more than 63 far pairs in 256 positions: a quarter of the wave-tiles of the default set)
                     uint32_t sq2, so2, Kf = 0;
                     far_push(farj, idx, r0, t0 + wave * RW, lane, off, sq2, so2);
                     if (lane < 63u && lane < npair - r0) {
                         v4u ga, gd; uint32_t gb, gc;
                         far_load<true, STRONG>(seg, sq2 - so2, ga, gb, gd, gc);
-                        Kf = far_match<STRONG, WIN_BYTES>(win32, sq2, ga, gb, gd, gc, edge, blk_end);
+                        Kf = far_match<STRONG, WIN_BYTES>(win32, sq2, so2, ga, gb, gd, gc, edge, blk_end);
                     }
-                    far_pull(farj, idx, r0, Kf, K);
+                    far_pull(farj, idx, r0, Kf, P);
                 }
             }
-            // ---- backward adoption: K = len << 6 | back << 3 | positions moved; the offset goes along
+            // ---- backward adoption on the packed keys (the offset goes along inside the key)
             if (adopt) {
                 {   // round 1: the right neighbour's match, one byte longer
-                    const uint32_t Kn = DPP_ROW_SHL1(K[0]), on = DPP_ROW_SHL1(off[0]);
-                    uint32_t K1[4] = {K[1], K[2], K[3], Kn}, o1[4] = {off[1], off[2], off[3], on};
+                    const uint32_t Pn = DPP_ROW_SHL1(P[0]);
+                    const uint32_t P1[4] = {P[1], P[2], P[3], Pn};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K1[j] + 57u;
-                        const bool a = (K1[j] & 0x38u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o1[j] : off[j];
-                    }
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<1>(P[j], P1[j]);
                 }
                 {   // round 2: the match two positions to the right (after round 1), two bytes longer
-                    const uint32_t Ka = DPP_ROW_SHL1(K[0]), Kb = DPP_ROW_SHL1(K[1]), oa = DPP_ROW_SHL1(off[0]), ob = DPP_ROW_SHL1(off[1]);
-                    uint32_t K2[4] = {K[2], K[3], Ka, Kb}, o2[4] = {off[2], off[3], oa, ob};
+                    const uint32_t Pa = DPP_ROW_SHL1(P[0]), Pb = DPP_ROW_SHL1(P[1]);
+                    const uint32_t P2[4] = {P[2], P[3], Pa, Pb};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K2[j] + 114u;
-                        const bool a = (K2[j] & 0x30u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o2[j] : off[j];
-                    }
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<2>(P[j], P2[j]);
                 }
                 if (STRONG) {   // round 3: four positions to the right = the same position of the next lane, four bytes longer
-                    uint32_t K4[4], o4[4];
+                    uint32_t P4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { K4[j] = DPP_ROW_SHL1(K[j]); o4[j] = DPP_ROW_SHL1(off[j]); }
+                    for (int j = 0; j < 4; j++) P4[j] = DPP_ROW_SHL1(P[j]);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t T = K4[j] + 228u;
-                        const bool a = (K4[j] & 0x20u) != 0 && T > (K[j] | 63u);
-                        K[j] = a ? T : K[j]; off[j] = a ? o4[j] : off[j];
-                    }
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<4>(P[j], P4[j]);
                 }
             }
-            // (the window chunk goes to LDS BEFORE the words are stored: the vector memory counter is in order, and waiting for the chunk's load behind the
-            // store would wait for the store's completion as well -- a memory round trip per tile on the four waves that carry the chunk)
+            __syncthreads();                                                        // every wave has looked up and matched: the window's oldest chunk is free
+            // (the window chunk goes to LDS BEHIND this barrier -- until round 4 before it, which cost the window a tile of look-back: a candidate up to NEAR back must
+            // still be there while the slowest wave matches --, and the words are stored behind it: the vector memory counter is in order, and a wait for the chunk's
+            // load behind this tile's stores would wait for their completion as well)
             if (tid < TILE_G / 16) {
                 const uint32_t wo = (loaded_end + tid * 16) & (WIN_BYTES - 1);
                 *(uint4 *)(lds + L_WIN + wo) = pf;
                 if (wo < WIN_MIRROR) *(uint4 *)(lds + L_WIN + WIN_BYTES + wo) = pf;
             }
-            if (W3) {
-                if (FULL || q0 < t1) {
-                    uint32_t ww[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t l = K[j] >> 6, lc = l < 5u ? 5u : (l > 36u ? 36u : l);       // (v_med3_u32: lengths below MIN_MATCH are strays of the adoption, nobody's match)
-                        ww[j] = (lc - 5u) | (off[j] << 5);
-                    }
-                    W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);                              // (q0 is a multiple of 4: the 12 bytes are dword-aligned)
-                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);   // bytes 0 1 2 of word 0, byte 0 of word 1
-                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);   // bytes 1 2 of word 1, bytes 0 1 of word 2
-                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);   // byte 2 of word 2, bytes 0 1 2 of word 3
-                }
-            } else if (FULL || q0 < t1) {
-                v4u wv; wv.x = (K[0] >> 6) | (off[0] << 6); wv.y = (K[1] >> 6) | (off[1] << 6); wv.z = (K[2] >> 6) | (off[2] << 6); wv.w = (K[3] >> 6) | (off[3] << 6);
-                __builtin_nontemporal_store(wv, (v4u *)(pb + q0));       // (streamed: the parse kernel reads the words, this one never; without the hint they push the
-                                                                         // segment's recent bytes -- where most far candidates lie -- out of L2: k_lzm + 1.5 %)
-            }
-#undef QW
-            loaded_end += TILE_G;
-            __syncthreads();                                                        // every wave has looked up
             if constexpr (TAB3) {
                 // one 64-bit maximum per even position: the word as the look-up saw it with this position's field replaced (position 0 is never stored:
                 // its entry could be the empty one)
@@ -357,6 +344,28 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 #pragma unroll
                 for (int j = 0; j < 4; j++) if (hv[j] && (ins_all || !(j & 1))) atomicMax(&table[hsh[j]], ((q0 + j + 1) << TAG_BITS) | tag[j]);
             }
+            if (W3) {
+                if (FULL || q0 < t1) {
+                    uint32_t ww[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t l = P[j] >> PK_LEN, lc = l < 5u ? 5u : (l > 36u ? 36u : l);   // (v_med3_u32: lengths below MIN_MATCH are strays of the adoption, nobody's match)
+                        ww[j] = (lc - 5u) | ((P[j] >> (PK_OFF - 5)) & (0xFFFFFu << 5));
+                    }
+                    W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);                              // (q0 is a multiple of 4: the 12 bytes are dword-aligned)
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);   // bytes 0 1 2 of word 0, byte 0 of word 1
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);   // bytes 1 2 of word 1, bytes 0 1 of word 2
+                    __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);   // byte 2 of word 2, bytes 0 1 2 of word 3
+                }
+            } else if (FULL || q0 < t1) {
+                v4u wv;
+                wv.x = (P[0] >> PK_LEN) | (P[0] & (0xFFFFFu << PK_OFF)); wv.y = (P[1] >> PK_LEN) | (P[1] & (0xFFFFFu << PK_OFF));
+                wv.z = (P[2] >> PK_LEN) | (P[2] & (0xFFFFFu << PK_OFF)); wv.w = (P[3] >> PK_LEN) | (P[3] & (0xFFFFFu << PK_OFF));
+                __builtin_nontemporal_store(wv, (v4u *)(pb + q0));       // (streamed: the parse kernel reads the words, this one never; without the hint they push the
+                                                                         // segment's recent bytes -- where most far candidates lie -- out of L2: k_lzm + 1.5 %)
+            }
+#undef QW
+            loaded_end += TILE_G;
             if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the atomics have reached L2)
             __syncthreads();                                                        // inserts + window chunk in place
             };
