@@ -94,12 +94,11 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
         l = 16 + first_diff16(y0, y1, y2, y3);
     }
     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-    if (l < MIN_MATCH) l = 0;
     const uint32_t xk = EW(0) ^ fa.x;
     uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                      // back << 3
     if (STRONG && xk == 0) bk3 = 32u + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], pq[0], shq) ^ fc) | 0xFFu) & 24u);
 #undef EW
-    return (STRONG && !l) ? 0u : pk_make(l, so, bk3);
+    return STRONG ? (l >= MIN_MATCH ? pk_make(l, so, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, so, bk3);
 }
 
 template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>
@@ -250,9 +249,10 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool edge = !FULL && blk_end - (t0 + wave * RW) < RW + CAP1;          // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t l = 0, bk3 = 0;
                 const uint32_t o = farj[j] ? 0u : off[j], q = q0 + j;
+                uint32_t Pj = 0;
                 if (o != 0) {
+                    uint32_t l, bk3;
                     // the candidate's bytes c - 8 .. c + 36 from ONE base address (the dword of c - 8; the mirror behind the window's end covers the base + 44):
                     // pc[0] = c - 8 .., pc[1] = c - 4 .., pc[2 .. 6] the first 16 (+ 4) bytes, pc[6 .. 10] the second
                     const uint32_t c8 = q8[j] - o;                                      // c - 8
@@ -274,14 +274,14 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                         l = 16 + first_diff16(y0, y1, y2, y3);
                     }
                     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-                    if (l < MIN_MATCH) l = 0;
                     const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
                     const uint32_t xk = bqj ^ bc;
                     bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                               // back << 3
                     if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                    // (a length below MIN_MATCH counts as 0; the sets with the third adoption round then drop the whole key -- 0 + 1 + 2 + 4 adopted bytes would be a match)
+                    Pj = STRONG ? (l >= MIN_MATCH ? pk_make(l, o, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, o, bk3);
                 }
-                P[j] = pk_make(l, o, bk3);
-                if (STRONG && !l) P[j] = 0;
+                P[j] = Pj;
             }
             // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)
             if (FAR && npair) {
@@ -401,7 +401,7 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
     uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
-    const uint32_t *win32 = (const uint32_t *)(winb + PAD);
+    if (!lds_base_is_zero(lds)) __builtin_trap();                                   // (lds_word: the segment's words are addressed from 0)
     for (uint32_t i = lane; i < SLOTS / 4; i += 64) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
     if (lane < PAD / 16) ((uint4 *)winb)[lane] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = lane * 16; i < ((seg_len + 15u) & ~15u) + 64; i += 64 * 16) *(uint4 *)(winb + PAD + i) = i < seg_len ? load_chunk(seg, i, seg_len) : make_uint4(0, 0, 0, 0);
@@ -411,16 +411,18 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
         const uint32_t blk_end = ((t0 & ~(bsz - 1)) + bsz < seg_len) ? (t0 & ~(bsz - 1)) + bsz : seg_len;
         const uint32_t t1 = blk_end - t0 < RW ? blk_end : t0 + RW;
         const uint32_t q0 = t0 + 4 * lane;
+        // (as in k_lzm: ONE base address per run of words -- the dword of q0 - 8 / c - 8, in front of the segment lie PAD bytes --, words by LDS byte address, packed keys)
+        constexpr uint32_t WB8 = SLOTS * 4 + PAD - 8;                              // LDS byte address of the segment's byte -8
         uint32_t D[9], Dm1, Dm2 = 0;
         {
-            const uint32_t *pq = win32 + (q0 >> 2);
+            lds_cu32 *pq = lds_word(WB8 + q0);
 #pragma unroll
-            for (int k = 0; k < 9; k++) D[k] = pq[k];
-            Dm1 = pq[-1];
-            if (STRONG) Dm2 = pq[-2];
+            for (int k = 0; k < 9; k++) D[k] = pq[k + 2];
+            Dm1 = pq[1];
+            if (STRONG) Dm2 = pq[0];
         }
 #define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
-        uint32_t hsh[4], tag[4], off[4], K[4];
+        uint32_t hsh[4], tag[4], off[4], P[4];
         bool hv[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -436,74 +438,55 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
         const bool edge = blk_end - t0 < RW + CAP1;                                 // (uniform) only a block's last sub-tiles can run into its end
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            uint32_t l = 0, bk = 0;
             const uint32_t o = off[j], q = q0 + j;
+            uint32_t Pj = 0;
             if (o != 0) {
-                const uint32_t c = q - o;
-                const uint32_t shc = (c & 3) * 8;
-                uint32_t w0, w1, w2, w3, bc, bc2 = 0;
-                {
-                    const uint32_t *pc = win32 + (c >> 2);
-                    const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = pc[-1];
-                    w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
-                    w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
-                    bc = __builtin_amdgcn_alignbit(d0, dm, shc);
-                    if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, pc[-2], shc);
-                }
+                const uint32_t c8 = q - 8 - o;                                      // c - 8 (c >= 8)
+                const uint32_t shc = c8 << 3;                                       // (v_alignbit takes the shift modulo 32: that of c)
+                lds_cu32 *pc = lds_word(WB8 + 8 + (c8 & ~3u));
+                const uint32_t dm = pc[1], d0 = pc[2], d1 = pc[3], d2 = pc[4], d3 = pc[5], d4 = pc[6];
+                const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, shc), w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
+                const uint32_t w2 = __builtin_amdgcn_alignbit(d3, d2, shc), w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
+                const uint32_t bc = __builtin_amdgcn_alignbit(d0, dm, shc);
+                uint32_t bc2 = 0;
+                if (STRONG) bc2 = __builtin_amdgcn_alignbit(dm, pc[0], shc);
                 const uint32_t x0 = QW(0, j) ^ w0, x1 = QW(1, j) ^ w1, x2 = QW(2, j) ^ w2, x3 = QW(3, j) ^ w3;
-                l = first_diff16(x0, x1, x2, x3);
+                uint32_t l = first_diff16(x0, x1, x2, x3);
                 if (l == 16) {
-                    uint32_t v0, v1, v2, v3;
-                    {
-                        const uint32_t *pc2 = win32 + ((c + 16) >> 2);
-                        const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
-                        v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
-                        v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
-                    }
+                    const uint32_t f1 = pc[7], f2 = pc[8], f3 = pc[9], f4 = pc[10];
+                    const uint32_t v0 = __builtin_amdgcn_alignbit(f1, d4, shc), v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
+                    const uint32_t v2 = __builtin_amdgcn_alignbit(f3, f2, shc), v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
                     const uint32_t y0 = QW(4, j) ^ v0, y1 = QW(5, j) ^ v1, y2 = QW(6, j) ^ v2, y3 = QW(7, j) ^ v3;
                     l = 16 + first_diff16(y0, y1, y2, y3);
                 }
                 if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-                if (l < MIN_MATCH) l = 0;
                 const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;           // the 4 bytes before q (q - 1 in the top byte)
                 const uint32_t xk = bqj ^ bc;
-                bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
-                if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk = 4 + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) >> 3); }
+                uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                          // back << 3
+                if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                Pj = STRONG ? (l >= MIN_MATCH ? pk_make(l, o, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, o, bk3);
             }
-            K[j] = (l << 6) | (bk << 3);
-            if (STRONG && !l) K[j] = 0;
+            P[j] = Pj;
         }
         if (adopt) {        // backward adoption, the rounds of k_lzm
             {
-                const uint32_t Kn = DPP_ROW_SHL1(K[0]), on = DPP_ROW_SHL1(off[0]);
-                uint32_t K1[4] = {K[1], K[2], K[3], Kn}, o1[4] = {off[1], off[2], off[3], on};
+                const uint32_t Pn = DPP_ROW_SHL1(P[0]);
+                const uint32_t P1[4] = {P[1], P[2], P[3], Pn};
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t T = K1[j] + 57u;
-                    const bool a = (K1[j] & 0x38u) != 0 && T > (K[j] | 63u);
-                    K[j] = a ? T : K[j]; off[j] = a ? o1[j] : off[j];
-                }
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<1>(P[j], P1[j]);
             }
             {
-                const uint32_t Ka = DPP_ROW_SHL1(K[0]), Kb = DPP_ROW_SHL1(K[1]), oa = DPP_ROW_SHL1(off[0]), ob = DPP_ROW_SHL1(off[1]);
-                uint32_t K2[4] = {K[2], K[3], Ka, Kb}, o2[4] = {off[2], off[3], oa, ob};
+                const uint32_t Pa = DPP_ROW_SHL1(P[0]), Pb = DPP_ROW_SHL1(P[1]);
+                const uint32_t P2[4] = {P[2], P[3], Pa, Pb};
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t T = K2[j] + 114u;
-                    const bool a = (K2[j] & 0x30u) != 0 && T > (K[j] | 63u);
-                    K[j] = a ? T : K[j]; off[j] = a ? o2[j] : off[j];
-                }
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<2>(P[j], P2[j]);
             }
             if (STRONG) {
-                uint32_t K4[4], o4[4];
+                uint32_t P4[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { K4[j] = DPP_ROW_SHL1(K[j]); o4[j] = DPP_ROW_SHL1(off[j]); }
+                for (int j = 0; j < 4; j++) P4[j] = DPP_ROW_SHL1(P[j]);
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t T = K4[j] + 228u;
-                    const bool a = (K4[j] & 0x20u) != 0 && T > (K[j] | 63u);
-                    K[j] = a ? T : K[j]; off[j] = a ? o4[j] : off[j];
-                }
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<4>(P[j], P4[j]);
             }
         }
         if (q0 < t1) {
@@ -511,8 +494,8 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
                 uint32_t ww[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t l = K[j] >> 6, lc = l < 5u ? 5u : (l > 36u ? 36u : l);
-                    ww[j] = (lc - 5u) | (off[j] << 5);
+                    const uint32_t l = P[j] >> PK_LEN, lc = l < 5u ? 5u : (l > 36u ? 36u : l);
+                    ww[j] = (lc - 5u) | ((P[j] >> (PK_OFF - 5)) & (0xFFFFFu << 5));
                 }
                 W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);
                 __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);
@@ -522,8 +505,10 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
                 const uint32_t lmax = (flags & FLAG_LEN36) ? 36u : 63u;            // (four-byte words behind the one-kernel form's match half keep the clamp of the three-byte ones)
                 uint32_t l4[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { const uint32_t l = K[j] >> 6; l4[j] = l < lmax ? l : lmax; }
-                v4u wv; wv.x = l4[0] | (off[0] << 6); wv.y = l4[1] | (off[1] << 6); wv.z = l4[2] | (off[2] << 6); wv.w = l4[3] | (off[3] << 6);
+                for (int j = 0; j < 4; j++) { const uint32_t l = P[j] >> PK_LEN; l4[j] = l < lmax ? l : lmax; }
+                v4u wv;
+                wv.x = l4[0] | (P[0] & (0xFFFFFu << PK_OFF)); wv.y = l4[1] | (P[1] & (0xFFFFFu << PK_OFF));
+                wv.z = l4[2] | (P[2] & (0xFFFFFu << PK_OFF)); wv.w = l4[3] | (P[3] & (0xFFFFFu << PK_OFF));
                 __builtin_nontemporal_store(wv, (v4u *)(pb + q0));
             }
         }
