@@ -85,8 +85,12 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "single_frame" [PNA_SINGLE_FRAME]     zstd: 1 = an entry's payload is ONE frame (one frame header, the 1 MiB segments' blocks behind each other, matches never
  *                                         cross a segment start) as the reference's encoder writes (lib/src/compress/zstandard.rs: one Encoder per entry);
  *                                         0 (default) = a frame per 1 MiB segment, which this library's decoder takes in parallel.  3 + 0..2 bytes per segment apart
- *   "zexec_par_min_mib" [PNA_ZEXEC_PAR_MIN_MIB]  decoder: single zstd frames of at least this many MiB (default 8, below 2 GiB) take the header walk +
+ *   "zexec_par_min_mib" [PNA_ZEXEC_PAR_MIN_MIB]  decoder: single zstd frames of at least this many MiB (default 8; any size) take the header walk +
  *                                         wave-per-block parse + pointer-jumping execution; 0 = never
+ *   "zdec_fallback_max_mib" [PNA_ZDEC_FALLBACK_MAX_MIB]  decoder: a zstd frame of more content than this that the parallel paths cannot take is refused (PNA_E_UNSUPPORTED)
+ *                                         instead of decoded by one workgroup at ~11 MiB/s; 0 (default): no limit
+ *   "zexec_win_mib" [PNA_ZEXEC_WIN_MIB]   decoder: the pointer-jumping execution runs a frame / stream in windows of whole blocks of at most this many MiB of output,
+ *                                         one after the other (default and maximum 1 024: a word counts 31 bits from its window's start; scratch = 4 bytes per byte of a window)
  *   "stream_batch_mib" [PNA_STREAM_BATCH_MIB] (256), "stream_overlap_mib" [PNA_STREAM_OVERLAP_MIB] (64), "stream_gather_wgs" [PNA_STREAM_GATHER_WGS] (48): the streaming
  *                                         facade's pipeline -- largest device batch, how much may queue before a second batch is cut while one is on the device,
  *                                         workgroups of the copy-in kernel

@@ -135,11 +135,13 @@ void k_inflate(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint
     if (!chunks && mode && IF_U(mode[f]) != 1u) return;                    // lane-per-piece decode (or the chunk mode) took this stream (VM_SERIAL = 1)
     const uint64_t src_off = (uint64_t)IF_U((uint32_t)frames[f].src_off) | ((uint64_t)IF_U((uint32_t)(frames[f].src_off >> 32)) << 32);
     const uint64_t dst_off = (uint64_t)IF_U((uint32_t)frames[f].dst_off) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_off >> 32)) << 32);
-    if (IF_U((uint32_t)(frames[f].src_len >> 32)) | IF_U((uint32_t)(frames[f].dst_len >> 32))) {      // this walk counts in 32 bits: streams of 4 GiB and more are decoded by pieces or not at all
+    if (IF_U((uint32_t)(frames[f].src_len >> 32)) | (chunks ? 0u : IF_U((uint32_t)(frames[f].dst_len >> 32)))) {      // this walk counts in 32 bits: streams of 4 GiB and more are decoded by pieces, in chunks
+                                                                                                                           // (whose output positions are 64-bit: only the COMPRESSED bytes must fit 32 bits there) or not at all
         if (l0) { frames[f].status = IF_UNSUPPORTED; fx[f].nblk = 0; }
         return;
     }
-    const uint32_t src_len = IF_U((uint32_t)frames[f].src_len), dst_len = IF_U((uint32_t)frames[f].dst_len);
+    const uint32_t src_len = IF_U((uint32_t)frames[f].src_len);
+    const uint64_t dst_len = (uint64_t)IF_U((uint32_t)frames[f].dst_len) | ((uint64_t)IF_U((uint32_t)(frames[f].dst_len >> 32)) << 32);
     const bool open = (IF_U(frames[f].out_len) & ZF_OPEN) != 0;        // dst_len is a capacity: the stream's size is reported back
     const uint64_t seq_base = (uint64_t)IF_U((uint32_t)fx[f].seq_base) | ((uint64_t)IF_U((uint32_t)(fx[f].seq_base >> 32)) << 32);
     const uint32_t seq_cap = IF_U(fx[f].seq_cap), blk_base = IF_U(fx[f].blk_base), blk_cap = IF_U(fx[f].blk_cap);

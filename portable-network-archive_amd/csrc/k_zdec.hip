@@ -608,7 +608,9 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
     ZFrameX x = fx[f];
     if (!ONE && x.pad) return;                                          // a large frame: k_zparse_a + k_zparse<true> take it
     const uint8_t *in = src + fr.src_off;
-    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;
+    const uint32_t in_len = (uint32_t)fr.src_len;
+    const uint64_t cap = fr.dst_len < 0xFFFFFFFFull ? fr.dst_len : 0xFFFFFFFFull;   // (literal positions count in 32 bits: a frame with 4 GiB of literals and more in compressed blocks is left to the one-workgroup kernel)
+    const uint64_t fcs_want = fr.dst_len;
     const bool open = (fr.out_len & ZF_OPEN) != 0;
     uint32_t status = fr.status, ip = 0;
     // ---- frame header
@@ -628,7 +630,7 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
                     uint64_t fcs = 0;
                     for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
                     if (fsz == 2) fcs += 256;
-                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
+                    if (fsz && (open ? fcs > fcs_want : fcs != fcs_want)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
             }
@@ -680,7 +682,7 @@ void k_zparse(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx, const uint8
                     else if (sf == 2) { streams = 4; hdr = 4; regen = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; }
                     else { streams = 4; hdr = 5; regen = (v >> 4) & 0x3FFFF; comp = (v >> 22) & 0x3FFFF; }
                 }
-                if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { bstat = regen > (128u << 10) ? ZD_CORRUPT : ZD_DSTSIZE; break; }
+                if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { bstat = regen > (128u << 10) ? ZD_CORRUPT : (fcs_want > cap ? ZD_UNSUPPORTED : ZD_DSTSIZE); break; }
                 b.ltype = ltype; b.regen = regen; b.streams = streams;
                 uint32_t pos = hdr;
                 if (ltype == 0) { if (pos + regen > len) { bstat = ZD_CORRUPT; break; } b.lit_off = pos; pos += regen; }
@@ -865,7 +867,9 @@ __global__ void k_zparse_a(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx
     ZFrame fr = frames[f];
     const ZFrameX x = fx[f];
     const uint8_t *in = src + fr.src_off;
-    const uint32_t in_len = (uint32_t)fr.src_len, cap = (uint32_t)fr.dst_len;
+    const uint32_t in_len = (uint32_t)fr.src_len;
+    const uint64_t cap = fr.dst_len < 0xFFFFFFFFull ? fr.dst_len : 0xFFFFFFFFull;   // (literal positions count in 32 bits: a frame with 4 GiB of literals and more in compressed blocks is left to the one-workgroup kernel)
+    const uint64_t fcs_want = fr.dst_len;
     const bool open = (fr.out_len & ZF_OPEN) != 0;
     uint32_t status = fr.status, ip = 0;
     if (status == ZD_OK) {
@@ -884,7 +888,7 @@ __global__ void k_zparse_a(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx
                     uint64_t fcs = 0;
                     for (uint32_t i = 0; i < fsz; i++) fcs |= (uint64_t)in[ip + i] << (8 * i);
                     if (fsz == 2) fcs += 256;
-                    if (fsz && (open ? fcs > cap : fcs != cap)) status = ZD_DSTSIZE;
+                    if (fsz && (open ? fcs > fcs_want : fcs != fcs_want)) status = ZD_DSTSIZE;
                     ip += fsz;
                 }
             }
@@ -924,7 +928,7 @@ __global__ void k_zparse_a(ZFrame *__restrict__ frames, ZFrameX *__restrict__ fx
                 else if (sf == 2) { hdr = 4; regen = (v >> 4) & 0x3FFF; comp = (v >> 18) & 0x3FFF; }
                 else { hdr = 5; regen = (v >> 4) & 0x3FFFF; comp = (v >> 22) & 0x3FFFF; }
             }
-            if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { status = regen > (128u << 10) ? ZD_CORRUPT : ZD_DSTSIZE; break; }
+            if (regen > (128u << 10) || (uint64_t)lit_pos + regen > cap) { status = regen > (128u << 10) ? ZD_CORRUPT : (fcs_want > cap ? ZD_UNSUPPORTED : ZD_DSTSIZE); break; }
             uint32_t pos = hdr + (ltype == 0 ? regen : (ltype == 1 ? 1u : comp));
             if (pos >= len) { status = ZD_CORRUPT; break; }                 // (the sequences section holds at least its count)
             const uint32_t b0 = p[pos++];
@@ -1421,14 +1425,14 @@ __global__ void k_zscan(const ZEntry *__restrict__ ents, uint32_t n, const uint8
     const uint64_t len = en.src_len;
     const uint32_t nfr = en.n_frames;
     // ONE frame that holds the whole entry, however large (what the reference writes: libzstd streaming, one frame per entry): it gets all of
-    // raw_len and -- below 4 GiB -- all the block descriptors, table slots and sequence records planned for the entry's frames (their regions are
+    // raw_len and -- its compressed bytes below 4 GiB -- all the block descriptors, table slots and sequence records planned for the entry's frames (their regions are
     // contiguous), so that its blocks are decoded side by side like those of many small frames (k_zparse .. k_zexec: a 64 MiB frame 10.7 MiB/s on
-    // the one-workgroup kernel).  A frame of 4 GiB and more, or one that still does not fit (k_zparse finds out), goes to that kernel.  The other
+    // the one-workgroup kernel).  A frame of 4 GiB of COMPRESSED bytes and more, or one that still does not fit (k_zparse finds out), goes to that kernel.  The other
     // frame slots planned for the entry are void.
     if (nfr > 1 && zscan_frame_end(p, 0, len) == len) {
         ZFrame fr; fr.src_off = en.src_off; fr.dst_off = en.dst_off; fr.src_len = len; fr.out_len = en.open ? ZF_OPEN : 0u;
         fr.dst_len = en.raw_len; fr.status = 2u;
-        if (len <= 0xFFFFFFFFull && en.raw_len <= 0xFFFFFFFFull && fx) {
+        if (len <= 0xFFFFFFFFull && fx) {                            // (content of any size: the parse counts output in 64 bits, the executor works in windows; a compressed size beyond 32 bits stays with the one-workgroup kernel)
             ZFrameX x = fx[en.first_frame];
             uint64_t nb = 0, ns = 0, nq = 0;
             for (uint32_t g = 0; g < nfr; g++) { const ZFrameX y = fx[en.first_frame + g]; nb += y.blk_cap; ns += y.slot_cap; nq += y.seq_cap; }

@@ -12,8 +12,11 @@
 //   k_zx_jump     rounds of word[p] = word[word[p]] over all unresolved words until every word holds a byte (chains halve per round: log2 of the longest
 //                 copy chain; racing reads see an older or a newer ancestor, both valid)
 //   k_zx_emit     the bytes
-// Scratch: 4 bytes per output byte.  Frames of 2 GiB and more, offsets beyond 2^28 - 16 and histories that chain "rep0 - 1" twice through a block
-// start keep the serial executor.  Integer / byte work, no MFMA.
+// Scratch: 4 bytes per output byte of a WINDOW.  A frame is executed in windows of whole blocks, at most 1 GiB of output each (the host cuts them: pna_decode.cpp zx_windows, option zexec_win_mib), one after the other:
+// a word counts from its window's first byte (31 bits), and a match byte whose source lies in FRONT of the window -- in a window that has been emitted --
+// is that byte, read from the output.  So a frame of any size takes this path (round 4, second half: until then frames of 2 GiB and more kept the
+// one-workgroup executor, ~11 MiB/s).  Offsets beyond 2^28 - 16 and histories that chain "rep0 - 1" twice through a block start keep the serial executor.
+// Integer / byte work, no MFMA.
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
@@ -115,17 +118,19 @@ __global__ void k_zrep_scan(ZxFrame *__restrict__ zf, const uint32_t *__restrict
 constexpr uint32_t ZXE_THREADS = 256;
 __global__ __launch_bounds__(ZXE_THREADS)
 void k_zx_expand(ZxFrame *__restrict__ zf, const ZBlock *__restrict__ blocks, const uint8_t *__restrict__ src, const uint8_t *__restrict__ lit_scratch,
-                 const uint64_t *__restrict__ seqs, const uint32_t *__restrict__ rep_start, uint32_t *__restrict__ words) {
+                 const uint64_t *__restrict__ seqs, const uint32_t *__restrict__ rep_start, uint32_t *__restrict__ words,
+                 const uint8_t *__restrict__ dst, uint32_t wb0, uint64_t win_off) {                 // the window: blocks from wb0 on (one workgroup each), its first byte frame-relative
     __shared__ uint32_t s_end[ZXE_THREADS];        // inclusive end (block-relative output position) of each sequence of the chunk
     __shared__ uint32_t s_lit[ZXE_THREADS];        // literal index behind each sequence's literals (inclusive prefix of ll)
     __shared__ uint32_t s_ll[ZXE_THREADS], s_off[ZXE_THREADS];
     __shared__ uint32_t s_scan[ZXE_THREADS];
     __shared__ uint32_t s_bad;
-    const uint32_t tid = threadIdx.x, k = blockIdx.x;
+    const uint32_t tid = threadIdx.x, k = wb0 + blockIdx.x;
     if (zf->status) return;
     const ZBlock b = blocks[zf->blk_base + k];
-    const uint64_t bpos64 = b.out_off - zf->dst_off;                          // block's first byte, frame-relative (< 2^31: the host's gate)
-    const uint32_t bpos = (uint32_t)bpos64;
+    const uint64_t bpos64 = b.out_off - zf->dst_off;                          // block's first byte, frame-relative
+    const uint32_t bpos = (uint32_t)(bpos64 - win_off);                       // ... and window-relative (< 2^30: the host's windows)
+    const uint8_t *done = dst + zf->dst_off;                                  // the frame's output: everything in front of the window is there
     uint32_t *w = words + bpos;
     const uint8_t *body = src + b.body;
     if (tid == 0) s_bad = 0;
@@ -171,7 +176,8 @@ void k_zx_expand(ZxFrame *__restrict__ zf, const ZBlock *__restrict__ blocks, co
             const uint32_t start = lo ? s_end[lo - 1] : op, rel = pos - start;
             uint32_t v;
             if (rel < s_ll[lo]) v = ZX_FLAG | LIT(s_lit[lo] + rel);
-            else v = bpos + pos - s_off[lo];
+            else if (s_off[lo] <= bpos + pos) v = bpos + pos - s_off[lo];      // the source inside the window: a pointer
+            else v = ZX_FLAG | done[bpos64 + pos - s_off[lo]];                  // ... in front of it: the byte (checked above: not in front of the frame)
             w[pos] = v;
         }
         const uint32_t T = s_end[nb - 1] - op, TL = s_lit[nb - 1] + s_ll[nb - 1] - litpos;
@@ -206,8 +212,8 @@ void k_zx_jump(ZxFrame *__restrict__ zf, uint32_t *__restrict__ words, uint64_t 
 
 // ------------------------------------------------------------------ k_zx_emit : the bytes
 __global__ __launch_bounds__(256)
-void k_zx_emit(const ZxFrame *__restrict__ zf, const uint32_t *__restrict__ words, uint8_t *__restrict__ dst, uint64_t n) {
-    uint8_t *out = dst + zf->dst_off;
+void k_zx_emit(const ZxFrame *__restrict__ zf, const uint32_t *__restrict__ words, uint8_t *__restrict__ dst, uint64_t n, uint64_t win_off) {
+    uint8_t *out = dst + zf->dst_off + win_off;
     for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (uint64_t)gridDim.x * 1024) {
         if (i + 4 <= n) {
             const uint4 q = *(const uint4 *)(words + i);
@@ -218,27 +224,35 @@ void k_zx_emit(const ZxFrame *__restrict__ zf, const uint32_t *__restrict__ word
     }
 }
 
-// host side: the five steps for ONE frame; `zf` (device) holds its description, `words` >= 4 * dst_len + 64 bytes of scratch, rep_scratch 24 * nblk bytes.
-// Returns after the emit has been queued; *rounds = jump rounds run.  The unresolved counter is read back between rounds (a few microseconds each).
+// host side: the steps for ONE frame; `zf` (device) holds its description, `words` >= 4 * min(dst_len, ZX_WIN_MAX + a block) + 64 bytes of scratch, rep_scratch 24 * nblk bytes;
+// win_blk[0 .. nwin]: the windows' first blocks (win_blk[nwin] = nblk), win_off[0 .. nwin]: their first bytes, frame-relative (win_off[nwin] = dst_len).
+// Returns after the last emit has been queued; *rounds = jump rounds run (all windows).  The unresolved counter is read back between rounds (a few microseconds each).
 int launch_zexec_par(ZxFrame *zf, const ZxFrame &h, const ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch, uint64_t *seqs, uint32_t *rep_scratch,
-                     uint32_t *words, uint8_t *dst, uint32_t *status_out, uint32_t *rounds_out, hipStream_t st) {
+                     uint32_t *words, uint8_t *dst, uint32_t *status_out, uint32_t *rounds_out, hipStream_t st,
+                     uint32_t nwin, const uint32_t *win_blk, const uint64_t *win_off) {
     uint32_t *rep_end = rep_scratch, *rep_start = rep_scratch + 3 * (size_t)h.nblk;
     hipLaunchKernelGGL(k_zrep_block, dim3(h.nblk), dim3(64), 0, st, zf, blocks, seqs, rep_end);
     hipLaunchKernelGGL(k_zrep_scan, dim3(1), dim3(64), 0, st, zf, (const uint32_t *)rep_end, rep_start);
-    hipLaunchKernelGGL(k_zx_expand, dim3(h.nblk), dim3(ZXE_THREADS), 0, st, zf, blocks, src, lit_scratch, (const uint64_t *)seqs, (const uint32_t *)rep_start, words);
-    ZxFrame cur;
-    if (hipMemcpyAsync(&cur, zf, sizeof cur, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    ZxFrame cur; cur.status = 0;
     uint32_t rounds = 0;
-    if (cur.status == 0) {
-        const uint32_t wgs = (uint32_t)((h.dst_len / 4096 + 1) < 16384 ? (h.dst_len / 4096 + 1) : 16384);
-        for (;; rounds++) {
-            if (rounds >= 64) { cur.status = ZX_CORRUPT; break; }                         // (2^64 positions: cannot happen for a well-formed chain)
+    for (uint32_t wi = 0; wi < nwin && cur.status == 0; wi++) {
+        const uint32_t b0 = win_blk[wi], b1 = win_blk[wi + 1];
+        const uint64_t a0 = win_off[wi], wlen = win_off[wi + 1] - a0;
+        if (b1 == b0) continue;
+        hipLaunchKernelGGL(k_zx_expand, dim3(b1 - b0), dim3(ZXE_THREADS), 0, st, zf, blocks, src, lit_scratch, (const uint64_t *)seqs, (const uint32_t *)rep_start, words,
+                           (const uint8_t *)dst, b0, a0);
+        if (hipMemcpyAsync(&cur, zf, sizeof cur, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (cur.status) break;
+        const uint32_t wgs = (uint32_t)((wlen / 4096 + 1) < 16384 ? (wlen / 4096 + 1) : 16384);
+        for (uint32_t r = 0;; r++) {
+            if (r >= 64) { cur.status = ZX_CORRUPT; break; }                              // (2^64 positions: cannot happen for a well-formed chain)
             if (hipMemsetAsync(&zf->unresolved, 0, 4, st) != hipSuccess) return -1;
-            hipLaunchKernelGGL(k_zx_jump, dim3(wgs), dim3(256), 0, st, zf, words, (uint64_t)h.dst_len);
+            hipLaunchKernelGGL(k_zx_jump, dim3(wgs), dim3(256), 0, st, zf, words, wlen);
             if (hipMemcpyAsync(&cur, zf, sizeof cur, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-            if (cur.unresolved == 0) { rounds++; break; }
+            rounds++;
+            if (cur.unresolved == 0) break;
         }
-        if (cur.status == 0) hipLaunchKernelGGL(k_zx_emit, dim3(wgs), dim3(256), 0, st, (const ZxFrame *)zf, (const uint32_t *)words, dst, (uint64_t)h.dst_len);
+        if (cur.status == 0) hipLaunchKernelGGL(k_zx_emit, dim3(wgs), dim3(256), 0, st, (const ZxFrame *)zf, (const uint32_t *)words, dst, wlen, a0);
     }
     if (status_out) *status_out = cur.status;
     if (rounds_out) *rounds_out = rounds;

@@ -81,7 +81,8 @@ void launch_zexec_groups(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *
                          const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 struct ZxFrame { uint64_t dst_off, dst_len; uint32_t blk_base, nblk, status, unresolved; };      // k_zexec_par.hip
 int launch_zexec_par(ZxFrame *zf, const ZxFrame &h, const ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch, uint64_t *seqs, uint32_t *rep_scratch,
-                     uint32_t *words, uint8_t *dst, uint32_t *status_out, uint32_t *rounds_out, hipStream_t st);
+                     uint32_t *words, uint8_t *dst, uint32_t *status_out, uint32_t *rounds_out, hipStream_t st,
+                     uint32_t nwin, const uint32_t *win_blk, const uint64_t *win_off);
 void launch_zexec(ZFrame *frames, const ZFrameX *fx, uint32_t n, ZBlock *blocks, const uint8_t *src, const uint8_t *lit_scratch,
                   const uint64_t *seqs, uint8_t *dst, hipStream_t st);
 std::string pna_sanitize_name(const char *name, size_t n);
@@ -165,6 +166,8 @@ struct Tuning {
     long stream_overlap_mib = 64;    // PNA_STREAM_OVERLAP_MIB: while a batch runs on the device the next one is taken (and copied in beside it) only once the queue holds this much
     long stream_batch_mib = 256;     // PNA_STREAM_BATCH_MIB: input bytes one batch of the streaming facade takes at most (the queue's rest is the next batch, which is copied in meanwhile)
     long zexec_par_min_mib = 8;      // PNA_ZEXEC_PAR_MIN_MIB: zstd frames whose content takes this many MiB and more are executed in parallel by pointer jumping (0: never)
+    long zdec_fallback_max_mib = 0;  // PNA_ZDEC_FALLBACK_MAX_MIB: zstd frames of more content than this that the parallel paths cannot take are REFUSED (PNA_E_UNSUPPORTED) instead of decoded by one workgroup at ~11 MiB/s (0: no limit) -- a host may prefer its CPU decoder
+    long zexec_win_mib = 1024;       // PNA_ZEXEC_WIN_MIB: output bytes of one window of the parallel executor (its words count 31 bits from the window's start: at most 1 024; tests take a few MiB)
     long small_geometry = 1;         // PNA_SMALL_GEOMETRY: 1 (default): segments of at most 4 096 bytes run the small geometry of the match finder (pna_dev.h SMALL_SEG: one wave per segment, sub-tiles of 256 positions); 0: the large one like every segment (they then find no match: one tile)
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB

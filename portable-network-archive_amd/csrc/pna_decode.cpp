@@ -1,5 +1,29 @@
 // pna_decode.cpp -- the decoders' host side: pna_gpu_decompress_batch[_device], open-size decode, the routing of large frames.
 #include "pna_ctx.h"
+
+// The parallel executor (k_zexec_par.hip) runs a frame / stream in WINDOWS of whole blocks, at most zexec_win_mib (1 024) MiB of output each (its words count 31 bits from the
+// window's start): the cuts, from the blocks' output offsets (k_zoff / the chunk decoder's count pass have set them).  One window for everything up to 1 GiB.
+static int zx_windows(pna_gpu_ctx *c, const ZxFrame &h, hipStream_t st, std::vector<uint32_t> &win_blk, std::vector<uint64_t> &win_off, uint64_t *max_win) {
+    win_blk.assign(1, 0u); win_off.assign(1, 0ull);
+    uint64_t mx = h.dst_len;
+    const uint64_t WMAX = (uint64_t)c->tun.zexec_win_mib << 20;
+    if (h.dst_len > WMAX) {
+        std::vector<ZBlock> hb(h.nblk);
+        HIPCHK(c, hipMemcpyAsync(hb.data(), (const ZBlock *)c->z_blocks.p + h.blk_base, (size_t)h.nblk * sizeof(ZBlock), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        mx = 0;
+        uint64_t start = 0;
+        for (uint32_t k = 0; k < h.nblk; k++) {
+            const uint64_t rel = hb[k].out_off - h.dst_off, end = rel + hb[k].out_len;
+            if (end - start > WMAX && rel > start) { mx = std::max(mx, rel - start); win_blk.push_back(k); win_off.push_back(rel); start = rel; }
+        }
+        mx = std::max(mx, h.dst_len - start);
+    }
+    win_blk.push_back(h.nblk); win_off.push_back(h.dst_len);
+    *max_win = mx;
+    return PNA_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Read side, Compression::Deflate: one zlib stream per entry (flate2::read::ZlibDecoder, lib/src/entry/read.rs:178-179).
 // k_inflate turns each stream into literals + (run, length, distance) records, k_zoff / k_zexec execute them, k_iadler_* check
@@ -127,7 +151,7 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
         pieces += (raw_len[i] + 65535) >> 16;
         if (pieces > 0xFFFFFFF0ull) return fail(c, PNA_E_INVAL, "batch too large for one decode call");
         // (open: raw_len is the room, the size comes out of the count; the stream must be worth it by its compressed size then)
-        if (spec_min && (open ? src_len[i] >= spec_min / 4 : raw_len[i] >= spec_min) && raw_len[i] < (1ull << 31) && src_len[i] < (1ull << 32) && src_len[i] >= 8ull * SPEC_CHUNK) cand.push_back((uint32_t)i);
+        if (spec_min && (open ? src_len[i] >= spec_min / 4 : raw_len[i] >= spec_min) && src_len[i] < (1ull << 32) && src_len[i] >= 8ull * SPEC_CHUNK) cand.push_back((uint32_t)i);   // (output of any size: the executor works in windows)
     }
     cbase[n] = (uint32_t)pieces;
     for (uint32_t i : cand) { cand_base.push_back(nblk); nblk += (src_len[i] + SPEC_CHUNK - 1) / SPEC_CHUNK; if (nblk > 0x7FFFFFFFull) return fail(c, PNA_E_INVAL, "batch too large for one decode call"); }
@@ -183,11 +207,13 @@ static int inflate_batch_device(pna_gpu_ctx *c, size_t n, const void *d_src, con
         auto &sp = spec[si];
         const uint32_t i = sp.first;
         ZxFrame h{frs[i].dst_off, spec_len[si], sp.second.blk_base, sp.second.nblk, 0, 0};
-        if (c->z_words.ensure(h.dst_len * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+        std::vector<uint32_t> wblk; std::vector<uint64_t> woff; uint64_t wmax = 0;
+        { const int rw = zx_windows(c, h, st, wblk, woff, &wmax); if (rw) return rw; }
+        if (c->z_words.ensure(wmax * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
         HIPCHK(c, hipMemcpyAsync(c->z_zxf.p, &h, sizeof h, hipMemcpyHostToDevice, st));
         uint32_t zst = 0, rounds = 0;
         if (launch_zexec_par((ZxFrame *)c->z_zxf.p, h, (const ZBlock *)c->z_blocks.p, (const uint8_t *)d_src, (const uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p,
-                             (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st) != 0) return fail(c, PNA_E_HIP, "parallel stream execution failed");
+                             (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st, (uint32_t)wblk.size() - 1, wblk.data(), woff.data()) != 0) return fail(c, PNA_E_HIP, "parallel stream execution failed");
         c->zexec_par_rounds = rounds;
         if (zst) { static const uint32_t corrupt = 1u; HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)i * sizeof(ZFrame) + offsetof(ZFrame, status), &corrupt, 4, hipMemcpyHostToDevice, st)); }
     }
@@ -318,7 +344,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
                 HIPCHK(c, hipMemcpyAsync(frs.data(), c->z_frames.p, nfr * sizeof(ZFrame), hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
                 for (uint64_t f = 0; f < nfr; f++)
-                    if (frs[f].status == 0 && frs[f].dst_len >= big_min && frs[f].dst_len < (1ull << 31) - 4096) big.push_back((uint32_t)f);
+                    if (frs[f].status == 0 && frs[f].dst_len >= big_min) big.push_back((uint32_t)f);            // (any size: the executor works in windows of 1 GiB)
                 if (!big.empty()) {
                     if (c->z_big.ensure(big.size() * 4 + 64) || c->z_one.ensure(nblk_cap * 4 + 64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
                     const uint32_t one = 1;
@@ -353,11 +379,13 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
             for (uint32_t f : big) {
                 if (frs[f].status) continue;
                 ZxFrame h{frs[f].dst_off, frs[f].dst_len, fxd[f].blk_base, fxd[f].nblk, 0, 0};
-                if (c->z_words.ensure(h.dst_len * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+                std::vector<uint32_t> wblk; std::vector<uint64_t> woff; uint64_t wmax = 0;
+                { const int rw = zx_windows(c, h, st, wblk, woff, &wmax); if (rw) return rw; }
+                if (c->z_words.ensure(wmax * 4 + 4096) || c->z_rep.ensure((size_t)h.nblk * 24 + 64) || c->z_zxf.ensure(64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
                 HIPCHK(c, hipMemcpyAsync(c->z_zxf.p, &h, sizeof h, hipMemcpyHostToDevice, st));
                 uint32_t zst = 0, rounds = 0;
                 if (launch_zexec_par((ZxFrame *)c->z_zxf.p, h, (const ZBlock *)c->z_blocks.p, (const uint8_t *)d_src, (const uint8_t *)c->z_lit.p, (uint64_t *)c->z_seqs.p,
-                                     (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st) != 0) return fail(c, PNA_E_HIP, "parallel frame execution failed");
+                                     (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st, (uint32_t)wblk.size() - 1, wblk.data(), woff.data()) != 0) return fail(c, PNA_E_HIP, "parallel frame execution failed");
                 c->zexec_par_rounds = rounds;
                 if (zst) {                                            // 2: the serial kernel takes the frame (it decodes from the source again); 3: corrupt
                     const uint32_t code = zst == 2 ? 2u : 1u;
@@ -377,6 +405,12 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
     // ---- frames the bounded pipeline could not take: one workgroup per frame
     std::vector<uint32_t> fb;
     for (uint64_t f = 0; f < nfr; f++) if (frs[f].status == 2) fb.push_back((uint32_t)f);
+    if (c->tun.zdec_fallback_max_mib > 0)
+        for (uint32_t f : fb) if (frs[f].dst_len > ((uint64_t)c->tun.zdec_fallback_max_mib << 20)) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "frame %u: %llu bytes of content would be decoded by one workgroup (option zdec_fallback_max_mib)", f, (unsigned long long)frs[f].dst_len);
+            return fail(c, PNA_E_UNSUPPORTED, msg);
+        }
     if (!fb.empty()) {
         std::vector<ZFrame> sub(fb.size());
         for (size_t k = 0; k < fb.size(); k++) { sub[k] = frs[fb[k]]; sub[k].status = 0; sub[k].out_len = 0; }

@@ -276,13 +276,12 @@ def test_deflate_entry_beyond_4gib_round_trips(big_ctx, pna, pf, codec):
 def test_one_foreign_zstd_frame_beyond_4gib(big_ctx, pna, pf, codec):
     """What the reference writes for a file of more than 4 GiB (tests/bats/large_file.bats; zstd::stream::write::Encoder, lib/src/compress.rs:32-41):
     ONE zstd frame, however large the entry.  The writer here is the system libzstd (one ZSTD_compress call: a single frame with an 8-byte
-    Frame_Content_Size); the device decoder takes the frame on one workgroup, its 32-bit positions re-based as it goes, and every byte is compared
-    in HBM; a flipped bit behind the 4 GiB mark of the content is found."""
+    Frame_Content_Size).  The device decoder parses its 33 000 blocks side by side and executes them by pointer jumping in WINDOWS of 1 GiB (k_zexec_par.hip: a word
+    counts 31 bits from its window's start, sources in front of the window are bytes of the output) -- round 4; until then one workgroup walked such a frame at
+    ~11 MiB/s, which the option zdec_fallback_max_mib refuses here so that a regression fails at once --; every byte is compared in HBM; a flipped bit behind the
+    4 GiB mark of the content is found."""
     if codec.system_libzstd() is None:
         pytest.skip("system libzstd (the writer of the test frame) is absent")
-    if os.environ.get("PNA_TEST_HUGE_FRAME") != "1":
-        pytest.skip("one workgroup decodes the 4 GiB frame at ~11 MiB/s (6 - 7 minutes): run with PNA_TEST_HUGE_FRAME=1; the moving bases are covered by "
-                    "test_one_workgroup_decoder_moves_its_bases, frames below 4 GiB by test_one_large_foreign_zstd_frame")
     gpu_ctx = big_ctx
     import numpy as np
     import torch
@@ -305,6 +304,7 @@ def test_one_foreign_zstd_frame_beyond_4gib(big_ctx, pna, pf, codec):
     del host
     comp = torch.from_numpy(buf[:n]).cuda()
     back = torch.zeros(big + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.set_option("zdec_fallback_max_mib", 64)
     gpu_ctx.decompress_batch_device(comp.data_ptr(), [0], [n], back.data_ptr(), [0], [big])
     assert torch.equal(back[:big], src[:big])
     bad = comp.clone()
@@ -313,6 +313,47 @@ def test_one_foreign_zstd_frame_beyond_4gib(big_ctx, pna, pf, codec):
     try:
         gpu_ctx.decompress_batch_device(bad.data_ptr(), [0], [n], back.data_ptr(), [0], [big])
         same = torch.equal(back[:big], src[:big])                                # (a flipped literal bit may still decode: then the content differs)
+    except pna.PnaGpuError:
+        same = False
+    assert not same
+
+
+@pytest.mark.gpu
+def test_one_foreign_zlib_stream_beyond_4gib(big_ctx, pna, pf, codec):
+    """The same file as Compression::Deflate from the reference's writer (flate2's ZlibEncoder: ONE zlib stream without sync flushes, lib/src/compress.rs:32-41), here from
+    the stdlib's zlib at level 1: more than 4 GiB of content.  The chunk decoder (block starts by trial, a wave per chunk, 64-bit output positions) hands its records to the
+    pointer-jumping executor, which runs them in windows of 1 GiB; until round 4's second half such a stream was PNA_E_UNSUPPORTED (and 2 - 4 GiB took the wave-per-stream
+    walk: 107 s per GiB).  Every byte is compared in HBM, the Adler-32 trailer is checked on the device, damage is refused or decodes differently."""
+    gpu_ctx = big_ctx
+    import numpy as np
+    import torch
+    n1, L = 4 * 1024 + 24, 1 << 20
+    big = n1 * L
+    assert big > 1 << 32
+    _need_hbm(torch, 60)
+    src = torch.empty(big + 4096, dtype=torch.uint8, device="cuda")
+    gpu_ctx.corpus_fill_device(0, 9900, n1, L, L, src.data_ptr())
+    host = src[:big].cpu().numpy()
+    co, parts = zlib.compressobj(1), []
+    for a in range(0, big, 256 << 20):
+        parts.append(co.compress(host[a:a + (256 << 20)].tobytes()))
+    parts.append(co.flush())
+    del host
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    del parts
+    n = buf.size
+    assert n < big // 2
+    comp = torch.from_numpy(buf.copy()).cuda()
+    back = torch.zeros(big + 64, dtype=torch.uint8, device="cuda")
+    gpu_ctx.decompress_batch_device(comp.data_ptr(), [0], [n], back.data_ptr(), [0], [big], algo=pna.ALGO_DEFLATE)
+    assert gpu_ctx.timing().lz_match_launches == 1                                # (decode calls: the streams that went through the chunk decoder)
+    assert torch.equal(back[:big], src[:big])
+    bad = comp.clone()
+    bad[n - 90000] ^= 0x08
+    back.zero_()
+    try:
+        gpu_ctx.decompress_batch_device(bad.data_ptr(), [0], [n], back.data_ptr(), [0], [big], algo=pna.ALGO_DEFLATE)
+        same = torch.equal(back[:big], src[:big])
     except pna.PnaGpuError:
         same = False
     assert not same

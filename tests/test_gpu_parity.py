@@ -1676,6 +1676,29 @@ def test_one_large_foreign_zstd_frame(gpu_ctx, pna, codec):
     assert t is not None
 
 
+def test_parallel_executor_runs_in_windows(gpu_ctx, pna, codec):
+    """The pointer-jumping executor (k_zexec_par.hip) takes a frame in WINDOWS of whole blocks -- a word counts from its window's start, a source in front of the
+    window is a byte of the output already written --, 1 GiB each by default (frames of 2 GiB and more: tests/test_gpu_full_size.py).  With windows of 3 MiB a 40 MiB
+    libzstd frame (window 2 - 8 MiB: matches reach across the cuts) crosses a dozen of them, a 20 MiB stdlib-zlib stream with windows of 1 MiB twenty: same bytes as
+    with one window, damage still refused or different."""
+    raw_d = b"".join(codec.corpus_file(i % 2, 9300 + i, 1 << 20) for i in range(20))
+    comp_d = zlib.compress(raw_d, 6)
+    cases = [(comp_d, raw_d, pna.ALGO_DEFLATE, 1)]
+    if codec.system_libzstd() is not None:
+        raw_z = b"".join(codec.corpus_file(i % 3, 9400 + i, 1 << 20) for i in range(40))
+        raw_z = raw_z[:20 << 20] + raw_z[1 << 20:9 << 20] + raw_z[20 << 20:]                  # (a repeat 19 MiB back: inside the window of the higher levels)
+        cases += [(_libzstd_one_frame(codec, raw_z, 3), raw_z, pna.ALGO_ZSTD, 3), (_libzstd_one_frame(codec, raw_z, 19), raw_z, pna.ALGO_ZSTD, 5)]
+    for comp, raw, algo, win in cases:
+        assert gpu_ctx.decompress_batch([comp], [len(raw)], algo=algo) == [raw]
+        with gpu_ctx.options(zexec_win_mib=(win, 1024)):
+            assert gpu_ctx.decompress_batch([comp], [len(raw)], algo=algo) == [raw], (algo, win)
+            bad = bytearray(comp); bad[len(bad) * 3 // 4] ^= 0x10
+            try:
+                assert gpu_ctx.decompress_batch([bytes(bad)], [len(raw)], algo=algo) != [raw]
+            except pna.PnaGpuError:
+                pass
+
+
 def test_large_foreign_zlib_streams_are_decoded_in_chunks(gpu_ctx, pna, codec):
     """One LARGE zlib stream of a foreign encoder (stdlib zlib: no sync flush every 128 KiB -- what the reference's flate2 writes for a large deflate entry) has no
     markers to cut it at: block starts are found by trial (k_ispec), the chunks between them walked side by side (k_inflate's chunk mode, count + emit), the records
