@@ -78,6 +78,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     const SegDesc sd = segs[blockIdx.x];
     const uint8_t *seg = src + sd.src_off;
     const uint32_t seg_len = sd.len;
+    if (MODE != 2 && !lds_base_is_zero(lds)) __builtin_trap();       // (lds_word: the window's words are addressed from 0)
     const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log, SC = seq_cap_of(blk_log);   // block size of the batch = stride of the per-block arrays
     if (MODE != 2 && (flags & FLAG_HAS_SMALL) && seg_len <= MID_SEG) return;         // (uniform) a short segment: k_lzms's (pna_dev.h; MODE 2 parses its words like any)
     uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
@@ -150,14 +151,16 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     continue;
                 }
                 {
-                    const uint32_t *p = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);    // p[1], p[2] may lie in the mirror
-                    const uint32_t sh = (q[r] & 3) * 8;
-                    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], dm = win32[((q[r] - 4) & (WIN_BYTES - 1)) >> 2];
+                    // ONE base address per run of window words (round 4, as in k_lzm): the dword that holds q - 8; what lies behind the window's end is its mirror
+                    // (48 bytes: the base + 44 at most), and the words are read by their LDS byte address (lz_common.h lds_word)
+                    lds_cu32 *p = lds_word(L_WIN + ((q[r] - 8) & (WIN_BYTES - 4)));
+                    const uint32_t sh = q[r] << 3;                                  // (v_alignbit takes the shift modulo 32)
+                    const uint32_t d0 = p[2], d1 = p[3], d2 = p[4], dm = p[1];
                     lo[r] = __builtin_amdgcn_alignbit(d1, d0, sh);
                     hi[r] = __builtin_amdgcn_alignbit(d2, d1, sh);
                     bq[r] = __builtin_amdgcn_alignbit(d0, dm, sh);                  // the 4 bytes before q (q - 1 in the top byte)
                     bq2[r] = 0;
-                    if (strong) bq2[r] = __builtin_amdgcn_alignbit(dm, win32[((q[r] - 8) & (WIN_BYTES - 1)) >> 2], sh);   // (uniform) and the 4 before those
+                    if (strong) bq2[r] = __builtin_amdgcn_alignbit(dm, p[0], sh);   // (uniform) and the 4 before those
                 }
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
                 sh3[r] = 0; w3[r] = 0;
@@ -209,19 +212,19 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const bool edge = blk_end - (t0 + wbase + 64u * r) < 64u + CAP1;       // (uniform) only the block's last groups can run into its end
                     // all 16 bytes at once: in a wave of 64 candidates some lane nearly always needs bytes 8..15, so a
                     // two-step form pays for both steps plus the exec-mask juggling between them (-0.7 %)
-                    const uint32_t *pq = win32 + ((q[r] & (WIN_BYTES - 1)) >> 2);
-                    const uint32_t shc = (c & 3) * 8, shq = (q[r] & 3) * 8;
+                    lds_cu32 *pq = lds_word(L_WIN + ((q[r] - 8) & (WIN_BYTES - 4)));   // pq[2 ..] = the words at q, pc[2 ..] those at c (one base each: see the look-up)
+                    lds_cu32 *pc = lds_word(L_WIN + ((c - 8) & (WIN_BYTES - 4)));
+                    const uint32_t shc = c << 3, shq = q[r] << 3;
                     uint32_t w0, w1, w2, w3, bc, bc2 = 0;                           // 16 bytes at c, the 4 (strong: 8) bytes before c
                     if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; bc2 = fc[r]; }
                     else {
-                        const uint32_t *pc = win32 + ((c & (WIN_BYTES - 1)) >> 2);
-                        const uint32_t d0 = pc[0], d1 = pc[1], d2 = pc[2], d3 = pc[3], d4 = pc[4], dm = win32[((c - 4) & (WIN_BYTES - 1)) >> 2];
+                        const uint32_t d0 = pc[2], d1 = pc[3], d2 = pc[4], d3 = pc[5], d4 = pc[6], dm = pc[1];
                         w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
                         w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
                         bc = __builtin_amdgcn_alignbit(d0, dm, shc);
-                        if (strong) bc2 = __builtin_amdgcn_alignbit(dm, win32[((c - 8) & (WIN_BYTES - 1)) >> 2], shc);
+                        if (strong) bc2 = __builtin_amdgcn_alignbit(dm, pc[0], shc);
                     }
-                    const uint32_t e2 = pq[2], e3 = pq[3], e4 = pq[4];
+                    const uint32_t e2 = pq[4], e3 = pq[5], e4 = pq[6];
                     const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
                     const uint32_t x2 = __builtin_amdgcn_alignbit(e3, e2, shq) ^ w2;
                     const uint32_t x3 = __builtin_amdgcn_alignbit(e4, e3, shq) ^ w3;
@@ -232,13 +235,12 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                             // the next 16 bytes, only for the lanes where everything before matched (same alignment as above): most capped
                             // matches end here, which keeps them off the wave-cooperative extension in the parse loop.  Far candidates
                             // fetch theirs from the segment now (rare: a few lanes per tile, and the line is usually still in L1 / L2)
-                            const uint32_t *pq2 = win32 + (((q[r] + k16) & (WIN_BYTES - 1)) >> 2);
-                            const uint32_t g0 = pq2[0], g1 = pq2[1], g2 = pq2[2], g3 = pq2[3], g4 = pq2[4];
+                            static_assert(CAP1 <= 32, "the bases' reach: the second 16 bytes end at base + 44, inside the window's 48-byte mirror");
+                            const uint32_t g0 = pq[2 + k16 / 4], g1 = pq[3 + k16 / 4], g2 = pq[4 + k16 / 4], g3 = pq[5 + k16 / 4], g4 = pq[6 + k16 / 4];
                             uint32_t v0, v1, v2, v3;
                             if (isfar) { const U4u t = *(const U4u *)(seg + c + k16); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
                             else {
-                                const uint32_t *pc2 = win32 + (((c + k16) & (WIN_BYTES - 1)) >> 2);
-                                const uint32_t f0 = pc2[0], f1 = pc2[1], f2 = pc2[2], f3 = pc2[3], f4 = pc2[4];
+                                const uint32_t f0 = pc[2 + k16 / 4], f1 = pc[3 + k16 / 4], f2 = pc[4 + k16 / 4], f3 = pc[5 + k16 / 4], f4 = pc[6 + k16 / 4];
                                 v0 = __builtin_amdgcn_alignbit(f1, f0, shc); v1 = __builtin_amdgcn_alignbit(f2, f1, shc);
                                 v2 = __builtin_amdgcn_alignbit(f3, f2, shc); v3 = __builtin_amdgcn_alignbit(f4, f3, shc);
                             }

@@ -34,12 +34,6 @@ __device__ __forceinline__ uint32_t pk_adopt(uint32_t P, uint32_t Pn) {         
     const bool a = (Pn & (0x38u & ~((S - 1) << 3))) != 0 && T > (P | PK_LOW);       // back >= S (S = 1, 2, 4: a test of the upper back bits)
     return a ? T : P;
 }
-// A window word by its LDS BYTE ADDRESS.  The kernels of this file have no static __shared__ variables, so their dynamic LDS starts at address 0 and the window (L_WIN = 0)
-// with it (checked once per workgroup: lds_base_is_zero); through the `lds` symbol every address computation ends in an add of the symbol's (zero) address that the
-// compiler cannot fold -- three v_add_u32 v, 0, v per match step.
-typedef const __attribute__((address_space(3))) uint32_t lds_cu32;
-__device__ __forceinline__ lds_cu32 *lds_word(uint32_t byte_addr) { return (lds_cu32 *)(uintptr_t)byte_addr; }
-__device__ __forceinline__ bool lds_base_is_zero(const uint8_t *dyn) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)dyn == 0u; }
 // GLOG != 0: the hash table of this workgroup lies in GLOBAL memory, 1 << GLOG slots (gtab + blockIdx.x << GLOG): the zstd levels 10 .. 22.  What a
 // 1 MiB segment's match finder can remember is what sets the ratio on text (24 512 slots in LDS 2.70, 2^19 slots 2.96), and LDS
 // cannot hold more; the high levels trade speed for it, as the reference's do.  Look-ups are loads that bypass the CU's L1 (agent-scope atomic loads:

@@ -88,6 +88,12 @@ __device__ __forceinline__ uint32_t row_scan_max(uint32_t v) {
     t = DPP_ROW_SHR(v, 4); v = v > t ? v : t; t = DPP_ROW_SHR(v, 8); v = v > t ? v : t; return v;
 }
 
+// A window word by its LDS BYTE ADDRESS.  The match kernels (k_lz, k_lzm, k_lzms) have no static __shared__ variables, so their dynamic LDS starts at address 0 and the window (L_WIN = 0)
+// with it (checked once per workgroup: lds_base_is_zero); through the `lds` symbol every address computation ends in an add of the symbol's (zero) address that the
+// compiler cannot fold -- three v_add_u32 v, 0, v per match step.
+typedef const __attribute__((address_space(3))) uint32_t lds_cu32;
+__device__ __forceinline__ lds_cu32 *lds_word(uint32_t byte_addr) { return (lds_cu32 *)(uintptr_t)byte_addr; }
+__device__ __forceinline__ bool lds_base_is_zero(const uint8_t *dyn) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)dyn == 0u; }
 // 8 / 4 bytes at an arbitrary segment position from the circular window
 template <uint32_t WB>
 __device__ __forceinline__ void fetch8(const uint32_t *win32, uint32_t pos, uint32_t &lo, uint32_t &hi) {

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pna = importlib.import_module("portable-network-archive_amd")
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
 ctx = pna.Context(0)
-ctx.set_option("trace", 1)
+ctx.set_option("trace", 1)                                       # (says why, when a stream is not decoded in chunks)
 L = 1 << 20
 src = torch.empty(mib * L + 4096, dtype=torch.uint8, device="cuda")
 ctx.corpus_fill_device(0, 9700, mib, L, L, src.data_ptr())

@@ -45,10 +45,19 @@ python3 scripts/zdec_one_frame_rate.py 256 > "$OUT/zdec_one_frame.txt" 2>&1
 python3 scripts/zdec_one_frame_rate.py 1024 >> "$OUT/zdec_one_frame.txt" 2>&1
 python3 scripts/decode_rate_foreign.py 2048 > "$OUT/decode_foreign_frames.txt" 2>&1
 python3 scripts/inflate_one_entry_rate.py 1024 > "$OUT/inflate_one_entry.txt" 2>&1
+python3 scripts/inflate_foreign_stream_rate.py 256 6 > "$OUT/inflate_foreign_stream.txt" 2>&1
+python3 scripts/inflate_foreign_stream_rate.py 1024 6 >> "$OUT/inflate_foreign_stream.txt" 2>&1
 echo decode done
 bash scripts/pmc_insts.sh 4096 > "$OUT/sq_counters.txt" 2>&1
 bash scripts/pmc_sq.sh 4096 >> "$OUT/sq_counters.txt" 2>&1
 bash scripts/pmc_traffic.sh 10000 > "$OUT/pmc_traffic.log" 2>&1
 cp gpurun_out/pmc/summary.json "$OUT/pmc_summary_raw.json" 2>/dev/null
 find "$OUT" -name "*kernel_stats.csv" | head
+fi
+if [ "$PART" = all ] || [ "$PART" = d ]; then
+# streams of 2 GiB and more: the parallel executor's windows (a failing parallel path is refused / falls to paths that end quickly: see the scripts)
+for m in 2560 4200 6000; do timeout -k 10 200 python3 scripts/zdec_huge_frame.py $m >> "$OUT/zdec_huge_frame.txt" 2>&1; done
+echo huge frames done
+for m in 2200 4300; do timeout -k 10 400 python3 scripts/inflate_huge_stream.py $m 2>&1 | grep -v "  compressed" >> "$OUT/inflate_huge_stream.txt"; done
+echo huge streams done
 fi
