@@ -94,7 +94,7 @@ void launch_zdec(ZFrame *, uint32_t, const uint8_t *, uint8_t *, uint8_t *, uint
 void launch_zparse_big_a(ZFrame *, ZFrameX *, const uint32_t *, uint32_t, const uint8_t *, ZBlock *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
 void launch_zparse_big_b(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, const uint32_t *, hipStream_t) { nostub("zparse"); }
 struct ZxFrame;
-int launch_zexec_par(ZxFrame *, const ZxFrame &, const ZBlock *, const uint8_t *, const uint8_t *, uint64_t *, uint32_t *, uint32_t *, uint8_t *, uint32_t *, uint32_t *, hipStream_t) { nostub("zexec_par"); return -1; }
+int launch_zexec_par(ZxFrame *, const ZxFrame &, const ZBlock *, const uint8_t *, const uint8_t *, uint64_t *, uint32_t *, uint32_t *, uint8_t *, uint32_t *, uint32_t *, hipStream_t, uint32_t, const uint32_t *, const uint64_t *) { nostub("zexec_par"); return -1; }
 void launch_zxxh(ZFrame *, uint32_t, const uint8_t *, const uint8_t *, hipStream_t) { nostub("zxxh"); }
 void launch_zscan(const ZEntry *, uint32_t, const uint8_t *, ZFrame *, ZFrameX *, hipStream_t) { nostub("zscan"); }
 void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStream_t) { nostub("zcount"); }
