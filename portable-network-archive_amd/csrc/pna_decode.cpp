@@ -51,29 +51,44 @@ static int inflate_spec_stream(pna_gpu_ctx *c, uint32_t f, const ZFrame &fr, con
     uint32_t m = (uint32_t)ch.size();
     auto why = [&](const char *what, uint64_t a, uint64_t b) { if (c->tun.trace) fprintf(stderr, "[pna inflate] stream %u of %llu B not decoded in chunks: %s (%llu, %llu)\n", f, (unsigned long long)fr.src_len, what, (unsigned long long)a, (unsigned long long)b); };
     if (m < 4) { why("too few block starts found", m, nch); return PNA_OK; }                                      // (stored data, or blocks of more than a chunk each: not worth the two passes)
-    auto run = [&](uint32_t emit) -> int {
-        HIPCHK(c, hipMemcpyAsync(d_chunks, ch.data(), (size_t)m * sizeof(ISChunkH), hipMemcpyHostToDevice, st));
-        launch_inflate_chunks((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, f, d_chunks, m, emit, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
+    // one walk over the chunks ch[idx[0 ..]] (idx empty: all of them): count pass (emit = 0) or emit pass
+    auto run = [&](uint32_t emit, const std::vector<uint32_t> &idx) -> int {
+        const uint32_t cnt = idx.empty() ? m : (uint32_t)idx.size();
+        std::vector<ISChunkH> sub;
+        if (!idx.empty()) { sub.resize(cnt); for (uint32_t i = 0; i < cnt; i++) sub[i] = ch[idx[i]]; }
+        ISChunkH *hp = idx.empty() ? ch.data() : sub.data();
+        HIPCHK(c, hipMemcpyAsync(d_chunks, hp, (size_t)cnt * sizeof(ISChunkH), hipMemcpyHostToDevice, st));
+        launch_inflate_chunks((ZFrame *)c->z_frames.p, (ZFrameX *)c->z_fx.p, f, d_chunks, cnt, emit, (const uint8_t *)d_src, (ZBlock *)c->z_blocks.p, (uint8_t *)c->z_lit.p,
                               (uint64_t *)c->z_seqs.p, st);
-        HIPCHK(c, hipMemcpyAsync(ch.data(), d_chunks, (size_t)m * sizeof(ISChunkH), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hp, d_chunks, (size_t)cnt * sizeof(ISChunkH), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        if (!idx.empty()) for (uint32_t i = 0; i < cnt; i++) ch[idx[i]] = sub[i];
         return PNA_OK;
     };
     // A walk that runs past its chunk's end says the NEXT chunk's start was not a block start (a well-formed header by chance: one in a few 10^9 bit positions --
-    // seen in a 445 MB stream): that chunk is dropped, its predecessor runs on to the start behind it, and the count is taken again.
+    // seen in a 445 MB stream, five of them in a 2 GB one): that chunk is dropped, its predecessor runs on to the start behind it and is counted again -- only it:
+    // the other chunks' counts stand (second half of round 4; before, every repair was a walk over the whole stream, one false start at a time).  A dropped chunk's
+    // own walk says nothing about the chunk behind it, which is judged in the next round by its new predecessor.
     int rc = PNA_OK;
+    std::vector<uint32_t> todo;                                      // (empty: everything)
     for (int round = 0;; round++) {
-        rc = run(0); if (rc) return rc;
-        std::vector<ISChunkH> keep;
-        bool dropped = false;
+        rc = run(0, todo); if (rc) return rc;
+        std::vector<ISChunkH> keep; keep.reserve(m);
+        todo.clear();
+        bool prev_dropped = false;
         for (uint32_t k = 0; k < m; k++) {
-            if (k > 0 && ch[k - 1].status == 4u /* IF_CHAIN */ && !dropped) { dropped = true; continue; }      // (one per round: the predecessor's next end decides about the one behind)
+            if (k > 0 && !prev_dropped && ch[k - 1].status == 4u /* IF_CHAIN */) {           // the predecessor (kept, its walk valid) ran past this chunk's start
+                if (todo.empty() || todo.back() != (uint32_t)keep.size() - 1) todo.push_back((uint32_t)keep.size() - 1);
+                prev_dropped = true;
+                continue;
+            }
+            prev_dropped = false;
             keep.push_back(ch[k]);
         }
-        if (!dropped) break;
+        if (todo.empty()) break;
         if (round >= 16) { why("too many false block starts", m, round); return PNA_OK; }
-        for (size_t k = 0; k < keep.size(); k++) keep[k].end_bit = k + 1 < keep.size() ? keep[k + 1].start_bit : ~0ull;
         ch.swap(keep); m = (uint32_t)ch.size();
+        for (uint32_t i : todo) { ISChunkH &h = ch[i]; const uint64_t sb = h.start_bit; h = ISChunkH{}; h.start_bit = sb; h.end_bit = i + 1 < m ? ch[i + 1].start_bit : ~0ull; }
     }
     uint64_t lit = 0, out = 0, rec = 0;
     for (uint32_t k = 0; k < m; k++) {
@@ -88,7 +103,7 @@ static int inflate_spec_stream(pna_gpu_ctx *c, uint32_t f, const ZFrame &fr, con
     if ((ch[m - 1].end_found + 7) / 8 != fr.src_len) { why("the last chunk does not end with the stream: end bit, stream bytes", ch[m - 1].end_found, fr.src_len); return PNA_OK; }
     lit = out = rec = 0;
     for (uint32_t k = 0; k < m; k++) { ISChunkH &h = ch[k]; h.lit_base = lit; h.out_base = out; h.rec_base = rec; lit += h.nlit; out += (uint64_t)h.nlit + h.mtot; rec += h.nrec; }
-    rc = run(1); if (rc) return rc;
+    rc = run(1, std::vector<uint32_t>()); if (rc) return rc;
     for (uint32_t k = 0; k < m; k++) if (ch[k].status) { why("a chunk's second walk failed: chunk, status", k, ch[k].status); return PNA_OK; }
     *nblk_out = m; *ok = true;
     return PNA_OK;
