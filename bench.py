@@ -100,7 +100,7 @@ def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing:
     return None
 
 
-def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes: int) -> dict:
+def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes: int, unique_files=None) -> dict:
     """The reference's create pipeline restated on the host cores (oracle/cpu_baseline.c), bounded sample of the same workload:
     normal archives = one entry per task on all usable cores (cli/src/command/core.rs:496-537), libzstd level 3 / zlib level 6
     streaming encoders (lib/src/entry/write.rs:257-262); --solid = ONE encoder on ONE thread (lib/src/archive/write.rs:459-463)."""
@@ -108,8 +108,15 @@ def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes
     L = codec.lib()
     cores = usable_cores()
     u64p = ctypes.POINTER(ctypes.c_uint64)
-    n_unique = max(1, min(64 if file_len >= (1 << 16) else 4096, sample_bytes // max(file_len, 1)))
-    data = b"".join(codec.corpus_file(kind, i, file_len) for i in range(n_unique))
+    # the sample's files: the workload's own -- all different, copied from the device's corpus (the same generator: oracle/corpus_model.c == k_corpus, tests) --
+    # when the caller hands them over (unique_files(k) -> the first k files back to back); the generator on the host otherwise (64 files, cycled)
+    want = max(1, sample_bytes // max(file_len, 1))
+    data = unique_files(want) if unique_files is not None else None
+    if data:
+        n_unique = len(data) // file_len
+    else:
+        n_unique = max(1, min(64 if file_len >= (1 << 16) else 4096, want))
+        data = b"".join(codec.corpus_file(kind, i, file_len) for i in range(n_unique))
     L.pna_cpu_zstd_version.restype = ctypes.c_uint
     L.pna_cpu_zlib_version.restype = ctypes.c_char_p
     zver = L.pna_cpu_zstd_version()
@@ -721,7 +728,11 @@ def main() -> None:
                     sample = (args.cpu_sample_mib or (1024 if args.algo == "zstd" else 192)) << 20
                 else:
                     sample = (args.cpu_sample_mib or (256 if args.algo == "zstd" else 48)) * cores << 20
-                line["cpu_baseline"] = cpu_baseline(args.algo, args.framing, args.kind, file_len, sample)
+                def unique_files(k):                            # the first k files of this rank's corpus (device -> host), back to back
+                    k = min(k, n_files)
+                    t = src[:k * stride].view(k, stride)[:, :file_len].contiguous() if stride != file_len else src[:k * file_len]
+                    return t.cpu().numpy().tobytes()
+                line["cpu_baseline"] = cpu_baseline(args.algo, args.framing, args.kind, file_len, sample, unique_files)
                 if e2e is not None and e2e.get("value") and line["cpu_baseline"].get("value"):
                     line["end_to_end"]["vs_cpu_baseline"] = round(e2e["value"] / line["cpu_baseline"]["value"], 2)
             except Exception as e:  # never lose the GPU number because the CPU leg failed
