@@ -282,7 +282,12 @@ int  pna_gpu_create_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n
  *     is what the reference writes, always work.
  *   PNA_ALGO_DEFLATE: one RFC 1950 zlib stream (any block types, sync-flush markers, window <= 32 KiB); Adler-32 is verified.
  *     Streams of 4 GiB and more (compressed or decoded) are decoded by their sync-flush delimited pieces -- what this library
- *     writes; a stream of that size without them is PNA_E_UNSUPPORTED (the wave-per-stream walk counts in 32 bits).
+ *     writes --, or, a foreign encoder's stream without such markers (one flate2 / zlib stream per entry: what the reference writes), in chunks between
+ *     block starts found by trial, as long as its COMPRESSED bytes stay below 4 GiB and it has dynamic blocks to find (up to ~5.9 GiB of content);
+ *     what fits neither is PNA_E_UNSUPPORTED (the wave-per-stream walk counts in 32 bits).
+ *   Single streams of any size are executed in parallel (zstd frames of 2 GiB and more since the second half of round 4: the executor's windows,
+ *     option "zexec_win_mib"); a zstd frame whose compressed bytes exceed 4 GiB, or which does not fit its pooled resources, is left to one workgroup
+ *     (~11 MiB/s) unless the option "zdec_fallback_max_mib" refuses it.
  * Errors: PNA_E_INVAL for corrupt / mismatching streams (pna_gpu_last_error names the entry), PNA_E_UNSUPPORTED for
  * dictionaries and other algorithms. */
 int  pna_gpu_decompress_batch(pna_gpu_ctx *ctx, int algo, size_t n, const void *const *src, const size_t *src_len,
