@@ -91,7 +91,7 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *                                         instead of decoded by one workgroup at ~11 MiB/s; 0 (default): no limit
  *   "zexec_win_mib" [PNA_ZEXEC_WIN_MIB]   decoder: the pointer-jumping execution runs a frame / stream in windows of whole blocks of at most this many MiB of output,
  *                                         one after the other (default and maximum 1 024: a word counts 31 bits from its window's start; scratch = 4 bytes per byte of a window)
- *   "stream_batch_mib" [PNA_STREAM_BATCH_MIB] (256), "stream_overlap_mib" [PNA_STREAM_OVERLAP_MIB] (64), "stream_gather_wgs" [PNA_STREAM_GATHER_WGS] (48): the streaming
+ *   "stream_batch_mib" [PNA_STREAM_BATCH_MIB] (256), "stream_overlap_mib" [PNA_STREAM_OVERLAP_MIB] (24), "stream_gather_wgs" [PNA_STREAM_GATHER_WGS] (48): the streaming
  *                                         facade's pipeline -- largest device batch, how much may queue before a second batch is cut while one is on the device,
  *                                         workgroups of the copy-in kernel
  *   "lazy2" [PNA_LAZY2]                   how far a start looks ahead before it is taken, beyond the next position: 2 (default), 1, 0
