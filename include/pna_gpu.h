@@ -64,7 +64,7 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  * consults the environment afterwards.  PNA_E_INVAL for unknown names and values out of range.
  *   "blk_log" [PNA_BLK_LOG]               block size of every batch = 1 << value (13..17); 0 = chosen by batch size (default)
  *   "unit_log" [PNA_LZ_UNIT_LOG]          LZ-stage units of 1 << value bytes (block size..20); 0 = chosen by batch size (default)
- *   "latency_max_mib" [PNA_LATENCY_MAX_MIB]  batches of at most this many MiB of input run in LATENCY MODE (default 192; 0 = never): smaller
+ *   "latency_max_mib" [PNA_LATENCY_MAX_MIB]  batches of at most this many MiB of input run in LATENCY MODE (default 128; 0 = never): smaller
  *                                         blocks inside the same frames and one LZ workgroup per unit instead of per segment, so that a handful
  *                                         of entries -- the CompressionWriter seam under the reference's thread pool -- fills the chip.  Same
  *                                         format, same decoders; ratio -0.1 .. -0.3 % (block headers).  pna_gpu_last_timing reports what was chosen.
