@@ -68,6 +68,8 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *                                         blocks inside the same frames and one LZ workgroup per unit instead of per segment, so that a handful
  *                                         of entries -- the CompressionWriter seam under the reference's thread pool -- fills the chip.  Same
  *                                         format, same decoders; ratio -0.1 .. -0.3 % (block headers).  pna_gpu_last_timing reports what was chosen.
+ *                                         zstd calls beyond the mode still take smaller blocks by their input (32 KiB up to 384 MiB, 64 KiB up to 1 GiB, 128 KiB
+ *                                         beyond: a batch's time below ~1 GiB is its blocks' chains); 0 = never AND 128 KiB blocks whatever the batch.
  *   "hist_by_block" [PNA_HIST_BY_BLOCK]   zstd entropy stage with statistics per block and three-lane state chains (1) or per segment and the one-kernel
  *                                         sequence coder (0); -1 (default): the first up to 40 960 blocks per sub-batch.  Same bytes either way.
  *   "lz_split" [PNA_LZ_SPLIT]             0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse

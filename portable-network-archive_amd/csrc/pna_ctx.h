@@ -232,6 +232,7 @@ struct pna_gpu_ctx {
     std::mutex lent_mu; std::vector<std::pair<const uint8_t *, size_t>> lent;
     DevBuf dp_in[4], dp_out[2];
     hipStream_t cp_in = nullptr, cp_out = nullptr;
+    uint64_t call_total = 0;                          // input bytes of the whole call that run_subbatch's sub-batch belongs to (0: the sub-batch is the call): decides the block size
     hipStream_t aux = nullptr;                        // entropy stage of chunk c runs here while k_lz works on chunk c+1
     static constexpr int MAXCH = 8;
     hipEvent_t ev_lz[MAXCH + 1] = {}, ev_en[MAXCH][4] = {}, ev_join = nullptr, ev_fork = nullptr;

@@ -602,7 +602,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     const uint32_t frame_max_payload = (fj && !fj->solid && !fj->cipher && max_len <= 16384) ? (uint32_t)std::min<size_t>(pna_gpu_bound(algo, (size_t)max_len), 0xFFFFFFFFu) : 0u;
     const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
     uint32_t blk_log = blk_log_for_longest(c, max_len), unit_log = 20;
-    if (latency && blk_log == PNA_BLK_LOG) {
+    if (latency && blk_log == PNA_BLK_LOG && algo != PNA_ALGO_ZSTD) {
         // blocks: 16 KiB up to 16 MiB of input (a block's sequence chain then is ~1 000 steps), then growing with the batch so that the
         // block count -- per-block fixed costs of the entropy kernels -- stays near 1 024 .. 2 048
         blk_log = 14;
@@ -610,6 +610,17 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         // units: about one per CU (256), never smaller than a block
         unit_log = blk_log;
         while (unit_log < 20 && (in_total >> unit_log) > 384) unit_log++;
+    } else if (blk_log == PNA_BLK_LOG && algo == PNA_ALGO_ZSTD && c->tun.latency_max_mib > 0 && !(c->call_flags & 0x100u)) {       // (latency_max_mib = 0: 128 KiB blocks whatever the batch)
+        // zstd, measured again on the round's final kernels (LAB_LOG.md 4.9: one device batch of n x 1 MiB): what a batch below ~1 GiB costs is its blocks' chains, so
+        // the blocks stay small well beyond the latency mode -- 16 KiB up to 32 MiB of input, 32 KiB up to 384 MiB, 64 KiB up to 1 GiB (256 MiB: 3.3 -> 2.5 ms, 512: 5.2 -> 4.6;
+        // ratio 2.847 -> 2.844 / 2.846), the call's whole input deciding where a large call is cut into sub-batches --, and UNITS pay only while they fit ONE round of
+        // the chip's CUs (every unit replays the packed table's walk up to its start): up to 64 MiB of input; beyond, whole segments (80 MiB: 2.55 -> 2.0 ms)
+        const uint64_t sz = std::max<uint64_t>(in_total, c->call_total);
+        blk_log = sz <= (32ull << 20) ? 14u : (sz <= (384ull << 20) ? 15u : (sz <= (1ull << 30) ? 16u : (uint32_t)PNA_BLK_LOG));
+        if (latency && in_total <= (64ull << 20)) {
+            unit_log = blk_log;
+            while (unit_log < 20 && (in_total >> unit_log) > c->n_cus) unit_log++;
+        }
     }
     if (c->tun.unit_log) unit_log = (uint32_t)std::max<long>(c->tun.unit_log, blk_log);
     if (unit_log < blk_log) unit_log = blk_log;
@@ -1135,6 +1146,8 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
     uint64_t out_base = 0, in_total = 0;
     size_t e = 0;
     plan_call(c, src_len, n);
+    { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += src_len[i]; c->call_total = t; }      // (the block size follows the call, not its sub-batches)
+    struct ClearTotal { pna_gpu_ctx *c; ~ClearTotal() { c->call_total = 0; } } clear_total{c};
     while (e < n) {
         size_t e1 = e; size_t blocks = 0;
         while (e1 < n) {
@@ -1260,6 +1273,8 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
+    { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += src_len[i]; c->call_total = t; }      // (the block size follows the call, not its sub-batches)
+    struct ClearTotal { pna_gpu_ctx *c; ~ClearTotal() { c->call_total = 0; } } clear_total{c};
     FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, entry_off != nullptr};
     size_t e = 0;
     plan_call(c, src_len, n);

@@ -89,8 +89,10 @@ def test_units_do_not_change_a_byte(pna, codec):
 
 
 def test_the_librarys_own_choice(pna, codec, monkeypatch):
-    """The default context: one 1 MiB entry runs in 64 units of 16 KiB blocks, a batch of 40 MiB in coarser ones, a batch beyond the mode's
-    limit in whole segments and 128 KiB blocks; the model with the reported block size reproduces each."""
+    """The default context: one 1 MiB entry runs in 64 units of 16 KiB blocks, a batch of 40 MiB in coarser ones (32 KiB blocks, units that fit one round of the
+    chip's CUs), a batch beyond the mode's limit in whole segments -- with blocks that still follow the call's size (zstd: 16 KiB up to 32 MiB of input, 32 KiB up to
+    384 MiB, 64 KiB up to 1 GiB, 128 KiB beyond: the headline) --, and with latency_max_mib = 0 in 128 KiB blocks whatever the batch; the model with the reported
+    block size reproduces each."""
     import torch  # noqa: F401
     one = codec.corpus_file(0, 700, 1 << 20)
     with pna.Context(0) as ctx:
@@ -101,15 +103,26 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
         ents = [codec.corpus_file(0, 701 + i, 1 << 20) for i in range(40)]
         outs = ctx.compress_batch(ents)
         t = ctx.timing()
-        assert 14 < t.blk_log <= 17 and 0 < t.lz_units <= 640, (t.blk_log, t.lz_units)
+        assert t.blk_log == 15 and 0 < t.lz_units <= 256, (t.blk_log, t.lz_units)
         pz = codec.params_for_level(3, blk_log=t.blk_log)
         for e, o in zip(ents[:4], outs[:4]):
             assert o == codec.model_compress(e, pz)
         ctx.set_option("latency_max_mib", 8)
         outs2 = ctx.compress_batch(ents[:12])
         t = ctx.timing()
+        assert (t.blk_log, t.lz_units) == (14, 0)
+        assert outs2[0] == codec.model_compress(ents[0], codec.params_for_level(3, blk_log=14))
+        outs3 = ctx.compress_batch(ents)                              # 40 MiB, beyond the mode's limit: 32 KiB blocks, whole segments
+        t = ctx.timing()
+        assert (t.blk_log, t.lz_units) == (15, 0)
+        assert outs3[1] == codec.model_compress(ents[1], codec.params_for_level(3, blk_log=15))
+        douts = ctx.compress_batch(ents[:12], algo=pna.ALGO_DEFLATE)   # deflate keeps its 128 KiB blocks outside the mode (every dynamic block repeats the code description)
+        assert ctx.timing().blk_log == 17 and zlib.decompress(douts[0]) == ents[0]
+        ctx.set_option("latency_max_mib", 0)
+        outs4 = ctx.compress_batch(ents[:12])
+        t = ctx.timing()
         assert (t.blk_log, t.lz_units) == (17, 0)
-        assert outs2[0] == codec.model_compress(ents[0], codec.params_for_level(3))
+        assert outs4[0] == codec.model_compress(ents[0], codec.params_for_level(3))
 
 
 def test_compression_writers_in_latency_mode(pna, codec, monkeypatch):
