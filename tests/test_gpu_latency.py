@@ -116,6 +116,12 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
         t = ctx.timing()
         assert (t.blk_log, t.lz_units) == (15, 0)
         assert outs3[1] == codec.model_compress(ents[1], codec.params_for_level(3, blk_log=15))
+        from oracle import pna_format as pf
+        arc = pna.create_archive(ctx, ["m%02d" % i for i in range(len(ents))], ents)    # the archive path follows the same rule: its payloads are the batch call's streams
+        assert ctx.timing().blk_log == 15
+        items = pf.read_archive(arc)[1]
+        assert [it.data for it in items] == outs3
+        assert [d for _, _, d in pna.extract_archive(ctx, arc)] == ents
         douts = ctx.compress_batch(ents[:12], algo=pna.ALGO_DEFLATE)   # deflate keeps its 128 KiB blocks outside the mode (every dynamic block repeats the code description)
         assert ctx.timing().blk_log == 17 and zlib.decompress(douts[0]) == ents[0]
         ctx.set_option("latency_max_mib", 0)
