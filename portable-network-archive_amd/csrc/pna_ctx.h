@@ -295,6 +295,13 @@ inline size_t plan_blocks(const pna_gpu_ctx *c, uint64_t len) {
 // Block size of a batch whose entries are all small: the per-block arrays have the block size as their stride, so a batch of 4 KiB entries on 128 KiB
 // blocks would spend 32 times the memory (and a sub-batch per 131 072 entries) that 8 KiB blocks need.  Entries of up to 64 KiB: the power of two that
 // holds the largest (>= 8 KiB); anything larger: 128 KiB.  (Latency mode, for small batches of large entries, chooses on top of this in run_subbatch.)
+// The input bytes of the whole call for the duration of a scope (pna_gpu_ctx::call_total: run_subbatch picks the block size by the call, not by its sub-batches)
+struct CallTotalScope {
+    pna_gpu_ctx *c;
+    template <class L> CallTotalScope(pna_gpu_ctx *ctx, const L *len, size_t n) : c(ctx) { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += len[i]; c->call_total = t; }
+    ~CallTotalScope() { c->call_total = 0; }
+    CallTotalScope(const CallTotalScope &) = delete; CallTotalScope &operator=(const CallTotalScope &) = delete;
+};
 inline uint32_t blk_log_for_longest(const pna_gpu_ctx *c, uint64_t mx) {
     if (c->tun.blk_log) return (uint32_t)c->tun.blk_log;
     if (mx > 65536) return PNA_BLK_LOG;

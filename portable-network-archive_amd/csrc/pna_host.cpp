@@ -1146,8 +1146,7 @@ extern "C" int pna_gpu_compress_batch_device(pna_gpu_ctx *c, int algo, int level
     uint64_t out_base = 0, in_total = 0;
     size_t e = 0;
     plan_call(c, src_len, n);
-    { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += src_len[i]; c->call_total = t; }      // (the block size follows the call, not its sub-batches)
-    struct ClearTotal { pna_gpu_ctx *c; ~ClearTotal() { c->call_total = 0; } } clear_total{c};
+    const CallTotalScope call_total(c, src_len, n);                                              // (the block size follows the call, not its sub-batches)
     while (e < n) {
         size_t e1 = e; size_t blocks = 0;
         while (e1 < n) {
@@ -1273,8 +1272,7 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
     std::vector<uint64_t> offs(n + 1);
     uint64_t pos = head.size(), in_total = 0;
-    { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += src_len[i]; c->call_total = t; }      // (the block size follows the call, not its sub-batches)
-    struct ClearTotal { pna_gpu_ctx *c; ~ClearTotal() { c->call_total = 0; } } clear_total{c};
+    const CallTotalScope call_total(c, src_len, n);                                              // (the block size follows the call, not its sub-batches)
     FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, entry_off != nullptr};
     size_t e = 0;
     plan_call(c, src_len, n);

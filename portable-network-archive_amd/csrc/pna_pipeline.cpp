@@ -348,8 +348,7 @@ static int create_archive_host_impl(pna_gpu_ctx *c, int algo, int level, size_t 
             }
         } catch (...) { std::lock_guard<std::mutex> lk(mu); stager_rc = PNA_E_NOMEM; staged = subs.size(); cv.notify_all(); }
     });
-    { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += len64[i]; c->call_total = t; }             // (the block size follows the archive, not its sub-batches)
-    struct ClearTotal { pna_gpu_ctx *c; ~ClearTotal() { c->call_total = 0; } } clear_total{c};
+    const CallTotalScope call_total(c, len64, n);                                                   // (the block size follows the archive, not its sub-batches)
     uint8_t *hp_out_dev[2] = {nullptr, nullptr};                 // device views of the page-locked output slots (the copy kernel's destination)
     const uint32_t d2h_wgs = (uint32_t)c->tun.d2h_wgs;
     for (size_t k = 0; k < subs.size() && rc == PNA_OK; k++) {
