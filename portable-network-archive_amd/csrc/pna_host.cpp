@@ -602,7 +602,11 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     const uint32_t frame_max_payload = (fj && !fj->solid && !fj->cipher && max_len <= 16384) ? (uint32_t)std::min<size_t>(pna_gpu_bound(algo, (size_t)max_len), 0xFFFFFFFFu) : 0u;
     const bool latency = c->tun.latency_max_mib > 0 && in_total <= ((uint64_t)c->tun.latency_max_mib << 20) && nseg_est <= 1024 && !(c->call_flags & 0x100u);
     uint32_t blk_log = blk_log_for_longest(c, max_len), unit_log = 20;
-    if (latency && blk_log == PNA_BLK_LOG && algo != PNA_ALGO_ZSTD) {
+    if (blk_log == PNA_BLK_LOG && algo != PNA_ALGO_ZSTD && c->tun.latency_max_mib > 0 && !(c->call_flags & 0x100u) && !(latency && in_total <= (64ull << 20))) {
+        // deflate beyond 64 MiB of input: whole segments, and 64 KiB blocks up to 384 MiB of the call's input (96 / 192 / 256 MiB: 1.78 / 2.19 / 2.52 -> 1.66 / 1.99 / 2.20 ms;
+        // ratio 2.540 -> 2.536: every dynamic block repeats the code description, so the blocks stay larger than zstd's)
+        if (std::max<uint64_t>(in_total, c->call_total) <= (384ull << 20)) blk_log = 16;
+    } else if (latency && blk_log == PNA_BLK_LOG && algo != PNA_ALGO_ZSTD) {
         // blocks: 16 KiB up to 16 MiB of input (a block's sequence chain then is ~1 000 steps), then growing with the batch so that the
         // block count -- per-block fixed costs of the entropy kernels -- stays near 1 024 .. 2 048
         blk_log = 14;

@@ -92,7 +92,7 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
     """The default context: one 1 MiB entry runs in 64 units of 16 KiB blocks, a batch of 40 MiB in coarser ones (32 KiB blocks, units that fit one round of the
     chip's CUs), a batch beyond the mode's limit in whole segments -- with blocks that still follow the call's size (zstd: 16 KiB up to 32 MiB of input, 32 KiB up to
     384 MiB, 64 KiB up to 1 GiB, 128 KiB beyond: the headline) --, and with latency_max_mib = 0 in 128 KiB blocks whatever the batch; the model with the reported
-    block size reproduces each."""
+    block size reproduces each.  Deflate: 64 KiB blocks between 64 and 384 MiB of input."""
     import torch  # noqa: F401
     one = codec.corpus_file(0, 700, 1 << 20)
     with pna.Context(0) as ctx:
@@ -122,8 +122,9 @@ def test_the_librarys_own_choice(pna, codec, monkeypatch):
         items = pf.read_archive(arc)[1]
         assert [it.data for it in items] == outs3
         assert [d for _, _, d in pna.extract_archive(ctx, arc)] == ents
-        douts = ctx.compress_batch(ents[:12], algo=pna.ALGO_DEFLATE)   # deflate keeps its 128 KiB blocks outside the mode (every dynamic block repeats the code description)
-        assert ctx.timing().blk_log == 17 and zlib.decompress(douts[0]) == ents[0]
+        douts = ctx.compress_batch(ents[:12], algo=pna.ALGO_DEFLATE)   # deflate outside the mode: 64 KiB blocks up to 384 MiB of input (every dynamic block repeats the code description: larger than zstd's)
+        assert ctx.timing().blk_log == 16 and zlib.decompress(douts[0]) == ents[0]
+        assert douts[0] == codec.deflate_model_compress(ents[0], codec.params_for_level(6, deflate=True, blk_log=16))
         ctx.set_option("latency_max_mib", 0)
         outs4 = ctx.compress_batch(ents[:12])
         t = ctx.timing()
