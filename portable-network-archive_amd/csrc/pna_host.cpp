@@ -615,7 +615,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         unit_log = blk_log;
         while (unit_log < 20 && (in_total >> unit_log) > 384) unit_log++;
     } else if (blk_log == PNA_BLK_LOG && algo == PNA_ALGO_ZSTD && c->tun.latency_max_mib > 0 && !(c->call_flags & 0x100u)) {       // (latency_max_mib = 0: 128 KiB blocks whatever the batch)
-        // zstd, measured again on the round's final kernels (LAB_LOG.md 4.9: one device batch of n x 1 MiB): what a batch below ~1 GiB costs is its blocks' chains, so
+        // zstd, measured again on the round's final kernels (LAB_LOG.md 4.10: one device batch of n x 1 MiB): what a batch below ~1 GiB costs is its blocks' chains, so
         // the blocks stay small well beyond the latency mode -- 16 KiB up to 32 MiB of input, 32 KiB up to 384 MiB, 64 KiB up to 1 GiB (256 MiB: 3.3 -> 2.5 ms, 512: 5.2 -> 4.6;
         // ratio 2.847 -> 2.844 / 2.846), the call's whole input deciding where a large call is cut into sub-batches --, and UNITS pay only while they fit ONE round of
         // the chip's CUs (every unit replays the packed table's walk up to its start): up to 64 MiB of input; beyond, whole segments (80 MiB: 2.55 -> 2.0 ms)
