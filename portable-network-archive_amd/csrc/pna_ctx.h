@@ -252,6 +252,7 @@ struct pna_gpu_ctx {
     uint64_t comb_batches = 0, comb_entries = 0, comb_max = 0, comb_seq = 0;
     uint32_t comb_linger_us = 0xFFFFFFFFu; // PNA_STREAM_LINGER_US: the leader waits this long for more finishes before it submits (unset: adaptive)
     size_t comb_last = 0;                  // entries of the previous batch
+    size_t comb_peak = 0;                  // the cohort the linger waits for: the largest recent batch (max(batch, peak - 1): a straggler's batch of one does not shrink it)
     // page-locked memory of the streaming facade: write() copies straight into 1 MiB slabs of a pool (no staging copy before the H2D
     // copy), the compressed streams come back into one of two page-locked output slots and the owners drain them from there
     std::mutex pool_mu;

@@ -216,8 +216,16 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
             {   // a short linger lets the other writers of the pool reach their finish(): with T writers in flight the batches then hold ~T
                 // entries instead of T / 2 (two alternating cohorts) -- 16 threads: 1.5 -> 2.7 GiB/s, 4: 0.40 -> 0.73, 64: 4.8 -> 5.4.
                 // Adaptive default: 200 us (a few % of a batch's latency) once more than one writer has been seen, none for a lone writer
+                // (second half of round 4: the linger ENDS as soon as the queue holds as many streams as the largest recent batch (comb_peak) -- the cohort has arrived --; a fixed 200 us
+                // was right for 16 writers and too long for 64, whose cohort of 32 then missed the device's next turn: 64 / 128 writers 18 / 21 -> 20 / 23 GiB/s)
                 const uint32_t lg = c->comb_linger_us != 0xFFFFFFFFu ? c->comb_linger_us : ((c->comb_last > 1 || c->comb_queue.size() > 1) ? 200u : 0u);
-                if (lg) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(lg)); lk.lock(); }
+                if (lg) {
+                    // with a batch on the device the linger ends early (the pipeline's regime: the cohort must not miss the device's next turn); with the device idle it runs its
+                    // time -- that is where two small cohorts merge into one batch again (16 writers as 8 + 8: 9.2 GiB/s; as one cohort: 10)
+                    const size_t want = (c->device_busy || c->staged_waiting) ? std::max<size_t>(c->comb_peak, 2) : (size_t)-1;
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(lg);
+                    while (c->comb_queue.size() < want && c->gate_cv.wait_until(lk, deadline) != std::cv_status::timeout) { }
+                }
             }
             // the batch: the queue's streams in arrival order up to stream_batch_mib of input -- s itself always (it may be anywhere in the queue)
             std::vector<pna_gpu_stream *> batch, rest;
@@ -231,7 +239,7 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
                 }
                 c->comb_queue.swap(rest);
             }
-            c->slot_pending[slot] = batch.size(); c->comb_last = batch.size();
+            c->slot_pending[slot] = batch.size(); c->comb_last = batch.size(); c->comb_peak = std::max<size_t>(batch.size(), c->comb_peak ? c->comb_peak - 1 : 0);
             for (pna_gpu_stream *x : batch) { x->slot = slot; x->queued = false; }
             lk.unlock();
             stream_run_batch(c, batch, slot, [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->comb_leader = false; c->staged_waiting++; c->comb_cv.notify_all(); },
