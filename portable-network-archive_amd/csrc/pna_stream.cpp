@@ -223,7 +223,7 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
                     // with a batch on the device the linger ends early (the pipeline's regime: the cohort must not miss the device's next turn); with the device idle it runs its
                     // time -- that is where two small cohorts merge into one batch again (16 writers as 8 + 8: 9.2 GiB/s; as one cohort: 10)
                     const size_t want = (c->device_busy || c->staged_waiting) ? std::max<size_t>(c->comb_peak, 2) : (size_t)-1;
-                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(lg);
+                    const auto deadline = std::chrono::system_clock::now() + std::chrono::microseconds(lg);       // (system_clock: pthread_cond_timedwait, which the thread sanitizer of this toolchain knows; steady_clock waits go through pthread_cond_clockwait, which it does not)
                     while (c->comb_queue.size() < want && c->gate_cv.wait_until(lk, deadline) != std::cv_status::timeout) { }
                 }
             }
