@@ -39,6 +39,7 @@ if [ "$PART" = all ] || [ "$PART" = b ]; then
 python3 scripts/stream_rate.py 4096 > "$OUT/stream_rate.txt" 2>&1
 python3 scripts/batch_latency.py > "$OUT/batch_latency.txt" 2>&1
 python3 scripts/batch_rate.py > "$OUT/batch_rate.txt" 2>&1
+python3 scripts/batch_sizes.py > "$OUT/batch_sizes.txt" 2>&1
 PNA_TRACE=1 python3 scripts/host_rate.py 10000 > "$OUT/host_rate.txt" 2> "$OUT/host_rate_trace.txt"
 echo seam done
 python3 scripts/zdec_one_frame_rate.py 256 > "$OUT/zdec_one_frame.txt" 2>&1
