@@ -61,8 +61,8 @@ def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
         table = "24512-entry LDS hash table" + ("" if fast else " over the even positions")
     look = ("look-back 32 KiB (inside the 64 KiB LDS window)" if defl else
             "look-back = the LDS window (56 064 B)" if fast else
-            "look-back = the whole 1 MiB segment (the match kernel verifies candidates up to 60 160 B back in its LDS window, older ones in HBM/L2)" if gtab else
-            "look-back 512 KiB of the segment (the match kernel verifies candidates up to %s B back in its LDS window, older ones in HBM/L2)" % ("11 008" if w16 else "27 392"))
+            "look-back = the whole 1 MiB segment (the match kernel verifies candidates up to 61 136 B back in its LDS window, older ones in HBM/L2)" if gtab else
+            "look-back 512 KiB of the segment (the match kernel verifies candidates up to %s B back in its LDS window, older ones in HBM/L2)" % ("11 984" if w16 else "28 368"))
     parse = "greedy+lazy3" if fast else ("greedy+lazy3 with backward adoption (3 rounds, 7 back bytes)" if strong else "greedy+lazy3 with backward adoption (2 rounds)")
     return f"GPU encoder: {table}, {look}, min_match 6, {parse}, 4096-position tiles"
 

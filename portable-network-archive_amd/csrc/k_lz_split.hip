@@ -104,9 +104,12 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     using GEO = LzGeo<WLOG, TAB3>;                          // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
     constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NW3 = GEO::WORDS3;
     // candidates at most NEAR back are verified in the window: the window gives way to the next chunk only BEHIND the tile's first barrier (round 4), so its look-back is a tile
-    // longer than the one-kernel form's (GEO::NEAR): 27 392 bytes with the 32 KiB window (far pairs per wave and tile 56.9 -> 52.6; same results -- NEAR only says where the bytes come from)
-    constexpr uint32_t NEAR = GEO::NEAR + TILE_G;
-    static_assert(WIN_BYTES >= TILE_G + LOOKAHEAD + 16 + NEAR + 8 + 200 && (!DEFL || NEAR >= 32768), "window: look-back (+ 8 back bytes) + this tile + look-ahead");
+    // longer than the one-kernel form's (GEO::NEAR): 27 392 (+ 976, below) bytes with the 32 KiB window (far pairs per wave and tile 56.9 -> 52.6; same results -- NEAR only says where the bytes come from)
+    // ... and this kernel reads at most 40 bytes past a position (the parse kernel extends long matches from memory), so its window runs LA = 64 bytes ahead of the tile instead of
+    // the one-kernel form's LOOKAHEAD + 16: another 976 bytes of look-back
+    constexpr uint32_t LA = 64;
+    constexpr uint32_t NEAR = GEO::NEAR + TILE_G + (LOOKAHEAD + 16 - LA);
+    static_assert(WIN_BYTES >= TILE_G + LA + NEAR + 8 + 200 && (!DEFL || NEAR >= 32768), "window: look-back (+ 8 back bytes) + this tile + look-ahead");
     static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -132,7 +135,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     for (uint32_t i = tid; i < (GLOG ? (4u << GLOG) : GEO::TABLE_BYTES) / 16; i += LZ_THREADS) ((uint4 *)table)[i] = make_uint4(0, 0, 0, 0);
     if (GLOG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (the zeros are in L2 before the pre-warm's atomics and the first look-ups)
     // a unit that starts inside the segment (latency mode): window and table as the segment-long walk has them there (k_lz.hip, lz_common.h)
-    uint32_t loaded_end = sd.u0 + TILE_G + LOOKAHEAD + 16;
+    uint32_t loaded_end = sd.u0 + TILE_G + LA;
     __syncthreads();
     if (sd.u0) {
         if constexpr (TAB3) lz_prewarm3<NW3>(table64, seg, seg_len, sd.u0, tid);
