@@ -199,18 +199,29 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             }
             // ---- candidates (rules as in k_lz)
             uint32_t off[4];
-            bool farj[4];
+            bool farj[4], nearj[4];
+            uint64_t fmj[4] = {0, 0, 0, 0};                                          // TAB3: the far lanes' masks
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if constexpr (TAB3) {
-                    // an entry = (position / 2) << 2 | tag: usable iff its position is >= 8 (entry >= 16: the empty entry 0 included), the tag agrees, the offset fits
-                    const uint32_t o = q0 + j - t3_pos(ent[j]);
-                    off[j] = ((ent[j] >= 16u) & ((ent[j] & 3u) == tag[j]) & (o <= max_off)) ? o : 0u;
+                    // an entry = (position / 2) << 2 | tag: usable iff its position is >= 8 (entry >= 16: the empty entry 0 included), the tag agrees, the offset fits.
+                    // Tag and offset in ONE subtraction (round 5): (q / 2 - 1) << 2 | my tag, less the entry, is 4 r1 with r1 = (offset - 2 - (j & 1)) / 2 where the tags agree
+                    // and has a low bit set where they do not; rotated right by two, r1 or something >= 2^30.  off[j] is only read under nearj / farj.
+                    const uint32_t dd = ((2u * q0 + 4u * (uint32_t)(j >> 1) - 4u) | tag[j]) - ent[j];
+                    const uint32_t r1 = __builtin_amdgcn_alignbit(dd, dd, 2);
+                    // (the three compares' lane masks are combined as SCALARS: a ballot of `a & b` makes the compiler build the boolean on the lanes first)
+                    const uint64_t mv = __builtin_amdgcn_ballot_w64(r1 < ((max_off - (uint32_t)(j & 1)) >> 1)) & __builtin_amdgcn_ballot_w64(ent[j] >= 16u);
+                    const uint64_t mn = __builtin_amdgcn_ballot_w64(r1 < ((NEAR - 1u) >> 1));   // (offset <= NEAR - 1 + (j & 1): inside the window)
+                    fmj[j] = mv & ~mn;
+                    nearj[j] = __builtin_amdgcn_inverse_ballot_w64(mv & mn);
+                    farj[j] = __builtin_amdgcn_inverse_ballot_w64(fmj[j]);
+                    off[j] = 2u * r1 + 2u + (uint32_t)(j & 1);
                 } else {
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
                 off[j] = ((c1 > 8) & ((ent[j] & TAG_MASK) == tag[j]) & (o <= max_off)) ? o : 0u;      // (& not &&: no short-circuit branches)
-                }
                 farj[j] = FAR && off[j] > NEAR;
+                nearj[j] = (off[j] != 0) & !farj[j];
+                }
             }
             // ---- the far candidates (more than NEAR bytes back: outside the window) are handled COMPACTED.  A vector load costs the CU's address unit 16
             // cycles per instruction whatever the number of active lanes, and nearly every wave and position j holds a far lane or two (3 - 6 % of the
@@ -225,7 +236,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             if (FAR) {
                 uint64_t fm[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) fm[j] = __ballot(farj[j]);
+                for (int j = 0; j < 4; j++) fm[j] = TAB3 ? fmj[j] : __builtin_amdgcn_ballot_w64(farj[j]);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     idx[j] = npair + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm[j], 0u));
@@ -246,9 +257,9 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const bool edge = !FULL && blk_end - (t0 + wave * RW) < RW + CAP1;          // (uniform) only the block's last waves can run into its end
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t o = farj[j] ? 0u : off[j], q = q0 + j;
+                const uint32_t o = off[j], q = q0 + j;
                 uint32_t Pj = 0;
-                if (o != 0) {
+                if (nearj[j]) {
                     uint32_t l, bk3;
                     // the candidate's bytes c - 8 .. c + 36 from ONE base address (the dword of c - 8; the mirror behind the window's end covers the base + 44):
                     // pc[0] = c - 8 .., pc[1] = c - 4 .., pc[2 .. 6] the first 16 (+ 4) bytes, pc[6 .. 10] the second

@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 #include "pna_dev.h"
 
+#ifndef PNA_EXP
+#define PNA_EXP 0          /* timing experiments (scripts/exp_variants.sh builds variants of the library with -DPNA_EXP=bits) */
+#endif
 namespace pna {
 
 constexpr uint32_t TAG_BITS = 11, TAG_MASK = (1u << TAG_BITS) - 1;
@@ -43,8 +46,8 @@ __device__ __forceinline__ uint32_t t3_tag(uint32_t h32) { return (h32 >> 16) & 
 // field at bit 0, 21 or 42 of the word WITHOUT a 64-bit shift (a quarter-rate instruction): v_alignbit_b32 takes the shift modulo 32 -- 0, 21, 10 -- over
 // {hi, lo} for the first two fields and over {hi, hi} for the third
 __device__ __forceinline__ uint32_t t3_field(uint64_t w, uint32_t sh) {
-    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-    return __builtin_amdgcn_alignbit(hi, sh == 42u ? hi : lo, sh) & T3_MASK;
+    if (PNA_EXP & 64) { const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32); return __builtin_amdgcn_alignbit(hi, sh == 42u ? hi : lo, sh) & T3_MASK; }
+    return (uint32_t)(w >> sh) & T3_MASK;
 }
 __device__ __forceinline__ uint32_t t3_entry(uint32_t q_even, uint32_t tag2) { return (q_even << 1) | tag2; }     // (q / 2) << 2 | tag
 __device__ __forceinline__ uint32_t t3_pos(uint32_t fld) { return (fld >> 1) & ~1u; }                             // the position an entry names
@@ -70,9 +73,11 @@ __device__ __forceinline__ uint32_t ffbl_hw(uint32_t x) { uint32_t r; asm("v_ffb
 __device__ __forceinline__ uint32_t first_diff16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
     const uint32_t f0 = ffbl_hw(x0), f1 = __builtin_elementwise_add_sat(ffbl_hw(x1), 32u), f2 = __builtin_elementwise_add_sat(ffbl_hw(x2), 64u),
                    f3 = __builtin_elementwise_add_sat(ffbl_hw(x3), 96u);
-    uint32_t m = f0 < f1 ? f0 : f1; const uint32_t n = f2 < f3 ? f2 : f3; m = m < n ? m : n;
-    m >>= 3;
-    return m < 16u ? m : 16u;
+    if (PNA_EXP & 32) { uint32_t m = f0 < f1 ? f0 : f1; const uint32_t n = f2 < f3 ? f2 : f3; m = m < n ? m : n; m >>= 3; return m < 16u ? m : 16u; }
+    uint32_t n, m;                                                                  // (two v_min3_u32 -- the cap of 16 bytes rides in the first; left to the compiler: three mins)
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(n) : "v"(f2), "v"(f3), "s"(128u));
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(f0), "v"(f1), "v"(n));
+    return m >> 3;
 }
 __device__ __forceinline__ uint64_t mlow(uint32_t n) { return n >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1); }   // bits [0, n)
 
