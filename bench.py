@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # what streaming kernels reach of it on MI355X (same guide, HBM section)
 def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
     """The level set behind the (clamped) `level` in words (pna_host.cpp level_flags / set_call_level)."""
     defl = algo == "deflate"
@@ -100,6 +101,20 @@ def recorded_traffic(n_files: int, file_len: int, algo: str, kind: int, framing:
     return None
 
 
+def recorded_issue(kernel: str):
+    """Issue-side counters of the dominant kernel from the committed SQ pass (profiles/r05_sq_issue.json, written by scripts/pmc_sq.sh on the GPU box):
+    VALU-active share of a wave's cycles x waves per SIMD = share of the SIMD's cycles with a vector instruction in flight, the LDS unit's share likewise.
+    Not measured inside this run (counters cannot be read from within the process)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_sq_issue.json")))
+        k = d[kernel]
+        return {"valu_active_per_wave_cycle": k["valu_active"], "waves_per_simd": k["waves_per_simd"], "issue_frac": round(k["valu_active"] * k["waves_per_simd"], 3),
+                "lds_active_per_wave_cycle": k.get("lds_active"), "lds_unit_frac": round(k.get("lds_active", 0) * k["waves_per_simd"] * 4, 3),
+                "valu_per_wave_tile": k.get("valu_per_wave_tile"), "source": "profiles/r05_sq_issue.json (rocprofv3 --pmc SQ_* passes of this build, scripts/pmc_sq.sh / pmc_insts.sh)"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes: int, unique_files=None) -> dict:
     """The reference's create pipeline restated on the host cores (oracle/cpu_baseline.c), bounded sample of the same workload:
     normal archives = one entry per task on all usable cores (cli/src/command/core.rs:496-537), libzstd level 3 / zlib level 6
@@ -156,11 +171,25 @@ def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes
     out1 = ctypes.c_uint64()
     n1 = max(1, n_files // max(cores, 1) // 4)
     secs1 = fn(buf, n1, file_len, file_len, 1, level, ctypes.byref(out1))
+    # the second bound: + the reference's serial tail (one thread: CRC-32 of every chunk + the write, behind the parallel phase -- the rayon scope ends
+    # before drain_entry_results starts, cli/src/command/core.rs:471-537), timed on the sample's compressed size
+    with_tail = tail_s = None
+    try:
+        L.pna_cpu_baseline_tail.restype = ctypes.c_double
+        L.pna_cpu_baseline_tail.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+        tail_s = L.pna_cpu_baseline_tail(int(out.value), max(1, int(out.value) // max(n_files, 1)))
+        if tail_s > 0:
+            with_tail = n_files * file_len / (secs + tail_s) / 2**20
+    except Exception:
+        pass
     return {"value": n_files * file_len / secs / 2**20, "unit": "MiB/s", "cores": cores, "kind": "port",
             "sample": f"{n_files} x {file_len} B {kind_txt} files ({n_unique} unique), {codec_txt} streaming, one entry per task on {cores} threads "
-                      f"(= usable cores: affinity / cgroup cpu.max; host has {os.cpu_count()} logical CPUs); parallel compression phase only -- the "
-                      f"reference's single-threaded re-order / CRC-32 / write tail (cli/src/command/core.rs:471-493) is not added, which favours the CPU figure",
+                      f"(= usable cores: {cores} of the host's {os.cpu_count()} logical CPUs -- affinity / cgroup cpu.max); `value` = the parallel compression phase only "
+                      f"(favours the CPU); `value_with_serial_tail` adds the reference's single-threaded re-order / CRC-32 / write tail "
+                      f"(cli/src/command/core.rs:471-493) as zlib crc32 + one copy of the compressed bytes on one thread",
             "ratio": n_files * file_len / max(out.value, 1),
+            "value_with_serial_tail": with_tail, "serial_tail_ms": round(tail_s * 1e3, 2) if tail_s and tail_s > 0 else None,
+            "host_logical_cpus": os.cpu_count(),
             "single_thread_mib_s": n1 * file_len / secs1 / 2**20 if secs1 > 0 else None}
 
 
@@ -194,6 +223,7 @@ def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, a
     # the same with the entries in page-locked slots of the library (pna_gpu_host_alloc: the host reads its files straight into them): no staging copy,
     # one host thread issues the copies
     slots = None
+    slot = None
     try:
         import numpy as np
         slot = pna.HostSlot(ctx, n_files * stride + 64)
@@ -209,12 +239,14 @@ def end_to_end(pna, ctx, src, n_files: int, file_len: int, stride: int, names, a
                 raise RuntimeError(f"pna_gpu_create_archive_host (slots) failed: {rc}")
             if it > 0:
                 sbest = dt if sbest is None else min(sbest, dt)
-        slot.free()
         slots = {"value": round(in_bytes / sbest / 2**20, 1), "unit": "MiB/s", "ms": round(sbest * 1e3, 2), "h2d_GBps": round(in_bytes / sbest / 1e9, 2),
                  "path": "the same entries in page-locked slots of pna_gpu_host_alloc (a host that reads its files straight into them): no staging copy, "
                          "one host thread issues the H2D copies"}
     except Exception as e:
         slots = {"value": None, "error": repr(e)}
+    finally:
+        if slot is not None:
+            slot.free()                                           # (page-locked: not left to the context's close when a run fails)
     return {"value": round(in_bytes / best / 2**20, 1), "unit": "MiB/s", "ms": round(best * 1e3, 2), "archive_bytes": count[0], "sink_calls": count[1],
             "from_host_slots": slots,
             "pcie_bytes": in_bytes + count[0], "pcie_GBps": round((in_bytes + count[0]) / best / 1e9, 2), "runs": runs,
@@ -324,9 +356,10 @@ def main() -> None:
     ap.add_argument("--gather-pieces", type=int, default=0,
                     help="archive framing: cut every rank's shard into this many pieces, each compressed and gathered on its own "
                          "(0 = 2 when N > 1, else 1)")
-    ap.add_argument("--gather", choices=["lib", "torch"], default="lib",
+    ap.add_argument("--gather", choices=["lib", "torch"], default="torch",
                     help="N > 1: the ordered gather through the library's own pna_gpu_gather_ordered_start / _wait (RCCL behind the C ABI, include/pna_gpu.h: "
-                         "the default) or through torch.distributed (nccl = RCCL); either way piece h travels while piece h + 1 is compressed")
+                         "opt-in until an N >= 2 hardware run of it is on record) or through torch.distributed (nccl = RCCL: the default); either way piece h travels "
+                         "while piece h + 1 is compressed")
     ap.add_argument("--no-verify", action="store_true", help="skip the device round trip of the last step's archive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory-to-sink leg (N = 1, archive framing)")
@@ -677,7 +710,7 @@ def main() -> None:
         line = {
             "metric": f"archive-create MiB/s (input bytes/sec), {args.algo}-{level}, {wl} {'enwik-style' if args.kind == 0 else 'random-text'} corpus"
                       + (f", {args.encrypt}" if args.encrypt != "none" else "") + ("" if args.framing != "none" else ", compressed streams only (no container)"),
-            "value": round(value, 1), "value_kind": "hbm_resident (inputs in HBM when the timed region starts, archive bytes left in HBM; the host-RAM-to-sink rate of "
+            "value": round(value, 1), "value_hbm_resident": round(value, 1), "value_kind": "hbm_resident (inputs in HBM when the timed region starts, archive bytes left in HBM; the host-RAM-to-sink rate of "
                                                     "SURVEY 8(d) is `end_to_end`)",
             "unit": "MiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -693,11 +726,16 @@ def main() -> None:
                        "gather_pieces": pieces,
                        "gather": (gather_note or ("library (RCCL behind the C ABI: pna_gpu_gather_ordered_start / _wait)" if lib_comm is not None else "torch.distributed")) if world > 1 else None},
             "ratio": round(in_all / max(out_all, 1), 4),
+            # N = 1: what ONE rank of the 8-rank strong-scaling run (configs[2]) would hand to the ordered gather per piece (2 pieces per rank): this step's
+            # archive bytes / 16 -- to be held against xGMI's ~153 GB/s per link
+            "gather_piece_bytes_at_8_ranks": (out_all // 16) if world == 1 and args.framing == "archive" else None,
             "verified": verified,                        # rank 0's archive decoded on the device == its inputs (None: not checked)
             "gathered_archive_verified": gathered_ok,    # N > 1: the archive gathered on rank 0 read back through the extract driver
             # (entries of at most 16 KiB: the match kernel of the short-segment geometry, k_lzms, takes every segment)
             "roofline": {"bound": "hbm", "kernel": ("k_lzms" if (file_len <= 16384 and args.framing != "solid") else "k_lzm") if split else "k_lz", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 5),   # against the ~6.3 TB/s a streaming kernel reaches on this part
+                         "issue": recorded_issue("k_lzm" if split else "k_lz"),           # what the kernel is bound by instead: vector issue + LDS (committed SQ counters)
                          "traffic": recorded_traffic(n_files, file_len, args.algo, args.kind, args.framing, "k_lzm" if split else "k_lz"),
                          "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on this build's LZ kernels "
                                            "(scripts/pmc_traffic.sh); not measured inside this run -- counters cannot be read from within the process",
@@ -735,6 +773,12 @@ def main() -> None:
                 line["cpu_baseline"] = cpu_baseline(args.algo, args.framing, args.kind, file_len, sample, unique_files)
                 if e2e is not None and e2e.get("value") and line["cpu_baseline"].get("value"):
                     line["end_to_end"]["vs_cpu_baseline"] = round(e2e["value"] / line["cpu_baseline"]["value"], 2)
+                    # SURVEY 8(d)'s metric beside the contract's `value` (which stays the HBM-resident rate: the bench contract forbids a PCIe-inclusive `value`
+                    # and a `vs_baseline` without a published number): host RAM -> sink, and its ratio to the CPU pipeline timed on this box, both bounds
+                    line["value_end_to_end"] = e2e["value"]
+                    line["vs_cpu_baseline_end_to_end"] = line["end_to_end"]["vs_cpu_baseline"]
+                    if line["cpu_baseline"].get("value_with_serial_tail"):
+                        line["vs_cpu_baseline_with_serial_tail_end_to_end"] = round(e2e["value"] / line["cpu_baseline"]["value_with_serial_tail"], 2)
             except Exception as e:  # never lose the GPU number because the CPU leg failed
                 line["cpu_baseline"] = {"value": None, "unit": "MiB/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)

@@ -334,7 +334,8 @@ int  pna_gpu_create_archive_part_host(pna_gpu_ctx *ctx, int algo, int level, siz
 /* One process driving several GPUs (SURVEY 8(b) `device_ids, n_devices`): n_ctx contexts (pna_gpu_init per device; they may share a
  * device), the entries cut into contiguous index ranges balanced by bytes, one range per context on a thread of its own through the bounded
  * host pipeline, the parts handed to the sink in index order -- the reference's fan-out + ordered drain (cli/src/command/core.rs:496-537,
- * 471-493) with devices in place of worker threads; no device-to-device traffic.  The archive equals pna_gpu_create_archive_host's. */
+ * 471-493) with devices in place of worker threads; no device-to-device traffic.  The archive equals pna_gpu_create_archive_host's (every range runs with
+ * the block size of the whole call's input bytes). */
 int  pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_t n_ctx, int algo, int level, size_t n, const char *const *names,
                                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 /* Zero-staging input.  The reference reads every file into memory of its own (fs::read, cli/src/command/core.rs:889-913 write_from_path) before the
@@ -350,7 +351,9 @@ int  pna_gpu_host_free(pna_gpu_ctx *ctx, void *buf);
 /* `pna append` (cli/src/command/append.rs:504-560 run_append_archive: open_archive_then_seek_to_end, add the new entries in order,
  * finalize): `archive` is the existing image (or its last part); *write_at receives the offset of its AEND chunk, and the sink receives
  * the bytes that belong there -- the n new entries, compressed on the device, then AEND.  The result, archive[0 .. write_at) followed by
- * the sink's bytes, equals the archive `pna create` writes from all entries at once. */
+ * the sink's bytes, is the archive `pna create` writes from all entries at once -- the same chunks in the same order; byte for byte where both calls
+ * choose the same block size (option `latency_max_mib` = 0 pins it: by default the block size of a call follows the CALL's input bytes, section "levels",
+ * so the old entries' payloads are those of the call that made them). */
 int  pna_gpu_append_archive_host(pna_gpu_ctx *ctx, int algo, int level, const void *archive, size_t archive_len, size_t n,
                                  const char *const *names, const void *const *src, const size_t *src_len, uint64_t *write_at,
                                  pna_sink_fn sink, void *user);
@@ -366,8 +369,10 @@ int  pna_gpu_append_archive_host(pna_gpu_ctx *ctx, int algo, int level, const vo
  *   d_out / out_cap matter on `root` only.  The root's capacity travels with the sizes, so the verdict is COLLECTIVE: when the parts do not fit, every
  *   rank returns PNA_E_DSTSIZE and no rank has sent anything (the communicator stays usable; sizes / total are filled in, so the host can retry with
  *   a larger destination).
- * pna_gpu_gather_ordered_start posts the gather and returns: the only thing it waits for is the 16-bytes-per-rank size exchange on the communicator's own
- * stream; the transfers are ordered behind the work already queued on `hip_stream` (the producer of d_local) and run on the communicator's stream, so
+ * pna_gpu_gather_ordered_start posts the gather and returns: what it waits for is the 16-bytes-per-rank size exchange on the communicator's own
+ * stream -- which runs BEHIND the transfers of the gathers posted before it (one stream per communicator: a second start therefore blocks until the first
+ * gather is done; the overlap that matters, a gather beside the NEXT piece's compression, comes from calling start after that compression was launched) --;
+ * the transfers are ordered behind the work already queued on `hip_stream` (the producer of d_local) and run on the communicator's stream, so
  * they overlap whatever the host launches next (the next piece's compression into another buffer).  pna_gpu_gather_wait blocks until the posted
  * gathers are done; d_local and d_out belong to the gather until then.  pna_gpu_gather_ticket = how many gathers the communicator has posted (the
  * latest one's ticket), pna_gpu_gather_wait_for(ticket) waits for the gathers up to that one only -- the double-buffering host waits for the gather

@@ -209,3 +209,35 @@ double pna_cpu_baseline_solid(const uint8_t *data, size_t n_files, size_t file_l
     if (out_total) *out_total = total;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* The reference's serial tail behind the parallel phase (cli/src/command/core.rs:471-493 drain_entry_results -> Archive::add_entry ->
+ * lib/src/chunk/write.rs: CRC-32 over every chunk, then the bytes go to the writer): ONE thread, once all entries are compressed (the rayon
+ * scope at core.rs:505-537 ends before the drain starts).  Timed here as zlib's crc32 (the reference uses crc32fast; both are table / SIMD CRCs
+ * of the same polynomial) plus one copy of `bytes` compressed bytes into a sink buffer, in chunks of `chunk` bytes.  Returns seconds, < 0 on failure. */
+typedef unsigned long (*fn_crc32)(unsigned long, const unsigned char *, unsigned);
+double pna_cpu_baseline_tail(size_t bytes, size_t chunk) {
+    if (load_zlib()) return -1.0;
+    fn_crc32 crc = (fn_crc32)dlsym(ZL.h, "crc32");
+    if (!crc || !bytes || !chunk) return -1.0;
+    const size_t win = bytes < ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);    /* a 256 MiB window, walked as often as needed */
+    unsigned char *src = (unsigned char *)malloc(win), *dst = (unsigned char *)malloc(win);
+    if (!src || !dst) { free(src); free(dst); return -1.0; }
+    uint32_t x = 12345u;
+    for (size_t i = 0; i < win; i++) { x = x * 1664525u + 1013904223u; src[i] = (unsigned char)(x >> 24); }
+    memset(dst, 0, win);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned long acc = 0;
+    for (size_t done = 0; done < bytes; ) {
+        const size_t off = done % win;
+        size_t n = chunk < bytes - done ? chunk : bytes - done;
+        if (n > win - off) n = win - off;
+        acc ^= crc(0, src + off, (unsigned)n);
+        memcpy(dst + off, src + off, n);
+        done += n;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    volatile unsigned long sinkv = acc ^ dst[win / 2]; (void)sinkv;
+    free(src); free(dst);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1470,6 +1470,12 @@ __global__ void k_zcount(const ZEntry *__restrict__ ents, uint32_t n, const uint
     const uint8_t *p = src + en.src_off;
     uint64_t ip = 0; uint32_t cnt = 0;
     while (ip < en.src_len) {
+        if (ip + 8 <= en.src_len && ((p[ip] | (p[ip + 1] << 8) | (p[ip + 2] << 16) | ((uint32_t)p[ip + 3] << 24)) & 0xFFFFFFF0u) == 0x184D2A50u) {   // a skippable frame: not counted
+            const uint64_t sz = (uint64_t)p[ip + 4] | ((uint64_t)p[ip + 5] << 8) | ((uint64_t)p[ip + 6] << 16) | ((uint64_t)p[ip + 7] << 24);
+            if (ip + 8 + sz > en.src_len) { cnt = 0; break; }
+            ip += 8 + sz;
+            continue;
+        }
         const uint64_t q = zscan_frame_end(p, ip, en.src_len);
         if (!q) { cnt = 0; break; }
         ip = q; cnt++;
@@ -1479,6 +1485,44 @@ __global__ void k_zcount(const ZEntry *__restrict__ ents, uint32_t n, const uint
 }
 void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_zcount, dim3((n + 63) / 64), dim3(64), 0, st, ents, n, src, counts);
+}
+
+// ------------------------------------------------------------------ k_zlist : the frames of ONE payload, whatever their sizes
+// zstd::stream::read::Decoder (decompress_reader, lib/src/entry/read.rs:171-190) reads ANY concatenation of frames, skippable frames (magic 0x184D2A5?, RFC 8878
+// 3.1.2: 4 bytes of length, then that many bytes to ignore) included.  k_zscan only knows the two shapes this library and the reference write -- one frame per
+// entry, or this library's 1 MiB grid --; a payload it cannot place goes through this walk: one thread lists up to `cap` zstd frames from `ip0` on (offset,
+// length, Frame_Content_Size or ~0 where the header carries none), skipping the skippable ones; hdr[0] = frames listed, hdr[1] = where the walk stopped
+// (== len: the payload is through), hdr[2] = 1 when the bytes at the stop are neither kind of frame / truncated.
+struct ZListItem { uint64_t off, len, fcs; };
+__global__ void k_zlist(const uint8_t *__restrict__ src, uint64_t base, uint64_t len, uint64_t ip0, ZListItem *__restrict__ items, uint32_t cap, uint64_t *__restrict__ hdr) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint8_t *p = src + base;
+    uint64_t ip = ip0; uint32_t cnt = 0; uint64_t bad = 0;
+    while (ip < len && cnt < cap) {
+        if (ip + 4 > len) { bad = 1; break; }
+        const uint32_t magic = p[ip] | (p[ip + 1] << 8) | (p[ip + 2] << 16) | ((uint32_t)p[ip + 3] << 24);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            if (ip + 8 > len) { bad = 1; break; }
+            const uint64_t sz = (uint64_t)p[ip + 4] | ((uint64_t)p[ip + 5] << 8) | ((uint64_t)p[ip + 6] << 16) | ((uint64_t)p[ip + 7] << 24);
+            if (ip + 8 + sz > len) { bad = 1; break; }
+            ip += 8 + sz;
+            continue;
+        }
+        const uint64_t q = zscan_frame_end(p, ip, len);
+        if (!q) { bad = 1; break; }
+        const uint32_t fhd = p[ip + 4];
+        const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, dict = fhd & 3;
+        const uint64_t fp = ip + 5 + (single ? 0 : 1) + (dict == 0 ? 0 : (dict == 1 ? 1 : (dict == 2 ? 2 : 4)));
+        const uint32_t fb = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+        uint64_t fcs = ~0ull;
+        if (fb) { fcs = 0; for (uint32_t i = 0; i < fb; i++) fcs |= (uint64_t)p[fp + i] << (8 * i); if (fb == 2) fcs += 256; }
+        items[cnt].off = base + ip; items[cnt].len = q - ip; items[cnt].fcs = fcs;
+        cnt++; ip = q;
+    }
+    hdr[0] = cnt; hdr[1] = ip; hdr[2] = bad;
+}
+void launch_zlist(const uint8_t *src, uint64_t base, uint64_t len, uint64_t ip0, void *items, uint32_t cap, uint64_t *hdr, hipStream_t st) {
+    hipLaunchKernelGGL(k_zlist, dim3(1), dim3(64), 0, st, src, base, len, ip0, (ZListItem *)items, cap, hdr);
 }
 
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, ZFrameX *fx, hipStream_t st) {

@@ -124,9 +124,12 @@ void k_zx_expand(ZxFrame *__restrict__ zf, const ZBlock *__restrict__ blocks, co
     __shared__ uint32_t s_lit[ZXE_THREADS];        // literal index behind each sequence's literals (inclusive prefix of ll)
     __shared__ uint32_t s_ll[ZXE_THREADS], s_off[ZXE_THREADS];
     __shared__ uint32_t s_scan[ZXE_THREADS];
-    __shared__ uint32_t s_bad;
+    __shared__ uint32_t s_bad, s_status;
     const uint32_t tid = threadIdx.x, k = wb0 + blockIdx.x;
-    if (zf->status) return;
+    // (other workgroups raise the status with atomicMax while this one runs: ONE thread reads it, so that every thread of the workgroup takes the same way past the barriers below)
+    if (tid == 0) s_status = zf->status;
+    __syncthreads();
+    if (s_status) return;
     const ZBlock b = blocks[zf->blk_base + k];
     const uint64_t bpos64 = b.out_off - zf->dst_off;                          // block's first byte, frame-relative
     const uint32_t bpos = (uint32_t)(bpos64 - win_off);                       // ... and window-relative (< 2^30: the host's windows)

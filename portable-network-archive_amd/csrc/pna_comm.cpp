@@ -125,7 +125,8 @@ extern "C" int pna_gather_verdict(const uint64_t *pairs, int nranks, int root, u
     return of[(size_t)nranks] > pairs[2 * root + 1] ? PNA_E_DSTSIZE : PNA_OK;
 }
 
-// The gather, posted: the size exchange (16 bytes per rank) runs on the communicator's OWN stream and is the only thing this call waits for; the parts'
+// The gather, posted: the size exchange (16 bytes per rank) runs on the communicator's OWN stream -- behind the transfers of earlier gathers, so a start waits for
+// those as well -- and is what this call waits for; the parts'
 // transfers are queued on that stream behind an event recorded on `hip_stream` (the stream whose work produced d_local) and the call returns.
 // pna_gpu_gather_wait() blocks until they are done; until then d_local and d_out belong to the gather.  So a host that compresses piece k + 1 into a
 // second buffer after this call overlaps it with piece k's transfer -- one RCCL stream per communicator, no RCCL call ever issued on the caller's stream.

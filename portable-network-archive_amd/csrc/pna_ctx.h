@@ -59,6 +59,7 @@ void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, u
 void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st);
 void launch_zscan(const ZEntry *ents, uint32_t n, const uint8_t *src, ZFrame *frames, ZFrameX *fx, hipStream_t st);
 void launch_zcount(const ZEntry *ents, uint32_t n, const uint8_t *src, uint32_t *counts, hipStream_t st);
+void launch_zlist(const uint8_t *src, uint64_t base, uint64_t len, uint64_t ip0, void *items, uint32_t cap, uint64_t *hdr, hipStream_t st);   // items: {off, len, fcs} x cap (24 B each)
 void launch_zparse(ZFrame *frames, ZFrameX *fx, uint32_t n, const uint8_t *src, ZBlock *blocks, ZTables *tabs, uint32_t *huf_list, uint32_t *seq_list,
                    void *work, hipStream_t st);
 void launch_zparse_big_a(ZFrame *frames, ZFrameX *fx, const uint32_t *big_list, uint32_t nbig, const uint8_t *src, ZBlock *blocks, uint32_t *one_list, void *work, hipStream_t st);
@@ -204,6 +205,7 @@ struct pna_gpu_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     DevBuf blk, tabs, seqs, lits, litc, seqc, seqw, seg_size, seg_off, stage_in, stage_out, ctab, pbuf;
+    DevBuf z_list;                                  // foreign multi-frame payloads: the frame list (k_zlist)
     DevBuf z_big, z_one;                            // large zstd frames: their numbers, their blocks (k_zparse_a -> k_zparse<true>)
     DevBuf z_spec;                                  // large foreign zlib streams: chunk starts + chunk descriptors (k_ispec, k_inflate's chunk mode)
     DevBuf z_words, z_rep, z_zxf;                   // the parallel executor of large zstd frames (k_zexec_par.hip): a word per output byte, histories per block
@@ -297,10 +299,15 @@ inline size_t plan_blocks(const pna_gpu_ctx *c, uint64_t len) {
 // blocks would spend 32 times the memory (and a sub-batch per 131 072 entries) that 8 KiB blocks need.  Entries of up to 64 KiB: the power of two that
 // holds the largest (>= 8 KiB); anything larger: 128 KiB.  (Latency mode, for small batches of large entries, chooses on top of this in run_subbatch.)
 // The input bytes of the whole call for the duration of a scope (pna_gpu_ctx::call_total: run_subbatch picks the block size by the call, not by its sub-batches)
+// A scope opened while another is open on the context (an entry point that cuts its call into parts or pieces and runs each through another entry point: the
+// multi-context create, the host form of compress_batch) leaves the outer total in place -- every part then picks the block size of the WHOLE call, so the
+// bytes do not depend on how the call was cut.
 struct CallTotalScope {
-    pna_gpu_ctx *c;
-    template <class L> CallTotalScope(pna_gpu_ctx *ctx, const L *len, size_t n) : c(ctx) { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += len[i]; c->call_total = t; }
-    ~CallTotalScope() { c->call_total = 0; }
+    pna_gpu_ctx *c; bool own;
+    template <class L> CallTotalScope(pna_gpu_ctx *ctx, const L *len, size_t n) : c(ctx), own(ctx->call_total == 0) {
+        if (own) { uint64_t t = 0; for (size_t i = 0; i < n; i++) t += len[i]; c->call_total = t; } }
+    CallTotalScope(pna_gpu_ctx *ctx, uint64_t total) : c(ctx), own(ctx->call_total == 0) { if (own) c->call_total = total; }
+    ~CallTotalScope() { if (own) c->call_total = 0; }
     CallTotalScope(const CallTotalScope &) = delete; CallTotalScope &operator=(const CallTotalScope &) = delete;
 };
 inline uint32_t blk_log_for_longest(const pna_gpu_ctx *c, uint64_t mx) {

@@ -269,7 +269,7 @@ extern "C" int pna_gpu_inflate_open_device(pna_gpu_ctx *c, const void *d_src, ui
 // ---------------------------------------------------------------------------------------------------------
 // Read side: decompress_reader (lib/src/entry/read.rs:171-190); entries already in device memory.
 static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
-                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st);
+                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st, bool allow_foreign = true);
 
 extern "C" int pna_gpu_decompress_batch_device(pna_gpu_ctx *c, int algo, size_t n, const void *d_src, const uint64_t *src_off,
                                                const uint64_t *src_len, void *d_dst, const uint64_t *dst_off, const uint64_t *raw_len,
@@ -307,8 +307,56 @@ extern "C" int pna_gpu_zstd_decompress_open_device(pna_gpu_ctx *c, const void *d
     return zstd_decode_device(c, 1, d_src, &src_off, &src_len, d_dst, &dst_off, &dst_cap, true, raw_len, st);
 }
 
+// A payload k_zscan could not place -- frames of other sizes than this library's grid, skippable frames between them: anything zstd::stream::read::Decoder
+// reads (lib/src/entry/read.rs:171-190) --: its frames are listed (k_zlist), every run of frames whose headers carry a content size is decoded as one batch of
+// single-frame entries (the pipeline above, side by side), a frame without one on its own with an open size (its content's length is only known once it is
+// decoded), one after the other.  `room` = the entry's raw length (open: its capacity); *found = the bytes produced.
+static int zstd_decode_foreign(pna_gpu_ctx *c, const void *d_src, uint64_t src_off, uint64_t src_len, void *d_dst, uint64_t dst_off, uint64_t room, bool open,
+                               uint64_t *found, hipStream_t st) {
+    struct Item { uint64_t off, len, fcs; };
+    constexpr uint32_t CAP = 4096;
+    if (c->z_list.ensure(CAP * sizeof(Item) + 64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
+    uint64_t *d_hdr = (uint64_t *)((uint8_t *)c->z_list.p + CAP * sizeof(Item));
+    std::vector<Item> items(CAP);
+    uint64_t ip = 0, produced = 0;
+    for (;;) {
+        uint64_t hdr[3] = {0, 0, 0};
+        launch_zlist((const uint8_t *)d_src, src_off, src_len, ip, c->z_list.p, CAP, d_hdr, st);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hdr, d_hdr, sizeof hdr, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (hdr[2]) return fail(c, PNA_E_INVAL, "corrupt stream (not a sequence of zstd frames)");
+        const size_t k = (size_t)hdr[0];
+        if (k) { HIPCHK(c, hipMemcpyAsync(items.data(), c->z_list.p, k * sizeof(Item), hipMemcpyDeviceToHost, st)); HIPCHK(c, hipStreamSynchronize(st)); }
+        for (size_t a = 0; a < k;) {
+            if (items[a].fcs != ~0ull) {                                  // a run of frames that say what they hold: one batch
+                size_t b = a; uint64_t pos = produced;
+                std::vector<uint64_t> so, sl, dof, rl;
+                while (b < k && items[b].fcs != ~0ull) {
+                    if (items[b].fcs > room - pos) return fail(c, PNA_E_INVAL, "size mismatch: the frames hold more than the entry's size");
+                    so.push_back(items[b].off); sl.push_back(items[b].len); dof.push_back(dst_off + pos); rl.push_back(items[b].fcs); pos += items[b].fcs; b++;
+                }
+                int rc = zstd_decode_device(c, so.size(), d_src, so.data(), sl.data(), d_dst, dof.data(), rl.data(), false, nullptr, st, false);
+                if (rc) return rc;
+                produced = pos; a = b;
+            } else {                                                      // no content size in the header: decoded with an open size
+                uint64_t cap = room - produced, got = 0, dof = dst_off + produced;
+                int rc = zstd_decode_device(c, 1, d_src, &items[a].off, &items[a].len, d_dst, &dof, &cap, true, &got, st, false);
+                if (rc) return rc;
+                produced += got; a++;
+            }
+        }
+        ip = hdr[1];
+        if (ip >= src_len) break;
+        if (k == 0) return fail(c, PNA_E_INVAL, "corrupt stream");        // (no progress: cannot happen with hdr[2] == 0)
+    }
+    if (!open && produced != room) return fail(c, PNA_E_INVAL, "size mismatch (the frames do not add up to the entry's size)");
+    *found = produced;
+    return PNA_OK;
+}
+
 static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const uint64_t *src_off, const uint64_t *src_len, void *d_dst,
-                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st) {
+                              const uint64_t *dst_off, const uint64_t *raw_len, bool open, uint64_t *raw_out, hipStream_t st, bool allow_foreign) {
     std::vector<ZEntry> ents(n);
     uint64_t nfr = 0;
     for (size_t i = 0; i < n; i++) {
@@ -362,7 +410,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
                     if (frs[f].status == 0 && frs[f].dst_len >= big_min) big.push_back((uint32_t)f);            // (any size: the executor works in windows of 1 GiB)
                 if (!big.empty()) {
                     if (c->z_big.ensure(big.size() * 4 + 64) || c->z_one.ensure(nblk_cap * 4 + 64)) return fail(c, PNA_E_NOMEM, "decoder workspace");
-                    const uint32_t one = 1;
+                    static const uint32_t one = 1;                        // (static: the copy is asynchronous, the source must outlive this scope)
                     for (uint32_t f : big) HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_fx.p + (size_t)f * sizeof(ZFrameX) + offsetof(ZFrameX, pad), &one, 4, hipMemcpyHostToDevice, st));
                     HIPCHK(c, hipMemcpyAsync(c->z_big.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, st));
                 }
@@ -403,8 +451,8 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
                                      (uint32_t *)c->z_rep.p, (uint32_t *)c->z_words.p, (uint8_t *)d_dst, &zst, &rounds, st, (uint32_t)wblk.size() - 1, wblk.data(), woff.data()) != 0) return fail(c, PNA_E_HIP, "parallel frame execution failed");
                 c->zexec_par_rounds = rounds;
                 if (zst) {                                            // 2: the serial kernel takes the frame (it decodes from the source again); 3: corrupt
-                    const uint32_t code = zst == 2 ? 2u : 1u;
-                    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)f * sizeof(ZFrame) + offsetof(ZFrame, status), &code, 4, hipMemcpyHostToDevice, st));
+                    static const uint32_t codes[2] = {1u, 2u};            // (static: the copy is asynchronous)
+                    HIPCHK(c, hipMemcpyAsync((uint8_t *)c->z_frames.p + (size_t)f * sizeof(ZFrame) + offsetof(ZFrame, status), &codes[zst == 2 ? 1 : 0], 4, hipMemcpyHostToDevice, st));
                 }
             }
         }
@@ -449,9 +497,18 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     c->timing = pna_gpu_timing{}; c->timing.ms_lz = ms;            // decoder time reported in the first stage slot
+    std::vector<uint64_t> foreign_len(n, ~0ull);                  // entries that went through zstd_decode_foreign: the bytes they produced
     for (size_t i = 0; i < n; i++)
         for (uint32_t f = 0; f < ents[i].n_frames; f++) {
             const ZFrame &fr = frs[ents[i].first_frame + f];
+            if (allow_foreign && (fr.status == 1 || fr.status == 3)) {
+                // not one of the two shapes k_zscan places (or a frame of the grid walk did not hold its MiB): the payload's frames as they are
+                uint64_t got = 0;
+                const int rcf = zstd_decode_foreign(c, d_src, src_off[i], src_len[i], d_dst, dst_off[i], raw_len[i], open, &got, st);
+                if (rcf) return rcf;
+                foreign_len[i] = got;
+                break;
+            }
             if (fr.status && fr.status != 4) {                    // 4: void slot behind a single frame that holds the whole entry
                 char msg[160];
                 snprintf(msg, sizeof msg, "entry %zu frame %u: %s (produced %u of %llu bytes)", i, f,
@@ -461,6 +518,7 @@ static int zstd_decode_device(pna_gpu_ctx *c, size_t n, const void *d_src, const
         }
     if (open && raw_out)
         for (size_t i = 0; i < n; i++) {                          // sizes found by the decoder: frames in front hold SEG_SIZE each
+            if (foreign_len[i] != ~0ull) { raw_out[i] = foreign_len[i]; continue; }
             uint64_t total = 0;
             for (uint32_t f = 0; f < ents[i].n_frames; f++) { const ZFrame &fr = frs[ents[i].first_frame + f]; if (fr.status != 4) total += fr.dst_len; }
             raw_out[i] = total;

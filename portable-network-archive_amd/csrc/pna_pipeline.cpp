@@ -1,6 +1,7 @@
 // pna_pipeline.cpp -- the host-memory create pipelines of libpna_gpu.so: bounded staging || H2D || kernels || D2H (pna_gpu_create_archive_host and its
 // forms, solid, multi-context, append, zero-staging host slots) and pna_gpu_compress_batch from host buffers.
 #include "pna_ctx.h"
+#include <memory>
 static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *src_len, const uint64_t *off, size_t e0, size_t e1, unsigned threads);
 
 // The same from host memory: one H2D of the entries, the device path above, one D2H of the archive, handed to the sink in
@@ -167,6 +168,9 @@ extern "C" int pna_gpu_create_archive_multi_host(pna_gpu_ctx *const *ctxs, size_
     // ctxs[0] (what pna_gpu_last_error of the first context reports).
     struct Part { std::vector<uint8_t> buf; int rc = PNA_OK; bool done = false; };
     std::vector<Part> parts(n_ctx);
+    // every range picks the block size of the WHOLE call (pna_ctx.h CallTotalScope): the archive equals pna_gpu_create_archive_host's on one context
+    std::vector<std::unique_ptr<CallTotalScope>> whole;
+    for (size_t r = 0; r < n_ctx; r++) whole.emplace_back(new CallTotalScope(ctxs[r], total));
     std::mutex mu; std::condition_variable cv;
     auto vec_sink = [](void *u, const void *b, size_t k) -> int { auto *v = (std::vector<uint8_t> *)u; try { v->insert(v->end(), (const uint8_t *)b, (const uint8_t *)b + k); } catch (...) { return 1; } return 0; };
     std::vector<std::thread> th;
@@ -409,6 +413,7 @@ extern "C" int pna_gpu_compress_batch(pna_gpu_ctx *c, int algo, int level, size_
         obase[i] = bound; bound += pna_gpu_bound(algo, src_len[i]);
     }
     off[n] = pos; obase[n] = bound;
+    const CallTotalScope call_total(c, src_len, n);              // (the pieces below pick the block size of the whole call: the bytes equal pna_gpu_compress_batch_device's)
     // Inputs are staged into page-locked memory by several threads and copied H2D, outputs copied D2H and scattered by several threads
     // (per-entry copies from pageable memory ran at ~1 GiB/s).  A large batch goes through in PIECES of >= 256 MiB (a round of the CUs:
     // the kernels' fixed latencies stay amortised): piece k + 1 is staged and copied while piece k is on the device, piece k - 1's results

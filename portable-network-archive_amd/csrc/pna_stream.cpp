@@ -87,7 +87,7 @@ extern "C" void pna_gpu_stream_abort(pna_gpu_stream *s) { if (s) { pool_put(s->c
 // streams are staged first) on the copy-in stream; `in_done()` then hands the leader's role on, and the next batch is copied in while this one runs;
 // (2) the device batch under run_mu; (3) ONE D2H copy of the group's streams into the slot's page-locked output on the copy-out stream.
 static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *> &batch, int slot, const std::function<void()> &in_done, const std::function<void()> &on_device,
-                             const std::function<void()> &off_device) {
+                             const std::function<void()> &off_device, const std::function<void()> &in_failed) {
     auto set_err = [&](int code, const char *what) { std::lock_guard<std::mutex> lk(c->err_mu); return fail(c, code, what); };
     auto fail_all = [&](int rc) { for (pna_gpu_stream *x : batch) if (x->rc == PNA_OK && !x->out) { x->rc = rc; x->out_len = 0; } };
     struct Grp { std::vector<pna_gpu_stream *> st; std::vector<uint64_t> off, len, doff; uint64_t in_base = 0, in_bytes = 0, bound = 0, out_base = 0; int rc = PNA_OK; };
@@ -155,7 +155,7 @@ static void stream_run_batch(pna_gpu_ctx *c, const std::vector<pna_gpu_stream *>
         if (rc0 == PNA_OK && hipStreamSynchronize(c->s_h2d) != hipSuccess) rc0 = set_err(PNA_E_HIP, "H2D copy failed");
     }
     in_done();                                                           // the leader's role is free (the next batch is taken once this one is on the device)
-    if (rc0 != PNA_OK) { on_device(); off_device(); fail_all(rc0); return; }
+    if (rc0 != PNA_OK) { in_failed(); fail_all(rc0); return; }          // (the batch never reaches the device: it only stops waiting -- device_busy belongs to the batch that IS there)
     const auto t1 = std::chrono::steady_clock::now();
     // ---- stage 2: the device batch (the context's kernels and workspaces: one at a time)
     auto t2 = t1;
@@ -244,7 +244,8 @@ extern "C" int pna_gpu_stream_finish(pna_gpu_stream *s) {
             lk.unlock();
             stream_run_batch(c, batch, slot, [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->comb_leader = false; c->staged_waiting++; c->comb_cv.notify_all(); },
                              [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->staged_waiting--; c->device_busy = true; c->gate_cv.notify_one(); },
-                             [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->device_busy = false; c->gate_cv.notify_one(); });
+                             [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->device_busy = false; c->gate_cv.notify_one(); },
+                             [&]() { std::lock_guard<std::mutex> g(c->comb_mu); c->staged_waiting--; c->gate_cv.notify_one(); });
             lk.lock();
             for (pna_gpu_stream *x : batch) x->done = true;          // owners may free their streams as soon as the lock is released
             c->comb_batches++; c->comb_entries += batch.size(); c->comb_max = std::max<uint64_t>(c->comb_max, batch.size());

@@ -1566,6 +1566,78 @@ def test_one_process_several_contexts(gpu_ctx, pna, pf, codec):
             c.close()
 
 
+def test_decoder_reads_what_the_reference_decoder_reads(gpu_ctx, pna, pf, codec):
+    """decompress_reader -> zstd::stream::read::Decoder (lib/src/entry/read.rs:171-190) reads ANY concatenation of frames: frames of any content size, with or
+    without Frame_Content_Size, with or without Content_Checksum, skippable frames (magic 0x184D2A5?) between them.  Random concatenations of libzstd frames
+    (levels 1 - 19, 1 B - 3 MiB of content) next to entries of this library's own shapes in ONE batch == oracle/zstd_dec.c (and the system libzstd);
+    a damaged checksum, a truncated skippable frame and a wrong entry size are refused."""
+    import random, struct
+    if codec.system_libzstd() is None:
+        pytest.skip("system libzstd not available")
+    rng = random.Random(20261005)
+    def frame(data, level, fcs, chk):
+        if fcs and not chk:
+            return codec.libzstd_compress(data, level)
+        return codec.libzstd_compress_checksum(data, level, extra=(() if fcs else ((200, 0),)) + (() if chk else ((201, 0),)))
+    def skippable():
+        body = bytes(rng.getrandbits(8) for _ in range(rng.choice((0, 1, 7, 300))))
+        return struct.pack("<II", 0x184D2A50 + rng.randrange(16), len(body)) + body
+    sizes = [1, 2, 17, 255, 4096, 70000, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, 3 << 20, 150000, 999]
+    payloads, raws = [], []
+    for e in range(14):
+        parts, raw = [], b""
+        for k in range(rng.randrange(1, 6)):
+            if rng.random() < 0.4:
+                parts.append(skippable())
+            n = rng.choice(sizes)
+            d = codec.corpus_file(rng.randrange(2), 5000 + 16 * e + k, n)
+            parts.append(frame(d, rng.choice((1, 3, 5, 9, 12, 19)), e % 3 != 0 and rng.random() < 0.7, rng.random() < 0.5))
+            raw += d
+        if rng.random() < 0.5:
+            parts.append(skippable())
+        payloads.append(b"".join(parts)); raws.append(raw)
+    # next to them: this library's own entry (1 MiB grid), one libzstd frame per entry (the reference's shape), an empty entry
+    own = codec.corpus_file(0, 5990, (2 << 20) + 12345)
+    payloads += [gpu_ctx.compress_batch([own])[0], codec.libzstd_compress(own, 3), gpu_ctx.compress_batch([b""])[0]]
+    raws += [own, own, b""]
+    for p, r in zip(payloads, raws):
+        assert codec.zstd_decompress(p, len(r)) == r and codec.libzstd_decompress_stream(p, len(r)) == r       # the checkers agree first
+    assert gpu_ctx.decompress_batch(payloads, [len(r) for r in raws]) == raws
+    # refusals: a checksum that does not match, a skippable frame cut short, a size that the frames do not add up to
+    d = codec.corpus_file(0, 5991, 50000)
+    good = skippable() + frame(d, 3, False, True) + frame(d, 5, True, True)
+    assert gpu_ctx.decompress_batch([good], [2 * len(d)]) == [d + d]
+    bad = bytearray(good); bad[-1] ^= 0x40
+    for payload, size in ((bytes(bad), 2 * len(d)), (good + struct.pack("<II", 0x184D2A51, 100) + b"xy", 2 * len(d)), (good, 2 * len(d) - 1), (good, 2 * len(d) + 1)):
+        with pytest.raises(pna.PnaGpuError):
+            gpu_ctx.decompress_batch([payload], [size])
+
+
+def test_default_contexts_cut_calls_without_changing_bytes(pna, pf, codec):
+    """The library's DEFAULT options (latency mode on, the block size follows the call's input bytes: 16 KiB up to 32 MiB, 32 KiB up to 384 MiB, ...): an
+    entry point that cuts its call -- the multi-context create into ranges, the host form of compress_batch into pieces -- gives every part the block size of
+    the WHOLE call, so the bytes equal the uncut call's (round-4 advisor finding: each part picked its own).  40 MiB sits between the first two thresholds:
+    two ranges of 20 MiB would take 16 KiB blocks where the whole call takes 32 KiB."""
+    import torch  # noqa: F401
+    ents = [codec.corpus_file(0, 4200 + i, 1 << 20) for i in range(40)]
+    names = [f"d/{i:02d}" for i in range(len(ents))]
+    ctxs = [pna.Context(0) for _ in range(3)]
+    try:
+        want = pna.create_archive(ctxs[0], names, ents)
+        assert ctxs[0].timing().blk_log == 15
+        for k in (2, 3):
+            assert pna.create_archive_multi(ctxs[:k], names, ents) == want, k
+        small = pna.create_archive(ctxs[0], names[:20], ents[:20])                    # (the premise: a 20 MiB call of its own does take other blocks)
+        assert ctxs[0].timing().blk_log == 14 and small[:len(want) // 4] != want[:len(want) // 4]
+        # compress_batch from host buffers in pieces of 16 MiB == in one piece
+        one = ctxs[0].compress_batch(ents)
+        ctxs[1].set_option("batch_piece_mib", 16)
+        assert ctxs[1].compress_batch(ents) == one
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_ordered_gather_over_rccl_single_rank(gpu_ctx, pna, pf, codec):
     """pna_gpu_gather_ordered on a communicator of ONE rank (RCCL initialises on a single device; the N-GPU run is the driver's): the all-gather of
     the sizes and the root's own copy run for real, the archive part arrives unchanged and reads back."""
