@@ -176,8 +176,9 @@ def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes
     with_tail = tail_s = None
     try:
         L.pna_cpu_baseline_tail.restype = ctypes.c_double
-        L.pna_cpu_baseline_tail.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
-        tail_s = L.pna_cpu_baseline_tail(int(out.value), max(1, int(out.value) // max(n_files, 1)))
+        L.pna_cpu_baseline_tail.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+        simd = ctypes.c_int(0)
+        tail_s = L.pna_cpu_baseline_tail(int(out.value), max(1, int(out.value) // max(n_files, 1)), ctypes.byref(simd))
         if tail_s > 0:
             with_tail = n_files * file_len / (secs + tail_s) / 2**20
     except Exception:
@@ -186,7 +187,7 @@ def cpu_baseline(algo: str, framing: str, kind: int, file_len: int, sample_bytes
             "sample": f"{n_files} x {file_len} B {kind_txt} files ({n_unique} unique), {codec_txt} streaming, one entry per task on {cores} threads "
                       f"(= usable cores: {cores} of the host's {os.cpu_count()} logical CPUs -- affinity / cgroup cpu.max); `value` = the parallel compression phase only "
                       f"(favours the CPU); `value_with_serial_tail` adds the reference's single-threaded re-order / CRC-32 / write tail "
-                      f"(cli/src/command/core.rs:471-493) as zlib crc32 + one copy of the compressed bytes on one thread",
+                      f"(cli/src/command/core.rs:471-493) as a carry-less-multiplication CRC-32 (the reference's crc32fast) + one copy of the compressed bytes on one thread",
             "ratio": n_files * file_len / max(out.value, 1),
             "value_with_serial_tail": with_tail, "serial_tail_ms": round(tail_s * 1e3, 2) if tail_s and tail_s > 0 else None,
             "host_logical_cpus": os.cpu_count(),

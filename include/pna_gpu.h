@@ -264,6 +264,11 @@ int  pna_gpu_create_solid_archive_enc_device(pna_gpu_ctx *ctx, int algo, int lev
                                              const pna_gpu_cipher *cipher, void *d_dst, size_t dst_cap, uint64_t *archive_len,
                                              void *hip_stream);
 
+/* The same from host memory.  zstd: STREAMING, as SolidArchive::add_entry feeds its one encoder (lib/src/archive/write.rs:575-580): the serialised inner
+ * entries reach the device in windows of `solid_win_mib` MiB (256) through two page-locked slots each way -- about four windows of page-locked memory
+ * whatever the archive's size --, the sink receives the head, one piece per window, the tail; inner entries of ANY size (FDAT chunks of at most
+ * 2^32 - 5 bytes, FlattenWriter's cut, lib/src/util/io.rs:60-77).  The bytes equal pna_gpu_create_solid_archive_device's.  deflate (one zlib stream
+ * with one Adler-32) and option single_frame: the whole stream in flight at once, inner entries below 2 GiB. */
 int  pna_gpu_create_solid_archive_host(pna_gpu_ctx *ctx, int algo, int level, size_t n, const char *const *names,
                                        const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user);
 
@@ -456,6 +461,9 @@ int  pna_gpu_debug_block(pna_gpu_ctx *ctx, uint32_t block, uint64_t *seqs, uint3
 /* Host walk through the device CRC schedule of k_frame with the same tables; returns crc32("FDAT" || payload).
  * CPU-only tests use it to check the table construction; it is not on any product path. */
 uint32_t pna_gpu_debug_crc_schedule(const void *payload, size_t len);
+
+/* Page-locked staging memory the context holds (the host pipelines' slots): tests pin the bounded-memory claims with it; not on any product path. */
+uint64_t pna_gpu_debug_pinned_bytes(pna_gpu_ctx *ctx);
 
 /* Diagnostic build of the LZ kernel (ctx created with flag 0x100): per-phase s_memtime sums over all waves, cleared on read. */
 int  pna_gpu_debug_lz_stamps(pna_gpu_ctx *ctx, unsigned long long *out8);

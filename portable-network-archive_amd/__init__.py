@@ -110,7 +110,7 @@ EXPORTS = [
     "pna_gpu_compress_batch", "pna_gpu_compress_batch_device", "pna_gpu_stream_new", "pna_gpu_stream_write",
     "pna_gpu_stream_flush", "pna_gpu_stream_finish", "pna_gpu_stream_abort", "pna_gpu_compress_solid",
     "pna_gpu_last_timing", "pna_gpu_debug_block", "pna_gpu_debug_lz_stamps", "pna_bench_corpus_fill_device",
-    "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule",
+    "pna_gpu_archive_bound", "pna_gpu_create_archive_device", "pna_gpu_create_archive_host", "pna_gpu_debug_crc_schedule", "pna_gpu_debug_pinned_bytes",
     "pna_gpu_solid_archive_bound", "pna_gpu_solid_archive_enc_bound", "pna_gpu_create_solid_archive_device", "pna_gpu_create_solid_archive_host",
     "pna_gpu_create_archive_part_device", "pna_gpu_decompress_batch", "pna_gpu_decompress_batch_device",
     "pna_gpu_archive_enc_bound", "pna_gpu_create_archive_enc_device", "pna_gpu_cipher_apply_device", "pna_gpu_create_archive_enc_host",

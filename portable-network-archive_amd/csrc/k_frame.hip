@@ -53,10 +53,14 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
     if (d.pad & 1) continue;                                         // record without a data chunk: the prefix is all of it
 
     const uint64_t pay = d.arc_off + d.prefix_len;                   // payload offset in dst
-    const uint32_t n = 4 + d.payload_len;                            // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
+    // pad bit 4 (with `verify`): a PIECE of a chunk -- the raw register R(0, M) of its bytes goes to verify[ent], the host chains the pieces by identity (3); the
+    // first piece carries the type bytes and the folded init value like a whole chunk, pad bit 8 = a later piece: its bytes alone (the streaming solid create:
+    // an inner entry's data chunk reaches the device window by window)
+    const uint32_t tlen = (d.pad & 8) ? 0u : 4u;
+    const uint32_t n = tlen + d.payload_len;                         // "FDAT" || payload  (payload_len <= 2^32 - 5 checked by the host)
     const uint32_t ntile = (n + FR_TILE - 1) / FR_TILE;
     const uint32_t pad = ntile * FR_TILE - n;                        // zero bytes put in front, < FR_TILE
-    const int64_t base = (int64_t)pay - 4 - (int64_t)pad;            // dst offset of message position 0 (may be negative)
+    const int64_t base = (int64_t)pay - (int64_t)tlen - (int64_t)pad; // dst offset of message position 0 (may be negative)
     const uint32_t a = (uint32_t)(base & 15);                        // two's complement: correct for negative base too
     uint32_t state = 0;
 
@@ -81,14 +85,14 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
 #pragma unroll
         for (int j = 0; j < 16; j++) w[j] = (uint32_t)((((uint64_t)w[j + 1] << 32) | w[j]) >> sh);
         const uint32_t p0 = k * FR_TILE + tid * 64;                  // message position of this piece
-        if (p0 < pad + 4) {                                          // first tile only: zero padding and the type bytes
+        if (p0 < pad + tlen) {                                       // first tile only: zero padding and the type bytes
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 uint32_t m = 0, x = 0;
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     const uint32_t p = p0 + 4 * j + b;
-                    if (p >= pad + 4) m |= 0xFFu << (8 * b);
+                    if (p >= pad + tlen) m |= 0xFFu << (8 * b);
                     else if (p >= pad) x |= ((ty_x >> (8 * (p - pad))) & 0xFFu) << (8 * b);
                 }
                 w[j] = (w[j] & m) | x;
@@ -109,6 +113,7 @@ void k_frame(const FrameDesc *__restrict__ fd, const uint8_t *__restrict__ blob,
         if ((tid & (2 * st - 1)) == 0) { const uint32_t pv = part[tid]; part[tid] = (pv ? gf2_mulmod(ct->sh[j], pv) : 0u) ^ part[tid + st]; }
         __syncthreads();
     }
+    if (verify && (d.pad & 4)) { if (tid == 0) verify[ent] = part[0]; continue; }
     if (verify) {
         if (tid == 0) {
             const uint8_t *q = dst + pay + d.payload_len;
@@ -267,6 +272,24 @@ void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, con
     }
     const uint32_t epw = 1u;
     if (n) hipLaunchKernelGGL(k_frame, dim3((n + epw - 1) / epw), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, verify, n, epw);
+}
+
+// Pieces of chunks (FrameDesc::pad bits 4 / 8, above): raw CRC registers into states[0 .. n)
+void launch_frame_pieces(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *states, hipStream_t st) {
+    const uint32_t ty_le = (uint32_t)(uint8_t)ty[0] | ((uint32_t)(uint8_t)ty[1] << 8) | ((uint32_t)(uint8_t)ty[2] << 16) | ((uint32_t)(uint8_t)ty[3] << 24);
+    if (n) hipLaunchKernelGGL(k_frame, dim3(n), dim3(FR_THREADS), 0, st, fd, (const uint8_t *)nullptr, ct, const_cast<uint8_t *>(buf), cap16, 0u, ~ty_le, 0u, states, n, 1u);
+}
+// Big-endian CRC fields written where the host says: patch i puts the bytes j of crc[i] with bit j of mask[i] set at dst[off[i] + j] (a field may straddle the
+// buffer's end: the host then hands the other bytes to the next window)
+struct CrcPatch { int64_t off; uint32_t crc, mask; };
+__global__ void k_crc_patch(const CrcPatch *__restrict__ p, uint32_t n, uint8_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CrcPatch q = p[i];
+    for (int j = 0; j < 4; j++) if ((q.mask >> j) & 1) dst[q.off + j] = (uint8_t)(q.crc >> (24 - 8 * j));
+}
+void launch_crc_patch(const void *patches, uint32_t n, uint8_t *dst, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_crc_patch, dim3((n + 255) / 256), dim3(256), 0, st, (const CrcPatch *)patches, n, dst);
 }
 
 // ------------------------------------------------------------------ k_gather : byte ranges from arbitrary offsets to 16-byte aligned ones

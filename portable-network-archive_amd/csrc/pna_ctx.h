@@ -54,6 +54,9 @@ void launch_link_copy(const uint8_t *src, uint8_t *dst, size_t n, uint32_t wgs, 
 void launch_link_gather(const void *segs, uint32_t nseg, uint32_t wgs, hipStream_t st);   // k_frame.hip: {src, dst, len} x nseg, page-locked sources
 void launch_layout(FrameDesc *fd, uint8_t *blob, const uint32_t *entry_seg, const uint64_t *seg_off, uint32_t nentry, uint32_t nseg, uint64_t out_base,
                    uint64_t *segdst, uint64_t *ent_off, uint64_t *total, hipStream_t st);
+void launch_frame_pieces(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *states, hipStream_t st);
+struct CrcPatchH { int64_t off; uint32_t crc, mask; };   // = CrcPatch of k_frame.hip
+void launch_crc_patch(const void *patches, uint32_t n, uint8_t *dst, hipStream_t st);
 void launch_frame_verify(const FrameDesc *fd, uint32_t n, const CrcTabs *ct, const uint8_t *buf, uint64_t cap16, const char ty[4], uint32_t *verify, hipStream_t st, uint32_t max_payload);
 void launch_zdec(ZFrame *frames, uint32_t n, const uint8_t *src, uint8_t *dst, uint8_t *lit_scratch, uint32_t dbg, hipStream_t st);
 void launch_zxxh(ZFrame *frames, uint32_t n, const uint8_t *src, const uint8_t *dst, hipStream_t st);
@@ -152,6 +155,7 @@ struct Tuning {
     long sub_ramp_down = 0;          // PNA_SUB_RAMP_DOWN: sub-batches shrink towards the end of the input (measured: no gain)
     long stage_threads = 0;          // PNA_STAGE_THREADS: host threads that stage entries into page-locked memory (0: min(8, cores / 2))
     long extract_win_mib = 1024;     // PNA_EXTRACT_WIN_MIB: archive bytes per window of the extract driver
+    long solid_win_mib = 256;        // PNA_SOLID_WIN_MIB: pna_gpu_create_solid_archive_host takes the serialised inner entries through in windows of this many MiB (page-locked memory: ~4 windows)
     long batch_piece_mib = 256;      // PNA_BATCH_PIECE_MIB: pna_gpu_compress_batch takes a large batch through in pieces of this size (0: one piece)
     long inflate_serial = 0;         // PNA_INFLATE_SERIAL: deflate decoding on the wave-per-stream walk only
     long zdec_serial = 0;            // PNA_ZDEC_SERIAL: zstd decoding with one workgroup per frame only
@@ -353,6 +357,8 @@ inline void plan_call(pna_gpu_ctx *c, const L *src_len, size_t n) {
 
 
 int  ensure_crc(pna_gpu_ctx *c);
+uint32_t crc_gf2_mulmod(uint32_t a, uint32_t b);       // a * b mod P of the CRC-32 (reflected bit order), x^e mod P: what chains the raw registers of a chunk's pieces
+uint32_t crc_gf2_xpow(uint64_t e);
 int  ensure_aes(pna_gpu_ctx *c);
 int  ensure_aes_dec(pna_gpu_ctx *c);
 int  check_cipher(pna_gpu_ctx *c, const pna_gpu_cipher *ci);

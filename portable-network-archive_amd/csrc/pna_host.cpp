@@ -7,7 +7,7 @@ static const TuningName TUNING_NAMES[] = {
     {"lz_split_min", "PNA_LZ_SPLIT_MIN", &Tuning::lz_split_min, 0, 1 << 30}, {"lz_pbuf_fail", "PNA_LZ_PBUF_FAIL", &Tuning::lz_pbuf_fail, 0, 1},
     {"pipeline_chunks", "PNA_PIPELINE_CHUNKS", &Tuning::pipeline_chunks, 1, 8}, {"max_chunk_size", "PNA_MAX_CHUNK_SIZE", &Tuning::max_chunk_size, 0, 0xFFFFFFFFl},
     {"sub_mib", "PNA_SUB_MIB", &Tuning::sub_mib, 16, 16384}, {"stage_threads", "PNA_STAGE_THREADS", &Tuning::stage_threads, 0, 64},
-    {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20},
+    {"extract_win_mib", "PNA_EXTRACT_WIN_MIB", &Tuning::extract_win_mib, 1, 1 << 20}, {"batch_piece_mib", "PNA_BATCH_PIECE_MIB", &Tuning::batch_piece_mib, 0, 1 << 20}, {"solid_win_mib", "PNA_SOLID_WIN_MIB", &Tuning::solid_win_mib, 1, 1 << 16},
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
@@ -171,6 +171,8 @@ extern "C" int pna_gpu_last_timing(const pna_gpu_ctx *c, pna_gpu_timing *out) {
 // ---------------------------------------------------------------------------------------------------------
 // One sub-batch: entries [e0, e1) -> segments -> kernels; output appended at d_dst + out_base.
 // ---- CRC-32 tables of the framing kernel (k_frame.hip explains the algebra)
+uint32_t crc_gf2_mulmod(uint32_t a, uint32_t b);
+uint32_t crc_gf2_xpow(uint64_t e);
 static uint32_t gf2_mulmod(uint32_t a, uint32_t b) {          // a * b mod P, reflected bit order (bit 31 = x^0)
     uint32_t p = 0;
     for (int i = 0; i < 32; i++) { if (a & 0x80000000u) p ^= b; a <<= 1; b = (b & 1) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
@@ -189,6 +191,8 @@ static void build_crc_tabs(CrcTabs &t) {
     for (int j = 0; j < 8; j++) t.sh[j] = gf2_xpow(8ull * 64 << j);
     for (int m = 1; m <= 4; m++) for (uint32_t k = 0; k < 64; k++) t.pw[m - 1][k] = gf2_xpow(8ull * 64 * m * k);
 }
+uint32_t crc_gf2_mulmod(uint32_t a, uint32_t b) { return gf2_mulmod(a, b); }
+uint32_t crc_gf2_xpow(uint64_t e) { return gf2_xpow(e); }
 int ensure_crc(pna_gpu_ctx *c) {
     if (c->crc_ready) return PNA_OK;
     CrcTabs t; build_crc_tabs(t);

@@ -2,14 +2,183 @@
 // forms, solid, multi-context, append, zero-staging host slots) and pna_gpu_compress_batch from host buffers.
 #include "pna_ctx.h"
 #include <memory>
+#include <atomic>
 static void parallel_stage(uint8_t *dst, const void *const *src, const size_t *src_len, const uint64_t *off, size_t e0, size_t e1, unsigned threads);
 
-// The same from host memory: one H2D of the entries, the device path above, one D2H of the archive, handed to the sink in
-// pieces of at most 16 MiB.  (The whole solid stream is in flight at once: a solid entry is one compression unit.)
+// `pna create --solid` from host memory (SolidArchive::add_entry streams the entries into ONE encoder, lib/src/archive/write.rs:575-580).
+// zstd: the serialised inner entries -- FHED | fSIZ | FDAT(data, crc) | FEND per entry, stored -- reach the device in WINDOWS of solid_win_mib MiB of that
+// stream (whole 1 MiB segments: every segment is a frame and an SDAT chunk of its own, so a window is compressed like the whole), through two page-locked
+// slots each way: ~4 windows of page-locked memory whatever the archive's size (round 4: the whole stream was staged, copied and held at once).  The host
+// writes the chunk framing and the entries' bytes where they stand in the stream while the device compresses the window before; the data chunks' CRC-32 are
+// the device's -- the raw CRC register of every piece of a chunk inside the window (k_frame's piece mode), chained by the host with CRC(A || B) =
+// x^(8|B|) CRC(A) + CRC(B) for a chunk that spans windows, written into the window (k_crc_patch) before it is compressed.  An inner entry is cut into
+// FDAT chunks of at most 2^32 - 5 bytes like FlattenWriter's (lib/src/util/io.rs:60-77): any size goes through (the one-shot device path: below 2 GiB).
+// The archive equals pna_gpu_create_solid_archive_device's byte for byte.  deflate (one zlib stream with one Adler-32 over everything) and the
+// single_frame option keep the one-shot form below.
+namespace {
+struct SolidSpan { uint64_t pos, len; uint32_t kind; uint32_t chunk; uint64_t a, b; };     // kind 0: blob[a ..), 1: entry a from byte b on, 2: the CRC of chunk `chunk`
+struct SolidChunk { uint32_t state = 0, crc = 0; uint64_t end = 0; bool started = false, done = false; };   // end: stream position behind the chunk's data
+}
+static int solid_stream_zstd(pna_gpu_ctx *c, int level, size_t n, const char *const *names, const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
+    const int algo = PNA_ALGO_ZSTD;
+    set_call_level(c, algo, level);
+    hipStream_t st = c->stream;
+    // ---- the stream's layout
+    std::vector<uint8_t> blob; std::vector<SolidSpan> spans; std::vector<SolidChunk> chunks;
+    const uint64_t CH = 0xFFFFFFFBull;
+    uint64_t pos = 0;
+    uint8_t fend[12] = {0, 0, 0, 0, 'F', 'E', 'N', 'D', 0, 0, 0, 0};
+    { const uint32_t fc = frame_fend_crc(); fend[8] = (uint8_t)(fc >> 24); fend[9] = (uint8_t)(fc >> 16); fend[10] = (uint8_t)(fc >> 8); fend[11] = (uint8_t)fc; }
+    auto lit = [&](size_t from) { const uint64_t l = blob.size() - from; spans.push_back(SolidSpan{pos, l, 0u, 0u, (uint64_t)from, 0}); pos += l; };
+    for (size_t i = 0; i < n; i++) {
+        const size_t b0 = blob.size();
+        if (src_len[i] == 0) { frame_inner_entry_empty(blob, names[i]); lit(b0); continue; }
+        const uint64_t L = src_len[i];
+        for (uint64_t o = 0; o < L; o += CH) {
+            const uint64_t cl = std::min<uint64_t>(CH, L - o);
+            const size_t b1 = blob.size();
+            if (o == 0) frame_entry_prefix(blob, names[i], PNA_ALGO_STORE, L, (uint32_t)cl);
+            else { const uint8_t h[8] = {(uint8_t)(cl >> 24), (uint8_t)(cl >> 16), (uint8_t)(cl >> 8), (uint8_t)cl, 'F', 'D', 'A', 'T'}; blob.insert(blob.end(), h, h + 8); }
+            lit(b1);
+            const uint32_t ci = (uint32_t)chunks.size();
+            chunks.emplace_back();
+            spans.push_back(SolidSpan{pos, cl, 1u, ci, (uint64_t)i, o}); pos += cl;
+            chunks[ci].end = pos;
+            spans.push_back(SolidSpan{pos, 4, 2u, ci, 0, 0}); pos += 4;
+            if (chunks.size() > 0x7FFFFFF0u) return fail(c, PNA_E_INVAL, "too many data chunks");
+        }
+        const size_t b2 = blob.size();
+        blob.insert(blob.end(), fend, fend + 12); lit(b2);
+    }
+    const uint64_t plain_len = pos;
+    // ---- the fixed chunks around the stream
+    std::vector<uint8_t> head, tail;
+    frame_archive_head(head, 0); frame_solid_head(head, algo);
+    frame_solid_tail(tail); frame_archive_tail(tail);
+    if (sink(user, head.data(), head.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    const uint64_t W = std::max<uint64_t>(1, (uint64_t)c->tun.solid_win_mib) << 20;           // a multiple of SEG_SIZE
+    const uint64_t nwin = (plain_len + W - 1) / W;
+    const uint64_t wcap_in = std::min<uint64_t>(W, plain_len) + 8192;
+    const uint64_t wcap_out = pna_gpu_bound(algo, (size_t)std::min<uint64_t>(W, plain_len)) + (std::min<uint64_t>(W, plain_len) / SEG_SIZE + 2) * 16 + 4096;
+    int rc = ensure_crc(c); if (rc) return rc;
+    if (c->stage_in.ensure(2 * wcap_in + 64) || c->stage_out.ensure(2 * wcap_out + 64) || c->hp_in[0].ensure(wcap_in) || c->hp_in[1].ensure(wcap_in) ||
+        c->hp_out[0].ensure(wcap_out) || c->hp_out[1].ensure(wcap_out)) return fail(c, PNA_E_NOMEM, "staging allocation failed");
+    const CallTotalScope call_total(c, plain_len);                                            // every window picks the block size of the whole stream
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = c->tun.stage_threads > 0 ? (unsigned)c->tun.stage_threads : std::min(8u, std::max(1u, hw / 2));
+    // assemble window k in its page-locked slot: framing bytes, entry bytes, the CRCs that are known; the pieces of data chunks inside it
+    struct Win { std::vector<FrameDesc> pieces; std::vector<uint32_t> piece_chunk; std::vector<uint64_t> piece_len; std::vector<uint32_t> crc_spans; uint64_t w0 = 0, w1 = 0; };
+    size_t cursor = 0;                                                                         // first span that reaches into the window
+    auto assemble = [&](uint64_t k, Win &w) {
+        w.pieces.clear(); w.piece_chunk.clear(); w.piece_len.clear(); w.crc_spans.clear();
+        w.w0 = k * W; w.w1 = std::min(plain_len, w.w0 + W);
+        uint8_t *slot = (uint8_t *)c->hp_in[k & 1].p;
+        struct Job { uint8_t *d; const uint8_t *s; uint64_t l; };
+        std::vector<Job> jobs;
+        while (cursor < spans.size() && spans[cursor].pos + spans[cursor].len <= w.w0) cursor++;
+        for (size_t j = cursor; j < spans.size() && spans[j].pos < w.w1; j++) {
+            const SolidSpan &sp = spans[j];
+            const uint64_t a = std::max(sp.pos, w.w0), b = std::min(sp.pos + sp.len, w.w1);
+            if (a >= b) continue;
+            uint8_t *d = slot + (a - w.w0);
+            if (sp.kind == 0) memcpy(d, blob.data() + sp.a + (a - sp.pos), b - a);
+            else if (sp.kind == 1) {
+                const uint8_t *sbase = (const uint8_t *)src[sp.a] + sp.b + (a - sp.pos);
+                for (uint64_t o = 0; o < b - a; o += (8u << 20)) jobs.push_back(Job{d + o, sbase + o, std::min<uint64_t>(8u << 20, b - a - o)});
+                w.pieces.push_back(FrameDesc{a - w.w0, (uint32_t)(b - a), 0u, 0u, 4u | (a == sp.pos ? 0u : 8u)});
+                w.piece_chunk.push_back(sp.chunk); w.piece_len.push_back(b - a);
+            } else {
+                const SolidChunk &cc = chunks[sp.chunk];
+                if (cc.done) for (uint64_t q = a; q < b; q++) slot[q - w.w0] = (uint8_t)(cc.crc >> (24 - 8 * (q - sp.pos)));
+                else { memset(d, 0, b - a); w.crc_spans.push_back((uint32_t)j); }
+            }
+        }
+        if (w.w1 - w.w0 < wcap_in) memset(slot + (w.w1 - w.w0), 0, std::min<uint64_t>(64, wcap_in - (w.w1 - w.w0)));
+        if (jobs.size() <= 1 || T <= 1) { for (const Job &jb : jobs) memcpy(jb.d, jb.s, jb.l); }
+        else {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < std::min<size_t>(T, jobs.size()); t++)
+                th.emplace_back([&]() { for (size_t q; (q = next.fetch_add(1)) < jobs.size();) memcpy(jobs[q].d, jobs[q].s, jobs[q].l); });
+            for (auto &x : th) x.join();
+        }
+    };
+    Win win[2];
+    if (nwin) assemble(0, win[0]);
+    DevBuf &dp = c->solid_place, &dd = c->solid_desc;                                          // patches, piece descriptors + states
+    for (uint64_t k = 0; k < nwin && rc == PNA_OK; k++) {
+        Win &w = win[k & 1];
+        const uint64_t wl = w.w1 - w.w0;
+        uint8_t *d_in = (uint8_t *)c->stage_in.p + (k & 1) * ((wcap_in + 255) & ~(uint64_t)255);
+        uint8_t *d_out = (uint8_t *)c->stage_out.p + (k & 1) * ((wcap_out + 255) & ~(uint64_t)255);
+        HIPCHK(c, hipMemcpyAsync(d_in, c->hp_in[k & 1].p, wl + std::min<uint64_t>(64, wcap_in - wl), hipMemcpyHostToDevice, st));
+        // the CRC registers of the window's pieces
+        const size_t np = w.pieces.size();
+        std::vector<uint32_t> states(np);
+        if (np) {
+            if (dd.ensure(np * (sizeof(FrameDesc) + 4) + 64)) return fail(c, PNA_E_NOMEM, "solid workspace");
+            uint32_t *d_states = (uint32_t *)((uint8_t *)dd.p + np * sizeof(FrameDesc));
+            HIPCHK(c, hipMemcpyAsync(dd.p, w.pieces.data(), np * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+            launch_frame_pieces((const FrameDesc *)dd.p, (uint32_t)np, (const CrcTabs *)c->crc_tabs.p, d_in, wcap_in & ~(uint64_t)15, "FDAT", d_states, st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(states.data(), d_states, np * 4, hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (size_t q = 0; q < np; q++) {
+            SolidChunk &cc = chunks[w.piece_chunk[q]];
+            cc.state = cc.started ? (crc_gf2_mulmod(crc_gf2_xpow(8 * w.piece_len[q]), cc.state) ^ states[q]) : states[q];
+            cc.started = true;
+            if (w.w0 + w.pieces[q].arc_off + w.piece_len[q] == cc.end) { cc.crc = ~cc.state; cc.done = true; }
+        }
+        std::vector<CrcPatchH> patches;
+        for (uint32_t j : w.crc_spans) {
+            const SolidSpan &sp = spans[j];
+            const SolidChunk &cc = chunks[sp.chunk];
+            if (!cc.done) return fail(c, PNA_E_INVAL, "internal: a chunk's CRC is due before its data is through");
+            uint32_t mask = 0;
+            for (int q = 0; q < 4; q++) if (sp.pos + q >= w.w0 && sp.pos + q < w.w1) mask |= 1u << q;
+            patches.push_back(CrcPatchH{(int64_t)sp.pos - (int64_t)w.w0, cc.crc, mask});
+        }
+        if (!patches.empty()) {
+            if (dp.ensure(patches.size() * sizeof(CrcPatchH) + 64)) return fail(c, PNA_E_NOMEM, "solid workspace");
+            HIPCHK(c, hipMemcpyAsync(dp.p, patches.data(), patches.size() * sizeof(CrcPatchH), hipMemcpyHostToDevice, st));
+            launch_crc_patch(dp.p, (uint32_t)patches.size(), d_in, st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(st));                                               // (`patches` is read by the copy)
+        }
+        // the next window is assembled on a thread of its own while the device compresses this one
+        std::thread next;
+        if (k + 1 < nwin) next = std::thread([&, k]() { assemble(k + 1, win[(k + 1) & 1]); });
+        const uint64_t off0 = 0, len0 = wl; uint64_t offs[2] = {0, 0};
+        FrameJob fj{nullptr, 1, nullptr, nullptr};
+        rc = run_subbatch(c, algo, d_in, &off0, &len0, 0, 1, d_out, wcap_out, 0, offs, st, false, &fj);
+        if (rc == PNA_OK && hipMemcpyAsync(c->hp_out[k & 1].p, d_out, offs[1], hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+        if (rc == PNA_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(c, PNA_E_HIP, "D2H copy failed");
+        if (next.joinable()) next.join();
+        if (rc == PNA_OK && offs[1] && sink(user, c->hp_out[k & 1].p, (size_t)offs[1]) != 0) rc = fail(c, PNA_E_SINK, "sink failed");
+    }
+    if (rc) return rc;
+    if (sink(user, tail.data(), tail.size()) != 0) return fail(c, PNA_E_SINK, "sink failed");
+    return PNA_OK;
+}
+
+// Page-locked staging memory the context holds right now (the slots of the host pipelines; plan blobs and tables excluded): what tests/ pin the
+// bounded-memory claims with.  Not a product path.
+extern "C" uint64_t pna_gpu_debug_pinned_bytes(pna_gpu_ctx *c) {
+    if (!c) return 0;
+    uint64_t t = 0;
+    for (auto &b : c->hp_in) t += b.cap;
+    for (auto &b : c->hp_out) t += b.cap;
+    return t;
+}
+
+// deflate / single_frame: one H2D of the entries, the device path, one D2H of the archive, handed to the sink in pieces of at most 16 MiB (the whole
+// stream is in flight at once: a zlib stream is one compression unit with one Adler-32)
 extern "C" int pna_gpu_create_solid_archive_host(pna_gpu_ctx *c, int algo, int level, size_t n, const char *const *names,
                                                  const void *const *src, const size_t *src_len, pna_sink_fn sink, void *user) {
     if (!c || !sink || (n && (!names || !src || !src_len))) return fail(c, PNA_E_INVAL, "null argument");
     HIPCHK(c, hipSetDevice(c->device));
+    if (algo == PNA_ALGO_ZSTD && n && !c->tun.single_frame && c->tun.solid_win_mib > 0) return solid_stream_zstd(c, level, n, names, src, src_len, sink, user);
     std::vector<uint64_t> off(n + 1), len(n);
     uint64_t pos = 0;
     for (size_t i = 0; i < n; i++) { off[i] = pos; len[i] = src_len[i]; pos = (pos + src_len[i] + 15) & ~(uint64_t)15; }

@@ -87,6 +87,27 @@ def test_solid_8gib_archive_round_trips(big_ctx, pna, pf, codec):
         assert dec(arc[off:off + ln].tobytes(), b - a) == inner_slice(a, b), k
         assert codec.zstd_decompress(arc[off:off + ln].tobytes(), b - a) == inner_slice(a, b), k
 
+    # ---- the same archive from PAGEABLE host memory, streamed through windows (pna_gpu_create_solid_archive_host: SolidArchive::add_entry streams its entries,
+    # lib/src/archive/write.rs:575-580): byte for byte the one assembled in HBM in one piece, with at most 1.5 GiB of page-locked memory for the 8 GiB
+    pos = [0]
+    same = [True]
+
+    def _sink(_u, buf, k):
+        piece = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_ubyte)), shape=(k,))
+        same[0] = same[0] and pos[0] + k <= len(arc) and bool(np.array_equal(piece, arc[pos[0]:pos[0] + k]))
+        pos[0] += k
+        return 0
+    scb = pna.SINK_FN(_sink)
+    base = host_src.ctypes.data
+    a_names = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+    a_src = (ctypes.c_void_p * n)(*[base + i * L for i in range(n)])
+    a_len = (ctypes.c_size_t * n)(*[L] * n)
+    gpu_ctx._check(gpu_ctx._L.pna_gpu_create_solid_archive_host(gpu_ctx._h, pna.ALGO_ZSTD, pna.LEVEL_DEFAULT, n, a_names, a_src, a_len, scb, None))
+    assert same[0] and pos[0] == len(arc)
+    gpu_ctx._L.pna_gpu_debug_pinned_bytes.restype = ctypes.c_uint64
+    gpu_ctx._L.pna_gpu_debug_pinned_bytes.argtypes = [ctypes.c_void_p]
+    assert gpu_ctx._L.pna_gpu_debug_pinned_bytes(gpu_ctx._h) <= (3 << 29), gpu_ctx._L.pna_gpu_debug_pinned_bytes(gpu_ctx._h)
+
     # ---- the whole archive through the extract driver (device CRCs, open-size decode, inner FDAT CRCs): every entry == its source
     seen = []
 

@@ -797,6 +797,48 @@ def test_solid_archive_assembled_in_hbm(gpu_ctx, pna, pf, codec, algo_name):
     assert pna.create_archive(gpu_ctx, names, ents, algo=algo, solid=True) == arc
 
 
+def test_solid_archive_streams_through_windows(gpu_ctx, pna, pf, codec):
+    """pna_gpu_create_solid_archive_host (zstd): the serialised inner entries go to the device in windows (option solid_win_mib; two page-locked slots each way
+    whatever the archive's size) -- SolidArchive::add_entry streams entries into one encoder (lib/src/archive/write.rs:575-580).  With windows of 1 MiB an
+    entry spans several, chunk headers, FEND and the 4 CRC bytes of a data chunk fall on a window's edge in every way (the sweep moves the edge through them);
+    every archive == the one assembled in HBM in one piece, and reads back."""
+    import torch
+    def device_one_shot(names, ents):
+        offs, pos = [], 0
+        for e in ents:
+            offs.append(pos); pos = (pos + len(e) + 15) & ~15
+        src = torch.zeros(pos + 8192, dtype=torch.uint8, device="cuda")
+        for o, e in zip(offs, ents):
+            if e:
+                src[o:o + len(e)] = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+        lens = [len(e) for e in ents]
+        cap = pna.solid_archive_bound(pna.ALGO_ZSTD, names, lens)
+        dst = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+        total = gpu_ctx.create_solid_archive_device(names, src.data_ptr(), offs, lens, dst.data_ptr(), cap, algo=pna.ALGO_ZSTD)
+        return dst[:total].cpu().numpy().tobytes()
+    big = codec.corpus_file(0, 7001, 2600000)
+    try:
+        for win in (1, 2):
+            gpu_ctx.set_option("solid_win_mib", win)
+            for delta in range(0, 24):
+                # the first entry's record ends `delta` bytes around the 1 MiB edge: its CRC field, FEND and the next entry's FHED straddle the edge in turn
+                first = codec.corpus_file(1, 7100 + delta, (1 << 20) - 70 - delta)
+                ents = [first, b"", big, b"", codec.corpus_file(0, 7002, 4096), codec.corpus_file(1, 7003, (1 << 20) + 5)] + ([] if delta % 3 else [b""])
+                names = [f"s/{i}.bin" for i in range(len(ents))]
+                got = pna.create_archive(gpu_ctx, names, ents, solid=True)
+                if delta % 6 == 0 or win == 1:
+                    assert got == device_one_shot(names, ents), (win, delta)
+                if delta == 5:
+                    assert [(n, d) for n, _, d in pna.extract_archive(gpu_ctx, got)] == list(zip(names, ents))
+        gpu_ctx.set_option("solid_win_mib", 1)
+        many = [codec.corpus_file(1, 7200 + i, 3000 + 37 * (i % 50)) for i in range(900)]              # many small inner entries: hundreds of chunks per window
+        nm = [f"m/{i}" for i in range(len(many))]
+        assert pna.create_archive(gpu_ctx, nm, many, solid=True) == device_one_shot(nm, many)
+        assert pna.create_archive(gpu_ctx, [], [], solid=True) == device_one_shot([], [])
+    finally:
+        gpu_ctx.set_option("solid_win_mib", 256)
+
+
 def test_archive_shards_concatenate(gpu_ctx, pna, pf, codec):
     """Two producers (ranks) each assemble their contiguous range of entries; head only on the first, AEND only on the last:
     the concatenation in rank order must be byte-identical to the archive one producer makes of all entries."""
