@@ -900,46 +900,60 @@ void k_seq(const SegDesc *__restrict__ segs, uint32_t nseg, const uint64_t *__re
     };
     // Sequences are consumed last-to-first in 32-byte chunks (4 sequences, two 16-byte loads per lane); the next
     // chunk is requested before the current one is encoded so the HBM/L2 latency overlaps the serial tANS chain.
+    // Round 5: what a sequence needs BESIDES the states -- its codes, extra bits, the three symbols' table entries (two dependent LDS round trips) -- is
+    // prepared for the four sequences of a chunk at once, ahead of the chain; on the chain itself a step is the three state look-ups (one round trip) and the
+    // puts.  (Until then every sequence walked LUT -> symbol entry -> state one after the other: ~1 400 cycles per sequence at one wave per SIMD, three
+    // quarters of them LDS latency.)  The block's last chunk (partial; its last sequence only sets the states) is peeled off the loop.
     uint32_t st_ml = 0, st_of = 0, st_ll = 0;
     const uint32_t top = nseq - 1;
     uint32_t k = top >> 2;
     const uint4 *bs4 = (const uint4 *)bs;
+    struct Prep { uint32_t x_lm, n_lm, x_of, n_of; SeqSym yo, ym, yl; };
+    auto prep = [&](uint64_t sq, Prep &P) {
+        uint32_t llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc;
+        codes(sq, llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc);
+        P.yo = tof->sym[oc]; P.ym = tml->sym[mc]; P.yl = tll->sym[lc];
+        P.x_lm = (llv - lbase) | ((mlv - mbase) << lbits); P.n_lm = lbits + mbits;     // literal-length and match-length extra bits (<= 16 + 16) as one field
+        P.x_of = ofb - (1u << oc); P.n_of = oc;                                        // then the offset's
+    };
+    auto step = [&](const Prep &P) {
+        // the three state flushes (<= 9 bits each) go out as one field
+        const uint32_t no = (st_of + P.yo.delta_nb) >> 16, nm = (st_ml + P.ym.delta_nb) >> 16, nl = (st_ll + P.yl.delta_nb) >> 16;
+        const uint32_t fv = (st_of & ((1u << no) - 1)) | ((st_ml & ((1u << nm) - 1)) << no) | ((st_ll & ((1u << nl) - 1)) << (no + nm));
+        st_of = tof->state[(int)(st_of >> no) + P.yo.delta_find];
+        st_ml = tml->state[(int)(st_ml >> nm) + P.ym.delta_find];
+        st_ll = tll->state[(int)(st_ll >> nl) + P.yl.delta_find];
+        put(fv, no + nm + nl);
+        put(P.x_lm, P.n_lm);
+        put(P.x_of, P.n_of);
+        flush();
+    };
     // (two chunks ahead: a chunk's four sequences are ~800 instructions = 1.6 us of one wave, about what a load takes under the stage's traffic -- with one
     // chunk in flight a third of the kernel's cycles were waits for it)
     uint4 a0 = bs4[2 * k], a1 = bs4[2 * k + 1];
-    uint4 n0 = a0, n1 = a1;
+    uint4 n0 = a0, n1 = a1, m0 = a0, m1 = a1;
     if (k > 0) { n0 = bs4[2 * (k - 1)]; n1 = bs4[2 * (k - 1) + 1]; }
-    bool first = true;
-    for (;;) {
-        uint4 m0 = n0, m1 = n1;
+    if (k > 1) { m0 = bs4[2 * (k - 2)]; m1 = bs4[2 * (k - 2) + 1]; }
+    {   // the last chunk: sequences top & 3 .. 0 of it; the block's last sequence only sets the initial states
+        const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
+                                (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
+        const uint32_t jt = top & 3u;
+        Prep P;
+        prep(jt == 3 ? sq[3] : (jt == 2 ? sq[2] : (jt == 1 ? sq[1] : sq[0])), P);
+        st_ml = P.ym.first_state; st_of = P.yo.first_state; st_ll = P.yl.first_state;
+        put(P.x_lm, P.n_lm); put(P.x_of, P.n_of); flush();
+        for (uint32_t j = jt; j-- > 0;) { prep(j == 2 ? sq[2] : (j == 1 ? sq[1] : sq[0]), P); step(P); }
+    }
+    while (k > 0) {
+        k--; a0 = n0; a1 = n1; n0 = m0; n1 = m1;
         if (k > 1) { m0 = bs4[2 * (k - 2)]; m1 = bs4[2 * (k - 2) + 1]; }
         const uint64_t sq[4] = {(uint64_t)a0.x | ((uint64_t)a0.y << 32), (uint64_t)a0.z | ((uint64_t)a0.w << 32),
                                 (uint64_t)a1.x | ((uint64_t)a1.y << 32), (uint64_t)a1.z | ((uint64_t)a1.w << 32)};
+        Prep P[4];
 #pragma unroll
-        for (int j = 3; j >= 0; j--) {
-            if (4 * k + (uint32_t)j > top) continue;
-            uint32_t llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc;
-            codes(sq[j], llv, mlv, ofb, lc, lbits, lbase, mc, mbits, mbase, oc);
-            const SeqSym yo = tof->sym[oc], ym = tml->sym[mc], yl = tll->sym[lc];
-            if (first) {                                       // the last sequence of the block only sets the initial states
-                st_ml = ym.first_state; st_of = yo.first_state; st_ll = yl.first_state;
-                first = false;
-            } else {
-                // the three state flushes (<= 9 bits each) go out as one field
-                const uint32_t no = (st_of + yo.delta_nb) >> 16, nm = (st_ml + ym.delta_nb) >> 16, nl = (st_ll + yl.delta_nb) >> 16;
-                const uint32_t fv = (st_of & ((1u << no) - 1)) | ((st_ml & ((1u << nm) - 1)) << no) | ((st_ll & ((1u << nl) - 1)) << (no + nm));
-                st_of = tof->state[(int)(st_of >> no) + yo.delta_find];
-                st_ml = tml->state[(int)(st_ml >> nm) + ym.delta_find];
-                st_ll = tll->state[(int)(st_ll >> nl) + yl.delta_find];
-                put(fv, no + nm + nl);
-            }
-            // literal-length and match-length extra bits (<= 16 + 16) as one field, then the offset's
-            put((llv - lbase) | ((mlv - mbase) << lbits), lbits + mbits);
-            put(ofb - (1u << oc), oc);
-            flush();
-        }
-        if (k == 0) break;
-        k--; a0 = n0; a1 = n1; n0 = m0; n1 = m1;
+        for (int j = 0; j < 4; j++) prep(sq[j], P[j]);
+#pragma unroll
+        for (int j = 3; j >= 0; j--) step(P[j]);
     }
     if (mml != 1) put(st_ml & ((1u << tl_ml) - 1), tl_ml);
     if (mof != 1) put(st_of & ((1u << tl_of) - 1), tl_of);

@@ -23,5 +23,7 @@ for k in default:10k_x_1mib deflate_4k_1m:deflate_1000000_x_4kib zstd_4k:zstd_26
 done
 for t in stream_rate batch_rate batch_sizes batch_latency host_rate zdec_one_frame decode_foreign_frames inflate_one_entry inflate_foreign_stream zdec_huge_frame inflate_huge_stream sq_counters; do [ -s "$S/$t.txt" ] && cp "$S/$t.txt" "$D/${TAG}_$t.txt"; done
 [ -s "$S/host_rate_trace.txt" ] && cp "$S/host_rate_trace.txt" "$D/${TAG}_create_pipeline_trace.txt"
+[ -s gpurun_out/pmc_sq/issue.json ] && cp gpurun_out/pmc_sq/issue.json "$D/${TAG}_sq_issue.json"
+[ -s gpurun_out/pmc_tcc/summary.txt ] && cp gpurun_out/pmc_tcc/summary.txt "$D/${TAG}_lzp_tcc.txt"
 [ -s "$S/pmc_summary_raw.json" ] && cp "$S/pmc_summary_raw.json" "$D/${TAG}_pmc_summary_raw.json"
 ls "$D" | grep "^${TAG}_" | wc -l

@@ -16,9 +16,14 @@ for p in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
     for row in csv.DictReader(open(p)):
         k = row["Kernel_Name"].split("(")[0]
         res[k][row["Counter_Name"]] = res[k].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+import json
+out = {}
 for k, v in res.items():
     if "k_lz" not in k: continue
     w = v.get("SQ_WAVES", 1) or 1
     tiles = 32 if "k_lzp" in k else 256
+    for short in ("k_lzm", "k_lzp"):
+        if short in k: out[short] = {n: round(x / w / tiles, 1) for n, x in v.items() if n != "SQ_WAVES"}
+    json.dump(out, open(os.path.join(sys.argv[1], "insts.json"), "w"))
     print(k[:48], {n: round(x / w / tiles, 1) for n, x in v.items() if n != "SQ_WAVES"}, f"(per wave and 4096-position tile; {tiles} tiles per wave)", "waves", w)
 PY
