@@ -1266,6 +1266,8 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (algo != PNA_ALGO_ZSTD && algo != PNA_ALGO_DEFLATE) return fail(c, PNA_E_UNSUPPORTED, "algorithm not implemented on the device path");
     if ((uintptr_t)d_dst & 15) return fail(c, PNA_E_INVAL, "archive buffer must be 16-byte aligned");
     if (cipher && cipher->encryption == PNA_ENC_NONE) cipher = nullptr;
+    const auto t_call0 = std::chrono::steady_clock::now();
+    auto call_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count(); };
     std::vector<uint8_t> own_ivs;
     const uint8_t *ivs = nullptr;
     if (cipher) { int rc = resolve_ivs(c, cipher, n, own_ivs, &ivs); if (rc) return rc; }
@@ -1291,8 +1293,10 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
             if (e1 > e && blocks + nb > c->max_blocks) break;
             blocks += nb; in_total += src_len[e1]; e1++;
         }
+        if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] sub-batch of %zu entries starts at %.2f ms of the call\n", e1 - e, call_ms());
         int rc = run_subbatch(c, algo, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap - tail.size(), pos, offs.data(), st, true, &fj);
         if (rc) return rc;
+        if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] sub-batch back at %.2f ms\n", call_ms());
         pos = offs[e1];
         e = e1;
     }
@@ -1303,6 +1307,7 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
     *archive_len = pos;
     c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
+    if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] call ends at %.2f ms\n", call_ms());
     return PNA_OK;
 }
 
