@@ -334,12 +334,51 @@ inline unsigned host_loop_threads(size_t n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     return (unsigned)std::min<size_t>(std::min<unsigned>(16u, hw), std::max<size_t>(1, n / 16384));
 }
+// The helper threads are a process-wide POOL (round 5): a sub-batch of 10^6 entries runs half a dozen of these loops, and starting + joining fifteen threads for each
+// was ~0.5 ms a time -- more than the loops themselves.  One job at a time (a second caller -- another context's thread -- starts threads of its own, as before).
+struct HostPool {
+    std::mutex mu, busy; std::condition_variable cv, done_cv;
+    std::vector<std::thread> th;
+    std::function<void(unsigned)> job; unsigned want = 0, gen = 0, left = 0; bool stop = false;
+    void worker(unsigned t) {
+        unsigned seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (gen != seen && t < want); });
+                if (stop) return;
+                seen = gen; j = job;
+            }
+            j(t);
+            { std::lock_guard<std::mutex> lk(mu); if (--left == 0) done_cv.notify_all(); }
+        }
+    }
+    // runs fn(1 .. nt - 1) on the pool's threads and fn(0) on the caller's; false: the pool is taken (the caller falls back)
+    bool run(unsigned nt, const std::function<void(unsigned)> &fn) {
+        if (!busy.try_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (th.size() + 1 < nt) { const unsigned t = (unsigned)th.size() + 1; th.emplace_back([this, t]() { worker(t); }); }
+            job = fn; want = nt; left = nt - 1; gen++;
+        }
+        cv.notify_all();
+        fn(0);
+        { std::unique_lock<std::mutex> lk(mu); done_cv.wait(lk, [&] { return left == 0; }); want = 0; }
+        busy.unlock();
+        return true;
+    }
+    ~HostPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto &x : th) x.join(); }
+};
+inline HostPool &host_pool() { static HostPool p; return p; }
 template <class F>
 inline void par_ranges(size_t n, unsigned nt, F &&fn) {
     if (nt <= 1) { fn(0u, (size_t)0, n); return; }
+    auto part = [&fn, n, nt](unsigned t) { if (t == 0) fn(0u, (size_t)0, n / nt); else fn(t, n * t / nt, n * (t + 1) / nt); };
+    if (host_pool().run(nt, part)) return;
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back([&fn, n, nt, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
-    fn(0u, (size_t)0, n / nt);
+    for (unsigned t = 1; t < nt; t++) th.emplace_back([&part, t]() { part(t); });
+    part(0);
     for (auto &x : th) x.join();
 }
 // per call: the block size the sub-batches are cut with and how many blocks fit the workspace budget

@@ -1280,21 +1280,32 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (part_flags & PNA_PART_TAIL) frame_archive_tail(tail);
     if (head.size() + tail.size() + 16 > dst_cap) return fail(c, PNA_E_DSTSIZE, "device destination too small");
     if (!head.empty()) HIPCHK(c, hipMemcpyAsync(d_dst, head.data(), head.size(), hipMemcpyHostToDevice, st));
-    std::vector<uint64_t> offs(n + 1);
-    uint64_t pos = head.size(), in_total = 0;
-    const CallTotalScope call_total(c, src_len, n);                                              // (the block size follows the call, not its sub-batches)
+    // (10^6 entries: the call's own loops over them -- the total, the longest, the sub-batch cut -- ran one after the other on one thread, ~2 ms in front of the first
+    // kernel and a zero-filled vector of offsets behind it; round 5: one pass on several threads, the cut by arithmetic where every entry is one block)
+    std::unique_ptr<uint64_t[]> offs_mem(new uint64_t[n + 1]);
+    uint64_t *offs = offs_mem.get();
+    uint64_t pos = head.size(), in_total = 0, longest = 0;
+    {
+        const unsigned nt = host_loop_threads(n);
+        std::vector<uint64_t> part_sum(nt, 0), part_max(nt, 0);
+        par_ranges(n, nt, [&](unsigned t, size_t a, size_t b) { uint64_t sm = 0, mx = 0; for (size_t i = a; i < b; i++) { sm += src_len[i]; mx = std::max<uint64_t>(mx, src_len[i]); } part_sum[t] = sm; part_max[t] = mx; });
+        for (unsigned t = 0; t < nt; t++) { in_total += part_sum[t]; longest = std::max(longest, part_max[t]); }
+    }
+    const CallTotalScope call_total(c, in_total);                                                // (the block size follows the call, not its sub-batches)
     FrameJob fj{names, 0, cipher, ivs, meta, max_chunk, entry_off != nullptr};
     size_t e = 0;
-    plan_call(c, src_len, n);
+    plan_call_longest(c, longest);
+    const bool one_block_each = longest <= ((uint64_t)1 << c->plan_log);
     while (e < n) {
         size_t e1 = e, blocks = 0;
-        while (e1 < n) {
+        if (one_block_each) e1 = std::min(n, e + std::max<size_t>(1, c->max_blocks));           // (an empty entry counts as a block of its own here: the cut only has to respect the budget)
+        else while (e1 < n) {
             size_t nb = plan_blocks(c, src_len[e1]);
             if (e1 > e && blocks + nb > c->max_blocks) break;
-            blocks += nb; in_total += src_len[e1]; e1++;
+            blocks += nb; e1++;
         }
         if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] sub-batch of %zu entries starts at %.2f ms of the call\n", e1 - e, call_ms());
-        int rc = run_subbatch(c, algo, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap - tail.size(), pos, offs.data(), st, true, &fj);
+        int rc = run_subbatch(c, algo, (const uint8_t *)d_src, src_off, src_len, e, e1, (uint8_t *)d_dst, dst_cap - tail.size(), pos, offs, st, true, &fj);
         if (rc) return rc;
         if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] sub-batch back at %.2f ms\n", call_ms());
         pos = offs[e1];
@@ -1304,7 +1315,7 @@ int create_archive_device_impl(pna_gpu_ctx *c, int algo, int level, size_t n, co
     if (!tail.empty()) HIPCHK(c, hipMemcpyAsync((uint8_t *)d_dst + pos, tail.data(), tail.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));
     pos += tail.size();
-    if (entry_off) memcpy(entry_off, offs.data(), (n + 1) * 8);
+    if (entry_off) memcpy(entry_off, offs, (n + 1) * 8);
     *archive_len = pos;
     c->timing.in_bytes = in_total; c->timing.out_bytes = pos;
     if (c->tun.trace) fprintf(stderr, "[pna create_archive_device] call ends at %.2f ms\n", call_ms());

@@ -98,6 +98,9 @@ int launch_zexec_par(ZxFrame *, const ZxFrame &, const ZBlock *, const uint8_t *
 void launch_zxxh(ZFrame *, uint32_t, const uint8_t *, const uint8_t *, hipStream_t) { nostub("zxxh"); }
 void launch_zscan(const ZEntry *, uint32_t, const uint8_t *, ZFrame *, ZFrameX *, hipStream_t) { nostub("zscan"); }
 void launch_zcount(const ZEntry *, uint32_t, const uint8_t *, uint32_t *, hipStream_t) { nostub("zcount"); }
+void launch_zlist(const uint8_t *, uint64_t, uint64_t, uint64_t, void *, uint32_t, uint64_t *, hipStream_t) { nostub("zlist"); }
+void launch_frame_pieces(const FrameDesc *, uint32_t, const CrcTabs *, const uint8_t *, uint64_t, const char[4], uint32_t *, hipStream_t) { nostub("frame_pieces"); }
+void launch_crc_patch(const void *, uint32_t, uint8_t *, hipStream_t) { nostub("crc_patch"); }
 void launch_zparse(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, ZTables *, uint32_t *, uint32_t *, void *, hipStream_t) { nostub("zparse"); }
 void launch_zstreams(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const void *, ZBlock *, const ZFrame *, const ZTables *, const uint8_t *, uint8_t *, uint64_t *, hipStream_t) { nostub("zstreams"); }
 void launch_inflate(ZFrame *, ZFrameX *, uint32_t, const uint8_t *, ZBlock *, uint8_t *, uint64_t *, const uint32_t *, hipStream_t) { nostub("inflate"); }
