@@ -543,7 +543,7 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
 // Same results as k_lz<MODE = 2> (and so as the fused kernel): tests/test_gpu_parity.py runs all three.
 constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, int LZD, bool W3>   // W3: the words take three bytes (k_lzm); LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
-__global__ __launch_bounds__(LZP_THREADS)   // (88 registers: 5 waves per SIMD; asked for 6 / 7 the allocator spills 4 / 9 registers and the kernel is no faster / 2 % slower)
+__global__ __launch_bounds__(LZP_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))   // (88 registers: 5 waves per SIMD; asked for 6 / 7 the allocator spills 4 / 9 registers and the kernel is no faster / 2 % slower)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
            BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
     constexpr uint32_t RW = 256, TG = 4096;
@@ -557,6 +557,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     // not LDS, bound the waves per CU (the kernel hides its memory latency by occupancy: 13 instead of 19 waves per CU cost it 12 %, 9 waves 36 %; above 20 nothing more is gained).
     uint4 (*rec)[TG / 64] = (uint4 (*)[TG / 64])l32;
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
+    __shared__ uint32_t lstage[264];                        // step 4: the literals of four regions (<= 1 024 bytes behind <= 3 carried ones), stored from here as dwords
     const uint32_t lane = threadIdx.x, w = lane & 15;
     const uint8_t *len8 = (const uint8_t *)l32;
     // one wave per block: block blk0 + blockIdx.x of the sub-batch, its segment from the block -> segment map (segs: all segments of the sub-batch)
@@ -587,6 +588,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     // literals: bits of the group's literal mask below this lane's four positions (lane i of a region: group i / 16, bits 4 (i % 16) ..)
     const uint64_t lit_below = ((uint64_t)1 << (4 * (lane & 15))) - 1;
     uint32_t next_free = 0, seq_run = 0, lit_run = 0, g_last1 = 1;     // block-level parse state (uniform)
+    uint32_t lcarry = 0;                                    // the < 4 literal bytes behind the block's last complete dword of literals (step 4)
 
     for (uint32_t T = tile0; T < ntile; T++) {
         const uint32_t t0 = T * TG, blk_start = t0 & ~(bsz - 1);
@@ -646,7 +648,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             lmask[lane] = make_uint4(em2[0], em2[1], cm2[0], cm2[1]);
         }
         __builtin_amdgcn_wave_barrier();
-        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; }
+        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; lcarry = 0; }
         // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it; half-groups of 32 positions: one-register masks
         const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
         uint64_t sel[4], cov[4], cm[4];
@@ -873,23 +875,45 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                 }
             }
         }
-        // ---- 4. literals, region by region, 4 consecutive positions per lane
+        // ---- 4. literals, region by region, 4 consecutive positions per lane.  Round 5: the lanes' one to four bytes go to an LDS stage (byte writes) and leave
+        // four regions at a time as aligned DWORDS, the < 4 bytes behind the last complete dword carried to the next chunk / tile (until then: four predicated byte
+        // stores per region to memory, 64 store instructions per tile -- a fifth of the kernel's time)
         {
             uint8_t *blit = lits + ((size_t)gblk << blk_log);
             const uint32_t sh = 4 * (lane & 15);
+            uint8_t *stage8 = (uint8_t *)lstage;
 #pragma unroll
-            for (uint32_t wr = 0; wr < 16; wr++) {
-                if (wr * RW >= npos) continue;                                      // (uniform)
-                const uint4 m = rec[0][wr * 4 + (lane >> 4)];
-                const uint32_t wd = lw[wr];
-                const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
-                const uint32_t nib = (uint32_t)(lm >> sh) & 15u;
-                const uint32_t pk = __builtin_amdgcn_perm(wd, wd, plut[nib]), cnt = (uint32_t)__popc(nib);
-                uint8_t *o = blit + m.z + (uint32_t)__popcll(lm & lit_below);
-                if (cnt > 0) o[0] = (uint8_t)pk;
-                if (cnt > 1) o[1] = (uint8_t)(pk >> 8);
-                if (cnt > 2) o[2] = (uint8_t)(pk >> 16);
-                if (cnt > 3) o[3] = (uint8_t)(pk >> 24);
+            for (uint32_t wq = 0; wq < 4; wq++) {
+                if (wq * 1024 >= npos) continue;                                    // (uniform)
+                const uint32_t L0 = rec[0][wq * 16].z, L1 = wq < 3 ? rec[0][wq * 16 + 16].z : lit_run;   // literal indices (block-relative) the chunk's regions cover
+                const uint32_t A0 = L0 & ~3u;
+                if (lane == 0) lstage[0] = lcarry;                                  // the bytes [A0, L0)
+                __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    const uint32_t wr = wq * 4 + i;
+                    if (wr * RW >= npos) continue;                                  // (uniform)
+                    const uint4 m = rec[0][wr * 4 + (lane >> 4)];
+                    const uint32_t wd = lw[wr];
+                    const uint64_t lm = (uint64_t)m.x | ((uint64_t)m.y << 32);
+                    const uint32_t nib = (uint32_t)(lm >> sh) & 15u;
+                    const uint32_t pk = __builtin_amdgcn_perm(wd, wd, plut[nib]), cnt = (uint32_t)__popc(nib);
+                    uint8_t *o = stage8 + (m.z + (uint32_t)__popcll(lm & lit_below) - A0);
+                    if (cnt > 0) o[0] = (uint8_t)pk;
+                    if (cnt > 1) o[1] = (uint8_t)(pk >> 8);
+                    if (cnt > 2) o[2] = (uint8_t)(pk >> 16);
+                    if (cnt > 3) o[3] = (uint8_t)(pk >> 24);
+                }
+                __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+                const uint32_t nfull = (L1 - A0) >> 2;                              // <= 256
+                uint32_t *g32 = (uint32_t *)(blit + A0);
+                for (uint32_t j = lane; j < nfull; j += 64) g32[j] = lstage[j];
+                lcarry = uni(lstage[nfull]);
+                __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+            }
+            if (t1 == blk_end) {                                                    // the block's last tile: the bytes behind its last complete dword
+                const uint32_t rem = lit_run & 3u;
+                if (lane < rem) blit[(lit_run & ~3u) + lane] = (uint8_t)(lcarry >> (8 * lane));
             }
         }
         __builtin_amdgcn_wave_barrier();
