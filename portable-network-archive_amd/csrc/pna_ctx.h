@@ -146,7 +146,8 @@ struct PinBuf {                                  // page-locked host staging: as
 // purpose, read ONCE in pna_gpu_init -- no entry point consults the environment afterwards.
 struct Tuning {
     long lz_split = 1;               // PNA_LZ_SPLIT: 0 one-kernel LZ stage, 1 split form for long runs (default), 2 split form with the wave-per-region parse kernel
-    long lz_split_blocks = 32768;    // PNA_LZ_SPLIT_BLOCKS: blocks per run of the split form (the words workspace holds one run)
+    long lz_split_blocks = 131072;   // PNA_LZ_SPLIT_BLOCKS: blocks per run of the split form (the words workspace holds one run: 3 bytes per input byte -- 16 GiB of input, 48 GiB of words at most; round 5:
+                                     // until then 32 768 = 4 GiB per run, and the 10 GiB headline paid three kernel tails per stage -- one run: 74.7 -> 73.5 ms; a workspace that cannot be had is halved, as before)
     long lz_split_min = 0;           // PNA_LZ_SPLIT_MIN: shortest run (segments) that takes the split form (0: every run; shorter ones take the one-kernel form)
     long lz_pbuf_fail = 0;           // PNA_LZ_PBUF_FAIL: testing -- behave as if the words workspace could not be allocated
     long pipeline_chunks = 1;        // PNA_PIPELINE_CHUNKS: zstd entropy stage of chunk k next to the LZ stage of chunk k + 1 (measured: slower)
