@@ -262,17 +262,17 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 uint32_t K = (l << 6) | (bk << 3);
                 if (STRONG && !l) K = 0;                                            // (three rounds could lift a stray back count to a "length" of 7 >= MIN_MATCH; with two it stays below)
                 if (adopt) {
-                {   // round 1: the right neighbour's match, one byte longer (lane 63 sees 0)
+                if (strong) {   // (uniform) the strong sets' round comes first (rounds 4, 1, 2): four lanes to the right, four bytes longer
+                    const uint32_t K4 = dpp_next_lane(dpp_next_lane(dpp_next_lane(dpp_next_lane(K)))), T = K4 + 228u;
+                    K = ((K4 & 0x20u) != 0 && T > (K | 63u)) ? T : K;
+                }
+                {   // the right neighbour's match, one byte longer (lane 63 sees 0)
                     const uint32_t K1 = dpp_next_lane(K), T = K1 + 57u;
                     K = ((K1 & 0x38u) != 0 && T > (K | 63u)) ? T : K;
                 }
-                {   // round 2: the match two lanes to the right (after round 1), two bytes longer
+                {   // the match two lanes to the right (after the round before), two bytes longer
                     const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 114u;
                     K = ((K2 & 0x30u) != 0 && T > (K | 63u)) ? T : K;
-                }
-                if (strong) {   // (uniform) round 3: four lanes to the right, four bytes longer
-                    const uint32_t K4 = dpp_next_lane(dpp_next_lane(dpp_next_lane(dpp_next_lane(K)))), T = K4 + 228u;
-                    K = ((K4 & 0x20u) != 0 && T > (K | 63u)) ? T : K;
                 }
                 l = K >> 6;
                 if (flags & FLAG_LEN36) l = l < 36u ? l : 36u;                      // (uniform) what the split form's 3-byte words keep

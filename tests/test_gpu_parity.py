@@ -276,7 +276,7 @@ def test_feature_subsets_bit_exact(pna, codec, flags):
     # level 2 (the light set) keeps the context's bits as they are; the default level adds the third adoption round (F_STRONG) where the bits allow it
     p = codec.params_for_level(3, ctx_flags=flags)
     p2 = codec.params_for_level(2, ctx_flags=flags)
-    assert (p.rounds == 0x421) == bool(flags & 0x20 and flags & 4) and p2.rounds == (0x421 if flags & 0x80 and flags & 0x20 else 0x21 if flags & 0x20 else 0)
+    assert (p.rounds == 0x214) == bool(flags & 0x20 and flags & 4) and p2.rounds == (0x214 if flags & 0x80 and flags & 0x20 else 0x21 if flags & 0x20 else 0)
     for e, o, o2 in zip(ents, outs, outs2):
         assert o == codec.model_compress(e, p)
         assert o2 == codec.model_compress(e, p2)
@@ -1324,7 +1324,7 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         assert codec.product_level_flags(level) == (fl, bool(gtab)), level
         pz = codec.params_for_level(level)
-        assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else 0x421 if fl == strong else 0x21), level
+        assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else 0x214 if fl == strong else 0x21), level
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
     assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1] and sizes[0] == sizes[3] == sizes[pna.LEVEL_DEFAULT]
