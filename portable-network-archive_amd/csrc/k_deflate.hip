@@ -455,11 +455,13 @@ __global__ __launch_bounds__(DB_THREADS)
 void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ seqs,
               const uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, const uint4 *__restrict__ ctab,
               const DeflTables *__restrict__ tabs, uint8_t *__restrict__ outc, uint32_t dbg) {
+    // Round 5: 25.5 -> 15.5 KiB of LDS per workgroup -- the kernel's time for small blocks is inversely proportional to the workgroups a CU holds (10^6 x 4 KiB: 8.6 ms at six,
+    // 11.8 at four, 22 at two): match bits and literal-bit prefixes per slot as 16-bit halves of words (both stay below 2^15 per tile: 2 048 x 15 + 342 x 48 bits), the
+    // literal bytes straight from memory (eight per thread, one unaligned 8-byte load) instead of through a staging array
     __shared__ uint32_t t_ll[288];
     __shared__ uint32_t t_d[32];
-    __shared__ uint32_t wm[TILE + 8];                        // match bits per literal slot
-    __shared__ uint32_t scanx[TILE + 8];                     // exclusive packed scan per slot: literal bits | match bits << 16
-    __shared__ uint32_t litbuf[TILE / 4 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t wm2[TILE / 2 + 8];                   // match bits per literal slot, two slots per word (atomic adds of a shifted value: no half overflows)
+    __shared__ __attribute__((aligned(16))) uint32_t lx2[TILE / 2 + 8];                   // literal bits in front of each slot (exclusive scan inside the tile), two slots per word
     __shared__ unsigned long long stage[DB_STAGE];
     __shared__ uint32_t wsum1[4], wsum2[4];
     (void)dbg;
@@ -470,7 +472,7 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
     for (uint32_t i = tid; i < 288; i += DB_THREADS) t_ll[i] = T->ll_code[i];
     if (tid < 32) t_d[tid] = T->d_code[tid];
     for (uint32_t i = tid; i < DB_STAGE; i += DB_THREADS) stage[i] = 0;
-    for (uint32_t i = tid; i < TILE + 8; i += DB_THREADS) wm[i] = 0;
+    for (uint32_t i = tid; i < TILE / 2 + 8; i += DB_THREADS) wm2[i] = 0;
     const uint32_t b = g - sd.blk_base, nblk = seg_nblk(sd), bsz = 1u << sd.blk_log;
     const uint32_t bl_len = sd.len - b * bsz < bsz ? sd.len - b * bsz : bsz;
     const bool last = (sd.first & 2) && (b + 1 == nblk);
@@ -499,7 +501,7 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
         const unsigned long long carry = stage[nfull];
         __syncthreads();
         for (uint32_t i = tid; i <= nfull + 1 && i < DB_STAGE; i += DB_THREADS) stage[i] = i == 0 ? carry : 0ull;
-        for (uint32_t i = tid; i <= nslots; i += DB_THREADS) wm[i] = 0;
+        for (uint32_t i = tid; i <= nslots / 2; i += DB_THREADS) wm2[i] = 0;
         flushed += nfull;
         __syncthreads();
     };
@@ -514,9 +516,10 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
         const uint32_t gf = (ns ? c.z : l1) - l0;            // slot of the tile's first match
         const uint32_t base = bitpos - (flushed << 6);      // staging bit offset of the tile's first token
 
-        // literal bytes of the tile -> LDS (aligned dword loads)
-        const uint32_t a0 = l0 & ~3u, ndw = nl ? ((l1 + 3 - a0) >> 2) : 0u;
-        for (uint32_t i = tid; i < ndw; i += DB_THREADS) litbuf[i] = *(const uint32_t *)(bl + a0 + 4 * i);
+        // this thread's eight literal bytes (slots 8 tid ..), requested now: one unaligned 8-byte load (the literal array of a block is followed by the next block's / the
+        // buffer's slack, so the load may run past nl)
+        typedef unsigned long long u64u __attribute__((aligned(1)));
+        const unsigned long long lit8 = tid * 8 < nl ? *(const u64u *)(bl + l0 + tid * 8) : 0ull;
 
         // ---- sequences: two per thread
         uint32_t mb[2] = {0, 0}, inc[2] = {0, 0};
@@ -544,24 +547,23 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
         const uint32_t ex1 = db_wg_scan(p1, wsum1, tid, tot1) - p1;
         const uint32_t slot0 = (ex1 & 0xFFFF) + inc[0], slot1 = slot0 + inc[1];
         const uint32_t mx0 = ex1 >> 16, mx1 = mx0 + mb[0];
-        if (mb[0]) atomicAdd(&wm[slot0], mb[0]);
-        if (mb[1]) atomicAdd(&wm[slot1], mb[1]);
+        if (mb[0]) atomicAdd(&wm2[slot0 >> 1], mb[0] << (16 * (slot0 & 1)));
+        if (mb[1]) atomicAdd(&wm2[slot1 >> 1], mb[1] << (16 * (slot1 & 1)));
         __syncthreads();
 
         // ---- literal slots: eight per thread
         uint32_t code[8], wmv[8];
         uint32_t lsum = 0, msum = 0;
         {
-            const uint32_t bo = (l0 - a0) + tid * 8;       // byte offset of this thread's first literal in litbuf
-            const uint32_t d0 = bo >> 2, sh = (bo & 3) * 8;
-            const uint32_t w0 = litbuf[d0], w1 = litbuf[d0 + 1], w2 = litbuf[d0 + 2];
-            const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+            const uint32_t x0 = (uint32_t)lit8, x1 = (uint32_t)(lit8 >> 32);
+            const uint4 wv = *(const uint4 *)&wm2[tid * 4];                         // the eight slots' match bits
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t sl = tid * 8 + i;
                 const uint32_t byte = ((i < 4 ? x0 : x1) >> (8 * (i & 3))) & 0xFF;
                 code[i] = sl < nl ? t_ll[byte] : 0u;
-                wmv[i] = wm[sl];
+                wmv[i] = (ww[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 lsum += code[i] >> 16; msum += wmv[i];
             }
         }
@@ -570,10 +572,10 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
         uint32_t run = db_wg_scan(p2, wsum2, tid, tot2) - p2;
         {
             unsigned long long acc = 0; uint32_t nacc = 0, aoff = 0;
+            uint32_t lxw[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const uint32_t sl = tid * 8 + i;
-                scanx[sl] = run;
+                lxw[i >> 1] |= (run & 0xFFFFu) << (16 * (i & 1));
                 const uint32_t ln = code[i] >> 16;
                 if (wmv[i] && nacc) { db_put(stage, aoff, acc, nacc); acc = 0; nacc = 0; }
                 if (ln) {
@@ -584,13 +586,14 @@ void k_dblock(const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk
                 run += ln | (wmv[i] << 16);
             }
             if (nacc) db_put(stage, aoff, acc, nacc);
-            if (tid == DB_THREADS - 1) scanx[TILE] = run;
+            *(uint4 *)&lx2[tid * 4] = make_uint4(lxw[0], lxw[1], lxw[2], lxw[3]);
+            if (tid == DB_THREADS - 1) lx2[TILE / 2] = run & 0xFFFFu;                 // (slot TILE: a match behind the tile's last literal)
         }
         __syncthreads();
 
         // ---- matches
-        if (mb[0]) db_put(stage, base + (scanx[slot0] & 0xFFFF) + mx0, tok[0], mb[0]);
-        if (mb[1]) db_put(stage, base + (scanx[slot1] & 0xFFFF) + mx1, tok[1], mb[1]);
+        if (mb[0]) db_put(stage, base + ((lx2[slot0 >> 1] >> (16 * (slot0 & 1))) & 0xFFFFu) + mx0, tok[0], mb[0]);
+        if (mb[1]) db_put(stage, base + ((lx2[slot1 >> 1] >> (16 * (slot1 & 1))) & 0xFFFFu) + mx1, tok[1], mb[1]);
         bitpos += (tot2 & 0xFFFF) + (tot1 >> 16);
         flush(nl);
     }
