@@ -174,7 +174,7 @@ class ZstdParams(ctypes.Structure):
                 ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
                 ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32), ("len_word_max", ctypes.c_uint32),
                 ("tab3", ctypes.c_uint32), ("mtile", ctypes.c_uint32), ("small_seg", ctypes.c_uint32), ("small_slots", ctypes.c_uint32),
-                ("small_tile", ctypes.c_uint32), ("mid_seg", ctypes.c_uint32), ("mid_slots", ctypes.c_uint32)]
+                ("small_tile", ctypes.c_uint32), ("mid_seg", ctypes.c_uint32), ("mid_slots", ctypes.c_uint32), ("cut_min", ctypes.c_uint32), ("far_slots", ctypes.c_uint32), ("far_from", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4
@@ -214,15 +214,15 @@ def level_win32k(level, deflate: bool = False, win32k: int = 1) -> int:
     return 2 if (not deflate and win32k and lv >= 6) else win32k
 
 
-def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1) -> "ZstdParams":
+def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1, far1: int = 1) -> "ZstdParams":
     fl, gtab = product_level_flags(level, deflate, ctx_flags)
-    p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3)
+    p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3, far1=far1)
     if deflate and level == 0:
         p.flags |= 0x200               # PNA_F_STORED: deflate level 0 = Compression::none(), stored blocks only (lib/src/compress/deflate.rs:89-101)
     return p
 
 
-def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2, tab3: int = 1) -> ZstdParams:
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2, tab3: int = 1, far1: int = 1) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
     F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
     (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB).  gtab: the match kernel's table lies in global
@@ -234,12 +234,15 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
     # even-position inserts and backward adoption -- 49 062 / 55 206 slots instead of 32 704 / 36 800
     packed = bool(tab3 and flags & F_INS2 and flags & F_ADOPT)
     p.tab3 = 0
+    p.far_slots = 0
     if not deflate and not (flags & F_FAR and flags & F_LAZY and not gtab and win32k):
         p.hash_log, p.near_off = 24512, 56064
     elif not deflate and win32k >= 2:
         p.hash_log, p.near_off, p.tab3 = (55206 if packed else 36800), 6912, int(packed)       # the 16 KiB window: the high set (and, with the product's option win32k = 2, the default set)
     elif not deflate:
         p.hash_log, p.near_off, p.tab3 = (49062 if packed else 32704), 23296, int(packed)
+        if packed and far1:            # FLAG_FAR1 (the product's option far1, default on): the light / default sets verify at most 63 far candidates (offset >= 28 368: beyond k_lzm's window) per wave of 256 positions
+            p.far_slots, p.far_from = 63, 28368
     p.flags = (p.flags & ~(F_HUF | F_FSE | F_LAZY)) | (flags & (F_HUF | F_FSE | F_LAZY)) if not deflate else ((p.flags & ~F_LAZY) | (flags & F_LAZY))
     p.flags &= ~0x180                      # two- and three-step lazy deferral go with F_LAZY (the product's option lazy2 = 2 / 1 / 0: both, the first, none -- the high sets keep the first)
     if flags & F_LAZY and (lazy2 or flags & F_STRONG):

@@ -153,7 +153,7 @@ size_t pna_deflate_bound(size_t n) {
 void pna_deflate_default_params(pna_zstd_params *p) {
     pna_zstd_default_params(p);
     p->max_off = 32768; p->max_len = 258; p->flags = PNA_F_LAZY | PNA_F_LAZY2 | PNA_F_LAZY3;
-    p->hash_log = 24512; p->near_off = 56064; p->tab3 = 0;      /* the 64 KiB-window geometry: the whole look-back lies in the window; 32-bit table entries */
+    p->hash_log = 24512; p->near_off = 56064; p->tab3 = 0; p->far_slots = 0;      /* the 64 KiB-window geometry: the whole look-back lies in the window; 32-bit table entries */
 }
 
 size_t pna_deflate_model_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const pna_zstd_params *p) {

@@ -30,6 +30,7 @@ void pna_zstd_default_params(pna_zstd_params *p) {
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
     p->blk_log = 0; p->len_word_max = 36; p->tab3 = 1;
     p->mtile = 0; p->small_seg = 4096; p->small_slots = 2048; p->small_tile = 256; p->mid_seg = 16384; p->mid_slots = 2048;
+    p->cut_min = 6; p->far_slots = 63; p->far_from = 28368;
 }
 const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp) {
     uint32_t slots = 0;
@@ -67,6 +68,13 @@ static uint32_t lz_hash(const uint8_t *p, uint32_t min_match, uint32_t hash_log)
      * LDS): index = floor(h * count / 2^32) */
     return hash_log <= 31 ? h >> (32 - hash_log) : (uint32_t)(((uint64_t)h * hash_log) >> 32);
 }
+/* the 32-bit hash itself (the packed table's tag = its bits 16..17) */
+static uint32_t lz_h32(const uint8_t *p, uint32_t min_match) {
+    uint32_t lo = rd32(p), hi = 0;
+    if (min_match >= 5) hi = p[4];
+    if (min_match >= 6) hi |= (uint32_t)p[5] << 8;
+    return lo * 0x9E3779B1u + hi * 0x85EBCA6Bu;
+}
 /* the packed table (tab3): slot = 3 * word + field; the word from the hash's top bits, the field from its low 16 */
 static uint32_t lz_hash3(const uint8_t *p, uint32_t min_match, uint32_t slots) {
     uint32_t lo = rd32(p);
@@ -100,7 +108,7 @@ static uint32_t lz_hash3(const uint8_t *p, uint32_t min_match, uint32_t slots) {
  *   F  merge of the regions in ascending order against the running end E of the emitted matches (E = next_free at the
  *      tile start): a region that lies entirely below E contributes nothing; otherwise a match that ends at or before E
  *      is dropped, a match that starts before E and ends r bytes after it is cut from the front (start E, length r, same
- *      offset) when r >= 3 and dropped otherwise, and any other match is emitted as parsed.  E becomes the end of every
+ *      offset) when r >= cut_min (3 for deflate, min_match for zstd) and dropped otherwise, and any other match is emitted as parsed.  E becomes the end of every
  *      emitted match; next_free = E after the tile.
  * Literals are the bytes not covered by matches, in order; the block's last literals follow the last sequence.
  */
@@ -149,6 +157,19 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
             if (q + 8 <= seg_len) {
                 uint32_t h = lz_hash(seg + q, p->min_match, p->hash_log);
                 if (q % ins_mod == 0 && table[h] < q + 1) table[h] = q + 1;
+            }
+        }
+        /* far candidates beyond the wave's slots (far_slots): dropped before M */
+        if (p->far_slots && p->tab3) {
+            for (uint32_t w0 = t0; w0 < t1; w0 += 256) {
+                uint32_t idx = 0;
+                for (uint32_t j = 0; j < 4; j++)
+                    for (uint32_t q = w0 + j; q < w0 + 256 && q < t1; q += 4) {
+                        const uint32_t c1 = cand[q - t0];
+                        if (c1 <= 8 || q - (c1 - 1) > p->max_off || q - (c1 - 1) < p->far_from) continue;
+                        if (((lz_h32(seg + q, p->min_match) ^ lz_h32(seg + c1 - 1, p->min_match)) >> 16) & 3u) continue;      /* foreign tag: no candidate for the device either */
+                        if (idx++ >= p->far_slots) cand[q - t0] = 0;
+                    }
             }
         }
         /* M */
@@ -207,7 +228,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
             if (q + l <= next_free || mr[i] <= next_free) continue;      /* mr = end of the match's region */
             if (q < next_free) {
                 uint32_t r = q + l - next_free;
-                if (r < 3) continue;
+                if (r < (p->cut_min ? p->cut_min : 3u)) continue;
                 c += next_free - q; q = next_free; l = r;
             }
             seqs[nseq].ll = q - lit_start; seqs[nseq].ml = l; seqs[nseq].off = q - c; nseq++;

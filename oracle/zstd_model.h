@@ -59,6 +59,13 @@ typedef struct {
     uint32_t small_slots, small_tile;
     uint32_t mid_seg, mid_slots;   /* a second tier of the same geometry: segments above small_seg and of at most mid_seg bytes (0 = none) with a table of mid_slots entries
                                     * (the device gives both tiers the same table and sizes the window by the tier: 8 KiB text entries 1.97 -> 2.16, 16 KiB 2.16 -> 2.24; zlib -6: 2.12 / 2.22) */
+    uint32_t cut_min;     /* F: a match the merge cuts from the front is kept iff at least this many bytes remain (0 = 3, the deflate minimum; the zstd sets: min_match --
+                           * a sequence of 3 - 5 bytes costs more than its bytes as literals: + 0.12 % of ratio on the corpus) */
+    uint32_t far_slots, far_from;   /* far_slots != 0 (the device's default / light zstd sets, round 5): the match kernel verifies at most far_slots FAR candidates (offset >= far_from: outside
+                           * its LDS window) per wave of 256 consecutive positions (tile start + 256 w ..) -- one compacted round of its 63 dense lanes instead of two.  The wave's far
+                           * candidates (usable: position >= 8, offset <= max_off, and the entry's 2-bit tag equals the position's -- a foreign tag costs the device a slot like a
+                           * true candidate) are numbered in the kernel's order, j-major: all positions with (q - wave start) % 4 == 0 in ascending order, then % 4 == 1, ...;
+                           * those numbered far_slots and up are dropped (no candidate).  Needs tab3. */
 } pna_zstd_params;
 /* the parameters segment `seg_len` bytes long runs with: p itself, or *tmp = p with the small geometry */
 const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp);

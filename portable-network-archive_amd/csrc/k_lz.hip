@@ -18,7 +18,7 @@
 //   with scalar loops on ballot masks, and publishes the end of its last match -> B3 -> inserts (ds_max_u32) -> MERGE: the running end E of the
 //   earlier waves' matches is a 16-lane prefix maximum (exact unless an end falls 1-2 bytes behind E: then a short serial
 //   scan); a wave entirely below E emits nothing, matches that end before E are dropped, the one straddling E is cut from
-//   the front (>= 3 bytes must remain),
+//   the front (>= CUT_MIN = 6 bytes must remain),
 //   everything else stands -> selection / literal masks -> counts -> B4 -> 16-lane DPP scans of the waves' counts ->
 //   emission of sequences and literals straight to HBM.
 //   Cross-lane traffic on this path: ballots, readlanes, DPP and two ds_bpermute per 64 positions.
@@ -189,6 +189,37 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t c1 = TAB3 ? t3_pos(ent[r]) + 1 : ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
                 off[r] = TAB3 ? ((ent[r] >= 16u && (ent[r] & 3u) == tag[r] && o <= max_off) ? o : 0u)
                               : ((c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u);
+            }
+            // FLAG_FAR1 (the default / light zstd sets, round 5): the split form's match kernel verifies at most 63 candidates beyond ITS window (offset >= GEO::NEARM) per
+            // wave of 256 positions -- one compacted round -- and drops the rest; its numbering is j-major over four consecutive positions per lane (all positions
+            // = 0 mod 4 of the wave in ascending order, then = 1 mod 4, ...).  The same candidates are dropped here: position 64 r + lane has class j = lane & 3, and its
+            // number is the count of the classes below, of its class in the groups before r, and of its class below the lane.
+            if constexpr (TAB3 && MODE != 2) {
+                if (flags & FLAG_FAR1) {                                            // (uniform)
+                    uint64_t fm[G]; uint32_t cls[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < G; r++) {
+                        fm[r] = __ballot(off[r] >= GEO::NEARM);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) cls[j] += (uint32_t)__builtin_popcountll(fm[r] & (0x1111111111111111ull << j));
+                    }
+                    const uint32_t j = lane & 3u;
+                    uint32_t run = j == 0 ? 0u : (j == 1 ? cls[0] : (j == 2 ? cls[0] + cls[1] : cls[0] + cls[1] + cls[2]));      // far candidates of the classes below mine
+                    const uint64_t mine = (0x1111111111111111ull << j) & lane_lt;                                                 // my class, below my lane
+#pragma unroll
+                    for (int r = 0; r < G; r++) {
+                        const uint32_t idx = run + (uint32_t)__builtin_popcountll(fm[r] & mine);
+                        if (off[r] >= GEO::NEARM && idx >= 63u) off[r] = 0;
+                        uint32_t c0 = (uint32_t)__builtin_popcountll(fm[r] & 0x1111111111111111ull), c1 = (uint32_t)__builtin_popcountll(fm[r] & 0x2222222222222222ull);
+                        uint32_t c2 = (uint32_t)__builtin_popcountll(fm[r] & 0x4444444444444444ull), c3 = (uint32_t)__builtin_popcountll(fm[r] & 0x8888888888888888ull);
+                        run += j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                if constexpr (MODE == 2) continue;
+                const uint32_t c1 = q[r] + 1 - off[r];                              // (only read where off[r] != 0)
                 if (FAR && seg_len > NEAR && max_off > NEAR) {                      // (uniform) shorter segments / near-only levels have no far candidates
                     const uint32_t fo = off[r] > NEAR ? c1 - 5 : 0u;                // byte offset of c - 4 in the segment
                     fa[r] = ld16u(seg + fo);
@@ -392,7 +423,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                 const uint32_t incl = row_scan_max(el_l);
                 const uint32_t before = DPP_ROW_SHR(incl, 1);                       // maximum over the earlier waves (0 for wave 0)
                 const uint32_t prev = before > c_in ? before : c_in;
-                const bool near = lv && el_l > prev && (el_l < prev + 3 || prev >= lane * RW + RW);
+                const bool near = lv && el_l > prev && (el_l < prev + CUT_MIN || prev >= lane * RW + RW);
                 if (__ballot(near) == 0 && !force_serial) {
                     const uint32_t m = wave ? rdlane(incl, wave - 1) : 0u, ma = rdlane(incl, LZ_WAVES - 1);
                     E = m > c_in ? m : c_in;
@@ -402,7 +433,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     for (uint32_t j = 0; j < LZ_WAVES; j++) {
                         if (j == wave) E = x;
                         const uint32_t ej = rdlane(el_l, j);
-                        if (x < j * RW + RW && ej >= x + 3) x = ej;
+                        if (x < j * RW + RW && ej >= x + CUT_MIN) x = ej;
                     }
                     tile_exit = x;
                 }
@@ -436,7 +467,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                         for (int r = 1; r < G; r++) if (g2 == (uint32_t)r) { l2 = rdlane(flen[r], s2); o2 = rdlane(off[r], s2); }
                         const uint32_t end2 = 64 * g2 + s2 + l2;                    // wave-relative end of the straddling match
                         const uint32_t rmn = end2 - Ew;
-                        if (rmn >= 3) {
+                        if (rmn >= CUT_MIN) {
 #pragma unroll
                             for (int r = 0; r < G; r++) if (grp == (uint32_t)r) { fsel[r] |= (uint64_t)1 << b; if (lane == b) { flen[r] = rmn; off[r] = o2; } }
                         } else {

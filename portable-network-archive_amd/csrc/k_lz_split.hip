@@ -109,6 +109,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     // the one-kernel form's LOOKAHEAD + 16: another 976 bytes of look-back
     constexpr uint32_t LA = 64;
     constexpr uint32_t NEAR = GEO::NEAR + TILE_G + (LOOKAHEAD + 16 - LA);
+    static_assert(NEAR == GEO::NEARM, "lz_common.h: the one-kernel form numbers this kernel's far candidates (FLAG_FAR1)");
     static_assert(WIN_BYTES >= TILE_G + LA + NEAR + 8 + 200 && (!DEFL || NEAR >= 32768), "window: look-back (+ 8 back bytes) + this tile + look-ahead");
     static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
@@ -298,6 +299,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, so, ffa, ffb, ffd, ffc, edge, blk_end);
                     far_pull(farj, idx, 0u, Kf, P);
                 }
+                if (!(flags & FLAG_FAR1))                                               // (uniform; FLAG_FAR1, the default and light sets since round 5: the pairs beyond the first 63 are dropped -- - 0.16 % of ratio, - 6 % of the kernel's time)
                 for (uint32_t r0 = 63; r0 < npair; r0 += 63) {                         // (more than 63 far pairs in 256 positions: a quarter of the wave-tiles of the default set)
                     uint32_t sq2, so2, Kf = 0;
                     far_push(farj, idx, r0, t0 + wave * RW, lane, off, sq2, so2);
@@ -720,7 +722,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             for (uint32_t k = 0; k < 16; k++) {
                 const uint32_t ek = rdlane(wend, k);
                 if (w == k) E = x;
-                if (x < k * RW + RW && ek >= x + 3) x = ek;
+                if (x < k * RW + RW && ek >= x + CUT_MIN) x = ek;
             }
             tile_exit = x;
         }
@@ -753,7 +755,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                     for (int r = 1; r < 4; r++) if (g2 == (uint32_t)r) { sc2 = sel[r] & cm[r]; pc2 = pc[r]; }
                     const uint32_t l2 = ((sc2 >> s2) & 1) ? xlen[w * 8 + ((pc2 + (uint32_t)__popcll(sc2 & mlow(s2))) & 7)] : (pw2 & 63u);
                     const uint32_t end2 = 64 * g2 + s2 + l2, rmn = end2 - Ew;
-                    if (rmn >= 3) {
+                    if (rmn >= CUT_MIN) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
                         cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;

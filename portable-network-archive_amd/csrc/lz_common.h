@@ -37,6 +37,7 @@ template <uint32_t WLOG, bool TAB3 = false> struct LzGeo {
     static constexpr uint32_t L_WPUB  = L_WEND + 4 * LZ_WAVES;    // 16 x 8 B
     static constexpr uint32_t L_TOTAL = L_WPUB + 8 * LZ_WAVES;
     static constexpr uint32_t NEAR    = WLOG == 16 ? NEAR_OFF : WIN - 2 * 1024 * LZ_G_ZSTD - LOOKAHEAD - 16 - 240;   // candidates at most this far back are verified in the window (32 KiB: 23 296; 16 KiB: 6 912)
+    static constexpr uint32_t NEARM   = NEAR + 1024 * LZ_G_ZSTD + (LOOKAHEAD + 16 - 64);   // the split form's match kernel (k_lzm) keeps a tile more of look-back in its window and runs only 64 bytes ahead: what it verifies in LDS (32 KiB: 28 368)
     static_assert(L_TOTAL <= 160 * 1024 && TABLE_BYTES % 16 == 0 && L_TABLE % 16 == 0, "k_lz's LDS: window + table + records within one CU's 160 KiB");
 };
 // the packed table's arithmetic: (word, bit position of the field) of a hash; the 21-bit entry of an even position; the word with a field replaced

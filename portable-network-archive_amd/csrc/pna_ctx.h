@@ -176,6 +176,7 @@ struct Tuning {
     long zexec_win_mib = 1024;       // PNA_ZEXEC_WIN_MIB: output bytes of one window of the parallel executor (its words count 31 bits from the window's start: at most 1 024; tests take a few MiB)
     long small_geometry = 1;         // PNA_SMALL_GEOMETRY: 1 (default): segments of at most 4 096 bytes run the small geometry of the match finder (pna_dev.h SMALL_SEG: one wave per segment, sub-tiles of 256 positions); 0: the large one like every segment (they then find no match: one tile)
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
+    long far1 = 1;                   // PNA_FAR1: 1 (default): the zstd light / default sets (packed table, 32 KiB window) verify at most 63 far candidates per wave of 256 positions -- one compacted round of k_lzm -- and drop the rest (FLAG_FAR1: - 0.16 % of ratio, - 6 % of the match kernel); 0: every far candidate, in as many rounds as it takes
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
     long strong_gtab = 1;            // PNA_STRONG_GTAB: zstd levels 10 .. 22 with the match kernel's hash tables in global memory (2^19 slots per segment); 0: the LDS table

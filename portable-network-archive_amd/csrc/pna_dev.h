@@ -25,6 +25,7 @@ constexpr uint32_t GROUPS_PER_WAVE = TILE / 64 / LZ_WAVES;   // 2
 #endif
 constexpr uint32_t HASH_ENTRIES = LZ_HASH_ENTRIES_VALUE;   // LDS hash table of k_lz: as many u32 entries as fit next to the 64 KiB window (index = mulhi(hash, entries))
 constexpr uint32_t MIN_MATCH  = 6;
+constexpr uint32_t CUT_MIN    = MIN_MATCH;  // the merge keeps a match it cuts from the front iff at least this many bytes remain (round 5: 3 until then -- a sequence of 3 - 5 bytes costs more than its bytes as literals; zstd-3 + 0.12 % of ratio, deflate + 0.06 %)
 #ifndef LZ_G_ZSTD_VALUE
 #define LZ_G_ZSTD_VALUE 4
 #endif
@@ -62,6 +63,7 @@ constexpr uint32_t FLAG_HAS_SMALL = 0x20000u;   // launch flag of the LZ kernels
 constexpr uint32_t FLAG_SMALL_ONLY = 0x40000u;  // (k_lzp) parse the blocks of short segments only: the pass behind a one-kernel launch, which skipped them
 constexpr uint32_t FLAG_TIER1 = 0x100000u, FLAG_TIER2 = 0x200000u;   // (with FLAG_HAS_SMALL) the launch holds segments of the first / second tier: which of k_lzms's two forms to launch
 constexpr uint32_t FLAG_ALL_SMALL = 0x80000u;   // every segment of the launch is short (or empty): the large geometry's kernels are not launched at all
+constexpr uint32_t FLAG_FAR1 = 0x1000000u;   // (with FLAG_TAB3 + FLAG_W32) at most 63 far candidates per wave of 256 positions are verified -- ONE compacted round of k_lzm --, the rest dropped (oracle: far_slots, far_from)
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy
 

@@ -316,6 +316,30 @@ def test_lds_geometries_equal_the_model(pna, codec, form):
     assert size[(1, 1, 3)] < size[(0, 1, 3)] and size[(1, 1, 7)] < size[(0, 1, 7)]        # the packed table remembers more
 
 
+@pytest.mark.parametrize("form", ["split", "one-kernel"])
+def test_far_candidates_beyond_one_round_are_dropped(pna, codec, form):
+    """FLAG_FAR1 (option far1, default 1; zstd levels 2 .. 5 on the packed 32 KiB-window geometry): the match kernel verifies at most 63 candidates beyond its window per
+    wave of 256 positions -- one compacted round of its dense lanes -- and drops the rest, numbered j-major over its four positions per lane; the one-kernel form, whose lanes
+    hold other positions, drops the same ones.  Both forms equal the model with far_slots = 63 / 0, and the option costs ratio, not correctness."""
+    import torch  # noqa: F401
+    ents = [codec.corpus_file(0, 2, (1 << 20) + 77), codec.corpus_file(0, 5, 2500000), codec.corpus_file(1, 3, 400000), codec.corpus_file(0, 8, 131072 + 4096 + 100)]
+    size = {}
+    with pna.Context(0) as ctx:
+        ctx.set_option("latency_max_mib", 0)
+        ctx.set_option("lz_split_min", 0 if form == "split" else 1 << 20)
+        for far1 in (1, 0):
+            ctx.set_option("far1", far1)
+            for lvl in (3, 2, 7):
+                outs = ctx.compress_batch(ents, level=lvl)
+                p = codec.params_for_level(lvl, far1=far1)
+                assert p.far_slots == (63 if (far1 and lvl < 6) else 0)
+                for e, o in zip(ents, outs):
+                    assert o == codec.model_compress(e, p), (far1, lvl, len(e))
+                    assert codec.zstd_decompress(o, len(e)) == e
+                size[(far1, lvl)] = sum(map(len, outs))
+    assert size[(0, 3)] < size[(1, 3)] < size[(0, 3)] * 1.01 and size[(0, 7)] == size[(1, 7)]
+
+
 def test_lz_stage_equals_model(gpu_ctx, codec):
     d = codec.corpus_file(0, 31, 700000)
     gpu_ctx.compress_batch([d])
