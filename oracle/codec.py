@@ -214,15 +214,16 @@ def level_win32k(level, deflate: bool = False, win32k: int = 1) -> int:
     return 2 if (not deflate and win32k and lv >= 6) else win32k
 
 
-def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1, far1: int = 1) -> "ZstdParams":
+def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1, far1: int = 1, strong2: int = 1) -> "ZstdParams":
     fl, gtab = product_level_flags(level, deflate, ctx_flags)
-    p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3, far1=far1)
+    high = bool(strong2) and not deflate and level is not None and level != -1000 and min(level, 22) >= 6        # zstd 6 .. 22 (the product's option strong2, default on)
+    p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3, far1=far1, strong2=high)
     if deflate and level == 0:
         p.flags |= 0x200               # PNA_F_STORED: deflate level 0 = Compression::none(), stored blocks only (lib/src/compress/deflate.rs:89-101)
     return p
 
 
-def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2, tab3: int = 1, far1: int = 1) -> ZstdParams:
+def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: bool = False, win32k: int = 1, lazy2: int = 2, tab3: int = 1, far1: int = 1, strong2: bool = False) -> ZstdParams:
     """The model parameters that correspond to the product's flag bits: without F_FAR the look-back ends with the LDS window, without
     F_ADOPT there is no backward adoption, without F_INS2 every position enters the table.  blk_log: the block size the device chose
     (pna_gpu_timing.blk_log: 13..16 in its latency mode for small batches, else 17 = 128 KiB).  gtab: the match kernel's table lies in global
@@ -257,6 +258,10 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
         p.rounds = 0x214                       # round 5: the round over four positions FIRST, then 1, then 2 (+ 0.03 % of ratio on the corpus for nothing)
         p.back_cap = 7
         p.flags |= 0x80
+    if strong2 and flags & F_STRONG and flags & F_ADOPT and not deflate and (gtab or (p.tab3 and p.hash_log == 55206)):
+        # the high and max sets (zstd 6 .. 22 on their standard geometries; round 5): a FOURTH adoption round over eight positions, first, and up to 15 back bytes -- levels 6 .. 9 2.864 -> 2.880
+        p.rounds = 0x2148
+        p.back_cap = 15
     if gtab:
         p.hash_log = 19                # zstd levels 10 .. 22: the match kernel's table lies in global memory, 2^19 slots per segment (index = the hash's top bits)
         p.max_off = 1 << 20            # ... and its words keep 4 bytes per position: the whole segment as look-back, no clamp of the adopted lengths

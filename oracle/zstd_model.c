@@ -125,6 +125,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     uint16_t *len0 = (uint16_t *)malloc(sizeof(uint16_t) * (T + 1)); uint32_t *cand0 = (uint32_t *)malloc(sizeof(uint32_t) * T);
     uint8_t *back0 = (uint8_t *)malloc(2 * (T + 1)), *far0 = back0 + T + 1;
     const uint32_t ins_mod = p->ins_mod ? p->ins_mod : 1;
+    const uint32_t min_c = p->back_cap > 7 ? 16u : 8u;            /* a usable candidate's position + 1 exceeds it */
     uint32_t *mq = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1) * 4), *ml = mq + T + 1, *mc = ml + T + 1, *mr = mc + T + 1;
     uint32_t *wbest = p->tab3 ? (uint32_t *)calloc(p->hash_log / 3 + 1, sizeof(uint32_t)) : NULL, *wlist = p->tab3 ? (uint32_t *)malloc(sizeof(uint32_t) * (T + 1)) : NULL;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
@@ -166,7 +167,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
                 for (uint32_t j = 0; j < 4; j++)
                     for (uint32_t q = w0 + j; q < w0 + 256 && q < t1; q += 4) {
                         const uint32_t c1 = cand[q - t0];
-                        if (c1 <= 8 || q - (c1 - 1) > p->max_off || q - (c1 - 1) < p->far_from) continue;
+                        if (c1 <= min_c || q - (c1 - 1) > p->max_off || q - (c1 - 1) < p->far_from) continue;
                         if (((lz_h32(seg + q, p->min_match) ^ lz_h32(seg + c1 - 1, p->min_match)) >> 16) & 3u) continue;      /* foreign tag: no candidate for the device either */
                         if (idx++ >= p->far_slots) cand[q - t0] = 0;
                     }
@@ -175,7 +176,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         /* M */
         for (uint32_t q = t0; q < t1; q++) {
             uint32_t c1 = cand[q - t0], l = 0, bk = 0, fr = 0;
-            if (c1 > 8 && q - (c1 - 1) <= p->max_off) {                  /* candidates at positions 0..7 are not used: 8 bytes before a candidate always exist */
+            if (c1 > min_c && q - (c1 - 1) <= p->max_off) {              /* candidates at positions 0..7 (0..15 with more than 7 back bytes) are not used: 8 (16) bytes before a candidate always exist */
                 uint32_t c = c1 - 1, lim = blk_end - q;
                 fr = p->near_off && q - c > p->near_off;
                 uint32_t cap = fr ? p->cap_far : p->cap1;

@@ -52,7 +52,7 @@ __device__ unsigned long long g_lz_stamps[8];
 // MODE: 0 = the whole stage in one kernel; 1 / 2 = its two halves as kernels of their own (launch_lz_split): 1 = look-up, match and
 // inserts only -- one word per position (length | offset << 6, after adoption) goes to `pbuf` --, 2 = parse, merge and emission from those
 // words (no window, no table: 192 bytes of LDS, two workgroups per CU).  Same code, same results: the halves only meet in `pbuf`.
-template <bool STAMP, int G, bool CT, bool STRONG, int MODE, uint32_t WLOG, bool TAB3 = false>   // TAB3: the packed table (lz_common.h)
+template <bool STAMP, int G, bool CT, int STRONG, int MODE, uint32_t WLOG, bool TAB3 = false>   // TAB3: the packed table (lz_common.h); STRONG: 0 / 1 / 2 as in k_lzm (2: a fourth adoption round over eight positions, 15 back bytes)
 __global__ __launch_bounds__(LZ_THREADS, MODE == 2 ? 8 : 4)   // (second figure: waves per SIMD the compiler must leave room for)
 void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint64_t *__restrict__ seqs,
           uint8_t *__restrict__ lits, BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_off, uint32_t max_len,
@@ -84,7 +84,8 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     uint32_t *pb = MODE ? pbuf + ((size_t)(sd.blk_base - blk0) << blk_log) : nullptr;   // the segment's words (split form)
     const uint32_t lazy = flags & F_LAZY;
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
-    constexpr bool strong = STRONG;   // (wave-uniform) level sets: pna_host.cpp level_flags()
+    constexpr bool strong = STRONG != 0, strong2 = STRONG == 2;   // (wave-uniform) level sets: pna_host.cpp level_flags()
+    constexpr uint32_t KL = strong2 ? 8u : 6u, KB = strong2 ? 4u : 3u, KLOW = (1u << KL) - 1u, MIN_C = strong2 ? 16u : 8u;   // the adoption key: len << KL | back << KB | lanes moved; a usable candidate lies at MIN_C or beyond
     const bool force_serial = (flags & FLAG_FORCE_SERIAL) != 0;
     const uint64_t lane_lt = ((uint64_t)1 << lane) - 1;   // lanes below this one
     const uint32_t wbase = wave * RW;                     // tile-relative first position of this wave
@@ -133,7 +134,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             LZ_STAMP(0);
 
             // ---- lookup
-            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G], bq2[G];
+            uint32_t q[G], lo[G], hi[G], hsh[G], tag[G], ent[G], bq[G], bq2[G], bq3[G], bq4[G];
             uint32_t sh3[G]; uint64_t w3[G];                                         // TAB3: the field's bit position and the word as the look-up saw it
             bool hv[G];
             // (uniform) a tile that lies wholly inside the block and at least 8 bytes before the segment end needs no per-lane range checks
@@ -147,7 +148,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const bool in = q[r] < t1;
                     pv[r] = in ? pb[q[r]] : 0u;
                     lo[r] = in ? seg[q[r]] : 0u;                                    // the literal byte
-                    hi[r] = hsh[r] = tag[r] = ent[r] = bq[r] = bq2[r] = 0;
+                    hi[r] = hsh[r] = tag[r] = ent[r] = bq[r] = bq2[r] = bq3[r] = bq4[r] = 0;
                     continue;
                 }
                 {
@@ -159,8 +160,10 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     lo[r] = __builtin_amdgcn_alignbit(d1, d0, sh);
                     hi[r] = __builtin_amdgcn_alignbit(d2, d1, sh);
                     bq[r] = __builtin_amdgcn_alignbit(d0, dm, sh);                  // the 4 bytes before q (q - 1 in the top byte)
-                    bq2[r] = 0;
+                    bq2[r] = bq3[r] = bq4[r] = 0;
                     if (strong) bq2[r] = __builtin_amdgcn_alignbit(dm, p[0], sh);   // (uniform) and the 4 before those
+                    if (strong2) { lds_cu32 *pe = lds_word(L_WIN + ((q[r] - 16) & (WIN_BYTES - 4))); const uint32_t e0 = pe[0], e1 = pe[1];      // (uniform) ... and the 8 before those
+                                   bq3[r] = __builtin_amdgcn_alignbit(p[0], e1, sh); bq4[r] = __builtin_amdgcn_alignbit(e1, e0, sh); }
                 }
                 const uint32_t h32 = lo[r] * 0x9E3779B1u + (hi[r] & 0xFFFFu) * 0x85EBCA6Bu;
                 sh3[r] = 0; w3[r] = 0;
@@ -180,15 +183,15 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
             // 16 bytes at the candidate requested from the segment now; the other lanes read the segment's first bytes (one line, no
             // exec masking), which nobody looks at.  A usable candidate lies at position >= 8, so the loads never reach below the segment.
             uint32_t off[G];
-            v4u fa[G]; uint32_t fb[G], fc[G];
+            v4u fa[G]; uint32_t fb[G], fc[G]; v2u fe[G];
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 if constexpr (MODE == 2) { off[r] = pv[r] >> 6; continue; }
-                fa[r] = 0; fb[r] = fc[r] = 0;
+                fa[r] = 0; fb[r] = fc[r] = 0; fe[r] = 0;
                 // (TAB3: an entry = (position / 2) << 2 | tag, usable from position 8 on: entry >= 16)
                 const uint32_t c1 = TAB3 ? t3_pos(ent[r]) + 1 : ent[r] >> TAG_BITS, o = q[r] + 1 - c1;
-                off[r] = TAB3 ? ((ent[r] >= 16u && (ent[r] & 3u) == tag[r] && o <= max_off) ? o : 0u)
-                              : ((c1 > 8 && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u);
+                off[r] = TAB3 ? ((ent[r] >= 2u * MIN_C && (ent[r] & 3u) == tag[r] && o <= max_off) ? o : 0u)
+                              : ((c1 > MIN_C && (ent[r] & TAG_MASK) == tag[r] && o <= max_off) ? o : 0u);
             }
             // FLAG_FAR1 (the default / light zstd sets, round 5): the split form's match kernel verifies at most 63 candidates beyond ITS window (offset >= GEO::NEARM) per
             // wave of 256 positions -- one compacted round -- and drops the rest; its numbering is j-major over four consecutive positions per lane (all positions
@@ -225,6 +228,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     fa[r] = ld16u(seg + fo);
                     fb[r] = *(const u32u *)(seg + fo + 16);
                     if (strong) fc[r] = *(const u32u *)(seg + (off[r] > NEAR ? fo - 4 : 0u));   // (uniform) bytes c - 8 .. c - 5
+                    if (strong2) __builtin_memcpy(&fe[r], seg + (off[r] > NEAR ? fo - 12 : 0u), 8);   // (uniform) bytes c - 16 .. c - 9
                 }
             }
             LZ_STAMP(1);
@@ -246,14 +250,16 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     lds_cu32 *pq = lds_word(L_WIN + ((q[r] - 8) & (WIN_BYTES - 4)));   // pq[2 ..] = the words at q, pc[2 ..] those at c (one base each: see the look-up)
                     lds_cu32 *pc = lds_word(L_WIN + ((c - 8) & (WIN_BYTES - 4)));
                     const uint32_t shc = c << 3, shq = q[r] << 3;
-                    uint32_t w0, w1, w2, w3, bc, bc2 = 0;                           // 16 bytes at c, the 4 (strong: 8) bytes before c
-                    if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; bc2 = fc[r]; }
+                    uint32_t w0, w1, w2, w3, bc, bc2 = 0, bc3 = 0, bc4 = 0;                // 16 bytes at c, the 4 (strong: 8, 16) bytes before c
+                    if (isfar) { bc = fa[r].x; w0 = fa[r].y; w1 = fa[r].z; w2 = fa[r].w; w3 = fb[r]; bc2 = fc[r]; bc3 = fe[r].y; bc4 = fe[r].x; }
                     else {
                         const uint32_t d0 = pc[2], d1 = pc[3], d2 = pc[4], d3 = pc[5], d4 = pc[6], dm = pc[1];
                         w0 = __builtin_amdgcn_alignbit(d1, d0, shc); w1 = __builtin_amdgcn_alignbit(d2, d1, shc);
                         w2 = __builtin_amdgcn_alignbit(d3, d2, shc); w3 = __builtin_amdgcn_alignbit(d4, d3, shc);
                         bc = __builtin_amdgcn_alignbit(d0, dm, shc);
                         if (strong) bc2 = __builtin_amdgcn_alignbit(dm, pc[0], shc);
+                        if (strong2) { lds_cu32 *pe = lds_word(L_WIN + ((c - 16) & (WIN_BYTES - 4))); const uint32_t e0 = pe[0], e1 = pe[1];
+                                       bc3 = __builtin_amdgcn_alignbit(pc[0], e1, shc); bc4 = __builtin_amdgcn_alignbit(e1, e0, shc); }
                     }
                     const uint32_t e2 = pq[4], e3 = pq[5], e4 = pq[6];
                     const uint32_t x0 = lo[r] ^ w0, x1 = hi[r] ^ w1;
@@ -287,27 +293,42 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
                     const uint32_t xk = bq[r] ^ bc;
                     bk = (uint32_t)__builtin_clz(xk | 0xFFu) >> 3;
                     if (strong && xk == 0) bk = 4 + ((uint32_t)__builtin_clz((bq2[r] ^ bc2) | 0xFFu) >> 3);
+                    if (strong2 && bk == 7 && bq2[r] == bc2) {                      // all eight agree: the eight before them, the sixteenth never counted
+                        const uint32_t x3 = bq3[r] ^ bc3;
+                        bk = x3 ? 8 + ((uint32_t)__builtin_clz(x3) >> 3) : 12 + ((uint32_t)__builtin_clz((bq4[r] ^ bc4) | 0xFFu) >> 3);
+                    }
                 }
                 // ---- backward adoption.  K = len << 6 | back << 3 | lanes the match was moved by.  A lane without a match may carry a stray
                 // back count and adopt "lengths" of 1..3 from such neighbours: they stay below MIN_MATCH and nobody reads them as a match.
-                uint32_t K = (l << 6) | (bk << 3);
+                uint32_t K = (l << KL) | (bk << KB);
                 if (STRONG && !l) K = 0;                                            // (three rounds could lift a stray back count to a "length" of 7 >= MIN_MATCH; with two it stays below)
                 if (adopt) {
+                // taking over the match S lanes to the right: + S bytes, back - S, moved + S; allowed iff its back count is at least S -- a test of the count's upper bits
+                constexpr uint32_t BM = ((strong2 ? 15u : 7u) << KB);
+#define K_STEP(S) ((uint32_t)(S) * ((1u << KL) - (1u << KB) + 1u))
+#define K_OK(S) (BM & ~(((uint32_t)(S) - 1u) << KB))
+                if (strong2) {  // (uniform) the high / max sets' round over eight lanes comes first (rounds 8, 4, 1, 2)
+                    const uint32_t K8r = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane + 8u) & 63u) << 2), (int)K);      // (every lane takes part: a lane switched off would hand out 0)
+                    const uint32_t K8 = lane < 56u ? K8r : 0u, T = K8 + K_STEP(8);
+                    K = ((K8 & K_OK(8)) != 0 && T > (K | KLOW)) ? T : K;
+                }
                 if (strong) {   // (uniform) the strong sets' round comes first (rounds 4, 1, 2): four lanes to the right, four bytes longer
-                    const uint32_t K4 = dpp_next_lane(dpp_next_lane(dpp_next_lane(dpp_next_lane(K)))), T = K4 + 228u;
-                    K = ((K4 & 0x20u) != 0 && T > (K | 63u)) ? T : K;
+                    const uint32_t K4 = dpp_next_lane(dpp_next_lane(dpp_next_lane(dpp_next_lane(K)))), T = K4 + K_STEP(4);
+                    K = ((K4 & K_OK(4)) != 0 && T > (K | KLOW)) ? T : K;
                 }
                 {   // the right neighbour's match, one byte longer (lane 63 sees 0)
-                    const uint32_t K1 = dpp_next_lane(K), T = K1 + 57u;
-                    K = ((K1 & 0x38u) != 0 && T > (K | 63u)) ? T : K;
+                    const uint32_t K1 = dpp_next_lane(K), T = K1 + K_STEP(1);
+                    K = ((K1 & K_OK(1)) != 0 && T > (K | KLOW)) ? T : K;
                 }
                 {   // the match two lanes to the right (after the round before), two bytes longer
-                    const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + 114u;
-                    K = ((K2 & 0x30u) != 0 && T > (K | 63u)) ? T : K;
+                    const uint32_t K2 = dpp_next_lane(dpp_next_lane(K)), T = K2 + K_STEP(2);
+                    K = ((K2 & K_OK(2)) != 0 && T > (K | KLOW)) ? T : K;
                 }
-                l = K >> 6;
+#undef K_STEP
+#undef K_OK
+                l = K >> KL;
                 if (flags & FLAG_LEN36) l = l < 36u ? l : 36u;                      // (uniform) what the split form's 3-byte words keep
-                off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & 7u)));          // the offset travels with the match
+                off[r] = (uint32_t)__shfl((int)o, (int)(lane + (K & ((1u << KB) - 1u))));   // the offset travels with the match
                 }
                 }
                 len[r] = l; flen[r] = l;
@@ -571,7 +592,7 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
     if (STAMP && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_lz_stamps[k], st_acc[k]);
 }
 
-template <int G, bool CT, bool STRONG, uint32_t WLOG, bool TAB3 = false>
+template <int G, bool CT, int STRONG, uint32_t WLOG, bool TAB3 = false>
 static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                         uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
     static constexpr uint32_t LT = LzGeo<WLOG, TAB3>::L_TOTAL;
@@ -599,11 +620,12 @@ static void launch_lz_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, 
 // ev_match, if given, is recorded between the two)
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
+    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);
     if (ctab) { if (strong) launch_lz_g<LZ_G_DEFLATE, true, true, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
                 else launch_lz_g<LZ_G_DEFLATE, true, false, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
     else if ((flags & FLAG_TAB3) && (flags & FLAG_W16)) {
-           if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+           if (strong2) launch_lz_g<LZ_G_ZSTD, false, 2, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+           else if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
            else launch_lz_g<LZ_G_ZSTD, false, false, 14, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
     else if ((flags & FLAG_TAB3) && (flags & FLAG_W32)) {
            if (strong) launch_lz_g<LZ_G_ZSTD, false, true, 15, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);

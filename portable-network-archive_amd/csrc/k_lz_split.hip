@@ -26,13 +26,27 @@ namespace pna {
 // The match key of k_lzm: length << 26 | offset << 6 | back << 3 in ONE register (offsets < 2^20, lengths <= 36 + 7, back <= 7), so that an adoption round
 // moves one value per position (one DPP, one select) instead of key and offset: taking over the match of position q + s is + (s << 26) - (s << 3), and
 // "strictly longer" is a compare against the own key with everything below the length set.
+// STRONG = 2 (the high and max zstd sets, round 5: a fourth adoption round over EIGHT positions and up to 15 back bytes): the back count takes four bits, << 2 (PKB).
 constexpr uint32_t PK_LEN = 26, PK_OFF = 6, PK_LOW = (1u << PK_LEN) - 1;
-__device__ __forceinline__ uint32_t pk_make(uint32_t l, uint32_t off, uint32_t bk3) { return (l << PK_LEN) | ((off << PK_OFF) | bk3); }
-template <uint32_t S>
+__host__ __device__ constexpr uint32_t pkb_of(int strong) { return strong == 2 ? 2u : 3u; }
+__device__ __forceinline__ uint32_t pk_make(uint32_t l, uint32_t off, uint32_t bkf) { return (l << PK_LEN) | ((off << PK_OFF) | bkf); }   // bkf: back << PKB
+template <uint32_t S, uint32_t PKB = 3>
 __device__ __forceinline__ uint32_t pk_adopt(uint32_t P, uint32_t Pn) {            // Pn: the key of position q + S
-    const uint32_t T = Pn + ((S << PK_LEN) - (S << 3));
-    const bool a = (Pn & (0x38u & ~((S - 1) << 3))) != 0 && T > (P | PK_LOW);       // back >= S (S = 1, 2, 4: a test of the upper back bits)
+    constexpr uint32_t BM = PKB == 2 ? 0x3Cu : 0x38u;
+    const uint32_t T = Pn + ((S << PK_LEN) - (S << PKB));
+    const bool a = (Pn & (BM & ~((S - 1) << PKB))) != 0 && T > (P | PK_LOW);        // back >= S (S = 1, 2, 4, 8: a test of the upper back bits)
     return a ? T : P;
+}
+#define DPP_ROW_SHL2(v) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x102, 0xF, 0xF, true))   // value of lane i + 2 inside the row of 16 (0 at its end)
+// back << 2 for up to 15 back bytes: x1 .. x4 = position XOR candidate of the four dwords before them, nearest first (the byte right before in x1's top byte); the equal bytes
+// from the top of x1 down, the sixteenth never counted -- the leading zero bits of the 128, the lowest byte of x4 forced to differ (first_diff16 upside down)
+__device__ __forceinline__ uint32_t ffbh_hw(uint32_t x) { uint32_t r; asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x)); return r; }    // 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t back15_field(uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) {
+    const uint32_t f1 = ffbh_hw(x1), f2 = __builtin_elementwise_add_sat(ffbh_hw(x2), 32u), f3 = __builtin_elementwise_add_sat(ffbh_hw(x3), 64u), f4 = ffbh_hw(x4 | 0xFFu) + 96u;
+    uint32_t n, m;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(n) : "v"(f2), "v"(f3), "v"(f4));
+    asm("v_min_u32 %0, %1, %2" : "=v"(m) : "v"(f1), "v"(n));
+    return (m >> 1) & 0x3Cu;
 }
 // GLOG != 0: the hash table of this workgroup lies in GLOBAL memory, 1 << GLOG slots (gtab + blockIdx.x << GLOG): the zstd levels 10 .. 22.  What a
 // 1 MiB segment's match finder can remember is what sets the ratio on text (24 512 slots in LDS 2.70, 2^19 slots 2.96), and LDS
@@ -53,13 +67,15 @@ __device__ __forceinline__ void far_push(const bool (&farj)[4], const uint32_t (
     sq = q0w + 4 * (w & 63u) + ((w >> 6) & 3u); so = w >> 8;
 }
 // the candidate's bytes c - 4 .. c + 32 (STRONG: from c - 8) from the segment in HBM / L2
-template <bool ON, bool STRONG>
-__device__ __forceinline__ void far_load(const uint8_t *seg, uint32_t c, v4u &fa, uint32_t &fb, v4u &fd, uint32_t &fc) {
+template <bool ON, int STRONG>
+__device__ __forceinline__ void far_load(const uint8_t *seg, uint32_t c, v4u &fa, uint32_t &fb, v4u &fd, uint32_t &fc, v2u &fe) {
+    fe = 0;
     if (!ON) { fa = 0; fd = 0; fb = fc = 0; return; }
     const uint8_t *pc = seg + c - 4;
     fa = ld16u(pc); fb = *(const u32u *)(pc + 16); fd = ld16u(pc + 20);
     fc = 0;
     if (STRONG) fc = *(const u32u *)(pc - 4);
+    if (STRONG == 2) __builtin_memcpy(&fe, pc - 12, 8);                            // bytes c - 16 .. c - 9 (a usable candidate lies at 16 or beyond)
 }
 // the owners take their results from the lanes that computed them
 __device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (&idx)[4], uint32_t r0, uint32_t Kf, uint32_t (&K)[4]) {   // K: packed keys (pk_make)
@@ -71,8 +87,8 @@ __device__ __forceinline__ void far_pull(const bool (&farj)[4], const uint32_t (
     }
 }
 // the match step of position q against those bytes: the packed key (pk_make) with the offset so, exactly as for a candidate inside the window
-template <bool STRONG, uint32_t WB>
-__device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q, uint32_t so, v4u fa, uint32_t fb, v4u fd, uint32_t fc, bool edge, uint32_t blk_end) {
+template <int STRONG, uint32_t WB>
+__device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q, uint32_t so, v4u fa, uint32_t fb, v4u fd, uint32_t fc, v2u fe, bool edge, uint32_t blk_end) {
     // the position's bytes q - 8 .. q + 36 from ONE base address (the dword that holds q - 8; what lies behind the window's end is its mirror):
     // pq[0] = q - 8 .., pq[1] = q - 4 .., pq[2 ..] = q ..
     lds_cu32 *pq = lds_word(L_WIN + ((q - 8) & (WB - 4)));
@@ -90,16 +106,21 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
     if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
     const uint32_t xk = EW(0) ^ fa.x;
     uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                      // back << 3
-    if (STRONG && xk == 0) bk3 = 32u + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], pq[0], shq) ^ fc) | 0xFFu) & 24u);
+    if (STRONG == 1 && xk == 0) bk3 = 32u + ((uint32_t)__builtin_clz((__builtin_amdgcn_alignbit(E[0], pq[0], shq) ^ fc) | 0xFFu) & 24u);
+    if (STRONG == 2) {
+        lds_cu32 *pe = lds_word(L_WIN + ((q - 16) & (WB - 4)));                      // the dwords of q - 16 and q - 12 (pq[0] holds q - 8)
+        const uint32_t e0 = pe[0], e1 = pe[1], p0 = pq[0];
+        bk3 = back15_field(xk, __builtin_amdgcn_alignbit(E[0], p0, shq) ^ fc, __builtin_amdgcn_alignbit(p0, e1, shq) ^ fe.y, __builtin_amdgcn_alignbit(e1, e0, shq) ^ fe.x);
+    }
 #undef EW
     return STRONG ? (l >= MIN_MATCH ? pk_make(l, so, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, so, bk3);
 }
 
-template <bool DEFL, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>
+template <bool DEFL, int STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>   // STRONG: 0 = two adoption rounds / 3 back bytes, 1 = + the round over four positions / 7 back bytes, 2 = + the round over eight / 15
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
            uint32_t *__restrict__ gtab) {
-    constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES;
+    constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES, PKB = pkb_of(STRONG), MIN_C = STRONG == 2 ? 16u : 8u;   // MIN_C: a usable candidate lies at this position or beyond (its back bytes exist)
     constexpr bool FAR = !DEFL && FARP;                     // deflate offsets (<= 32 KiB) never leave the LDS window; FARP = false: a zstd launch whose look-back ends with the window (the fast set)
     using GEO = LzGeo<WLOG, TAB3>;                          // (lz_common.h) these names hide the 64 KiB geometry's constants of pna_dev.h
     constexpr uint32_t WIN_BYTES = GEO::WIN, HASH_ENTRIES = GEO::ENTRIES, L_TABLE = GEO::L_TABLE, NW3 = GEO::WORDS3;
@@ -165,13 +186,14 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             const uint32_t q0 = t0 + wave * RW + 4 * lane;
             // ---- the bytes around the lane's positions: D[k] = bytes q0 + 4 k .. + 3, Dm = the 4 (8) before q0.  ONE base address (the dword of q0 - 8): what
             // lies behind the window's end is its mirror (48 bytes: the base + 44)
-            uint32_t D[9], Dm1, Dm2 = 0;
+            uint32_t D[9], Dm1, Dm2 = 0, Dm3 = 0, Dm4 = 0;
             {
                 lds_cu32 *pq = lds_word(L_WIN + ((q0 - 8) & (WIN_BYTES - 1)));
 #pragma unroll
                 for (int k = 0; k < 9; k++) D[k] = pq[k + 2];
                 Dm1 = pq[1];
                 if (STRONG) Dm2 = pq[0];
+                if (STRONG == 2) { lds_cu32 *pe = lds_word(L_WIN + ((q0 - 16) & (WIN_BYTES - 1))); Dm4 = pe[0]; Dm3 = pe[1]; }
             }
 #define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
             // ---- look-up
@@ -211,7 +233,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     const uint32_t dd = ((2u * q0 + 4u * (uint32_t)(j >> 1) - 4u) | tag[j]) - ent[j];
                     const uint32_t r1 = __builtin_amdgcn_alignbit(dd, dd, 2);
                     // (the three compares' lane masks are combined as SCALARS: a ballot of `a & b` makes the compiler build the boolean on the lanes first)
-                    const uint64_t mv = __builtin_amdgcn_ballot_w64(r1 < ((max_off - (uint32_t)(j & 1)) >> 1)) & __builtin_amdgcn_ballot_w64(ent[j] >= 16u);
+                    const uint64_t mv = __builtin_amdgcn_ballot_w64(r1 < ((max_off - (uint32_t)(j & 1)) >> 1)) & __builtin_amdgcn_ballot_w64(ent[j] >= 2u * MIN_C);
                     const uint64_t mn = __builtin_amdgcn_ballot_w64(r1 < ((NEAR - 1u) >> 1));   // (offset <= NEAR - 1 + (j & 1): inside the window)
                     fmj[j] = mv & ~mn;
                     nearj[j] = __builtin_amdgcn_inverse_ballot_w64(mv & mn);
@@ -219,7 +241,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     off[j] = 2u * r1 + 2u + (uint32_t)(j & 1);
                 } else {
                 const uint32_t c1 = ent[j] >> TAG_BITS, o = q0 + j + 1 - c1;
-                off[j] = ((c1 > 8) & ((ent[j] & TAG_MASK) == tag[j]) & (o <= max_off)) ? o : 0u;      // (& not &&: no short-circuit branches)
+                off[j] = ((c1 > MIN_C) & ((ent[j] & TAG_MASK) == tag[j]) & (o <= max_off)) ? o : 0u;  // (& not &&: no short-circuit branches)
                 farj[j] = FAR && off[j] > NEAR;
                 nearj[j] = (off[j] != 0) & !farj[j];
                 }
@@ -247,8 +269,8 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 far_push(farj, idx, 0u, t0 + wave * RW, lane, off, sq, so);
             }
             const bool slot0 = FAR && lane < 63u && lane < npair;
-            v4u ffa, ffd; uint32_t ffb, ffc;
-            far_load<FAR, STRONG>(seg, slot0 ? sq - so : 8u, ffa, ffb, ffd, ffc);
+            v4u ffa, ffd; uint32_t ffb, ffc; v2u ffe;
+            far_load<FAR, STRONG>(seg, slot0 ? sq - so : 16u, ffa, ffb, ffd, ffc, ffe);
             // ---- match: the candidates inside the window.  P[j] = the packed key (pk_make): length, offset, back bytes
             // (Round 4, measured and dropped: the bytes 16 .. 35 compared ONCE per lane and offset in a wave-uniform loop -- a lane's positions inside a long
             // match share the offset, position j's length is position A's less j - A --: bit-exact, and 11 % SLOWER than the four in-place compares below;
@@ -286,7 +308,13 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;       // the 4 bytes before q (q - 1 in the top byte)
                     const uint32_t xk = bqj ^ bc;
                     bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                               // back << 3
-                    if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                    if (STRONG == 1 && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                    if (STRONG == 2) {                                                             // up to 15 back bytes: the dwords of c - 16 and c - 12 from a base of their own (the mirror covers base + 44)
+                        lds_cu32 *pe = lds_word(L_WIN + ((c8 - 8) & (WIN_BYTES - 4)));
+                        const uint32_t e0 = pe[0], e1 = pe[1], p0 = pc[0];
+                        const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2, bq3 = j ? __builtin_amdgcn_alignbyte(Dm2, Dm3, j) : Dm3, bq4 = j ? __builtin_amdgcn_alignbyte(Dm3, Dm4, j) : Dm4;
+                        bk3 = back15_field(xk, bq2 ^ bc2, bq3 ^ __builtin_amdgcn_alignbit(p0, e1, shc), bq4 ^ __builtin_amdgcn_alignbit(e1, e0, shc));      // back << 2
+                    }
                     // (a length below MIN_MATCH counts as 0; the sets with the third adoption round then drop the whole key -- 0 + 1 + 2 + 4 adopted bytes would be a match)
                     Pj = STRONG ? (l >= MIN_MATCH ? pk_make(l, o, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, o, bk3);
                 }
@@ -296,7 +324,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             if (FAR && npair) {
                 {
                     uint32_t Kf = 0;
-                    if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, so, ffa, ffb, ffd, ffc, edge, blk_end);
+                    if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, so, ffa, ffb, ffd, ffc, ffe, edge, blk_end);
                     far_pull(farj, idx, 0u, Kf, P);
                 }
                 if (!(flags & FLAG_FAR1))                                               // (uniform; FLAG_FAR1, the default and light sets since round 5: the pairs beyond the first 63 are dropped -- - 0.16 % of ratio, - 6 % of the kernel's time)
@@ -304,33 +332,40 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     uint32_t sq2, so2, Kf = 0;
                     far_push(farj, idx, r0, t0 + wave * RW, lane, off, sq2, so2);
                     if (lane < 63u && lane < npair - r0) {
-                        v4u ga, gd; uint32_t gb, gc;
-                        far_load<true, STRONG>(seg, sq2 - so2, ga, gb, gd, gc);
-                        Kf = far_match<STRONG, WIN_BYTES>(win32, sq2, so2, ga, gb, gd, gc, edge, blk_end);
+                        v4u ga, gd; uint32_t gb, gc; v2u ge;
+                        far_load<true, STRONG>(seg, sq2 - so2, ga, gb, gd, gc, ge);
+                        Kf = far_match<STRONG, WIN_BYTES>(win32, sq2, so2, ga, gb, gd, gc, ge, edge, blk_end);
                     }
                     far_pull(farj, idx, r0, Kf, P);
                 }
             }
             // ---- backward adoption on the packed keys (the offset goes along inside the key)
             if (adopt) {
+                if (STRONG == 2) {   // the high / max sets (round 5): a round over EIGHT positions first (the model's 0x2148) -- the same position two lanes on, eight bytes longer
+                    uint32_t P8[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) P8[j] = DPP_ROW_SHL2(P[j]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<8, PKB>(P[j], P8[j]);
+                }
                 if (STRONG) {   // the strong sets' round over four positions comes FIRST (round 5: rounds 4, 1, 2 -- the model's 0x214 --: + 0.03 % of ratio for nothing): the same position of the next lane, four bytes longer
                     uint32_t P4[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) P4[j] = DPP_ROW_SHL1(P[j]);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<4>(P[j], P4[j]);
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<4, PKB>(P[j], P4[j]);
                 }
                 {   // the right neighbour's match, one byte longer
                     const uint32_t Pn = DPP_ROW_SHL1(P[0]);
                     const uint32_t P1[4] = {P[1], P[2], P[3], Pn};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<1>(P[j], P1[j]);
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<1, PKB>(P[j], P1[j]);
                 }
                 {   // the match two positions to the right (after the round before), two bytes longer
                     const uint32_t Pa = DPP_ROW_SHL1(P[0]), Pb = DPP_ROW_SHL1(P[1]);
                     const uint32_t P2[4] = {P[2], P[3], Pa, Pb};
 #pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<2>(P[j], P2[j]);
+                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<2, PKB>(P[j], P2[j]);
                 }
             }
             __syncthreads();                                                        // every wave has looked up and matched: the window's oldest chunk is free
@@ -395,10 +430,10 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
 // (seg_min, seg_max] and has LDS for the table and a window of seg_max bytes (dynamic: 12.4 KiB per wave for the first tier, 16.5 .. 24.5 for the second).
 constexpr uint32_t LZMS_PAD = 64;
 __host__ __device__ constexpr uint32_t lzms_lds(uint32_t seg_max) { return SMALL_SLOTS * 4 + LZMS_PAD + ((seg_max + 255u) & ~255u) + 64; }
-template <bool STRONG, bool W3>
+template <int STRONG, bool W3>
 __global__ __launch_bounds__(64)
 void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t *__restrict__ pbuf, uint32_t blk0, uint32_t seg_min, uint32_t seg_max) {
-    constexpr uint32_t RW = 256, PAD = LZMS_PAD, SLOTS = SMALL_SLOTS;
+    constexpr uint32_t RW = 256, PAD = LZMS_PAD, SLOTS = SMALL_SLOTS, PKB = pkb_of(STRONG), MIN_C = STRONG == 2 ? 16u : 8u;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *table = (uint32_t *)lds;
     uint8_t *winb = lds + SLOTS * 4;                            // 64 bytes in front of the segment (read, never used), the segment, zeros behind it
@@ -423,13 +458,14 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
         const uint32_t q0 = t0 + 4 * lane;
         // (as in k_lzm: ONE base address per run of words -- the dword of q0 - 8 / c - 8, in front of the segment lie PAD bytes --, words by LDS byte address, packed keys)
         constexpr uint32_t WB8 = SLOTS * 4 + PAD - 8;                              // LDS byte address of the segment's byte -8
-        uint32_t D[9], Dm1, Dm2 = 0;
+        uint32_t D[9], Dm1, Dm2 = 0, Dm3 = 0, Dm4 = 0;
         {
             lds_cu32 *pq = lds_word(WB8 + q0);
 #pragma unroll
             for (int k = 0; k < 9; k++) D[k] = pq[k + 2];
             Dm1 = pq[1];
             if (STRONG) Dm2 = pq[0];
+            if (STRONG == 2) { lds_cu32 *pe = lds_word(WB8 - 8 + q0); Dm4 = pe[0]; Dm3 = pe[1]; }      // (PAD = 64 bytes lie in front of the segment)
         }
 #define QW(k, j) ((j) ? __builtin_amdgcn_alignbyte(D[(k) + 1], D[k], (j)) : D[k])          /* 4 bytes at position j, + 4 k */
         uint32_t hsh[4], tag[4], off[4], P[4];
@@ -443,7 +479,7 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
             tag[j] = (h32 >> 6) & TAG_MASK;
             const uint32_t e = table[hsh[j]], ent = hv[j] ? e : 0u;
             const uint32_t c1 = ent >> TAG_BITS;
-            off[j] = ((c1 > 8) & ((ent & TAG_MASK) == tag[j])) ? q + 1 - c1 : 0u;
+            off[j] = ((c1 > MIN_C) & ((ent & TAG_MASK) == tag[j])) ? q + 1 - c1 : 0u;
         }
         const bool edge = blk_end - t0 < RW + CAP1;                                 // (uniform) only a block's last sub-tiles can run into its end
 #pragma unroll
@@ -473,30 +509,43 @@ void k_lzms(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, u
                 const uint32_t bqj = j ? __builtin_amdgcn_alignbyte(D[0], Dm1, j) : Dm1;           // the 4 bytes before q (q - 1 in the top byte)
                 const uint32_t xk = bqj ^ bc;
                 uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                          // back << 3
-                if (STRONG && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                if (STRONG == 1 && xk == 0) { const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2; bk3 = 32u + ((uint32_t)__builtin_clz((bq2 ^ bc2) | 0xFFu) & 24u); }
+                if (STRONG == 2) {                                                                 // up to 15 back bytes (k_lzm)
+                    lds_cu32 *pe = lds_word(WB8 + 8 + ((c8 - 8) & ~3u));                              // the dword of c - 16 (c >= 16)
+                    const uint32_t e0 = pe[0], e1 = pe[1], p0 = pc[0];
+                    const uint32_t bq2 = j ? __builtin_amdgcn_alignbyte(Dm1, Dm2, j) : Dm2, bq3 = j ? __builtin_amdgcn_alignbyte(Dm2, Dm3, j) : Dm3, bq4 = j ? __builtin_amdgcn_alignbyte(Dm3, Dm4, j) : Dm4;
+                    bk3 = back15_field(xk, bq2 ^ bc2, bq3 ^ __builtin_amdgcn_alignbit(p0, e1, shc), bq4 ^ __builtin_amdgcn_alignbit(e1, e0, shc));          // back << 2
+                }
                 Pj = STRONG ? (l >= MIN_MATCH ? pk_make(l, o, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, o, bk3);
             }
             P[j] = Pj;
         }
-        if (adopt) {        // backward adoption, the rounds of k_lzm (strong sets: 4, 1, 2)
+        if (adopt) {        // backward adoption, the rounds of k_lzm (strong sets: 4, 1, 2; the high / max sets: 8, 4, 1, 2)
+            if (STRONG == 2) {
+                uint32_t P8[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) P8[j] = DPP_ROW_SHL2(P[j]);
+#pragma unroll
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<8, PKB>(P[j], P8[j]);
+            }
             if (STRONG) {
                 uint32_t P4[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) P4[j] = DPP_ROW_SHL1(P[j]);
 #pragma unroll
-                for (int j = 0; j < 4; j++) P[j] = pk_adopt<4>(P[j], P4[j]);
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<4, PKB>(P[j], P4[j]);
             }
             {
                 const uint32_t Pn = DPP_ROW_SHL1(P[0]);
                 const uint32_t P1[4] = {P[1], P[2], P[3], Pn};
 #pragma unroll
-                for (int j = 0; j < 4; j++) P[j] = pk_adopt<1>(P[j], P1[j]);
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<1, PKB>(P[j], P1[j]);
             }
             {
                 const uint32_t Pa = DPP_ROW_SHL1(P[0]), Pb = DPP_ROW_SHL1(P[1]);
                 const uint32_t P2[4] = {P[2], P[3], Pa, Pb};
 #pragma unroll
-                for (int j = 0; j < 4; j++) P[j] = pk_adopt<2>(P[j], P2[j]);
+                for (int j = 0; j < 4; j++) P[j] = pk_adopt<2, PKB>(P[j], P2[j]);
             }
         }
         if (q0 < t1) {
@@ -923,7 +972,7 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     }
 }
 
-template <bool CT, bool STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT, bool TAB3 = false>
+template <bool CT, int STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP = !CT, bool TAB3 = false>
 static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                            uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
     constexpr uint32_t LT = GLOG ? LzGeo<WLOG>::L_TABLE : LzGeo<WLOG, TAB3>::L_TOTAL;
@@ -945,12 +994,14 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
 // gtab != nullptr (zstd, strong set): the match kernel's hash tables in global memory, nseg << GTAB_LOG words
 void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                      uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
+    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);     // (FLAG_STRONG2: only with the global table or the packed 16 KiB geometry)
     if (ctab) { if (strong) launch_split_g<true, true, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
                 else launch_split_g<true, false, 0, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
-    else if (strong && gtab) launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+    else if (strong && gtab) { if (strong2) launch_split_g<false, 2, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg);
+                               else launch_split_g<false, true, GTAB_LOG, 16>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, gtab, pg); }
     else if ((flags & FLAG_TAB3) && (flags & FLAG_W16)) {
-           if (strong) launch_split_g<false, true, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           if (strong2) launch_split_g<false, 2, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
+           else if (strong) launch_split_g<false, true, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
            else launch_split_g<false, false, 0, 14, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg); }
     else if ((flags & FLAG_TAB3) && (flags & FLAG_W32)) {
            if (strong) launch_split_g<false, true, 0, 15, true, true>(src, segs, nseg, seqs, lits, blk, ctab, flags, max_off, max_len, st, pbuf, blk0, ev_match, nullptr, pg);
@@ -969,12 +1020,13 @@ void launch_lz_split(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
 // three bytes (the caller's choice: every launch but the zstd levels with the table in global memory takes them, as in the split form).
 void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                      uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, const LzParseGrid *pg, bool w3) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT);
+    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);
 #define LZMS(ST_, W3_) do { \
         if (flags & FLAG_TIER1) hipLaunchKernelGGL((k_lzms<ST_, W3_>), dim3(nseg), dim3(64), lzms_lds(SMALL_SEG), st, src, segs, flags, pbuf, blk0, 0u, SMALL_SEG); \
         if (flags & FLAG_TIER2) { const uint32_t mx = 8192u + 4096u * ((flags >> FLAG_T2_SHIFT) & 3u); \
                                   hipLaunchKernelGGL((k_lzms<ST_, W3_>), dim3(nseg), dim3(64), lzms_lds(mx), st, src, segs, flags, pbuf, blk0, SMALL_SEG, mx); } } while (0)
-    if (strong) { if (w3) LZMS(true, true); else LZMS(true, false); }
+    if (strong2) { if (w3) LZMS(2, true); else LZMS(2, false); }
+    else if (strong) { if (w3) LZMS(true, true); else LZMS(true, false); }
     else { if (w3) LZMS(false, true); else LZMS(false, false); }
 #undef LZMS
     if (!pg || pg->nb == 0) return;

@@ -120,6 +120,7 @@ typedef uint32_t u32u __attribute__((aligned(1)));
 // 16 bytes at any byte address as ONE register tuple: the load writes it in place (the components of the struct above get moved behind the load,
 // which puts a wait for the load right there)
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) W12 { uint32_t x, y, z; };   // four 3-byte words = 12 bytes at a dword-aligned address (a 3-element vector type would be 16 bytes wide)
 __device__ __forceinline__ v4u ld16u(const uint8_t *p) { v4u v; __builtin_memcpy(&v, p, 16); return v; }
 

@@ -11,7 +11,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"strong2", "PNA_STRONG2", &Tuning::strong2, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 extern "C" const char *pna_gpu_strerror(int code) {
@@ -158,6 +158,7 @@ void set_call_level(pna_gpu_ctx *c, int algo, int level) {
     c->call_w16 = c->call_w32 && (c->tun.win32k >= 2 || pna_gpu_clamp_level(algo, level) >= 6);          // the high set's geometry (round 4: chosen by the level, no longer by F_STRONG)
     c->call_stored = !zstd && pna_gpu_clamp_level(algo, level) == 0;
     c->call_tab3 = c->call_w32 && (c->call_flags & F_INS2) && (c->call_flags & F_ADOPT) && c->tun.tab3 != 0;
+    c->call_strong2 = zstd && pna_gpu_clamp_level(algo, level) >= 6 && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong2 != 0 && (c->call_gtab || (c->call_tab3 && c->call_w16));
     c->call_lazy2 = (c->call_flags & F_LAZY) && (c->tun.lazy2 != 0 || (c->call_flags & F_STRONG));   // every lazy set defers over two positions (the high sets always did)
     c->call_lazy3 = c->call_lazy2 && c->tun.lazy2 >= 2;                                               // ... and over three (option lazy2 = 2, the default)
 }
@@ -747,7 +748,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         for (int k = 0; k < nch; k++) {
             const uint32_t s0 = (uint32_t)((uint64_t)nseg * k / nch), s1 = (uint32_t)((uint64_t)nseg * (k + 1) / nch);
             const uint32_t g0 = segs[s0].blk_base, g1 = s1 < nseg ? segs[s1].blk_base : nblk;
-            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? (c->call_w16 ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36) | (c->call_tab3 ? FLAG_TAB3 : 0u) | ((c->call_tab3 && !c->call_w16 && c->tun.far1) ? FLAG_FAR1 : 0u) | small_fl;
+            const uint32_t zfl = (c->call_flags & 0x3FFu) | (c->call_w32 ? (c->call_w16 ? FLAG_W16 : FLAG_W32) : 0u) | (c->call_lazy2 ? FLAG_LAZY2 : 0u) | (c->call_lazy3 ? FLAG_LAZY3 : 0u) | (c->call_gtab ? 0u : FLAG_LEN36) | (c->call_tab3 ? FLAG_TAB3 : 0u) | ((c->call_tab3 && !c->call_w16 && c->tun.far1) ? FLAG_FAR1 : 0u) | (c->call_strong2 ? FLAG_STRONG2 : 0u) | small_fl;
             const uint32_t zmax = (c->call_flags & F_FAR) ? (c->call_gtab ? MAX_OFF : MAX_OFF_W3) : NEAR_OFF;   // (3-byte words keep 19 bits of offset)
             if (unit_mode) {
                 // (nch == 1: one launch over all units; the strong set: split form over the units, tables in global memory)

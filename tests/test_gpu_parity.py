@@ -340,6 +340,31 @@ def test_far_candidates_beyond_one_round_are_dropped(pna, codec, form):
     assert size[(0, 3)] < size[(1, 3)] < size[(0, 3)] * 1.01 and size[(0, 7)] == size[(1, 7)]
 
 
+@pytest.mark.parametrize("form", ["split", "one-kernel"])
+def test_high_sets_adopt_over_eight_positions(pna, codec, form):
+    """FLAG_STRONG2 (option strong2, default 1): zstd levels 6 .. 22 on their standard geometries (the packed 16 KiB-window table; the table in global memory) run a fourth
+    adoption round over eight positions, first, and count up to 15 back bytes (model: rounds 0x2148, back_cap 15; a usable candidate lies at position 16 or beyond).
+    Both forms of the LZ stage, short segments (the small geometry) included, equal the model; the option off gives the default set's three rounds; more rounds compress better."""
+    import torch  # noqa: F401
+    ents = [codec.corpus_file(0, 2, (1 << 20) + 77), codec.corpus_file(0, 5, 1500000), codec.corpus_file(1, 3, 400000), codec.corpus_file(0, 8, 131072 + 4096 + 100),
+            codec.corpus_file(0, 9, 3000), codec.corpus_file(0, 10, 9000), b"ab" * 40, b"", (b"0123456789abcdefXYZ" * 3000)[:50000]]
+    size = {}
+    with pna.Context(0) as ctx:
+        ctx.set_option("latency_max_mib", 0)
+        ctx.set_option("lz_split_min", 0 if form == "split" else 1 << 20)
+        for s2 in (1, 0):
+            ctx.set_option("strong2", s2)
+            for lvl in (7, 12, 3):
+                outs = ctx.compress_batch(ents, level=lvl)
+                p = codec.params_for_level(lvl, strong2=s2)
+                assert (p.rounds, p.back_cap) == ((0x2148, 15) if (s2 and lvl >= 6) else (0x214, 7))
+                for e, o in zip(ents, outs):
+                    assert o == codec.model_compress(e, p), (s2, lvl, len(e))
+                    assert codec.zstd_decompress(o, len(e)) == e
+                size[(s2, lvl)] = sum(map(len, outs))
+    assert size[(1, 7)] < size[(0, 7)] and size[(1, 12)] < size[(0, 12)] and size[(1, 3)] == size[(0, 3)]
+
+
 def test_lz_stage_equals_model(gpu_ctx, codec):
     d = codec.corpus_file(0, 31, 700000)
     gpu_ctx.compress_batch([d])
@@ -1335,8 +1360,8 @@ def test_device_decoder_reads_libzstd_frames_of_many_levels(gpu_ctx, pna, codec)
 def test_levels_select_the_parse(gpu_ctx, pna, codec):
     """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto parameter sets -- fast (greedy,
     LDS-window look-back, every position in the table), balanced (deflate only: + even-position table, backward adoption), default
-    (+ 1 MiB look-back, lazy deferral over three positions; zstd: the match finder's 32 KiB-window geometry with 32 704 table slots), high (+ third
-    adoption round; zstd: 16 KiB window, 36 800 slots) and, zstd only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact
+    (+ 1 MiB look-back, lazy deferral over three positions; zstd: the match finder's 32 KiB-window geometry with the packed table of 49 062 slots, a third
+    adoption round), high (zstd 6 .. 9: 16 KiB window, 55 206 slots, a fourth adoption round over eight positions and 15 back bytes) and, zstd only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact
     with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
@@ -1348,7 +1373,8 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         assert codec.product_level_flags(level) == (fl, bool(gtab)), level
         pz = codec.params_for_level(level)
-        assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else 0x214 if fl == strong else 0x21), level
+        high = level != pna.LEVEL_DEFAULT and level >= 6                  # zstd 6 .. 22: a fourth adoption round over eight positions, 15 back bytes (FLAG_STRONG2)
+        assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else (0x2148 if high else 0x214) if fl == strong else 0x21) and pz.back_cap == (0 if fl == fast else 15 if high else 7 if fl == strong else 3), level
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
     assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1] and sizes[0] == sizes[3] == sizes[pna.LEVEL_DEFAULT]
