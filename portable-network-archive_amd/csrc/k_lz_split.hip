@@ -116,10 +116,7 @@ __device__ __forceinline__ uint32_t far_match(const uint32_t *win32, uint32_t q,
     return STRONG ? (l >= MIN_MATCH ? pk_make(l, so, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, so, bk3);
 }
 
-// FAD (round 5, the split form's second shape; option lz_fad, OFF by default -- LAB_LOG.md 5.7 has the measurements): this kernel stops behind the window's candidates -- no far
-// candidates, no adoption, no words -- and hands one KEY per position (pk_make; a far candidate as offset << 6 | 1) to k_fad below, an LDS-free kernel meant to run next to the following
-// run's k_lzm.  Same words; 29 % less time in this kernel, but k_fad costs four times what the far path costs in here, and its waves keep this kernel's workgroups off the CUs.
-template <bool DEFL, int STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3, bool FAD = false>   // STRONG: 0 = two adoption rounds / 3 back bytes, 1 = + the round over four positions / 7 back bytes, 2 = + the round over eight / 15
+template <bool DEFL, int STRONG, uint32_t GLOG, uint32_t WLOG, bool FARP, bool TAB3>   // STRONG: 0 = two adoption rounds / 3 back bytes, 1 = + the round over four positions / 7 back bytes, 2 = + the round over eight / 15
 __global__ __launch_bounds__(LZ_THREADS)
 void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, uint32_t max_off, uint32_t *__restrict__ pbuf, uint32_t blk0,
            uint32_t *__restrict__ gtab) {
@@ -136,8 +133,6 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     static_assert(NEAR == GEO::NEARM, "lz_common.h: the one-kernel form numbers this kernel's far candidates (FLAG_FAR1)");
     static_assert(WIN_BYTES >= TILE_G + LA + NEAR + 8 + 200 && (!DEFL || NEAR >= 32768), "window: look-back (+ 8 back bytes) + this tile + look-ahead");
     static_assert(!TAB3 || (GLOG == 0 && !DEFL && FAR), "the packed table: zstd sets with the table in LDS and far candidates");
-    static_assert(!FAD || TAB3, "the two-kernel match half: the packed-table sets");
-    constexpr bool FARH = FAR && !FAD;                       // the far candidates are verified HERE
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && WIN_MIRROR >= 40, "k_lzm: four positions per lane, 36 bytes read behind a lane's first position");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *win32 = (uint32_t *)(lds + L_WIN);
@@ -154,7 +149,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
     // The words: one per position, length | offset.  With the table in LDS (GLOG = 0) they take THREE bytes -- 5 bits for the length (0, or length - 5
     // for 6 .. 36: adopted lengths beyond 36 are clamped, FLAG_LEN36 tells the one-kernel form to do the same) and 19 for the offset (MAX_OFF_W3) --:
     // the parse kernel's time is the time to stream them (42 GB per step at 4 bytes).  With the table in global memory: 4 bytes, 6 + 20 bits.
-    constexpr bool W3 = GLOG == 0 && !FAD;                  // (FAD: four-byte keys)
+    constexpr bool W3 = GLOG == 0;
     uint32_t *pb = pbuf + ((size_t)(sd.blk_base - blk0) << blk_log);
     uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
     const bool adopt = (flags & F_ADOPT) != 0, ins_all = !(flags & F_INS2);
@@ -261,7 +256,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             // (The first round's loads are issued whether the wave holds a far pair or not -- nearly every wave does --, lanes without a pair reading the
             // segment's first bytes: a load under a branch makes the compiler copy the loaded tuple behind the branch, with a wait for it right there.)
             uint32_t idx[4] = {0, 0, 0, 0}, npair = 0, sq = 0, so = 0;
-            if (FARH) {
+            if (FAR) {
                 uint64_t fm[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) fm[j] = TAB3 ? fmj[j] : __builtin_amdgcn_ballot_w64(farj[j]);
@@ -273,9 +268,9 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 npair = uni(npair);
                 far_push(farj, idx, 0u, t0 + wave * RW, lane, off, sq, so);
             }
-            const bool slot0 = FARH && lane < 63u && lane < npair;
+            const bool slot0 = FAR && lane < 63u && lane < npair;
             v4u ffa, ffd; uint32_t ffb, ffc; v2u ffe;
-            far_load<FARH, STRONG>(seg, slot0 ? sq - so : 16u, ffa, ffb, ffd, ffc, ffe);
+            far_load<FAR, STRONG>(seg, slot0 ? sq - so : 16u, ffa, ffb, ffd, ffc, ffe);
             // ---- match: the candidates inside the window.  P[j] = the packed key (pk_make): length, offset, back bytes
             // (Round 4, measured and dropped: the bytes 16 .. 35 compared ONCE per lane and offset in a wave-uniform loop -- a lane's positions inside a long
             // match share the offset, position j's length is position A's less j - A --: bit-exact, and 11 % SLOWER than the four in-place compares below;
@@ -326,7 +321,7 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                 P[j] = Pj;
             }
             // ---- the far pairs' match step (first round: the bytes requested above have had the near candidates' match step to arrive)
-            if (FARH && npair) {
+            if (FAR && npair) {
                 {
                     uint32_t Kf = 0;
                     if (slot0) Kf = far_match<STRONG, WIN_BYTES>(win32, sq, so, ffa, ffb, ffd, ffc, ffe, edge, blk_end);
@@ -344,12 +339,8 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     far_pull(farj, idx, r0, Kf, P);
                 }
             }
-            if (FAD) {                                              // the far candidates go on as they are: offset << 6 | 1 (a near key's low bits are 0)
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (farj[j]) P[j] = (off[j] << PK_OFF) | 1u;
-            }
             // ---- backward adoption on the packed keys (the offset goes along inside the key)
-            if (adopt && !FAD) {
+            if (adopt) {
                 if (STRONG == 2) {   // the high / max sets (round 5): a round over EIGHT positions first (the model's 0x2148) -- the same position two lanes on, eight bytes longer
                     uint32_t P8[4];
 #pragma unroll
@@ -411,8 +402,6 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);   // bytes 1 2 of word 1, bytes 0 1 of word 2
                     __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);   // byte 2 of word 2, bytes 0 1 2 of word 3
                 }
-            } else if (FAD) {
-                if (FULL || q0 < t1) { v4u kv; kv.x = P[0]; kv.y = P[1]; kv.z = P[2]; kv.w = P[3]; __builtin_nontemporal_store(kv, (v4u *)(pb + q0)); }
             } else if (FULL || q0 < t1) {
                 v4u wv;
                 wv.x = (P[0] >> PK_LEN) | (P[0] & (0xFFFFFu << PK_OFF)); wv.y = (P[1] >> PK_LEN) | (P[1] & (0xFFFFFu << PK_OFF));
@@ -426,142 +415,6 @@ void k_lzm(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, ui
             __syncthreads();                                                        // inserts + window chunk in place
             };
             if (tile_full && !(TAB3 && t0 == 0)) tile_body(std::true_type{}); else tile_body(std::false_type{});
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_fad -- the far candidates and the backward adoption of the split form's second shape (k_lzm<FAD>): ONE WAVE per segment and wave region (the 256 positions
-// 256 w .. of every tile, four per lane: exactly the positions of k_lzm's wave w), NO LDS -- its workgroups fit next to k_lzm's, which fill a CU's LDS with four waves
-// per SIMD and leave half of the SIMD's issue slots idle.  Per tile: the four keys of the lane (k_lzm<FAD>), the far pairs numbered and compacted as in k_lzm (ballot,
-// mbcnt, ds_permute -- the crossbar, no LDS memory), candidate AND position bytes from the segment in memory (unaligned 16-byte loads: no alignment code), the same
-// match step, the owners pull the keys, the adoption rounds, the tile's words.  Same words as k_lzm without FAD (tests: both shapes against the model).
-template <bool G>   // bytes [pos, pos + 16) of the segment; G: every byte guarded (zero outside [0, seg_len): what the match kernel's LDS window holds there)
-__device__ __forceinline__ v4u fad_ld16(const uint8_t *seg, uint32_t pos, uint32_t seg_len) {
-    if (!G) return ld16u(seg + pos);
-    if (pos + 16 <= seg_len) return ld16u(seg + pos);
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < 16; k++) if (pos + k < seg_len) w[k >> 2] |= (uint32_t)seg[pos + k] << (8 * (k & 3));
-    v4u v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3]; return v;
-}
-template <bool G>
-__device__ __forceinline__ uint32_t fad_ld4(const uint8_t *seg, uint32_t pos, uint32_t seg_len) {
-    if (!G || pos + 4 <= seg_len) return *(const u32u *)(seg + pos);
-    uint32_t w = 0;
-    for (uint32_t k = 0; k < 4; k++) if (pos + k < seg_len) w |= (uint32_t)seg[pos + k] << (8 * k);
-    return w;
-}
-// the match step of position q (>= 16) against the candidate's bytes (far_load), the position's bytes from memory: the packed key as far_match gives it
-template <int STRONG, bool G>
-__device__ __forceinline__ uint32_t fad_match(const uint8_t *seg, uint32_t seg_len, uint32_t q, uint32_t so, v4u fa, uint32_t fb, v4u fd, uint32_t fc, v2u fe, bool edge, uint32_t blk_end) {
-    const v4u qa = fad_ld16<G>(seg, q - 4, seg_len);                               // q - 4 .. q + 11
-    const uint32_t qb = fad_ld4<G>(seg, q + 12, seg_len);
-    const v4u qd = fad_ld16<G>(seg, q + 16, seg_len);                              // q + 16 .. q + 31
-    uint32_t l = first_diff16(qa.y ^ fa.y, qa.z ^ fa.z, qa.w ^ fa.w, qb ^ fb);
-    if (l == 16) l = 16 + first_diff16(qd.x ^ fd.x, qd.y ^ fd.y, qd.z ^ fd.z, qd.w ^ fd.w);
-    if (edge) { const uint32_t lim = blk_end - q; l = l < lim ? l : lim; }
-    const uint32_t xk = qa.x ^ fa.x;
-    uint32_t bk3 = (uint32_t)__builtin_clz(xk | 0xFFu) & 24u;                      // back << 3
-    if (STRONG == 1 && xk == 0) bk3 = 32u + ((uint32_t)__builtin_clz((*(const u32u *)(seg + q - 8) ^ fc) | 0xFFu) & 24u);
-    if (STRONG == 2) {
-        v2u qe; __builtin_memcpy(&qe, seg + q - 16, 8);
-        bk3 = back15_field(xk, *(const u32u *)(seg + q - 8) ^ fc, qe.y ^ fe.y, qe.x ^ fe.x);                // back << 2
-    }
-    return STRONG ? (l >= MIN_MATCH ? pk_make(l, so, bk3) : 0u) : pk_make(l >= MIN_MATCH ? l : 0u, so, bk3);
-}
-template <int STRONG>
-__global__ __launch_bounds__(64)
-void k_fad(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uint32_t flags, const uint32_t *__restrict__ kbuf, uint32_t kblk0, uint32_t *__restrict__ pbuf, uint32_t blk0) {
-    constexpr uint32_t RW = 256, TILE_G = RW * LZ_WAVES, PKB = pkb_of(STRONG);
-    const uint32_t lane = threadIdx.x, wave = blockIdx.x & (LZ_WAVES - 1);
-    const SegDesc sd = segs[blockIdx.x / LZ_WAVES];
-    const uint8_t *seg = src + sd.src_off;
-    const uint32_t seg_len = sd.len;
-    if ((flags & FLAG_HAS_SMALL) && seg_len <= MID_SEG) return;       // (uniform) a short segment: k_lzms's
-    const uint32_t blk_log = sd.blk_log, bsz = 1u << blk_log;
-    const uint32_t *kb = kbuf + ((size_t)(sd.blk_base - kblk0) << blk_log);
-    uint8_t *pb8 = (uint8_t *)pbuf + 3 * ((size_t)(sd.blk_base - blk0) << blk_log);
-    const bool adopt = (flags & F_ADOPT) != 0;
-    for (uint32_t blk_start = sd.u0; blk_start < sd.u1; blk_start += bsz) {
-        const uint32_t blk_end = (seg_len - blk_start < bsz) ? seg_len : blk_start + bsz;
-        for (uint32_t t0 = blk_start; t0 < blk_end; t0 += TILE_G) {
-            const uint32_t t1 = (blk_end - t0 < TILE_G) ? blk_end : t0 + TILE_G;
-            if (t0 + wave * RW >= t1) continue;                                         // (uniform) the region lies behind the block's end
-            // (as in k_lzm) FULL: every position of the tile inside the block, the match step's bytes inside the segment
-            const bool tile_full = (t1 - t0 == TILE_G) && (t0 + TILE_G + 8 <= seg_len) && (blk_end - t0 >= TILE_G + CAP1) && t0 != 0;
-            auto tile_body = [&](auto full_t) __attribute__((always_inline)) {
-            constexpr bool FULL = decltype(full_t)::value;
-            const uint32_t q0 = t0 + wave * RW + 4 * lane;
-            uint32_t P[4] = {0, 0, 0, 0}, off[4];
-            bool farj[4];
-            if (FULL || q0 < t1) { const v4u kv = __builtin_nontemporal_load((const v4u *)(kb + q0)); P[0] = kv.x; P[1] = kv.y; P[2] = kv.z; P[3] = kv.w; }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { farj[j] = (P[j] & 1u) != 0; off[j] = (P[j] >> PK_OFF) & 0xFFFFFu; if (farj[j]) P[j] = 0; }
-            // ---- the far pairs, numbered and compacted as in k_lzm (j-major; FLAG_FAR1: one round, the pairs beyond 63 are dropped)
-            uint32_t idx[4], npair = 0, sq, so;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint64_t fm = __builtin_amdgcn_ballot_w64(farj[j]);
-                idx[j] = npair + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                npair += (uint32_t)__builtin_popcountll(fm);
-            }
-            npair = uni(npair);
-            const bool edge = !FULL && blk_end - (t0 + wave * RW) < RW + CAP1;          // (uniform) only the block's last waves can run into its end
-            for (uint32_t r0 = 0; r0 < npair; r0 += 63) {
-                if (r0 && (flags & FLAG_FAR1)) break;
-                far_push(farj, idx, r0, t0 + wave * RW, lane, off, sq, so);
-                uint32_t Kf = 0;
-                if (lane < 63u && lane < npair - r0) {
-                    v4u fa, fd; uint32_t fb, fc; v2u fe;
-                    far_load<true, STRONG>(seg, sq - so, fa, fb, fd, fc, fe);
-                    Kf = fad_match<STRONG, !FULL>(seg, seg_len, sq, so, fa, fb, fd, fc, fe, edge, blk_end);
-                }
-                far_pull(farj, idx, r0, Kf, P);
-            }
-            // ---- backward adoption on the packed keys (k_lzm)
-            if (adopt) {
-                if (STRONG == 2) {
-                    uint32_t P8[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P8[j] = DPP_ROW_SHL2(P[j]);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<8, PKB>(P[j], P8[j]);
-                }
-                if (STRONG) {
-                    uint32_t P4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P4[j] = DPP_ROW_SHL1(P[j]);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<4, PKB>(P[j], P4[j]);
-                }
-                {
-                    const uint32_t Pn = DPP_ROW_SHL1(P[0]);
-                    const uint32_t P1[4] = {P[1], P[2], P[3], Pn};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<1, PKB>(P[j], P1[j]);
-                }
-                {
-                    const uint32_t Pa = DPP_ROW_SHL1(P[0]), Pb = DPP_ROW_SHL1(P[1]);
-                    const uint32_t P2[4] = {P[2], P[3], Pa, Pb};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) P[j] = pk_adopt<2, PKB>(P[j], P2[j]);
-                }
-            }
-            // ---- the words (three bytes each: k_lzm)
-            if (FULL || q0 < t1) {
-                uint32_t ww[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t l = P[j] >> PK_LEN, lc = l < 5u ? 5u : (l > 36u ? 36u : l);
-                    ww[j] = (lc - 5u) | ((P[j] >> (PK_OFF - 5)) & (0xFFFFFu << 5));
-                }
-                W12 *o = (W12 *)(pb8 + 3 * (size_t)q0);
-                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[1], ww[0], 0x04020100u), &o->x);
-                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[2], ww[1], 0x05040201u), &o->y);
-                __builtin_nontemporal_store(__builtin_amdgcn_perm(ww[3], ww[2], 0x06050402u), &o->z);
-            }
-            };
-            if (tile_full) tile_body(std::true_type{}); else tile_body(std::false_type{});
         }
     }
 }
@@ -1183,45 +1036,6 @@ void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
     if (ctab) { if (flags & FLAG_LAZY3) LZP_SMALL(true, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(true, 2); else LZP_SMALL(true, 1); }
     else { if (flags & FLAG_LAZY3) LZP_SMALL(false, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(false, 2); else LZP_SMALL(false, 1); }
 #undef LZP_SMALL
-}
-// ---- the split form's second shape (k_lzm<FAD> -> keys -> k_fad -> words -> k_lzp); the packed-table zstd sets only
-template <int STRONG, uint32_t WLOG>
-static void launch_lzm_keys_g(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint32_t flags, uint32_t max_off, hipStream_t st, uint32_t *kbuf, uint32_t kblk0) {
-    constexpr uint32_t LT = LzGeo<WLOG, true>::L_TOTAL;
-    static const hipError_t attr_set = hipFuncSetAttribute((const void *)k_lzm<false, STRONG, 0, WLOG, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LT);   // once per process, thread-safe
-    (void)attr_set;
-    hipLaunchKernelGGL((k_lzm<false, STRONG, 0, WLOG, true, true, true>), dim3(nseg), dim3(LZ_THREADS), LT, st, src, segs, flags, max_off, kbuf, kblk0, (uint32_t *)nullptr);
-}
-// the match kernel without far candidates and adoption over `nseg` segments: one key per position into kbuf (4 bytes per position of the run's blocks, kblk0 = the first of them)
-void launch_lzm_keys(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint32_t flags, uint32_t max_off, hipStream_t st, uint32_t *kbuf, uint32_t kblk0) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);
-    if (flags & FLAG_W16) { if (strong2) launch_lzm_keys_g<2, 14>(src, segs, nseg, flags, max_off, st, kbuf, kblk0);
-                            else if (strong) launch_lzm_keys_g<1, 14>(src, segs, nseg, flags, max_off, st, kbuf, kblk0);
-                            else launch_lzm_keys_g<0, 14>(src, segs, nseg, flags, max_off, st, kbuf, kblk0); }
-    else { if (strong) launch_lzm_keys_g<1, 15>(src, segs, nseg, flags, max_off, st, kbuf, kblk0);
-           else launch_lzm_keys_g<0, 15>(src, segs, nseg, flags, max_off, st, kbuf, kblk0); }
-}
-// far candidates + adoption + words of the same segments (LDS-free: meant to run on another stream next to the following run's match kernel)
-void launch_fad(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint32_t flags, hipStream_t st, const uint32_t *kbuf, uint32_t kblk0, uint32_t *pbuf, uint32_t blk0) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);
-    if (strong2) hipLaunchKernelGGL((k_fad<2>), dim3(nseg * LZ_WAVES), dim3(64), 0, st, src, segs, flags, kbuf, kblk0, pbuf, blk0);
-    else if (strong) hipLaunchKernelGGL((k_fad<1>), dim3(nseg * LZ_WAVES), dim3(64), 0, st, src, segs, flags, kbuf, kblk0, pbuf, blk0);
-    else hipLaunchKernelGGL((k_fad<0>), dim3(nseg * LZ_WAVES), dim3(64), 0, st, src, segs, flags, kbuf, kblk0, pbuf, blk0);
-}
-// the short segments' match kernels (words straight into pbuf) and the parse kernel over the blocks of pg: what launch_lz_split does behind its match kernel
-void launch_lzp_words(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf,
-                      uint32_t blk0, const LzParseGrid *pg) {
-    const bool strong = (flags & F_STRONG) && (flags & F_ADOPT), strong2 = strong && (flags & FLAG_STRONG2);
-#define LZMS3(ST_) do { \
-        if (flags & FLAG_TIER1) hipLaunchKernelGGL((k_lzms<ST_, true>), dim3(nseg), dim3(64), lzms_lds(SMALL_SEG), st, src, segs, flags, pbuf, blk0, 0u, SMALL_SEG); \
-        if (flags & FLAG_TIER2) { const uint32_t mx = 8192u + 4096u * ((flags >> FLAG_T2_SHIFT) & 3u); \
-                                  hipLaunchKernelGGL((k_lzms<ST_, true>), dim3(nseg), dim3(64), lzms_lds(mx), st, src, segs, flags, pbuf, blk0, SMALL_SEG, mx); } } while (0)
-    if (strong2) LZMS3(2); else if (strong) LZMS3(1); else LZMS3(0);
-#undef LZMS3
-    if (!pg || pg->nb == 0) return;
-    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<false, 3, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, (uint4 *)nullptr, flags, max_len, pbuf, blk0);
-    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<false, 2, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, (uint4 *)nullptr, flags, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lzp<false, 1, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, (uint4 *)nullptr, flags, max_len, pbuf, blk0);
 }
 uint32_t lz_gtab_log() { return GTAB_LOG; }
 void lzp_read_stamps(unsigned long long *out) {

@@ -30,10 +30,6 @@ void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
 void launch_lz(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint4 *ctab,
                uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, uint32_t *pbuf, uint32_t blk0, hipEvent_t ev_match, uint32_t *gtab, const LzParseGrid *pg);
 uint32_t lz_gtab_log();
-void launch_lzm_keys(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint32_t flags, uint32_t max_off, hipStream_t st, uint32_t *kbuf, uint32_t kblk0);                       // k_lz_split.hip: the split form's second shape
-void launch_fad(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint32_t flags, hipStream_t st, const uint32_t *kbuf, uint32_t kblk0, uint32_t *pbuf, uint32_t blk0);
-void launch_lzp_words(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uint64_t *seqs, uint8_t *lits, BlkInfo *blk, uint32_t flags, uint32_t max_len, hipStream_t st, uint32_t *pbuf,
-                      uint32_t blk0, const LzParseGrid *pg);
 void launch_deflate_stage1(const uint8_t *src, const SegDesc *segs, uint32_t nseg, const uint32_t *blk_seg, uint32_t nblk,
                            const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, const uint4 *ctab, DeflTables *tabs, uint8_t *outc,
                            uint64_t *seg_size, uint64_t *seg_off, hipStream_t st, hipEvent_t *ev, uint32_t dbg, bool stored_only, bool wave_per_seg);
@@ -181,10 +177,6 @@ struct Tuning {
     long small_geometry = 1;         // PNA_SMALL_GEOMETRY: 1 (default): segments of at most 4 096 bytes run the small geometry of the match finder (pna_dev.h SMALL_SEG: one wave per segment, sub-tiles of 256 positions); 0: the large one like every segment (they then find no match: one tile)
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long strong2 = 1;                // PNA_STRONG2: 1 (default): zstd levels 6 .. 22 on their standard geometries adopt over eight positions as well and count up to 15 back bytes (levels 6 - 9: 2.864 -> 2.880); 0: the default set's three rounds
-    long lz_fad = 0;                 // PNA_LZ_FAD: 1: long runs of the packed-table zstd sets take the split LZ stage's second shape -- k_lzm without far candidates and adoption, k_fad (LDS-free) beside the next run's k_lzm, k_lzp: same bytes, measured SLOWER (LAB_LOG.md 5.7); 0 (default): far candidates and adoption inside k_lzm
-    long lz_fad_min = 512;           // PNA_LZ_FAD_MIN: fewest segments of a sub-batch that take that shape (two rounds of the CUs: fewer have nothing to run beside)
-    long lz_fad_run_segs = 0;        // PNA_LZ_FAD_RUN_SEGS: testing -- segments per run whatever the device's CUs (0: lz_fad_run rounds)
-    long lz_fad_run = 5;             // PNA_LZ_FAD_RUN: segments per run of that shape, in rounds of the device's CUs (5 x 256 one-MiB segments)
     long far1 = 1;                   // PNA_FAR1: 1 (default): the zstd light / default sets (packed table, 32 KiB window) verify at most 63 far candidates per wave of 256 positions -- one compacted round of k_lzm -- and drop the rest (FLAG_FAR1: - 0.16 % of ratio, - 6 % of the match kernel); 0: every far candidate, in as many rounds as it takes
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
@@ -229,8 +221,6 @@ struct pna_gpu_ctx {
     std::vector<uint64_t> pl_off, pl_len, pl_cap, pl_eoff;   // the host pipeline's per-entry plan (staging offsets, lengths, capacity terms), kept between calls
     uint32_t inflate_spec_streams = 0;              // streams of the latest inflate call that went through the speculative chunk decoder (diagnostics)
     DevBuf c_vocab, c_cum, c_phr;
-    DevBuf kbuf;                                    // the split LZ stage's second shape: the keys of two runs (k_lzm<FAD> -> k_fad), 4 bytes per position
-    hipStream_t fad_st = nullptr; std::vector<hipEvent_t> fad_ev;   // ... the stream k_fad runs on next to the following run's match kernel, an event pair per run
     DevBuf gtab;                                    // hash tables of the strong level set's match kernel (global memory)
     DevBuf fr_desc, fr_blob, fr_segdst, fr_entoff, crc_tabs;
     PinBuf h_entoff;

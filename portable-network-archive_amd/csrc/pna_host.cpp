@@ -11,7 +11,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"lz_fad", "PNA_LZ_FAD", &Tuning::lz_fad, 0, 1}, {"lz_fad_run", "PNA_LZ_FAD_RUN", &Tuning::lz_fad_run, 1, 64}, {"lz_fad_min", "PNA_LZ_FAD_MIN", &Tuning::lz_fad_min, 1, 1 << 30}, {"lz_fad_run_segs", "PNA_LZ_FAD_RUN_SEGS", &Tuning::lz_fad_run_segs, 0, 1 << 30}, {"strong2", "PNA_STRONG2", &Tuning::strong2, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"strong2", "PNA_STRONG2", &Tuning::strong2, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 extern "C" const char *pna_gpu_strerror(int code) {
@@ -93,9 +93,6 @@ extern "C" void pna_gpu_shutdown(pna_gpu_ctx *c) {
     for (auto &e : c->ev_out) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_lz) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->lzm_ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->fad_ev) if (e) (void)hipEventDestroy(e);
-    if (c->fad_st) (void)hipStreamDestroy(c->fad_st);
-    c->kbuf.release();
     for (auto &e : c->ev_ci) if (e) (void)hipEventDestroy(e);
     for (auto &r : c->ev_en) for (auto &e : r) if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -448,46 +445,6 @@ static int lz_small_pass(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *se
     return PNA_OK;
 }
 
-// The split form's SECOND SHAPE (round 5; the packed-table zstd sets, long runs): the match kernel keeps all of a CU's LDS with four waves per SIMD and leaves about half of the
-// SIMDs' issue slots idle (scripts/corun.py: an LDS-free vector kernel runs at its full rate beside it) -- so the part of its work that needs no LDS, the far candidates and the
-// adoption, is a kernel of its own (k_fad) on a second stream: run r's k_fad beside run r + 1's k_lzm<FAD>, the keys of two runs in kbuf, the words of all runs in pbuf, the parse
-// kernel over everything behind the last k_fad.  Same words.  Returns 1 when the runs were queued, 0 when the caller should take the first shape (workspace not to be had), < 0 on errors.
-static int lz_stage_fad(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, uint32_t nseg_all, uint32_t s0, uint32_t s1, uint32_t nblk,
-                        uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
-    const uint32_t bl = segs[s0].blk_log;
-    const uint32_t b0 = segs[s0].blk_base, b1 = s1 < nseg_all ? segs[s1].blk_base : nblk;
-    const uint32_t rs = c->tun.lz_fad_run_segs ? (uint32_t)c->tun.lz_fad_run_segs : (uint32_t)c->tun.lz_fad_run * c->n_cus;   // segments per run
-    uint32_t run_blk = 0;                                                                          // the largest run's blocks
-    for (uint32_t a = s0; a < s1; a += rs) { const uint32_t b = std::min(a + rs, s1); run_blk = std::max(run_blk, (b < nseg_all ? segs[b].blk_base : nblk) - segs[a].blk_base); }
-    if (c->pbuf.ensure(((size_t)std::max<uint32_t>(b1 - b0, 1) << bl) * 4) || c->kbuf.ensure(((size_t)std::max<uint32_t>(run_blk, 1) << bl) * 4 * 2)) { (void)hipGetLastError(); return 0; }
-    if (!c->fad_st) HIPCHK(c, hipStreamCreateWithFlags(&c->fad_st, hipStreamNonBlocking));
-    const uint32_t nruns = (s1 - s0 + rs - 1) / rs;
-    while (c->fad_ev.size() < 2 * (size_t)nruns + 1) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->fad_ev.push_back(e); }
-    uint32_t *kb[2] = {(uint32_t *)c->kbuf.p, (uint32_t *)c->kbuf.p + ((size_t)run_blk << bl)};
-    // (the second stream starts behind everything queued so far: the plan's upload, the memsets)
-    HIPCHK(c, hipEventRecord(c->fad_ev[2 * nruns], st)); HIPCHK(c, hipStreamWaitEvent(c->fad_st, c->fad_ev[2 * nruns], 0));
-    uint32_t r = 0;
-    for (uint32_t a = s0; a < s1; a += rs, r++) {
-        const uint32_t b = std::min(a + rs, s1);
-        if (r >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->fad_ev[2 * (r - 2) + 1], 0));                // the keys of run r - 2 have been read
-        hipEvent_t e1 = nullptr;
-        if (timed) {
-            while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
-            HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2; c->lzm_nl.push_back(1);
-        }
-        launch_lzm_keys(d_src, c->d_segs + a, b - a, flags, max_off, st, kb[r & 1], segs[a].blk_base);
-        if (e1) HIPCHK(c, hipEventRecord(e1, st));
-        HIPCHK(c, hipEventRecord(c->fad_ev[2 * r], st));
-        HIPCHK(c, hipStreamWaitEvent(c->fad_st, c->fad_ev[2 * r], 0));
-        launch_fad(d_src, c->d_segs + a, b - a, flags, c->fad_st, kb[r & 1], segs[a].blk_base, (uint32_t *)c->pbuf.p, b0);
-        HIPCHK(c, hipEventRecord(c->fad_ev[2 * r + 1], c->fad_st));
-    }
-    HIPCHK(c, hipStreamWaitEvent(st, c->fad_ev[2 * (nruns - 1) + 1], 0));                            // (the second stream works in order: its last kernel is the last to end)
-    const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};
-    launch_lzp_words(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, flags, max_len, st, (uint32_t *)c->pbuf.p, b0, &pg);
-    return 1;
-}
-
 static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, uint32_t nseg_all, uint32_t s0, uint32_t s1, uint32_t nblk, uint4 *ctab,
                     uint32_t flags, uint32_t max_off, uint32_t max_len, hipStream_t st, bool timed) {
     const int env_split = (int)c->tun.lz_split;
@@ -509,10 +466,6 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
             const uint32_t round = c->n_cus * bps, even = ((total + nruns - 1) / nruns + round - 1) / round * round;
             if (even < split_blocks) split_blocks = even;
         }
-    }
-    if (!ctab && !gt && !fused && !waveparse && (flags & FLAG_TAB3) && !(flags & FLAG_ALL_SMALL) && c->tun.lz_fad && !c->tun.lz_pbuf_fail && s1 - s0 >= (uint32_t)c->tun.lz_fad_min && s1 - s0 >= (uint32_t)c->tun.lz_split_min) {
-        const int rc = lz_stage_fad(c, d_src, segs, nseg_all, s0, s1, nblk, flags, max_off, max_len, st, timed);
-        if (rc) return rc < 0 ? rc : PNA_OK;
     }
     const uint32_t s1_all = s1; bool fused_tail = false;
     // The split form at every size: its parse kernel runs one wave per BLOCK (a block's parse depends on nothing outside the block), so a short run no

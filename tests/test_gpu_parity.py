@@ -365,32 +365,6 @@ def test_high_sets_adopt_over_eight_positions(pna, codec, form):
     assert size[(1, 7)] < size[(0, 7)] and size[(1, 12)] < size[(0, 12)] and size[(1, 3)] == size[(0, 3)]
 
 
-def test_split_form_second_shape_equals_the_model(pna, codec):
-    """The split LZ stage's second shape (option lz_fad, off by default: it is correct and slower, LAB_LOG.md 5.7; with it, sub-batches of lz_fad_min = 512 segments and more): k_lzm<FAD> leaves one key per position (the window's
-    candidates matched, a far candidate as its offset), k_fad -- no LDS, on a stream of its own next to the following run's match kernel -- verifies the far candidates against the
-    segment in memory, runs the adoption rounds and writes the words, k_lzp parses all runs.  Same bytes as the first shape and as the model: every packed-table level set, several runs
-    (lz_fad_run_segs = 3: the keys' two halves in turn), short segments, empty entries, entries that end inside a tile, a block and a match step."""
-    import torch  # noqa: F401
-    ents = [codec.corpus_file(0, 2, (1 << 20) + 77), codec.corpus_file(0, 5, 2500000), codec.corpus_file(1, 3, 400000), codec.corpus_file(0, 8, 131072 + 4096 + 100), b"",
-            codec.corpus_file(0, 9, 3000), codec.corpus_file(0, 10, 9000), codec.corpus_file(0, 11, 70000), (b"0123456789abcdefXYZ" * 40000)[:700001], codec.corpus_file(0, 12, 131072 + 17),
-            codec.corpus_file(0, 13, 40000) * 30, codec.corpus_file(2, 14, 300000), codec.corpus_file(0, 15, 4096 * 3 + 31)]
-    with pna.Context(0) as ctx:
-        ctx.set_option("latency_max_mib", 0)
-        ctx.set_option("lz_split_min", 0)
-        for lvl in (3, 2, 7):
-            p = codec.params_for_level(lvl)
-            want = [codec.model_compress(e, p) for e in ents]
-            for fad, run_segs in ((0, 0), (1, 0), (1, 3), (1, 1)):
-                ctx.set_option("lz_fad", fad); ctx.set_option("lz_fad_min", 1); ctx.set_option("lz_fad_run_segs", run_segs)
-                outs = ctx.compress_batch(ents, level=lvl)
-                for i, (o, w) in enumerate(zip(outs, want)):
-                    assert o == w, (lvl, fad, run_segs, i, len(ents[i]))
-        ctx.set_option("lz_fad", 1); ctx.set_option("lz_fad_run_segs", 2); ctx.set_option("far1", 0); ctx.set_option("strong2", 0)
-        for lvl in (3, 7):
-            p = codec.params_for_level(lvl, far1=0, strong2=0)
-            assert ctx.compress_batch(ents, level=lvl) == [codec.model_compress(e, p) for e in ents], lvl
-
-
 def test_lz_stage_equals_model(gpu_ctx, codec):
     d = codec.corpus_file(0, 31, 700000)
     gpu_ctx.compress_batch([d])
