@@ -174,7 +174,7 @@ class ZstdParams(ctypes.Structure):
                 ("ins_mod", ctypes.c_uint32), ("back_cap", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
                 ("near_off", ctypes.c_uint32), ("cap_far", ctypes.c_uint32), ("blk_log", ctypes.c_uint32), ("len_word_max", ctypes.c_uint32),
                 ("tab3", ctypes.c_uint32), ("mtile", ctypes.c_uint32), ("small_seg", ctypes.c_uint32), ("small_slots", ctypes.c_uint32),
-                ("small_tile", ctypes.c_uint32), ("mid_seg", ctypes.c_uint32), ("mid_slots", ctypes.c_uint32), ("cut_min", ctypes.c_uint32), ("far_slots", ctypes.c_uint32), ("far_from", ctypes.c_uint32)]
+                ("small_tile", ctypes.c_uint32), ("mid_seg", ctypes.c_uint32), ("mid_slots", ctypes.c_uint32), ("cut_min", ctypes.c_uint32), ("fixup", ctypes.c_uint32), ("far_slots", ctypes.c_uint32), ("far_from", ctypes.c_uint32)]
 
 
 F_HUF, F_FSE, F_LAZY = 1, 2, 4

@@ -30,7 +30,7 @@ void pna_zstd_default_params(pna_zstd_params *p) {
     p->ins_mod = 2; p->back_cap = 3; p->rounds = 0x21; p->near_off = 23296; p->cap_far = 32;
     p->blk_log = 0; p->len_word_max = 36; p->tab3 = 1;
     p->mtile = 0; p->small_seg = 4096; p->small_slots = 2048; p->small_tile = 256; p->mid_seg = 16384; p->mid_slots = 2048;
-    p->cut_min = 6; p->far_slots = 63; p->far_from = 28368;
+    p->cut_min = 6; p->far_slots = 63; p->far_from = 28368; p->fixup = 1;
 }
 const pna_zstd_params *pna_seg_params(const pna_zstd_params *p, uint32_t seg_len, pna_zstd_params *tmp) {
     uint32_t slots = 0;
@@ -127,6 +127,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
     const uint32_t ins_mod = p->ins_mod ? p->ins_mod : 1;
     const uint32_t min_c = p->back_cap > 7 ? 16u : 8u;            /* a usable candidate's position + 1 exceeds it */
     uint32_t *mq = (uint32_t *)malloc(sizeof(uint32_t) * (T + 1) * 4), *ml = mq + T + 1, *mc = ml + T + 1, *mr = mc + T + 1;
+    uint8_t *vis = (uint8_t *)calloc(T + 1, 1);                   /* F (fixup): positions a region's own walk stood on */
     uint32_t *wbest = p->tab3 ? (uint32_t *)calloc(p->hash_log / 3 + 1, sizeof(uint32_t)) : NULL, *wlist = p->tab3 ? (uint32_t *)malloc(sizeof(uint32_t) * (T + 1)) : NULL;
     for (uint32_t t0 = blk_start; t0 < blk_end; t0 += T) {
         uint32_t t1 = t0 + T < blk_end ? t0 + T : blk_end;
@@ -201,18 +202,20 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         }
         if (p->len_word_max) for (uint32_t i = 0; i < t1 - t0; i++) if (len[i] > p->len_word_max) len[i] = (uint16_t)p->len_word_max;
         /* P */
+#define PNA_TAKE(q_, l_) ((l_) >= p->min_match && \
+            !((p->flags & PNA_F_LAZY) && ((q_) & 63) != 63 && (q_) + 1 < t1 && len[(q_) + 1 - t0] > (l_)) && \
+            !((p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY2) && ((q_) & 63) < 62 && (q_) + 2 < t1 && len[(q_) + 2 - t0] > (l_) + 1) && \
+            !((p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY3) && ((q_) & 63) < 61 && (q_) + 3 < t1 && len[(q_) + 3 - t0] > (l_) + 2))
         uint32_t ext_lim = t1 + p->lookahead < blk_end ? t1 + p->lookahead : blk_end;
         uint32_t R = p->region ? p->region : T;
         uint32_t nm = 0;                                  /* matches of this tile: mq (start), ml (length), mc (candidate) */
+        memset(vis, 0, T + 1);
         for (uint32_t r0 = t0; r0 < t1; r0 += R) {
             uint32_t r1 = r0 + R < t1 ? r0 + R : t1;
             for (uint32_t q = (next_free > r0 ? next_free : r0); q < r1; ) {
                 uint32_t l = len[q - t0];
-                int take = l >= p->min_match;
-                if (take && (p->flags & PNA_F_LAZY) && (q & 63) != 63 && q + 1 < t1 && len[q + 1 - t0] > l) take = 0;
-                if (take && (p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY2) && (q & 63) < 62 && q + 2 < t1 && len[q + 2 - t0] > l + 1) take = 0;
-                if (take && (p->flags & PNA_F_LAZY) && (p->flags & PNA_F_LAZY3) && (q & 63) < 61 && q + 3 < t1 && len[q + 3 - t0] > l + 2) take = 0;
-                if (!take) { q++; continue; }
+                vis[q - t0] = 1;                                     /* the region's walk stands on q */
+                if (!PNA_TAKE(q, l)) { q++; continue; }
                 uint32_t c = cand[q - t0] - 1;
                 if (l >= (far[q - t0] ? p->cap_far : p->cap1)) {
                     uint32_t el = ext_lim;
@@ -229,7 +232,26 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
             if (q + l <= next_free || mr[i] <= next_free) continue;      /* mr = end of the match's region */
             if (q < next_free) {
                 uint32_t r = q + l - next_free;
-                if (r < (p->cut_min ? p->cut_min : 3u)) continue;
+                if (r < (p->cut_min ? p->cut_min : 3u)) {
+                    /* fixup (round 5): instead of only dropping the remainder, ONE match from inside it -- the first position s in [E, end of the straddling match) that the
+                     * walk's own rule would take, if its match is not a capped one (no extension here), ends inside the region and the tile, and ends on a position the
+                     * region's walk stood on: from there on the region's parse is the one that entered at E.  The region's matches that start before that end are dropped
+                     * with the straddling one.  Only where the straddling match itself ends inside its region (its end is then a position the walk stood on). */
+                    if (p->fixup && q + l < mr[i]) {
+                        uint32_t s = next_free;
+                        while (s < q + l && !PNA_TAKE(s, len[s - t0])) s++;
+                        if (s < q + l) {
+                            const uint32_t l2 = len[s - t0], x = s + l2;
+                            if (l2 < (far[s - t0] ? p->cap_far : p->cap1) && x < mr[i] && x < t1 && vis[x - t0]) {
+                                seqs[nseq].ll = s - lit_start; seqs[nseq].ml = l2; seqs[nseq].off = s - (cand[s - t0] - 1); nseq++;
+                                memcpy(lits + nlit, seg + lit_start, s - lit_start); nlit += s - lit_start;
+                                lit_start = x; next_free = x;
+                                while (i + 1 < nm && mr[i + 1] == mr[i] && mq[i + 1] < x) i++;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 c += next_free - q; q = next_free; l = r;
             }
             seqs[nseq].ll = q - lit_start; seqs[nseq].ml = l; seqs[nseq].off = q - c; nseq++;
@@ -238,7 +260,7 @@ uint32_t pna_lz_block(const uint8_t *seg, uint32_t seg_len, uint32_t blk_start, 
         }
     }
     memcpy(lits + nlit, seg + lit_start, blk_end - lit_start); nlit += blk_end - lit_start;
-    free(cand); free(len); free(mq); free(back); free(len0); free(cand0); free(back0); free(wbest); free(wlist);
+    free(vis); free(cand); free(len); free(mq); free(back); free(len0); free(cand0); free(back0); free(wbest); free(wlist);
     *nlit_out = nlit;
     return nseq;
 }

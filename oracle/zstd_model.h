@@ -61,6 +61,8 @@ typedef struct {
                                     * (the device gives both tiers the same table and sizes the window by the tier: 8 KiB text entries 1.97 -> 2.16, 16 KiB 2.16 -> 2.24; zlib -6: 2.12 / 2.22) */
     uint32_t cut_min;     /* F: a match the merge cuts from the front is kept iff at least this many bytes remain (0 = 3, the deflate minimum; the zstd sets: min_match --
                            * a sequence of 3 - 5 bytes costs more than its bytes as literals: + 0.12 % of ratio on the corpus) */
+    uint32_t fixup;       /* F: 1 = where the merge drops the remainder of a straddling match (shorter than cut_min), ONE match found inside that remainder is emitted if it ends on a
+                           * position the region's own walk stood on (pna_lz_block, F): + 0.07 % of ratio -- most of what parsing a tile's regions blind to each other loses */
     uint32_t far_slots, far_from;   /* far_slots != 0 (the device's default / light zstd sets, round 5): the match kernel verifies at most far_slots FAR candidates (offset >= far_from: outside
                            * its LDS window) per wave of 256 consecutive positions (tile start + 256 w ..) -- one compacted round of its 63 dense lanes instead of two.  The wave's far
                            * candidates (usable: position >= 8, offset <= max_off, and the entry's 2-bit tag equals the position's -- a foreign tag costs the device a slot like a

@@ -492,12 +492,41 @@ void k_lz(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, uin
 #pragma unroll
                             for (int r = 0; r < G; r++) if (grp == (uint32_t)r) { fsel[r] |= (uint64_t)1 << b; if (lane == b) { flen[r] = rmn; off[r] = o2; } }
                         } else {
-                            // its last 1-2 bytes stay literals
+                            // its last bytes (fewer than CUT_MIN) stay literals -- or, round 5 (the model's `fixup`, as in k_lzp): ONE match from inside them, the first start in
+                            // [E, end2) the walk's rule would take, if it is not a capped one, ends inside the region and the tile and on a position the walk stood on
+                            uint32_t fx_s = RW, fx_x = 0;
+                            if (end2 < RW) {
+                                uint64_t eg = effm[0], eg1 = G > 1 ? effm[1] : 0;
+#pragma unroll
+                                for (int r = 1; r < G; r++) if (grp == (uint32_t)r) { eg = effm[r]; eg1 = r + 1 < G ? effm[r + 1 < G ? r + 1 : r] : 0; }
+                                const uint32_t w8 = (uint32_t)((eg >> b) | (b ? eg1 << (64 - b) : 0)) & ((1u << rmn) - 1u);
+                                if (w8) {
+                                    const uint32_t sp = Ew + (uint32_t)__builtin_ctz(w8), gs = sp >> 6, ls = sp & 63;
+                                    uint32_t L = rdlane(len[0], ls);
+#pragma unroll
+                                    for (int r = 1; r < G; r++) if (gs == (uint32_t)r) L = rdlane(len[r], ls);
+                                    const uint32_t x = sp + L;
+                                    if (L < CAP1 && x < RW && x < in0) {
+                                        const uint32_t gx = x >> 6, bx = x & 63;
+                                        uint64_t cvx = cov[0], slx = sel[0];
+#pragma unroll
+                                        for (int r = 1; r < G; r++) if (gx == (uint32_t)r) { cvx = cov[r]; slx = sel[r]; }
+                                        if (!((cvx >> bx) & 1) || ((slx >> bx) & 1)) { fx_s = sp; fx_x = x; }
+                                    }
+                                }
+                            }
 #pragma unroll
                             for (int r = 0; r < G; r++) {
                                 const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
-                                const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
+                                const uint32_t zend = fx_s < RW ? fx_x : end2;
+                                const uint32_t z0 = zend > 64u * r ? (zend - 64u * r < 64 ? zend - 64u * r : 64u) : 0u;
                                 cv[r] &= ~(mlow(z0) & ~mlow(a0));
+                                if (fx_s < RW) {
+                                    const uint32_t s0 = fx_s > 64u * r ? (fx_s - 64u * r < 64 ? fx_s - 64u * r : 64u) : 0u;
+                                    cv[r] |= mlow(z0) & ~mlow(s0);
+                                    fsel[r] &= ~mlow(z0);
+                                    if ((fx_s >> 6) == (uint32_t)r) fsel[r] |= (uint64_t)1 << (fx_s & 63);
+                                }
                             }
                         }
                     }

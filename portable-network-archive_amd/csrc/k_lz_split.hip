@@ -809,11 +809,44 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                         for (int r = 0; r < 4; r++) if (grp == (uint32_t)r) fsel[r] |= (uint64_t)1 << b;
                         cut_r = grp; cut_b = b; cut_len = rmn; cut_off = pw2 >> 6;
                     } else {
+                        // The remainder is dropped.  Round 5 (the model's `fixup`): ONE match from inside it -- the first start in [E, end of the straddling match) the walk's own
+                        // rule would take, if it is not a capped one, ends inside the region and the tile, and ends on a position the region's walk stood on (uncovered, or a
+                        // chosen start): from there on the region's parse is the one that entered at E.  Only where the straddling match ends inside the region.
+                        uint32_t fx_s = RW, fx_x = 0;                                   // the fix-up match's start and end (region-relative); RW = none
+                        if (end2 < RW) {
+                            uint64_t eg = 0, eg1 = 0, cg2 = 0, cg3 = 0;                 // start and cap masks of group grp and of the one behind it
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const uint64_t e64 = (uint64_t)em_lo[r] | ((uint64_t)em_hi[r] << 32);
+                                if (grp == (uint32_t)r) { eg = e64; cg2 = cm[r]; }
+                                if (grp + 1 == (uint32_t)r) { eg1 = e64; cg3 = cm[r]; }
+                            }
+                            const uint32_t want = (1u << rmn) - 1u;                     // (rmn < CUT_MIN: the window [E, end2) is at most five positions)
+                            const uint32_t w8 = (uint32_t)((eg >> b) | (b ? eg1 << (64 - b) : 0)) & want, c8 = (uint32_t)((cg2 >> b) | (b ? cg3 << (64 - b) : 0));
+                            if (w8) {
+                                const uint32_t ds = (uint32_t)__builtin_ctz(w8), sp = Ew + ds;
+                                const uint32_t L = len8[wbase + sp], x = sp + L;
+                                if (!((c8 >> ds) & 1) && x < RW && x < in0) {
+                                    const uint32_t gx = x >> 6, bx = x & 63;
+                                    uint64_t cvx = cov[0], slx = sel[0];
+#pragma unroll
+                                    for (int r = 1; r < 4; r++) if (gx == (uint32_t)r) { cvx = cov[r]; slx = sel[r]; }
+                                    if (!((cvx >> bx) & 1) || ((slx >> bx) & 1)) { fx_s = sp; fx_x = x; }
+                                }
+                            }
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const uint32_t a0 = Ew > 64u * r ? (Ew - 64u * r < 64 ? Ew - 64u * r : 64u) : 0u;
-                            const uint32_t z0 = end2 > 64u * r ? (end2 - 64u * r < 64 ? end2 - 64u * r : 64u) : 0u;
+                            const uint32_t zend = fx_s < RW ? fx_x : end2;              // coverage is cleared up to the straddling match's end, or up to the fix-up match's (>= that end)
+                            const uint32_t z0 = zend > 64u * r ? (zend - 64u * r < 64 ? zend - 64u * r : 64u) : 0u;
                             cv[r] &= ~(mlow(z0) & ~mlow(a0));
+                            if (fx_s < RW) {
+                                const uint32_t s0 = fx_s > 64u * r ? (fx_s - 64u * r < 64 ? fx_s - 64u * r : 64u) : 0u;
+                                cv[r] |= mlow(z0) & ~mlow(s0);                          // the fix-up match's positions
+                                fsel[r] &= ~mlow(z0);                                   // the region's starts before its end go with the straddling match
+                                if ((fx_s >> 6) == (uint32_t)r) fsel[r] |= (uint64_t)1 << (fx_s & 63);
+                            }
                         }
                     }
                 }
