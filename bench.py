@@ -44,7 +44,7 @@ def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
         # segments of at most 16 KiB: the short-segment geometry, whatever the level's table
         strong = level >= 9 if defl else (level >= 3 or level == 0)
         fast = level <= 3 if defl else (level < 0 or level == 1)
-        high = not defl and level >= 6
+        high = not defl and level >= 4
         parse = "greedy+lazy3" if fast else ("greedy+lazy3 with backward adoption (4 rounds, 15 back bytes)" if high else "greedy+lazy3 with backward adoption (3 rounds, 7 back bytes)" if strong else "greedy+lazy3 with backward adoption (2 rounds)")
         return (f"GPU encoder, short-segment geometry: one wave per entry, 2048-entry LDS hash table" + ("" if fast else " over the even positions") +
                 f", the whole entry as look-back, look-ups and inserts alternating per 256 positions, min_match 6, {parse}, 4096-position parse tiles")
@@ -53,7 +53,7 @@ def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
     fast = level <= 3 if defl else (level < 0 or level == 1)
     gtab = not defl and level >= 10
     strong = level >= 9 if defl else (level >= 3 or level == 0)
-    w16 = not defl and not fast and not gtab and level >= 6
+    w16 = not defl and not fast and not gtab and level >= 4
     packed = not defl and not fast and not gtab
     if gtab:
         table = "2^19-slot hash table per segment in global memory over the even positions"
@@ -65,7 +65,7 @@ def encoder_text(algo: str, level: int, entry_bytes: int = 1 << 20) -> str:
             "look-back = the LDS window (56 064 B)" if fast else
             "look-back = the whole 1 MiB segment (the match kernel verifies candidates up to 61 136 B back in its LDS window, older ones in HBM/L2)" if gtab else
             "look-back 512 KiB of the segment (the match kernel verifies candidates up to %s B back in its LDS window, older ones in HBM/L2)" % ("11 984" if w16 else "28 368"))
-    high = not defl and level >= 6                                   # FLAG_STRONG2: the packed 16 KiB geometry and the global table
+    high = not defl and level >= 4                                   # FLAG_STRONG2: the packed 16 KiB geometry and the global table
     far1 = packed and not w16                                       # FLAG_FAR1: the light and default sets
     parse = "greedy+lazy3" if fast else ("greedy+lazy3 with backward adoption (4 rounds, 15 back bytes)" if high else "greedy+lazy3 with backward adoption (3 rounds, 7 back bytes)" if strong else "greedy+lazy3 with backward adoption (2 rounds)")
     if far1:

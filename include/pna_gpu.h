@@ -76,16 +76,16 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "lz_split_blocks" [PNA_LZ_SPLIT_BLOCKS]  blocks per run of the split form (default 131 072 = 16 GiB of input, 48 GiB of workspace; halved while the workspace cannot be had)
  *   "lz_split_min" [PNA_LZ_SPLIT_MIN]     shortest run, in segments, that takes the split form (default 0: every run)
  *   "lz_pbuf_fail" [PNA_LZ_PBUF_FAIL]     testing: behave as if the split form's workspace could not be allocated
- *   "win32k" [PNA_WIN32K]                 LDS geometry of the zstd match finder: 1 (default) the light and default level sets on a 32 KiB window, the high set on
+ *   "win32k" [PNA_WIN32K]                 LDS geometry of the zstd match finder: 1 (default) the light and default level sets (zstd 2, 3) on a 32 KiB window, the high set (4 .. 9) on
  *                                         a 16 KiB window; 0: both on 64 KiB; 2: both on 16 KiB.  Other bytes, same format
  *   "tab3" [PNA_TAB3]                     the hash table of the zstd light / default / high sets: 1 (default) PACKED, three 21-bit entries (even position + 2-bit tag) per
  *                                         64-bit LDS word -- 49 062 slots next to the 32 KiB window, 55 206 next to the 16 KiB one; 0: one 32-bit entry per slot
  *                                         (32 704 / 36 800: round 3's table).  Other bytes (ratio 2.847 against 2.759 on text at the default level), same format
- *   "far1" [PNA_FAR1]                     1 (default): the zstd light / default sets (levels 2 .. 5: packed table, 32 KiB window) verify at most 63 candidates beyond the match kernel's LDS window
+ *   "far1" [PNA_FAR1]                     1 (default): the zstd light / default sets (levels 2, 3: packed table, 32 KiB window) verify at most 63 candidates beyond the match kernel's LDS window
  *                                         per wave of 256 positions -- one compacted round of far candidates -- and drop the rest (round 5: - 0.16 % of ratio, - 8.5 % of the match kernel);
  *                                         0: every far candidate, in as many rounds as it takes.  Other bytes, same format
- *   "strong2" [PNA_STRONG2]               1 (default): zstd levels 6 .. 22 on their standard geometries run a fourth backward-adoption round over eight positions and count up to 15 back bytes
- *                                         (round 5: levels 6 - 9 2.860 -> 2.883 on text, 10 - 22 2.977 -> 3.002); 0: the default level's three rounds.  Other bytes, same format
+ *   "strong2" [PNA_STRONG2]               1 (default): zstd levels 4 .. 22 (the high and max sets) on their standard geometries run a fourth backward-adoption round over eight positions and count up to
+ *                                         15 back bytes (round 5: the high set 2.860 -> 2.883 on text, 10 - 22 2.977 -> 3.002); 0: the default level's three rounds.  Other bytes, same format
  *   "small_geometry" [PNA_SMALL_GEOMETRY] 1 (default): segments of at most 16 KiB -- small entries, the tail of longer ones -- are matched by one wave each with look-ups and inserts
  *                                         alternating per 256 positions (k_lzms) instead of by a workgroup per 4 096: such a segment's first tile finds nothing in the large
  *                                         geometry (4 KiB text entries: ratio 1.77 -> 2.04, libzstd -3: 2.05).  0: the large geometry for every segment.  Other bytes, same format

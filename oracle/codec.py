@@ -189,7 +189,7 @@ def default_params() -> ZstdParams:
 
 def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = None):
     """(flags, gtab): the level sets behind the reference's level scale as the product maps them (pna_host.cpp level_flags / set_call_level):
-    zstd < 0, 1 fast; 2 light; 0, 3..5 default (+ F_STRONG, round 4); 6..9 high (the 16 KiB window: level_win32k); 10..22 max (+ the hash table in global memory) -- deflate 1..3, 4..8, 9 (deflate 0: stored blocks only, params_for_level).  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
+    zstd < 0, 1 fast; 2 light; 0, 3 default (+ F_STRONG, round 4); 4..9 high (the 16 KiB window: level_win32k; a fourth adoption round); 10..22 max (+ the hash table in global memory) -- deflate 1..3, 4..8, 9 (deflate 0: stored blocks only, params_for_level).  ctx_flags: the context's own flag bits where a test creates it with explicit ones (default: the library's choice)."""
     base = ctx_flags if ctx_flags is not None else ((F_ADOPT | F_INS2 | F_LAZY) if deflate else (F_HUF | F_FSE | F_LAZY | F_FAR | F_ADOPT | F_INS2))
     if deflate:
         lv = 6 if level is None or level == -1000 else (9 if level < 0 or level > 9 else level)      # (PNA_LEVEL_DEFAULT; a negative Custom(n) wraps and clamps to 9)
@@ -208,15 +208,18 @@ def product_level_flags(level, deflate: bool = False, ctx_flags: int | None = No
     return fl, bool(not deflate and lv >= 10 and fl & F_STRONG and fl & F_ADOPT)
 
 
+HIGH_FROM = 4          # the first zstd level of the high set (pna_host.cpp)
+
+
 def level_win32k(level, deflate: bool = False, win32k: int = 1) -> int:
-    """The window geometry a zstd level runs with the context's option win32k (1 by default): levels 6..9 take the 16 KiB window (2), the others the option's."""
+    """The window geometry a zstd level runs with the context's option win32k (1 by default): levels 4..9 take the 16 KiB window (2), the others the option's."""
     lv = 3 if level is None or level == -1000 else min(level, 22)
-    return 2 if (not deflate and win32k and lv >= 6) else win32k
+    return 2 if (not deflate and win32k and lv >= HIGH_FROM) else win32k
 
 
 def params_for_level(level, deflate: bool = False, blk_log: int = 0, ctx_flags: int | None = None, win32k: int = 1, tab3: int = 1, far1: int = 1, strong2: int = 1) -> "ZstdParams":
     fl, gtab = product_level_flags(level, deflate, ctx_flags)
-    high = bool(strong2) and not deflate and level is not None and level != -1000 and min(level, 22) >= 6        # zstd 6 .. 22 (the product's option strong2, default on)
+    high = bool(strong2) and not deflate and level is not None and level != -1000 and min(level, 22) >= HIGH_FROM        # zstd 4 .. 22 (the product's option strong2, default on)
     p = params_for_flags(fl, deflate=deflate, blk_log=blk_log, gtab=gtab, win32k=level_win32k(level, deflate, win32k), tab3=tab3, far1=far1, strong2=high)
     if deflate and level == 0:
         p.flags |= 0x200               # PNA_F_STORED: deflate level 0 = Compression::none(), stored blocks only (lib/src/compress/deflate.rs:89-101)
@@ -259,7 +262,7 @@ def params_for_flags(flags: int, deflate: bool = False, blk_log: int = 0, gtab: 
         p.back_cap = 7
         p.flags |= 0x80
     if strong2 and flags & F_STRONG and flags & F_ADOPT and not deflate and (gtab or (p.tab3 and p.hash_log == 55206)):
-        # the high and max sets (zstd 6 .. 22 on their standard geometries; round 5): a FOURTH adoption round over eight positions, first, and up to 15 back bytes -- levels 6 .. 9 2.864 -> 2.880
+        # the high and max sets (zstd 4 .. 22 on their standard geometries; round 5): a FOURTH adoption round over eight positions, first, and up to 15 back bytes -- levels 6 .. 9 2.864 -> 2.880
         p.rounds = 0x2148
         p.back_cap = 15
     if gtab:

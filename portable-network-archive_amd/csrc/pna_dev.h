@@ -64,7 +64,7 @@ constexpr uint32_t FLAG_SMALL_ONLY = 0x40000u;  // (k_lzp) parse the blocks of s
 constexpr uint32_t FLAG_TIER1 = 0x100000u, FLAG_TIER2 = 0x200000u;   // (with FLAG_HAS_SMALL) the launch holds segments of the first / second tier: which of k_lzms's two forms to launch
 constexpr uint32_t FLAG_ALL_SMALL = 0x80000u;   // every segment of the launch is short (or empty): the large geometry's kernels are not launched at all
 constexpr uint32_t FLAG_FAR1 = 0x1000000u;   // (with FLAG_TAB3 + FLAG_W32) at most 63 far candidates per wave of 256 positions are verified -- ONE compacted round of k_lzm --, the rest dropped (oracle: far_slots, far_from)
-constexpr uint32_t FLAG_STRONG2 = 0x2000000u; // (with F_STRONG; the packed 16 KiB geometry or the table in global memory: zstd 6 .. 22) a fourth adoption round over eight positions, first, and up to 15 back bytes (oracle: rounds 0x2148, back_cap 15; usable candidates lie at position 16 or beyond)
+constexpr uint32_t FLAG_STRONG2 = 0x2000000u; // (with F_STRONG; the packed 16 KiB geometry or the table in global memory: zstd 4 .. 22) a fourth adoption round over eight positions, first, and up to 15 back bytes (oracle: rounds 0x2148, back_cap 15; usable candidates lie at position 16 or beyond)
 constexpr uint32_t FLAG_W32 = 0x2000u;   // launch flag of the LZ kernels: the 32 KiB-window geometry (zstd only; lz_common.h LzGeo)
 constexpr uint32_t F_FAR = 0x10, F_ADOPT = 0x20, F_INS2 = 0x40, F_STRONG = 0x80;   // look-back beyond the LDS window; backward adoption; only even positions enter the table; third adoption round (7 back bytes) + two-step lazy
 

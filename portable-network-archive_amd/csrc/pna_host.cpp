@@ -135,11 +135,12 @@ extern "C" int pna_gpu_clamp_level(int algo, int level) {
 //   stored    deflate 0                      Compression::none(): stored blocks only (no match finder, header 78 01)
 //   fast      zstd < 0 and 1, deflate 1..3   every position in the table, look-back = the LDS window, no backward adoption; lazy deferral as below
 //   light     zstd 2,         deflate 4..8   + even-position table, backward adoption (two rounds), 1 MiB look-back (zstd), lazy deferral over three positions
-//   default   zstd 0, 3..5                   + a third adoption round (matches move back by up to 7 positions): ratio at the reference's default level (round 4)
-//   high      zstd 6..9,      deflate 9      the default set on the 16 KiB-window geometry (more table slots, more candidates verified in HBM / L2); deflate: + third round
+//   default   zstd 0, 3                      + a third adoption round (matches move back by up to 7 positions): ratio at the reference's default level (round 4)
+//   high      zstd 4..9,      deflate 9      the default set on the 16 KiB-window geometry (more table slots, more candidates verified in HBM / L2) + a fourth adoption round over eight positions, 15 back bytes; deflate: + third round
 //   max       zstd 10..22                    + the match kernel's hash table in global memory: 2^19 slots per segment instead of what LDS holds
 // zstd light / default run the match finder's 32 KiB-window geometry, high the 16 KiB one (lz_common.h LzGeo), both with the PACKED table (three 21-bit
 // entries per 64-bit LDS word: 49 062 / 55 206 slots; option tab3 = 0: 32-bit entries, 32 704 / 36 800); the others and deflate the 64 KiB geometry (24 512).
+constexpr int HIGH_FROM = 4;        // the first zstd level of the high set
 static uint32_t level_flags(const pna_gpu_ctx *c, int algo, int level) {
     const int lv = pna_gpu_clamp_level(algo, level);
     const bool fast = algo == PNA_ALGO_DEFLATE ? lv <= 3 : (lv < 0 || lv == 1);
@@ -155,10 +156,10 @@ void set_call_level(pna_gpu_ctx *c, int algo, int level) {
     const bool zstd = algo != PNA_ALGO_DEFLATE;
     c->call_gtab = zstd && pna_gpu_clamp_level(algo, level) >= 10 && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong_gtab != 0;
     c->call_w32 = zstd && !c->call_gtab && (c->call_flags & F_FAR) && (c->call_flags & F_LAZY) && c->tun.win32k != 0;
-    c->call_w16 = c->call_w32 && (c->tun.win32k >= 2 || pna_gpu_clamp_level(algo, level) >= 6);          // the high set's geometry (round 4: chosen by the level, no longer by F_STRONG)
+    c->call_w16 = c->call_w32 && (c->tun.win32k >= 2 || pna_gpu_clamp_level(algo, level) >= HIGH_FROM);   // the high set's geometry (round 4: chosen by the level, no longer by F_STRONG; round 5: from level 4 on -- libzstd 1.5.7's own 4 / 5 give 2.863 / 2.906 on the corpus, the default set 2.850, the high set 2.884)
     c->call_stored = !zstd && pna_gpu_clamp_level(algo, level) == 0;
     c->call_tab3 = c->call_w32 && (c->call_flags & F_INS2) && (c->call_flags & F_ADOPT) && c->tun.tab3 != 0;
-    c->call_strong2 = zstd && pna_gpu_clamp_level(algo, level) >= 6 && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong2 != 0 && (c->call_gtab || (c->call_tab3 && c->call_w16));
+    c->call_strong2 = zstd && pna_gpu_clamp_level(algo, level) >= HIGH_FROM && (c->call_flags & F_STRONG) && (c->call_flags & F_ADOPT) && c->tun.strong2 != 0 && (c->call_gtab || (c->call_tab3 && c->call_w16));
     c->call_lazy2 = (c->call_flags & F_LAZY) && (c->tun.lazy2 != 0 || (c->call_flags & F_STRONG));   // every lazy set defers over two positions (the high sets always did)
     c->call_lazy3 = c->call_lazy2 && c->tun.lazy2 >= 2;                                               // ... and over three (option lazy2 = 2, the default)
 }

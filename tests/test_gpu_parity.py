@@ -332,7 +332,7 @@ def test_far_candidates_beyond_one_round_are_dropped(pna, codec, form):
             for lvl in (3, 2, 7):
                 outs = ctx.compress_batch(ents, level=lvl)
                 p = codec.params_for_level(lvl, far1=far1)
-                assert p.far_slots == (63 if (far1 and lvl < 6) else 0)
+                assert p.far_slots == (63 if (far1 and lvl < 4) else 0)
                 for e, o in zip(ents, outs):
                     assert o == codec.model_compress(e, p), (far1, lvl, len(e))
                     assert codec.zstd_decompress(o, len(e)) == e
@@ -357,7 +357,7 @@ def test_high_sets_adopt_over_eight_positions(pna, codec, form):
             for lvl in (7, 12, 3):
                 outs = ctx.compress_batch(ents, level=lvl)
                 p = codec.params_for_level(lvl, strong2=s2)
-                assert (p.rounds, p.back_cap) == ((0x2148, 15) if (s2 and lvl >= 6) else (0x214, 7))
+                assert (p.rounds, p.back_cap) == ((0x2148, 15) if (s2 and lvl >= 4) else (0x214, 7))
                 for e, o in zip(ents, outs):
                     assert o == codec.model_compress(e, p), (s2, lvl, len(e))
                     assert codec.zstd_decompress(o, len(e)) == e
@@ -1361,7 +1361,7 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
     """The reference's level scale (lib/src/compress/zstandard.rs:43-57, deflate.rs:89-101) maps onto parameter sets -- fast (greedy,
     LDS-window look-back, every position in the table), balanced (deflate only: + even-position table, backward adoption), default
     (+ 1 MiB look-back, lazy deferral over three positions; zstd: the match finder's 32 KiB-window geometry with the packed table of 49 062 slots, a third
-    adoption round), high (zstd 6 .. 9: 16 KiB window, 55 206 slots, a fourth adoption round over eight positions and 15 back bytes) and, zstd only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact
+    adoption round), high (zstd 4 .. 9: 16 KiB window, 55 206 slots, a fourth adoption round over eight positions and 15 back bytes) and, zstd only, max (+ the hash table in global memory, 2^19 slots) --, each bit-exact
     with the model; stronger sets compress better."""
     data = [codec.corpus_file(0, 77, 400000), codec.corpus_file(1, 78, 70000), b"", codec.corpus_file(0, 79, (1 << 20) + 5)]
     std = codec.F_HUF | codec.F_FSE | codec.F_FAR | codec.F_ADOPT | codec.F_INS2
@@ -1369,15 +1369,15 @@ def test_levels_select_the_parse(gpu_ctx, pna, codec):
     strong = dflt | codec.F_STRONG
     sizes = {}
     for level, fl, gtab, slots in ((-5, fast, 0, 24512), (1, fast, 0, 24512), (2, dflt, 0, 49062), (0, strong, 0, 49062), (3, strong, 0, 49062), (pna.LEVEL_DEFAULT, strong, 0, 49062),
-                                   (5, strong, 0, 49062), (6, strong, 0, 55206), (9, strong, 0, 55206), (10, strong, 1, 19), (19, strong, 1, 19), (22, strong, 1, 19), (99, strong, 1, 19)):
+                                   (4, strong, 0, 55206), (5, strong, 0, 55206), (6, strong, 0, 55206), (9, strong, 0, 55206), (10, strong, 1, 19), (19, strong, 1, 19), (22, strong, 1, 19), (99, strong, 1, 19)):
         outs = gpu_ctx.compress_batch(data, algo=pna.ALGO_ZSTD, level=level)
         assert codec.product_level_flags(level) == (fl, bool(gtab)), level
         pz = codec.params_for_level(level)
-        high = level != pna.LEVEL_DEFAULT and level >= 6                  # zstd 6 .. 22: a fourth adoption round over eight positions, 15 back bytes (FLAG_STRONG2)
+        high = level != pna.LEVEL_DEFAULT and level >= 4                  # zstd 4 .. 22: a fourth adoption round over eight positions, 15 back bytes (FLAG_STRONG2)
         assert pz.hash_log == slots and pz.rounds == (0 if fl == fast else (0x2148 if high else 0x214) if fl == strong else 0x21) and pz.back_cap == (0 if fl == fast else 15 if high else 7 if fl == strong else 3), level
         assert outs == [codec.model_compress(d, pz) for d in data], level
         sizes[level] = sum(map(len, outs))
-    assert sizes[19] < sizes[6] < sizes[3] < sizes[2] < sizes[1] and sizes[0] == sizes[3] == sizes[pna.LEVEL_DEFAULT]
+    assert sizes[19] < sizes[6] == sizes[4] < sizes[3] < sizes[2] < sizes[1] and sizes[0] == sizes[3] == sizes[pna.LEVEL_DEFAULT]
     dstd = codec.F_ADOPT | codec.F_INS2
     # deflate level 0 is Compression::none() (lib/src/compress/deflate.rs:89-101): stored blocks only, header 78 01 -- not the fast set
     outs0 = gpu_ctx.compress_batch(data, algo=pna.ALGO_DEFLATE, level=0)
