@@ -81,6 +81,8 @@ const char *pna_gpu_last_error(const pna_gpu_ctx *ctx);
  *   "tab3" [PNA_TAB3]                     the hash table of the zstd light / default / high sets: 1 (default) PACKED, three 21-bit entries (even position + 2-bit tag) per
  *                                         64-bit LDS word -- 49 062 slots next to the 32 KiB window, 55 206 next to the 16 KiB one; 0: one 32-bit entry per slot
  *                                         (32 704 / 36 800: round 3's table).  Other bytes (ratio 2.847 against 2.759 on text at the default level), same format
+ *   "seq_hist" [PNA_SEQ_HIST]             1 (default): large zstd batches -- the parse kernel of the split LZ stage counts every block's sequence codes, the statistics kernel walks the literals only; 0: it
+ *                                         reads the sequences once more.  Same bytes
  *   "far1" [PNA_FAR1]                     1 (default): the zstd light / default sets (levels 2, 3: packed table, 32 KiB window) verify at most 63 candidates beyond the match kernel's LDS window
  *                                         per wave of 256 positions -- one compacted round of far candidates -- and drop the rest (round 5: - 0.16 % of ratio, - 8.5 % of the match kernel);
  *                                         0: every far candidate, in as many rounds as it takes.  Other bytes, same format

@@ -468,7 +468,8 @@ void k_hist(const uint32_t *__restrict__ blk_seg, const uint64_t *__restrict__ s
 // PRE: the histograms were gathered by k_hist (`hist`, 448 counters per segment); otherwise this workgroup walks the segment's blocks itself
 // LEAN (batches of single-block segments, i.e. many small entries): two copies of the literal histogram and one of the code histograms instead of eight and
 // four -- 13 KiB of LDS instead of 22, eleven workgroups per CU instead of seven; the kernel's time there is wave 0's chain of dependent steps x the entries in flight.
-template <bool PRE, bool LEAN>
+// PRE = 2 (round 5; large batches behind the split LZ stage): the LITERALS are walked here, the sequence codes were counted by the parse kernel (k_lzp: hist words 256 .. 447)
+template <int PRE, bool LEAN>
 __global__ __launch_bounds__(ST_THREADS)
 void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs, const uint8_t *__restrict__ lits,
              const BlkInfo *__restrict__ blk, SegTables *__restrict__ tabs, uint32_t flags, const uint32_t *__restrict__ hist) {
@@ -504,7 +505,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
     }
     __syncthreads();
     uint32_t nseq_seg = 0;
-    for (uint32_t b = 0; b < (PRE ? 0u : nblk); b++) {
+    for (uint32_t b = 0; b < (PRE == 1 ? 0u : nblk); b++) {
         const uint32_t g = sd.blk_base + b;
         const uint32_t nlit = blk[g].nlit, nseq = blk[g].nseq;
         nseq_seg += nseq;
@@ -522,7 +523,7 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         }
         for (uint32_t j = (n16 << 4) + tid; j < nlit; j += ST_THREADS) atomicAdd(&hl[bl[j]], 1u);
         const uint64_t *bs = seqs + (size_t)g * seq_cap_of(sd.blk_log);
-        for (uint32_t i = tid; i < nseq; i += ST_THREADS) {
+        for (uint32_t i = tid; i < (PRE ? 0u : nseq); i += ST_THREADS) {
             const uint64_t s = bs[i];
             const uint32_t llv = seq_ll(s), mb = seq_ml(s) - 3;
             atomicAdd(&h_seq[0][tid & (HS - 1)][llv < 64 ? (uint32_t)s_llc[llv] : hb(llv) + 19], 1u);
@@ -531,12 +532,16 @@ void k_stats(const SegDesc *__restrict__ segs, const uint64_t *__restrict__ seqs
         }
     }
     __syncthreads();
-    if (PRE) {
+    if (PRE == 1) {
         const uint32_t *hs = hist + (size_t)blockIdx.x * HIST_WORDS;
         count[tid] = hs[tid];
         if (tid < 192) scount[tid >> 6][tid & 63] = hs[256 + tid];
         __syncthreads();
         for (uint32_t s = 0; s < 36; s++) nseq_seg += scount[0][s];             // every sequence has one literal-length code
+    } else if (PRE == 2) {
+        const uint32_t *hs = hist + (size_t)blockIdx.x * HIST_WORDS;
+        { uint32_t c = 0; for (uint32_t k = 0; k < HL; k++) c += h_lit[k][tid]; count[tid] = c; }
+        if (tid < 192) scount[tid >> 6][tid & 63] = hs[256 + tid];
     } else {
         { uint32_t c = 0; for (uint32_t k = 0; k < HL; k++) c += h_lit[k][tid]; count[tid] = c; }
         if (tid < 192) { uint32_t w = tid >> 6, s = tid & 63, c = 0; for (uint32_t k = 0; k < HS; k++) c += h_seq[w][k][s]; scount[w][s] = c; }
@@ -1305,18 +1310,20 @@ void k_scan_launch_big(const uint64_t *in, uint64_t *out, uint32_t n, hipStream_
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
                           uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev /* 3 events: after stats, lit, seq; may be null */,
-                          hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block /* no segment of the chunk holds more than one block */) {
+                          hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block /* no segment of the chunk holds more than one block */, const uint32_t *seq_hist) {
     // side != null (large batches, the one-kernel sequence coder): the literal coder runs on a second stream NEXT TO the sequence coder -- both only
     // need the tables; k_seq is a few long chains per SIMD (1 250 waves of 64 chains on 1 024 SIMDs: issue slots to spare), k_lit streams memory
     const uint32_t bps_log = single_block ? 0u : 20u - blk_log;             // block slots per segment: the blocks of a full one (SEG_SIZE = 1 MiB), or the one block every segment has
     const uint32_t seq_wgs = (uint32_t)((((uint64_t)ns << bps_log) + 63) / 64);
     if (hist) {                                                             // histograms per block, tables from the counters (the caller zeroed them)
         if (nb) hipLaunchKernelGGL(k_hist, dim3(nb), dim3(ST_THREADS), 0, st, blk_seg, seqs, lits, blk, hist, (uint16_t *)seqw, g0, blk_log);
-        hipLaunchKernelGGL((k_stats<true, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
+        hipLaunchKernelGGL((k_stats<1, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, hist + (size_t)s0 * HIST_WORDS);
     } else if (single_block)
-        hipLaunchKernelGGL((k_stats<false, true>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_stats<0, true>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
+    else if (seq_hist)                                                        // the parse kernel counted the sequence codes (seq_hist: the segments' counters)
+        hipLaunchKernelGGL((k_stats<2, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, seq_hist + (size_t)s0 * HIST_WORDS);
     else
-        hipLaunchKernelGGL((k_stats<false, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_stats<0, false>), dim3(ns), dim3(ST_THREADS), 0, st, segs + s0, seqs, lits, blk, tabs + s0, flags, (const uint32_t *)nullptr);
     if (ev) (void)hipEventRecord(ev[0], st);
     const bool forked = side && !hist && nb;
     if (forked) {

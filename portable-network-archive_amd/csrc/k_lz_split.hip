@@ -596,7 +596,7 @@ constexpr uint32_t LZP_THREADS = 64;
 template <bool CT, int LZD, bool W3>   // W3: the words take three bytes (k_lzm); LZD: how many positions ahead a start looks before it is taken (lazy deferral: 1, 2 or 3; without F_LAZY none)
 __global__ __launch_bounds__(LZP_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5)))   // (88 registers: 5 waves per SIMD; asked for 6 / 7 the allocator spills 4 / 9 registers and the kernel is no faster / 2 % slower)
 void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, const uint32_t *__restrict__ blk_seg, uint64_t *__restrict__ seqs, uint8_t *__restrict__ lits,
-           BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0) {
+           BlkInfo *__restrict__ blk, uint4 *__restrict__ ctab, uint32_t flags, uint32_t max_len, const uint32_t *__restrict__ pbuf, uint32_t blk0, uint32_t *__restrict__ hist) {
     constexpr uint32_t RW = 256, TG = 4096;
     static_assert(LZ_G_ZSTD == 4 && LZ_G_DEFLATE == 4 && (1u << BLK_LOG_MIN) % TG == 0 && CAP1 == 32, "k_lzp: regions of 4 groups, tiles of 16 regions");
     __shared__ __attribute__((aligned(16))) uint32_t l32[TG / 4];   // the tile's match lengths, one byte per position; from the end of step 2 on: the records (below)
@@ -608,6 +608,10 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     // not LDS, bound the waves per CU (the kernel hides its memory latency by occupancy: 13 instead of 19 waves per CU cost it 12 %, 9 waves 36 %; above 20 nothing more is gained).
     uint4 (*rec)[TG / 64] = (uint4 (*)[TG / 64])l32;
     __shared__ uint16_t xlen[16 * 8];                       // lengths of a region's extended matches, in the order the walk met them (<= 256 / 32)
+    // hist != nullptr (zstd, large batches; round 5): the block's sequence codes are counted HERE -- 3 x 64 counters (one copy: a second one takes the wave's LDS over 8 KiB and the CU from 20 waves to 19), added to the segment's
+    // counters in memory when the block is through -- instead of by k_stats, which read all 8-byte sequences once more for them (1.5 of its 2.6 ms per 10 000 segments)
+    __shared__ uint32_t shist[192];
+    __shared__ uint8_t s_llc[64], s_mlc[128];               // codes of the small literal / match lengths (RFC 8878 3.1.1.3.2.1.1)
     __shared__ uint32_t lstage[264];                        // step 4: the literals of four regions (<= 1 024 bytes behind <= 3 carried ones), stored from here as dwords
     const uint32_t lane = threadIdx.x, w = lane & 15;
     const uint8_t *len8 = (const uint8_t *)l32;
@@ -631,6 +635,12 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
     const uint32_t bs0 = (gb - sd.blk_base) << blk_log, bs1 = seg_len - bs0 < bsz ? seg_len : bs0 + bsz;    // (an empty segment's only block: no tiles)
     const uint32_t tile0 = bs0 / TG, ntile = bs0 < seg_len ? (bs1 + TG - 1) / TG : tile0;
     const bool lv = lane < 16;
+    if (hist) {                                             // (uniform)
+        const uint32_t i = lane, m0 = lane, m1 = lane + 64;
+        s_llc[i] = (uint8_t)(i < 16 ? i : (i < 24 ? 16 + ((i - 16) >> 1) : (i < 32 ? 20 + ((i - 24) >> 2) : (i < 48 ? 22 + ((i - 32) >> 3) : 24))));
+        s_mlc[m0] = (uint8_t)(m0 < 32 ? m0 : (m0 < 40 ? 32 + ((m0 - 32) >> 1) : (m0 < 48 ? 36 + ((m0 - 40) >> 2) : 38 + ((m0 - 48) >> 3))));
+        s_mlc[m1] = (uint8_t)(m1 < 96 ? 40 + ((m1 - 64) >> 4) : 42);
+    }
     if (lv) {                                               // selector of nibble n: the bytes whose bits are set, lowest first
         uint32_t sel = 0, j = 0;
         for (uint32_t bit = 0; bit < 4; bit++) if ((lane >> bit) & 1) { sel |= bit << (8 * j); j++; }
@@ -699,7 +709,8 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
             lmask[lane] = make_uint4(em2[0], em2[1], cm2[0], cm2[1]);
         }
         __builtin_amdgcn_wave_barrier();
-        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; lcarry = 0; }
+        if (t0 == blk_start) { next_free = blk_start; seq_run = 0; lit_run = 0; g_last1 = 1; lcarry = 0;
+                               if (hist) { for (uint32_t i = lane; i < 192; i += 64) shist[i] = 0; __builtin_amdgcn_wave_barrier(); } }
         // ---- 2. the region's greedy walk, from the tile's carry if that reaches into it; half-groups of 32 positions: one-register masks
         const uint32_t c_in = next_free > t0 ? next_free - t0 : 0u;
         uint64_t sel[4], cov[4], cm[4];
@@ -954,10 +965,22 @@ void k_lzp(const uint8_t *__restrict__ src, const SegDesc *__restrict__ segs, co
                         const uint32_t lq = (uint32_t)__popcll(lm & mlow(s));
                         const uint32_t ll = first ? rc.x + lq : lq - prev;
                         if (idx < SC) bseq[idx] = seq_pack(ll, ml, of);
+                        if (hist) {
+                            const uint32_t mb = ml - 3u, of3 = of + 3u;
+                            uint32_t *hh = shist;
+                            atomicAdd(&hh[ll < 64 ? (uint32_t)s_llc[ll] : 50u - (uint32_t)__builtin_clz(ll)], 1u);                 // hb(ll) + 19
+                            atomicAdd(&hh[64 + 31u - (uint32_t)__builtin_clz(of3)], 1u);                                           // hb(offset + 3)
+                            atomicAdd(&hh[128 + (mb < 128 ? (uint32_t)s_mlc[mb] : 67u - (uint32_t)__builtin_clz(mb))], 1u);       // hb(ml - 3) + 36
+                        }
                         idx++; prev = lq; first = false;
                     }
                 }
             }
+        }
+        if (hist && t1 == blk_end) {                            // (uniform) the block's counters go to its segment's
+            __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory");
+            uint32_t *hs = hist + (size_t)blk_seg[gb] * 448u + 256u;
+            for (uint32_t i = lane; i < 192; i += 64) { const uint32_t v = shist[i]; if (v) atomicAdd(&hs[i], v); }
         }
         // ---- 4. literals, region by region, 4 consecutive positions per lane.  Round 5: the lanes' one to four bytes go to an LDS stage (byte writes) and leave
         // four regions at a time as aligned DWORDS, the < 4 bytes behind the last complete dword carried to the next chunk / tile (until then: four predicated byte
@@ -1018,9 +1041,9 @@ static void launch_split_g(const uint8_t *src, const SegDesc *segs, uint32_t nse
                               hipLaunchKernelGGL((k_lzms<STRONG, W3>), dim3(nseg), dim3(64), lzms_lds(mx), st, src, segs, flags, pbuf, blk0, SMALL_SEG, mx); }
     if (ev_match) (void)hipEventRecord(ev_match, st);
     if (!pg || pg->nb == 0) return;                            // (no grid: the caller wants the match kernel alone; a run of empty entries has segments and no blocks)
-    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
-    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
-    else hipLaunchKernelGGL((k_lzp<CT, 1, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0);
+    if (flags & FLAG_LAZY3) hipLaunchKernelGGL((k_lzp<CT, 3, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0, pg->hist);
+    else if (flags & FLAG_LAZY2) hipLaunchKernelGGL((k_lzp<CT, 2, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0, pg->hist);
+    else hipLaunchKernelGGL((k_lzp<CT, 1, W3>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, flags, max_len, pbuf, blk0, pg->hist);
 }
 // match kernel + parse kernel over `nseg` segments; pbuf holds one word per position of the launch's blocks, blk0 = the first of them; ctab != nullptr:
 // a deflate launch (chunk table, look-back inside the LDS window); ev_match, if given, is recorded between the two kernels
@@ -1064,8 +1087,8 @@ void launch_lz_small(const uint8_t *src, const SegDesc *segs, uint32_t nseg, uin
 #undef LZMS
     if (!pg || pg->nb == 0) return;
     const uint32_t pf = flags | FLAG_SMALL_ONLY;
-#define LZP_SMALL(CT_, LZD_) do { if (w3) hipLaunchKernelGGL((k_lzp<CT_, LZD_, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0); \
-                                  else hipLaunchKernelGGL((k_lzp<CT_, LZD_, false>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0); } while (0)
+#define LZP_SMALL(CT_, LZD_) do { if (w3) hipLaunchKernelGGL((k_lzp<CT_, LZD_, true>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0, pg->hist); \
+                                  else hipLaunchKernelGGL((k_lzp<CT_, LZD_, false>), dim3(pg->nb), dim3(LZP_THREADS), 0, st, src, pg->segs_all, pg->blk_seg, seqs, lits, blk, ctab, pf, max_len, pbuf, blk0, pg->hist); } while (0)
     if (ctab) { if (flags & FLAG_LAZY3) LZP_SMALL(true, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(true, 2); else LZP_SMALL(true, 1); }
     else { if (flags & FLAG_LAZY3) LZP_SMALL(false, 3); else if (flags & FLAG_LAZY2) LZP_SMALL(false, 2); else LZP_SMALL(false, 1); }
 #undef LZP_SMALL

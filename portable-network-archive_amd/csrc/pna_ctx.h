@@ -38,7 +38,7 @@ void launch_deflate_write(const uint8_t *src, const SegDesc *segs, const uint32_
                           uint8_t *dst, hipStream_t st, bool stored_only, bool small_blocks);
 void launch_entropy_chunk(const SegDesc *segs, uint32_t s0, uint32_t ns, const uint32_t *blk_seg, uint32_t g0, uint32_t nb,
                           const uint64_t *seqs, const uint8_t *lits, BlkInfo *blk, SegTables *tabs, uint8_t *litc, uint8_t *seqc, uint32_t *seqw,
-                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block);
+                          uint32_t flags, uint32_t blk_log, uint32_t *hist, hipStream_t st, hipEvent_t *ev, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool single_block, const uint32_t *seq_hist);
 void launch_default_tables(hipStream_t st);   // k_entropy.hip: the predefined sequence tables, once per device
 void launch_plan(const SegDesc *segs, uint32_t nseg, BlkInfo *blk, const SegTables *tabs, uint64_t *seg_size, uint64_t *seg_off,
                  uint32_t flags, hipStream_t st);
@@ -177,6 +177,7 @@ struct Tuning {
     long small_geometry = 1;         // PNA_SMALL_GEOMETRY: 1 (default): segments of at most 4 096 bytes run the small geometry of the match finder (pna_dev.h SMALL_SEG: one wave per segment, sub-tiles of 256 positions); 0: the large one like every segment (they then find no match: one tile)
     long tab3 = 1;                   // PNA_TAB3: 1 (default): the zstd sets on the 32 / 16 KiB geometries keep their table PACKED (three 21-bit entries per 64-bit LDS word: 49 062 / 55 206 slots, lz_common.h); 0: 32-bit entries (32 704 / 36 800)
     long strong2 = 1;                // PNA_STRONG2: 1 (default): zstd levels 4 .. 22 on their standard geometries adopt over eight positions as well and count up to 15 back bytes (levels 6 - 9: 2.864 -> 2.880); 0: the default set's three rounds
+    long seq_hist = 1;               // PNA_SEQ_HIST: 1 (default): large zstd batches behind the split LZ stage -- the parse kernel counts every block's sequence codes, k_stats walks the literals only (2.6 -> 1.1 ms per 10 000 segments, + 0.5 in the parse kernel); 0: k_stats reads the sequences once more
     long far1 = 1;                   // PNA_FAR1: 1 (default): the zstd light / default sets (packed table, 32 KiB window) verify at most 63 far candidates per wave of 256 positions -- one compacted round of k_lzm -- and drop the rest (FLAG_FAR1: - 0.16 % of ratio, - 6 % of the match kernel); 0: every far candidate, in as many rounds as it takes
     long win32k = 1;                 // PNA_WIN32K: 1 (default): the zstd default set on the 32 KiB-window geometry of the match finder (32 704 table slots), the high set on the 16 KiB one (36 800); 0: both on 64 KiB / 24 512; 2: both on 16 KiB
     long lit_beside_seq = 1;         // PNA_LIT_BESIDE_SEQ: large zstd batches: the literal coder on a second stream next to the sequence coder
@@ -205,6 +206,7 @@ struct pna_gpu_ctx {
     uint32_t n_cus = 256;                           // compute units of the device (hipDeviceProp_t::multiProcessorCount): a full round of one-workgroup-per-CU kernels
     bool call_stored = false;                       // deflate level 0: stored blocks only (Compression::none())
     bool call_strong2 = false;                      // ... the high / max sets' fourth adoption round and 15 back bytes (FLAG_STRONG2: zstd 4 .. 22 on the packed 16 KiB geometry or the global table)
+    uint32_t *lzp_hist = nullptr; bool lzp_hist_all = false;   // the current sub-batch: the counters the parse kernel adds the sequence codes to (null: none), and whether EVERY segment's parse did
     bool call_tab3 = false;                         // ... its table packed (lz_common.h TAB3)
     bool call_w16 = false;                          // ... the 16 KiB window (zstd 6..9)
     bool call_gtab = false, call_w32 = false;       // ... and where the match finder's table lies / its LDS geometry (set_call_level)

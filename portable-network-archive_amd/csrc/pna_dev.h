@@ -90,7 +90,8 @@ struct SegDesc {
 };
 // the parse kernel of the split LZ form runs one wave per BLOCK (a block's parse depends on nothing outside it): all segments of the sub-batch, the
 // block -> segment map, and the launch's blocks [blk0, blk0 + nb)
-struct LzParseGrid { const SegDesc *segs_all; const uint32_t *blk_seg; uint32_t nb; };
+struct LzParseGrid { const SegDesc *segs_all; const uint32_t *blk_seg; uint32_t nb;
+                     uint32_t *hist = nullptr; };    // hist (round 5; zstd, large batches): the segments' histogram counters (448 words each: k_entropy.hip HIST_WORDS) -- the parse kernel adds every block's sequence codes to words 256 .. 447 of its segment, so that k_stats reads the literals only
 constexpr uint32_t BLK_LOG_MIN = 13;   // smallest block of the latency mode (bounds: pna_gpu_bound)
 static_assert(sizeof(SegDesc) == 40, "SegDesc layout");
 // sequences a block of 1 << blk_log bytes can hold: a match is >= MIN_MATCH bytes but for one front-cut match (>= 3 bytes) per 256-position parse region

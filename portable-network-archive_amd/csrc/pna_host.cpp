@@ -11,7 +11,7 @@ static const TuningName TUNING_NAMES[] = {
     {"inflate_serial", "PNA_INFLATE_SERIAL", &Tuning::inflate_serial, 0, 1}, {"zdec_serial", "PNA_ZDEC_SERIAL", &Tuning::zdec_serial, 0, 1}, {"zdec_dbg", "PNA_ZDEC_DBG", &Tuning::zdec_dbg, 0, 15},
     {"blk_log", "PNA_BLK_LOG", &Tuning::blk_log, 0, PNA_BLK_LOG}, {"unit_log", "PNA_LZ_UNIT_LOG", &Tuning::unit_log, 0, 20},
     {"latency_max_mib", "PNA_LATENCY_MAX_MIB", &Tuning::latency_max_mib, 0, 1 << 20}, {"hist_by_block", "PNA_HIST_BY_BLOCK", &Tuning::hist_by_block, -1, 1},
-    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"strong2", "PNA_STRONG2", &Tuning::strong2, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
+    {"d2h_wgs", "PNA_D2H_WGS", &Tuning::d2h_wgs, 0, 4096}, {"trace", "PNA_TRACE", &Tuning::trace, 0, 1}, {"dev_layout", "PNA_DEV_LAYOUT", &Tuning::dev_layout, 0, 1}, {"strong_gtab", "PNA_STRONG_GTAB", &Tuning::strong_gtab, 0, 1}, {"win32k", "PNA_WIN32K", &Tuning::win32k, 0, 2}, {"tab3", "PNA_TAB3", &Tuning::tab3, 0, 1}, {"far1", "PNA_FAR1", &Tuning::far1, 0, 1}, {"seq_hist", "PNA_SEQ_HIST", &Tuning::seq_hist, 0, 1}, {"strong2", "PNA_STRONG2", &Tuning::strong2, 0, 1}, {"small_geometry", "PNA_SMALL_GEOMETRY", &Tuning::small_geometry, 0, 1}, {"zexec_par_min_mib", "PNA_ZEXEC_PAR_MIN_MIB", &Tuning::zexec_par_min_mib, 0, 1 << 20}, {"zexec_win_mib", "PNA_ZEXEC_WIN_MIB", &Tuning::zexec_win_mib, 1, 1024}, {"zdec_fallback_max_mib", "PNA_ZDEC_FALLBACK_MAX_MIB", &Tuning::zdec_fallback_max_mib, 0, 1 << 30}, {"stream_batch_mib", "PNA_STREAM_BATCH_MIB", &Tuning::stream_batch_mib, 1, 1 << 16}, {"stream_gather_wgs", "PNA_STREAM_GATHER_WGS", &Tuning::stream_gather_wgs, 0, 4096}, {"stream_overlap_mib", "PNA_STREAM_OVERLAP_MIB", &Tuning::stream_overlap_mib, 0, 1 << 16}, {"single_frame", "PNA_SINGLE_FRAME", &Tuning::single_frame, 0, 1}, {"lazy2", "PNA_LAZY2", &Tuning::lazy2, 0, 2}, {"tail_units", "PNA_TAIL_UNITS", &Tuning::tail_units, 0, 1}, {"lit_beside_seq", "PNA_LIT_BESIDE_SEQ", &Tuning::lit_beside_seq, 0, 1}, {"sub_ramp_down", "PNA_SUB_RAMP_DOWN", &Tuning::sub_ramp_down, 0, 1},
 };
 
 extern "C" const char *pna_gpu_strerror(int code) {
@@ -495,7 +495,9 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
             while (c->lzm_ev.size() < c->lzm_used + 2) { hipEvent_t e = nullptr; HIPCHK(c, hipEventCreate(&e)); c->lzm_ev.push_back(e); }
             HIPCHK(c, hipEventRecord(c->lzm_ev[c->lzm_used], st)); e1 = c->lzm_ev[c->lzm_used + 1]; c->lzm_used += 2; c->lzm_nl.push_back(1);
         }
-        const LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};            // the parse kernel: one wave per block of the run
+        LzParseGrid pg{c->d_segs, c->d_blk_seg, b1 - b0};                  // the parse kernel: one wave per block of the run
+        pg.hist = c->lzp_hist;                                            // (the sequence codes' counters, where the entropy stage takes them from the parse kernel)
+        if (waveparse) c->lzp_hist_all = false;
         // The match kernel runs one workgroup per segment and CU, all of equal length: a run of 3 334 segments is 13 full rounds of the 256 CUs and a 14th for
         // 6 of them.  The segments behind the last full round are therefore cut into UNITS of one block each (table pre-warmed: the same words, SS4a), a launch
         // of their own behind the full rounds: R x 8 short workgroups instead of R long ones next to 256 - R idle CUs.
@@ -527,6 +529,7 @@ static int lz_stage(pna_gpu_ctx *c, const uint8_t *d_src, const SegDesc *segs, u
         a = b;
         if (a >= s1) return PNA_OK;
     }
+    c->lzp_hist_all = false;                                           // (the one-kernel form: its parse counts nothing)
     if (!(flags & FLAG_ALL_SMALL)) launch_lz(d_src, c->d_segs + s0, s1 - s0, (uint64_t *)c->seqs.p, (uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, ctab, flags, max_off, max_len, st, nullptr, 0, nullptr, nullptr, nullptr);
     if (flags & FLAG_HAS_SMALL) { const int rc = lz_small_pass(c, d_src, segs, nseg_all, s0, s1, nblk, ctab, flags, max_len, st); if (rc) return rc; }   // (the one-kernel form skips the short segments)
     if (fused_tail) return lz_stage(c, d_src, segs, nseg_all, s1, s1_all, nblk, ctab, flags, max_off, max_len, st, timed);   // (a short run in the middle: only with tiny PNA_LZ_SPLIT_BLOCKS)
@@ -694,7 +697,9 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
     const bool single_block = max_len <= bsz;
     const bool hist_on = algo == PNA_ALGO_ZSTD && !(c->call_flags & 0x1000u) && !single_block &&
                          ((c->call_flags & 0x2000u) || (c->tun.hist_by_block < 0 ? nblk <= 40960u : c->tun.hist_by_block != 0));
-    const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + (hist_on ? (size_t)nseg * 448 * 4 : 0);
+    // round 5: large zstd batches behind the split LZ stage -- the parse kernel counts the sequence codes per block into the segments' counters, k_stats walks the literals only
+    const bool seq_hist = algo == PNA_ALGO_ZSTD && !hist_on && !single_block && c->tun.seq_hist != 0;
+    const size_t o_hist = ((size_t)(nblk + 1) * sizeof(BlkInfo) + 15) & ~(size_t)15, blk_bytes = o_hist + ((hist_on || seq_hist) ? (size_t)nseg * 448 * 4 : 0);
     if (c->blk.ensure(blk_bytes) || c->tabs.ensure((size_t)nseg * std::max(sizeof(SegTables), sizeof(DeflTables))) ||
         (algo == PNA_ALGO_DEFLATE && c->ctab.ensure(((size_t)(nblk + 1) << (blk_log - 11)) * 16)) ||
         c->seqs.ensure((size_t)(nblk + 1) * seq_cap_of(blk_log) * 8) || c->lits.ensure((size_t)(nblk + 1) << blk_log) ||
@@ -710,6 +715,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
         HIPCHK(c, hipMemsetAsync(c->blk.p, 0, blk_bytes, st));                     // BlkInfo of every block and, behind them, the segments' histogram counters
     }
     c->lzm_used = 0; c->lzm_nl.clear();
+    c->lzp_hist = nullptr; c->lzp_hist_all = false;
     const bool defl = algo == PNA_ALGO_DEFLATE;
     // the short segments' geometry (k_lzms): a launch flag tells the large geometry's kernels to skip them; a sub-batch of short segments only launches none of those
     const uint32_t small_fl = (c->tun.small_geometry && (n_short || n_mid))
@@ -761,7 +767,10 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
                           zmax, 0xFFFFFFFFu, st, gt ? (uint32_t *)c->pbuf.p : nullptr, 0, nullptr, gt ? (uint32_t *)c->gtab.p : nullptr, gt ? &pgu : nullptr);
                 if (!gt && (zfl & FLAG_HAS_SMALL)) { const int rc = lz_small_pass(c, d_src, segs, nseg, 0, nseg, nblk, nullptr, zfl, 0xFFFFFFFFu, st); if (rc) return rc; }   // (the split form above takes them itself)
             }
-            else { const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, zmax, 0xFFFFFFFFu, st, timed); if (rc) return rc; }
+            else {
+                c->lzp_hist = (seq_hist && nch == 1) ? c->d_hist : nullptr; c->lzp_hist_all = c->lzp_hist != nullptr;
+                const int rc = lz_stage(c, d_src, segs, nseg, s0, s1, nblk, nullptr, zfl, zmax, 0xFFFFFFFFu, st, timed); if (rc) return rc;
+            }
             // (one chunk: everything stays on `st` -- a hand-over to the auxiliary stream and back costs ~45 us of idle device, a tenth of a small batch)
             hipStream_t est = nch > 1 ? c->aux : st;
             HIPCHK(c, hipEventRecord(c->ev_lz[k + 1], st));
@@ -770,7 +779,7 @@ int run_subbatch(pna_gpu_ctx *c, int algo, const uint8_t *d_src, const uint64_t 
             launch_entropy_chunk(c->d_segs, s0, s1 - s0, c->d_blk_seg, g0, g1 - g0, (const uint64_t *)c->seqs.p,
                                  (const uint8_t *)c->lits.p, (BlkInfo *)c->blk.p, (SegTables *)c->tabs.p, (uint8_t *)c->litc.p, (uint8_t *)c->seqc.p,
                                  (uint32_t *)c->seqw.p, c->call_flags, blk_log, hist_on ? c->d_hist : nullptr, est, &c->ev_en[k][1],
-                                 (nch == 1 && c->tun.lit_beside_seq) ? c->aux : nullptr, c->ev_fork, c->ev_join, single_block);
+                                 (nch == 1 && c->tun.lit_beside_seq) ? c->aux : nullptr, c->ev_fork, c->ev_join, single_block, c->lzp_hist_all ? c->d_hist : nullptr);
         }
         if (nch > 1) { HIPCHK(c, hipEventRecord(c->ev_join, c->aux)); HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0)); }
         if (timed) HIPCHK(c, hipEventRecord(c->ev[4], st));

@@ -17,7 +17,7 @@ void launch_lz_small(const uint8_t *, const SegDesc *, uint32_t, uint64_t *, uin
 void launch_default_tables(hipStream_t) {}
 uint32_t lz_gtab_log() { return 19; }
 void launch_entropy_chunk(const SegDesc *, uint32_t, uint32_t, const uint32_t *, uint32_t, uint32_t, const uint64_t *, const uint8_t *, BlkInfo *, SegTables *,
-                          uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t, hipEvent_t *, hipStream_t, hipEvent_t, hipEvent_t, bool) {}
+                          uint8_t *, uint8_t *, uint32_t *, uint32_t, uint32_t, uint32_t *, hipStream_t, hipEvent_t *, hipStream_t, hipEvent_t, hipEvent_t, bool, const uint32_t *) {}
 static uint64_t seg_bytes(const SegDesc &sd) {
     if (sd.len == 0) return 9;
     return 6 + 3ull * seg_nblk(sd) + sd.len;
