@@ -160,7 +160,7 @@ def _fuzz_one(gpu_ctx, pna, codec, text, rnd):
             elif k < 0.60:
                 o = rnd.randrange(len(text) - 300); buf += text[o:o + rnd.randrange(3, 300)]
             else:                                                   # copy of an earlier fragment (overlapping copies included)
-                d = rnd.choice((1, 2, 3, 5, 8, 64, 4096, 32768, 56064, 60000, 131072)) if rnd.random() < 0.5 else rnd.randrange(1, len(buf) + 1)
+                d = rnd.choice((1, 2, 3, 5, 8, 64, 4096, 28367, 28368, 28369, 32768, 56064, 60000, 131072)) if rnd.random() < 0.5 else rnd.randrange(1, len(buf) + 1)   # (28 368: where the match kernel's window ends -- FLAG_FAR1's border)
                 d = min(d, len(buf)); n = rnd.randrange(3, 2000)
                 st = len(buf) - d
                 for t in range(n):
@@ -197,7 +197,7 @@ def test_lz_stage_fuzz_large_entries(gpu_ctx, pna, codec):
             elif k < 0.55:
                 o = rnd.randrange(len(text) - 4000); buf += text[o:o + rnd.randrange(3, 4000)]
             else:
-                d = rnd.choice((1, 7, 4096, 51968, 51969, 56064, 56065, 65536, 131072, 500000, (1 << 20) - 1, 1 << 20, (1 << 20) + 1))
+                d = rnd.choice((1, 7, 4096, 11983, 11984, 11985, 28367, 28368, 28369, 51968, 51969, 56064, 56065, 65536, 131072, 500000, (1 << 20) - 1, 1 << 20, (1 << 20) + 1))
                 d = min(d, len(buf)); n = rnd.randrange(3, 20000)
                 buf += (bytes(buf[len(buf) - d:]) * (n // d + 1))[:n]          # an overlapping copy repeats its period
         ents.append(bytes(buf[:target]))
